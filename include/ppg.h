@@ -1,0 +1,247 @@
+/*
+ * ppg.h — C-ABI of libppg_hip.so, the MI355X-native GuidedPathTracer hot path.
+ *
+ * Every entry point replaces a piece of the reference integrator plugin
+ * (mitsuba/src/integrators/path/guided_path.cpp, cited as GP:line) or of the Mitsuba Integrator
+ * interface it implements (mitsuba/include/mitsuba/render/integrator.h, cited as IH:line).
+ * The reference-side binding a Mitsuba maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; all pointers are host pointers unless the name says `dev`.
+ *   - every function returns PPG_OK (0) or a negative error code; ppg_last_error() gives the text.
+ *     No exception crosses this boundary (the reference uses Assert/Log(EError) → throw; GP:1023).
+ *   - one context per GPU, driven by one host thread; ppg_cancel() is the only call that may come
+ *     from another thread (mirrors Integrator::cancel(), IH:84 / GP:1643-1648).
+ *   - the caller owns every buffer it passes in; ppg_set_scene() copies.
+ */
+#ifndef PPG_H
+#define PPG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PPG_OK 0
+#define PPG_ERR_INVALID (-1)   /* bad argument / unknown enum string (reference: Assert(false), GP:1023...) */
+#define PPG_ERR_DEVICE (-2)    /* HIP error */
+#define PPG_ERR_STATE (-3)     /* call out of order (no scene, render not begun, ...) */
+#define PPG_ERR_CANCELLED (-4) /* ppg_cancel() was called; render() returns false in the reference (GP:1584) */
+#define PPG_ERR_NOMEM (-5)
+
+typedef struct ppg_ctx ppg_ctx;
+
+/* ------------------------------------------------------------------------------------------------
+ * Integrator properties.  Names, meaning and defaults are the reference's:
+ *   GuidedPathTracer(const Properties&)      GP:1014-1085
+ *   MonteCarloIntegrator(const Properties&)  mitsuba/src/librender/integrator.cpp:190-225
+ * String-valued properties stay strings so that an unknown value is rejected exactly where the
+ * reference asserts.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ppg_config {
+    const char *nee;                      /* "never" | "kickstart" | "always"          GP:1015-1024 (default "never") */
+    const char *sampleCombination;        /* "discard" | "automatic" | "inversevar"    GP:1026-1035 (default "automatic") */
+    const char *spatialFilter;            /* "nearest" | "stochastic" | "box"          GP:1037-1046 (default "nearest") */
+    const char *directionalFilter;        /* "nearest" | "box"                         GP:1048-1055 (default "nearest") */
+    const char *bsdfSamplingFractionLoss; /* "none" | "kl" | "var"                     GP:1057-1066 (default "none") */
+    int32_t sdTreeMaxMemory;              /* MB, -1 = unlimited                        GP:1068 */
+    int32_t sTreeThreshold;               /* 12000                                     GP:1069 */
+    float dTreeThreshold;                 /* 0.01                                      GP:1070 */
+    float bsdfSamplingFraction;           /* 0.5                                       GP:1071 */
+    int32_t sppPerPass;                   /* 4                                         GP:1072 */
+    const char *budgetType;               /* "spp" | "seconds" (default "seconds")     GP:1074-1081 */
+    float budget;                         /* 300                                       GP:1083 */
+    int32_t dumpSDTree;                   /* 0                                         GP:1084 */
+    /* MonteCarloIntegrator */
+    int32_t rrDepth;                      /* 5   integrator.cpp:192 */
+    int32_t maxDepth;                     /* -1  integrator.cpp:197 */
+    int32_t strictNormals;                /* 0   integrator.cpp:213 */
+    int32_t hideEmitters;                 /* 0   integrator.cpp:218 */
+    /* Build-specific (no reference counterpart) */
+    uint64_t seed;                        /* key of the counter-based sampler that replaces the per-thread SFMT
+                                             streams of samplers/independent.cpp (XML `seed` is ignored there) */
+    int32_t device;                       /* HIP device ordinal */
+    const char *dumpPrefix;               /* "<dest>" of the "<dest>-NN.sdt" dumps, GP:1192-1195; may be NULL */
+} ppg_config;
+
+/* Fills *cfg with the reference defaults listed above. */
+void ppg_config_default(ppg_config *cfg);
+
+/* ------------------------------------------------------------------------------------------------
+ * Scene: what GuidedPathTracer::render() reaches through `Scene*` (GP:1516-1527, 1784, 1934, 2193),
+ * flattened.  Triangles only; per-triangle BSDF and emitter indices.
+ * ---------------------------------------------------------------------------------------------- */
+enum { PPG_BSDF_DIFFUSE = 0 /* mitsuba/src/bsdfs/diffuse.cpp:110-150 (one-sided Lambertian) */ };
+
+typedef struct ppg_material {
+    int32_t type;         /* PPG_BSDF_* */
+    float reflectance[3]; /* linear RGB (SPECTRUM_SAMPLES=3 build of the reference) */
+    float param[4];       /* reserved for the "next" BSDF rows */
+} ppg_material;
+
+typedef struct ppg_emitter {
+    float radiance[3]; /* area light, mitsuba/src/emitters/area.cpp:104-109 */
+    float _pad;
+} ppg_emitter;
+
+typedef struct ppg_camera {
+    /* row-major 4x4, exactly the matrices of mitsuba/src/sensors/perspective.cpp:150-164 (m_sampleToCamera)
+       and the sensor's world transform; rays follow perspective.cpp:271-298 */
+    float sample_to_camera[16];
+    float camera_to_world[16];
+    float near_clip, far_clip;
+    int32_t width, height; /* film / crop size in pixels */
+} ppg_camera;
+
+typedef struct ppg_scene {
+    uint32_t n_vertices;
+    const float *positions;       /* [n_vertices*3] */
+    const float *normals;         /* [n_vertices*3] or NULL → face normals (skdtree.h:388-401) */
+    uint32_t n_triangles;
+    const uint32_t *indices;      /* [n_triangles*3] */
+    const uint32_t *tri_material; /* [n_triangles] index into materials */
+    const int32_t *tri_emitter;   /* [n_triangles] index into emitters, -1 = not an emitter */
+    uint32_t n_materials;
+    const ppg_material *materials;
+    uint32_t n_emitters;
+    const ppg_emitter *emitters;
+    ppg_camera camera;
+} ppg_scene;
+
+/* ------------------------------------------------------------------------------------------------
+ * Statistics returned by the stepwise calls (the numbers the reference logs).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ppg_pass_stats {   /* GP:1321-1326 "… seconds, Total passes, Var, TTUV, STUV" */
+    double seconds;
+    int32_t passes_rendered_total;
+    int32_t passes_rendered_local;
+    float variance;
+    uint64_t samples;             /* pixels × spp rendered by this call (this shard) */
+    uint64_t rays;                /* "Normal rays traced" (skdtree.cpp:46,123) */
+    uint64_t path_length_sum;     /* Σ rRec.depth, avgPathLength GP:2147-2148 */
+    uint64_t vertices_committed;  /* records that reached DTreeWrapper::record */
+} ppg_pass_stats;
+
+typedef struct ppg_tree_stats {   /* GP:1176-1186 "Distribution statistics" */
+    int32_t min_depth, max_depth;  float avg_depth;
+    float min_mean_radiance, avg_mean_radiance, max_mean_radiance;
+    uint64_t min_nodes, max_nodes; float avg_nodes;
+    float min_stat_weight, avg_stat_weight, max_stat_weight;
+    uint32_t n_leaves;            /* S-tree leaves (nPoints, GP:1135) */
+    uint32_t n_stree_nodes;
+    uint64_t n_dtree_nodes;       /* Σ numNodes over the sampling D-trees */
+} ppg_tree_stats;
+
+/* ------------------------------------------------------------------------------------------------
+ * Life cycle.
+ * ---------------------------------------------------------------------------------------------- */
+/* Replaces CreateInstance(props) → new GuidedPathTracer(props) (cobject.h:99-107, GP:1014, 2421-2422). */
+int ppg_create(const ppg_config *cfg, ppg_ctx **out);
+void ppg_destroy(ppg_ctx *ctx);
+const char *ppg_last_error(const ppg_ctx *ctx); /* ctx may be NULL: error of the last failed ppg_create */
+const char *ppg_description(void);              /* GetDescription(), cobject.h:107: "Guided path tracer" */
+
+/* Replaces Scene::preprocess/initialize as far as this path needs it (scene.cpp:322-384): copies the
+   triangles, builds the BVH that stands in for the SAH kd-tree (skdtree.cpp:112-142), uploads. */
+int ppg_set_scene(ppg_ctx *ctx, const ppg_scene *scene);
+
+/* Multi-GPU image sharding (no reference counterpart; BlockedRenderProcess hands 32×32 blocks to
+   worker threads, renderproc.cpp:69-87).  Tile t (row-major, tile_size² pixels) is rendered by
+   rank t % world.  Default: rank 0 of 1. */
+int ppg_set_shard(ppg_ctx *ctx, int32_t rank, int32_t world, int32_t tile_size);
+
+/* ------------------------------------------------------------------------------------------------
+ * Rendering.  ppg_render() is GuidedPathTracer::render() (GP:1516-1585, IH:74-75) in one call.
+ * The stepwise calls expose its phases so a multi-GPU driver can all-reduce the SD-tree statistics
+ * between ppg_render_passes() and ppg_build_sdtree(); ppg_render() is exactly their composition
+ * (renderSPP GP:1342-1426 / renderTime GP:1434-1514).
+ * ---------------------------------------------------------------------------------------------- */
+int ppg_render(ppg_ctx *ctx);
+
+int ppg_begin_render(ppg_ctx *ctx);                       /* GP:1519-1550: new STree(aabb), buffers, m_iter = 0 */
+int ppg_begin_iteration(ppg_ctx *ctx, int32_t is_final);  /* GP:1378-1381: m_isFinalIter, film->clear(), resetSDTree() GP:1108-1113 */
+int ppg_set_final(ppg_ctx *ctx, int32_t is_final);        /* GP:1409 / 1492: m_isFinalIter = true before the FINAL passes */
+int ppg_set_do_nee(ppg_ctx *ctx, int32_t do_nee);         /* GP:1362 m_doNee */
+int ppg_render_passes(ppg_ctx *ctx, int32_t n_passes, ppg_pass_stats *stats); /* performRenderPasses GP:1210-1329 */
+int ppg_build_sdtree(ppg_ctx *ctx, ppg_tree_stats *stats);                    /* buildSDTree GP:1115-1189 */
+int ppg_end_iteration(ppg_ctx *ctx);                      /* GP:1417-1422: optional dump, ++m_iter */
+int ppg_end_render(ppg_ctx *ctx);                         /* GP:1567-1582: inverse-variance combination into the film */
+
+/* Integrator::cancel() (IH:84, GP:1643-1648).  Thread-safe; the running ppg_render / ppg_render_passes
+   call returns PPG_ERR_CANCELLED. */
+int ppg_cancel(ppg_ctx *ctx);
+
+/* Film read-back: weight-normalised RGB, row-major [height][width][3] (hdrfilm develop, fmtconv.cpp:1036-1044). */
+int ppg_read_film(ppg_ctx *ctx, float *rgb);
+/* Per-pixel variance estimate of the last ppg_render_passes (m_varianceBuffer, GP:1298-1314), [h][w][3]. */
+int ppg_read_variance(ppg_ctx *ctx, float *rgb);
+
+/* dumpSDTree (GP:1191-1208) in the byte format of DTreeWrapper::dump (GP:699-711), readable by
+   visualizer/src/main.cpp:142-176.  camera_matrix = row-major 4x4 world transform. */
+int ppg_dump_sdtree(ppg_ctx *ctx, const char *path);
+
+/* ------------------------------------------------------------------------------------------------
+ * SD-tree access (parity tests, multi-GPU reduction, visualisation).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ppg_sdtree_info {
+    uint32_t n_stree_nodes;
+    uint32_t n_leaves;
+    uint64_t n_sampling_nodes; /* total quadtree nodes of all sampling D-trees (shared blocks counted once) */
+    uint64_t n_building_nodes; /* total quadtree nodes of all building D-trees */
+    float aabb_min[3], aabb_max[3]; /* cubified, GP:857-859 */
+    int32_t iter;
+    int32_t is_built;
+} ppg_sdtree_info;
+
+int ppg_sdtree_info_get(ppg_ctx *ctx, ppg_sdtree_info *info);
+
+/* S-tree nodes in the reference's numbering (STreeNode, GP:740-845): per node axis, children[2]
+   (0,0 for a leaf).  Arrays sized n_stree_nodes. */
+int ppg_sdtree_read_stree(ppg_ctx *ctx, int32_t *axis, uint32_t *children /* [n*2] */);
+
+/* Per S-tree node D-tree headers (only meaningful for leaves).  which: 0 = sampling, 1 = building.
+   offset = first node of that tree in the node arrays read by ppg_sdtree_read_dtree_nodes. */
+int ppg_sdtree_read_dtree_headers(ppg_ctx *ctx, int32_t which, uint64_t *offset, uint32_t *num_nodes,
+                                  int32_t *max_depth, float *sum, double *stat_weight);
+
+/* Quadtree nodes (QuadTreeNode, GP:158-371) of all D-trees of one kind, concatenated.
+   sums [n*4]: sampling → the float sums; building → the accumulated sums converted to float.
+   children [n*4] (uint16, 0 = leaf slot).  fixed_sums may be NULL; building only: the raw 2^-PPG_FIXED_SHIFT
+   fixed-point accumulators. */
+int ppg_sdtree_read_dtree_nodes(ppg_ctx *ctx, int32_t which, float *sums, uint16_t *children, uint64_t *fixed_sums);
+
+/* learned BSDF sampling fraction state per S-tree node (AdamOptimizer::State, GP:116-124): theta only */
+int ppg_sdtree_read_adam(ppg_ctx *ctx, float *theta);
+
+/* Device pointers to the accumulate-only statistics of the *building* SD-tree, for the per-iteration
+   all-reduce(sum) of a multi-GPU render.  Both arrays are int64/uint64 fixed-point,
+   so an integer sum is exact and order independent.  Valid until the next ppg_begin_iteration. */
+int ppg_sdtree_stat_buffers(ppg_ctx *ctx, void **dev_sums, uint64_t *n_sums, void **dev_weights, uint64_t *n_weights);
+/* Device pointers to the film accumulators (float RGB sums + sample counts), for the final gather. */
+int ppg_film_buffers(ppg_ctx *ctx, void **dev_rgb_sum /* float[h*w*3] */, void **dev_weight /* float[h*w] */);
+/* Device pointers to image / squared image of the current ppg_render_passes for the variance reduction:
+   call between ppg_render_passes_nostat() and ppg_finish_passes() when sharded. */
+int ppg_image_buffers(ppg_ctx *ctx, void **dev_image /* float[h*w*3] */, void **dev_sq_image /* float[h*w*3] */);
+int ppg_render_passes_nostat(ppg_ctx *ctx, int32_t n_passes); /* GP:1217-1286 only */
+int ppg_finish_passes(ppg_ctx *ctx, ppg_pass_stats *stats);   /* GP:1288-1328 only */
+
+/* Batched queries against the current *sampling* SD-tree (what Li does per vertex):
+   pdf  = DTreeWrapper::pdf(dir) of the leaf containing p        (GP:623-625, 897-905)
+   dirs = DTreeWrapper::sample(sampler) with the build's sampler keyed by (seed, i)  (GP:619-621) */
+int ppg_query_pdf(ppg_ctx *ctx, uint32_t n, const float *positions, const float *dirs, float *pdf_out);
+int ppg_query_sample(ppg_ctx *ctx, uint32_t n, const float *positions, uint64_t seed, float *dirs_out);
+
+/* Kernel timing of the last ppg_render_passes, measured with HIP events on the stream the kernels
+   run on: names[i] → accumulated milliseconds and launch count.  Used by bench.py's roofline block. */
+typedef struct ppg_kernel_time { const char *name; double ms; uint64_t launches; uint64_t units; } ppg_kernel_time;
+int ppg_kernel_times(ppg_ctx *ctx, ppg_kernel_time *out, uint32_t cap, uint32_t *n);
+int ppg_enable_kernel_timing(ppg_ctx *ctx, int32_t enable);
+
+#define PPG_FIXED_SHIFT 24 /* building sums / weights are accumulated as round(x * 2^24) in uint64 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PPG_H */

@@ -1,0 +1,129 @@
+/*
+ * ppg_detmath.h — the numerical contract shared by the HIP kernels and the CPU oracle.
+ *
+ * The reference calls libm (sincos, atan2, exp, pow; guided_path.cpp:65, 100, 404, 592, 603, 681 and
+ * warp.cpp:81-102).  libm results differ in the last ulp between glibc and the AMD device library, which
+ * would make "same seed ⇒ same path" impossible across CPU and GPU.  Both sides therefore evaluate
+ * these functions with the fixed sequences of IEEE-754 single-precision +,-,*,/ below (Cephes-style
+ * range reduction + polynomial, max error ≈ 1–2 ulp on the ranges used), and both are compiled with
+ * -ffp-contract=off, so every result is bit-identical on x86-64 and gfx950.
+ *
+ * tests/test_detmath.py checks these against numpy's libm within a stated ulp bound.
+ */
+#ifndef PPG_DETMATH_H
+#define PPG_DETMATH_H
+
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIPCC__)
+#define PPG_HD __host__ __device__ inline
+#else
+#define PPG_HD inline
+#endif
+
+#define PPG_PI_F 3.14159265358979323846f      /* M_PI of the reference, constants.h:63,80 (float) */
+#define PPG_INV_PI_F 0.31830988618379067154f  /* INV_PI, constants.h */
+#define PPG_EPSILON 1e-4f                     /* Epsilon, constants.h:28 */
+
+PPG_HD uint32_t ppg_f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+PPG_HD float ppg_u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+PPG_HD bool ppg_isfinite(float x) { return (ppg_f2u(x) & 0x7f800000u) != 0x7f800000u; }
+PPG_HD float ppg_max(float a, float b) { return (a < b) ? b : a; } /* std::max semantics */
+PPG_HD float ppg_min(float a, float b) { return (b < a) ? b : a; } /* std::min semantics */
+PPG_HD float ppg_abs(float x) { return ppg_u2f(ppg_f2u(x) & 0x7fffffffu); }
+
+/* 2^n for -126 <= n <= 127, exact. */
+PPG_HD float ppg_exp2i(int n) { return ppg_u2f((uint32_t)(n + 127) << 23); }
+
+/* sin and cos of x (|x| < ~8192), Cephes sinf/cosf scheme. */
+PPG_HD void ppg_sincos(float xx, float *s_out, float *c_out) {
+    float x = ppg_abs(xx);
+    int sin_neg = (xx < 0.0f);
+    int cos_neg = 0;
+    int j = (int)(x * 1.27323954473516f); /* 4/pi */
+    float y = (float)j;
+    if (j & 1) { j += 1; y += 1.0f; }
+    j &= 7;
+    if (j > 3) { sin_neg = !sin_neg; cos_neg = !cos_neg; j -= 4; }
+    if (j > 1) cos_neg = !cos_neg;
+    x = ((x - y * 0.78515625f) - y * 2.4187564849853515625e-4f) - y * 3.77489497744594108e-8f;
+    float z = x * x;
+    float pc = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z - 0.5f * z + 1.0f;
+    float ps = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * x + x;
+    float s, c;
+    if (j == 1 || j == 2) { s = pc; c = ps; } else { s = ps; c = pc; }
+    *s_out = sin_neg ? -s : s;
+    *c_out = cos_neg ? -c : c;
+}
+
+/* atan(x), Cephes atanf scheme. */
+PPG_HD float ppg_atan(float xx) {
+    float x = ppg_abs(xx);
+    float y;
+    if (x > 2.414213562373095f) { y = 1.5707963267948966192f; x = -(1.0f / x); }
+    else if (x > 0.4142135623730950f) { y = 0.7853981633974483096f; x = (x - 1.0f) / (x + 1.0f); }
+    else y = 0.0f;
+    float z = x * x;
+    y += (((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z * x + x;
+    return (xx < 0.0f) ? -y : y;
+}
+
+/* atan2(y, x) with the usual quadrant rules (finite inputs). */
+PPG_HD float ppg_atan2(float y, float x) {
+    if (x == 0.0f) {
+        if (y == 0.0f) return 0.0f;
+        return (y > 0.0f) ? 1.5707963267948966192f : -1.5707963267948966192f;
+    }
+    float a = ppg_atan(y / x);
+    if (x < 0.0f) a = (y < 0.0f) ? (a - PPG_PI_F) : (a + PPG_PI_F);
+    return a;
+}
+
+/* exp(x) for |x| <= 80, Cephes expf scheme. */
+PPG_HD float ppg_exp(float x) {
+    if (x > 80.0f) x = 80.0f;
+    if (x < -80.0f) x = -80.0f;
+    float t = 1.44269504088896341f * x + 0.5f;
+    float fz = (float)(int)t;
+    if (fz > t) fz -= 1.0f; /* floor */
+    x -= fz * 0.693359375f;
+    x -= fz * -2.12194440e-4f;
+    int n = (int)fz;
+    float z = x * x;
+    z = (((((1.9875691500e-4f * x + 1.3981999507e-3f) * x + 8.3334519073e-3f) * x + 4.1665795894e-2f) * x
+          + 1.6666665459e-1f) * x + 5.0000001201e-1f) * z + x + 1.0f;
+    return z * ppg_exp2i(n);
+}
+
+/* b^n for integer n >= 0 by binary exponentiation (stands in for std::pow(beta, iter), GP:100). */
+PPG_HD float ppg_powi(float b, int n) {
+    float r = 1.0f;
+    while (n > 0) {
+        if (n & 1) r = r * b;
+        b = b * b;
+        n >>= 1;
+    }
+    return r;
+}
+
+/* Fixed-point accumulation of SD-tree statistics: round-to-nearest-even of x * 2^24 as uint64.
+   Caller guarantees x finite and >= 0; values >= 2^39 saturate (never reached by radiance data). */
+PPG_HD uint64_t ppg_to_fixed(float x) {
+    float v = x * 16777216.0f;
+    if (!(v < 9.2233720368547758e18f)) return 0x7fffffffffffffffull;
+    return (uint64_t)__builtin_rintf(v); /* exactly specified: nearest-even (v_rndne_f32 / rintf) */
+}
+PPG_HD float ppg_from_fixed(uint64_t a) { return (float)a * 5.9604644775390625e-8f; /* 2^-24 */ }
+
+/* Signed variant for Adam gradient sums, scale 2^20, |x| clamped to 2^40. */
+PPG_HD int64_t ppg_to_sfixed(float x) {
+    float a = ppg_abs(x);
+    if (!(a < 1.099511627776e12f)) a = 1.099511627776e12f;
+    int64_t r = (int64_t)__builtin_rintf(a * 1048576.0f);
+    return (x < 0.0f) ? -r : r;
+}
+PPG_HD float ppg_from_sfixed(int64_t a) { return (float)a * 9.5367431640625e-7f; /* 2^-20 */ }
+
+#endif /* PPG_DETMATH_H */

@@ -1,0 +1,330 @@
+"""ctypes binding of include/ppg.h.
+
+The product path is `Engine.hip()`: it loads practical-path-guiding_amd/lib/libppg_hip.so and raises
+if the library is missing — there is no CPU fallback.  `Engine(lib, prefix="ppgo_")` lets tests/ and
+bench.py's cpu_baseline drive the oracle through the identical call sequence.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PKG = os.path.dirname(_HERE)
+
+
+def hip_library_path():
+    return os.path.join(_PKG, "lib", "libppg_hip.so")
+
+
+class PPGError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("ppg error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Config(C.Structure):
+    """ppg_config — property names and defaults of guided_path.cpp:1014-1085 / integrator.cpp:190-225."""
+    _fields_ = [
+        ("nee", C.c_char_p), ("sampleCombination", C.c_char_p), ("spatialFilter", C.c_char_p),
+        ("directionalFilter", C.c_char_p), ("bsdfSamplingFractionLoss", C.c_char_p),
+        ("sdTreeMaxMemory", C.c_int32), ("sTreeThreshold", C.c_int32), ("dTreeThreshold", C.c_float),
+        ("bsdfSamplingFraction", C.c_float), ("sppPerPass", C.c_int32), ("budgetType", C.c_char_p),
+        ("budget", C.c_float), ("dumpSDTree", C.c_int32), ("rrDepth", C.c_int32), ("maxDepth", C.c_int32),
+        ("strictNormals", C.c_int32), ("hideEmitters", C.c_int32), ("seed", C.c_uint64), ("device", C.c_int32),
+        ("dumpPrefix", C.c_char_p),
+    ]
+
+    DEFAULTS = dict(nee="never", sampleCombination="automatic", spatialFilter="nearest", directionalFilter="nearest",
+                    bsdfSamplingFractionLoss="none", sdTreeMaxMemory=-1, sTreeThreshold=12000, dTreeThreshold=0.01,
+                    bsdfSamplingFraction=0.5, sppPerPass=4, budgetType="seconds", budget=300.0, dumpSDTree=0,
+                    rrDepth=5, maxDepth=-1, strictNormals=0, hideEmitters=0, seed=0, device=0, dumpPrefix=None)
+
+    @classmethod
+    def make(cls, **props):
+        unknown = set(props) - set(cls.DEFAULTS)
+        if unknown:
+            raise KeyError("unknown integrator properties: %s" % sorted(unknown))
+        vals = dict(cls.DEFAULTS)
+        vals.update(props)
+        cfg = cls()
+        cfg._keep = []
+        for k, v in vals.items():
+            if isinstance(v, str):
+                v = v.encode()
+                cfg._keep.append(v)
+            if isinstance(v, bool):
+                v = int(v)
+            setattr(cfg, k, v)
+        return cfg
+
+
+class Material(C.Structure):
+    _fields_ = [("type", C.c_int32), ("reflectance", C.c_float * 3), ("param", C.c_float * 4)]
+
+
+class Emitter(C.Structure):
+    _fields_ = [("radiance", C.c_float * 3), ("_pad", C.c_float)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("sample_to_camera", C.c_float * 16), ("camera_to_world", C.c_float * 16),
+                ("near_clip", C.c_float), ("far_clip", C.c_float), ("width", C.c_int32), ("height", C.c_int32)]
+
+
+class Scene(C.Structure):
+    _fields_ = [("n_vertices", C.c_uint32), ("positions", C.POINTER(C.c_float)), ("normals", C.POINTER(C.c_float)),
+                ("n_triangles", C.c_uint32), ("indices", C.POINTER(C.c_uint32)), ("tri_material", C.POINTER(C.c_uint32)),
+                ("tri_emitter", C.POINTER(C.c_int32)), ("n_materials", C.c_uint32), ("materials", C.POINTER(Material)),
+                ("n_emitters", C.c_uint32), ("emitters", C.POINTER(Emitter)), ("camera", Camera)]
+
+
+class _StatsMixin:
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class PassStats(C.Structure, _StatsMixin):
+    _fields_ = [("seconds", C.c_double), ("passes_rendered_total", C.c_int32), ("passes_rendered_local", C.c_int32),
+                ("variance", C.c_float), ("samples", C.c_uint64), ("rays", C.c_uint64), ("path_length_sum", C.c_uint64),
+                ("vertices_committed", C.c_uint64)]
+
+
+class TreeStats(C.Structure, _StatsMixin):
+    _fields_ = [("min_depth", C.c_int32), ("max_depth", C.c_int32), ("avg_depth", C.c_float),
+                ("min_mean_radiance", C.c_float), ("avg_mean_radiance", C.c_float), ("max_mean_radiance", C.c_float),
+                ("min_nodes", C.c_uint64), ("max_nodes", C.c_uint64), ("avg_nodes", C.c_float),
+                ("min_stat_weight", C.c_float), ("avg_stat_weight", C.c_float), ("max_stat_weight", C.c_float),
+                ("n_leaves", C.c_uint32), ("n_stree_nodes", C.c_uint32), ("n_dtree_nodes", C.c_uint64)]
+
+
+class SDTreeInfo(C.Structure):
+    _fields_ = [("n_stree_nodes", C.c_uint32), ("n_leaves", C.c_uint32), ("n_sampling_nodes", C.c_uint64),
+                ("n_building_nodes", C.c_uint64), ("aabb_min", C.c_float * 3), ("aabb_max", C.c_float * 3),
+                ("iter", C.c_int32), ("is_built", C.c_int32)]
+
+
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("ms", C.c_double), ("launches", C.c_uint64), ("units", C.c_uint64)]
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+class Engine:
+    """One integrator context (ppg_ctx).  Methods are 1:1 with include/ppg.h."""
+
+    def __init__(self, lib, prefix="ppg_", **props):
+        if isinstance(lib, str):
+            if not os.path.exists(lib):
+                raise FileNotFoundError(
+                    "%s not found — build it with `python __graft_entry__.py` (no CPU fallback exists)" % lib)
+            lib = C.CDLL(lib)
+        self.lib, self.prefix = lib, prefix
+        self.cfg = Config.make(**props)
+        self.props = dict(Config.DEFAULTS, **props)
+        self.ctx = C.c_void_p()
+        self._f("last_error").restype = C.c_char_p
+        self._f("last_error").argtypes = [C.c_void_p]
+        rc = self._f("create")(C.byref(self.cfg), C.byref(self.ctx))
+        if rc != 0:
+            raise PPGError(rc, (self._f("last_error")(None) or b"").decode())
+        self._scene_keep = None
+        self.width = self.height = 0
+
+    @classmethod
+    def hip(cls, **props):
+        return cls(hip_library_path(), "ppg_", **props)
+
+    def _f(self, name):
+        return getattr(self.lib, self.prefix + name)
+
+    def _call(self, name, *args):
+        rc = self._f(name)(self.ctx, *args)
+        if rc != 0:
+            raise PPGError(rc, (self._f("last_error")(self.ctx) or b"").decode())
+        return rc
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            f = self._f("destroy")
+            f.restype = None
+            f(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- scene -------------------------------------------------------------------------------
+    def set_scene(self, desc):
+        s = Scene()
+        pos = np.ascontiguousarray(desc.positions, np.float32)
+        idx = np.ascontiguousarray(desc.indices, np.uint32)
+        tm = np.ascontiguousarray(desc.tri_material, np.uint32)
+        te = np.ascontiguousarray(desc.tri_emitter, np.int32)
+        nrm = None if desc.normals is None else np.ascontiguousarray(desc.normals, np.float32)
+        mats = (Material * len(desc.materials))()
+        for i, m in enumerate(desc.materials):
+            mats[i].type = m.get("type", 0)
+            mats[i].reflectance[:] = [float(v) for v in m["reflectance"]]
+        ems = (Emitter * max(1, len(desc.emitters)))()
+        for i, e in enumerate(desc.emitters):
+            ems[i].radiance[:] = [float(v) for v in e["radiance"]]
+        s.n_vertices, s.positions = pos.shape[0], _fp(pos)
+        if nrm is not None:
+            s.normals = _fp(nrm)
+        s.n_triangles, s.indices = idx.shape[0], _p(idx, C.c_uint32)
+        s.tri_material = _p(tm, C.c_uint32)
+        s.tri_emitter = _p(te, C.c_int32)
+        s.n_materials, s.materials = len(desc.materials), mats
+        s.n_emitters, s.emitters = len(desc.emitters), ems
+        cam = desc.camera
+        s.camera.sample_to_camera[:] = [float(v) for v in np.asarray(cam["sample_to_camera"], np.float32).reshape(-1)]
+        s.camera.camera_to_world[:] = [float(v) for v in np.asarray(cam["camera_to_world"], np.float32).reshape(-1)]
+        s.camera.near_clip, s.camera.far_clip = cam["near_clip"], cam["far_clip"]
+        s.camera.width, s.camera.height = cam["width"], cam["height"]
+        self._scene_keep = (pos, idx, tm, te, nrm, mats, ems)
+        self._call("set_scene", C.byref(s))
+        self.width, self.height = cam["width"], cam["height"]
+
+    def set_shard(self, rank, world, tile_size=32):
+        self._call("set_shard", C.c_int32(rank), C.c_int32(world), C.c_int32(tile_size))
+
+    # -- rendering ---------------------------------------------------------------------------
+    def render(self):
+        self._call("render")
+
+    def begin_render(self):
+        self._call("begin_render")
+
+    def begin_iteration(self, is_final):
+        self._call("begin_iteration", C.c_int32(int(is_final)))
+
+    def set_final(self, is_final):
+        self._call("set_final", C.c_int32(int(is_final)))
+
+    def set_do_nee(self, v):
+        self._call("set_do_nee", C.c_int32(int(v)))
+
+    def render_passes(self, n):
+        st = PassStats()
+        self._call("render_passes", C.c_int32(n), C.byref(st))
+        return st
+
+    def render_passes_nostat(self, n):
+        self._call("render_passes_nostat", C.c_int32(n))
+
+    def finish_passes(self):
+        st = PassStats()
+        self._call("finish_passes", C.byref(st))
+        return st
+
+    def build_sdtree(self):
+        st = TreeStats()
+        self._call("build_sdtree", C.byref(st))
+        return st
+
+    def end_iteration(self):
+        self._call("end_iteration")
+
+    def end_render(self):
+        self._call("end_render")
+
+    def cancel(self):
+        self._call("cancel")
+
+    def read_film(self):
+        out = np.empty((self.height, self.width, 3), np.float32)
+        self._call("read_film", _fp(out))
+        return out
+
+    def read_variance(self):
+        out = np.empty((self.height, self.width, 3), np.float32)
+        self._call("read_variance", _fp(out))
+        return out
+
+    def dump_sdtree(self, path):
+        self._call("dump_sdtree", path.encode())
+
+    # -- SD-tree access ----------------------------------------------------------------------
+    def sdtree_info(self):
+        info = SDTreeInfo()
+        self._call("sdtree_info_get", C.byref(info))
+        return info
+
+    def read_sdtree(self):
+        """The S-tree and both D-tree sets in the reference's node numbering (dict of numpy arrays)."""
+        info = self.sdtree_info()
+        n = info.n_stree_nodes
+        axis = np.zeros(n, np.int32)
+        children = np.zeros((n, 2), np.uint32)
+        self._call("sdtree_read_stree", _p(axis, C.c_int32), _p(children, C.c_uint32))
+        out = {"axis": axis, "children": children, "n_leaves": info.n_leaves, "iter": info.iter,
+               "aabb_min": np.array(info.aabb_min[:], np.float32), "aabb_max": np.array(info.aabb_max[:], np.float32)}
+        for which, name, total in ((0, "sampling", info.n_sampling_nodes), (1, "building", info.n_building_nodes)):
+            off = np.zeros(n, np.uint64)
+            nn = np.zeros(n, np.uint32)
+            md = np.zeros(n, np.int32)
+            sm = np.zeros(n, np.float32)
+            sw = np.zeros(n, np.float64)
+            self._call("sdtree_read_dtree_headers", C.c_int32(which), _p(off, C.c_uint64), _p(nn, C.c_uint32),
+                       _p(md, C.c_int32), _fp(sm), _p(sw, C.c_double))
+            total = int(total)
+            sums = np.zeros((total, 4), np.float32)
+            ch = np.zeros((total, 4), np.uint16)
+            fx = np.zeros((total, 4), np.uint64)
+            self._call("sdtree_read_dtree_nodes", C.c_int32(which), _fp(sums), _p(ch, C.c_uint16), _p(fx, C.c_uint64))
+            out[name] = {"offset": off, "num_nodes": nn, "max_depth": md, "sum": sm, "stat_weight": sw,
+                         "node_sums": sums, "node_children": ch, "node_fixed": fx}
+        theta = np.zeros(n, np.float32)
+        self._call("sdtree_read_adam", _fp(theta))
+        out["theta"] = theta
+        return out
+
+    def query_pdf(self, positions, dirs):
+        p = np.ascontiguousarray(positions, np.float32)
+        d = np.ascontiguousarray(dirs, np.float32)
+        out = np.empty(p.shape[0], np.float32)
+        self._call("query_pdf", C.c_uint32(p.shape[0]), _fp(p), _fp(d), _fp(out))
+        return out
+
+    def query_sample(self, positions, seed):
+        p = np.ascontiguousarray(positions, np.float32)
+        out = np.empty((p.shape[0], 3), np.float32)
+        self._call("query_sample", C.c_uint32(p.shape[0]), _fp(p), C.c_uint64(seed), _fp(out))
+        return out
+
+    # -- HIP-only: device buffers and kernel timing --------------------------------------------
+    def stat_buffers(self):
+        ps, pw = C.c_void_p(), C.c_void_p()
+        ns, nw = C.c_uint64(), C.c_uint64()
+        self._call("sdtree_stat_buffers", C.byref(ps), C.byref(ns), C.byref(pw), C.byref(nw))
+        return (ps.value, ns.value), (pw.value, nw.value)
+
+    def film_buffers(self):
+        a, b = C.c_void_p(), C.c_void_p()
+        self._call("film_buffers", C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def image_buffers(self):
+        a, b = C.c_void_p(), C.c_void_p()
+        self._call("image_buffers", C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def enable_kernel_timing(self, on=True):
+        self._call("enable_kernel_timing", C.c_int32(int(on)))
+
+    def kernel_times(self):
+        arr = (KernelTime * 64)()
+        n = C.c_uint32()
+        self._call("kernel_times", arr, C.c_uint32(64), C.byref(n))
+        return [dict(name=arr[i].name.decode(), ms=arr[i].ms, launches=arr[i].launches, units=arr[i].units)
+                for i in range(n.value)]

@@ -1,0 +1,183 @@
+"""Procedural scene descriptions handed to ppg_set_scene().
+
+`cbox_scene()` restates /root/reference/scenes/cbox/cbox.xml + meshes/*.obj: 36 triangles, five
+Lambertian BSDFs, the upside-down area light, the pinhole camera.  Coordinates are the vertex data
+of the classic Cornell box; RGB values were derived from the XML's spectra with
+tools/derive_cbox_rgb.py (dev-time; it reads the CIE tables from the reference checkout).  The GPU
+box has no /root/reference, hence code instead of files.
+
+`room_scene()` is the "kitchen-class" stand-in of SURVEY.md §8(d) S3: a closed room lit only through
+a slit, filled with tessellated boxes — many triangles, hard indirect light, Lambertian only.
+"""
+import math
+
+import numpy as np
+
+
+class SceneDesc:
+    def __init__(self, positions, indices, tri_material, tri_emitter, materials, emitters, camera, normals=None):
+        self.positions, self.indices = positions, indices
+        self.tri_material, self.tri_emitter = tri_material, tri_emitter
+        self.materials, self.emitters, self.camera, self.normals = materials, emitters, camera, normals
+
+    @property
+    def n_triangles(self):
+        return int(np.asarray(self.indices).shape[0])
+
+
+def perspective_camera(origin, target, up, fov_deg, fov_axis, near, far, width, height):
+    """Matrices of sensors/perspective.cpp:150-164 (m_sampleToCamera) and Transform::lookAt
+    (transform.cpp:191-214); fov-axis handling of sensor.cpp:239-264.  Computed in double, stored as
+    float32 (these are inputs to both the HIP path and the oracle, not part of either)."""
+    aspect = float(width) / float(height)
+    axis = fov_axis
+    if axis == "smaller":
+        axis = "y" if aspect > 1 else "x"
+    elif axis == "larger":
+        axis = "x" if aspect > 1 else "y"
+    if axis == "x":
+        xfov = float(fov_deg)
+    elif axis == "y":  # setYFov → xfov = 2 atan(tan(yfov / 2) * aspect)
+        xfov = math.degrees(2.0 * math.atan(math.tan(0.5 * math.radians(fov_deg)) * aspect))
+    else:
+        raise ValueError("fovAxis %r not supported" % fov_axis)
+
+    def scale(v):
+        return np.diag([v[0], v[1], v[2], 1.0]).astype(np.float64)
+
+    def translate(v):
+        m = np.eye(4)
+        m[:3, 3] = v
+        return m
+
+    recip = 1.0 / (far - near)
+    cot = 1.0 / math.tan(math.radians(xfov / 2.0))
+    persp = np.array([[cot, 0, 0, 0], [0, cot, 0, 0], [0, 0, far * recip, -near * far * recip], [0, 0, 1, 0]], np.float64)
+    cam_to_sample = scale([-0.5, -0.5 * aspect, 1.0]) @ translate([-1.0, -1.0 / aspect, 0.0]) @ persp
+    sample_to_camera = np.linalg.inv(cam_to_sample).astype(np.float32)
+
+    p, t, u = (np.asarray(v, np.float64) for v in (origin, target, up))
+    d = (t - p) / np.linalg.norm(t - p)
+    left = np.cross(u, d)
+    left /= np.linalg.norm(left)
+    new_up = np.cross(d, left)
+    c2w = np.eye(4)
+    c2w[:3, 0], c2w[:3, 1], c2w[:3, 2], c2w[:3, 3] = left, new_up, d, p
+    return dict(sample_to_camera=sample_to_camera, camera_to_world=c2w.astype(np.float32), near_clip=float(near),
+                far_clip=float(far), width=int(width), height=int(height))
+
+
+# linear RGB of the spectra in scenes/cbox/cbox.xml (tools/derive_cbox_rgb.py)
+CBOX_RGB = {
+    "box": (0.88579154, 0.698900044, 0.666440606),
+    "white": (0.88579154, 0.698900044, 0.666440606),
+    "red": (0.570083559, 0.0430142134, 0.0443643667),
+    "green": (0.10540954, 0.377989352, 0.076434195),
+    "light": (0.936401188, 0.740475953, 0.705280542),
+}
+CBOX_EMITTER_RGB = (36.7738686, 21.976778, 5.50738001)
+
+
+def _extruded_box(footprint, h):
+    """Top, four sides, bottom of a box whose top face has the (x, z) corners `footprint` in the
+    winding of meshes/cbox_{small,large}box.obj (all faces wound to face outwards)."""
+    a, b, c, d = footprint
+    quads = [[(a[0], h, a[1]), (b[0], h, b[1]), (c[0], h, c[1]), (d[0], h, d[1])]]
+    ring = [a, d, c, b]
+    for i in range(4):
+        p, q = ring[i], ring[(i + 1) % 4]
+        quads.append([(p[0], 0.0, p[1]), (p[0], h, p[1]), (q[0], h, q[1]), (q[0], 0.0, q[1])])
+    quads.append([(d[0], 0.0, d[1]), (c[0], 0.0, c[1]), (b[0], 0.0, b[1]), (a[0], 0.0, a[1])])
+    return quads
+
+
+def _assemble(quads, names, materials, emitters, cam):
+    pos, idx, tmat, tem = [], [], [], []
+    for verts, mat, em in quads:
+        base = len(pos)
+        pos.extend(verts)
+        idx.extend([(base, base + 1, base + 2), (base, base + 2, base + 3)])  # obj.cpp: "f 1 2 3 4" → fan
+        tmat.extend([names.index(mat)] * 2)
+        tem.extend([em] * 2)
+    return SceneDesc(np.array(pos, np.float32), np.array(idx, np.uint32), np.array(tmat, np.uint32),
+                     np.array(tem, np.int32), materials, emitters, cam)
+
+
+def cbox_scene(width=512, height=512):
+    f32 = np.float32
+    quads = []  # (four vertices, material name, emitter index)
+    # luminaire: <rotate x="1" angle="180"/> then <translate y="1020" z="550"/>  →  (x, 1020 - y, 550 - z)
+    lum = [(343.0, 548.79999, 227.0), (343.0, 548.79999, 332.0), (213.0, 548.79999, 332.0), (213.0, 548.79999, 227.0)]
+    lum = [(x, float(f32(1020.0) - f32(y)), float(f32(550.0) - f32(z))) for (x, y, z) in lum]
+    quads.append((lum, "light", 0))
+    quads.append(([(552.79999, 0, 0), (0, 0, 0), (0, 0, 559.20001), (549.59998, 0, 559.20001)], "white", -1))  # floor
+    quads.append(([(556, 548.79999, 0), (556, 548.79999, 559.20001), (0, 548.79999, 559.20001), (0, 548.79999, 0)], "white", -1))  # ceiling
+    quads.append(([(549.59998, 0, 559.20001), (0, 0, 559.20001), (0, 548.79999, 559.20001), (556, 548.79999, 559.20001)], "white", -1))  # back
+    quads.append(([(0, 0, 559.20001), (0, 0, 0), (0, 548.79999, 0), (0, 548.79999, 559.20001)], "green", -1))
+    quads.append(([(552.79999, 0, 0), (549.59998, 0, 559.20001), (556, 548.79999, 559.20001), (556, 548.79999, 0)], "red", -1))
+    for q in _extruded_box([(130.0, 65.0), (82.0, 225.0), (240.0, 272.0), (290.0, 114.0)], 165.0):
+        quads.append((q, "box", -1))
+    for q in _extruded_box([(423.0, 247.0), (265.0, 296.0), (314.0, 456.0), (472.0, 406.0)], 330.0):
+        quads.append((q, "box", -1))
+    names = ["box", "white", "red", "green", "light"]
+    materials = [dict(type=0, reflectance=CBOX_RGB[n]) for n in names]
+    emitters = [dict(radiance=CBOX_EMITTER_RGB)]
+    cam = perspective_camera((278, 273, -800), (278, 273, -799), (0, 1, 0), 39.3077, "smaller", 10.0, 2800.0, width, height)
+    return _assemble(quads, names, materials, emitters, cam)
+
+
+def room_scene(width=1280, height=720, n_boxes=2000, tess=4, seed=1234):
+    """Kitchen-class stand-in: 4 x 3 x 5 m closed room, one emitter behind a
+    ceiling slit (all light is indirect), `n_boxes` random boxes each face tessellated tess x tess.
+    Triangles = 12 * tess^2 * n_boxes + room.  Deterministic in `seed`."""
+    rng = np.random.RandomState(seed)
+    quads = []
+
+    def add_box(lo, hi, mat):
+        (x0, y0, z0), (x1, y1, z1) = lo, hi
+        faces = [
+            [(x0, y1, z0), (x0, y1, z1), (x1, y1, z1), (x1, y1, z0)],  # top (+y)
+            [(x0, y0, z0), (x1, y0, z0), (x1, y0, z1), (x0, y0, z1)],  # bottom (-y)
+            [(x0, y0, z0), (x0, y1, z0), (x1, y1, z0), (x1, y0, z0)],  # -z
+            [(x1, y0, z1), (x1, y1, z1), (x0, y1, z1), (x0, y0, z1)],  # +z
+            [(x0, y0, z1), (x0, y1, z1), (x0, y1, z0), (x0, y0, z0)],  # -x
+            [(x1, y0, z0), (x1, y1, z0), (x1, y1, z1), (x1, y0, z1)],  # +x
+        ]
+        for f in faces:
+            a, b, c, d = (np.array(v, np.float64) for v in f)
+            for i in range(tess):
+                for j in range(tess):
+                    u0, u1, v0, v1 = i / tess, (i + 1) / tess, j / tess, (j + 1) / tess
+                    P = lambda u, v: tuple(a + (b - a) * u + (d - a) * v)  # noqa: E731
+                    quads.append(([P(u0, v0), P(u1, v0), P(u1, v1), P(u0, v1)], mat, -1))
+
+    def add_room_face(f, mat, em=-1):
+        quads.append((f, mat, em))
+
+    X, Y, Z = 4.0, 3.0, 5.0
+    add_room_face([(0, 0, 0), (0, 0, Z), (X, 0, Z), (X, 0, 0)], "floor")
+    add_room_face([(0, 0, Z), (0, Y, Z), (X, Y, Z), (X, 0, Z)], "wall")       # back  (+z), faces -z
+    add_room_face([(0, 0, 0), (X, 0, 0), (X, Y, 0), (0, Y, 0)], "wall")       # front (z=0), faces +z
+    add_room_face([(0, 0, 0), (0, Y, 0), (0, Y, Z), (0, 0, Z)], "left")       # x=0, faces +x
+    add_room_face([(X, 0, 0), (X, 0, Z), (X, Y, Z), (X, Y, 0)], "right")      # x=X, faces -x
+    # ceiling with a slit along x at z in [2.3, 2.7]; light box above the slit
+    add_room_face([(0, Y, 0), (X, Y, 0), (X, Y, 2.3), (0, Y, 2.3)], "wall")
+    add_room_face([(0, Y, 2.7), (X, Y, 2.7), (X, Y, Z), (0, Y, Z)], "wall")
+    add_room_face([(0, Y + 0.5, 2.3), (X, Y + 0.5, 2.3), (X, Y + 0.5, 2.7), (0, Y + 0.5, 2.7)], "light", 0)  # emitter, faces down
+    add_room_face([(0, Y, 2.3), (X, Y, 2.3), (X, Y + 0.5, 2.3), (0, Y + 0.5, 2.3)], "wall")
+    add_room_face([(0, Y, 2.7), (0, Y + 0.5, 2.7), (X, Y + 0.5, 2.7), (X, Y, 2.7)], "wall")
+    add_room_face([(0, Y, 2.3), (0, Y + 0.5, 2.3), (0, Y + 0.5, 2.7), (0, Y, 2.7)], "wall")
+    add_room_face([(X, Y, 2.3), (X, Y, 2.7), (X, Y + 0.5, 2.7), (X, Y + 0.5, 2.3)], "wall")
+    mats = ["floor", "wall", "left", "right", "light", "b0", "b1", "b2"]
+    for k in range(n_boxes):
+        sx, sz = rng.uniform(0.05, 0.25, 2)
+        sy = rng.uniform(0.05, 0.9)
+        cx, cz = rng.uniform(0.3, X - 0.3), rng.uniform(1.2, Z - 0.3)
+        y0 = 0.0 if rng.rand() < 0.7 else rng.uniform(0.3, 2.0)
+        add_box((cx - sx, y0, cz - sz), (cx + sx, y0 + sy, cz + sz), "b%d" % (k % 3))
+    refl = {"floor": (0.6, 0.55, 0.5), "wall": (0.75, 0.75, 0.75), "left": (0.6, 0.1, 0.1), "right": (0.1, 0.5, 0.15),
+            "light": (0.0, 0.0, 0.0), "b0": (0.7, 0.6, 0.4), "b1": (0.3, 0.4, 0.7), "b2": (0.8, 0.8, 0.8)}
+    materials = [dict(type=0, reflectance=refl[m]) for m in mats]
+    emitters = [dict(radiance=(60.0, 55.0, 45.0))]
+    cam = perspective_camera((2.0, 1.5, 0.15), (2.0, 1.2, 3.0), (0, 1, 0), 70.0, "x", 0.05, 100.0, width, height)
+    return _assemble(quads, mats, materials, emitters, cam)

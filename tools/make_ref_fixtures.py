@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""Dev-time tool: mine the reference's shipped renders for known answers (DATA, not source).
+
+Reads  /root/reference/scenes/*/*.exr   (only available in the development container)
+Writes tests/golden/ref_logs.json       parsed per-iteration log lines embedded in the EXR headers
+                                        (written by mitsuba/src/films/hdrfilm.cpp:527-534; the lines
+                                        themselves are printed by guided_path.cpp:1176-1186, 1325, 1376)
+       tests/golden/ref_cbox_images.npz 64x64 block-averaged RGB of cbox.exr / cbox-improved.exr + mean RGB
+
+These are the only outputs of the reference integrator that exist for this path (SURVEY.md §4, §6,
+§8(c)); the oracle is pinned against them statistically (tests/test_oracle_reference_pins.py).
+"""
+import json, os, re, sys
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from exr_min import read_exr, read_header, attr_string  # noqa: E402
+
+REF = "/root/reference/scenes"
+OUT = os.path.join(HERE, "..", "tests", "golden")
+SCENES = ["cbox/cbox", "cbox/cbox-improved", "kitchen/kitchen", "kitchen/kitchen-improved",
+          "spaceship/spaceship", "spaceship/spaceship-improved"]
+
+F = r"([-+0-9.eE#INFa-z]+)"
+
+
+def fnum(s):
+    s = s.strip().rstrip(".")
+    if "#INF" in s or s in ("inf", "-inf"):
+        return float("-inf") if s.startswith("-") else float("inf")
+    return float(s)
+
+
+def triple(s):
+    a, b, c = [fnum(x) for x in s.split(",")]
+    return [a, b, c]
+
+
+def parse_log(log):
+    res = {"iterations": []}
+    m = re.search(r"Starting render job \((\d+)x(\d+), (\d+) cores", log)
+    res["width"], res["height"], res["cores"] = int(m.group(1)), int(m.group(2)), int(m.group(3))
+    cur = None
+    for line in log.split("\n"):
+        m = re.search(r"ITERATION (\d+), (\d+) passes", line)
+        if m:
+            cur = {"iter": int(m.group(1)), "passes": int(m.group(2))}
+            res["iterations"].append(cur)
+            continue
+        m = re.search(r"FINAL (\d+) passes", line)
+        if m and cur is not None:
+            cur["final_passes"] = int(m.group(1))
+        m = re.search(F + r" seconds, Total passes: (\d+), Var: " + F + ",", line)
+        if m and cur is not None:
+            cur.setdefault("seconds", []).append(fnum(m.group(1)))
+            cur.setdefault("total_passes", []).append(int(m.group(2)))
+            cur.setdefault("var", []).append(fnum(m.group(3)))
+        for key, pat in (("depth", "Depth"), ("mean_radiance", "Mean radiance"),
+                         ("node_count", "Node count"), ("stat_weight", r"Stat\. weight")):
+            m = re.search(pat + r"\s*= \[(.*)\]", line)
+            if m and cur is not None:
+                cur[key] = triple(m.group(1))
+        m = re.search(r"Render time: " + F + "([sm])", line)
+        if m:
+            res["render_time_s"] = fnum(m.group(1)) * (60.0 if m.group(2) == "m" else 1.0)
+        m = re.search(r"Normal rays traced : " + F + " ([MG])", line)
+        if m:
+            res["rays"] = fnum(m.group(1)) * (1e9 if m.group(2) == "G" else 1e6)
+        m = re.search(r"Average path length : " + F + r" \(" + F + " ([MG]) / " + F + " ([MG])", line)
+        if m:
+            res["avg_path_length"] = fnum(m.group(1))
+            res["samples"] = fnum(m.group(4)) * (1e9 if m.group(5) == "G" else 1e6)
+    return res
+
+
+def main():
+    logs = {}
+    for s in SCENES:
+        buf = open(os.path.join(REF, s + ".exr"), "rb").read()
+        attrs, _ = read_header(buf)
+        logs[os.path.basename(s)] = parse_log(attr_string(attrs, "log"))
+    with open(os.path.join(OUT, "ref_logs.json"), "w") as f:
+        json.dump({"source": "log attribute of /root/reference/scenes/*/*.exr (tag 2024_10_08)",
+                   "generator": "tools/make_ref_fixtures.py", "scenes": logs}, f, indent=1, allow_nan=True)
+    imgs = {}
+    for s in ("cbox/cbox", "cbox/cbox-improved"):
+        _, ch = read_exr(os.path.join(REF, s + ".exr"))
+        rgb = np.stack([ch["R"], ch["G"], ch["B"]], -1).astype(np.float64)
+        H, W, _ = rgb.shape
+        b = 8
+        small = rgb.reshape(H // b, b, W // b, b, 3).mean((1, 3))
+        key = os.path.basename(s).replace("-", "_")
+        imgs[key + "_block8"] = small.astype(np.float32)
+        imgs[key + "_mean_rgb"] = rgb.mean((0, 1)).astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "ref_cbox_images.npz"), **imgs)
+    print({k: (v.shape, v.mean()) for k, v in imgs.items()})
+    for k, v in logs.items():
+        print(k, [(i["iter"], i["passes"]) for i in v["iterations"]], v.get("avg_path_length"))
+
+
+if __name__ == "__main__":
+    main()
