@@ -1896,6 +1896,22 @@ void ppgo_dir_to_canonical(const float *d, float *xy) {
     xy[0] = p.x; xy[1] = p.y;
 }
 
+// element-wise evaluation of the shared numerical contract (tests/test_detmath.py)
+int ppgo_math_eval(int32_t op, uint32_t n, const float *a, const float *b, float *out0, float *out1) {
+    for (uint32_t i = 0; i < n; ++i) {
+        switch (op) {
+            case 0: ppg_sincos(a[i], &out0[i], &out1[i]); break;
+            case 1: out0[i] = ppg_atan2(a[i], b[i]); break;
+            case 2: out0[i] = ppg_exp(a[i]); break;
+            case 3: out0[i] = ppg_from_fixed(ppg_to_fixed(a[i])); break;
+            case 4: out0[i] = ppg_rand((uint32_t)i * 2654435761u + 17u, (uint32_t)b[i]); break;
+            case 5: out0[i] = ppg_powi(a[i], (int)b[i]); break;
+            default: return PPG_ERR_INVALID;
+        }
+    }
+    return PPG_OK;
+}
+
 int ppgo_dtree_exercise(int32_t acc_mode, int32_t directional_filter, float rho, uint32_t n, const float *xy, const float *irradiance,
                         const float *weight, uint32_t m, const float *query_xy, uint64_t seed, float *pdf_out, float *sample_xy_out,
                         uint32_t *num_nodes_out, float *node_sums_out, uint16_t *node_children_out, float *stat_weight_out,

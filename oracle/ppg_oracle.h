@@ -73,6 +73,8 @@ int ppgo_ka_adam(int32_t n, float product, float wo_pdf, float bsdf_pdf, float d
 /* canonicalToDir / dirToCanonical (GP:586-608) */
 void ppgo_canonical_to_dir(float x, float y, float *d);
 void ppgo_dir_to_canonical(const float *d, float *xy);
+/* element-wise ppg_detmath.h / ppg_rng.h evaluation: op 0 sincos(a), 1 atan2(a,b), 2 exp(a), 3 fixed round trip, 4 rand, 5 powi */
+int ppgo_math_eval(int32_t op, uint32_t n, const float *a, const float *b, float *out0, float *out1);
 /* D-tree exercise: record `n` (canonical xy, irradiance, weight) samples into a fresh wrapper with the
    given filter / acc mode, build, reset(rho), record again, build; then evaluate pdf at `m` query
    points and draw `m` samples keyed (seed, i).  Outputs node arrays of the final sampling tree. */

@@ -1,0 +1,433 @@
+/*
+ * ppg_device.h — device-side data layout and per-path building blocks of the guided path tracer.
+ *
+ * Layout (everything lives in HBM, flat arrays, no pointers inside nodes):
+ *   triangles   3 x float4 per triangle in BVH-leaf order: (p0, material), (p1, emitter), (p2, original index)
+ *   BVH2        64-byte nodes: both child boxes + child refs (one node visit = one 64 B read)
+ *   S-tree      int4 per node {axis, child0, child1, 0}; child0 == 0 ⇔ leaf   (STreeNode, GP:740-845)
+ *   leaf hdr    LeafHdr per S-tree node (D-tree descriptors + Adam state)      (DTreeWrapper, GP:570-738)
+ *   sampling D-trees  SNode pool: float sum[4] + u16 child[4] + pad = 32 B     (QuadTreeNode, GP:158-371)
+ *   building D-trees  bchild pool (u16x4) + bacc pool (u64x4 fixed point), index-aligned with the SNode
+ *                     pool of the next iteration
+ * GP:n = /root/reference/mitsuba/src/integrators/path/guided_path.cpp:n.
+ *
+ * All floating-point expressions are written out operation by operation (no FMA contraction, no libm)
+ * so that the result of every path is bit-identical to the CPU oracle given the same sampler key.
+ */
+#ifndef PPG_DEVICE_H
+#define PPG_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ppg_detmath.h"
+#include "../../include/ppg_rng.h"
+
+#define D __device__ __forceinline__
+
+struct F3 {
+    float x, y, z;
+};
+D F3 f3(float x, float y, float z) { F3 r; r.x = x; r.y = y; r.z = z; return r; }
+D F3 f3s(float v) { return f3(v, v, v); }
+D F3 operator+(F3 a, F3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }
+D F3 operator-(F3 a, F3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
+D F3 operator*(F3 a, float f) { return f3(a.x * f, a.y * f, a.z * f); }
+D F3 operator-(F3 a) { return f3(-a.x, -a.y, -a.z); }
+D F3 mul3(F3 a, F3 b) { return f3(a.x * b.x, a.y * b.y, a.z * b.z); }
+D F3 div3(F3 a, float f) { float r = 1.0f / f; return f3(a.x * r, a.y * r, a.z * r); }  // vector.h:535-542
+D float dot3(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+D F3 cross3(F3 a, F3 b) { return f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+D float len3(F3 v) { return __builtin_sqrtf(dot3(v, v)); }
+D F3 norm3(F3 v) { return div3(v, len3(v)); }  // vector.h:625-627
+D float comp3(F3 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
+D bool iszero3(F3 s) { return s.x == 0.0f && s.y == 0.0f && s.z == 0.0f; }
+D bool isvalid3(F3 s) {  // spectrum.h:467-472
+    return ppg_isfinite(s.x) && !(s.x < 0.0f) && ppg_isfinite(s.y) && !(s.y < 0.0f) && ppg_isfinite(s.z) && !(s.z < 0.0f);
+}
+D float avg3(F3 s) { float r = 0.0f; r += s.x; r += s.y; r += s.z; return r * (1.0f / 3); }  // spectrum.h:481-486
+D float max3(F3 s) { return ppg_max(ppg_max(s.x, s.y), s.z); }
+D F3 ld3(const float4 *p) { float4 v = *p; return f3(v.x, v.y, v.z); }
+
+// ------------------------------------------------------------------------------------------------
+// Scene
+// ------------------------------------------------------------------------------------------------
+struct BvhNode {  // 64 B
+    float lo0[3], hi0[3], lo1[3], hi1[3];
+    int c0, c1;   // n > 0: first triangle (leaf-order index); n == 0: node index
+    int n0, n1;   // > 0 leaf with n triangles, 0 interior, < 0 empty
+};
+
+struct DevCamera {
+    float s2c[16], c2w[16];
+    float near_clip, far_clip, inv_w, inv_h;
+    int width, height;
+};
+
+struct DevScene {
+    const float4 *tris;     // 3 per triangle
+    const float4 *normals;  // 3 per triangle or nullptr
+    const BvhNode *bvh;
+    const float4 *materials;  // (reflectance rgb, type)
+    const float4 *emitters;   // (radiance rgb, -)
+    int n_tris;
+    DevCamera cam;
+};
+
+struct Hit {
+    float t, u, v;
+    int prim;  // leaf-order triangle index, -1 = miss
+};
+
+// Möller–Trumbore, identical arithmetic to oracle Scene::triHit; accepts mint <= t <= maxt.
+D bool tri_hit(const float4 *T, F3 o, F3 d, float mint, float maxt, float &tt, float &uu, float &vv) {
+    F3 p0 = ld3(T), p1 = ld3(T + 1), p2 = ld3(T + 2);
+    F3 e1 = p1 - p0, e2 = p2 - p0;
+    F3 pvec = cross3(d, e2);
+    float det = dot3(e1, pvec);
+    if (det == 0.0f) return false;
+    float inv = 1.0f / det;
+    F3 tvec = o - p0;
+    float u = dot3(tvec, pvec) * inv;
+    if (u < 0.0f || u > 1.0f) return false;
+    F3 qvec = cross3(tvec, e1);
+    float v = dot3(d, qvec) * inv;
+    if (v < 0.0f || u + v > 1.0f) return false;
+    float th = dot3(e2, qvec) * inv;
+    if (!(th >= mint && th <= maxt)) return false;
+    tt = th; uu = u; vv = v;
+    return true;
+}
+
+D float safe_inv(float d) { return d == 0.0f ? 1e30f : 1.0f / d; }
+
+// conservative slab test against a (padded) box; returns entry distance in tn
+D bool box_hit(const float *lo, const float *hi, F3 o, F3 id, float t0, float t1, float &tn) {
+    float ax = (lo[0] - o.x) * id.x, bx = (hi[0] - o.x) * id.x;
+    float ay = (lo[1] - o.y) * id.y, by = (hi[1] - o.y) * id.y;
+    float az = (lo[2] - o.z) * id.z, bz = (hi[2] - o.z) * id.z;
+    float n = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), t0));
+    float f = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), t1));
+    tn = n;
+    return n <= f;
+}
+
+// Closest hit by (t, original primitive index) — order independent, equals brute force.
+D Hit trace_closest(const DevScene &S, F3 o, F3 d, float mint, float maxt) {
+    Hit best;
+    best.t = __builtin_inff(); best.u = 0; best.v = 0; best.prim = -1;
+    int bestOrig = 0x7fffffff;
+    F3 id = f3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
+    int stack[48];
+    int sp = 0;
+    int cur = 0;
+    for (;;) {
+        const BvhNode nd = S.bvh[cur];
+        float tlim = fminf(maxt, best.t);
+        float tn0, tn1;
+        bool h0 = nd.n0 >= 0 && box_hit(nd.lo0, nd.hi0, o, id, mint, tlim, tn0);
+        bool h1 = nd.n1 >= 0 && box_hit(nd.lo1, nd.hi1, o, id, mint, tlim, tn1);
+        int next0 = -1, next1 = -1;
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            bool h = side ? h1 : h0;
+            int n = side ? nd.n1 : nd.n0, c = side ? nd.c1 : nd.c0;
+            if (!h) continue;
+            if (n > 0) {
+                for (int k = c; k < c + n; ++k) {
+                    float tt, uu, vv;
+                    const float4 *T = S.tris + 3 * k;
+                    if (tri_hit(T, o, d, mint, maxt, tt, uu, vv)) {
+                        int orig = __float_as_int(T[2].w);
+                        if (tt < best.t || (tt == best.t && orig < bestOrig)) {
+                            best.t = tt; best.u = uu; best.v = vv; best.prim = k; bestOrig = orig;
+                        }
+                    }
+                }
+            } else if (side == 0) next0 = c; else next1 = c;
+        }
+        if (next0 >= 0 && next1 >= 0) {
+            if (tn1 < tn0) { int t = next0; next0 = next1; next1 = t; }
+            stack[sp++] = next1;
+            cur = next0;
+        } else if (next0 >= 0) cur = next0;
+        else if (next1 >= 0) cur = next1;
+        else {
+            if (sp == 0) break;
+            cur = stack[--sp];
+        }
+    }
+    return best;
+}
+
+// Intersection record: fillIntersectionRecord (skdtree.h:343-430) + computeShadingFrame (util.cpp:603-608)
+struct Isect {
+    F3 p, geoN, s, t, n, wi;
+    int material, emitter;
+};
+D F3 to_local(const Isect &I, F3 v) { return f3(dot3(v, I.s), dot3(v, I.t), dot3(v, I.n)); }
+D F3 to_world(const Isect &I, F3 v) { return I.s * v.x + I.t * v.y + I.n * v.z; }
+
+D void fill_isect(const DevScene &S, const Hit &h, F3 d, Isect &I) {
+    const float4 *T = S.tris + 3 * h.prim;
+    float4 q0 = T[0], q1 = T[1];
+    F3 p0 = f3(q0.x, q0.y, q0.z), p1 = f3(q1.x, q1.y, q1.z), p2 = ld3(T + 2);
+    F3 b = f3(1 - h.u - h.v, h.u, h.v);
+    I.p = p0 * b.x + p1 * b.y + p2 * b.z;
+    F3 side1 = p1 - p0, side2 = p2 - p0;
+    F3 fn = cross3(side1, side2);
+    float len = len3(fn);
+    if (!(fn.x == 0 && fn.y == 0 && fn.z == 0)) fn = div3(fn, len);
+    F3 shN;
+    if (S.normals) {
+        const float4 *Nn = S.normals + 3 * h.prim;
+        shN = norm3(ld3(Nn) * b.x + ld3(Nn + 1) * b.y + ld3(Nn + 2) * b.z);
+        if (dot3(fn, shN) < 0) fn = -fn;
+    } else {
+        shN = fn;
+    }
+    I.geoN = fn;
+    I.n = shN;
+    I.s = norm3(side1 - shN * dot3(shN, side1));
+    I.t = cross3(shN, I.s);
+    I.wi = to_local(I, -d);
+    I.material = __float_as_int(q0.w);
+    I.emitter = __float_as_int(q1.w);
+}
+
+// AreaLight::eval (area.cpp:104-109)
+D F3 eval_Le(const DevScene &S, const Isect &I, F3 dir) {
+    if (I.emitter < 0) return f3s(0.0f);
+    if (dot3(I.n, dir) <= 0) return f3s(0.0f);
+    float4 r = S.emitters[I.emitter];
+    return f3(r.x, r.y, r.z);
+}
+
+// Transform::operator()(Point) (transform.h:108-125) and operator()(Vector) (:175-183)
+D F3 xf_point(const float *m, F3 p) {
+    float x = m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3];
+    float y = m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7];
+    float z = m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11];
+    float w = m[12] * p.x + m[13] * p.y + m[14] * p.z + m[15];
+    if (w == 1.0f) return f3(x, y, z);
+    return div3(f3(x, y, z), w);
+}
+D F3 xf_vec(const float *m, F3 v) {
+    return f3(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z, m[8] * v.x + m[9] * v.y + m[10] * v.z);
+}
+
+// warp.cpp:81-102, 43-52
+D void disk_concentric(float sx, float sy, float &px, float &py) {
+    float r1 = 2.0f * sx - 1.0f;
+    float r2 = 2.0f * sy - 1.0f;
+    float phi, r;
+    if (r1 == 0 && r2 == 0) {
+        r = phi = 0;
+    } else if (r1 * r1 > r2 * r2) {
+        r = r1;
+        phi = (PPG_PI_F / 4.0f) * (r2 / r1);
+    } else {
+        r = r2;
+        phi = (PPG_PI_F / 2.0f) - (r1 / r2) * (PPG_PI_F / 4.0f);
+    }
+    float c, s;
+    ppg_sincos(phi, &s, &c);
+    px = r * c; py = r * s;
+}
+D F3 cosine_hemisphere(float sx, float sy) {
+    float px, py;
+    disk_concentric(sx, sy, px, py);
+    float z = __builtin_sqrtf(ppg_max(0.0f, 1.0f - px * px - py * py));
+    if (z == 0) z = 1e-10f;
+    return f3(px, py, z);
+}
+
+// SmoothDiffuse (diffuse.cpp:110-150)
+D F3 diffuse_eval(F3 refl, F3 wi, F3 wo) {
+    if (wi.z <= 0 || wo.z <= 0) return f3s(0.0f);
+    return refl * (PPG_INV_PI_F * wo.z);
+}
+D float diffuse_pdf(F3 wi, F3 wo) {
+    if (wi.z <= 0 || wo.z <= 0) return 0.0f;
+    return PPG_INV_PI_F * wo.z;
+}
+
+// ------------------------------------------------------------------------------------------------
+// SD-tree
+// ------------------------------------------------------------------------------------------------
+struct __attribute__((aligned(32))) SNode {  // sampling quadtree node, 32 B
+    float sum[4];
+    unsigned short child[4];
+    unsigned int pad[2];
+};
+
+struct __attribute__((aligned(16))) LeafHdr {  // one per S-tree node, 64 B
+    unsigned int s_base, s_num;  // sampling D-tree: first node in the SNode pool, node count
+    float s_sum, s_statw;        // DTree::m_atomic {sum, statisticalWeight} of the sampling tree (GP:538-557)
+    unsigned int b_base, b_num;  // building D-tree block in bchild / bacc
+    int s_depth, b_depth;        // m_maxDepth
+    float theta;                 // AdamOptimizer::State (GP:116-124)
+    int adam_iter;
+    float adam_m, adam_v;
+    float b_statw;               // statisticalWeightBuilding() as float (valid after build; halved by refine)
+    unsigned int pad[3];
+};
+
+struct DevTree {
+    const int4 *stree;            // {axis, child0, child1, -}
+    LeafHdr *hdr;                 // per S-tree node
+    const SNode *snodes;          // sampling pool
+    const ushort4 *bchild;        // building pool topology
+    unsigned long long *bacc;     // building pool accumulators [node*4 + slot], 2^-24 fixed point
+    unsigned long long *bweight;  // per S-tree node: building statistical weight accumulator
+    long long *adam_grad;         // per S-tree node: per-pass Σ gradient·weight (2^-20)
+    unsigned long long *adam_w;   // per S-tree node: per-pass Σ weight (2^-24)
+    float aabb_min[3], aabb_ext[3];  // cubified AABB (GP:857-859)
+    float aabb_max[3];
+    int is_built;
+};
+
+// STree::dTreeWrapper (GP:897-905) + STreeNode::dTreeWrapper (GP:761-769): leaf index and voxel size
+D int stree_lookup(const DevTree &T, F3 pw, F3 &size) {
+    size = f3(T.aabb_ext[0], T.aabb_ext[1], T.aabb_ext[2]);
+    float p[3];
+    p[0] = (pw.x - T.aabb_min[0]) / size.x;
+    p[1] = (pw.y - T.aabb_min[1]) / size.y;
+    p[2] = (pw.z - T.aabb_min[2]) / size.z;
+    float sz[3] = {size.x, size.y, size.z};
+    int idx = 0;
+    for (;;) {
+        int4 n = T.stree[idx];
+        if (n.y == 0) break;
+        int a = n.x;
+        sz[a] /= 2;
+        if (p[a] < 0.5f) {
+            p[a] *= 2;
+            idx = n.y;
+        } else {
+            p[a] = (p[a] - 0.5f) * 2;
+            idx = n.z;
+        }
+    }
+    size = f3(sz[0], sz[1], sz[2]);
+    return idx;
+}
+
+// DTreeWrapper::canonicalToDir / dirToCanonical (GP:586-608)
+D F3 canonical_to_dir(float px, float py) {
+    const float cosTheta = 2 * px - 1;
+    const float phi = 2 * PPG_PI_F * py;
+    const float sinTheta = __builtin_sqrtf(1 - cosTheta * cosTheta);
+    float sinPhi, cosPhi;
+    ppg_sincos(phi, &sinPhi, &cosPhi);
+    return f3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
+}
+D void dir_to_canonical(F3 d, float &px, float &py) {
+    if (!ppg_isfinite(d.x) || !ppg_isfinite(d.y) || !ppg_isfinite(d.z)) { px = 0; py = 0; return; }
+    const float cosTheta = ppg_min(ppg_max(d.z, -1.0f), 1.0f);
+    float phi = ppg_atan2(d.y, d.x);
+    while (phi < 0) phi = (float)((double)phi + 2.0 * (double)PPG_PI_F);
+    px = (cosTheta + 1) / 2;
+    py = phi / (2 * PPG_PI_F);
+}
+
+// QuadTreeNode::childIndex (GP:205-217)
+D int quad_child_index(float &px, float &py) {
+    int res = 0;
+    if (px < 0.5f) px *= 2; else { px = (px - 0.5f) * 2; res |= 1; }
+    if (py < 0.5f) py *= 2; else { py = (py - 0.5f) * 2; res |= 2; }
+    return res;
+}
+
+// DTree::mean (GP:387-393)
+D float dtree_mean(float sum, float statw) {
+    if (statw == 0) return 0;
+    const float factor = 1 / (PPG_PI_F * 4 * statw);
+    return factor * sum;
+}
+
+// DTree::pdf + QuadTreeNode::pdf (GP:415-421, 232-245), iterative
+D float dtree_pdf(const DevTree &T, const LeafHdr &h, float px, float py) {
+    if (!(dtree_mean(h.s_sum, h.s_statw) > 0)) return 1 / (4 * PPG_PI_F);
+    // the recursion multiplies factors from the leaf upwards: f1 * (f2 * (f3 * ...)); keep that order
+    float factors[24];
+    int nf = 0;
+    unsigned int node = 0;
+    float result;
+    for (;;) {
+        const SNode n = T.snodes[h.s_base + node];
+        const int index = quad_child_index(px, py);
+        if (!(n.sum[index] > 0)) { result = 0; break; }
+        const float factor = 4 * n.sum[index] / (n.sum[0] + n.sum[1] + n.sum[2] + n.sum[3]);
+        if (n.child[index] == 0) { result = factor; break; }
+        factors[nf++] = factor;
+        node = n.child[index];
+    }
+    for (int i = nf - 1; i >= 0; --i) result = factors[i] * result;
+    return result / (4 * PPG_PI_F);
+}
+
+// DTree::sample + QuadTreeNode::sample (GP:431-442, 257-301), iterative.
+// The recursion returns origin + 0.5 * child.sample(); unrolled as a stack of origins.
+D void dtree_sample(const DevTree &T, const LeafHdr &h, uint32_t key, uint32_t &dim, float &ox, float &oy) {
+    if (!(dtree_mean(h.s_sum, h.s_statw) > 0)) {
+        ox = ppg_rand(key, dim++);
+        oy = ppg_rand(key, dim++);
+        return;
+    }
+    float orgx[24], orgy[24];
+    int depth = 0;
+    unsigned int node = 0;
+    float rx, ry;
+    for (;;) {
+        const SNode n = T.snodes[h.s_base + node];
+        int index = 0;
+        float topLeft = n.sum[0];
+        float topRight = n.sum[1];
+        float partial = topLeft + n.sum[2];
+        float total = partial + topRight + n.sum[3];
+        if (!(total > 0.0f)) {
+            rx = ppg_rand(key, dim++);
+            ry = ppg_rand(key, dim++);
+            break;
+        }
+        float boundary = partial / total;
+        float ogx = 0.0f, ogy = 0.0f;
+        float sample = ppg_rand(key, dim++);
+        if (sample < boundary) {
+            sample /= boundary;
+            boundary = topLeft / partial;
+        } else {
+            partial = total - partial;
+            ogx = 0.5f;
+            sample = (sample - boundary) / (1.0f - boundary);
+            boundary = topRight / partial;
+            index |= 1 << 0;
+        }
+        if (sample < boundary) {
+            sample /= boundary;
+        } else {
+            ogy = 0.5f;
+            sample = (sample - boundary) / (1.0f - boundary);
+            index |= 1 << 1;
+        }
+        orgx[depth] = ogx; orgy[depth] = ogy;
+        ++depth;
+        if (n.child[index] == 0) {
+            rx = ppg_rand(key, dim++);
+            ry = ppg_rand(key, dim++);
+            break;
+        }
+        node = n.child[index];
+    }
+    for (int i = depth - 1; i >= 0; --i) {
+        rx = orgx[i] + 0.5f * rx;
+        ry = orgy[i] + 0.5f * ry;
+    }
+    ox = ppg_min(ppg_max(rx, 0.0f), 1.0f);
+    oy = ppg_min(ppg_max(ry, 0.0f), 1.0f);
+}
+
+D float logistic(float x) { return 1 / (1 + ppg_exp(-x)); }  // GP:64-66
+
+#endif

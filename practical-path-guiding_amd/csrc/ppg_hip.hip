@@ -1,0 +1,1113 @@
+/*
+ * ppg_hip.hip — libppg_hip.so: host side of the MI355X guided path tracer behind the C-ABI of include/ppg.h.
+ *
+ * Host responsibilities (thin): property parsing (GP:1014-1085), BVH build, pool management, the
+ * iteration schedule of render()/renderSPP()/renderTime() (GP:1342-1585), S-tree refine (GP:957-998 — a
+ * few thousand nodes, done on the host mirror and uploaded), statistics.  Everything per path, per
+ * D-tree node or per pixel runs in the kernels of ppg_kernels.h.
+ */
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/ppg.h"
+#include "ppg_kernels.h"
+
+namespace {
+
+thread_local std::string g_createError;
+
+#define HIP_CHECK(expr)                                                                             \
+    do {                                                                                            \
+        hipError_t _e = (expr);                                                                     \
+        if (_e != hipSuccess) {                                                                     \
+            ctx->error = std::string(#expr) + ": " + hipGetErrorString(_e);                         \
+            return PPG_ERR_DEVICE;                                                                  \
+        }                                                                                           \
+    } while (0)
+
+template <typename T> struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t reserve(size_t n, bool keep = false) {
+        if (n <= cap) return hipSuccess;
+        size_t ncap = std::max(n, cap + cap / 2);
+        T *np = nullptr;
+        hipError_t e = hipMalloc(&np, ncap * sizeof(T));
+        if (e != hipSuccess) return e;
+        if (keep && p && cap) e = hipMemcpy(np, p, cap * sizeof(T), hipMemcpyDeviceToDevice);
+        if (p) (void)hipFree(p);
+        p = np; cap = ncap;
+        return e;
+    }
+};
+
+struct HostSNode {  // host mirror of one S-tree node (STreeNode, GP:740-845)
+    int axis = 0;
+    uint32_t child[2] = {0, 0};
+    bool isLeaf() const { return child[0] == 0; }
+};
+
+int parseEnum(const char *s, const char *dflt, std::initializer_list<const char *> names) {
+    std::string v = s ? s : dflt;
+    int i = 0;
+    for (const char *n : names) {
+        if (v == n) return i;
+        ++i;
+    }
+    return -1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// BVH2 construction (binned SAH), stands in for Scene::initialize → ShapeKDTree::build
+// ------------------------------------------------------------------------------------------------
+struct BvhBuilder {
+    const float *pos; const uint32_t *idx;
+    std::vector<uint32_t> order;
+    std::vector<float> bmin, bmax, cent;  // per tri
+    std::vector<BvhNode> nodes;
+    float pad;
+
+    struct Box { float lo[3], hi[3]; };
+    static Box empty() { Box b; for (int a = 0; a < 3; ++a) { b.lo[a] = INFINITY; b.hi[a] = -INFINITY; } return b; }
+    static void grow(Box &b, const float *lo, const float *hi) { for (int a = 0; a < 3; ++a) { b.lo[a] = std::min(b.lo[a], lo[a]); b.hi[a] = std::max(b.hi[a], hi[a]); } }
+    static float area(const Box &b) { float d[3] = {b.hi[0] - b.lo[0], b.hi[1] - b.lo[1], b.hi[2] - b.lo[2]}; if (d[0] < 0) return 0; return 2 * (d[0] * d[1] + d[1] * d[2] + d[2] * d[0]); }
+
+    Box boundsOf(int first, int count) const {
+        Box b = empty();
+        for (int i = first; i < first + count; ++i) grow(b, &bmin[3 * order[i]], &bmax[3 * order[i]]);
+        return b;
+    }
+
+    // returns (ref, n): n > 0 leaf [ref, ref+n), n == 0 interior node ref
+    void build(int first, int count, int &ref, int &n, Box &box) {
+        box = boundsOf(first, count);
+        if (count <= 4) { ref = first; n = count; return; }
+        Box cb = empty();
+        for (int i = first; i < first + count; ++i) grow(cb, &cent[3 * order[i]], &cent[3 * order[i]]);
+        int bestAxis = -1, bestSplit = -1; float bestCost = INFINITY;
+        const int NB = 16;
+        for (int a = 0; a < 3; ++a) {
+            float ext = cb.hi[a] - cb.lo[a];
+            if (!(ext > 0)) continue;
+            Box bb[NB]; int bc[NB];
+            for (int k = 0; k < NB; ++k) { bb[k] = empty(); bc[k] = 0; }
+            for (int i = first; i < first + count; ++i) {
+                int k = std::min(NB - 1, (int)((cent[3 * order[i] + a] - cb.lo[a]) / ext * NB));
+                grow(bb[k], &bmin[3 * order[i]], &bmax[3 * order[i]]); bc[k]++;
+            }
+            float la[NB]; int lc[NB]; Box acc = empty(); int c = 0;
+            for (int k = 0; k < NB; ++k) { if (bc[k]) grow(acc, bb[k].lo, bb[k].hi); c += bc[k]; la[k] = area(acc); lc[k] = c; }
+            acc = empty(); c = 0;
+            for (int k = NB - 1; k > 0; --k) {
+                if (bc[k]) grow(acc, bb[k].lo, bb[k].hi); c += bc[k];
+                if (lc[k - 1] == 0 || c == 0) continue;
+                float cost = la[k - 1] * lc[k - 1] + area(acc) * c;
+                if (cost < bestCost) { bestCost = cost; bestAxis = a; bestSplit = k; }
+            }
+        }
+        int mid;
+        if (bestAxis < 0) {
+            mid = first + count / 2;
+        } else {
+            float ext = cb.hi[bestAxis] - cb.lo[bestAxis], lo = cb.lo[bestAxis];
+            auto it = std::partition(order.begin() + first, order.begin() + first + count, [&](uint32_t t) {
+                int k = std::min(NB - 1, (int)((cent[3 * t + bestAxis] - lo) / ext * NB));
+                return k < bestSplit;
+            });
+            mid = (int)(it - order.begin());
+            if (mid == first || mid == first + count) mid = first + count / 2;
+        }
+        int me = (int)nodes.size();
+        nodes.emplace_back();
+        int r0, n0, r1, n1; Box b0, b1;
+        build(first, mid - first, r0, n0, b0);
+        build(mid, first + count - mid, r1, n1, b1);
+        BvhNode &nd = nodes[me];
+        for (int a = 0; a < 3; ++a) { nd.lo0[a] = b0.lo[a] - pad; nd.hi0[a] = b0.hi[a] + pad; nd.lo1[a] = b1.lo[a] - pad; nd.hi1[a] = b1.hi[a] + pad; }
+        nd.c0 = r0; nd.n0 = n0; nd.c1 = r1; nd.n1 = n1;
+        ref = me; n = 0;
+    }
+
+    void run(const float *positions, const uint32_t *indices, uint32_t nTris, float padAbs) {
+        pos = positions; idx = indices; pad = padAbs;
+        order.resize(nTris); bmin.resize(3 * (size_t)nTris); bmax.resize(3 * (size_t)nTris); cent.resize(3 * (size_t)nTris);
+        for (uint32_t t = 0; t < nTris; ++t) {
+            order[t] = t;
+            for (int a = 0; a < 3; ++a) {
+                float v0 = pos[3 * idx[3 * t] + a], v1 = pos[3 * idx[3 * t + 1] + a], v2 = pos[3 * idx[3 * t + 2] + a];
+                bmin[3 * t + a] = std::min(v0, std::min(v1, v2)); bmax[3 * t + a] = std::max(v0, std::max(v1, v2));
+                cent[3 * t + a] = 0.5f * (bmin[3 * t + a] + bmax[3 * t + a]);
+            }
+        }
+        nodes.clear();
+        nodes.reserve(nTris);
+        int ref, n; Box b;
+        nodes.emplace_back();  // root placeholder, must be an interior node
+        if (nTris <= 4) {
+            BvhNode &nd = nodes[0];
+            Box bb = boundsOf(0, (int)nTris);
+            for (int a = 0; a < 3; ++a) { nd.lo0[a] = bb.lo[a] - pad; nd.hi0[a] = bb.hi[a] + pad; nd.lo1[a] = 0; nd.hi1[a] = 0; }
+            nd.c0 = 0; nd.n0 = (int)nTris; nd.c1 = 0; nd.n1 = -1;
+            return;
+        }
+        nodes.pop_back();
+        build(0, (int)nTris, ref, n, b);  // nTris > 4 ⇒ root is interior and lands at index 0
+    }
+};
+
+struct KernelTimer {
+    struct Rec { hipEvent_t a, b; int id; uint64_t units; };
+    std::vector<std::string> names;
+    std::vector<double> ms;
+    std::vector<uint64_t> launches, units;
+    std::vector<Rec> pending;
+    std::vector<hipEvent_t> pool;
+    bool enabled = false;
+    int idOf(const char *n) {
+        for (size_t i = 0; i < names.size(); ++i) if (names[i] == n) return (int)i;
+        names.push_back(n); ms.push_back(0); launches.push_back(0); units.push_back(0);
+        return (int)names.size() - 1;
+    }
+    hipEvent_t ev() { if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; } hipEvent_t e; (void)hipEventCreate(&e); return e; }
+    void resolve() {
+        for (auto &r : pending) {
+            (void)hipEventSynchronize(r.b);
+            float t = 0; (void)hipEventElapsedTime(&t, r.a, r.b);
+            ms[r.id] += t; launches[r.id]++; units[r.id] += r.units;
+            pool.push_back(r.a); pool.push_back(r.b);
+        }
+        pending.clear();
+    }
+    void reset() { resolve(); for (size_t i = 0; i < ms.size(); ++i) { ms[i] = 0; launches[i] = 0; units[i] = 0; } }
+};
+
+}  // namespace
+
+struct ppg_ctx {
+    // properties (GP:1014-1085)
+    int nee = 0, sampleCombination = 1, spatialFilter = 0, directionalFilter = 0, loss = 0, budgetType = 1;
+    int sdTreeMaxMemory = -1, sTreeThreshold = 12000, sppPerPass = 4, rrDepth = 5, maxDepth = -1;
+    float dTreeThreshold = 0.01f, bsdfSamplingFraction = 0.5f, budget = 300.0f;
+    bool dumpSDTree = false, strictNormals = false, hideEmitters = false;
+    uint64_t seed = 0;
+    int device = 0;
+    std::string dumpPrefix, error;
+    hipStream_t stream = nullptr;
+
+    // scene
+    bool haveScene = false;
+    DevBuf<float4> d_tris, d_normals, d_materials, d_emitters;
+    DevBuf<BvhNode> d_bvh;
+    DevScene scene{};
+    float aabbMin[3], aabbMax[3];  // Scene::getAABB()
+    int W = 0, H = 0;
+
+    // shard
+    int shardRank = 0, shardWorld = 1, tileSize = 32;
+    DevBuf<unsigned int> d_pixels;
+    unsigned int nPix = 0;
+
+    // path state
+    DevBuf<float4> d_ray_o, d_ray_d, d_thr, d_li, d_hit, d_vd, d_vthr, d_vbsdf, d_vrad, d_vo, d_vvox;
+    DevBuf<uint4> d_misc;
+    DevBuf<unsigned int> d_queue[2];
+    DevBuf<Counters> d_counters;
+    PathState paths{};
+    int maxVertices = 0;
+
+    // film
+    DevBuf<float> d_image, d_sq, d_imageW, d_film, d_filmW, d_var, d_lum, d_tmp;
+    std::vector<DevBuf<float>> images;  // inverse-variance copies (weight-normalised)
+    std::vector<float> variances;
+
+    // SD-tree
+    bool treeAlive = false;
+    std::vector<HostSNode> snodes;
+    std::vector<LeafHdr> hdr;  // host mirror (valid after build / refine)
+    std::vector<unsigned int> leaves;
+    DevBuf<int4> d_stree;
+    DevBuf<LeafHdr> d_hdr;
+    DevBuf<SNode> d_snodes[2];
+    int cur = 0;  // d_snodes[cur] = sampling pool
+    size_t nSamplingNodes = 0, nBuildingNodes = 0;
+    DevBuf<ushort4> d_bchild;
+    DevBuf<unsigned long long> d_bacc, d_bweight, d_adamW, d_total;
+    DevBuf<long long> d_adamGrad;
+    DevBuf<unsigned int> d_leaves, d_counts, d_offsets;
+    float treeMin[3], treeMax[3], treeExt[3];
+    bool isBuilt = false, isFinalIter = false, doNee = false;
+    int iter = 0, passesRendered = 0, passesRenderedThisIter = 0, passesLocal = 0;
+    std::chrono::steady_clock::time_point startTime, passStart;
+    std::atomic<bool> cancelled{false};
+    float lastVariance = 0;
+    ppg_pass_stats lastStats{};
+    KernelTimer timer;
+
+    DevTree devTree() {
+        DevTree T{};
+        T.stree = d_stree.p; T.hdr = d_hdr.p; T.snodes = d_snodes[cur].p; T.bchild = d_bchild.p; T.bacc = d_bacc.p;
+        T.bweight = d_bweight.p; T.adam_grad = d_adamGrad.p; T.adam_w = d_adamW.p;
+        for (int a = 0; a < 3; ++a) { T.aabb_min[a] = treeMin[a]; T.aabb_ext[a] = treeExt[a]; T.aabb_max[a] = treeMax[a]; }
+        T.is_built = isBuilt ? 1 : 0;
+        return T;
+    }
+    RenderParams params() const {
+        RenderParams R{};
+        R.nee = nee; R.spatial_filter = spatialFilter; R.directional_filter = directionalFilter; R.loss = loss;
+        R.bsdf_sampling_fraction = bsdfSamplingFraction; R.rr_depth = rrDepth; R.max_depth = maxDepth;
+        R.strict_normals = strictNormals; R.hide_emitters = hideEmitters; R.spp = sppPerPass;
+        R.is_final_iter = isFinalIter; R.do_nee = doNee; R.seed = seed; R.pass_index = (unsigned int)passesRendered;
+        R.max_vertices = maxVertices;
+        return R;
+    }
+};
+
+namespace {
+
+template <typename F> void timedLaunch(ppg_ctx *ctx, const char *name, uint64_t units, F &&launch) {
+    if (!ctx->timer.enabled) { launch(); return; }
+    KernelTimer::Rec r; r.a = ctx->timer.ev(); r.b = ctx->timer.ev(); r.id = ctx->timer.idOf(name); r.units = units;
+    (void)hipEventRecord(r.a, ctx->stream);
+    launch();
+    (void)hipEventRecord(r.b, ctx->stream);
+    ctx->timer.pending.push_back(r);
+}
+
+int gridFor(size_t n, int block = PPG_BLOCK, int maxBlocks = 256 * 8) {
+    size_t b = (n + block - 1) / block;
+    return (int)std::max<size_t>(1, std::min<size_t>(b, (size_t)maxBlocks));
+}
+
+float elapsedSeconds(std::chrono::steady_clock::time_point start) {  // GP:1428-1432
+    auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - start);
+    return (float)ms.count() / 1000;
+}
+
+int uploadTree(ppg_ctx *ctx) {
+    size_t n = ctx->snodes.size();
+    std::vector<int4> st(n);
+    for (size_t i = 0; i < n; ++i) st[i] = make_int4(ctx->snodes[i].axis, (int)ctx->snodes[i].child[0], (int)ctx->snodes[i].child[1], 0);
+    HIP_CHECK(ctx->d_stree.reserve(n));
+    HIP_CHECK(ctx->d_hdr.reserve(n));
+    HIP_CHECK(hipMemcpyAsync(ctx->d_stree.p, st.data(), n * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
+    HIP_CHECK(hipMemcpyAsync(ctx->d_hdr.p, ctx->hdr.data(), n * sizeof(LeafHdr), hipMemcpyHostToDevice, ctx->stream));
+    ctx->leaves.clear();
+    for (size_t i = 0; i < n; ++i) if (ctx->snodes[i].isLeaf()) ctx->leaves.push_back((unsigned int)i);
+    HIP_CHECK(ctx->d_leaves.reserve(ctx->leaves.size()));
+    HIP_CHECK(ctx->d_counts.reserve(ctx->leaves.size()));
+    HIP_CHECK(ctx->d_offsets.reserve(ctx->leaves.size()));
+    HIP_CHECK(hipMemcpyAsync(ctx->d_leaves.p, ctx->leaves.data(), ctx->leaves.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_CHECK(ctx->d_bweight.reserve(n));
+    HIP_CHECK(ctx->d_adamW.reserve(n));
+    HIP_CHECK(ctx->d_adamGrad.reserve(n));
+    HIP_CHECK(hipMemsetAsync(ctx->d_bweight.p, 0, n * 8, ctx->stream));
+    HIP_CHECK(hipMemsetAsync(ctx->d_adamW.p, 0, n * 8, ctx->stream));
+    HIP_CHECK(hipMemsetAsync(ctx->d_adamGrad.p, 0, n * 8, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));  // st is a stack-local staging buffer
+    return PPG_OK;
+}
+
+// STree::refine (GP:957-998) + subdivide (GP:876-895) on the host mirror; the D-trees of a split leaf are
+// shared by reference (both children point at the parent's sampling block; reset() rebuilds `building`).
+void refineHost(ppg_ctx *ctx, size_t sTreeThreshold, int maxMB) {
+    auto &nodes = ctx->snodes;
+    auto &hdr = ctx->hdr;
+    if (maxMB >= 0) {
+        size_t foot = 0;  // approxMemoryFootprint with the reference's sizeof (QuadTreeNode 24 B, DTree 40 B)
+        for (size_t i = 0; i < nodes.size(); ++i) foot += nodes[i].isLeaf() ? ((size_t)hdr[i].b_num * 24 + 40) + ((size_t)hdr[i].s_num * 24 + 40) : 2 * (24 + 40);
+        if (foot / 1000000 >= (size_t)maxMB) return;
+    }
+    struct SN { size_t index; int depth; };
+    std::vector<SN> stack;
+    stack.push_back({0, 1});
+    while (!stack.empty()) {
+        SN s = stack.back();
+        stack.pop_back();
+        if (nodes[s.index].isLeaf()) {
+            if (nodes.size() < std::numeric_limits<uint32_t>::max() - 1 && hdr[s.index].b_statw > (float)sTreeThreshold) {
+                size_t base = nodes.size();
+                nodes.resize(base + 2);
+                hdr.resize(base + 2);
+                for (int i = 0; i < 2; ++i) {
+                    nodes[s.index].child[i] = (uint32_t)(base + i);
+                    nodes[base + i].axis = (nodes[s.index].axis + 1) % 3;
+                    hdr[base + i] = hdr[s.index];
+                    hdr[base + i].b_statw = hdr[base + i].b_statw / 2;
+                }
+                LeafHdr cleared{};  // cur.dTree = {}
+                cleared.s_base = 0; cleared.s_num = 0;
+                hdr[s.index] = cleared;
+            }
+        }
+        if (!nodes[s.index].isLeaf())
+            for (int i = 0; i < 2; ++i) stack.push_back({nodes[s.index].child[i], s.depth + 1});
+    }
+}
+
+int resetSDTree(ppg_ctx *ctx) {  // GP:1108-1113
+    double thr = std::sqrt(std::ldexp(1.0, ctx->iter) * ctx->sppPerPass / 4) * ctx->sTreeThreshold;
+    refineHost(ctx, (size_t)thr, ctx->sdTreeMaxMemory);
+    int rc = uploadTree(ctx);
+    if (rc) return rc;
+    unsigned int nl = (unsigned int)ctx->leaves.size();
+    HIP_CHECK(ctx->d_total.reserve(1));
+    DevTree T = ctx->devTree();
+    int blocks = (int)((nl + 127) / 128);
+    timedLaunch(ctx, "k_dtree_reset<count>", nl, [&] {
+        hipLaunchKernelGGL(k_dtree_reset<false>, dim3(blocks), dim3(128), 0, ctx->stream, T, ctx->d_leaves.p, nl, 20, ctx->dTreeThreshold,
+                           ctx->d_counts.p, (ushort4 *)nullptr);
+    });
+    hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_counts.p, ctx->d_offsets.p, nl, ctx->d_total.p);
+    unsigned long long total = 0;
+    HIP_CHECK(hipMemcpyAsync(&total, ctx->d_total.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (total > 0xfffffff0ull) { ctx->error = "building D-tree pool exceeds 2^32 nodes"; return PPG_ERR_NOMEM; }
+    ctx->nBuildingNodes = (size_t)total;
+    HIP_CHECK(ctx->d_bchild.reserve(total));
+    HIP_CHECK(ctx->d_bacc.reserve(total * 4));
+    HIP_CHECK(ctx->d_snodes[ctx->cur ^ 1].reserve(total));
+    HIP_CHECK(hipMemsetAsync(ctx->d_bacc.p, 0, total * 4 * 8, ctx->stream));
+    hipLaunchKernelGGL(k_assign_blocks, dim3(blocks), dim3(128), 0, ctx->stream, T, ctx->d_leaves.p, nl, ctx->d_counts.p, ctx->d_offsets.p);
+    T = ctx->devTree();
+    timedLaunch(ctx, "k_dtree_reset<fill>", nl, [&] {
+        hipLaunchKernelGGL(k_dtree_reset<true>, dim3(blocks), dim3(128), 0, ctx->stream, T, ctx->d_leaves.p, nl, 20, ctx->dTreeThreshold,
+                           ctx->d_counts.p, ctx->d_bchild.p);
+    });
+    HIP_CHECK(hipGetLastError());
+    return PPG_OK;
+}
+
+int buildSDTree(ppg_ctx *ctx, ppg_tree_stats *st) {  // GP:1115-1189
+    unsigned int nl = (unsigned int)ctx->leaves.size();
+    DevTree T = ctx->devTree();
+    int blocks = (int)((nl + 127) / 128);
+    timedLaunch(ctx, "k_dtree_build", nl, [&] {
+        hipLaunchKernelGGL(k_dtree_build, dim3(blocks), dim3(128), 0, ctx->stream, T, ctx->d_leaves.p, nl, ctx->d_snodes[ctx->cur ^ 1].p);
+    });
+    HIP_CHECK(hipGetLastError());
+    ctx->cur ^= 1;  // sampling = building
+    ctx->nSamplingNodes = ctx->nBuildingNodes;
+    HIP_CHECK(hipMemcpyAsync(ctx->hdr.data(), ctx->d_hdr.p, ctx->hdr.size() * sizeof(LeafHdr), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    // statistics, in S-tree node order like forEachDTreeWrapperConst (GP:1138-1174)
+    int maxDepth = 0, minDepth = std::numeric_limits<int>::max();
+    float avgDepth = 0, maxAvgRadiance = 0, minAvgRadiance = std::numeric_limits<float>::max(), avgAvgRadiance = 0;
+    size_t maxNodes = 0, minNodes = std::numeric_limits<size_t>::max();
+    float avgNodes = 0, maxSW = 0, minSW = std::numeric_limits<float>::max(), avgSW = 0;
+    int nPoints = 0, nPointsNodes = 0;
+    uint64_t totalNodes = 0;
+    for (unsigned int leaf : ctx->leaves) {
+        const LeafHdr &h = ctx->hdr[leaf];
+        const int depth = h.s_depth;
+        maxDepth = std::max(maxDepth, depth); minDepth = std::min(minDepth, depth); avgDepth += depth;
+        float avgRadiance = 0;
+        if (h.s_statw != 0) { const float factor = 1 / (PPG_PI_F * 4 * h.s_statw); avgRadiance = factor * h.s_sum; }
+        maxAvgRadiance = ppg_max(maxAvgRadiance, avgRadiance); minAvgRadiance = ppg_min(minAvgRadiance, avgRadiance);
+        avgAvgRadiance += avgRadiance;
+        if (h.s_num > 1) {
+            const size_t nodes = h.s_num;
+            maxNodes = std::max(maxNodes, nodes); minNodes = std::min(minNodes, nodes); avgNodes += nodes; ++nPointsNodes;
+        }
+        totalNodes += h.s_num;
+        maxSW = ppg_max(maxSW, h.s_statw); minSW = ppg_min(minSW, h.s_statw); avgSW += h.s_statw;
+        ++nPoints;
+    }
+    if (nPoints > 0) {
+        avgDepth /= nPoints; avgAvgRadiance /= nPoints;
+        if (nPointsNodes > 0) avgNodes /= nPointsNodes;
+        avgSW /= nPoints;
+    }
+    if (st) {
+        st->min_depth = minDepth; st->max_depth = maxDepth; st->avg_depth = avgDepth;
+        st->min_mean_radiance = minAvgRadiance; st->avg_mean_radiance = avgAvgRadiance; st->max_mean_radiance = maxAvgRadiance;
+        st->min_nodes = minNodes; st->max_nodes = maxNodes; st->avg_nodes = avgNodes;
+        st->min_stat_weight = minSW; st->avg_stat_weight = avgSW; st->max_stat_weight = maxSW;
+        st->n_leaves = (uint32_t)nPoints; st->n_stree_nodes = (uint32_t)ctx->snodes.size(); st->n_dtree_nodes = totalNodes;
+    }
+    ctx->isBuilt = true;
+    return PPG_OK;
+}
+
+int allocPaths(ppg_ctx *ctx) {
+    // owned pixel list
+    std::vector<unsigned int> pix;
+    int tilesX = (ctx->W + ctx->tileSize - 1) / ctx->tileSize;
+    for (int y = 0; y < ctx->H; ++y)
+        for (int x = 0; x < ctx->W; ++x) {
+            int t = (y / ctx->tileSize) * tilesX + (x / ctx->tileSize);
+            if (ctx->shardWorld <= 1 || t % ctx->shardWorld == ctx->shardRank) pix.push_back((unsigned int)(y * ctx->W + x));
+        }
+    ctx->nPix = (unsigned int)pix.size();
+    HIP_CHECK(ctx->d_pixels.reserve(std::max<size_t>(1, pix.size())));
+    if (!pix.empty()) HIP_CHECK(hipMemcpy(ctx->d_pixels.p, pix.data(), pix.size() * 4, hipMemcpyHostToDevice));
+    size_t n = (size_t)ctx->nPix * ctx->sppPerPass;
+    if (n > 0xfffffff0ull) { ctx->error = "too many paths per pass"; return PPG_ERR_INVALID; }
+    size_t nn = std::max<size_t>(1, n);
+    ctx->maxVertices = PPG_MAX_VERTICES;
+    if (ctx->maxDepth > 0) ctx->maxVertices = std::max(1, std::min(PPG_MAX_VERTICES, ctx->maxDepth - 1));
+    HIP_CHECK(ctx->d_ray_o.reserve(nn)); HIP_CHECK(ctx->d_ray_d.reserve(nn)); HIP_CHECK(ctx->d_thr.reserve(nn));
+    HIP_CHECK(ctx->d_li.reserve(nn)); HIP_CHECK(ctx->d_hit.reserve(nn)); HIP_CHECK(ctx->d_misc.reserve(nn));
+    HIP_CHECK(ctx->d_queue[0].reserve(nn)); HIP_CHECK(ctx->d_queue[1].reserve(nn));
+    size_t nv = nn * (size_t)ctx->maxVertices;
+    HIP_CHECK(ctx->d_vd.reserve(nv)); HIP_CHECK(ctx->d_vthr.reserve(nv)); HIP_CHECK(ctx->d_vbsdf.reserve(nv)); HIP_CHECK(ctx->d_vrad.reserve(nv));
+    if (ctx->spatialFilter != SF_NEAREST) { HIP_CHECK(ctx->d_vo.reserve(nv)); HIP_CHECK(ctx->d_vvox.reserve(nv)); }
+    HIP_CHECK(ctx->d_counters.reserve(1));
+    PathState &P = ctx->paths;
+    P.n_paths = (unsigned int)n; P.n_pix = ctx->nPix; P.pixels = ctx->d_pixels.p;
+    P.ray_o = ctx->d_ray_o.p; P.ray_d = ctx->d_ray_d.p; P.thr = ctx->d_thr.p; P.li = ctx->d_li.p; P.hit = ctx->d_hit.p; P.misc = ctx->d_misc.p;
+    P.v_d = ctx->d_vd.p; P.v_thr = ctx->d_vthr.p; P.v_bsdf = ctx->d_vbsdf.p; P.v_rad = ctx->d_vrad.p;
+    P.v_o = ctx->spatialFilter != SF_NEAREST ? ctx->d_vo.p : nullptr;
+    P.v_vox = ctx->spatialFilter != SF_NEAREST ? ctx->d_vvox.p : nullptr;
+    return PPG_OK;
+}
+
+// one BlockedRenderProcess (GP:1087-1106 / renderBlock GP:1587-1641) over all owned pixels
+int renderOnePass(ppg_ctx *ctx) {
+    PathState P = ctx->paths;
+    if (P.n_paths == 0) return PPG_OK;
+    DevScene S = ctx->scene;
+    DevTree T = ctx->devTree();
+    RenderParams R = ctx->params();
+    Counters *C = ctx->d_counters.p;
+    const int grid = gridFor(P.n_paths);
+    hipStream_t s = ctx->stream;
+    timedLaunch(ctx, "k_generate", P.n_paths, [&] { hipLaunchKernelGGL(k_generate, dim3(grid), dim3(PPG_BLOCK), 0, s, P, S, R); });
+    HIP_CHECK(hipMemsetAsync(&C->queue_count[0], 0, 8, s));
+    // bounce 1 works on all paths (no queue); afterwards queues alternate
+    unsigned int *qIn = nullptr; const unsigned int *cntIn = nullptr;
+    const int maxBounces = ctx->maxDepth > 0 ? ctx->maxDepth : 1 << 20;
+    unsigned int hostCount = P.n_paths;
+    for (int b = 0; b < maxBounces; ++b) {
+        int w = b & 1;  // output queue index
+        timedLaunch(ctx, "k_trace", hostCount, [&] { hipLaunchKernelGGL(k_trace, dim3(grid), dim3(PPG_BLOCK), 0, s, P, S, qIn, cntIn, P.n_paths, C); });
+        HIP_CHECK(hipMemsetAsync(&C->queue_count[w], 0, 4, s));
+        timedLaunch(ctx, "k_shade", hostCount, [&] {
+            hipLaunchKernelGGL(k_shade, dim3(grid), dim3(PPG_BLOCK), 0, s, P, S, T, R, qIn, cntIn, P.n_paths, ctx->d_queue[w].p, &C->queue_count[w], C);
+        });
+        qIn = ctx->d_queue[w].p; cntIn = &C->queue_count[w];
+        // unbounded paths (maxDepth < 0) and kernel timing need the live count; bounded paths run a fixed schedule without a sync
+        if (ctx->maxDepth < 0 || ctx->timer.enabled) {
+            HIP_CHECK(hipMemcpyAsync(&hostCount, cntIn, 4, hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+            if (hostCount == 0) break;
+        }
+    }
+    // the last shade of a bounded schedule terminates every path (depth >= maxDepth), no trailing trace needed
+    if (!ctx->isFinalIter) {
+        timedLaunch(ctx, "k_commit", P.n_paths, [&] { hipLaunchKernelGGL(k_commit, dim3(grid), dim3(PPG_BLOCK), 0, s, P, T, R, C); });
+        if (ctx->loss != LOSS_NONE && ctx->isBuilt) {
+            unsigned int nn = (unsigned int)ctx->snodes.size();
+            hipLaunchKernelGGL(k_adam_step, dim3((nn + 255) / 256), dim3(256), 0, s, T, nn);
+        }
+    }
+    timedLaunch(ctx, "k_film", P.n_pix, [&] {
+        hipLaunchKernelGGL(k_film, dim3((P.n_pix + 255) / 256), dim3(256), 0, s, P, ctx->sppPerPass, ctx->d_image.p, ctx->d_sq.p, ctx->d_imageW.p,
+                           ctx->d_film.p, ctx->d_filmW.p);
+    });
+    HIP_CHECK(hipGetLastError());
+    return PPG_OK;
+}
+
+int renderPassesNoStat(ppg_ctx *ctx, int numPasses) {  // GP:1217-1286
+    size_t n = (size_t)ctx->W * ctx->H;
+    HIP_CHECK(hipMemsetAsync(ctx->d_image.p, 0, 3 * n * 4, ctx->stream));
+    HIP_CHECK(hipMemsetAsync(ctx->d_sq.p, 0, 3 * n * 4, ctx->stream));
+    HIP_CHECK(hipMemsetAsync(ctx->d_imageW.p, 0, n * 4, ctx->stream));
+    HIP_CHECK(hipMemsetAsync(ctx->d_counters.p, 0, sizeof(Counters), ctx->stream));
+    ctx->passStart = std::chrono::steady_clock::now();
+    ctx->passesLocal = 0;
+    for (int i = 0; i < numPasses; ++i) {
+        if (ctx->cancelled.load()) break;
+        int rc = renderOnePass(ctx);
+        if (rc) return rc;
+        ++ctx->passesRendered; ++ctx->passesRenderedThisIter; ++ctx->passesLocal;
+        if (ctx->budgetType == 1) {  // seconds: the reference checks after every finished pass (GP:1259-1262)
+            HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            if (elapsedSeconds(ctx->startTime) > ctx->budget) break;
+        }
+    }
+    return ctx->cancelled.load() ? PPG_ERR_CANCELLED : PPG_OK;
+}
+
+int finishPasses(ppg_ctx *ctx, ppg_pass_stats *st) {  // GP:1288-1328
+    const int n = ctx->W * ctx->H;
+    const int N = ctx->passesLocal * ctx->sppPerPass;
+    if (ctx->sampleCombination == 2) {  // inversevar: m_images.push_back(image->clone())
+        ctx->images.emplace_back();
+        HIP_CHECK(ctx->images.back().reserve(3 * (size_t)n));
+        hipLaunchKernelGGL(k_normalise, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, ctx->d_image.p, ctx->d_imageW.p, ctx->images.back().p);
+    }
+    hipLaunchKernelGGL(k_variance, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, N, ctx->d_image.p, ctx->d_sq.p, ctx->d_imageW.p, ctx->d_var.p, ctx->d_lum.p);
+    std::vector<float> lum(n);
+    Counters c{};
+    HIP_CHECK(hipMemcpyAsync(lum.data(), ctx->d_lum.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipMemcpyAsync(&c, ctx->d_counters.p, sizeof c, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    float variance = 0;  // summed in the reference's x-major order (GP:1303-1311)
+    for (int x = 0; x < ctx->W; ++x)
+        for (int y = 0; y < ctx->H; ++y) variance += lum[(size_t)y * ctx->W + x];
+    variance /= (float)ctx->W * ctx->H * (N - 1);
+    if (ctx->sampleCombination == 2) ctx->variances.push_back(variance);
+    ctx->lastVariance = variance;
+    ppg_pass_stats s{};
+    s.seconds = elapsedSeconds(ctx->passStart);
+    s.passes_rendered_total = ctx->passesRendered; s.passes_rendered_local = ctx->passesLocal; s.variance = variance;
+    s.samples = (uint64_t)ctx->nPix * ctx->passesLocal * ctx->sppPerPass;
+    s.rays = c.rays; s.path_length_sum = c.path_len; s.vertices_committed = c.committed;
+    ctx->lastStats = s;
+    if (st) *st = s;
+    ctx->timer.resolve();
+    return PPG_OK;
+}
+
+int beginRender(ppg_ctx *ctx) {  // GP:1519-1550
+    HIP_CHECK(hipSetDevice(ctx->device));
+    int rc = allocPaths(ctx);
+    if (rc) return rc;
+    // new STree(scene->getAABB()), cubified (GP:850-860)
+    float maxSize = 0;
+    for (int a = 0; a < 3; ++a) maxSize = ppg_max(maxSize, ctx->aabbMax[a] - ctx->aabbMin[a]);
+    {
+        float sx = ctx->aabbMax[0] - ctx->aabbMin[0], sy = ctx->aabbMax[1] - ctx->aabbMin[1], sz = ctx->aabbMax[2] - ctx->aabbMin[2];
+        maxSize = ppg_max(ppg_max(sx, sy), sz);
+    }
+    for (int a = 0; a < 3; ++a) {
+        ctx->treeMin[a] = ctx->aabbMin[a];
+        ctx->treeMax[a] = ctx->aabbMin[a] + maxSize;
+        ctx->treeExt[a] = ctx->treeMax[a] - ctx->treeMin[a];  // AABB::getExtents() = max - min
+    }
+    ctx->snodes.assign(1, HostSNode());
+    ctx->hdr.assign(1, LeafHdr{});
+    // the initial sampling D-tree: one node, all sums 0 (DTree(), GP:376-381)
+    HIP_CHECK(ctx->d_snodes[0].reserve(1));
+    HIP_CHECK(hipMemsetAsync(ctx->d_snodes[0].p, 0, sizeof(SNode), ctx->stream));
+    ctx->cur = 0;
+    ctx->hdr[0].s_base = 0; ctx->hdr[0].s_num = 1;
+    ctx->nSamplingNodes = 1; ctx->nBuildingNodes = 0;
+    ctx->iter = 0; ctx->isFinalIter = false; ctx->isBuilt = false;
+    size_t n = (size_t)ctx->W * ctx->H;
+    HIP_CHECK(ctx->d_image.reserve(3 * n)); HIP_CHECK(ctx->d_sq.reserve(3 * n)); HIP_CHECK(ctx->d_imageW.reserve(n));
+    HIP_CHECK(ctx->d_film.reserve(3 * n)); HIP_CHECK(ctx->d_filmW.reserve(n)); HIP_CHECK(ctx->d_var.reserve(3 * n));
+    HIP_CHECK(ctx->d_lum.reserve(n)); HIP_CHECK(ctx->d_tmp.reserve(3 * n));
+    HIP_CHECK(hipMemsetAsync(ctx->d_film.p, 0, 3 * n * 4, ctx->stream));
+    HIP_CHECK(hipMemsetAsync(ctx->d_filmW.p, 0, n * 4, ctx->stream));
+    HIP_CHECK(hipMemsetAsync(ctx->d_var.p, 0, 3 * n * 4, ctx->stream));
+    HIP_CHECK(hipMemsetAsync(ctx->d_image.p, 0, 3 * n * 4, ctx->stream));
+    HIP_CHECK(hipMemsetAsync(ctx->d_sq.p, 0, 3 * n * 4, ctx->stream));
+    HIP_CHECK(hipMemsetAsync(ctx->d_imageW.p, 0, n * 4, ctx->stream));
+    ctx->images.clear(); ctx->variances.clear();
+    ctx->startTime = std::chrono::steady_clock::now();
+    ctx->passesRendered = 0; ctx->passesRenderedThisIter = 0;
+    ctx->cancelled.store(false);
+    ctx->treeAlive = true;
+    return PPG_OK;
+}
+
+int beginIteration(ppg_ctx *ctx, bool isFinal) {  // GP:1378-1381
+    ctx->isFinalIter = isFinal;
+    size_t n = (size_t)ctx->W * ctx->H;
+    HIP_CHECK(hipMemsetAsync(ctx->d_film.p, 0, 3 * n * 4, ctx->stream));
+    HIP_CHECK(hipMemsetAsync(ctx->d_filmW.p, 0, n * 4, ctx->stream));
+    return resetSDTree(ctx);
+}
+
+int dumpSDTreeFile(ppg_ctx *ctx, const char *path);
+
+int endIteration(ppg_ctx *ctx) {  // GP:1417-1422
+    if (ctx->dumpSDTree && !ctx->isFinalIter && !ctx->dumpPrefix.empty()) {
+        char buf[1024];
+        snprintf(buf, sizeof buf, "%s-%02d.sdt", ctx->dumpPrefix.c_str(), ctx->iter);
+        int rc = dumpSDTreeFile(ctx, buf);
+        if (rc) return rc;
+    }
+    ++ctx->iter;
+    ctx->passesRenderedThisIter = 0;
+    return PPG_OK;
+}
+
+int endRender(ppg_ctx *ctx) {  // GP:1567-1582
+    if (ctx->sampleCombination == 2 && !ctx->images.empty()) {
+        const int n = ctx->W * ctx->H;
+        HIP_CHECK(hipMemsetAsync(ctx->d_film.p, 0, 3 * (size_t)n * 4, ctx->stream));
+        std::vector<float> ones((size_t)n, 1.0f);
+        HIP_CHECK(hipMemcpyAsync(ctx->d_filmW.p, ones.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+        size_t begin = ctx->images.size() - std::min(ctx->images.size(), (size_t)4);
+        float totalWeight = 0;
+        for (size_t i = begin; i < ctx->variances.size(); ++i) totalWeight += 1.0f / ctx->variances[i];
+        for (size_t i = begin; i < ctx->images.size(); ++i) {
+            float mult = 1.0f / ctx->variances[i] / totalWeight;
+            hipLaunchKernelGGL(k_axpy, dim3((3 * n + 255) / 256), dim3(256), 0, ctx->stream, 3 * n, mult, ctx->images[i].p, ctx->d_film.p);
+        }
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
+    return PPG_OK;
+}
+
+bool doNeeWithSpp(const ppg_ctx *ctx, int spp) {  // GP:1331-1340
+    switch (ctx->nee) {
+        case NEE_NEVER: return false;
+        case NEE_KICKSTART: return spp < 128;
+        default: return true;
+    }
+}
+
+int renderSPP(ppg_ctx *ctx) {  // GP:1342-1426
+    size_t sampleCount = (size_t)ctx->budget;
+    int nPasses = (int)std::ceil(sampleCount / (float)ctx->sppPerPass);
+    float currentVarAtEnd = std::numeric_limits<float>::infinity();
+    while (ctx->passesRendered < nPasses) {
+        const int sppRendered = ctx->passesRendered * ctx->sppPerPass;
+        ctx->doNee = doNeeWithSpp(ctx, sppRendered);
+        int remainingPasses = nPasses - ctx->passesRendered;
+        int passesThisIteration = std::min(remainingPasses, 1 << ctx->iter);
+        if (remainingPasses - passesThisIteration < 2 * passesThisIteration) passesThisIteration = remainingPasses;
+        int rc = beginIteration(ctx, passesThisIteration >= remainingPasses);
+        if (rc) return rc;
+        ppg_pass_stats st;
+        if ((rc = renderPassesNoStat(ctx, passesThisIteration))) return rc;
+        if ((rc = finishPasses(ctx, &st))) return rc;
+        float variance = st.variance;
+        const float lastVarAtEnd = currentVarAtEnd;
+        currentVarAtEnd = passesThisIteration * variance / remainingPasses;
+        remainingPasses -= passesThisIteration;
+        if (ctx->sampleCombination == 1 && remainingPasses > 0 &&
+            (remainingPasses < passesThisIteration || (sppRendered > 256 && currentVarAtEnd > lastVarAtEnd))) {
+            ctx->isFinalIter = true;
+            if ((rc = renderPassesNoStat(ctx, remainingPasses))) return rc;
+            if ((rc = finishPasses(ctx, &st))) return rc;
+        }
+        if ((rc = buildSDTree(ctx, nullptr))) return rc;
+        if ((rc = endIteration(ctx))) return rc;
+    }
+    return PPG_OK;
+}
+
+int renderTime(ppg_ctx *ctx) {  // GP:1434-1514
+    float nSeconds = ctx->budget;
+    float currentVarAtEnd = std::numeric_limits<float>::infinity();
+    float elapsed = 0;
+    while (elapsed < nSeconds) {
+        const int sppRendered = ctx->passesRendered * ctx->sppPerPass;
+        ctx->doNee = doNeeWithSpp(ctx, sppRendered);
+        float remainingTime = nSeconds - elapsed;
+        const int passesThisIteration = 1 << ctx->iter;
+        const auto startIter = std::chrono::steady_clock::now();
+        int rc = beginIteration(ctx, false);
+        if (rc) return rc;
+        ppg_pass_stats st;
+        if ((rc = renderPassesNoStat(ctx, passesThisIteration))) return rc;
+        if ((rc = finishPasses(ctx, &st))) return rc;
+        float variance = st.variance;
+        const float secondsIter = elapsedSeconds(startIter);
+        const float lastVarAtEnd = currentVarAtEnd;
+        currentVarAtEnd = secondsIter * variance / remainingTime;
+        remainingTime -= secondsIter;
+        if (ctx->sampleCombination == 1 && remainingTime > 0 &&
+            (remainingTime < secondsIter || (sppRendered > 256 && currentVarAtEnd > lastVarAtEnd))) {
+            ctx->isFinalIter = true;
+            do {
+                if ((rc = renderPassesNoStat(ctx, passesThisIteration))) return rc;
+                if ((rc = finishPasses(ctx, &st))) return rc;
+                elapsed = elapsedSeconds(ctx->startTime);
+            } while (elapsed < nSeconds);
+        }
+        if ((rc = buildSDTree(ctx, nullptr))) return rc;
+        if ((rc = endIteration(ctx))) return rc;
+        elapsed = elapsedSeconds(ctx->startTime);
+    }
+    return PPG_OK;
+}
+
+// gather one kind of D-trees per S-tree leaf into host arrays (expands shared sampling blocks)
+int gatherDTrees(ppg_ctx *ctx, int which, std::vector<float> &sums, std::vector<uint16_t> &children, std::vector<uint64_t> *fixed) {
+    sums.clear(); children.clear(); if (fixed) fixed->clear();
+    if (which == 0) {
+        std::vector<SNode> pool(ctx->nSamplingNodes);
+        if (!pool.empty()) HIP_CHECK(hipMemcpy(pool.data(), ctx->d_snodes[ctx->cur].p, pool.size() * sizeof(SNode), hipMemcpyDeviceToHost));
+        for (unsigned int leaf : ctx->leaves) {
+            const LeafHdr &h = ctx->hdr[leaf];
+            for (unsigned int n = 0; n < h.s_num; ++n)
+                for (int j = 0; j < 4; ++j) {
+                    sums.push_back(pool[h.s_base + n].sum[j]); children.push_back(pool[h.s_base + n].child[j]);
+                    if (fixed) fixed->push_back(0);
+                }
+        }
+    } else {
+        std::vector<ushort4> ch(ctx->nBuildingNodes);
+        std::vector<unsigned long long> acc(ctx->nBuildingNodes * 4);
+        if (!ch.empty()) {
+            HIP_CHECK(hipMemcpy(ch.data(), ctx->d_bchild.p, ch.size() * sizeof(ushort4), hipMemcpyDeviceToHost));
+            HIP_CHECK(hipMemcpy(acc.data(), ctx->d_bacc.p, acc.size() * 8, hipMemcpyDeviceToHost));
+        }
+        std::vector<LeafHdr> dh(ctx->hdr.size());
+        HIP_CHECK(hipMemcpy(dh.data(), ctx->d_hdr.p, dh.size() * sizeof(LeafHdr), hipMemcpyDeviceToHost));
+        for (unsigned int leaf : ctx->leaves) {
+            const LeafHdr &h = dh[leaf];
+            for (unsigned int n = 0; n < h.b_num; ++n) {
+                const unsigned short cc[4] = {ch[h.b_base + n].x, ch[h.b_base + n].y, ch[h.b_base + n].z, ch[h.b_base + n].w};
+                for (int j = 0; j < 4; ++j) {
+                    uint64_t a = acc[(size_t)(h.b_base + n) * 4 + j];
+                    sums.push_back(cc[j] == 0 ? ppg_from_fixed(a) : 0.0f); children.push_back(cc[j]);
+                    if (fixed) fixed->push_back(a);
+                }
+            }
+        }
+    }
+    return PPG_OK;
+}
+
+int dumpSDTreeFile(ppg_ctx *ctx, const char *path) {  // GP:1191-1208 + STree::dump GP:945-951 + DTreeWrapper::dump GP:699-711
+    std::vector<SNode> pool(ctx->nSamplingNodes);
+    if (!pool.empty()) HIP_CHECK(hipMemcpy(pool.data(), ctx->d_snodes[ctx->cur].p, pool.size() * sizeof(SNode), hipMemcpyDeviceToHost));
+    FILE *f = fopen(path, "wb");
+    if (!f) { ctx->error = std::string("cannot open ") + path; return PPG_ERR_INVALID; }
+    fwrite(ctx->scene.cam.c2w, 4, 16, f);
+    // STreeNode::forEachLeaf (GP:796-813): depth-first, child 0 before child 1
+    struct E { size_t idx; float p[3], s[3]; };
+    std::vector<E> st;
+    E root; root.idx = 0;
+    for (int a = 0; a < 3; ++a) { root.p[a] = ctx->treeMin[a]; root.s[a] = ctx->treeMax[a] - ctx->treeMin[a]; }
+    st.push_back(root);
+    while (!st.empty()) {
+        E e = st.back(); st.pop_back();
+        const HostSNode &n = ctx->snodes[e.idx];
+        if (n.isLeaf()) {
+            const LeafHdr &h = ctx->hdr[e.idx];
+            if (h.s_statw > 0) {
+                float mean = 0;
+                if (h.s_statw != 0) { const float factor = 1 / (PPG_PI_F * 4 * h.s_statw); mean = factor * h.s_sum; }
+                float hd[7] = {e.p[0], e.p[1], e.p[2], e.s[0], e.s[1], e.s[2], mean};
+                fwrite(hd, 4, 7, f);
+                uint64_t sw = (uint64_t)h.s_statw, nn = h.s_num;
+                fwrite(&sw, 8, 1, f); fwrite(&nn, 8, 1, f);
+                for (unsigned int k = 0; k < h.s_num; ++k)
+                    for (int j = 0; j < 4; ++j) { fwrite(&pool[h.s_base + k].sum[j], 4, 1, f); fwrite(&pool[h.s_base + k].child[j], 2, 1, f); }
+            }
+        } else {
+            E c0 = e, c1 = e;
+            c0.s[n.axis] /= 2; c1.s[n.axis] = c0.s[n.axis];
+            c0.idx = n.child[0]; c1.idx = n.child[1];
+            c1.p[n.axis] += c1.s[n.axis];
+            st.push_back(c1); st.push_back(c0);
+        }
+    }
+    fclose(f);
+    return PPG_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+// C-ABI (include/ppg.h)
+// ================================================================================================
+extern "C" {
+
+void ppg_config_default(ppg_config *cfg) {
+    memset(cfg, 0, sizeof *cfg);
+    cfg->nee = "never"; cfg->sampleCombination = "automatic"; cfg->spatialFilter = "nearest"; cfg->directionalFilter = "nearest";
+    cfg->bsdfSamplingFractionLoss = "none"; cfg->sdTreeMaxMemory = -1; cfg->sTreeThreshold = 12000; cfg->dTreeThreshold = 0.01f;
+    cfg->bsdfSamplingFraction = 0.5f; cfg->sppPerPass = 4; cfg->budgetType = "seconds"; cfg->budget = 300.0f; cfg->dumpSDTree = 0;
+    cfg->rrDepth = 5; cfg->maxDepth = -1; cfg->strictNormals = 0; cfg->hideEmitters = 0; cfg->seed = 0; cfg->device = 0; cfg->dumpPrefix = nullptr;
+}
+
+const char *ppg_description(void) { return "Guided path tracer"; }
+
+int ppg_create(const ppg_config *cfg, ppg_ctx **out) {
+    if (!cfg || !out) { g_createError = "null argument"; return PPG_ERR_INVALID; }
+    std::unique_ptr<ppg_ctx> c(new ppg_ctx());
+#define PARSE(field, dflt, target, ...)                                                                                  \
+    c->target = parseEnum(cfg->field, dflt, {__VA_ARGS__});                                                              \
+    if (c->target < 0) { g_createError = std::string("invalid value for '" #field "': ") + (cfg->field ? cfg->field : ""); return PPG_ERR_INVALID; }
+    PARSE(nee, "never", nee, "never", "kickstart", "always")
+    PARSE(sampleCombination, "automatic", sampleCombination, "discard", "automatic", "inversevar")
+    PARSE(spatialFilter, "nearest", spatialFilter, "nearest", "stochastic", "box")
+    PARSE(directionalFilter, "nearest", directionalFilter, "nearest", "box")
+    PARSE(bsdfSamplingFractionLoss, "none", loss, "none", "kl", "var")
+    PARSE(budgetType, "seconds", budgetType, "spp", "seconds")
+#undef PARSE
+    if (c->nee != NEE_NEVER) { g_createError = "nee != \"never\" is not implemented yet (SURVEY.md §8(f2))"; return PPG_ERR_INVALID; }
+    c->sdTreeMaxMemory = cfg->sdTreeMaxMemory; c->sTreeThreshold = cfg->sTreeThreshold; c->dTreeThreshold = cfg->dTreeThreshold;
+    c->bsdfSamplingFraction = cfg->bsdfSamplingFraction; c->sppPerPass = cfg->sppPerPass; c->budget = cfg->budget;
+    c->dumpSDTree = cfg->dumpSDTree != 0; c->rrDepth = cfg->rrDepth; c->maxDepth = cfg->maxDepth;
+    c->strictNormals = cfg->strictNormals != 0; c->hideEmitters = cfg->hideEmitters != 0; c->seed = cfg->seed; c->device = cfg->device;
+    if (cfg->dumpPrefix) c->dumpPrefix = cfg->dumpPrefix;
+    if (c->sppPerPass <= 0) { g_createError = "sppPerPass must be > 0"; return PPG_ERR_INVALID; }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) { g_createError = std::string("no HIP device available: ") + hipGetErrorString(e); return PPG_ERR_DEVICE; }
+    if (c->device < 0 || c->device >= ndev) { g_createError = "device ordinal out of range"; return PPG_ERR_INVALID; }
+    if ((e = hipSetDevice(c->device)) != hipSuccess || (e = hipStreamCreate(&c->stream)) != hipSuccess) {
+        g_createError = std::string("HIP init failed: ") + hipGetErrorString(e);
+        return PPG_ERR_DEVICE;
+    }
+    *out = c.release();
+    return PPG_OK;
+}
+
+void ppg_destroy(ppg_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); }
+    ctx->timer.resolve();
+    for (auto e : ctx->timer.pool) (void)hipEventDestroy(e);
+    hipStream_t s = ctx->stream;
+    delete ctx;
+    if (s) (void)hipStreamDestroy(s);
+}
+
+const char *ppg_last_error(const ppg_ctx *ctx) { return ctx ? ctx->error.c_str() : g_createError.c_str(); }
+
+int ppg_set_scene(ppg_ctx *ctx, const ppg_scene *s) {
+    if (!s || !s->positions || !s->indices || !s->tri_material || !s->tri_emitter || !s->materials || s->n_triangles == 0) {
+        ctx->error = "incomplete scene";
+        return PPG_ERR_INVALID;
+    }
+    HIP_CHECK(hipSetDevice(ctx->device));
+    for (uint32_t t = 0; t < s->n_triangles; ++t) {
+        if (s->tri_material[t] >= s->n_materials || s->tri_emitter[t] >= (int32_t)s->n_emitters) { ctx->error = "index out of range"; return PPG_ERR_INVALID; }
+        if (s->materials[s->tri_material[t]].type != PPG_BSDF_DIFFUSE) { ctx->error = "unsupported BSDF type"; return PPG_ERR_INVALID; }
+        for (int k = 0; k < 3; ++k) if (s->indices[3 * t + k] >= s->n_vertices) { ctx->error = "vertex index out of range"; return PPG_ERR_INVALID; }
+    }
+    // Scene::getAABB(): kd-tree box enlarged by MTS_KD_AABB_EPSILON (gkdtree.h:1213-1220) + sensor position (scene.cpp:386-414)
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (size_t t = 0; t < 3 * (size_t)s->n_triangles; ++t)
+        for (int a = 0; a < 3; ++a) { float v = s->positions[3 * s->indices[t] + a]; mn[a] = ppg_min(mn[a], v); mx[a] = ppg_max(mx[a], v); }
+    const float eps = 1e-3f;
+    for (int a = 0; a < 3; ++a) {
+        ctx->aabbMin[a] = mn[a] - ((mx[a] - mn[a]) * eps + eps);
+        ctx->aabbMax[a] = mx[a] + ((mx[a] - ctx->aabbMin[a]) * eps + eps);
+        float c = s->camera.camera_to_world[4 * a + 3];
+        ctx->aabbMin[a] = ppg_min(ctx->aabbMin[a], c);
+        ctx->aabbMax[a] = ppg_max(ctx->aabbMax[a], c);
+    }
+    float ext = 0;
+    for (int a = 0; a < 3; ++a) ext = std::max(ext, mx[a] - mn[a]);
+    BvhBuilder bb;
+    bb.run(s->positions, s->indices, s->n_triangles, 1e-4f * ext + 1e-30f);
+    std::vector<float4> tris(3 * (size_t)s->n_triangles), nrm;
+    if (s->normals) nrm.resize(tris.size());
+    for (uint32_t k = 0; k < s->n_triangles; ++k) {
+        uint32_t t = bb.order[k];
+        for (int v = 0; v < 3; ++v) {
+            const float *p = s->positions + 3 * s->indices[3 * t + v];
+            float w = v == 0 ? __builtin_bit_cast(float, (int)s->tri_material[t]) : (v == 1 ? __builtin_bit_cast(float, (int)s->tri_emitter[t]) : __builtin_bit_cast(float, (int)t));
+            tris[3 * k + v] = make_float4(p[0], p[1], p[2], w);
+            if (s->normals) { const float *n = s->normals + 3 * s->indices[3 * t + v]; nrm[3 * k + v] = make_float4(n[0], n[1], n[2], 0); }
+        }
+    }
+    std::vector<float4> mats(s->n_materials), ems(std::max<uint32_t>(1, s->n_emitters));
+    for (uint32_t i = 0; i < s->n_materials; ++i) mats[i] = make_float4(s->materials[i].reflectance[0], s->materials[i].reflectance[1], s->materials[i].reflectance[2], (float)s->materials[i].type);
+    for (uint32_t i = 0; i < s->n_emitters; ++i) ems[i] = make_float4(s->emitters[i].radiance[0], s->emitters[i].radiance[1], s->emitters[i].radiance[2], 0);
+    HIP_CHECK(ctx->d_tris.reserve(tris.size()));
+    HIP_CHECK(hipMemcpy(ctx->d_tris.p, tris.data(), tris.size() * sizeof(float4), hipMemcpyHostToDevice));
+    if (s->normals) { HIP_CHECK(ctx->d_normals.reserve(nrm.size())); HIP_CHECK(hipMemcpy(ctx->d_normals.p, nrm.data(), nrm.size() * sizeof(float4), hipMemcpyHostToDevice)); }
+    HIP_CHECK(ctx->d_bvh.reserve(bb.nodes.size()));
+    HIP_CHECK(hipMemcpy(ctx->d_bvh.p, bb.nodes.data(), bb.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice));
+    HIP_CHECK(ctx->d_materials.reserve(mats.size()));
+    HIP_CHECK(hipMemcpy(ctx->d_materials.p, mats.data(), mats.size() * sizeof(float4), hipMemcpyHostToDevice));
+    HIP_CHECK(ctx->d_emitters.reserve(ems.size()));
+    HIP_CHECK(hipMemcpy(ctx->d_emitters.p, ems.data(), ems.size() * sizeof(float4), hipMemcpyHostToDevice));
+    DevScene &S = ctx->scene;
+    S.tris = ctx->d_tris.p; S.normals = s->normals ? ctx->d_normals.p : nullptr; S.bvh = ctx->d_bvh.p;
+    S.materials = ctx->d_materials.p; S.emitters = ctx->d_emitters.p; S.n_tris = (int)s->n_triangles;
+    memcpy(S.cam.s2c, s->camera.sample_to_camera, 64); memcpy(S.cam.c2w, s->camera.camera_to_world, 64);
+    S.cam.near_clip = s->camera.near_clip; S.cam.far_clip = s->camera.far_clip;
+    S.cam.width = s->camera.width; S.cam.height = s->camera.height;
+    S.cam.inv_w = 1.0f / (float)s->camera.width; S.cam.inv_h = 1.0f / (float)s->camera.height;
+    ctx->W = s->camera.width; ctx->H = s->camera.height;
+    ctx->haveScene = true;
+    ctx->treeAlive = false;
+    return PPG_OK;
+}
+
+int ppg_set_shard(ppg_ctx *ctx, int32_t rank, int32_t world, int32_t tile_size) {
+    if (world < 1 || rank < 0 || rank >= world || tile_size < 1) { ctx->error = "bad shard"; return PPG_ERR_INVALID; }
+    ctx->shardRank = rank; ctx->shardWorld = world; ctx->tileSize = tile_size;
+    return PPG_OK;
+}
+
+#define NEED_SCENE if (!ctx->haveScene) { ctx->error = "no scene"; return PPG_ERR_STATE; }
+#define NEED_TREE if (!ctx->treeAlive) { ctx->error = "render not begun"; return PPG_ERR_STATE; }
+
+int ppg_begin_render(ppg_ctx *ctx) { NEED_SCENE return beginRender(ctx); }
+int ppg_begin_iteration(ppg_ctx *ctx, int32_t is_final) { NEED_TREE return beginIteration(ctx, is_final != 0); }
+int ppg_set_final(ppg_ctx *ctx, int32_t is_final) { ctx->isFinalIter = is_final != 0; return PPG_OK; }
+int ppg_set_do_nee(ppg_ctx *ctx, int32_t do_nee) { ctx->doNee = do_nee != 0; return PPG_OK; }
+int ppg_render_passes_nostat(ppg_ctx *ctx, int32_t n) { NEED_TREE return renderPassesNoStat(ctx, n); }
+int ppg_finish_passes(ppg_ctx *ctx, ppg_pass_stats *st) { NEED_TREE return finishPasses(ctx, st); }
+int ppg_render_passes(ppg_ctx *ctx, int32_t n, ppg_pass_stats *st) {
+    NEED_TREE
+    int rc = renderPassesNoStat(ctx, n);
+    if (rc && rc != PPG_ERR_CANCELLED) return rc;
+    int rc2 = finishPasses(ctx, st);
+    return rc ? rc : rc2;
+}
+int ppg_build_sdtree(ppg_ctx *ctx, ppg_tree_stats *st) { NEED_TREE return buildSDTree(ctx, st); }
+int ppg_end_iteration(ppg_ctx *ctx) { NEED_TREE return endIteration(ctx); }
+int ppg_end_render(ppg_ctx *ctx) { NEED_TREE return endRender(ctx); }
+int ppg_cancel(ppg_ctx *ctx) { ctx->cancelled.store(true); return PPG_OK; }
+
+int ppg_render(ppg_ctx *ctx) {  // GP:1516-1585
+    NEED_SCENE
+    int rc = beginRender(ctx);
+    if (rc) return rc;
+    rc = ctx->budgetType == 0 ? renderSPP(ctx) : renderTime(ctx);
+    if (rc) return rc;
+    return endRender(ctx);
+}
+
+int ppg_read_film(ppg_ctx *ctx, float *rgb) {
+    NEED_SCENE
+    const int n = ctx->W * ctx->H;
+    if (!ctx->d_film.p || !ctx->d_tmp.p) { ctx->error = "nothing rendered"; return PPG_ERR_STATE; }
+    hipLaunchKernelGGL(k_normalise, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, ctx->d_film.p, ctx->d_filmW.p, ctx->d_tmp.p);
+    HIP_CHECK(hipMemcpyAsync(rgb, ctx->d_tmp.p, 3 * (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return PPG_OK;
+}
+int ppg_read_variance(ppg_ctx *ctx, float *rgb) {
+    NEED_SCENE
+    if (!ctx->d_var.p) { ctx->error = "nothing rendered"; return PPG_ERR_STATE; }
+    HIP_CHECK(hipMemcpy(rgb, ctx->d_var.p, 3 * (size_t)ctx->W * ctx->H * 4, hipMemcpyDeviceToHost));
+    return PPG_OK;
+}
+int ppg_dump_sdtree(ppg_ctx *ctx, const char *path) { NEED_TREE return dumpSDTreeFile(ctx, path); }
+
+int ppg_sdtree_info_get(ppg_ctx *ctx, ppg_sdtree_info *info) {
+    NEED_TREE
+    memset(info, 0, sizeof *info);
+    info->n_stree_nodes = (uint32_t)ctx->snodes.size();
+    std::vector<LeafHdr> dh(ctx->hdr);
+    if (ctx->d_hdr.p && ctx->d_hdr.cap >= dh.size()) HIP_CHECK(hipMemcpy(dh.data(), ctx->d_hdr.p, dh.size() * sizeof(LeafHdr), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < ctx->snodes.size(); ++i)
+        if (ctx->snodes[i].isLeaf()) { info->n_leaves++; info->n_sampling_nodes += ctx->hdr[i].s_num; info->n_building_nodes += dh[i].b_num; }
+    for (int a = 0; a < 3; ++a) { info->aabb_min[a] = ctx->treeMin[a]; info->aabb_max[a] = ctx->treeMax[a]; }
+    info->iter = ctx->iter; info->is_built = ctx->isBuilt;
+    return PPG_OK;
+}
+
+int ppg_sdtree_read_stree(ppg_ctx *ctx, int32_t *axis, uint32_t *children) {
+    NEED_TREE
+    for (size_t i = 0; i < ctx->snodes.size(); ++i) { axis[i] = ctx->snodes[i].axis; children[2 * i] = ctx->snodes[i].child[0]; children[2 * i + 1] = ctx->snodes[i].child[1]; }
+    return PPG_OK;
+}
+
+int ppg_sdtree_read_dtree_headers(ppg_ctx *ctx, int32_t which, uint64_t *offset, uint32_t *num_nodes, int32_t *max_depth, float *sum, double *stat_weight) {
+    NEED_TREE
+    std::vector<LeafHdr> dh(ctx->hdr.size());
+    std::vector<unsigned long long> bw(ctx->hdr.size(), 0);
+    if (ctx->d_hdr.p) {
+        HIP_CHECK(hipMemcpy(dh.data(), ctx->d_hdr.p, dh.size() * sizeof(LeafHdr), hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(bw.data(), ctx->d_bweight.p, bw.size() * 8, hipMemcpyDeviceToHost));
+    } else dh = ctx->hdr;
+    uint64_t off = 0;
+    for (size_t i = 0; i < ctx->snodes.size(); ++i) {
+        if (!ctx->snodes[i].isLeaf()) { offset[i] = 0; num_nodes[i] = 0; max_depth[i] = 0; sum[i] = 0; stat_weight[i] = 0; continue; }
+        const LeafHdr &h = dh[i];
+        offset[i] = off;
+        if (which == 0) { num_nodes[i] = h.s_num; max_depth[i] = h.s_depth; sum[i] = h.s_sum; stat_weight[i] = h.s_statw; off += h.s_num; }
+        else {
+            num_nodes[i] = h.b_num; max_depth[i] = h.b_depth; sum[i] = which == 1 ? 0.0f : 0.0f;
+            stat_weight[i] = bw[i] ? (double)bw[i] / 16777216.0 : (double)h.b_statw;
+            off += h.b_num;
+        }
+    }
+    return PPG_OK;
+}
+
+int ppg_sdtree_read_dtree_nodes(ppg_ctx *ctx, int32_t which, float *sums, uint16_t *children, uint64_t *fixed_sums) {
+    NEED_TREE
+    std::vector<float> s; std::vector<uint16_t> c; std::vector<uint64_t> f;
+    int rc = gatherDTrees(ctx, which, s, c, fixed_sums ? &f : nullptr);
+    if (rc) return rc;
+    memcpy(sums, s.data(), s.size() * 4);
+    memcpy(children, c.data(), c.size() * 2);
+    if (fixed_sums) memcpy(fixed_sums, f.data(), f.size() * 8);
+    return PPG_OK;
+}
+
+int ppg_sdtree_read_adam(ppg_ctx *ctx, float *theta) {
+    NEED_TREE
+    std::vector<LeafHdr> dh(ctx->hdr.size());
+    if (ctx->d_hdr.p) HIP_CHECK(hipMemcpy(dh.data(), ctx->d_hdr.p, dh.size() * sizeof(LeafHdr), hipMemcpyDeviceToHost));
+    else dh = ctx->hdr;
+    for (size_t i = 0; i < dh.size(); ++i) theta[i] = dh[i].theta;
+    return PPG_OK;
+}
+
+int ppg_sdtree_stat_buffers(ppg_ctx *ctx, void **dev_sums, uint64_t *n_sums, void **dev_weights, uint64_t *n_weights) {
+    NEED_TREE
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    *dev_sums = ctx->d_bacc.p; *n_sums = ctx->nBuildingNodes * 4;
+    *dev_weights = ctx->d_bweight.p; *n_weights = ctx->snodes.size();
+    return PPG_OK;
+}
+int ppg_film_buffers(ppg_ctx *ctx, void **dev_rgb_sum, void **dev_weight) {
+    NEED_TREE
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    *dev_rgb_sum = ctx->d_film.p; *dev_weight = ctx->d_filmW.p;
+    return PPG_OK;
+}
+int ppg_image_buffers(ppg_ctx *ctx, void **dev_image, void **dev_sq_image) {
+    NEED_TREE
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    *dev_image = ctx->d_image.p; *dev_sq_image = ctx->d_sq.p;
+    return PPG_OK;
+}
+
+int ppg_query_pdf(ppg_ctx *ctx, uint32_t n, const float *positions, const float *dirs, float *pdf_out) {
+    NEED_TREE
+    if (n == 0) return PPG_OK;
+    DevBuf<float> dp, dd, dout;
+    HIP_CHECK(dp.reserve(3 * (size_t)n)); HIP_CHECK(dd.reserve(3 * (size_t)n)); HIP_CHECK(dout.reserve(n));
+    HIP_CHECK(hipMemcpy(dp.p, positions, 12 * (size_t)n, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(dd.p, dirs, 12 * (size_t)n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_query_pdf, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->devTree(), n, dp.p, dd.p, dout.p);
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    HIP_CHECK(hipMemcpy(pdf_out, dout.p, 4 * (size_t)n, hipMemcpyDeviceToHost));
+    return PPG_OK;
+}
+int ppg_query_sample(ppg_ctx *ctx, uint32_t n, const float *positions, uint64_t seed, float *dirs_out) {
+    NEED_TREE
+    if (n == 0) return PPG_OK;
+    DevBuf<float> dp, dout;
+    HIP_CHECK(dp.reserve(3 * (size_t)n)); HIP_CHECK(dout.reserve(3 * (size_t)n));
+    HIP_CHECK(hipMemcpy(dp.p, positions, 12 * (size_t)n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_query_sample, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->devTree(), n, dp.p, (unsigned long long)seed, dout.p);
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    HIP_CHECK(hipMemcpy(dirs_out, dout.p, 12 * (size_t)n, hipMemcpyDeviceToHost));
+    return PPG_OK;
+}
+
+int ppg_enable_kernel_timing(ppg_ctx *ctx, int32_t enable) {
+    ctx->timer.reset();
+    ctx->timer.enabled = enable != 0;
+    return PPG_OK;
+}
+int ppg_kernel_times(ppg_ctx *ctx, ppg_kernel_time *out, uint32_t cap, uint32_t *n) {
+    ctx->timer.resolve();
+    uint32_t k = 0;
+    for (size_t i = 0; i < ctx->timer.names.size() && k < cap; ++i, ++k) {
+        out[k].name = ctx->timer.names[i].c_str(); out[k].ms = ctx->timer.ms[i]; out[k].launches = ctx->timer.launches[i]; out[k].units = ctx->timer.units[i];
+    }
+    *n = k;
+    return PPG_OK;
+}
+
+}  // extern "C"

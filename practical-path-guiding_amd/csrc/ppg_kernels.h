@@ -1,0 +1,727 @@
+/*
+ * ppg_kernels.h — wavefront kernels of the guided path tracer (included by ppg_hip.hip).
+ *
+ * One render pass (= one BlockedRenderProcess of the reference, GP:1087-1106) is
+ *     k_generate → [k_trace → k_shade]* → k_commit → (k_adam_step) → k_film
+ * over SoA path state.  Path i = j * n_pix + k is sample j of the k-th owned pixel, so a wave holds 64
+ * neighbouring pixels.  Queues are arrays of path indices compacted with one wave-aggregated atomic;
+ * all accumulation into shared state is integer (fixed point), so results do not depend on the order
+ * in which waves run.  k_shade(b) finishes bounce b-1 (GP:2078-2145) with the hit found by k_trace and
+ * starts bounce b (GP:1902-2040).
+ */
+#ifndef PPG_KERNELS_H
+#define PPG_KERNELS_H
+
+#include "ppg_device.h"
+
+#define PPG_MAX_VERTICES 32  // MAX_NUM_VERTICES, GP:1771
+#define PPG_BLOCK 256
+
+enum { NEE_NEVER = 0, NEE_KICKSTART = 1, NEE_ALWAYS = 2 };
+enum { SF_NEAREST = 0, SF_STOCHASTIC = 1, SF_BOX = 2 };
+enum { DF_NEAREST = 0, DF_BOX = 1 };
+enum { LOSS_NONE = 0, LOSS_KL = 1, LOSS_VAR = 2 };
+
+// flags word of a path
+#define FL_DEPTH_MASK 0x000fffffu  // rRec.depth
+#define FL_NV_SHIFT 20             // nVertices (0..32), 6 bits
+#define FL_NV_MASK (0x3fu << FL_NV_SHIFT)
+#define FL_SCATTERED (1u << 26)
+#define FL_EMITTED_OK (1u << 27)   // rRec.type & EEmittedRadiance
+#define FL_PENDING (1u << 28)      // a bounce was sampled; its trace result is consumed by the next k_shade
+#define FL_PEND_TREE (1u << 29)    // that bounce had a D-tree
+#define FL_PEND_DELTA (1u << 30)   // that bounce sampled a delta component
+
+struct RenderParams {
+    int nee, spatial_filter, directional_filter, loss;
+    float bsdf_sampling_fraction;
+    int rr_depth, max_depth, strict_normals, hide_emitters;
+    int spp;              // sppPerPass
+    int is_final_iter, do_nee;
+    unsigned long long seed;
+    unsigned int pass_index;  // m_passesRendered at the start of this pass
+    int max_vertices;         // vertex slots allocated per path
+};
+
+struct PathState {
+    unsigned int n_paths;  // n_pix * spp
+    unsigned int n_pix;    // owned pixels
+    const unsigned int *pixels;  // owned pixel list (row-major pixel indices)
+    float4 *ray_o;   // (o, mint)
+    float4 *ray_d;   // (d, maxt)
+    float4 *thr;     // (throughput, eta)
+    float4 *li;      // (Li, woPdf of the pending bounce)
+    float4 *hit;     // (t, u, v, prim)
+    uint4 *misc;     // (key, dim, flags, leaf of the pending bounce)
+    // vertex slots, index = slot * n_paths + path
+    float4 *v_d;     // (ray.d, woPdf)
+    float4 *v_thr;   // (throughput, bsdfPdf)
+    float4 *v_bsdf;  // (bsdfVal, dTreePdf)
+    float4 *v_rad;   // (radiance, leaf | delta << 31)
+    float4 *v_o;     // (ray.o, -)        only if spatial filter != nearest
+    float4 *v_vox;   // (voxel size, -)   only if spatial filter != nearest
+};
+
+struct Counters {  // device-resident, zeroed per ppg_render_passes
+    unsigned long long rays, path_len, committed;
+    unsigned int queue_count[2];
+};
+
+// wave-aggregated append: returns the slot for lanes with `pred`
+D unsigned int queue_append(unsigned int *counter, bool pred) {
+    unsigned long long mask = __ballot(pred);
+    if (mask == 0) return 0;
+    int leader = __ffsll((long long)mask) - 1;
+    int lane = threadIdx.x & 63;
+    unsigned int base = 0;
+    if (lane == leader) base = atomicAdd(counter, (unsigned int)__popcll(mask));
+    base = __shfl(base, leader);
+    return base + (unsigned int)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
+D void wave_add_u64(unsigned long long *dst, unsigned long long v) {
+    // sum over the wave, one atomic
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(dst, v);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_generate — renderBlock's sample loop head (GP:1613-1630) + PerspectiveCamera::sampleRayDifferential
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PPG_BLOCK) void k_generate(PathState P, DevScene S, RenderParams R) {
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < P.n_paths; i += gridDim.x * blockDim.x) {
+        unsigned int k = i % P.n_pix, j = i / P.n_pix;
+        unsigned int pixel = P.pixels[k];
+        unsigned int key = ppg_path_key(R.seed, pixel, R.pass_index * (unsigned int)R.spp + j);
+        unsigned int dim = 0;
+        float u1 = ppg_rand(key, dim++);
+        float u2 = ppg_rand(key, dim++);
+        int px = (int)(pixel % (unsigned int)S.cam.width), py = (int)(pixel / (unsigned int)S.cam.width);
+        float sx = (float)px + u1, sy = (float)py + u2;  // GP:1620
+        F3 nearP = xf_point(S.cam.s2c, f3(sx * S.cam.inv_w, sy * S.cam.inv_h, 0.0f));
+        F3 dl = norm3(nearP);
+        float invZ = 1.0f / dl.z;
+        float mint = S.cam.near_clip * invZ, maxt = S.cam.far_clip * invZ;
+        F3 o = f3(S.cam.c2w[3], S.cam.c2w[7], S.cam.c2w[11]);
+        F3 d = xf_vec(S.cam.c2w, dl);
+        P.ray_o[i] = make_float4(o.x, o.y, o.z, mint);
+        P.ray_d[i] = make_float4(d.x, d.y, d.z, maxt);
+        P.thr[i] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+        P.li[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        P.misc[i] = make_uint4(key, dim, 1u | FL_EMITTED_OK, 0u);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_trace — Scene::rayIntersect (skdtree.cpp:112-142) for every queued path
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PPG_BLOCK) void k_trace(PathState P, DevScene S, const unsigned int *queue, const unsigned int *count_ptr,
+                                                     unsigned int count_all, Counters *C) {
+    unsigned int count = queue ? *count_ptr : count_all;
+    for (unsigned int q = blockIdx.x * blockDim.x + threadIdx.x; q < count; q += gridDim.x * blockDim.x) {
+        unsigned int i = queue ? queue[q] : q;
+        float4 ro = P.ray_o[i], rd = P.ray_d[i];
+        F3 o = f3(ro.x, ro.y, ro.z), d = f3(rd.x, rd.y, rd.z);
+        float rayMinT = ro.w;
+        if (rayMinT == PPG_EPSILON)  // adaptive ray epsilon
+            rayMinT *= ppg_max(ppg_max(ppg_max(ppg_abs(o.x), ppg_abs(o.y)), ppg_abs(o.z)), PPG_EPSILON);
+        Hit h = trace_closest(S, o, d, rayMinT, rd.w);
+        P.hit[i] = make_float4(h.t, h.u, h.v, __int_as_float(h.prim));
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&C->rays, (unsigned long long)count);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_shade — Li's loop body (GP:1798-2146), surface branch, nee = never
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PPG_BLOCK) void k_shade(PathState P, DevScene S, DevTree T, RenderParams R, const unsigned int *queue,
+                                                     const unsigned int *count_ptr, unsigned int count_all, unsigned int *next_queue,
+                                                     unsigned int *next_count, Counters *C) {
+    unsigned int count = queue ? *count_ptr : count_all;
+    unsigned int total = gridDim.x * blockDim.x;
+    unsigned int rounds = (count + total - 1) / total;
+    for (unsigned int r = 0; r < rounds; ++r) {
+        unsigned int q = r * total + blockIdx.x * blockDim.x + threadIdx.x;
+        bool active = q < count;
+        bool alive = false;
+        unsigned long long plen = 0;
+        unsigned int i = 0;
+        if (active) {
+            i = queue ? queue[q] : q;
+            uint4 m = P.misc[i];
+            unsigned int key = m.x, dim = m.y, flags = m.z;
+            unsigned int depth = flags & FL_DEPTH_MASK;
+            unsigned int nV = (flags & FL_NV_MASK) >> FL_NV_SHIFT;
+            float4 t4 = P.thr[i], l4 = P.li[i], h4 = P.hit[i], d4 = P.ray_d[i];
+            F3 thr = f3(t4.x, t4.y, t4.z);
+            float eta = t4.w;
+            F3 Li = f3(l4.x, l4.y, l4.z);
+            F3 d = f3(d4.x, d4.y, d4.z);
+            Hit h;
+            h.t = h4.x; h.u = h4.y; h.v = h4.z; h.prim = __float_as_int(h4.w);
+            const bool valid = h.prim >= 0;
+            Isect I;
+            if (valid) fill_isect(S, h, d, I);
+            bool go = true;
+
+            if (flags & FL_PENDING) {
+                // ---- second half of the previous bounce: GP:2078-2145 ----
+                F3 value = valid ? eval_Le(S, I, -d) : f3s(0.0f);  // rayIntersectAndLookForEmitter, GP:2229-2234
+                const float woPdf = l4.w;
+                const bool isDelta = (flags & FL_PEND_DELTA) != 0;
+                const bool hasTree = (flags & FL_PEND_TREE) != 0;
+                float pa = woPdf * woPdf, pb = 0.0f * 0.0f;  // miWeight(woPdf, emitterPdf = 0), GP:2247-2250
+                const float weight = pa / (pa + pb);
+                F3 L = mul3(thr, value) * weight;
+                if (!iszero3(L)) {  // recordRadiance, GP:1791-1796
+                    Li = Li + L;
+                    for (unsigned int v = 0; v < nV; ++v) {
+                        float4 rr = P.v_rad[(size_t)v * P.n_paths + i];
+                        rr.x += L.x; rr.y += L.y; rr.z += L.z;
+                        P.v_rad[(size_t)v * P.n_paths + i] = rr;
+                    }
+                }
+                if ((!isDelta || R.loss != LOSS_NONE) && hasTree && nV < PPG_MAX_VERTICES && nV < (unsigned int)R.max_vertices &&
+                    !R.is_final_iter) {
+                    if (1 / woPdf > 0) {  // the other vertex fields were written when the bounce was sampled
+                        F3 rad = (R.nee == NEE_ALWAYS) ? f3s(0.0f) : L;
+                        unsigned int bits = m.w | (isDelta ? 0x80000000u : 0u);
+                        P.v_rad[(size_t)nV * P.n_paths + i] = make_float4(rad.x, rad.y, rad.z, __uint_as_float(bits));
+                        ++nV;
+                    }
+                }
+                flags &= ~FL_EMITTED_OK;  // rRec.type = ERadianceNoEmission
+                if (depth++ >= (unsigned int)R.rr_depth) {  // Russian roulette, GP:2124-2142
+                    float successProb = 1.0f;
+                    if (hasTree && !isDelta) {
+                        if (!T.is_built) successProb = max3(thr) * eta * eta;
+                        successProb = ppg_max(0.1f, ppg_min(successProb, 0.99f));
+                    }
+                    if (ppg_rand(key, dim++) >= successProb) go = false;
+                    else thr = div3(thr, successProb);
+                }
+                if (go) {
+                    flags |= FL_SCATTERED;
+                    if (!((int)depth <= R.max_depth || R.max_depth < 0)) go = false;
+                }
+                flags &= ~(FL_PENDING | FL_PEND_TREE | FL_PEND_DELTA);
+            }
+
+            // ---- first half of this bounce: GP:1902-2040 ----
+            if (go && !valid) go = false;  // no environment emitter in the supported scene subset
+            if (go) {
+                if (I.emitter >= 0 && (flags & FL_EMITTED_OK) && (!R.hide_emitters || (flags & FL_SCATTERED)))
+                    Li = Li + mul3(thr, eval_Le(S, I, -d));  // GP:1917-1919 (nVertices == 0 here)
+                if ((int)depth >= R.max_depth && R.max_depth != -1) go = false;
+            }
+            if (go) {
+                float wiDotGeoN = -dot3(I.geoN, d), wiDotShN = I.wi.z;
+                if (wiDotGeoN * wiDotShN < 0 && R.strict_normals) go = false;
+            }
+            if (go) {
+                F3 vox;
+                const int leaf = stree_lookup(T, I.p, vox);  // GP:1942-1944
+                const LeafHdr hd = T.hdr[leaf];
+                float frac = R.bsdf_sampling_fraction;  // GP:1946-1949
+                if (R.loss != LOSS_NONE) frac = logistic(hd.theta);
+                float4 mat = S.materials[I.material];
+                F3 refl = f3(mat.x, mat.y, mat.z);
+
+                // sampleMat, GP:1650-1691
+                float sx = ppg_rand(key, dim++);
+                float sy = ppg_rand(key, dim++);
+                F3 wo_l, bsdfWeight;
+                float woPdf, bsdfPdf, dTreePdf;
+                if (!T.is_built) {
+                    if (I.wi.z <= 0) {
+                        bsdfWeight = f3s(0.0f); bsdfPdf = 0.0f; wo_l = f3s(0.0f);
+                    } else {
+                        wo_l = cosine_hemisphere(sx, sy);
+                        bsdfPdf = PPG_INV_PI_F * wo_l.z;
+                        bsdfWeight = refl;
+                    }
+                    woPdf = bsdfPdf;
+                    dTreePdf = 0;
+                } else {
+                    F3 result;
+                    bool zero = false;
+                    if (sx < frac) {
+                        sx /= frac;
+                        if (I.wi.z <= 0) {
+                            zero = true;
+                        } else {
+                            wo_l = cosine_hemisphere(sx, sy);
+                            bsdfPdf = PPG_INV_PI_F * wo_l.z;
+                            result = refl;
+                            if (iszero3(result)) zero = true;
+                            else result = result * bsdfPdf;
+                        }
+                    } else {
+                        // sample.x is remapped but unused on this branch (GP:1680-1682)
+                        float cx, cy;
+                        dtree_sample(T, hd, key, dim, cx, cy);
+                        wo_l = to_local(I, canonical_to_dir(cx, cy));
+                        result = diffuse_eval(refl, I.wi, wo_l);
+                    }
+                    if (zero) {
+                        woPdf = bsdfPdf = dTreePdf = 0;
+                        bsdfWeight = f3s(0.0f);
+                        wo_l = f3s(0.0f);
+                    } else {
+                        // pdfMat, GP:1693-1710
+                        dTreePdf = 0;
+                        bsdfPdf = diffuse_pdf(I.wi, wo_l);
+                        if (!ppg_isfinite(bsdfPdf)) {
+                            woPdf = 0;
+                        } else {
+                            float cx, cy;
+                            dir_to_canonical(to_world(I, wo_l), cx, cy);
+                            dTreePdf = dtree_pdf(T, hd, cx, cy);
+                            woPdf = frac * bsdfPdf + (1 - frac) * dTreePdf;
+                        }
+                        bsdfWeight = (woPdf == 0) ? f3s(0.0f) : div3(result, woPdf);
+                    }
+                }
+                if (iszero3(bsdfWeight)) go = false;  // GP:2024-2025
+                if (go) {
+                    const F3 wo = to_world(I, wo_l);
+                    float woDotGeoN = dot3(I.geoN, wo);
+                    if (woDotGeoN * wo_l.z <= 0 && R.strict_normals) go = false;  // GP:2031-2032
+                    if (go) {
+                        thr = mul3(thr, bsdfWeight);  // GP:2039-2040 (eta *= 1)
+                        d = wo;
+                        P.ray_o[i] = make_float4(I.p.x, I.p.y, I.p.z, PPG_EPSILON);
+                        P.ray_d[i] = make_float4(wo.x, wo.y, wo.z, __builtin_inff());
+                        if (nV < PPG_MAX_VERTICES && nV < (unsigned int)R.max_vertices && !R.is_final_iter) {
+                            size_t vi = (size_t)nV * P.n_paths + i;
+                            F3 bv = bsdfWeight * woPdf;
+                            P.v_d[vi] = make_float4(wo.x, wo.y, wo.z, woPdf);
+                            P.v_thr[vi] = make_float4(thr.x, thr.y, thr.z, bsdfPdf);
+                            P.v_bsdf[vi] = make_float4(bv.x, bv.y, bv.z, dTreePdf);
+                            if (P.v_o) {
+                                P.v_o[vi] = make_float4(I.p.x, I.p.y, I.p.z, 0.0f);
+                                P.v_vox[vi] = make_float4(vox.x, vox.y, vox.z, 0.0f);
+                            }
+                        }
+                        flags |= FL_PENDING | FL_PEND_TREE;
+                        m.w = (unsigned int)leaf;
+                        l4.w = woPdf;
+                        alive = true;
+                    }
+                }
+            }
+            flags = (flags & ~(FL_DEPTH_MASK | FL_NV_MASK)) | (depth & FL_DEPTH_MASK) | (nV << FL_NV_SHIFT);
+            P.misc[i] = make_uint4(key, dim, flags, m.w);
+            P.li[i] = make_float4(Li.x, Li.y, Li.z, l4.w);
+            if (alive) P.thr[i] = make_float4(thr.x, thr.y, thr.z, eta);
+            else plen = depth;  // avgPathLength += rRec.depth, GP:2147-2148
+        }
+        unsigned int slot = queue_append(next_count, alive);
+        if (alive) next_queue[slot] = i;
+        wave_add_u64(&C->path_len, plen);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Splatting: DTree::recordIrradiance (GP:395-413) into the building tree of one S-tree leaf
+// ------------------------------------------------------------------------------------------------
+D void dtree_record(const DevTree &T, int leaf, float px, float py, float irradiance, float w, int dfilter) {
+    if (!(ppg_isfinite(w) && w > 0)) return;
+    atomicAdd(&T.bweight[leaf], ppg_to_fixed(w));
+    if (!(ppg_isfinite(irradiance) && irradiance > 0)) return;
+    const unsigned int base = T.hdr[leaf].b_base;
+    if (dfilter == DF_NEAREST) {  // QuadTreeNode::record, GP:303-312
+        unsigned int node = 0;
+        for (;;) {
+            int index = quad_child_index(px, py);
+            unsigned short c = ((const unsigned short *)&T.bchild[base + node])[index];
+            if (c == 0) {
+                atomicAdd(&T.bacc[(size_t)(base + node) * 4 + index], ppg_to_fixed(irradiance * w));
+                break;
+            }
+            node = c;
+        }
+    } else {
+        // depthAt (GP:247-255), then the box splat (GP:403-409, 322-338) with an explicit stack
+        int depth = 0;
+        {
+            float qx = px, qy = py;
+            unsigned int node = 0;
+            for (;;) {
+                int index = quad_child_index(qx, qy);
+                ++depth;
+                unsigned short c = ((const unsigned short *)&T.bchild[base + node])[index];
+                if (c == 0) break;
+                node = c;
+            }
+        }
+        const float size = ppg_exp2i(-depth);
+        const float ox = px - size / 2, oy = py - size / 2;
+        const float value = irradiance * w / (size * size);
+        struct E { unsigned int node; float x, y, s; };
+        E st[64];
+        int sp = 0;
+        st[sp++] = E{0u, 0.0f, 0.0f, 1.0f};
+        while (sp) {
+            E e = st[--sp];
+            float childSize = e.s / 2;
+            ushort4 ch = T.bchild[base + e.node];
+            const unsigned short cc[4] = {ch.x, ch.y, ch.z, ch.w};
+            // the reference recurses depth-first in child order; contributions to distinct leaf slots commute (integer adds)
+            for (int i = 0; i < 4; ++i) {
+                float cx = e.x, cy = e.y;
+                if (i & 1) cx += childSize;
+                if (i & 2) cy += childSize;
+                float lx = ppg_max(ppg_min(ox + size, cx + childSize) - ppg_max(ox, cx), 0.0f);
+                float ly = ppg_max(ppg_min(oy + size, cy + childSize) - ppg_max(oy, cy), 0.0f);
+                float ww = lx * ly;
+                if (ww > 0.0f) {
+                    if (cc[i] == 0) atomicAdd(&T.bacc[(size_t)(base + e.node) * 4 + i], ppg_to_fixed(value * ww));
+                    else st[sp++] = E{cc[i], cx, cy, childSize};
+                }
+            }
+        }
+    }
+}
+
+struct Rec {  // DTreeRecord, GP:562-568
+    F3 d;
+    float radiance, product, woPdf, bsdfPdf, dTreePdf, statisticalWeight;
+    bool isDelta;
+};
+
+// DTreeWrapper::record (GP:575-584) incl. the gradient of optimizeBsdfSamplingFraction (GP:672-697);
+// the Adam step itself is taken once per pass by k_adam_step from the exact sums accumulated here.
+D void wrapper_record(const DevTree &T, int leaf, const Rec &rec, int dfilter, int loss) {
+    if (!rec.isDelta) {
+        float irradiance = rec.radiance / rec.woPdf;
+        float px, py;
+        dir_to_canonical(rec.d, px, py);
+        dtree_record(T, leaf, px, py, irradiance, rec.statisticalWeight, dfilter);
+    }
+    if (loss != LOSS_NONE && rec.product > 0) {
+        float variable = T.hdr[leaf].theta;
+        float samplingFraction = logistic(variable);
+        float mixPdf = samplingFraction * rec.bsdfPdf + (1 - samplingFraction) * rec.dTreePdf;
+        float r = rec.product / mixPdf;
+        float ratio = (loss == LOSS_KL) ? r : r * r;
+        float dLoss_dSamplingFraction = -ratio / rec.woPdf * (rec.bsdfPdf - rec.dTreePdf);
+        float dLoss_dVariable = dLoss_dSamplingFraction * (samplingFraction * (1 - samplingFraction));
+        float l2RegGradient = 0.01f * variable;
+        float lossGradient = l2RegGradient + dLoss_dVariable;
+        atomicAdd((unsigned long long *)&T.adam_grad[leaf], (unsigned long long)ppg_to_sfixed(lossGradient * rec.statisticalWeight));
+        atomicAdd(&T.adam_w[leaf], ppg_to_fixed(rec.statisticalWeight));
+    }
+}
+
+// STree::record + STreeNode::record (GP:935-943, 823-839): box spatial filter
+D void stree_record_box(const DevTree &T, F3 p, F3 vox, Rec rec, int dfilter, int loss) {
+    float volume = 1;
+    volume *= vox.x; volume *= vox.y; volume *= vox.z;
+    rec.statisticalWeight /= volume;
+    F3 min1 = p - vox * 0.5f, max1 = p + vox * 0.5f;
+    struct E { int node; float mx, my, mz, sx, sy, sz; };
+    E st[96];
+    int sp = 0;
+    st[sp++] = E{0, T.aabb_min[0], T.aabb_min[1], T.aabb_min[2], T.aabb_ext[0], T.aabb_ext[1], T.aabb_ext[2]};
+    while (sp) {
+        E e = st[--sp];
+        float lx = ppg_max(ppg_min(max1.x, e.mx + e.sx) - ppg_max(min1.x, e.mx), 0.0f);
+        float ly = ppg_max(ppg_min(max1.y, e.my + e.sy) - ppg_max(min1.y, e.my), 0.0f);
+        float lz = ppg_max(ppg_min(max1.z, e.mz + e.sz) - ppg_max(min1.z, e.mz), 0.0f);
+        float w = lx * ly * lz;
+        if (!(w > 0)) continue;
+        int4 n = T.stree[e.node];
+        if (n.y == 0) {
+            Rec r2 = rec;
+            r2.statisticalWeight = rec.statisticalWeight * w;
+            wrapper_record(T, e.node, r2, dfilter, loss);
+        } else {
+            float m2[3] = {e.mx, e.my, e.mz}, s2[3] = {e.sx, e.sy, e.sz};
+            s2[n.x] /= 2;
+            E c0 = E{n.y, m2[0], m2[1], m2[2], s2[0], s2[1], s2[2]};
+            m2[n.x] += s2[n.x];
+            E c1 = E{n.z, m2[0], m2[1], m2[2], s2[0], s2[1], s2[2]};
+            if (sp + 2 <= 96) { st[sp++] = c1; st[sp++] = c0; }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_commit — Vertex::commit for every recorded vertex of every path (GP:1730-1768, 2150-2154)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PPG_BLOCK) void k_commit(PathState P, DevTree T, RenderParams R, Counters *C) {
+    unsigned int total = gridDim.x * blockDim.x;
+    unsigned int rounds = (P.n_paths + total - 1) / total;
+    for (unsigned int r = 0; r < rounds; ++r) {
+        unsigned int i = r * total + blockIdx.x * blockDim.x + threadIdx.x;
+        unsigned long long committed = 0;
+        if (i < P.n_paths) {
+            uint4 m = P.misc[i];
+            unsigned int key = m.x, dim = m.y;
+            unsigned int nV = (m.z & FL_NV_MASK) >> FL_NV_SHIFT;
+            const float statisticalWeight = (R.nee == NEE_KICKSTART && R.do_nee) ? 0.5f : 1.0f;
+            const int loss = T.is_built ? R.loss : LOSS_NONE;
+            for (unsigned int v = 0; v < nV; ++v) {
+                size_t vi = (size_t)v * P.n_paths + i;
+                float4 a = P.v_d[vi], b = P.v_thr[vi], c = P.v_bsdf[vi], e = P.v_rad[vi];
+                const float woPdf = a.w, bsdfPdf = b.w, dTreePdf = c.w;
+                F3 radiance = f3(e.x, e.y, e.z), bsdfVal = f3(c.x, c.y, c.z), throughput = f3(b.x, b.y, b.z);
+                unsigned int bits = __float_as_uint(e.w);
+                if (!(woPdf > 0) || !isvalid3(radiance) || !isvalid3(bsdfVal)) continue;
+                F3 localRadiance = f3s(0.0f);
+                if (throughput.x * woPdf > PPG_EPSILON) localRadiance.x = radiance.x / throughput.x;
+                if (throughput.y * woPdf > PPG_EPSILON) localRadiance.y = radiance.y / throughput.y;
+                if (throughput.z * woPdf > PPG_EPSILON) localRadiance.z = radiance.z / throughput.z;
+                F3 product = mul3(localRadiance, bsdfVal);
+                Rec rec;
+                rec.d = f3(a.x, a.y, a.z);
+                rec.radiance = avg3(localRadiance); rec.product = avg3(product);
+                rec.woPdf = woPdf; rec.bsdfPdf = bsdfPdf; rec.dTreePdf = dTreePdf;
+                rec.statisticalWeight = statisticalWeight;
+                rec.isDelta = (bits & 0x80000000u) != 0;
+                const int leaf = (int)(bits & 0x7fffffffu);
+                if (R.spatial_filter == SF_NEAREST) {
+                    wrapper_record(T, leaf, rec, R.directional_filter, loss);
+                } else {
+                    float4 o4 = P.v_o[vi], x4 = P.v_vox[vi];
+                    F3 ro = f3(o4.x, o4.y, o4.z), vox = f3(x4.x, x4.y, x4.z);
+                    if (R.spatial_filter == SF_STOCHASTIC) {  // GP:1746-1763
+                        F3 offset = vox;
+                        offset.x *= ppg_rand(key, dim++) - 0.5f;
+                        offset.y *= ppg_rand(key, dim++) - 0.5f;
+                        offset.z *= ppg_rand(key, dim++) - 0.5f;
+                        F3 og = ro + offset;
+                        og.x = ppg_min(ppg_max(og.x, T.aabb_min[0]), T.aabb_max[0]);  // AABB::clip
+                        og.y = ppg_min(ppg_max(og.y, T.aabb_min[1]), T.aabb_max[1]);
+                        og.z = ppg_min(ppg_max(og.z, T.aabb_min[2]), T.aabb_max[2]);
+                        F3 dummy;
+                        int splat = stree_lookup(T, og, dummy);
+                        wrapper_record(T, splat, rec, R.directional_filter, loss);
+                    } else {
+                        stree_record_box(T, ro, vox, rec, R.directional_filter, loss);
+                    }
+                }
+                ++committed;
+            }
+        }
+        wave_add_u64(&C->committed, committed);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_adam_step — one AdamOptimizer::step (GP:97-109) per D-tree and pass from the exact per-pass sums
+// ------------------------------------------------------------------------------------------------
+__global__ void k_adam_step(DevTree T, unsigned int n_nodes) {
+    unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    unsigned long long wacc = T.adam_w[i];
+    if (wacc == 0) return;
+    float w = ppg_from_fixed(wacc);
+    if (w > 1.0f) {  // batchAccumulation > batchSize
+        LeafHdr h = T.hdr[i];
+        float gradient = ppg_from_sfixed(T.adam_grad[i]) / w;
+        ++h.adam_iter;
+        float lr = 0.01f * __builtin_sqrtf(1 - ppg_powi(0.999f, h.adam_iter)) / (1 - ppg_powi(0.9f, h.adam_iter));
+        h.adam_m = 0.9f * h.adam_m + (1 - 0.9f) * gradient;
+        h.adam_v = 0.999f * h.adam_v + (1 - 0.999f) * gradient * gradient;
+        h.theta -= lr * h.adam_m / (__builtin_sqrtf(h.adam_v) + 1e-08f);
+        h.theta = ppg_min(ppg_max(h.theta, -20.0f), 20.0f);
+        T.hdr[i] = h;
+    }
+    T.adam_grad[i] = 0;
+    T.adam_w[i] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_film — block->put / squaredBlock->put / film->put for the spp samples of each owned pixel
+// (GP:1633-1640; box filter ⇒ own pixel, unit weight)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_film(PathState P, int spp, float *image, float *sq_image, float *image_w, float *film, float *film_w) {
+    unsigned int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= P.n_pix) return;
+    unsigned int pixel = P.pixels[k];
+    float ir = image[3 * pixel], ig = image[3 * pixel + 1], ib = image[3 * pixel + 2];
+    float sr = sq_image[3 * pixel], sg = sq_image[3 * pixel + 1], sb = sq_image[3 * pixel + 2];
+    float fr = film[3 * pixel], fg = film[3 * pixel + 1], fb = film[3 * pixel + 2];
+    float iw = image_w[pixel], fw = film_w[pixel];
+    for (int j = 0; j < spp; ++j) {
+        float4 l = P.li[(size_t)j * P.n_pix + k];
+        ir += l.x; ig += l.y; ib += l.z;
+        sr += l.x * l.x; sg += l.y * l.y; sb += l.z * l.z;
+        fr += l.x; fg += l.y; fb += l.z;
+        iw += 1.0f; fw += 1.0f;
+    }
+    image[3 * pixel] = ir; image[3 * pixel + 1] = ig; image[3 * pixel + 2] = ib;
+    sq_image[3 * pixel] = sr; sq_image[3 * pixel + 1] = sg; sq_image[3 * pixel + 2] = sb;
+    film[3 * pixel] = fr; film[3 * pixel + 1] = fg; film[3 * pixel + 2] = fb;
+    image_w[pixel] = iw; film_w[pixel] = fw;
+}
+
+// per-pixel variance estimate of performRenderPasses (GP:1300-1311); the clamped luminance goes to `lum`
+__global__ void k_variance(int n, int N, const float *image, const float *sq_image, const float *image_w, float *var_rgb, float *lum) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float w = image_w[i];
+    float iw = w != 0 ? 1.0f / w : 0.0f;
+    F3 pixel = f3(image[3 * i] * iw, image[3 * i + 1] * iw, image[3 * i + 2] * iw);
+    F3 sq = f3(sq_image[3 * i] * iw, sq_image[3 * i + 1] * iw, sq_image[3 * i + 2] * iw);
+    F3 localVar = sq - div3(mul3(pixel, pixel), (float)N);
+    var_rgb[3 * i] = localVar.x; var_rgb[3 * i + 1] = localVar.y; var_rgb[3 * i + 2] = localVar.z;
+    float l = localVar.x * 0.212671f + localVar.y * 0.715160f + localVar.z * 0.072169f;
+    lum[i] = ppg_min(l, 10000.0f);
+}
+
+__global__ void k_normalise(int n, const float *rgb_sum, const float *w, float *out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float ww = w[i];
+    float iw = ww != 0 ? 1.0f / ww : 0.0f;
+    out[3 * i] = rgb_sum[3 * i] * iw; out[3 * i + 1] = rgb_sum[3 * i + 1] * iw; out[3 * i + 2] = rgb_sum[3 * i + 2] * iw;
+}
+
+__global__ void k_axpy(int n, float a, const float *x, float *y) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] += x[i] * a;
+}
+
+// ------------------------------------------------------------------------------------------------
+// SD-tree rebuild kernels
+// ------------------------------------------------------------------------------------------------
+// DTree::reset (GP:456-514): one lane walks the reference's LIFO stack for one S-tree leaf, so the node
+// numbering equals the reference's.  WRITE = false only counts nodes (first pass); an exclusive scan over
+// the counts gives every leaf its block in the building pool; WRITE = true emits the child indices.
+template <bool WRITE>
+__global__ void k_dtree_reset(DevTree T, const unsigned int *leaves, unsigned int n_leaves, int newMaxDepth, float rho,
+                              unsigned int *counts, ushort4 *bchild_out) {
+    unsigned int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_leaves) return;
+    const unsigned int leaf = leaves[k];
+    const LeafHdr h = T.hdr[leaf];
+    const float total = h.s_sum;
+    const SNode *prev = T.snodes + h.s_base;
+    const unsigned int base = WRITE ? h.b_base : 0;
+    struct E { unsigned short nodeIndex, otherIndex; unsigned char depth, isThis; float val; };
+    E st[64];
+    int sp = 0;
+    st[sp++] = E{0, 0, 1, 0, 0.0f};
+    unsigned int size = 1;
+    int maxDepth = 0;
+    if (WRITE) bchild_out[base] = make_ushort4(0, 0, 0, 0);
+    bool abort = false;
+    while (sp && !abort) {
+        E s = st[--sp];
+        if ((int)s.depth > maxDepth) maxDepth = s.depth;
+        unsigned short ch[4] = {0, 0, 0, 0};
+        SNode other;
+        if (!s.isThis) other = prev[s.otherIndex];
+        for (int i = 0; i < 4; ++i) {
+            const float osum = s.isThis ? s.val : other.sum[i];
+            const float fraction = total > 0 ? (osum / total) : ppg_exp2i(-2 * (int)s.depth);
+            if ((int)s.depth < newMaxDepth && fraction > rho) {
+                if (!s.isThis && other.child[i] != 0) st[sp++] = E{(unsigned short)size, other.child[i], (unsigned char)(s.depth + 1), 0, 0.0f};
+                else st[sp++] = E{(unsigned short)size, (unsigned short)size, (unsigned char)(s.depth + 1), 1, osum / 4};
+                ch[i] = (unsigned short)size;
+                if (WRITE) bchild_out[base + size] = make_ushort4(0, 0, 0, 0);
+                ++size;
+                if (size > 65535u) { abort = true; break; }
+            }
+        }
+        if (WRITE) bchild_out[base + s.nodeIndex] = make_ushort4(ch[0], ch[1], ch[2], ch[3]);
+    }
+    if (!WRITE) counts[k] = size;
+    else { T.hdr[leaf].b_depth = maxDepth; }
+}
+
+// DTree::build (GP:520-533, 346-366) + `sampling = building` (GP:610-613): children always have larger
+// indices than their parent, so one backwards sweep evaluates the recursion's post-order.
+__global__ void k_dtree_build(DevTree T, const unsigned int *leaves, unsigned int n_leaves, SNode *snodes_out) {
+    unsigned int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_leaves) return;
+    const unsigned int leaf = leaves[k];
+    LeafHdr h = T.hdr[leaf];
+    const unsigned int base = h.b_base;
+    for (int n = (int)h.b_num - 1; n >= 0; --n) {
+        ushort4 c4 = T.bchild[base + n];
+        const unsigned short cc[4] = {c4.x, c4.y, c4.z, c4.w};
+        SNode out;
+        for (int j = 0; j < 4; ++j) {
+            out.child[j] = cc[j];
+            if (cc[j] == 0) {
+                out.sum[j] = ppg_from_fixed(T.bacc[(size_t)(base + n) * 4 + j]);
+            } else {
+                const SNode c = snodes_out[base + cc[j]];
+                float sum = 0;
+                for (int q = 0; q < 4; ++q) sum += c.sum[q];
+                out.sum[j] = sum;
+            }
+        }
+        out.pad[0] = out.pad[1] = 0;
+        snodes_out[base + n] = out;
+    }
+    const SNode root = snodes_out[base];
+    float sum = 0;
+    for (int i = 0; i < 4; ++i) sum += root.sum[i];
+    h.s_base = base; h.s_num = h.b_num; h.s_depth = h.b_depth;
+    h.s_sum = sum;
+    h.s_statw = ppg_from_fixed(T.bweight[leaf]);
+    h.b_statw = h.s_statw;
+    T.hdr[leaf] = h;
+}
+
+// exclusive scan of `counts` (n small: one S-tree leaf each) by a single workgroup; total → *total_out
+__global__ void k_scan_exclusive(const unsigned int *counts, unsigned int *offsets, unsigned int n, unsigned long long *total_out) {
+    __shared__ unsigned long long part[1024];
+    __shared__ unsigned long long carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (unsigned int start = 0; start < n; start += 1024) {
+        unsigned int i = start + threadIdx.x;
+        unsigned long long v = i < n ? counts[i] : 0;
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (unsigned int off = 1; off < 1024; off <<= 1) {
+            unsigned long long t = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+            __syncthreads();
+            part[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < n) offsets[i] = (unsigned int)(carry + part[threadIdx.x] - v);
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += part[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total_out = carry;
+}
+
+__global__ void k_assign_blocks(DevTree T, const unsigned int *leaves, unsigned int n_leaves, const unsigned int *counts,
+                                const unsigned int *offsets) {
+    unsigned int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_leaves) return;
+    T.hdr[leaves[k]].b_base = offsets[k];
+    T.hdr[leaves[k]].b_num = counts[k];
+}
+
+// batched queries (ppg_query_pdf / ppg_query_sample)
+__global__ void k_query_pdf(DevTree T, unsigned int n, const float *pos, const float *dirs, float *out) {
+    unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    F3 vox;
+    int leaf = stree_lookup(T, f3(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]), vox);
+    float cx, cy;
+    dir_to_canonical(f3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]), cx, cy);
+    out[i] = dtree_pdf(T, T.hdr[leaf], cx, cy);
+}
+__global__ void k_query_sample(DevTree T, unsigned int n, const float *pos, unsigned long long seed, float *out) {
+    unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    F3 vox;
+    int leaf = stree_lookup(T, f3(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]), vox);
+    unsigned int key = ppg_path_key(seed, i, 0), dim = 0;
+    float cx, cy;
+    dtree_sample(T, T.hdr[leaf], key, dim, cx, cy);
+    F3 d = canonical_to_dir(cx, cy);
+    out[3 * i] = d.x; out[3 * i + 1] = d.y; out[3 * i + 2] = d.z;
+}
+
+#endif
