@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""bench.py — Msamples/s of the guided path tracer hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): procedural CBOX (= scenes/cbox/cbox.xml, 36 triangles) at 1280x720,
+4 spp per pass, default SD-tree parameters (sTreeThreshold 12000, dTreeThreshold 0.01,
+bsdfSamplingFraction 0.5, nearest filters, sampleCombination automatic), maxDepth 10 / rrDepth 10 /
+strictNormals as in the scene file, budgetType = spp.
+
+A "step" is one render pass = one BlockedRenderProcess of the reference: every pixel x sppPerPass paths
+through Li, splatted into the SD-tree, accumulated into the film.  The timed region is a complete
+GuidedPathTracer::render() of K passes (budget = K x 4 spp) following the reference's iteration schedule
+1, 2, 4, ... (guided_path.cpp:1342-1426), so SD-tree refine / reset / build between iterations ARE inside
+the timed region and scene upload / BVH build are not.  Warm-up = one throw-away
+render of W passes.  value = pixels x spp x K / seconds, whole job over all GPUs.
+
+Multi-GPU (`torchrun ... bench.py --gpus N`): the fixed image is sharded by 32x32 tiles over the ranks
+(strong scaling); per iteration the building SD-tree statistics are all-reduced over RCCL
+(ppg_host/distributed.py).
+
+Adds to the JSON line: `roofline` for the dominant kernel (HIP-event durations measured in-process on
+the kernel's own stream; algorithmic bytes per DESIGN.md) and, on rank 0 at N = 1, `cpu_baseline` = the
+oracle restatement timed on the host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "practical-path-guiding_amd"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def algorithmic_bytes_per_ray():
+    """SURVEY.md §8(d), per traced ray (one k_trace + one k_shade visit), CBOX: see DESIGN.md §roofline."""
+    return dict(
+        trace=32 + 16 + 10 * 64 + 4 * 48,          # ray read, hit write, ~10 BVH2 nodes, ~4 triangles
+        shade=32 + 16 + 16 + 16 + 16 + 3 * 48      # ray/hit/thr/li/misc reads
+        + 32 + 16 + 16 + 16                        # ray/thr/li/misc writes
+        + 10 * 16 + 64                             # S-tree levels + leaf header
+        + (0.5 * 5 + 5) * 32                       # D-tree levels in sample (half the vertices) + pdf
+        + 4 * 16,                                  # speculative vertex record
+    )
+
+
+def run(args):
+    import numpy as np
+    import ppg_host
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if args.gpus > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl")
+        assert dist.get_world_size() == args.gpus, "launch with --nproc-per-node == --gpus"
+    import torch  # noqa: F811  (device sync + barrier plumbing only)
+
+    spp = args.spp
+    props = dict(budgetType="spp", sppPerPass=spp, maxDepth=10, rrDepth=10, strictNormals=1, seed=1234, device=local_rank)
+    scene = ppg_host.cbox_scene(args.width, args.height)
+
+    def make(budget_passes, timing=False):
+        e = ppg_host.Engine.hip(budget=float(budget_passes * spp), **props)
+        e.set_scene(scene)
+        if world > 1:
+            e.set_shard(rank, world, 32)
+        if timing:
+            e.enable_kernel_timing(True)
+        red = None
+        if world > 1:
+            from ppg_host.distributed import TorchReducer
+            red = TorchReducer(dist, torch.device("cuda", local_rank))
+        return ppg_host.GuidedPathTracer(engine=e, reducer=red)
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    if args.warmup > 0:
+        make(args.warmup).render()
+    gpt = make(args.steps)
+    sync()
+    t0 = time.perf_counter()
+    gpt.render()
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    samples = args.width * args.height * spp * args.steps
+    rays = sum(s["rays"] for it in gpt.iterations for s in it["stats"])
+    own_samples = sum(s["samples"] for it in gpt.iterations for s in it["stats"])
+    var_last = gpt.iterations[-1]["stats"][-1]["variance"]
+    out = {
+        "metric": "Msamples/s", "value": samples / dt / 1e6, "unit": "Msamples/s", "n_gpus": args.gpus, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "cbox-720p: procedural CBOX (36 tris), %dx%d, %d spp/pass, %d passes, default SD-tree params, "
+                               "maxDepth 10" % (args.width, args.height, spp, args.steps),
+                   "iterations": [it["passes"] for it in gpt.iterations], "parallelism": "tiles%d" % args.gpus,
+                   "rays_per_sample": rays / max(1, own_samples), "variance_last_iteration": var_last},
+    }
+
+    if rank == 0 and not args.no_roofline:
+        # separate instrumented render: per-kernel HIP-event durations on the kernels' stream
+        g2 = make(args.steps, timing=True)
+        g2.render()
+        times = g2.engine.kernel_times()
+        dom = max(times, key=lambda k: k["ms"])
+        per_ray = algorithmic_bytes_per_ray()
+        key = "trace" if dom["name"] == "k_trace" else "shade"
+        bytes_per_unit = per_ray.get(key, per_ray["shade"]) if dom["name"] in ("k_trace", "k_shade") else 4 * 64 + 200
+        avg_units = dom["units"] / max(1, dom["launches"])
+        avg_ms = dom["ms"] / max(1, dom["launches"])
+        achieved = bytes_per_unit * avg_units / (avg_ms * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": dom["name"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms, "launches": dom["launches"],
+                           "algorithmic_bytes_per_unit": bytes_per_unit, "avg_units_per_launch": avg_units,
+                           "kernels_ms": {k["name"]: round(k["ms"], 3) for k in times}}
+
+    if rank == 0 and args.gpus == 1 and not args.no_cpu:
+        # CPU baseline: the oracle (a port, not the reference binary) on the host cores, bounded sample:
+        # the same scene/resolution/settings, the first `cpu_passes` passes of the same schedule.
+        import ctypes
+        cores = os.cpu_count() or 1
+        lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "libppg_oracle.so"))
+        cp = args.cpu_passes
+        o = ppg_host.Engine(lib, "ppgo_", budget=float(cp * spp), **{k: v for k, v in props.items() if k != "device"})
+        lib.ppgo_set_modes(o.ctx, 0, 0, cores)
+        o.set_scene(scene)
+        t1 = time.perf_counter()
+        o.render()
+        dtc = time.perf_counter() - t1
+        out["cpu_baseline"] = {"value": args.width * args.height * spp * cp / dtc / 1e6, "unit": "Msamples/s", "cores": cores,
+                               "kind": "port", "sample": "first %d passes (%d spp) of the same render(), oracle restatement, OpenMP over 32x32 blocks"
+                               % (cp, cp * spp), "seconds": dtc}
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=255, help="render passes in the timed render() (budget = steps * spp)")
+    ap.add_argument("--warmup", type=int, default=3, help="passes of the throw-away warm-up render")
+    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--height", type=int, default=720)
+    ap.add_argument("--spp", type=int, default=4)
+    ap.add_argument("--cpu-passes", type=int, default=7, help="passes timed on the CPU baseline (bounded sample)")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    run(ap.parse_args())
+
+
+if __name__ == "__main__":
+    main()

@@ -223,7 +223,8 @@ int ppg_sdtree_stat_buffers(ppg_ctx *ctx, void **dev_sums, uint64_t *n_sums, voi
 int ppg_film_buffers(ppg_ctx *ctx, void **dev_rgb_sum /* float[h*w*3] */, void **dev_weight /* float[h*w] */);
 /* Device pointers to image / squared image of the current ppg_render_passes for the variance reduction:
    call between ppg_render_passes_nostat() and ppg_finish_passes() when sharded. */
-int ppg_image_buffers(ppg_ctx *ctx, void **dev_image /* float[h*w*3] */, void **dev_sq_image /* float[h*w*3] */);
+int ppg_image_buffers(ppg_ctx *ctx, void **dev_image /* float[h*w*3] */, void **dev_sq_image /* float[h*w*3] */,
+                      void **dev_weight /* float[h*w] */);
 int ppg_render_passes_nostat(ppg_ctx *ctx, int32_t n_passes); /* GP:1217-1286 only */
 int ppg_finish_passes(ppg_ctx *ctx, ppg_pass_stats *stats);   /* GP:1288-1328 only */
 

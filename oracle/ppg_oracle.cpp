@@ -1834,6 +1834,7 @@ int ppgo_film_ptrs(ppgo_ctx *ctx, float **rgb_sum, float **weight) {
     *rgb_sum = ctx->gpt.m_film.data(); *weight = ctx->gpt.m_filmW.data();
     return PPG_OK;
 }
+int ppgo_image_weight_ptr(ppgo_ctx *ctx, float **w) { *w = ctx->gpt.m_imageW.data(); return PPG_OK; }
 int ppgo_image_ptrs(ppgo_ctx *ctx, float **image, float **sq_image) {
     *image = ctx->gpt.m_image.data(); *sq_image = ctx->gpt.m_squaredImage.data();
     return PPG_OK;

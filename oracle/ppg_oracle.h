@@ -58,6 +58,7 @@ int ppgo_stat_import(ppgo_ctx *ctx, const uint64_t *sums, uint64_t n_sums, const
 int ppgo_stat_sizes(ppgo_ctx *ctx, uint64_t *n_sums, uint64_t *n_weights);
 int ppgo_film_ptrs(ppgo_ctx *ctx, float **rgb_sum, float **weight);
 int ppgo_image_ptrs(ppgo_ctx *ctx, float **image, float **sq_image);
+int ppgo_image_weight_ptr(ppgo_ctx *ctx, float **w);
 
 int ppgo_query_pdf(ppgo_ctx *ctx, uint32_t n, const float *positions, const float *dirs, float *pdf_out);
 int ppgo_query_sample(ppgo_ctx *ctx, uint32_t n, const float *positions, uint64_t seed, float *dirs_out);

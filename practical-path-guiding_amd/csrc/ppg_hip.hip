@@ -1064,10 +1064,10 @@ int ppg_film_buffers(ppg_ctx *ctx, void **dev_rgb_sum, void **dev_weight) {
     *dev_rgb_sum = ctx->d_film.p; *dev_weight = ctx->d_filmW.p;
     return PPG_OK;
 }
-int ppg_image_buffers(ppg_ctx *ctx, void **dev_image, void **dev_sq_image) {
+int ppg_image_buffers(ppg_ctx *ctx, void **dev_image, void **dev_sq_image, void **dev_weight) {
     NEED_TREE
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    *dev_image = ctx->d_image.p; *dev_sq_image = ctx->d_sq.p;
+    *dev_image = ctx->d_image.p; *dev_sq_image = ctx->d_sq.p; *dev_weight = ctx->d_imageW.p;
     return PPG_OK;
 }
 

@@ -8,3 +8,4 @@
 """
 from .bindings import Engine, PPGError, Config, PassStats, TreeStats, hip_library_path  # noqa: F401
 from .scenes import SceneDesc, cbox_scene, perspective_camera  # noqa: F401
+from .integrator import GuidedPathTracer  # noqa: F401,E402

@@ -315,9 +315,14 @@ class Engine:
         return a.value, b.value
 
     def image_buffers(self):
-        a, b = C.c_void_p(), C.c_void_p()
-        self._call("image_buffers", C.byref(a), C.byref(b))
+        a, b, w = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._call("image_buffers", C.byref(a), C.byref(b), C.byref(w))
+        self._image_w = w.value
         return a.value, b.value
+
+    def image_weight_buffer(self):
+        self.image_buffers()
+        return self._image_w
 
     def enable_kernel_timing(self, on=True):
         self._call("enable_kernel_timing", C.c_int32(int(on)))

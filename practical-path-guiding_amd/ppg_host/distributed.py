@@ -1,0 +1,107 @@
+"""Tile-sharded multi-GPU rendering: one process per GPU, RCCL over xGMI through torch.distributed.
+
+Pixels are independent inside an iteration (the sampling SD-tree is frozen; the building tree only
+accumulates — guided_path.cpp:610-613, 308, 332, 397), so every rank renders the 32x32 tiles t with
+t % world == rank for all passes and the only exchange per iteration is
+    all_reduce(SUM) of the building tree's fixed-point leaf sums   (uint64 as int64, exact, order independent)
+    all_reduce(SUM) of the per-D-tree statistical weights           (same)
+    all_reduce(SUM) of image / squared image of the iteration       (disjoint supports → exact)
+after which refine/reset/build are deterministic functions of identical data on every rank: the SD-tree
+topology stays bit-identical across ranks and equal to a single-GPU render.  torch is plumbing here
+(device-pointer views + the collective); all compute is in libppg_hip.so.
+
+`TorchReducer` works on device pointers (HIP engine, backend nccl = RCCL).
+`HostReducer` is the same exchange over host arrays (gloo) and exists for the CPU tests that drive the
+oracle through this exact control flow.
+"""
+import ctypes as C
+
+import numpy as np
+
+
+class _DevArray:
+    """Exposes a raw device pointer to torch through __cuda_array_interface__ (zero copy)."""
+
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 3}
+
+
+def _view(torch, ptr, n, typestr, device):
+    return torch.as_tensor(_DevArray(ptr, n, typestr), device=device)
+
+
+class TorchReducer:
+    def __init__(self, dist, device):
+        import torch
+        self.torch, self.dist, self.device = torch, dist, device
+
+    def reduce_sdtree(self, e):
+        (ps, ns), (pw, nw) = e.stat_buffers()
+        for ptr, n in ((ps, ns), (pw, nw)):
+            if n:
+                self.dist.all_reduce(_view(self.torch, ptr, n, "<i8", self.device))
+        self.torch.cuda.synchronize()
+
+    def reduce_images(self, e):
+        n = e.width * e.height
+        a, b = e.image_buffers()
+        for ptr in (a, b):
+            self.dist.all_reduce(_view(self.torch, ptr, 3 * n, "<f4", self.device))
+        w = e.image_weight_buffer()
+        self.dist.all_reduce(_view(self.torch, w, n, "<f4", self.device))
+        self.torch.cuda.synchronize()
+
+    def reduce_film(self, e, inverse_variance=False):
+        if inverse_variance:
+            return  # the retained iteration images were already reduced by reduce_images
+        n = e.width * e.height
+        a, w = e.film_buffers()
+        self.dist.all_reduce(_view(self.torch, a, 3 * n, "<f4", self.device))
+        self.dist.all_reduce(_view(self.torch, w, n, "<f4", self.device))
+        self.torch.cuda.synchronize()
+
+
+class HostReducer:
+    """Same exchange for an oracle engine (host memory, gloo)."""
+
+    def __init__(self, dist):
+        import torch
+        self.torch, self.dist = torch, dist
+
+    def _allreduce_np(self, arr):
+        t = self.torch.from_numpy(arr)
+        self.dist.all_reduce(t)
+        return arr
+
+    def reduce_sdtree(self, e):
+        ns, nw = C.c_uint64(), C.c_uint64()
+        e._call("stat_sizes", C.byref(ns), C.byref(nw))
+        sums = np.zeros(ns.value, np.int64)
+        wts = np.zeros(nw.value, np.int64)
+        u64 = C.POINTER(C.c_uint64)
+        e._call("stat_export", sums.ctypes.data_as(u64), ns, wts.ctypes.data_as(u64), nw)
+        self._allreduce_np(sums)
+        self._allreduce_np(wts)
+        e._call("stat_import", sums.ctypes.data_as(u64), ns, wts.ctypes.data_as(u64), nw)
+
+    def _ptr_arrays(self, e, fn, sizes):
+        a, b = C.POINTER(C.c_float)(), C.POINTER(C.c_float)()
+        e._call(fn, C.byref(a), C.byref(b))
+        return [np.ctypeslib.as_array(p, shape=(s,)) for p, s in zip((a, b), sizes)]
+
+    def reduce_images(self, e):
+        n = e.width * e.height
+        img, sq = self._ptr_arrays(e, "image_ptrs", (3 * n, 3 * n))
+        self._allreduce_np(img)
+        self._allreduce_np(sq)
+        w = C.POINTER(C.c_float)()
+        e._call("image_weight_ptr", C.byref(w))
+        self._allreduce_np(np.ctypeslib.as_array(w, shape=(n,)))
+
+    def reduce_film(self, e, inverse_variance=False):
+        if inverse_variance:
+            return
+        n = e.width * e.height
+        film, w = self._ptr_arrays(e, "film_ptrs", (3 * n, n))
+        self._allreduce_np(film)
+        self._allreduce_np(w)

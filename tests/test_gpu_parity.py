@@ -1,0 +1,316 @@
+"""GPU parity tests (run with -m gpu on an MI355X).  Everything goes through the C-ABI of libppg_hip.so.
+
+Bar: bit-exact against the CPU oracle — film pixels (per-pixel L2 = 0), SD-tree
+topology, fixed-point statistics, learned sampling fractions, ray / path-length / record counters —
+because both sides evaluate the same IEEE-754 expression sequence (include/ppg_detmath.h, no FMA
+contraction) on the same counter-based sampler, and all shared accumulation is integer.
+"""
+import ctypes as C
+import os
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from conftest import CBOX_PROPS, GOLDEN, IMPROVED, make_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def hip(**props):
+    import ppg_host
+    return ppg_host.Engine.hip(**props)
+
+
+def assert_tree_equal(a, b):
+    assert np.array_equal(a["children"], b["children"]) and np.array_equal(a["axis"], b["axis"])
+    for k in ("sampling", "building"):
+        assert np.array_equal(a[k]["num_nodes"], b[k]["num_nodes"]), k
+        assert np.array_equal(a[k]["node_children"], b[k]["node_children"]), k
+        assert np.array_equal(a[k]["node_fixed"], b[k]["node_fixed"]), k
+        assert np.array_equal(a[k]["node_sums"], b[k]["node_sums"]), k
+        assert np.array_equal(a[k]["max_depth"], b[k]["max_depth"]), k
+    assert np.array_equal(a["sampling"]["sum"], b["sampling"]["sum"])
+    assert np.array_equal(a["sampling"]["stat_weight"], b["sampling"]["stat_weight"])
+    assert np.array_equal(a["theta"], b["theta"])
+
+
+@pytest.mark.parametrize("case,extra", [("default", {}), ("improved", IMPROVED),
+                                        ("boxbox", dict(spatialFilter="box", directionalFilter="box", bsdfSamplingFractionLoss="var",
+                                                        sTreeThreshold=600, sampleCombination="discard"))])
+def test_against_committed_golden_vectors(case, extra):
+    import ppg_host
+    g = np.load(os.path.join(GOLDEN, "oracle_cbox_%s.npz" % case))
+    e = hip(budget=float(g["budget"]), seed=int(g["seed"]), **dict(CBOX_PROPS, **extra))
+    gpt = ppg_host.GuidedPathTracer(engine=e)
+    film = gpt.render(ppg_host.cbox_scene(int(g["res"]), int(g["res"])))
+    assert np.array_equal(film, g["film"]), np.abs(film - g["film"]).max()
+    t = e.read_sdtree()
+    assert np.array_equal(t["children"], g["stree_children"]) and np.array_equal(t["axis"], g["stree_axis"])
+    assert np.array_equal(t["sampling"]["node_children"], g["dtree_children"])
+    assert np.array_equal(t["sampling"]["node_sums"], g["dtree_sums"])
+    assert np.array_equal(t["sampling"]["num_nodes"], g["dtree_num"]) and np.array_equal(t["theta"], g["theta"])
+    stats = np.array([[s["rays"], s["path_length_sum"], s["vertices_committed"]] for it in gpt.iterations for s in it["stats"]], np.uint64)
+    assert np.array_equal(stats, g["stats"])
+    var = np.array([s["variance"] for it in gpt.iterations for s in it["stats"]], np.float32)
+    assert np.array_equal(var, g["variance"], equal_nan=True)
+    assert [it["passes"] for it in gpt.iterations] == list(g["passes"])
+
+
+@pytest.mark.parametrize("res,budget,extra", [((160, 90), 60, {}), ((96, 96), 31, IMPROVED), ((64, 64), 124, dict(maxDepth=-1, rrDepth=5, strictNormals=0)),
+                                              ((64, 40), 28, dict(maxDepth=2)), ((48, 48), 40, dict(sppPerPass=8, dTreeThreshold=0.002, sTreeThreshold=300))])
+def test_stepwise_against_live_oracle(oracle_lib, res, budget, extra):
+    """Every phase of every iteration compared: reset topology, accumulated statistics, built trees, film."""
+    import ppg_host
+    props = dict(CBOX_PROPS, budget=budget, seed=99, **extra)
+    scene = ppg_host.cbox_scene(*res)
+    g, o = hip(**props), make_oracle(oracle_lib, threads=os.cpu_count() or 8, **props)
+    g.set_scene(scene); o.set_scene(scene)
+    g.begin_render(); o.begin_render()
+    spp = props.get("sppPerPass", 4)
+    passes, it, done = int(np.ceil(budget / spp)), 0, 0
+    while done < passes:
+        p = min(passes - done, 1 << it)
+        if passes - done - p < 2 * p:
+            p = passes - done
+        final = p >= passes - done
+        g.begin_iteration(final); o.begin_iteration(final)
+        a, b = g.read_sdtree(), o.read_sdtree()
+        assert np.array_equal(a["children"], b["children"]) and np.array_equal(a["building"]["node_children"], b["building"]["node_children"])
+        sg, so = g.render_passes(p), o.render_passes(p)
+        for f in ("samples", "rays", "path_length_sum", "vertices_committed", "passes_rendered_total"):
+            assert getattr(sg, f) == getattr(so, f), f
+        assert sg.variance == so.variance or (np.isnan(sg.variance) and np.isnan(so.variance)) or (np.isinf(sg.variance) and np.isinf(so.variance))
+        a, b = g.read_sdtree(), o.read_sdtree()
+        assert np.array_equal(a["building"]["node_fixed"], b["building"]["node_fixed"])
+        tg, to = g.build_sdtree(), o.build_sdtree()
+        assert tg.as_dict() == to.as_dict()
+        g.end_iteration(); o.end_iteration()
+        assert_tree_equal(g.read_sdtree(), o.read_sdtree())
+        assert np.array_equal(g.read_film(), o.read_film())
+        assert np.array_equal(g.read_variance(), o.read_variance(), equal_nan=True)
+        done += p; it += 1
+    g.end_render(); o.end_render()
+    assert np.array_equal(g.read_film(), o.read_film())
+
+
+def test_full_size_720p_against_oracle(oracle_lib):
+    """BASELINE.json configs[1] at its real size (1280x720, 4 spp/pass), first three iterations."""
+    import ppg_host
+    props = dict(CBOX_PROPS, budget=28, seed=1234)
+    scene = ppg_host.cbox_scene(1280, 720)
+    g, o = hip(**props), make_oracle(oracle_lib, threads=os.cpu_count() or 8, **props)
+    ig = ppg_host.GuidedPathTracer(engine=g).render(scene)
+    io = ppg_host.GuidedPathTracer(engine=o).render(scene)
+    assert np.array_equal(ig, io)
+    assert_tree_equal(g.read_sdtree(), o.read_sdtree())
+
+
+def test_full_size_invariants():
+    """Size-independent properties at 1280x720 that need no oracle: run-to-run determinism, the statistical-weight
+    checksum (Σ leaf weights == records committed, nearest filters, weight 1), interior sums == Σ children,
+    guiding pdfs integrate to one."""
+    import ppg_host
+    scene = ppg_host.cbox_scene(1280, 720)
+    runs = []
+    for _ in range(2):
+        e = hip(budget=60, seed=5, **CBOX_PROPS)
+        e.set_scene(scene); e.begin_render()
+        for it, p in enumerate([1, 2, 4]):
+            e.begin_iteration(False)
+            st = e.render_passes(p)
+            t = e.read_sdtree()
+            leaf = t["children"][:, 0] == 0
+            assert int(round(t["building"]["stat_weight"][leaf].sum())) == st.vertices_committed
+            assert st.samples == 1280 * 720 * 4 * p and st.rays == st.path_length_sum
+            e.build_sdtree(); e.end_iteration()
+        runs.append((e.read_film(), e.read_sdtree()))
+        t = runs[-1][1]["sampling"]
+        off = 0
+        for n in t["num_nodes"][runs[-1][1]["children"][:, 0] == 0][:200]:
+            sums, ch = t["node_sums"][off:off + n], t["node_children"][off:off + n]
+            for k in range(n):
+                for j in range(4):
+                    if ch[k, j]:
+                        assert abs(sums[k, j] - sums[ch[k, j]].sum()) <= 2e-6 * max(1.0, sums[k, j])
+            off += n
+    assert np.array_equal(runs[0][0], runs[1][0])
+    assert_tree_equal(runs[0][1], runs[1][1])
+    # pdf over the sphere integrates to 1 in every populated leaf we probe
+    e = hip(budget=60, seed=5, **CBOX_PROPS)
+    img = ppg_host.GuidedPathTracer(engine=e).render(scene)
+    assert np.array_equal(img[..., :], img) and img.mean() > 0.05
+    rng = np.random.RandomState(0)
+    pos = np.array([[278, 5, 280], [5, 270, 280], [278, 540, 280]], np.float32)
+    u = rng.rand(200000, 2)
+    z = 2 * u[:, 0] - 1; phi = 2 * np.pi * u[:, 1]; r = np.sqrt(1 - z * z)
+    dirs = np.stack([r * np.cos(phi), r * np.sin(phi), z], -1).astype(np.float32)
+    for p in pos:
+        pdf = e.query_pdf(np.repeat(p[None], len(dirs), 0), dirs)
+        assert abs(pdf.mean() * 4 * np.pi - 1) < 0.02
+
+
+def test_cpp_render_loop_equals_python_driver():
+    import ppg_host
+    scene = ppg_host.cbox_scene(80, 60)
+    for extra in ({}, IMPROVED):
+        props = dict(CBOX_PROPS, budget=60, seed=3, **extra)
+        a = hip(**props); a.set_scene(scene); a.render()
+        b = hip(**props)
+        img = ppg_host.GuidedPathTracer(engine=b).render(scene)
+        assert np.array_equal(a.read_film(), img)
+        assert_tree_equal(a.read_sdtree(), b.read_sdtree())
+
+
+def test_queries_match_oracle(oracle_lib):
+    import ppg_host
+    props = dict(CBOX_PROPS, budget=60, seed=21)
+    scene = ppg_host.cbox_scene(64, 64)
+    g, o = hip(**props), make_oracle(oracle_lib, **props)
+    for e in (g, o):
+        e.set_scene(scene); e.render()
+    rng = np.random.RandomState(4)
+    pos = (rng.rand(5000, 3) * [550, 540, 550]).astype(np.float32)
+    d = rng.randn(5000, 3); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    assert np.array_equal(g.query_pdf(pos, d.astype(np.float32)), o.query_pdf(pos, d.astype(np.float32)))
+    sg, so = g.query_sample(pos, 77), o.query_sample(pos, 77)
+    assert np.array_equal(sg, so) and np.allclose(np.linalg.norm(sg, axis=1), 1, atol=1e-5)
+
+
+def test_large_scene_bvh_against_oracle(oracle_lib):
+    """~50k triangles: the product's SAH BVH and the oracle's own median-split BVH must agree on every closest hit."""
+    import ppg_host
+    scene = ppg_host.room_scene(160, 90, n_boxes=260, tess=4)
+    assert scene.n_triangles > 45000
+    props = dict(budgetType="spp", budget=28, maxDepth=8, rrDepth=5, seed=8, sTreeThreshold=2000)
+    g, o = hip(**props), make_oracle(oracle_lib, threads=os.cpu_count() or 8, **props)
+    ig = ppg_host.GuidedPathTracer(engine=g).render(scene)
+    io = ppg_host.GuidedPathTracer(engine=o).render(scene)
+    assert ig.mean() > 1e-3
+    assert np.array_equal(ig, io)
+    assert_tree_equal(g.read_sdtree(), o.read_sdtree())
+
+
+def test_edge_cases(oracle_lib):
+    import ppg_host
+    # 1x1 film; 1 spp and a single pass (N - 1 = 0 → non-finite variance like the reference's "-1.#INF"); maxDepth = 1
+    for res, props in (((1, 1), dict(budget=12)), ((33, 17), dict(budget=1, sppPerPass=1)), ((16, 16), dict(budget=8, maxDepth=1))):
+        p = dict(CBOX_PROPS, seed=2, **props)
+        g, o = hip(**p), make_oracle(oracle_lib, **p)
+        scene = ppg_host.cbox_scene(*res)
+        ig = ppg_host.GuidedPathTracer(engine=g).render(scene)
+        io = ppg_host.GuidedPathTracer(engine=o).render(scene)
+        assert np.array_equal(ig, io)
+    # every ray misses: empty image, untouched SD-tree
+    scene = ppg_host.cbox_scene(32, 32)
+    scene.camera = ppg_host.perspective_camera((278, 273, -800), (278, 273, -2000), (0, 1, 0), 39.3, "x", 10, 2800, 32, 32)
+    g = hip(budget=8, seed=1, **CBOX_PROPS)
+    img = ppg_host.GuidedPathTracer(engine=g).render(scene)
+    assert img.max() == 0 and g.read_sdtree()["n_leaves"] == 1
+    # vertex normals present (shading frame from interpolated normals, skdtree.h:388-401)
+    scene = ppg_host.cbox_scene(40, 40)
+    idx = scene.indices.reshape(-1)
+    fn = np.cross(scene.positions[scene.indices[:, 1]] - scene.positions[scene.indices[:, 0]], scene.positions[scene.indices[:, 2]] - scene.positions[scene.indices[:, 0]])
+    fn /= np.linalg.norm(fn, axis=1, keepdims=True)
+    nrm = np.zeros_like(scene.positions)
+    nrm[idx] = np.repeat(fn, 3, 0) + 0.05 * np.random.RandomState(0).randn(len(idx), 3)
+    scene.normals = (nrm / np.linalg.norm(nrm, axis=1, keepdims=True)).astype(np.float32)
+    p = dict(CBOX_PROPS, budget=28, seed=6)
+    g, o = hip(**p), make_oracle(oracle_lib, **p)
+    assert np.array_equal(ppg_host.GuidedPathTracer(engine=g).render(scene), ppg_host.GuidedPathTracer(engine=o).render(scene))
+    # errors: calls out of order, unsupported property value
+    e = hip(budget=4, **CBOX_PROPS)
+    with pytest.raises(ppg_host.PPGError) as ei:
+        e.render()
+    assert ei.value.code == -3
+    with pytest.raises(ppg_host.PPGError):
+        hip(nee="always")
+
+
+def test_sharded_contexts_on_one_gpu_equal_unsharded():
+    """Two contexts render rank 0 / rank 1 of a 2-way tile shard on the same GPU; the exchange the RCCL driver
+    performs (int64 sums of the building statistics, float sums of disjoint image tiles) is done by hand."""
+    import ppg_host
+    import torch
+    from ppg_host.distributed import _view
+    dev = torch.device("cuda", 0)
+    scene = ppg_host.cbox_scene(96, 64)
+    props = dict(CBOX_PROPS, budget=60, seed=31)
+    ref = hip(**props)
+    ref_img = ppg_host.GuidedPathTracer(engine=ref).render(scene)
+
+    class PairReducer:  # all-reduce over the two local contexts
+        def __init__(self, engines):
+            self.engines = engines
+            self.pending = {}
+
+        def _sum(self, key, views):
+            total = views[0].clone()
+            for v in views[1:]:
+                total += v
+            for v in views:
+                v.copy_(total)
+            torch.cuda.synchronize()
+
+        def reduce_sdtree(self):
+            bufs = [e.stat_buffers() for e in self.engines]
+            for k in range(2):
+                if bufs[0][k][1]:
+                    self._sum(k, [_view(torch, b[k][0], b[k][1], "<i8", dev) for b in bufs])
+
+        def reduce_images(self):
+            n = 96 * 64
+            for sel in (0, 1):
+                self._sum(sel, [_view(torch, e.image_buffers()[sel], 3 * n, "<f4", dev) for e in self.engines])
+            self._sum(2, [_view(torch, e.image_weight_buffer(), n, "<f4", dev) for e in self.engines])
+
+        def reduce_film(self):
+            n = 96 * 64
+            self._sum(0, [_view(torch, e.film_buffers()[0], 3 * n, "<f4", dev) for e in self.engines])
+            self._sum(1, [_view(torch, e.film_buffers()[1], n, "<f4", dev) for e in self.engines])
+
+    engines = [hip(**props) for _ in range(2)]
+    for r, e in enumerate(engines):
+        e.set_scene(scene); e.set_shard(r, 2, 16); e.begin_render()
+    red = PairReducer(engines)
+    for it, p in enumerate([1, 2, 4, 8]):
+        final = it == 3
+        for e in engines:
+            e.begin_iteration(final)
+        for e in engines:
+            e.render_passes_nostat(p)
+        red.reduce_images()
+        stats = [e.finish_passes() for e in engines]
+        assert stats[0].variance == stats[1].variance
+        if not final:
+            red.reduce_sdtree()
+        for e in engines:
+            e.build_sdtree(); e.end_iteration()
+    red.reduce_film()
+    for e in engines:
+        e.end_render()
+        assert np.array_equal(e.read_film(), ref_img)
+        assert_tree_equal(e.read_sdtree(), ref.read_sdtree())
+
+
+def test_cancel_from_another_thread():
+    import ppg_host
+    e = hip(budgetType="spp", budget=40000, maxDepth=10, rrDepth=10, strictNormals=1)
+    e.set_scene(ppg_host.cbox_scene(640, 360))
+    threading.Timer(0.3, e.cancel).start()
+    t0 = time.time()
+    with pytest.raises(ppg_host.PPGError) as ei:
+        e.render()
+    assert ei.value.code == -4 and time.time() - t0 < 30  # render() returns false when cancelled (GP:1584, 1643-1648)
+
+
+def test_sdt_dump_equals_oracle_bytes(oracle_lib, tmp_path):
+    import ppg_host
+    props = dict(CBOX_PROPS, budget=28, seed=12)
+    scene = ppg_host.cbox_scene(48, 48)
+    g, o = hip(**props), make_oracle(oracle_lib, **props)
+    for e in (g, o):
+        e.set_scene(scene); e.render()
+    g.dump_sdtree(str(tmp_path / "g.sdt")); o.dump_sdtree(str(tmp_path / "o.sdt"))
+    assert open(tmp_path / "g.sdt", "rb").read() == open(tmp_path / "o.sdt", "rb").read()

@@ -1,0 +1,142 @@
+"""Host logic on CPU: the Python mirror of render() equals the single-call render(), oracle determinism
+across thread counts (fixed-point accumulation), sharded rendering over gloo equals single-rank rendering,
+.sdt dump format, and the committed golden vectors still match the oracle."""
+import os
+import struct
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import CBOX_PROPS, GOLDEN, IMPROVED, ROOT, make_oracle
+
+
+def _tree_equal(a, b):
+    if not (np.array_equal(a["children"], b["children"]) and np.array_equal(a["axis"], b["axis"])):
+        return False
+    for k in ("sampling", "building"):
+        for f in ("num_nodes", "node_children", "node_sums", "max_depth"):
+            if not np.array_equal(a[k][f], b[k][f]):
+                return False
+    return np.array_equal(a["theta"], b["theta"])
+
+
+def test_python_driver_equals_single_call_render(oracle_lib):
+    import ppg_host
+    scene = ppg_host.cbox_scene(48, 48)
+    for extra in (dict(), IMPROVED):
+        props = dict(CBOX_PROPS, budget=60, seed=9, **extra)
+        a = make_oracle(oracle_lib, **props); a.set_scene(scene); a.render(); img_a = a.read_film()
+        b = make_oracle(oracle_lib, **props)
+        img_b = ppg_host.GuidedPathTracer(engine=b).render(scene)
+        assert np.array_equal(img_a, img_b)
+        assert _tree_equal(a.read_sdtree(), b.read_sdtree())
+
+
+def test_fixed_point_accumulation_is_thread_count_invariant(oracle_lib):
+    import ppg_host
+    scene = ppg_host.cbox_scene(40, 40)
+    outs = []
+    for threads in (1, 7):
+        e = make_oracle(oracle_lib, threads=threads, budget=60, seed=3, **dict(CBOX_PROPS, **IMPROVED))
+        e.set_scene(scene); e.render()
+        outs.append((e.read_film(), e.read_sdtree()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and _tree_equal(outs[0][1], outs[1][1])
+
+
+def test_float_accumulation_mode_is_statistically_the_same(oracle_lib):
+    # acc_mode FLOAT = the reference's sequential float adds (GP:59-62); FIXED must not change the estimate
+    import ppg_host
+    scene = ppg_host.cbox_scene(48, 48)
+    imgs = []
+    for acc in (0, 1):
+        e = make_oracle(oracle_lib, threads=1, acc=acc, budget=28, seed=5, **CBOX_PROPS)
+        e.set_scene(scene); e.begin_render()
+        e.begin_iteration(False); e.render_passes(1); t = e.build_sdtree(); e.end_iteration()
+        imgs.append((e.read_film(), t.avg_stat_weight, t.avg_mean_radiance))
+    assert np.array_equal(imgs[0][0], imgs[1][0])  # iteration 0 does not depend on the SD-tree
+    assert imgs[0][1] == imgs[1][1] and abs(imgs[0][2] / imgs[1][2] - 1) < 1e-4
+
+
+def test_sdt_dump_format(oracle_lib, tmp_path):
+    # byte layout of guided_path.cpp:1197-1205 + 699-711, as read by visualizer/src/main.cpp:142-176
+    import ppg_host
+    e = make_oracle(oracle_lib, budget=12, seed=1, **CBOX_PROPS)
+    e.set_scene(ppg_host.cbox_scene(32, 32)); e.render()
+    path = str(tmp_path / "t.sdt")
+    e.dump_sdtree(path)
+    buf = open(path, "rb").read()
+    cam = struct.unpack_from("<16f", buf, 0)
+    assert abs(cam[3] - 278) < 1e-3 and abs(cam[11] + 800) < 1e-3  # camera-to-world translation column
+    off, trees = 64, 0
+    tree = e.read_sdtree()
+    while off < len(buf):
+        px, py, pz, sx, sy, sz, mean = struct.unpack_from("<7f", buf, off); off += 28
+        sw, nn = struct.unpack_from("<QQ", buf, off); off += 16
+        assert sx > 0 and sw > 0 and 1 <= nn <= 65536 and mean >= 0
+        for _ in range(nn * 4):
+            s, c = struct.unpack_from("<fH", buf, off); off += 6
+            assert s >= 0 and c < nn
+        trees += 1
+    assert off == len(buf) and trees == int((tree["sampling"]["stat_weight"] > 0).sum())
+
+
+def test_golden_vectors_match_oracle(oracle_lib):
+    # tests/golden/oracle_cbox_*.npz were written by tools/make_oracle_golden.py; the GPU tests compare against the same files
+    import ppg_host
+    g = np.load(os.path.join(GOLDEN, "oracle_cbox_default.npz"))
+    e = make_oracle(oracle_lib, budget=float(g["budget"]), seed=int(g["seed"]), **CBOX_PROPS)
+    e.set_scene(ppg_host.cbox_scene(int(g["res"]), int(g["res"]))); e.render()
+    assert np.array_equal(e.read_film(), g["film"])
+    t = e.read_sdtree()
+    assert np.array_equal(t["children"], g["stree_children"]) and np.array_equal(t["sampling"]["node_children"], g["dtree_children"])
+    assert np.array_equal(t["sampling"]["node_sums"], g["dtree_sums"])
+
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "..", "tests"))
+import ctypes, numpy as np, torch.distributed as dist
+import ppg_host
+from ppg_host.distributed import HostReducer
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+lib = ctypes.CDLL(sys.argv[2])
+props = dict(budgetType="spp", maxDepth=10, rrDepth=10, strictNormals=1, budget=60, seed=17)
+if sys.argv[4] == "inversevar":
+    props.update(sampleCombination="inversevar", spatialFilter="stochastic", directionalFilter="box", sTreeThreshold=2000)
+e = ppg_host.Engine(lib, "ppgo_", **props)
+lib.ppgo_set_modes(e.ctx, 0, 0, 2)
+scene = ppg_host.cbox_scene(64, 48)
+e.set_scene(scene); e.set_shard(rank, world, 16)
+img = ppg_host.GuidedPathTracer(engine=e, reducer=HostReducer(dist)).render()
+t = e.read_sdtree()
+np.savez(os.path.join(sys.argv[3], "rank%d.npz" % rank), film=img, children=t["children"], dch=t["sampling"]["node_children"], dsum=t["sampling"]["node_sums"])
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("mode", ["default", "inversevar"])
+def test_sharded_render_over_gloo_equals_single_rank(oracle_lib, tmp_path, mode):
+    """world_size 2, gloo: tiles sharded, SD-tree statistics all-reduced as int64 → the merged render is
+    bit-identical to the unsharded one on every rank."""
+    import ppg_host
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + os.getpid() % 2000), OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", env["MASTER_PORT"], str(script), os.path.join(ROOT, "practical-path-guiding_amd"),
+           os.path.join(ROOT, "oracle", "libppg_oracle.so"), str(tmp_path), mode]
+    subprocess.run(cmd, check=True, env=env, timeout=600, capture_output=True)
+    props = dict(CBOX_PROPS, budget=60, seed=17)
+    if mode == "inversevar":
+        props.update(sampleCombination="inversevar", spatialFilter="stochastic", directionalFilter="box", sTreeThreshold=2000)
+    e = make_oracle(oracle_lib, threads=4, **props)
+    e.set_scene(ppg_host.cbox_scene(64, 48)); e.render()
+    ref_img, ref_t = e.read_film(), e.read_sdtree()
+    for r in range(2):
+        got = np.load(tmp_path / ("rank%d.npz" % r))
+        assert np.array_equal(got["children"], ref_t["children"])
+        assert np.array_equal(got["dch"], ref_t["sampling"]["node_children"]) and np.array_equal(got["dsum"], ref_t["sampling"]["node_sums"])
+        assert np.array_equal(got["film"], ref_img)

@@ -1,0 +1,103 @@
+"""Pin (1) of the oracle: the known answers of SURVEY.md §8(c) / Appendix A (obtained there by compiling
+guided_path.cpp:33-1007) and the algebraic identities of Appendix A."""
+import ctypes as C
+
+import numpy as np
+
+
+def test_fresh_reset_is_depth4_85_nodes(oracle_lib):
+    # every reference log: "Depth = [4, 4, 4] ... Node count = [85, 85, 85]" at iteration 0 (GP:456-514, rho = 0.01)
+    nn, d, pdf = C.c_uint32(), C.c_int32(), C.c_float()
+    assert oracle_lib.ppgo_ka_fresh_reset(C.c_float(0.01), C.byref(nn), C.byref(d), C.byref(pdf)) == 0
+    assert (nn.value, d.value) == (85, 4)
+    assert abs(pdf.value - 0.0795775) < 1e-7  # 1 / (4 pi): no data yet (GP:415-418)
+
+
+def test_refine_known_answer(oracle_lib):
+    # refine(W = 4 349 763, thr = 16 970) -> 512 leaves (GP:957-998)
+    nl, nn = C.c_uint32(), C.c_uint32()
+    assert oracle_lib.ppgo_ka_refine(C.c_float(4349763), C.c_uint64(16970), C.byref(nl), C.byref(nn)) == 0
+    assert (nl.value, nn.value) == (512, 1023)
+    oracle_lib.ppgo_ka_refine(C.c_float(16970), C.c_uint64(16970), C.byref(nl), C.byref(nn))
+    assert nl.value == 1  # split only if weight > threshold (GP:953-955)
+    oracle_lib.ppgo_ka_refine(C.c_float(16971), C.c_uint64(16970), C.byref(nl), C.byref(nn))
+    assert nl.value == 2
+
+
+def test_adam_known_answer(oracle_lib):
+    # 10 identical KL records -> fraction 0.512494385 (GP:672-697, 85-109).
+    # ppg_detmath's exp/powi differ from libm by <= 1 ulp, hence the 2e-7 tolerance.
+    fr = C.c_float()
+    oracle_lib.ppgo_ka_adam(10, C.c_float(.5), C.c_float(.2), C.c_float(.3), C.c_float(.1), C.c_float(1), 1, C.byref(fr))
+    assert abs(fr.value - 0.512494385) < 2e-7
+    oracle_lib.ppgo_ka_adam(1, C.c_float(.5), C.c_float(.2), C.c_float(.3), C.c_float(.1), C.c_float(1), 1, C.byref(fr))
+    assert fr.value == 0.5  # batchAccumulation 1 > batchSize 1 is false: no step yet (GP:89)
+
+
+def test_canonical_direction_maps(oracle_lib):
+    oracle_lib.ppgo_canonical_to_dir.restype = None
+    oracle_lib.ppgo_dir_to_canonical.restype = None
+    rng = np.random.RandomState(3)
+    for _ in range(2000):
+        x, y = rng.rand(2).astype(np.float32)
+        d = (C.c_float * 3)()
+        oracle_lib.ppgo_canonical_to_dir(C.c_float(x), C.c_float(y), d)
+        dd = np.array(d[:])
+        assert abs(np.linalg.norm(dd) - 1) < 1e-6 and abs(dd[2] - (2 * x - 1)) < 1e-6  # GP:586-595
+        xy = (C.c_float * 2)()
+        oracle_lib.ppgo_dir_to_canonical(d, xy)
+        assert abs(xy[0] - x) < 1e-6 and min(abs(xy[1] - y), 1 - abs(xy[1] - y)) < 2e-5 / max(1e-3, np.sqrt(1 - dd[2] ** 2))
+    bad = (C.c_float * 3)(float("nan"), 0, 0)
+    xy = (C.c_float * 2)()
+    oracle_lib.ppgo_dir_to_canonical(bad, xy)
+    assert (xy[0], xy[1]) == (0.0, 0.0)  # GP:598-600
+
+
+def _exercise(lib, acc, dfilter, xy, irr, w, q, seed=5, rho=0.01):
+    n, m = len(irr), len(q)
+    fp = C.POINTER(C.c_float)
+    xy = np.ascontiguousarray(xy, np.float32); irr = np.ascontiguousarray(irr, np.float32)
+    w = np.ascontiguousarray(w, np.float32); q = np.ascontiguousarray(q, np.float32)
+    pdf = np.zeros(m, np.float32); smp = np.zeros((m, 2), np.float32)
+    nn = C.c_uint32(); sums = np.zeros((65536, 4), np.float32); ch = np.zeros((65536, 4), np.uint16)
+    sw, ts = C.c_float(), C.c_float()
+    rc = lib.ppgo_dtree_exercise(acc, dfilter, C.c_float(rho), n, xy.ctypes.data_as(fp), irr.ctypes.data_as(fp), w.ctypes.data_as(fp), m,
+                                 q.ctypes.data_as(fp), C.c_uint64(seed), pdf.ctypes.data_as(fp), smp.ctypes.data_as(fp), C.byref(nn),
+                                 sums.ctypes.data_as(fp), ch.ctypes.data_as(C.POINTER(C.c_uint16)), C.byref(sw), C.byref(ts))
+    assert rc == 0
+    return dict(pdf=pdf, samples=smp, n=nn.value, sums=sums[:nn.value], children=ch[:nn.value], statw=sw.value, total=ts.value)
+
+
+def test_dtree_pdf_integrates_to_one_and_matches_samples(oracle_lib):
+    rng = np.random.RandomState(11)
+    # a peaked distribution: most energy near (0.7, 0.2)
+    xy = np.clip(np.concatenate([rng.normal([0.7, 0.2], 0.03, (6000, 2)), rng.rand(2000, 2)]), 0, 0.999999)
+    irr = rng.uniform(0.5, 1.5, len(xy)); w = np.ones(len(xy))
+    g = (np.stack(np.meshgrid(np.arange(256), np.arange(256)), -1).reshape(-1, 2) + 0.5) / 256
+    for acc in (0, 1):  # fixed point and the reference's float accumulation agree to rounding
+        r = _exercise(oracle_lib, acc, 0, xy, irr, w, g)
+        assert 40 <= r["n"] <= 400 and r["statw"] == len(xy)
+        assert abs(r["pdf"].mean() * 4 * np.pi - 1.0) < 1e-3  # pdf over the sphere integrates to 1 (GP:232-245, 420)
+        s = r["samples"]
+        frac_in_peak = ((np.abs(s[:, 0] - 0.7) < 0.1) & (np.abs(s[:, 1] - 0.2) < 0.1)).mean()
+        assert frac_in_peak > 0.6  # samples follow the recorded energy (GP:257-301)
+        # interior sums equal the sum of their children (build, GP:346-366)
+        for k in range(r["n"]):
+            for j in range(4):
+                c = r["children"][k, j]
+                if c:
+                    assert abs(r["sums"][k, j] - r["sums"][c].sum()) <= 1e-5 * max(1.0, r["sums"][k, j])
+    a, b = _exercise(oracle_lib, 0, 0, xy, irr, w, g), _exercise(oracle_lib, 1, 0, xy, irr, w, g)
+    assert a["n"] == b["n"] and np.array_equal(a["children"], b["children"])  # same topology either way
+    assert np.allclose(a["sums"], b["sums"], rtol=2e-4, atol=1e-4)
+
+
+def test_dtree_box_filter_conserves_interior_energy(oracle_lib):
+    rng = np.random.RandomState(2)
+    xy = rng.uniform(0.3, 0.7, (3000, 2))  # far from the border: the box splat loses nothing (GP:403-409)
+    irr = rng.uniform(0.5, 1.5, len(xy)); w = np.ones(len(xy))
+    q = rng.rand(10, 2)
+    near, box = _exercise(oracle_lib, 0, 0, xy, irr, w, q), _exercise(oracle_lib, 0, 1, xy, irr, w, q)
+    assert abs(box["total"] - near["total"]) < 2e-3 * near["total"]
+    edge = _exercise(oracle_lib, 0, 1, np.full((100, 2), 0.001), np.ones(100), np.ones(100), q)
+    assert 20 < edge["total"] < 75  # energy outside [0,1]^2 is lost, as in the reference
