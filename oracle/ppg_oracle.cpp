@@ -1769,7 +1769,7 @@ int ppgo_sdtree_read_dtree_headers(ppgo_ctx *ctx, int32_t which, uint64_t *offse
         if (!nodes[i].isLeaf) { offset[i] = 0; num_nodes[i] = 0; max_depth[i] = 0; sum[i] = 0; stat_weight[i] = 0; continue; }
         const DTree &t = which == 0 ? nodes[i].dTree.sampling : nodes[i].dTree.building;
         offset[i] = off; num_nodes[i] = (uint32_t)t.numNodes(); max_depth[i] = t.depth(); sum[i] = t.sumValue();
-        if (which == 1 && ctx->gpt.modes.acc == PPGO_ACC_FIXED && t.statAcc() != 0) stat_weight[i] = (double)t.statAcc() / 16777216.0;
+        if (which == 1 && ctx->gpt.modes.acc == PPGO_ACC_FIXED) stat_weight[i] = (double)t.statAcc() / 16777216.0;
         else stat_weight[i] = t.statisticalWeight();
         off += t.numNodes();
     }

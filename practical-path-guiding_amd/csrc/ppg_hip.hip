@@ -1023,8 +1023,8 @@ int ppg_sdtree_read_dtree_headers(ppg_ctx *ctx, int32_t which, uint64_t *offset,
         offset[i] = off;
         if (which == 0) { num_nodes[i] = h.s_num; max_depth[i] = h.s_depth; sum[i] = h.s_sum; stat_weight[i] = h.s_statw; off += h.s_num; }
         else {
-            num_nodes[i] = h.b_num; max_depth[i] = h.b_depth; sum[i] = which == 1 ? 0.0f : 0.0f;
-            stat_weight[i] = bw[i] ? (double)bw[i] / 16777216.0 : (double)h.b_statw;
+            num_nodes[i] = h.b_num; max_depth[i] = h.b_depth; sum[i] = 0.0f;
+            stat_weight[i] = (double)bw[i] / 16777216.0;  // the accumulator of the current iteration
             off += h.b_num;
         }
     }

@@ -139,6 +139,8 @@ class Engine:
 
     @classmethod
     def hip(cls, **props):
+        # If the process is going to use torch.distributed (RCCL) it must import torch *before* this call:
+        # torch ships its own HIP runtime and only one runtime per process can own the GPUs.
         return cls(hip_library_path(), "ppg_", **props)
 
     def _f(self, name):

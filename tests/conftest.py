@@ -5,6 +5,11 @@ import sys
 
 import pytest
 
+try:  # torch bundles its own HIP runtime: it must be loaded before libppg_hip.so pulls in /opt/rocm's, or torch.cuda sees no GPU
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "practical-path-guiding_amd")
 for p in (PKG, ROOT):

@@ -28,9 +28,9 @@ def assert_tree_equal(a, b):
     for k in ("sampling", "building"):
         assert np.array_equal(a[k]["num_nodes"], b[k]["num_nodes"]), k
         assert np.array_equal(a[k]["node_children"], b[k]["node_children"]), k
-        assert np.array_equal(a[k]["node_fixed"], b[k]["node_fixed"]), k
-        assert np.array_equal(a[k]["node_sums"], b[k]["node_sums"]), k
         assert np.array_equal(a[k]["max_depth"], b[k]["max_depth"]), k
+    assert np.array_equal(a["building"]["node_fixed"], b["building"]["node_fixed"])  # raw 2^-24 fixed-point accumulators
+    assert np.array_equal(a["sampling"]["node_sums"], b["sampling"]["node_sums"])    # built float sums incl. interior nodes
     assert np.array_equal(a["sampling"]["sum"], b["sampling"]["sum"])
     assert np.array_equal(a["sampling"]["stat_weight"], b["sampling"]["stat_weight"])
     assert np.array_equal(a["theta"], b["theta"])
