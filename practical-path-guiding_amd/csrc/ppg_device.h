@@ -112,8 +112,16 @@ D bool box_hit(const float *lo, const float *hi, F3 o, F3 id, float t0, float t1
     return n <= f;
 }
 
+// Scene cache in LDS: the first `n_nodes` BVH nodes and (if they all fit) the triangles.  Small scenes such
+// as CBOX live there entirely; for large ones the top of the tree, which every ray visits, does.
+struct LdsScene {
+    const BvhNode *nodes;
+    const float4 *tris;
+    int n_nodes, n_tris;
+};
+
 // Closest hit by (t, original primitive index) — order independent, equals brute force.
-D Hit trace_closest(const DevScene &S, F3 o, F3 d, float mint, float maxt) {
+D Hit trace_closest(const DevScene &S, const LdsScene &L, F3 o, F3 d, float mint, float maxt) {
     Hit best;
     best.t = __builtin_inff(); best.u = 0; best.v = 0; best.prim = -1;
     int bestOrig = 0x7fffffff;
@@ -122,7 +130,7 @@ D Hit trace_closest(const DevScene &S, F3 o, F3 d, float mint, float maxt) {
     int sp = 0;
     int cur = 0;
     for (;;) {
-        const BvhNode nd = S.bvh[cur];
+        const BvhNode nd = cur < L.n_nodes ? L.nodes[cur] : S.bvh[cur];
         float tlim = fminf(maxt, best.t);
         float tn0, tn1;
         bool h0 = nd.n0 >= 0 && box_hit(nd.lo0, nd.hi0, o, id, mint, tlim, tn0);
@@ -136,7 +144,7 @@ D Hit trace_closest(const DevScene &S, F3 o, F3 d, float mint, float maxt) {
             if (n > 0) {
                 for (int k = c; k < c + n; ++k) {
                     float tt, uu, vv;
-                    const float4 *T = S.tris + 3 * k;
+                    const float4 *T = (k < L.n_tris ? L.tris : S.tris) + 3 * k;
                     if (tri_hit(T, o, d, mint, maxt, tt, uu, vv)) {
                         int orig = __float_as_int(T[2].w);
                         if (tt < best.t || (tt == best.t && orig < bestOrig)) {
@@ -285,31 +293,55 @@ struct DevTree {
     float aabb_min[3], aabb_ext[3];  // cubified AABB (GP:857-859)
     float aabb_max[3];
     int is_built;
+    // Lookup accelerator: the S-tree cycles its split axis x,y,z, so the first 3*GRID_BITS levels of any descent
+    // are determined by the top GRID_BITS bits of each normalised coordinate.  grid[cell] = node reached after
+    // min(3*GRID_BITS, depth of the leaf) levels | levels << 27.  One read replaces up to 18 dependent ones.
+    const unsigned int *grid;
 };
+#define PPG_GRID_BITS 6
+#define PPG_GRID_DIM (1 << PPG_GRID_BITS)
+#define PPG_GRID_LEVELS (3 * PPG_GRID_BITS)
 
-// STree::dTreeWrapper (GP:897-905) + STreeNode::dTreeWrapper (GP:761-769): leaf index and voxel size
+// STree::dTreeWrapper (GP:897-905) + STreeNode::dTreeWrapper (GP:761-769): leaf index and voxel size.
+// The reference halves p[axis] / size[axis] level by level; every one of those operations is exact in
+// binary floating point (×2, −0.5 on [0.5,1), ÷2), so jumping 18 levels through the grid and computing
+// the voxel size as extent · 2^-n gives bit-identical results (tests compare against the literal descent
+// of the oracle).
 D int stree_lookup(const DevTree &T, F3 pw, F3 &size) {
     size = f3(T.aabb_ext[0], T.aabb_ext[1], T.aabb_ext[2]);
     float p[3];
     p[0] = (pw.x - T.aabb_min[0]) / size.x;
     p[1] = (pw.y - T.aabb_min[1]) / size.y;
     p[2] = (pw.z - T.aabb_min[2]) / size.z;
-    float sz[3] = {size.x, size.y, size.z};
-    int idx = 0;
-    for (;;) {
-        int4 n = T.stree[idx];
-        if (n.y == 0) break;
-        int a = n.x;
-        sz[a] /= 2;
-        if (p[a] < 0.5f) {
-            p[a] *= 2;
-            idx = n.y;
-        } else {
-            p[a] = (p[a] - 0.5f) * 2;
-            idx = n.z;
+    int cell[3];
+    float rem[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float s = p[a] * (float)PPG_GRID_DIM;
+        int c = (s < (float)PPG_GRID_DIM) ? ((s < 0.0f) ? 0 : (int)s) : (PPG_GRID_DIM - 1);  // out-of-cube points follow child 0 / child 1 forever
+        cell[a] = c;
+        rem[a] = s - (float)c;
+    }
+    const unsigned int e = T.grid[(cell[2] * PPG_GRID_DIM + cell[1]) * PPG_GRID_DIM + cell[0]];
+    int idx = (int)(e & 0x07ffffffu);
+    int depth = (int)(e >> 27);
+    if (depth == PPG_GRID_LEVELS) {  // possibly deeper than the grid: continue the literal descent on the remainders
+        for (;;) {
+            int4 n = T.stree[idx];
+            if (n.y == 0) break;
+            int a = n.x;
+            ++depth;
+            if (rem[a] < 0.5f) {
+                rem[a] *= 2;
+                idx = n.y;
+            } else {
+                rem[a] = (rem[a] - 0.5f) * 2;
+                idx = n.z;
+            }
         }
     }
-    size = f3(sz[0], sz[1], sz[2]);
+    // levels along x, y, z of a leaf at depth D (root splits x, then y, z, x, ...)
+    size = f3(size.x * ppg_exp2i(-((depth + 2) / 3)), size.y * ppg_exp2i(-((depth + 1) / 3)), size.z * ppg_exp2i(-(depth / 3)));
     return idx;
 }
 
@@ -339,6 +371,26 @@ D int quad_child_index(float &px, float &py) {
     return res;
 }
 
+// One sampling node in registers: sums as float4, children as packed u16x4.  Dynamic indexing of a struct
+// would send it through LDS/scratch and serialise its two 16-byte loads; selects keep it in VGPRs.
+struct NodeR {
+    float4 s;
+    uint2 c;
+};
+D NodeR load_node(const SNode *p) {
+    NodeR n;
+    const float4 *q = reinterpret_cast<const float4 *>(p);
+    n.s = q[0];
+    float4 t = q[1];
+    n.c = make_uint2(__float_as_uint(t.x), __float_as_uint(t.y));
+    return n;
+}
+D float node_sum(const NodeR &n, int i) { return i == 0 ? n.s.x : (i == 1 ? n.s.y : (i == 2 ? n.s.z : n.s.w)); }
+D unsigned int node_child(const NodeR &n, int i) {
+    unsigned int w = (i & 2) ? n.c.y : n.c.x;
+    return (i & 1) ? (w >> 16) : (w & 0xffffu);
+}
+
 // DTree::mean (GP:387-393)
 D float dtree_mean(float sum, float statw) {
     if (statw == 0) return 0;
@@ -347,21 +399,23 @@ D float dtree_mean(float sum, float statw) {
 }
 
 // DTree::pdf + QuadTreeNode::pdf (GP:415-421, 232-245), iterative
-D float dtree_pdf(const DevTree &T, const LeafHdr &h, float px, float py) {
+template <typename Stack>
+D float dtree_pdf(const DevTree &T, const LeafHdr &h, float px, float py, Stack factors) {
     if (!(dtree_mean(h.s_sum, h.s_statw) > 0)) return 1 / (4 * PPG_PI_F);
     // the recursion multiplies factors from the leaf upwards: f1 * (f2 * (f3 * ...)); keep that order
-    float factors[24];
     int nf = 0;
     unsigned int node = 0;
     float result;
     for (;;) {
-        const SNode n = T.snodes[h.s_base + node];
+        const NodeR n = load_node(T.snodes + h.s_base + node);
         const int index = quad_child_index(px, py);
-        if (!(n.sum[index] > 0)) { result = 0; break; }
-        const float factor = 4 * n.sum[index] / (n.sum[0] + n.sum[1] + n.sum[2] + n.sum[3]);
-        if (n.child[index] == 0) { result = factor; break; }
+        const float si = node_sum(n, index);
+        if (!(si > 0)) { result = 0; break; }
+        const float factor = 4 * si / (n.s.x + n.s.y + n.s.z + n.s.w);
+        const unsigned int c = node_child(n, index);
+        if (c == 0) { result = factor; break; }
         factors[nf++] = factor;
-        node = n.child[index];
+        node = c;
     }
     for (int i = nf - 1; i >= 0; --i) result = factors[i] * result;
     return result / (4 * PPG_PI_F);
@@ -375,17 +429,17 @@ D void dtree_sample(const DevTree &T, const LeafHdr &h, uint32_t key, uint32_t &
         oy = ppg_rand(key, dim++);
         return;
     }
-    float orgx[24], orgy[24];
+    unsigned int orgx = 0, orgy = 0;  // origin.x / origin.y of level i is 0.5 iff bit i is set (GP:271, 282, 291)
     int depth = 0;
     unsigned int node = 0;
     float rx, ry;
     for (;;) {
-        const SNode n = T.snodes[h.s_base + node];
+        const NodeR n = load_node(T.snodes + h.s_base + node);
         int index = 0;
-        float topLeft = n.sum[0];
-        float topRight = n.sum[1];
-        float partial = topLeft + n.sum[2];
-        float total = partial + topRight + n.sum[3];
+        float topLeft = n.s.x;
+        float topRight = n.s.y;
+        float partial = topLeft + n.s.z;
+        float total = partial + topRight + n.s.w;
         if (!(total > 0.0f)) {
             rx = ppg_rand(key, dim++);
             ry = ppg_rand(key, dim++);
@@ -411,22 +465,35 @@ D void dtree_sample(const DevTree &T, const LeafHdr &h, uint32_t key, uint32_t &
             sample = (sample - boundary) / (1.0f - boundary);
             index |= 1 << 1;
         }
-        orgx[depth] = ogx; orgy[depth] = ogy;
+        if (ogx != 0.0f) orgx |= 1u << depth;
+        if (ogy != 0.0f) orgy |= 1u << depth;
         ++depth;
-        if (n.child[index] == 0) {
+        const unsigned int c = node_child(n, index);
+        if (c == 0) {
             rx = ppg_rand(key, dim++);
             ry = ppg_rand(key, dim++);
             break;
         }
-        node = n.child[index];
+        node = c;
     }
     for (int i = depth - 1; i >= 0; --i) {
-        rx = orgx[i] + 0.5f * rx;
-        ry = orgy[i] + 0.5f * ry;
+        rx = (((orgx >> i) & 1u) ? 0.5f : 0.0f) + 0.5f * rx;
+        ry = (((orgy >> i) & 1u) ? 0.5f : 0.0f) + 0.5f * ry;
     }
     ox = ppg_min(ppg_max(rx, 0.0f), 1.0f);
     oy = ppg_min(ppg_max(ry, 0.0f), 1.0f);
 }
+
+// per-thread column of a [depth][threads] LDS array: conflict-free, costs no registers
+struct LdsColumn {
+    float *base;
+    int stride;
+    D float &operator[](int i) const { return base[i * stride]; }
+};
+struct RegColumn {
+    float v[24];
+    D float &operator[](int i) { return v[i]; }
+};
 
 D float logistic(float x) { return 1 / (1 + ppg_exp(-x)); }  // GP:64-66
 

@@ -226,8 +226,10 @@ struct ppg_ctx {
     // path state
     DevBuf<float4> d_ray_o, d_ray_d, d_thr, d_li, d_hit, d_vd, d_vthr, d_vbsdf, d_vrad, d_vo, d_vvox;
     DevBuf<uint4> d_misc;
-    DevBuf<unsigned int> d_queue[2];
-    DevBuf<Counters> d_counters;
+    DevBuf<unsigned int> d_queue[2], d_qcount[2], d_qtotal;
+    DevBuf<BlockStats> d_stats;
+    Queues queues{};
+    int nBlocks = 2048;  // persistent workgroups of the path kernels (8 per CU)
     PathState paths{};
     int maxVertices = 0;
 
@@ -249,7 +251,8 @@ struct ppg_ctx {
     DevBuf<ushort4> d_bchild;
     DevBuf<unsigned long long> d_bacc, d_bweight, d_adamW, d_total;
     DevBuf<long long> d_adamGrad;
-    DevBuf<unsigned int> d_leaves, d_counts, d_offsets;
+    DevBuf<unsigned int> d_leaves, d_counts, d_offsets, d_grid;
+    int ldsNodes = 0, ldsTris = 0;  // scene part cached in LDS by k_trace
     float treeMin[3], treeMax[3], treeExt[3];
     bool isBuilt = false, isFinalIter = false, doNee = false;
     int iter = 0, passesRendered = 0, passesRenderedThisIter = 0, passesLocal = 0;
@@ -265,6 +268,7 @@ struct ppg_ctx {
         T.bweight = d_bweight.p; T.adam_grad = d_adamGrad.p; T.adam_w = d_adamW.p;
         for (int a = 0; a < 3; ++a) { T.aabb_min[a] = treeMin[a]; T.aabb_ext[a] = treeExt[a]; T.aabb_max[a] = treeMax[a]; }
         T.is_built = isBuilt ? 1 : 0;
+        T.grid = d_grid.p;
         return T;
     }
     RenderParams params() const {
@@ -319,6 +323,10 @@ int uploadTree(ppg_ctx *ctx) {
     HIP_CHECK(hipMemsetAsync(ctx->d_bweight.p, 0, n * 8, ctx->stream));
     HIP_CHECK(hipMemsetAsync(ctx->d_adamW.p, 0, n * 8, ctx->stream));
     HIP_CHECK(hipMemsetAsync(ctx->d_adamGrad.p, 0, n * 8, ctx->stream));
+    if (n >= (1u << 27)) { ctx->error = "S-tree exceeds 2^27 nodes"; return PPG_ERR_NOMEM; }
+    const unsigned int cells = PPG_GRID_DIM * PPG_GRID_DIM * PPG_GRID_DIM;
+    HIP_CHECK(ctx->d_grid.reserve(cells));
+    hipLaunchKernelGGL(k_build_grid, dim3((cells + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_stree.p, ctx->d_grid.p);
     HIP_CHECK(hipStreamSynchronize(ctx->stream));  // st is a stack-local staging buffer
     return PPG_OK;
 }
@@ -463,11 +471,18 @@ int allocPaths(ppg_ctx *ctx) {
     if (ctx->maxDepth > 0) ctx->maxVertices = std::max(1, std::min(PPG_MAX_VERTICES, ctx->maxDepth - 1));
     HIP_CHECK(ctx->d_ray_o.reserve(nn)); HIP_CHECK(ctx->d_ray_d.reserve(nn)); HIP_CHECK(ctx->d_thr.reserve(nn));
     HIP_CHECK(ctx->d_li.reserve(nn)); HIP_CHECK(ctx->d_hit.reserve(nn)); HIP_CHECK(ctx->d_misc.reserve(nn));
-    HIP_CHECK(ctx->d_queue[0].reserve(nn)); HIP_CHECK(ctx->d_queue[1].reserve(nn));
+    if (const char *nbEnv = getenv("PPG_BLOCKS")) ctx->nBlocks = std::max(1, atoi(nbEnv));
+    const size_t nb = (size_t)ctx->nBlocks;
+    const size_t chunks = (nn + PPG_CHUNK - 1) / PPG_CHUNK;
+    const size_t cap = ((chunks + nb - 1) / nb) * PPG_CHUNK;
+    for (int k = 0; k < 2; ++k) { HIP_CHECK(ctx->d_queue[k].reserve(cap * nb)); HIP_CHECK(ctx->d_qcount[k].reserve(nb)); }
+    HIP_CHECK(ctx->d_stats.reserve(nb)); HIP_CHECK(ctx->d_qtotal.reserve(1));
+    ctx->queues.items[0] = ctx->d_queue[0].p; ctx->queues.items[1] = ctx->d_queue[1].p;
+    ctx->queues.count[0] = ctx->d_qcount[0].p; ctx->queues.count[1] = ctx->d_qcount[1].p;
+    ctx->queues.cap = (unsigned int)cap; ctx->queues.stats = ctx->d_stats.p;
     size_t nv = nn * (size_t)ctx->maxVertices;
     HIP_CHECK(ctx->d_vd.reserve(nv)); HIP_CHECK(ctx->d_vthr.reserve(nv)); HIP_CHECK(ctx->d_vbsdf.reserve(nv)); HIP_CHECK(ctx->d_vrad.reserve(nv));
     if (ctx->spatialFilter != SF_NEAREST) { HIP_CHECK(ctx->d_vo.reserve(nv)); HIP_CHECK(ctx->d_vvox.reserve(nv)); }
-    HIP_CHECK(ctx->d_counters.reserve(1));
     PathState &P = ctx->paths;
     P.n_paths = (unsigned int)n; P.n_pix = ctx->nPix; P.pixels = ctx->d_pixels.p;
     P.ray_o = ctx->d_ray_o.p; P.ray_d = ctx->d_ray_d.p; P.thr = ctx->d_thr.p; P.li = ctx->d_li.p; P.hit = ctx->d_hit.p; P.misc = ctx->d_misc.p;
@@ -484,33 +499,36 @@ int renderOnePass(ppg_ctx *ctx) {
     DevScene S = ctx->scene;
     DevTree T = ctx->devTree();
     RenderParams R = ctx->params();
-    Counters *C = ctx->d_counters.p;
-    const int grid = gridFor(P.n_paths);
+    Queues Q = ctx->queues;
+    const int grid = ctx->nBlocks;
+    const int gridAll = gridFor(P.n_paths);
     hipStream_t s = ctx->stream;
-    timedLaunch(ctx, "k_generate", P.n_paths, [&] { hipLaunchKernelGGL(k_generate, dim3(grid), dim3(PPG_BLOCK), 0, s, P, S, R); });
-    HIP_CHECK(hipMemsetAsync(&C->queue_count[0], 0, 8, s));
-    // bounce 1 works on all paths (no queue); afterwards queues alternate
-    unsigned int *qIn = nullptr; const unsigned int *cntIn = nullptr;
+    timedLaunch(ctx, "k_generate", P.n_paths, [&] { hipLaunchKernelGGL(k_generate, dim3(gridAll), dim3(PPG_BLOCK), 0, s, P, S, R); });
+    // bounce 1 works on all paths (no queue); afterwards the two queue sets alternate
+    int qin = -1;
     const int maxBounces = ctx->maxDepth > 0 ? ctx->maxDepth : 1 << 20;
     unsigned int hostCount = P.n_paths;
+    const bool smallScene = ctx->scene.n_tris <= 64 && ctx->ldsTris == ctx->scene.n_tris && !getenv("PPG_FORCE_BVH");
+    const size_t ldsBytes = (smallScene ? 0 : (size_t)ctx->ldsNodes * 64) + (size_t)ctx->ldsTris * 48;
     for (int b = 0; b < maxBounces; ++b) {
-        int w = b & 1;  // output queue index
-        timedLaunch(ctx, "k_trace", hostCount, [&] { hipLaunchKernelGGL(k_trace, dim3(grid), dim3(PPG_BLOCK), 0, s, P, S, qIn, cntIn, P.n_paths, C); });
-        HIP_CHECK(hipMemsetAsync(&C->queue_count[w], 0, 4, s));
-        timedLaunch(ctx, "k_shade", hostCount, [&] {
-            hipLaunchKernelGGL(k_shade, dim3(grid), dim3(PPG_BLOCK), 0, s, P, S, T, R, qIn, cntIn, P.n_paths, ctx->d_queue[w].p, &C->queue_count[w], C);
+        int qout = b & 1;
+        timedLaunch(ctx, "k_trace", hostCount, [&] {
+            if (smallScene) hipLaunchKernelGGL(k_trace<true>, dim3(grid), dim3(PPG_BLOCK), ldsBytes, s, P, S, Q, qin, 0, ctx->ldsTris);
+            else hipLaunchKernelGGL(k_trace<false>, dim3(grid), dim3(PPG_BLOCK), ldsBytes, s, P, S, Q, qin, ctx->ldsNodes, ctx->ldsTris);
         });
-        qIn = ctx->d_queue[w].p; cntIn = &C->queue_count[w];
+        timedLaunch(ctx, "k_shade", hostCount, [&] { hipLaunchKernelGGL(k_shade, dim3(grid), dim3(PPG_BLOCK), 0, s, P, S, T, R, Q, qin, qout); });
+        qin = qout;
         // unbounded paths (maxDepth < 0) and kernel timing need the live count; bounded paths run a fixed schedule without a sync
         if (ctx->maxDepth < 0 || ctx->timer.enabled) {
-            HIP_CHECK(hipMemcpyAsync(&hostCount, cntIn, 4, hipMemcpyDeviceToHost, s));
+            hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(256), 0, s, Q.count[qin], (unsigned int)grid, ctx->d_qtotal.p);
+            HIP_CHECK(hipMemcpyAsync(&hostCount, ctx->d_qtotal.p, 4, hipMemcpyDeviceToHost, s));
             HIP_CHECK(hipStreamSynchronize(s));
             if (hostCount == 0) break;
         }
     }
     // the last shade of a bounded schedule terminates every path (depth >= maxDepth), no trailing trace needed
     if (!ctx->isFinalIter) {
-        timedLaunch(ctx, "k_commit", P.n_paths, [&] { hipLaunchKernelGGL(k_commit, dim3(grid), dim3(PPG_BLOCK), 0, s, P, T, R, C); });
+        timedLaunch(ctx, "k_commit", P.n_paths, [&] { hipLaunchKernelGGL(k_commit, dim3(grid), dim3(PPG_BLOCK), 0, s, P, T, R, Q); });
         if (ctx->loss != LOSS_NONE && ctx->isBuilt) {
             unsigned int nn = (unsigned int)ctx->snodes.size();
             hipLaunchKernelGGL(k_adam_step, dim3((nn + 255) / 256), dim3(256), 0, s, T, nn);
@@ -529,7 +547,7 @@ int renderPassesNoStat(ppg_ctx *ctx, int numPasses) {  // GP:1217-1286
     HIP_CHECK(hipMemsetAsync(ctx->d_image.p, 0, 3 * n * 4, ctx->stream));
     HIP_CHECK(hipMemsetAsync(ctx->d_sq.p, 0, 3 * n * 4, ctx->stream));
     HIP_CHECK(hipMemsetAsync(ctx->d_imageW.p, 0, n * 4, ctx->stream));
-    HIP_CHECK(hipMemsetAsync(ctx->d_counters.p, 0, sizeof(Counters), ctx->stream));
+    HIP_CHECK(hipMemsetAsync(ctx->d_stats.p, 0, sizeof(BlockStats) * (size_t)ctx->nBlocks, ctx->stream));
     ctx->passStart = std::chrono::steady_clock::now();
     ctx->passesLocal = 0;
     for (int i = 0; i < numPasses; ++i) {
@@ -555,10 +573,12 @@ int finishPasses(ppg_ctx *ctx, ppg_pass_stats *st) {  // GP:1288-1328
     }
     hipLaunchKernelGGL(k_variance, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, N, ctx->d_image.p, ctx->d_sq.p, ctx->d_imageW.p, ctx->d_var.p, ctx->d_lum.p);
     std::vector<float> lum(n);
-    Counters c{};
+    std::vector<BlockStats> bs((size_t)ctx->nBlocks);
     HIP_CHECK(hipMemcpyAsync(lum.data(), ctx->d_lum.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_CHECK(hipMemcpyAsync(&c, ctx->d_counters.p, sizeof c, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipMemcpyAsync(bs.data(), ctx->d_stats.p, bs.size() * sizeof(BlockStats), hipMemcpyDeviceToHost, ctx->stream));
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    BlockStats c{};
+    for (const BlockStats &x : bs) { c.rays += x.rays; c.path_len += x.path_len; c.committed += x.committed; }
     float variance = 0;  // summed in the reference's x-major order (GP:1303-1311)
     for (int x = 0; x < ctx->W; ++x)
         for (int y = 0; y < ctx->H; ++y) variance += lum[(size_t)y * ctx->W + x];
@@ -931,6 +951,12 @@ int ppg_set_scene(ppg_ctx *ctx, const ppg_scene *s) {
     S.cam.width = s->camera.width; S.cam.height = s->camera.height;
     S.cam.inv_w = 1.0f / (float)s->camera.width; S.cam.inv_h = 1.0f / (float)s->camera.height;
     ctx->W = s->camera.width; ctx->H = s->camera.height;
+    {   // LDS budget of k_trace: 32 KB keeps 5 workgroups per CU resident
+        const size_t budget = 32 * 1024;
+        ctx->ldsNodes = (int)std::min<size_t>(bb.nodes.size(), budget / 64);
+        size_t left = budget - (size_t)ctx->ldsNodes * 64;
+        ctx->ldsTris = ((size_t)s->n_triangles * 48 <= left) ? (int)s->n_triangles : 0;
+    }
     ctx->haveScene = true;
     ctx->treeAlive = false;
     return PPG_OK;

@@ -16,6 +16,9 @@
 
 #define PPG_MAX_VERTICES 32  // MAX_NUM_VERTICES, GP:1771
 #define PPG_BLOCK 256
+#ifndef PPG_SHADE_WAVES
+#define PPG_SHADE_WAVES 2  // min waves per SIMD requested for k_shade (register budget), tuned on MI355X
+#endif
 
 enum { NEE_NEVER = 0, NEE_KICKSTART = 1, NEE_ALWAYS = 2 };
 enum { SF_NEAREST = 0, SF_STOCHASTIC = 1, SF_BOX = 2 };
@@ -62,27 +65,86 @@ struct PathState {
     float4 *v_vox;   // (voxel size, -)   only if spatial filter != nearest
 };
 
-struct Counters {  // device-resident, zeroed per ppg_render_passes
+// Per-workgroup statistics (zeroed per ppg_render_passes, summed on the host).  A single global counter
+// would take one same-address atomic per wave and round — measured at ~11 ns each that was half of
+// k_shade's run time — so every persistent workgroup owns a private record and a private slice of the queues.
+struct BlockStats {
     unsigned long long rays, path_len, committed;
-    unsigned int queue_count[2];
 };
 
-// wave-aggregated append: returns the slot for lanes with `pred`
-D unsigned int queue_append(unsigned int *counter, bool pred) {
+// Queues: workgroup b owns entries [b * cap, b * cap + count[b]).  Paths are dealt to workgroups in chunks of
+// PPG_CHUNK consecutive indices at the first bounce and stay with their workgroup, so compaction needs
+// only an LDS counter and queue reads/writes stay coalesced.
+struct Queues {
+    unsigned int *items[2];
+    unsigned int *count[2];  // [n_blocks]
+    unsigned int cap;        // entries per workgroup
+    BlockStats *stats;       // [n_blocks]
+};
+
+// wave-aggregated append to the workgroup's queue slice: one LDS atomic per wave
+D unsigned int queue_append(unsigned int *lds_counter, bool pred) {
     unsigned long long mask = __ballot(pred);
     if (mask == 0) return 0;
     int leader = __ffsll((long long)mask) - 1;
     int lane = threadIdx.x & 63;
     unsigned int base = 0;
-    if (lane == leader) base = atomicAdd(counter, (unsigned int)__popcll(mask));
+    if (lane == leader) base = atomicAdd(lds_counter, (unsigned int)__popcll(mask));
     base = __shfl(base, leader);
     return base + (unsigned int)__popcll(mask & ((1ull << lane) - 1ull));
 }
 
-D void wave_add_u64(unsigned long long *dst, unsigned long long v) {
-    // sum over the wave, one atomic
+// workgroup-wide sum of a per-thread count into the workgroup's private statistics word (no global atomics)
+D void block_add_u64(unsigned long long *lds_acc, unsigned long long *dst, unsigned long long v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-    if ((threadIdx.x & 63) == 0 && v) atomicAdd(dst, v);
+    if (threadIdx.x == 0) *lds_acc = 0;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(lds_acc, v);
+    __syncthreads();
+    if (threadIdx.x == 0) *dst += *lds_acc;
+}
+
+// number of paths workgroup b handles at the first bounce and its k-th path (chunks dealt round-robin)
+// (chunks of one wave: 64 neighbouring pixels; dealing small chunks round-robin spreads empty image regions
+// evenly over the workgroups, whose queue slices then shrink at the same rate)
+#define PPG_CHUNK 64
+D unsigned int first_share(unsigned int n_paths, unsigned int b, unsigned int nb) {
+    unsigned int chunks = (n_paths + PPG_CHUNK - 1) / PPG_CHUNK;
+    unsigned int mine = chunks > b ? (chunks - b + nb - 1) / nb : 0;
+    return mine * PPG_CHUNK;  // the last chunk may be partial: callers test i < n_paths
+}
+D unsigned int first_path(unsigned int k, unsigned int b, unsigned int nb) { return ((k / PPG_CHUNK) * nb + b) * PPG_CHUNK + (k % PPG_CHUNK); }
+
+
+// Keyed accumulation with wave-level pre-combination: lanes of a wave that add to the same key are summed
+// in registers and issue ONE atomic (up to ROUNDS distinct keys are combined, the rest go out directly).
+// Early iterations send every record of a wave to the same D-tree (iteration 0: all of them to one
+// statistical-weight counter — 15 M same-address atomics per pass at 720p without this).  Integer adds
+// commute, so the combination does not change the result.  Must be called by all lanes of the wave.
+template <int ROUNDS>
+D void wave_key_add(unsigned long long *dst, unsigned int key, unsigned long long val, bool active) {
+    unsigned long long todo = __ballot(active);
+    const int lane = threadIdx.x & 63;
+#pragma unroll 1
+    for (int r = 0; r < ROUNDS && todo; ++r) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const unsigned int k = __shfl(key, leader);
+        const bool mine = active && key == k;
+        const unsigned long long grp = __ballot(mine);
+        const unsigned long long vl = __shfl(val, leader);
+        unsigned long long total;
+        if (__ballot(mine && val != vl) == 0) {
+            total = vl * (unsigned long long)__popcll(grp);  // all equal (unit weights): no reduction needed
+        } else {
+            unsigned long long v = mine ? val : 0ull;
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            total = v;
+        }
+        if (lane == leader) atomicAdd(dst + k, total);
+        todo &= ~grp;
+        if (mine) active = false;
+    }
+    if (active) atomicAdd(dst + key, val);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -115,39 +177,100 @@ __global__ __launch_bounds__(PPG_BLOCK) void k_generate(PathState P, DevScene S,
 // ------------------------------------------------------------------------------------------------
 // k_trace — Scene::rayIntersect (skdtree.cpp:112-142) for every queued path
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(PPG_BLOCK) void k_trace(PathState P, DevScene S, const unsigned int *queue, const unsigned int *count_ptr,
-                                                     unsigned int count_all, Counters *C) {
-    unsigned int count = queue ? *count_ptr : count_all;
-    for (unsigned int q = blockIdx.x * blockDim.x + threadIdx.x; q < count; q += gridDim.x * blockDim.x) {
-        unsigned int i = queue ? queue[q] : q;
+// SMALL: the whole scene (<= 64 triangles) is tested from LDS without a BVH — every lane reads the same
+// triangle (LDS broadcast), no divergence, no dependent memory chain.  Same (t, original index) minimum.
+template <bool SMALL>
+__global__ __launch_bounds__(PPG_BLOCK) void k_trace(PathState P, DevScene S, Queues Q, int qin, int lds_nodes, int lds_tris) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    __shared__ unsigned long long acc;
+    LdsScene L;
+    {
+        float4 *dst = (float4 *)lds_raw;
+        const float4 *srcN = (const float4 *)S.bvh;
+        const int nN = lds_nodes * 4, nT = lds_tris * 3;
+        for (int k = threadIdx.x; k < nN; k += blockDim.x) dst[k] = srcN[k];
+        for (int k = threadIdx.x; k < nT; k += blockDim.x) dst[nN + k] = S.tris[k];
+        __syncthreads();
+        L.nodes = (const BvhNode *)lds_raw; L.tris = dst + nN; L.n_nodes = lds_nodes; L.n_tris = lds_tris;
+    }
+    const unsigned int b = blockIdx.x, nb = gridDim.x;
+    const unsigned int count = qin >= 0 ? Q.count[qin][b] : first_share(P.n_paths, b, nb);
+    const unsigned int *items = qin >= 0 ? Q.items[qin] + (size_t)b * Q.cap : nullptr;
+    unsigned int traced = 0;
+    for (unsigned int k = threadIdx.x; k < count; k += blockDim.x) {
+        unsigned int i = items ? items[k] : first_path(k, b, nb);
+        if (i >= P.n_paths) continue;
         float4 ro = P.ray_o[i], rd = P.ray_d[i];
         F3 o = f3(ro.x, ro.y, ro.z), d = f3(rd.x, rd.y, rd.z);
         float rayMinT = ro.w;
         if (rayMinT == PPG_EPSILON)  // adaptive ray epsilon
             rayMinT *= ppg_max(ppg_max(ppg_max(ppg_abs(o.x), ppg_abs(o.y)), ppg_abs(o.z)), PPG_EPSILON);
-        Hit h = trace_closest(S, o, d, rayMinT, rd.w);
+        Hit h;
+        if (SMALL) {
+            h.t = __builtin_inff(); h.u = 0; h.v = 0; h.prim = -1;
+            int bestOrig = 0x7fffffff;
+            for (int k = 0; k < lds_tris; ++k) {
+                float tt, uu, vv;
+                const float4 *Tk = L.tris + 3 * k;
+                if (tri_hit(Tk, o, d, rayMinT, rd.w, tt, uu, vv)) {
+                    int orig = __float_as_int(Tk[2].w);
+                    if (tt < h.t || (tt == h.t && orig < bestOrig)) { h.t = tt; h.u = uu; h.v = vv; h.prim = k; bestOrig = orig; }
+                }
+            }
+        } else {
+            h = trace_closest(S, L, o, d, rayMinT, rd.w);
+        }
         P.hit[i] = make_float4(h.t, h.u, h.v, __int_as_float(h.prim));
+        ++traced;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&C->rays, (unsigned long long)count);
+    block_add_u64(&acc, &Q.stats[b].rays, traced);
+}
+
+// grid[cell] for stree_lookup: descend at most PPG_GRID_LEVELS levels along the cell's coordinate bits
+__global__ void k_build_grid(const int4 *stree, unsigned int *grid) {
+    unsigned int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= PPG_GRID_DIM * PPG_GRID_DIM * PPG_GRID_DIM) return;
+    unsigned int coord[3] = {c % PPG_GRID_DIM, (c / PPG_GRID_DIM) % PPG_GRID_DIM, c / (PPG_GRID_DIM * PPG_GRID_DIM)};
+    int used[3] = {0, 0, 0};
+    int idx = 0, depth = 0;
+    for (; depth < PPG_GRID_LEVELS; ++depth) {
+        int4 n = stree[idx];
+        if (n.y == 0) break;
+        int a = n.x;
+        unsigned int bit = (coord[a] >> (PPG_GRID_BITS - 1 - used[a])) & 1u;
+        ++used[a];
+        idx = bit ? n.z : n.y;
+    }
+    grid[c] = (unsigned int)idx | ((unsigned int)depth << 27);
 }
 
 // ------------------------------------------------------------------------------------------------
 // k_shade — Li's loop body (GP:1798-2146), surface branch, nee = never
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(PPG_BLOCK) void k_shade(PathState P, DevScene S, DevTree T, RenderParams R, const unsigned int *queue,
-                                                     const unsigned int *count_ptr, unsigned int count_all, unsigned int *next_queue,
-                                                     unsigned int *next_count, Counters *C) {
-    unsigned int count = queue ? *count_ptr : count_all;
-    unsigned int total = gridDim.x * blockDim.x;
-    unsigned int rounds = (count + total - 1) / total;
+__global__ __launch_bounds__(PPG_BLOCK, PPG_SHADE_WAVES) void k_shade(PathState P, DevScene S, DevTree T, RenderParams R, Queues Q, int qin, int qout) {
+    __shared__ float pdf_factors[20 * PPG_BLOCK];  // QuadTreeNode::pdf's per-level factors (tree depth <= 20, GP:1112)
+    __shared__ unsigned int out_count;
+    __shared__ unsigned long long acc;
+    const LdsColumn fcol{pdf_factors + threadIdx.x, PPG_BLOCK};
+    const unsigned int b = blockIdx.x, nb = gridDim.x;
+    const unsigned int count = qin >= 0 ? Q.count[qin][b] : first_share(P.n_paths, b, nb);
+    const unsigned int *items = qin >= 0 ? Q.items[qin] + (size_t)b * Q.cap : nullptr;
+    unsigned int *out_items = Q.items[qout] + (size_t)b * Q.cap;
+    if (threadIdx.x == 0) out_count = 0;
+    __syncthreads();
+    unsigned long long plen_sum = 0;
+    const unsigned int rounds = (count + PPG_BLOCK - 1) / PPG_BLOCK;
     for (unsigned int r = 0; r < rounds; ++r) {
-        unsigned int q = r * total + blockIdx.x * blockDim.x + threadIdx.x;
+        unsigned int q = r * PPG_BLOCK + threadIdx.x;
         bool active = q < count;
         bool alive = false;
         unsigned long long plen = 0;
         unsigned int i = 0;
         if (active) {
-            i = queue ? queue[q] : q;
+            i = items ? items[q] : first_path(q, b, nb);
+            active = i < P.n_paths;
+        }
+        if (active) {
             uint4 m = P.misc[i];
             unsigned int key = m.x, dim = m.y, flags = m.z;
             unsigned int depth = flags & FL_DEPTH_MASK;
@@ -175,10 +298,17 @@ __global__ __launch_bounds__(PPG_BLOCK) void k_shade(PathState P, DevScene S, De
                 F3 L = mul3(thr, value) * weight;
                 if (!iszero3(L)) {  // recordRadiance, GP:1791-1796
                     Li = Li + L;
-                    for (unsigned int v = 0; v < nV; ++v) {
-                        float4 rr = P.v_rad[(size_t)v * P.n_paths + i];
-                        rr.x += L.x; rr.y += L.y; rr.z += L.z;
-                        P.v_rad[(size_t)v * P.n_paths + i] = rr;
+                    for (unsigned int v0 = 0; v0 < nV; v0 += 4) {  // 4 independent loads in flight, then 4 stores
+                        float4 rr[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (v0 + k < nV) rr[k] = P.v_rad[(size_t)(v0 + k) * P.n_paths + i];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (v0 + k < nV) {
+                                rr[k].x += L.x; rr[k].y += L.y; rr[k].z += L.z;
+                                P.v_rad[(size_t)(v0 + k) * P.n_paths + i] = rr[k];
+                            }
                     }
                 }
                 if ((!isDelta || R.loss != LOSS_NONE) && hasTree && nV < PPG_MAX_VERTICES && nV < (unsigned int)R.max_vertices &&
@@ -220,7 +350,11 @@ __global__ __launch_bounds__(PPG_BLOCK) void k_shade(PathState P, DevScene S, De
             }
             if (go) {
                 F3 vox;
+#if defined(PPG_ABLATE) && PPG_ABLATE == 3
+                const int leaf = 0; vox = f3s(1.0f);
+#else
                 const int leaf = stree_lookup(T, I.p, vox);  // GP:1942-1944
+#endif
                 const LeafHdr hd = T.hdr[leaf];
                 float frac = R.bsdf_sampling_fraction;  // GP:1946-1949
                 if (R.loss != LOSS_NONE) frac = logistic(hd.theta);
@@ -232,7 +366,11 @@ __global__ __launch_bounds__(PPG_BLOCK) void k_shade(PathState P, DevScene S, De
                 float sy = ppg_rand(key, dim++);
                 F3 wo_l, bsdfWeight;
                 float woPdf, bsdfPdf, dTreePdf;
+#if defined(PPG_ABLATE) && PPG_ABLATE == 1
+                if (true) {
+#else
                 if (!T.is_built) {
+#endif
                     if (I.wi.z <= 0) {
                         bsdfWeight = f3s(0.0f); bsdfPdf = 0.0f; wo_l = f3s(0.0f);
                     } else {
@@ -276,7 +414,7 @@ __global__ __launch_bounds__(PPG_BLOCK) void k_shade(PathState P, DevScene S, De
                         } else {
                             float cx, cy;
                             dir_to_canonical(to_world(I, wo_l), cx, cy);
-                            dTreePdf = dtree_pdf(T, hd, cx, cy);
+                            dTreePdf = dtree_pdf(T, hd, cx, cy, fcol);
                             woPdf = frac * bsdfPdf + (1 - frac) * dTreePdf;
                         }
                         bsdfWeight = (woPdf == 0) ? f3s(0.0f) : div3(result, woPdf);
@@ -292,7 +430,11 @@ __global__ __launch_bounds__(PPG_BLOCK) void k_shade(PathState P, DevScene S, De
                         d = wo;
                         P.ray_o[i] = make_float4(I.p.x, I.p.y, I.p.z, PPG_EPSILON);
                         P.ray_d[i] = make_float4(wo.x, wo.y, wo.z, __builtin_inff());
+#if defined(PPG_ABLATE) && PPG_ABLATE == 2
+                        if (false) {
+#else
                         if (nV < PPG_MAX_VERTICES && nV < (unsigned int)R.max_vertices && !R.is_final_iter) {
+#endif
                             size_t vi = (size_t)nV * P.n_paths + i;
                             F3 bv = bsdfWeight * woPdf;
                             P.v_d[vi] = make_float4(wo.x, wo.y, wo.z, woPdf);
@@ -316,25 +458,42 @@ __global__ __launch_bounds__(PPG_BLOCK) void k_shade(PathState P, DevScene S, De
             if (alive) P.thr[i] = make_float4(thr.x, thr.y, thr.z, eta);
             else plen = depth;  // avgPathLength += rRec.depth, GP:2147-2148
         }
-        unsigned int slot = queue_append(next_count, alive);
-        if (alive) next_queue[slot] = i;
-        wave_add_u64(&C->path_len, plen);
+        unsigned int slot = queue_append(&out_count, alive);
+        if (alive) out_items[slot] = i;
+        plen_sum += plen;
     }
+    __syncthreads();
+    if (threadIdx.x == 0) Q.count[qout][b] = out_count;
+    block_add_u64(&acc, &Q.stats[b].path_len, plen_sum);
+}
+
+// sum of count[b] (the host needs it only for unbounded paths and for kernel timing)
+__global__ void k_sum_counts(const unsigned int *count, unsigned int nb, unsigned int *total) {
+    __shared__ unsigned int acc;
+    if (threadIdx.x == 0) acc = 0;
+    __syncthreads();
+    unsigned int v = 0;
+    for (unsigned int k = threadIdx.x; k < nb; k += blockDim.x) v += count[k];
+    atomicAdd(&acc, v);
+    __syncthreads();
+    if (threadIdx.x == 0) *total = acc;
 }
 
 // ------------------------------------------------------------------------------------------------
 // Splatting: DTree::recordIrradiance (GP:395-413) into the building tree of one S-tree leaf
 // ------------------------------------------------------------------------------------------------
+// (the `statisticalWeight += w` half of recordIrradiance is done by the caller, wave-combined)
 D void dtree_record(const DevTree &T, int leaf, float px, float py, float irradiance, float w, int dfilter) {
     if (!(ppg_isfinite(w) && w > 0)) return;
-    atomicAdd(&T.bweight[leaf], ppg_to_fixed(w));
     if (!(ppg_isfinite(irradiance) && irradiance > 0)) return;
     const unsigned int base = T.hdr[leaf].b_base;
     if (dfilter == DF_NEAREST) {  // QuadTreeNode::record, GP:303-312
         unsigned int node = 0;
         for (;;) {
             int index = quad_child_index(px, py);
-            unsigned short c = ((const unsigned short *)&T.bchild[base + node])[index];
+            uint2 cw = *reinterpret_cast<const uint2 *>(&T.bchild[base + node]);
+            unsigned int w32 = (index & 2) ? cw.y : cw.x;
+            unsigned int c = (index & 1) ? (w32 >> 16) : (w32 & 0xffffu);
             if (c == 0) {
                 atomicAdd(&T.bacc[(size_t)(base + node) * 4 + index], ppg_to_fixed(irradiance * w));
                 break;
@@ -392,25 +551,45 @@ struct Rec {  // DTreeRecord, GP:562-568
 
 // DTreeWrapper::record (GP:575-584) incl. the gradient of optimizeBsdfSamplingFraction (GP:672-697);
 // the Adam step itself is taken once per pass by k_adam_step from the exact sums accumulated here.
-D void wrapper_record(const DevTree &T, int leaf, const Rec &rec, int dfilter, int loss) {
-    if (!rec.isDelta) {
-        float irradiance = rec.radiance / rec.woPdf;
-        float px, py;
+// COMBINE: called by all lanes of a wave (inactive lanes pass active = false); the per-D-tree counters
+// are then pre-combined across the wave.
+template <bool COMBINE>
+D void wrapper_record(const DevTree &T, int leaf, const Rec &rec, int dfilter, int loss, bool active) {
+    const bool irr = active && !rec.isDelta;
+    float irradiance = 0, px = 0, py = 0;
+    if (irr) {
+        irradiance = rec.radiance / rec.woPdf;
         dir_to_canonical(rec.d, px, py);
-        dtree_record(T, leaf, px, py, irradiance, rec.statisticalWeight, dfilter);
     }
-    if (loss != LOSS_NONE && rec.product > 0) {
-        float variable = T.hdr[leaf].theta;
-        float samplingFraction = logistic(variable);
-        float mixPdf = samplingFraction * rec.bsdfPdf + (1 - samplingFraction) * rec.dTreePdf;
-        float r = rec.product / mixPdf;
-        float ratio = (loss == LOSS_KL) ? r : r * r;
-        float dLoss_dSamplingFraction = -ratio / rec.woPdf * (rec.bsdfPdf - rec.dTreePdf);
-        float dLoss_dVariable = dLoss_dSamplingFraction * (samplingFraction * (1 - samplingFraction));
-        float l2RegGradient = 0.01f * variable;
-        float lossGradient = l2RegGradient + dLoss_dVariable;
-        atomicAdd((unsigned long long *)&T.adam_grad[leaf], (unsigned long long)ppg_to_sfixed(lossGradient * rec.statisticalWeight));
-        atomicAdd(&T.adam_w[leaf], ppg_to_fixed(rec.statisticalWeight));
+    const bool wOk = irr && ppg_isfinite(rec.statisticalWeight) && rec.statisticalWeight > 0;
+    const unsigned long long wf = wOk ? ppg_to_fixed(rec.statisticalWeight) : 0ull;
+    if (COMBINE) wave_key_add<3>(T.bweight, (unsigned int)leaf, wf, wOk);
+    else if (wOk) atomicAdd(&T.bweight[leaf], wf);
+    if (wOk) dtree_record(T, leaf, px, py, irradiance, rec.statisticalWeight, dfilter);
+
+    const bool adam = active && loss != LOSS_NONE && rec.product > 0;
+    if (loss != LOSS_NONE) {
+        unsigned long long g = 0, w = 0;
+        if (adam) {
+            float variable = T.hdr[leaf].theta;
+            float samplingFraction = logistic(variable);
+            float mixPdf = samplingFraction * rec.bsdfPdf + (1 - samplingFraction) * rec.dTreePdf;
+            float r = rec.product / mixPdf;
+            float ratio = (loss == LOSS_KL) ? r : r * r;
+            float dLoss_dSamplingFraction = -ratio / rec.woPdf * (rec.bsdfPdf - rec.dTreePdf);
+            float dLoss_dVariable = dLoss_dSamplingFraction * (samplingFraction * (1 - samplingFraction));
+            float l2RegGradient = 0.01f * variable;
+            float lossGradient = l2RegGradient + dLoss_dVariable;
+            g = (unsigned long long)ppg_to_sfixed(lossGradient * rec.statisticalWeight);
+            w = ppg_to_fixed(rec.statisticalWeight);
+        }
+        if (COMBINE) {
+            wave_key_add<3>((unsigned long long *)T.adam_grad, (unsigned int)leaf, g, adam);
+            wave_key_add<3>(T.adam_w, (unsigned int)leaf, w, adam);
+        } else if (adam) {
+            atomicAdd((unsigned long long *)&T.adam_grad[leaf], g);
+            atomicAdd(&T.adam_w[leaf], w);
+        }
     }
 }
 
@@ -435,7 +614,7 @@ D void stree_record_box(const DevTree &T, F3 p, F3 vox, Rec rec, int dfilter, in
         if (n.y == 0) {
             Rec r2 = rec;
             r2.statisticalWeight = rec.statisticalWeight * w;
-            wrapper_record(T, e.node, r2, dfilter, loss);
+            wrapper_record<false>(T, e.node, r2, dfilter, loss, true);
         } else {
             float m2[3] = {e.mx, e.my, e.mz}, s2[3] = {e.sx, e.sy, e.sz};
             s2[n.x] /= 2;
@@ -450,63 +629,76 @@ D void stree_record_box(const DevTree &T, F3 p, F3 vox, Rec rec, int dfilter, in
 // ------------------------------------------------------------------------------------------------
 // k_commit — Vertex::commit for every recorded vertex of every path (GP:1730-1768, 2150-2154)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(PPG_BLOCK) void k_commit(PathState P, DevTree T, RenderParams R, Counters *C) {
+__global__ __launch_bounds__(PPG_BLOCK) void k_commit(PathState P, DevTree T, RenderParams R, Queues Q) {
+    __shared__ unsigned long long acc;
+    unsigned long long committed_sum = 0;
     unsigned int total = gridDim.x * blockDim.x;
     unsigned int rounds = (P.n_paths + total - 1) / total;
+    const float statisticalWeight = (R.nee == NEE_KICKSTART && R.do_nee) ? 0.5f : 1.0f;
+    const int loss = T.is_built ? R.loss : LOSS_NONE;
     for (unsigned int r = 0; r < rounds; ++r) {
         unsigned int i = r * total + blockIdx.x * blockDim.x + threadIdx.x;
         unsigned long long committed = 0;
+        unsigned int key = 0, dim = 0, nV = 0;
         if (i < P.n_paths) {
             uint4 m = P.misc[i];
-            unsigned int key = m.x, dim = m.y;
-            unsigned int nV = (m.z & FL_NV_MASK) >> FL_NV_SHIFT;
-            const float statisticalWeight = (R.nee == NEE_KICKSTART && R.do_nee) ? 0.5f : 1.0f;
-            const int loss = T.is_built ? R.loss : LOSS_NONE;
-            for (unsigned int v = 0; v < nV; ++v) {
-                size_t vi = (size_t)v * P.n_paths + i;
+            key = m.x; dim = m.y;
+            nV = (m.z & FL_NV_MASK) >> FL_NV_SHIFT;
+        }
+        // all lanes of the wave walk the vertex slots together (the per-D-tree counters are wave-combined)
+        for (unsigned int v = 0; __any(v < nV); ++v) {
+            bool act = v < nV;
+            Rec rec;
+            rec.d = f3s(0.0f); rec.radiance = rec.product = rec.woPdf = rec.bsdfPdf = rec.dTreePdf = 0; rec.statisticalWeight = statisticalWeight;
+            rec.isDelta = false;
+            int leaf = 0;
+            size_t vi = (size_t)v * P.n_paths + i;
+            if (act) {
                 float4 a = P.v_d[vi], b = P.v_thr[vi], c = P.v_bsdf[vi], e = P.v_rad[vi];
                 const float woPdf = a.w, bsdfPdf = b.w, dTreePdf = c.w;
                 F3 radiance = f3(e.x, e.y, e.z), bsdfVal = f3(c.x, c.y, c.z), throughput = f3(b.x, b.y, b.z);
                 unsigned int bits = __float_as_uint(e.w);
-                if (!(woPdf > 0) || !isvalid3(radiance) || !isvalid3(bsdfVal)) continue;
-                F3 localRadiance = f3s(0.0f);
-                if (throughput.x * woPdf > PPG_EPSILON) localRadiance.x = radiance.x / throughput.x;
-                if (throughput.y * woPdf > PPG_EPSILON) localRadiance.y = radiance.y / throughput.y;
-                if (throughput.z * woPdf > PPG_EPSILON) localRadiance.z = radiance.z / throughput.z;
-                F3 product = mul3(localRadiance, bsdfVal);
-                Rec rec;
-                rec.d = f3(a.x, a.y, a.z);
-                rec.radiance = avg3(localRadiance); rec.product = avg3(product);
-                rec.woPdf = woPdf; rec.bsdfPdf = bsdfPdf; rec.dTreePdf = dTreePdf;
-                rec.statisticalWeight = statisticalWeight;
-                rec.isDelta = (bits & 0x80000000u) != 0;
-                const int leaf = (int)(bits & 0x7fffffffu);
-                if (R.spatial_filter == SF_NEAREST) {
-                    wrapper_record(T, leaf, rec, R.directional_filter, loss);
+                if (!(woPdf > 0) || !isvalid3(radiance) || !isvalid3(bsdfVal)) {
+                    act = false;
                 } else {
-                    float4 o4 = P.v_o[vi], x4 = P.v_vox[vi];
-                    F3 ro = f3(o4.x, o4.y, o4.z), vox = f3(x4.x, x4.y, x4.z);
-                    if (R.spatial_filter == SF_STOCHASTIC) {  // GP:1746-1763
-                        F3 offset = vox;
-                        offset.x *= ppg_rand(key, dim++) - 0.5f;
-                        offset.y *= ppg_rand(key, dim++) - 0.5f;
-                        offset.z *= ppg_rand(key, dim++) - 0.5f;
-                        F3 og = ro + offset;
-                        og.x = ppg_min(ppg_max(og.x, T.aabb_min[0]), T.aabb_max[0]);  // AABB::clip
-                        og.y = ppg_min(ppg_max(og.y, T.aabb_min[1]), T.aabb_max[1]);
-                        og.z = ppg_min(ppg_max(og.z, T.aabb_min[2]), T.aabb_max[2]);
-                        F3 dummy;
-                        int splat = stree_lookup(T, og, dummy);
-                        wrapper_record(T, splat, rec, R.directional_filter, loss);
-                    } else {
-                        stree_record_box(T, ro, vox, rec, R.directional_filter, loss);
-                    }
+                    F3 localRadiance = f3s(0.0f);
+                    if (throughput.x * woPdf > PPG_EPSILON) localRadiance.x = radiance.x / throughput.x;
+                    if (throughput.y * woPdf > PPG_EPSILON) localRadiance.y = radiance.y / throughput.y;
+                    if (throughput.z * woPdf > PPG_EPSILON) localRadiance.z = radiance.z / throughput.z;
+                    F3 product = mul3(localRadiance, bsdfVal);
+                    rec.d = f3(a.x, a.y, a.z);
+                    rec.radiance = avg3(localRadiance); rec.product = avg3(product);
+                    rec.woPdf = woPdf; rec.bsdfPdf = bsdfPdf; rec.dTreePdf = dTreePdf;
+                    rec.isDelta = (bits & 0x80000000u) != 0;
+                    leaf = (int)(bits & 0x7fffffffu);
+                    ++committed;
                 }
-                ++committed;
+            }
+            if (R.spatial_filter == SF_BOX) {
+                if (act) {
+                    float4 o4 = P.v_o[vi], x4 = P.v_vox[vi];
+                    stree_record_box(T, f3(o4.x, o4.y, o4.z), f3(x4.x, x4.y, x4.z), rec, R.directional_filter, loss);
+                }
+            } else {
+                if (act && R.spatial_filter == SF_STOCHASTIC) {  // GP:1746-1763
+                    float4 o4 = P.v_o[vi], x4 = P.v_vox[vi];
+                    F3 offset = f3(x4.x, x4.y, x4.z);
+                    offset.x *= ppg_rand(key, dim++) - 0.5f;
+                    offset.y *= ppg_rand(key, dim++) - 0.5f;
+                    offset.z *= ppg_rand(key, dim++) - 0.5f;
+                    F3 og = f3(o4.x, o4.y, o4.z) + offset;
+                    og.x = ppg_min(ppg_max(og.x, T.aabb_min[0]), T.aabb_max[0]);  // AABB::clip
+                    og.y = ppg_min(ppg_max(og.y, T.aabb_min[1]), T.aabb_max[1]);
+                    og.z = ppg_min(ppg_max(og.z, T.aabb_min[2]), T.aabb_max[2]);
+                    F3 dummy;
+                    leaf = stree_lookup(T, og, dummy);
+                }
+                wrapper_record<true>(T, leaf, rec, R.directional_filter, loss, act);
             }
         }
-        wave_add_u64(&C->committed, committed);
+        committed_sum += committed;
     }
+    block_add_u64(&acc, &Q.stats[blockIdx.x].committed, committed_sum);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -710,7 +902,8 @@ __global__ void k_query_pdf(DevTree T, unsigned int n, const float *pos, const f
     int leaf = stree_lookup(T, f3(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]), vox);
     float cx, cy;
     dir_to_canonical(f3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]), cx, cy);
-    out[i] = dtree_pdf(T, T.hdr[leaf], cx, cy);
+    RegColumn col;
+    out[i] = dtree_pdf<RegColumn &>(T, T.hdr[leaf], cx, cy, col);
 }
 __global__ void k_query_sample(DevTree T, unsigned int n, const float *pos, unsigned long long seed, float *out) {
     unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -14,7 +14,8 @@ _PKG = os.path.dirname(_HERE)
 
 
 def hip_library_path():
-    return os.path.join(_PKG, "lib", "libppg_hip.so")
+    # PPG_HIP_LIB selects an alternative build of the same library (kernel tuning A/B runs)
+    return os.environ.get("PPG_HIP_LIB") or os.path.join(_PKG, "lib", "libppg_hip.so")
 
 
 class PPGError(RuntimeError):
