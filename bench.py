@@ -53,12 +53,13 @@ def run(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if args.gpus > 1:
+    if args.gpus > 1 or args.force_dist:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl")
         assert dist.get_world_size() == args.gpus, "launch with --nproc-per-node == --gpus"
+        world = dist.get_world_size()
     import torch  # noqa: F811  (device sync + barrier plumbing only)
 
     spp = args.spp
@@ -73,7 +74,7 @@ def run(args):
         if timing:
             e.enable_kernel_timing(True)
         red = None
-        if world > 1:
+        if dist is not None:
             from ppg_host.distributed import TorchReducer
             red = TorchReducer(dist, torch.device("cuda", local_rank))
         return ppg_host.GuidedPathTracer(engine=e, reducer=red)
@@ -161,6 +162,7 @@ def main():
     ap.add_argument("--cpu-passes", type=int, default=7, help="passes timed on the CPU baseline (bounded sample)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the reducer even with one rank (plumbing check)")
     run(ap.parse_args())
 
 

@@ -6,6 +6,10 @@
  * are not reproducible even between two runs of the reference).  Here the n-th draw of a path is a
  * pure function of (seed, pixel, sample index, n): next1D() = ppg_rand(key, dim++), next2D() =
  * (ppg_rand(key, dim), ppg_rand(key, dim+1)), in the same call order as the reference's Li().
+ * The three draws of the stochastic spatial filter for recorded vertex i (GP:1753-1755) use dimensions
+ * D + 3i .. D + 3i + 2, D = the path's draw count when Li's loop ended (the reference draws them from the
+ * stream in vertex order, skipping invalid vertices; any fixed assignment is statistically equivalent and
+ * this one lets vertices be committed independently).
  * Floats are built from 23 random mantissa bits like random.cpp:630-639.
  */
 #ifndef PPG_RNG_H

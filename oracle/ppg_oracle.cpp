@@ -1463,7 +1463,9 @@ public:
         pc.pathLen += (uint64_t)depth;  // avgPathLength += rRec.depth, GP:2147-2148
 
         if (nVertices > 0 && !m_isFinalIter) {  // GP:2150-2154
+            const uint32_t dimEnd = sampler.dim;
             for (int i = 0; i < nVertices; ++i) {
+                sampler.dim = dimEnd + 3u * (uint32_t)i;  // sampler contract: the commit draws of vertex i (ppg_rng.h)
                 bool ok = vertices[i].commit(*m_sdTree, m_nee == EKickstart && m_doNee ? 0.5f : 1.0f, m_spatialFilter,
                                              m_directionalFilter, m_isBuilt ? m_bsdfSamplingFractionLoss : ENone, &sampler, modes);
                 if (ok) pc.committed++;

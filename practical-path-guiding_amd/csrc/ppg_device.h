@@ -287,9 +287,15 @@ struct DevTree {
     const SNode *snodes;          // sampling pool
     const ushort4 *bchild;        // building pool topology
     unsigned long long *bacc;     // building pool accumulators [node*4 + slot], 2^-24 fixed point
-    unsigned long long *bweight;  // per S-tree node: building statistical weight accumulator
+    unsigned long long *bweight;  // per S-tree node: building statistical weight accumulator (folded, see *_rep)
     long long *adam_grad;         // per S-tree node: per-pass Σ gradient·weight (2^-20)
     unsigned long long *adam_w;   // per S-tree node: per-pass Σ weight (2^-24)
+    // Replicated accumulation targets [node * PPG_REPLICAS + r]: a popular S-tree leaf receives several percent of all
+    // records of a pass and one address sustains only ~90 atomics/µs; workgroups spread over the replicas,
+    // k_fold_replicas adds them into the compact arrays above (integer sums: exact).
+    unsigned long long *bweight_rep;
+    unsigned long long *adam_grad_rep;
+    unsigned long long *adam_w_rep;
     float aabb_min[3], aabb_ext[3];  // cubified AABB (GP:857-859)
     float aabb_max[3];
     int is_built;
@@ -298,6 +304,7 @@ struct DevTree {
     // min(3*GRID_BITS, depth of the leaf) levels | levels << 27.  One read replaces up to 18 dependent ones.
     const unsigned int *grid;
 };
+#define PPG_REPLICAS 32
 #define PPG_GRID_BITS 6
 #define PPG_GRID_DIM (1 << PPG_GRID_BITS)
 #define PPG_GRID_LEVELS (3 * PPG_GRID_BITS)

@@ -249,7 +249,7 @@ struct ppg_ctx {
     int cur = 0;  // d_snodes[cur] = sampling pool
     size_t nSamplingNodes = 0, nBuildingNodes = 0;
     DevBuf<ushort4> d_bchild;
-    DevBuf<unsigned long long> d_bacc, d_bweight, d_adamW, d_total;
+    DevBuf<unsigned long long> d_bacc, d_bweight, d_adamW, d_total, d_bweightRep, d_adamGradRep, d_adamWRep;
     DevBuf<long long> d_adamGrad;
     DevBuf<unsigned int> d_leaves, d_counts, d_offsets, d_grid;
     int ldsNodes = 0, ldsTris = 0;  // scene part cached in LDS by k_trace
@@ -266,6 +266,7 @@ struct ppg_ctx {
         DevTree T{};
         T.stree = d_stree.p; T.hdr = d_hdr.p; T.snodes = d_snodes[cur].p; T.bchild = d_bchild.p; T.bacc = d_bacc.p;
         T.bweight = d_bweight.p; T.adam_grad = d_adamGrad.p; T.adam_w = d_adamW.p;
+        T.bweight_rep = d_bweightRep.p; T.adam_grad_rep = d_adamGradRep.p; T.adam_w_rep = d_adamWRep.p;
         for (int a = 0; a < 3; ++a) { T.aabb_min[a] = treeMin[a]; T.aabb_ext[a] = treeExt[a]; T.aabb_max[a] = treeMax[a]; }
         T.is_built = isBuilt ? 1 : 0;
         T.grid = d_grid.p;
@@ -323,6 +324,13 @@ int uploadTree(ppg_ctx *ctx) {
     HIP_CHECK(hipMemsetAsync(ctx->d_bweight.p, 0, n * 8, ctx->stream));
     HIP_CHECK(hipMemsetAsync(ctx->d_adamW.p, 0, n * 8, ctx->stream));
     HIP_CHECK(hipMemsetAsync(ctx->d_adamGrad.p, 0, n * 8, ctx->stream));
+    HIP_CHECK(ctx->d_bweightRep.reserve(n * PPG_REPLICAS));
+    HIP_CHECK(hipMemsetAsync(ctx->d_bweightRep.p, 0, n * PPG_REPLICAS * 8, ctx->stream));
+    if (ctx->loss != LOSS_NONE) {
+        HIP_CHECK(ctx->d_adamGradRep.reserve(n * PPG_REPLICAS)); HIP_CHECK(ctx->d_adamWRep.reserve(n * PPG_REPLICAS));
+        HIP_CHECK(hipMemsetAsync(ctx->d_adamGradRep.p, 0, n * PPG_REPLICAS * 8, ctx->stream));
+        HIP_CHECK(hipMemsetAsync(ctx->d_adamWRep.p, 0, n * PPG_REPLICAS * 8, ctx->stream));
+    }
     if (n >= (1u << 27)) { ctx->error = "S-tree exceeds 2^27 nodes"; return PPG_ERR_NOMEM; }
     const unsigned int cells = PPG_GRID_DIM * PPG_GRID_DIM * PPG_GRID_DIM;
     HIP_CHECK(ctx->d_grid.reserve(cells));
@@ -401,7 +409,16 @@ int resetSDTree(ppg_ctx *ctx) {  // GP:1108-1113
     return PPG_OK;
 }
 
+int foldWeights(ppg_ctx *ctx) {
+    unsigned int nn = (unsigned int)ctx->snodes.size();
+    if (!ctx->d_bweightRep.p || nn == 0) return PPG_OK;
+    hipLaunchKernelGGL(k_fold_replicas, dim3((nn + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_bweight.p, ctx->d_bweightRep.p, nn);
+    HIP_CHECK(hipGetLastError());
+    return PPG_OK;
+}
+
 int buildSDTree(ppg_ctx *ctx, ppg_tree_stats *st) {  // GP:1115-1189
+    { int rc = foldWeights(ctx); if (rc) return rc; }
     unsigned int nl = (unsigned int)ctx->leaves.size();
     DevTree T = ctx->devTree();
     int blocks = (int)((nl + 127) / 128);
@@ -528,7 +545,17 @@ int renderOnePass(ppg_ctx *ctx) {
     }
     // the last shade of a bounded schedule terminates every path (depth >= maxDepth), no trailing trace needed
     if (!ctx->isFinalIter) {
-        timedLaunch(ctx, "k_commit", P.n_paths, [&] { hipLaunchKernelGGL(k_commit, dim3(grid), dim3(PPG_BLOCK), 0, s, P, T, R, Q); });
+        timedLaunch(ctx, "k_commit", P.n_paths, [&] {
+#define PPG_COMMIT(SFV, DFV) hipLaunchKernelGGL((k_commit<SFV, DFV>), dim3(grid), dim3(PPG_BLOCK), 0, s, P, T, R, Q)
+            const int sf = ctx->spatialFilter, df = ctx->directionalFilter;
+            if (sf == SF_NEAREST && df == DF_NEAREST) PPG_COMMIT(SF_NEAREST, DF_NEAREST);
+            else if (sf == SF_NEAREST) PPG_COMMIT(SF_NEAREST, DF_BOX);
+            else if (sf == SF_STOCHASTIC && df == DF_NEAREST) PPG_COMMIT(SF_STOCHASTIC, DF_NEAREST);
+            else if (sf == SF_STOCHASTIC) PPG_COMMIT(SF_STOCHASTIC, DF_BOX);
+            else if (df == DF_NEAREST) PPG_COMMIT(SF_BOX, DF_NEAREST);
+            else PPG_COMMIT(SF_BOX, DF_BOX);
+#undef PPG_COMMIT
+        });
         if (ctx->loss != LOSS_NONE && ctx->isBuilt) {
             unsigned int nn = (unsigned int)ctx->snodes.size();
             hipLaunchKernelGGL(k_adam_step, dim3((nn + 255) / 256), dim3(256), 0, s, T, nn);
@@ -1038,6 +1065,7 @@ int ppg_sdtree_read_dtree_headers(ppg_ctx *ctx, int32_t which, uint64_t *offset,
     NEED_TREE
     std::vector<LeafHdr> dh(ctx->hdr.size());
     std::vector<unsigned long long> bw(ctx->hdr.size(), 0);
+    { int rc = foldWeights(ctx); if (rc) return rc; }
     if (ctx->d_hdr.p) {
         HIP_CHECK(hipMemcpy(dh.data(), ctx->d_hdr.p, dh.size() * sizeof(LeafHdr), hipMemcpyDeviceToHost));
         HIP_CHECK(hipMemcpy(bw.data(), ctx->d_bweight.p, bw.size() * 8, hipMemcpyDeviceToHost));
@@ -1079,6 +1107,7 @@ int ppg_sdtree_read_adam(ppg_ctx *ctx, float *theta) {
 
 int ppg_sdtree_stat_buffers(ppg_ctx *ctx, void **dev_sums, uint64_t *n_sums, void **dev_weights, uint64_t *n_weights) {
     NEED_TREE
+    { int rc = foldWeights(ctx); if (rc) return rc; }
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
     *dev_sums = ctx->d_bacc.p; *n_sums = ctx->nBuildingNodes * 4;
     *dev_weights = ctx->d_bweight.p; *n_weights = ctx->snodes.size();

@@ -495,7 +495,11 @@ D void dtree_record(const DevTree &T, int leaf, float px, float py, float irradi
             unsigned int w32 = (index & 2) ? cw.y : cw.x;
             unsigned int c = (index & 1) ? (w32 >> 16) : (w32 & 0xffffu);
             if (c == 0) {
+#if !(defined(PPG_ABLATE) && PPG_ABLATE == 4)
                 atomicAdd(&T.bacc[(size_t)(base + node) * 4 + index], ppg_to_fixed(irradiance * w));
+#else
+                if (irradiance == 123.456f) T.bacc[0] = 1;
+#endif
                 break;
             }
             node = c;
@@ -563,8 +567,12 @@ D void wrapper_record(const DevTree &T, int leaf, const Rec &rec, int dfilter, i
     }
     const bool wOk = irr && ppg_isfinite(rec.statisticalWeight) && rec.statisticalWeight > 0;
     const unsigned long long wf = wOk ? ppg_to_fixed(rec.statisticalWeight) : 0ull;
-    if (COMBINE) wave_key_add<3>(T.bweight, (unsigned int)leaf, wf, wOk);
-    else if (wOk) atomicAdd(&T.bweight[leaf], wf);
+#if defined(PPG_ABLATE) && PPG_ABLATE == 5
+    if (wf == 12345ull) T.bweight[0] = 1;
+#else
+    if (COMBINE) wave_key_add<3>(T.bweight_rep, (unsigned int)leaf * PPG_REPLICAS + (blockIdx.x & (PPG_REPLICAS - 1)), wf, wOk);
+#endif
+    else if (wOk) atomicAdd(&T.bweight_rep[(size_t)leaf * PPG_REPLICAS + (blockIdx.x & (PPG_REPLICAS - 1))], wf);
     if (wOk) dtree_record(T, leaf, px, py, irradiance, rec.statisticalWeight, dfilter);
 
     const bool adam = active && loss != LOSS_NONE && rec.product > 0;
@@ -583,12 +591,13 @@ D void wrapper_record(const DevTree &T, int leaf, const Rec &rec, int dfilter, i
             g = (unsigned long long)ppg_to_sfixed(lossGradient * rec.statisticalWeight);
             w = ppg_to_fixed(rec.statisticalWeight);
         }
+        const unsigned int rk = (unsigned int)leaf * PPG_REPLICAS + (blockIdx.x & (PPG_REPLICAS - 1));
         if (COMBINE) {
-            wave_key_add<3>((unsigned long long *)T.adam_grad, (unsigned int)leaf, g, adam);
-            wave_key_add<3>(T.adam_w, (unsigned int)leaf, w, adam);
+            wave_key_add<3>(T.adam_grad_rep, rk, g, adam);
+            wave_key_add<3>(T.adam_w_rep, rk, w, adam);
         } else if (adam) {
-            atomicAdd((unsigned long long *)&T.adam_grad[leaf], g);
-            atomicAdd(&T.adam_w[leaf], w);
+            atomicAdd(&T.adam_grad_rep[rk], g);
+            atomicAdd(&T.adam_w_rep[rk], w);
         }
     }
 }
@@ -629,74 +638,76 @@ D void stree_record_box(const DevTree &T, F3 p, F3 vox, Rec rec, int dfilter, in
 // ------------------------------------------------------------------------------------------------
 // k_commit — Vertex::commit for every recorded vertex of every path (GP:1730-1768, 2150-2154)
 // ------------------------------------------------------------------------------------------------
+// Work item w = (vertex slot v, path i), slot-major: a wave handles the same slot of 64 neighbouring paths, whose
+// vertices tend to lie in the same S-tree leaf (so the per-leaf counters combine) and whose loads coalesce.
+// The stochastic filter's three draws for slot v use sampler dimensions dim_end + 3v .. +2 (dim_end = the
+// path's dimension counter when Li returned) — the same rule as the oracle.
+template <int SF, int DF>
 __global__ __launch_bounds__(PPG_BLOCK) void k_commit(PathState P, DevTree T, RenderParams R, Queues Q) {
     __shared__ unsigned long long acc;
     unsigned long long committed_sum = 0;
-    unsigned int total = gridDim.x * blockDim.x;
-    unsigned int rounds = (P.n_paths + total - 1) / total;
     const float statisticalWeight = (R.nee == NEE_KICKSTART && R.do_nee) ? 0.5f : 1.0f;
     const int loss = T.is_built ? R.loss : LOSS_NONE;
-    for (unsigned int r = 0; r < rounds; ++r) {
-        unsigned int i = r * total + blockIdx.x * blockDim.x + threadIdx.x;
-        unsigned long long committed = 0;
-        unsigned int key = 0, dim = 0, nV = 0;
-        if (i < P.n_paths) {
+    const unsigned long long items = (unsigned long long)R.max_vertices * P.n_paths;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long w0 = (unsigned long long)blockIdx.x * blockDim.x; w0 < items; w0 += stride) {
+        const unsigned long long w = w0 + threadIdx.x;
+        bool act = w < items;
+        unsigned int v = 0, i = 0, key = 0, dim = 0;
+        if (act) {
+            v = (unsigned int)(w / P.n_paths); i = (unsigned int)(w % P.n_paths);
             uint4 m = P.misc[i];
-            key = m.x; dim = m.y;
-            nV = (m.z & FL_NV_MASK) >> FL_NV_SHIFT;
+            key = m.x; dim = m.y + 3u * v;
+            act = v < ((m.z & FL_NV_MASK) >> FL_NV_SHIFT);
         }
-        // all lanes of the wave walk the vertex slots together (the per-D-tree counters are wave-combined)
-        for (unsigned int v = 0; __any(v < nV); ++v) {
-            bool act = v < nV;
-            Rec rec;
-            rec.d = f3s(0.0f); rec.radiance = rec.product = rec.woPdf = rec.bsdfPdf = rec.dTreePdf = 0; rec.statisticalWeight = statisticalWeight;
-            rec.isDelta = false;
-            int leaf = 0;
-            size_t vi = (size_t)v * P.n_paths + i;
-            if (act) {
-                float4 a = P.v_d[vi], b = P.v_thr[vi], c = P.v_bsdf[vi], e = P.v_rad[vi];
-                const float woPdf = a.w, bsdfPdf = b.w, dTreePdf = c.w;
-                F3 radiance = f3(e.x, e.y, e.z), bsdfVal = f3(c.x, c.y, c.z), throughput = f3(b.x, b.y, b.z);
-                unsigned int bits = __float_as_uint(e.w);
-                if (!(woPdf > 0) || !isvalid3(radiance) || !isvalid3(bsdfVal)) {
-                    act = false;
-                } else {
-                    F3 localRadiance = f3s(0.0f);
-                    if (throughput.x * woPdf > PPG_EPSILON) localRadiance.x = radiance.x / throughput.x;
-                    if (throughput.y * woPdf > PPG_EPSILON) localRadiance.y = radiance.y / throughput.y;
-                    if (throughput.z * woPdf > PPG_EPSILON) localRadiance.z = radiance.z / throughput.z;
-                    F3 product = mul3(localRadiance, bsdfVal);
-                    rec.d = f3(a.x, a.y, a.z);
-                    rec.radiance = avg3(localRadiance); rec.product = avg3(product);
-                    rec.woPdf = woPdf; rec.bsdfPdf = bsdfPdf; rec.dTreePdf = dTreePdf;
-                    rec.isDelta = (bits & 0x80000000u) != 0;
-                    leaf = (int)(bits & 0x7fffffffu);
-                    ++committed;
-                }
-            }
-            if (R.spatial_filter == SF_BOX) {
-                if (act) {
-                    float4 o4 = P.v_o[vi], x4 = P.v_vox[vi];
-                    stree_record_box(T, f3(o4.x, o4.y, o4.z), f3(x4.x, x4.y, x4.z), rec, R.directional_filter, loss);
-                }
+        if (!__any(act)) continue;
+        Rec rec;
+        rec.d = f3s(0.0f); rec.radiance = rec.product = rec.woPdf = rec.bsdfPdf = rec.dTreePdf = 0; rec.statisticalWeight = statisticalWeight;
+        rec.isDelta = false;
+        int leaf = 0;
+        const size_t vi = (size_t)v * P.n_paths + i;
+        if (act) {
+            float4 a = P.v_d[vi], b = P.v_thr[vi], c = P.v_bsdf[vi], e = P.v_rad[vi];
+            const float woPdf = a.w, bsdfPdf = b.w, dTreePdf = c.w;
+            F3 radiance = f3(e.x, e.y, e.z), bsdfVal = f3(c.x, c.y, c.z), throughput = f3(b.x, b.y, b.z);
+            unsigned int bits = __float_as_uint(e.w);
+            if (!(woPdf > 0) || !isvalid3(radiance) || !isvalid3(bsdfVal)) {
+                act = false;
             } else {
-                if (act && R.spatial_filter == SF_STOCHASTIC) {  // GP:1746-1763
-                    float4 o4 = P.v_o[vi], x4 = P.v_vox[vi];
-                    F3 offset = f3(x4.x, x4.y, x4.z);
-                    offset.x *= ppg_rand(key, dim++) - 0.5f;
-                    offset.y *= ppg_rand(key, dim++) - 0.5f;
-                    offset.z *= ppg_rand(key, dim++) - 0.5f;
-                    F3 og = f3(o4.x, o4.y, o4.z) + offset;
-                    og.x = ppg_min(ppg_max(og.x, T.aabb_min[0]), T.aabb_max[0]);  // AABB::clip
-                    og.y = ppg_min(ppg_max(og.y, T.aabb_min[1]), T.aabb_max[1]);
-                    og.z = ppg_min(ppg_max(og.z, T.aabb_min[2]), T.aabb_max[2]);
-                    F3 dummy;
-                    leaf = stree_lookup(T, og, dummy);
-                }
-                wrapper_record<true>(T, leaf, rec, R.directional_filter, loss, act);
+                F3 localRadiance = f3s(0.0f);
+                if (throughput.x * woPdf > PPG_EPSILON) localRadiance.x = radiance.x / throughput.x;
+                if (throughput.y * woPdf > PPG_EPSILON) localRadiance.y = radiance.y / throughput.y;
+                if (throughput.z * woPdf > PPG_EPSILON) localRadiance.z = radiance.z / throughput.z;
+                F3 product = mul3(localRadiance, bsdfVal);
+                rec.d = f3(a.x, a.y, a.z);
+                rec.radiance = avg3(localRadiance); rec.product = avg3(product);
+                rec.woPdf = woPdf; rec.bsdfPdf = bsdfPdf; rec.dTreePdf = dTreePdf;
+                rec.isDelta = (bits & 0x80000000u) != 0;
+                leaf = (int)(bits & 0x7fffffffu);
+                ++committed_sum;
             }
         }
-        committed_sum += committed;
+        if (SF == SF_BOX) {
+            if (act) {
+                float4 o4 = P.v_o[vi], x4 = P.v_vox[vi];
+                stree_record_box(T, f3(o4.x, o4.y, o4.z), f3(x4.x, x4.y, x4.z), rec, DF, loss);
+            }
+        } else {
+            if (SF == SF_STOCHASTIC && act) {  // GP:1746-1763
+                float4 o4 = P.v_o[vi], x4 = P.v_vox[vi];
+                F3 offset = f3(x4.x, x4.y, x4.z);
+                offset.x *= ppg_rand(key, dim++) - 0.5f;
+                offset.y *= ppg_rand(key, dim++) - 0.5f;
+                offset.z *= ppg_rand(key, dim++) - 0.5f;
+                F3 og = f3(o4.x, o4.y, o4.z) + offset;
+                og.x = ppg_min(ppg_max(og.x, T.aabb_min[0]), T.aabb_max[0]);  // AABB::clip
+                og.y = ppg_min(ppg_max(og.y, T.aabb_min[1]), T.aabb_max[1]);
+                og.z = ppg_min(ppg_max(og.z, T.aabb_min[2]), T.aabb_max[2]);
+                F3 dummy;
+                leaf = stree_lookup(T, og, dummy);
+            }
+            wrapper_record<true>(T, leaf, rec, DF, loss, act);
+        }
     }
     block_add_u64(&acc, &Q.stats[blockIdx.x].committed, committed_sum);
 }
@@ -704,10 +715,30 @@ __global__ __launch_bounds__(PPG_BLOCK) void k_commit(PathState P, DevTree T, Re
 // ------------------------------------------------------------------------------------------------
 // k_adam_step — one AdamOptimizer::step (GP:97-109) per D-tree and pass from the exact per-pass sums
 // ------------------------------------------------------------------------------------------------
+// compact[i] += Σ_r rep[i][r]; rep = 0.  Idempotent (a second call adds zeros).
+__global__ void k_fold_replicas(unsigned long long *compact, unsigned long long *rep, unsigned int n_nodes) {
+    unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    unsigned long long s = 0;
+    for (int r = 0; r < PPG_REPLICAS; ++r) {
+        unsigned long long v = rep[(size_t)i * PPG_REPLICAS + r];
+        if (v) { s += v; rep[(size_t)i * PPG_REPLICAS + r] = 0; }
+    }
+    if (s) compact[i] += s;
+}
+
 __global__ void k_adam_step(DevTree T, unsigned int n_nodes) {
     unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_nodes) return;
-    unsigned long long wacc = T.adam_w[i];
+    unsigned long long wacc = 0, gacc = 0;
+    for (int r = 0; r < PPG_REPLICAS; ++r) {
+        unsigned long long w = T.adam_w_rep[(size_t)i * PPG_REPLICAS + r];
+        if (w) {
+            wacc += w; gacc += T.adam_grad_rep[(size_t)i * PPG_REPLICAS + r];
+            T.adam_w_rep[(size_t)i * PPG_REPLICAS + r] = 0; T.adam_grad_rep[(size_t)i * PPG_REPLICAS + r] = 0;
+        }
+    }
+    T.adam_grad[i] = (long long)gacc;
     if (wacc == 0) return;
     float w = ppg_from_fixed(wacc);
     if (w > 1.0f) {  // batchAccumulation > batchSize
