@@ -220,6 +220,7 @@ struct ppg_ctx {
 
     // shard
     int shardRank = 0, shardWorld = 1, tileSize = 32;
+    bool pathsReady = false;
     DevBuf<unsigned int> d_pixels;
     unsigned int nPix = 0;
 
@@ -496,7 +497,7 @@ int allocPaths(ppg_ctx *ctx) {
     HIP_CHECK(ctx->d_stats.reserve(nb)); HIP_CHECK(ctx->d_qtotal.reserve(1));
     ctx->queues.items[0] = ctx->d_queue[0].p; ctx->queues.items[1] = ctx->d_queue[1].p;
     ctx->queues.count[0] = ctx->d_qcount[0].p; ctx->queues.count[1] = ctx->d_qcount[1].p;
-    ctx->queues.cap = (unsigned int)cap; ctx->queues.stats = ctx->d_stats.p;
+    ctx->queues.cap = (unsigned int)cap; ctx->queues.stats = ctx->d_stats.p; ctx->queues.n_blocks = (unsigned int)nb;
     size_t nv = nn * (size_t)ctx->maxVertices;
     HIP_CHECK(ctx->d_vd.reserve(nv)); HIP_CHECK(ctx->d_vthr.reserve(nv)); HIP_CHECK(ctx->d_vbsdf.reserve(nv)); HIP_CHECK(ctx->d_vrad.reserve(nv));
     if (ctx->spatialFilter != SF_NEAREST) { HIP_CHECK(ctx->d_vo.reserve(nv)); HIP_CHECK(ctx->d_vvox.reserve(nv)); }
@@ -520,20 +521,32 @@ int renderOnePass(ppg_ctx *ctx) {
     const int grid = ctx->nBlocks;
     const int gridAll = gridFor(P.n_paths);
     hipStream_t s = ctx->stream;
-    timedLaunch(ctx, "k_generate", P.n_paths, [&] { hipLaunchKernelGGL(k_generate, dim3(gridAll), dim3(PPG_BLOCK), 0, s, P, S, R); });
+    const bool smallScene = ctx->scene.n_tris <= 64 && ctx->ldsTris == ctx->scene.n_tris && !getenv("PPG_FORCE_BVH");
+    // Tracing inside k_generate / k_shade (no k_trace launch, no ray/hit round trip) was measured SLOWER on MI355X
+    // (cbox-720p, 63 passes: 184 ms vs 172 ms for generate+trace+shade): the fused kernel needs 142 VGPRs (3 waves/SIMD)
+    // and only the surviving lanes trace.  Kept selectable for re-measurement on other scenes.
+    const bool fused = smallScene && getenv("PPG_FUSE");
+    const size_t triBytes = (size_t)ctx->scene.n_tris * 48;
+    timedLaunch(ctx, "k_generate", P.n_paths, [&] {
+        if (fused) hipLaunchKernelGGL(k_generate<true>, dim3(gridAll), dim3(PPG_BLOCK), triBytes, s, P, S, R, Q);
+        else hipLaunchKernelGGL(k_generate<false>, dim3(gridAll), dim3(PPG_BLOCK), 0, s, P, S, R, Q);
+    });
     // bounce 1 works on all paths (no queue); afterwards the two queue sets alternate
     int qin = -1;
     const int maxBounces = ctx->maxDepth > 0 ? ctx->maxDepth : 1 << 20;
     unsigned int hostCount = P.n_paths;
-    const bool smallScene = ctx->scene.n_tris <= 64 && ctx->ldsTris == ctx->scene.n_tris && !getenv("PPG_FORCE_BVH");
     const size_t ldsBytes = (smallScene ? 0 : (size_t)ctx->ldsNodes * 64) + (size_t)ctx->ldsTris * 48;
     for (int b = 0; b < maxBounces; ++b) {
         int qout = b & 1;
-        timedLaunch(ctx, "k_trace", hostCount, [&] {
-            if (smallScene) hipLaunchKernelGGL(k_trace<true>, dim3(grid), dim3(PPG_BLOCK), ldsBytes, s, P, S, Q, qin, 0, ctx->ldsTris);
-            else hipLaunchKernelGGL(k_trace<false>, dim3(grid), dim3(PPG_BLOCK), ldsBytes, s, P, S, Q, qin, ctx->ldsNodes, ctx->ldsTris);
+        if (!fused)
+            timedLaunch(ctx, "k_trace", hostCount, [&] {
+                if (smallScene) hipLaunchKernelGGL(k_trace<true>, dim3(grid), dim3(PPG_BLOCK), ldsBytes, s, P, S, Q, qin, 0, ctx->ldsTris);
+                else hipLaunchKernelGGL(k_trace<false>, dim3(grid), dim3(PPG_BLOCK), ldsBytes, s, P, S, Q, qin, ctx->ldsNodes, ctx->ldsTris);
+            });
+        timedLaunch(ctx, fused ? "k_shade<fused>" : "k_shade", hostCount, [&] {
+            if (fused) hipLaunchKernelGGL(k_shade<true>, dim3(grid), dim3(PPG_BLOCK), triBytes, s, P, S, T, R, Q, qin, qout);
+            else hipLaunchKernelGGL(k_shade<false>, dim3(grid), dim3(PPG_BLOCK), 0, s, P, S, T, R, Q, qin, qout);
         });
-        timedLaunch(ctx, "k_shade", hostCount, [&] { hipLaunchKernelGGL(k_shade, dim3(grid), dim3(PPG_BLOCK), 0, s, P, S, T, R, Q, qin, qout); });
         qin = qout;
         // unbounded paths (maxDepth < 0) and kernel timing need the live count; bounded paths run a fixed schedule without a sync
         if (ctx->maxDepth < 0 || ctx->timer.enabled) {
@@ -623,10 +636,22 @@ int finishPasses(ppg_ctx *ctx, ppg_pass_stats *st) {  // GP:1288-1328
     return PPG_OK;
 }
 
+int allocFilm(ppg_ctx *ctx) {
+    size_t n = (size_t)ctx->W * ctx->H;
+    HIP_CHECK(ctx->d_image.reserve(3 * n)); HIP_CHECK(ctx->d_sq.reserve(3 * n)); HIP_CHECK(ctx->d_imageW.reserve(n));
+    HIP_CHECK(ctx->d_film.reserve(3 * n)); HIP_CHECK(ctx->d_filmW.reserve(n)); HIP_CHECK(ctx->d_var.reserve(3 * n));
+    HIP_CHECK(ctx->d_lum.reserve(n)); HIP_CHECK(ctx->d_tmp.reserve(3 * n));
+    return PPG_OK;
+}
+
 int beginRender(ppg_ctx *ctx) {  // GP:1519-1550
     HIP_CHECK(hipSetDevice(ctx->device));
-    int rc = allocPaths(ctx);
-    if (rc) return rc;
+    if (!ctx->pathsReady) {  // buffers are sized by scene + shard; normally done by ppg_set_scene / ppg_set_shard
+        int rc = allocPaths(ctx);
+        if (rc) return rc;
+        if ((rc = allocFilm(ctx))) return rc;
+        ctx->pathsReady = true;
+    }
     // new STree(scene->getAABB()), cubified (GP:850-860)
     float maxSize = 0;
     for (int a = 0; a < 3; ++a) maxSize = ppg_max(maxSize, ctx->aabbMax[a] - ctx->aabbMin[a]);
@@ -649,9 +674,6 @@ int beginRender(ppg_ctx *ctx) {  // GP:1519-1550
     ctx->nSamplingNodes = 1; ctx->nBuildingNodes = 0;
     ctx->iter = 0; ctx->isFinalIter = false; ctx->isBuilt = false;
     size_t n = (size_t)ctx->W * ctx->H;
-    HIP_CHECK(ctx->d_image.reserve(3 * n)); HIP_CHECK(ctx->d_sq.reserve(3 * n)); HIP_CHECK(ctx->d_imageW.reserve(n));
-    HIP_CHECK(ctx->d_film.reserve(3 * n)); HIP_CHECK(ctx->d_filmW.reserve(n)); HIP_CHECK(ctx->d_var.reserve(3 * n));
-    HIP_CHECK(ctx->d_lum.reserve(n)); HIP_CHECK(ctx->d_tmp.reserve(3 * n));
     HIP_CHECK(hipMemsetAsync(ctx->d_film.p, 0, 3 * n * 4, ctx->stream));
     HIP_CHECK(hipMemsetAsync(ctx->d_filmW.p, 0, n * 4, ctx->stream));
     HIP_CHECK(hipMemsetAsync(ctx->d_var.p, 0, 3 * n * 4, ctx->stream));
@@ -986,12 +1008,26 @@ int ppg_set_scene(ppg_ctx *ctx, const ppg_scene *s) {
     }
     ctx->haveScene = true;
     ctx->treeAlive = false;
+    ctx->pathsReady = false;
+    {   // scene preprocessing also sizes the per-pass buffers (path state, vertex slots, queues, film)
+        int rc = allocPaths(ctx);
+        if (rc) return rc;
+        if ((rc = allocFilm(ctx))) return rc;
+        ctx->pathsReady = true;
+    }
     return PPG_OK;
 }
 
 int ppg_set_shard(ppg_ctx *ctx, int32_t rank, int32_t world, int32_t tile_size) {
     if (world < 1 || rank < 0 || rank >= world || tile_size < 1) { ctx->error = "bad shard"; return PPG_ERR_INVALID; }
     ctx->shardRank = rank; ctx->shardWorld = world; ctx->tileSize = tile_size;
+    ctx->pathsReady = false;
+    if (ctx->haveScene) {
+        int rc = allocPaths(ctx);
+        if (rc) return rc;
+        if ((rc = allocFilm(ctx))) return rc;
+        ctx->pathsReady = true;
+    }
     return PPG_OK;
 }
 

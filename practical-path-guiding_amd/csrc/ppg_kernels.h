@@ -79,6 +79,7 @@ struct Queues {
     unsigned int *items[2];
     unsigned int *count[2];  // [n_blocks]
     unsigned int cap;        // entries per workgroup
+    unsigned int n_blocks;
     BlockStats *stats;       // [n_blocks]
 };
 
@@ -147,10 +148,40 @@ D void wave_key_add(unsigned long long *dst, unsigned int key, unsigned long lon
     if (active) atomicAdd(dst + key, val);
 }
 
+// Closest hit over `n_tris` triangles held in LDS, no BVH (small scenes): every lane reads the same triangle
+// (LDS broadcast), no divergence, no dependent memory chain; same (t, original index) minimum as the BVH.
+D Hit trace_small(const float4 *lds_tris, int n_tris, F3 o, F3 d, float rayMint, float maxt) {
+    float rayMinT = rayMint;
+    if (rayMinT == PPG_EPSILON)  // adaptive ray epsilon, skdtree.cpp:125-129
+        rayMinT *= ppg_max(ppg_max(ppg_max(ppg_abs(o.x), ppg_abs(o.y)), ppg_abs(o.z)), PPG_EPSILON);
+    Hit h;
+    h.t = __builtin_inff(); h.u = 0; h.v = 0; h.prim = -1;
+    int bestOrig = 0x7fffffff;
+    for (int k = 0; k < n_tris; ++k) {
+        float tt, uu, vv;
+        const float4 *Tk = lds_tris + 3 * k;
+        if (tri_hit(Tk, o, d, rayMinT, maxt, tt, uu, vv)) {
+            int orig = __float_as_int(Tk[2].w);
+            if (tt < h.t || (tt == h.t && orig < bestOrig)) { h.t = tt; h.u = uu; h.v = vv; h.prim = k; bestOrig = orig; }
+        }
+    }
+    return h;
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_generate — renderBlock's sample loop head (GP:1613-1630) + PerspectiveCamera::sampleRayDifferential
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(PPG_BLOCK) void k_generate(PathState P, DevScene S, RenderParams R) {
+// FUSED (small scenes): the camera ray is traced right here from the LDS copy of the scene.
+template <bool FUSED>
+__global__ __launch_bounds__(PPG_BLOCK) void k_generate(PathState P, DevScene S, RenderParams R, Queues Q) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    __shared__ unsigned long long acc;
+    const float4 *lds_tris = (const float4 *)lds_raw;
+    if (FUSED) {
+        for (int k = threadIdx.x; k < 3 * S.n_tris; k += blockDim.x) ((float4 *)lds_raw)[k] = S.tris[k];
+        __syncthreads();
+    }
+    unsigned int traced = 0;
     for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < P.n_paths; i += gridDim.x * blockDim.x) {
         unsigned int k = i % P.n_pix, j = i / P.n_pix;
         unsigned int pixel = P.pixels[k];
@@ -166,12 +197,19 @@ __global__ __launch_bounds__(PPG_BLOCK) void k_generate(PathState P, DevScene S,
         float mint = S.cam.near_clip * invZ, maxt = S.cam.far_clip * invZ;
         F3 o = f3(S.cam.c2w[3], S.cam.c2w[7], S.cam.c2w[11]);
         F3 d = xf_vec(S.cam.c2w, dl);
-        P.ray_o[i] = make_float4(o.x, o.y, o.z, mint);
+        if (FUSED) {
+            Hit h = trace_small(lds_tris, S.n_tris, o, d, mint, maxt);
+            P.hit[i] = make_float4(h.t, h.u, h.v, __int_as_float(h.prim));
+            ++traced;
+        } else {
+            P.ray_o[i] = make_float4(o.x, o.y, o.z, mint);
+        }
         P.ray_d[i] = make_float4(d.x, d.y, d.z, maxt);
         P.thr[i] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
         P.li[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         P.misc[i] = make_uint4(key, dim, 1u | FL_EMITTED_OK, 0u);
     }
+    if (FUSED) block_add_u64(&acc, &Q.stats[blockIdx.x % Q.n_blocks].rays, traced);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -202,22 +240,13 @@ __global__ __launch_bounds__(PPG_BLOCK) void k_trace(PathState P, DevScene S, Qu
         if (i >= P.n_paths) continue;
         float4 ro = P.ray_o[i], rd = P.ray_d[i];
         F3 o = f3(ro.x, ro.y, ro.z), d = f3(rd.x, rd.y, rd.z);
-        float rayMinT = ro.w;
-        if (rayMinT == PPG_EPSILON)  // adaptive ray epsilon
-            rayMinT *= ppg_max(ppg_max(ppg_max(ppg_abs(o.x), ppg_abs(o.y)), ppg_abs(o.z)), PPG_EPSILON);
         Hit h;
         if (SMALL) {
-            h.t = __builtin_inff(); h.u = 0; h.v = 0; h.prim = -1;
-            int bestOrig = 0x7fffffff;
-            for (int k = 0; k < lds_tris; ++k) {
-                float tt, uu, vv;
-                const float4 *Tk = L.tris + 3 * k;
-                if (tri_hit(Tk, o, d, rayMinT, rd.w, tt, uu, vv)) {
-                    int orig = __float_as_int(Tk[2].w);
-                    if (tt < h.t || (tt == h.t && orig < bestOrig)) { h.t = tt; h.u = uu; h.v = vv; h.prim = k; bestOrig = orig; }
-                }
-            }
+            h = trace_small(L.tris, lds_tris, o, d, ro.w, rd.w);
         } else {
+            float rayMinT = ro.w;
+            if (rayMinT == PPG_EPSILON)  // adaptive ray epsilon
+                rayMinT *= ppg_max(ppg_max(ppg_max(ppg_abs(o.x), ppg_abs(o.y)), ppg_abs(o.z)), PPG_EPSILON);
             h = trace_closest(S, L, o, d, rayMinT, rd.w);
         }
         P.hit[i] = make_float4(h.t, h.u, h.v, __int_as_float(h.prim));
@@ -247,7 +276,15 @@ __global__ void k_build_grid(const int4 *stree, unsigned int *grid) {
 // ------------------------------------------------------------------------------------------------
 // k_shade — Li's loop body (GP:1798-2146), surface branch, nee = never
 // ------------------------------------------------------------------------------------------------
+// FUSED (small scenes): the ray sampled here is traced here too (scene in LDS), k_trace is not launched.
+template <bool FUSED>
 __global__ __launch_bounds__(PPG_BLOCK, PPG_SHADE_WAVES) void k_shade(PathState P, DevScene S, DevTree T, RenderParams R, Queues Q, int qin, int qout) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const float4 *lds_tris = (const float4 *)lds_raw;
+    if (FUSED) {
+        for (int k = threadIdx.x; k < 3 * S.n_tris; k += blockDim.x) ((float4 *)lds_raw)[k] = S.tris[k];
+    }
+    unsigned int traced = 0;
     __shared__ float pdf_factors[20 * PPG_BLOCK];  // QuadTreeNode::pdf's per-level factors (tree depth <= 20, GP:1112)
     __shared__ unsigned int out_count;
     __shared__ unsigned long long acc;
@@ -428,7 +465,13 @@ __global__ __launch_bounds__(PPG_BLOCK, PPG_SHADE_WAVES) void k_shade(PathState 
                     if (go) {
                         thr = mul3(thr, bsdfWeight);  // GP:2039-2040 (eta *= 1)
                         d = wo;
-                        P.ray_o[i] = make_float4(I.p.x, I.p.y, I.p.z, PPG_EPSILON);
+                        if (FUSED) {
+                            Hit hn = trace_small(lds_tris, S.n_tris, I.p, wo, PPG_EPSILON, __builtin_inff());
+                            P.hit[i] = make_float4(hn.t, hn.u, hn.v, __int_as_float(hn.prim));
+                            ++traced;
+                        } else {
+                            P.ray_o[i] = make_float4(I.p.x, I.p.y, I.p.z, PPG_EPSILON);
+                        }
                         P.ray_d[i] = make_float4(wo.x, wo.y, wo.z, __builtin_inff());
 #if defined(PPG_ABLATE) && PPG_ABLATE == 2
                         if (false) {
@@ -465,6 +508,7 @@ __global__ __launch_bounds__(PPG_BLOCK, PPG_SHADE_WAVES) void k_shade(PathState 
     __syncthreads();
     if (threadIdx.x == 0) Q.count[qout][b] = out_count;
     block_add_u64(&acc, &Q.stats[b].path_len, plen_sum);
+    if (FUSED) block_add_u64(&acc, &Q.stats[b].rays, traced);
 }
 
 // sum of count[b] (the host needs it only for unbounded paths and for kernel timing)
