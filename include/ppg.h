@@ -228,6 +228,14 @@ int ppg_image_buffers(ppg_ctx *ctx, void **dev_image /* float[h*w*3] */, void **
 int ppg_render_passes_nostat(ppg_ctx *ctx, int32_t n_passes); /* GP:1217-1286 only */
 int ppg_finish_passes(ppg_ctx *ctx, ppg_pass_stats *stats);   /* GP:1288-1328 only */
 
+/* Per-pass hook for multi-GPU learning of the BSDF sampling fraction: called after the records of a pass were
+   accumulated and before the per-pass Adam step, i.e. where the reference would have taken its
+   steps under the spin-lock (GP:672-697).  The hook all-reduces the buffers of ppg_adam_buffers (int64 / uint64
+   fixed-point sums per S-tree node) so that every rank takes the identical step.  Return non-zero to abort. */
+typedef int (*ppg_pass_hook)(void *user);
+int ppg_set_pass_hook(ppg_ctx *ctx, ppg_pass_hook hook, void *user);
+int ppg_adam_buffers(ppg_ctx *ctx, void **dev_grad, void **dev_weight, uint64_t *n);
+
 /* Batched queries against the current *sampling* SD-tree (what Li does per vertex):
    pdf  = DTreeWrapper::pdf(dir) of the leaf containing p        (GP:623-625, 897-905)
    dirs = DTreeWrapper::sample(sampler) with the build's sampler keyed by (seed, i)  (GP:619-621) */

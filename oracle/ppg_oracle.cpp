@@ -1083,6 +1083,8 @@ public:
     int m_passesLocal = 0;
     PathCounters m_counters;
     volatile bool cancelled = false;
+    ppg_pass_hook passHook = nullptr;
+    void *passHookUser = nullptr;
     std::string error;
 
     int W() const { return scene.cam.width; }
@@ -1256,8 +1258,10 @@ public:
             rays += pc.rays; plen += pc.pathLen; comm += pc.committed;
         }
         m_counters.rays += rays; m_counters.pathLen += plen; m_counters.committed += comm;
-        if (m_bsdfSamplingFractionLoss != ENone && modes.adam == PPGO_ADAM_PER_PASS && m_isBuilt && !m_isFinalIter)
+        if (m_bsdfSamplingFractionLoss != ENone && modes.adam == PPGO_ADAM_PER_PASS && m_isBuilt && !m_isFinalIter) {
+            if (passHook) passHook(passHookUser);  // sharded rendering: the driver all-reduces the per-pass sums here
             m_sdTree->forEachDTreeWrapper([](DTreeWrapper *d) { d->bsdfSamplingFractionOptimizer.endPass(); });
+        }
     }
 
     // PerspectiveCamera::sampleRayDifferential perspective.cpp:271-298
@@ -1830,6 +1834,21 @@ int ppgo_stat_import(ppgo_ctx *ctx, const uint64_t *sums, uint64_t n_sums, const
     if (s != n_sums || w != n_weights) return PPG_ERR_INVALID;
     for (auto &n : ctx->gpt.m_sdTree->nodes())
         if (n.isLeaf) n.dTree.building.importAcc(sums, weights);
+    return PPG_OK;
+}
+int ppgo_set_pass_hook(ppgo_ctx *ctx, ppg_pass_hook hook, void *user) { ctx->gpt.passHook = hook; ctx->gpt.passHookUser = user; return PPG_OK; }
+int ppgo_adam_export(ppgo_ctx *ctx, int64_t *grad, uint64_t *weight, uint64_t n) {
+    NEED_TREE
+    auto &nodes = ctx->gpt.m_sdTree->nodes();
+    if (n != nodes.size()) return PPG_ERR_INVALID;
+    for (size_t i = 0; i < nodes.size(); ++i) { grad[i] = nodes[i].dTree.bsdfSamplingFractionOptimizer.passGradient; weight[i] = nodes[i].dTree.bsdfSamplingFractionOptimizer.passWeight; }
+    return PPG_OK;
+}
+int ppgo_adam_import(ppgo_ctx *ctx, const int64_t *grad, const uint64_t *weight, uint64_t n) {
+    NEED_TREE
+    auto &nodes = ctx->gpt.m_sdTree->nodes();
+    if (n != nodes.size()) return PPG_ERR_INVALID;
+    for (size_t i = 0; i < nodes.size(); ++i) { nodes[i].dTree.bsdfSamplingFractionOptimizer.passGradient = grad[i]; nodes[i].dTree.bsdfSamplingFractionOptimizer.passWeight = weight[i]; }
     return PPG_OK;
 }
 int ppgo_film_ptrs(ppgo_ctx *ctx, float **rgb_sum, float **weight) {

@@ -262,6 +262,8 @@ struct ppg_ctx {
     float lastVariance = 0;
     ppg_pass_stats lastStats{};
     KernelTimer timer;
+    ppg_pass_hook passHook = nullptr;
+    void *passHookUser = nullptr;
 
     DevTree devTree() {
         DevTree T{};
@@ -571,6 +573,11 @@ int renderOnePass(ppg_ctx *ctx) {
         });
         if (ctx->loss != LOSS_NONE && ctx->isBuilt) {
             unsigned int nn = (unsigned int)ctx->snodes.size();
+            hipLaunchKernelGGL(k_adam_fold, dim3((nn + 255) / 256), dim3(256), 0, s, T, nn);
+            if (ctx->passHook) {  // multi-GPU: the driver all-reduces the per-pass sums here
+                HIP_CHECK(hipStreamSynchronize(s));
+                if (ctx->passHook(ctx->passHookUser) != 0) { ctx->error = "pass hook failed"; return PPG_ERR_INVALID; }
+            }
             hipLaunchKernelGGL(k_adam_step, dim3((nn + 255) / 256), dim3(256), 0, s, T, nn);
         }
     }
@@ -1159,6 +1166,13 @@ int ppg_image_buffers(ppg_ctx *ctx, void **dev_image, void **dev_sq_image, void 
     NEED_TREE
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
     *dev_image = ctx->d_image.p; *dev_sq_image = ctx->d_sq.p; *dev_weight = ctx->d_imageW.p;
+    return PPG_OK;
+}
+
+int ppg_set_pass_hook(ppg_ctx *ctx, ppg_pass_hook hook, void *user) { ctx->passHook = hook; ctx->passHookUser = user; return PPG_OK; }
+int ppg_adam_buffers(ppg_ctx *ctx, void **dev_grad, void **dev_weight, uint64_t *n) {
+    NEED_TREE
+    *dev_grad = ctx->d_adamGrad.p; *dev_weight = ctx->d_adamW.p; *n = ctx->snodes.size();
     return PPG_OK;
 }
 

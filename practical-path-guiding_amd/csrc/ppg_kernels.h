@@ -157,6 +157,8 @@ D Hit trace_small(const float4 *lds_tris, int n_tris, F3 o, F3 d, float rayMint,
     Hit h;
     h.t = __builtin_inff(); h.u = 0; h.v = 0; h.prim = -1;
     int bestOrig = 0x7fffffff;
+    // (a branch-free, unrolled variant of this loop was measured 18 % slower: most triangles are rejected by the
+    //  whole wave at the first test)
     for (int k = 0; k < n_tris; ++k) {
         float tt, uu, vv;
         const float4 *Tk = lds_tris + 3 * k;
@@ -771,7 +773,8 @@ __global__ void k_fold_replicas(unsigned long long *compact, unsigned long long 
     if (s) compact[i] += s;
 }
 
-__global__ void k_adam_step(DevTree T, unsigned int n_nodes) {
+// fold the replicated per-pass sums into adam_grad / adam_w (compact, one entry per S-tree node)
+__global__ void k_adam_fold(DevTree T, unsigned int n_nodes) {
     unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_nodes) return;
     unsigned long long wacc = 0, gacc = 0;
@@ -783,6 +786,13 @@ __global__ void k_adam_step(DevTree T, unsigned int n_nodes) {
         }
     }
     T.adam_grad[i] = (long long)gacc;
+    T.adam_w[i] = wacc;
+}
+
+__global__ void k_adam_step(DevTree T, unsigned int n_nodes) {
+    unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    unsigned long long wacc = T.adam_w[i];
     if (wacc == 0) return;
     float w = ppg_from_fixed(wacc);
     if (w > 1.0f) {  // batchAccumulation > batchSize

@@ -327,6 +327,26 @@ class Engine:
         self.image_buffers()
         return self._image_w
 
+    def adam_buffers(self):
+        g, w, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
+        self._call("adam_buffers", C.byref(g), C.byref(w), C.byref(n))
+        return g.value, w.value, n.value
+
+    def set_pass_hook(self, fn):
+        """fn() is called once per render pass between the accumulation of the Adam sums and the Adam step."""
+        HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p)
+
+        def tramp(_user):
+            try:
+                fn()
+                return 0
+            except Exception:  # pragma: no cover - surfaced as PPG_ERR_INVALID by the library
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._hook_keep = HOOK(tramp) if fn is not None else HOOK(0)
+        self._call("set_pass_hook", self._hook_keep, None)
+
     def enable_kernel_timing(self, on=True):
         self._call("enable_kernel_timing", C.c_int32(int(on)))
 

@@ -51,6 +51,13 @@ class TorchReducer:
         self.dist.all_reduce(_view(self.torch, w, n, "<f4", self.device))
         self.torch.cuda.synchronize()
 
+    def reduce_adam(self, e):
+        g, w, n = e.adam_buffers()
+        if n:
+            self.dist.all_reduce(_view(self.torch, g, n, "<i8", self.device))
+            self.dist.all_reduce(_view(self.torch, w, n, "<i8", self.device))
+            self.torch.cuda.synchronize()
+
     def reduce_film(self, e, inverse_variance=False):
         if inverse_variance:
             return  # the retained iteration images were already reduced by reduce_images
@@ -97,6 +104,15 @@ class HostReducer:
         w = C.POINTER(C.c_float)()
         e._call("image_weight_ptr", C.byref(w))
         self._allreduce_np(np.ctypeslib.as_array(w, shape=(n,)))
+
+    def reduce_adam(self, e):
+        n = int(e.sdtree_info().n_stree_nodes)
+        g = np.zeros(n, np.int64)
+        w = np.zeros(n, np.int64)
+        e._call("adam_export", g.ctypes.data_as(C.POINTER(C.c_int64)), w.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_uint64(n))
+        self._allreduce_np(g)
+        self._allreduce_np(w)
+        e._call("adam_import", g.ctypes.data_as(C.POINTER(C.c_int64)), w.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_uint64(n))
 
     def reduce_film(self, e, inverse_variance=False):
         if inverse_variance:

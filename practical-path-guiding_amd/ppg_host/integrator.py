@@ -43,6 +43,8 @@ class GuidedPathTracer:
         if scene is not None:
             e.set_scene(scene)
         e.begin_render()
+        if self.reducer is not None and p["bsdfSamplingFractionLoss"] != "none":
+            e.set_pass_hook(lambda: self.reducer.reduce_adam(e))  # every rank takes the same per-pass Adam step
         self.iterations = []
         spp = p["sppPerPass"]
         automatic = p["sampleCombination"] == "automatic"

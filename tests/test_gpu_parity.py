@@ -314,3 +314,39 @@ def test_sdt_dump_equals_oracle_bytes(oracle_lib, tmp_path):
         e.set_scene(scene); e.render()
     g.dump_sdtree(str(tmp_path / "g.sdt")); o.dump_sdtree(str(tmp_path / "o.sdt"))
     assert open(tmp_path / "g.sdt", "rb").read() == open(tmp_path / "o.sdt", "rb").read()
+
+
+def test_pass_hook_sees_the_per_pass_adam_sums():
+    """The multi-GPU Adam exchange point: the hook runs once per training pass after the sums were folded and
+    before the step; an identity hook must not change anything, and the buffers must hold the pass's sums."""
+    import ppg_host
+    import torch
+    from ppg_host.distributed import _view
+    dev = torch.device("cuda", 0)
+    scene = ppg_host.cbox_scene(64, 64)
+    props = dict(CBOX_PROPS, budget=31, seed=4, **IMPROVED)
+    ref = hip(**props)
+    ref_img = ppg_host.GuidedPathTracer(engine=ref).render(scene)
+    e = hip(**props)
+    seen = []
+
+    def hook():
+        g, w, n = e.adam_buffers()
+        wt = _view(torch, w, n, "<i8", dev)
+        seen.append(int((wt > 0).sum().item()))
+
+    e.set_scene(scene)
+    e.begin_render()
+    e.set_pass_hook(hook)
+    e.close_hook = hook
+    gpt = ppg_host.GuidedPathTracer(engine=e)
+    # drive the phases by hand so that begin_render is not repeated
+    passes = [1, 2, 4, 8, 16]
+    for it, p in enumerate(passes):
+        e.begin_iteration(it == len(passes) - 1)
+        e.render_passes(p)
+        e.build_sdtree(); e.end_iteration()
+    e.end_render()
+    assert np.array_equal(e.read_film(), ref_img)
+    assert np.array_equal(e.read_sdtree()["theta"], ref.read_sdtree()["theta"])
+    assert len(seen) == 2 + 4 + 8 and max(seen) > 0  # training passes after the first build; none in the final iteration

@@ -106,18 +106,20 @@ lib = ctypes.CDLL(sys.argv[2])
 props = dict(budgetType="spp", maxDepth=10, rrDepth=10, strictNormals=1, budget=60, seed=17)
 if sys.argv[4] == "inversevar":
     props.update(sampleCombination="inversevar", spatialFilter="stochastic", directionalFilter="box", sTreeThreshold=2000)
+if sys.argv[4] == "improved":
+    props.update(sampleCombination="inversevar", bsdfSamplingFractionLoss="kl", spatialFilter="stochastic", directionalFilter="box", sTreeThreshold=2000, sppPerPass=1)
 e = ppg_host.Engine(lib, "ppgo_", **props)
 lib.ppgo_set_modes(e.ctx, 0, 0, 2)
 scene = ppg_host.cbox_scene(64, 48)
 e.set_scene(scene); e.set_shard(rank, world, 16)
 img = ppg_host.GuidedPathTracer(engine=e, reducer=HostReducer(dist)).render()
 t = e.read_sdtree()
-np.savez(os.path.join(sys.argv[3], "rank%d.npz" % rank), film=img, children=t["children"], dch=t["sampling"]["node_children"], dsum=t["sampling"]["node_sums"])
+np.savez(os.path.join(sys.argv[3], "rank%d.npz" % rank), film=img, children=t["children"], dch=t["sampling"]["node_children"], dsum=t["sampling"]["node_sums"], theta=t["theta"])
 dist.barrier(); dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("mode", ["default", "inversevar"])
+@pytest.mark.parametrize("mode", ["default", "inversevar", "improved"])
 def test_sharded_render_over_gloo_equals_single_rank(oracle_lib, tmp_path, mode):
     """world_size 2, gloo: tiles sharded, SD-tree statistics all-reduced as int64 → the merged render is
     bit-identical to the unsharded one on every rank (SURVEY.md §8(e))."""
@@ -132,6 +134,9 @@ def test_sharded_render_over_gloo_equals_single_rank(oracle_lib, tmp_path, mode)
     props = dict(CBOX_PROPS, budget=60, seed=17)
     if mode == "inversevar":
         props.update(sampleCombination="inversevar", spatialFilter="stochastic", directionalFilter="box", sTreeThreshold=2000)
+    if mode == "improved":  # learned BSDF sampling fraction: the per-pass Adam sums are all-reduced through the pass hook
+        props.update(sampleCombination="inversevar", bsdfSamplingFractionLoss="kl", spatialFilter="stochastic", directionalFilter="box",
+                     sTreeThreshold=2000, sppPerPass=1)
     e = make_oracle(oracle_lib, threads=4, **props)
     e.set_scene(ppg_host.cbox_scene(64, 48)); e.render()
     ref_img, ref_t = e.read_film(), e.read_sdtree()
@@ -140,3 +145,4 @@ def test_sharded_render_over_gloo_equals_single_rank(oracle_lib, tmp_path, mode)
         assert np.array_equal(got["children"], ref_t["children"])
         assert np.array_equal(got["dch"], ref_t["sampling"]["node_children"]) and np.array_equal(got["dsum"], ref_t["sampling"]["node_sums"])
         assert np.array_equal(got["film"], ref_img)
+        assert np.array_equal(got["theta"], ref_t["theta"])
