@@ -33,16 +33,38 @@ sys.path.insert(0, os.path.join(ROOT, "practical-path-guiding_amd"))
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-def algorithmic_bytes_per_ray():
-    """SURVEY.md §8(d), per traced ray (one k_trace + one k_shade visit), CBOX: see DESIGN.md §roofline."""
-    return dict(
-        trace=32 + 16 + 10 * 64 + 4 * 48,          # ray read, hit write, ~10 BVH2 nodes, ~4 triangles
-        shade=32 + 16 + 16 + 16 + 16 + 3 * 48      # ray/hit/thr/li/misc reads
-        + 32 + 16 + 16 + 16                        # ray/thr/li/misc writes
-        + 10 * 16 + 64                             # S-tree levels + leaf header
-        + (0.5 * 5 + 5) * 32                       # D-tree levels in sample (half the vertices) + pdf
-        + 4 * 16,                                  # speculative vertex record
-    )
+def algorithmic_bytes(work=None, rays=None):
+    """ALGORITHMIC bytes per unit of each path kernel: bytes the kernel's algorithm touches per
+    unit, cache-oblivious, from the data layout of ppg_kernels.h and the operation counts measured by the CPU
+    restatement on the same workload (`work` = ppgo_work_counters, `rays` = rays traced in that run).
+    Without counters the a-priori CBOX values of a 63-pass run are used."""
+    if work and rays:
+        lookups = work[1] / rays                       # S-tree lookups (= bounces sampled) per traced ray
+        ds = work[2] / rays                            # D-tree levels descended while sampling, per ray
+        dp = work[4] / rays                            # ... while evaluating the pdf, per ray
+    else:
+        lookups, ds, dp = 0.70, 1.31, 2.48
+    state_rd = 4 + 5 * 16                              # queue entry, ray_d, thr, li, hit, misc
+    state_wr = 5 * 16 * lookups                        # ray_o, ray_d, thr, li (per surviving path) + misc
+    shade = (state_rd + state_wr + 48 + 16             # + hit triangle (3 float4) + material
+             + lookups * (4 + 64)                      # grid cell + leaf header
+             + (ds + dp) * 32                          # sampling-tree nodes
+             + lookups * 64)                           # speculative vertex record (4 float4)
+    return {"k_shade": shade,
+            "k_trace": 32 + 16,                        # small scene: ray in, hit out (triangles are LDS resident)
+            "k_commit": 16 + 64 + 5 * 8 + 16,          # per recorded vertex: misc, vertex, descent, 2 atomics
+            "k_generate": 80, "k_film": 4 * 16 + 88,
+            "detail": {"lookups_per_ray": lookups, "dtree_sample_levels_per_ray": ds, "dtree_pdf_levels_per_ray": dp}}
+
+
+def measured_traffic():
+    """HBM bytes per unit from profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes,
+    calibrated as MI355X_MICROARCH.md prescribes; written by tools/collect_profiles.py on the GPU box)."""
+    p = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        return json.load(open(p))
+    except Exception:
+        return None
 
 
 def run(args):
@@ -111,23 +133,7 @@ def run(args):
                    "rays_per_sample": rays / max(1, own_samples), "variance_last_iteration": var_last},
     }
 
-    if rank == 0 and not args.no_roofline:
-        # separate instrumented render: per-kernel HIP-event durations on the kernels' stream
-        g2 = make(args.steps, timing=True)
-        g2.render()
-        times = g2.engine.kernel_times()
-        dom = max(times, key=lambda k: k["ms"])
-        per_ray = algorithmic_bytes_per_ray()
-        key = "trace" if dom["name"] == "k_trace" else "shade"
-        bytes_per_unit = per_ray.get(key, per_ray["shade"]) if dom["name"] in ("k_trace", "k_shade") else 4 * 64 + 200
-        avg_units = dom["units"] / max(1, dom["launches"])
-        avg_ms = dom["ms"] / max(1, dom["launches"])
-        achieved = bytes_per_unit * avg_units / (avg_ms * 1e-3) / 1e9
-        out["roofline"] = {"bound": "hbm", "kernel": dom["name"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms, "launches": dom["launches"],
-                           "algorithmic_bytes_per_unit": bytes_per_unit, "avg_units_per_launch": avg_units,
-                           "kernels_ms": {k["name"]: round(k["ms"], 3) for k in times}}
-
+    work = rays_cpu = None
     if rank == 0 and args.gpus == 1 and not args.no_cpu:
         # CPU baseline: the oracle (a port, not the reference binary) on the host cores, bounded sample:
         # the same scene/resolution/settings, the first `cpu_passes` passes of the same schedule.
@@ -137,13 +143,41 @@ def run(args):
         cp = args.cpu_passes
         o = ppg_host.Engine(lib, "ppgo_", budget=float(cp * spp), **{k: v for k, v in props.items() if k != "device"})
         lib.ppgo_set_modes(o.ctx, 0, 0, cores)
+        og = ppg_host.GuidedPathTracer(engine=o)
         o.set_scene(scene)
         t1 = time.perf_counter()
-        o.render()
+        og.render()
         dtc = time.perf_counter() - t1
+        wk = (ctypes.c_uint64 * 8)()
+        lib.ppgo_work_counters(o.ctx, wk)
+        work = list(wk)
+        rays_cpu = sum(s["rays"] for it in og.iterations for s in it["stats"])
         out["cpu_baseline"] = {"value": args.width * args.height * spp * cp / dtc / 1e6, "unit": "Msamples/s", "cores": cores,
                                "kind": "port", "sample": "first %d passes (%d spp) of the same render(), oracle restatement, OpenMP over 32x32 blocks"
                                % (cp, cp * spp), "seconds": dtc}
+
+    if rank == 0 and not args.no_roofline:
+        # separate instrumented render: per-kernel HIP-event durations on the kernels' stream
+        g2 = make(args.steps, timing=True)
+        g2.render()
+        times = g2.engine.kernel_times()
+        dom = max(times, key=lambda k: k["ms"])
+        alg = algorithmic_bytes(work, rays_cpu)
+        name = dom["name"].split("<")[0]
+        bytes_per_unit = alg.get(name, alg["k_shade"])
+        avg_units = dom["units"] / max(1, dom["launches"])
+        avg_ms = dom["ms"] / max(1, dom["launches"])
+        achieved = bytes_per_unit * avg_units / (avg_ms * 1e-3) / 1e9
+        tr = measured_traffic()
+        traffic = None
+        if tr and name in tr.get("bytes_per_unit", {}):
+            traffic = tr["bytes_per_unit"][name] * avg_units
+        out["roofline"] = {"bound": "hbm", "kernel": dom["name"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": avg_ms, "launches": dom["launches"],
+                           "algorithmic_bytes_per_unit": bytes_per_unit, "avg_units_per_launch": avg_units, "unit_of_work": "traced ray",
+                           "operation_counts": alg["detail"], "kernels_ms": {k["name"]: round(k["ms"], 3) for k in times},
+                           "note": "tree/scene bytes are cache resident: `traffic` (PMC) is what actually reaches HBM"}
+
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

@@ -152,6 +152,10 @@ struct Modes {
 
 inline Float logistic(Float x) { return 1 / (1 + ppg_exp(-x)); }  // GP:64-66
 
+// Work counters for the algorithmic-bytes accounting of SURVEY.md §8(d) (levels visited per operation).
+enum { CNT_STREE_LEVELS, CNT_STREE_LOOKUPS, CNT_DSAMPLE_LEVELS, CNT_DSAMPLE_CALLS, CNT_DPDF_LEVELS, CNT_DPDF_CALLS, CNT_DRECORD_LEVELS, CNT_DRECORD_CALLS, CNT_N };
+thread_local uint64_t t_cnt[CNT_N];
+
 // ------------------------------------------------------------------------------------------------
 // AdamOptimizer  GP:69-133
 // ------------------------------------------------------------------------------------------------
@@ -245,6 +249,7 @@ public:
     }
 
     Float pdf(Point2 &p, const std::vector<QuadTreeNode> &nodes) const {  // GP:232-245
+        ++t_cnt[CNT_DPDF_LEVELS];
         const int index = childIndex(p);
         if (!(sum(index) > 0)) return 0;
         const Float factor = 4 * sum(index) / (sum(0) + sum(1) + sum(2) + sum(3));
@@ -259,6 +264,7 @@ public:
     }
 
     Point2 sample(Sampler *sampler, const std::vector<QuadTreeNode> &nodes) const {  // GP:257-301
+        ++t_cnt[CNT_DSAMPLE_LEVELS];
         int index = 0;
         Float topLeft = sum(0);
         Float topRight = sum(1);
@@ -300,6 +306,7 @@ public:
     }
 
     void record(Point2 &p, Float irradiance, std::vector<QuadTreeNode> &nodes, int accMode) {  // GP:303-312
+        ++t_cnt[CNT_DRECORD_LEVELS];
         int index = childIndex(p);
         if (isLeaf(index)) add(index, irradiance, accMode);
         else nodes[child(index)].record(p, irradiance, nodes, accMode);
@@ -376,6 +383,7 @@ public:
             else __atomic_fetch_add(&m_statAcc, ppg_to_fixed(statisticalWeight), __ATOMIC_RELAXED);
 
             if (ppg_isfinite(irradiance) && irradiance > 0) {
+                ++t_cnt[CNT_DRECORD_CALLS];
                 if (directionalFilter == EDNearest) {
                     m_nodes[0].record(p, irradiance * statisticalWeight, m_nodes, accMode);
                 } else {
@@ -392,6 +400,7 @@ public:
     }
 
     Float pdf(Point2 p) const {  // GP:415-421
+        ++t_cnt[CNT_DPDF_CALLS];
         if (!(mean() > 0)) return 1 / (4 * PPG_PI_F);
         return m_nodes[0].pdf(p, m_nodes) / (4 * PPG_PI_F);
     }
@@ -399,6 +408,7 @@ public:
     int depth() const { return m_maxDepth; }
 
     Point2 sample(Sampler *sampler) const {  // GP:431-442
+        ++t_cnt[CNT_DSAMPLE_CALLS];
         if (!(mean() > 0)) return sampler->next2D();
         Point2 res = m_nodes[0].sample(sampler, m_nodes);
         res.x = ppg_min(ppg_max(res.x, 0.0f), 1.0f);  // math::clamp
@@ -614,6 +624,7 @@ struct STreeNode {
     int nodeIndex(Point &p) const { return children[childIndex(p)]; }
 
     DTreeWrapper *dTreeWrapper(Point &p, Vec &size, std::vector<STreeNode> &nodes) {  // GP:761-769
+        ++t_cnt[CNT_STREE_LEVELS];
         if (isLeaf) return &dTree;
         size[axis] /= 2;
         return nodes[nodeIndex(p)].dTreeWrapper(p, size, nodes);
@@ -701,6 +712,7 @@ public:
         p.x /= size.x;
         p.y /= size.y;
         p.z /= size.z;
+        ++t_cnt[CNT_STREE_LOOKUPS];
         return m_nodes[0].dTreeWrapper(p, size, m_nodes);
     }
     DTreeWrapper *dTreeWrapper(Point p) {
@@ -1082,6 +1094,7 @@ public:
     std::chrono::steady_clock::time_point m_startTime, m_passStart;
     int m_passesLocal = 0;
     PathCounters m_counters;
+    uint64_t m_work[CNT_N] = {};
     volatile bool cancelled = false;
     ppg_pass_hook passHook = nullptr;
     void *passHookUser = nullptr;
@@ -1233,6 +1246,8 @@ public:
 #endif
         for (int b = 0; b < bx * by; ++b) {
             PathCounters pc;
+            uint64_t cnt0[CNT_N];
+            memcpy(cnt0, t_cnt, sizeof cnt0);
             int x0 = (b % bx) * bs, y0 = (b / bx) * bs;
             for (int y = y0; y < std::min(y0 + bs, h); ++y)
                 for (int x = x0; x < std::min(x0 + bs, w); ++x) {
@@ -1256,6 +1271,7 @@ public:
                     }
                 }
             rays += pc.rays; plen += pc.pathLen; comm += pc.committed;
+            for (int k = 0; k < CNT_N; ++k) __atomic_fetch_add(&m_work[k], t_cnt[k] - cnt0[k], __ATOMIC_RELAXED);
         }
         m_counters.rays += rays; m_counters.pathLen += plen; m_counters.committed += comm;
         if (m_bsdfSamplingFractionLoss != ENone && modes.adam == PPGO_ADAM_PER_PASS && m_isBuilt && !m_isFinalIter) {
@@ -1836,6 +1852,7 @@ int ppgo_stat_import(ppgo_ctx *ctx, const uint64_t *sums, uint64_t n_sums, const
         if (n.isLeaf) n.dTree.building.importAcc(sums, weights);
     return PPG_OK;
 }
+int ppgo_work_counters(ppgo_ctx *ctx, uint64_t *out8) { memcpy(out8, ctx->gpt.m_work, sizeof ctx->gpt.m_work); return PPG_OK; }
 int ppgo_set_pass_hook(ppgo_ctx *ctx, ppg_pass_hook hook, void *user) { ctx->gpt.passHook = hook; ctx->gpt.passHookUser = user; return PPG_OK; }
 int ppgo_adam_export(ppgo_ctx *ctx, int64_t *grad, uint64_t *weight, uint64_t n) {
     NEED_TREE

@@ -56,6 +56,8 @@ int ppgo_sdtree_read_adam(ppgo_ctx *ctx, float *theta);
 int ppgo_stat_export(ppgo_ctx *ctx, uint64_t *sums, uint64_t n_sums, uint64_t *weights, uint64_t n_weights);
 int ppgo_stat_import(ppgo_ctx *ctx, const uint64_t *sums, uint64_t n_sums, const uint64_t *weights, uint64_t n_weights);
 int ppgo_stat_sizes(ppgo_ctx *ctx, uint64_t *n_sums, uint64_t *n_weights);
+/* levels visited since create: {S-tree levels, lookups, D-tree sample levels, calls, pdf levels, calls, record levels, calls} */
+int ppgo_work_counters(ppgo_ctx *ctx, uint64_t *out8);
 int ppgo_set_pass_hook(ppgo_ctx *ctx, ppg_pass_hook hook, void *user);
 int ppgo_adam_export(ppgo_ctx *ctx, int64_t *grad, uint64_t *weight, uint64_t n);
 int ppgo_adam_import(ppgo_ctx *ctx, const int64_t *grad, const uint64_t *weight, uint64_t n);
