@@ -58,6 +58,16 @@ struct BvhNode {  // 64 B
     int n0, n1;   // > 0 leaf with n triangles, 0 interior, < 0 empty
 };
 
+// BVH4 node, 128 B = one L2 line: child boxes in SoA (six float4 loads in flight at once), then child refs.
+// child >= 0: interior node index; child < 0: leaf, ~child = (first triangle << 3) | (count - 1); an unused
+// slot is marked PPG_BVH4_EMPTY.
+#define PPG_BVH4_EMPTY 0x7fffffff
+struct Bvh4Node {
+    float lox[4], loy[4], loz[4], hix[4], hiy[4], hiz[4];
+    int child[4];
+    int pad[4];
+};
+
 struct DevCamera {
     float s2c[16], c2w[16];
     float near_clip, far_clip, inv_w, inv_h;
@@ -68,6 +78,7 @@ struct DevScene {
     const float4 *tris;     // 3 per triangle
     const float4 *normals;  // 3 per triangle or nullptr
     const BvhNode *bvh;
+    const Bvh4Node *bvh4;     // same tree collapsed to 4-wide nodes (generic traversal)
     const float4 *materials;  // (reflectance rgb, type)
     const float4 *emitters;   // (radiance rgb, -)
     int n_tris;
@@ -163,6 +174,91 @@ D Hit trace_closest(const DevScene &S, const LdsScene &L, F3 o, F3 d, float mint
         else {
             if (sp == 0) break;
             cur = stack[--sp];
+        }
+    }
+    return best;
+}
+
+// Traversal stack: the first PPG_LDS_STACK entries of every lane live in an LDS column (conflict-free, no
+// scratch traffic), deeper entries — rare — in a small private array.
+#define PPG_LDS_STACK 24
+struct TStack {
+    int *lds;      // this lane's column, stride blockDim.x
+    int stride;
+    int over[24];
+    int sp;
+    D void push(int v) { if (sp < PPG_LDS_STACK) lds[sp * stride] = v; else over[sp - PPG_LDS_STACK] = v; ++sp; }
+    D int pop() { --sp; return sp < PPG_LDS_STACK ? lds[sp * stride] : over[sp - PPG_LDS_STACK]; }
+};
+
+// Closest hit by (t, original primitive index) through the BVH4 — equals brute force (conservative culling).
+D Hit trace_closest4(const DevScene &S, int *lds_stack_col, int stride, F3 o, F3 d, float mint, float maxt) {
+    Hit best;
+    best.t = __builtin_inff(); best.u = 0; best.v = 0; best.prim = -1;
+    int bestOrig = 0x7fffffff;
+    const F3 id = f3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
+    TStack st;
+    st.lds = lds_stack_col; st.stride = stride; st.sp = 0;
+    int cur = 0;
+    for (;;) {
+        const float4 *nd = reinterpret_cast<const float4 *>(S.bvh4 + cur);
+        const float4 lx = nd[0], ly = nd[1], lz = nd[2], hx = nd[3], hy = nd[4], hz = nd[5];
+        const int4 ch = *reinterpret_cast<const int4 *>(nd + 6);
+        const float tlim = fminf(maxt, best.t);
+        float tn[4];
+        bool hit[4];
+        const float lxs[4] = {lx.x, lx.y, lx.z, lx.w}, lys[4] = {ly.x, ly.y, ly.z, ly.w}, lzs[4] = {lz.x, lz.y, lz.z, lz.w};
+        const float hxs[4] = {hx.x, hx.y, hx.z, hx.w}, hys[4] = {hy.x, hy.y, hy.z, hy.w}, hzs[4] = {hz.x, hz.y, hz.z, hz.w};
+        const int chs[4] = {ch.x, ch.y, ch.z, ch.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float ax = (lxs[k] - o.x) * id.x, bx = (hxs[k] - o.x) * id.x;
+            float ay = (lys[k] - o.y) * id.y, by = (hys[k] - o.y) * id.y;
+            float az = (lzs[k] - o.z) * id.z, bz = (hzs[k] - o.z) * id.z;
+            float n = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), mint));
+            float f = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tlim));
+            tn[k] = n;
+            hit[k] = (n <= f) && chs[k] != PPG_BVH4_EMPTY;
+        }
+        // leaves first (they can only shorten the ray), then the interior children nearest-first
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (hit[k] && chs[k] < 0) {
+                const int code = ~chs[k];
+                const int first = code >> 3, cnt = (code & 7) + 1;
+                for (int q = first; q < first + cnt; ++q) {
+                    float tt, uu, vv;
+                    const float4 *T = S.tris + 3 * q;
+                    if (tri_hit(T, o, d, mint, maxt, tt, uu, vv)) {
+                        int orig = __float_as_int(T[2].w);
+                        if (tt < best.t || (tt == best.t && orig < bestOrig)) { best.t = tt; best.u = uu; best.v = vv; best.prim = q; bestOrig = orig; }
+                    }
+                }
+                hit[k] = false;
+            }
+        }
+        // collect interior hits, order by entry distance (insertion sort of <= 4)
+        int cn[4];
+        float ct[4];
+        int m = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (hit[k] && tn[k] <= best.t) {
+                int j = m++;
+                cn[j] = chs[k]; ct[j] = tn[k];
+                while (j > 0 && ct[j - 1] > ct[j]) {
+                    float tf = ct[j]; ct[j] = ct[j - 1]; ct[j - 1] = tf;
+                    int tc = cn[j]; cn[j] = cn[j - 1]; cn[j - 1] = tc;
+                    --j;
+                }
+            }
+        }
+        if (m > 0) {
+            for (int j = m - 1; j >= 1; --j) st.push(cn[j]);
+            cur = cn[0];
+        } else {
+            if (st.sp == 0) break;
+            cur = st.pop();
         }
     }
     return best;

@@ -144,6 +144,45 @@ struct BvhBuilder {
         ref = me; n = 0;
     }
 
+    // ---- collapse the binary tree to 4-wide nodes (children = the 2..4 descendants obtained by repeatedly opening
+    // the interior child with the largest surface area) ----
+    std::vector<Bvh4Node> nodes4;
+    struct Ref { int ref, n; float lo[3], hi[3]; };
+    static float areaRef(const Ref &r) { float d[3] = {r.hi[0] - r.lo[0], r.hi[1] - r.lo[1], r.hi[2] - r.lo[2]}; return 2 * (d[0] * d[1] + d[1] * d[2] + d[2] * d[0]); }
+    void childrenOf(int node2, Ref out[2]) const {
+        const BvhNode &nd = nodes[node2];
+        out[0].ref = nd.c0; out[0].n = nd.n0; out[1].ref = nd.c1; out[1].n = nd.n1;
+        for (int a = 0; a < 3; ++a) { out[0].lo[a] = nd.lo0[a]; out[0].hi[a] = nd.hi0[a]; out[1].lo[a] = nd.lo1[a]; out[1].hi[a] = nd.hi1[a]; }
+    }
+    int make4(int node2) {
+        Ref ch[4]; int m = 2;
+        childrenOf(node2, ch);
+        if (ch[1].n < 0) m = 1;  // single-leaf root
+        while (m < 4) {
+            int pick = -1; float best = -1;
+            for (int k = 0; k < m; ++k) if (ch[k].n == 0 && areaRef(ch[k]) > best) { best = areaRef(ch[k]); pick = k; }
+            if (pick < 0) break;
+            Ref two[2]; childrenOf(ch[pick].ref, two);
+            ch[pick] = two[0]; ch[m++] = two[1];
+        }
+        int me = (int)nodes4.size();
+        nodes4.emplace_back();
+        Bvh4Node nd;
+        for (int k = 0; k < 4; ++k) {
+            if (k < m) {
+                nd.lox[k] = ch[k].lo[0]; nd.loy[k] = ch[k].lo[1]; nd.loz[k] = ch[k].lo[2];
+                nd.hix[k] = ch[k].hi[0]; nd.hiy[k] = ch[k].hi[1]; nd.hiz[k] = ch[k].hi[2];
+                if (ch[k].n > 0) nd.child[k] = ~((ch[k].ref << 3) | (ch[k].n - 1));
+                else nd.child[k] = make4(ch[k].ref);
+            } else {
+                nd.lox[k] = nd.loy[k] = nd.loz[k] = 0; nd.hix[k] = nd.hiy[k] = nd.hiz[k] = 0; nd.child[k] = PPG_BVH4_EMPTY;
+            }
+            nd.pad[k] = 0;
+        }
+        nodes4[me] = nd;
+        return me;
+    }
+
     void run(const float *positions, const uint32_t *indices, uint32_t nTris, float padAbs) {
         pos = positions; idx = indices; pad = padAbs;
         order.resize(nTris); bmin.resize(3 * (size_t)nTris); bmax.resize(3 * (size_t)nTris); cent.resize(3 * (size_t)nTris);
@@ -164,10 +203,13 @@ struct BvhBuilder {
             Box bb = boundsOf(0, (int)nTris);
             for (int a = 0; a < 3; ++a) { nd.lo0[a] = bb.lo[a] - pad; nd.hi0[a] = bb.hi[a] + pad; nd.lo1[a] = 0; nd.hi1[a] = 0; }
             nd.c0 = 0; nd.n0 = (int)nTris; nd.c1 = 0; nd.n1 = -1;
+            nodes4.clear(); make4(0);
             return;
         }
         nodes.pop_back();
         build(0, (int)nTris, ref, n, b);  // nTris > 4 ⇒ root is interior and lands at index 0
+        nodes4.clear(); nodes4.reserve(nodes.size() / 2 + 1);
+        make4(0);
     }
 };
 
@@ -214,6 +256,7 @@ struct ppg_ctx {
     bool haveScene = false;
     DevBuf<float4> d_tris, d_normals, d_materials, d_emitters;
     DevBuf<BvhNode> d_bvh;
+    DevBuf<Bvh4Node> d_bvh4;
     DevScene scene{};
     float aabbMin[3], aabbMax[3];  // Scene::getAABB()
     int W = 0, H = 0;
@@ -537,7 +580,7 @@ int renderOnePass(ppg_ctx *ctx) {
     int qin = -1;
     const int maxBounces = ctx->maxDepth > 0 ? ctx->maxDepth : 1 << 20;
     unsigned int hostCount = P.n_paths;
-    const size_t ldsBytes = (smallScene ? 0 : (size_t)ctx->ldsNodes * 64) + (size_t)ctx->ldsTris * 48;
+    const size_t ldsBytes = smallScene ? (size_t)ctx->ldsTris * 48 : (size_t)PPG_LDS_STACK * PPG_BLOCK * 4;
     for (int b = 0; b < maxBounces; ++b) {
         int qout = b & 1;
         if (!fused)
@@ -556,6 +599,14 @@ int renderOnePass(ppg_ctx *ctx) {
             HIP_CHECK(hipMemcpyAsync(&hostCount, ctx->d_qtotal.p, 4, hipMemcpyDeviceToHost, s));
             HIP_CHECK(hipStreamSynchronize(s));
             if (hostCount == 0) break;
+            // unbounded paths: hand the thin tail to the per-workgroup bounce loop (one launch, no more host round trips)
+            if (ctx->maxDepth < 0 && !fused && hostCount < std::max<unsigned int>(P.n_paths / 4, 1u) && !getenv("PPG_NO_TAIL")) {
+                timedLaunch(ctx, "k_tail", hostCount, [&] {
+                    if (smallScene) hipLaunchKernelGGL(k_tail<true>, dim3(grid), dim3(PPG_BLOCK), ldsBytes, s, P, S, T, R, Q, qin, 0, ctx->ldsTris);
+                    else hipLaunchKernelGGL(k_tail<false>, dim3(grid), dim3(PPG_BLOCK), ldsBytes, s, P, S, T, R, Q, qin, ctx->ldsNodes, ctx->ldsTris);
+                });
+                break;
+            }
         }
     }
     // the last shade of a bounded schedule terminates every path (depth >= maxDepth), no trailing trace needed
@@ -995,12 +1046,14 @@ int ppg_set_scene(ppg_ctx *ctx, const ppg_scene *s) {
     if (s->normals) { HIP_CHECK(ctx->d_normals.reserve(nrm.size())); HIP_CHECK(hipMemcpy(ctx->d_normals.p, nrm.data(), nrm.size() * sizeof(float4), hipMemcpyHostToDevice)); }
     HIP_CHECK(ctx->d_bvh.reserve(bb.nodes.size()));
     HIP_CHECK(hipMemcpy(ctx->d_bvh.p, bb.nodes.data(), bb.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice));
+    HIP_CHECK(ctx->d_bvh4.reserve(bb.nodes4.size()));
+    HIP_CHECK(hipMemcpy(ctx->d_bvh4.p, bb.nodes4.data(), bb.nodes4.size() * sizeof(Bvh4Node), hipMemcpyHostToDevice));
     HIP_CHECK(ctx->d_materials.reserve(mats.size()));
     HIP_CHECK(hipMemcpy(ctx->d_materials.p, mats.data(), mats.size() * sizeof(float4), hipMemcpyHostToDevice));
     HIP_CHECK(ctx->d_emitters.reserve(ems.size()));
     HIP_CHECK(hipMemcpy(ctx->d_emitters.p, ems.data(), ems.size() * sizeof(float4), hipMemcpyHostToDevice));
     DevScene &S = ctx->scene;
-    S.tris = ctx->d_tris.p; S.normals = s->normals ? ctx->d_normals.p : nullptr; S.bvh = ctx->d_bvh.p;
+    S.tris = ctx->d_tris.p; S.normals = s->normals ? ctx->d_normals.p : nullptr; S.bvh = ctx->d_bvh.p; S.bvh4 = ctx->d_bvh4.p;
     S.materials = ctx->d_materials.p; S.emitters = ctx->d_emitters.p; S.n_tris = (int)s->n_triangles;
     memcpy(S.cam.s2c, s->camera.sample_to_camera, 64); memcpy(S.cam.c2w, s->camera.camera_to_world, 64);
     S.cam.near_clip = s->camera.near_clip; S.cam.far_clip = s->camera.far_clip;

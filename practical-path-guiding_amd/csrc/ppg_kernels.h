@@ -219,24 +219,23 @@ __global__ __launch_bounds__(PPG_BLOCK) void k_generate(PathState P, DevScene S,
 // ------------------------------------------------------------------------------------------------
 // SMALL: the whole scene (<= 64 triangles) is tested from LDS without a BVH — every lane reads the same
 // triangle (LDS broadcast), no divergence, no dependent memory chain.  Same (t, original index) minimum.
-template <bool SMALL>
-__global__ __launch_bounds__(PPG_BLOCK) void k_trace(PathState P, DevScene S, Queues Q, int qin, int lds_nodes, int lds_tris) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    __shared__ unsigned long long acc;
+// stage the scene cache of LdsScene (first n_nodes BVH nodes, then n_tris triangles) into `lds_raw`
+D LdsScene stage_scene(const DevScene &S, unsigned char *lds_raw, int lds_nodes, int lds_tris) {
     LdsScene L;
-    {
-        float4 *dst = (float4 *)lds_raw;
-        const float4 *srcN = (const float4 *)S.bvh;
-        const int nN = lds_nodes * 4, nT = lds_tris * 3;
-        for (int k = threadIdx.x; k < nN; k += blockDim.x) dst[k] = srcN[k];
-        for (int k = threadIdx.x; k < nT; k += blockDim.x) dst[nN + k] = S.tris[k];
-        __syncthreads();
-        L.nodes = (const BvhNode *)lds_raw; L.tris = dst + nN; L.n_nodes = lds_nodes; L.n_tris = lds_tris;
-    }
-    const unsigned int b = blockIdx.x, nb = gridDim.x;
-    const unsigned int count = qin >= 0 ? Q.count[qin][b] : first_share(P.n_paths, b, nb);
-    const unsigned int *items = qin >= 0 ? Q.items[qin] + (size_t)b * Q.cap : nullptr;
-    unsigned int traced = 0;
+    float4 *dst = (float4 *)lds_raw;
+    const float4 *srcN = (const float4 *)S.bvh;
+    const int nN = lds_nodes * 4, nT = lds_tris * 3;
+    for (int k = threadIdx.x; k < nN; k += blockDim.x) dst[k] = srcN[k];
+    for (int k = threadIdx.x; k < nT; k += blockDim.x) dst[nN + k] = S.tris[k];
+    __syncthreads();
+    L.nodes = (const BvhNode *)lds_raw; L.tris = dst + nN; L.n_nodes = lds_nodes; L.n_tris = lds_tris;
+    return L;
+}
+
+// trace the rays of one queue slice (thread t handles entries t, t + 256, ... — the same mapping as shade_slice)
+template <bool SMALL>
+D void trace_slice(const PathState &P, const DevScene &S, const LdsScene &L, int *lds_stack, const unsigned int *items, unsigned int count,
+                   unsigned int b, unsigned int nb, unsigned int &traced) {
     for (unsigned int k = threadIdx.x; k < count; k += blockDim.x) {
         unsigned int i = items ? items[k] : first_path(k, b, nb);
         if (i >= P.n_paths) continue;
@@ -244,16 +243,33 @@ __global__ __launch_bounds__(PPG_BLOCK) void k_trace(PathState P, DevScene S, Qu
         F3 o = f3(ro.x, ro.y, ro.z), d = f3(rd.x, rd.y, rd.z);
         Hit h;
         if (SMALL) {
-            h = trace_small(L.tris, lds_tris, o, d, ro.w, rd.w);
+            h = trace_small(L.tris, L.n_tris, o, d, ro.w, rd.w);
         } else {
             float rayMinT = ro.w;
             if (rayMinT == PPG_EPSILON)  // adaptive ray epsilon
                 rayMinT *= ppg_max(ppg_max(ppg_max(ppg_abs(o.x), ppg_abs(o.y)), ppg_abs(o.z)), PPG_EPSILON);
-            h = trace_closest(S, L, o, d, rayMinT, rd.w);
+            h = trace_closest4(S, lds_stack + threadIdx.x, PPG_BLOCK, o, d, rayMinT, rd.w);
         }
         P.hit[i] = make_float4(h.t, h.u, h.v, __int_as_float(h.prim));
         ++traced;
     }
+}
+
+// SMALL: the whole scene (<= 64 triangles) is tested from LDS without a BVH.
+template <bool SMALL>
+__global__ __launch_bounds__(PPG_BLOCK) void k_trace(PathState P, DevScene S, Queues Q, int qin, int lds_nodes, int lds_tris) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    __shared__ unsigned long long acc;
+    const unsigned int b = blockIdx.x, nb = gridDim.x;
+    const unsigned int count = qin >= 0 ? Q.count[qin][b] : first_share(P.n_paths, b, nb);
+    if (count == 0) return;  // (uniform per workgroup)
+    // dynamic LDS: SMALL → the triangles; otherwise the traversal stacks [PPG_LDS_STACK][PPG_BLOCK]
+    LdsScene L;
+    if (SMALL) L = stage_scene(S, lds_raw, 0, lds_tris);
+    else { L.nodes = nullptr; L.tris = nullptr; L.n_nodes = 0; L.n_tris = 0; }
+    const unsigned int *items = qin >= 0 ? Q.items[qin] + (size_t)b * Q.cap : nullptr;
+    unsigned int traced = 0;
+    trace_slice<SMALL>(P, S, L, (int *)lds_raw, items, count, b, nb, traced);
     block_add_u64(&acc, &Q.stats[b].rays, traced);
 }
 
@@ -278,26 +294,11 @@ __global__ void k_build_grid(const int4 *stree, unsigned int *grid) {
 // ------------------------------------------------------------------------------------------------
 // k_shade — Li's loop body (GP:1798-2146), surface branch, nee = never
 // ------------------------------------------------------------------------------------------------
-// FUSED (small scenes): the ray sampled here is traced here too (scene in LDS), k_trace is not launched.
+// One queue slice through Li's loop body.  FUSED (small scenes): the ray sampled here is traced here too.
 template <bool FUSED>
-__global__ __launch_bounds__(PPG_BLOCK, PPG_SHADE_WAVES) void k_shade(PathState P, DevScene S, DevTree T, RenderParams R, Queues Q, int qin, int qout) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    const float4 *lds_tris = (const float4 *)lds_raw;
-    if (FUSED) {
-        for (int k = threadIdx.x; k < 3 * S.n_tris; k += blockDim.x) ((float4 *)lds_raw)[k] = S.tris[k];
-    }
-    unsigned int traced = 0;
-    __shared__ float pdf_factors[20 * PPG_BLOCK];  // QuadTreeNode::pdf's per-level factors (tree depth <= 20, GP:1112)
-    __shared__ unsigned int out_count;
-    __shared__ unsigned long long acc;
-    const LdsColumn fcol{pdf_factors + threadIdx.x, PPG_BLOCK};
-    const unsigned int b = blockIdx.x, nb = gridDim.x;
-    const unsigned int count = qin >= 0 ? Q.count[qin][b] : first_share(P.n_paths, b, nb);
-    const unsigned int *items = qin >= 0 ? Q.items[qin] + (size_t)b * Q.cap : nullptr;
-    unsigned int *out_items = Q.items[qout] + (size_t)b * Q.cap;
-    if (threadIdx.x == 0) out_count = 0;
-    __syncthreads();
-    unsigned long long plen_sum = 0;
+D void shade_slice(const PathState &P, const DevScene &S, const DevTree &T, const RenderParams &R, const unsigned int *items, unsigned int count,
+                   unsigned int b, unsigned int nb, unsigned int *out_items, unsigned int *out_count, const LdsColumn &fcol,
+                   const float4 *lds_tris, unsigned long long &plen_sum, unsigned int &traced) {
     const unsigned int rounds = (count + PPG_BLOCK - 1) / PPG_BLOCK;
     for (unsigned int r = 0; r < rounds; ++r) {
         unsigned int q = r * PPG_BLOCK + threadIdx.x;
@@ -503,14 +504,71 @@ __global__ __launch_bounds__(PPG_BLOCK, PPG_SHADE_WAVES) void k_shade(PathState 
             if (alive) P.thr[i] = make_float4(thr.x, thr.y, thr.z, eta);
             else plen = depth;  // avgPathLength += rRec.depth, GP:2147-2148
         }
-        unsigned int slot = queue_append(&out_count, alive);
+        unsigned int slot = queue_append(out_count, alive);
         if (alive) out_items[slot] = i;
         plen_sum += plen;
     }
+}
+
+template <bool FUSED>
+__global__ __launch_bounds__(PPG_BLOCK, PPG_SHADE_WAVES) void k_shade(PathState P, DevScene S, DevTree T, RenderParams R, Queues Q, int qin, int qout) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    __shared__ float pdf_factors[20 * PPG_BLOCK];  // QuadTreeNode::pdf's per-level factors (tree depth <= 20, GP:1112)
+    __shared__ unsigned int out_count;
+    __shared__ unsigned long long acc;
+    const float4 *lds_tris = (const float4 *)lds_raw;
+    if (FUSED) {
+        for (int k = threadIdx.x; k < 3 * S.n_tris; k += blockDim.x) ((float4 *)lds_raw)[k] = S.tris[k];
+    }
+    const LdsColumn fcol{pdf_factors + threadIdx.x, PPG_BLOCK};
+    const unsigned int b = blockIdx.x, nb = gridDim.x;
+    const unsigned int count = qin >= 0 ? Q.count[qin][b] : first_share(P.n_paths, b, nb);
+    const unsigned int *items = qin >= 0 ? Q.items[qin] + (size_t)b * Q.cap : nullptr;
+    if (threadIdx.x == 0) out_count = 0;
+    __syncthreads();
+    unsigned long long plen_sum = 0;
+    unsigned int traced = 0;
+    shade_slice<FUSED>(P, S, T, R, items, count, b, nb, Q.items[qout] + (size_t)b * Q.cap, &out_count, fcol, lds_tris, plen_sum, traced);
     __syncthreads();
     if (threadIdx.x == 0) Q.count[qout][b] = out_count;
     block_add_u64(&acc, &Q.stats[b].path_len, plen_sum);
     if (FUSED) block_add_u64(&acc, &Q.stats[b].rays, traced);
+}
+
+// Tail of unbounded paths (maxDepth < 0): once few paths are left, every workgroup keeps bouncing its own queue
+// slice — trace phase, shade phase, swap — until the slice is empty, inside ONE launch.  The slices are private
+// to a workgroup, so no grid-wide synchronisation (and no host round trip per bounce) is needed.
+template <bool SMALL>
+__global__ __launch_bounds__(PPG_BLOCK, PPG_SHADE_WAVES) void k_tail(PathState P, DevScene S, DevTree T, RenderParams R, Queues Q, int qin,
+                                                                    int lds_nodes, int lds_tris) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    __shared__ float pdf_factors[20 * PPG_BLOCK];
+    __shared__ unsigned int out_count;
+    __shared__ unsigned long long acc;
+    const LdsColumn fcol{pdf_factors + threadIdx.x, PPG_BLOCK};
+    const unsigned int b = blockIdx.x, nb = gridDim.x;
+    unsigned int count = Q.count[qin][b];
+    if (count == 0) return;
+    LdsScene L;
+    if (SMALL) L = stage_scene(S, lds_raw, 0, lds_tris);
+    else { L.nodes = nullptr; L.tris = nullptr; L.n_nodes = 0; L.n_tris = 0; }
+    unsigned long long plen_sum = 0;
+    unsigned int traced = 0, dummy = 0;
+    int cur = qin;
+    while (count > 0) {
+        const unsigned int *items = Q.items[cur] + (size_t)b * Q.cap;
+        trace_slice<SMALL>(P, S, L, (int *)lds_raw, items, count, b, nb, traced);
+        if (threadIdx.x == 0) out_count = 0;
+        __syncthreads();
+        shade_slice<false>(P, S, T, R, items, count, b, nb, Q.items[cur ^ 1] + (size_t)b * Q.cap, &out_count, fcol, L.tris, plen_sum, dummy);
+        __syncthreads();  // queue writes of this workgroup are visible to it after the barrier (same CU, write-through L1)
+        count = out_count;
+        cur ^= 1;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { Q.count[0][b] = 0; Q.count[1][b] = 0; }
+    block_add_u64(&acc, &Q.stats[b].path_len, plen_sum);
+    block_add_u64(&acc, &Q.stats[b].rays, traced);
 }
 
 // sum of count[b] (the host needs it only for unbounded paths and for kernel timing)

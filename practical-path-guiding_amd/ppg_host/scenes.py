@@ -129,55 +129,62 @@ def cbox_scene(width=512, height=512):
 def room_scene(width=1280, height=720, n_boxes=2000, tess=4, seed=1234):
     """Kitchen-class stand-in: 4 x 3 x 5 m closed room, one emitter behind a
     ceiling slit (all light is indirect), `n_boxes` random boxes each face tessellated tess x tess.
-    Triangles = 12 * tess^2 * n_boxes + room.  Deterministic in `seed`."""
+    Triangles = 12 * tess^2 * n_boxes + 24.  Deterministic in `seed`; Lambertian only."""
     rng = np.random.RandomState(seed)
-    quads = []
+    mats = ["floor", "wall", "left", "right", "light", "b0", "b1", "b2"]
+    quads, qmat, qem = [], [], []  # arrays of shape [n, 4, 3]
 
-    def add_box(lo, hi, mat):
-        (x0, y0, z0), (x1, y1, z1) = lo, hi
-        faces = [
+    def add_quads(q, mat, em=-1):
+        q = np.asarray(q, np.float64).reshape(-1, 4, 3)
+        quads.append(q)
+        qmat.append(np.full(len(q), mats.index(mat), np.uint32))
+        qem.append(np.full(len(q), em, np.int32))
+
+    X, Y, Z = 4.0, 3.0, 5.0
+    add_quads([(0, 0, 0), (0, 0, Z), (X, 0, Z), (X, 0, 0)], "floor")
+    add_quads([(0, 0, Z), (0, Y, Z), (X, Y, Z), (X, 0, Z)], "wall")       # back (z = Z), faces -z
+    add_quads([(0, 0, 0), (X, 0, 0), (X, Y, 0), (0, Y, 0)], "wall")       # front (z = 0), faces +z
+    add_quads([(0, 0, 0), (0, Y, 0), (0, Y, Z), (0, 0, Z)], "left")       # x = 0, faces +x
+    add_quads([(X, 0, 0), (X, 0, Z), (X, Y, Z), (X, Y, 0)], "right")      # x = X, faces -x
+    # ceiling with a slit along x at z in [2.3, 2.7]; light box above the slit
+    add_quads([(0, Y, 0), (X, Y, 0), (X, Y, 2.3), (0, Y, 2.3)], "wall")
+    add_quads([(0, Y, 2.7), (X, Y, 2.7), (X, Y, Z), (0, Y, Z)], "wall")
+    add_quads([(0, Y + 0.5, 2.3), (X, Y + 0.5, 2.3), (X, Y + 0.5, 2.7), (0, Y + 0.5, 2.7)], "light", 0)  # emitter, faces down
+    add_quads([(0, Y, 2.3), (X, Y, 2.3), (X, Y + 0.5, 2.3), (0, Y + 0.5, 2.3)], "wall")
+    add_quads([(0, Y, 2.7), (0, Y + 0.5, 2.7), (X, Y + 0.5, 2.7), (X, Y, 2.7)], "wall")
+    add_quads([(0, Y, 2.3), (0, Y + 0.5, 2.3), (0, Y + 0.5, 2.7), (0, Y, 2.7)], "wall")
+    add_quads([(X, Y, 2.3), (X, Y, 2.7), (X, Y + 0.5, 2.7), (X, Y + 0.5, 2.3)], "wall")
+
+    ii, jj = np.meshgrid(np.arange(tess), np.arange(tess), indexing="ij")
+    u0, u1, v0, v1 = (ii / tess).ravel(), ((ii + 1) / tess).ravel(), (jj / tess).ravel(), ((jj + 1) / tess).ravel()
+    for k in range(n_boxes):
+        sx, sz = rng.uniform(0.05, 0.25, 2)
+        sy = rng.uniform(0.05, 0.9)
+        cx, cz = rng.uniform(0.3, X - 0.3), rng.uniform(1.2, Z - 0.3)
+        y0 = 0.0 if rng.rand() < 0.7 else rng.uniform(0.3, 2.0)
+        x0, x1, z0, z1, y1 = cx - sx, cx + sx, cz - sz, cz + sz, y0 + sy
+        faces = np.array([
             [(x0, y1, z0), (x0, y1, z1), (x1, y1, z1), (x1, y1, z0)],  # top (+y)
             [(x0, y0, z0), (x1, y0, z0), (x1, y0, z1), (x0, y0, z1)],  # bottom (-y)
             [(x0, y0, z0), (x0, y1, z0), (x1, y1, z0), (x1, y0, z0)],  # -z
             [(x1, y0, z1), (x1, y1, z1), (x0, y1, z1), (x0, y0, z1)],  # +z
             [(x0, y0, z1), (x0, y1, z1), (x0, y1, z0), (x0, y0, z0)],  # -x
             [(x1, y0, z0), (x1, y1, z0), (x1, y1, z1), (x1, y0, z1)],  # +x
-        ]
-        for f in faces:
-            a, b, c, d = (np.array(v, np.float64) for v in f)
-            for i in range(tess):
-                for j in range(tess):
-                    u0, u1, v0, v1 = i / tess, (i + 1) / tess, j / tess, (j + 1) / tess
-                    P = lambda u, v: tuple(a + (b - a) * u + (d - a) * v)  # noqa: E731
-                    quads.append(([P(u0, v0), P(u1, v0), P(u1, v1), P(u0, v1)], mat, -1))
-
-    def add_room_face(f, mat, em=-1):
-        quads.append((f, mat, em))
-
-    X, Y, Z = 4.0, 3.0, 5.0
-    add_room_face([(0, 0, 0), (0, 0, Z), (X, 0, Z), (X, 0, 0)], "floor")
-    add_room_face([(0, 0, Z), (0, Y, Z), (X, Y, Z), (X, 0, Z)], "wall")       # back  (+z), faces -z
-    add_room_face([(0, 0, 0), (X, 0, 0), (X, Y, 0), (0, Y, 0)], "wall")       # front (z=0), faces +z
-    add_room_face([(0, 0, 0), (0, Y, 0), (0, Y, Z), (0, 0, Z)], "left")       # x=0, faces +x
-    add_room_face([(X, 0, 0), (X, 0, Z), (X, Y, Z), (X, Y, 0)], "right")      # x=X, faces -x
-    # ceiling with a slit along x at z in [2.3, 2.7]; light box above the slit
-    add_room_face([(0, Y, 0), (X, Y, 0), (X, Y, 2.3), (0, Y, 2.3)], "wall")
-    add_room_face([(0, Y, 2.7), (X, Y, 2.7), (X, Y, Z), (0, Y, Z)], "wall")
-    add_room_face([(0, Y + 0.5, 2.3), (X, Y + 0.5, 2.3), (X, Y + 0.5, 2.7), (0, Y + 0.5, 2.7)], "light", 0)  # emitter, faces down
-    add_room_face([(0, Y, 2.3), (X, Y, 2.3), (X, Y + 0.5, 2.3), (0, Y + 0.5, 2.3)], "wall")
-    add_room_face([(0, Y, 2.7), (0, Y + 0.5, 2.7), (X, Y + 0.5, 2.7), (X, Y, 2.7)], "wall")
-    add_room_face([(0, Y, 2.3), (0, Y + 0.5, 2.3), (0, Y + 0.5, 2.7), (0, Y, 2.7)], "wall")
-    add_room_face([(X, Y, 2.3), (X, Y, 2.7), (X, Y + 0.5, 2.7), (X, Y + 0.5, 2.3)], "wall")
-    mats = ["floor", "wall", "left", "right", "light", "b0", "b1", "b2"]
-    for k in range(n_boxes):
-        sx, sz = rng.uniform(0.05, 0.25, 2)
-        sy = rng.uniform(0.05, 0.9)
-        cx, cz = rng.uniform(0.3, X - 0.3), rng.uniform(1.2, Z - 0.3)
-        y0 = 0.0 if rng.rand() < 0.7 else rng.uniform(0.3, 2.0)
-        add_box((cx - sx, y0, cz - sz), (cx + sx, y0 + sy, cz + sz), "b%d" % (k % 3))
+        ], np.float64)
+        a, b, d = faces[:, 0][:, None, :], faces[:, 1][:, None, :], faces[:, 3][:, None, :]
+        P = lambda u, v: a + (b - a) * u[None, :, None] + (d - a) * v[None, :, None]  # noqa: E731
+        sub = np.stack([P(u0, v0), P(u1, v0), P(u1, v1), P(u0, v1)], axis=2)  # [6, tess^2, 4, 3]
+        add_quads(sub.reshape(-1, 4, 3), "b%d" % (k % 3))
+    q = np.concatenate(quads).astype(np.float32)
+    n = len(q)
+    positions = q.reshape(-1, 3)
+    base = (np.arange(n, dtype=np.uint32) * 4)[:, None]
+    indices = np.concatenate([base + np.array([0, 1, 2], np.uint32), base + np.array([0, 2, 3], np.uint32)], axis=1).reshape(-1, 3)
+    tri_mat = np.repeat(np.concatenate(qmat), 2)
+    tri_em = np.repeat(np.concatenate(qem), 2)
     refl = {"floor": (0.6, 0.55, 0.5), "wall": (0.75, 0.75, 0.75), "left": (0.6, 0.1, 0.1), "right": (0.1, 0.5, 0.15),
             "light": (0.0, 0.0, 0.0), "b0": (0.7, 0.6, 0.4), "b1": (0.3, 0.4, 0.7), "b2": (0.8, 0.8, 0.8)}
     materials = [dict(type=0, reflectance=refl[m]) for m in mats]
     emitters = [dict(radiance=(60.0, 55.0, 45.0))]
     cam = perspective_camera((2.0, 1.5, 0.15), (2.0, 1.2, 3.0), (0, 1, 0), 70.0, "x", 0.05, 100.0, width, height)
-    return _assemble(quads, mats, materials, emitters, cam)
+    return SceneDesc(positions, indices, tri_mat.astype(np.uint32), tri_em.astype(np.int32), materials, emitters, cam)
