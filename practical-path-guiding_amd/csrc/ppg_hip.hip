@@ -305,6 +305,7 @@ struct ppg_ctx {
     float lastVariance = 0;
     ppg_pass_stats lastStats{};
     KernelTimer timer;
+    std::vector<unsigned int> tailCounts;
     ppg_pass_hook passHook = nullptr;
     void *passHookUser = nullptr;
 
@@ -601,10 +602,24 @@ int renderOnePass(ppg_ctx *ctx) {
             if (hostCount == 0) break;
             // unbounded paths: hand the thin tail to the per-workgroup bounce loop (one launch, no more host round trips)
             if (ctx->maxDepth < 0 && !fused && hostCount < std::max<unsigned int>(P.n_paths / 4, 1u) && !getenv("PPG_NO_TAIL")) {
+                // re-deal the survivors densely to fewer workgroups (the slices have thinned to a few dozen paths each)
+                const unsigned int nbTail = std::max(64u, std::min((unsigned int)grid, hostCount / 768u + 1u));
+                const unsigned int capTail = (hostCount + nbTail - 1) / nbTail;
+                HIP_CHECK(ctx->d_offsets.reserve((size_t)grid));
+                hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, s, Q.count[qin], ctx->d_offsets.p, (unsigned int)grid, ctx->d_total.p);
+                hipLaunchKernelGGL(k_gather_slices, dim3(grid), dim3(PPG_BLOCK), 0, s, Q.items[qin], Q.count[qin], ctx->d_offsets.p, Q.cap, Q.items[qin ^ 1]);
+                ctx->tailCounts.assign((size_t)grid, 0u);
+                for (unsigned int t = 0; t < nbTail; ++t) ctx->tailCounts[t] = std::min(capTail, hostCount - std::min(hostCount, t * capTail));
+                HIP_CHECK(hipMemcpyAsync(Q.count[qin ^ 1], ctx->tailCounts.data(), (size_t)grid * 4, hipMemcpyHostToDevice, s));
+                Queues Qt = Q;
+                Qt.items[0] = Q.items[qin ^ 1]; Qt.items[1] = Q.items[qin];
+                Qt.count[0] = Q.count[qin ^ 1]; Qt.count[1] = Q.count[qin];
+                Qt.cap = capTail; Qt.n_blocks = nbTail;
                 timedLaunch(ctx, "k_tail", hostCount, [&] {
-                    if (smallScene) hipLaunchKernelGGL(k_tail<true>, dim3(grid), dim3(PPG_BLOCK), ldsBytes, s, P, S, T, R, Q, qin, 0, ctx->ldsTris);
-                    else hipLaunchKernelGGL(k_tail<false>, dim3(grid), dim3(PPG_BLOCK), ldsBytes, s, P, S, T, R, Q, qin, ctx->ldsNodes, ctx->ldsTris);
+                    if (smallScene) hipLaunchKernelGGL(k_tail<true>, dim3(nbTail), dim3(PPG_BLOCK), ldsBytes, s, P, S, T, R, Qt, 0, 0, ctx->ldsTris);
+                    else hipLaunchKernelGGL(k_tail<false>, dim3(nbTail), dim3(PPG_BLOCK), ldsBytes, s, P, S, T, R, Qt, 0, ctx->ldsNodes, ctx->ldsTris);
                 });
+                HIP_CHECK(hipStreamSynchronize(s));  // tailCounts is reused by the next pass
                 break;
             }
         }

@@ -232,24 +232,117 @@ D LdsScene stage_scene(const DevScene &S, unsigned char *lds_raw, int lds_nodes,
     return L;
 }
 
-// trace the rays of one queue slice (thread t handles entries t, t + 256, ... — the same mapping as shade_slice)
+// BVH4 traversal of one queue slice with ray replacement: a lane whose ray is finished immediately takes the next
+// entry of the slice (LDS ticket), so a wave stays full until the slice is empty instead of idling until its
+// longest ray is done — secondary rays are incoherent and their traversal lengths differ by an order of magnitude.
+D void trace_slice_bvh4(const PathState &P, const DevScene &S, int *lds_stack, unsigned int *ticket, const unsigned int *items,
+                        unsigned int count, unsigned int b, unsigned int nb, unsigned int &traced) {
+    if (threadIdx.x == 0) *ticket = 0;
+    __syncthreads();
+    TStack st;
+    st.lds = lds_stack + threadIdx.x; st.stride = PPG_BLOCK; st.sp = 0;
+    bool have = false;
+    unsigned int i = 0;
+    F3 o = f3s(0.0f), d = f3s(0.0f), id = f3s(0.0f);
+    float mint = 0, maxt = 0;
+    Hit best;
+    best.t = 0; best.u = 0; best.v = 0; best.prim = -1;
+    int bestOrig = 0, cur = 0;
+    for (;;) {
+        if (!have) {
+            unsigned int k = atomicAdd(ticket, 1u);
+            if (k >= count) break;
+            i = items ? items[k] : first_path(k, b, nb);
+            if (i >= P.n_paths) continue;
+            float4 ro = P.ray_o[i], rd = P.ray_d[i];
+            o = f3(ro.x, ro.y, ro.z); d = f3(rd.x, rd.y, rd.z);
+            mint = ro.w; maxt = rd.w;
+            if (mint == PPG_EPSILON)  // adaptive ray epsilon
+                mint *= ppg_max(ppg_max(ppg_max(ppg_abs(o.x), ppg_abs(o.y)), ppg_abs(o.z)), PPG_EPSILON);
+            id = f3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
+            best.t = __builtin_inff(); best.u = 0; best.v = 0; best.prim = -1;
+            bestOrig = 0x7fffffff; cur = 0; st.sp = 0;
+            have = true;
+        }
+        // ---- one node ----
+        const float4 *nd = reinterpret_cast<const float4 *>(S.bvh4 + cur);
+        const float4 lx = nd[0], ly = nd[1], lz = nd[2], hx = nd[3], hy = nd[4], hz = nd[5];
+        const int4 ch = *reinterpret_cast<const int4 *>(nd + 6);
+        const float tlim = fminf(maxt, best.t);
+        float tn[4];
+        bool hit[4];
+        const float lxs[4] = {lx.x, lx.y, lx.z, lx.w}, lys[4] = {ly.x, ly.y, ly.z, ly.w}, lzs[4] = {lz.x, lz.y, lz.z, lz.w};
+        const float hxs[4] = {hx.x, hx.y, hx.z, hx.w}, hys[4] = {hy.x, hy.y, hy.z, hy.w}, hzs[4] = {hz.x, hz.y, hz.z, hz.w};
+        const int chs[4] = {ch.x, ch.y, ch.z, ch.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float ax = (lxs[k] - o.x) * id.x, bx = (hxs[k] - o.x) * id.x;
+            float ay = (lys[k] - o.y) * id.y, by = (hys[k] - o.y) * id.y;
+            float az = (lzs[k] - o.z) * id.z, bz = (hzs[k] - o.z) * id.z;
+            float n = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), mint));
+            float f = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tlim));
+            tn[k] = n;
+            hit[k] = (n <= f) && chs[k] != PPG_BVH4_EMPTY;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (hit[k] && chs[k] < 0) {  // leaves first: they can only shorten the ray
+                const int code = ~chs[k];
+                const int first = code >> 3, cnt = (code & 7) + 1;
+                for (int q = first; q < first + cnt; ++q) {
+                    float tt, uu, vv;
+                    const float4 *T = S.tris + 3 * q;
+                    if (tri_hit(T, o, d, mint, maxt, tt, uu, vv)) {
+                        int orig = __float_as_int(T[2].w);
+                        if (tt < best.t || (tt == best.t && orig < bestOrig)) { best.t = tt; best.u = uu; best.v = vv; best.prim = q; bestOrig = orig; }
+                    }
+                }
+                hit[k] = false;
+            }
+        }
+        int cn[4];
+        float ct[4];
+        int m = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (hit[k] && tn[k] <= best.t) {  // interior children, nearest first
+                int j = m++;
+                cn[j] = chs[k]; ct[j] = tn[k];
+                while (j > 0 && ct[j - 1] > ct[j]) {
+                    float tf = ct[j]; ct[j] = ct[j - 1]; ct[j - 1] = tf;
+                    int tc = cn[j]; cn[j] = cn[j - 1]; cn[j - 1] = tc;
+                    --j;
+                }
+            }
+        }
+        if (m > 0) {
+            for (int j = m - 1; j >= 1; --j) st.push(cn[j]);
+            cur = cn[0];
+        } else if (st.sp > 0) {
+            cur = st.pop();
+        } else {
+            P.hit[i] = make_float4(best.t, best.u, best.v, __int_as_float(best.prim));
+            ++traced;
+            have = false;
+        }
+    }
+    __syncthreads();
+}
+
+// trace the rays of one queue slice
 template <bool SMALL>
-D void trace_slice(const PathState &P, const DevScene &S, const LdsScene &L, int *lds_stack, const unsigned int *items, unsigned int count,
-                   unsigned int b, unsigned int nb, unsigned int &traced) {
+D void trace_slice(const PathState &P, const DevScene &S, const LdsScene &L, int *lds_stack, unsigned int *ticket, const unsigned int *items,
+                   unsigned int count, unsigned int b, unsigned int nb, unsigned int &traced) {
+    if (!SMALL) {
+        trace_slice_bvh4(P, S, lds_stack, ticket, items, count, b, nb, traced);
+        return;
+    }
     for (unsigned int k = threadIdx.x; k < count; k += blockDim.x) {
         unsigned int i = items ? items[k] : first_path(k, b, nb);
         if (i >= P.n_paths) continue;
         float4 ro = P.ray_o[i], rd = P.ray_d[i];
         F3 o = f3(ro.x, ro.y, ro.z), d = f3(rd.x, rd.y, rd.z);
-        Hit h;
-        if (SMALL) {
-            h = trace_small(L.tris, L.n_tris, o, d, ro.w, rd.w);
-        } else {
-            float rayMinT = ro.w;
-            if (rayMinT == PPG_EPSILON)  // adaptive ray epsilon
-                rayMinT *= ppg_max(ppg_max(ppg_max(ppg_abs(o.x), ppg_abs(o.y)), ppg_abs(o.z)), PPG_EPSILON);
-            h = trace_closest4(S, lds_stack + threadIdx.x, PPG_BLOCK, o, d, rayMinT, rd.w);
-        }
+        Hit h = trace_small(L.tris, L.n_tris, o, d, ro.w, rd.w);
         P.hit[i] = make_float4(h.t, h.u, h.v, __int_as_float(h.prim));
         ++traced;
     }
@@ -260,6 +353,7 @@ template <bool SMALL>
 __global__ __launch_bounds__(PPG_BLOCK) void k_trace(PathState P, DevScene S, Queues Q, int qin, int lds_nodes, int lds_tris) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __shared__ unsigned long long acc;
+    __shared__ unsigned int ticket;
     const unsigned int b = blockIdx.x, nb = gridDim.x;
     const unsigned int count = qin >= 0 ? Q.count[qin][b] : first_share(P.n_paths, b, nb);
     if (count == 0) return;  // (uniform per workgroup)
@@ -269,7 +363,7 @@ __global__ __launch_bounds__(PPG_BLOCK) void k_trace(PathState P, DevScene S, Qu
     else { L.nodes = nullptr; L.tris = nullptr; L.n_nodes = 0; L.n_tris = 0; }
     const unsigned int *items = qin >= 0 ? Q.items[qin] + (size_t)b * Q.cap : nullptr;
     unsigned int traced = 0;
-    trace_slice<SMALL>(P, S, L, (int *)lds_raw, items, count, b, nb, traced);
+    trace_slice<SMALL>(P, S, L, (int *)lds_raw, &ticket, items, count, b, nb, traced);
     block_add_u64(&acc, &Q.stats[b].rays, traced);
 }
 
@@ -543,7 +637,7 @@ __global__ __launch_bounds__(PPG_BLOCK, PPG_SHADE_WAVES) void k_tail(PathState P
                                                                     int lds_nodes, int lds_tris) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __shared__ float pdf_factors[20 * PPG_BLOCK];
-    __shared__ unsigned int out_count;
+    __shared__ unsigned int out_count, ticket;
     __shared__ unsigned long long acc;
     const LdsColumn fcol{pdf_factors + threadIdx.x, PPG_BLOCK};
     const unsigned int b = blockIdx.x, nb = gridDim.x;
@@ -557,7 +651,8 @@ __global__ __launch_bounds__(PPG_BLOCK, PPG_SHADE_WAVES) void k_tail(PathState P
     int cur = qin;
     while (count > 0) {
         const unsigned int *items = Q.items[cur] + (size_t)b * Q.cap;
-        trace_slice<SMALL>(P, S, L, (int *)lds_raw, items, count, b, nb, traced);
+        trace_slice<SMALL>(P, S, L, (int *)lds_raw, &ticket, items, count, b, nb, traced);
+        __syncthreads();  // hits written by any lane of the workgroup are read by the shade phase
         if (threadIdx.x == 0) out_count = 0;
         __syncthreads();
         shade_slice<false>(P, S, T, R, items, count, b, nb, Q.items[cur ^ 1] + (size_t)b * Q.cap, &out_count, fcol, L.tris, plen_sum, dummy);
@@ -569,6 +664,13 @@ __global__ __launch_bounds__(PPG_BLOCK, PPG_SHADE_WAVES) void k_tail(PathState P
     if (threadIdx.x == 0) { Q.count[0][b] = 0; Q.count[1][b] = 0; }
     block_add_u64(&acc, &Q.stats[b].path_len, plen_sum);
     block_add_u64(&acc, &Q.stats[b].rays, traced);
+}
+
+// copy every workgroup's queue slice into one dense array (offsets = exclusive scan of the slice counts)
+__global__ void k_gather_slices(const unsigned int *items, const unsigned int *count, const unsigned int *offsets, unsigned int cap,
+                                unsigned int *dense) {
+    const unsigned int b = blockIdx.x, n = count[b], off = offsets[b];
+    for (unsigned int k = threadIdx.x; k < n; k += blockDim.x) dense[off + k] = items[(size_t)b * cap + k];
 }
 
 // sum of count[b] (the host needs it only for unbounded paths and for kernel timing)
