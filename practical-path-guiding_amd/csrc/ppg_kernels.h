@@ -43,6 +43,7 @@ struct RenderParams {
     int is_final_iter, do_nee;
     unsigned long long seed;
     unsigned int pass_index;  // m_passesRendered at the start of this pass
+    unsigned int pass_index_spp;  // sample index of the batch's first sample = pass_index * sppPerPass
     int max_vertices;         // vertex slots allocated per path
 };
 
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(PPG_BLOCK) void k_generate(PathState P, DevScene S,
     for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < P.n_paths; i += gridDim.x * blockDim.x) {
         unsigned int k = i % P.n_pix, j = i / P.n_pix;
         unsigned int pixel = P.pixels[k];
-        unsigned int key = ppg_path_key(R.seed, pixel, R.pass_index * (unsigned int)R.spp + j);
+        unsigned int key = ppg_path_key(R.seed, pixel, R.pass_index_spp + j);
         unsigned int dim = 0;
         float u1 = ppg_rand(key, dim++);
         float u2 = ppg_rand(key, dim++);
