@@ -231,7 +231,7 @@ int ppg_finish_passes(ppg_ctx *ctx, ppg_pass_stats *stats);   /* GP:1288-1328 on
 /* Per-pass hook for multi-GPU learning of the BSDF sampling fraction: called after the records of a pass were
    accumulated and before the per-pass Adam step, i.e. where the reference would have taken its
    steps under the spin-lock (GP:672-697).  The hook all-reduces the buffers of ppg_adam_buffers (int64 / uint64
-   fixed-point sums per S-tree node) so that every rank takes the identical step.  Return non-zero to abort. */
+   fixed-point sums, PPG_ADAM_BATCHES per S-tree node) so that every rank takes the identical step.  Return non-zero to abort. */
 typedef int (*ppg_pass_hook)(void *user);
 int ppg_set_pass_hook(ppg_ctx *ctx, ppg_pass_hook hook, void *user);
 int ppg_adam_buffers(ppg_ctx *ctx, void **dev_grad, void **dev_weight, uint64_t *n);
@@ -248,6 +248,7 @@ typedef struct ppg_kernel_time { const char *name; double ms; uint64_t launches;
 int ppg_kernel_times(ppg_ctx *ctx, ppg_kernel_time *out, uint32_t cap, uint32_t *n);
 int ppg_enable_kernel_timing(ppg_ctx *ctx, int32_t enable);
 
+#define PPG_ADAM_BATCHES 64 /* mini-batches per D-tree and render pass of the deterministic Adam rule */
 #define PPG_FIXED_SHIFT 24 /* building sums / weights are accumulated as round(x * 2^24) in uint64 */
 
 #ifdef __cplusplus

@@ -189,15 +189,22 @@ public:
     Float variable() const { return m_state.variable; }
 
     // PER_PASS mode: exact integer sums of gradient*weight (2^-20) and weight (2^-24), see header.
-    int64_t passGradient = 0;
-    uint64_t passWeight = 0;
+    // Records are dealt to PPG_ADAM_BATCHES mini-batches by a hash of (path key, vertex slot); at the end of a pass
+    // every mini-batch whose weight exceeds batchSize takes one step (in index order) with its mean gradient — all
+    // gradients of a pass are evaluated at the fraction the pass started with.  A mini-batch that is still too
+    // light keeps accumulating (like append(), GP:85-95, it never drops a record).
+    int64_t passGradient[PPG_ADAM_BATCHES] = {};
+    uint64_t passWeight[PPG_ADAM_BATCHES] = {};
     void endPass() {
-        if (passWeight != 0) {
-            Float w = ppg_from_fixed(passWeight);
-            if (w > (Float)m_hparams.batchSize) step(ppg_from_sfixed(passGradient) / w);
+        for (int k = 0; k < PPG_ADAM_BATCHES; ++k) {
+            if (passWeight[k] == 0) continue;
+            Float w = ppg_from_fixed(passWeight[k]);
+            if (w > (Float)m_hparams.batchSize) {
+                step(ppg_from_sfixed(passGradient[k]) / w);
+                passGradient[k] = 0;
+                passWeight[k] = 0;
+            }
         }
-        passGradient = 0;
-        passWeight = 0;
     }
 
 private:
@@ -507,6 +514,7 @@ struct DTreeRecord {
     Float woPdf, bsdfPdf, dTreePdf;
     Float statisticalWeight;
     bool isDelta;
+    int adamBatch = 0;  // mini-batch of the per-pass Adam rule (PER_PASS mode only)
 };
 
 struct DTreeWrapper {
@@ -574,9 +582,9 @@ public:
         if (modes.adam == PPGO_ADAM_SEQUENTIAL) {
             bsdfSamplingFractionOptimizer.append(lossGradient, rec.statisticalWeight);
         } else {
-            __atomic_fetch_add(&bsdfSamplingFractionOptimizer.passGradient,
+            __atomic_fetch_add(&bsdfSamplingFractionOptimizer.passGradient[rec.adamBatch],
                                ppg_to_sfixed(lossGradient * rec.statisticalWeight), __ATOMIC_RELAXED);
-            __atomic_fetch_add(&bsdfSamplingFractionOptimizer.passWeight, ppg_to_fixed(rec.statisticalWeight),
+            __atomic_fetch_add(&bsdfSamplingFractionOptimizer.passWeight[rec.adamBatch], ppg_to_fixed(rec.statisticalWeight),
                                __ATOMIC_RELAXED);
         }
     }
@@ -657,7 +665,7 @@ struct STreeNode {
         if (w > 0) {
             if (isLeaf) {
                 dTree.record({rec.d, rec.radiance, rec.product, rec.woPdf, rec.bsdfPdf, rec.dTreePdf,
-                              rec.statisticalWeight * w, rec.isDelta},
+                              rec.statisticalWeight * w, rec.isDelta, rec.adamBatch},
                              directionalFilter, loss, modes);
             } else {
                 size2[axis] /= 2;
@@ -1114,7 +1122,11 @@ public:
         // std::pow(2, m_iter) is a double power; the whole expression is double, then truncated to size_t
         double thr = std::sqrt(std::ldexp(1.0, m_iter) * m_sppPerPass / 4) * m_sTreeThreshold;
         m_sdTree->refine((size_t)thr, m_sdTreeMaxMemory);
-        m_sdTree->forEachDTreeWrapper([this](DTreeWrapper *dTree) { dTree->reset(20, m_dTreeThreshold); });
+        m_sdTree->forEachDTreeWrapper([this](DTreeWrapper *dTree) {
+            dTree->reset(20, m_dTreeThreshold);
+            // PER_PASS Adam: mini-batches that stayed below batchSize are dropped at the iteration boundary
+            for (int k = 0; k < PPG_ADAM_BATCHES; ++k) { dTree->bsdfSamplingFractionOptimizer.passGradient[k] = 0; dTree->bsdfSamplingFractionOptimizer.passWeight[k] = 0; }
+        });
     }
 
     void buildSDTree(ppg_tree_stats *st) {  // GP:1115-1189
@@ -1277,6 +1289,12 @@ public:
         if (m_bsdfSamplingFractionLoss != ENone && modes.adam == PPGO_ADAM_PER_PASS && m_isBuilt && !m_isFinalIter) {
             if (passHook) passHook(passHookUser);  // sharded rendering: the driver all-reduces the per-pass sums here
             m_sdTree->forEachDTreeWrapper([](DTreeWrapper *d) { d->bsdfSamplingFractionOptimizer.endPass(); });
+            // sharded: the hook summed the mini-batch sums over all ranks; what is carried to the next pass must
+            // exist once, so only rank 0 keeps it
+            if (shardWorld > 1 && shardRank != 0)
+                m_sdTree->forEachDTreeWrapper([](DTreeWrapper *d) {
+                    for (int k = 0; k < PPG_ADAM_BATCHES; ++k) { d->bsdfSamplingFractionOptimizer.passGradient[k] = 0; d->bsdfSamplingFractionOptimizer.passWeight[k] = 0; }
+                });
         }
     }
 
@@ -1358,14 +1376,15 @@ public:
         void record(const Spectrum &r) { radiance = radiance + r; }
 
         bool commit(STree &sdTree, Float statisticalWeight, ESpatialFilter spatialFilter, EDirectionalFilter directionalFilter,
-                    ELoss loss, Sampler *sampler, const Modes &modes) {
+                    ELoss loss, Sampler *sampler, const Modes &modes, int slot) {
             if (!(woPdf > 0) || !isValid(radiance) || !isValid(bsdfVal)) return false;
             Spectrum localRadiance(0.0f);
             if (throughput[0] * woPdf > PPG_EPSILON) localRadiance[0] = radiance[0] / throughput[0];
             if (throughput[1] * woPdf > PPG_EPSILON) localRadiance[1] = radiance[1] / throughput[1];
             if (throughput[2] * woPdf > PPG_EPSILON) localRadiance[2] = radiance[2] / throughput[2];
             Spectrum product = mul(localRadiance, bsdfVal);
-            DTreeRecord rec{rayD, average(localRadiance), average(product), woPdf, bsdfPdf, dTreePdf, statisticalWeight, isDelta};
+            DTreeRecord rec{rayD, average(localRadiance), average(product), woPdf, bsdfPdf, dTreePdf, statisticalWeight, isDelta,
+                            (int)(ppg_hash32(sampler->key ^ (0x9e3779b9u * (uint32_t)(slot + 1))) & (PPG_ADAM_BATCHES - 1))};
             switch (spatialFilter) {
                 case ESNearest:
                     dTree->record(rec, directionalFilter, loss, modes);
@@ -1487,7 +1506,7 @@ public:
             for (int i = 0; i < nVertices; ++i) {
                 sampler.dim = dimEnd + 3u * (uint32_t)i;  // sampler contract: the commit draws of vertex i (ppg_rng.h)
                 bool ok = vertices[i].commit(*m_sdTree, m_nee == EKickstart && m_doNee ? 0.5f : 1.0f, m_spatialFilter,
-                                             m_directionalFilter, m_isBuilt ? m_bsdfSamplingFractionLoss : ENone, &sampler, modes);
+                                             m_directionalFilter, m_isBuilt ? m_bsdfSamplingFractionLoss : ENone, &sampler, modes, i);
                 if (ok) pc.committed++;
             }
         }
@@ -1857,15 +1876,23 @@ int ppgo_set_pass_hook(ppgo_ctx *ctx, ppg_pass_hook hook, void *user) { ctx->gpt
 int ppgo_adam_export(ppgo_ctx *ctx, int64_t *grad, uint64_t *weight, uint64_t n) {
     NEED_TREE
     auto &nodes = ctx->gpt.m_sdTree->nodes();
-    if (n != nodes.size()) return PPG_ERR_INVALID;
-    for (size_t i = 0; i < nodes.size(); ++i) { grad[i] = nodes[i].dTree.bsdfSamplingFractionOptimizer.passGradient; weight[i] = nodes[i].dTree.bsdfSamplingFractionOptimizer.passWeight; }
+    if (n != nodes.size() * PPG_ADAM_BATCHES) return PPG_ERR_INVALID;
+    for (size_t i = 0; i < nodes.size(); ++i)
+        for (int k = 0; k < PPG_ADAM_BATCHES; ++k) {
+            grad[i * PPG_ADAM_BATCHES + k] = nodes[i].dTree.bsdfSamplingFractionOptimizer.passGradient[k];
+            weight[i * PPG_ADAM_BATCHES + k] = nodes[i].dTree.bsdfSamplingFractionOptimizer.passWeight[k];
+        }
     return PPG_OK;
 }
 int ppgo_adam_import(ppgo_ctx *ctx, const int64_t *grad, const uint64_t *weight, uint64_t n) {
     NEED_TREE
     auto &nodes = ctx->gpt.m_sdTree->nodes();
-    if (n != nodes.size()) return PPG_ERR_INVALID;
-    for (size_t i = 0; i < nodes.size(); ++i) { nodes[i].dTree.bsdfSamplingFractionOptimizer.passGradient = grad[i]; nodes[i].dTree.bsdfSamplingFractionOptimizer.passWeight = weight[i]; }
+    if (n != nodes.size() * PPG_ADAM_BATCHES) return PPG_ERR_INVALID;
+    for (size_t i = 0; i < nodes.size(); ++i)
+        for (int k = 0; k < PPG_ADAM_BATCHES; ++k) {
+            nodes[i].dTree.bsdfSamplingFractionOptimizer.passGradient[k] = grad[i * PPG_ADAM_BATCHES + k];
+            nodes[i].dTree.bsdfSamplingFractionOptimizer.passWeight[k] = weight[i * PPG_ADAM_BATCHES + k];
+        }
     return PPG_OK;
 }
 int ppgo_film_ptrs(ppgo_ctx *ctx, float **rgb_sum, float **weight) {
@@ -1921,7 +1948,7 @@ int ppgo_ka_refine(float Wt, uint64_t thr, uint32_t *n_leaves, uint32_t *n_nodes
 int ppgo_ka_adam(int32_t n, float product, float wo_pdf, float bsdf_pdf, float dtree_pdf, float weight, int32_t loss, float *fraction) {
     DTreeWrapper w;
     Modes m; m.acc = PPGO_ACC_FLOAT; m.adam = PPGO_ADAM_SEQUENTIAL;
-    DTreeRecord rec{Vec(0, 0, 1), 1.0f, product, wo_pdf, bsdf_pdf, dtree_pdf, weight, true /* isDelta: only the Adam half */};
+    DTreeRecord rec{Vec(0, 0, 1), 1.0f, product, wo_pdf, bsdf_pdf, dtree_pdf, weight, true /* isDelta: only the Adam half */, 0};
     for (int i = 0; i < n; ++i) w.record(rec, EDNearest, loss == 1 ? EKL : EVariance, m);
     *fraction = w.bsdfSamplingFraction();
     return PPG_OK;

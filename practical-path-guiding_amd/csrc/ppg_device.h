@@ -22,6 +22,7 @@
 
 #include "../../include/ppg_detmath.h"
 #include "../../include/ppg_rng.h"
+#include "../../include/ppg.h"
 
 #define D __device__ __forceinline__
 
@@ -384,14 +385,12 @@ struct DevTree {
     const ushort4 *bchild;        // building pool topology
     unsigned long long *bacc;     // building pool accumulators [node*4 + slot], 2^-24 fixed point
     unsigned long long *bweight;  // per S-tree node: building statistical weight accumulator (folded, see *_rep)
-    long long *adam_grad;         // per S-tree node: per-pass Σ gradient·weight (2^-20)
-    unsigned long long *adam_w;   // per S-tree node: per-pass Σ weight (2^-24)
+    long long *adam_grad;         // [node * PPG_ADAM_BATCHES + k]: Σ gradient·weight of mini-batch k (2^-20)
+    unsigned long long *adam_w;   // [node * PPG_ADAM_BATCHES + k]: Σ weight (2^-24)
     // Replicated accumulation targets [node * PPG_REPLICAS + r]: a popular S-tree leaf receives several percent of all
     // records of a pass and one address sustains only ~90 atomics/µs; workgroups spread over the replicas,
     // k_fold_replicas adds them into the compact arrays above (integer sums: exact).
     unsigned long long *bweight_rep;
-    unsigned long long *adam_grad_rep;
-    unsigned long long *adam_w_rep;
     float aabb_min[3], aabb_ext[3];  // cubified AABB (GP:857-859)
     float aabb_max[3];
     int is_built;

@@ -294,7 +294,7 @@ struct ppg_ctx {
     int cur = 0;  // d_snodes[cur] = sampling pool
     size_t nSamplingNodes = 0, nBuildingNodes = 0;
     DevBuf<ushort4> d_bchild;
-    DevBuf<unsigned long long> d_bacc, d_bweight, d_adamW, d_total, d_bweightRep, d_adamGradRep, d_adamWRep;
+    DevBuf<unsigned long long> d_bacc, d_bweight, d_adamW, d_total, d_bweightRep;
     DevBuf<long long> d_adamGrad;
     DevBuf<unsigned int> d_leaves, d_counts, d_offsets, d_grid;
     int ldsNodes = 0, ldsTris = 0;  // scene part cached in LDS by k_trace
@@ -314,7 +314,7 @@ struct ppg_ctx {
         DevTree T{};
         T.stree = d_stree.p; T.hdr = d_hdr.p; T.snodes = d_snodes[cur].p; T.bchild = d_bchild.p; T.bacc = d_bacc.p;
         T.bweight = d_bweight.p; T.adam_grad = d_adamGrad.p; T.adam_w = d_adamW.p;
-        T.bweight_rep = d_bweightRep.p; T.adam_grad_rep = d_adamGradRep.p; T.adam_w_rep = d_adamWRep.p;
+        T.bweight_rep = d_bweightRep.p;
         for (int a = 0; a < 3; ++a) { T.aabb_min[a] = treeMin[a]; T.aabb_ext[a] = treeExt[a]; T.aabb_max[a] = treeMax[a]; }
         T.is_built = isBuilt ? 1 : 0;
         T.grid = d_grid.p;
@@ -367,18 +367,16 @@ int uploadTree(ppg_ctx *ctx) {
     HIP_CHECK(ctx->d_offsets.reserve(ctx->leaves.size()));
     HIP_CHECK(hipMemcpyAsync(ctx->d_leaves.p, ctx->leaves.data(), ctx->leaves.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     HIP_CHECK(ctx->d_bweight.reserve(n));
-    HIP_CHECK(ctx->d_adamW.reserve(n));
-    HIP_CHECK(ctx->d_adamGrad.reserve(n));
     HIP_CHECK(hipMemsetAsync(ctx->d_bweight.p, 0, n * 8, ctx->stream));
-    HIP_CHECK(hipMemsetAsync(ctx->d_adamW.p, 0, n * 8, ctx->stream));
-    HIP_CHECK(hipMemsetAsync(ctx->d_adamGrad.p, 0, n * 8, ctx->stream));
+    {   // Adam mini-batch sums; what stayed below batchSize is dropped at the iteration boundary
+        const size_t na = ctx->loss != LOSS_NONE ? n * PPG_ADAM_BATCHES : 1;
+        HIP_CHECK(ctx->d_adamW.reserve(na));
+        HIP_CHECK(ctx->d_adamGrad.reserve(na));
+        HIP_CHECK(hipMemsetAsync(ctx->d_adamW.p, 0, na * 8, ctx->stream));
+        HIP_CHECK(hipMemsetAsync(ctx->d_adamGrad.p, 0, na * 8, ctx->stream));
+    }
     HIP_CHECK(ctx->d_bweightRep.reserve(n * PPG_REPLICAS));
     HIP_CHECK(hipMemsetAsync(ctx->d_bweightRep.p, 0, n * PPG_REPLICAS * 8, ctx->stream));
-    if (ctx->loss != LOSS_NONE) {
-        HIP_CHECK(ctx->d_adamGradRep.reserve(n * PPG_REPLICAS)); HIP_CHECK(ctx->d_adamWRep.reserve(n * PPG_REPLICAS));
-        HIP_CHECK(hipMemsetAsync(ctx->d_adamGradRep.p, 0, n * PPG_REPLICAS * 8, ctx->stream));
-        HIP_CHECK(hipMemsetAsync(ctx->d_adamWRep.p, 0, n * PPG_REPLICAS * 8, ctx->stream));
-    }
     if (n >= (1u << 27)) { ctx->error = "S-tree exceeds 2^27 nodes"; return PPG_ERR_NOMEM; }
     const unsigned int cells = PPG_GRID_DIM * PPG_GRID_DIM * PPG_GRID_DIM;
     HIP_CHECK(ctx->d_grid.reserve(cells));
@@ -660,12 +658,16 @@ int renderBatch(ppg_ctx *ctx, int batch) {
         });
         if (ctx->loss != LOSS_NONE && ctx->isBuilt) {
             unsigned int nn = (unsigned int)ctx->snodes.size();
-            hipLaunchKernelGGL(k_adam_fold, dim3((nn + 255) / 256), dim3(256), 0, s, T, nn);
             if (ctx->passHook) {  // multi-GPU: the driver all-reduces the per-pass sums here
                 HIP_CHECK(hipStreamSynchronize(s));
                 if (ctx->passHook(ctx->passHookUser) != 0) { ctx->error = "pass hook failed"; return PPG_ERR_INVALID; }
             }
             hipLaunchKernelGGL(k_adam_step, dim3((nn + 255) / 256), dim3(256), 0, s, T, nn);
+            if (ctx->shardWorld > 1 && ctx->shardRank != 0) {
+                // sharded: the hook summed the mini-batch sums over all ranks; the part carried to the next pass must exist once
+                HIP_CHECK(hipMemsetAsync(ctx->d_adamW.p, 0, (size_t)nn * PPG_ADAM_BATCHES * 8, s));
+                HIP_CHECK(hipMemsetAsync(ctx->d_adamGrad.p, 0, (size_t)nn * PPG_ADAM_BATCHES * 8, s));
+            }
         }
     }
     timedLaunch(ctx, "k_film", P.n_pix, [&] {
@@ -1265,7 +1267,8 @@ int ppg_image_buffers(ppg_ctx *ctx, void **dev_image, void **dev_sq_image, void 
 int ppg_set_pass_hook(ppg_ctx *ctx, ppg_pass_hook hook, void *user) { ctx->passHook = hook; ctx->passHookUser = user; return PPG_OK; }
 int ppg_adam_buffers(ppg_ctx *ctx, void **dev_grad, void **dev_weight, uint64_t *n) {
     NEED_TREE
-    *dev_grad = ctx->d_adamGrad.p; *dev_weight = ctx->d_adamW.p; *n = ctx->snodes.size();
+    *dev_grad = ctx->d_adamGrad.p; *dev_weight = ctx->d_adamW.p;
+    *n = ctx->loss != LOSS_NONE ? ctx->snodes.size() * PPG_ADAM_BATCHES : 0;
     return PPG_OK;
 }
 

@@ -758,6 +758,7 @@ struct Rec {  // DTreeRecord, GP:562-568
     F3 d;
     float radiance, product, woPdf, bsdfPdf, dTreePdf, statisticalWeight;
     bool isDelta;
+    int adamBatch;  // mini-batch of the per-pass Adam rule: hash(path key, vertex slot) & (PPG_ADAM_BATCHES - 1)
 };
 
 // DTreeWrapper::record (GP:575-584) incl. the gradient of optimizeBsdfSamplingFraction (GP:672-697);
@@ -798,13 +799,11 @@ D void wrapper_record(const DevTree &T, int leaf, const Rec &rec, int dfilter, i
             g = (unsigned long long)ppg_to_sfixed(lossGradient * rec.statisticalWeight);
             w = ppg_to_fixed(rec.statisticalWeight);
         }
-        const unsigned int rk = (unsigned int)leaf * PPG_REPLICAS + (blockIdx.x & (PPG_REPLICAS - 1));
-        if (COMBINE) {
-            wave_key_add<3>(T.adam_grad_rep, rk, g, adam);
-            wave_key_add<3>(T.adam_w_rep, rk, w, adam);
-        } else if (adam) {
-            atomicAdd(&T.adam_grad_rep[rk], g);
-            atomicAdd(&T.adam_w_rep[rk], w);
+        // 64 mini-batches per D-tree already spread a popular leaf's records over 64 addresses: plain atomics
+        if (adam) {
+            const size_t ak = (size_t)leaf * PPG_ADAM_BATCHES + (size_t)rec.adamBatch;
+            atomicAdd((unsigned long long *)&T.adam_grad[ak], g);
+            atomicAdd(&T.adam_w[ak], w);
         }
     }
 }
@@ -870,7 +869,7 @@ __global__ __launch_bounds__(PPG_BLOCK) void k_commit(PathState P, DevTree T, Re
         if (!__any(act)) continue;
         Rec rec;
         rec.d = f3s(0.0f); rec.radiance = rec.product = rec.woPdf = rec.bsdfPdf = rec.dTreePdf = 0; rec.statisticalWeight = statisticalWeight;
-        rec.isDelta = false;
+        rec.isDelta = false; rec.adamBatch = 0;
         int leaf = 0;
         const size_t vi = (size_t)v * P.n_paths + i;
         if (act) {
@@ -890,6 +889,7 @@ __global__ __launch_bounds__(PPG_BLOCK) void k_commit(PathState P, DevTree T, Re
                 rec.radiance = avg3(localRadiance); rec.product = avg3(product);
                 rec.woPdf = woPdf; rec.bsdfPdf = bsdfPdf; rec.dTreePdf = dTreePdf;
                 rec.isDelta = (bits & 0x80000000u) != 0;
+                rec.adamBatch = (int)(ppg_hash32(key ^ (0x9e3779b9u * (v + 1u))) & (PPG_ADAM_BATCHES - 1));
                 leaf = (int)(bits & 0x7fffffffu);
                 ++committed_sum;
             }
@@ -934,41 +934,31 @@ __global__ void k_fold_replicas(unsigned long long *compact, unsigned long long 
     if (s) compact[i] += s;
 }
 
-// fold the replicated per-pass sums into adam_grad / adam_w (compact, one entry per S-tree node)
-__global__ void k_adam_fold(DevTree T, unsigned int n_nodes) {
-    unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_nodes) return;
-    unsigned long long wacc = 0, gacc = 0;
-    for (int r = 0; r < PPG_REPLICAS; ++r) {
-        unsigned long long w = T.adam_w_rep[(size_t)i * PPG_REPLICAS + r];
-        if (w) {
-            wacc += w; gacc += T.adam_grad_rep[(size_t)i * PPG_REPLICAS + r];
-            T.adam_w_rep[(size_t)i * PPG_REPLICAS + r] = 0; T.adam_grad_rep[(size_t)i * PPG_REPLICAS + r] = 0;
-        }
-    }
-    T.adam_grad[i] = (long long)gacc;
-    T.adam_w[i] = wacc;
-}
-
+// AdamOptimizer::step (GP:97-109) for every mini-batch of every D-tree whose accumulated weight exceeds batchSize
+// (= 1), in mini-batch order; lighter mini-batches keep accumulating (append(), GP:85-95).
 __global__ void k_adam_step(DevTree T, unsigned int n_nodes) {
     unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_nodes) return;
-    unsigned long long wacc = T.adam_w[i];
-    if (wacc == 0) return;
-    float w = ppg_from_fixed(wacc);
-    if (w > 1.0f) {  // batchAccumulation > batchSize
-        LeafHdr h = T.hdr[i];
-        float gradient = ppg_from_sfixed(T.adam_grad[i]) / w;
+    LeafHdr h = T.hdr[i];
+    bool stepped = false;
+    for (int k = 0; k < PPG_ADAM_BATCHES; ++k) {
+        const size_t ak = (size_t)i * PPG_ADAM_BATCHES + k;
+        unsigned long long wacc = T.adam_w[ak];
+        if (wacc == 0) continue;
+        float w = ppg_from_fixed(wacc);
+        if (!(w > 1.0f)) continue;  // batchAccumulation > batchSize
+        float gradient = ppg_from_sfixed(T.adam_grad[ak]) / w;
         ++h.adam_iter;
         float lr = 0.01f * __builtin_sqrtf(1 - ppg_powi(0.999f, h.adam_iter)) / (1 - ppg_powi(0.9f, h.adam_iter));
         h.adam_m = 0.9f * h.adam_m + (1 - 0.9f) * gradient;
         h.adam_v = 0.999f * h.adam_v + (1 - 0.999f) * gradient * gradient;
         h.theta -= lr * h.adam_m / (__builtin_sqrtf(h.adam_v) + 1e-08f);
         h.theta = ppg_min(ppg_max(h.theta, -20.0f), 20.0f);
-        T.hdr[i] = h;
+        T.adam_grad[ak] = 0;
+        T.adam_w[ak] = 0;
+        stepped = true;
     }
-    T.adam_grad[i] = 0;
-    T.adam_w[i] = 0;
+    if (stepped) T.hdr[i] = h;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -106,7 +106,7 @@ class HostReducer:
         self._allreduce_np(np.ctypeslib.as_array(w, shape=(n,)))
 
     def reduce_adam(self, e):
-        n = int(e.sdtree_info().n_stree_nodes)
+        n = int(e.sdtree_info().n_stree_nodes) * 64  # PPG_ADAM_BATCHES mini-batches per node
         g = np.zeros(n, np.int64)
         w = np.zeros(n, np.int64)
         e._call("adam_export", g.ctypes.data_as(C.POINTER(C.c_int64)), w.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_uint64(n))
