@@ -7,7 +7,7 @@ WRITE_SIZE need separate passes: MI355X_MICROARCH.md §rocprofv3 PMC slots):
   2. --pmc FETCH_SIZE                → bytes read through the L2's memory side, per kernel
   3. --pmc WRITE_SIZE TCC_HIT TCC_MISS
 Calibration (the guide: FETCH_SIZE under-reports wide streaming reads by 2x on gfx950, WRITE_SIZE is
-uncalibrated): k_generate writes exactly 80 B per path and k_film reads exactly spp*16 + 48 B per pixel, both
+uncalibrated): k_generate writes exactly 80 B per path and k_film reads exactly 16 B per sample + 48 B per pixel and launch, both
 pure streams; their known byte counts give the read / write correction factors applied to all kernels.
 Output: profiles/r01_pmc_traffic.json {bytes_per_unit: {kernel: HBM bytes per unit}, ...}.
 """
@@ -65,7 +65,7 @@ units["k_commit"] = committed  # unit of k_commit = recorded vertex
 
 KB = 1024.0
 gen_known_wr = 80.0 * units["k_generate"]                       # ray_o, ray_d, thr, li, misc
-film_known_rd = (SPP * 16.0 + 4 + 11 * 4) * units["k_film"]      # li samples + pixel index + 11 accumulators
+film_known_rd = 16.0 * W * H * SPP * STEPS + (4 + 11 * 4) * units["k_film"]  # every li sample once + per launch and pixel: index + 11 accumulators
 wr_factor = gen_known_wr / (a3["k_generate"]["WRITE_SIZE"] * KB) if a3["k_generate"]["WRITE_SIZE"] else None
 rd_factor = film_known_rd / (a2["k_film"]["FETCH_SIZE"] * KB) if a2["k_film"]["FETCH_SIZE"] else None
 res = {"source": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE TCC_HIT TCC_MISS, bench.py --steps %d (cbox-720p)" % STEPS,
