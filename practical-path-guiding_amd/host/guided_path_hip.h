@@ -1,0 +1,238 @@
+/*
+ * guided_path_hip.h — C++ host side above the C-ABI: the integrator object a C++ application holds instead of
+ * mitsuba's GuidedPathTracer (guided_path.cpp:1012-2419, cited GP:line).
+ *
+ *   GuidedPathTracerHIP gpt(props);          // props: the reference's property names (GP:1014-1085)
+ *   gpt.render(scene, log);                  // render() — drives renderSPP / renderTime phase by phase and
+ *                                            //            prints the reference's log lines (GP:1176-1186, 1325, 1376)
+ *   gpt.cancel();                            // from another thread (GP:1643-1648)
+ *   gpt.film();                              // weight-normalised RGB
+ *
+ * Everything heavy happens behind include/ppg.h in libppg_hip.so; this file only sequences the phases.
+ */
+#ifndef GUIDED_PATH_HIP_H
+#define GUIDED_PATH_HIP_H
+
+#include <algorithm>
+#include <chrono>
+#include <cstdarg>
+#include <cmath>
+#include <cstdio>
+#include <functional>
+#include <limits>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/ppg.h"
+
+namespace ppg {
+
+// Flat scene owned by the host (what ppg_set_scene copies from)
+struct SceneData {
+    std::vector<float> positions, normals;
+    std::vector<uint32_t> indices, triMaterial;
+    std::vector<int32_t> triEmitter;
+    std::vector<ppg_material> materials;
+    std::vector<ppg_emitter> emitters;
+    ppg_camera camera{};
+
+    ppg_scene view() const {
+        ppg_scene s{};
+        s.n_vertices = (uint32_t)(positions.size() / 3); s.positions = positions.data();
+        s.normals = normals.empty() ? nullptr : normals.data();
+        s.n_triangles = (uint32_t)(indices.size() / 3); s.indices = indices.data();
+        s.tri_material = triMaterial.data(); s.tri_emitter = triEmitter.data();
+        s.n_materials = (uint32_t)materials.size(); s.materials = materials.data();
+        s.n_emitters = (uint32_t)emitters.size(); s.emitters = emitters.data();
+        s.camera = camera;
+        return s;
+    }
+};
+
+// Properties: string map with the typed getters of mitsuba/core/properties.h as far as this plugin uses them
+class Properties {
+public:
+    std::map<std::string, std::string> values;
+    std::string getString(const std::string &k, const std::string &d) const { auto it = values.find(k); return it == values.end() ? d : it->second; }
+    int getInteger(const std::string &k, int d) const { auto it = values.find(k); return it == values.end() ? d : std::stoi(it->second); }
+    float getFloat(const std::string &k, float d) const { auto it = values.find(k); return it == values.end() ? d : std::stof(it->second); }
+    bool getBoolean(const std::string &k, bool d) const {
+        auto it = values.find(k);
+        if (it == values.end()) return d;
+        return it->second == "true" || it->second == "1";
+    }
+};
+
+class GuidedPathTracerHIP {
+public:
+    typedef std::function<void(const std::string &)> Log;
+
+    explicit GuidedPathTracerHIP(const Properties &props) {  // GP:1014-1085 + MonteCarloIntegrator (integrator.cpp:190-225)
+        ppg_config_default(&m_cfg);
+        m_str[0] = props.getString("nee", "never"); m_cfg.nee = m_str[0].c_str();
+        m_str[1] = props.getString("sampleCombination", "automatic"); m_cfg.sampleCombination = m_str[1].c_str();
+        m_str[2] = props.getString("spatialFilter", "nearest"); m_cfg.spatialFilter = m_str[2].c_str();
+        m_str[3] = props.getString("directionalFilter", "nearest"); m_cfg.directionalFilter = m_str[3].c_str();
+        m_str[4] = props.getString("bsdfSamplingFractionLoss", "none"); m_cfg.bsdfSamplingFractionLoss = m_str[4].c_str();
+        m_str[5] = props.getString("budgetType", "seconds"); m_cfg.budgetType = m_str[5].c_str();
+        m_str[6] = props.getString("dumpPrefix", ""); m_cfg.dumpPrefix = m_str[6].empty() ? nullptr : m_str[6].c_str();
+        m_cfg.sdTreeMaxMemory = props.getInteger("sdTreeMaxMemory", -1);
+        m_cfg.sTreeThreshold = props.getInteger("sTreeThreshold", 12000);
+        m_cfg.dTreeThreshold = props.getFloat("dTreeThreshold", 0.01f);
+        m_cfg.bsdfSamplingFraction = props.getFloat("bsdfSamplingFraction", 0.5f);
+        m_cfg.sppPerPass = props.getInteger("sppPerPass", 4);
+        m_cfg.budget = props.getFloat("budget", 300.0f);
+        m_cfg.dumpSDTree = props.getBoolean("dumpSDTree", false);
+        m_cfg.rrDepth = props.getInteger("rrDepth", 5);
+        m_cfg.maxDepth = props.getInteger("maxDepth", -1);
+        m_cfg.strictNormals = props.getBoolean("strictNormals", false);
+        m_cfg.hideEmitters = props.getBoolean("hideEmitters", false);
+        m_cfg.seed = (uint64_t)std::stoull(props.getString("seed", "0"));
+        m_cfg.device = props.getInteger("device", 0);
+        if (ppg_create(&m_cfg, &m_ctx) != PPG_OK) throw std::runtime_error(std::string("ppg_create: ") + ppg_last_error(nullptr));
+    }
+    ~GuidedPathTracerHIP() { ppg_destroy(m_ctx); }
+    GuidedPathTracerHIP(const GuidedPathTracerHIP &) = delete;
+    GuidedPathTracerHIP &operator=(const GuidedPathTracerHIP &) = delete;
+
+    void cancel() { ppg_cancel(m_ctx); }  // GP:1643-1648
+
+    // render(): GP:1516-1585.  Returns false when cancelled, throws on errors.
+    bool render(const SceneData &scene, const Log &log = Log()) {
+        ppg_scene sv = scene.view();
+        check(ppg_set_scene(m_ctx, &sv), "ppg_set_scene");
+        m_w = scene.camera.width; m_h = scene.camera.height;
+        check(ppg_begin_render(m_ctx), "ppg_begin_render");
+        say(log, fmt("Starting render job (%ix%i, MI355X) ..", m_w, m_h));
+        const bool spp = std::string(m_cfg.budgetType) == "spp";
+        bool ok = spp ? renderSPP(log) : renderTime(log);
+        if (ok) check(ppg_end_render(m_ctx), "ppg_end_render");
+        return ok;
+    }
+
+    std::vector<float> film() {
+        std::vector<float> rgb((size_t)m_w * m_h * 3);
+        check(ppg_read_film(m_ctx, rgb.data()), "ppg_read_film");
+        return rgb;
+    }
+    ppg_ctx *context() { return m_ctx; }
+
+private:
+    static std::string fmt(const char *f, ...) __attribute__((format(printf, 1, 2))) {
+        char buf[1024];
+        va_list ap; va_start(ap, f); vsnprintf(buf, sizeof buf, f, ap); va_end(ap);
+        return buf;
+    }
+    static void say(const Log &log, const std::string &s) { if (log) log(s); }
+    void check(int rc, const char *what) { if (rc != PPG_OK && rc != PPG_ERR_CANCELLED) throw std::runtime_error(std::string(what) + ": " + ppg_last_error(m_ctx)); }
+
+    // performRenderPasses, GP:1210-1329
+    bool passes(int n, ppg_pass_stats &st, const Log &log) {
+        say(log, fmt("Rendering %d render passes.", n));
+        int rc = ppg_render_passes(m_ctx, n, &st);
+        check(rc, "ppg_render_passes");
+        const float ttuv = (float)st.seconds * st.variance, stuv = st.passes_rendered_local * m_cfg.sppPerPass * st.variance;
+        say(log, fmt("%.2f seconds, Total passes: %d, Var: %f, TTUV: %f, STUV: %f.", st.seconds, st.passes_rendered_total, st.variance, ttuv, stuv));
+        m_passesRendered = st.passes_rendered_total;
+        return rc == PPG_OK;
+    }
+    void build(const Log &log) {  // buildSDTree, GP:1115-1189
+        say(log, "Building distributions for sampling.");
+        ppg_tree_stats t;
+        check(ppg_build_sdtree(m_ctx, &t), "ppg_build_sdtree");
+        say(log, fmt("Distribution statistics:\n  Depth         = [%d, %f, %d]\n  Mean radiance = [%f, %f, %f]\n  Node count    = [%llu, %f, %llu]\n"
+                     "  Stat. weight  = [%f, %f, %f]\n",
+                     t.min_depth, t.avg_depth, t.max_depth, t.min_mean_radiance, t.avg_mean_radiance, t.max_mean_radiance,
+                     (unsigned long long)t.min_nodes, t.avg_nodes, (unsigned long long)t.max_nodes, t.min_stat_weight, t.avg_stat_weight,
+                     t.max_stat_weight));
+    }
+    bool doNeeWithSpp(int spp) const {  // GP:1331-1340
+        const std::string nee = m_cfg.nee;
+        return nee == "never" ? false : (nee == "kickstart" ? spp < 128 : true);
+    }
+
+    bool renderSPP(const Log &log) {  // GP:1342-1426
+        const size_t sampleCount = (size_t)m_cfg.budget;
+        const int nPasses = (int)std::ceil(sampleCount / (float)m_cfg.sppPerPass);
+        float currentVarAtEnd = std::numeric_limits<float>::infinity();
+        const bool automatic = std::string(m_cfg.sampleCombination) == "automatic";
+        int iter = 0;
+        m_passesRendered = 0;
+        while (m_passesRendered < nPasses) {
+            const int sppRendered = m_passesRendered * m_cfg.sppPerPass;
+            ppg_set_do_nee(m_ctx, doNeeWithSpp(sppRendered));
+            int remainingPasses = nPasses - m_passesRendered;
+            int passesThisIteration = std::min(remainingPasses, 1 << iter);
+            if (remainingPasses - passesThisIteration < 2 * passesThisIteration) passesThisIteration = remainingPasses;
+            say(log, fmt("ITERATION %d, %d passes", iter, passesThisIteration));
+            say(log, "Resetting distributions for sampling.");
+            check(ppg_begin_iteration(m_ctx, passesThisIteration >= remainingPasses), "ppg_begin_iteration");
+            ppg_pass_stats st;
+            if (!passes(passesThisIteration, st, log)) return false;
+            const float lastVarAtEnd = currentVarAtEnd;
+            currentVarAtEnd = passesThisIteration * st.variance / remainingPasses;
+            say(log, fmt("Extrapolated var:\n  Last:    %f\n  Current: %f\n", lastVarAtEnd, currentVarAtEnd));
+            remainingPasses -= passesThisIteration;
+            if (automatic && remainingPasses > 0 && (remainingPasses < passesThisIteration || (sppRendered > 256 && currentVarAtEnd > lastVarAtEnd))) {
+                say(log, fmt("FINAL %d passes", remainingPasses));
+                ppg_set_final(m_ctx, 1);
+                if (!passes(remainingPasses, st, log)) return false;
+            }
+            build(log);
+            check(ppg_end_iteration(m_ctx), "ppg_end_iteration");
+            ++iter;
+        }
+        return true;
+    }
+
+    bool renderTime(const Log &log) {  // GP:1434-1514
+        const float nSeconds = m_cfg.budget;
+        float currentVarAtEnd = std::numeric_limits<float>::infinity();
+        const bool automatic = std::string(m_cfg.sampleCombination) == "automatic";
+        const auto start = std::chrono::steady_clock::now();
+        auto elapsed = [&](std::chrono::steady_clock::time_point t0) {
+            return (float)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() / 1000;
+        };
+        float elapsedSeconds = 0;
+        int iter = 0;
+        m_passesRendered = 0;
+        while (elapsedSeconds < nSeconds) {
+            const int sppRendered = m_passesRendered * m_cfg.sppPerPass;
+            ppg_set_do_nee(m_ctx, doNeeWithSpp(sppRendered));
+            float remainingTime = nSeconds - elapsedSeconds;
+            const int passesThisIteration = 1 << iter;
+            say(log, fmt("ITERATION %d, %d passes", iter, passesThisIteration));
+            const auto startIter = std::chrono::steady_clock::now();
+            check(ppg_begin_iteration(m_ctx, 0), "ppg_begin_iteration");
+            ppg_pass_stats st;
+            if (!passes(passesThisIteration, st, log)) return false;
+            const float secondsIter = elapsed(startIter);
+            const float lastVarAtEnd = currentVarAtEnd;
+            currentVarAtEnd = secondsIter * st.variance / remainingTime;
+            remainingTime -= secondsIter;
+            if (automatic && remainingTime > 0 && (remainingTime < secondsIter || (sppRendered > 256 && currentVarAtEnd > lastVarAtEnd))) {
+                say(log, fmt("FINAL %f seconds", remainingTime));
+                ppg_set_final(m_ctx, 1);
+                do {
+                    if (!passes(passesThisIteration, st, log)) return false;
+                    elapsedSeconds = elapsed(start);
+                } while (elapsedSeconds < nSeconds);
+            }
+            build(log);
+            check(ppg_end_iteration(m_ctx), "ppg_end_iteration");
+            ++iter;
+            elapsedSeconds = elapsed(start);
+        }
+        return true;
+    }
+
+    ppg_config m_cfg;
+    ppg_ctx *m_ctx = nullptr;
+    std::string m_str[7];
+    int m_w = 0, m_h = 0, m_passesRendered = 0;
+};
+
+}  // namespace ppg
+#endif

@@ -1,0 +1,133 @@
+/*
+ * ppg_render — stand-alone C++ driver of the guided path tracer (the role `mitsuba scene.xml` plays for
+ * plugins/guided_path.so; flags follow mitsuba.cpp:154-250 where they apply).
+ *
+ *   ppg_render [-D key=value]... [-o out.pfm] [-q] scene.ppgs
+ *   ppg_render --cbox WIDTHxHEIGHT [-D key=value]... [-o out.pfm]
+ *
+ * scene.ppgs is the flat binary scene written by ppg_host.scenes.save_scene() (header "PPGS", then the arrays of
+ * include/ppg.h's ppg_scene).  --cbox builds scenes/cbox/cbox.xml procedurally like ppg_host.scenes.cbox_scene.
+ * -D sets integrator properties (reference names: budget, budgetType, sppPerPass, sTreeThreshold, ...).
+ * Output: PFM (little endian RGB float), the log lines of the reference on stdout.
+ */
+#include <cstdarg>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+
+#include "guided_path_hip.h"
+
+using namespace ppg;
+
+static bool loadScene(const char *path, SceneData &s) {
+    std::ifstream f(path, std::ios::binary);
+    char magic[4];
+    uint32_t hdr[6];
+    if (!f.read(magic, 4) || memcmp(magic, "PPGS", 4) != 0 || !f.read((char *)hdr, sizeof hdr)) return false;
+    const uint32_t nv = hdr[0], nt = hdr[1], nm = hdr[2], ne = hdr[3], hasN = hdr[4];
+    s.positions.resize(3 * (size_t)nv); f.read((char *)s.positions.data(), s.positions.size() * 4);
+    if (hasN) { s.normals.resize(3 * (size_t)nv); f.read((char *)s.normals.data(), s.normals.size() * 4); }
+    s.indices.resize(3 * (size_t)nt); f.read((char *)s.indices.data(), s.indices.size() * 4);
+    s.triMaterial.resize(nt); f.read((char *)s.triMaterial.data(), (size_t)nt * 4);
+    s.triEmitter.resize(nt); f.read((char *)s.triEmitter.data(), (size_t)nt * 4);
+    s.materials.resize(nm); f.read((char *)s.materials.data(), (size_t)nm * sizeof(ppg_material));
+    s.emitters.resize(ne); f.read((char *)s.emitters.data(), (size_t)ne * sizeof(ppg_emitter));
+    f.read((char *)&s.camera, sizeof(ppg_camera));
+    return (bool)f;
+}
+
+struct M4 { double m[16]; };  // row major
+
+static void cboxScene(int w, int h, SceneData &s) {
+    // geometry / colours: see ppg_host/scenes.py:cbox_scene (scenes/cbox/cbox.xml + meshes/*.obj of the reference)
+    struct Q { float v[4][3]; int mat, em; };
+    std::vector<Q> quads;
+    auto quad = [&](std::initializer_list<std::initializer_list<float>> vs, int mat, int em) {
+        Q q; int i = 0; for (auto &v : vs) { int j = 0; for (float c : v) q.v[i][j++] = c; ++i; } q.mat = mat; q.em = em; quads.push_back(q);
+    };
+    const float ly = 1020.0f - 548.79999f, z0 = 550.0f - 227.0f, z1 = 550.0f - 332.0f;
+    quad({{343, ly, z0}, {343, ly, z1}, {213, ly, z1}, {213, ly, z0}}, 4, 0);
+    quad({{552.79999f, 0, 0}, {0, 0, 0}, {0, 0, 559.20001f}, {549.59998f, 0, 559.20001f}}, 1, -1);
+    quad({{556, 548.79999f, 0}, {556, 548.79999f, 559.20001f}, {0, 548.79999f, 559.20001f}, {0, 548.79999f, 0}}, 1, -1);
+    quad({{549.59998f, 0, 559.20001f}, {0, 0, 559.20001f}, {0, 548.79999f, 559.20001f}, {556, 548.79999f, 559.20001f}}, 1, -1);
+    quad({{0, 0, 559.20001f}, {0, 0, 0}, {0, 548.79999f, 0}, {0, 548.79999f, 559.20001f}}, 3, -1);
+    quad({{552.79999f, 0, 0}, {549.59998f, 0, 559.20001f}, {556, 548.79999f, 559.20001f}, {556, 548.79999f, 0}}, 2, -1);
+    auto box = [&](const float fp[4][2], float hh) {
+        const float *a = fp[0], *b = fp[1], *c = fp[2], *d = fp[3];
+        quad({{a[0], hh, a[1]}, {b[0], hh, b[1]}, {c[0], hh, c[1]}, {d[0], hh, d[1]}}, 0, -1);
+        const float *ring[4] = {a, d, c, b};
+        for (int i = 0; i < 4; ++i) { const float *p = ring[i], *q = ring[(i + 1) % 4]; quad({{p[0], 0, p[1]}, {p[0], hh, p[1]}, {q[0], hh, q[1]}, {q[0], 0, q[1]}}, 0, -1); }
+        quad({{d[0], 0, d[1]}, {c[0], 0, c[1]}, {b[0], 0, b[1]}, {a[0], 0, a[1]}}, 0, -1);
+    };
+    const float sm[4][2] = {{130, 65}, {82, 225}, {240, 272}, {290, 114}}, lg[4][2] = {{423, 247}, {265, 296}, {314, 456}, {472, 406}};
+    box(sm, 165); box(lg, 330);
+    for (auto &q : quads) {
+        uint32_t base = (uint32_t)(s.positions.size() / 3);
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < 3; ++j) s.positions.push_back(q.v[i][j]);
+        const uint32_t idx[6] = {base, base + 1, base + 2, base, base + 2, base + 3};
+        s.indices.insert(s.indices.end(), idx, idx + 6);
+        for (int t = 0; t < 2; ++t) { s.triMaterial.push_back((uint32_t)q.mat); s.triEmitter.push_back(q.em); }
+    }
+    const float rgb[5][3] = {{0.88579154f, 0.698900044f, 0.666440606f}, {0.88579154f, 0.698900044f, 0.666440606f}, {0.570083559f, 0.0430142134f, 0.0443643667f},
+                             {0.10540954f, 0.377989352f, 0.076434195f}, {0.936401188f, 0.740475953f, 0.705280542f}};
+    for (auto &c : rgb) { ppg_material m{}; m.type = PPG_BSDF_DIFFUSE; memcpy(m.reflectance, c, 12); s.materials.push_back(m); }
+    ppg_emitter e{}; e.radiance[0] = 36.7738686f; e.radiance[1] = 21.976778f; e.radiance[2] = 5.50738001f; s.emitters.push_back(e);
+    // perspective camera: sensor.cpp:239-264, perspective.cpp:150-164, transform.cpp:99-123, 191-214
+    const double aspect = (double)w / h, fov = 39.3077, nearC = 10, farC = 2800;
+    const double xfov = aspect > 1 ? 2 * std::atan(std::tan(0.5 * fov * M_PI / 180) * aspect) * 180 / M_PI : fov;  // fovAxis "smaller"
+    const double cot = 1 / std::tan(xfov / 2 * M_PI / 180), recip = 1 / (farC - nearC);
+    // cameraToSample = scale(-0.5, -0.5*aspect, 1) * translate(-1, -1/aspect, 0) * perspective  → invert analytically
+    // x_s = -0.5 (cot x / z - 1), y_s = -0.5 aspect (cot y / z - 1 / aspect), z_s = far recip (1 - near / z)
+    M4 inv{};  // sample → camera, homogeneous: (x, y, z, w) = (-(2 xs - 1)/cot, -(2 ys / aspect - 1/aspect)/cot, 1, (far - zs (far - near)) / (near far))
+    inv.m[0] = -2 / cot; inv.m[3] = 1 / cot;
+    inv.m[5] = -2 / (aspect * cot); inv.m[7] = 1 / (aspect * cot);
+    inv.m[11] = 1;
+    inv.m[14] = -(farC - nearC) / (nearC * farC); inv.m[15] = 1 / nearC;
+    (void)recip;
+    for (int i = 0; i < 16; ++i) s.camera.sample_to_camera[i] = (float)inv.m[i];
+    // lookAt(origin (278, 273, -800), target = origin + z, up = y): dir = z, left = up x dir = x, newUp = y
+    const double c2w[16] = {1, 0, 0, 278, 0, 1, 0, 273, 0, 0, 1, -800, 0, 0, 0, 1};
+    for (int i = 0; i < 16; ++i) s.camera.camera_to_world[i] = (float)c2w[i];
+    s.camera.near_clip = (float)nearC; s.camera.far_clip = (float)farC; s.camera.width = w; s.camera.height = h;
+}
+
+static void writePFM(const char *path, const std::vector<float> &rgb, int w, int h) {
+    std::ofstream f(path, std::ios::binary);
+    f << "PF\n" << w << " " << h << "\n-1.0\n";
+    for (int y = h - 1; y >= 0; --y) f.write((const char *)&rgb[(size_t)y * w * 3], (size_t)w * 12);  // PFM is bottom-up
+}
+
+int main(int argc, char **argv) {
+    Properties props;
+    std::string out = "out.pfm", scenePath;
+    bool quiet = false;
+    int cw = 0, ch = 0;
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        if (a == "-D" && i + 1 < argc) {
+            std::string kv = argv[++i];
+            size_t eq = kv.find('=');
+            if (eq == std::string::npos) { std::cerr << "-D expects key=value\n"; return 2; }
+            props.values[kv.substr(0, eq)] = kv.substr(eq + 1);
+        } else if (a == "-o" && i + 1 < argc) out = argv[++i];
+        else if (a == "-q") quiet = true;
+        else if (a == "--cbox" && i + 1 < argc) { if (sscanf(argv[++i], "%dx%d", &cw, &ch) != 2) { std::cerr << "--cbox WxH\n"; return 2; } }
+        else if (a == "-h" || a == "--help") { std::cout << "usage: ppg_render [-D key=value]... [-o out.pfm] [-q] (scene.ppgs | --cbox WxH)\n"; return 0; }
+        else scenePath = a;
+    }
+    SceneData scene;
+    if (cw > 0) cboxScene(cw, ch, scene);
+    else if (scenePath.empty() || !loadScene(scenePath.c_str(), scene)) { std::cerr << "cannot load scene '" << scenePath << "'\n"; return 2; }
+    try {
+        GuidedPathTracerHIP gpt(props);
+        const auto t0 = std::chrono::steady_clock::now();
+        bool ok = gpt.render(scene, quiet ? GuidedPathTracerHIP::Log() : [](const std::string &s) { std::cout << s << std::endl; });
+        const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (!quiet) std::cout << "Render time: " << sec << "s" << (ok ? "" : " (cancelled)") << std::endl;
+        writePFM(out.c_str(), gpt.film(), scene.camera.width, scene.camera.height);
+        return ok ? 0 : 1;
+    } catch (const std::exception &e) {
+        std::cerr << "error: " << e.what() << std::endl;
+        return 3;
+    }
+}

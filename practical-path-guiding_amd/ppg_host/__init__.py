@@ -7,5 +7,5 @@
 `distributed` tile-sharded multi-GPU driver (one process per GPU, RCCL all-reduce of SD-tree statistics)
 """
 from .bindings import Engine, PPGError, Config, PassStats, TreeStats, hip_library_path  # noqa: F401
-from .scenes import SceneDesc, cbox_scene, perspective_camera, room_scene  # noqa: F401
+from .scenes import SceneDesc, cbox_scene, perspective_camera, room_scene, save_scene  # noqa: F401
 from .integrator import GuidedPathTracer  # noqa: F401,E402

@@ -25,6 +25,32 @@ class SceneDesc:
         return int(np.asarray(self.indices).shape[0])
 
 
+def save_scene(desc, path):
+    """Write the flat binary scene read by host/ppg_render.cpp: "PPGS", 6 x uint32 {n_vertices, n_triangles, n_materials,
+    n_emitters, has_normals, 0}, then positions, [normals], indices, tri_material, tri_emitter, materials
+    (ppg_material: int32 type, 3 + 4 floats), emitters (4 floats), camera (ppg_camera)."""
+    import struct
+    pos = np.ascontiguousarray(desc.positions, np.float32)
+    idx = np.ascontiguousarray(desc.indices, np.uint32)
+    with open(path, "wb") as f:
+        f.write(b"PPGS")
+        f.write(struct.pack("<6I", pos.shape[0], idx.shape[0], len(desc.materials), len(desc.emitters), 0 if desc.normals is None else 1, 0))
+        f.write(pos.tobytes())
+        if desc.normals is not None:
+            f.write(np.ascontiguousarray(desc.normals, np.float32).tobytes())
+        f.write(idx.tobytes())
+        f.write(np.ascontiguousarray(desc.tri_material, np.uint32).tobytes())
+        f.write(np.ascontiguousarray(desc.tri_emitter, np.int32).tobytes())
+        for m in desc.materials:
+            f.write(struct.pack("<i7f", m.get("type", 0), *[float(np.float32(v)) for v in m["reflectance"]], 0, 0, 0, 0))
+        for e in desc.emitters:
+            f.write(struct.pack("<4f", *[float(np.float32(v)) for v in e["radiance"]], 0))
+        c = desc.camera
+        f.write(np.asarray(c["sample_to_camera"], np.float32).tobytes())
+        f.write(np.asarray(c["camera_to_world"], np.float32).tobytes())
+        f.write(struct.pack("<2f2i", c["near_clip"], c["far_clip"], c["width"], c["height"]))
+
+
 def perspective_camera(origin, target, up, fov_deg, fov_axis, near, far, width, height):
     """Matrices of sensors/perspective.cpp:150-164 (m_sampleToCamera) and Transform::lookAt
     (transform.cpp:191-214); fov-axis handling of sensor.cpp:239-264.  Computed in double, stored as

@@ -1,0 +1,86 @@
+"""The C++ host side above the C-ABI (practical-path-guiding_amd/host): class GuidedPathTracerHIP + the ppg_render driver."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import CBOX_PROPS, PKG, ROOT
+
+BIN = os.path.join(PKG, "bin", "ppg_render")
+
+
+@pytest.fixture(scope="module")
+def ppg_render():
+    if not os.path.exists(BIN):
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "__graft_entry__.py")])
+    return BIN
+
+
+def read_pfm(path):
+    with open(path, "rb") as f:
+        assert f.readline().strip() == b"PF"
+        w, h = map(int, f.readline().split())
+        assert float(f.readline()) < 0  # little endian
+        data = np.frombuffer(f.read(), "<f4").reshape(h, w, 3)
+    return data[::-1]  # PFM is bottom-up
+
+
+def test_driver_builds_and_rejects_bad_input(ppg_render, tmp_path):
+    r = subprocess.run([ppg_render, "--help"], capture_output=True, text=True)
+    assert r.returncode == 0 and "usage" in r.stdout
+    r = subprocess.run([ppg_render, str(tmp_path / "missing.ppgs")], capture_output=True, text=True)
+    assert r.returncode == 2 and "cannot load scene" in r.stderr
+    r = subprocess.run([ppg_render, "--cbox", "8x8", "-D", "spatialFilter=gauss"], capture_output=True, text=True)
+    assert r.returncode == 3 and ("spatialFilter" in r.stderr or "HIP device" in r.stderr)  # unknown enum value / no GPU here
+
+
+def test_scene_file_round_trip(tmp_path):
+    import struct
+    import ppg_host
+    s = ppg_host.cbox_scene(40, 30)
+    p = tmp_path / "cbox.ppgs"
+    ppg_host.save_scene(s, str(p))
+    buf = p.read_bytes()
+    assert buf[:4] == b"PPGS"
+    nv, nt, nm, ne, has_n, _ = struct.unpack_from("<6I", buf, 4)
+    assert (nv, nt, nm, ne, has_n) == (72, 36, 5, 1, 0)
+    off = 28
+    assert np.array_equal(np.frombuffer(buf, np.float32, nv * 3, off).reshape(-1, 3), s.positions)
+    expect = 28 + nv * 12 + nt * 12 + nt * 4 + nt * 4 + nm * 32 + ne * 16 + (16 + 16) * 4 + 16
+    assert len(buf) == expect
+    w, h = struct.unpack_from("<2i", buf, len(buf) - 8)
+    assert (w, h) == (40, 30)
+
+
+@pytest.mark.gpu
+def test_cpp_driver_equals_python_path(ppg_render, tmp_path):
+    import ppg_host
+    scene = ppg_host.cbox_scene(96, 64)
+    path = str(tmp_path / "cbox.ppgs")
+    ppg_host.save_scene(scene, path)
+    for extra in ({}, dict(sampleCombination="inversevar", bsdfSamplingFractionLoss="kl", spatialFilter="stochastic", directionalFilter="box",
+                           sTreeThreshold=4000, sppPerPass=1)):
+        props = dict(CBOX_PROPS, budget=60, seed=5, **extra)
+        out = str(tmp_path / "out.pfm")
+        args = [ppg_render, "-o", out]
+        for k, v in props.items():
+            args += ["-D", "%s=%s" % (k, v)]
+        r = subprocess.run(args + [path], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        its = [int(m) for m in re.findall(r"ITERATION \d+, (\d+) passes", r.stdout)]
+        e = ppg_host.Engine.hip(**props)
+        gpt = ppg_host.GuidedPathTracer(engine=e)
+        img = gpt.render(scene)
+        assert its == [it["passes"] for it in gpt.iterations]
+        assert "Distribution statistics" in r.stdout and "Total passes" in r.stdout  # the reference's log lines (GP:1176-1186, 1325)
+        assert np.array_equal(read_pfm(out), img)
+    # the built-in procedural CBOX (own C++ camera maths) renders the same picture up to the camera matrix's last bit
+    out2 = str(tmp_path / "cbox.pfm")
+    r = subprocess.run([ppg_render, "--cbox", "96x64", "-q", "-o", out2] + sum([["-D", "%s=%s" % kv] for kv in dict(CBOX_PROPS, budget=60, seed=5).items()], []),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    a, b = read_pfm(out2), ppg_host.GuidedPathTracer(engine=ppg_host.Engine.hip(**dict(CBOX_PROPS, budget=60, seed=5))).render(scene)
+    assert abs(a.mean() / b.mean() - 1) < 0.05
