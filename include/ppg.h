@@ -73,7 +73,12 @@ void ppg_config_default(ppg_config *cfg);
  * Scene: what GuidedPathTracer::render() reaches through `Scene*` (GP:1516-1527, 1784, 1934, 2193),
  * flattened.  Triangles only; per-triangle BSDF and emitter indices.
  * ---------------------------------------------------------------------------------------------- */
-enum { PPG_BSDF_DIFFUSE = 0 /* mitsuba/src/bsdfs/diffuse.cpp:110-150 (one-sided Lambertian) */ };
+enum {
+    PPG_BSDF_DIFFUSE = 0,          /* mitsuba/src/bsdfs/diffuse.cpp:110-150 (one-sided Lambertian) */
+    PPG_BSDF_TWOSIDED_DIFFUSE = 1, /* twosided.cpp:100-180 around one diffuse BRDF (same on both sides) */
+    PPG_BSDF_MIRROR = 2            /* conductor.cpp:220-290 with material "none" (Fresnel = 1): ideal specular reflection,
+                                      reflectance = specularReflectance; a delta BSDF — never guided (GP:1942-1944, 1654) */
+};
 
 typedef struct ppg_material {
     int32_t type;         /* PPG_BSDF_* */

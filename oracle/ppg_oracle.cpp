@@ -1058,6 +1058,60 @@ struct Diffuse {
     }
 };
 
+// BSDF dispatch: getType / eval / pdf / sample of the supported plugins
+struct BSDF {
+    static bool isSmooth(const ppg_material &m) { return m.type != PPG_BSDF_MIRROR; }   // getType() & ESmooth
+    static bool allDelta(const ppg_material &m) { return m.type == PPG_BSDF_MIRROR; }   // (type & EDelta) == (type & EAll)
+
+    static Spectrum eval(const ppg_material &m, const BRec &b) {
+        switch (m.type) {
+            case PPG_BSDF_DIFFUSE: return Diffuse::eval(m, b);
+            case PPG_BSDF_TWOSIDED_DIFFUSE: {  // twosided.cpp eval: flip both directions onto the front side
+                BRec c = b;
+                if (c.wi.z > 0) return Diffuse::eval(m, c);
+                c.wi.z *= -1; c.wo.z *= -1;
+                return Diffuse::eval(m, c);
+            }
+            default: return Spectrum(0.0f);  // conductor.cpp:222-237: zero for the solid-angle measure
+        }
+    }
+    static Float pdf(const ppg_material &m, const BRec &b) {
+        switch (m.type) {
+            case PPG_BSDF_DIFFUSE: return Diffuse::pdf(m, b);
+            case PPG_BSDF_TWOSIDED_DIFFUSE: {
+                BRec c = b;
+                if (c.wi.z > 0) return Diffuse::pdf(m, c);
+                c.wi.z *= -1; c.wo.z *= -1;
+                return Diffuse::pdf(m, c);
+            }
+            default: return 0.0f;
+        }
+    }
+    static Spectrum sample(const ppg_material &m, BRec &b, Float &pdf, const Point2 &sample) {
+        switch (m.type) {
+            case PPG_BSDF_DIFFUSE: return Diffuse::sample(m, b, pdf, sample);
+            case PPG_BSDF_TWOSIDED_DIFFUSE: {  // twosided.cpp:160-180
+                bool flipped = false;
+                if (b.wi.z < 0) { b.wi.z *= -1; flipped = true; }
+                Spectrum result = Diffuse::sample(m, b, pdf, sample);
+                if (flipped) {
+                    b.wi.z *= -1;
+                    if (!isZero(result) && pdf != 0) b.wo.z *= -1;
+                }
+                return result;
+            }
+            default: {  // conductor.cpp:268-284, material "none"
+                if (b.wi.z <= 0) { pdf = 0.0f; return Spectrum(0.0f); }
+                b.wo = Vec(-b.wi.x, -b.wi.y, b.wi.z);  // reflect(wi)
+                b.eta = 1.0f;
+                b.sampledDelta = true;
+                pdf = 1;
+                return Diffuse::refl(m);
+            }
+        }
+    }
+};
+
 // ------------------------------------------------------------------------------------------------
 // GuidedPathTracer GP:1012-2419
 // ------------------------------------------------------------------------------------------------
@@ -1315,8 +1369,8 @@ public:
     Spectrum sampleMat(const ppg_material &bsdf, BRec &bRec, const Frame &shFrame, Float &woPdf, Float &bsdfPdf, Float &dTreePdf,
                        Float bsdfSamplingFraction, Sampler &sampler, const DTreeWrapper *dTree) const {
         Point2 sample = sampler.next2D();
-        if (!m_isBuilt || !dTree) {
-            Spectrum result = Diffuse::sample(bsdf, bRec, bsdfPdf, sample);
+        if (!m_isBuilt || !dTree || BSDF::allDelta(bsdf)) {
+            Spectrum result = BSDF::sample(bsdf, bRec, bsdfPdf, sample);
             woPdf = bsdfPdf;
             dTreePdf = 0;
             return result;
@@ -1324,10 +1378,15 @@ public:
         Spectrum result;
         if (sample.x < bsdfSamplingFraction) {
             sample.x /= bsdfSamplingFraction;
-            result = Diffuse::sample(bsdf, bRec, bsdfPdf, sample);
+            result = BSDF::sample(bsdf, bRec, bsdfPdf, sample);
             if (isZero(result)) {
                 woPdf = bsdfPdf = dTreePdf = 0;
                 return Spectrum(0.0f);
+            }
+            if (bRec.sampledDelta) {  // GP:1672-1676 (unreachable with the supported BSDFs: a delta lobe implies all-delta here)
+                dTreePdf = 0;
+                woPdf = bsdfPdf * bsdfSamplingFraction;
+                return result / bsdfSamplingFraction;
             }
             result = result * bsdfPdf;
         } else {
@@ -1335,7 +1394,7 @@ public:
             bRec.wo = shFrame.toLocal(dTree->sample(&sampler));
             bRec.sampledDelta = false;
             bRec.eta = 1.0f;
-            result = Diffuse::eval(bsdf, bRec);
+            result = BSDF::eval(bsdf, bRec);
         }
         pdfMat(woPdf, bsdfPdf, dTreePdf, bsdfSamplingFraction, bsdf, bRec, shFrame, dTree);
         if (woPdf == 0) return Spectrum(0.0f);
@@ -1345,11 +1404,11 @@ public:
     void pdfMat(Float &woPdf, Float &bsdfPdf, Float &dTreePdf, Float bsdfSamplingFraction, const ppg_material &bsdf, const BRec &bRec,
                 const Frame &shFrame, const DTreeWrapper *dTree) const {
         dTreePdf = 0;
-        if (!m_isBuilt || !dTree) {
-            woPdf = bsdfPdf = Diffuse::pdf(bsdf, bRec);
+        if (!m_isBuilt || !dTree || BSDF::allDelta(bsdf)) {
+            woPdf = bsdfPdf = BSDF::pdf(bsdf, bRec);
             return;
         }
-        bsdfPdf = Diffuse::pdf(bsdf, bRec);
+        bsdfPdf = BSDF::pdf(bsdf, bRec);
         if (!ppg_isfinite(bsdfPdf)) {
             woPdf = 0;
             return;
@@ -1444,7 +1503,8 @@ public:
 
             const ppg_material &bsdf = scene.materials[its.material];
             Vec dTreeVoxelSize;
-            DTreeWrapper *dTree = m_sdTree->dTreeWrapper(its.p, dTreeVoxelSize);  // diffuse is ESmooth, GP:1942-1944
+            DTreeWrapper *dTree = nullptr;
+            if (BSDF::isSmooth(bsdf)) dTree = m_sdTree->dTreeWrapper(its.p, dTreeVoxelSize);  // GP:1942-1944
 
             Float bsdfSamplingFraction = m_bsdfSamplingFraction;  // GP:1946-1949
             if (dTree && m_bsdfSamplingFractionLoss != ENone) bsdfSamplingFraction = dTree->bsdfSamplingFraction();
@@ -1718,7 +1778,7 @@ int ppgo_set_scene(ppgo_ctx *ctx, const ppg_scene *s) {
     if (s->n_emitters) sc.emitters.assign(s->emitters, s->emitters + s->n_emitters);
     for (uint32_t t = 0; t < s->n_triangles; ++t) {
         if (sc.triMat[t] >= s->n_materials || sc.triEmitter[t] >= (int32_t)s->n_emitters) { ctx->gpt.error = "index out of range"; return PPG_ERR_INVALID; }
-        if (sc.materials[sc.triMat[t]].type != PPG_BSDF_DIFFUSE) { ctx->gpt.error = "unsupported BSDF type"; return PPG_ERR_INVALID; }
+        if (sc.materials[sc.triMat[t]].type < 0 || sc.materials[sc.triMat[t]].type > PPG_BSDF_MIRROR) { ctx->gpt.error = "unsupported BSDF type"; return PPG_ERR_INVALID; }
         for (int k = 0; k < 3; ++k) if (sc.idx[3 * t + k] >= s->n_vertices) { ctx->gpt.error = "vertex index out of range"; return PPG_ERR_INVALID; }
     }
     sc.cam = s->camera;

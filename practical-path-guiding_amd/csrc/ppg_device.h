@@ -357,6 +357,47 @@ D float diffuse_pdf(F3 wi, F3 wo) {
     return PPG_INV_PI_F * wo.z;
 }
 
+// BSDF dispatch over the supported plugins (include/ppg.h PPG_BSDF_*): diffuse.cpp:110-150, twosided.cpp:100-180
+// (one diffuse BRDF on both sides), conductor.cpp:220-290 with material "none" (ideal mirror, delta)
+D bool bsdf_is_smooth(int type) { return type != PPG_BSDF_MIRROR; }
+D F3 bsdf_eval(int type, F3 refl, F3 wi, F3 wo) {
+    if (type == PPG_BSDF_DIFFUSE) return diffuse_eval(refl, wi, wo);
+    if (type == PPG_BSDF_TWOSIDED_DIFFUSE) {
+        if (wi.z > 0) return diffuse_eval(refl, wi, wo);
+        wi.z *= -1; wo.z *= -1;
+        return diffuse_eval(refl, wi, wo);
+    }
+    return f3s(0.0f);
+}
+D float bsdf_pdf(int type, F3 wi, F3 wo) {
+    if (type == PPG_BSDF_DIFFUSE) return diffuse_pdf(wi, wo);
+    if (type == PPG_BSDF_TWOSIDED_DIFFUSE) {
+        if (wi.z > 0) return diffuse_pdf(wi, wo);
+        wi.z *= -1; wo.z *= -1;
+        return diffuse_pdf(wi, wo);
+    }
+    return 0.0f;
+}
+// returns the sampling weight f·cos/pdf; wo, pdf, delta are outputs
+D F3 bsdf_sample(int type, F3 refl, F3 wi, float sx, float sy, F3 &wo, float &pdf, bool &delta) {
+    delta = false;
+    wo = f3s(0.0f);
+    if (type == PPG_BSDF_MIRROR) {
+        if (wi.z <= 0) { pdf = 0.0f; return f3s(0.0f); }
+        wo = f3(-wi.x, -wi.y, wi.z);  // reflect(wi)
+        pdf = 1;
+        delta = true;
+        return refl;
+    }
+    bool flipped = false;
+    if (type == PPG_BSDF_TWOSIDED_DIFFUSE && wi.z < 0) { wi.z *= -1; flipped = true; }
+    if (wi.z <= 0) { pdf = 0.0f; return f3s(0.0f); }
+    wo = cosine_hemisphere(sx, sy);
+    pdf = PPG_INV_PI_F * wo.z;
+    if (flipped && !iszero3(refl) && pdf != 0) wo.z *= -1;
+    return refl;
+}
+
 // ------------------------------------------------------------------------------------------------
 // SD-tree
 // ------------------------------------------------------------------------------------------------
@@ -500,9 +541,16 @@ D float dtree_mean(float sum, float statw) {
     return factor * sum;
 }
 
+// what sampling / pdf evaluation need of a leaf's header
+struct DTreeRef {
+    unsigned int s_base;
+    float s_sum, s_statw;
+};
+D DTreeRef dtree_ref(const LeafHdr &h) { DTreeRef r; r.s_base = h.s_base; r.s_sum = h.s_sum; r.s_statw = h.s_statw; return r; }
+
 // DTree::pdf + QuadTreeNode::pdf (GP:415-421, 232-245), iterative
 template <typename Stack>
-D float dtree_pdf(const DevTree &T, const LeafHdr &h, float px, float py, Stack factors) {
+D float dtree_pdf(const DevTree &T, const DTreeRef &h, float px, float py, Stack factors) {
     if (!(dtree_mean(h.s_sum, h.s_statw) > 0)) return 1 / (4 * PPG_PI_F);
     // the recursion multiplies factors from the leaf upwards: f1 * (f2 * (f3 * ...)); keep that order
     int nf = 0;
@@ -525,7 +573,7 @@ D float dtree_pdf(const DevTree &T, const LeafHdr &h, float px, float py, Stack 
 
 // DTree::sample + QuadTreeNode::sample (GP:431-442, 257-301), iterative.
 // The recursion returns origin + 0.5 * child.sample(); unrolled as a stack of origins.
-D void dtree_sample(const DevTree &T, const LeafHdr &h, uint32_t key, uint32_t &dim, float &ox, float &oy) {
+D void dtree_sample(const DevTree &T, const DTreeRef &h, uint32_t key, uint32_t &dim, float &ox, float &oy) {
     if (!(dtree_mean(h.s_sum, h.s_statw) > 0)) {
         ox = ppg_rand(key, dim++);
         oy = ppg_rand(key, dim++);

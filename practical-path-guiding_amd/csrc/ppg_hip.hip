@@ -1050,7 +1050,7 @@ int ppg_set_scene(ppg_ctx *ctx, const ppg_scene *s) {
     HIP_CHECK(hipSetDevice(ctx->device));
     for (uint32_t t = 0; t < s->n_triangles; ++t) {
         if (s->tri_material[t] >= s->n_materials || s->tri_emitter[t] >= (int32_t)s->n_emitters) { ctx->error = "index out of range"; return PPG_ERR_INVALID; }
-        if (s->materials[s->tri_material[t]].type != PPG_BSDF_DIFFUSE) { ctx->error = "unsupported BSDF type"; return PPG_ERR_INVALID; }
+        if (s->materials[s->tri_material[t]].type < 0 || s->materials[s->tri_material[t]].type > PPG_BSDF_MIRROR) { ctx->error = "unsupported BSDF type"; return PPG_ERR_INVALID; }
         for (int k = 0; k < 3; ++k) if (s->indices[3 * t + k] >= s->n_vertices) { ctx->error = "vertex index out of range"; return PPG_ERR_INVALID; }
     }
     // Scene::getAABB(): kd-tree box enlarged by MTS_KD_AABB_EPSILON (gkdtree.h:1213-1220) + sensor position (scene.cpp:386-414)

@@ -17,7 +17,7 @@
 #define PPG_MAX_VERTICES 32  // MAX_NUM_VERTICES, GP:1771
 #define PPG_BLOCK 256
 #ifndef PPG_SHADE_WAVES
-#define PPG_SHADE_WAVES 2  // min waves per SIMD requested for k_shade (register budget), tuned on MI355X
+#define PPG_SHADE_WAVES 4  // waves per SIMD requested for k_shade: 128 VGPRs without spilling (5 or 6 spill and are slower, 2-3 waste occupancy)
 #endif
 
 enum { NEE_NEVER = 0, NEE_KICKSTART = 1, NEE_ALWAYS = 2 };
@@ -484,35 +484,30 @@ D void shade_slice(const PathState &P, const DevScene &S, const DevTree &T, cons
                 if (wiDotGeoN * wiDotShN < 0 && R.strict_normals) go = false;
             }
             if (go) {
-                F3 vox;
-#if defined(PPG_ABLATE) && PPG_ABLATE == 3
-                const int leaf = 0; vox = f3s(1.0f);
-#else
-                const int leaf = stree_lookup(T, I.p, vox);  // GP:1942-1944
-#endif
-                const LeafHdr hd = T.hdr[leaf];
-                float frac = R.bsdf_sampling_fraction;  // GP:1946-1949
-                if (R.loss != LOSS_NONE) frac = logistic(hd.theta);
                 float4 mat = S.materials[I.material];
-                F3 refl = f3(mat.x, mat.y, mat.z);
+                const F3 refl = f3(mat.x, mat.y, mat.z);
+                const int mtype = (int)mat.w;
+                const bool smooth = bsdf_is_smooth(mtype);  // bsdf->getType() & ESmooth: only those are guided
+                F3 vox = f3s(0.0f);
+                int leaf = 0;
+                DTreeRef hd;
+                hd.s_base = 0; hd.s_sum = 0; hd.s_statw = 0;
+                float frac = R.bsdf_sampling_fraction;  // GP:1946-1949
+                if (smooth) {
+                    leaf = stree_lookup(T, I.p, vox);  // GP:1942-1944
+                    const float4 h4 = *reinterpret_cast<const float4 *>(&T.hdr[leaf]);  // {s_base, s_num, s_sum, s_statw}
+                    hd.s_base = __float_as_uint(h4.x); hd.s_sum = h4.z; hd.s_statw = h4.w;
+                    if (R.loss != LOSS_NONE) frac = logistic(T.hdr[leaf].theta);
+                }
 
                 // sampleMat, GP:1650-1691
                 float sx = ppg_rand(key, dim++);
                 float sy = ppg_rand(key, dim++);
                 F3 wo_l, bsdfWeight;
                 float woPdf, bsdfPdf, dTreePdf;
-#if defined(PPG_ABLATE) && PPG_ABLATE == 1
-                if (true) {
-#else
-                if (!T.is_built) {
-#endif
-                    if (I.wi.z <= 0) {
-                        bsdfWeight = f3s(0.0f); bsdfPdf = 0.0f; wo_l = f3s(0.0f);
-                    } else {
-                        wo_l = cosine_hemisphere(sx, sy);
-                        bsdfPdf = PPG_INV_PI_F * wo_l.z;
-                        bsdfWeight = refl;
-                    }
+                bool sampledDelta = false;
+                if (!T.is_built || !smooth) {  // !m_isBuilt || !dTree || all components are delta
+                    bsdfWeight = bsdf_sample(mtype, refl, I.wi, sx, sy, wo_l, bsdfPdf, sampledDelta);
                     woPdf = bsdfPdf;
                     dTreePdf = 0;
                 } else {
@@ -520,21 +515,15 @@ D void shade_slice(const PathState &P, const DevScene &S, const DevTree &T, cons
                     bool zero = false;
                     if (sx < frac) {
                         sx /= frac;
-                        if (I.wi.z <= 0) {
-                            zero = true;
-                        } else {
-                            wo_l = cosine_hemisphere(sx, sy);
-                            bsdfPdf = PPG_INV_PI_F * wo_l.z;
-                            result = refl;
-                            if (iszero3(result)) zero = true;
-                            else result = result * bsdfPdf;
-                        }
+                        result = bsdf_sample(mtype, refl, I.wi, sx, sy, wo_l, bsdfPdf, sampledDelta);
+                        if (iszero3(result)) zero = true;
+                        else result = result * bsdfPdf;
                     } else {
                         // sample.x is remapped but unused on this branch (GP:1680-1682)
                         float cx, cy;
                         dtree_sample(T, hd, key, dim, cx, cy);
                         wo_l = to_local(I, canonical_to_dir(cx, cy));
-                        result = diffuse_eval(refl, I.wi, wo_l);
+                        result = bsdf_eval(mtype, refl, I.wi, wo_l);
                     }
                     if (zero) {
                         woPdf = bsdfPdf = dTreePdf = 0;
@@ -543,7 +532,7 @@ D void shade_slice(const PathState &P, const DevScene &S, const DevTree &T, cons
                     } else {
                         // pdfMat, GP:1693-1710
                         dTreePdf = 0;
-                        bsdfPdf = diffuse_pdf(I.wi, wo_l);
+                        bsdfPdf = bsdf_pdf(mtype, I.wi, wo_l);
                         if (!ppg_isfinite(bsdfPdf)) {
                             woPdf = 0;
                         } else {
@@ -574,7 +563,7 @@ D void shade_slice(const PathState &P, const DevScene &S, const DevTree &T, cons
 #if defined(PPG_ABLATE) && PPG_ABLATE == 2
                         if (false) {
 #else
-                        if (nV < PPG_MAX_VERTICES && nV < (unsigned int)R.max_vertices && !R.is_final_iter) {
+                        if (smooth && nV < PPG_MAX_VERTICES && nV < (unsigned int)R.max_vertices && !R.is_final_iter) {
 #endif
                             size_t vi = (size_t)nV * P.n_paths + i;
                             F3 bv = bsdfWeight * woPdf;
@@ -586,7 +575,7 @@ D void shade_slice(const PathState &P, const DevScene &S, const DevTree &T, cons
                                 P.v_vox[vi] = make_float4(vox.x, vox.y, vox.z, 0.0f);
                             }
                         }
-                        flags |= FL_PENDING | FL_PEND_TREE;
+                        flags |= FL_PENDING | (smooth ? FL_PEND_TREE : 0u) | (sampledDelta ? FL_PEND_DELTA : 0u);
                         m.w = (unsigned int)leaf;
                         l4.w = woPdf;
                         alive = true;
@@ -1139,7 +1128,7 @@ __global__ void k_query_pdf(DevTree T, unsigned int n, const float *pos, const f
     float cx, cy;
     dir_to_canonical(f3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]), cx, cy);
     RegColumn col;
-    out[i] = dtree_pdf<RegColumn &>(T, T.hdr[leaf], cx, cy, col);
+    out[i] = dtree_pdf<RegColumn &>(T, dtree_ref(T.hdr[leaf]), cx, cy, col);
 }
 __global__ void k_query_sample(DevTree T, unsigned int n, const float *pos, unsigned long long seed, float *out) {
     unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1148,7 +1137,7 @@ __global__ void k_query_sample(DevTree T, unsigned int n, const float *pos, unsi
     int leaf = stree_lookup(T, f3(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]), vox);
     unsigned int key = ppg_path_key(seed, i, 0), dim = 0;
     float cx, cy;
-    dtree_sample(T, T.hdr[leaf], key, dim, cx, cy);
+    dtree_sample(T, dtree_ref(T.hdr[leaf]), key, dim, cx, cy);
     F3 d = canonical_to_dir(cx, cy);
     out[3 * i] = d.x; out[3 * i + 1] = d.y; out[3 * i + 2] = d.z;
 }

@@ -350,3 +350,36 @@ def test_pass_hook_sees_the_per_pass_adam_sums():
     assert np.array_equal(e.read_film(), ref_img)
     assert np.array_equal(e.read_sdtree()["theta"], ref.read_sdtree()["theta"])
     assert len(seen) == 2 + 4 + 8 and max(seen) > 0  # training passes after the first build; none in the final iteration
+
+
+def _materials_scene(res):
+    """CBOX with the tall box turned into an ideal mirror (conductor, material "none") and the short box into a
+    two-sided diffuse surface whose faces are wound inside-out (so the flipped side is the one that is seen)."""
+    import ppg_host
+    scene = ppg_host.cbox_scene(*res)
+    scene.materials = list(scene.materials) + [dict(type=2, reflectance=(0.95, 0.93, 0.88)), dict(type=1, reflectance=(0.3, 0.5, 0.8))]
+    tm = scene.tri_material.copy()
+    tm[24:36] = 5                       # tall box  -> mirror
+    tm[12:24] = 6                       # short box -> twosided diffuse
+    scene.tri_material = tm
+    idx = scene.indices.copy()
+    idx[12:24] = idx[12:24][:, ::-1]    # flip the winding: the geometric normal now points into the box
+    scene.indices = idx
+    return scene
+
+
+@pytest.mark.parametrize("extra", [{}, IMPROVED])
+def test_mirror_and_twosided_materials_against_oracle(oracle_lib, extra):
+    """First slice of SURVEY.md §8(f1): a delta BSDF (never guided, no vertex recorded, no Russian roulette clamp —
+    GP:1654, 1942-1944, 2093, 2126) and twosided(diffuse)."""
+    import ppg_host
+    scene = _materials_scene((96, 96))
+    props = dict(CBOX_PROPS, budget=60, seed=77, **extra)
+    props.update(maxDepth=12, rrDepth=4)
+    g, o = hip(**props), make_oracle(oracle_lib, threads=os.cpu_count() or 8, **props)
+    ig = ppg_host.GuidedPathTracer(engine=g).render(scene)
+    io = ppg_host.GuidedPathTracer(engine=o).render(scene)
+    assert np.array_equal(ig, io)
+    assert_tree_equal(g.read_sdtree(), o.read_sdtree())
+    plain = ppg_host.GuidedPathTracer(engine=hip(**props)).render(ppg_host.cbox_scene(96, 96))
+    assert np.abs(ig - plain).mean() > 1e-3  # the materials are really in effect
