@@ -1121,6 +1121,7 @@ int ppg_set_scene(ppg_ctx *ctx, const ppg_scene *s) {
 }
 
 int ppg_set_shard(ppg_ctx *ctx, int32_t rank, int32_t world, int32_t tile_size) {
+    (void)hipSetDevice(ctx->device);
     if (world < 1 || rank < 0 || rank >= world || tile_size < 1) { ctx->error = "bad shard"; return PPG_ERR_INVALID; }
     ctx->shardRank = rank; ctx->shardWorld = world; ctx->tileSize = tile_size;
     ctx->pathsReady = false;
@@ -1133,8 +1134,9 @@ int ppg_set_shard(ppg_ctx *ctx, int32_t rank, int32_t world, int32_t tile_size) 
     return PPG_OK;
 }
 
-#define NEED_SCENE if (!ctx->haveScene) { ctx->error = "no scene"; return PPG_ERR_STATE; }
-#define NEED_TREE if (!ctx->treeAlive) { ctx->error = "render not begun"; return PPG_ERR_STATE; }
+// every entry point re-selects the context's device: the caller (torch / RCCL in a multi-GPU process) may have changed it
+#define NEED_SCENE (void)hipSetDevice(ctx->device); if (!ctx->haveScene) { ctx->error = "no scene"; return PPG_ERR_STATE; }
+#define NEED_TREE (void)hipSetDevice(ctx->device); if (!ctx->treeAlive) { ctx->error = "render not begun"; return PPG_ERR_STATE; }
 
 int ppg_begin_render(ppg_ctx *ctx) { NEED_SCENE return beginRender(ctx); }
 int ppg_begin_iteration(ppg_ctx *ctx, int32_t is_final) { NEED_TREE return beginIteration(ctx, is_final != 0); }
