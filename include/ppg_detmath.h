@@ -25,6 +25,7 @@
 #define PPG_PI_F 3.14159265358979323846f      /* M_PI of the reference, constants.h:63,80 (float) */
 #define PPG_INV_PI_F 0.31830988618379067154f  /* INV_PI, constants.h */
 #define PPG_EPSILON 1e-4f                     /* Epsilon, constants.h:28 */
+#define PPG_SHADOW_EPSILON 1e-3f              /* ShadowEpsilon, constants.h:29 */
 
 PPG_HD uint32_t ppg_f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 PPG_HD float ppg_u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }

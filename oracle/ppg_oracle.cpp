@@ -804,7 +804,50 @@ struct Intersection {
     uint32_t material = 0;
 };
 
+// DiscreteDistribution (pmf.h:30-189): float running sums, normalize(), sample()/sampleReuse()
+struct Pmf {
+    std::vector<Float> cdf{0.0f};
+    Float sum = 0, normalization = 0;
+    void append(Float v) { cdf.push_back(cdf.back() + v); }
+    Float operator[](size_t i) const { return cdf[i + 1] - cdf[i]; }
+    Float normalize() {  // pmf.h:101-114
+        sum = cdf.back();
+        if (sum > 0) {
+            normalization = 1.0f / sum;
+            for (size_t i = 1; i < cdf.size(); ++i) cdf[i] *= normalization;
+            cdf.back() = 1.0f;
+        } else {
+            normalization = 0.0f;
+        }
+        return sum;
+    }
+    size_t sample(Float v) const {  // pmf.h:124-136
+        ptrdiff_t entry = std::lower_bound(cdf.begin(), cdf.end(), v) - cdf.begin();
+        size_t index = std::min(cdf.size() - 2, (size_t)std::max((ptrdiff_t)0, entry - 1));
+        while ((*this)[index] == 0 && index < cdf.size() - 1) ++index;
+        return index;
+    }
+    size_t sampleReuse(Float &v, Float &pdf) const {  // pmf.h:183-188
+        size_t index = sample(v);
+        pdf = (*this)[index];
+        v = (v - cdf[index]) / (cdf[index + 1] - cdf[index]);
+        return index;
+    }
+};
+
+// DirectSamplingRecord subset (common.h / records.inl:160-178)
+struct DRec {
+    Point ref, p;
+    Vec refN, n, d;
+    Float dist = 0, pdf = 0;
+    int emitter = -1;
+};
+
 struct Scene {
+    // one area emitter = the triangles carrying its id, in index order (area.cpp: one emitter per shape)
+    struct EmitterMesh { std::vector<uint32_t> tris; Pmf areaDistr; Float surfaceArea = -1, invSurfaceArea = -1; };
+    std::vector<EmitterMesh> emMesh;
+    Pmf emitterPDF;
     std::vector<Point> P;
     std::vector<Vec> N;
     bool hasNormals = false;
@@ -840,6 +883,78 @@ struct Scene {
         }
         bvh.clear();
         if (nTris() > 64) buildBVH();
+        // TriMesh::prepareSamplingTable (trimesh.cpp:388-403) per emitter; Scene::configure's emitter pmf
+        // (scene.cpp:375-380, samplingWeight = 1)
+        emMesh.assign(emitters.size(), EmitterMesh());
+        for (uint32_t t = 0; t < nTris(); ++t)
+            if (triEmitter[t] >= 0) emMesh[triEmitter[t]].tris.push_back(t);
+        emitterPDF = Pmf();
+        for (EmitterMesh &m : emMesh) {
+            for (uint32_t t : m.tris) {
+                const Point &p0 = P[idx[3 * t]], &p1 = P[idx[3 * t + 1]], &p2 = P[idx[3 * t + 2]];
+                m.areaDistr.append(0.5f * length(cross(p1 - p0, p2 - p0)));  // Triangle::surfaceArea, triangle.cpp:61-67
+            }
+            if (!m.tris.empty()) {
+                m.surfaceArea = m.areaDistr.normalize();
+                m.invSurfaceArea = 1.0f / m.surfaceArea;
+            }
+            emitterPDF.append(1.0f);
+        }
+        if (!emMesh.empty()) emitterPDF.normalize();
+    }
+
+    // Scene::sampleAttenuatedEmitterDirect (scene.cpp:876-897) → AreaLight::sampleDirect (area.cpp:158-173) →
+    // Shape::sampleDirect (shape.cpp:102-115) → TriMesh::samplePosition (trimesh.cpp:412-423) →
+    // Triangle::sample (triangle.cpp:24-58), then evalTransmittance (scene.cpp:619-679) without media / null BSDFs
+    Spectrum sampleEmitterDirect(DRec &dRec, Point2 sample, uint64_t &shadowRays) const {
+        dRec.pdf = 0;
+        if (emMesh.empty()) return Spectrum(0.0f);
+        Float emPdf;
+        size_t index = emitterPDF.sampleReuse(sample.x, emPdf);
+        const EmitterMesh &m = emMesh[index];
+        if (m.tris.empty()) return Spectrum(0.0f);
+        Float dummy;
+        size_t ti = m.areaDistr.sampleReuse(sample.y, dummy);
+        const uint32_t t = m.tris[ti];
+        const uint32_t i0 = idx[3 * t], i1 = idx[3 * t + 1], i2 = idx[3 * t + 2];
+        const Point &p0 = P[i0], &p1 = P[i1], &p2 = P[i2];
+        Float a = std::sqrt(ppg_max(0.0f, 1.0f - sample.x));  // warp::squareToUniformTriangle, warp.cpp:76-79
+        Point2 bary{1 - a, a * sample.y};
+        Vec sideA = p1 - p0, sideB = p2 - p0;
+        dRec.p = p0 + sideA * bary.x + sideB * bary.y;
+        if (hasNormals) dRec.n = normalize(N[i0] * (1.0f - bary.x - bary.y) + N[i1] * bary.x + N[i2] * bary.y);
+        else dRec.n = normalize(cross(sideA, sideB));
+        dRec.pdf = m.invSurfaceArea;
+        dRec.d = dRec.p - dRec.ref;
+        Float distSquared = dot(dRec.d, dRec.d);
+        dRec.dist = std::sqrt(distSquared);
+        dRec.d = dRec.d / dRec.dist;
+        Float dp = ppg_abs(dot(dRec.d, dRec.n));
+        dRec.pdf *= dp != 0 ? (distSquared / dp) : 0.0f;
+        if (!(dot(dRec.d, dRec.refN) >= 0 && dot(dRec.d, dRec.n) < 0 && dRec.pdf != 0)) {
+            dRec.pdf = 0.0f;
+            return Spectrum(0.0f);
+        }
+        const float *r = emitters[index].radiance;
+        Spectrum value = Spectrum(r[0], r[1], r[2]) / dRec.pdf;
+        // evalTransmittance(its.p, true, dRec.p, true, ...): shadow ray [Epsilon, dist·(1 − ShadowEpsilon)]
+        Intersection occ;
+        ++shadowRays;
+        if (rayIntersect(dRec.ref, dRec.d, PPG_EPSILON, dRec.dist * (1 - PPG_SHADOW_EPSILON), occ)) return Spectrum(0.0f);
+        value = value / emPdf;  // transmittance = 1
+        dRec.emitter = (int)index;
+        dRec.pdf *= emPdf;
+        return value;
+    }
+
+    // Scene::pdfEmitterDirect (scene.cpp:949-952) → AreaLight::pdfDirect (area.cpp:175-183) → Shape::pdfDirect
+    // (shape.cpp:117-126), solid-angle measure
+    Float pdfEmitterDirect(const DRec &dRec) const {
+        if (dRec.emitter < 0) return 0.0f;
+        Float pdf = 0.0f;
+        if (dot(dRec.d, dRec.refN) >= 0 && dot(dRec.d, dRec.n) < 0)
+            pdf = emMesh[dRec.emitter].invSurfaceArea * (dRec.dist * dRec.dist) / ppg_abs(dot(dRec.d, dRec.n));
+        return pdf * (1.0f * emitterPDF.normalization);  // pdfEmitterDiscrete, scene.h:848-850
     }
 
     void triBounds(uint32_t t, Point &mn, Point &mx) const {
@@ -1062,6 +1177,8 @@ struct Diffuse {
 struct BSDF {
     static bool isSmooth(const ppg_material &m) { return m.type != PPG_BSDF_MIRROR; }   // getType() & ESmooth
     static bool allDelta(const ppg_material &m) { return m.type == PPG_BSDF_MIRROR; }   // (type & EDelta) == (type & EAll)
+    // getType() & (ETransmission | EBackSide): twosided sets EBackSide (twosided.cpp:97-101)
+    static bool hasBackSideOrTransmission(const ppg_material &m) { return m.type == PPG_BSDF_TWOSIDED_DIFFUSE; }
 
     static Spectrum eval(const ppg_material &m, const BRec &b) {
         switch (m.type) {
@@ -1116,7 +1233,7 @@ struct BSDF {
 // GuidedPathTracer GP:1012-2419
 // ------------------------------------------------------------------------------------------------
 struct PathCounters {
-    uint64_t rays = 0, pathLen = 0, committed = 0;
+    uint64_t rays = 0, pathLen = 0, committed = 0;  // rays includes shadow rays
 };
 
 class GuidedPathTracer {
@@ -1466,7 +1583,7 @@ public:
         }
     };
 
-    // Li GP:1712-2157, surface branch, nee = never
+    // Li GP:1712-2157, surface branch
     Spectrum Li(Point o, Vec d, Float rayMint, Float rayMaxt, Sampler &sampler, PathCounters &pc) {
         static const int MAX_NUM_VERTICES = 32;
         std::array<Vertex, MAX_NUM_VERTICES> vertices;
@@ -1514,6 +1631,39 @@ public:
             Float woPdf, bsdfPdf, dTreePdf;
             Spectrum bsdfWeight = sampleMat(bsdf, bRec, its.shFrame, woPdf, bsdfPdf, dTreePdf, bsdfSamplingFraction, sampler, dTree);
 
+            // Luminaire sampling, GP:1962-2021
+            DRec dRec;  // DirectSamplingRecord dRec(its), records.inl:160-164
+            dRec.ref = its.p;
+            dRec.refN = BSDF::hasBackSideOrTransmission(bsdf) ? Vec(0.0f) : its.shFrame.n;
+            if (m_doNee && BSDF::isSmooth(bsdf)) {
+                Spectrum value = scene.sampleEmitterDirect(dRec, sampler.next2D(), pc.rays);
+                if (!isZero(value)) {
+                    BRec bRecE;
+                    bRecE.wi = its.wi;
+                    bRecE.wo = its.shFrame.toLocal(dRec.d);
+                    Float woDotGeoNE = dot(its.geoN, dRec.d);
+                    if (!m_strictNormals || woDotGeoNE * bRecE.wo.z > 0) {
+                        const Spectrum bsdfVal = BSDF::eval(bsdf, bRecE);
+                        Float woPdfE = 0, bsdfPdfE = 0, dTreePdfE = 0;
+                        pdfMat(woPdfE, bsdfPdfE, dTreePdfE, bsdfSamplingFraction, bsdf, bRecE, its.shFrame, dTree);
+                        const Float weight = miWeight(dRec.pdf, woPdfE);
+                        value = mul(value, bsdfVal);
+                        Spectrum L = mul(throughput, value) * weight;
+                        if (!m_isFinalIter && m_nee != EAlways) {
+                            if (dTree) {
+                                Vertex v{dTree, dTreeVoxelSize, its.p, dRec.d, mul(throughput, bsdfVal) / dRec.pdf, bsdfVal, L,
+                                         dRec.pdf, bsdfPdfE, dTreePdfE, false};
+                                Sampler cs{sampler.key, PPG_DIM_NEE_COMMIT + 3u * (uint32_t)depth};  // sampler contract, ppg_rng.h
+                                if (v.commit(*m_sdTree, 0.5f, m_spatialFilter, m_directionalFilter,
+                                             m_isBuilt ? m_bsdfSamplingFractionLoss : ENone, &cs, modes, (int)PPG_SLOT_NEE + depth))
+                                    pc.committed++;
+                            }
+                        }
+                        recordRadiance(L);
+                    }
+                }
+            }
+
             if (isZero(bsdfWeight)) break;  // GP:2024-2025
 
             const Vec wo = its.shFrame.toWorld(bRec.wo);  // GP:2028-2032
@@ -1528,11 +1678,15 @@ public:
             Spectrum value(0.0f);
             scene.rayIntersect(o, d, PPG_EPSILON, std::numeric_limits<Float>::infinity(), its);
             pc.rays++;
-            if (its.valid && its.emitter >= 0) value = scene.Le(its, -d);
+            if (its.valid && its.emitter >= 0) {
+                // dRec.setQuery(ray, its), records.inl:170-178
+                dRec.p = its.p; dRec.n = its.shFrame.n; dRec.d = d; dRec.dist = its.t; dRec.emitter = its.emitter;
+                value = scene.Le(its, -d);
+            }
 
             {  // GP:2083-2111
                 bool isDelta = bRec.sampledDelta;
-                const Float emitterPdf = 0;  // !m_doNee
+                const Float emitterPdf = (m_doNee && !isDelta && !isZero(value)) ? scene.pdfEmitterDirect(dRec) : 0;
                 const Float weight = miWeight(woPdf, emitterPdf);
                 Spectrum L = mul(throughput, value) * weight;
                 if (!isZero(L)) recordRadiance(L);
@@ -1738,7 +1892,6 @@ int ppgo_create(const ppg_config *cfg, ppgo_ctx **out) {
     PARSE(bsdfSamplingFractionLoss, "none", g.m_bsdfSamplingFractionLoss, ELoss, "none", "kl", "var")
     PARSE(budgetType, "seconds", g.m_budgetType, EBudget, "spp", "seconds")
 #undef PARSE
-    if (g.m_nee != ENever) { g_createError = "nee != \"never\" is not implemented (SURVEY.md §8(f2))"; return PPG_ERR_INVALID; }
     g.m_sdTreeMaxMemory = cfg->sdTreeMaxMemory; g.m_sTreeThreshold = cfg->sTreeThreshold;
     g.m_dTreeThreshold = cfg->dTreeThreshold; g.m_bsdfSamplingFraction = cfg->bsdfSamplingFraction;
     g.m_sppPerPass = cfg->sppPerPass; g.m_budget = cfg->budget; g.m_dumpSDTree = cfg->dumpSDTree != 0;

@@ -84,6 +84,14 @@ struct DevScene {
     const float4 *emitters;   // (radiance rgb, -)
     int n_tris;
     DevCamera cam;
+    // next-event estimation: one area emitter = the triangles carrying its id, in index order
+    int n_emitters;
+    const float *em_sel_cdf;   // [n_emitters + 1] emitter pmf (Scene::configure, samplingWeight = 1)
+    float em_sel_norm;         // DiscreteDistribution::getNormalization()
+    const int4 *em_info;       // (first triangle, triangle count, first cdf entry, invSurfaceArea bits)
+    const float *em_area_cdf;  // per emitter: count + 1 entries (TriMesh::prepareSamplingTable)
+    const float4 *em_tris;     // 3 per emitter triangle: positions
+    const float4 *em_normals;  // 3 per emitter triangle or nullptr
 };
 
 struct Hit {
@@ -193,6 +201,8 @@ struct TStack {
 };
 
 // Closest hit by (t, original primitive index) through the BVH4 — equals brute force (conservative culling).
+// ANY: return at the first triangle hit (shadow rays; only prim >= 0 is meaningful then).
+template <bool ANY = false>
 D Hit trace_closest4(const DevScene &S, int *lds_stack_col, int stride, F3 o, F3 d, float mint, float maxt) {
     Hit best;
     best.t = __builtin_inff(); best.u = 0; best.v = 0; best.prim = -1;
@@ -231,6 +241,7 @@ D Hit trace_closest4(const DevScene &S, int *lds_stack_col, int stride, F3 o, F3
                     float tt, uu, vv;
                     const float4 *T = S.tris + 3 * q;
                     if (tri_hit(T, o, d, mint, maxt, tt, uu, vv)) {
+                        if (ANY) { best.t = tt; best.prim = q; return best; }
                         int orig = __float_as_int(T[2].w);
                         if (tt < best.t || (tt == best.t && orig < bestOrig)) { best.t = tt; best.u = uu; best.v = vv; best.prim = q; bestOrig = orig; }
                     }
@@ -306,6 +317,69 @@ D F3 eval_Le(const DevScene &S, const Isect &I, F3 dir) {
     if (dot3(I.n, dir) <= 0) return f3s(0.0f);
     float4 r = S.emitters[I.emitter];
     return f3(r.x, r.y, r.z);
+}
+
+// DiscreteDistribution::sample (pmf.h:124-136) on a normalised cdf with `entries` values (cdf[0] = 0)
+D int pmf_sample(const float *cdf, int entries, float v) {
+    int lo = 0, hi = entries;  // std::lower_bound: first position with cdf[pos] >= v
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (cdf[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    int index = lo - 1;
+    if (index < 0) index = 0;
+    if (index > entries - 2) index = entries - 2;
+    while (index < entries - 1 && cdf[index + 1] - cdf[index] == 0) ++index;
+    return index;
+}
+
+// Direct illumination sample on an area emitter — Scene::sampleAttenuatedEmitterDirect (scene.cpp:876-897) up to,
+// not including, the transmittance test: emitter choice, AreaLight::sampleDirect (area.cpp:158-173),
+// Shape::sampleDirect (shape.cpp:102-115), TriMesh::samplePosition (trimesh.cpp:412-423), Triangle::sample
+// (triangle.cpp:24-58).  Returns radiance / pdf (solid angle, before the emitter-choice probability), or zero
+// with ds.pdf = 0.
+struct DirectSample {
+    F3 n, d;
+    float dist, pdf, em_pdf;
+};
+D F3 emitter_sample_direct(const DevScene &S, F3 ref, F3 refN, float sx, float sy, DirectSample &ds) {
+    ds.pdf = 0; ds.em_pdf = 0; ds.dist = 0; ds.n = f3s(0.0f); ds.d = f3s(0.0f);
+    if (S.n_emitters == 0) return f3s(0.0f);
+    const int e = pmf_sample(S.em_sel_cdf, S.n_emitters + 1, sx);
+    const float c0 = S.em_sel_cdf[e], c1 = S.em_sel_cdf[e + 1];
+    ds.em_pdf = c1 - c0;
+    sx = (sx - c0) / (c1 - c0);  // sampleReuse, pmf.h:183-188
+    const int4 info = S.em_info[e];
+    if (info.y == 0) return f3s(0.0f);
+    const float *acdf = S.em_area_cdf + info.z;
+    const int ti = pmf_sample(acdf, info.y + 1, sy);
+    const float a0 = acdf[ti], a1 = acdf[ti + 1];
+    sy = (sy - a0) / (a1 - a0);
+    const float4 *T = S.em_tris + 3 * (size_t)(info.x + ti);
+    const F3 p0 = ld3(T), p1 = ld3(T + 1), p2 = ld3(T + 2);
+    const float a = __builtin_sqrtf(ppg_max(0.0f, 1.0f - sx));  // warp::squareToUniformTriangle, warp.cpp:76-79
+    const float bx = 1 - a, by = a * sy;
+    const F3 sideA = p1 - p0, sideB = p2 - p0;
+    const F3 p = p0 + sideA * bx + sideB * by;
+    if (S.em_normals) {
+        const float4 *Nn = S.em_normals + 3 * (size_t)(info.x + ti);
+        ds.n = norm3(ld3(Nn) * (1.0f - bx - by) + ld3(Nn + 1) * bx + ld3(Nn + 2) * by);
+    } else {
+        ds.n = norm3(cross3(sideA, sideB));
+    }
+    ds.pdf = __int_as_float(info.w);  // invSurfaceArea
+    F3 d = p - ref;
+    const float distSquared = dot3(d, d);
+    ds.dist = __builtin_sqrtf(distSquared);
+    ds.d = div3(d, ds.dist);
+    const float dp = ppg_abs(dot3(ds.d, ds.n));
+    ds.pdf *= dp != 0 ? (distSquared / dp) : 0.0f;
+    if (!(dot3(ds.d, refN) >= 0 && dot3(ds.d, ds.n) < 0 && ds.pdf != 0)) {
+        ds.pdf = 0.0f;
+        return f3s(0.0f);
+    }
+    const float4 r = S.emitters[e];
+    return div3(f3(r.x, r.y, r.z), ds.pdf);
 }
 
 // Transform::operator()(Point) (transform.h:108-125) and operator()(Vector) (:175-183)

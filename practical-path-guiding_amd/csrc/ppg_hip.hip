@@ -254,7 +254,9 @@ struct ppg_ctx {
 
     // scene
     bool haveScene = false;
-    DevBuf<float4> d_tris, d_normals, d_materials, d_emitters;
+    DevBuf<float4> d_tris, d_normals, d_materials, d_emitters, d_emTris, d_emNrm;
+    DevBuf<float> d_emSel, d_emArea;
+    DevBuf<int4> d_emInfo;
     DevBuf<BvhNode> d_bvh;
     DevBuf<Bvh4Node> d_bvh4;
     DevScene scene{};
@@ -591,6 +593,7 @@ int renderBatch(ppg_ctx *ctx, int batch) {
     // (cbox-720p, 63 passes: 184 ms vs 172 ms for generate+trace+shade): the fused kernel needs 142 VGPRs (3 waves/SIMD)
     // and only the surviving lanes trace.  Kept selectable for re-measurement on other scenes.
     const bool fused = smallScene && getenv("PPG_FUSE");
+    const bool neeOn = ctx->doNee;  // m_doNee of this iteration (doNeeWithSpp, GP:1331-1340)
     const size_t triBytes = (size_t)ctx->scene.n_tris * 48;
     timedLaunch(ctx, "k_generate", P.n_paths, [&] {
         if (fused) hipLaunchKernelGGL(k_generate<true>, dim3(gridAll), dim3(PPG_BLOCK), triBytes, s, P, S, R, Q);
@@ -608,9 +611,14 @@ int renderBatch(ppg_ctx *ctx, int batch) {
                 if (smallScene) hipLaunchKernelGGL(k_trace<true>, dim3(grid), dim3(PPG_BLOCK), ldsBytes, s, P, S, Q, qin, 0, ctx->ldsTris);
                 else hipLaunchKernelGGL(k_trace<false>, dim3(grid), dim3(PPG_BLOCK), ldsBytes, s, P, S, Q, qin, ctx->ldsNodes, ctx->ldsTris);
             });
-        timedLaunch(ctx, fused ? "k_shade<fused>" : "k_shade", hostCount, [&] {
-            if (fused) hipLaunchKernelGGL(k_shade<true>, dim3(grid), dim3(PPG_BLOCK), triBytes, s, P, S, T, R, Q, qin, qout);
-            else hipLaunchKernelGGL(k_shade<false>, dim3(grid), dim3(PPG_BLOCK), 0, s, P, S, T, R, Q, qin, qout);
+        timedLaunch(ctx, fused ? "k_shade<fused>" : (neeOn ? "k_shade<nee>" : "k_shade"), hostCount, [&] {
+            const int small = smallScene ? 1 : 0;
+            if (neeOn) {  // luminaire sampling: the shadow ray needs the staged triangles or a BVH stack column per lane
+                const size_t neeBytes = smallScene ? triBytes : (size_t)PPG_LDS_STACK * PPG_BLOCK * 4;
+                if (fused) hipLaunchKernelGGL((k_shade<true, true>), dim3(grid), dim3(PPG_BLOCK), triBytes, s, P, S, T, R, Q, qin, qout, small);
+                else hipLaunchKernelGGL((k_shade<false, true>), dim3(grid), dim3(PPG_BLOCK), neeBytes, s, P, S, T, R, Q, qin, qout, small);
+            } else if (fused) hipLaunchKernelGGL((k_shade<true, false>), dim3(grid), dim3(PPG_BLOCK), triBytes, s, P, S, T, R, Q, qin, qout, small);
+            else hipLaunchKernelGGL((k_shade<false, false>), dim3(grid), dim3(PPG_BLOCK), 0, s, P, S, T, R, Q, qin, qout, small);
         });
         qin = qout;
         // unbounded paths (maxDepth < 0) and kernel timing need the live count; bounded paths run a fixed schedule without a sync
@@ -635,8 +643,10 @@ int renderBatch(ppg_ctx *ctx, int batch) {
                 Qt.count[0] = Q.count[qin ^ 1]; Qt.count[1] = Q.count[qin];
                 Qt.cap = capTail; Qt.n_blocks = nbTail;
                 timedLaunch(ctx, "k_tail", hostCount, [&] {
-                    if (smallScene) hipLaunchKernelGGL(k_tail<true>, dim3(nbTail), dim3(PPG_BLOCK), ldsBytes, s, P, S, T, R, Qt, 0, 0, ctx->ldsTris);
-                    else hipLaunchKernelGGL(k_tail<false>, dim3(nbTail), dim3(PPG_BLOCK), ldsBytes, s, P, S, T, R, Qt, 0, ctx->ldsNodes, ctx->ldsTris);
+                    if (smallScene && neeOn) hipLaunchKernelGGL((k_tail<true, true>), dim3(nbTail), dim3(PPG_BLOCK), ldsBytes, s, P, S, T, R, Qt, 0, 0, ctx->ldsTris);
+                    else if (smallScene) hipLaunchKernelGGL((k_tail<true, false>), dim3(nbTail), dim3(PPG_BLOCK), ldsBytes, s, P, S, T, R, Qt, 0, 0, ctx->ldsTris);
+                    else if (neeOn) hipLaunchKernelGGL((k_tail<false, true>), dim3(nbTail), dim3(PPG_BLOCK), ldsBytes, s, P, S, T, R, Qt, 0, ctx->ldsNodes, ctx->ldsTris);
+                    else hipLaunchKernelGGL((k_tail<false, false>), dim3(nbTail), dim3(PPG_BLOCK), ldsBytes, s, P, S, T, R, Qt, 0, ctx->ldsNodes, ctx->ldsTris);
                 });
                 HIP_CHECK(hipStreamSynchronize(s));  // tailCounts is reused by the next pass
                 break;
@@ -1010,7 +1020,6 @@ int ppg_create(const ppg_config *cfg, ppg_ctx **out) {
     PARSE(bsdfSamplingFractionLoss, "none", loss, "none", "kl", "var")
     PARSE(budgetType, "seconds", budgetType, "spp", "seconds")
 #undef PARSE
-    if (c->nee != NEE_NEVER) { g_createError = "nee != \"never\" is not implemented yet (SURVEY.md §8(f2))"; return PPG_ERR_INVALID; }
     c->sdTreeMaxMemory = cfg->sdTreeMaxMemory; c->sTreeThreshold = cfg->sTreeThreshold; c->dTreeThreshold = cfg->dTreeThreshold;
     c->bsdfSamplingFraction = cfg->bsdfSamplingFraction; c->sppPerPass = cfg->sppPerPass; c->budget = cfg->budget;
     c->dumpSDTree = cfg->dumpSDTree != 0; c->rrDepth = cfg->rrDepth; c->maxDepth = cfg->maxDepth;
@@ -1094,6 +1103,59 @@ int ppg_set_scene(ppg_ctx *ctx, const ppg_scene *s) {
     HIP_CHECK(hipMemcpy(ctx->d_materials.p, mats.data(), mats.size() * sizeof(float4), hipMemcpyHostToDevice));
     HIP_CHECK(ctx->d_emitters.reserve(ems.size()));
     HIP_CHECK(hipMemcpy(ctx->d_emitters.p, ems.data(), ems.size() * sizeof(float4), hipMemcpyHostToDevice));
+    {   // luminaire sampling tables: TriMesh::prepareSamplingTable (trimesh.cpp:388-403) per emitter (= the triangles
+        // carrying its id, in index order) and Scene::configure's emitter pmf (scene.cpp:375-380, samplingWeight = 1);
+        // float running sums and DiscreteDistribution::normalize() (pmf.h:101-114) exactly as the oracle builds them
+        const uint32_t ne = s->n_emitters;
+        std::vector<std::vector<uint32_t>> emTris(ne);
+        for (uint32_t t = 0; t < s->n_triangles; ++t) if (s->tri_emitter[t] >= 0) emTris[s->tri_emitter[t]].push_back(t);
+        std::vector<float> selCdf(1, 0.0f), areaCdf;
+        std::vector<int4> info(std::max<uint32_t>(1, ne));
+        std::vector<float4> etris, enrm;
+        auto normalize = [](std::vector<float> &cdf, size_t first, size_t entries, float &sum) {
+            sum = cdf[first + entries - 1];
+            if (sum > 0) {
+                float normalization = 1.0f / sum;
+                for (size_t i = 1; i < entries; ++i) cdf[first + i] *= normalization;
+                cdf[first + entries - 1] = 1.0f;
+                return normalization;
+            }
+            return 0.0f;
+        };
+        for (uint32_t e = 0; e < ne; ++e) {
+            const size_t first = areaCdf.size();
+            areaCdf.push_back(0.0f);
+            const int firstTri = (int)(etris.size() / 3);
+            for (uint32_t t : emTris[e]) {
+                const float *p0 = s->positions + 3 * s->indices[3 * t], *p1 = s->positions + 3 * s->indices[3 * t + 1], *p2 = s->positions + 3 * s->indices[3 * t + 2];
+                const float ax = p1[0] - p0[0], ay = p1[1] - p0[1], az = p1[2] - p0[2];
+                const float bx = p2[0] - p0[0], by = p2[1] - p0[1], bz = p2[2] - p0[2];
+                const float cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx;
+                areaCdf.push_back(areaCdf.back() + 0.5f * std::sqrt(cx * cx + cy * cy + cz * cz));  // Triangle::surfaceArea, triangle.cpp:61-67
+                for (int v = 0; v < 3; ++v) {
+                    const float *p = s->positions + 3 * s->indices[3 * t + v];
+                    etris.push_back(make_float4(p[0], p[1], p[2], 0));
+                    if (s->normals) { const float *n = s->normals + 3 * s->indices[3 * t + v]; enrm.push_back(make_float4(n[0], n[1], n[2], 0)); }
+                }
+            }
+            float area = 0, inv = -1;
+            if (!emTris[e].empty()) { normalize(areaCdf, first, emTris[e].size() + 1, area); inv = 1.0f / area; }
+            info[e] = make_int4(firstTri, (int)emTris[e].size(), (int)first, __builtin_bit_cast(int, inv));
+            selCdf.push_back(selCdf.back() + 1.0f);
+        }
+        float selSum = 0, selNorm = 0;
+        if (ne) selNorm = normalize(selCdf, 0, selCdf.size(), selSum);
+        if (etris.empty()) etris.push_back(make_float4(0, 0, 0, 0));
+        if (areaCdf.empty()) areaCdf.push_back(0.0f);
+        HIP_CHECK(ctx->d_emSel.reserve(selCdf.size())); HIP_CHECK(hipMemcpy(ctx->d_emSel.p, selCdf.data(), selCdf.size() * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(ctx->d_emArea.reserve(areaCdf.size())); HIP_CHECK(hipMemcpy(ctx->d_emArea.p, areaCdf.data(), areaCdf.size() * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(ctx->d_emInfo.reserve(info.size())); HIP_CHECK(hipMemcpy(ctx->d_emInfo.p, info.data(), info.size() * sizeof(int4), hipMemcpyHostToDevice));
+        HIP_CHECK(ctx->d_emTris.reserve(etris.size())); HIP_CHECK(hipMemcpy(ctx->d_emTris.p, etris.data(), etris.size() * sizeof(float4), hipMemcpyHostToDevice));
+        if (!enrm.empty()) { HIP_CHECK(ctx->d_emNrm.reserve(enrm.size())); HIP_CHECK(hipMemcpy(ctx->d_emNrm.p, enrm.data(), enrm.size() * sizeof(float4), hipMemcpyHostToDevice)); }
+        DevScene &S = ctx->scene;
+        S.n_emitters = (int)ne; S.em_sel_cdf = ctx->d_emSel.p; S.em_sel_norm = selNorm; S.em_info = ctx->d_emInfo.p;
+        S.em_area_cdf = ctx->d_emArea.p; S.em_tris = ctx->d_emTris.p; S.em_normals = enrm.empty() ? nullptr : ctx->d_emNrm.p;
+    }
     DevScene &S = ctx->scene;
     S.tris = ctx->d_tris.p; S.normals = s->normals ? ctx->d_normals.p : nullptr; S.bvh = ctx->d_bvh.p; S.bvh4 = ctx->d_bvh4.p;
     S.materials = ctx->d_materials.p; S.emitters = ctx->d_emitters.p; S.n_tris = (int)s->n_triangles;

@@ -34,6 +34,7 @@ enum { LOSS_NONE = 0, LOSS_KL = 1, LOSS_VAR = 2 };
 #define FL_PENDING (1u << 28)      // a bounce was sampled; its trace result is consumed by the next k_shade
 #define FL_PEND_TREE (1u << 29)    // that bounce had a D-tree
 #define FL_PEND_DELTA (1u << 30)   // that bounce sampled a delta component
+#define FL_PEND_REFN (1u << 31)    // dot(ray.d, dRec.refN) >= 0 at the vertex that sampled the bounce (AreaLight::pdfDirect, area.cpp:175-183)
 
 struct RenderParams {
     int nee, spatial_filter, directional_filter, loss;
@@ -387,295 +388,6 @@ __global__ void k_build_grid(const int4 *stree, unsigned int *grid) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_shade — Li's loop body (GP:1798-2146), surface branch, nee = never
-// ------------------------------------------------------------------------------------------------
-// One queue slice through Li's loop body.  FUSED (small scenes): the ray sampled here is traced here too.
-template <bool FUSED>
-D void shade_slice(const PathState &P, const DevScene &S, const DevTree &T, const RenderParams &R, const unsigned int *items, unsigned int count,
-                   unsigned int b, unsigned int nb, unsigned int *out_items, unsigned int *out_count, const LdsColumn &fcol,
-                   const float4 *lds_tris, unsigned long long &plen_sum, unsigned int &traced) {
-    const unsigned int rounds = (count + PPG_BLOCK - 1) / PPG_BLOCK;
-    for (unsigned int r = 0; r < rounds; ++r) {
-        unsigned int q = r * PPG_BLOCK + threadIdx.x;
-        bool active = q < count;
-        bool alive = false;
-        unsigned long long plen = 0;
-        unsigned int i = 0;
-        if (active) {
-            i = items ? items[q] : first_path(q, b, nb);
-            active = i < P.n_paths;
-        }
-        if (active) {
-            uint4 m = P.misc[i];
-            unsigned int key = m.x, dim = m.y, flags = m.z;
-            unsigned int depth = flags & FL_DEPTH_MASK;
-            unsigned int nV = (flags & FL_NV_MASK) >> FL_NV_SHIFT;
-            float4 t4 = P.thr[i], l4 = P.li[i], h4 = P.hit[i], d4 = P.ray_d[i];
-            F3 thr = f3(t4.x, t4.y, t4.z);
-            float eta = t4.w;
-            F3 Li = f3(l4.x, l4.y, l4.z);
-            F3 d = f3(d4.x, d4.y, d4.z);
-            Hit h;
-            h.t = h4.x; h.u = h4.y; h.v = h4.z; h.prim = __float_as_int(h4.w);
-            const bool valid = h.prim >= 0;
-            Isect I;
-            if (valid) fill_isect(S, h, d, I);
-            bool go = true;
-
-            if (flags & FL_PENDING) {
-                // ---- second half of the previous bounce: GP:2078-2145 ----
-                F3 value = valid ? eval_Le(S, I, -d) : f3s(0.0f);  // rayIntersectAndLookForEmitter, GP:2229-2234
-                const float woPdf = l4.w;
-                const bool isDelta = (flags & FL_PEND_DELTA) != 0;
-                const bool hasTree = (flags & FL_PEND_TREE) != 0;
-                float pa = woPdf * woPdf, pb = 0.0f * 0.0f;  // miWeight(woPdf, emitterPdf = 0), GP:2247-2250
-                const float weight = pa / (pa + pb);
-                F3 L = mul3(thr, value) * weight;
-                if (!iszero3(L)) {  // recordRadiance, GP:1791-1796
-                    Li = Li + L;
-                    for (unsigned int v0 = 0; v0 < nV; v0 += 4) {  // 4 independent loads in flight, then 4 stores
-                        float4 rr[4];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            if (v0 + k < nV) rr[k] = P.v_rad[(size_t)(v0 + k) * P.n_paths + i];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            if (v0 + k < nV) {
-                                rr[k].x += L.x; rr[k].y += L.y; rr[k].z += L.z;
-                                P.v_rad[(size_t)(v0 + k) * P.n_paths + i] = rr[k];
-                            }
-                    }
-                }
-                if ((!isDelta || R.loss != LOSS_NONE) && hasTree && nV < PPG_MAX_VERTICES && nV < (unsigned int)R.max_vertices &&
-                    !R.is_final_iter) {
-                    if (1 / woPdf > 0) {  // the other vertex fields were written when the bounce was sampled
-                        F3 rad = (R.nee == NEE_ALWAYS) ? f3s(0.0f) : L;
-                        unsigned int bits = m.w | (isDelta ? 0x80000000u : 0u);
-                        P.v_rad[(size_t)nV * P.n_paths + i] = make_float4(rad.x, rad.y, rad.z, __uint_as_float(bits));
-                        ++nV;
-                    }
-                }
-                flags &= ~FL_EMITTED_OK;  // rRec.type = ERadianceNoEmission
-                if (depth++ >= (unsigned int)R.rr_depth) {  // Russian roulette, GP:2124-2142
-                    float successProb = 1.0f;
-                    if (hasTree && !isDelta) {
-                        if (!T.is_built) successProb = max3(thr) * eta * eta;
-                        successProb = ppg_max(0.1f, ppg_min(successProb, 0.99f));
-                    }
-                    if (ppg_rand(key, dim++) >= successProb) go = false;
-                    else thr = div3(thr, successProb);
-                }
-                if (go) {
-                    flags |= FL_SCATTERED;
-                    if (!((int)depth <= R.max_depth || R.max_depth < 0)) go = false;
-                }
-                flags &= ~(FL_PENDING | FL_PEND_TREE | FL_PEND_DELTA);
-            }
-
-            // ---- first half of this bounce: GP:1902-2040 ----
-            if (go && !valid) go = false;  // no environment emitter in the supported scene subset
-            if (go) {
-                if (I.emitter >= 0 && (flags & FL_EMITTED_OK) && (!R.hide_emitters || (flags & FL_SCATTERED)))
-                    Li = Li + mul3(thr, eval_Le(S, I, -d));  // GP:1917-1919 (nVertices == 0 here)
-                if ((int)depth >= R.max_depth && R.max_depth != -1) go = false;
-            }
-            if (go) {
-                float wiDotGeoN = -dot3(I.geoN, d), wiDotShN = I.wi.z;
-                if (wiDotGeoN * wiDotShN < 0 && R.strict_normals) go = false;
-            }
-            if (go) {
-                float4 mat = S.materials[I.material];
-                const F3 refl = f3(mat.x, mat.y, mat.z);
-                const int mtype = (int)mat.w;
-                const bool smooth = bsdf_is_smooth(mtype);  // bsdf->getType() & ESmooth: only those are guided
-                F3 vox = f3s(0.0f);
-                int leaf = 0;
-                DTreeRef hd;
-                hd.s_base = 0; hd.s_sum = 0; hd.s_statw = 0;
-                float frac = R.bsdf_sampling_fraction;  // GP:1946-1949
-                if (smooth) {
-                    leaf = stree_lookup(T, I.p, vox);  // GP:1942-1944
-                    const float4 h4 = *reinterpret_cast<const float4 *>(&T.hdr[leaf]);  // {s_base, s_num, s_sum, s_statw}
-                    hd.s_base = __float_as_uint(h4.x); hd.s_sum = h4.z; hd.s_statw = h4.w;
-                    if (R.loss != LOSS_NONE) frac = logistic(T.hdr[leaf].theta);
-                }
-
-                // sampleMat, GP:1650-1691
-                float sx = ppg_rand(key, dim++);
-                float sy = ppg_rand(key, dim++);
-                F3 wo_l, bsdfWeight;
-                float woPdf, bsdfPdf, dTreePdf;
-                bool sampledDelta = false;
-                if (!T.is_built || !smooth) {  // !m_isBuilt || !dTree || all components are delta
-                    bsdfWeight = bsdf_sample(mtype, refl, I.wi, sx, sy, wo_l, bsdfPdf, sampledDelta);
-                    woPdf = bsdfPdf;
-                    dTreePdf = 0;
-                } else {
-                    F3 result;
-                    bool zero = false;
-                    if (sx < frac) {
-                        sx /= frac;
-                        result = bsdf_sample(mtype, refl, I.wi, sx, sy, wo_l, bsdfPdf, sampledDelta);
-                        if (iszero3(result)) zero = true;
-                        else result = result * bsdfPdf;
-                    } else {
-                        // sample.x is remapped but unused on this branch (GP:1680-1682)
-                        float cx, cy;
-                        dtree_sample(T, hd, key, dim, cx, cy);
-                        wo_l = to_local(I, canonical_to_dir(cx, cy));
-                        result = bsdf_eval(mtype, refl, I.wi, wo_l);
-                    }
-                    if (zero) {
-                        woPdf = bsdfPdf = dTreePdf = 0;
-                        bsdfWeight = f3s(0.0f);
-                        wo_l = f3s(0.0f);
-                    } else {
-                        // pdfMat, GP:1693-1710
-                        dTreePdf = 0;
-                        bsdfPdf = bsdf_pdf(mtype, I.wi, wo_l);
-                        if (!ppg_isfinite(bsdfPdf)) {
-                            woPdf = 0;
-                        } else {
-                            float cx, cy;
-                            dir_to_canonical(to_world(I, wo_l), cx, cy);
-                            dTreePdf = dtree_pdf(T, hd, cx, cy, fcol);
-                            woPdf = frac * bsdfPdf + (1 - frac) * dTreePdf;
-                        }
-                        bsdfWeight = (woPdf == 0) ? f3s(0.0f) : div3(result, woPdf);
-                    }
-                }
-                if (iszero3(bsdfWeight)) go = false;  // GP:2024-2025
-                if (go) {
-                    const F3 wo = to_world(I, wo_l);
-                    float woDotGeoN = dot3(I.geoN, wo);
-                    if (woDotGeoN * wo_l.z <= 0 && R.strict_normals) go = false;  // GP:2031-2032
-                    if (go) {
-                        thr = mul3(thr, bsdfWeight);  // GP:2039-2040 (eta *= 1)
-                        d = wo;
-                        if (FUSED) {
-                            Hit hn = trace_small(lds_tris, S.n_tris, I.p, wo, PPG_EPSILON, __builtin_inff());
-                            P.hit[i] = make_float4(hn.t, hn.u, hn.v, __int_as_float(hn.prim));
-                            ++traced;
-                        } else {
-                            P.ray_o[i] = make_float4(I.p.x, I.p.y, I.p.z, PPG_EPSILON);
-                        }
-                        P.ray_d[i] = make_float4(wo.x, wo.y, wo.z, __builtin_inff());
-#if defined(PPG_ABLATE) && PPG_ABLATE == 2
-                        if (false) {
-#else
-                        if (smooth && nV < PPG_MAX_VERTICES && nV < (unsigned int)R.max_vertices && !R.is_final_iter) {
-#endif
-                            size_t vi = (size_t)nV * P.n_paths + i;
-                            F3 bv = bsdfWeight * woPdf;
-                            P.v_d[vi] = make_float4(wo.x, wo.y, wo.z, woPdf);
-                            P.v_thr[vi] = make_float4(thr.x, thr.y, thr.z, bsdfPdf);
-                            P.v_bsdf[vi] = make_float4(bv.x, bv.y, bv.z, dTreePdf);
-                            if (P.v_o) {
-                                P.v_o[vi] = make_float4(I.p.x, I.p.y, I.p.z, 0.0f);
-                                P.v_vox[vi] = make_float4(vox.x, vox.y, vox.z, 0.0f);
-                            }
-                        }
-                        flags |= FL_PENDING | (smooth ? FL_PEND_TREE : 0u) | (sampledDelta ? FL_PEND_DELTA : 0u);
-                        m.w = (unsigned int)leaf;
-                        l4.w = woPdf;
-                        alive = true;
-                    }
-                }
-            }
-            flags = (flags & ~(FL_DEPTH_MASK | FL_NV_MASK)) | (depth & FL_DEPTH_MASK) | (nV << FL_NV_SHIFT);
-            P.misc[i] = make_uint4(key, dim, flags, m.w);
-            P.li[i] = make_float4(Li.x, Li.y, Li.z, l4.w);
-            if (alive) P.thr[i] = make_float4(thr.x, thr.y, thr.z, eta);
-            else plen = depth;  // avgPathLength += rRec.depth, GP:2147-2148
-        }
-        unsigned int slot = queue_append(out_count, alive);
-        if (alive) out_items[slot] = i;
-        plen_sum += plen;
-    }
-}
-
-template <bool FUSED>
-__global__ __launch_bounds__(PPG_BLOCK, PPG_SHADE_WAVES) void k_shade(PathState P, DevScene S, DevTree T, RenderParams R, Queues Q, int qin, int qout) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    __shared__ float pdf_factors[20 * PPG_BLOCK];  // QuadTreeNode::pdf's per-level factors (tree depth <= 20, GP:1112)
-    __shared__ unsigned int out_count;
-    __shared__ unsigned long long acc;
-    const float4 *lds_tris = (const float4 *)lds_raw;
-    if (FUSED) {
-        for (int k = threadIdx.x; k < 3 * S.n_tris; k += blockDim.x) ((float4 *)lds_raw)[k] = S.tris[k];
-    }
-    const LdsColumn fcol{pdf_factors + threadIdx.x, PPG_BLOCK};
-    const unsigned int b = blockIdx.x, nb = gridDim.x;
-    const unsigned int count = qin >= 0 ? Q.count[qin][b] : first_share(P.n_paths, b, nb);
-    const unsigned int *items = qin >= 0 ? Q.items[qin] + (size_t)b * Q.cap : nullptr;
-    if (threadIdx.x == 0) out_count = 0;
-    __syncthreads();
-    unsigned long long plen_sum = 0;
-    unsigned int traced = 0;
-    shade_slice<FUSED>(P, S, T, R, items, count, b, nb, Q.items[qout] + (size_t)b * Q.cap, &out_count, fcol, lds_tris, plen_sum, traced);
-    __syncthreads();
-    if (threadIdx.x == 0) Q.count[qout][b] = out_count;
-    block_add_u64(&acc, &Q.stats[b].path_len, plen_sum);
-    if (FUSED) block_add_u64(&acc, &Q.stats[b].rays, traced);
-}
-
-// Tail of unbounded paths (maxDepth < 0): once few paths are left, every workgroup keeps bouncing its own queue
-// slice — trace phase, shade phase, swap — until the slice is empty, inside ONE launch.  The slices are private
-// to a workgroup, so no grid-wide synchronisation (and no host round trip per bounce) is needed.
-template <bool SMALL>
-__global__ __launch_bounds__(PPG_BLOCK, PPG_SHADE_WAVES) void k_tail(PathState P, DevScene S, DevTree T, RenderParams R, Queues Q, int qin,
-                                                                    int lds_nodes, int lds_tris) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    __shared__ float pdf_factors[20 * PPG_BLOCK];
-    __shared__ unsigned int out_count, ticket;
-    __shared__ unsigned long long acc;
-    const LdsColumn fcol{pdf_factors + threadIdx.x, PPG_BLOCK};
-    const unsigned int b = blockIdx.x, nb = gridDim.x;
-    unsigned int count = Q.count[qin][b];
-    if (count == 0) return;
-    LdsScene L;
-    if (SMALL) L = stage_scene(S, lds_raw, 0, lds_tris);
-    else { L.nodes = nullptr; L.tris = nullptr; L.n_nodes = 0; L.n_tris = 0; }
-    unsigned long long plen_sum = 0;
-    unsigned int traced = 0, dummy = 0;
-    int cur = qin;
-    while (count > 0) {
-        const unsigned int *items = Q.items[cur] + (size_t)b * Q.cap;
-        trace_slice<SMALL>(P, S, L, (int *)lds_raw, &ticket, items, count, b, nb, traced);
-        __syncthreads();  // hits written by any lane of the workgroup are read by the shade phase
-        if (threadIdx.x == 0) out_count = 0;
-        __syncthreads();
-        shade_slice<false>(P, S, T, R, items, count, b, nb, Q.items[cur ^ 1] + (size_t)b * Q.cap, &out_count, fcol, L.tris, plen_sum, dummy);
-        __syncthreads();  // queue writes of this workgroup are visible to it after the barrier (same CU, write-through L1)
-        count = out_count;
-        cur ^= 1;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) { Q.count[0][b] = 0; Q.count[1][b] = 0; }
-    block_add_u64(&acc, &Q.stats[b].path_len, plen_sum);
-    block_add_u64(&acc, &Q.stats[b].rays, traced);
-}
-
-// copy every workgroup's queue slice into one dense array (offsets = exclusive scan of the slice counts)
-__global__ void k_gather_slices(const unsigned int *items, const unsigned int *count, const unsigned int *offsets, unsigned int cap,
-                                unsigned int *dense) {
-    const unsigned int b = blockIdx.x, n = count[b], off = offsets[b];
-    for (unsigned int k = threadIdx.x; k < n; k += blockDim.x) dense[off + k] = items[(size_t)b * cap + k];
-}
-
-// sum of count[b] (the host needs it only for unbounded paths and for kernel timing)
-__global__ void k_sum_counts(const unsigned int *count, unsigned int nb, unsigned int *total) {
-    __shared__ unsigned int acc;
-    if (threadIdx.x == 0) acc = 0;
-    __syncthreads();
-    unsigned int v = 0;
-    for (unsigned int k = threadIdx.x; k < nb; k += blockDim.x) v += count[k];
-    atomicAdd(&acc, v);
-    __syncthreads();
-    if (threadIdx.x == 0) *total = acc;
-}
-
-// ------------------------------------------------------------------------------------------------
 // Splatting: DTree::recordIrradiance (GP:395-413) into the building tree of one S-tree leaf
 // ------------------------------------------------------------------------------------------------
 // (the `statisticalWeight += w` half of recordIrradiance is done by the caller, wave-combined)
@@ -830,6 +542,435 @@ D void stree_record_box(const DevTree &T, F3 p, F3 vox, Rec rec, int dfilter, in
     }
 }
 
+// Vertex::commit up to the spatial-filter dispatch (GP:1730-1744): false = the vertex is dropped
+D bool vertex_to_rec(F3 radiance, F3 bsdfVal, F3 throughput, float woPdf, float bsdfPdf, float dTreePdf, F3 d, bool isDelta,
+                     unsigned int key, unsigned int slot, float statisticalWeight, Rec &rec) {
+    if (!(woPdf > 0) || !isvalid3(radiance) || !isvalid3(bsdfVal)) return false;
+    F3 localRadiance = f3s(0.0f);
+    if (throughput.x * woPdf > PPG_EPSILON) localRadiance.x = radiance.x / throughput.x;
+    if (throughput.y * woPdf > PPG_EPSILON) localRadiance.y = radiance.y / throughput.y;
+    if (throughput.z * woPdf > PPG_EPSILON) localRadiance.z = radiance.z / throughput.z;
+    F3 product = mul3(localRadiance, bsdfVal);
+    rec.d = d;
+    rec.radiance = avg3(localRadiance); rec.product = avg3(product);
+    rec.woPdf = woPdf; rec.bsdfPdf = bsdfPdf; rec.dTreePdf = dTreePdf;
+    rec.statisticalWeight = statisticalWeight;
+    rec.isDelta = isDelta;
+    rec.adamBatch = (int)(ppg_hash32(key ^ (0x9e3779b9u * (slot + 1u))) & (PPG_ADAM_BATCHES - 1));
+    return true;
+}
+
+// the stochastic filter's jittered lookup (GP:1746-1763)
+D int stochastic_leaf(const DevTree &T, F3 o, F3 vox, unsigned int key, unsigned int dim) {
+    F3 offset = vox;
+    offset.x *= ppg_rand(key, dim++) - 0.5f;
+    offset.y *= ppg_rand(key, dim++) - 0.5f;
+    offset.z *= ppg_rand(key, dim++) - 0.5f;
+    F3 og = o + offset;
+    og.x = ppg_min(ppg_max(og.x, T.aabb_min[0]), T.aabb_max[0]);  // AABB::clip
+    og.y = ppg_min(ppg_max(og.y, T.aabb_min[1]), T.aabb_max[1]);
+    og.z = ppg_min(ppg_max(og.z, T.aabb_min[2]), T.aabb_max[2]);
+    F3 dummy;
+    return stree_lookup(T, og, dummy);
+}
+
+// Vertex::commit's filter dispatch for ONE lane (the direct-light vertex of GP:1994-2010, committed inside Li's loop)
+D void commit_single(const DevTree &T, int sfilter, int dfilter, int loss, int leaf, F3 o, F3 vox, const Rec &rec, unsigned int key,
+                     unsigned int dim) {
+    if (sfilter == SF_BOX) {
+        stree_record_box(T, o, vox, rec, dfilter, loss);
+    } else {
+        if (sfilter == SF_STOCHASTIC) leaf = stochastic_leaf(T, o, vox, key, dim);
+        wrapper_record<false>(T, leaf, rec, dfilter, loss, true);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_shade — Li's loop body (GP:1798-2146), surface branch
+// ------------------------------------------------------------------------------------------------
+// Shadow-ray test of Scene::evalTransmittance (scene.cpp:619-679) without media / null BSDFs: true = occluded.
+// small_tris != nullptr: the whole scene is staged in LDS (brute force); otherwise BVH4 any-hit with this lane's
+// LDS stack column.
+D bool shadow_occluded(const DevScene &S, const float4 *small_tris, int *stack_col, F3 o, F3 d, float maxt) {
+    if (small_tris) return trace_small(small_tris, S.n_tris, o, d, PPG_EPSILON, maxt).prim >= 0;
+    float rayMinT = PPG_EPSILON;  // adaptive ray epsilon, skdtree.cpp:125-129
+    rayMinT *= ppg_max(ppg_max(ppg_max(ppg_abs(o.x), ppg_abs(o.y)), ppg_abs(o.z)), PPG_EPSILON);
+    return trace_closest4<true>(S, stack_col, PPG_BLOCK, o, d, rayMinT, maxt).prim >= 0;
+}
+
+// LDS the next-event-estimation variants add to k_shade / k_tail
+struct NeeLds {
+    const float4 *small_tris;  // staged triangles (small scenes) or nullptr
+    int *stack_col;            // BVH4 stack column of this lane
+};
+
+// One queue slice through Li's loop body.  FUSED (small scenes): the ray sampled here is traced here too.
+// NEE: the variant with luminaire sampling (GP:1962-2021) and MIS against it (GP:2083-2088); the shadow ray is
+// traced and the direct-light vertex committed in place, as in the reference's loop.
+template <bool FUSED, bool NEE>
+D void shade_slice(const PathState &P, const DevScene &S, const DevTree &T, const RenderParams &R, const unsigned int *items, unsigned int count,
+                   unsigned int b, unsigned int nb, unsigned int *out_items, unsigned int *out_count, const LdsColumn &fcol,
+                   const float4 *lds_tris, unsigned long long &plen_sum, unsigned int &traced, const NeeLds &nee,
+                   unsigned long long &committed) {
+    const unsigned int rounds = (count + PPG_BLOCK - 1) / PPG_BLOCK;
+    for (unsigned int r = 0; r < rounds; ++r) {
+        unsigned int q = r * PPG_BLOCK + threadIdx.x;
+        bool active = q < count;
+        bool alive = false;
+        unsigned long long plen = 0;
+        unsigned int i = 0;
+        if (active) {
+            i = items ? items[q] : first_path(q, b, nb);
+            active = i < P.n_paths;
+        }
+        if (active) {
+            uint4 m = P.misc[i];
+            unsigned int key = m.x, dim = m.y, flags = m.z;
+            unsigned int depth = flags & FL_DEPTH_MASK;
+            unsigned int nV = (flags & FL_NV_MASK) >> FL_NV_SHIFT;
+            float4 t4 = P.thr[i], l4 = P.li[i], h4 = P.hit[i], d4 = P.ray_d[i];
+            F3 thr = f3(t4.x, t4.y, t4.z);
+            float eta = t4.w;
+            F3 Li = f3(l4.x, l4.y, l4.z);
+            F3 d = f3(d4.x, d4.y, d4.z);
+            Hit h;
+            h.t = h4.x; h.u = h4.y; h.v = h4.z; h.prim = __float_as_int(h4.w);
+            const bool valid = h.prim >= 0;
+            Isect I;
+            if (valid) fill_isect(S, h, d, I);
+            bool go = true;
+
+            if (flags & FL_PENDING) {
+                // ---- second half of the previous bounce: GP:2078-2145 ----
+                F3 value = valid ? eval_Le(S, I, -d) : f3s(0.0f);  // rayIntersectAndLookForEmitter, GP:2229-2234
+                const float woPdf = l4.w;
+                const bool isDelta = (flags & FL_PEND_DELTA) != 0;
+                const bool hasTree = (flags & FL_PEND_TREE) != 0;
+                float emitterPdf = 0.0f;  // GP:2085: scene->pdfEmitterDirect(dRec) (scene.cpp:949-952, area.cpp:175-183, shape.cpp:117-126)
+                if (NEE && R.do_nee && !isDelta && !iszero3(value)) {
+                    float pdfDirect = 0.0f;
+                    const float dn = dot3(d, I.n);
+                    if ((flags & FL_PEND_REFN) && dn < 0)
+                        pdfDirect = __int_as_float(S.em_info[I.emitter].w) * (h.t * h.t) / ppg_abs(dn);
+                    emitterPdf = pdfDirect * (1.0f * S.em_sel_norm);
+                }
+                float pa = woPdf * woPdf, pb = emitterPdf * emitterPdf;  // miWeight(woPdf, emitterPdf), GP:2247-2250
+                const float weight = pa / (pa + pb);
+                F3 L = mul3(thr, value) * weight;
+                if (!iszero3(L)) {  // recordRadiance, GP:1791-1796
+                    Li = Li + L;
+                    for (unsigned int v0 = 0; v0 < nV; v0 += 4) {  // 4 independent loads in flight, then 4 stores
+                        float4 rr[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (v0 + k < nV) rr[k] = P.v_rad[(size_t)(v0 + k) * P.n_paths + i];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (v0 + k < nV) {
+                                rr[k].x += L.x; rr[k].y += L.y; rr[k].z += L.z;
+                                P.v_rad[(size_t)(v0 + k) * P.n_paths + i] = rr[k];
+                            }
+                    }
+                }
+                if ((!isDelta || R.loss != LOSS_NONE) && hasTree && nV < PPG_MAX_VERTICES && nV < (unsigned int)R.max_vertices &&
+                    !R.is_final_iter) {
+                    if (1 / woPdf > 0) {  // the other vertex fields were written when the bounce was sampled
+                        F3 rad = (R.nee == NEE_ALWAYS) ? f3s(0.0f) : L;
+                        unsigned int bits = m.w | (isDelta ? 0x80000000u : 0u);
+                        P.v_rad[(size_t)nV * P.n_paths + i] = make_float4(rad.x, rad.y, rad.z, __uint_as_float(bits));
+                        ++nV;
+                    }
+                }
+                flags &= ~FL_EMITTED_OK;  // rRec.type = ERadianceNoEmission
+                if (depth++ >= (unsigned int)R.rr_depth) {  // Russian roulette, GP:2124-2142
+                    float successProb = 1.0f;
+                    if (hasTree && !isDelta) {
+                        if (!T.is_built) successProb = max3(thr) * eta * eta;
+                        successProb = ppg_max(0.1f, ppg_min(successProb, 0.99f));
+                    }
+                    if (ppg_rand(key, dim++) >= successProb) go = false;
+                    else thr = div3(thr, successProb);
+                }
+                if (go) {
+                    flags |= FL_SCATTERED;
+                    if (!((int)depth <= R.max_depth || R.max_depth < 0)) go = false;
+                }
+                flags &= ~(FL_PENDING | FL_PEND_TREE | FL_PEND_DELTA | FL_PEND_REFN);
+            }
+
+            // ---- first half of this bounce: GP:1902-2040 ----
+            if (go && !valid) go = false;  // no environment emitter in the supported scene subset
+            if (go) {
+                if (I.emitter >= 0 && (flags & FL_EMITTED_OK) && (!R.hide_emitters || (flags & FL_SCATTERED)))
+                    Li = Li + mul3(thr, eval_Le(S, I, -d));  // GP:1917-1919 (nVertices == 0 here)
+                if ((int)depth >= R.max_depth && R.max_depth != -1) go = false;
+            }
+            if (go) {
+                float wiDotGeoN = -dot3(I.geoN, d), wiDotShN = I.wi.z;
+                if (wiDotGeoN * wiDotShN < 0 && R.strict_normals) go = false;
+            }
+            if (go) {
+                float4 mat = S.materials[I.material];
+                const F3 refl = f3(mat.x, mat.y, mat.z);
+                const int mtype = (int)mat.w;
+                const bool smooth = bsdf_is_smooth(mtype);  // bsdf->getType() & ESmooth: only those are guided
+                F3 vox = f3s(0.0f);
+                int leaf = 0;
+                DTreeRef hd;
+                hd.s_base = 0; hd.s_sum = 0; hd.s_statw = 0;
+                float frac = R.bsdf_sampling_fraction;  // GP:1946-1949
+                if (smooth) {
+                    leaf = stree_lookup(T, I.p, vox);  // GP:1942-1944
+                    const float4 h4 = *reinterpret_cast<const float4 *>(&T.hdr[leaf]);  // {s_base, s_num, s_sum, s_statw}
+                    hd.s_base = __float_as_uint(h4.x); hd.s_sum = h4.z; hd.s_statw = h4.w;
+                    if (R.loss != LOSS_NONE) frac = logistic(T.hdr[leaf].theta);
+                }
+
+                // sampleMat, GP:1650-1691
+                float sx = ppg_rand(key, dim++);
+                float sy = ppg_rand(key, dim++);
+                F3 wo_l, bsdfWeight;
+                float woPdf, bsdfPdf, dTreePdf;
+                bool sampledDelta = false;
+                if (!T.is_built || !smooth) {  // !m_isBuilt || !dTree || all components are delta
+                    bsdfWeight = bsdf_sample(mtype, refl, I.wi, sx, sy, wo_l, bsdfPdf, sampledDelta);
+                    woPdf = bsdfPdf;
+                    dTreePdf = 0;
+                } else {
+                    F3 result;
+                    bool zero = false;
+                    if (sx < frac) {
+                        sx /= frac;
+                        result = bsdf_sample(mtype, refl, I.wi, sx, sy, wo_l, bsdfPdf, sampledDelta);
+                        if (iszero3(result)) zero = true;
+                        else result = result * bsdfPdf;
+                    } else {
+                        // sample.x is remapped but unused on this branch (GP:1680-1682)
+                        float cx, cy;
+                        dtree_sample(T, hd, key, dim, cx, cy);
+                        wo_l = to_local(I, canonical_to_dir(cx, cy));
+                        result = bsdf_eval(mtype, refl, I.wi, wo_l);
+                    }
+                    if (zero) {
+                        woPdf = bsdfPdf = dTreePdf = 0;
+                        bsdfWeight = f3s(0.0f);
+                        wo_l = f3s(0.0f);
+                    } else {
+                        // pdfMat, GP:1693-1710
+                        dTreePdf = 0;
+                        bsdfPdf = bsdf_pdf(mtype, I.wi, wo_l);
+                        if (!ppg_isfinite(bsdfPdf)) {
+                            woPdf = 0;
+                        } else {
+                            float cx, cy;
+                            dir_to_canonical(to_world(I, wo_l), cx, cy);
+                            dTreePdf = dtree_pdf(T, hd, cx, cy, fcol);
+                            woPdf = frac * bsdfPdf + (1 - frac) * dTreePdf;
+                        }
+                        bsdfWeight = (woPdf == 0) ? f3s(0.0f) : div3(result, woPdf);
+                    }
+                }
+                // Luminaire sampling, GP:1962-2021
+                const F3 refN = (mtype == PPG_BSDF_TWOSIDED_DIFFUSE) ? f3s(0.0f) : I.n;  // DirectSamplingRecord(its), records.inl:160-164
+                if (NEE && R.do_nee && smooth) {
+                    const float ex = ppg_rand(key, dim++);
+                    const float ey = ppg_rand(key, dim++);
+                    DirectSample ds;
+                    F3 value = emitter_sample_direct(S, I.p, refN, ex, ey, ds);
+                    if (ds.pdf != 0) {
+                        ++traced;
+                        if (shadow_occluded(S, nee.small_tris, nee.stack_col, I.p, ds.d, ds.dist * (1 - PPG_SHADOW_EPSILON))) {
+                            value = f3s(0.0f);
+                        } else {
+                            value = div3(value, ds.em_pdf);
+                            ds.pdf *= ds.em_pdf;
+                        }
+                    }
+                    if (!iszero3(value)) {
+                        const F3 wo_e = to_local(I, ds.d);
+                        const float woDotGeoNE = dot3(I.geoN, ds.d);
+                        if (!R.strict_normals || woDotGeoNE * wo_e.z > 0) {
+                            const F3 bsdfVal = bsdf_eval(mtype, refl, I.wi, wo_e);
+                            float woPdfE = 0, bsdfPdfE = 0, dTreePdfE = 0;  // pdfMat, GP:1693-1710
+                            if (!T.is_built) {
+                                woPdfE = bsdfPdfE = bsdf_pdf(mtype, I.wi, wo_e);
+                            } else {
+                                bsdfPdfE = bsdf_pdf(mtype, I.wi, wo_e);
+                                if (ppg_isfinite(bsdfPdfE)) {
+                                    float cx, cy;
+                                    dir_to_canonical(to_world(I, wo_e), cx, cy);
+                                    dTreePdfE = dtree_pdf(T, hd, cx, cy, fcol);
+                                    woPdfE = frac * bsdfPdfE + (1 - frac) * dTreePdfE;
+                                }
+                            }
+                            const float qa = ds.pdf * ds.pdf, qb = woPdfE * woPdfE;
+                            const float weightE = qa / (qa + qb);
+                            value = mul3(value, bsdfVal);
+                            const F3 L = mul3(thr, value) * weightE;
+                            if (!R.is_final_iter && R.nee != NEE_ALWAYS) {  // the direct-light vertex, GP:1994-2010
+                                Rec rec;
+                                if (vertex_to_rec(L, bsdfVal, div3(mul3(thr, bsdfVal), ds.pdf), ds.pdf, bsdfPdfE, dTreePdfE, ds.d, false, key,
+                                                  PPG_SLOT_NEE + depth, 0.5f, rec)) {
+                                    commit_single(T, R.spatial_filter, R.directional_filter, T.is_built ? R.loss : LOSS_NONE, leaf, I.p, vox, rec,
+                                                  key, PPG_DIM_NEE_COMMIT + 3u * depth);
+                                    ++committed;
+                                }
+                            }
+                            if (!iszero3(L)) {  // recordRadiance, GP:1791-1796
+                                Li = Li + L;
+                                for (unsigned int v0 = 0; v0 < nV; ++v0) {
+                                    float4 rr = P.v_rad[(size_t)v0 * P.n_paths + i];
+                                    rr.x += L.x; rr.y += L.y; rr.z += L.z;
+                                    P.v_rad[(size_t)v0 * P.n_paths + i] = rr;
+                                }
+                            }
+                        }
+                    }
+                }
+                if (iszero3(bsdfWeight)) go = false;  // GP:2024-2025
+                if (go) {
+                    const F3 wo = to_world(I, wo_l);
+                    float woDotGeoN = dot3(I.geoN, wo);
+                    if (woDotGeoN * wo_l.z <= 0 && R.strict_normals) go = false;  // GP:2031-2032
+                    if (go) {
+                        thr = mul3(thr, bsdfWeight);  // GP:2039-2040 (eta *= 1)
+                        d = wo;
+                        if (FUSED) {
+                            Hit hn = trace_small(lds_tris, S.n_tris, I.p, wo, PPG_EPSILON, __builtin_inff());
+                            P.hit[i] = make_float4(hn.t, hn.u, hn.v, __int_as_float(hn.prim));
+                            ++traced;
+                        } else {
+                            P.ray_o[i] = make_float4(I.p.x, I.p.y, I.p.z, PPG_EPSILON);
+                        }
+                        P.ray_d[i] = make_float4(wo.x, wo.y, wo.z, __builtin_inff());
+#if defined(PPG_ABLATE) && PPG_ABLATE == 2
+                        if (false) {
+#else
+                        if (smooth && nV < PPG_MAX_VERTICES && nV < (unsigned int)R.max_vertices && !R.is_final_iter) {
+#endif
+                            size_t vi = (size_t)nV * P.n_paths + i;
+                            F3 bv = bsdfWeight * woPdf;
+                            P.v_d[vi] = make_float4(wo.x, wo.y, wo.z, woPdf);
+                            P.v_thr[vi] = make_float4(thr.x, thr.y, thr.z, bsdfPdf);
+                            P.v_bsdf[vi] = make_float4(bv.x, bv.y, bv.z, dTreePdf);
+                            if (P.v_o) {
+                                P.v_o[vi] = make_float4(I.p.x, I.p.y, I.p.z, 0.0f);
+                                P.v_vox[vi] = make_float4(vox.x, vox.y, vox.z, 0.0f);
+                            }
+                        }
+                        flags |= FL_PENDING | (smooth ? FL_PEND_TREE : 0u) | (sampledDelta ? FL_PEND_DELTA : 0u);
+                        if (NEE && dot3(wo, refN) >= 0) flags |= FL_PEND_REFN;
+                        m.w = (unsigned int)leaf;
+                        l4.w = woPdf;
+                        alive = true;
+                    }
+                }
+            }
+            flags = (flags & ~(FL_DEPTH_MASK | FL_NV_MASK)) | (depth & FL_DEPTH_MASK) | (nV << FL_NV_SHIFT);
+            P.misc[i] = make_uint4(key, dim, flags, m.w);
+            P.li[i] = make_float4(Li.x, Li.y, Li.z, l4.w);
+            if (alive) P.thr[i] = make_float4(thr.x, thr.y, thr.z, eta);
+            else plen = depth;  // avgPathLength += rRec.depth, GP:2147-2148
+        }
+        unsigned int slot = queue_append(out_count, alive);
+        if (alive) out_items[slot] = i;
+        plen_sum += plen;
+    }
+}
+
+template <bool FUSED, bool NEE>
+__global__ __launch_bounds__(PPG_BLOCK, PPG_SHADE_WAVES) void k_shade(PathState P, DevScene S, DevTree T, RenderParams R, Queues Q, int qin, int qout,
+                                                                     int small_scene) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    __shared__ float pdf_factors[20 * PPG_BLOCK];  // QuadTreeNode::pdf's per-level factors (tree depth <= 20, GP:1112)
+    __shared__ unsigned int out_count;
+    __shared__ unsigned long long acc;
+    const float4 *lds_tris = (const float4 *)lds_raw;
+    const bool staged = FUSED || (NEE && small_scene);  // dynamic LDS: the triangles (small scenes) or the shadow rays' BVH stack columns
+    if (staged) {
+        for (int k = threadIdx.x; k < 3 * S.n_tris; k += blockDim.x) ((float4 *)lds_raw)[k] = S.tris[k];
+    }
+    NeeLds nee;
+    nee.small_tris = staged ? lds_tris : nullptr;
+    nee.stack_col = (int *)lds_raw + threadIdx.x;
+    const LdsColumn fcol{pdf_factors + threadIdx.x, PPG_BLOCK};
+    const unsigned int b = blockIdx.x, nb = gridDim.x;
+    const unsigned int count = qin >= 0 ? Q.count[qin][b] : first_share(P.n_paths, b, nb);
+    const unsigned int *items = qin >= 0 ? Q.items[qin] + (size_t)b * Q.cap : nullptr;
+    if (threadIdx.x == 0) out_count = 0;
+    __syncthreads();
+    unsigned long long plen_sum = 0, committed = 0;
+    unsigned int traced = 0;
+    shade_slice<FUSED, NEE>(P, S, T, R, items, count, b, nb, Q.items[qout] + (size_t)b * Q.cap, &out_count, fcol, lds_tris, plen_sum, traced, nee,
+                            committed);
+    __syncthreads();
+    if (threadIdx.x == 0) Q.count[qout][b] = out_count;
+    block_add_u64(&acc, &Q.stats[b].path_len, plen_sum);
+    if (FUSED || NEE) block_add_u64(&acc, &Q.stats[b].rays, traced);
+    if (NEE) block_add_u64(&acc, &Q.stats[b].committed, committed);
+}
+
+// Tail of unbounded paths (maxDepth < 0): once few paths are left, every workgroup keeps bouncing its own queue
+// slice — trace phase, shade phase, swap — until the slice is empty, inside ONE launch.  The slices are private
+// to a workgroup, so no grid-wide synchronisation (and no host round trip per bounce) is needed.
+template <bool SMALL, bool NEE>
+__global__ __launch_bounds__(PPG_BLOCK, PPG_SHADE_WAVES) void k_tail(PathState P, DevScene S, DevTree T, RenderParams R, Queues Q, int qin,
+                                                                    int lds_nodes, int lds_tris) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    __shared__ float pdf_factors[20 * PPG_BLOCK];
+    __shared__ unsigned int out_count, ticket;
+    __shared__ unsigned long long acc;
+    const LdsColumn fcol{pdf_factors + threadIdx.x, PPG_BLOCK};
+    const unsigned int b = blockIdx.x, nb = gridDim.x;
+    unsigned int count = Q.count[qin][b];
+    if (count == 0) return;
+    LdsScene L;
+    if (SMALL) L = stage_scene(S, lds_raw, 0, lds_tris);
+    else { L.nodes = nullptr; L.tris = nullptr; L.n_nodes = 0; L.n_tris = 0; }
+    NeeLds nee;
+    nee.small_tris = SMALL ? L.tris : nullptr;   // SMALL: all triangles are staged
+    nee.stack_col = (int *)lds_raw + threadIdx.x;  // !SMALL: the trace phase's stack columns are idle during the shade phase
+    unsigned long long plen_sum = 0, committed = 0;
+    unsigned int traced = 0, shadow = 0;
+    int cur = qin;
+    while (count > 0) {
+        const unsigned int *items = Q.items[cur] + (size_t)b * Q.cap;
+        trace_slice<SMALL>(P, S, L, (int *)lds_raw, &ticket, items, count, b, nb, traced);
+        __syncthreads();  // hits written by any lane of the workgroup are read by the shade phase
+        if (threadIdx.x == 0) out_count = 0;
+        __syncthreads();
+        shade_slice<false, NEE>(P, S, T, R, items, count, b, nb, Q.items[cur ^ 1] + (size_t)b * Q.cap, &out_count, fcol, L.tris, plen_sum, shadow,
+                                nee, committed);
+        __syncthreads();  // queue writes of this workgroup are visible to it after the barrier (same CU, write-through L1)
+        count = out_count;
+        cur ^= 1;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { Q.count[0][b] = 0; Q.count[1][b] = 0; }
+    block_add_u64(&acc, &Q.stats[b].path_len, plen_sum);
+    block_add_u64(&acc, &Q.stats[b].rays, traced + (NEE ? shadow : 0u));
+    if (NEE) block_add_u64(&acc, &Q.stats[b].committed, committed);
+}
+
+// copy every workgroup's queue slice into one dense array (offsets = exclusive scan of the slice counts)
+__global__ void k_gather_slices(const unsigned int *items, const unsigned int *count, const unsigned int *offsets, unsigned int cap,
+                                unsigned int *dense) {
+    const unsigned int b = blockIdx.x, n = count[b], off = offsets[b];
+    for (unsigned int k = threadIdx.x; k < n; k += blockDim.x) dense[off + k] = items[(size_t)b * cap + k];
+}
+
+// sum of count[b] (the host needs it only for unbounded paths and for kernel timing)
+__global__ void k_sum_counts(const unsigned int *count, unsigned int nb, unsigned int *total) {
+    __shared__ unsigned int acc;
+    if (threadIdx.x == 0) acc = 0;
+    __syncthreads();
+    unsigned int v = 0;
+    for (unsigned int k = threadIdx.x; k < nb; k += blockDim.x) v += count[k];
+    atomicAdd(&acc, v);
+    __syncthreads();
+    if (threadIdx.x == 0) *total = acc;
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_commit — Vertex::commit for every recorded vertex of every path (GP:1730-1768, 2150-2154)
 // ------------------------------------------------------------------------------------------------
@@ -866,19 +1007,10 @@ __global__ __launch_bounds__(PPG_BLOCK) void k_commit(PathState P, DevTree T, Re
             const float woPdf = a.w, bsdfPdf = b.w, dTreePdf = c.w;
             F3 radiance = f3(e.x, e.y, e.z), bsdfVal = f3(c.x, c.y, c.z), throughput = f3(b.x, b.y, b.z);
             unsigned int bits = __float_as_uint(e.w);
-            if (!(woPdf > 0) || !isvalid3(radiance) || !isvalid3(bsdfVal)) {
+            const bool isDelta = (bits & 0x80000000u) != 0;
+            if (!vertex_to_rec(radiance, bsdfVal, throughput, woPdf, bsdfPdf, dTreePdf, f3(a.x, a.y, a.z), isDelta, key, v, statisticalWeight, rec)) {
                 act = false;
             } else {
-                F3 localRadiance = f3s(0.0f);
-                if (throughput.x * woPdf > PPG_EPSILON) localRadiance.x = radiance.x / throughput.x;
-                if (throughput.y * woPdf > PPG_EPSILON) localRadiance.y = radiance.y / throughput.y;
-                if (throughput.z * woPdf > PPG_EPSILON) localRadiance.z = radiance.z / throughput.z;
-                F3 product = mul3(localRadiance, bsdfVal);
-                rec.d = f3(a.x, a.y, a.z);
-                rec.radiance = avg3(localRadiance); rec.product = avg3(product);
-                rec.woPdf = woPdf; rec.bsdfPdf = bsdfPdf; rec.dTreePdf = dTreePdf;
-                rec.isDelta = (bits & 0x80000000u) != 0;
-                rec.adamBatch = (int)(ppg_hash32(key ^ (0x9e3779b9u * (v + 1u))) & (PPG_ADAM_BATCHES - 1));
                 leaf = (int)(bits & 0x7fffffffu);
                 ++committed_sum;
             }
@@ -891,16 +1023,7 @@ __global__ __launch_bounds__(PPG_BLOCK) void k_commit(PathState P, DevTree T, Re
         } else {
             if (SF == SF_STOCHASTIC && act) {  // GP:1746-1763
                 float4 o4 = P.v_o[vi], x4 = P.v_vox[vi];
-                F3 offset = f3(x4.x, x4.y, x4.z);
-                offset.x *= ppg_rand(key, dim++) - 0.5f;
-                offset.y *= ppg_rand(key, dim++) - 0.5f;
-                offset.z *= ppg_rand(key, dim++) - 0.5f;
-                F3 og = f3(o4.x, o4.y, o4.z) + offset;
-                og.x = ppg_min(ppg_max(og.x, T.aabb_min[0]), T.aabb_max[0]);  // AABB::clip
-                og.y = ppg_min(ppg_max(og.y, T.aabb_min[1]), T.aabb_max[1]);
-                og.z = ppg_min(ppg_max(og.z, T.aabb_min[2]), T.aabb_max[2]);
-                F3 dummy;
-                leaf = stree_lookup(T, og, dummy);
+                leaf = stochastic_leaf(T, f3(o4.x, o4.y, o4.z), f3(x4.x, x4.y, x4.z), key, dim);
             }
             wrapper_record<true>(T, leaf, rec, DF, loss, act);
         }

@@ -225,7 +225,7 @@ def test_edge_cases(oracle_lib):
         e.render()
     assert ei.value.code == -3
     with pytest.raises(ppg_host.PPGError):
-        hip(nee="always")
+        hip(nee="sometimes")
 
 
 def test_sharded_contexts_on_one_gpu_equal_unsharded():
@@ -383,3 +383,48 @@ def test_mirror_and_twosided_materials_against_oracle(oracle_lib, extra):
     assert_tree_equal(g.read_sdtree(), o.read_sdtree())
     plain = ppg_host.GuidedPathTracer(engine=hip(**props)).render(ppg_host.cbox_scene(96, 96))
     assert np.abs(ig - plain).mean() > 1e-3  # the materials are really in effect
+
+
+def _stats(gpt):
+    return [[s["rays"], s["path_length_sum"], s["vertices_committed"]] for it in gpt.iterations for s in it["stats"]]
+
+
+@pytest.mark.parametrize("res,budget,extra", [
+    ((64, 64), 60, dict(nee="always")),
+    ((48, 48), 508, dict(nee="kickstart")),  # the 128-spp switch of doNeeWithSpp (GP:1331-1340) is crossed: the last iteration starts at 252 spp
+    ((64, 64), 60, dict(nee="kickstart", **IMPROVED)),
+    ((48, 48), 60, dict(nee="kickstart", spatialFilter="box", directionalFilter="box", bsdfSamplingFractionLoss="var", sTreeThreshold=600)),
+    ((64, 64), 124, dict(nee="always", maxDepth=-1, rrDepth=5, strictNormals=0)),
+])
+def test_next_event_estimation_against_oracle(oracle_lib, res, budget, extra):
+    """nee = always / kickstart (GP:1962-2021, 2083-2088): luminaire sampling with the shadow ray traced inside Li's loop,
+    MIS against the mixture pdf, the direct-light vertex committed in place with statistical weight 0.5."""
+    import ppg_host
+    props = dict(CBOX_PROPS, budget=budget, seed=5)
+    props.update(extra)
+    scene = ppg_host.cbox_scene(*res)
+    g, o = hip(**props), make_oracle(oracle_lib, threads=os.cpu_count() or 8, **props)
+    gg, go = ppg_host.GuidedPathTracer(engine=g), ppg_host.GuidedPathTracer(engine=o)
+    ig, io = gg.render(scene), go.render(scene)
+    assert _stats(gg) == _stats(go)
+    assert np.array_equal(ig, io)
+    assert_tree_equal(g.read_sdtree(), o.read_sdtree())
+    never = ppg_host.GuidedPathTracer(engine=hip(**dict(props, nee="never"))).render(scene)
+    assert np.abs(ig - never).mean() > 1e-3 and abs(ig.mean() / never.mean() - 1) < 0.05  # a different, equally unbiased estimator
+
+
+def test_next_event_estimation_bvh_scene_and_materials(oracle_lib):
+    """Shadow rays through the BVH4 (any-hit) on a ~50k-triangle scene; twosided receivers (dRec.refN = 0) and a mirror."""
+    import ppg_host
+    scene = ppg_host.room_scene(120, 68, n_boxes=260, tess=4)
+    props = dict(budgetType="spp", budget=28, maxDepth=8, rrDepth=5, seed=8, sTreeThreshold=2000, nee="kickstart")
+    g, o = hip(**props), make_oracle(oracle_lib, threads=os.cpu_count() or 8, **props)
+    ig = ppg_host.GuidedPathTracer(engine=g).render(scene)
+    io = ppg_host.GuidedPathTracer(engine=o).render(scene)
+    assert ig.mean() > 1e-3 and np.array_equal(ig, io)
+    assert_tree_equal(g.read_sdtree(), o.read_sdtree())
+    scene = _materials_scene((64, 64))
+    props = dict(CBOX_PROPS, budget=60, seed=78, nee="always", maxDepth=12, rrDepth=4, **IMPROVED)
+    g, o = hip(**props), make_oracle(oracle_lib, threads=os.cpu_count() or 8, **props)
+    assert np.array_equal(ppg_host.GuidedPathTracer(engine=g).render(scene), ppg_host.GuidedPathTracer(engine=o).render(scene))
+    assert_tree_equal(g.read_sdtree(), o.read_sdtree())

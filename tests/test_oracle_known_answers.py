@@ -101,3 +101,58 @@ def test_dtree_box_filter_conserves_interior_energy(oracle_lib):
     assert abs(box["total"] - near["total"]) < 2e-3 * near["total"]
     edge = _exercise(oracle_lib, 0, 1, np.full((100, 2), 0.001), np.ones(100), np.ones(100), q)
     assert 20 < edge["total"] < 75  # energy outside [0,1]^2 is lost, as in the reference
+
+
+def _floor_and_lamp(res, lamp_half=0.05, lamp_h=1.0):
+    """A 20 x 20 diffuse floor (albedo 0.5) at y = 0 and a small square lamp (radiance 100) at height lamp_h
+    facing down, seen from above by an orthogonal-ish narrow camera that does not see the lamp's front."""
+    import ppg_host
+    from ppg_host.scenes import SceneDesc
+    P = np.array([[-10, 0, -10], [10, 0, -10], [10, 0, 10], [-10, 0, 10],
+                  [-lamp_half, lamp_h, -lamp_half], [lamp_half, lamp_h, -lamp_half], [lamp_half, lamp_h, lamp_half], [-lamp_half, lamp_h, lamp_half]], np.float32)
+    I = np.array([[0, 2, 1], [0, 3, 2],      # floor, normal +y
+                  [4, 5, 6], [4, 6, 7]], np.uint32)  # lamp, normal -y
+    cam = ppg_host.perspective_camera((0.0, 30.0, 0.0), (0.0, 0.0, 0.0), (0, 0, 1), 4.0, "x", 0.1, 100.0, res, res)
+    return SceneDesc(P, I, np.array([0, 0, 1, 1], np.uint32), np.array([-1, -1, 0, 0], np.int32),
+                     [dict(type=0, reflectance=(0.5, 0.5, 0.5)), dict(type=0, reflectance=(0, 0, 0))],
+                     [dict(radiance=(100.0, 100.0, 100.0))], cam)
+
+
+def test_next_event_estimation_matches_the_analytic_direct_light(oracle_lib):
+    """maxDepth = 2 (direct light only).  Under the lamp the floor's radiance is rho/pi * L * A * cos^2 / r^2 (small
+    lamp: A = 0.01, r = 1).  nee = always (luminaire sampling + MIS, GP:1962-2021, 2083-2088) and nee = never must both
+    converge to it; NEE with far less noise."""
+    import ppg_host
+    from conftest import make_oracle
+    res = 24
+    scene = _floor_and_lamp(res)
+    # the camera sees a ~2.1 m wide patch centred under the lamp: analytic value per pixel
+    half = 30.0 * np.tan(np.radians(2.0))
+    xs = (np.arange(res) + 0.5) / res * 2 * half - half
+    X, Z = np.meshgrid(xs, xs)
+    r2 = X ** 2 + Z ** 2 + 1.0
+    analytic = 0.5 / np.pi * 100.0 * 0.01 * (1.0 / r2) / r2  # cos = 1 / r at both ends
+    out = {}
+    for nee, budget in (("always", 64), ("never", 512)):
+        e = make_oracle(oracle_lib, threads=16, budgetType="spp", budget=budget, maxDepth=2, rrDepth=10, nee=nee, seed=3)
+        img = ppg_host.GuidedPathTracer(engine=e).render(scene)
+        out[nee] = img[..., 0]
+    assert abs(out["always"].mean() / analytic.mean() - 1) < 0.01
+    assert abs(out["never"].mean() / analytic.mean() - 1) < 0.05
+    err_nee = np.abs(out["always"] - analytic.T).mean() / analytic.mean()
+    err_bsdf = np.abs(out["never"] - analytic.T).mean() / analytic.mean()
+    assert err_nee < 0.03 and err_nee < err_bsdf / 4  # the profile matches pixel by pixel (the scene is symmetric, so .T is harmless)
+
+
+def test_nee_modes_agree_on_cbox(oracle_lib):
+    import ppg_host
+    from conftest import CBOX_PROPS, make_oracle
+    means = {}
+    for nee in ("never", "always", "kickstart"):
+        e = make_oracle(oracle_lib, threads=16, **dict(CBOX_PROPS, budget=31, nee=nee, seed=11))
+        g = ppg_host.GuidedPathTracer(engine=e)
+        means[nee] = g.render(ppg_host.cbox_scene(96, 96)).reshape(-1, 3).mean(0)
+        if nee == "kickstart":  # both the path vertices and the direct-light vertices carry weight 0.5 (GP:2005, 2152)
+            assert all(abs(it["tree"]["max_stat_weight"] * 2 - round(it["tree"]["max_stat_weight"] * 2)) < 1e-3 for it in g.iterations[1:2])
+    for nee in ("always", "kickstart"):
+        assert np.all(np.abs(means[nee] / means["never"] - 1) < 0.03), means
