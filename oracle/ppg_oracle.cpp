@@ -10,7 +10,9 @@
  *   STreeNode GP:740-845 · STree GP:848-1007 · GuidedPathTracer GP:1012-2419 (surface branch; the medium
  *   branch GP:1803-1893 is unreachable in every config) — plus the callees listed in
  *   diffuse.cpp:110-150, warp.cpp:43-52/81-102, area.cpp:104-109,
- *   perspective.cpp:271-298, skdtree.cpp:112-142 (ray epsilon), skdtree.h:343-430, util.cpp:592-608.
+ *   perspective.cpp:271-298, skdtree.cpp:112-142 (ray epsilon), skdtree.h:343-430, util.cpp:592-608;
+ *   for next-event estimation scene.cpp:619-679/876-897/949-952, area.cpp:158-183, shape.cpp:102-126,
+ *   trimesh.cpp:388-423, triangle.cpp:24-67, pmf.h:101-188, records.inl:160-178.
  *   The code is written recursively / object-per-node like the reference, on purpose: the HIP product
  *   uses flat arrays and wavefront kernels, so the two share no implementation.
  *
@@ -24,6 +26,9 @@
  *         ref_cbox_images.npz, mined by tools/make_ref_fixtures.py): iteration schedules exactly,
  *         iteration-0/1 SD-tree statistics, average path length, variance sequence and the CBOX
  *         image statistically                                   tests/test_oracle_reference_pins.py
+ *     (3) next-event estimation (no reference log uses it): the analytic irradiance under a small lamp
+ *         (within 1 %) and agreement of nee = never / kickstart / always on CBOX
+ *                                                               tests/test_oracle_known_answers.py
  *
  * Deliberate, documented deviations (DESIGN.md §"numerical contract"):
  *   - sampler: counter-based (include/ppg_rng.h) instead of per-thread SFMT streams;
