@@ -4,6 +4,8 @@
  *
  *   ppg_render [-D key=value]... [-o out.pfm] [-q] scene.ppgs
  *   ppg_render --cbox WIDTHxHEIGHT [-D key=value]... [-o out.pfm]
+ * A Mitsuba scene XML is converted first: `python -m ppg_host scene.xml --ppgs scene.ppgs` (also writes scene.ppgs.props,
+ * the XML's integrator properties, which are picked up here).
  *
  * scene.ppgs is the flat binary scene written by ppg_host.scenes.save_scene() (header "PPGS", then the arrays of
  * include/ppg.h's ppg_scene).  --cbox builds scenes/cbox/cbox.xml procedurally like ppg_host.scenes.cbox_scene.
@@ -114,6 +116,20 @@ int main(int argc, char **argv) {
         else if (a == "--cbox" && i + 1 < argc) { if (sscanf(argv[++i], "%dx%d", &cw, &ch) != 2) { std::cerr << "--cbox WxH\n"; return 2; } }
         else if (a == "-h" || a == "--help") { std::cout << "usage: ppg_render [-D key=value]... [-o out.pfm] [-q] (scene.ppgs | --cbox WxH)\n"; return 0; }
         else scenePath = a;
+    }
+    // scene.ppgs.props (written next to the flat scene by `python -m ppg_host scene.xml --ppgs scene.ppgs`): the XML's
+    // integrator properties, one key=value per line; -D on the command line wins
+    if (!scenePath.empty()) {
+        std::ifstream pf(scenePath + ".props");
+        std::string line;
+        while (std::getline(pf, line)) {
+            size_t eq = line.find('=');
+            if (eq == std::string::npos) continue;
+            std::string k = line.substr(0, eq), v = line.substr(eq + 1);
+            if (v == "True") v = "true";
+            if (v == "False") v = "false";
+            if (!props.values.count(k)) props.values[k] = v;
+        }
     }
     SceneData scene;
     if (cw > 0) cboxScene(cw, ch, scene);

@@ -1,0 +1,546 @@
+"""Loader for the subset of Mitsuba 0.6 scene XML the reference's bundled scenes use:
+
+  integrator  guided_path (every property of GP:1014-1085 and integrator.cpp:192-218)
+  sensor      perspective (fov, fovAxis, nearClip, farClip, toWorld; focusDistance ignored: pinhole),
+              nested sampler (independent; sampleCount / seed do not steer guided_path, GP:1342-1374) and
+              film hdrfilm (width, height; rfilter box)
+  shapes      obj (filename, toWorld, faceNormals, flipNormals, flipTexCoords, collapse), rectangle (toWorld, flipNormals)
+  bsdfs       diffuse, twosided(diffuse), conductor(material none) — top level with id, nested, or <ref id>
+  emitters    area (nested in a shape)
+  values      <spectrum>, <rgb>, <srgb> (spectrum.py), <transform> of translate / rotate / scale / lookAt / matrix,
+              <default name value> and $name substitution (mitsuba -D, mitsuba.cpp:58-87)
+
+Anything else raises SceneError naming the plugin (Mitsuba would load it; this path cannot render it yet —
+SURVEY.md §8(f1)/(f2)).  With strict=False unsupported BSDFs become diffuse(0.5) and are listed in `warnings`.
+
+The OBJ reader follows shapes/obj.cpp:198-342 (fan triangulation of n-gons, negative indices, one mesh per `g` /
+`usemtl` run, vertices merged per mesh on identical (position, normal, uv), normals transformed by the inverse
+transpose) and TriMesh::computeNormals (trimesh.cpp:608-676: angle-weighted vertex normals when the file has none
+and faceNormals is off).  Arithmetic is float32 like the reference's SINGLE_PRECISION build.
+"""
+import math
+import os
+import re
+import xml.etree.ElementTree as ET
+
+import numpy as np
+
+from . import spectrum
+from .scenes import SceneDesc, perspective_camera_from_matrix
+
+f32 = np.float32
+GUIDED_PATH_PROPS = {  # name → type (GP:1014-1085, integrator.cpp:192-218)
+    "nee": str, "sampleCombination": str, "spatialFilter": str, "directionalFilter": str, "bsdfSamplingFractionLoss": str,
+    "budgetType": str, "sdTreeMaxMemory": int, "sTreeThreshold": int, "dTreeThreshold": float, "bsdfSamplingFraction": float,
+    "sppPerPass": int, "budget": float, "dumpSDTree": int, "rrDepth": int, "maxDepth": int, "strictNormals": int, "hideEmitters": int,
+}
+
+
+class SceneError(ValueError):
+    pass
+
+
+# ---------------------------------------------------------------------------------------------- transforms
+def _translate(x, y, z):
+    m = np.eye(4, dtype=f32)
+    m[:3, 3] = (x, y, z)
+    return m
+
+
+def _scale(x, y, z):
+    return np.diag(np.array([x, y, z, 1], f32))
+
+
+def _rotate(axis, angle_deg):  # Transform::rotate, transform.cpp:65-97
+    a = np.asarray(axis, f32)
+    a = a / f32(np.sqrt(np.dot(a, a)))
+    th = f32(angle_deg) * f32(math.pi / 180.0)
+    s, c = f32(np.sin(th)), f32(np.cos(th))
+    x, y, z = a
+    one = f32(1)
+    m = np.eye(4, dtype=f32)
+    m[0, :3] = (x * x + (one - x * x) * c, x * y * (one - c) - z * s, x * z * (one - c) + y * s)
+    m[1, :3] = (x * y * (one - c) + z * s, y * y + (one - y * y) * c, y * z * (one - c) - x * s)
+    m[2, :3] = (x * z * (one - c) - y * s, y * z * (one - c) + x * s, z * z + (one - z * z) * c)
+    return m
+
+
+def _look_at(origin, target, up):  # Transform::lookAt, transform.cpp:191-214
+    p, t, u = (np.asarray(v, f32) for v in (origin, target, up))
+    d = t - p
+    d = d / f32(np.sqrt(np.dot(d, d)))
+    left = np.cross(u, d).astype(f32)
+    left = left / f32(np.sqrt(np.dot(left, left)))
+    new_up = np.cross(d, left).astype(f32)
+    m = np.eye(4, dtype=f32)
+    m[:3, 0], m[:3, 1], m[:3, 2], m[:3, 3] = left, new_up, d, p
+    return m
+
+
+def _floats(text):
+    return [float(v) for v in text.replace(",", " ").split()]
+
+
+def _transform(elem, sub):
+    m = np.eye(4, dtype=f32)
+    for c in elem:
+        g = lambda k, d: float(sub(c.get(k, str(d))))  # noqa: E731
+        if c.tag == "translate":
+            t = _translate(g("x", 0), g("y", 0), g("z", 0))
+        elif c.tag == "scale":
+            t = _scale(*([g("value", 1)] * 3)) if c.get("value") is not None else _scale(g("x", 1), g("y", 1), g("z", 1))
+        elif c.tag == "rotate":
+            t = _rotate((g("x", 0), g("y", 0), g("z", 0)), g("angle", 0))
+        elif c.tag == "lookAt" or c.tag == "lookat":
+            o, tg = _floats(sub(c.get("origin"))), _floats(sub(c.get("target")))
+            up = _floats(sub(c.get("up"))) if c.get("up") else None
+            if up is None:  # scenehandler.cpp: any vector orthogonal to the viewing direction
+                d = np.asarray(tg) - np.asarray(o)
+                up = np.cross(d, (1, 0, 0) if abs(d[0]) < abs(d[1]) else (0, 1, 0))
+            t = _look_at(o, tg, up)
+        elif c.tag == "matrix":
+            v = _floats(sub(c.get("value")))
+            if len(v) != 16:
+                raise SceneError("<matrix> needs 16 values")
+            t = np.asarray(v, f32).reshape(4, 4)
+        else:
+            raise SceneError("unsupported transform element <%s>" % c.tag)
+        m = (t @ m).astype(f32)  # scenehandler.cpp: later elements are applied after earlier ones
+    return m
+
+
+def _xf_points(m, p):
+    q = p @ m[:3, :3].T + m[:3, 3]
+    w = p @ m[3, :3] + m[3, 3]
+    return np.where((w != 1)[:, None], q / w[:, None], q).astype(f32)
+
+
+def _xf_normals(m, n):
+    inv_t = np.linalg.inv(m.astype(np.float64))[:3, :3].T.astype(f32)  # Transform::operator()(Normal): inverse transpose
+    return (n @ inv_t.T).astype(f32)
+
+
+# ---------------------------------------------------------------------------------------------- OBJ
+def _fetch_lines(path):
+    with open(path, "r", errors="replace") as f:
+        pending = ""
+        for raw in f:
+            line = pending + raw.rstrip(" \t\r\n")
+            if line.endswith("\\"):  # obj.cpp:166-188: a trailing backslash continues the line
+                pending = line[:-1]
+                continue
+            pending = ""
+            yield line
+        if pending:
+            yield pending
+
+
+def _unit_angle(u, v):  # util.h:309-314
+    d = np.sum(u * v, 1)
+    return np.where(d < 0, f32(math.pi) - f32(2) * np.arcsin(f32(0.5) * np.linalg.norm(v + u, axis=1).astype(f32)),
+                    f32(2) * np.arcsin(f32(0.5) * np.linalg.norm(v - u, axis=1).astype(f32))).astype(f32)
+
+
+def compute_normals(pos, tris, flip=False):
+    """TriMesh::computeNormals, smooth branch (trimesh.cpp:631-671): angle-weighted face normals, triangle-major."""
+    n = np.zeros_like(pos, dtype=f32)
+    p = pos[tris]  # (T, 3, 3)
+    a, b = p[:, 1] - p[:, 0], p[:, 2] - p[:, 0]
+    fn = np.cross(a, b).astype(f32)
+    ln = np.sqrt(np.sum(fn * fn, 1)).astype(f32)
+    ok = ln != 0
+    fn[ok] = fn[ok] / ln[ok, None]
+    idx, contrib = [], []
+    for i in range(3):
+        v0, v1, v2 = p[:, i], p[:, (i + 1) % 3], p[:, (i + 2) % 3]
+        sa, sb = (v1 - v0).astype(f32), (v2 - v0).astype(f32)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            ua = sa / np.sqrt(np.sum(sa * sa, 1)).astype(f32)[:, None]
+            ub = sb / np.sqrt(np.sum(sb * sb, 1)).astype(f32)[:, None]
+            ang = _unit_angle(ua, ub)
+        idx.append(tris[:, i]); contrib.append(fn * ang[:, None])
+    order = np.stack(idx, 1).reshape(-1)            # triangle-major: (t0 c0, t0 c1, t0 c2, t1 c0, ...)
+    vals = np.stack(contrib, 1).reshape(-1, 3)
+    keep = np.repeat(ok, 3)                          # degenerate triangles contribute nothing ("break" at i == 0)
+    np.add.at(n, order[keep], vals[keep])
+    length = np.sqrt(np.sum(n * n, 1)).astype(f32)
+    if flip:
+        length = -length
+    bad = length == 0
+    with np.errstate(invalid="ignore", divide="ignore"):
+        n = (n / length[:, None]).astype(f32)
+    n[bad] = (1, 0, 0)
+    return n
+
+
+def load_obj(path, to_world=None, face_normals=False, flip_normals=False, flip_tex_coords=True, collapse=False):
+    """→ list of meshes dict(name, material, positions (V,3), normals (V,3) or None, indices (T,3)) in world space."""
+    to_world = np.eye(4, dtype=f32) if to_world is None else to_world
+    V, N, UV = [], [], []
+    tris, meshes = [], []
+    material = ""
+    name = os.path.splitext(os.path.basename(path))[0]
+
+    def corner(tok):
+        parts = tok.split("/")
+        p = int(parts[0])
+        uv = int(parts[1]) if len(parts) >= 2 and parts[1] else 0
+        n = int(parts[2]) if len(parts) == 3 and parts[2] else 0
+        if len(parts) > 3:
+            raise SceneError("%s: invalid OBJ face format %r" % (path, tok))
+        return p, uv, n
+
+    def flush(mesh_name):
+        nonlocal tris
+        if not tris:
+            return
+        pos_w = _xf_points(to_world, np.asarray(V, f32).reshape(-1, 3)) if V else np.zeros((0, 3), f32)
+        nrm_w = None
+        if N:
+            nrm_w = _xf_normals(to_world, np.asarray(N, f32).reshape(-1, 3))
+            ln = np.sqrt(np.sum(nrm_w * nrm_w, 1)).astype(f32)
+            nz = ln != 0
+            nrm_w[nz] = nrm_w[nz] / ln[nz, None]
+        uvs = np.asarray(UV, f32).reshape(-1, 2) if UV else np.zeros((0, 2), f32)
+        vmap, vp, vn, idx = {}, [], [], []
+        has_normals = False
+        for t in tris:
+            tri = []
+            for (p, uv, n) in t:
+                if p < 0: p += len(V) + 1
+                if n < 0: n += len(N) + 1
+                if uv < 0: uv += len(UV) + 1
+                if p <= 0 or p > len(V):
+                    raise SceneError("%s: vertex index %d out of bounds (max %d)" % (path, p, len(V)))
+                if n > len(N) or uv > len(UV):
+                    raise SceneError("%s: normal / uv index out of bounds" % path)
+                pn = tuple(nrm_w[n - 1]) if n else (0.0, 0.0, 0.0)
+                has_normals |= bool(n)
+                puv = tuple(uvs[uv - 1]) if uv else (0.0, 0.0)
+                key = (tuple(pos_w[p - 1]), pn, puv)
+                k = vmap.get(key)
+                if k is None:
+                    k = vmap[key] = len(vp)
+                    vp.append(key[0]); vn.append(pn)
+                tri.append(k)
+            idx.append(tri)
+        pos = np.asarray(vp, f32).reshape(-1, 3)
+        idx = np.asarray(idx, np.uint32).reshape(-1, 3)
+        normals = np.asarray(vn, f32).reshape(-1, 3) if has_normals else None
+        # TriMesh::computeNormals (trimesh.cpp:608-676)
+        if face_normals:
+            normals = None
+            if flip_normals:
+                idx = idx[:, [1, 0, 2]]
+        elif normals is not None:
+            if flip_normals:
+                normals = -normals
+        else:
+            normals = compute_normals(pos, idx, flip_normals)
+        meshes.append(dict(name=mesh_name, material=material, positions=pos, normals=normals, indices=idx))
+        tris = []
+
+    for line in _fetch_lines(path):
+        tok = line.split()
+        if not tok:
+            continue
+        if tok[0] == "v":
+            V.append([float(v) for v in tok[1:4]])
+        elif tok[0] == "vn":
+            N.append([float(v) for v in tok[1:4]])
+        elif tok[0] == "vt":
+            u, v = float(tok[1]), float(tok[2]) if len(tok) > 2 else 0.0
+            UV.append([u, 1 - v if flip_tex_coords else v])
+        elif tok[0] == "g" and not collapse:
+            flush(name)
+            name = line[1:].strip()
+        elif tok[0] == "usemtl":
+            if not collapse:
+                flush(name)
+            material = line[6:].strip()
+        elif tok[0] == "f":
+            c = [corner(t) for t in tok[1:]]
+            if len(c) < 3:
+                raise SceneError("%s: face with fewer than 3 vertices" % path)
+            for k in range(1, len(c) - 1):  # n-gons as a fan (obj.cpp:322-334)
+                tris.append((c[0], c[k], c[k + 1]))
+    flush(name)
+    return meshes
+
+
+def rectangle_mesh(to_world, flip_normals=False):
+    """shapes/rectangle.cpp:170-203 (createTriMesh)."""
+    m = to_world
+    if flip_normals:
+        m = (m @ _scale(1, 1, -1)).astype(f32)  # rectangle.cpp:82-83
+    pos = _xf_points(m, np.array([[-1, -1, 0], [1, -1, 0], [1, 1, 0], [-1, 1, 0]], f32))
+    n = _xf_normals(m, np.array([[0, 0, 1]], f32))[0]
+    n = (n / f32(np.sqrt(np.dot(n, n)))).astype(f32)
+    return dict(name="rectangle", material="", positions=pos, normals=np.repeat(n[None], 4, 0), indices=np.array([[0, 1, 2], [2, 3, 0]], np.uint32))
+
+
+# ---------------------------------------------------------------------------------------------- scene
+def _props(elem, sub):
+    out = {}
+    for c in elem:
+        n = c.get("name")
+        if c.tag == "boolean":
+            out[n] = sub(c.get("value")).strip().lower() == "true"
+        elif c.tag == "integer":
+            out[n] = int(sub(c.get("value")))
+        elif c.tag == "float":
+            out[n] = float(sub(c.get("value")))
+        elif c.tag == "string":
+            out[n] = sub(c.get("value"))
+    return out
+
+
+def load_scene(path, defines=None, strict=True, width=None, height=None):
+    """Parse `path` → (SceneDesc, integrator properties for ppg_create, info dict).
+
+    defines: {"name": "value"} like `mitsuba -D name=value`; width/height override the film size."""
+    root = ET.parse(path).getroot()
+    if root.tag != "scene":
+        raise SceneError("%s: root element is <%s>, expected <scene>" % (path, root.tag))
+    base = os.path.dirname(os.path.abspath(path))
+    params = dict(defines or {})
+    for d in root.iter("default"):
+        params.setdefault(d.get("name"), d.get("value"))
+
+    def sub(text):
+        if text is None or "$" not in text:
+            return text
+        def rep(mo):
+            k = mo.group(1)
+            if k not in params:
+                raise SceneError("undefined parameter $%s (pass it with -D %s=...)" % (k, k))
+            return str(params[k])
+        return re.sub(r"\$(\w+)", rep, text)
+
+    warnings = []
+    # ---- integrator
+    integ = root.find("integrator")
+    if integ is None:
+        raise SceneError("no <integrator>")
+    if integ.get("type") != "guided_path":
+        raise SceneError("integrator type %r is not supported: this path implements 'guided_path' only" % integ.get("type"))
+    props = {}
+    for k, v in _props(integ, sub).items():
+        if k not in GUIDED_PATH_PROPS:
+            warnings.append("integrator property %r is not used by guided_path" % k)  # Mitsuba warns about unqueried properties, too
+            continue
+        props[k] = GUIDED_PATH_PROPS[k](v)
+    # ---- sensor / film
+    sensor = root.find("sensor")
+    if sensor is None:
+        raise SceneError("no <sensor>")
+    if sensor.get("type") != "perspective":
+        raise SceneError("sensor type %r is not supported (perspective only)" % sensor.get("type"))
+    sp = _props(sensor, sub)
+    film = sensor.find("film")
+    fp = _props(film, sub) if film is not None else {}
+    if film is not None and film.get("type") not in ("hdrfilm", "ldrfilm", None):
+        raise SceneError("film type %r is not supported" % film.get("type"))
+    rf = film.find("rfilter") if film is not None else None
+    if rf is not None and rf.get("type") != "box":
+        raise SceneError("rfilter type %r is not supported (box only; hdrfilm's default 'gaussian' neither)" % rf.get("type"))
+    if rf is None:
+        warnings.append("no <rfilter>: Mitsuba would default to gaussian; the box filter is used")
+    W = int(width or fp.get("width", 768)); H = int(height or fp.get("height", 576))
+    if "fov" not in sp:
+        raise SceneError("perspective sensor without 'fov' (focalLength is not supported)")
+    tw = sensor.find("transform")
+    c2w = _transform(tw, sub) if tw is not None else np.eye(4, dtype=f32)
+    camera = perspective_camera_from_matrix(c2w, sp["fov"], str(sp.get("fovAxis", "x")).lower(), sp.get("nearClip", 1e-2), sp.get("farClip", 1e4), W, H)
+    sampler = sensor.find("sampler")
+    info = dict(width=W, height=H, sample_count=_props(sampler, sub).get("sampleCount") if sampler is not None else None)
+
+    # ---- bsdfs
+    materials, mat_index, by_id = [], {}, {}
+
+    def colour(elem, name, default):
+        for c in elem:
+            if c.get("name") == name:
+                if c.tag in ("rgb", "srgb", "spectrum"):
+                    if c.get("filename"):
+                        raise SceneError("<spectrum filename=...> is not supported")
+                    return spectrum.parse(c.tag, sub(c.get("value")))
+                if c.tag == "texture" or c.tag == "ref":
+                    raise SceneError("textured %r is not supported (SURVEY.md §8 f1)" % name)
+        return np.full(3, default, f32)
+
+    def make_bsdf(elem):
+        t = elem.get("type")
+        if t == "diffuse":
+            return dict(type=0, reflectance=tuple(float(v) for v in colour(elem, "reflectance", 0.5)))
+        if t == "twosided":
+            inner = [c for c in elem if c.tag == "bsdf"]
+            if len(inner) == 1 and inner[0].get("type") == "diffuse":
+                return dict(type=1, reflectance=tuple(float(v) for v in colour(inner[0], "reflectance", 0.5)))
+            t = "twosided(%s)" % ",".join(c.get("type", "?") for c in inner)
+        elif t == "conductor":
+            p = _props(elem, sub)
+            if p.get("material", "Cu") == "none":
+                return dict(type=2, reflectance=tuple(float(v) for v in colour(elem, "specularReflectance", 1.0)))
+            t = "conductor(material=%s)" % p.get("material", "Cu")
+        if strict:
+            raise SceneError("bsdf type %r is not supported yet (diffuse, twosided(diffuse), conductor(material=none); SURVEY.md §8 f1)" % t)
+        warnings.append("bsdf %r replaced by diffuse(0.5)" % t)
+        return dict(type=0, reflectance=(0.5, 0.5, 0.5))
+
+    def intern(m):
+        key = (m["type"],) + tuple(m["reflectance"])
+        if key not in mat_index:
+            mat_index[key] = len(materials)
+            materials.append(m)
+        return mat_index[key]
+
+    for b in root.findall("bsdf"):
+        if b.get("id"):
+            by_id[b.get("id")] = intern(make_bsdf(b))
+    for tex in root.findall("texture"):
+        warnings.append("top-level texture %r ignored" % tex.get("id"))
+    for em in root.findall("emitter"):
+        raise SceneError("emitter type %r is not supported (area emitters on shapes only; SURVEY.md §8 f2)" % em.get("type"))
+
+    # ---- shapes
+    collected, emitters = [], []
+    default_mat = None
+    for sh in root.findall("shape"):
+        t = sh.get("type")
+        sprops = _props(sh, sub)
+        tw = sh.find("transform")
+        m = _transform(tw, sub) if tw is not None else np.eye(4, dtype=f32)
+        if t == "obj":
+            fn = sprops.get("filename")
+            if not fn:
+                raise SceneError("obj shape without filename")
+            if "maxSmoothAngle" in sprops or "shapeIndex" in sprops:
+                raise SceneError("obj: maxSmoothAngle / shapeIndex are not supported")
+            full = fn if os.path.isabs(fn) else os.path.join(base, fn)
+            if not os.path.exists(full):
+                raise SceneError("Wavefront OBJ file '%s' not found!" % full)  # obj.cpp:230
+            meshes = load_obj(full, m, bool(sprops.get("faceNormals", False)), bool(sprops.get("flipNormals", False)),
+                              bool(sprops.get("flipTexCoords", True)), bool(sprops.get("collapse", False)))
+        elif t == "rectangle":
+            meshes = [rectangle_mesh(m, bool(sprops.get("flipNormals", False)))]
+        else:
+            raise SceneError("shape type %r is not supported (obj, rectangle)" % t)
+        # material: nested <bsdf> or <ref id>; Mitsuba's default is diffuse(0.5)
+        mat = None
+        for c in sh:
+            if c.tag == "bsdf":
+                mat = intern(make_bsdf(c))
+            elif c.tag == "ref":
+                rid = c.get("id")
+                if rid not in by_id:
+                    raise SceneError("<ref id=%r>: no such bsdf" % rid)
+                mat = by_id[rid]
+        if mat is None:
+            if default_mat is None:
+                default_mat = intern(dict(type=0, reflectance=(0.5, 0.5, 0.5)))
+            mat = default_mat
+        em = -1
+        e = sh.find("emitter")
+        if e is not None:
+            if e.get("type") != "area":
+                raise SceneError("emitter type %r on a shape is not supported (area only)" % e.get("type"))
+            if len(meshes) > 1:
+                raise SceneError("Cannot attach an emitter to an OBJ file containing multiple objects!")  # obj.cpp:757-759
+            em = len(emitters)
+            emitters.append(dict(radiance=tuple(float(v) for v in colour(e, "radiance", 1.0))))
+        for mesh in meshes:
+            collected.append((mesh, mat, em))
+    if not collected:
+        raise SceneError("scene without shapes")
+    # one vertex-normal array for the whole scene: a faceNormals mesh living next to smooth ones gets its vertices
+    # un-shared and its face normals written out (same shading frame as "no normals": skdtree.h:388-401)
+    any_normals = any(m["normals"] is not None for m, _, _ in collected)
+    pos, nrm, idx, tmat, tem = [], [], [], [], []
+    nv = 0
+    for mesh, mat, em in collected:
+        p, i, n = mesh["positions"], mesh["indices"], mesh["normals"]
+        if any_normals and n is None:
+            p = p[i.reshape(-1)]
+            a, b = p[1::3] - p[0::3], p[2::3] - p[0::3]
+            fnrm = np.cross(a, b).astype(f32)
+            ln = np.sqrt(np.sum(fnrm * fnrm, 1)).astype(f32)
+            fnrm[ln != 0] = fnrm[ln != 0] / ln[ln != 0, None]
+            n = np.repeat(fnrm, 3, 0)
+            i = np.arange(p.shape[0], dtype=np.uint32).reshape(-1, 3)
+        T = i.shape[0]
+        pos.append(p); idx.append(i + np.uint32(nv)); nrm.append(n)
+        nv += p.shape[0]
+        tmat.append(np.full(T, mat, np.uint32)); tem.append(np.full(T, em, np.int32))
+    normals = np.concatenate(nrm).astype(f32) if any_normals else None
+    desc = SceneDesc(np.concatenate(pos).astype(f32), np.concatenate(idx).astype(np.uint32), np.concatenate(tmat), np.concatenate(tem),
+                     materials, emitters, camera, normals)
+    info["warnings"] = warnings
+    return desc, props, info
+
+
+# ---------------------------------------------------------------------------------------------- writer
+def save_scene_xml(desc, props, directory, name="scene"):
+    """Write `desc` as <directory>/<name>.xml + meshes/*.obj in the subset above (one OBJ per material / emitter group),
+    so that a procedural scene can be rendered by the reference itself — or read back by load_scene().  Returns the XML path."""
+    os.makedirs(os.path.join(directory, "meshes"), exist_ok=True)
+    cam = desc.camera
+    c = lambda v: ", ".join(repr(float(x)) for x in v)  # noqa: E731
+    out = ['<?xml version="1.0" encoding="utf-8"?>', '<scene version="0.5.0">', '\t<integrator type="guided_path">']
+    for k, v in props.items():
+        if k not in GUIDED_PATH_PROPS:
+            continue
+        t = GUIDED_PATH_PROPS[k]
+        if k in ("strictNormals", "hideEmitters", "dumpSDTree"):
+            out.append('\t\t<boolean name="%s" value="%s"/>' % (k, "true" if v else "false"))
+        elif t is int:
+            out.append('\t\t<integer name="%s" value="%d"/>' % (k, int(v)))
+        elif t is float:
+            out.append('\t\t<float name="%s" value="%r"/>' % (k, float(v)))
+        else:
+            out.append('\t\t<string name="%s" value="%s"/>' % (k, v))
+    out += ['\t</integrator>', '\t<sensor type="perspective">',
+            '\t\t<string name="fovAxis" value="%s"/>' % cam.get("fov_axis", "x"), '\t\t<float name="fov" value="%r"/>' % float(cam["fov"]),
+            '\t\t<float name="nearClip" value="%r"/>' % float(cam["near_clip"]), '\t\t<float name="farClip" value="%r"/>' % float(cam["far_clip"]),
+            '\t\t<transform name="toWorld">', '\t\t\t<matrix value="%s"/>' % " ".join(repr(float(x)) for x in np.asarray(cam["camera_to_world"]).reshape(-1)),
+            '\t\t</transform>', '\t\t<sampler type="independent"/>', '\t\t<film type="hdrfilm">',
+            '\t\t\t<integer name="width" value="%d"/>' % cam["width"], '\t\t\t<integer name="height" value="%d"/>' % cam["height"],
+            '\t\t\t<boolean name="banner" value="false"/>', '\t\t\t<rfilter type="box"/>', '\t\t</film>', '\t</sensor>']
+    for i, m in enumerate(desc.materials):
+        t = int(m.get("type", 0))
+        rgb = '<rgb name="%s" value="%s"/>' % ("specularReflectance" if t == 2 else "reflectance", c(m["reflectance"]))
+        if t == 0:
+            out.append('\t<bsdf type="diffuse" id="mat%d">%s</bsdf>' % (i, rgb))
+        elif t == 1:
+            out.append('\t<bsdf type="twosided" id="mat%d"><bsdf type="diffuse">%s</bsdf></bsdf>' % (i, rgb))
+        else:
+            out.append('\t<bsdf type="conductor" id="mat%d"><string name="material" value="none"/>%s</bsdf>' % (i, rgb))
+    tm, te = np.asarray(desc.tri_material), np.asarray(desc.tri_emitter)
+    idx, pos = np.asarray(desc.indices), np.asarray(desc.positions)
+    groups = sorted({(int(a), int(b)) for a, b in zip(tm, te)}, key=lambda g: (g[1] < 0, g[1], g[0]))  # emitters first, in emitter order
+    for gi, (mat, em) in enumerate(groups):
+        sel = np.nonzero((tm == mat) & (te == em))[0]
+        fn = "meshes/%s_%03d.obj" % (name, gi)
+        with open(os.path.join(directory, fn), "w") as f:
+            used = np.unique(idx[sel])
+            remap = {int(v): k + 1 for k, v in enumerate(used)}
+            for v in used:
+                f.write("v %r %r %r\n" % tuple(float(x) for x in pos[v]))
+            if desc.normals is not None:
+                for v in used:
+                    f.write("vn %r %r %r\n" % tuple(float(x) for x in np.asarray(desc.normals)[v]))
+            for t in sel:
+                f.write("f " + " ".join(("%d//%d" % (remap[int(v)], remap[int(v)])) if desc.normals is not None else str(remap[int(v)]) for v in idx[t]) + "\n")
+        out.append('\t<shape type="obj">')
+        out.append('\t\t<string name="filename" value="%s"/>' % fn)
+        if desc.normals is None:
+            out.append('\t\t<boolean name="faceNormals" value="true"/>')
+        out.append('\t\t<ref id="mat%d"/>' % mat)
+        if em >= 0:
+            out.append('\t\t<emitter type="area"><rgb name="radiance" value="%s"/></emitter>' % c(desc.emitters[em]["radiance"]))
+        out.append('\t</shape>')
+    out.append('</scene>')
+    path = os.path.join(directory, name + ".xml")
+    with open(path, "w") as f:
+        f.write("\n".join(out) + "\n")
+    return path

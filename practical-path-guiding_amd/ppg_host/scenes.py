@@ -51,10 +51,9 @@ def save_scene(desc, path):
         f.write(struct.pack("<2f2i", c["near_clip"], c["far_clip"], c["width"], c["height"]))
 
 
-def perspective_camera(origin, target, up, fov_deg, fov_axis, near, far, width, height):
-    """Matrices of sensors/perspective.cpp:150-164 (m_sampleToCamera) and Transform::lookAt
-    (transform.cpp:191-214); fov-axis handling of sensor.cpp:239-264.  Computed in double, stored as
-    float32 (these are inputs to both the HIP path and the oracle, not part of either)."""
+def _sample_to_camera(fov_deg, fov_axis, near, far, width, height):
+    """m_sampleToCamera of sensors/perspective.cpp:150-164; fov-axis handling of sensor.cpp:239-264.  Computed in
+    double, stored as float32 (an input to both the HIP path and the oracle, not part of either)."""
     aspect = float(width) / float(height)
     axis = fov_axis
     if axis == "smaller":
@@ -65,6 +64,10 @@ def perspective_camera(origin, target, up, fov_deg, fov_axis, near, far, width, 
         xfov = float(fov_deg)
     elif axis == "y":  # setYFov → xfov = 2 atan(tan(yfov / 2) * aspect)
         xfov = math.degrees(2.0 * math.atan(math.tan(0.5 * math.radians(fov_deg)) * aspect))
+    elif axis == "diagonal":  # setDiagonalFov, sensor.cpp:296-301
+        diagonal = 2.0 * math.tan(0.5 * math.radians(fov_deg))
+        w = diagonal / math.sqrt(1.0 + 1.0 / (aspect * aspect))
+        xfov = math.degrees(2.0 * math.atan(w * 0.5))
     else:
         raise ValueError("fovAxis %r not supported" % fov_axis)
 
@@ -80,8 +83,18 @@ def perspective_camera(origin, target, up, fov_deg, fov_axis, near, far, width, 
     cot = 1.0 / math.tan(math.radians(xfov / 2.0))
     persp = np.array([[cot, 0, 0, 0], [0, cot, 0, 0], [0, 0, far * recip, -near * far * recip], [0, 0, 1, 0]], np.float64)
     cam_to_sample = scale([-0.5, -0.5 * aspect, 1.0]) @ translate([-1.0, -1.0 / aspect, 0.0]) @ persp
-    sample_to_camera = np.linalg.inv(cam_to_sample).astype(np.float32)
+    return np.linalg.inv(cam_to_sample).astype(np.float32)
 
+
+def perspective_camera_from_matrix(camera_to_world, fov_deg, fov_axis, near, far, width, height):
+    """Camera record from a ready toWorld matrix (what the XML loader has)."""
+    return dict(sample_to_camera=_sample_to_camera(fov_deg, fov_axis, near, far, width, height),
+                camera_to_world=np.asarray(camera_to_world, np.float32).reshape(4, 4), near_clip=float(near), far_clip=float(far),
+                width=int(width), height=int(height), fov=float(fov_deg), fov_axis=str(fov_axis))
+
+
+def perspective_camera(origin, target, up, fov_deg, fov_axis, near, far, width, height):
+    """Transform::lookAt (transform.cpp:191-214) + the projection above."""
     p, t, u = (np.asarray(v, np.float64) for v in (origin, target, up))
     d = (t - p) / np.linalg.norm(t - p)
     left = np.cross(u, d)
@@ -89,8 +102,7 @@ def perspective_camera(origin, target, up, fov_deg, fov_axis, near, far, width, 
     new_up = np.cross(d, left)
     c2w = np.eye(4)
     c2w[:3, 0], c2w[:3, 1], c2w[:3, 2], c2w[:3, 3] = left, new_up, d, p
-    return dict(sample_to_camera=sample_to_camera, camera_to_world=c2w.astype(np.float32), near_clip=float(near),
-                far_clip=float(far), width=int(width), height=int(height))
+    return perspective_camera_from_matrix(c2w.astype(np.float32), fov_deg, fov_axis, near, far, width, height)
 
 
 # linear RGB of the spectra in scenes/cbox/cbox.xml (tools/derive_cbox_rgb.py)

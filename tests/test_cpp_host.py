@@ -84,3 +84,29 @@ def test_cpp_driver_equals_python_path(ppg_render, tmp_path):
     assert r.returncode == 0, r.stderr
     a, b = read_pfm(out2), ppg_host.GuidedPathTracer(engine=ppg_host.Engine.hip(**dict(CBOX_PROPS, budget=60, seed=5))).render(scene)
     assert abs(a.mean() / b.mean() - 1) < 0.05
+
+
+@pytest.mark.gpu
+def test_scene_xml_through_both_drivers(ppg_render, tmp_path):
+    """Mitsuba scene XML → (a) `python -m ppg_host` → EXR with the render log attached, (b) --ppgs + .props → the C++
+    driver; both equal a direct render of the loaded scene."""
+    import ppg_host
+    from ppg_host.__main__ import main
+    from ppg_host.imageio import read_exr
+    props = dict(CBOX_PROPS, budget=28.0, nee="kickstart", sTreeThreshold=3000)
+    props["strictNormals"] = 1
+    xml = ppg_host.save_scene_xml(ppg_host.cbox_scene(80, 60), props, str(tmp_path), name="box")
+    desc, loaded, _ = ppg_host.load_scene(xml)
+    assert loaded == {k: (float(v) if k == "budget" else v) for k, v in props.items()}
+    want = ppg_host.GuidedPathTracer(**loaded).render(desc)
+    exr = str(tmp_path / "box.exr")
+    assert main([xml, "-o", exr, "-q"]) == 0
+    img, attrs = read_exr(exr)
+    assert np.array_equal(img, want)
+    assert attrs["log"].count("Total passes") == 3 and "Distribution statistics" in attrs["log"] and "Msamples/s" in attrs["log"]
+    flat = str(tmp_path / "box.ppgs")
+    assert main([xml, "--ppgs", flat, "-q"]) == 0
+    out = str(tmp_path / "box.pfm")
+    r = subprocess.run([ppg_render, "-q", "-o", out, flat], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert np.array_equal(read_pfm(out), want)
