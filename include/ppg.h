@@ -75,16 +75,33 @@ void ppg_config_default(ppg_config *cfg);
  * ---------------------------------------------------------------------------------------------- */
 enum {
     PPG_BSDF_DIFFUSE = 0,          /* mitsuba/src/bsdfs/diffuse.cpp:110-150 (one-sided Lambertian) */
-    PPG_BSDF_TWOSIDED_DIFFUSE = 1, /* twosided.cpp:100-180 around one diffuse BRDF (same on both sides) */
-    PPG_BSDF_MIRROR = 2            /* conductor.cpp:220-290 with material "none" (Fresnel = 1): ideal specular reflection,
-                                      reflectance = specularReflectance; a delta BSDF — never guided (GP:1942-1944, 1654) */
+    PPG_BSDF_TWOSIDED_DIFFUSE = 1, /* = PPG_BSDF_DIFFUSE with PPG_MAT_TWOSIDED (kept for the round-1 callers) */
+    PPG_BSDF_MIRROR = 2,           /* conductor.cpp:220-290 with material "none" (eta = 0, k = 1: Fresnel = 1): ideal specular
+                                      reflection, reflectance = specularReflectance; a delta BSDF — never guided (GP:1942-1944, 1654) */
+    PPG_BSDF_CONDUCTOR = 3,        /* conductor.cpp:220-290: smooth conductor, fresnelConductorExact(eta, k) (util.cpp:739-761) */
+    PPG_BSDF_ROUGHCONDUCTOR = 4,   /* roughconductor.cpp:247-415 with the isotropic GGX distribution and visible-normal
+                                      sampling (microfacet.h:191-276, 425-540, 645-690): glossy ⇒ smooth ⇒ guided */
+    PPG_BSDF_PLASTIC = 5,          /* plastic.cpp:247-455: delta specular coat over a diffuse base — the mixed delta/smooth
+                                      case of sampleMat (GP:1672-1676) */
+    PPG_BSDF_DIELECTRIC = 6        /* dielectric.cpp:229-400: smooth glass, delta reflection + delta refraction, tracks eta */
+};
+enum {
+    PPG_MAT_TWOSIDED = 1,          /* wrap the (one-sided) BRDF in twosided.cpp:100-180, same BRDF on both sides */
+    PPG_MAT_NONLINEAR = 2          /* plastic: nonlinear = true (plastic.cpp:164) */
 };
 
 typedef struct ppg_material {
     int32_t type;         /* PPG_BSDF_* */
-    float reflectance[3]; /* linear RGB (SPECTRUM_SAMPLES=3 build of the reference) */
-    float param[4];       /* reserved for the "next" BSDF rows */
-} ppg_material;
+    float reflectance[3]; /* linear RGB (SPECTRUM_SAMPLES=3 build of the reference): diffuse `reflectance`; plastic
+                             `diffuseReflectance`; conductors and dielectric `specularReflectance` */
+    float specular[3];    /* plastic `specularReflectance`; dielectric `specularTransmittance` */
+    float alpha;          /* roughconductor: GGX roughness `alpha` (clamped to >= 1e-4 like microfacet.h:135) */
+    float eta[3];         /* conductors: eta per channel (already divided by extEta, roughconductor.cpp:185-186);
+                             plastic / dielectric: eta[0] = intIOR / extIOR */
+    float k[3];           /* conductors: k per channel */
+    int32_t flags;        /* PPG_MAT_* */
+    int32_t _reserved;
+} ppg_material;           /* 64 bytes */
 
 typedef struct ppg_emitter {
     float radiance[3]; /* area light, mitsuba/src/emitters/area.cpp:104-109 */

@@ -83,6 +83,11 @@ PPG_HD float ppg_atan2(float y, float x) {
 }
 
 /* exp(x) for |x| <= 80, Cephes expf scheme. */
+/* acos / tan for the visible-normal sampling of microfacet.h:425-470, 645-690 — via the routines above so that CPU and
+   GPU agree to the bit: acos(x) = atan2(sqrt((1 - x)(1 + x)), x), tan(x) = sin / cos */
+PPG_HD float ppg_acos(float x) { return ppg_atan2(__builtin_sqrtf(ppg_max(0.0f, (1.0f - x) * (1.0f + x))), x); }
+PPG_HD float ppg_tan(float x) { float s, c; ppg_sincos(x, &s, &c); return s / c; }
+
 PPG_HD float ppg_exp(float x) {
     if (x > 80.0f) x = 80.0f;
     if (x < -80.0f) x = -80.0f;
@@ -126,5 +131,27 @@ PPG_HD int64_t ppg_to_sfixed(float x) {
     return (x < 0.0f) ? -r : r;
 }
 PPG_HD float ppg_from_sfixed(int64_t a) { return (float)a * 9.5367431640625e-7f; /* 2^-20 */ }
+
+/* Scene-setup constant of the plastic BSDF: fresnelDiffuseReflectance(eta, fast = false) (util.cpp:797-861), the
+   hemispherical average ∫0^1 F(sqrt(xi), eta) dxi of the unpolarised dielectric Fresnel reflectance
+   (fresnelDielectricExt, util.cpp:651-681).  The reference integrates adaptively (Gauss-Lobatto, 1e-5); here composite
+   Simpson with 4096 intervals in double — plain IEEE operations, so the oracle and the HIP library's host code obtain the
+   same float.  Host only. */
+inline double ppg_fresnel_dielectric_d(double cosThetaI, double eta) {
+    if (eta == 1.0) return 0.0;
+    double scale = (cosThetaI > 0) ? 1.0 / eta : eta;
+    double cosThetaTSqr = 1.0 - (1.0 - cosThetaI * cosThetaI) * (scale * scale);
+    if (cosThetaTSqr <= 0.0) return 1.0;
+    double ci = cosThetaI < 0 ? -cosThetaI : cosThetaI, ct = __builtin_sqrt(cosThetaTSqr);
+    double Rs = (ci - eta * ct) / (ci + eta * ct), Rp = (eta * ci - ct) / (eta * ci + ct);
+    return 0.5 * (Rs * Rs + Rp * Rp);
+}
+inline float ppg_fresnel_diffuse_reflectance(float eta) {
+    const int n = 4096;
+    const double h = 1.0 / n;
+    double acc = ppg_fresnel_dielectric_d(0.0, (double)eta) + ppg_fresnel_dielectric_d(1.0, (double)eta);
+    for (int i = 1; i < n; ++i) acc += ((i & 1) ? 4.0 : 2.0) * ppg_fresnel_dielectric_d(__builtin_sqrt(i * h), (double)eta);
+    return (float)(acc * h / 3.0);
+}
 
 #endif /* PPG_DETMATH_H */

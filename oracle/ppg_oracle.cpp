@@ -794,6 +794,33 @@ private:
     AABB m_aabb;
 };
 
+// BSDFSamplingRecord subset
+struct BRec {
+    Vec wi, wo;
+    Float eta = 1.0f;
+    bool sampledDelta = false;
+};
+
+// A BSDF instance: the ABI record plus what the plugin's configure() precomputes
+struct Material : ppg_material {
+    Float fdrInt = 0, specularSamplingWeight = 0, invEta2 = 0;  // plastic.cpp:191-204
+    Spectrum R() const { return Spectrum(reflectance[0], reflectance[1], reflectance[2]); }
+    Spectrum S() const { return Spectrum(specular[0], specular[1], specular[2]); }
+    Spectrum Eta() const { return Spectrum(eta[0], eta[1], eta[2]); }
+    Spectrum K() const { return Spectrum(k[0], k[1], k[2]); }
+    void configure() {
+        if (type == PPG_BSDF_TWOSIDED_DIFFUSE) { type = PPG_BSDF_DIFFUSE; flags |= PPG_MAT_TWOSIDED; }
+        if (type == PPG_BSDF_MIRROR) { for (int i = 0; i < 3; ++i) { eta[i] = 0.0f; k[i] = 1.0f; } }  // material "none", conductor.cpp:171-173
+        if (type == PPG_BSDF_ROUGHCONDUCTOR) alpha = ppg_max(alpha, 1e-4f);  // microfacet.h:135
+        if (type == PPG_BSDF_PLASTIC) {
+            fdrInt = ppg_fresnel_diffuse_reflectance(1 / eta[0]);
+            Float dAvg = luminance(R()), sAvg = luminance(S());
+            specularSamplingWeight = sAvg / (dAvg + sAvg);
+            invEta2 = 1 / (eta[0] * eta[0]);
+        }
+    }
+};
+
 // ------------------------------------------------------------------------------------------------
 // Scene: triangles + the callees of Li ("direct callees")
 // ------------------------------------------------------------------------------------------------
@@ -858,7 +885,7 @@ struct Scene {
     bool hasNormals = false;
     std::vector<uint32_t> idx, triMat;
     std::vector<int32_t> triEmitter;
-    std::vector<ppg_material> materials;
+    std::vector<Material> materials;
     std::vector<ppg_emitter> emitters;
     ppg_camera cam;
     AABB aabb;  // what Scene::getAABB() returns: the kd-tree's enlarged box (gkdtree.h:1213-1220)
@@ -1150,87 +1177,309 @@ inline Vec squareToCosineHemisphere(const Point2 &sample) {
 }
 inline Float squareToCosineHemispherePdf(const Vec &d) { return PPG_INV_PI_F * d.z; }  // warp.h
 
-// BSDFSamplingRecord subset
-struct BRec {
-    Vec wi, wo;
-    Float eta = 1.0f;
-    bool sampledDelta = false;
-};
+// util.cpp:651-681
+inline Float fresnelDielectricExt(Float cosThetaI_, Float &cosThetaT_, Float eta) {
+    if (eta == 1) { cosThetaT_ = -cosThetaI_; return 0.0f; }
+    Float scale = (cosThetaI_ > 0) ? 1 / eta : eta, cosThetaTSqr = 1 - (1 - cosThetaI_ * cosThetaI_) * (scale * scale);
+    if (cosThetaTSqr <= 0.0f) { cosThetaT_ = 0.0f; return 1.0f; }
+    Float cosThetaI = ppg_abs(cosThetaI_);
+    Float cosThetaT = std::sqrt(cosThetaTSqr);
+    Float Rs = (cosThetaI - eta * cosThetaT) / (cosThetaI + eta * cosThetaT);
+    Float Rp = (eta * cosThetaI - cosThetaT) / (eta * cosThetaI + cosThetaT);
+    cosThetaT_ = (cosThetaI_ > 0) ? -cosThetaT : cosThetaT;
+    return 0.5f * (Rs * Rs + Rp * Rp);
+}
+inline Float fresnelDielectricExt(Float cosThetaI, Float eta) { Float t; return fresnelDielectricExt(cosThetaI, t, eta); }
+
+inline Spectrum safeSqrt(const Spectrum &s) {
+    return Spectrum(std::sqrt(ppg_max(0.0f, s.x)), std::sqrt(ppg_max(0.0f, s.y)), std::sqrt(ppg_max(0.0f, s.z)));
+}
+inline Spectrum cdiv(const Spectrum &a, const Spectrum &b) { return Spectrum(a.x / b.x, a.y / b.y, a.z / b.z); }
+
+// util.cpp:739-761
+inline Spectrum fresnelConductorExact(Float cosThetaI, const Spectrum &eta, const Spectrum &k) {
+    Float cosThetaI2 = cosThetaI * cosThetaI, sinThetaI2 = 1 - cosThetaI2, sinThetaI4 = sinThetaI2 * sinThetaI2;
+    Spectrum temp1 = mul(eta, eta) - mul(k, k) - Spectrum(sinThetaI2),
+             a2pb2 = safeSqrt(mul(temp1, temp1) + mul(mul(mul(k, k), eta), eta) * 4.0f),
+             a = safeSqrt((a2pb2 + temp1) * 0.5f);
+    Spectrum term1 = a2pb2 + Spectrum(cosThetaI2), term2 = a * (2 * cosThetaI);
+    Spectrum Rs2 = cdiv(term1 - term2, term1 + term2);
+    Spectrum term3 = a2pb2 * cosThetaI2 + Spectrum(sinThetaI4), term4 = term2 * sinThetaI2;
+    Spectrum Rp2 = cdiv(mul(Rs2, term3 - term4), term3 + term4);
+    return (Rp2 + Rs2) * 0.5f;
+}
 
 // SmoothDiffuse diffuse.cpp:110-150
 struct Diffuse {
-    static Spectrum refl(const ppg_material &m) { return Spectrum(m.reflectance[0], m.reflectance[1], m.reflectance[2]); }
-    static Spectrum eval(const ppg_material &m, const BRec &b) {
+    static Spectrum eval(const Material &m, const BRec &b) {
         if (b.wi.z <= 0 || b.wo.z <= 0) return Spectrum(0.0f);
-        return refl(m) * (PPG_INV_PI_F * b.wo.z);
+        return m.R() * (PPG_INV_PI_F * b.wo.z);
     }
-    static Float pdf(const ppg_material &, const BRec &b) {
+    static Float pdf(const Material &, const BRec &b) {
         if (b.wi.z <= 0 || b.wo.z <= 0) return 0.0f;
         return squareToCosineHemispherePdf(b.wo);
     }
-    static Spectrum sample(const ppg_material &m, BRec &b, Float &pdf, const Point2 &sample) {
+    static Spectrum sample(const Material &m, BRec &b, Float &pdf, const Point2 &sample) {
         if (b.wi.z <= 0) { pdf = 0.0f; return Spectrum(0.0f); }
         b.wo = squareToCosineHemisphere(sample);
         b.eta = 1.0f;
         b.sampledDelta = false;
         pdf = squareToCosineHemispherePdf(b.wo);
-        return refl(m);
+        return m.R();
     }
 };
 
-// BSDF dispatch: getType / eval / pdf / sample of the supported plugins
-struct BSDF {
-    static bool isSmooth(const ppg_material &m) { return m.type != PPG_BSDF_MIRROR; }   // getType() & ESmooth
-    static bool allDelta(const ppg_material &m) { return m.type == PPG_BSDF_MIRROR; }   // (type & EDelta) == (type & EAll)
-    // getType() & (ETransmission | EBackSide): twosided sets EBackSide (twosided.cpp:97-101)
-    static bool hasBackSideOrTransmission(const ppg_material &m) { return m.type == PPG_BSDF_TWOSIDED_DIFFUSE; }
+// SmoothConductor conductor.cpp:220-290 (solid-angle measure: eval = pdf = 0)
+struct Conductor {
+    static Spectrum sample(const Material &m, BRec &b, Float &pdf, const Point2 &) {
+        if (b.wi.z <= 0) { pdf = 0.0f; return Spectrum(0.0f); }
+        b.wo = Vec(-b.wi.x, -b.wi.y, b.wi.z);  // reflect(wi)
+        b.eta = 1.0f;
+        b.sampledDelta = true;
+        pdf = 1;
+        return mul(m.R(), fresnelConductorExact(b.wi.z, m.Eta(), m.K()));
+    }
+};
 
-    static Spectrum eval(const ppg_material &m, const BRec &b) {
+// MicrofacetDistribution, isotropic GGX with visible-normal sampling (microfacet.h)
+struct GGX {
+    Float alpha;
+    Float eval(const Vec &m) const {  // microfacet.h:191-237
+        if (m.z <= 0) return 0.0f;
+        Float cosTheta2 = m.z * m.z;
+        Float beckmannExponent = ((m.x * m.x) / (alpha * alpha) + (m.y * m.y) / (alpha * alpha)) / cosTheta2;
+        Float root = ((Float)1 + beckmannExponent) * cosTheta2;
+        Float result = (Float)1 / (PPG_PI_F * alpha * alpha * root * root);
+        if (result * m.z < 1e-20f) result = 0;
+        return result;
+    }
+    static Float hypot2(Float a, Float b) {  // math.cpp:74-86
+        Float r;
+        if (ppg_abs(a) > ppg_abs(b)) { r = b / a; r = ppg_abs(a) * std::sqrt(1.0f + r * r); }
+        else if (b != 0.0f) { r = a / b; r = ppg_abs(b) * std::sqrt(1.0f + r * r); }
+        else r = 0.0f;
+        return r;
+    }
+    Float smithG1(const Vec &v, const Vec &m) const {  // microfacet.h:476-516
+        if (dot(v, m) * v.z <= 0) return 0.0f;
+        Float temp = 1 - v.z * v.z;
+        Float tanTheta = temp <= 0.0f ? 0.0f : ppg_abs(std::sqrt(temp) / v.z);  // |Frame::tanTheta(v)|, frame.h:122-127
+        if (tanTheta == 0.0f) return 1.0f;
+        Float root = alpha * tanTheta;  // projectRoughness: isotropic ⇒ alpha
+        return 2.0f / (1.0f + hypot2(1.0f, root));
+    }
+    Float G(const Vec &wi, const Vec &wo, const Vec &m) const { return smithG1(wi, m) * smithG1(wo, m); }
+    Float pdfVisible(const Vec &wi, const Vec &m) const {  // microfacet.h:462-466
+        if (wi.z == 0) return 0.0f;
+        return smithG1(wi, m) * ppg_abs(dot(wi, m)) * eval(m) / ppg_abs(wi.z);
+    }
+    static void sampleVisible11(Float thetaI, Point2 sample, Float &sx, Float &sy) {  // microfacet.h:645-690
+        if (thetaI < 1e-4f) {
+            Float sinPhi, cosPhi;
+            Float r = std::sqrt(ppg_max(0.0f, sample.x / (1 - sample.x)));
+            ppg_sincos(2 * PPG_PI_F * sample.y, &sinPhi, &cosPhi);
+            sx = r * cosPhi; sy = r * sinPhi;
+            return;
+        }
+        Float tanThetaI = ppg_tan(thetaI);
+        Float a = 1 / tanThetaI;
+        Float G1 = 2.0f / (1.0f + std::sqrt(ppg_max(0.0f, 1.0f + 1.0f / (a * a))));
+        Float A = 2.0f * sample.x / G1 - 1.0f;
+        if (ppg_abs(A) == 1) A -= (A < 0 ? -1.0f : 1.0f) * PPG_EPSILON;  // math::signum never returns 0 (math.h:269-277)
+        Float tmp = 1.0f / (A * A - 1.0f);
+        Float B = tanThetaI;
+        Float D = std::sqrt(ppg_max(0.0f, B * B * tmp * tmp - (A * A - B * B) * tmp));
+        Float slope_x_1 = B * tmp - D;
+        Float slope_x_2 = B * tmp + D;
+        sx = (A < 0.0f || slope_x_2 > 1.0f / tanThetaI) ? slope_x_1 : slope_x_2;
+        Float S;
+        if (sample.y > 0.5f) { S = 1.0f; sample.y = 2.0f * (sample.y - 0.5f); }
+        else { S = -1.0f; sample.y = 2.0f * (0.5f - sample.y); }
+        Float z = (sample.y * (sample.y * (sample.y * (-(Float)0.365728915865723) + (Float)0.790235037209296) - (Float)0.424965825137544) +
+                   (Float)0.000152998850436920) /
+                  (sample.y * (sample.y * (sample.y * (sample.y * (Float)0.169507819808272 - (Float)0.397203533833404) - (Float)0.232500544458471) +
+                               (Float)1) - (Float)0.539825872510702);
+        sy = S * z * std::sqrt(1.0f + sx * sx);
+    }
+    Vec sampleVisible(const Vec &_wi, const Point2 &sample) const {  // microfacet.h:425-460
+        Vec wi = normalize(Vec(alpha * _wi.x, alpha * _wi.y, _wi.z));
+        Float theta = 0, phi = 0;
+        if (wi.z < (Float)0.99999) {
+            theta = ppg_acos(wi.z);
+            phi = ppg_atan2(wi.y, wi.x);
+        }
+        Float sinPhi, cosPhi;
+        ppg_sincos(phi, &sinPhi, &cosPhi);
+        Float sx, sy;
+        sampleVisible11(theta, sample, sx, sy);
+        Float rx = cosPhi * sx - sinPhi * sy, ry = sinPhi * sx + cosPhi * sy;
+        rx *= alpha; ry *= alpha;
+        Float normalization = (Float)1 / std::sqrt(rx * rx + ry * ry + (Float)1.0);
+        return Vec(-rx * normalization, -ry * normalization, normalization);
+    }
+};
+
+// RoughConductor roughconductor.cpp:247-415 (sampleVisible = true)
+struct RoughConductor {
+    static Vec reflect(const Vec &wi, const Vec &m) { return m * (2 * dot(wi, m)) - wi; }  // roughconductor.cpp:243-245
+    static Spectrum eval(const Material &mt, const BRec &b) {
+        if (b.wi.z <= 0 || b.wo.z <= 0) return Spectrum(0.0f);
+        Vec H = normalize(b.wo + b.wi);
+        GGX distr{mt.alpha};
+        const Float D = distr.eval(H);
+        if (D == 0) return Spectrum(0.0f);
+        const Spectrum F = mul(fresnelConductorExact(dot(b.wi, H), mt.Eta(), mt.K()), mt.R());
+        const Float G = distr.G(b.wi, b.wo, H);
+        Float model = D * G / (4.0f * b.wi.z);
+        return F * model;
+    }
+    static Float pdf(const Material &mt, const BRec &b) {
+        if (b.wi.z <= 0 || b.wo.z <= 0) return 0.0f;
+        Vec H = normalize(b.wo + b.wi);
+        GGX distr{mt.alpha};
+        return distr.eval(H) * distr.smithG1(b.wi, H) / (4.0f * b.wi.z);
+    }
+    static Spectrum sample(const Material &mt, BRec &b, Float &pdf, const Point2 &sample) {
+        pdf = 0;
+        if (b.wi.z < 0) return Spectrum(0.0f);
+        GGX distr{mt.alpha};
+        Vec m = distr.sampleVisible(b.wi, sample);
+        pdf = distr.pdfVisible(b.wi, m);
+        if (pdf == 0) return Spectrum(0.0f);
+        b.wo = reflect(b.wi, m);
+        b.eta = 1.0f;
+        b.sampledDelta = false;
+        if (b.wo.z <= 0) return Spectrum(0.0f);
+        Spectrum F = mul(fresnelConductorExact(dot(b.wi, m), mt.Eta(), mt.K()), mt.R());
+        Float weight = distr.smithG1(b.wo, m);
+        pdf /= 4.0f * dot(b.wo, m);
+        return F * weight;
+    }
+};
+
+// SmoothPlastic plastic.cpp:247-455
+struct Plastic {
+    static Spectrum diffTerm(const Material &m) {
+        Spectrum diff = m.R();
+        if (m.flags & PPG_MAT_NONLINEAR) return cdiv(diff, Spectrum(1.0f) - diff * m.fdrInt);
+        return diff / (1 - m.fdrInt);
+    }
+    static Float probSpecular(const Material &m, Float Fi) {
+        return (Fi * m.specularSamplingWeight) / (Fi * m.specularSamplingWeight + (1 - Fi) * (1 - m.specularSamplingWeight));
+    }
+    static Spectrum eval(const Material &m, const BRec &b) {  // solid-angle measure: the diffuse component
+        if (b.wo.z <= 0 || b.wi.z <= 0) return Spectrum(0.0f);
+        Float Fi = fresnelDielectricExt(b.wi.z, m.eta[0]);
+        Float Fo = fresnelDielectricExt(b.wo.z, m.eta[0]);
+        return diffTerm(m) * (squareToCosineHemispherePdf(b.wo) * m.invEta2 * (1 - Fi) * (1 - Fo));
+    }
+    static Float pdf(const Material &m, const BRec &b) {
+        if (b.wo.z <= 0 || b.wi.z <= 0) return 0.0f;
+        Float Fi = fresnelDielectricExt(b.wi.z, m.eta[0]);
+        return squareToCosineHemispherePdf(b.wo) * (1 - probSpecular(m, Fi));
+    }
+    static Spectrum sample(const Material &m, BRec &b, Float &pdf, const Point2 &sample) {
+        pdf = 0;
+        if (b.wi.z <= 0) return Spectrum(0.0f);
+        Float Fi = fresnelDielectricExt(b.wi.z, m.eta[0]);
+        b.eta = 1.0f;
+        Float pS = probSpecular(m, Fi);
+        if (sample.x < pS) {
+            b.sampledDelta = true;
+            b.wo = Vec(-b.wi.x, -b.wi.y, b.wi.z);
+            pdf = pS;
+            return m.S() * Fi / pS;
+        }
+        b.sampledDelta = false;
+        b.wo = squareToCosineHemisphere(Point2{(sample.x - pS) / (1 - pS), sample.y});
+        Float Fo = fresnelDielectricExt(b.wo.z, m.eta[0]);
+        pdf = (1 - pS) * squareToCosineHemispherePdf(b.wo);
+        return diffTerm(m) * (m.invEta2 * (1 - Fi) * (1 - Fo) / (1 - pS));
+    }
+};
+
+// SmoothDielectric dielectric.cpp:229-400 (ERadiance mode)
+struct Dielectric {
+    static Spectrum sample(const Material &m, BRec &b, Float &pdf, const Point2 &sample) {
+        Float cosThetaT;
+        const Float eta = m.eta[0], invEta = 1 / eta;
+        Float F = fresnelDielectricExt(b.wi.z, cosThetaT, eta);
+        b.sampledDelta = true;
+        if (sample.x <= F) {
+            b.wo = Vec(-b.wi.x, -b.wi.y, b.wi.z);
+            b.eta = 1.0f;
+            pdf = F;
+            return m.R();
+        }
+        Float scale = -(cosThetaT < 0 ? invEta : eta);  // refract(), dielectric.cpp:222-225
+        b.wo = Vec(scale * b.wi.x, scale * b.wi.y, cosThetaT);
+        b.eta = cosThetaT < 0 ? eta : invEta;
+        pdf = 1 - F;
+        Float factor = cosThetaT < 0 ? invEta : eta;
+        return m.S() * (factor * factor);
+    }
+};
+
+// BSDF dispatch: getType / eval / pdf / sample (solid-angle measure) of the supported plugins, incl. the TwoSided adapter
+struct BSDF {
+    static bool isSmooth(const Material &m) {  // getType() & ESmooth (diffuse or glossy components)
+        return m.type == PPG_BSDF_DIFFUSE || m.type == PPG_BSDF_ROUGHCONDUCTOR || m.type == PPG_BSDF_PLASTIC;
+    }
+    static bool allDelta(const Material &m) { return !isSmooth(m); }  // (type & EDelta) == (type & EAll)
+    // getType() & (ETransmission | EBackSide): twosided sets EBackSide (twosided.cpp:97-101), the dielectric both
+    static bool hasBackSideOrTransmission(const Material &m) { return (m.flags & PPG_MAT_TWOSIDED) || m.type == PPG_BSDF_DIELECTRIC; }
+
+    static Spectrum evalOne(const Material &m, const BRec &b) {
         switch (m.type) {
             case PPG_BSDF_DIFFUSE: return Diffuse::eval(m, b);
-            case PPG_BSDF_TWOSIDED_DIFFUSE: {  // twosided.cpp eval: flip both directions onto the front side
-                BRec c = b;
-                if (c.wi.z > 0) return Diffuse::eval(m, c);
-                c.wi.z *= -1; c.wo.z *= -1;
-                return Diffuse::eval(m, c);
-            }
-            default: return Spectrum(0.0f);  // conductor.cpp:222-237: zero for the solid-angle measure
+            case PPG_BSDF_ROUGHCONDUCTOR: return RoughConductor::eval(m, b);
+            case PPG_BSDF_PLASTIC: return Plastic::eval(m, b);
+            default: return Spectrum(0.0f);  // delta components are zero for the solid-angle measure (conductor.cpp:222-237)
         }
     }
-    static Float pdf(const ppg_material &m, const BRec &b) {
+    static Float pdfOne(const Material &m, const BRec &b) {
         switch (m.type) {
             case PPG_BSDF_DIFFUSE: return Diffuse::pdf(m, b);
-            case PPG_BSDF_TWOSIDED_DIFFUSE: {
-                BRec c = b;
-                if (c.wi.z > 0) return Diffuse::pdf(m, c);
-                c.wi.z *= -1; c.wo.z *= -1;
-                return Diffuse::pdf(m, c);
-            }
+            case PPG_BSDF_ROUGHCONDUCTOR: return RoughConductor::pdf(m, b);
+            case PPG_BSDF_PLASTIC: return Plastic::pdf(m, b);
             default: return 0.0f;
         }
     }
-    static Spectrum sample(const ppg_material &m, BRec &b, Float &pdf, const Point2 &sample) {
+    static Spectrum sampleOne(const Material &m, BRec &b, Float &pdf, const Point2 &sample) {
         switch (m.type) {
             case PPG_BSDF_DIFFUSE: return Diffuse::sample(m, b, pdf, sample);
-            case PPG_BSDF_TWOSIDED_DIFFUSE: {  // twosided.cpp:160-180
-                bool flipped = false;
-                if (b.wi.z < 0) { b.wi.z *= -1; flipped = true; }
-                Spectrum result = Diffuse::sample(m, b, pdf, sample);
-                if (flipped) {
-                    b.wi.z *= -1;
-                    if (!isZero(result) && pdf != 0) b.wo.z *= -1;
-                }
-                return result;
-            }
-            default: {  // conductor.cpp:268-284, material "none"
-                if (b.wi.z <= 0) { pdf = 0.0f; return Spectrum(0.0f); }
-                b.wo = Vec(-b.wi.x, -b.wi.y, b.wi.z);  // reflect(wi)
-                b.eta = 1.0f;
-                b.sampledDelta = true;
-                pdf = 1;
-                return Diffuse::refl(m);
-            }
+            case PPG_BSDF_MIRROR:
+            case PPG_BSDF_CONDUCTOR: return Conductor::sample(m, b, pdf, sample);
+            case PPG_BSDF_ROUGHCONDUCTOR: return RoughConductor::sample(m, b, pdf, sample);
+            case PPG_BSDF_PLASTIC: return Plastic::sample(m, b, pdf, sample);
+            case PPG_BSDF_DIELECTRIC: return Dielectric::sample(m, b, pdf, sample);
+            default: pdf = 0; return Spectrum(0.0f);
         }
+    }
+    static bool twoSided(const Material &m) { return (m.flags & PPG_MAT_TWOSIDED) && m.type != PPG_BSDF_DIELECTRIC; }
+
+    static Spectrum eval(const Material &m, const BRec &b) {
+        if (!twoSided(m) || b.wi.z > 0) return evalOne(m, b);
+        BRec c = b;  // twosided.cpp:120-135: flip both directions onto the front side
+        c.wi.z *= -1; c.wo.z *= -1;
+        return evalOne(m, c);
+    }
+    static Float pdf(const Material &m, const BRec &b) {
+        if (!twoSided(m) || b.wi.z > 0) return pdfOne(m, b);
+        BRec c = b;
+        c.wi.z *= -1; c.wo.z *= -1;
+        return pdfOne(m, c);
+    }
+    static Spectrum sample(const Material &m, BRec &b, Float &pdf, const Point2 &sample) {
+        if (!twoSided(m)) return sampleOne(m, b, pdf, sample);
+        bool flipped = false;  // twosided.cpp:160-180
+        if (b.wi.z < 0) { b.wi.z *= -1; flipped = true; }
+        Spectrum result = sampleOne(m, b, pdf, sample);
+        if (flipped) {
+            b.wi.z *= -1;
+            if (!isZero(result) && pdf != 0) b.wo.z *= -1;
+        }
+        return result;
     }
 };
 
@@ -1488,7 +1737,7 @@ public:
     }
 
     // sampleMat / pdfMat GP:1650-1710 (diffuse BSDF: smooth, no delta component)
-    Spectrum sampleMat(const ppg_material &bsdf, BRec &bRec, const Frame &shFrame, Float &woPdf, Float &bsdfPdf, Float &dTreePdf,
+    Spectrum sampleMat(const Material &bsdf, BRec &bRec, const Frame &shFrame, Float &woPdf, Float &bsdfPdf, Float &dTreePdf,
                        Float bsdfSamplingFraction, Sampler &sampler, const DTreeWrapper *dTree) const {
         Point2 sample = sampler.next2D();
         if (!m_isBuilt || !dTree || BSDF::allDelta(bsdf)) {
@@ -1523,7 +1772,7 @@ public:
         return result / woPdf;
     }
 
-    void pdfMat(Float &woPdf, Float &bsdfPdf, Float &dTreePdf, Float bsdfSamplingFraction, const ppg_material &bsdf, const BRec &bRec,
+    void pdfMat(Float &woPdf, Float &bsdfPdf, Float &dTreePdf, Float bsdfSamplingFraction, const Material &bsdf, const BRec &bRec,
                 const Frame &shFrame, const DTreeWrapper *dTree) const {
         dTreePdf = 0;
         if (!m_isBuilt || !dTree || BSDF::allDelta(bsdf)) {
@@ -1623,7 +1872,7 @@ public:
             Float wiDotGeoN = -dot(its.geoN, d), wiDotShN = its.wi.z;  // GP:1929-1932
             if (wiDotGeoN * wiDotShN < 0 && m_strictNormals) break;
 
-            const ppg_material &bsdf = scene.materials[its.material];
+            const Material &bsdf = scene.materials[its.material];
             Vec dTreeVoxelSize;
             DTreeWrapper *dTree = nullptr;
             if (BSDF::isSmooth(bsdf)) dTree = m_sdTree->dTreeWrapper(its.p, dTreeVoxelSize);  // GP:1942-1944
@@ -1932,11 +2181,18 @@ int ppgo_set_scene(ppgo_ctx *ctx, const ppg_scene *s) {
     sc.idx.assign(s->indices, s->indices + 3 * (size_t)s->n_triangles);
     sc.triMat.assign(s->tri_material, s->tri_material + s->n_triangles);
     sc.triEmitter.assign(s->tri_emitter, s->tri_emitter + s->n_triangles);
-    sc.materials.assign(s->materials, s->materials + s->n_materials);
+    sc.materials.clear();
+    for (uint32_t i = 0; i < s->n_materials; ++i) {
+        Material m;
+        static_cast<ppg_material &>(m) = s->materials[i];
+        if (m.type < 0 || m.type > PPG_BSDF_DIELECTRIC) { ctx->gpt.error = "unsupported BSDF type"; return PPG_ERR_INVALID; }
+        if ((m.type == PPG_BSDF_PLASTIC || m.type == PPG_BSDF_DIELECTRIC) && !(m.eta[0] > 0)) { ctx->gpt.error = "plastic / dielectric need eta[0] = intIOR / extIOR > 0"; return PPG_ERR_INVALID; }
+        m.configure();
+        sc.materials.push_back(m);
+    }
     if (s->n_emitters) sc.emitters.assign(s->emitters, s->emitters + s->n_emitters);
     for (uint32_t t = 0; t < s->n_triangles; ++t) {
         if (sc.triMat[t] >= s->n_materials || sc.triEmitter[t] >= (int32_t)s->n_emitters) { ctx->gpt.error = "index out of range"; return PPG_ERR_INVALID; }
-        if (sc.materials[sc.triMat[t]].type < 0 || sc.materials[sc.triMat[t]].type > PPG_BSDF_MIRROR) { ctx->gpt.error = "unsupported BSDF type"; return PPG_ERR_INVALID; }
         for (int k = 0; k < 3; ++k) if (sc.idx[3 * t + k] >= s->n_vertices) { ctx->gpt.error = "vertex index out of range"; return PPG_ERR_INVALID; }
     }
     sc.cam = s->camera;
@@ -2222,6 +2478,42 @@ int ppgo_dtree_exercise(int32_t acc_mode, int32_t directional_filter, float rho,
         }
     *stat_weight_out = w.sampling.statisticalWeight();
     *tree_sum_out = w.sampling.sumValue();
+    return PPG_OK;
+}
+
+// BSDF plug-in interface of the supported materials, element-wise (tests/test_bsdfs.py: the chi-square-style checks the
+// reference applies to its BSDFs, M/src/tests/test_chisquare.cpp).  wi / wo are in the local shading frame.
+int ppgo_bsdf_eval(const ppg_material *mat, uint32_t n, const float *wi, const float *wo, float *f_out, float *pdf_out) {
+    Material m; static_cast<ppg_material &>(m) = *mat;
+    if (m.type < 0 || m.type > PPG_BSDF_DIELECTRIC) return PPG_ERR_INVALID;
+    m.configure();
+    for (uint32_t i = 0; i < n; ++i) {
+        BRec b; b.wi = Vec(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]); b.wo = Vec(wo[3 * i], wo[3 * i + 1], wo[3 * i + 2]);
+        Spectrum f = BSDF::eval(m, b);
+        f_out[3 * i] = f.x; f_out[3 * i + 1] = f.y; f_out[3 * i + 2] = f.z;
+        pdf_out[i] = BSDF::pdf(m, b);
+    }
+    return PPG_OK;
+}
+int ppgo_bsdf_sample(const ppg_material *mat, uint32_t n, const float *wi, const float *sample_xy, float *wo_out, float *weight_out,
+                     float *pdf_out, float *eta_out, int32_t *delta_out) {
+    Material m; static_cast<ppg_material &>(m) = *mat;
+    if (m.type < 0 || m.type > PPG_BSDF_DIELECTRIC) return PPG_ERR_INVALID;
+    m.configure();
+    for (uint32_t i = 0; i < n; ++i) {
+        BRec b; b.wi = Vec(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]);
+        Float pdf = 0;
+        Spectrum w = BSDF::sample(m, b, pdf, Point2{sample_xy[2 * i], sample_xy[2 * i + 1]});
+        wo_out[3 * i] = b.wo.x; wo_out[3 * i + 1] = b.wo.y; wo_out[3 * i + 2] = b.wo.z;
+        weight_out[3 * i] = w.x; weight_out[3 * i + 1] = w.y; weight_out[3 * i + 2] = w.z;
+        pdf_out[i] = pdf; eta_out[i] = b.eta; delta_out[i] = b.sampledDelta ? 1 : 0;
+    }
+    return PPG_OK;
+}
+int ppgo_bsdf_flags(const ppg_material *mat, int32_t *is_smooth, int32_t *all_delta, int32_t *backside_or_transmission) {
+    Material m; static_cast<ppg_material &>(m) = *mat;
+    m.configure();
+    *is_smooth = BSDF::isSmooth(m); *all_delta = BSDF::allDelta(m); *backside_or_transmission = BSDF::hasBackSideOrTransmission(m);
     return PPG_OK;
 }
 

@@ -81,6 +81,10 @@ void ppgo_canonical_to_dir(float x, float y, float *d);
 void ppgo_dir_to_canonical(const float *d, float *xy);
 /* element-wise ppg_detmath.h / ppg_rng.h evaluation: op 0 sincos(a), 1 atan2(a,b), 2 exp(a), 3 fixed round trip, 4 rand, 5 powi */
 int ppgo_math_eval(int32_t op, uint32_t n, const float *a, const float *b, float *out0, float *out1);
+int ppgo_bsdf_eval(const ppg_material *mat, uint32_t n, const float *wi, const float *wo, float *f_out, float *pdf_out);
+int ppgo_bsdf_sample(const ppg_material *mat, uint32_t n, const float *wi, const float *sample_xy, float *wo_out, float *weight_out,
+                     float *pdf_out, float *eta_out, int32_t *delta_out);
+int ppgo_bsdf_flags(const ppg_material *mat, int32_t *is_smooth, int32_t *all_delta, int32_t *backside_or_transmission);
 /* D-tree exercise: record `n` (canonical xy, irradiance, weight) samples into a fresh wrapper with the
    given filter / acc mode, build, reset(rho), record again, build; then evaluate pdf at `m` query
    points and draw `m` samples keyed (seed, i).  Outputs node arrays of the final sampling tree. */

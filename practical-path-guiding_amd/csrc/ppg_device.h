@@ -473,6 +473,259 @@ D F3 bsdf_sample(int type, F3 refl, F3 wi, float sx, float sy, F3 &wo, float &pd
 }
 
 // ------------------------------------------------------------------------------------------------
+// Full material set (kernel variants instantiated with FULL = true; scenes with only diffuse / two-sided diffuse / mirror
+// materials keep the lean functions above).  Expression order follows the cited reference code, like the oracle's.
+// ------------------------------------------------------------------------------------------------
+struct Mat {
+    int type, flags;          // type normalised: TWOSIDED_DIFFUSE → DIFFUSE + PPG_MAT_TWOSIDED
+    F3 refl, spec, eta, k;
+    float alpha, fdr_int;
+};
+D Mat load_material(const DevScene &S, int id) {
+    const float4 *m = S.materials + 4 * (size_t)id;
+    const float4 a = m[0], b = m[1], c = m[2], d = m[3];
+    Mat M;
+    M.type = (int)a.w; M.flags = __float_as_int(c.w);
+    if (M.type == PPG_BSDF_TWOSIDED_DIFFUSE) { M.type = PPG_BSDF_DIFFUSE; M.flags |= PPG_MAT_TWOSIDED; }
+    M.refl = f3(a.x, a.y, a.z); M.spec = f3(b.x, b.y, b.z); M.eta = f3(c.x, c.y, c.z); M.k = f3(d.x, d.y, d.z);
+    M.alpha = b.w; M.fdr_int = d.w;
+    return M;
+}
+D bool mat_is_smooth(const Mat &M) { return M.type == PPG_BSDF_DIFFUSE || M.type == PPG_BSDF_ROUGHCONDUCTOR || M.type == PPG_BSDF_PLASTIC; }
+D bool mat_two_sided(const Mat &M) { return (M.flags & PPG_MAT_TWOSIDED) && M.type != PPG_BSDF_DIELECTRIC; }
+D bool mat_backside_or_transmission(const Mat &M) { return (M.flags & PPG_MAT_TWOSIDED) || M.type == PPG_BSDF_DIELECTRIC; }
+
+D F3 cdiv3(F3 a, F3 b) { return f3(a.x / b.x, a.y / b.y, a.z / b.z); }
+D F3 safe_sqrt3(F3 s) { return f3(__builtin_sqrtf(ppg_max(0.0f, s.x)), __builtin_sqrtf(ppg_max(0.0f, s.y)), __builtin_sqrtf(ppg_max(0.0f, s.z))); }
+D float lum3(F3 s) { return s.x * 0.212671f + s.y * 0.715160f + s.z * 0.072169f; }
+
+// util.cpp:651-681
+D float fresnel_dielectric_ext(float cosThetaI_, float &cosThetaT_, float eta) {
+    if (eta == 1) { cosThetaT_ = -cosThetaI_; return 0.0f; }
+    float scale = (cosThetaI_ > 0) ? 1 / eta : eta, cosThetaTSqr = 1 - (1 - cosThetaI_ * cosThetaI_) * (scale * scale);
+    if (cosThetaTSqr <= 0.0f) { cosThetaT_ = 0.0f; return 1.0f; }
+    float cosThetaI = ppg_abs(cosThetaI_);
+    float cosThetaT = __builtin_sqrtf(cosThetaTSqr);
+    float Rs = (cosThetaI - eta * cosThetaT) / (cosThetaI + eta * cosThetaT);
+    float Rp = (eta * cosThetaI - cosThetaT) / (eta * cosThetaI + cosThetaT);
+    cosThetaT_ = (cosThetaI_ > 0) ? -cosThetaT : cosThetaT;
+    return 0.5f * (Rs * Rs + Rp * Rp);
+}
+D float fresnel_dielectric_ext(float cosThetaI, float eta) { float t; return fresnel_dielectric_ext(cosThetaI, t, eta); }
+
+// util.cpp:739-761
+D F3 fresnel_conductor_exact(float cosThetaI, F3 eta, F3 k) {
+    float cosThetaI2 = cosThetaI * cosThetaI, sinThetaI2 = 1 - cosThetaI2, sinThetaI4 = sinThetaI2 * sinThetaI2;
+    F3 temp1 = mul3(eta, eta) - mul3(k, k) - f3s(sinThetaI2);
+    F3 a2pb2 = safe_sqrt3(mul3(temp1, temp1) + mul3(mul3(mul3(k, k), eta), eta) * 4.0f);
+    F3 a = safe_sqrt3((a2pb2 + temp1) * 0.5f);
+    F3 term1 = a2pb2 + f3s(cosThetaI2), term2 = a * (2 * cosThetaI);
+    F3 Rs2 = cdiv3(term1 - term2, term1 + term2);
+    F3 term3 = a2pb2 * cosThetaI2 + f3s(sinThetaI4), term4 = term2 * sinThetaI2;
+    F3 Rp2 = cdiv3(mul3(Rs2, term3 - term4), term3 + term4);
+    return (Rp2 + Rs2) * 0.5f;
+}
+
+// MicrofacetDistribution, isotropic GGX, visible-normal sampling (microfacet.h:191-237, 425-540, 645-690)
+D float ggx_eval(float alpha, F3 m) {
+    if (m.z <= 0) return 0.0f;
+    float cosTheta2 = m.z * m.z;
+    float beckmannExponent = ((m.x * m.x) / (alpha * alpha) + (m.y * m.y) / (alpha * alpha)) / cosTheta2;
+    float root = (1.0f + beckmannExponent) * cosTheta2;
+    float result = 1.0f / (PPG_PI_F * alpha * alpha * root * root);
+    if (result * m.z < 1e-20f) result = 0;
+    return result;
+}
+D float hypot2f(float a, float b) {  // math.cpp:74-86
+    float r;
+    if (ppg_abs(a) > ppg_abs(b)) { r = b / a; r = ppg_abs(a) * __builtin_sqrtf(1.0f + r * r); }
+    else if (b != 0.0f) { r = a / b; r = ppg_abs(b) * __builtin_sqrtf(1.0f + r * r); }
+    else r = 0.0f;
+    return r;
+}
+D float ggx_smith_g1(float alpha, F3 v, F3 m) {
+    if (dot3(v, m) * v.z <= 0) return 0.0f;
+    float temp = 1 - v.z * v.z;
+    float tanTheta = temp <= 0.0f ? 0.0f : ppg_abs(__builtin_sqrtf(temp) / v.z);
+    if (tanTheta == 0.0f) return 1.0f;
+    float root = alpha * tanTheta;
+    return 2.0f / (1.0f + hypot2f(1.0f, root));
+}
+D float ggx_pdf_visible(float alpha, F3 wi, F3 m) {
+    if (wi.z == 0) return 0.0f;
+    return ggx_smith_g1(alpha, wi, m) * ppg_abs(dot3(wi, m)) * ggx_eval(alpha, m) / ppg_abs(wi.z);
+}
+D void ggx_sample_visible11(float thetaI, float u, float v, float &sx, float &sy) {
+    if (thetaI < 1e-4f) {
+        float sinPhi, cosPhi;
+        float r = __builtin_sqrtf(ppg_max(0.0f, u / (1 - u)));
+        ppg_sincos(2 * PPG_PI_F * v, &sinPhi, &cosPhi);
+        sx = r * cosPhi; sy = r * sinPhi;
+        return;
+    }
+    float tanThetaI = ppg_tan(thetaI);
+    float a = 1 / tanThetaI;
+    float G1 = 2.0f / (1.0f + __builtin_sqrtf(ppg_max(0.0f, 1.0f + 1.0f / (a * a))));
+    float A = 2.0f * u / G1 - 1.0f;
+    if (ppg_abs(A) == 1) A -= (A < 0 ? -1.0f : 1.0f) * PPG_EPSILON;
+    float tmp = 1.0f / (A * A - 1.0f);
+    float B = tanThetaI;
+    float Dq = __builtin_sqrtf(ppg_max(0.0f, B * B * tmp * tmp - (A * A - B * B) * tmp));
+    float slope_x_1 = B * tmp - Dq;
+    float slope_x_2 = B * tmp + Dq;
+    sx = (A < 0.0f || slope_x_2 > 1.0f / tanThetaI) ? slope_x_1 : slope_x_2;
+    float S;
+    if (v > 0.5f) { S = 1.0f; v = 2.0f * (v - 0.5f); }
+    else { S = -1.0f; v = 2.0f * (0.5f - v); }
+    float z = (v * (v * (v * (-0.365728915865723f) + 0.790235037209296f) - 0.424965825137544f) + 0.000152998850436920f) /
+              (v * (v * (v * (v * 0.169507819808272f - 0.397203533833404f) - 0.232500544458471f) + 1.0f) - 0.539825872510702f);
+    sy = S * z * __builtin_sqrtf(1.0f + sx * sx);
+}
+D F3 ggx_sample_visible(float alpha, F3 _wi, float u, float v) {
+    F3 wi = norm3(f3(alpha * _wi.x, alpha * _wi.y, _wi.z));
+    float theta = 0, phi = 0;
+    if (wi.z < 0.99999f) {
+        theta = ppg_acos(wi.z);
+        phi = ppg_atan2(wi.y, wi.x);
+    }
+    float sinPhi, cosPhi;
+    ppg_sincos(phi, &sinPhi, &cosPhi);
+    float sx, sy;
+    ggx_sample_visible11(theta, u, v, sx, sy);
+    float rx = cosPhi * sx - sinPhi * sy, ry = sinPhi * sx + cosPhi * sy;
+    rx *= alpha; ry *= alpha;
+    float normalization = 1.0f / __builtin_sqrtf(rx * rx + ry * ry + 1.0f);
+    return f3(-rx * normalization, -ry * normalization, normalization);
+}
+
+// plastic.cpp:191-204 (configure) — recomputed per call from the material record, same arithmetic as the oracle's configure()
+D float plastic_prob_specular(const Mat &M, float Fi) {
+    float dAvg = lum3(M.refl), sAvg = lum3(M.spec);
+    float w = sAvg / (dAvg + sAvg);
+    return (Fi * w) / (Fi * w + (1 - Fi) * (1 - w));
+}
+D F3 plastic_diff_term(const Mat &M) {
+    if (M.flags & PPG_MAT_NONLINEAR) return cdiv3(M.refl, f3s(1.0f) - M.refl * M.fdr_int);
+    return div3(M.refl, 1 - M.fdr_int);
+}
+
+// one-sided plugins, solid-angle measure
+D F3 mat_eval_one(const Mat &M, F3 wi, F3 wo) {
+    if (M.type == PPG_BSDF_DIFFUSE) return diffuse_eval(M.refl, wi, wo);
+    if (M.type == PPG_BSDF_ROUGHCONDUCTOR) {  // roughconductor.cpp:247-282
+        if (wi.z <= 0 || wo.z <= 0) return f3s(0.0f);
+        F3 H = norm3(wo + wi);
+        const float Dm = ggx_eval(M.alpha, H);
+        if (Dm == 0) return f3s(0.0f);
+        const F3 F = mul3(fresnel_conductor_exact(dot3(wi, H), M.eta, M.k), M.refl);
+        const float G = ggx_smith_g1(M.alpha, wi, H) * ggx_smith_g1(M.alpha, wo, H);
+        float model = Dm * G / (4.0f * wi.z);
+        return F * model;
+    }
+    if (M.type == PPG_BSDF_PLASTIC) {  // plastic.cpp:247-281, diffuse component
+        if (wo.z <= 0 || wi.z <= 0) return f3s(0.0f);
+        float Fi = fresnel_dielectric_ext(wi.z, M.eta.x);
+        float Fo = fresnel_dielectric_ext(wo.z, M.eta.x);
+        const float invEta2 = 1 / (M.eta.x * M.eta.x);
+        return plastic_diff_term(M) * ((PPG_INV_PI_F * wo.z) * invEta2 * (1 - Fi) * (1 - Fo));
+    }
+    return f3s(0.0f);
+}
+D float mat_pdf_one(const Mat &M, F3 wi, F3 wo) {
+    if (M.type == PPG_BSDF_DIFFUSE) return diffuse_pdf(wi, wo);
+    if (M.type == PPG_BSDF_ROUGHCONDUCTOR) {  // roughconductor.cpp:284-307
+        if (wi.z <= 0 || wo.z <= 0) return 0.0f;
+        F3 H = norm3(wo + wi);
+        return ggx_eval(M.alpha, H) * ggx_smith_g1(M.alpha, wi, H) / (4.0f * wi.z);
+    }
+    if (M.type == PPG_BSDF_PLASTIC) {  // plastic.cpp:283-311
+        if (wo.z <= 0 || wi.z <= 0) return 0.0f;
+        float Fi = fresnel_dielectric_ext(wi.z, M.eta.x);
+        return (PPG_INV_PI_F * wo.z) * (1 - plastic_prob_specular(M, Fi));
+    }
+    return 0.0f;
+}
+D F3 mat_sample_one(const Mat &M, F3 wi, float sx, float sy, F3 &wo, float &pdf, bool &delta, float &eta) {
+    delta = false; eta = 1.0f; pdf = 0.0f; wo = f3s(0.0f);
+    switch (M.type) {
+        case PPG_BSDF_DIFFUSE:
+            if (wi.z <= 0) return f3s(0.0f);
+            wo = cosine_hemisphere(sx, sy);
+            pdf = PPG_INV_PI_F * wo.z;
+            return M.refl;
+        case PPG_BSDF_MIRROR:
+        case PPG_BSDF_CONDUCTOR:  // conductor.cpp:268-284
+            if (wi.z <= 0) return f3s(0.0f);
+            wo = f3(-wi.x, -wi.y, wi.z);
+            delta = true;
+            pdf = 1;
+            return mul3(M.refl, fresnel_conductor_exact(wi.z, M.eta, M.k));
+        case PPG_BSDF_ROUGHCONDUCTOR: {  // roughconductor.cpp:367-415
+            if (wi.z < 0) return f3s(0.0f);
+            F3 m = ggx_sample_visible(M.alpha, wi, sx, sy);
+            pdf = ggx_pdf_visible(M.alpha, wi, m);
+            if (pdf == 0) return f3s(0.0f);
+            wo = m * (2 * dot3(wi, m)) - wi;
+            if (wo.z <= 0) return f3s(0.0f);
+            F3 F = mul3(fresnel_conductor_exact(dot3(wi, m), M.eta, M.k), M.refl);
+            float weight = ggx_smith_g1(M.alpha, wo, m);
+            pdf /= 4.0f * dot3(wo, m);
+            return F * weight;
+        }
+        case PPG_BSDF_PLASTIC: {  // plastic.cpp:368-425
+            if (wi.z <= 0) return f3s(0.0f);
+            float Fi = fresnel_dielectric_ext(wi.z, M.eta.x);
+            float pS = plastic_prob_specular(M, Fi);
+            if (sx < pS) {
+                delta = true;
+                wo = f3(-wi.x, -wi.y, wi.z);
+                pdf = pS;
+                return div3(M.spec * Fi, pS);
+            }
+            wo = cosine_hemisphere((sx - pS) / (1 - pS), sy);
+            float Fo = fresnel_dielectric_ext(wo.z, M.eta.x);
+            pdf = (1 - pS) * (PPG_INV_PI_F * wo.z);
+            const float invEta2 = 1 / (M.eta.x * M.eta.x);
+            return plastic_diff_term(M) * (invEta2 * (1 - Fi) * (1 - Fo) / (1 - pS));
+        }
+        case PPG_BSDF_DIELECTRIC: {  // dielectric.cpp:271-312, ERadiance
+            float cosThetaT;
+            const float e = M.eta.x, invEta = 1 / e;
+            float F = fresnel_dielectric_ext(wi.z, cosThetaT, e);
+            delta = true;
+            if (sx <= F) {
+                wo = f3(-wi.x, -wi.y, wi.z);
+                pdf = F;
+                return M.refl;
+            }
+            float scale = -(cosThetaT < 0 ? invEta : e);
+            wo = f3(scale * wi.x, scale * wi.y, cosThetaT);
+            eta = cosThetaT < 0 ? e : invEta;
+            pdf = 1 - F;
+            float factor = cosThetaT < 0 ? invEta : e;
+            return M.spec * (factor * factor);
+        }
+    }
+    return f3s(0.0f);
+}
+// + the TwoSided adapter (twosided.cpp:120-180)
+D F3 mat_eval(const Mat &M, F3 wi, F3 wo) {
+    if (mat_two_sided(M) && !(wi.z > 0)) { wi.z *= -1; wo.z *= -1; }
+    return mat_eval_one(M, wi, wo);
+}
+D float mat_pdf(const Mat &M, F3 wi, F3 wo) {
+    if (mat_two_sided(M) && !(wi.z > 0)) { wi.z *= -1; wo.z *= -1; }
+    return mat_pdf_one(M, wi, wo);
+}
+D F3 mat_sample(const Mat &M, F3 wi, float sx, float sy, F3 &wo, float &pdf, bool &delta, float &eta) {
+    bool flipped = false;
+    if (mat_two_sided(M) && wi.z < 0) { wi.z *= -1; flipped = true; }
+    F3 result = mat_sample_one(M, wi, sx, sy, wo, pdf, delta, eta);
+    if (flipped && !iszero3(result) && pdf != 0) wo.z *= -1;
+    return result;
+}
+
+// ------------------------------------------------------------------------------------------------
 // SD-tree
 // ------------------------------------------------------------------------------------------------
 struct __attribute__((aligned(32))) SNode {  // sampling quadtree node, 32 B

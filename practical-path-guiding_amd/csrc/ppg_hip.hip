@@ -254,6 +254,7 @@ struct ppg_ctx {
 
     // scene
     bool haveScene = false;
+    bool fullMaterials = false;
     DevBuf<float4> d_tris, d_normals, d_materials, d_emitters, d_emTris, d_emNrm;
     DevBuf<float> d_emSel, d_emArea;
     DevBuf<int4> d_emInfo;
@@ -594,6 +595,7 @@ int renderBatch(ppg_ctx *ctx, int batch) {
     // and only the surviving lanes trace.  Kept selectable for re-measurement on other scenes.
     const bool fused = smallScene && getenv("PPG_FUSE");
     const bool neeOn = ctx->doNee;  // m_doNee of this iteration (doNeeWithSpp, GP:1331-1340)
+    const bool fullMats = ctx->fullMaterials;  // any BSDF beyond diffuse / two-sided diffuse / mirror: the FULL kernel variants
     const size_t triBytes = (size_t)ctx->scene.n_tris * 48;
     timedLaunch(ctx, "k_generate", P.n_paths, [&] {
         if (fused) hipLaunchKernelGGL(k_generate<true>, dim3(gridAll), dim3(PPG_BLOCK), triBytes, s, P, S, R, Q);
@@ -611,14 +613,24 @@ int renderBatch(ppg_ctx *ctx, int batch) {
                 if (smallScene) hipLaunchKernelGGL(k_trace<true>, dim3(grid), dim3(PPG_BLOCK), ldsBytes, s, P, S, Q, qin, 0, ctx->ldsTris);
                 else hipLaunchKernelGGL(k_trace<false>, dim3(grid), dim3(PPG_BLOCK), ldsBytes, s, P, S, Q, qin, ctx->ldsNodes, ctx->ldsTris);
             });
-        timedLaunch(ctx, fused ? "k_shade<fused>" : (neeOn ? "k_shade<nee>" : "k_shade"), hostCount, [&] {
+        timedLaunch(ctx, fused ? "k_shade<fused>" : (neeOn ? "k_shade<nee>" : (fullMats ? "k_shade<full>" : "k_shade")), hostCount, [&] {
             const int small = smallScene ? 1 : 0;
-            if (neeOn) {  // luminaire sampling: the shadow ray needs the staged triangles or a BVH stack column per lane
-                const size_t neeBytes = smallScene ? triBytes : (size_t)PPG_LDS_STACK * PPG_BLOCK * 4;
-                if (fused) hipLaunchKernelGGL((k_shade<true, true>), dim3(grid), dim3(PPG_BLOCK), triBytes, s, P, S, T, R, Q, qin, qout, small);
-                else hipLaunchKernelGGL((k_shade<false, true>), dim3(grid), dim3(PPG_BLOCK), neeBytes, s, P, S, T, R, Q, qin, qout, small);
-            } else if (fused) hipLaunchKernelGGL((k_shade<true, false>), dim3(grid), dim3(PPG_BLOCK), triBytes, s, P, S, T, R, Q, qin, qout, small);
-            else hipLaunchKernelGGL((k_shade<false, false>), dim3(grid), dim3(PPG_BLOCK), 0, s, P, S, T, R, Q, qin, qout, small);
+            // dynamic LDS: the staged triangles (fused, or luminaire sampling on a small scene) or the shadow rays' BVH stack columns
+            const size_t neeBytes = smallScene ? triBytes : (size_t)PPG_LDS_STACK * PPG_BLOCK * 4;
+            const size_t lds = fused ? triBytes : (neeOn ? neeBytes : 0);
+#define PPG_SHADE(F, N, M) hipLaunchKernelGGL((k_shade<F, N, M>), dim3(grid), dim3(PPG_BLOCK), lds, s, P, S, T, R, Q, qin, qout, small)
+            const int variant = (fused ? 4 : 0) | (neeOn ? 2 : 0) | (fullMats ? 1 : 0);
+            switch (variant) {
+                case 0: PPG_SHADE(false, false, false); break;
+                case 1: PPG_SHADE(false, false, true); break;
+                case 2: PPG_SHADE(false, true, false); break;
+                case 3: PPG_SHADE(false, true, true); break;
+                case 4: PPG_SHADE(true, false, false); break;
+                case 5: PPG_SHADE(true, false, true); break;
+                case 6: PPG_SHADE(true, true, false); break;
+                default: PPG_SHADE(true, true, true); break;
+            }
+#undef PPG_SHADE
         });
         qin = qout;
         // unbounded paths (maxDepth < 0) and kernel timing need the live count; bounded paths run a fixed schedule without a sync
@@ -643,10 +655,18 @@ int renderBatch(ppg_ctx *ctx, int batch) {
                 Qt.count[0] = Q.count[qin ^ 1]; Qt.count[1] = Q.count[qin];
                 Qt.cap = capTail; Qt.n_blocks = nbTail;
                 timedLaunch(ctx, "k_tail", hostCount, [&] {
-                    if (smallScene && neeOn) hipLaunchKernelGGL((k_tail<true, true>), dim3(nbTail), dim3(PPG_BLOCK), ldsBytes, s, P, S, T, R, Qt, 0, 0, ctx->ldsTris);
-                    else if (smallScene) hipLaunchKernelGGL((k_tail<true, false>), dim3(nbTail), dim3(PPG_BLOCK), ldsBytes, s, P, S, T, R, Qt, 0, 0, ctx->ldsTris);
-                    else if (neeOn) hipLaunchKernelGGL((k_tail<false, true>), dim3(nbTail), dim3(PPG_BLOCK), ldsBytes, s, P, S, T, R, Qt, 0, ctx->ldsNodes, ctx->ldsTris);
-                    else hipLaunchKernelGGL((k_tail<false, false>), dim3(nbTail), dim3(PPG_BLOCK), ldsBytes, s, P, S, T, R, Qt, 0, ctx->ldsNodes, ctx->ldsTris);
+#define PPG_TAIL(SM, N, M) hipLaunchKernelGGL((k_tail<SM, N, M>), dim3(nbTail), dim3(PPG_BLOCK), ldsBytes, s, P, S, T, R, Qt, 0, (SM) ? 0 : ctx->ldsNodes, ctx->ldsTris)
+                    switch ((smallScene ? 4 : 0) | (neeOn ? 2 : 0) | (fullMats ? 1 : 0)) {
+                        case 0: PPG_TAIL(false, false, false); break;
+                        case 1: PPG_TAIL(false, false, true); break;
+                        case 2: PPG_TAIL(false, true, false); break;
+                        case 3: PPG_TAIL(false, true, true); break;
+                        case 4: PPG_TAIL(true, false, false); break;
+                        case 5: PPG_TAIL(true, false, true); break;
+                        case 6: PPG_TAIL(true, true, false); break;
+                        default: PPG_TAIL(true, true, true); break;
+                    }
+#undef PPG_TAIL
                 });
                 HIP_CHECK(hipStreamSynchronize(s));  // tailCounts is reused by the next pass
                 break;
@@ -1059,7 +1079,7 @@ int ppg_set_scene(ppg_ctx *ctx, const ppg_scene *s) {
     HIP_CHECK(hipSetDevice(ctx->device));
     for (uint32_t t = 0; t < s->n_triangles; ++t) {
         if (s->tri_material[t] >= s->n_materials || s->tri_emitter[t] >= (int32_t)s->n_emitters) { ctx->error = "index out of range"; return PPG_ERR_INVALID; }
-        if (s->materials[s->tri_material[t]].type < 0 || s->materials[s->tri_material[t]].type > PPG_BSDF_MIRROR) { ctx->error = "unsupported BSDF type"; return PPG_ERR_INVALID; }
+        if (s->materials[s->tri_material[t]].type < 0 || s->materials[s->tri_material[t]].type > PPG_BSDF_DIELECTRIC) { ctx->error = "unsupported BSDF type"; return PPG_ERR_INVALID; }
         for (int k = 0; k < 3; ++k) if (s->indices[3 * t + k] >= s->n_vertices) { ctx->error = "vertex index out of range"; return PPG_ERR_INVALID; }
     }
     // Scene::getAABB(): kd-tree box enlarged by MTS_KD_AABB_EPSILON (gkdtree.h:1213-1220) + sensor position (scene.cpp:386-414)
@@ -1089,8 +1109,25 @@ int ppg_set_scene(ppg_ctx *ctx, const ppg_scene *s) {
             if (s->normals) { const float *n = s->normals + 3 * s->indices[3 * t + v]; nrm[3 * k + v] = make_float4(n[0], n[1], n[2], 0); }
         }
     }
-    std::vector<float4> mats(s->n_materials), ems(std::max<uint32_t>(1, s->n_emitters));
-    for (uint32_t i = 0; i < s->n_materials; ++i) mats[i] = make_float4(s->materials[i].reflectance[0], s->materials[i].reflectance[1], s->materials[i].reflectance[2], (float)s->materials[i].type);
+    // material table: 4 x float4 per BSDF = (reflectance, type) (specular, alpha) (eta, flags) (k, fdrInt); the lean kernels read
+    // only the first.  configure()-time normalisation as in the plugins: "none" conductor = (eta 0, k 1) (conductor.cpp:171-173),
+    // GGX alpha clamped (microfacet.h:135), plastic's internal diffuse Fresnel reflectance (plastic.cpp:191-193)
+    std::vector<float4> mats(4 * (size_t)s->n_materials), ems(std::max<uint32_t>(1, s->n_emitters));
+    ctx->fullMaterials = false;
+    for (uint32_t i = 0; i < s->n_materials; ++i) {
+        ppg_material m = s->materials[i];
+        if (m.type == PPG_BSDF_DIFFUSE && m.flags == PPG_MAT_TWOSIDED) { m.type = PPG_BSDF_TWOSIDED_DIFFUSE; m.flags = 0; }
+        if (m.type == PPG_BSDF_TWOSIDED_DIFFUSE) m.flags &= ~PPG_MAT_TWOSIDED;
+        if (m.type == PPG_BSDF_MIRROR) for (int c = 0; c < 3; ++c) { m.eta[c] = 0.0f; m.k[c] = 1.0f; }
+        if (m.type == PPG_BSDF_ROUGHCONDUCTOR) m.alpha = ppg_max(m.alpha, 1e-4f);
+        if ((m.type == PPG_BSDF_PLASTIC || m.type == PPG_BSDF_DIELECTRIC) && !(m.eta[0] > 0)) { ctx->error = "plastic / dielectric need eta[0] = intIOR / extIOR > 0"; return PPG_ERR_INVALID; }
+        const float fdrInt = m.type == PPG_BSDF_PLASTIC ? ppg_fresnel_diffuse_reflectance(1 / m.eta[0]) : 0.0f;
+        if (m.type > PPG_BSDF_MIRROR || m.flags != 0) ctx->fullMaterials = true;
+        mats[4 * i + 0] = make_float4(m.reflectance[0], m.reflectance[1], m.reflectance[2], (float)m.type);
+        mats[4 * i + 1] = make_float4(m.specular[0], m.specular[1], m.specular[2], m.alpha);
+        mats[4 * i + 2] = make_float4(m.eta[0], m.eta[1], m.eta[2], __builtin_bit_cast(float, m.flags));
+        mats[4 * i + 3] = make_float4(m.k[0], m.k[1], m.k[2], fdrInt);
+    }
     for (uint32_t i = 0; i < s->n_emitters; ++i) ems[i] = make_float4(s->emitters[i].radiance[0], s->emitters[i].radiance[1], s->emitters[i].radiance[2], 0);
     HIP_CHECK(ctx->d_tris.reserve(tris.size()));
     HIP_CHECK(hipMemcpy(ctx->d_tris.p, tris.data(), tris.size() * sizeof(float4), hipMemcpyHostToDevice));

@@ -607,7 +607,8 @@ struct NeeLds {
 // One queue slice through Li's loop body.  FUSED (small scenes): the ray sampled here is traced here too.
 // NEE: the variant with luminaire sampling (GP:1962-2021) and MIS against it (GP:2083-2088); the shadow ray is
 // traced and the direct-light vertex committed in place, as in the reference's loop.
-template <bool FUSED, bool NEE>
+// FULL: the complete material set (ppg_device.h "Full material set"); otherwise only diffuse / two-sided diffuse / mirror.
+template <bool FUSED, bool NEE, bool FULL>
 D void shade_slice(const PathState &P, const DevScene &S, const DevTree &T, const RenderParams &R, const unsigned int *items, unsigned int count,
                    unsigned int b, unsigned int nb, unsigned int *out_items, unsigned int *out_count, const LdsColumn &fcol,
                    const float4 *lds_tris, unsigned long long &plen_sum, unsigned int &traced, const NeeLds &nee,
@@ -710,10 +711,20 @@ D void shade_slice(const PathState &P, const DevScene &S, const DevTree &T, cons
                 if (wiDotGeoN * wiDotShN < 0 && R.strict_normals) go = false;
             }
             if (go) {
-                float4 mat = S.materials[I.material];
-                const F3 refl = f3(mat.x, mat.y, mat.z);
-                const int mtype = (int)mat.w;
-                const bool smooth = bsdf_is_smooth(mtype);  // bsdf->getType() & ESmooth: only those are guided
+                Mat M;
+                if (FULL) {
+                    M = load_material(S, I.material);
+                } else {
+                    const float4 mat = S.materials[4 * (size_t)I.material];
+                    M.type = (int)mat.w; M.flags = 0; M.refl = f3(mat.x, mat.y, mat.z);
+                }
+                const bool smooth = FULL ? mat_is_smooth(M) : bsdf_is_smooth(M.type);  // bsdf->getType() & ESmooth: only those are guided
+                auto b_eval = [&](F3 wi_, F3 wo_) { return FULL ? mat_eval(M, wi_, wo_) : bsdf_eval(M.type, M.refl, wi_, wo_); };
+                auto b_pdf = [&](F3 wi_, F3 wo_) { return FULL ? mat_pdf(M, wi_, wo_) : bsdf_pdf(M.type, wi_, wo_); };
+                float sampledEta = 1.0f;
+                auto b_sample = [&](float u_, float v_, F3 &wo_, float &pdf_, bool &delta_) {
+                    return FULL ? mat_sample(M, I.wi, u_, v_, wo_, pdf_, delta_, sampledEta) : bsdf_sample(M.type, M.refl, I.wi, u_, v_, wo_, pdf_, delta_);
+                };
                 F3 vox = f3s(0.0f);
                 int leaf = 0;
                 DTreeRef hd;
@@ -733,32 +744,38 @@ D void shade_slice(const PathState &P, const DevScene &S, const DevTree &T, cons
                 float woPdf, bsdfPdf, dTreePdf;
                 bool sampledDelta = false;
                 if (!T.is_built || !smooth) {  // !m_isBuilt || !dTree || all components are delta
-                    bsdfWeight = bsdf_sample(mtype, refl, I.wi, sx, sy, wo_l, bsdfPdf, sampledDelta);
+                    bsdfWeight = b_sample(sx, sy, wo_l, bsdfPdf, sampledDelta);
                     woPdf = bsdfPdf;
                     dTreePdf = 0;
                 } else {
                     F3 result;
-                    bool zero = false;
+                    bool zero = false, deltaEarly = false;
                     if (sx < frac) {
                         sx /= frac;
-                        result = bsdf_sample(mtype, refl, I.wi, sx, sy, wo_l, bsdfPdf, sampledDelta);
+                        result = b_sample(sx, sy, wo_l, bsdfPdf, sampledDelta);
                         if (iszero3(result)) zero = true;
+                        else if (FULL && sampledDelta) deltaEarly = true;  // GP:1672-1676: a delta lobe of a mixed BSDF
                         else result = result * bsdfPdf;
                     } else {
                         // sample.x is remapped but unused on this branch (GP:1680-1682)
                         float cx, cy;
                         dtree_sample(T, hd, key, dim, cx, cy);
                         wo_l = to_local(I, canonical_to_dir(cx, cy));
-                        result = bsdf_eval(mtype, refl, I.wi, wo_l);
+                        sampledEta = 1.0f;
+                        result = b_eval(I.wi, wo_l);
                     }
                     if (zero) {
                         woPdf = bsdfPdf = dTreePdf = 0;
                         bsdfWeight = f3s(0.0f);
                         wo_l = f3s(0.0f);
+                    } else if (deltaEarly) {
+                        dTreePdf = 0;
+                        woPdf = bsdfPdf * frac;
+                        bsdfWeight = div3(result, frac);
                     } else {
                         // pdfMat, GP:1693-1710
                         dTreePdf = 0;
-                        bsdfPdf = bsdf_pdf(mtype, I.wi, wo_l);
+                        bsdfPdf = b_pdf(I.wi, wo_l);
                         if (!ppg_isfinite(bsdfPdf)) {
                             woPdf = 0;
                         } else {
@@ -771,7 +788,8 @@ D void shade_slice(const PathState &P, const DevScene &S, const DevTree &T, cons
                     }
                 }
                 // Luminaire sampling, GP:1962-2021
-                const F3 refN = (mtype == PPG_BSDF_TWOSIDED_DIFFUSE) ? f3s(0.0f) : I.n;  // DirectSamplingRecord(its), records.inl:160-164
+                const bool noRefN = FULL ? mat_backside_or_transmission(M) : (M.type == PPG_BSDF_TWOSIDED_DIFFUSE);
+                const F3 refN = noRefN ? f3s(0.0f) : I.n;  // DirectSamplingRecord(its), records.inl:160-164
                 if (NEE && R.do_nee && smooth) {
                     const float ex = ppg_rand(key, dim++);
                     const float ey = ppg_rand(key, dim++);
@@ -790,12 +808,12 @@ D void shade_slice(const PathState &P, const DevScene &S, const DevTree &T, cons
                         const F3 wo_e = to_local(I, ds.d);
                         const float woDotGeoNE = dot3(I.geoN, ds.d);
                         if (!R.strict_normals || woDotGeoNE * wo_e.z > 0) {
-                            const F3 bsdfVal = bsdf_eval(mtype, refl, I.wi, wo_e);
+                            const F3 bsdfVal = b_eval(I.wi, wo_e);
                             float woPdfE = 0, bsdfPdfE = 0, dTreePdfE = 0;  // pdfMat, GP:1693-1710
                             if (!T.is_built) {
-                                woPdfE = bsdfPdfE = bsdf_pdf(mtype, I.wi, wo_e);
+                                woPdfE = bsdfPdfE = b_pdf(I.wi, wo_e);
                             } else {
-                                bsdfPdfE = bsdf_pdf(mtype, I.wi, wo_e);
+                                bsdfPdfE = b_pdf(I.wi, wo_e);
                                 if (ppg_isfinite(bsdfPdfE)) {
                                     float cx, cy;
                                     dir_to_canonical(to_world(I, wo_e), cx, cy);
@@ -833,7 +851,8 @@ D void shade_slice(const PathState &P, const DevScene &S, const DevTree &T, cons
                     float woDotGeoN = dot3(I.geoN, wo);
                     if (woDotGeoN * wo_l.z <= 0 && R.strict_normals) go = false;  // GP:2031-2032
                     if (go) {
-                        thr = mul3(thr, bsdfWeight);  // GP:2039-2040 (eta *= 1)
+                        thr = mul3(thr, bsdfWeight);  // GP:2039-2040
+                        if (FULL) eta *= sampledEta;
                         d = wo;
                         if (FUSED) {
                             Hit hn = trace_small(lds_tris, S.n_tris, I.p, wo, PPG_EPSILON, __builtin_inff());
@@ -878,7 +897,7 @@ D void shade_slice(const PathState &P, const DevScene &S, const DevTree &T, cons
     }
 }
 
-template <bool FUSED, bool NEE>
+template <bool FUSED, bool NEE, bool FULL>
 __global__ __launch_bounds__(PPG_BLOCK, PPG_SHADE_WAVES) void k_shade(PathState P, DevScene S, DevTree T, RenderParams R, Queues Q, int qin, int qout,
                                                                      int small_scene) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -901,8 +920,8 @@ __global__ __launch_bounds__(PPG_BLOCK, PPG_SHADE_WAVES) void k_shade(PathState 
     __syncthreads();
     unsigned long long plen_sum = 0, committed = 0;
     unsigned int traced = 0;
-    shade_slice<FUSED, NEE>(P, S, T, R, items, count, b, nb, Q.items[qout] + (size_t)b * Q.cap, &out_count, fcol, lds_tris, plen_sum, traced, nee,
-                            committed);
+    shade_slice<FUSED, NEE, FULL>(P, S, T, R, items, count, b, nb, Q.items[qout] + (size_t)b * Q.cap, &out_count, fcol, lds_tris, plen_sum, traced,
+                                  nee, committed);
     __syncthreads();
     if (threadIdx.x == 0) Q.count[qout][b] = out_count;
     block_add_u64(&acc, &Q.stats[b].path_len, plen_sum);
@@ -913,7 +932,7 @@ __global__ __launch_bounds__(PPG_BLOCK, PPG_SHADE_WAVES) void k_shade(PathState 
 // Tail of unbounded paths (maxDepth < 0): once few paths are left, every workgroup keeps bouncing its own queue
 // slice — trace phase, shade phase, swap — until the slice is empty, inside ONE launch.  The slices are private
 // to a workgroup, so no grid-wide synchronisation (and no host round trip per bounce) is needed.
-template <bool SMALL, bool NEE>
+template <bool SMALL, bool NEE, bool FULL>
 __global__ __launch_bounds__(PPG_BLOCK, PPG_SHADE_WAVES) void k_tail(PathState P, DevScene S, DevTree T, RenderParams R, Queues Q, int qin,
                                                                     int lds_nodes, int lds_tris) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -939,8 +958,8 @@ __global__ __launch_bounds__(PPG_BLOCK, PPG_SHADE_WAVES) void k_tail(PathState P
         __syncthreads();  // hits written by any lane of the workgroup are read by the shade phase
         if (threadIdx.x == 0) out_count = 0;
         __syncthreads();
-        shade_slice<false, NEE>(P, S, T, R, items, count, b, nb, Q.items[cur ^ 1] + (size_t)b * Q.cap, &out_count, fcol, L.tris, plen_sum, shadow,
-                                nee, committed);
+        shade_slice<false, NEE, FULL>(P, S, T, R, items, count, b, nb, Q.items[cur ^ 1] + (size_t)b * Q.cap, &out_count, fcol, L.tris, plen_sum,
+                                      shadow, nee, committed);
         __syncthreads();  // queue writes of this workgroup are visible to it after the barrier (same CU, write-through L1)
         count = out_count;
         cur ^= 1;

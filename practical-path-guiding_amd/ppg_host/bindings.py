@@ -61,7 +61,29 @@ class Config(C.Structure):
 
 
 class Material(C.Structure):
-    _fields_ = [("type", C.c_int32), ("reflectance", C.c_float * 3), ("param", C.c_float * 4)]
+    """ppg_material (include/ppg.h).  Scene descriptions carry materials as dicts: type, reflectance and — by type —
+    specular, alpha, eta (3 values, or one number for plastic / dielectric), k, twosided, nonlinear."""
+    _fields_ = [("type", C.c_int32), ("reflectance", C.c_float * 3), ("specular", C.c_float * 3), ("alpha", C.c_float),
+                ("eta", C.c_float * 3), ("k", C.c_float * 3), ("flags", C.c_int32), ("_reserved", C.c_int32)]
+
+    BSDF = dict(diffuse=0, twosided_diffuse=1, mirror=2, conductor=3, roughconductor=4, plastic=5, dielectric=6)
+
+    @classmethod
+    def from_dict(cls, m):
+        def three(v, default):
+            v = default if v is None else v
+            v = [v] * 3 if np.isscalar(v) else list(v)
+            return [float(np.float32(x)) for x in v]
+        o = cls()
+        t = m.get("type", 0)
+        o.type = cls.BSDF[t] if isinstance(t, str) else int(t)
+        o.reflectance[:] = three(m.get("reflectance"), 0.5 if o.type in (0, 1, 5) else 1.0)
+        o.specular[:] = three(m.get("specular"), 1.0)
+        o.alpha = float(m.get("alpha", 0.1))
+        o.eta[:] = three(m.get("eta"), 0.0 if o.type in (2, 3, 4) else 1.5046)  # dielectric / plastic default: bk7 / polypropylene-ish
+        o.k[:] = three(m.get("k"), 1.0)
+        o.flags = (1 if m.get("twosided") else 0) | (2 if m.get("nonlinear") else 0)
+        return o
 
 
 class Emitter(C.Structure):
@@ -176,8 +198,7 @@ class Engine:
         nrm = None if desc.normals is None else np.ascontiguousarray(desc.normals, np.float32)
         mats = (Material * len(desc.materials))()
         for i, m in enumerate(desc.materials):
-            mats[i].type = m.get("type", 0)
-            mats[i].reflectance[:] = [float(v) for v in m["reflectance"]]
+            mats[i] = Material.from_dict(m)
         ems = (Emitter * max(1, len(desc.emitters)))()
         for i, e in enumerate(desc.emitters):
             ems[i].radiance[:] = [float(v) for v in e["radiance"]]

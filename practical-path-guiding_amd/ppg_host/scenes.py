@@ -28,7 +28,7 @@ class SceneDesc:
 def save_scene(desc, path):
     """Write the flat binary scene read by host/ppg_render.cpp: "PPGS", 6 x uint32 {n_vertices, n_triangles, n_materials,
     n_emitters, has_normals, 0}, then positions, [normals], indices, tri_material, tri_emitter, materials
-    (ppg_material: int32 type, 3 + 4 floats), emitters (4 floats), camera (ppg_camera)."""
+    (ppg_material, 64 bytes each), emitters (4 floats), camera (ppg_camera)."""
     import struct
     pos = np.ascontiguousarray(desc.positions, np.float32)
     idx = np.ascontiguousarray(desc.indices, np.uint32)
@@ -41,8 +41,9 @@ def save_scene(desc, path):
         f.write(idx.tobytes())
         f.write(np.ascontiguousarray(desc.tri_material, np.uint32).tobytes())
         f.write(np.ascontiguousarray(desc.tri_emitter, np.int32).tobytes())
+        from .bindings import Material
         for m in desc.materials:
-            f.write(struct.pack("<i7f", m.get("type", 0), *[float(np.float32(v)) for v in m["reflectance"]], 0, 0, 0, 0))
+            f.write(bytes(Material.from_dict(m)))  # ppg_material, 64 bytes
         for e in desc.emitters:
             f.write(struct.pack("<4f", *[float(np.float32(v)) for v in e["radiance"]], 0))
         c = desc.camera

@@ -428,3 +428,48 @@ def test_next_event_estimation_bvh_scene_and_materials(oracle_lib):
     g, o = hip(**props), make_oracle(oracle_lib, threads=os.cpu_count() or 8, **props)
     assert np.array_equal(ppg_host.GuidedPathTracer(engine=g).render(scene), ppg_host.GuidedPathTracer(engine=o).render(scene))
     assert_tree_equal(g.read_sdtree(), o.read_sdtree())
+
+
+def _full_materials_scene(res):
+    """CBOX with the BSDFs of SURVEY.md §8(f1): GGX gold floor, copper back wall (smooth conductor), plastic short box,
+    glass tall box, a two-sided rough aluminium-like ceiling."""
+    import ppg_host
+    scene = ppg_host.cbox_scene(*res)
+    base = len(scene.materials)
+    scene.materials = list(scene.materials) + [
+        dict(type="roughconductor", alpha=0.2, eta=(0.143, 0.375, 1.442), k=(3.983, 2.386, 1.603), reflectance=(1, 1, 1)),          # +0 floor
+        dict(type="conductor", eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14), reflectance=(0.95, 0.95, 0.95)),                         # +1 back wall
+        dict(type="plastic", reflectance=(0.2, 0.35, 0.7), specular=(1, 1, 1), eta=1.49),                                           # +2 short box
+        dict(type="dielectric", eta=1.5, reflectance=(1, 1, 1), specular=(0.98, 0.99, 0.98)),                                       # +3 tall box
+        dict(type="roughconductor", alpha=0.45, eta=(1.66, 0.88, 0.52), k=(9.2, 6.3, 4.8), reflectance=(0.9, 0.9, 0.9), twosided=True),  # +4 ceiling
+    ]
+    tm = scene.tri_material.copy()
+    tm[2:4] = base + 0      # floor
+    tm[4:6] = base + 4      # ceiling
+    tm[6:8] = base + 1      # back wall
+    tm[12:24] = base + 2    # short box
+    tm[24:36] = base + 3    # tall box
+    scene.tri_material = tm
+    return scene
+
+
+@pytest.mark.parametrize("extra", [{}, IMPROVED, dict(nee="kickstart", bsdfSamplingFractionLoss="var"), dict(maxDepth=-1, rrDepth=3, strictNormals=0)],
+                         ids=["default", "improved", "nee-kickstart-var", "unbounded-rr"])
+def test_glossy_plastic_and_glass_materials_against_oracle(oracle_lib, extra):
+    """roughconductor (GGX, visible normals) is smooth ⇒ guided, with the learned BSDF sampling fraction
+    doing real work; plastic mixes a delta lobe into a guided BSDF (GP:1672-1676, delta vertices recorded for Adam, GP:2093);
+    the dielectric is all-delta, transmits, and scales eta for Russian roulette (GP:2040, 2130)."""
+    import ppg_host
+    scene = _full_materials_scene((72, 72))
+    assert [int(t) for t in np.bincount(scene.tri_material)] and scene.tri_emitter[0] == 0
+    props = dict(CBOX_PROPS, budget=60, seed=12)
+    props.update(maxDepth=14, rrDepth=5)
+    props.update(extra)
+    g, o = hip(**props), make_oracle(oracle_lib, threads=os.cpu_count() or 8, **props)
+    gg, go = ppg_host.GuidedPathTracer(engine=g), ppg_host.GuidedPathTracer(engine=o)
+    ig, io = gg.render(scene), go.render(scene)
+    assert _stats(gg) == _stats(go)
+    assert np.array_equal(ig, io, equal_nan=True)
+    assert_tree_equal(g.read_sdtree(), o.read_sdtree())
+    plain = ppg_host.GuidedPathTracer(engine=hip(**props)).render(ppg_host.cbox_scene(72, 72))
+    assert np.nanmean(np.abs(ig - plain)) > 5e-3
