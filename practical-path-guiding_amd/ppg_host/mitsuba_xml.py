@@ -5,7 +5,8 @@
               nested sampler (independent; sampleCount / seed do not steer guided_path, GP:1342-1374) and
               film hdrfilm (width, height; rfilter box)
   shapes      obj (filename, toWorld, faceNormals, flipNormals, flipTexCoords, collapse), rectangle (toWorld, flipNormals)
-  bsdfs       diffuse, twosided(diffuse), conductor(material none) — top level with id, nested, or <ref id>
+  bsdfs       diffuse, conductor (material none, or explicit eta / k), roughconductor (ggx, isotropic), plastic, dielectric,
+              twosided(any of the BRDFs) — top level with id, nested, or <ref id>
   emitters    area (nested in a shape)
   values      <spectrum>, <rgb>, <srgb> (spectrum.py), <transform> of translate / rotate / scale / lookAt / matrix,
               <default name value> and $name substitution (mitsuba -D, mitsuba.cpp:58-87)
@@ -369,27 +370,79 @@ def load_scene(path, defines=None, strict=True, width=None, height=None):
                     raise SceneError("textured %r is not supported (SURVEY.md §8 f1)" % name)
         return np.full(3, default, f32)
 
-    def make_bsdf(elem):
+    IOR = {"vacuum": 1.0, "air": 1.000277, "water": 1.3330, "polypropylene": 1.49, "bk7": 1.5046, "diamond": 2.419}  # well-known constants (cf. ior.h)
+
+    def lookup_ior(p, name, default):  # lookupIOR, ior.h:95-111: a number or a material name
+        v = p.get(name, default)
+        if isinstance(v, (int, float)):
+            return float(v)
+        if str(v).lower() not in IOR:
+            raise SceneError("IOR name %r is not in the built-in list %s; give a number" % (v, sorted(IOR)))
+        return IOR[str(v).lower()]
+
+    def microfacet_alpha(p, what):  # MicrofacetDistribution(props), microfacet.h:99-145
+        if str(p.get("distribution", "beckmann")).lower() != "ggx":
+            raise SceneError("%s: distribution %r is not supported (ggx only)" % (what, p.get("distribution", "beckmann")))
+        if "alphaU" in p or "alphaV" in p:
+            if p.get("alphaU") != p.get("alphaV"):
+                raise SceneError("%s: anisotropic roughness is not supported" % what)
+            return float(p["alphaU"])
+        if not p.get("sampleVisible", True):
+            raise SceneError("%s: sampleVisible=false is not supported" % what)
+        return float(p.get("alpha", 0.1))
+
+    def conductor_ior(elem, p, what):
+        ext = lookup_ior(p, "extEta", "air")
+        if str(p.get("material", "Cu")).lower() == "none":
+            eta, k = np.zeros(3, f32), np.ones(3, f32)
+        else:
+            have = {c.get("name") for c in elem}
+            if not ({"eta", "k"} <= have):
+                raise SceneError("%s(material=%s): measured IOR spectra (data/ior/*.spd) are not bundled; give <spectrum|rgb name=\"eta\"> and \"k\""
+                                 % (what, p.get("material", "Cu")))
+            eta, k = colour(elem, "eta", 0.0), colour(elem, "k", 1.0)
+        return tuple(float(v) for v in (eta / f32(ext))), tuple(float(v) for v in (k / f32(ext)))  # roughconductor.cpp:185-186
+
+    def make_bsdf(elem, allow_twosided=True):
         t = elem.get("type")
+        p = _props(elem, sub)
+        rgb = lambda name, d: tuple(float(v) for v in colour(elem, name, d))  # noqa: E731
         if t == "diffuse":
-            return dict(type=0, reflectance=tuple(float(v) for v in colour(elem, "reflectance", 0.5)))
-        if t == "twosided":
+            return dict(type=0, reflectance=rgb("reflectance", 0.5))
+        if t == "twosided" and allow_twosided:
             inner = [c for c in elem if c.tag == "bsdf"]
-            if len(inner) == 1 and inner[0].get("type") == "diffuse":
-                return dict(type=1, reflectance=tuple(float(v) for v in colour(inner[0], "reflectance", 0.5)))
+            if len(inner) == 1:
+                m = make_bsdf(inner[0], allow_twosided=False)
+                if m["type"] == 6:
+                    raise SceneError("twosided(dielectric): only BRDFs can be two-sided (twosided.cpp:84-88)")
+                if m["type"] == 0 and not m.get("_substituted"):
+                    return dict(type=1, reflectance=m["reflectance"])
+                return dict(m, twosided=True)
             t = "twosided(%s)" % ",".join(c.get("type", "?") for c in inner)
         elif t == "conductor":
-            p = _props(elem, sub)
-            if p.get("material", "Cu") == "none":
-                return dict(type=2, reflectance=tuple(float(v) for v in colour(elem, "specularReflectance", 1.0)))
-            t = "conductor(material=%s)" % p.get("material", "Cu")
+            if str(p.get("material", "Cu")).lower() == "none":
+                return dict(type=2, reflectance=rgb("specularReflectance", 1.0))
+            eta, k = conductor_ior(elem, p, t)
+            return dict(type=3, reflectance=rgb("specularReflectance", 1.0), eta=eta, k=k)
+        elif t == "roughconductor":
+            eta, k = conductor_ior(elem, p, t)
+            return dict(type=4, reflectance=rgb("specularReflectance", 1.0), eta=eta, k=k, alpha=microfacet_alpha(p, t))
+        elif t == "plastic":
+            eta = lookup_ior(p, "intIOR", "polypropylene") / lookup_ior(p, "extIOR", "air")
+            return dict(type=5, reflectance=rgb("diffuseReflectance", 0.5), specular=rgb("specularReflectance", 1.0), eta=float(f32(eta)),
+                        nonlinear=bool(p.get("nonlinear", False)))
+        elif t == "dielectric":
+            eta = lookup_ior(p, "intIOR", "bk7") / lookup_ior(p, "extIOR", "air")
+            return dict(type=6, reflectance=rgb("specularReflectance", 1.0), specular=rgb("specularTransmittance", 1.0), eta=float(f32(eta)))
         if strict:
-            raise SceneError("bsdf type %r is not supported yet (diffuse, twosided(diffuse), conductor(material=none); SURVEY.md §8 f1)" % t)
+            raise SceneError("bsdf type %r is not supported yet (diffuse, conductor, roughconductor(ggx), plastic, dielectric, twosided(...); "
+                             "SURVEY.md §8 f1)" % t)
         warnings.append("bsdf %r replaced by diffuse(0.5)" % t)
-        return dict(type=0, reflectance=(0.5, 0.5, 0.5))
+        return dict(type=0, reflectance=(0.5, 0.5, 0.5), _substituted=True)
 
     def intern(m):
-        key = (m["type"],) + tuple(m["reflectance"])
+        m = {k: v for k, v in m.items() if not k.startswith("_")}
+        key = tuple(sorted((k, tuple(v) if isinstance(v, (tuple, list)) else v) for k, v in m.items()))
         if key not in mat_index:
             mat_index[key] = len(materials)
             materials.append(m)
@@ -506,15 +559,29 @@ def save_scene_xml(desc, props, directory, name="scene"):
             '\t\t</transform>', '\t\t<sampler type="independent"/>', '\t\t<film type="hdrfilm">',
             '\t\t\t<integer name="width" value="%d"/>' % cam["width"], '\t\t\t<integer name="height" value="%d"/>' % cam["height"],
             '\t\t\t<boolean name="banner" value="false"/>', '\t\t\t<rfilter type="box"/>', '\t\t</film>', '\t</sensor>']
+    from .bindings import Material
     for i, m in enumerate(desc.materials):
-        t = int(m.get("type", 0))
-        rgb = '<rgb name="%s" value="%s"/>' % ("specularReflectance" if t == 2 else "reflectance", c(m["reflectance"]))
-        if t == 0:
-            out.append('\t<bsdf type="diffuse" id="mat%d">%s</bsdf>' % (i, rgb))
-        elif t == 1:
-            out.append('\t<bsdf type="twosided" id="mat%d"><bsdf type="diffuse">%s</bsdf></bsdf>' % (i, rgb))
+        t = m.get("type", 0)
+        t = Material.BSDF[t] if isinstance(t, str) else int(t)
+        M = Material.from_dict(m)
+        R, S, E, K = (c(getattr(M, n)) for n in ("reflectance", "specular", "eta", "k"))
+        one = '<float name="extIOR" value="1.0"/><float name="intIOR" value="%r"/>' % float(M.eta[0])
+        body = {
+            0: '<bsdf type="diffuse"%%s><rgb name="reflectance" value="%s"/></bsdf>' % R,
+            1: '<bsdf type="diffuse"%%s><rgb name="reflectance" value="%s"/></bsdf>' % R,
+            2: '<bsdf type="conductor"%%s><string name="material" value="none"/><rgb name="specularReflectance" value="%s"/></bsdf>' % R,
+            3: '<bsdf type="conductor"%%s><float name="extEta" value="1.0"/><rgb name="eta" value="%s"/><rgb name="k" value="%s"/>'
+               '<rgb name="specularReflectance" value="%s"/></bsdf>' % (E, K, R),
+            4: '<bsdf type="roughconductor"%%s><string name="distribution" value="ggx"/><float name="alpha" value="%r"/><float name="extEta" value="1.0"/>'
+               '<rgb name="eta" value="%s"/><rgb name="k" value="%s"/><rgb name="specularReflectance" value="%s"/></bsdf>' % (float(M.alpha), E, K, R),
+            5: '<bsdf type="plastic"%%s>%s<rgb name="diffuseReflectance" value="%s"/><rgb name="specularReflectance" value="%s"/>'
+               '<boolean name="nonlinear" value="%s"/></bsdf>' % (one, R, S, "true" if M.flags & 2 else "false"),
+            6: '<bsdf type="dielectric"%%s>%s<rgb name="specularReflectance" value="%s"/><rgb name="specularTransmittance" value="%s"/></bsdf>' % (one, R, S),
+        }[t]
+        if t == 1 or (M.flags & 1 and t != 6):
+            out.append('\t<bsdf type="twosided" id="mat%d">%s</bsdf>' % (i, body % ""))
         else:
-            out.append('\t<bsdf type="conductor" id="mat%d"><string name="material" value="none"/>%s</bsdf>' % (i, rgb))
+            out.append('\t' + body % (' id="mat%d"' % i))
     tm, te = np.asarray(desc.tri_material), np.asarray(desc.tri_emitter)
     idx, pos = np.asarray(desc.indices), np.asarray(desc.positions)
     groups = sorted({(int(a), int(b)) for a, b in zip(tm, te)}, key=lambda g: (g[1] < 0, g[1], g[0]))  # emitters first, in emitter order

@@ -228,3 +228,51 @@ def test_cli_converts_to_the_flat_scene_of_the_cpp_driver(tmp_path):
     raw = open(out, "rb").read()
     assert raw[:4] == b"PPGS" and np.frombuffer(raw, "<u4", 6, 4).tolist()[1:5] == [36, 4, 1, 0]  # vertices merge per mesh (obj.cpp:600-608)
     assert set(open(out + ".props").read().split()) == {"budgetType=spp", "budget=8.0", "maxDepth=5", "rrDepth=3"}
+
+
+def test_glossy_plugins_parse_like_their_constructors(tmp_path):
+    extra = """
+    <shape type="rectangle"><bsdf type="roughconductor"> <string name="material" value="none"/> <string name="distribution" value="ggx"/>
+        <float name="alpha" value="0.15"/> </bsdf></shape>
+    <shape type="rectangle"><bsdf type="twosided"><bsdf type="roughconductor"> <string name="distribution" value="ggx"/>
+        <rgb name="eta" value="0.2, 0.9, 1.1"/> <rgb name="k" value="3.9, 2.4, 2.1"/> <rgb name="specularReflectance" value="0.5, 0.6, 0.7"/>
+        </bsdf></bsdf></shape>
+    <shape type="rectangle"><bsdf type="plastic"> <rgb name="diffuseReflectance" value="0.1, 0.2, 0.3"/> <boolean name="nonlinear" value="true"/> </bsdf></shape>
+    <shape type="rectangle"><bsdf type="dielectric"> <string name="intIOR" value="water"/> <float name="extIOR" value="1.0"/> </bsdf></shape>
+    <shape type="rectangle"><bsdf type="conductor"> <float name="extEta" value="2"/> <spectrum name="eta" value="1.0"/> <spectrum name="k" value="3.0"/> </bsdf></shape>
+    """
+    desc, _, _ = ppg_host.load_scene(_write(tmp_path, extra), defines=dict(nee="never"))
+    m = [desc.materials[i] for i in desc.tri_material[7::2]]
+    f = lambda *v: tuple(float(np.float32(x)) for x in v)  # noqa: E731
+    air = np.float32(1.000277)
+    assert m[0] == dict(type=4, reflectance=f(1, 1, 1), eta=f(0, 0, 0), k=tuple(float(np.float32(1) / air) for _ in range(3)), alpha=0.15)
+    assert m[1]["twosided"] and m[1]["type"] == 4 and m[1]["alpha"] == 0.1 and m[1]["reflectance"] == f(0.5, 0.6, 0.7)  # alpha default, microfacet.h:99-100
+    assert np.allclose(m[1]["eta"], np.float32([0.2, 0.9, 1.1]) / air, rtol=1e-7)  # divided by extEta = air (roughconductor.cpp:183-186)
+    assert m[2] == dict(type=5, reflectance=f(0.1, 0.2, 0.3), specular=f(1, 1, 1), eta=float(np.float32(1.49 / 1.000277)), nonlinear=True)  # polypropylene / air
+    assert m[3] == dict(type=6, reflectance=f(1, 1, 1), specular=f(1, 1, 1), eta=float(np.float32(1.333)))
+    assert m[4] == dict(type=3, reflectance=f(1, 1, 1), eta=f(0.5, 0.5, 0.5), k=f(1.5, 1.5, 1.5))
+    for bad, needle in (('<bsdf type="roughconductor"><string name="distribution" value="ggx"/></bsdf>', "data/ior"),
+                        ('<bsdf type="roughconductor"><string name="material" value="none"/></bsdf>', "beckmann"),
+                        ('<bsdf type="roughconductor"><string name="material" value="none"/><string name="distribution" value="ggx"/>'
+                         '<float name="alphaU" value="0.1"/><float name="alphaV" value="0.3"/></bsdf>', "anisotropic"),
+                        ('<bsdf type="dielectric"><string name="intIOR" value="unobtainium"/></bsdf>', "unobtainium"),
+                        ('<bsdf type="twosided"><bsdf type="dielectric"/></bsdf>', "two-sided")):
+        with pytest.raises(mitsuba_xml.SceneError, match=needle):
+            ppg_host.load_scene(_write(tmp_path, '<shape type="rectangle">%s</shape>' % bad), defines=dict(nee="never"))
+
+
+def test_full_material_set_survives_the_xml_round_trip(tmp_path):
+    from ppg_host.bindings import Material
+    scene = ppg_host.cbox_scene(16, 16)
+    scene.materials = list(scene.materials) + [
+        dict(type="roughconductor", alpha=0.2, eta=(0.143, 0.375, 1.442), k=(3.983, 2.386, 1.603), reflectance=(1, 1, 1)),
+        dict(type="conductor", eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14), reflectance=(0.95, 0.95, 0.95), twosided=True),
+        dict(type="plastic", reflectance=(0.2, 0.35, 0.7), specular=(1, 0.9, 0.8), eta=1.49, nonlinear=True),
+        dict(type="dielectric", eta=1.5, reflectance=(1, 1, 1), specular=(0.98, 0.99, 0.98)),
+        dict(type="mirror", reflectance=(0.7, 0.8, 0.9)), dict(type=1, reflectance=(0.3, 0.3, 0.3))]
+    tm = scene.tri_material.copy(); tm[2:14:2] = np.arange(5, 11); scene.tri_material = tm
+    back, _, info = ppg_host.load_scene(ppg_host.save_scene_xml(scene, dict(budgetType="spp", budget=8.0), str(tmp_path)))
+    assert not info["warnings"]
+    per_tri = lambda s: sorted((tuple(np.sort(t.reshape(-1))), bytes(Material.from_dict(s.materials[m])))  # noqa: E731
+                               for t, m in zip(s.positions[s.indices.astype(int)], s.tri_material))
+    assert per_tri(back) == per_tri(scene)
