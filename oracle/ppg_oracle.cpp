@@ -33,8 +33,8 @@
  * Deliberate, documented deviations (DESIGN.md §"numerical contract"):
  *   - sampler: counter-based (include/ppg_rng.h) instead of per-thread SFMT streams;
  *   - libm sincos/atan2/exp/pow → include/ppg_detmath.h (bit-reproducible on CPU and GPU);
- *   - ray/triangle test: Möller–Trumbore, closest hit by (t, primitive index), instead of the
- *     kd-tree + Wald projection test ("geometrically equal, not bit-equal");
+ *   - ray/triangle test: the reference's own TriAccel projection test (triaccel.h), closest hit by (t, primitive
+ *     index) over all triangles / an own BVH instead of the kd-tree's traversal order (ties only);
  *   - SD-tree statistics are accumulated in 2^-24 fixed point (order independent) when
  *     acc_mode = FIXED (default); acc_mode = FLOAT is the reference's sequential float adds
  *     (GP:59-62) and is what pin (1) exercises;
@@ -913,6 +913,7 @@ struct Scene {
             aabb.min[a] = ppg_min(aabb.min[a], c);
             aabb.max[a] = ppg_max(aabb.max[a], c);
         }
+        buildAccel();
         bvh.clear();
         if (nTris() > 64) buildBVH();
         // TriMesh::prepareSamplingTable (trimesh.cpp:388-403) per emitter; Scene::configure's emitter pmf
@@ -1036,31 +1037,63 @@ struct Scene {
         buildRec(0, (int)order.size());
     }
 
-    // Möller–Trumbore; accepts mint <= t <= maxt (skdtree.cpp:125-133 + triaccel interval test)
+    // TriAccel (triaccel.h:36-199): Wald's pre-projected triangle, the test Mitsuba's kd-tree leaves run
+    struct TriAccel {
+        uint32_t k;
+        Float n_u, n_v, n_d, a_u, a_v, b_nu, b_nv, c_nu, c_nv;
+        int load(const Point &A, const Point &B, const Point &C) {  // triaccel.h:62-97
+            static const int waldModulo[4] = {1, 2, 0, 1};
+            Vec b = C - A, c = B - A, N = cross(c, b);
+            k = 0;
+            for (int j = 0; j < 3; j++)
+                if (ppg_abs(N[j]) > ppg_abs(N[k])) k = j;
+            uint32_t u = waldModulo[k], v = waldModulo[k + 1];
+            const Float n_k = N[k], denom = b[u] * c[v] - b[v] * c[u];
+            n_u = n_v = n_d = a_u = a_v = b_nu = b_nv = c_nu = c_nv = 0;
+            if (denom == 0) { k = 3; return 1; }
+            n_u = N[u] / n_k;
+            n_v = N[v] / n_k;
+            n_d = dot(Vec(A), N) / n_k;
+            b_nu = b[u] / denom;
+            b_nv = -b[v] / denom;
+            a_u = A[u];
+            a_v = A[v];
+            c_nu = c[v] / denom;
+            c_nv = -c[u] / denom;
+            return 0;
+        }
+        bool rayIntersect(const Point &o, const Vec &d, Float mint, Float maxt, Float &u, Float &v, Float &t) const {  // triaccel.h:99-195
+            Float o_u, o_v, o_k, d_u, d_v, d_k;
+            switch (k) {
+                case 0: o_u = o[1]; o_v = o[2]; o_k = o[0]; d_u = d[1]; d_v = d[2]; d_k = d[0]; break;
+                case 1: o_u = o[2]; o_v = o[0]; o_k = o[1]; d_u = d[2]; d_v = d[0]; d_k = d[1]; break;
+                case 2: o_u = o[0]; o_v = o[1]; o_k = o[2]; d_u = d[0]; d_v = d[1]; d_k = d[2]; break;
+                default: return false;
+            }
+            t = (n_d - o_u * n_u - o_v * n_v - o_k) / (d_u * n_u + d_v * n_v + d_k);
+            if (t < mint || t > maxt) return false;
+            const Float hu = o_u + t * d_u - a_u;
+            const Float hv = o_v + t * d_v - a_v;
+            u = hv * b_nu + hu * b_nv;
+            v = hu * c_nu + hv * c_nv;
+            return u >= 0 && v >= 0 && u + v <= 1.0f;
+        }
+    };
+    std::vector<TriAccel> accel;
+    void buildAccel() {
+        accel.resize(nTris());
+        for (size_t t = 0; t < nTris(); ++t) accel[t].load(P[idx[3 * t]], P[idx[3 * t + 1]], P[idx[3 * t + 2]]);
+    }
+
     bool triHit(uint32_t t, const Point &o, const Vec &d, Float mint, Float maxt, Float &tt, Float &uu, Float &vv) const {
-        const Point &p0 = P[idx[3 * t]], &p1 = P[idx[3 * t + 1]], &p2 = P[idx[3 * t + 2]];
-        Vec e1 = p1 - p0, e2 = p2 - p0;
-        Vec pvec = cross(d, e2);
-        Float det = dot(e1, pvec);
-        if (det == 0.0f) return false;
-        Float inv = 1.0f / det;
-        Vec tvec = o - p0;
-        Float u = dot(tvec, pvec) * inv;
-        if (u < 0.0f || u > 1.0f) return false;
-        Vec qvec = cross(tvec, e1);
-        Float v = dot(d, qvec) * inv;
-        if (v < 0.0f || u + v > 1.0f) return false;
-        Float th = dot(e2, qvec) * inv;
-        if (!(th >= mint && th <= maxt)) return false;
-        tt = th; uu = u; vv = v;
-        return true;
+        return accel[t].rayIntersect(o, d, mint, maxt, uu, vv, tt);
     }
 
     bool closest(const Point &o, const Vec &d, Float mint, Float maxt, Float &bt, Float &bu, Float &bv, int &bp) const {
         bt = std::numeric_limits<Float>::infinity(); bp = -1;
         auto consider = [&](uint32_t t) {
             Float tt, uu, vv;
-            if (triHit(t, o, d, mint, maxt, tt, uu, vv)) {
+            if (triHit(t, o, d, mint, ppg_min(maxt, bt), tt, uu, vv)) {
                 if (tt < bt || (tt == bt && (int)t < bp)) { bt = tt; bu = uu; bv = vv; bp = (int)t; }
             }
         };

@@ -76,7 +76,10 @@ struct DevCamera {
 };
 
 struct DevScene {
-    const float4 *tris;     // 3 per triangle
+    const float4 *tris;     // 3 per triangle: positions (.w = material, emitter, original index) — intersection records only
+    const float4 *accel;    // 3 per triangle: TriAccel (triaccel.h:36-58), what the traversal reads
+    const float4 *accel_small;  // small scenes (brute force from LDS): the same records sorted by projection axis k,
+    int small_n[3];             // n[k] of them per axis (degenerate triangles dropped); record[2].z = leaf-order index
     const float4 *normals;  // 3 per triangle or nullptr
     const BvhNode *bvh;
     const Bvh4Node *bvh4;     // same tree collapsed to 4-wide nodes (generic traversal)
@@ -99,23 +102,45 @@ struct Hit {
     int prim;  // leaf-order triangle index, -1 = miss
 };
 
-// Möller–Trumbore, identical arithmetic to oracle Scene::triHit; accepts mint <= t <= maxt.
-D bool tri_hit(const float4 *T, F3 o, F3 d, float mint, float maxt, float &tt, float &uu, float &vv) {
-    F3 p0 = ld3(T), p1 = ld3(T + 1), p2 = ld3(T + 2);
-    F3 e1 = p1 - p0, e2 = p2 - p0;
-    F3 pvec = cross3(d, e2);
-    float det = dot3(e1, pvec);
-    if (det == 0.0f) return false;
-    float inv = 1.0f / det;
-    F3 tvec = o - p0;
-    float u = dot3(tvec, pvec) * inv;
-    if (u < 0.0f || u > 1.0f) return false;
-    F3 qvec = cross3(tvec, e1);
-    float v = dot3(d, qvec) * inv;
-    if (v < 0.0f || u + v > 1.0f) return false;
-    float th = dot3(e2, qvec) * inv;
-    if (!(th >= mint && th <= maxt)) return false;
-    tt = th; uu = u; vv = v;
+// TriAccel::rayIntersect (triaccel.h:99-195) — Wald's pre-projected triangle test, the one Mitsuba's kd-tree leaves run;
+// identical arithmetic to the oracle's.  A = 3 float4: (n_u, n_v, n_d, k) (a_u, a_v, b_nu, b_nv) (c_nu, c_nv, -, original index).
+// Every lane of a wave tests the same triangle in the brute-force loop, so the switch on k is wave-uniform there.
+D bool tri_hit(const float4 *A, F3 o, F3 d, float mint, float maxt, float &tt, float &uu, float &vv) {
+    const float4 a0 = A[0];
+    const int k = __float_as_int(a0.w);
+    float o_u, o_v, o_k, d_u, d_v, d_k;
+    if (k == 0) { o_u = o.y; o_v = o.z; o_k = o.x; d_u = d.y; d_v = d.z; d_k = d.x; }
+    else if (k == 1) { o_u = o.z; o_v = o.x; o_k = o.y; d_u = d.z; d_v = d.x; d_k = d.y; }
+    else if (k == 2) { o_u = o.x; o_v = o.y; o_k = o.z; d_u = d.x; d_v = d.y; d_k = d.z; }
+    else return false;
+    const float t = (a0.z - o_u * a0.x - o_v * a0.y - o_k) / (d_u * a0.x + d_v * a0.y + d_k);
+    if (t < mint || t > maxt) return false;
+    const float4 a1 = A[1];
+    const float hu = o_u + t * d_u - a1.x;
+    const float hv = o_v + t * d_v - a1.y;
+    const float u = hv * a1.z + hu * a1.w;
+    const float4 a2 = A[2];
+    const float v = hu * a2.x + hv * a2.y;
+    if (!(u >= 0 && v >= 0 && u + v <= 1.0f)) return false;
+    tt = t; uu = u; vv = v;
+    return true;
+}
+
+// The same test with the projection axis known at compile time (small scenes: triangles are grouped by axis, so the
+// component selection is hoisted out of the loop).  (o_u, o_v, o_k) / (d_u, d_v, d_k) are already permuted.
+D bool tri_hit_axis(const float4 *A, float o_u, float o_v, float o_k, float d_u, float d_v, float d_k, float mint, float maxt, float &tt,
+                    float &uu, float &vv) {
+    const float4 a0 = A[0];
+    const float t = (a0.z - o_u * a0.x - o_v * a0.y - o_k) / (d_u * a0.x + d_v * a0.y + d_k);
+    if (t < mint || t > maxt) return false;
+    const float4 a1 = A[1];
+    const float hu = o_u + t * d_u - a1.x;
+    const float hv = o_v + t * d_v - a1.y;
+    const float u = hv * a1.z + hu * a1.w;
+    const float4 a2 = A[2];
+    const float v = hu * a2.x + hv * a2.y;
+    if (!(u >= 0 && v >= 0 && u + v <= 1.0f)) return false;
+    tt = t; uu = u; vv = v;
     return true;
 }
 
@@ -164,8 +189,8 @@ D Hit trace_closest(const DevScene &S, const LdsScene &L, F3 o, F3 d, float mint
             if (n > 0) {
                 for (int k = c; k < c + n; ++k) {
                     float tt, uu, vv;
-                    const float4 *T = (k < L.n_tris ? L.tris : S.tris) + 3 * k;
-                    if (tri_hit(T, o, d, mint, maxt, tt, uu, vv)) {
+                    const float4 *T = (k < L.n_tris ? L.tris : S.accel) + 3 * k;
+                    if (tri_hit(T, o, d, mint, fminf(maxt, best.t), tt, uu, vv)) {
                         int orig = __float_as_int(T[2].w);
                         if (tt < best.t || (tt == best.t && orig < bestOrig)) {
                             best.t = tt; best.u = uu; best.v = vv; best.prim = k; bestOrig = orig;
@@ -239,8 +264,8 @@ D Hit trace_closest4(const DevScene &S, int *lds_stack_col, int stride, F3 o, F3
                 const int first = code >> 3, cnt = (code & 7) + 1;
                 for (int q = first; q < first + cnt; ++q) {
                     float tt, uu, vv;
-                    const float4 *T = S.tris + 3 * q;
-                    if (tri_hit(T, o, d, mint, maxt, tt, uu, vv)) {
+                    const float4 *T = S.accel + 3 * q;
+                    if (tri_hit(T, o, d, mint, fminf(maxt, best.t), tt, uu, vv)) {
                         if (ANY) { best.t = tt; best.prim = q; return best; }
                         int orig = __float_as_int(T[2].w);
                         if (tt < best.t || (tt == best.t && orig < bestOrig)) { best.t = tt; best.u = uu; best.v = vv; best.prim = q; bestOrig = orig; }

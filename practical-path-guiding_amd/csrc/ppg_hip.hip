@@ -255,7 +255,7 @@ struct ppg_ctx {
     // scene
     bool haveScene = false;
     bool fullMaterials = false;
-    DevBuf<float4> d_tris, d_normals, d_materials, d_emitters, d_emTris, d_emNrm;
+    DevBuf<float4> d_tris, d_accel, d_accelSmall, d_normals, d_materials, d_emitters, d_emTris, d_emNrm;
     DevBuf<float> d_emSel, d_emArea;
     DevBuf<int4> d_emInfo;
     DevBuf<BvhNode> d_bvh;
@@ -1098,10 +1098,33 @@ int ppg_set_scene(ppg_ctx *ctx, const ppg_scene *s) {
     for (int a = 0; a < 3; ++a) ext = std::max(ext, mx[a] - mn[a]);
     BvhBuilder bb;
     bb.run(s->positions, s->indices, s->n_triangles, 1e-4f * ext + 1e-30f);
-    std::vector<float4> tris(3 * (size_t)s->n_triangles), nrm;
+    std::vector<float4> tris(3 * (size_t)s->n_triangles), nrm, accel(3 * (size_t)s->n_triangles);
     if (s->normals) nrm.resize(tris.size());
     for (uint32_t k = 0; k < s->n_triangles; ++k) {
         uint32_t t = bb.order[k];
+        {   // TriAccel::load (triaccel.h:62-97), same float operations as the oracle's
+            const float *A = s->positions + 3 * s->indices[3 * t], *B = s->positions + 3 * s->indices[3 * t + 1], *C = s->positions + 3 * s->indices[3 * t + 2];
+            static const int waldModulo[4] = {1, 2, 0, 1};
+            const float b[3] = {C[0] - A[0], C[1] - A[1], C[2] - A[2]}, c[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]};
+            const float N[3] = {c[1] * b[2] - c[2] * b[1], c[2] * b[0] - c[0] * b[2], c[0] * b[1] - c[1] * b[0]};
+            int kk = 0;
+            for (int j = 0; j < 3; j++) if (ppg_abs(N[j]) > ppg_abs(N[kk])) kk = j;
+            const int u = waldModulo[kk], v = waldModulo[kk + 1];
+            const float n_k = N[kk], denom = b[u] * c[v] - b[v] * c[u];
+            float n_u = 0, n_v = 0, n_d = 0, a_u = 0, a_v = 0, b_nu = 0, b_nv = 0, c_nu = 0, c_nv = 0;
+            if (denom == 0) {
+                kk = 3;
+            } else {
+                n_u = N[u] / n_k; n_v = N[v] / n_k;
+                n_d = (A[0] * N[0] + A[1] * N[1] + A[2] * N[2]) / n_k;
+                b_nu = b[u] / denom; b_nv = -b[v] / denom;
+                a_u = A[u]; a_v = A[v];
+                c_nu = c[v] / denom; c_nv = -c[u] / denom;
+            }
+            accel[3 * k + 0] = make_float4(n_u, n_v, n_d, __builtin_bit_cast(float, kk));
+            accel[3 * k + 1] = make_float4(a_u, a_v, b_nu, b_nv);
+            accel[3 * k + 2] = make_float4(c_nu, c_nv, 0.0f, __builtin_bit_cast(float, (int)t));
+        }
         for (int v = 0; v < 3; ++v) {
             const float *p = s->positions + 3 * s->indices[3 * t + v];
             float w = v == 0 ? __builtin_bit_cast(float, (int)s->tri_material[t]) : (v == 1 ? __builtin_bit_cast(float, (int)s->tri_emitter[t]) : __builtin_bit_cast(float, (int)t));
@@ -1131,6 +1154,27 @@ int ppg_set_scene(ppg_ctx *ctx, const ppg_scene *s) {
     for (uint32_t i = 0; i < s->n_emitters; ++i) ems[i] = make_float4(s->emitters[i].radiance[0], s->emitters[i].radiance[1], s->emitters[i].radiance[2], 0);
     HIP_CHECK(ctx->d_tris.reserve(tris.size()));
     HIP_CHECK(hipMemcpy(ctx->d_tris.p, tris.data(), tris.size() * sizeof(float4), hipMemcpyHostToDevice));
+    HIP_CHECK(ctx->d_accel.reserve(accel.size()));
+    HIP_CHECK(hipMemcpy(ctx->d_accel.p, accel.data(), accel.size() * sizeof(float4), hipMemcpyHostToDevice));
+    {   // small scenes are traced by brute force from LDS: the same records grouped by projection axis (degenerate ones dropped,
+        // the rest padded with never-hit records so that n_tris records can always be staged), leaf-order index in record[2].z
+        std::vector<float4> small(accel.size(), make_float4(0, 0, 0, __builtin_bit_cast(float, 3)));
+        int n[3] = {0, 0, 0};
+        if (s->n_triangles <= 64) {
+            size_t w = 0;
+            for (int axis = 0; axis < 3; ++axis)
+                for (uint32_t k = 0; k < s->n_triangles; ++k)
+                    if (__builtin_bit_cast(int, accel[3 * k].w) == axis) {
+                        small[3 * w] = accel[3 * k]; small[3 * w + 1] = accel[3 * k + 1]; small[3 * w + 2] = accel[3 * k + 2];
+                        small[3 * w + 2].z = __builtin_bit_cast(float, (int)k);
+                        ++w; ++n[axis];
+                    }
+        }
+        HIP_CHECK(ctx->d_accelSmall.reserve(small.size()));
+        HIP_CHECK(hipMemcpy(ctx->d_accelSmall.p, small.data(), small.size() * sizeof(float4), hipMemcpyHostToDevice));
+        for (int axis = 0; axis < 3; ++axis) ctx->scene.small_n[axis] = n[axis];
+        ctx->scene.accel_small = ctx->d_accelSmall.p;
+    }
     if (s->normals) { HIP_CHECK(ctx->d_normals.reserve(nrm.size())); HIP_CHECK(hipMemcpy(ctx->d_normals.p, nrm.data(), nrm.size() * sizeof(float4), hipMemcpyHostToDevice)); }
     HIP_CHECK(ctx->d_bvh.reserve(bb.nodes.size()));
     HIP_CHECK(hipMemcpy(ctx->d_bvh.p, bb.nodes.data(), bb.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice));
@@ -1194,7 +1238,7 @@ int ppg_set_scene(ppg_ctx *ctx, const ppg_scene *s) {
         S.em_area_cdf = ctx->d_emArea.p; S.em_tris = ctx->d_emTris.p; S.em_normals = enrm.empty() ? nullptr : ctx->d_emNrm.p;
     }
     DevScene &S = ctx->scene;
-    S.tris = ctx->d_tris.p; S.normals = s->normals ? ctx->d_normals.p : nullptr; S.bvh = ctx->d_bvh.p; S.bvh4 = ctx->d_bvh4.p;
+    S.tris = ctx->d_tris.p; S.accel = ctx->d_accel.p; S.normals = s->normals ? ctx->d_normals.p : nullptr; S.bvh = ctx->d_bvh.p; S.bvh4 = ctx->d_bvh4.p;
     S.materials = ctx->d_materials.p; S.emitters = ctx->d_emitters.p; S.n_tris = (int)s->n_triangles;
     memcpy(S.cam.s2c, s->camera.sample_to_camera, 64); memcpy(S.cam.c2w, s->camera.camera_to_world, 64);
     S.cam.near_clip = s->camera.near_clip; S.cam.far_clip = s->camera.far_clip;

@@ -150,23 +150,33 @@ D void wave_key_add(unsigned long long *dst, unsigned int key, unsigned long lon
     if (active) atomicAdd(dst + key, val);
 }
 
-// Closest hit over `n_tris` triangles held in LDS, no BVH (small scenes): every lane reads the same triangle
-// (LDS broadcast), no divergence, no dependent memory chain; same (t, original index) minimum as the BVH.
-D Hit trace_small(const float4 *lds_tris, int n_tris, F3 o, F3 d, float rayMint, float maxt) {
+// Closest hit over the triangles of a small scene held in LDS, no BVH: every lane reads the same triangle (LDS broadcast),
+// no dependent memory chain; same (t, original index) minimum as the BVH.  The records are grouped by projection axis
+// (DevScene::accel_small), one loop per axis with the ray components permuted once.
+D Hit trace_small(const float4 *lds_tris, const DevScene &S, F3 o, F3 d, float rayMint, float maxt) {
     float rayMinT = rayMint;
     if (rayMinT == PPG_EPSILON)  // adaptive ray epsilon, skdtree.cpp:125-129
         rayMinT *= ppg_max(ppg_max(ppg_max(ppg_abs(o.x), ppg_abs(o.y)), ppg_abs(o.z)), PPG_EPSILON);
     Hit h;
     h.t = __builtin_inff(); h.u = 0; h.v = 0; h.prim = -1;
     int bestOrig = 0x7fffffff;
-    // (a branch-free, unrolled variant of this loop was measured 18 % slower: most triangles are rejected by the
-    //  whole wave at the first test)
-    for (int k = 0; k < n_tris; ++k) {
-        float tt, uu, vv;
-        const float4 *Tk = lds_tris + 3 * k;
-        if (tri_hit(Tk, o, d, rayMinT, maxt, tt, uu, vv)) {
-            int orig = __float_as_int(Tk[2].w);
-            if (tt < h.t || (tt == h.t && orig < bestOrig)) { h.t = tt; h.u = uu; h.v = vv; h.prim = k; bestOrig = orig; }
+    const float4 *Tk = lds_tris;
+#pragma unroll
+    for (int axis = 0; axis < 3; ++axis) {
+        // triaccel.h:113-140: k = 0 → (u, v, k) = (y, z, x); k = 1 → (z, x, y); k = 2 → (x, y, z)
+        const float o_u = axis == 0 ? o.y : (axis == 1 ? o.z : o.x), o_v = axis == 0 ? o.z : (axis == 1 ? o.x : o.y);
+        const float o_k = axis == 0 ? o.x : (axis == 1 ? o.y : o.z);
+        const float d_u = axis == 0 ? d.y : (axis == 1 ? d.z : d.x), d_v = axis == 0 ? d.z : (axis == 1 ? d.x : d.y);
+        const float d_k = axis == 0 ? d.x : (axis == 1 ? d.y : d.z);
+        const int n = S.small_n[axis];
+        for (int k = 0; k < n; ++k, Tk += 3) {
+            float tt, uu, vv;
+            // t == h.t still passes: ties go to the smaller original index
+            if (tri_hit_axis(Tk, o_u, o_v, o_k, d_u, d_v, d_k, rayMinT, fminf(maxt, h.t), tt, uu, vv)) {
+                const float4 a2 = Tk[2];
+                const int orig = __float_as_int(a2.w);
+                if (tt < h.t || (tt == h.t && orig < bestOrig)) { h.t = tt; h.u = uu; h.v = vv; h.prim = __float_as_int(a2.z); bestOrig = orig; }
+            }
         }
     }
     return h;
@@ -182,7 +192,7 @@ __global__ __launch_bounds__(PPG_BLOCK) void k_generate(PathState P, DevScene S,
     __shared__ unsigned long long acc;
     const float4 *lds_tris = (const float4 *)lds_raw;
     if (FUSED) {
-        for (int k = threadIdx.x; k < 3 * S.n_tris; k += blockDim.x) ((float4 *)lds_raw)[k] = S.tris[k];
+        for (int k = threadIdx.x; k < 3 * S.n_tris; k += blockDim.x) ((float4 *)lds_raw)[k] = S.accel_small[k];
         __syncthreads();
     }
     unsigned int traced = 0;
@@ -202,7 +212,7 @@ __global__ __launch_bounds__(PPG_BLOCK) void k_generate(PathState P, DevScene S,
         F3 o = f3(S.cam.c2w[3], S.cam.c2w[7], S.cam.c2w[11]);
         F3 d = xf_vec(S.cam.c2w, dl);
         if (FUSED) {
-            Hit h = trace_small(lds_tris, S.n_tris, o, d, mint, maxt);
+            Hit h = trace_small(lds_tris, S, o, d, mint, maxt);
             P.hit[i] = make_float4(h.t, h.u, h.v, __int_as_float(h.prim));
             ++traced;
         } else {
@@ -228,7 +238,7 @@ D LdsScene stage_scene(const DevScene &S, unsigned char *lds_raw, int lds_nodes,
     const float4 *srcN = (const float4 *)S.bvh;
     const int nN = lds_nodes * 4, nT = lds_tris * 3;
     for (int k = threadIdx.x; k < nN; k += blockDim.x) dst[k] = srcN[k];
-    for (int k = threadIdx.x; k < nT; k += blockDim.x) dst[nN + k] = S.tris[k];
+    for (int k = threadIdx.x; k < nT; k += blockDim.x) dst[nN + k] = S.accel_small[k];  // small scenes only (grouped by axis)
     __syncthreads();
     L.nodes = (const BvhNode *)lds_raw; L.tris = dst + nN; L.n_nodes = lds_nodes; L.n_tris = lds_tris;
     return L;
@@ -293,8 +303,8 @@ D void trace_slice_bvh4(const PathState &P, const DevScene &S, int *lds_stack, u
                 const int first = code >> 3, cnt = (code & 7) + 1;
                 for (int q = first; q < first + cnt; ++q) {
                     float tt, uu, vv;
-                    const float4 *T = S.tris + 3 * q;
-                    if (tri_hit(T, o, d, mint, maxt, tt, uu, vv)) {
+                    const float4 *T = S.accel + 3 * q;
+                    if (tri_hit(T, o, d, mint, fminf(maxt, best.t), tt, uu, vv)) {
                         int orig = __float_as_int(T[2].w);
                         if (tt < best.t || (tt == best.t && orig < bestOrig)) { best.t = tt; best.u = uu; best.v = vv; best.prim = q; bestOrig = orig; }
                     }
@@ -344,7 +354,7 @@ D void trace_slice(const PathState &P, const DevScene &S, const LdsScene &L, int
         if (i >= P.n_paths) continue;
         float4 ro = P.ray_o[i], rd = P.ray_d[i];
         F3 o = f3(ro.x, ro.y, ro.z), d = f3(rd.x, rd.y, rd.z);
-        Hit h = trace_small(L.tris, L.n_tris, o, d, ro.w, rd.w);
+        Hit h = trace_small(L.tris, S, o, d, ro.w, rd.w);
         P.hit[i] = make_float4(h.t, h.u, h.v, __int_as_float(h.prim));
         ++traced;
     }
@@ -592,7 +602,7 @@ D void commit_single(const DevTree &T, int sfilter, int dfilter, int loss, int l
 // small_tris != nullptr: the whole scene is staged in LDS (brute force); otherwise BVH4 any-hit with this lane's
 // LDS stack column.
 D bool shadow_occluded(const DevScene &S, const float4 *small_tris, int *stack_col, F3 o, F3 d, float maxt) {
-    if (small_tris) return trace_small(small_tris, S.n_tris, o, d, PPG_EPSILON, maxt).prim >= 0;
+    if (small_tris) return trace_small(small_tris, S, o, d, PPG_EPSILON, maxt).prim >= 0;
     float rayMinT = PPG_EPSILON;  // adaptive ray epsilon, skdtree.cpp:125-129
     rayMinT *= ppg_max(ppg_max(ppg_max(ppg_abs(o.x), ppg_abs(o.y)), ppg_abs(o.z)), PPG_EPSILON);
     return trace_closest4<true>(S, stack_col, PPG_BLOCK, o, d, rayMinT, maxt).prim >= 0;
@@ -855,7 +865,7 @@ D void shade_slice(const PathState &P, const DevScene &S, const DevTree &T, cons
                         if (FULL) eta *= sampledEta;
                         d = wo;
                         if (FUSED) {
-                            Hit hn = trace_small(lds_tris, S.n_tris, I.p, wo, PPG_EPSILON, __builtin_inff());
+                            Hit hn = trace_small(lds_tris, S, I.p, wo, PPG_EPSILON, __builtin_inff());
                             P.hit[i] = make_float4(hn.t, hn.u, hn.v, __int_as_float(hn.prim));
                             ++traced;
                         } else {
@@ -907,7 +917,7 @@ __global__ __launch_bounds__(PPG_BLOCK, PPG_SHADE_WAVES) void k_shade(PathState 
     const float4 *lds_tris = (const float4 *)lds_raw;
     const bool staged = FUSED || (NEE && small_scene);  // dynamic LDS: the triangles (small scenes) or the shadow rays' BVH stack columns
     if (staged) {
-        for (int k = threadIdx.x; k < 3 * S.n_tris; k += blockDim.x) ((float4 *)lds_raw)[k] = S.tris[k];
+        for (int k = threadIdx.x; k < 3 * S.n_tris; k += blockDim.x) ((float4 *)lds_raw)[k] = S.accel_small[k];
     }
     NeeLds nee;
     nee.small_tris = staged ? lds_tris : nullptr;
