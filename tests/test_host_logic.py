@@ -108,6 +108,8 @@ if sys.argv[4] == "inversevar":
     props.update(sampleCombination="inversevar", spatialFilter="stochastic", directionalFilter="box", sTreeThreshold=2000)
 if sys.argv[4] == "improved":
     props.update(sampleCombination="inversevar", bsdfSamplingFractionLoss="kl", spatialFilter="stochastic", directionalFilter="box", sTreeThreshold=2000, sppPerPass=1)
+if sys.argv[4] == "nee":
+    props.update(nee="kickstart", bsdfSamplingFractionLoss="var", spatialFilter="box", sTreeThreshold=2000)
 e = ppg_host.Engine(lib, "ppgo_", **props)
 lib.ppgo_set_modes(e.ctx, 0, 0, 2)
 scene = ppg_host.cbox_scene(64, 48)
@@ -119,7 +121,7 @@ dist.barrier(); dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("mode", ["default", "inversevar", "improved"])
+@pytest.mark.parametrize("mode", ["default", "inversevar", "improved", "nee"])
 def test_sharded_render_over_gloo_equals_single_rank(oracle_lib, tmp_path, mode):
     """world_size 2, gloo: tiles sharded, SD-tree statistics all-reduced as int64 → the merged render is
     bit-identical to the unsharded one on every rank."""
@@ -137,6 +139,8 @@ def test_sharded_render_over_gloo_equals_single_rank(oracle_lib, tmp_path, mode)
     if mode == "improved":  # learned BSDF sampling fraction: the per-pass Adam sums are all-reduced through the pass hook
         props.update(sampleCombination="inversevar", bsdfSamplingFractionLoss="kl", spatialFilter="stochastic", directionalFilter="box",
                      sTreeThreshold=2000, sppPerPass=1)
+    if mode == "nee":  # direct-light vertices are committed inside Li's loop on whichever rank owns the pixel
+        props.update(nee="kickstart", bsdfSamplingFractionLoss="var", spatialFilter="box", sTreeThreshold=2000)
     e = make_oracle(oracle_lib, threads=4, **props)
     e.set_scene(ppg_host.cbox_scene(64, 48)); e.render()
     ref_img, ref_t = e.read_film(), e.read_sdtree()
