@@ -83,8 +83,12 @@ enum {
                                       sampling (microfacet.h:191-276, 425-540, 645-690): glossy ⇒ smooth ⇒ guided */
     PPG_BSDF_PLASTIC = 5,          /* plastic.cpp:247-455: delta specular coat over a diffuse base — the mixed delta/smooth
                                       case of sampleMat (GP:1672-1676) */
-    PPG_BSDF_DIELECTRIC = 6        /* dielectric.cpp:229-400: smooth glass, delta reflection + delta refraction, tracks eta */
+    PPG_BSDF_DIELECTRIC = 6,       /* dielectric.cpp:229-400: smooth glass, delta reflection + delta refraction, tracks eta */
+    PPG_BSDF_THINDIELECTRIC = 7    /* thindielectric.cpp:152-252: delta reflection + a NULL (pass-through) component — exercises Li's
+                                      null branch (GP:2045-2075) and the look-through of rayIntersectAndLookForEmitter /
+                                      evalTransmittance (GP:2184-2245, scene.cpp:619-679) */
 };
+#define PPG_BSDF_LAST PPG_BSDF_THINDIELECTRIC
 enum {
     PPG_MAT_TWOSIDED = 1,          /* wrap the (one-sided) BRDF in twosided.cpp:100-180, same BRDF on both sides */
     PPG_MAT_NONLINEAR = 2          /* plastic: nonlinear = true (plastic.cpp:164) */
@@ -94,10 +98,10 @@ typedef struct ppg_material {
     int32_t type;         /* PPG_BSDF_* */
     float reflectance[3]; /* linear RGB (SPECTRUM_SAMPLES=3 build of the reference): diffuse `reflectance`; plastic
                              `diffuseReflectance`; conductors and dielectric `specularReflectance` */
-    float specular[3];    /* plastic `specularReflectance`; dielectric `specularTransmittance` */
+    float specular[3];    /* plastic `specularReflectance`; dielectric / thindielectric `specularTransmittance` */
     float alpha;          /* roughconductor: GGX roughness `alpha` (clamped to >= 1e-4 like microfacet.h:135) */
     float eta[3];         /* conductors: eta per channel (already divided by extEta, roughconductor.cpp:185-186);
-                             plastic / dielectric: eta[0] = intIOR / extIOR */
+                             plastic / dielectric / thindielectric: eta[0] = intIOR / extIOR */
     float k[3];           /* conductors: k per channel */
     int32_t flags;        /* PPG_MAT_* */
     int32_t _reserved;

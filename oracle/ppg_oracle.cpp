@@ -798,7 +798,8 @@ private:
 struct BRec {
     Vec wi, wo;
     Float eta = 1.0f;
-    bool sampledDelta = false;
+    bool sampledDelta = false;  // sampledType & EDelta (EDelta includes ENull, bsdf.h:280)
+    bool sampledNull = false;   // sampledType == ENull
 };
 
 // A BSDF instance: the ABI record plus what the plugin's configure() precomputes
@@ -939,7 +940,39 @@ struct Scene {
     // Scene::sampleAttenuatedEmitterDirect (scene.cpp:876-897) → AreaLight::sampleDirect (area.cpp:158-173) →
     // Shape::sampleDirect (shape.cpp:102-115) → TriMesh::samplePosition (trimesh.cpp:412-423) →
     // Triangle::sample (triangle.cpp:24-58), then evalTransmittance (scene.cpp:619-679) without media / null BSDFs
-    Spectrum sampleEmitterDirect(DRec &dRec, Point2 sample, uint64_t &shadowRays) const {
+    // Scene::evalTransmittance (scene.cpp:619-679), surfaces only: 0 behind an occluder, otherwise the product of the
+    // null components (BSDF::eval with typeMask = ENull, EDiscrete, in the GEOMETRIC frame) of the surfaces passed.
+    // evalNull(material, cosThetaI) is supplied by the caller (the BSDF dispatch is defined further down).
+    template <typename HasNull, typename EvalNull>
+    Spectrum evalTransmittance(const Point &p1, const Point &p2, int &interactions, uint64_t &rays, HasNull hasNull, EvalNull evalNull) const {
+        Vec d = p2 - p1;
+        Float remaining = length(d);
+        d = d / remaining;
+        const Float lengthFactor = 1 - PPG_SHADOW_EPSILON;  // p2OnSurface
+        Point o = p1;
+        Float mint = PPG_EPSILON, maxt = remaining * lengthFactor;  // p1OnSurface
+        Spectrum transmittance(1.0f);
+        Intersection its;
+        int maxInteractions = interactions;
+        interactions = 0;
+        while (remaining > 0) {
+            ++rays;
+            bool surface = rayIntersect(o, d, mint, maxt, its);
+            if (surface && (interactions == maxInteractions || !hasNull(materials[its.material]))) return Spectrum(0.0f);
+            if (!surface || isZero(transmittance)) break;
+            Float cosThetaI = dot(its.geoN, -d);  // wi = -wo in Frame(its.geoFrame.n)
+            transmittance = mul(transmittance, evalNull(materials[its.material], cosThetaI));
+            if (++interactions > 100) break;
+            o = o + d * its.t;
+            remaining -= its.t;
+            maxt = remaining * lengthFactor;
+            mint = PPG_EPSILON;
+        }
+        return transmittance;
+    }
+
+    template <typename HasNull, typename EvalNull>
+    Spectrum sampleEmitterDirect(DRec &dRec, Point2 sample, uint64_t &shadowRays, int interactions, HasNull hasNull, EvalNull evalNull) const {
         dRec.pdf = 0;
         if (emMesh.empty()) return Spectrum(0.0f);
         Float emPdf;
@@ -970,11 +1003,10 @@ struct Scene {
         }
         const float *r = emitters[index].radiance;
         Spectrum value = Spectrum(r[0], r[1], r[2]) / dRec.pdf;
-        // evalTransmittance(its.p, true, dRec.p, true, ...): shadow ray [Epsilon, dist·(1 − ShadowEpsilon)]
-        Intersection occ;
-        ++shadowRays;
-        if (rayIntersect(dRec.ref, dRec.d, PPG_EPSILON, dRec.dist * (1 - PPG_SHADOW_EPSILON), occ)) return Spectrum(0.0f);
-        value = value / emPdf;  // transmittance = 1
+        // value *= evalTransmittance(its.p, true, dRec.p, true, ...) / emPdf
+        Spectrum tr = evalTransmittance(dRec.ref, dRec.p, interactions, shadowRays, hasNull, evalNull);
+        if (isZero(tr)) return Spectrum(0.0f);
+        value = mul(value, tr) / emPdf;
         dRec.emitter = (int)index;
         dRec.pdf *= emPdf;
         return value;
@@ -1453,6 +1485,32 @@ struct Dielectric {
     }
 };
 
+// ThinDielectric thindielectric.cpp:152-252
+struct ThinDielectric {
+    static Float R(const Material &m, Float cosThetaI) {  // incl. internal reflections: R' = R + TRT + TR^3T + ..
+        Float R = fresnelDielectricExt(ppg_abs(cosThetaI), m.eta[0]), T = 1 - R;
+        if (R < 1) R += T * T * R / (1 - R * R);
+        return R;
+    }
+    static Spectrum sample(const Material &m, BRec &b, Float &pdf, const Point2 &sample) {
+        Float R = ThinDielectric::R(m, b.wi.z);
+        b.eta = 1.0f;
+        b.sampledDelta = true;
+        if (sample.x <= R) {
+            b.sampledNull = false;
+            b.wo = Vec(-b.wi.x, -b.wi.y, b.wi.z);
+            pdf = R;
+            return m.R();
+        }
+        b.sampledNull = true;
+        b.wo = -b.wi;  // transmit()
+        pdf = 1 - R;
+        return m.S();
+    }
+    // eval(BSDFSamplingRecord(its, -wo, wo), EDiscrete) with typeMask = ENull: what a ray passing straight through keeps
+    static Spectrum evalNull(const Material &m, Float cosThetaI) { return m.S() * (1 - R(m, cosThetaI)); }
+};
+
 // BSDF dispatch: getType / eval / pdf / sample (solid-angle measure) of the supported plugins, incl. the TwoSided adapter
 struct BSDF {
     static bool isSmooth(const Material &m) {  // getType() & ESmooth (diffuse or glossy components)
@@ -1460,7 +1518,11 @@ struct BSDF {
     }
     static bool allDelta(const Material &m) { return !isSmooth(m); }  // (type & EDelta) == (type & EAll)
     // getType() & (ETransmission | EBackSide): twosided sets EBackSide (twosided.cpp:97-101), the dielectric both
-    static bool hasBackSideOrTransmission(const Material &m) { return (m.flags & PPG_MAT_TWOSIDED) || m.type == PPG_BSDF_DIELECTRIC; }
+    static bool hasBackSideOrTransmission(const Material &m) {
+        return (m.flags & PPG_MAT_TWOSIDED) || m.type == PPG_BSDF_DIELECTRIC || m.type == PPG_BSDF_THINDIELECTRIC;
+    }
+    static bool hasNull(const Material &m) { return m.type == PPG_BSDF_THINDIELECTRIC; }  // getType() & ENull
+    static Spectrum evalNull(const Material &m, Float cosThetaI) { return ThinDielectric::evalNull(m, cosThetaI); }
 
     static Spectrum evalOne(const Material &m, const BRec &b) {
         switch (m.type) {
@@ -1486,10 +1548,11 @@ struct BSDF {
             case PPG_BSDF_ROUGHCONDUCTOR: return RoughConductor::sample(m, b, pdf, sample);
             case PPG_BSDF_PLASTIC: return Plastic::sample(m, b, pdf, sample);
             case PPG_BSDF_DIELECTRIC: return Dielectric::sample(m, b, pdf, sample);
+            case PPG_BSDF_THINDIELECTRIC: return ThinDielectric::sample(m, b, pdf, sample);
             default: pdf = 0; return Spectrum(0.0f);
         }
     }
-    static bool twoSided(const Material &m) { return (m.flags & PPG_MAT_TWOSIDED) && m.type != PPG_BSDF_DIELECTRIC; }
+    static bool twoSided(const Material &m) { return (m.flags & PPG_MAT_TWOSIDED) && m.type != PPG_BSDF_DIELECTRIC && m.type != PPG_BSDF_THINDIELECTRIC; }
 
     static Spectrum eval(const Material &m, const BRec &b) {
         if (!twoSided(m) || b.wi.z > 0) return evalOne(m, b);
@@ -1923,7 +1986,8 @@ public:
             dRec.ref = its.p;
             dRec.refN = BSDF::hasBackSideOrTransmission(bsdf) ? Vec(0.0f) : its.shFrame.n;
             if (m_doNee && BSDF::isSmooth(bsdf)) {
-                Spectrum value = scene.sampleEmitterDirect(dRec, sampler.next2D(), pc.rays);
+                int interactions = m_maxDepth - depth - 1;
+                Spectrum value = scene.sampleEmitterDirect(dRec, sampler.next2D(), pc.rays, interactions, BSDF::hasNull, BSDF::evalNull);
                 if (!isZero(value)) {
                     BRec bRecE;
                     bRecE.wi = its.wi;
@@ -1961,14 +2025,49 @@ public:
             throughput = mul(throughput, bsdfWeight);
             eta *= bRec.eta;
 
-            // rayIntersectAndLookForEmitter GP:2184-2245 without null BSDFs / environment
+            if (bRec.sampledNull) {  // index-matched pass-through, GP:2045-2075
+                if (m_bsdfSamplingFractionLoss != ENone && dTree && nVertices < MAX_NUM_VERTICES && !m_isFinalIter) {
+                    if (1 / woPdf > 0) {
+                        vertices[nVertices] = Vertex{dTree, dTreeVoxelSize, o, d, throughput, bsdfWeight * woPdf, Spectrum(0.0f), woPdf, bsdfPdf, dTreePdf, true};
+                        ++nVertices;
+                    }
+                }
+                emittedAllowed = !scattered;  // rRec.type = scattered ? ERadianceNoEmission : ERadiance
+                scene.rayIntersect(o, d, PPG_EPSILON, std::numeric_limits<Float>::infinity(), its);
+                pc.rays++;
+                depth++;
+                continue;
+            }
+
+            // rayIntersectAndLookForEmitter GP:2184-2245 (no media, no environment emitter): `its` stays the FIRST surface hit;
+            // the search for an emitter continues through surfaces that have a null component
             Spectrum value(0.0f);
-            scene.rayIntersect(o, d, PPG_EPSILON, std::numeric_limits<Float>::infinity(), its);
-            pc.rays++;
-            if (its.valid && its.emitter >= 0) {
-                // dRec.setQuery(ray, its), records.inl:170-178
-                dRec.p = its.p; dRec.n = its.shFrame.n; dRec.d = d; dRec.dist = its.t; dRec.emitter = its.emitter;
-                value = scene.Le(its, -d);
+            {
+                Intersection its2, *cur = &its;
+                Spectrum transmittance(1.0f);
+                Point ro = o;
+                Float mint = PPG_EPSILON;
+                const int maxInteractions = m_maxDepth - depth - 1;
+                int interactions = 0;
+                bool surface = false, abandoned = false;
+                while (true) {
+                    surface = scene.rayIntersect(ro, d, mint, std::numeric_limits<Float>::infinity(), *cur);
+                    pc.rays++;
+                    if (surface && (interactions == maxInteractions || !BSDF::hasNull(scene.materials[cur->material]) || cur->emitter >= 0)) break;
+                    if (!surface) break;
+                    if (isZero(transmittance)) { abandoned = true; break; }
+                    Float cosThetaI = -cur->shFrame.toLocal(d).z;  // bRec(its, -wo, wo) in the shading frame
+                    transmittance = mul(transmittance, BSDF::evalNull(scene.materials[cur->material], cosThetaI));
+                    ro = ro + d * cur->t;
+                    mint = PPG_EPSILON;
+                    cur = &its2;
+                    if (++interactions > 100) { abandoned = true; break; }
+                }
+                if (!abandoned && surface && cur->emitter >= 0) {
+                    // dRec.setQuery(ray, *its), records.inl:170-178 (dist is measured from the LAST ray origin, as in the reference)
+                    dRec.p = cur->p; dRec.n = cur->shFrame.n; dRec.d = d; dRec.dist = cur->t; dRec.emitter = cur->emitter;
+                    value = mul(transmittance, scene.Le(*cur, -d));
+                }
             }
 
             {  // GP:2083-2111
@@ -2218,8 +2317,8 @@ int ppgo_set_scene(ppgo_ctx *ctx, const ppg_scene *s) {
     for (uint32_t i = 0; i < s->n_materials; ++i) {
         Material m;
         static_cast<ppg_material &>(m) = s->materials[i];
-        if (m.type < 0 || m.type > PPG_BSDF_DIELECTRIC) { ctx->gpt.error = "unsupported BSDF type"; return PPG_ERR_INVALID; }
-        if ((m.type == PPG_BSDF_PLASTIC || m.type == PPG_BSDF_DIELECTRIC) && !(m.eta[0] > 0)) { ctx->gpt.error = "plastic / dielectric need eta[0] = intIOR / extIOR > 0"; return PPG_ERR_INVALID; }
+        if (m.type < 0 || m.type > PPG_BSDF_LAST) { ctx->gpt.error = "unsupported BSDF type"; return PPG_ERR_INVALID; }
+        if ((m.type == PPG_BSDF_PLASTIC || m.type == PPG_BSDF_DIELECTRIC || m.type == PPG_BSDF_THINDIELECTRIC) && !(m.eta[0] > 0)) { ctx->gpt.error = "plastic / dielectric need eta[0] = intIOR / extIOR > 0"; return PPG_ERR_INVALID; }
         m.configure();
         sc.materials.push_back(m);
     }
@@ -2518,7 +2617,7 @@ int ppgo_dtree_exercise(int32_t acc_mode, int32_t directional_filter, float rho,
 // reference applies to its BSDFs, M/src/tests/test_chisquare.cpp).  wi / wo are in the local shading frame.
 int ppgo_bsdf_eval(const ppg_material *mat, uint32_t n, const float *wi, const float *wo, float *f_out, float *pdf_out) {
     Material m; static_cast<ppg_material &>(m) = *mat;
-    if (m.type < 0 || m.type > PPG_BSDF_DIELECTRIC) return PPG_ERR_INVALID;
+    if (m.type < 0 || m.type > PPG_BSDF_LAST) return PPG_ERR_INVALID;
     m.configure();
     for (uint32_t i = 0; i < n; ++i) {
         BRec b; b.wi = Vec(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]); b.wo = Vec(wo[3 * i], wo[3 * i + 1], wo[3 * i + 2]);
@@ -2531,7 +2630,7 @@ int ppgo_bsdf_eval(const ppg_material *mat, uint32_t n, const float *wi, const f
 int ppgo_bsdf_sample(const ppg_material *mat, uint32_t n, const float *wi, const float *sample_xy, float *wo_out, float *weight_out,
                      float *pdf_out, float *eta_out, int32_t *delta_out) {
     Material m; static_cast<ppg_material &>(m) = *mat;
-    if (m.type < 0 || m.type > PPG_BSDF_DIELECTRIC) return PPG_ERR_INVALID;
+    if (m.type < 0 || m.type > PPG_BSDF_LAST) return PPG_ERR_INVALID;
     m.configure();
     for (uint32_t i = 0; i < n; ++i) {
         BRec b; b.wi = Vec(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]);

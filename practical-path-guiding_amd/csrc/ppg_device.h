@@ -88,6 +88,7 @@ struct DevScene {
     int n_tris;
     DevCamera cam;
     // next-event estimation: one area emitter = the triangles carrying its id, in index order
+    int has_null;              // some BSDF has a null (pass-through) component: the look-through code of the FULL kernels is live
     int n_emitters;
     const float *em_sel_cdf;   // [n_emitters + 1] emitter pmf (Scene::configure, samplingWeight = 1)
     float em_sel_norm;         // DiscreteDistribution::getNormalization()
@@ -517,8 +518,11 @@ D Mat load_material(const DevScene &S, int id) {
     return M;
 }
 D bool mat_is_smooth(const Mat &M) { return M.type == PPG_BSDF_DIFFUSE || M.type == PPG_BSDF_ROUGHCONDUCTOR || M.type == PPG_BSDF_PLASTIC; }
-D bool mat_two_sided(const Mat &M) { return (M.flags & PPG_MAT_TWOSIDED) && M.type != PPG_BSDF_DIELECTRIC; }
-D bool mat_backside_or_transmission(const Mat &M) { return (M.flags & PPG_MAT_TWOSIDED) || M.type == PPG_BSDF_DIELECTRIC; }
+D bool mat_two_sided(const Mat &M) { return (M.flags & PPG_MAT_TWOSIDED) && M.type != PPG_BSDF_DIELECTRIC && M.type != PPG_BSDF_THINDIELECTRIC; }
+D bool mat_backside_or_transmission(const Mat &M) {
+    return (M.flags & PPG_MAT_TWOSIDED) || M.type == PPG_BSDF_DIELECTRIC || M.type == PPG_BSDF_THINDIELECTRIC;
+}
+D bool mat_has_null(const Mat &M) { return M.type == PPG_BSDF_THINDIELECTRIC; }  // getType() & ENull
 
 D F3 cdiv3(F3 a, F3 b) { return f3(a.x / b.x, a.y / b.y, a.z / b.z); }
 D F3 safe_sqrt3(F3 s) { return f3(__builtin_sqrtf(ppg_max(0.0f, s.x)), __builtin_sqrtf(ppg_max(0.0f, s.y)), __builtin_sqrtf(ppg_max(0.0f, s.z))); }
@@ -634,6 +638,15 @@ D F3 plastic_diff_term(const Mat &M) {
     return div3(M.refl, 1 - M.fdr_int);
 }
 
+// thindielectric.cpp:160-164: slab reflectance incl. internal reflections R' = R + TRT + TR^3T + ..
+D float thin_R(const Mat &M, float cosThetaI) {
+    float Rr = fresnel_dielectric_ext(ppg_abs(cosThetaI), M.eta.x), Tt = 1 - Rr;
+    if (Rr < 1) Rr += Tt * Tt * Rr / (1 - Rr * Rr);
+    return Rr;
+}
+// BSDF::eval(BSDFSamplingRecord(its, -wo, wo), EDiscrete) restricted to the null component: what a ray going straight through keeps
+D F3 mat_eval_null(const Mat &M, float cosThetaI) { return M.spec * (1 - thin_R(M, cosThetaI)); }
+
 // one-sided plugins, solid-angle measure
 D F3 mat_eval_one(const Mat &M, F3 wi, F3 wo) {
     if (M.type == PPG_BSDF_DIFFUSE) return diffuse_eval(M.refl, wi, wo);
@@ -670,8 +683,8 @@ D float mat_pdf_one(const Mat &M, F3 wi, F3 wo) {
     }
     return 0.0f;
 }
-D F3 mat_sample_one(const Mat &M, F3 wi, float sx, float sy, F3 &wo, float &pdf, bool &delta, float &eta) {
-    delta = false; eta = 1.0f; pdf = 0.0f; wo = f3s(0.0f);
+D F3 mat_sample_one(const Mat &M, F3 wi, float sx, float sy, F3 &wo, float &pdf, bool &delta, float &eta, bool &isnull) {
+    delta = false; eta = 1.0f; pdf = 0.0f; wo = f3s(0.0f); isnull = false;
     switch (M.type) {
         case PPG_BSDF_DIFFUSE:
             if (wi.z <= 0) return f3s(0.0f);
@@ -730,6 +743,19 @@ D F3 mat_sample_one(const Mat &M, F3 wi, float sx, float sy, F3 &wo, float &pdf,
             float factor = cosThetaT < 0 ? invEta : e;
             return M.spec * (factor * factor);
         }
+        case PPG_BSDF_THINDIELECTRIC: {  // thindielectric.cpp:203-232
+            const float Rr = thin_R(M, wi.z);
+            delta = true;
+            if (sx <= Rr) {
+                wo = f3(-wi.x, -wi.y, wi.z);
+                pdf = Rr;
+                return M.refl;
+            }
+            isnull = true;
+            wo = -wi;  // transmit()
+            pdf = 1 - Rr;
+            return M.spec;
+        }
     }
     return f3s(0.0f);
 }
@@ -742,10 +768,10 @@ D float mat_pdf(const Mat &M, F3 wi, F3 wo) {
     if (mat_two_sided(M) && !(wi.z > 0)) { wi.z *= -1; wo.z *= -1; }
     return mat_pdf_one(M, wi, wo);
 }
-D F3 mat_sample(const Mat &M, F3 wi, float sx, float sy, F3 &wo, float &pdf, bool &delta, float &eta) {
+D F3 mat_sample(const Mat &M, F3 wi, float sx, float sy, F3 &wo, float &pdf, bool &delta, float &eta, bool &isnull) {
     bool flipped = false;
     if (mat_two_sided(M) && wi.z < 0) { wi.z *= -1; flipped = true; }
-    F3 result = mat_sample_one(M, wi, sx, sy, wo, pdf, delta, eta);
+    F3 result = mat_sample_one(M, wi, sx, sy, wo, pdf, delta, eta, isnull);
     if (flipped && !iszero3(result) && pdf != 0) wo.z *= -1;
     return result;
 }

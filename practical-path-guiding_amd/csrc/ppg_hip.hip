@@ -283,6 +283,8 @@ struct ppg_ctx {
 
     // film
     DevBuf<float> d_image, d_sq, d_imageW, d_film, d_filmW, d_var, d_lum, d_tmp;
+    float *h_lum = nullptr;  // pinned staging of d_lum (variance sum on the host, finishPasses)
+    size_t h_lumCap = 0;
     std::vector<DevBuf<float>> images;  // inverse-variance copies (weight-normalised)
     std::vector<float> variances;
 
@@ -617,7 +619,7 @@ int renderBatch(ppg_ctx *ctx, int batch) {
             const int small = smallScene ? 1 : 0;
             // dynamic LDS: the staged triangles (fused, or luminaire sampling on a small scene) or the shadow rays' BVH stack columns
             const size_t neeBytes = smallScene ? triBytes : (size_t)PPG_LDS_STACK * PPG_BLOCK * 4;
-            const size_t lds = fused ? triBytes : (neeOn ? neeBytes : 0);
+            const size_t lds = fused ? triBytes : ((neeOn || ctx->scene.has_null) ? neeBytes : 0);
 #define PPG_SHADE(F, N, M) hipLaunchKernelGGL((k_shade<F, N, M>), dim3(grid), dim3(PPG_BLOCK), lds, s, P, S, T, R, Q, qin, qout, small)
             const int variant = (fused ? 4 : 0) | (neeOn ? 2 : 0) | (fullMats ? 1 : 0);
             switch (variant) {
@@ -741,17 +743,16 @@ int finishPasses(ppg_ctx *ctx, ppg_pass_stats *st) {  // GP:1288-1328
         HIP_CHECK(ctx->images.back().reserve(3 * (size_t)n));
         hipLaunchKernelGGL(k_normalise, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, ctx->d_image.p, ctx->d_imageW.p, ctx->images.back().p);
     }
-    hipLaunchKernelGGL(k_variance, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, N, ctx->d_image.p, ctx->d_sq.p, ctx->d_imageW.p, ctx->d_var.p, ctx->d_lum.p);
-    std::vector<float> lum(n);
+    hipLaunchKernelGGL(k_variance, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, ctx->W, N, ctx->d_image.p, ctx->d_sq.p, ctx->d_imageW.p, ctx->d_var.p, ctx->d_lum.p);
+    float *lum = ctx->h_lum;  // pinned
     std::vector<BlockStats> bs((size_t)ctx->nBlocks);
-    HIP_CHECK(hipMemcpyAsync(lum.data(), ctx->d_lum.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipMemcpyAsync(lum, ctx->d_lum.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_CHECK(hipMemcpyAsync(bs.data(), ctx->d_stats.p, bs.size() * sizeof(BlockStats), hipMemcpyDeviceToHost, ctx->stream));
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
     BlockStats c{};
     for (const BlockStats &x : bs) { c.rays += x.rays; c.path_len += x.path_len; c.committed += x.committed; }
     float variance = 0;  // summed in the reference's x-major order (GP:1303-1311)
-    for (int x = 0; x < ctx->W; ++x)
-        for (int y = 0; y < ctx->H; ++y) variance += lum[(size_t)y * ctx->W + x];
+    for (int k = 0; k < n; ++k) variance += lum[k];  // k = x * H + y
     variance /= (float)ctx->W * ctx->H * (N - 1);
     if (ctx->sampleCombination == 2) ctx->variances.push_back(variance);
     ctx->lastVariance = variance;
@@ -771,6 +772,12 @@ int allocFilm(ppg_ctx *ctx) {
     HIP_CHECK(ctx->d_image.reserve(3 * n)); HIP_CHECK(ctx->d_sq.reserve(3 * n)); HIP_CHECK(ctx->d_imageW.reserve(n));
     HIP_CHECK(ctx->d_film.reserve(3 * n)); HIP_CHECK(ctx->d_filmW.reserve(n)); HIP_CHECK(ctx->d_var.reserve(3 * n));
     HIP_CHECK(ctx->d_lum.reserve(n)); HIP_CHECK(ctx->d_tmp.reserve(3 * n));
+    if (ctx->h_lumCap < n) {
+        if (ctx->h_lum) (void)hipHostFree(ctx->h_lum);
+        ctx->h_lum = nullptr; ctx->h_lumCap = 0;
+        HIP_CHECK(hipHostMalloc((void **)&ctx->h_lum, n * sizeof(float), hipHostMallocDefault));
+        ctx->h_lumCap = n;
+    }
     return PPG_OK;
 }
 
@@ -1064,6 +1071,7 @@ void ppg_destroy(ppg_ctx *ctx) {
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); }
     ctx->timer.resolve();
     for (auto e : ctx->timer.pool) (void)hipEventDestroy(e);
+    if (ctx->h_lum) (void)hipHostFree(ctx->h_lum);
     hipStream_t s = ctx->stream;
     delete ctx;
     if (s) (void)hipStreamDestroy(s);
@@ -1079,7 +1087,7 @@ int ppg_set_scene(ppg_ctx *ctx, const ppg_scene *s) {
     HIP_CHECK(hipSetDevice(ctx->device));
     for (uint32_t t = 0; t < s->n_triangles; ++t) {
         if (s->tri_material[t] >= s->n_materials || s->tri_emitter[t] >= (int32_t)s->n_emitters) { ctx->error = "index out of range"; return PPG_ERR_INVALID; }
-        if (s->materials[s->tri_material[t]].type < 0 || s->materials[s->tri_material[t]].type > PPG_BSDF_DIELECTRIC) { ctx->error = "unsupported BSDF type"; return PPG_ERR_INVALID; }
+        if (s->materials[s->tri_material[t]].type < 0 || s->materials[s->tri_material[t]].type > PPG_BSDF_LAST) { ctx->error = "unsupported BSDF type"; return PPG_ERR_INVALID; }
         for (int k = 0; k < 3; ++k) if (s->indices[3 * t + k] >= s->n_vertices) { ctx->error = "vertex index out of range"; return PPG_ERR_INVALID; }
     }
     // Scene::getAABB(): kd-tree box enlarged by MTS_KD_AABB_EPSILON (gkdtree.h:1213-1220) + sensor position (scene.cpp:386-414)
@@ -1137,15 +1145,17 @@ int ppg_set_scene(ppg_ctx *ctx, const ppg_scene *s) {
     // GGX alpha clamped (microfacet.h:135), plastic's internal diffuse Fresnel reflectance (plastic.cpp:191-193)
     std::vector<float4> mats(4 * (size_t)s->n_materials), ems(std::max<uint32_t>(1, s->n_emitters));
     ctx->fullMaterials = false;
+    bool hasNull = false;
     for (uint32_t i = 0; i < s->n_materials; ++i) {
         ppg_material m = s->materials[i];
         if (m.type == PPG_BSDF_DIFFUSE && m.flags == PPG_MAT_TWOSIDED) { m.type = PPG_BSDF_TWOSIDED_DIFFUSE; m.flags = 0; }
         if (m.type == PPG_BSDF_TWOSIDED_DIFFUSE) m.flags &= ~PPG_MAT_TWOSIDED;
         if (m.type == PPG_BSDF_MIRROR) for (int c = 0; c < 3; ++c) { m.eta[c] = 0.0f; m.k[c] = 1.0f; }
         if (m.type == PPG_BSDF_ROUGHCONDUCTOR) m.alpha = ppg_max(m.alpha, 1e-4f);
-        if ((m.type == PPG_BSDF_PLASTIC || m.type == PPG_BSDF_DIELECTRIC) && !(m.eta[0] > 0)) { ctx->error = "plastic / dielectric need eta[0] = intIOR / extIOR > 0"; return PPG_ERR_INVALID; }
+        if ((m.type == PPG_BSDF_PLASTIC || m.type == PPG_BSDF_DIELECTRIC || m.type == PPG_BSDF_THINDIELECTRIC) && !(m.eta[0] > 0)) { ctx->error = "plastic / dielectric need eta[0] = intIOR / extIOR > 0"; return PPG_ERR_INVALID; }
         const float fdrInt = m.type == PPG_BSDF_PLASTIC ? ppg_fresnel_diffuse_reflectance(1 / m.eta[0]) : 0.0f;
         if (m.type > PPG_BSDF_MIRROR || m.flags != 0) ctx->fullMaterials = true;
+        if (m.type == PPG_BSDF_THINDIELECTRIC) hasNull = true;
         mats[4 * i + 0] = make_float4(m.reflectance[0], m.reflectance[1], m.reflectance[2], (float)m.type);
         mats[4 * i + 1] = make_float4(m.specular[0], m.specular[1], m.specular[2], m.alpha);
         mats[4 * i + 2] = make_float4(m.eta[0], m.eta[1], m.eta[2], __builtin_bit_cast(float, m.flags));
@@ -1239,7 +1249,7 @@ int ppg_set_scene(ppg_ctx *ctx, const ppg_scene *s) {
     }
     DevScene &S = ctx->scene;
     S.tris = ctx->d_tris.p; S.accel = ctx->d_accel.p; S.normals = s->normals ? ctx->d_normals.p : nullptr; S.bvh = ctx->d_bvh.p; S.bvh4 = ctx->d_bvh4.p;
-    S.materials = ctx->d_materials.p; S.emitters = ctx->d_emitters.p; S.n_tris = (int)s->n_triangles;
+    S.materials = ctx->d_materials.p; S.emitters = ctx->d_emitters.p; S.n_tris = (int)s->n_triangles; S.has_null = hasNull ? 1 : 0;
     memcpy(S.cam.s2c, s->camera.sample_to_camera, 64); memcpy(S.cam.c2w, s->camera.camera_to_world, 64);
     S.cam.near_clip = s->camera.near_clip; S.cam.far_clip = s->camera.far_clip;
     S.cam.width = s->camera.width; S.cam.height = s->camera.height;

@@ -26,7 +26,8 @@ enum { DF_NEAREST = 0, DF_BOX = 1 };
 enum { LOSS_NONE = 0, LOSS_KL = 1, LOSS_VAR = 2 };
 
 // flags word of a path
-#define FL_DEPTH_MASK 0x000fffffu  // rRec.depth
+#define FL_DEPTH_MASK 0x0007ffffu  // rRec.depth
+#define FL_PEND_NULL (1u << 19)    // the sampled bounce was a null (pass-through) interaction, GP:2045-2075
 #define FL_NV_SHIFT 20             // nVertices (0..32), 6 bits
 #define FL_NV_MASK (0x3fu << FL_NV_SHIFT)
 #define FL_SCATTERED (1u << 26)
@@ -608,6 +609,42 @@ D bool shadow_occluded(const DevScene &S, const float4 *small_tris, int *stack_c
     return trace_closest4<true>(S, stack_col, PPG_BLOCK, o, d, rayMinT, maxt).prim >= 0;
 }
 
+// closest hit for rays traced inside k_shade (look-through / transmittance loops): LDS brute force or BVH4 with the lane's stack column
+D Hit trace_inline(const DevScene &S, const float4 *small_tris, int *stack_col, F3 o, F3 d, float maxt) {
+    if (small_tris) return trace_small(small_tris, S, o, d, PPG_EPSILON, maxt);
+    float rayMinT = PPG_EPSILON;  // adaptive ray epsilon, skdtree.cpp:125-129
+    rayMinT *= ppg_max(ppg_max(ppg_max(ppg_abs(o.x), ppg_abs(o.y)), ppg_abs(o.z)), PPG_EPSILON);
+    return trace_closest4<false>(S, stack_col, PPG_BLOCK, o, d, rayMinT, maxt);
+}
+
+// Scene::evalTransmittance (scene.cpp:619-679), surfaces only, for scenes with null-component BSDFs: zero behind an occluder,
+// otherwise the product of the null components (evaluated in the geometric frame) of the surfaces passed.
+D F3 shadow_transmittance(const DevScene &S, const float4 *small_tris, int *stack_col, F3 p1, F3 d, float remaining, int maxInteractions,
+                          unsigned int &traced) {
+    const float lengthFactor = 1 - PPG_SHADOW_EPSILON;
+    F3 o = p1;
+    float maxt = remaining * lengthFactor;
+    F3 transmittance = f3s(1.0f);
+    int interactions = 0;
+    while (remaining > 0) {
+        ++traced;
+        const Hit h = trace_inline(S, small_tris, stack_col, o, d, maxt);
+        const bool surface = h.prim >= 0;
+        Mat M;
+        Isect I;
+        if (surface) { fill_isect(S, h, d, I); M = load_material(S, I.material); }
+        if (surface && (interactions == maxInteractions || !mat_has_null(M))) return f3s(0.0f);
+        if (!surface || iszero3(transmittance)) break;
+        const float cosThetaI = dot3(I.geoN, -d);
+        transmittance = mul3(transmittance, mat_eval_null(M, cosThetaI));
+        if (++interactions > 100) break;
+        o = o + d * h.t;
+        remaining -= h.t;
+        maxt = remaining * lengthFactor;
+    }
+    return transmittance;
+}
+
 // LDS the next-event-estimation variants add to k_shade / k_tail
 struct NeeLds {
     const float4 *small_tris;  // staged triangles (small scenes) or nullptr
@@ -651,18 +688,61 @@ D void shade_slice(const PathState &P, const DevScene &S, const DevTree &T, cons
             if (valid) fill_isect(S, h, d, I);
             bool go = true;
 
-            if (flags & FL_PENDING) {
+            if (FULL && (flags & FL_PENDING) && (flags & FL_PEND_NULL)) {
+                // ---- the previous bounce passed straight through a null component, GP:2045-2075: no emitter lookup, no MIS,
+                // no Russian roulette; rRec.type = scattered ? ERadianceNoEmission : ERadiance; rRec.depth++; continue ----
+                if (flags & FL_SCATTERED) flags &= ~FL_EMITTED_OK; else flags |= FL_EMITTED_OK;
+                ++depth;
+                if (!((int)depth <= R.max_depth || R.max_depth < 0)) go = false;
+                flags &= ~(FL_PENDING | FL_PEND_TREE | FL_PEND_DELTA | FL_PEND_REFN | FL_PEND_NULL);
+            } else if (flags & FL_PENDING) {
                 // ---- second half of the previous bounce: GP:2078-2145 ----
                 F3 value = valid ? eval_Le(S, I, -d) : f3s(0.0f);  // rayIntersectAndLookForEmitter, GP:2229-2234
+                // dRec.setQuery(ray, its) of the emitter that was found (records.inl:170-178)
+                F3 em_n = I.n;
+                float em_dist = h.t;
+                int em_id = I.emitter;
+                if (FULL && S.has_null && valid && I.emitter < 0) {
+                    // rayIntersectAndLookForEmitter GP:2184-2245: the path continues from THIS hit, but the search for an emitter
+                    // goes on through surfaces that have a null component (traced in place)
+                    Mat Mc = load_material(S, I.material);
+                    if (mat_has_null(Mc)) {
+                        const float4 ro4 = P.ray_o[i];
+                        F3 ro = f3(ro4.x, ro4.y, ro4.z);
+                        F3 transmittance = f3s(1.0f);
+                        const int maxInteractions = R.max_depth - (int)depth - 1;
+                        int interactions = 0;
+                        bool abandoned = false, surface = true;
+                        Hit hc = h;
+                        Isect Ic = I;
+                        for (;;) {
+                            if (interactions == maxInteractions || !mat_has_null(Mc) || Ic.emitter >= 0) break;
+                            if (iszero3(transmittance)) { abandoned = true; break; }
+                            const float cosThetaI = -to_local(Ic, d).z;  // bRec(its, -wo, wo) in the shading frame
+                            transmittance = mul3(transmittance, mat_eval_null(Mc, cosThetaI));
+                            ro = ro + d * hc.t;
+                            if (++interactions > 100) { abandoned = true; break; }
+                            hc = trace_inline(S, nee.small_tris, nee.stack_col, ro, d, __builtin_inff());
+                            ++traced;
+                            if (hc.prim < 0) { surface = false; break; }
+                            fill_isect(S, hc, d, Ic);
+                            Mc = load_material(S, Ic.material);
+                        }
+                        if (!abandoned && surface && Ic.emitter >= 0) {
+                            value = mul3(transmittance, eval_Le(S, Ic, -d));
+                            em_n = Ic.n; em_dist = hc.t; em_id = Ic.emitter;  // dist from the LAST ray origin, as in the reference
+                        }
+                    }
+                }
                 const float woPdf = l4.w;
                 const bool isDelta = (flags & FL_PEND_DELTA) != 0;
                 const bool hasTree = (flags & FL_PEND_TREE) != 0;
                 float emitterPdf = 0.0f;  // GP:2085: scene->pdfEmitterDirect(dRec) (scene.cpp:949-952, area.cpp:175-183, shape.cpp:117-126)
                 if (NEE && R.do_nee && !isDelta && !iszero3(value)) {
                     float pdfDirect = 0.0f;
-                    const float dn = dot3(d, I.n);
+                    const float dn = dot3(d, em_n);
                     if ((flags & FL_PEND_REFN) && dn < 0)
-                        pdfDirect = __int_as_float(S.em_info[I.emitter].w) * (h.t * h.t) / ppg_abs(dn);
+                        pdfDirect = __int_as_float(S.em_info[em_id].w) * (em_dist * em_dist) / ppg_abs(dn);
                     emitterPdf = pdfDirect * (1.0f * S.em_sel_norm);
                 }
                 float pa = woPdf * woPdf, pb = emitterPdf * emitterPdf;  // miWeight(woPdf, emitterPdf), GP:2247-2250
@@ -732,8 +812,10 @@ D void shade_slice(const PathState &P, const DevScene &S, const DevTree &T, cons
                 auto b_eval = [&](F3 wi_, F3 wo_) { return FULL ? mat_eval(M, wi_, wo_) : bsdf_eval(M.type, M.refl, wi_, wo_); };
                 auto b_pdf = [&](F3 wi_, F3 wo_) { return FULL ? mat_pdf(M, wi_, wo_) : bsdf_pdf(M.type, wi_, wo_); };
                 float sampledEta = 1.0f;
+                bool sampledNull = false;
                 auto b_sample = [&](float u_, float v_, F3 &wo_, float &pdf_, bool &delta_) {
-                    return FULL ? mat_sample(M, I.wi, u_, v_, wo_, pdf_, delta_, sampledEta) : bsdf_sample(M.type, M.refl, I.wi, u_, v_, wo_, pdf_, delta_);
+                    return FULL ? mat_sample(M, I.wi, u_, v_, wo_, pdf_, delta_, sampledEta, sampledNull)
+                                : bsdf_sample(M.type, M.refl, I.wi, u_, v_, wo_, pdf_, delta_);
                 };
                 F3 vox = f3s(0.0f);
                 int leaf = 0;
@@ -771,7 +853,7 @@ D void shade_slice(const PathState &P, const DevScene &S, const DevTree &T, cons
                         float cx, cy;
                         dtree_sample(T, hd, key, dim, cx, cy);
                         wo_l = to_local(I, canonical_to_dir(cx, cy));
-                        sampledEta = 1.0f;
+                        sampledEta = 1.0f; sampledNull = false;
                         result = b_eval(I.wi, wo_l);
                     }
                     if (zero) {
@@ -806,12 +888,18 @@ D void shade_slice(const PathState &P, const DevScene &S, const DevTree &T, cons
                     DirectSample ds;
                     F3 value = emitter_sample_direct(S, I.p, refN, ex, ey, ds);
                     if (ds.pdf != 0) {
-                        ++traced;
-                        if (shadow_occluded(S, nee.small_tris, nee.stack_col, I.p, ds.d, ds.dist * (1 - PPG_SHADOW_EPSILON))) {
-                            value = f3s(0.0f);
+                        if (FULL && S.has_null) {  // value *= evalTransmittance(...) / emPdf, scene.cpp:887-889
+                            const F3 tr = shadow_transmittance(S, nee.small_tris, nee.stack_col, I.p, ds.d, ds.dist, R.max_depth - (int)depth - 1, traced);
+                            if (iszero3(tr)) value = f3s(0.0f);
+                            else { value = div3(mul3(value, tr), ds.em_pdf); ds.pdf *= ds.em_pdf; }
                         } else {
-                            value = div3(value, ds.em_pdf);
-                            ds.pdf *= ds.em_pdf;
+                            ++traced;
+                            if (shadow_occluded(S, nee.small_tris, nee.stack_col, I.p, ds.d, ds.dist * (1 - PPG_SHADOW_EPSILON))) {
+                                value = f3s(0.0f);
+                            } else {
+                                value = div3(value, ds.em_pdf);
+                                ds.pdf *= ds.em_pdf;
+                            }
                         }
                     }
                     if (!iszero3(value)) {
@@ -889,6 +977,9 @@ D void shade_slice(const PathState &P, const DevScene &S, const DevTree &T, cons
                         }
                         flags |= FL_PENDING | (smooth ? FL_PEND_TREE : 0u) | (sampledDelta ? FL_PEND_DELTA : 0u);
                         if (NEE && dot3(wo, refN) >= 0) flags |= FL_PEND_REFN;
+                        // GP:2045-2075: a sampled null interaction.  (Its vertex record, GP:2051-2068, needs a D-tree, i.e. a smooth/null
+                        // hybrid such as `mask`; the only null BSDF supported, thindielectric, is all-delta and has none.)
+                        if (FULL && sampledNull) flags |= FL_PEND_NULL;
                         m.w = (unsigned int)leaf;
                         l4.w = woPdf;
                         alive = true;
@@ -915,7 +1006,8 @@ __global__ __launch_bounds__(PPG_BLOCK, PPG_SHADE_WAVES) void k_shade(PathState 
     __shared__ unsigned int out_count;
     __shared__ unsigned long long acc;
     const float4 *lds_tris = (const float4 *)lds_raw;
-    const bool staged = FUSED || (NEE && small_scene);  // dynamic LDS: the triangles (small scenes) or the shadow rays' BVH stack columns
+    // dynamic LDS: the triangles (small scenes) or the BVH stack columns of the rays traced in place (shadow rays, look-through)
+    const bool staged = FUSED || ((NEE || (FULL && S.has_null)) && small_scene);
     if (staged) {
         for (int k = threadIdx.x; k < 3 * S.n_tris; k += blockDim.x) ((float4 *)lds_raw)[k] = S.accel_small[k];
     }
@@ -935,7 +1027,7 @@ __global__ __launch_bounds__(PPG_BLOCK, PPG_SHADE_WAVES) void k_shade(PathState 
     __syncthreads();
     if (threadIdx.x == 0) Q.count[qout][b] = out_count;
     block_add_u64(&acc, &Q.stats[b].path_len, plen_sum);
-    if (FUSED || NEE) block_add_u64(&acc, &Q.stats[b].rays, traced);
+    if (FUSED || NEE || FULL) block_add_u64(&acc, &Q.stats[b].rays, traced);
     if (NEE) block_add_u64(&acc, &Q.stats[b].committed, committed);
 }
 
@@ -977,7 +1069,7 @@ __global__ __launch_bounds__(PPG_BLOCK, PPG_SHADE_WAVES) void k_tail(PathState P
     }
     if (threadIdx.x == 0) { Q.count[0][b] = 0; Q.count[1][b] = 0; }
     block_add_u64(&acc, &Q.stats[b].path_len, plen_sum);
-    block_add_u64(&acc, &Q.stats[b].rays, traced + (NEE ? shadow : 0u));
+    block_add_u64(&acc, &Q.stats[b].rays, traced + ((NEE || FULL) ? shadow : 0u));
     if (NEE) block_add_u64(&acc, &Q.stats[b].committed, committed);
 }
 
@@ -1127,8 +1219,9 @@ __global__ void k_film(PathState P, int spp, float *image, float *sq_image, floa
     image_w[pixel] = iw; film_w[pixel] = fw;
 }
 
-// per-pixel variance estimate of performRenderPasses (GP:1300-1311); the clamped luminance goes to `lum`
-__global__ void k_variance(int n, int N, const float *image, const float *sq_image, const float *image_w, float *var_rgb, float *lum) {
+// per-pixel variance estimate of performRenderPasses (GP:1300-1311); the clamped luminance goes to `lum`, stored x-major
+// (index x * H + y) — the order the reference's serial loop sums it in, so the host adds a contiguous array
+__global__ void k_variance(int n, int W, int N, const float *image, const float *sq_image, const float *image_w, float *var_rgb, float *lum) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float w = image_w[i];
@@ -1138,7 +1231,8 @@ __global__ void k_variance(int n, int N, const float *image, const float *sq_ima
     F3 localVar = sq - div3(mul3(pixel, pixel), (float)N);
     var_rgb[3 * i] = localVar.x; var_rgb[3 * i + 1] = localVar.y; var_rgb[3 * i + 2] = localVar.z;
     float l = localVar.x * 0.212671f + localVar.y * 0.715160f + localVar.z * 0.072169f;
-    lum[i] = ppg_min(l, 10000.0f);
+    const int x = i % W, y = i / W, H = n / W;
+    lum[(size_t)x * H + y] = ppg_min(l, 10000.0f);
 }
 
 __global__ void k_normalise(int n, const float *rgb_sum, const float *w, float *out) {

@@ -66,7 +66,7 @@ class Material(C.Structure):
     _fields_ = [("type", C.c_int32), ("reflectance", C.c_float * 3), ("specular", C.c_float * 3), ("alpha", C.c_float),
                 ("eta", C.c_float * 3), ("k", C.c_float * 3), ("flags", C.c_int32), ("_reserved", C.c_int32)]
 
-    BSDF = dict(diffuse=0, twosided_diffuse=1, mirror=2, conductor=3, roughconductor=4, plastic=5, dielectric=6)
+    BSDF = dict(diffuse=0, twosided_diffuse=1, mirror=2, conductor=3, roughconductor=4, plastic=5, dielectric=6, thindielectric=7)
 
     @classmethod
     def from_dict(cls, m):

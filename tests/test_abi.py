@@ -69,7 +69,7 @@ def test_unknown_property_name_is_an_error():
 def test_oracle_rejects_unknown_bsdf_type(oracle_lib):
     import ppg_host
     scene = ppg_host.cbox_scene(8, 8)
-    scene.materials[0]["type"] = 7
+    scene.materials[0]["type"] = 99
     e = ppg_host.Engine(oracle_lib, "ppgo_", budgetType="spp", budget=4)
     with pytest.raises(ppg_host.PPGError):
         e.set_scene(scene)

@@ -202,3 +202,25 @@ def test_flags(oracle_lib):
     assert flags(dict(type="diffuse")) == (1, 0, 0) and flags(dict(type=1)) == (1, 0, 1)
     assert flags(dict(type="mirror")) == (0, 1, 0) and flags(dict(type="conductor", twosided=True)) == (0, 1, 1)
     assert flags(GOLD) == (1, 0, 0) and flags(dict(type="plastic")) == (1, 0, 0) and flags(dict(type="dielectric")) == (0, 1, 1)
+
+
+def test_thindielectric_null_component(oracle_lib):
+    eta = 1.5
+    mat = dict(type="thindielectric", eta=eta, reflectance=(1, 1, 1), specular=(0.9, 0.95, 1.0))
+    rng = np.random.RandomState(6)
+    xy = rng.rand(200000, 2).astype(np.float32)
+    for wi in (unit((0, 0, 1)), unit((0.6, 0.1, -0.5)), unit((0.95, 0, 0.1))):
+        wo, w, pdf, e, delta = bsdf_sample(oracle_lib, mat, wi, xy)
+        ci = abs(float(wi[2])); ct = np.sqrt(1 - (1 - ci * ci) / eta ** 2)
+        R = 0.5 * (((ci - eta * ct) / (ci + eta * ct)) ** 2 + ((eta * ci - ct) / (eta * ci + ct)) ** 2)
+        Rp = R + (1 - R) ** 2 * R / (1 - R * R)  # = 2R / (1 + R): all internal bounces of the slab
+        assert abs(Rp - 2 * R / (1 + R)) < 1e-12
+        refl = wo[:, 2] * wi[2] > 0
+        assert np.all(delta == 1) and np.all(e == 1)
+        assert abs(refl.mean() - Rp) < 0.004 and np.allclose(pdf[refl], Rp, atol=1e-6) and np.allclose(pdf[~refl], 1 - Rp, atol=1e-6)
+        assert np.allclose(wo[refl], wi * [-1, -1, 1], atol=1e-7) and np.allclose(wo[~refl], -wi, atol=1e-7)  # straight through
+        assert np.allclose(w[refl], 1) and np.allclose(w[~refl], np.float32([0.9, 0.95, 1.0]))
+    m = Material.from_dict(mat)
+    a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+    oracle_lib.ppgo_bsdf_flags(C.byref(m), C.byref(a), C.byref(b), C.byref(c))
+    assert (a.value, b.value, c.value) == (0, 1, 1)

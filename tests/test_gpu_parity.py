@@ -473,3 +473,62 @@ def test_glossy_plastic_and_glass_materials_against_oracle(oracle_lib, extra):
     assert_tree_equal(g.read_sdtree(), o.read_sdtree())
     plain = ppg_host.GuidedPathTracer(engine=hip(**props)).render(ppg_host.cbox_scene(72, 72))
     assert np.nanmean(np.abs(ig - plain)) > 5e-3
+
+
+def _pane_scene(res):
+    """CBOX + two thin-dielectric panes: a horizontal one between the (upward-facing) luminaire and the ceiling and a vertical
+    "window" across the room — most paths cross a null component, emitters are found through one or two panes."""
+    import ppg_host
+    scene = ppg_host.cbox_scene(*res)
+    base_v = len(scene.positions)
+    quads = [[(150, 510, 170), (400, 510, 170), (400, 510, 390), (150, 510, 390)],   # above the luminaire
+             [(20, 20, 300), (530, 20, 300), (530, 500, 300), (20, 500, 300)]]       # the window
+    pos = np.array([p for q in quads for p in q], np.float32)
+    idx = np.array([[base_v + 4 * k + a for a in tri] for k in range(len(quads)) for tri in ((0, 1, 2), (0, 2, 3))], np.uint32)
+    scene.positions = np.vstack([scene.positions, pos]).astype(np.float32)
+    scene.indices = np.vstack([scene.indices, idx]).astype(np.uint32)
+    scene.materials = list(scene.materials) + [dict(type="thindielectric", eta=1.5, reflectance=(1, 1, 1), specular=(0.95, 0.97, 0.95))]
+    scene.tri_material = np.concatenate([scene.tri_material, np.full(len(idx), len(scene.materials) - 1)]).astype(np.uint32)
+    scene.tri_emitter = np.concatenate([scene.tri_emitter, np.full(len(idx), -1)]).astype(np.int32)
+    return scene
+
+
+@pytest.mark.parametrize("extra", [{}, dict(nee="always"), dict(nee="kickstart", **IMPROVED), dict(maxDepth=-1, rrDepth=3, strictNormals=0, nee="kickstart"),
+                                   dict(maxDepth=3)],
+                         ids=["default", "nee-always", "nee-kickstart-improved", "unbounded", "depth3-budget"])
+def test_null_component_bsdf_against_oracle(oracle_lib, extra):
+    """thindielectric: Li's null branch (GP:2045-2075: no MIS, no roulette, emission re-enabled only before the first real
+    scattering), emitters found THROUGH null surfaces (GP:2184-2245) within the interaction budget maxDepth - depth - 1, shadow
+    rays attenuated by them (scene.cpp:619-679)."""
+    import ppg_host
+    scene = _pane_scene((64, 64))
+    props = dict(CBOX_PROPS, budget=60, seed=21)
+    props.update(maxDepth=12, rrDepth=5)
+    props.update(extra)
+    g, o = hip(**props), make_oracle(oracle_lib, threads=os.cpu_count() or 8, **props)
+    gg, go = ppg_host.GuidedPathTracer(engine=g), ppg_host.GuidedPathTracer(engine=o)
+    ig, io = gg.render(scene), go.render(scene)
+    assert _stats(gg) == _stats(go)
+    assert np.array_equal(ig, io, equal_nan=True)
+    assert_tree_equal(g.read_sdtree(), o.read_sdtree())
+    plain = ppg_host.GuidedPathTracer(engine=hip(**props)).render(ppg_host.cbox_scene(64, 64))
+    assert np.nanmean(np.abs(ig - plain)) > 2e-3
+
+
+def test_null_component_bsdf_on_a_bvh_scene(oracle_lib):
+    import ppg_host
+    scene = ppg_host.room_scene(96, 54, n_boxes=200, tess=4)
+    # a large pane across the room below the slit light
+    base_v = len(scene.positions)
+    pos = np.array([(0.2, 2.2, 0.2), (3.8, 2.2, 0.2), (3.8, 2.2, 4.8), (0.2, 2.2, 4.8)], np.float32)
+    scene.positions = np.vstack([scene.positions, pos]).astype(np.float32)
+    scene.indices = np.vstack([scene.indices, [[base_v, base_v + 1, base_v + 2], [base_v, base_v + 2, base_v + 3]]]).astype(np.uint32)
+    scene.materials = list(scene.materials) + [dict(type="thindielectric", eta=1.33, reflectance=(1, 1, 1), specular=(1, 1, 1))]
+    scene.tri_material = np.concatenate([scene.tri_material, [len(scene.materials) - 1] * 2]).astype(np.uint32)
+    scene.tri_emitter = np.concatenate([scene.tri_emitter, [-1, -1]]).astype(np.int32)
+    props = dict(budgetType="spp", budget=28, maxDepth=9, rrDepth=5, seed=8, sTreeThreshold=2000, nee="kickstart")
+    g, o = hip(**props), make_oracle(oracle_lib, threads=os.cpu_count() or 8, **props)
+    gg, go = ppg_host.GuidedPathTracer(engine=g), ppg_host.GuidedPathTracer(engine=o)
+    ig, io = gg.render(scene), go.render(scene)
+    assert _stats(gg) == _stats(go) and ig.mean() > 1e-3 and np.array_equal(ig, io)
+    assert_tree_equal(g.read_sdtree(), o.read_sdtree())

@@ -1,24 +1,40 @@
-import sys, time, os
+"""Wall time per phase of render() (begin_iteration = S-tree refine on the host mirror + upload + D-tree reset;
+passes; finish = variance; build).  usage: phase_timing.py [cbox|room] [passes]"""
+import sys, time
 sys.path.insert(0, '/root/repo/practical-path-guiding_amd')
-import torch, ppg_host
-props = dict(budgetType="spp", sppPerPass=4, maxDepth=10, rrDepth=10, strictNormals=1, seed=1234, budget=4.0*255)
-scene = ppg_host.cbox_scene(1280, 720)
-WORLD = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+import torch, ppg_host  # noqa
+which = sys.argv[1] if len(sys.argv) > 1 else "cbox"
+n_pass = int(sys.argv[2]) if len(sys.argv) > 2 else (255 if which == "cbox" else 127)
+if which == "cbox":
+    props = dict(budgetType="spp", sppPerPass=4, maxDepth=10, rrDepth=10, strictNormals=1, seed=1234)
+    scene = ppg_host.cbox_scene(1280, 720)
+else:
+    props = dict(budgetType="spp", sppPerPass=1, seed=1234, sampleCombination="inversevar", bsdfSamplingFractionLoss="kl", spatialFilter="stochastic",
+                 directionalFilter="box", sTreeThreshold=4000)
+    scene = ppg_host.room_scene(1280, 720, n_boxes=1820, tess=8)
+props["budget"] = float(n_pass * props["sppPerPass"])
+passes, it, left = [], 0, n_pass
+while left > 0:
+    p = min(left, 1 << it)
+    if left - p < 2 * p:
+        p = left
+    passes.append(p); left -= p; it += 1
 for rep in range(2):
     e = ppg_host.Engine.hip(**props); e.set_scene(scene)
-    if WORLD > 1: e.set_shard(0, WORLD, 32)
-    t = {}
+    t, per_it = {}, []
     def T(name, f, *a):
-        torch.cuda.synchronize(); t0=time.perf_counter(); r=f(*a); torch.cuda.synchronize(); t[name]=t.get(name,0)+time.perf_counter()-t0; return r
-    t0=time.perf_counter()
+        torch.cuda.synchronize(); t0 = time.perf_counter(); r = f(*a); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        t[name] = t.get(name, 0) + dt; return dt
+    t0 = time.perf_counter()
     T('begin_render', e.begin_render)
-    passes=[1,2,4,8,16,32,64,128]
-    for it,p in enumerate(passes):
-        T('begin_iteration', e.begin_iteration, it==len(passes)-1)
-        T('passes', e.render_passes_nostat, p)
+    for it, p in enumerate(passes):
+        a = T('begin_iteration', e.begin_iteration, it == len(passes) - 1)
+        b = T('passes', e.render_passes_nostat, p)
         T('finish', e.finish_passes)
-        T('build', e.build_sdtree)
+        c = T('build', e.build_sdtree)
         T('end_it', e.end_iteration)
+        per_it.append((p, round(a * 1e3, 2), round(b * 1e3, 2), round(c * 1e3, 2), e.sdtree_info().n_leaves))
     T('end_render', e.end_render)
-    tot=time.perf_counter()-t0
-    print(rep, 'total %.1f ms'%(tot*1e3), {k:round(v*1e3,2) for k,v in t.items()}, 'Msamples/s', 1280*720*4*255/tot/1e6/WORLD)
+    tot = time.perf_counter() - t0
+    print(rep, which, 'total %.1f ms' % (tot * 1e3), {k: round(v * 1e3, 2) for k, v in t.items()}, 'Msamples/s %.1f' % (1280 * 720 * props["budget"] / tot / 1e6))
+print("per iteration (passes, begin_iteration ms, passes ms, build ms, leaves):", per_it)
