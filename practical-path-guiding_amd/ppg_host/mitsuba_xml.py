@@ -5,7 +5,7 @@
               nested sampler (independent; sampleCount / seed do not steer guided_path, GP:1342-1374) and
               film hdrfilm (width, height; rfilter box)
   shapes      obj (filename, toWorld, faceNormals, flipNormals, flipTexCoords, collapse), rectangle (toWorld, flipNormals)
-  bsdfs       diffuse, conductor (material none, or explicit eta / k), roughconductor (ggx, isotropic), plastic, dielectric,
+  bsdfs       diffuse, conductor (material none, or explicit eta / k), roughconductor (ggx, isotropic), plastic, dielectric, thindielectric,
               twosided(any of the BRDFs) — top level with id, nested, or <ref id>
   emitters    area (nested in a shape)
   values      <spectrum>, <rgb>, <srgb> (spectrum.py), <transform> of translate / rotate / scale / lookAt / matrix,
@@ -413,7 +413,7 @@ def load_scene(path, defines=None, strict=True, width=None, height=None):
             inner = [c for c in elem if c.tag == "bsdf"]
             if len(inner) == 1:
                 m = make_bsdf(inner[0], allow_twosided=False)
-                if m["type"] == 6:
+                if m["type"] in (6, 7):
                     raise SceneError("twosided(dielectric): only BRDFs can be two-sided (twosided.cpp:84-88)")
                 if m["type"] == 0 and not m.get("_substituted"):
                     return dict(type=1, reflectance=m["reflectance"])
@@ -434,8 +434,11 @@ def load_scene(path, defines=None, strict=True, width=None, height=None):
         elif t == "dielectric":
             eta = lookup_ior(p, "intIOR", "bk7") / lookup_ior(p, "extIOR", "air")
             return dict(type=6, reflectance=rgb("specularReflectance", 1.0), specular=rgb("specularTransmittance", 1.0), eta=float(f32(eta)))
+        elif t == "thindielectric":
+            eta = lookup_ior(p, "intIOR", "bk7") / lookup_ior(p, "extIOR", "air")
+            return dict(type=7, reflectance=rgb("specularReflectance", 1.0), specular=rgb("specularTransmittance", 1.0), eta=float(f32(eta)))
         if strict:
-            raise SceneError("bsdf type %r is not supported yet (diffuse, conductor, roughconductor(ggx), plastic, dielectric, twosided(...); "
+            raise SceneError("bsdf type %r is not supported yet (diffuse, conductor, roughconductor(ggx), plastic, dielectric, thindielectric, twosided(...); "
                              "SURVEY.md §8 f1)" % t)
         warnings.append("bsdf %r replaced by diffuse(0.5)" % t)
         return dict(type=0, reflectance=(0.5, 0.5, 0.5), _substituted=True)
@@ -577,8 +580,9 @@ def save_scene_xml(desc, props, directory, name="scene"):
             5: '<bsdf type="plastic"%%s>%s<rgb name="diffuseReflectance" value="%s"/><rgb name="specularReflectance" value="%s"/>'
                '<boolean name="nonlinear" value="%s"/></bsdf>' % (one, R, S, "true" if M.flags & 2 else "false"),
             6: '<bsdf type="dielectric"%%s>%s<rgb name="specularReflectance" value="%s"/><rgb name="specularTransmittance" value="%s"/></bsdf>' % (one, R, S),
+            7: '<bsdf type="thindielectric"%%s>%s<rgb name="specularReflectance" value="%s"/><rgb name="specularTransmittance" value="%s"/></bsdf>' % (one, R, S),
         }[t]
-        if t == 1 or (M.flags & 1 and t != 6):
+        if t == 1 or (M.flags & 1 and t not in (6, 7)):
             out.append('\t<bsdf type="twosided" id="mat%d">%s</bsdf>' % (i, body % ""))
         else:
             out.append('\t' + body % (' id="mat%d"' % i))
