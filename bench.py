@@ -167,11 +167,15 @@ def run(args):
                                "kind": "port", "sample": "first %d passes (%d spp) of the same render(), oracle restatement, OpenMP over 32x32 blocks"
                                % (cp, cp * spp), "seconds": dtc}
 
-    if rank == 0 and not args.no_roofline:
-        # separate instrumented render: per-kernel HIP-event durations on the kernels' stream
+    times = None
+    if not args.no_roofline:
+        # separate instrumented render: per-kernel HIP-event durations on the kernels' stream.  EVERY rank runs it (the render
+        # contains collectives); rank 0 reports its own kernels.
         g2 = make(args.steps, timing=True)
         g2.render()
         times = g2.engine.kernel_times()
+        sync()
+    if rank == 0 and times:
         dom = max(times, key=lambda k: k["ms"])
         alg = algorithmic_bytes(work, rays_cpu)
         name = dom["name"].split("<")[0]
@@ -189,11 +193,12 @@ def run(args):
                            "operation_counts": alg["detail"], "kernels_ms": {k["name"]: round(k["ms"], 3) for k in times},
                            "note": "tree/scene bytes are cache resident: `traffic` (PMC) is what actually reaches HBM"}
 
-    if rank == 0:
-        print(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:  # the one JSON line is the last thing written
+        sys.stdout.flush(); sys.stderr.flush()
+        print(json.dumps(out), flush=True)
 
 
 def main():
