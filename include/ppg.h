@@ -134,6 +134,8 @@ typedef struct ppg_scene {
     uint32_t n_emitters;
     const ppg_emitter *emitters;
     ppg_camera camera;
+    const float *environment;     /* NULL, or float[3]: radiance of a constant environment emitter (emitters/constant.cpp) — what rays
+                                     that leave the scene see (GP:1902-1914, 2236-2243) and one more emitter for luminaire sampling */
 } ppg_scene;
 
 /* ------------------------------------------------------------------------------------------------

@@ -876,11 +876,19 @@ struct DRec {
     int emitter = -1;
 };
 
+inline Vec squareToCosineHemisphere(const Point2 &sample);  // warp.cpp:43-52, defined below
+
 struct Scene {
     // one area emitter = the triangles carrying its id, in index order (area.cpp: one emitter per shape)
     struct EmitterMesh { std::vector<uint32_t> tris; Pmf areaDistr; Float surfaceArea = -1, invSurfaceArea = -1; };
     std::vector<EmitterMesh> emMesh;
     Pmf emitterPDF;
+    // ConstantBackgroundEmitter (constant.cpp): the last entry of the emitter list; bounding sphere of createShape() (constant.cpp:67-78)
+    bool hasEnv = false;
+    Spectrum envRadiance;
+    Point bsCenter;
+    Float bsRadius = 0;
+    int envIndex() const { return (int)emMesh.size(); }
     std::vector<Point> P;
     std::vector<Vec> N;
     bool hasNormals = false;
@@ -934,7 +942,82 @@ struct Scene {
             }
             emitterPDF.append(1.0f);
         }
-        if (!emMesh.empty()) emitterPDF.normalize();
+        if (hasEnv) {
+            emitterPDF.append(1.0f);
+            bsCenter = (aabb.max + aabb.min) * 0.5f;  // AABB::getBSphere, aabb.cpp:44-47
+            bsRadius = ppg_max(PPG_EPSILON, length(bsCenter - aabb.max) * 1.5f);
+        }
+        if (!emMesh.empty() || hasEnv) emitterPDF.normalize();
+    }
+
+    // BSphere::rayIntersect (bsphere.h:88-95) + solveQuadratic (util.cpp:447-485)
+    bool bsphereIntersect(const Point &o_, const Vec &d, Float &nearHit, Float &farHit) const {
+        Vec o = o_ - bsCenter;
+        Float A = dot(d, d), B = 2 * dot(o, d), Cq = dot(o, o) - bsRadius * bsRadius;
+        if (A == 0) {
+            if (B != 0) { nearHit = farHit = -Cq / B; return true; }
+            return false;
+        }
+        Float discrim = B * B - 4.0f * A * Cq;
+        if (discrim < 0) return false;
+        Float temp, sqrtDiscrim = std::sqrt(discrim);
+        if (B < 0) temp = -0.5f * (B - sqrtDiscrim);
+        else temp = -0.5f * (B + sqrtDiscrim);
+        nearHit = temp / A;
+        farHit = Cq / temp;
+        if (nearHit > farHit) std::swap(nearHit, farHit);
+        return true;
+    }
+    // ConstantBackgroundEmitter::fillDirectSamplingRecord (constant.cpp:240-254)
+    bool envFillDirectSamplingRecord(DRec &dRec, const Point &o, const Vec &d) const {
+        Float nearT, farT;
+        if (!bsphereIntersect(o, d, nearT, farT) || nearT > 0 || farT < 0) return false;
+        dRec.p = o + d * farT;
+        dRec.n = normalize(bsCenter - dRec.p);
+        dRec.emitter = envIndex();
+        dRec.d = d;
+        dRec.dist = farT;
+        return true;
+    }
+    // ConstantBackgroundEmitter::sampleDirect (constant.cpp:176-214)
+    Spectrum envSampleDirect(DRec &dRec, const Point2 &sample) const {
+        Vec d;
+        Float pdf;
+        const bool hasRefN = !(dRec.refN.x == 0 && dRec.refN.y == 0 && dRec.refN.z == 0);
+        if (hasRefN) {
+            d = squareToCosineHemisphere(sample);
+            pdf = PPG_INV_PI_F * d.z;
+            // Frame(dRec.refN): coordinateSystem (util.cpp:592-601)
+            const Vec &a = dRec.refN;
+            Vec sF, tF;
+            if (ppg_abs(a.x) > ppg_abs(a.y)) {
+                Float invLen = 1.0f / std::sqrt(a.x * a.x + a.z * a.z);
+                tF = Vec(a.z * invLen, 0.0f, -a.x * invLen);
+            } else {
+                Float invLen = 1.0f / std::sqrt(a.y * a.y + a.z * a.z);
+                tF = Vec(0.0f, a.z * invLen, -a.y * invLen);
+            }
+            sF = cross(tF, a);
+            d = sF * d.x + tF * d.y + a * d.z;
+        } else {
+            Float z = 1.0f - 2.0f * sample.y;  // warp::squareToUniformSphere, warp.cpp:25-31
+            Float r = std::sqrt(ppg_max(0.0f, 1.0f - z * z));
+            Float sinPhi, cosPhi;
+            ppg_sincos(2.0f * PPG_PI_F * sample.x, &sinPhi, &cosPhi);
+            d = Vec(r * cosPhi, r * sinPhi, z);
+            pdf = PPG_INV_PI_F * 0.25f;  // INV_FOURPI
+        }
+        Float nearT, farT;
+        dRec.pdf = 0.0f;
+        if (!bsphereIntersect(dRec.ref, d, nearT, farT)) return Spectrum(0.0f);
+        if (!(nearT < 0 && farT > 0)) return Spectrum(0.0f);
+        dRec.p = dRec.ref + d * farT;
+        dRec.n = normalize(bsCenter - dRec.p);
+        dRec.d = d;
+        dRec.dist = farT;
+        dRec.pdf = pdf;
+        if (hasRefN && dot(dRec.d, dRec.refN) <= 0) return Spectrum(0.0f);
+        return envRadiance / pdf;
     }
 
     // Scene::sampleAttenuatedEmitterDirect (scene.cpp:876-897) → AreaLight::sampleDirect (area.cpp:158-173) →
@@ -944,11 +1027,12 @@ struct Scene {
     // null components (BSDF::eval with typeMask = ENull, EDiscrete, in the GEOMETRIC frame) of the surfaces passed.
     // evalNull(material, cosThetaI) is supplied by the caller (the BSDF dispatch is defined further down).
     template <typename HasNull, typename EvalNull>
-    Spectrum evalTransmittance(const Point &p1, const Point &p2, int &interactions, uint64_t &rays, HasNull hasNull, EvalNull evalNull) const {
+    Spectrum evalTransmittance(const Point &p1, const Point &p2, bool p2OnSurface, int &interactions, uint64_t &rays, HasNull hasNull,
+                               EvalNull evalNull) const {
         Vec d = p2 - p1;
         Float remaining = length(d);
         d = d / remaining;
-        const Float lengthFactor = 1 - PPG_SHADOW_EPSILON;  // p2OnSurface
+        const Float lengthFactor = p2OnSurface ? (1 - PPG_SHADOW_EPSILON) : 1;
         Point o = p1;
         Float mint = PPG_EPSILON, maxt = remaining * lengthFactor;  // p1OnSurface
         Spectrum transmittance(1.0f);
@@ -974,39 +1058,47 @@ struct Scene {
     template <typename HasNull, typename EvalNull>
     Spectrum sampleEmitterDirect(DRec &dRec, Point2 sample, uint64_t &shadowRays, int interactions, HasNull hasNull, EvalNull evalNull) const {
         dRec.pdf = 0;
-        if (emMesh.empty()) return Spectrum(0.0f);
+        if (emMesh.empty() && !hasEnv) return Spectrum(0.0f);
         Float emPdf;
         size_t index = emitterPDF.sampleReuse(sample.x, emPdf);
-        const EmitterMesh &m = emMesh[index];
-        if (m.tris.empty()) return Spectrum(0.0f);
-        Float dummy;
-        size_t ti = m.areaDistr.sampleReuse(sample.y, dummy);
-        const uint32_t t = m.tris[ti];
-        const uint32_t i0 = idx[3 * t], i1 = idx[3 * t + 1], i2 = idx[3 * t + 2];
-        const Point &p0 = P[i0], &p1 = P[i1], &p2 = P[i2];
-        Float a = std::sqrt(ppg_max(0.0f, 1.0f - sample.x));  // warp::squareToUniformTriangle, warp.cpp:76-79
-        Point2 bary{1 - a, a * sample.y};
-        Vec sideA = p1 - p0, sideB = p2 - p0;
-        dRec.p = p0 + sideA * bary.x + sideB * bary.y;
-        if (hasNormals) dRec.n = normalize(N[i0] * (1.0f - bary.x - bary.y) + N[i1] * bary.x + N[i2] * bary.y);
-        else dRec.n = normalize(cross(sideA, sideB));
-        dRec.pdf = m.invSurfaceArea;
-        dRec.d = dRec.p - dRec.ref;
-        Float distSquared = dot(dRec.d, dRec.d);
-        dRec.dist = std::sqrt(distSquared);
-        dRec.d = dRec.d / dRec.dist;
-        Float dp = ppg_abs(dot(dRec.d, dRec.n));
-        dRec.pdf *= dp != 0 ? (distSquared / dp) : 0.0f;
-        if (!(dot(dRec.d, dRec.refN) >= 0 && dot(dRec.d, dRec.n) < 0 && dRec.pdf != 0)) {
-            dRec.pdf = 0.0f;
-            return Spectrum(0.0f);
+        Spectrum value(0.0f);
+        const bool isEnv = hasEnv && (int)index == envIndex();
+        if (isEnv) {
+            value = envSampleDirect(dRec, sample);
+        } else {
+            const EmitterMesh &m = emMesh[index];
+            if (m.tris.empty()) return Spectrum(0.0f);
+            Float dummy;
+            size_t ti = m.areaDistr.sampleReuse(sample.y, dummy);
+            const uint32_t t = m.tris[ti];
+            const uint32_t i0 = idx[3 * t], i1 = idx[3 * t + 1], i2 = idx[3 * t + 2];
+            const Point &p0 = P[i0], &p1 = P[i1], &p2 = P[i2];
+            Float a = std::sqrt(ppg_max(0.0f, 1.0f - sample.x));  // warp::squareToUniformTriangle, warp.cpp:76-79
+            Point2 bary{1 - a, a * sample.y};
+            Vec sideA = p1 - p0, sideB = p2 - p0;
+            dRec.p = p0 + sideA * bary.x + sideB * bary.y;
+            if (hasNormals) dRec.n = normalize(N[i0] * (1.0f - bary.x - bary.y) + N[i1] * bary.x + N[i2] * bary.y);
+            else dRec.n = normalize(cross(sideA, sideB));
+            dRec.pdf = m.invSurfaceArea;
+            dRec.d = dRec.p - dRec.ref;
+            Float distSquared = dot(dRec.d, dRec.d);
+            dRec.dist = std::sqrt(distSquared);
+            dRec.d = dRec.d / dRec.dist;
+            Float dp = ppg_abs(dot(dRec.d, dRec.n));
+            dRec.pdf *= dp != 0 ? (distSquared / dp) : 0.0f;
+            if (!(dot(dRec.d, dRec.refN) >= 0 && dot(dRec.d, dRec.n) < 0 && dRec.pdf != 0)) {
+                dRec.pdf = 0.0f;
+                return Spectrum(0.0f);
+            }
+            const float *r = emitters[index].radiance;
+            value = Spectrum(r[0], r[1], r[2]) / dRec.pdf;
         }
-        const float *r = emitters[index].radiance;
-        Spectrum value = Spectrum(r[0], r[1], r[2]) / dRec.pdf;
-        // value *= evalTransmittance(its.p, true, dRec.p, true, ...) / emPdf
-        Spectrum tr = evalTransmittance(dRec.ref, dRec.p, interactions, shadowRays, hasNull, evalNull);
-        if (isZero(tr)) return Spectrum(0.0f);
-        value = mul(value, tr) / emPdf;
+        if (dRec.pdf == 0) return Spectrum(0.0f);  // scene.cpp:885, 896
+        // value *= evalTransmittance(its.p, true, dRec.p, emitter->isOnSurface(), ...) / emPdf
+        if (!isZero(value)) {
+            Spectrum tr = evalTransmittance(dRec.ref, dRec.p, !isEnv, interactions, shadowRays, hasNull, evalNull);
+            value = mul(value, tr) / emPdf;
+        }
         dRec.emitter = (int)index;
         dRec.pdf *= emPdf;
         return value;
@@ -1017,7 +1109,10 @@ struct Scene {
     Float pdfEmitterDirect(const DRec &dRec) const {
         if (dRec.emitter < 0) return 0.0f;
         Float pdf = 0.0f;
-        if (dot(dRec.d, dRec.refN) >= 0 && dot(dRec.d, dRec.n) < 0)
+        if (hasEnv && dRec.emitter == envIndex()) {  // ConstantBackgroundEmitter::pdfDirect, constant.cpp:216-231 (solid angle)
+            const bool hasRefN = !(dRec.refN.x == 0 && dRec.refN.y == 0 && dRec.refN.z == 0);
+            pdf = hasRefN ? PPG_INV_PI_F * ppg_max(0.0f, dot(dRec.d, dRec.refN)) : PPG_INV_PI_F * 0.25f;
+        } else if (dot(dRec.d, dRec.refN) >= 0 && dot(dRec.d, dRec.n) < 0)
             pdf = emMesh[dRec.emitter].invSurfaceArea * (dRec.dist * dRec.dist) / ppg_abs(dot(dRec.d, dRec.n));
         return pdf * (1.0f * emitterPDF.normalization);  // pdfEmitterDiscrete, scene.h:848-850
     }
@@ -1956,8 +2051,8 @@ public:
         };
 
         while (depth <= m_maxDepth || m_maxDepth < 0) {
-            if (!its.valid) {
-                // no environment emitter in the supported scene subset: evalEnvironment == 0 (GP:1902-1914)
+            if (!its.valid) {  // GP:1902-1914: radiance from a background luminaire
+                if (emittedAllowed && (!m_hideEmitters || scattered) && scene.hasEnv) recordRadiance(mul(throughput, scene.envRadiance));
                 break;
             }
             if (its.emitter >= 0 && emittedAllowed && (!m_hideEmitters || scattered))
@@ -2039,7 +2134,7 @@ public:
                 continue;
             }
 
-            // rayIntersectAndLookForEmitter GP:2184-2245 (no media, no environment emitter): `its` stays the FIRST surface hit;
+            // rayIntersectAndLookForEmitter GP:2184-2245 (no media): `its` stays the FIRST surface hit;
             // the search for an emitter continues through surfaces that have a null component
             Spectrum value(0.0f);
             {
@@ -2067,6 +2162,9 @@ public:
                     // dRec.setQuery(ray, *its), records.inl:170-178 (dist is measured from the LAST ray origin, as in the reference)
                     dRec.p = cur->p; dRec.n = cur->shFrame.n; dRec.d = d; dRec.dist = cur->t; dRec.emitter = cur->emitter;
                     value = mul(transmittance, scene.Le(*cur, -d));
+                } else if (!abandoned && !surface && scene.hasEnv && scene.envFillDirectSamplingRecord(dRec, ro, d)) {  // GP:2236-2243
+                    value = mul(transmittance, scene.envRadiance);
+                    dRec.dist = std::numeric_limits<Float>::infinity();
                 }
             }
 
@@ -2313,6 +2411,8 @@ int ppgo_set_scene(ppgo_ctx *ctx, const ppg_scene *s) {
     sc.idx.assign(s->indices, s->indices + 3 * (size_t)s->n_triangles);
     sc.triMat.assign(s->tri_material, s->tri_material + s->n_triangles);
     sc.triEmitter.assign(s->tri_emitter, s->tri_emitter + s->n_triangles);
+    sc.hasEnv = s->environment != nullptr;
+    if (sc.hasEnv) sc.envRadiance = Spectrum(s->environment[0], s->environment[1], s->environment[2]);
     sc.materials.clear();
     for (uint32_t i = 0; i < s->n_materials; ++i) {
         Material m;

@@ -89,8 +89,10 @@ struct DevScene {
     DevCamera cam;
     // next-event estimation: one area emitter = the triangles carrying its id, in index order
     int has_null;              // some BSDF has a null (pass-through) component: the look-through code of the FULL kernels is live
-    int n_emitters;
-    const float *em_sel_cdf;   // [n_emitters + 1] emitter pmf (Scene::configure, samplingWeight = 1)
+    float4 env;                // constant environment emitter (constant.cpp): radiance rgb, w != 0 if present (FULL kernels only);
+    float4 bsphere;            // its bounding sphere (constant.cpp:67-78): centre, radius; it is emitter number n_emitters
+    int n_emitters;            // area emitters
+    const float *em_sel_cdf;   // [n_emitters (+ 1 with an environment emitter) + 1] emitter pmf (Scene::configure, samplingWeight = 1)
     float em_sel_norm;         // DiscreteDistribution::getNormalization()
     const int4 *em_info;       // (first triangle, triangle count, first cdf entry, invSurfaceArea bits)
     const float *em_area_cdf;  // per emitter: count + 1 entries (TriMesh::prepareSamplingTable)
@@ -367,14 +369,91 @@ D int pmf_sample(const float *cdf, int entries, float v) {
 struct DirectSample {
     F3 n, d;
     float dist, pdf, em_pdf;
+    bool is_env;
+    F3 sd;        // direction and length of the shadow ray: Scene::evalTransmittance recomputes them from the two end points
+    float sdist;  // (scene.cpp:621-623) — identical to (d, dist) for area emitters, a rounding apart for the environment emitter
 };
+
+D F3 cosine_hemisphere(float sx, float sy);  // defined below
+
+// BSphere::rayIntersect (bsphere.h:88-95) + solveQuadratic (util.cpp:447-485) against the environment emitter's sphere
+D bool bsphere_intersect(const DevScene &S, F3 o_, F3 d, float &nearHit, float &farHit) {
+    F3 o = o_ - f3(S.bsphere.x, S.bsphere.y, S.bsphere.z);
+    float A = dot3(d, d), B = 2 * dot3(o, d), Cq = dot3(o, o) - S.bsphere.w * S.bsphere.w;
+    if (A == 0) {
+        if (B != 0) { nearHit = farHit = -Cq / B; return true; }
+        return false;
+    }
+    float discrim = B * B - 4.0f * A * Cq;
+    if (discrim < 0) return false;
+    float temp, sqrtDiscrim = __builtin_sqrtf(discrim);
+    if (B < 0) temp = -0.5f * (B - sqrtDiscrim);
+    else temp = -0.5f * (B + sqrtDiscrim);
+    nearHit = temp / A;
+    farHit = Cq / temp;
+    if (nearHit > farHit) { float t = nearHit; nearHit = farHit; farHit = t; }
+    return true;
+}
+// ConstantBackgroundEmitter::fillDirectSamplingRecord (constant.cpp:240-254): can a ray that left the scene be attributed to it?
+D bool env_fill_direct(const DevScene &S, F3 o, F3 d) {
+    float nearT, farT;
+    return bsphere_intersect(S, o, d, nearT, farT) && !(nearT > 0) && !(farT < 0);
+}
+// ConstantBackgroundEmitter::pdfDirect (constant.cpp:216-231), solid angle; cos_refn = dot(d, refN), or < -1.5 when refN = 0
+D float env_pdf_direct(float cos_refn) { return cos_refn < -1.5f ? PPG_INV_PI_F * 0.25f : PPG_INV_PI_F * ppg_max(0.0f, cos_refn); }
+// ConstantBackgroundEmitter::sampleDirect (constant.cpp:176-214)
+D F3 env_sample_direct(const DevScene &S, F3 ref, F3 refN, float sx, float sy, DirectSample &ds) {
+    F3 d;
+    float pdf;
+    const bool hasRefN = !(refN.x == 0 && refN.y == 0 && refN.z == 0);
+    if (hasRefN) {
+        const F3 l = cosine_hemisphere(sx, sy);
+        pdf = PPG_INV_PI_F * l.z;
+        F3 sF, tF;  // Frame(dRec.refN): coordinateSystem, util.cpp:592-601
+        if (ppg_abs(refN.x) > ppg_abs(refN.y)) {
+            float invLen = 1.0f / __builtin_sqrtf(refN.x * refN.x + refN.z * refN.z);
+            tF = f3(refN.z * invLen, 0.0f, -refN.x * invLen);
+        } else {
+            float invLen = 1.0f / __builtin_sqrtf(refN.y * refN.y + refN.z * refN.z);
+            tF = f3(0.0f, refN.z * invLen, -refN.y * invLen);
+        }
+        sF = cross3(tF, refN);
+        d = sF * l.x + tF * l.y + refN * l.z;
+    } else {
+        float z = 1.0f - 2.0f * sy;  // warp::squareToUniformSphere, warp.cpp:25-31
+        float r = __builtin_sqrtf(ppg_max(0.0f, 1.0f - z * z));
+        float sinPhi, cosPhi;
+        ppg_sincos(2.0f * PPG_PI_F * sx, &sinPhi, &cosPhi);
+        d = f3(r * cosPhi, r * sinPhi, z);
+        pdf = PPG_INV_PI_F * 0.25f;
+    }
+    float nearT, farT;
+    ds.pdf = 0.0f;
+    if (!bsphere_intersect(S, ref, d, nearT, farT)) return f3s(0.0f);
+    if (!(nearT < 0 && farT > 0)) return f3s(0.0f);
+    const F3 p = ref + d * farT;
+    ds.n = norm3(f3(S.bsphere.x, S.bsphere.y, S.bsphere.z) - p);
+    ds.d = d;
+    ds.dist = farT;
+    ds.pdf = pdf;
+    const F3 pd = p - ref;
+    ds.sdist = len3(pd);
+    ds.sd = div3(pd, ds.sdist);
+    if (hasRefN && dot3(ds.d, refN) <= 0) return f3s(0.0f);
+    return div3(f3(S.env.x, S.env.y, S.env.z), pdf);
+}
 D F3 emitter_sample_direct(const DevScene &S, F3 ref, F3 refN, float sx, float sy, DirectSample &ds) {
-    ds.pdf = 0; ds.em_pdf = 0; ds.dist = 0; ds.n = f3s(0.0f); ds.d = f3s(0.0f);
-    if (S.n_emitters == 0) return f3s(0.0f);
-    const int e = pmf_sample(S.em_sel_cdf, S.n_emitters + 1, sx);
+    ds.pdf = 0; ds.em_pdf = 0; ds.dist = 0; ds.n = f3s(0.0f); ds.d = f3s(0.0f); ds.is_env = false; ds.sd = f3s(0.0f); ds.sdist = 0;
+    const int n_sel = S.n_emitters + (S.env.w != 0 ? 1 : 0);
+    if (n_sel == 0) return f3s(0.0f);
+    const int e = pmf_sample(S.em_sel_cdf, n_sel + 1, sx);
     const float c0 = S.em_sel_cdf[e], c1 = S.em_sel_cdf[e + 1];
     ds.em_pdf = c1 - c0;
     sx = (sx - c0) / (c1 - c0);  // sampleReuse, pmf.h:183-188
+    if (e == S.n_emitters) {  // the environment emitter is the last one
+        ds.is_env = true;
+        return env_sample_direct(S, ref, refN, sx, sy, ds);
+    }
     const int4 info = S.em_info[e];
     if (info.y == 0) return f3s(0.0f);
     const float *acdf = S.em_area_cdf + info.z;
@@ -398,6 +477,7 @@ D F3 emitter_sample_direct(const DevScene &S, F3 ref, F3 refN, float sx, float s
     const float distSquared = dot3(d, d);
     ds.dist = __builtin_sqrtf(distSquared);
     ds.d = div3(d, ds.dist);
+    ds.sd = ds.d; ds.sdist = ds.dist;
     const float dp = ppg_abs(dot3(ds.d, ds.n));
     ds.pdf *= dp != 0 ? (distSquared / dp) : 0.0f;
     if (!(dot3(ds.d, refN) >= 0 && dot3(ds.d, ds.n) < 0 && ds.pdf != 0)) {

@@ -256,7 +256,7 @@ struct ppg_ctx {
     bool haveScene = false;
     bool fullMaterials = false;
     DevBuf<float4> d_tris, d_accel, d_accelSmall, d_normals, d_materials, d_emitters, d_emTris, d_emNrm;
-    DevBuf<float> d_emSel, d_emArea;
+    DevBuf<float> d_emSel, d_emArea, d_neeCos;
     DevBuf<int4> d_emInfo;
     DevBuf<BvhNode> d_bvh;
     DevBuf<Bvh4Node> d_bvh4;
@@ -574,6 +574,8 @@ int allocPaths(ppg_ctx *ctx) {
     P.v_d = ctx->d_vd.p; P.v_thr = ctx->d_vthr.p; P.v_bsdf = ctx->d_vbsdf.p; P.v_rad = ctx->d_vrad.p;
     P.v_o = ctx->spatialFilter != SF_NEAREST ? ctx->d_vo.p : nullptr;
     P.v_vox = ctx->spatialFilter != SF_NEAREST ? ctx->d_vvox.p : nullptr;
+    P.nee_cos = nullptr;
+    if (ctx->scene.env.w != 0 && ctx->nee != NEE_NEVER) { HIP_CHECK(ctx->d_neeCos.reserve(nn)); P.nee_cos = ctx->d_neeCos.p; }
     return PPG_OK;
 }
 
@@ -1234,8 +1236,9 @@ int ppg_set_scene(ppg_ctx *ctx, const ppg_scene *s) {
             info[e] = make_int4(firstTri, (int)emTris[e].size(), (int)first, __builtin_bit_cast(int, inv));
             selCdf.push_back(selCdf.back() + 1.0f);
         }
+        if (s->environment) selCdf.push_back(selCdf.back() + 1.0f);  // the environment emitter is the last one
         float selSum = 0, selNorm = 0;
-        if (ne) selNorm = normalize(selCdf, 0, selCdf.size(), selSum);
+        if (selCdf.size() > 1) selNorm = normalize(selCdf, 0, selCdf.size(), selSum);
         if (etris.empty()) etris.push_back(make_float4(0, 0, 0, 0));
         if (areaCdf.empty()) areaCdf.push_back(0.0f);
         HIP_CHECK(ctx->d_emSel.reserve(selCdf.size())); HIP_CHECK(hipMemcpy(ctx->d_emSel.p, selCdf.data(), selCdf.size() * 4, hipMemcpyHostToDevice));
@@ -1244,6 +1247,17 @@ int ppg_set_scene(ppg_ctx *ctx, const ppg_scene *s) {
         HIP_CHECK(ctx->d_emTris.reserve(etris.size())); HIP_CHECK(hipMemcpy(ctx->d_emTris.p, etris.data(), etris.size() * sizeof(float4), hipMemcpyHostToDevice));
         if (!enrm.empty()) { HIP_CHECK(ctx->d_emNrm.reserve(enrm.size())); HIP_CHECK(hipMemcpy(ctx->d_emNrm.p, enrm.data(), enrm.size() * sizeof(float4), hipMemcpyHostToDevice)); }
         DevScene &S = ctx->scene;
+        if (s->environment) {  // ConstantBackgroundEmitter: bounding sphere of createShape() (constant.cpp:67-78) around Scene::getAABB()
+            float c[3], r2 = 0;
+            for (int a = 0; a < 3; ++a) { c[a] = (ctx->aabbMax[a] + ctx->aabbMin[a]) * 0.5f; }
+            const float dx = c[0] - ctx->aabbMax[0], dy = c[1] - ctx->aabbMax[1], dz = c[2] - ctx->aabbMax[2];
+            r2 = dx * dx + dy * dy + dz * dz;
+            S.env = make_float4(s->environment[0], s->environment[1], s->environment[2], 1.0f);
+            S.bsphere = make_float4(c[0], c[1], c[2], ppg_max(PPG_EPSILON, std::sqrt(r2) * 1.5f));
+            ctx->fullMaterials = true;  // the environment code lives in the FULL kernel variants
+        } else {
+            S.env = make_float4(0, 0, 0, 0); S.bsphere = make_float4(0, 0, 0, 0);
+        }
         S.n_emitters = (int)ne; S.em_sel_cdf = ctx->d_emSel.p; S.em_sel_norm = selNorm; S.em_info = ctx->d_emInfo.p;
         S.em_area_cdf = ctx->d_emArea.p; S.em_tris = ctx->d_emTris.p; S.em_normals = enrm.empty() ? nullptr : ctx->d_emNrm.p;
     }

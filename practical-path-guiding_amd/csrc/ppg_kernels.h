@@ -66,6 +66,8 @@ struct PathState {
     float4 *v_rad;   // (radiance, leaf | delta << 31)
     float4 *v_o;     // (ray.o, -)        only if spatial filter != nearest
     float4 *v_vox;   // (voxel size, -)   only if spatial filter != nearest
+    float *nee_cos;  // dot(ray.d, dRec.refN) of the pending bounce (-2 when refN = 0): ConstantBackgroundEmitter::pdfDirect needs the
+                     // value, not just its sign; only allocated for scenes with an environment emitter
 };
 
 // Per-workgroup statistics (zeroed per ppg_render_passes, summed on the host).  A single global counter
@@ -619,9 +621,8 @@ D Hit trace_inline(const DevScene &S, const float4 *small_tris, int *stack_col, 
 
 // Scene::evalTransmittance (scene.cpp:619-679), surfaces only, for scenes with null-component BSDFs: zero behind an occluder,
 // otherwise the product of the null components (evaluated in the geometric frame) of the surfaces passed.
-D F3 shadow_transmittance(const DevScene &S, const float4 *small_tris, int *stack_col, F3 p1, F3 d, float remaining, int maxInteractions,
-                          unsigned int &traced) {
-    const float lengthFactor = 1 - PPG_SHADOW_EPSILON;
+D F3 shadow_transmittance(const DevScene &S, const float4 *small_tris, int *stack_col, F3 p1, F3 d, float remaining, float lengthFactor,
+                          int maxInteractions, unsigned int &traced) {
     F3 o = p1;
     float maxt = remaining * lengthFactor;
     F3 transmittance = f3s(1.0f);
@@ -702,6 +703,10 @@ D void shade_slice(const PathState &P, const DevScene &S, const DevTree &T, cons
                 F3 em_n = I.n;
                 float em_dist = h.t;
                 int em_id = I.emitter;
+                if (FULL && !valid && S.env.w != 0) {  // GP:2236-2243: the ray left the scene
+                    const float4 ro4 = P.ray_o[i];
+                    if (env_fill_direct(S, f3(ro4.x, ro4.y, ro4.z), d)) { value = f3(S.env.x, S.env.y, S.env.z); em_id = S.n_emitters; }
+                }
                 if (FULL && S.has_null && valid && I.emitter < 0) {
                     // rayIntersectAndLookForEmitter GP:2184-2245: the path continues from THIS hit, but the search for an emitter
                     // goes on through surfaces that have a null component (traced in place)
@@ -731,6 +736,9 @@ D void shade_slice(const PathState &P, const DevScene &S, const DevTree &T, cons
                         if (!abandoned && surface && Ic.emitter >= 0) {
                             value = mul3(transmittance, eval_Le(S, Ic, -d));
                             em_n = Ic.n; em_dist = hc.t; em_id = Ic.emitter;  // dist from the LAST ray origin, as in the reference
+                        } else if (!abandoned && !surface && S.env.w != 0 && env_fill_direct(S, ro, d)) {
+                            value = mul3(transmittance, f3(S.env.x, S.env.y, S.env.z));
+                            em_id = S.n_emitters;
                         }
                     }
                 }
@@ -741,7 +749,9 @@ D void shade_slice(const PathState &P, const DevScene &S, const DevTree &T, cons
                 if (NEE && R.do_nee && !isDelta && !iszero3(value)) {
                     float pdfDirect = 0.0f;
                     const float dn = dot3(d, em_n);
-                    if ((flags & FL_PEND_REFN) && dn < 0)
+                    if (FULL && em_id == S.n_emitters) {
+                        pdfDirect = env_pdf_direct(P.nee_cos[i]);
+                    } else if ((flags & FL_PEND_REFN) && dn < 0)
                         pdfDirect = __int_as_float(S.em_info[em_id].w) * (em_dist * em_dist) / ppg_abs(dn);
                     emitterPdf = pdfDirect * (1.0f * S.em_sel_norm);
                 }
@@ -790,7 +800,11 @@ D void shade_slice(const PathState &P, const DevScene &S, const DevTree &T, cons
             }
 
             // ---- first half of this bounce: GP:1902-2040 ----
-            if (go && !valid) go = false;  // no environment emitter in the supported scene subset
+            if (go && !valid) {  // GP:1902-1914: possibly radiance from a background luminaire, then the path ends
+                if (FULL && S.env.w != 0 && (flags & FL_EMITTED_OK) && (!R.hide_emitters || (flags & FL_SCATTERED)))
+                    Li = Li + mul3(thr, f3(S.env.x, S.env.y, S.env.z));  // (nVertices == 0 whenever emission is still enabled)
+                go = false;
+            }
             if (go) {
                 if (I.emitter >= 0 && (flags & FL_EMITTED_OK) && (!R.hide_emitters || (flags & FL_SCATTERED)))
                     Li = Li + mul3(thr, eval_Le(S, I, -d));  // GP:1917-1919 (nVertices == 0 here)
@@ -889,12 +903,13 @@ D void shade_slice(const PathState &P, const DevScene &S, const DevTree &T, cons
                     F3 value = emitter_sample_direct(S, I.p, refN, ex, ey, ds);
                     if (ds.pdf != 0) {
                         if (FULL && S.has_null) {  // value *= evalTransmittance(...) / emPdf, scene.cpp:887-889
-                            const F3 tr = shadow_transmittance(S, nee.small_tris, nee.stack_col, I.p, ds.d, ds.dist, R.max_depth - (int)depth - 1, traced);
+                            const F3 tr = shadow_transmittance(S, nee.small_tris, nee.stack_col, I.p, ds.sd, ds.sdist, ds.is_env ? 1.0f : 1 - PPG_SHADOW_EPSILON,
+                                                               R.max_depth - (int)depth - 1, traced);
                             if (iszero3(tr)) value = f3s(0.0f);
                             else { value = div3(mul3(value, tr), ds.em_pdf); ds.pdf *= ds.em_pdf; }
                         } else {
                             ++traced;
-                            if (shadow_occluded(S, nee.small_tris, nee.stack_col, I.p, ds.d, ds.dist * (1 - PPG_SHADOW_EPSILON))) {
+                            if (shadow_occluded(S, nee.small_tris, nee.stack_col, I.p, ds.sd, ds.sdist * ((FULL && ds.is_env) ? 1.0f : 1 - PPG_SHADOW_EPSILON))) {
                                 value = f3s(0.0f);
                             } else {
                                 value = div3(value, ds.em_pdf);
@@ -977,6 +992,7 @@ D void shade_slice(const PathState &P, const DevScene &S, const DevTree &T, cons
                         }
                         flags |= FL_PENDING | (smooth ? FL_PEND_TREE : 0u) | (sampledDelta ? FL_PEND_DELTA : 0u);
                         if (NEE && dot3(wo, refN) >= 0) flags |= FL_PEND_REFN;
+                        if (NEE && FULL && P.nee_cos) P.nee_cos[i] = noRefN ? -2.0f : dot3(wo, refN);
                         // GP:2045-2075: a sampled null interaction.  (Its vertex record, GP:2051-2068, needs a D-tree, i.e. a smooth/null
                         // hybrid such as `mask`; the only null BSDF supported, thindielectric, is all-delta and has none.)
                         if (FULL && sampledNull) flags |= FL_PEND_NULL;

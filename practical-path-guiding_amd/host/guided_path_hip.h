@@ -37,6 +37,8 @@ struct SceneData {
     std::vector<ppg_material> materials;
     std::vector<ppg_emitter> emitters;
     ppg_camera camera{};
+    bool hasEnvironment = false;  // constant environment emitter
+    float environment[3] = {0, 0, 0};
 
     ppg_scene view() const {
         ppg_scene s{};
@@ -47,6 +49,7 @@ struct SceneData {
         s.n_materials = (uint32_t)materials.size(); s.materials = materials.data();
         s.n_emitters = (uint32_t)emitters.size(); s.emitters = emitters.data();
         s.camera = camera;
+        s.environment = hasEnvironment ? environment : nullptr;
         return s;
     }
 };

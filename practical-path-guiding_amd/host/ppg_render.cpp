@@ -35,6 +35,8 @@ static bool loadScene(const char *path, SceneData &s) {
     s.materials.resize(nm); f.read((char *)s.materials.data(), (size_t)nm * sizeof(ppg_material));
     s.emitters.resize(ne); f.read((char *)s.emitters.data(), (size_t)ne * sizeof(ppg_emitter));
     f.read((char *)&s.camera, sizeof(ppg_camera));
+    s.hasEnvironment = hdr[5] != 0;
+    if (s.hasEnvironment) f.read((char *)s.environment, 12);
     return (bool)f;
 }
 

@@ -99,7 +99,7 @@ class Scene(C.Structure):
     _fields_ = [("n_vertices", C.c_uint32), ("positions", C.POINTER(C.c_float)), ("normals", C.POINTER(C.c_float)),
                 ("n_triangles", C.c_uint32), ("indices", C.POINTER(C.c_uint32)), ("tri_material", C.POINTER(C.c_uint32)),
                 ("tri_emitter", C.POINTER(C.c_int32)), ("n_materials", C.c_uint32), ("materials", C.POINTER(Material)),
-                ("n_emitters", C.c_uint32), ("emitters", C.POINTER(Emitter)), ("camera", Camera)]
+                ("n_emitters", C.c_uint32), ("emitters", C.POINTER(Emitter)), ("camera", Camera), ("environment", C.POINTER(C.c_float))]
 
 
 class _StatsMixin:
@@ -210,6 +210,10 @@ class Engine:
         s.tri_emitter = _p(te, C.c_int32)
         s.n_materials, s.materials = len(desc.materials), mats
         s.n_emitters, s.emitters = len(desc.emitters), ems
+        env = getattr(desc, "environment", None)
+        if env is not None:
+            env_arr = (C.c_float * 3)(*[float(v) for v in env])
+            s.environment = C.cast(env_arr, C.POINTER(C.c_float))
         cam = desc.camera
         s.camera.sample_to_camera[:] = [float(v) for v in np.asarray(cam["sample_to_camera"], np.float32).reshape(-1)]
         s.camera.camera_to_world[:] = [float(v) for v in np.asarray(cam["camera_to_world"], np.float32).reshape(-1)]

@@ -7,7 +7,7 @@
   shapes      obj (filename, toWorld, faceNormals, flipNormals, flipTexCoords, collapse), rectangle (toWorld, flipNormals)
   bsdfs       diffuse, conductor (material none, or explicit eta / k), roughconductor (ggx, isotropic), plastic, dielectric, thindielectric,
               twosided(any of the BRDFs) — top level with id, nested, or <ref id>
-  emitters    area (nested in a shape)
+  emitters    area (nested in a shape), constant (environment)
   values      <spectrum>, <rgb>, <srgb> (spectrum.py), <transform> of translate / rotate / scale / lookAt / matrix,
               <default name value> and $name substitution (mitsuba -D, mitsuba.cpp:58-87)
 
@@ -456,8 +456,12 @@ def load_scene(path, defines=None, strict=True, width=None, height=None):
             by_id[b.get("id")] = intern(make_bsdf(b))
     for tex in root.findall("texture"):
         warnings.append("top-level texture %r ignored" % tex.get("id"))
+    environment = None
     for em in root.findall("emitter"):
-        raise SceneError("emitter type %r is not supported (area emitters on shapes only; SURVEY.md §8 f2)" % em.get("type"))
+        if em.get("type") == "constant" and environment is None:
+            environment = tuple(float(v) for v in colour(em, "radiance", 1.0))
+            continue
+        raise SceneError("emitter type %r is not supported (area emitters on shapes and one `constant` environment emitter; SURVEY.md §8 f2)" % em.get("type"))
 
     # ---- shapes
     collected, emitters = [], []
@@ -530,7 +534,7 @@ def load_scene(path, defines=None, strict=True, width=None, height=None):
         tmat.append(np.full(T, mat, np.uint32)); tem.append(np.full(T, em, np.int32))
     normals = np.concatenate(nrm).astype(f32) if any_normals else None
     desc = SceneDesc(np.concatenate(pos).astype(f32), np.concatenate(idx).astype(np.uint32), np.concatenate(tmat), np.concatenate(tem),
-                     materials, emitters, camera, normals)
+                     materials, emitters, camera, normals, environment)
     info["warnings"] = warnings
     return desc, props, info
 
@@ -610,6 +614,8 @@ def save_scene_xml(desc, props, directory, name="scene"):
         if em >= 0:
             out.append('\t\t<emitter type="area"><rgb name="radiance" value="%s"/></emitter>' % c(desc.emitters[em]["radiance"]))
         out.append('\t</shape>')
+    if getattr(desc, "environment", None) is not None:
+        out.append('\t<emitter type="constant"><rgb name="radiance" value="%s"/></emitter>' % c(desc.environment))
     out.append('</scene>')
     path = os.path.join(directory, name + ".xml")
     with open(path, "w") as f:

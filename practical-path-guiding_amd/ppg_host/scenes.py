@@ -15,10 +15,11 @@ import numpy as np
 
 
 class SceneDesc:
-    def __init__(self, positions, indices, tri_material, tri_emitter, materials, emitters, camera, normals=None):
+    def __init__(self, positions, indices, tri_material, tri_emitter, materials, emitters, camera, normals=None, environment=None):
         self.positions, self.indices = positions, indices
         self.tri_material, self.tri_emitter = tri_material, tri_emitter
         self.materials, self.emitters, self.camera, self.normals = materials, emitters, camera, normals
+        self.environment = environment  # None or (r, g, b): constant environment emitter
 
     @property
     def n_triangles(self):
@@ -27,14 +28,16 @@ class SceneDesc:
 
 def save_scene(desc, path):
     """Write the flat binary scene read by host/ppg_render.cpp: "PPGS", 6 x uint32 {n_vertices, n_triangles, n_materials,
-    n_emitters, has_normals, 0}, then positions, [normals], indices, tri_material, tri_emitter, materials
-    (ppg_material, 64 bytes each), emitters (4 floats), camera (ppg_camera)."""
+    n_emitters, has_normals, has_environment}, then positions, [normals], indices, tri_material, tri_emitter, materials
+    (ppg_material, 64 bytes each), emitters (4 floats), camera (ppg_camera), [environment radiance: 3 floats]."""
     import struct
     pos = np.ascontiguousarray(desc.positions, np.float32)
     idx = np.ascontiguousarray(desc.indices, np.uint32)
     with open(path, "wb") as f:
         f.write(b"PPGS")
-        f.write(struct.pack("<6I", pos.shape[0], idx.shape[0], len(desc.materials), len(desc.emitters), 0 if desc.normals is None else 1, 0))
+        env = getattr(desc, "environment", None)
+        f.write(struct.pack("<6I", pos.shape[0], idx.shape[0], len(desc.materials), len(desc.emitters), 0 if desc.normals is None else 1,
+                            0 if env is None else 1))
         f.write(pos.tobytes())
         if desc.normals is not None:
             f.write(np.ascontiguousarray(desc.normals, np.float32).tobytes())
@@ -50,6 +53,8 @@ def save_scene(desc, path):
         f.write(np.asarray(c["sample_to_camera"], np.float32).tobytes())
         f.write(np.asarray(c["camera_to_world"], np.float32).tobytes())
         f.write(struct.pack("<2f2i", c["near_clip"], c["far_clip"], c["width"], c["height"]))
+        if env is not None:
+            f.write(struct.pack("<3f", *[float(np.float32(v)) for v in env]))
 
 
 def _sample_to_camera(fov_deg, fov_axis, near, far, width, height):

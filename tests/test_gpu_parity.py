@@ -532,3 +532,32 @@ def test_null_component_bsdf_on_a_bvh_scene(oracle_lib):
     ig, io = gg.render(scene), go.render(scene)
     assert _stats(gg) == _stats(go) and ig.mean() > 1e-3 and np.array_equal(ig, io)
     assert_tree_equal(g.read_sdtree(), o.read_sdtree())
+
+
+@pytest.mark.parametrize("extra", [dict(nee="never"), dict(nee="always"), dict(nee="kickstart", **IMPROVED), dict(nee="always", hideEmitters=1, maxDepth=-1, rrDepth=3)],
+                         ids=["never", "nee-always", "nee-kickstart-improved", "hidden-unbounded"])
+def test_constant_environment_emitter_against_oracle(oracle_lib, extra):
+    """emitters/constant.cpp: an open scene (CBOX without ceiling and back wall) under a constant sky next to the area light — Li's
+    miss branch (GP:1902-1914), the escape branch of rayIntersectAndLookForEmitter (GP:2236-2243), luminaire sampling over two
+    emitters with the environment's cosine / uniform-sphere sampling, and its pdf in the MIS weights (constant.cpp:176-231).  A pane
+    makes escaping rays pass a null surface first; a two-sided floor exercises refN = 0 (uniform-sphere sampling)."""
+    import ppg_host
+    scene = _pane_scene((56, 56))
+    keep = np.ones(len(scene.indices), bool)
+    keep[4:8] = False          # drop ceiling and back wall
+    scene.indices, scene.tri_material, scene.tri_emitter = scene.indices[keep], scene.tri_material[keep], scene.tri_emitter[keep]
+    scene.materials = list(scene.materials) + [dict(type="diffuse", reflectance=(0.6, 0.6, 0.6), twosided=True)]
+    tm = scene.tri_material.copy(); tm[2:4] = len(scene.materials) - 1; scene.tri_material = tm   # floor
+    scene.environment = (0.5, 0.7, 1.1)
+    props = dict(CBOX_PROPS, budget=60, seed=33)
+    props.update(maxDepth=9, rrDepth=5)
+    props.update(extra)
+    g, o = hip(**props), make_oracle(oracle_lib, threads=os.cpu_count() or 8, **props)
+    gg, go = ppg_host.GuidedPathTracer(engine=g), ppg_host.GuidedPathTracer(engine=o)
+    ig, io = gg.render(scene), go.render(scene)
+    assert _stats(gg) == _stats(go)
+    assert np.array_equal(ig, io, equal_nan=True)
+    assert_tree_equal(g.read_sdtree(), o.read_sdtree())
+    scene.environment = None
+    dark = ppg_host.GuidedPathTracer(engine=hip(**props)).render(scene)
+    assert np.nanmean(ig) > 1.3 * np.nanmean(dark)

@@ -277,3 +277,17 @@ def test_full_material_set_survives_the_xml_round_trip(tmp_path):
     per_tri = lambda s: sorted((tuple(np.sort(t.reshape(-1))), bytes(Material.from_dict(s.materials[m])))  # noqa: E731
                                for t, m in zip(s.positions[s.indices.astype(int)], s.tri_material))
     assert per_tri(back) == per_tri(scene)
+
+
+def test_environment_emitter_in_xml_and_flat_file(tmp_path):
+    import struct
+    scene = ppg_host.cbox_scene(16, 16)
+    scene.environment = (0.25, 0.5, 1.0)
+    back, _, _ = ppg_host.load_scene(ppg_host.save_scene_xml(scene, dict(budgetType="spp", budget=8.0), str(tmp_path)))
+    assert back.environment == (0.25, 0.5, 1.0)
+    p = str(tmp_path / "e.ppgs")
+    ppg_host.save_scene(back, p)
+    raw = open(p, "rb").read()
+    assert struct.unpack_from("<6I", raw, 4)[5] == 1 and struct.unpack_from("<3f", raw, len(raw) - 12) == (0.25, 0.5, 1.0)
+    with pytest.raises(mitsuba_xml.SceneError, match="envmap"):
+        ppg_host.load_scene(_write(tmp_path, '<emitter type="envmap"/>'), defines=dict(nee="never"))

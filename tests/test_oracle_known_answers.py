@@ -198,3 +198,38 @@ def test_light_through_a_thin_pane_matches_the_analytic_transmission(oracle_lib)
     # without interaction budget (maxDepth = 3 → maxInteractions = 0 at the floor) the pane counts as an occluder (GP:2196, scene.cpp:636)
     e = make_oracle(oracle_lib, threads=16, budgetType="spp", budget=16, maxDepth=3, rrDepth=10, nee="always", seed=4)
     assert ppg_host.GuidedPathTracer(engine=e).render(scene)[..., 0][outside].max() == 0
+
+
+def test_constant_environment_emitter_furnace_and_mis(oracle_lib):
+    """A diffuse floor (albedo 0.5) under a constant sky of radiance (1, 2, 3) (emitters/constant.cpp): with direct light only the floor's
+    radiance is albedo x L — exactly, for BSDF sampling (every cosine-sampled ray escapes and sees the sky: GP:2236-2243), and
+    with luminaire sampling (cosine-hemisphere sampling about dRec.refN, constant.cpp:176-214) MIS-combined with it (GP:2083-2088,
+    constant.cpp:216-231).  A second emitter (the lamp) makes the emitter pmf non-trivial (scene.cpp:375-380)."""
+    import ppg_host
+    from conftest import make_oracle
+    res = 16
+    scene = _floor_and_lamp(res)
+    scene.environment = (1.0, 2.0, 3.0)
+    scene.emitters = [dict(radiance=(0.0, 0.0, 0.0))]  # lamp switched off: still sampled with probability 1/2, contributes nothing
+    scene.positions = scene.positions.copy(); scene.positions[4:8, 0] += 200.0  # ... and moved aside so that it does not hide the sky
+    half = 30.0 * np.tan(np.radians(2.0))
+    xs = (np.arange(res) + 0.5) / res * 2 * half - half
+    X, Z = np.meshgrid(xs, xs)
+    lit = np.ones_like(X, bool)
+    for nee, budget in (("never", 8), ("always", 256), ("kickstart", 256)):
+        e = make_oracle(oracle_lib, threads=16, budgetType="spp", budget=budget, maxDepth=2, rrDepth=10, nee=nee, seed=2, hideEmitters=1)
+        img = ppg_host.GuidedPathTracer(engine=e).render(scene)
+        want = 0.5 * np.array([1.0, 2.0, 3.0])
+        m = img[lit].mean(0)
+        if nee == "never":
+            assert np.abs(img[lit] / want - 1).max() < 1e-5   # zero-variance: every sample returns albedo x L
+        else:
+            assert np.abs(m / want - 1).max() < 0.03, (nee, m)
+    # the sky is visible to camera rays unless hideEmitters is set (GP:1906-1907)
+    cam_up = ppg_host.perspective_camera((0.0, 1.0, 0.0), (0.0, 30.0, 0.0), (0, 0, 1), 4.0, "x", 0.1, 100.0, res, res)
+    scene.camera = cam_up
+    scene.positions = scene.positions.copy(); scene.positions[4:8, 1] = -5.0  # move the lamp out of view
+    for hide, want in ((0, (1.0, 2.0, 3.0)), (1, (0.0, 0.0, 0.0))):
+        e = make_oracle(oracle_lib, threads=4, budgetType="spp", budget=4, maxDepth=3, nee="never", seed=2, hideEmitters=hide)
+        img = ppg_host.GuidedPathTracer(engine=e).render(scene)
+        assert np.allclose(img.reshape(-1, 3), want)
