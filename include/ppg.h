@@ -91,7 +91,10 @@ enum {
 #define PPG_BSDF_LAST PPG_BSDF_THINDIELECTRIC
 enum {
     PPG_MAT_TWOSIDED = 1,          /* wrap the (one-sided) BRDF in twosided.cpp:100-180, same BRDF on both sides */
-    PPG_MAT_NONLINEAR = 2          /* plastic: nonlinear = true (plastic.cpp:164) */
+    PPG_MAT_NONLINEAR = 2,         /* plastic: nonlinear = true (plastic.cpp:164) */
+    PPG_MAT_MASK = 4               /* wrap the BSDF (outside a two-sided adapter, if any) in mask.cpp:108-214 with constant `opacity`: a
+                                      smooth/null hybrid — its sampled pass-through is recorded for the sampling-fraction optimiser
+                                      (GP:2047-2068) */
 };
 
 typedef struct ppg_material {
@@ -105,7 +108,9 @@ typedef struct ppg_material {
     float k[3];           /* conductors: k per channel */
     int32_t flags;        /* PPG_MAT_* */
     int32_t _reserved;
-} ppg_material;           /* 64 bytes */
+    float opacity[3];     /* PPG_MAT_MASK: opacity (mask.cpp, default 0.5) */
+    float _pad;
+} ppg_material;           /* 80 bytes */
 
 typedef struct ppg_emitter {
     float radiance[3]; /* area light, mitsuba/src/emitters/area.cpp:104-109 */

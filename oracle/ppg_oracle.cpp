@@ -809,6 +809,8 @@ struct Material : ppg_material {
     Spectrum S() const { return Spectrum(specular[0], specular[1], specular[2]); }
     Spectrum Eta() const { return Spectrum(eta[0], eta[1], eta[2]); }
     Spectrum K() const { return Spectrum(k[0], k[1], k[2]); }
+    Spectrum Opacity() const { return Spectrum(opacity[0], opacity[1], opacity[2]); }
+    bool masked() const { return (flags & PPG_MAT_MASK) != 0; }
     void configure() {
         if (type == PPG_BSDF_TWOSIDED_DIFFUSE) { type = PPG_BSDF_DIFFUSE; flags |= PPG_MAT_TWOSIDED; }
         if (type == PPG_BSDF_MIRROR) { for (int i = 0; i < 3; ++i) { eta[i] = 0.0f; k[i] = 1.0f; } }  // material "none", conductor.cpp:171-173
@@ -1614,10 +1616,13 @@ struct BSDF {
     static bool allDelta(const Material &m) { return !isSmooth(m); }  // (type & EDelta) == (type & EAll)
     // getType() & (ETransmission | EBackSide): twosided sets EBackSide (twosided.cpp:97-101), the dielectric both
     static bool hasBackSideOrTransmission(const Material &m) {
-        return (m.flags & PPG_MAT_TWOSIDED) || m.type == PPG_BSDF_DIELECTRIC || m.type == PPG_BSDF_THINDIELECTRIC;
+        return (m.flags & (PPG_MAT_TWOSIDED | PPG_MAT_MASK)) || m.type == PPG_BSDF_DIELECTRIC || m.type == PPG_BSDF_THINDIELECTRIC;  // mask: mask.cpp:103
     }
-    static bool hasNull(const Material &m) { return m.type == PPG_BSDF_THINDIELECTRIC; }  // getType() & ENull
-    static Spectrum evalNull(const Material &m, Float cosThetaI) { return ThinDielectric::evalNull(m, cosThetaI); }
+    static bool hasNull(const Material &m) { return m.masked() || m.type == PPG_BSDF_THINDIELECTRIC; }  // getType() & ENull
+    static Spectrum evalNull(const Material &m, Float cosThetaI) {  // eval(bRec(its, -wo, wo), EDiscrete), typeMask = ENull
+        if (m.masked()) return Spectrum(1.0f) - m.Opacity();  // mask.cpp:115-116
+        return ThinDielectric::evalNull(m, cosThetaI);
+    }
 
     static Spectrum evalOne(const Material &m, const BRec &b) {
         switch (m.type) {
@@ -1649,19 +1654,46 @@ struct BSDF {
     }
     static bool twoSided(const Material &m) { return (m.flags & PPG_MAT_TWOSIDED) && m.type != PPG_BSDF_DIELECTRIC && m.type != PPG_BSDF_THINDIELECTRIC; }
 
-    static Spectrum eval(const Material &m, const BRec &b) {
+    static Spectrum evalTS(const Material &m, const BRec &b) {
         if (!twoSided(m) || b.wi.z > 0) return evalOne(m, b);
         BRec c = b;  // twosided.cpp:120-135: flip both directions onto the front side
         c.wi.z *= -1; c.wo.z *= -1;
         return evalOne(m, c);
     }
-    static Float pdf(const Material &m, const BRec &b) {
+    static Float pdfTS(const Material &m, const BRec &b) {
         if (!twoSided(m) || b.wi.z > 0) return pdfOne(m, b);
         BRec c = b;
         c.wi.z *= -1; c.wo.z *= -1;
         return pdfOne(m, c);
     }
-    static Spectrum sample(const Material &m, BRec &b, Float &pdf, const Point2 &sample) {
+    // Mask adapter (mask.cpp:108-214), solid-angle measure for eval / pdf
+    static Spectrum eval(const Material &m, const BRec &b) {
+        Spectrum r = evalTS(m, b);
+        return m.masked() ? mul(r, m.Opacity()) : r;
+    }
+    static Float pdf(const Material &m, const BRec &b) {
+        Float r = pdfTS(m, b);
+        return m.masked() ? r * luminance(m.Opacity()) : r;
+    }
+    static Spectrum sample(const Material &m, BRec &b, Float &pdf, const Point2 &_sample) {
+        if (!m.masked()) return sampleTS(m, b, pdf, _sample);
+        Point2 sample(_sample);
+        Spectrum opacity = m.Opacity();
+        Float prob = luminance(opacity);
+        if (sample.x < prob) {
+            sample.x /= prob;
+            Spectrum result = mul(sampleTS(m, b, pdf, sample), opacity) / prob;
+            pdf *= prob;
+            return result;
+        }
+        b.wo = -b.wi;
+        b.eta = 1.0f;
+        b.sampledDelta = true;
+        b.sampledNull = true;
+        pdf = 1 - prob;
+        return (Spectrum(1.0f) - opacity) / pdf;
+    }
+    static Spectrum sampleTS(const Material &m, BRec &b, Float &pdf, const Point2 &sample) {
         if (!twoSided(m)) return sampleOne(m, b, pdf, sample);
         bool flipped = false;  // twosided.cpp:160-180
         if (b.wi.z < 0) { b.wi.z *= -1; flipped = true; }

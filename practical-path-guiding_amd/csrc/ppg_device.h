@@ -584,25 +584,29 @@ D F3 bsdf_sample(int type, F3 refl, F3 wi, float sx, float sy, F3 &wo, float &pd
 // ------------------------------------------------------------------------------------------------
 struct Mat {
     int type, flags;          // type normalised: TWOSIDED_DIFFUSE → DIFFUSE + PPG_MAT_TWOSIDED
-    F3 refl, spec, eta, k;
+    F3 refl, spec, eta, k, opacity;
     float alpha, fdr_int;
 };
+#define PPG_MAT_STRIDE 5  // float4 per material: (reflectance, type) (specular, alpha) (eta, flags) (k, fdrInt) (opacity, -)
 D Mat load_material(const DevScene &S, int id) {
-    const float4 *m = S.materials + 4 * (size_t)id;
+    const float4 *m = S.materials + PPG_MAT_STRIDE * (size_t)id;
     const float4 a = m[0], b = m[1], c = m[2], d = m[3];
+    const float4 e = m[4];
     Mat M;
     M.type = (int)a.w; M.flags = __float_as_int(c.w);
     if (M.type == PPG_BSDF_TWOSIDED_DIFFUSE) { M.type = PPG_BSDF_DIFFUSE; M.flags |= PPG_MAT_TWOSIDED; }
     M.refl = f3(a.x, a.y, a.z); M.spec = f3(b.x, b.y, b.z); M.eta = f3(c.x, c.y, c.z); M.k = f3(d.x, d.y, d.z);
     M.alpha = b.w; M.fdr_int = d.w;
+    M.opacity = f3(e.x, e.y, e.z);
     return M;
 }
 D bool mat_is_smooth(const Mat &M) { return M.type == PPG_BSDF_DIFFUSE || M.type == PPG_BSDF_ROUGHCONDUCTOR || M.type == PPG_BSDF_PLASTIC; }
 D bool mat_two_sided(const Mat &M) { return (M.flags & PPG_MAT_TWOSIDED) && M.type != PPG_BSDF_DIELECTRIC && M.type != PPG_BSDF_THINDIELECTRIC; }
+D bool mat_masked(const Mat &M) { return (M.flags & PPG_MAT_MASK) != 0; }
 D bool mat_backside_or_transmission(const Mat &M) {
-    return (M.flags & PPG_MAT_TWOSIDED) || M.type == PPG_BSDF_DIELECTRIC || M.type == PPG_BSDF_THINDIELECTRIC;
+    return (M.flags & (PPG_MAT_TWOSIDED | PPG_MAT_MASK)) || M.type == PPG_BSDF_DIELECTRIC || M.type == PPG_BSDF_THINDIELECTRIC;
 }
-D bool mat_has_null(const Mat &M) { return M.type == PPG_BSDF_THINDIELECTRIC; }  // getType() & ENull
+D bool mat_has_null(const Mat &M) { return mat_masked(M) || M.type == PPG_BSDF_THINDIELECTRIC; }  // getType() & ENull
 
 D F3 cdiv3(F3 a, F3 b) { return f3(a.x / b.x, a.y / b.y, a.z / b.z); }
 D F3 safe_sqrt3(F3 s) { return f3(__builtin_sqrtf(ppg_max(0.0f, s.x)), __builtin_sqrtf(ppg_max(0.0f, s.y)), __builtin_sqrtf(ppg_max(0.0f, s.z))); }
@@ -725,7 +729,10 @@ D float thin_R(const Mat &M, float cosThetaI) {
     return Rr;
 }
 // BSDF::eval(BSDFSamplingRecord(its, -wo, wo), EDiscrete) restricted to the null component: what a ray going straight through keeps
-D F3 mat_eval_null(const Mat &M, float cosThetaI) { return M.spec * (1 - thin_R(M, cosThetaI)); }
+D F3 mat_eval_null(const Mat &M, float cosThetaI) {
+    if (mat_masked(M)) return f3s(1.0f) - M.opacity;  // mask.cpp:115-116
+    return M.spec * (1 - thin_R(M, cosThetaI));
+}
 
 // one-sided plugins, solid-angle measure
 D F3 mat_eval_one(const Mat &M, F3 wi, F3 wo) {
@@ -839,16 +846,35 @@ D F3 mat_sample_one(const Mat &M, F3 wi, float sx, float sy, F3 &wo, float &pdf,
     }
     return f3s(0.0f);
 }
-// + the TwoSided adapter (twosided.cpp:120-180)
+// + the TwoSided adapter (twosided.cpp:120-180) and, outside it, the Mask adapter (mask.cpp:108-214)
 D F3 mat_eval(const Mat &M, F3 wi, F3 wo) {
     if (mat_two_sided(M) && !(wi.z > 0)) { wi.z *= -1; wo.z *= -1; }
-    return mat_eval_one(M, wi, wo);
+    F3 r = mat_eval_one(M, wi, wo);
+    return mat_masked(M) ? mul3(r, M.opacity) : r;
 }
 D float mat_pdf(const Mat &M, F3 wi, F3 wo) {
     if (mat_two_sided(M) && !(wi.z > 0)) { wi.z *= -1; wo.z *= -1; }
-    return mat_pdf_one(M, wi, wo);
+    float r = mat_pdf_one(M, wi, wo);
+    return mat_masked(M) ? r * lum3(M.opacity) : r;
 }
+D F3 mat_sample_ts(const Mat &M, F3 wi, float sx, float sy, F3 &wo, float &pdf, bool &delta, float &eta, bool &isnull);
 D F3 mat_sample(const Mat &M, F3 wi, float sx, float sy, F3 &wo, float &pdf, bool &delta, float &eta, bool &isnull) {
+    if (!mat_masked(M)) return mat_sample_ts(M, wi, sx, sy, wo, pdf, delta, eta, isnull);
+    const float prob = lum3(M.opacity);
+    if (sx < prob) {
+        sx /= prob;
+        F3 result = div3(mul3(mat_sample_ts(M, wi, sx, sy, wo, pdf, delta, eta, isnull), M.opacity), prob);
+        pdf *= prob;
+        return result;
+    }
+    wo = -wi;
+    eta = 1.0f;
+    delta = true;
+    isnull = true;
+    pdf = 1 - prob;
+    return div3(f3s(1.0f) - M.opacity, pdf);
+}
+D F3 mat_sample_ts(const Mat &M, F3 wi, float sx, float sy, F3 &wo, float &pdf, bool &delta, float &eta, bool &isnull) {
     bool flipped = false;
     if (mat_two_sided(M) && wi.z < 0) { wi.z *= -1; flipped = true; }
     F3 result = mat_sample_one(M, wi, sx, sy, wo, pdf, delta, eta, isnull);

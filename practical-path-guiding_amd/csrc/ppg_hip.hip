@@ -1145,7 +1145,7 @@ int ppg_set_scene(ppg_ctx *ctx, const ppg_scene *s) {
     // material table: 4 x float4 per BSDF = (reflectance, type) (specular, alpha) (eta, flags) (k, fdrInt); the lean kernels read
     // only the first.  configure()-time normalisation as in the plugins: "none" conductor = (eta 0, k 1) (conductor.cpp:171-173),
     // GGX alpha clamped (microfacet.h:135), plastic's internal diffuse Fresnel reflectance (plastic.cpp:191-193)
-    std::vector<float4> mats(4 * (size_t)s->n_materials), ems(std::max<uint32_t>(1, s->n_emitters));
+    std::vector<float4> mats(PPG_MAT_STRIDE * (size_t)s->n_materials), ems(std::max<uint32_t>(1, s->n_emitters));
     ctx->fullMaterials = false;
     bool hasNull = false;
     for (uint32_t i = 0; i < s->n_materials; ++i) {
@@ -1157,11 +1157,12 @@ int ppg_set_scene(ppg_ctx *ctx, const ppg_scene *s) {
         if ((m.type == PPG_BSDF_PLASTIC || m.type == PPG_BSDF_DIELECTRIC || m.type == PPG_BSDF_THINDIELECTRIC) && !(m.eta[0] > 0)) { ctx->error = "plastic / dielectric need eta[0] = intIOR / extIOR > 0"; return PPG_ERR_INVALID; }
         const float fdrInt = m.type == PPG_BSDF_PLASTIC ? ppg_fresnel_diffuse_reflectance(1 / m.eta[0]) : 0.0f;
         if (m.type > PPG_BSDF_MIRROR || m.flags != 0) ctx->fullMaterials = true;
-        if (m.type == PPG_BSDF_THINDIELECTRIC) hasNull = true;
-        mats[4 * i + 0] = make_float4(m.reflectance[0], m.reflectance[1], m.reflectance[2], (float)m.type);
-        mats[4 * i + 1] = make_float4(m.specular[0], m.specular[1], m.specular[2], m.alpha);
-        mats[4 * i + 2] = make_float4(m.eta[0], m.eta[1], m.eta[2], __builtin_bit_cast(float, m.flags));
-        mats[4 * i + 3] = make_float4(m.k[0], m.k[1], m.k[2], fdrInt);
+        if (m.type == PPG_BSDF_THINDIELECTRIC || (m.flags & PPG_MAT_MASK)) hasNull = true;
+        mats[PPG_MAT_STRIDE * i + 0] = make_float4(m.reflectance[0], m.reflectance[1], m.reflectance[2], (float)m.type);
+        mats[PPG_MAT_STRIDE * i + 1] = make_float4(m.specular[0], m.specular[1], m.specular[2], m.alpha);
+        mats[PPG_MAT_STRIDE * i + 2] = make_float4(m.eta[0], m.eta[1], m.eta[2], __builtin_bit_cast(float, m.flags));
+        mats[PPG_MAT_STRIDE * i + 3] = make_float4(m.k[0], m.k[1], m.k[2], fdrInt);
+        mats[PPG_MAT_STRIDE * i + 4] = make_float4(m.opacity[0], m.opacity[1], m.opacity[2], 0.0f);
     }
     for (uint32_t i = 0; i < s->n_emitters; ++i) ems[i] = make_float4(s->emitters[i].radiance[0], s->emitters[i].radiance[1], s->emitters[i].radiance[2], 0);
     HIP_CHECK(ctx->d_tris.reserve(tris.size()));

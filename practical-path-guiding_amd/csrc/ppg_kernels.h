@@ -819,7 +819,7 @@ D void shade_slice(const PathState &P, const DevScene &S, const DevTree &T, cons
                 if (FULL) {
                     M = load_material(S, I.material);
                 } else {
-                    const float4 mat = S.materials[4 * (size_t)I.material];
+                    const float4 mat = S.materials[PPG_MAT_STRIDE * (size_t)I.material];
                     M.type = (int)mat.w; M.flags = 0; M.refl = f3(mat.x, mat.y, mat.z);
                 }
                 const bool smooth = FULL ? mat_is_smooth(M) : bsdf_is_smooth(M.type);  // bsdf->getType() & ESmooth: only those are guided
@@ -993,9 +993,17 @@ D void shade_slice(const PathState &P, const DevScene &S, const DevTree &T, cons
                         flags |= FL_PENDING | (smooth ? FL_PEND_TREE : 0u) | (sampledDelta ? FL_PEND_DELTA : 0u);
                         if (NEE && dot3(wo, refN) >= 0) flags |= FL_PEND_REFN;
                         if (NEE && FULL && P.nee_cos) P.nee_cos[i] = noRefN ? -2.0f : dot3(wo, refN);
-                        // GP:2045-2075: a sampled null interaction.  (Its vertex record, GP:2051-2068, needs a D-tree, i.e. a smooth/null
-                        // hybrid such as `mask`; the only null BSDF supported, thindielectric, is all-delta and has none.)
-                        if (FULL && sampledNull) flags |= FL_PEND_NULL;
+                        if (FULL && sampledNull) {
+                            // GP:2045-2075: a sampled null interaction.  Smooth/null hybrids (mask) record it for the sampling-fraction
+                            // optimiser (GP:2047-2068): the slot's d / throughput / bsdfVal were written just above; radiance stays 0, delta.
+                            flags |= FL_PEND_NULL;
+                            if (R.loss != LOSS_NONE && smooth && nV < PPG_MAX_VERTICES && nV < (unsigned int)R.max_vertices && !R.is_final_iter) {
+                                if (1 / woPdf > 0) {
+                                    P.v_rad[(size_t)nV * P.n_paths + i] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float((unsigned int)leaf | 0x80000000u));
+                                    ++nV;
+                                }
+                            }
+                        }
                         m.w = (unsigned int)leaf;
                         l4.w = woPdf;
                         alive = true;

@@ -6,7 +6,7 @@
               film hdrfilm (width, height; rfilter box)
   shapes      obj (filename, toWorld, faceNormals, flipNormals, flipTexCoords, collapse), rectangle (toWorld, flipNormals)
   bsdfs       diffuse, conductor (material none, or explicit eta / k), roughconductor (ggx, isotropic), plastic, dielectric, thindielectric,
-              twosided(any of the BRDFs) — top level with id, nested, or <ref id>
+              mask (constant opacity), twosided(any of the BRDFs) — top level with id, nested, or <ref id>
   emitters    area (nested in a shape), constant (environment)
   values      <spectrum>, <rgb>, <srgb> (spectrum.py), <transform> of translate / rotate / scale / lookAt / matrix,
               <default name value> and $name substitution (mitsuba -D, mitsuba.cpp:58-87)
@@ -419,6 +419,16 @@ def load_scene(path, defines=None, strict=True, width=None, height=None):
                     return dict(type=1, reflectance=m["reflectance"])
                 return dict(m, twosided=True)
             t = "twosided(%s)" % ",".join(c.get("type", "?") for c in inner)
+        elif t == "mask" and allow_twosided:
+            inner = [c for c in elem if c.tag == "bsdf"]
+            if len(inner) == 1:
+                m = make_bsdf(inner[0])
+                if "opacity" in m:
+                    raise SceneError("mask(mask(...)) is not supported")
+                if m["type"] == 1:
+                    m = dict(type=0, reflectance=m["reflectance"], twosided=True)
+                return dict(m, opacity=rgb("opacity", 0.5))
+            t = "mask(%s)" % ",".join(c.get("type", "?") for c in inner)
         elif t == "conductor":
             if str(p.get("material", "Cu")).lower() == "none":
                 return dict(type=2, reflectance=rgb("specularReflectance", 1.0))
@@ -586,7 +596,11 @@ def save_scene_xml(desc, props, directory, name="scene"):
             6: '<bsdf type="dielectric"%%s>%s<rgb name="specularReflectance" value="%s"/><rgb name="specularTransmittance" value="%s"/></bsdf>' % (one, R, S),
             7: '<bsdf type="thindielectric"%%s>%s<rgb name="specularReflectance" value="%s"/><rgb name="specularTransmittance" value="%s"/></bsdf>' % (one, R, S),
         }[t]
-        if t == 1 or (M.flags & 1 and t not in (6, 7)):
+        twos = t == 1 or (M.flags & 1 and t not in (6, 7))
+        if M.flags & 4:
+            inner = ('<bsdf type="twosided">%s</bsdf>' % (body % "")) if twos else body % ""
+            out.append('\t<bsdf type="mask" id="mat%d"><rgb name="opacity" value="%s"/>%s</bsdf>' % (i, c(M.opacity), inner))
+        elif twos:
             out.append('\t<bsdf type="twosided" id="mat%d">%s</bsdf>' % (i, body % ""))
         else:
             out.append('\t' + body % (' id="mat%d"' % i))

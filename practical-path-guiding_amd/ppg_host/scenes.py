@@ -29,7 +29,7 @@ class SceneDesc:
 def save_scene(desc, path):
     """Write the flat binary scene read by host/ppg_render.cpp: "PPGS", 6 x uint32 {n_vertices, n_triangles, n_materials,
     n_emitters, has_normals, has_environment}, then positions, [normals], indices, tri_material, tri_emitter, materials
-    (ppg_material, 64 bytes each), emitters (4 floats), camera (ppg_camera), [environment radiance: 3 floats]."""
+    (ppg_material, 80 bytes each), emitters (4 floats), camera (ppg_camera), [environment radiance: 3 floats]."""
     import struct
     pos = np.ascontiguousarray(desc.positions, np.float32)
     idx = np.ascontiguousarray(desc.indices, np.uint32)
@@ -46,7 +46,7 @@ def save_scene(desc, path):
         f.write(np.ascontiguousarray(desc.tri_emitter, np.int32).tobytes())
         from .bindings import Material
         for m in desc.materials:
-            f.write(bytes(Material.from_dict(m)))  # ppg_material, 64 bytes
+            f.write(bytes(Material.from_dict(m)))  # ppg_material, 80 bytes
         for e in desc.emitters:
             f.write(struct.pack("<4f", *[float(np.float32(v)) for v in e["radiance"]], 0))
         c = desc.camera

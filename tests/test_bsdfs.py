@@ -224,3 +224,29 @@ def test_thindielectric_null_component(oracle_lib):
     a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
     oracle_lib.ppgo_bsdf_flags(C.byref(m), C.byref(a), C.byref(b), C.byref(c))
     assert (a.value, b.value, c.value) == (0, 1, 1)
+
+
+def test_mask_adapter(oracle_lib):
+    """mask.cpp:108-214 around a diffuse BRDF: pass-through with probability 1 - luminance(opacity) and weight (1 - opacity) / (1 - prob);
+    otherwise the nested sample scaled by opacity / prob; eval / pdf of the solid-angle measure scaled by opacity / prob."""
+    op = np.float32([0.9, 0.6, 0.3])
+    base = dict(type="diffuse", reflectance=(0.5, 0.6, 0.7))
+    mat = dict(base, opacity=tuple(op))
+    prob = float(np.float32(op[0] * np.float32(0.212671) + op[1] * np.float32(0.715160) + op[2] * np.float32(0.072169)))
+    rng = np.random.RandomState(8)
+    xy = rng.rand(200000, 2).astype(np.float32)
+    wi = unit((0.3, 0.2, 0.9))
+    wo, w, pdf, e, delta = bsdf_sample(oracle_lib, mat, wi, xy)
+    null = np.all(np.isclose(wo, -wi, atol=1e-7), axis=1)
+    assert abs(null.mean() - (1 - prob)) < 0.004 and np.all(delta[null] == 1) and np.all(delta[~null] == 0)
+    assert np.allclose(pdf[null], 1 - prob, rtol=1e-6) and np.allclose(w[null], (1 - op) / (1 - prob), rtol=1e-5)
+    f, p = bsdf_eval(oracle_lib, mat, wi, wo[~null])
+    f0, p0 = bsdf_eval(oracle_lib, base, wi, wo[~null])
+    assert np.allclose(f, f0 * op, rtol=1e-6) and np.allclose(p, p0 * prob, rtol=1e-6)
+    assert np.allclose(w[~null], f / p[:, None], rtol=2e-3) and np.allclose(pdf[~null], p, rtol=2e-3)
+    # energy: E[weight] = opacity * albedo + (1 - opacity)
+    assert np.allclose(w.astype(np.float64).mean(0), op * np.float32([0.5, 0.6, 0.7]) + (1 - op), atol=0.01)
+    m = Material.from_dict(mat)
+    a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+    oracle_lib.ppgo_bsdf_flags(C.byref(m), C.byref(a), C.byref(b), C.byref(c))
+    assert (a.value, b.value, c.value) == (1, 0, 1)  # still smooth (guided), not all-delta, EBackSide set by the null component

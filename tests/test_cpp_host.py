@@ -49,7 +49,7 @@ def test_scene_file_round_trip(tmp_path):
     assert (nv, nt, nm, ne, has_n) == (72, 36, 5, 1, 0)
     off = 28
     assert np.array_equal(np.frombuffer(buf, np.float32, nv * 3, off).reshape(-1, 3), s.positions)
-    expect = 28 + nv * 12 + nt * 12 + nt * 4 + nt * 4 + nm * 64 + ne * 16 + (16 + 16) * 4 + 16
+    expect = 28 + nv * 12 + nt * 12 + nt * 4 + nt * 4 + nm * 80 + ne * 16 + (16 + 16) * 4 + 16
     assert len(buf) == expect
     w, h = struct.unpack_from("<2i", buf, len(buf) - 8)
     assert (w, h) == (40, 30)

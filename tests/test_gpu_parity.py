@@ -561,3 +561,24 @@ def test_constant_environment_emitter_against_oracle(oracle_lib, extra):
     scene.environment = None
     dark = ppg_host.GuidedPathTracer(engine=hip(**props)).render(scene)
     assert np.nanmean(ig) > 1.3 * np.nanmean(dark)
+
+
+@pytest.mark.parametrize("extra", [dict(bsdfSamplingFractionLoss="kl"), dict(nee="kickstart", **IMPROVED), dict(nee="always", maxDepth=-1, rrDepth=3, strictNormals=0)],
+                         ids=["kl", "nee-kickstart-improved", "nee-always-unbounded"])
+def test_mask_bsdf_against_oracle(oracle_lib, extra):
+    """mask (a smooth/null hybrid): the surface is guided, its sampled pass-through is a delta vertex recorded for the sampling-fraction
+    optimiser (GP:2047-2068), emitters are seen through it (GP:2184-2245) and shadow rays are attenuated by 1 - opacity."""
+    import ppg_host
+    scene = _pane_scene((56, 56))
+    scene.materials[-1] = dict(type="diffuse", reflectance=(0.7, 0.7, 0.7), twosided=True, opacity=(0.35, 0.4, 0.45))   # the panes: masked, two-sided
+    scene.materials = list(scene.materials) + [dict(type="roughconductor", alpha=0.3, eta=(0.2, 0.9, 1.1), k=(3.9, 2.4, 2.1), opacity=(0.8, 0.8, 0.8))]
+    tm = scene.tri_material.copy(); tm[12:24] = len(scene.materials) - 1; scene.tri_material = tm   # short box: masked GGX
+    props = dict(CBOX_PROPS, budget=60, seed=45)
+    props.update(maxDepth=11, rrDepth=5)
+    props.update(extra)
+    g, o = hip(**props), make_oracle(oracle_lib, threads=os.cpu_count() or 8, **props)
+    gg, go = ppg_host.GuidedPathTracer(engine=g), ppg_host.GuidedPathTracer(engine=o)
+    ig, io = gg.render(scene), go.render(scene)
+    assert _stats(gg) == _stats(go)
+    assert np.array_equal(ig, io, equal_nan=True)
+    assert_tree_equal(g.read_sdtree(), o.read_sdtree())

@@ -270,8 +270,10 @@ def test_full_material_set_survives_the_xml_round_trip(tmp_path):
         dict(type="plastic", reflectance=(0.2, 0.35, 0.7), specular=(1, 0.9, 0.8), eta=1.49, nonlinear=True),
         dict(type="dielectric", eta=1.5, reflectance=(1, 1, 1), specular=(0.98, 0.99, 0.98)),
         dict(type="mirror", reflectance=(0.7, 0.8, 0.9)), dict(type=1, reflectance=(0.3, 0.3, 0.3)),
-        dict(type="thindielectric", eta=1.33, reflectance=(1, 1, 1), specular=(0.9, 0.9, 1.0))]
-    tm = scene.tri_material.copy(); tm[2:16:2] = np.arange(5, 12); scene.tri_material = tm
+        dict(type="thindielectric", eta=1.33, reflectance=(1, 1, 1), specular=(0.9, 0.9, 1.0)),
+        dict(type="diffuse", reflectance=(0.2, 0.3, 0.4), twosided=True, opacity=(0.5, 0.6, 0.7)),
+        dict(type="plastic", reflectance=(0.2, 0.3, 0.4), eta=1.4, opacity=(0.25, 0.25, 0.25))]
+    tm = scene.tri_material.copy(); tm[2:20:2] = np.arange(5, 14); scene.tri_material = tm
     back, _, info = ppg_host.load_scene(ppg_host.save_scene_xml(scene, dict(budgetType="spp", budget=8.0), str(tmp_path)))
     assert not info["warnings"]
     per_tri = lambda s: sorted((tuple(np.sort(t.reshape(-1))), bytes(Material.from_dict(s.materials[m])))  # noqa: E731
