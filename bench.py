@@ -94,11 +94,11 @@ def run(args):
         # BASELINE.json configs[2] "kitchen-class improved": the bundled KITCHEN lacks 6 meshes and cannot travel to the GPU
         # box, so this is the labelled procedural stand-in of SURVEY.md §8(d) S3 (Lambertian only) with the README's
         # "improved" preset; maxDepth -1 / rrDepth 5 as in kitchen-improved.xml.
-        scene = ppg_host.room_scene(args.width, args.height, n_boxes=args.room_boxes, tess=8)
+        scene = ppg_host.room_scene(args.width, args.height, n_boxes=args.room_boxes, tess=8, glossy=args.glossy)
         props.update(sampleCombination="inversevar", bsdfSamplingFractionLoss="kl", spatialFilter="stochastic", directionalFilter="box",
                      sTreeThreshold=4000, maxDepth=-1, rrDepth=5, strictNormals=0)
-        workload = "room-720p (kitchen-class STAND-IN, %d Lambertian triangles), %dx%d, %d spp/pass, %d passes, improved preset" % (
-            scene.n_triangles, args.width, args.height, spp, args.steps)
+        workload = "room-720p (kitchen-class STAND-IN, %d %s triangles), %dx%d, %d spp/pass, %d passes, improved preset" % (
+            scene.n_triangles, "Lambertian / GGX(0.1) / plastic" if args.glossy else "Lambertian", args.width, args.height, spp, args.steps)
 
     def make(budget_passes, timing=False):
         e = ppg_host.Engine.hip(budget=float(budget_passes * spp), **props)
@@ -211,6 +211,7 @@ def main():
     ap.add_argument("--spp", type=int, default=4)
     ap.add_argument("--scene", choices=["cbox", "room"], default="cbox", help="room = kitchen-class procedural stand-in, improved preset")
     ap.add_argument("--room-boxes", type=int, default=1820, help="boxes of the room scene (768 triangles each)")
+    ap.add_argument("--glossy", action="store_true", help="room scene with the S3 material mix (GGX alpha 0.1 metal, plastic) instead of Lambertian only")
     ap.add_argument("--cpu-passes", type=int, default=7, help="passes timed on the CPU baseline (bounded sample)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")

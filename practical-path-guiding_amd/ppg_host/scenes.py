@@ -7,7 +7,8 @@ tools/derive_cbox_rgb.py (dev-time; it reads the CIE tables from the reference c
 box has no /root/reference, hence code instead of files.
 
 `room_scene()` is the "kitchen-class" stand-in of SURVEY.md §8(d) S3: a closed room lit only through
-a slit, filled with tessellated boxes — many triangles, hard indirect light, Lambertian only.
+a slit, filled with tessellated boxes — many triangles, hard indirect light; Lambertian, or (glossy=True) the S3 material mix
+with GGX metal and plastic.
 """
 import math
 
@@ -170,10 +171,11 @@ def cbox_scene(width=512, height=512):
     return _assemble(quads, names, materials, emitters, cam)
 
 
-def room_scene(width=1280, height=720, n_boxes=2000, tess=4, seed=1234):
+def room_scene(width=1280, height=720, n_boxes=2000, tess=4, seed=1234, glossy=False):
     """Kitchen-class stand-in: 4 x 3 x 5 m closed room, one emitter behind a
     ceiling slit (all light is indirect), `n_boxes` random boxes each face tessellated tess x tess.
-    Triangles = 12 * tess^2 * n_boxes + 24.  Deterministic in `seed`; Lambertian only."""
+    Triangles = 12 * tess^2 * n_boxes + 24.  Deterministic in `seed`.  Lambertian only, or with glossy=True the S3 material mix:
+    one box material in three becomes GGX (alpha 0.1) metal, one plastic, the floor plastic (same geometry)."""
     rng = np.random.RandomState(seed)
     mats = ["floor", "wall", "left", "right", "light", "b0", "b1", "b2"]
     quads, qmat, qem = [], [], []  # arrays of shape [n, 4, 3]
@@ -229,6 +231,10 @@ def room_scene(width=1280, height=720, n_boxes=2000, tess=4, seed=1234):
     refl = {"floor": (0.6, 0.55, 0.5), "wall": (0.75, 0.75, 0.75), "left": (0.6, 0.1, 0.1), "right": (0.1, 0.5, 0.15),
             "light": (0.0, 0.0, 0.0), "b0": (0.7, 0.6, 0.4), "b1": (0.3, 0.4, 0.7), "b2": (0.8, 0.8, 0.8)}
     materials = [dict(type=0, reflectance=refl[m]) for m in mats]
+    if glossy:
+        materials[mats.index("b0")] = dict(type="roughconductor", alpha=0.1, eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14), reflectance=(1.0, 1.0, 1.0))
+        materials[mats.index("b1")] = dict(type="plastic", reflectance=refl["b1"], specular=(1.0, 1.0, 1.0), eta=1.49)
+        materials[mats.index("floor")] = dict(type="plastic", reflectance=refl["floor"], specular=(1.0, 1.0, 1.0), eta=1.49)
     emitters = [dict(radiance=(60.0, 55.0, 45.0))]
     cam = perspective_camera((2.0, 1.5, 0.15), (2.0, 1.2, 3.0), (0, 1, 0), 70.0, "x", 0.05, 100.0, width, height)
     return SceneDesc(positions, indices, tri_mat.astype(np.uint32), tri_em.astype(np.int32), materials, emitters, cam)
