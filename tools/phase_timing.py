@@ -1,10 +1,12 @@
 """Wall time per phase of render() (begin_iteration = S-tree refine on the host mirror + upload + D-tree reset;
-passes; finish = variance; build).  usage: phase_timing.py [cbox|room] [passes]"""
+passes; finish = variance; build).  usage: phase_timing.py [cbox|room] [passes] [world]
+world > 1: time rank 0's share of a `world`-way tile shard (no collectives: the compute + fixed host part of one rank)."""
 import sys, time
 sys.path.insert(0, '/root/repo/practical-path-guiding_amd')
 import torch, ppg_host  # noqa
 which = sys.argv[1] if len(sys.argv) > 1 else "cbox"
 n_pass = int(sys.argv[2]) if len(sys.argv) > 2 else (255 if which == "cbox" else 127)
+WORLD = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 if which == "cbox":
     props = dict(budgetType="spp", sppPerPass=4, maxDepth=10, rrDepth=10, strictNormals=1, seed=1234)
     scene = ppg_host.cbox_scene(1280, 720)
@@ -21,6 +23,8 @@ while left > 0:
     passes.append(p); left -= p; it += 1
 for rep in range(2):
     e = ppg_host.Engine.hip(**props); e.set_scene(scene)
+    if WORLD > 1:
+        e.set_shard(0, WORLD, 32)
     t, per_it = {}, []
     def T(name, f, *a):
         torch.cuda.synchronize(); t0 = time.perf_counter(); r = f(*a); torch.cuda.synchronize(); dt = time.perf_counter() - t0
@@ -36,5 +40,5 @@ for rep in range(2):
         per_it.append((p, round(a * 1e3, 2), round(b * 1e3, 2), round(c * 1e3, 2), e.sdtree_info().n_leaves))
     T('end_render', e.end_render)
     tot = time.perf_counter() - t0
-    print(rep, which, 'total %.1f ms' % (tot * 1e3), {k: round(v * 1e3, 2) for k, v in t.items()}, 'Msamples/s %.1f' % (1280 * 720 * props["budget"] / tot / 1e6))
+    print(rep, which, 'world', WORLD, 'total %.1f ms' % (tot * 1e3), {k: round(v * 1e3, 2) for k, v in t.items()}, 'Msamples/s %.1f' % (1280 * 720 * props["budget"] / tot / 1e6))
 print("per iteration (passes, begin_iteration ms, passes ms, build ms, leaves):", per_it)
