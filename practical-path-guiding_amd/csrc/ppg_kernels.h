@@ -416,11 +416,7 @@ D void dtree_record(const DevTree &T, int leaf, float px, float py, float irradi
             unsigned int w32 = (index & 2) ? cw.y : cw.x;
             unsigned int c = (index & 1) ? (w32 >> 16) : (w32 & 0xffffu);
             if (c == 0) {
-#if !(defined(PPG_ABLATE) && PPG_ABLATE == 4)
                 atomicAdd(&T.bacc[(size_t)(base + node) * 4 + index], ppg_to_fixed(irradiance * w));
-#else
-                if (irradiance == 123.456f) T.bacc[0] = 1;
-#endif
                 break;
             }
             node = c;
@@ -489,11 +485,7 @@ D void wrapper_record(const DevTree &T, int leaf, const Rec &rec, int dfilter, i
     }
     const bool wOk = irr && ppg_isfinite(rec.statisticalWeight) && rec.statisticalWeight > 0;
     const unsigned long long wf = wOk ? ppg_to_fixed(rec.statisticalWeight) : 0ull;
-#if defined(PPG_ABLATE) && PPG_ABLATE == 5
-    if (wf == 12345ull) T.bweight[0] = 1;
-#else
     if (COMBINE) wave_key_add<3>(T.bweight_rep, (unsigned int)leaf * PPG_REPLICAS + (blockIdx.x & (PPG_REPLICAS - 1)), wf, wOk);
-#endif
     else if (wOk) atomicAdd(&T.bweight_rep[(size_t)leaf * PPG_REPLICAS + (blockIdx.x & (PPG_REPLICAS - 1))], wf);
     if (wOk) dtree_record(T, leaf, px, py, irradiance, rec.statisticalWeight, dfilter);
 
@@ -975,11 +967,7 @@ D void shade_slice(const PathState &P, const DevScene &S, const DevTree &T, cons
                             P.ray_o[i] = make_float4(I.p.x, I.p.y, I.p.z, PPG_EPSILON);
                         }
                         P.ray_d[i] = make_float4(wo.x, wo.y, wo.z, __builtin_inff());
-#if defined(PPG_ABLATE) && PPG_ABLATE == 2
-                        if (false) {
-#else
                         if (smooth && nV < PPG_MAX_VERTICES && nV < (unsigned int)R.max_vertices && !R.is_final_iter) {
-#endif
                             size_t vi = (size_t)nV * P.n_paths + i;
                             F3 bv = bsdfWeight * woPdf;
                             P.v_d[vi] = make_float4(wo.x, wo.y, wo.z, woPdf);

@@ -4,6 +4,7 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "practical-path-guiding_amd"))
 import numpy as np
+import torch  # noqa: F401  (its HIP runtime must be loaded before libppg_hip.so)
 import ppg_host
 
 res = int(sys.argv[1]) if len(sys.argv) > 1 else 64
