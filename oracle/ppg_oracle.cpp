@@ -1847,7 +1847,7 @@ public:
             if (cancelled) break;
             renderOnePass();
             ++m_passesRendered; ++m_passesRenderedThisIter; ++m_passesLocal;
-            if (m_budgetType == ESeconds && computeElapsedSeconds(m_startTime) > m_budget) break;  // GP:1259-1262
+            if (m_budgetType == ESeconds && (int)computeElapsedSeconds(m_startTime) > m_budget) break;  // GP:1259-1262: whole seconds
         }
     }
 

@@ -729,7 +729,7 @@ int renderPassesNoStat(ppg_ctx *ctx, int numPasses) {  // GP:1217-1286
         i += batch;
         if (ctx->budgetType == 1) {  // seconds: the reference checks after every finished pass (GP:1259-1262)
             HIP_CHECK(hipStreamSynchronize(ctx->stream));
-            if (elapsedSeconds(ctx->startTime) > ctx->budget) break;
+            if ((int)elapsedSeconds(ctx->startTime) > ctx->budget) break;  // `progress = (int) elapsed; shouldAbort = progress > m_budget`
         } else if ((i & 63) < batch) {
             HIP_CHECK(hipStreamSynchronize(ctx->stream));  // bound the launch queue; also lets ppg_cancel() take effect
         }

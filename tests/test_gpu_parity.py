@@ -582,3 +582,25 @@ def test_mask_bsdf_against_oracle(oracle_lib, extra):
     assert _stats(gg) == _stats(go)
     assert np.array_equal(ig, io, equal_nan=True)
     assert_tree_equal(g.read_sdtree(), o.read_sdtree())
+
+
+def test_time_budget_automatic_dumps_and_memory_cap(oracle_lib, tmp_path):
+    """budgetType = seconds (the reference's default) on the GPU; the automatic per-iteration .sdt dumps; sdTreeMaxMemory — the latter two
+    compared with the oracle."""
+    import ppg_host
+    from test_host_logic import _time_budget_checks
+    _time_budget_checks(lambda **p: hip(**p), ppg_host.cbox_scene(160, 90), 0.5)
+    scene = ppg_host.cbox_scene(48, 48)
+    for name, mk in (("g", hip), ("o", lambda **p: make_oracle(oracle_lib, **p))):
+        e = mk(budget=60, seed=2, dumpSDTree=1, dumpPrefix=str(tmp_path / name), **CBOX_PROPS)
+        ppg_host.GuidedPathTracer(engine=e).render(scene)
+    gf, of = sorted(f for f in os.listdir(tmp_path) if f.startswith("g-")), sorted(f for f in os.listdir(tmp_path) if f.startswith("o-"))
+    assert len(gf) == 3 and [f[1:] for f in gf] == [f[1:] for f in of]
+    for a, b in zip(gf, of):
+        assert open(tmp_path / a, "rb").read() == open(tmp_path / b, "rb").read()
+    for cap, leaves in ((0, 1), (1, None)):
+        p = dict(CBOX_PROPS, budget=124, seed=2, sTreeThreshold=200, sdTreeMaxMemory=cap)
+        g, o = hip(**p), make_oracle(oracle_lib, **p)
+        assert np.array_equal(ppg_host.GuidedPathTracer(engine=g).render(scene), ppg_host.GuidedPathTracer(engine=o).render(scene))
+        assert_tree_equal(g.read_sdtree(), o.read_sdtree())
+        assert leaves is None or g.read_sdtree()["n_leaves"] == leaves

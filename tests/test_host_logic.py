@@ -150,3 +150,51 @@ def test_sharded_render_over_gloo_equals_single_rank(oracle_lib, tmp_path, mode)
         assert np.array_equal(got["dch"], ref_t["sampling"]["node_children"]) and np.array_equal(got["dsum"], ref_t["sampling"]["node_sums"])
         assert np.array_equal(got["film"], ref_img)
         assert np.array_equal(got["theta"], ref_t["theta"])
+
+
+def _time_budget_checks(make_engine, scene, budget):
+    """renderTime (GP:1434-1514): iterations of 1, 2, 4, ... passes until the budget is spent; with sampleCombination = automatic the
+    last iteration keeps rendering batches of its own size until the time is up (GP:1482-1501)."""
+    import time
+    import ppg_host
+    for combo in ("automatic", "discard"):
+        e = make_engine(budgetType="seconds", budget=budget, sampleCombination=combo, seed=5, maxDepth=6)
+        g = ppg_host.GuidedPathTracer(engine=e)
+        t0 = time.monotonic()
+        img = g.render(scene)
+        dt = time.monotonic() - t0
+        passes = [it["passes"] for it in g.iterations]
+        assert passes == [1 << k for k in range(len(passes))] and len(passes) >= 2
+        assert dt >= budget * 0.98 and np.isfinite(img).all() and img.mean() > 0.01
+        # inside an iteration the reference aborts only once the elapsed time in WHOLE seconds exceeds the budget (GP:1259-1262)
+        done = g.iterations[-1]["stats"][-1]["passes_rendered_total"]
+        assert sum(passes[:-1]) < done
+        if combo == "discard":
+            assert done <= sum(passes) and all(len(it["stats"]) == 1 for it in g.iterations)
+        assert dt < budget + 1.5
+        # the single-call entry point runs the same loop
+        e2 = make_engine(budgetType="seconds", budget=budget / 2, sampleCombination=combo, seed=5, maxDepth=6)
+        e2.set_scene(scene)
+        t0 = time.monotonic(); e2.render(); dt2 = time.monotonic() - t0
+        assert dt2 >= budget / 2 * 0.98 and np.isfinite(e2.read_film()).all()
+
+
+def test_time_budget_on_the_oracle(oracle_lib):
+    import ppg_host
+    _time_budget_checks(lambda **p: make_oracle(oracle_lib, threads=4, **p), ppg_host.cbox_scene(24, 24), 0.6)
+
+
+def test_automatic_sdt_dumps_and_memory_cap(oracle_lib, tmp_path):
+    import ppg_host
+    scene = ppg_host.cbox_scene(32, 32)
+    prefix = str(tmp_path / "run")
+    e = make_oracle(oracle_lib, budget=60, seed=2, dumpSDTree=1, dumpPrefix=prefix, **CBOX_PROPS)
+    g = ppg_host.GuidedPathTracer(engine=e); g.render(scene)
+    # "<dest>-%02d.sdt" after every training iteration, none for the final one (GP:1191-1195, 1417-1420)
+    files = sorted(os.listdir(tmp_path))
+    assert files == ["run-%02d.sdt" % k for k in range(len(g.iterations) - 1)]
+    assert all(os.path.getsize(tmp_path / f) > 64 for f in files)
+    # sdTreeMaxMemory (GP:957-962): once the footprint estimate reaches the cap the S-tree stops being refined
+    free = make_oracle(oracle_lib, budget=124, seed=2, sTreeThreshold=200, **CBOX_PROPS); free.set_scene(scene); free.render()
+    capped = make_oracle(oracle_lib, budget=124, seed=2, sTreeThreshold=200, sdTreeMaxMemory=0, **CBOX_PROPS); capped.set_scene(scene); capped.render()
+    assert capped.read_sdtree()["n_leaves"] == 1 < free.read_sdtree()["n_leaves"]  # footprint / 1e6 >= 0 always: never refined
