@@ -2,9 +2,10 @@
  * ppg_hip.hip — libppg_hip.so: host side of the MI355X guided path tracer behind the C-ABI of include/ppg.h.
  *
  * Host responsibilities (thin): property parsing (GP:1014-1085), BVH build, pool management, the
- * iteration schedule of render()/renderSPP()/renderTime() (GP:1342-1585), S-tree refine (GP:957-998 — a
- * few thousand nodes, done on the host mirror and uploaded), statistics.  Everything per path, per
- * D-tree node or per pixel runs in the kernels of ppg_kernels.h.
+ * iteration schedule of render()/renderSPP()/renderTime() (GP:1342-1585), the statistics log.  Everything per
+ * path, per S-tree / D-tree node or per pixel runs in the kernels of ppg_kernels.h — including the SD-tree rebuild
+ * between iterations (S-tree refine, D-tree reset and build); the host keeps a read-back mirror of the S-tree for
+ * the log, the dumps and the readers.
  */
 #include <hip/hip_runtime.h>
 
@@ -302,6 +303,9 @@ struct ppg_ctx {
     DevBuf<unsigned long long> d_bacc, d_bweight, d_adamW, d_total, d_bweightRep;
     DevBuf<long long> d_adamGrad;
     DevBuf<unsigned int> d_leaves, d_counts, d_offsets, d_grid;
+    DevBuf<unsigned int> d_dfs[2], d_refEv, d_refLv, d_refEvOff, d_refLvOff;  // S-tree refine: leaves in the reference's (right-first) visiting order
+    int dfsCur = 0;
+    unsigned int dfsCount = 0;
     int ldsNodes = 0, ldsTris = 0;  // scene part cached in LDS by k_trace
     float treeMin[3], treeMax[3], treeExt[3];
     bool isBuilt = false, isFinalIter = false, doNee = false;
@@ -357,14 +361,18 @@ float elapsedSeconds(std::chrono::steady_clock::time_point start) {  // GP:1428-
     return (float)ms.count() / 1000;
 }
 
-int uploadTree(ppg_ctx *ctx) {
+// nodes: also copy the S-tree nodes and leaf headers host → device (only needed when the host mirror is the newer copy, i.e. for the
+// single root node at the start of a render; afterwards the device refines the tree and the host mirror is downloaded from it)
+int uploadTree(ppg_ctx *ctx, bool nodes) {
     size_t n = ctx->snodes.size();
-    std::vector<int4> st(n);
-    for (size_t i = 0; i < n; ++i) st[i] = make_int4(ctx->snodes[i].axis, (int)ctx->snodes[i].child[0], (int)ctx->snodes[i].child[1], 0);
-    HIP_CHECK(ctx->d_stree.reserve(n));
-    HIP_CHECK(ctx->d_hdr.reserve(n));
-    HIP_CHECK(hipMemcpyAsync(ctx->d_stree.p, st.data(), n * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
-    HIP_CHECK(hipMemcpyAsync(ctx->d_hdr.p, ctx->hdr.data(), n * sizeof(LeafHdr), hipMemcpyHostToDevice, ctx->stream));
+    std::vector<int4> st(nodes ? n : 0);
+    if (nodes) {
+        for (size_t i = 0; i < n; ++i) st[i] = make_int4(ctx->snodes[i].axis, (int)ctx->snodes[i].child[0], (int)ctx->snodes[i].child[1], 0);
+        HIP_CHECK(ctx->d_stree.reserve(n));
+        HIP_CHECK(ctx->d_hdr.reserve(n));
+        HIP_CHECK(hipMemcpyAsync(ctx->d_stree.p, st.data(), n * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
+        HIP_CHECK(hipMemcpyAsync(ctx->d_hdr.p, ctx->hdr.data(), n * sizeof(LeafHdr), hipMemcpyHostToDevice, ctx->stream));
+    }
     ctx->leaves.clear();
     for (size_t i = 0; i < n; ++i) if (ctx->snodes[i].isLeaf()) ctx->leaves.push_back((unsigned int)i);
     HIP_CHECK(ctx->d_leaves.reserve(ctx->leaves.size()));
@@ -390,47 +398,52 @@ int uploadTree(ppg_ctx *ctx) {
     return PPG_OK;
 }
 
-// STree::refine (GP:957-998) + subdivide (GP:876-895) on the host mirror; the D-trees of a split leaf are
-// shared by reference (both children point at the parent's sampling block; reset() rebuilds `building`).
-void refineHost(ppg_ctx *ctx, size_t sTreeThreshold, int maxMB) {
+// STree::refine (GP:957-998) + subdivide (GP:876-895) on the device (k_refine_count → scans → k_refine_fill, ppg_kernels.h);
+// the host mirror (node array, leaf headers) is then downloaded — it feeds the statistics log, the dumps and the readers.
+int refineDevice(ppg_ctx *ctx, size_t sTreeThreshold, int maxMB) {
     auto &nodes = ctx->snodes;
     auto &hdr = ctx->hdr;
     if (maxMB >= 0) {
         size_t foot = 0;  // approxMemoryFootprint with the reference's sizeof (QuadTreeNode 24 B, DTree 40 B)
         for (size_t i = 0; i < nodes.size(); ++i) foot += nodes[i].isLeaf() ? ((size_t)hdr[i].b_num * 24 + 40) + ((size_t)hdr[i].s_num * 24 + 40) : 2 * (24 + 40);
-        if (foot / 1000000 >= (size_t)maxMB) return;
+        if (foot / 1000000 >= (size_t)maxMB) return PPG_OK;
     }
-    struct SN { size_t index; int depth; };
-    std::vector<SN> stack;
-    stack.push_back({0, 1});
-    while (!stack.empty()) {
-        SN s = stack.back();
-        stack.pop_back();
-        if (nodes[s.index].isLeaf()) {
-            if (nodes.size() < std::numeric_limits<uint32_t>::max() - 1 && hdr[s.index].b_statw > (float)sTreeThreshold) {
-                size_t base = nodes.size();
-                nodes.resize(base + 2);
-                hdr.resize(base + 2);
-                for (int i = 0; i < 2; ++i) {
-                    nodes[s.index].child[i] = (uint32_t)(base + i);
-                    nodes[base + i].axis = (nodes[s.index].axis + 1) % 3;
-                    hdr[base + i] = hdr[s.index];
-                    hdr[base + i].b_statw = hdr[base + i].b_statw / 2;
-                }
-                LeafHdr cleared{};  // cur.dTree = {}
-                cleared.s_base = 0; cleared.s_num = 0;
-                hdr[s.index] = cleared;
-            }
-        }
-        if (!nodes[s.index].isLeaf())
-            for (int i = 0; i < 2; ++i) stack.push_back({nodes[s.index].child[i], s.depth + 1});
-    }
+    const unsigned int nl = ctx->dfsCount, nOld = (unsigned int)nodes.size();
+    hipStream_t s = ctx->stream;
+    HIP_CHECK(ctx->d_refEv.reserve(nl)); HIP_CHECK(ctx->d_refLv.reserve(nl)); HIP_CHECK(ctx->d_refEvOff.reserve(nl)); HIP_CHECK(ctx->d_refLvOff.reserve(nl));
+    HIP_CHECK(ctx->d_total.reserve(2));
+    hipLaunchKernelGGL(k_refine_count, dim3((nl + 255) / 256), dim3(256), 0, s, ctx->d_hdr.p, ctx->d_dfs[ctx->dfsCur].p, nl, (float)sTreeThreshold,
+                       ctx->d_refEv.p, ctx->d_refLv.p);
+    hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, s, ctx->d_refEv.p, ctx->d_refEvOff.p, nl, ctx->d_total.p);
+    hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, s, ctx->d_refLv.p, ctx->d_refLvOff.p, nl, ctx->d_total.p + 1);
+    unsigned long long totals[2] = {0, 0};
+    HIP_CHECK(hipMemcpyAsync(totals, ctx->d_total.p, 16, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    if (totals[0] == 0) return PPG_OK;  // no leaf exceeded the threshold
+    const unsigned long long nNew = (unsigned long long)nOld + 2ull * totals[0];
+    if (nNew >= (1ull << 27)) { ctx->error = "S-tree exceeds 2^27 nodes"; return PPG_ERR_NOMEM; }
+    HIP_CHECK(ctx->d_stree.reserve((size_t)nNew, true));
+    HIP_CHECK(ctx->d_hdr.reserve((size_t)nNew, true));
+    HIP_CHECK(ctx->d_dfs[ctx->dfsCur ^ 1].reserve((size_t)totals[1]));
+    hipLaunchKernelGGL(k_refine_fill, dim3(nl), dim3(256), 0, s, ctx->d_stree.p, ctx->d_hdr.p, ctx->d_dfs[ctx->dfsCur].p, nl, nOld, ctx->d_refEv.p,
+                       ctx->d_refEvOff.p, ctx->d_refLvOff.p, ctx->d_dfs[ctx->dfsCur ^ 1].p);
+    ctx->dfsCur ^= 1;
+    ctx->dfsCount = (unsigned int)totals[1];
+    std::vector<int4> st((size_t)nNew);
+    hdr.resize((size_t)nNew);
+    HIP_CHECK(hipMemcpyAsync(st.data(), ctx->d_stree.p, st.size() * sizeof(int4), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipMemcpyAsync(hdr.data(), ctx->d_hdr.p, hdr.size() * sizeof(LeafHdr), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    nodes.resize((size_t)nNew);
+    for (size_t i = 0; i < nodes.size(); ++i) { nodes[i].axis = st[i].x; nodes[i].child[0] = (uint32_t)st[i].y; nodes[i].child[1] = (uint32_t)st[i].z; }
+    return PPG_OK;
 }
 
 int resetSDTree(ppg_ctx *ctx) {  // GP:1108-1113
     double thr = std::sqrt(std::ldexp(1.0, ctx->iter) * ctx->sppPerPass / 4) * ctx->sTreeThreshold;
-    refineHost(ctx, (size_t)thr, ctx->sdTreeMaxMemory);
-    int rc = uploadTree(ctx);
+    int rc = refineDevice(ctx, (size_t)thr, ctx->sdTreeMaxMemory);
+    if (rc) return rc;
+    rc = uploadTree(ctx, false);
     if (rc) return rc;
     unsigned int nl = (unsigned int)ctx->leaves.size();
     HIP_CHECK(ctx->d_total.reserve(1));
@@ -810,6 +823,14 @@ int beginRender(ppg_ctx *ctx) {  // GP:1519-1550
     HIP_CHECK(hipMemsetAsync(ctx->d_snodes[0].p, 0, sizeof(SNode), ctx->stream));
     ctx->cur = 0;
     ctx->hdr[0].s_base = 0; ctx->hdr[0].s_num = 1;
+    {   // the root node goes to the device once; from here on the device owns the S-tree (refineDevice) and the host mirrors it
+        int rc = uploadTree(ctx, true);
+        if (rc) return rc;
+        const unsigned int root = 0;
+        HIP_CHECK(ctx->d_dfs[0].reserve(1));
+        HIP_CHECK(hipMemcpy(ctx->d_dfs[0].p, &root, 4, hipMemcpyHostToDevice));
+        ctx->dfsCur = 0; ctx->dfsCount = 1;
+    }
     ctx->nSamplingNodes = 1; ctx->nBuildingNodes = 0;
     ctx->iter = 0; ctx->isFinalIter = false; ctx->isBuilt = false;
     size_t n = (size_t)ctx->W * ctx->H;

@@ -1344,6 +1344,80 @@ __global__ void k_dtree_build(DevTree T, const unsigned int *leaves, unsigned in
     T.hdr[leaf] = h;
 }
 
+// ------------------------------------------------------------------------------------------------
+// STree::refine (GP:957-998) + STreeNode::subdivide (GP:876-895) on the device
+// ------------------------------------------------------------------------------------------------
+// The reference walks the tree with an explicit LIFO stack (child 0 pushed first, so child 1 is visited first) and
+// subdivides a leaf while its building weight exceeds the threshold; every subdivision appends two nodes that inherit the
+// parent's D-trees with half its weight.  A leaf of weight W therefore becomes a COMPLETE binary subtree of depth
+// n = #{halvings until W / 2^n <= threshold}, all of whose 2^n - 1 subdivisions happen consecutively (the stack finishes a
+// subtree before anything else), in right-first preorder.  With the old leaves kept in that right-first order (`dfs`), node
+// numbers are closed-form:
+//   first new node of old leaf j      = n_old + 2 * (number of subdivisions of the leaves before j)      (exclusive scan)
+//   children of subdivision e of leaf j = base_j + 2 e, base_j + 2 e + 1                                   (e = preorder index)
+// so every subdivision of every leaf can be written independently.  Results are identical to the serial loop, node for node.
+__global__ void k_refine_count(const LeafHdr *hdr, const unsigned int *dfs, unsigned int n_leaves, float threshold, unsigned int *events,
+                               unsigned int *new_leaves) {
+    unsigned int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_leaves) return;
+    float w = hdr[dfs[j]].b_statw;
+    unsigned int n = 0;
+    while (w > threshold && n < 30u) { w = w / 2; ++n; }  // shallSplit (GP:953-955); children get half the weight (GP:886)
+    events[j] = (1u << n) - 1u;
+    new_leaves[j] = 1u << n;
+}
+
+// one workgroup per old leaf; thread e handles subdivision e of that leaf's subtree
+__global__ void k_refine_fill(int4 *stree, LeafHdr *hdr, const unsigned int *dfs, unsigned int n_leaves, unsigned int n_old,
+                              const unsigned int *events, const unsigned int *ev_off, const unsigned int *lv_off, unsigned int *dfs_out) {
+    const unsigned int j = blockIdx.x;
+    if (j >= n_leaves) return;
+    const unsigned int L = dfs[j];
+    const unsigned int n_ev = events[j];
+    if (n_ev == 0) {
+        if (threadIdx.x == 0) dfs_out[lv_off[j]] = L;
+        return;
+    }
+    unsigned int n = 0;
+    while (((1u << n) - 1u) < n_ev) ++n;  // depth of the complete subtree
+    __shared__ LeafHdr H;
+    __shared__ int axis0;
+    if (threadIdx.x == 0) { H = hdr[L]; axis0 = stree[L].x; }
+    __syncthreads();
+    const unsigned int base = n_old + 2u * ev_off[j];
+    LeafHdr cleared;  // cur.dTree = {} (GP:893)
+    {
+        unsigned int *z = reinterpret_cast<unsigned int *>(&cleared);
+        for (unsigned int q = 0; q < sizeof(LeafHdr) / 4; ++q) z[q] = 0u;
+    }
+    for (unsigned int e = threadIdx.x; e < n_ev; e += blockDim.x) {
+        // locate subdivision e: walk down from the leaf; at depth k each child subtree holds S = 2^(n-k-1) - 1 subdivisions,
+        // the right child's come first
+        unsigned int node = L, k = 0, cur = 0, rem = e, pos = 0;
+        while (rem != 0) {
+            rem -= 1;
+            const unsigned int S = (1u << (n - k - 1)) - 1u;
+            if (rem < S) { node = base + 2u * cur + 1u; cur = cur + 1u; }
+            else { rem -= S; node = base + 2u * cur; cur = cur + 1u + S; pos += 1u << (n - k - 1); }
+            ++k;
+        }
+        const unsigned int c0 = base + 2u * e, c1 = c0 + 1u;
+        stree[node] = make_int4((axis0 + (int)k) % 3, (int)c0, (int)c1, 0);
+        hdr[node] = cleared;
+        if (k + 1 == n) {  // the children are the new leaves: copies of the old leaf with the weight halved once per level
+            LeafHdr h = H;
+            float w = h.b_statw;
+            for (unsigned int t = 0; t <= k; ++t) w = w / 2;
+            h.b_statw = w;
+            const int ax = (axis0 + (int)k + 1) % 3;
+            stree[c0] = make_int4(ax, 0, 0, 0); hdr[c0] = h;
+            stree[c1] = make_int4(ax, 0, 0, 0); hdr[c1] = h;
+            dfs_out[lv_off[j] + pos] = c1;       // right child first
+            dfs_out[lv_off[j] + pos + 1u] = c0;
+        }
+    }
+}
+
 // exclusive scan of `counts` (n small: one S-tree leaf each) by a single workgroup; total → *total_out
 __global__ void k_scan_exclusive(const unsigned int *counts, unsigned int *offsets, unsigned int n, unsigned long long *total_out) {
     __shared__ unsigned long long part[1024];
