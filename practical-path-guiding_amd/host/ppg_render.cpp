@@ -2,6 +2,7 @@
  * ppg_render — stand-alone C++ driver of the guided path tracer (the role `mitsuba scene.xml` plays for
  * plugins/guided_path.so; flags follow mitsuba.cpp:154-250 where they apply).
  *
+ *   ppg_render [-D key=value]... [-o out.pfm] [-q] scene.xml      (Mitsuba scene XML, supported subset: host/scene_xml.h)
  *   ppg_render [-D key=value]... [-o out.pfm] [-q] scene.ppgs
  *   ppg_render --cbox WIDTHxHEIGHT [-D key=value]... [-o out.pfm]
  * A Mitsuba scene XML is converted first: `python -m ppg_host scene.xml --ppgs scene.ppgs` (also writes scene.ppgs.props,
@@ -18,6 +19,7 @@
 #include <iostream>
 
 #include "guided_path_hip.h"
+#include "scene_xml.h"
 
 using namespace ppg;
 
@@ -101,11 +103,30 @@ static void writePFM(const char *path, const std::vector<float> &rgb, int w, int
     for (int y = h - 1; y >= 0; --y) f.write((const char *)&rgb[(size_t)y * w * 3], (size_t)w * 12);  // PFM is bottom-up
 }
 
+// the flat scene file of ppg_host.save_scene (for tests and for handing a loaded XML scene to other tools)
+static bool saveScene(const char *path, const SceneData &s) {
+    std::ofstream f(path, std::ios::binary);
+    const uint32_t hdr[6] = {(uint32_t)(s.positions.size() / 3), (uint32_t)(s.indices.size() / 3), (uint32_t)s.materials.size(), (uint32_t)s.emitters.size(),
+                             s.normals.empty() ? 0u : 1u, s.hasEnvironment ? 1u : 0u};
+    f.write("PPGS", 4); f.write((const char *)hdr, sizeof hdr);
+    f.write((const char *)s.positions.data(), s.positions.size() * 4);
+    if (!s.normals.empty()) f.write((const char *)s.normals.data(), s.normals.size() * 4);
+    f.write((const char *)s.indices.data(), s.indices.size() * 4);
+    f.write((const char *)s.triMaterial.data(), s.triMaterial.size() * 4);
+    f.write((const char *)s.triEmitter.data(), s.triEmitter.size() * 4);
+    f.write((const char *)s.materials.data(), s.materials.size() * sizeof(ppg_material));
+    f.write((const char *)s.emitters.data(), s.emitters.size() * sizeof(ppg_emitter));
+    f.write((const char *)&s.camera, sizeof(ppg_camera));
+    if (s.hasEnvironment) f.write((const char *)s.environment, 12);
+    return (bool)f;
+}
+
 int main(int argc, char **argv) {
     Properties props;
-    std::string out = "out.pfm", scenePath;
-    bool quiet = false;
-    int cw = 0, ch = 0;
+    std::string out = "out.pfm", scenePath, dumpScene;
+    bool quiet = false, lenient = false;
+    int cw = 0, ch = 0, sw = 0, sh = 0;
+    std::map<std::string, std::string> defines;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         if (a == "-D" && i + 1 < argc) {
@@ -113,10 +134,14 @@ int main(int argc, char **argv) {
             size_t eq = kv.find('=');
             if (eq == std::string::npos) { std::cerr << "-D expects key=value\n"; return 2; }
             props.values[kv.substr(0, eq)] = kv.substr(eq + 1);
+            defines[kv.substr(0, eq)] = kv.substr(eq + 1);  // also a $name for a scene XML, like mitsuba -D (mitsuba.cpp:58-87)
         } else if (a == "-o" && i + 1 < argc) out = argv[++i];
+        else if (a == "--ppgs" && i + 1 < argc) dumpScene = argv[++i];
+        else if (a == "--lenient") lenient = true;
+        else if (a == "--size" && i + 1 < argc) { if (sscanf(argv[++i], "%dx%d", &sw, &sh) != 2) { std::cerr << "--size WxH\n"; return 2; } }
         else if (a == "-q") quiet = true;
         else if (a == "--cbox" && i + 1 < argc) { if (sscanf(argv[++i], "%dx%d", &cw, &ch) != 2) { std::cerr << "--cbox WxH\n"; return 2; } }
-        else if (a == "-h" || a == "--help") { std::cout << "usage: ppg_render [-D key=value]... [-o out.pfm] [-q] (scene.ppgs | --cbox WxH)\n"; return 0; }
+        else if (a == "-h" || a == "--help") { std::cout << "usage: ppg_render [-D key=value]... [-o out.pfm] [-q] [--size WxH] [--lenient] [--ppgs flat-scene-out] (scene.xml | scene.ppgs | --cbox WxH)\n"; return 0; }
         else scenePath = a;
     }
     // scene.ppgs.props (written next to the flat scene by `python -m ppg_host scene.xml --ppgs scene.ppgs`): the XML's
@@ -134,8 +159,25 @@ int main(int argc, char **argv) {
         }
     }
     SceneData scene;
+    const bool isXml = scenePath.size() > 4 && scenePath.compare(scenePath.size() - 4, 4, ".xml") == 0;
     if (cw > 0) cboxScene(cw, ch, scene);
-    else if (scenePath.empty() || !loadScene(scenePath.c_str(), scene)) { std::cerr << "cannot load scene '" << scenePath << "'\n"; return 2; }
+    else if (isXml) {
+        try {
+            LoadedScene ls = SceneXmlLoader(scenePath, defines, !lenient, sw, sh).load();
+            for (auto &w : ls.warnings) if (!quiet) std::cerr << "warning: " << w << std::endl;
+            scene = std::move(ls.scene);
+            for (auto &kv : ls.integrator.values) if (!props.values.count(kv.first)) props.values[kv.first] = kv.second;  // -D on the command line wins
+        } catch (const std::exception &e) {
+            std::cerr << "cannot load scene '" << scenePath << "': " << e.what() << std::endl;
+            return 2;
+        }
+    } else if (scenePath.empty() || !loadScene(scenePath.c_str(), scene)) { std::cerr << "cannot load scene '" << scenePath << "'\n"; return 2; }
+    if (!dumpScene.empty()) {  // convert only (no GPU needed)
+        if (!saveScene(dumpScene.c_str(), scene)) { std::cerr << "cannot write '" << dumpScene << "'\n"; return 2; }
+        std::ofstream pf(dumpScene + ".props");
+        for (auto &kv : props.values) pf << kv.first << "=" << kv.second << "\n";
+        return 0;
+    }
     try {
         GuidedPathTracerHIP gpt(props);
         const auto t0 = std::chrono::steady_clock::now();

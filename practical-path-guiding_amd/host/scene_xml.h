@@ -1,0 +1,741 @@
+/*
+ * scene_xml.h — C++ loader for the subset of Mitsuba 0.6 scene XML the reference's bundled scenes use, so that
+ * `ppg_render scene.xml` reads what `mitsuba scene.xml` reads:
+ *
+ *   integrator  guided_path (properties of guided_path.cpp:1014-1085 and integrator.cpp:192-218)
+ *   sensor      perspective (fov, fovAxis, nearClip, farClip, toWorld), film hdrfilm (width, height; rfilter box)
+ *   shapes      obj (filename, toWorld, faceNormals, flipNormals, flipTexCoords, collapse), rectangle (toWorld, flipNormals)
+ *   bsdfs       diffuse, conductor, roughconductor (ggx, isotropic), plastic, dielectric, thindielectric, mask (constant opacity),
+ *               twosided(BRDF) — top level with id, nested, or <ref id>
+ *   emitters    area (nested in a shape), constant (environment)
+ *   values      <spectrum>, <rgb>, <srgb>; <transform> of translate / rotate / scale / lookAt / matrix; <default> and $name
+ *
+ * Anything else throws std::runtime_error naming the plugin.  Same semantics as ppg_host/mitsuba_xml.py (the two are tested against each
+ * other); the OBJ reader follows shapes/obj.cpp:198-342 and TriMesh::computeNormals (trimesh.cpp:608-676).  Header only.
+ */
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "guided_path_hip.h"
+
+namespace ppg {
+
+// ------------------------------------------------------------------------------------------------ minimal XML
+struct XmlNode {
+    std::string tag;
+    std::vector<std::pair<std::string, std::string>> attrs;
+    std::vector<XmlNode> children;
+    const std::string *attr(const std::string &k) const {
+        for (auto &a : attrs) if (a.first == k) return &a.second;
+        return nullptr;
+    }
+    std::string get(const std::string &k, const std::string &d = "") const { auto *a = attr(k); return a ? *a : d; }
+    const XmlNode *child(const std::string &t) const {
+        for (auto &c : children) if (c.tag == t) return &c;
+        return nullptr;
+    }
+};
+
+class XmlParser {
+public:
+    explicit XmlParser(const std::string &text) : s(text), p(0) {}
+    XmlNode parseDocument() {
+        skipMisc();
+        XmlNode root = parseElement();
+        return root;
+    }
+
+private:
+    const std::string &s;
+    size_t p;
+    [[noreturn]] void fail(const std::string &m) const { throw std::runtime_error("XML: " + m + " at offset " + std::to_string(p)); }
+    void skipWs() { while (p < s.size() && std::isspace((unsigned char)s[p])) ++p; }
+    bool starts(const char *t) const { return s.compare(p, strlen(t), t) == 0; }
+    void skipMisc() {
+        for (;;) {
+            skipWs();
+            if (starts("<?")) { size_t e = s.find("?>", p); if (e == std::string::npos) fail("unterminated <?"); p = e + 2; }
+            else if (starts("<!--")) { size_t e = s.find("-->", p); if (e == std::string::npos) fail("unterminated comment"); p = e + 3; }
+            else if (starts("<!")) { size_t e = s.find('>', p); if (e == std::string::npos) fail("unterminated <!"); p = e + 1; }
+            else break;
+        }
+    }
+    static std::string unescape(const std::string &v) {
+        std::string o;
+        for (size_t i = 0; i < v.size(); ++i) {
+            if (v[i] != '&') { o += v[i]; continue; }
+            static const std::pair<const char *, char> ent[] = {{"&quot;", '"'}, {"&amp;", '&'}, {"&lt;", '<'}, {"&gt;", '>'}, {"&apos;", '\''}};
+            bool done = false;
+            for (auto &e : ent) if (v.compare(i, strlen(e.first), e.first) == 0) { o += e.second; i += strlen(e.first) - 1; done = true; break; }
+            if (!done) o += v[i];
+        }
+        return o;
+    }
+    std::string name() {
+        size_t b = p;
+        while (p < s.size() && (std::isalnum((unsigned char)s[p]) || s[p] == '_' || s[p] == '-' || s[p] == ':' || s[p] == '.')) ++p;
+        if (p == b) fail("name expected");
+        return s.substr(b, p - b);
+    }
+    XmlNode parseElement() {
+        if (p >= s.size() || s[p] != '<') fail("'<' expected");
+        ++p;
+        XmlNode n;
+        n.tag = name();
+        for (;;) {
+            skipWs();
+            if (p >= s.size()) fail("unterminated tag");
+            if (s[p] == '/') { if (s.compare(p, 2, "/>") != 0) fail("'/>' expected"); p += 2; return n; }
+            if (s[p] == '>') { ++p; break; }
+            std::string k = name();
+            skipWs();
+            if (p >= s.size() || s[p] != '=') fail("'=' expected");
+            ++p; skipWs();
+            if (p >= s.size() || (s[p] != '"' && s[p] != '\'')) fail("quoted value expected");
+            char q = s[p++];
+            size_t e = s.find(q, p);
+            if (e == std::string::npos) fail("unterminated attribute");
+            n.attrs.emplace_back(k, unescape(s.substr(p, e - p)));
+            p = e + 1;
+        }
+        for (;;) {  // content
+            size_t lt = s.find('<', p);
+            if (lt == std::string::npos) fail("unterminated element <" + n.tag + ">");
+            p = lt;
+            if (starts("<!--")) { size_t e = s.find("-->", p); if (e == std::string::npos) fail("unterminated comment"); p = e + 3; continue; }
+            if (starts("</")) {
+                p += 2;
+                std::string t = name();
+                if (t != n.tag) fail("</" + t + "> closes <" + n.tag + ">");
+                skipWs();
+                if (p >= s.size() || s[p] != '>') fail("'>' expected");
+                ++p;
+                return n;
+            }
+            n.children.push_back(parseElement());
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ small float algebra
+struct Mat4 {
+    float m[16];
+    static Mat4 identity() { Mat4 r{}; r.m[0] = r.m[5] = r.m[10] = r.m[15] = 1; return r; }
+    Mat4 operator*(const Mat4 &o) const {
+        Mat4 r{};
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { float a = 0; for (int k = 0; k < 4; ++k) a += m[4 * i + k] * o.m[4 * k + j]; r.m[4 * i + j] = a; }
+        return r;
+    }
+};
+struct V3 { float x, y, z; };
+inline V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline V3 normalized(V3 a) { float l = std::sqrt(dot(a, a)); return {a.x / l, a.y / l, a.z / l}; }
+inline V3 xfPoint(const Mat4 &m, V3 p) {
+    float x = m.m[0] * p.x + m.m[1] * p.y + m.m[2] * p.z + m.m[3], y = m.m[4] * p.x + m.m[5] * p.y + m.m[6] * p.z + m.m[7];
+    float z = m.m[8] * p.x + m.m[9] * p.y + m.m[10] * p.z + m.m[11], w = m.m[12] * p.x + m.m[13] * p.y + m.m[14] * p.z + m.m[15];
+    if (w != 1) { x /= w; y /= w; z /= w; }
+    return {x, y, z};
+}
+// inverse transpose of the upper 3x3 in double (Transform::operator()(Normal))
+inline void normalMatrix(const Mat4 &m, double out[9]) {
+    const double a = m.m[0], b = m.m[1], c = m.m[2], d = m.m[4], e = m.m[5], f = m.m[6], g = m.m[8], h = m.m[9], i = m.m[10];
+    const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+    const double inv[9] = {(e * i - f * h) / det, (c * h - b * i) / det, (b * f - c * e) / det, (f * g - d * i) / det, (a * i - c * g) / det,
+                           (c * d - a * f) / det, (d * h - e * g) / det, (b * g - a * h) / det, (a * e - b * d) / det};
+    for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 3; ++cc) out[3 * r + cc] = inv[3 * cc + r];  // transpose
+}
+inline V3 xfNormal(const double nm[9], V3 n) {
+    return {(float)(nm[0] * n.x + nm[1] * n.y + nm[2] * n.z), (float)(nm[3] * n.x + nm[4] * n.y + nm[5] * n.z), (float)(nm[6] * n.x + nm[7] * n.y + nm[8] * n.z)};
+}
+
+// ------------------------------------------------------------------------------------------------ colour values (ppg_host/spectrum.py)
+namespace detail {
+static const double kCIE[471][3] = {
+#include "cie1931_xyz_1nm.inc"
+};
+inline double evalInterp(const std::vector<double> &lam, const std::vector<double> &val, double g) {  // incl. the reversed lerp, spectrum.cpp:693-706
+    if (lam.size() < 2 || g < lam.front() || g > lam.back()) return 0.0;
+    size_t i = std::lower_bound(lam.begin(), lam.end(), g) - lam.begin();
+    if (lam[std::min(i, lam.size() - 1)] == g) return val[std::min(i, lam.size() - 1)];
+    i = std::max<size_t>(1, std::min(i, lam.size() - 1));
+    const double a = lam[i - 1], b = lam[i], fa = val[i - 1], fb = val[i], t = (g - a) / (b - a);
+    return (1 - t) * fb + t * fa;
+}
+}  // namespace detail
+
+inline void interpolatedToRGB(std::vector<double> lam, std::vector<double> val, float rgb[3]) {
+    using namespace detail;
+    const double spacing = (lam.back() - lam.front()) / (lam.size() - 1);  // zeroExtend, spectrum.cpp:630-648
+    if (val.front() != 0) { lam.insert(lam.begin(), lam.front() - spacing); val.insert(val.begin(), 0.0); }
+    if (val.back() != 0) { lam.push_back(lam.back() + spacing); val.push_back(0.0); }
+    std::vector<double> wl(471), cx(471), cy(471), cz(471);
+    for (int i = 0; i < 471; ++i) { wl[i] = 360.0 + i; cx[i] = kCIE[i][0]; cy[i] = kCIE[i][1]; cz[i] = kCIE[i][2]; }
+    const double step = 0.00731;  // off-node sampling: exact hits have measure zero
+    double X = 0, Y = 0, Z = 0, N = 0, pg = 0, ps[4] = {0, 0, 0, 0};
+    bool first = true;
+    for (long k = 0;; ++k) {
+        const double g = 360.0 + k * step;
+        if (!(g < 830.0)) break;
+        const double s = evalInterp(lam, val, g), x = evalInterp(wl, cx, g), y = evalInterp(wl, cy, g), z = evalInterp(wl, cz, g);
+        const double cur[4] = {s * x, s * y, s * z, y};
+        if (!first) { const double h = 0.5 * (g - pg); X += h * (cur[0] + ps[0]); Y += h * (cur[1] + ps[1]); Z += h * (cur[2] + ps[2]); N += h * (cur[3] + ps[3]); }
+        first = false; pg = g;
+        for (int c = 0; c < 4; ++c) ps[c] = cur[c];
+    }
+    X /= N; Y /= N; Z /= N;
+    const double r = 3.240479 * X - 1.537150 * Y - 0.498535 * Z, gg = -0.969256 * X + 1.875991 * Y + 0.041556 * Z, b = 0.055648 * X - 0.204043 * Y + 1.057311 * Z;
+    rgb[0] = (float)std::max(r, 0.0); rgb[1] = (float)std::max(gg, 0.0); rgb[2] = (float)std::max(b, 0.0);
+}
+
+inline std::vector<double> parseFloats(std::string t) {
+    for (char &c : t) if (c == ',') c = ' ';
+    std::istringstream is(t);
+    std::vector<double> v;
+    double x;
+    while (is >> x) v.push_back(x);
+    return v;
+}
+
+inline void parseColour(const std::string &tag, const std::string &value, float rgb[3]) {
+    if (tag == "rgb" || tag == "srgb") {
+        double c[3];
+        std::string v = value;
+        v.erase(0, v.find_first_not_of(" \t"));
+        if (!v.empty() && v[0] == '#') {
+            for (int k = 0; k < 3; ++k) c[k] = std::stoi(v.substr(1 + 2 * k, 2), nullptr, 16) / 255.0;
+        } else {
+            auto f = parseFloats(v);
+            if (f.size() == 1) f = {f[0], f[0], f[0]};
+            if (f.size() != 3) throw std::runtime_error("expected 1 or 3 colour components, got '" + value + "'");
+            for (int k = 0; k < 3; ++k) c[k] = f[k];
+        }
+        for (int k = 0; k < 3; ++k) rgb[k] = (float)(tag == "srgb" ? (c[k] <= 0.04045 ? c[k] / 12.92 : std::pow((c[k] + 0.055) / 1.055, 2.4)) : c[k]);
+        return;
+    }
+    if (tag == "spectrum") {
+        if (value.find(':') != std::string::npos) {
+            std::string t = value;
+            for (char &ch : t) if (ch == ',' || ch == ':') ch = ' ';
+            auto f = parseFloats(t);
+            std::vector<double> lam, val;
+            for (size_t k = 0; k + 1 < f.size(); k += 2) { lam.push_back(f[k]); val.push_back(f[k + 1]); }
+            interpolatedToRGB(lam, val, rgb);
+            return;
+        }
+        auto f = parseFloats(value);
+        if (f.size() == 1) { rgb[0] = rgb[1] = rgb[2] = (float)f[0]; return; }
+        if (f.size() == 3) { for (int k = 0; k < 3; ++k) rgb[k] = (float)f[k]; return; }
+    }
+    throw std::runtime_error("unsupported colour element <" + tag + " value=\"" + value + "\">");
+}
+
+// ------------------------------------------------------------------------------------------------ OBJ (shapes/obj.cpp:198-342)
+struct Mesh {
+    std::vector<V3> positions, normals;  // normals empty = none
+    std::vector<uint32_t> indices;
+};
+
+inline float unitAngle(V3 u, V3 v) {  // util.h:309-314
+    V3 s{v.x + u.x, v.y + u.y, v.z + u.z}, d{v.x - u.x, v.y - u.y, v.z - u.z};
+    if (dot(u, v) < 0) return 3.14159265358979323846f - 2 * std::asin(0.5f * std::sqrt(dot(s, s)));
+    return 2 * std::asin(0.5f * std::sqrt(dot(d, d)));
+}
+
+inline void computeNormals(Mesh &m, bool flip) {  // TriMesh::computeNormals, smooth branch (trimesh.cpp:631-671)
+    m.normals.assign(m.positions.size(), V3{0, 0, 0});
+    for (size_t t = 0; t + 2 < m.indices.size(); t += 3) {
+        V3 n{0, 0, 0};
+        for (int i = 0; i < 3; ++i) {
+            const V3 &v0 = m.positions[m.indices[t + i]], &v1 = m.positions[m.indices[t + (i + 1) % 3]], &v2 = m.positions[m.indices[t + (i + 2) % 3]];
+            V3 sideA = v1 - v0, sideB = v2 - v0;
+            if (i == 0) {
+                n = cross(sideA, sideB);
+                float len = std::sqrt(dot(n, n));
+                if (len == 0) break;
+                n = {n.x / len, n.y / len, n.z / len};
+            }
+            float angle = unitAngle(normalized(sideA), normalized(sideB));
+            V3 &dst = m.normals[m.indices[t + i]];
+            dst = {dst.x + n.x * angle, dst.y + n.y * angle, dst.z + n.z * angle};
+        }
+    }
+    for (V3 &n : m.normals) {
+        float len = std::sqrt(dot(n, n));
+        if (flip) len *= -1;
+        if (len != 0) n = {n.x / len, n.y / len, n.z / len};
+        else n = {1, 0, 0};
+    }
+}
+
+inline std::vector<Mesh> loadOBJ(const std::string &path, const Mat4 &toWorld, bool faceNormals, bool flipNormals, bool flipTexCoords, bool collapse) {
+    std::ifstream is(path);
+    if (!is) throw std::runtime_error("Wavefront OBJ file '" + path + "' not found!");
+    std::vector<V3> V, N;
+    std::vector<std::pair<float, float>> UV;
+    struct Corner { int p, uv, n; };
+    std::vector<Corner> tris;  // 3 per triangle
+    std::vector<Mesh> meshes;
+    double nm[9];
+    normalMatrix(toWorld, nm);
+    auto flush = [&]() {
+        if (tris.empty()) return;
+        std::vector<V3> pw(V.size()), nw(N.size());
+        for (size_t i = 0; i < V.size(); ++i) pw[i] = xfPoint(toWorld, V[i]);
+        for (size_t i = 0; i < N.size(); ++i) {
+            V3 n = xfNormal(nm, N[i]);
+            float l = std::sqrt(dot(n, n));
+            nw[i] = l != 0 ? V3{n.x / l, n.y / l, n.z / l} : n;
+        }
+        struct Key { float v[8]; bool operator<(const Key &o) const { return std::lexicographical_compare(v, v + 8, o.v, o.v + 8); } };
+        std::map<Key, uint32_t> vmap;
+        Mesh m;
+        std::vector<V3> vn;
+        bool hasNormals = false;
+        for (const Corner &c : tris) {
+            int p = c.p, n = c.n, uv = c.uv;
+            if (p < 0) p += (int)V.size() + 1;
+            if (n < 0) n += (int)N.size() + 1;
+            if (uv < 0) uv += (int)UV.size() + 1;
+            if (p <= 0 || p > (int)V.size()) throw std::runtime_error(path + ": vertex index out of bounds");
+            if (n > (int)N.size() || uv > (int)UV.size()) throw std::runtime_error(path + ": normal / uv index out of bounds");
+            V3 pn = n ? nw[n - 1] : V3{0, 0, 0};
+            hasNormals |= n != 0;
+            std::pair<float, float> puv = uv ? UV[uv - 1] : std::make_pair(0.0f, 0.0f);
+            Key k{{pw[p - 1].x, pw[p - 1].y, pw[p - 1].z, pn.x, pn.y, pn.z, puv.first, puv.second}};
+            auto it = vmap.find(k);
+            uint32_t id;
+            if (it == vmap.end()) { id = (uint32_t)m.positions.size(); vmap[k] = id; m.positions.push_back(pw[p - 1]); vn.push_back(pn); }
+            else id = it->second;
+            m.indices.push_back(id);
+        }
+        if (faceNormals) {
+            if (flipNormals) for (size_t t = 0; t + 2 < m.indices.size(); t += 3) std::swap(m.indices[t], m.indices[t + 1]);
+        } else if (hasNormals) {
+            m.normals = vn;
+            if (flipNormals) for (V3 &n : m.normals) n = {-n.x, -n.y, -n.z};
+        } else {
+            computeNormals(m, flipNormals);
+        }
+        meshes.push_back(std::move(m));
+        tris.clear();
+    };
+    std::string line, pending;
+    auto handle = [&](const std::string &ln) {
+        std::istringstream iss(ln);
+        std::string buf;
+        if (!(iss >> buf)) return;
+        if (buf == "v") { V3 p{0, 0, 0}; iss >> p.x >> p.y >> p.z; V.push_back(p); }
+        else if (buf == "vn") { V3 n{0, 0, 0}; iss >> n.x >> n.y >> n.z; N.push_back(n); }
+        else if (buf == "vt") { float u = 0, v = 0; iss >> u >> v; UV.emplace_back(u, flipTexCoords ? 1 - v : v); }
+        else if (buf == "g" && !collapse) flush();
+        else if (buf == "usemtl") { if (!collapse) flush(); }
+        else if (buf == "f") {
+            std::vector<Corner> cs;
+            std::string tok;
+            while (iss >> tok) {
+                Corner c{0, 0, 0};
+                size_t a = tok.find('/');
+                c.p = std::atoi(tok.substr(0, a).c_str());
+                if (a != std::string::npos) {
+                    size_t b = tok.find('/', a + 1);
+                    std::string suv = tok.substr(a + 1, b == std::string::npos ? std::string::npos : b - a - 1);
+                    if (!suv.empty()) c.uv = std::atoi(suv.c_str());
+                    if (b != std::string::npos && b + 1 < tok.size()) c.n = std::atoi(tok.substr(b + 1).c_str());
+                }
+                cs.push_back(c);
+            }
+            if (cs.size() < 3) throw std::runtime_error(path + ": face with fewer than 3 vertices");
+            for (size_t k = 1; k + 1 < cs.size(); ++k) { tris.push_back(cs[0]); tris.push_back(cs[k]); tris.push_back(cs[k + 1]); }  // fan
+        }
+    };
+    while (std::getline(is, line)) {
+        while (!line.empty() && (line.back() == '\r' || line.back() == '\n' || line.back() == '\t' || line.back() == ' ')) line.pop_back();
+        if (!line.empty() && line.back() == '\\') { line.pop_back(); pending += line; continue; }  // obj.cpp:166-188
+        handle(pending + line);
+        pending.clear();
+    }
+    if (!pending.empty()) handle(pending);
+    flush();
+    return meshes;
+}
+
+// ------------------------------------------------------------------------------------------------ the scene
+struct LoadedScene {
+    SceneData scene;
+    Properties integrator;          // guided_path properties as given in the XML
+    std::vector<std::string> warnings;
+};
+
+class SceneXmlLoader {
+public:
+    SceneXmlLoader(const std::string &path, const std::map<std::string, std::string> &defines, bool strict = true, int width = 0, int height = 0)
+        : m_path(path), m_params(defines), m_strict(strict), m_w(width), m_h(height) {}
+
+    LoadedScene load() {
+        std::ifstream f(m_path, std::ios::binary);
+        if (!f) throw std::runtime_error("cannot open '" + m_path + "'");
+        std::stringstream ss; ss << f.rdbuf();
+        const std::string text = ss.str();
+        XmlNode root = XmlParser(text).parseDocument();
+        if (root.tag != "scene") throw std::runtime_error(m_path + ": root element is <" + root.tag + ">, expected <scene>");
+        size_t slash = m_path.find_last_of('/');
+        m_base = slash == std::string::npos ? "." : m_path.substr(0, slash);
+        collectDefaults(root);
+        LoadedScene out;
+        // integrator
+        const XmlNode *integ = root.child("integrator");
+        if (!integ) throw std::runtime_error("no <integrator>");
+        if (integ->get("type") != "guided_path") throw std::runtime_error("integrator type '" + integ->get("type") + "' is not supported: this path implements 'guided_path' only");
+        static const char *known[] = {"nee", "sampleCombination", "spatialFilter", "directionalFilter", "bsdfSamplingFractionLoss", "budgetType", "sdTreeMaxMemory",
+                                      "sTreeThreshold", "dTreeThreshold", "bsdfSamplingFraction", "sppPerPass", "budget", "dumpSDTree", "rrDepth", "maxDepth",
+                                      "strictNormals", "hideEmitters"};
+        for (auto &c : integ->children) {
+            if (!c.attr("name")) continue;
+            const std::string k = c.get("name"), v = sub(c.get("value"));
+            if (std::find_if(std::begin(known), std::end(known), [&](const char *n) { return k == n; }) == std::end(known)) {
+                out.warnings.push_back("integrator property '" + k + "' is not used by guided_path");
+                continue;
+            }
+            out.integrator.values[k] = v;
+        }
+        // sensor
+        const XmlNode *sensor = root.child("sensor");
+        if (!sensor) throw std::runtime_error("no <sensor>");
+        if (sensor->get("type") != "perspective") throw std::runtime_error("sensor type '" + sensor->get("type") + "' is not supported (perspective only)");
+        auto sp = props(*sensor);
+        const XmlNode *film = sensor->child("film");
+        std::map<std::string, std::string> fp;
+        if (film) {
+            fp = props(*film);
+            const XmlNode *rf = film->child("rfilter");
+            if (rf && rf->get("type") != "box") throw std::runtime_error("rfilter type '" + rf->get("type") + "' is not supported (box only; hdrfilm's default 'gaussian' neither)");
+            if (!rf) out.warnings.push_back("no <rfilter>: Mitsuba would default to gaussian; the box filter is used");
+        }
+        const int W = m_w ? m_w : (fp.count("width") ? std::stoi(fp["width"]) : 768), H = m_h ? m_h : (fp.count("height") ? std::stoi(fp["height"]) : 576);
+        if (!sp.count("fov")) throw std::runtime_error("perspective sensor without 'fov' (focalLength is not supported)");
+        Mat4 c2w = Mat4::identity();
+        if (const XmlNode *tw = sensor->child("transform")) c2w = transform(*tw);
+        std::string axis = sp.count("fovAxis") ? sp["fovAxis"] : "x";
+        std::transform(axis.begin(), axis.end(), axis.begin(), ::tolower);
+        makeCamera(out.scene.camera, c2w, std::stod(sp["fov"]), axis, sp.count("nearClip") ? std::stod(sp["nearClip"]) : 1e-2,
+                   sp.count("farClip") ? std::stod(sp["farClip"]) : 1e4, W, H);
+        // bsdfs
+        for (auto &b : root.children) if (b.tag == "bsdf" && b.attr("id")) m_byId[b.get("id")] = intern(makeBsdf(b, true, out), out);
+        for (auto &e : root.children) {
+            if (e.tag != "emitter") continue;
+            if (e.get("type") == "constant" && !out.scene.hasEnvironment) { out.scene.hasEnvironment = true; colour(e, "radiance", 1.0f, out.scene.environment); continue; }
+            throw std::runtime_error("emitter type '" + e.get("type") + "' is not supported (area emitters on shapes and one `constant` environment emitter; SURVEY.md §8 f2)");
+        }
+        // shapes
+        struct Part { Mesh mesh; uint32_t mat; int em; };
+        std::vector<Part> parts;
+        int defaultMat = -1;
+        for (auto &sh : root.children) {
+            if (sh.tag != "shape") continue;
+            const std::string t = sh.get("type");
+            auto pr = props(sh);
+            Mat4 m = Mat4::identity();
+            if (const XmlNode *tw = sh.child("transform")) m = transform(*tw);
+            std::vector<Mesh> meshes;
+            if (t == "obj") {
+                if (!pr.count("filename")) throw std::runtime_error("obj shape without filename");
+                if (pr.count("maxSmoothAngle") || pr.count("shapeIndex")) throw std::runtime_error("obj: maxSmoothAngle / shapeIndex are not supported");
+                std::string fn = pr["filename"];
+                if (fn.empty() || fn[0] != '/') fn = m_base + "/" + fn;
+                meshes = loadOBJ(fn, m, flag(pr, "faceNormals", false), flag(pr, "flipNormals", false), flag(pr, "flipTexCoords", true), flag(pr, "collapse", false));
+            } else if (t == "rectangle") {
+                meshes.push_back(rectangle(m, flag(pr, "flipNormals", false)));
+            } else {
+                throw std::runtime_error("shape type '" + t + "' is not supported (obj, rectangle)");
+            }
+            int mat = -1;
+            for (auto &c : sh.children) {
+                if (c.tag == "bsdf") mat = (int)intern(makeBsdf(c, true, out), out);
+                else if (c.tag == "ref") {
+                    auto it = m_byId.find(c.get("id"));
+                    if (it == m_byId.end()) throw std::runtime_error("<ref id=\"" + c.get("id") + "\">: no such bsdf");
+                    mat = (int)it->second;
+                }
+            }
+            if (mat < 0) {
+                if (defaultMat < 0) { ppg_material d{}; d.type = PPG_BSDF_DIFFUSE; d.reflectance[0] = d.reflectance[1] = d.reflectance[2] = 0.5f; defaults(d); defaultMat = (int)intern(d, out); }
+                mat = defaultMat;
+            }
+            int em = -1;
+            if (const XmlNode *e = sh.child("emitter")) {
+                if (e->get("type") != "area") throw std::runtime_error("emitter type '" + e->get("type") + "' on a shape is not supported (area only)");
+                if (meshes.size() > 1) throw std::runtime_error("Cannot attach an emitter to an OBJ file containing multiple objects!");
+                em = (int)out.scene.emitters.size();
+                ppg_emitter pe{};
+                colour(*e, "radiance", 1.0f, pe.radiance);
+                out.scene.emitters.push_back(pe);
+            }
+            for (auto &mm : meshes) parts.push_back(Part{std::move(mm), (uint32_t)mat, em});
+        }
+        if (parts.empty()) throw std::runtime_error("scene without shapes");
+        bool anyNormals = false;
+        for (auto &p : parts) anyNormals |= !p.mesh.normals.empty();
+        SceneData &S = out.scene;
+        for (auto &p : parts) {
+            Mesh &m = p.mesh;
+            if (anyNormals && m.normals.empty()) {  // un-share the vertices, write the face normals out
+                Mesh u;
+                for (size_t t = 0; t + 2 < m.indices.size(); t += 3) {
+                    V3 a = m.positions[m.indices[t]], b = m.positions[m.indices[t + 1]], c = m.positions[m.indices[t + 2]];
+                    V3 n = cross(b - a, c - a);
+                    float l = std::sqrt(dot(n, n));
+                    if (l != 0) n = {n.x / l, n.y / l, n.z / l};
+                    for (V3 q : {a, b, c}) { u.indices.push_back((uint32_t)u.positions.size()); u.positions.push_back(q); u.normals.push_back(n); }
+                }
+                m = std::move(u);
+            }
+            const uint32_t base = (uint32_t)(S.positions.size() / 3);
+            for (size_t i = 0; i < m.positions.size(); ++i) {
+                S.positions.insert(S.positions.end(), {m.positions[i].x, m.positions[i].y, m.positions[i].z});
+                if (anyNormals) S.normals.insert(S.normals.end(), {m.normals[i].x, m.normals[i].y, m.normals[i].z});
+            }
+            for (uint32_t id : m.indices) S.indices.push_back(base + id);
+            for (size_t t = 0; t < m.indices.size() / 3; ++t) { S.triMaterial.push_back(p.mat); S.triEmitter.push_back(p.em); }
+        }
+        return out;
+    }
+
+private:
+    std::string m_path, m_base;
+    std::map<std::string, std::string> m_params;
+    bool m_strict;
+    int m_w, m_h;
+    std::map<std::string, uint32_t> m_byId;
+    std::vector<std::string> m_matKeys;
+
+    void collectDefaults(const XmlNode &n) {
+        if (n.tag == "default" && n.attr("name") && !m_params.count(n.get("name"))) m_params[n.get("name")] = n.get("value");
+        for (auto &c : n.children) collectDefaults(c);
+    }
+    std::string sub(const std::string &t) const {
+        if (t.find('$') == std::string::npos) return t;
+        std::string o;
+        for (size_t i = 0; i < t.size();) {
+            if (t[i] != '$') { o += t[i++]; continue; }
+            size_t j = i + 1;
+            while (j < t.size() && (std::isalnum((unsigned char)t[j]) || t[j] == '_')) ++j;
+            const std::string k = t.substr(i + 1, j - i - 1);
+            auto it = m_params.find(k);
+            if (it == m_params.end()) throw std::runtime_error("undefined parameter $" + k + " (pass it with -D " + k + "=...)");
+            o += it->second;
+            i = j;
+        }
+        return o;
+    }
+    std::map<std::string, std::string> props(const XmlNode &e) const {
+        std::map<std::string, std::string> o;
+        for (auto &c : e.children)
+            if ((c.tag == "boolean" || c.tag == "integer" || c.tag == "float" || c.tag == "string") && c.attr("name")) o[c.get("name")] = sub(c.get("value"));
+        return o;
+    }
+    static bool flag(const std::map<std::string, std::string> &p, const std::string &k, bool d) {
+        auto it = p.find(k);
+        if (it == p.end()) return d;
+        std::string v = it->second;
+        std::transform(v.begin(), v.end(), v.begin(), ::tolower);
+        return v == "true" || v == "1";
+    }
+    void colour(const XmlNode &e, const std::string &name, float dflt, float rgb[3]) const {
+        for (auto &c : e.children) {
+            if (c.get("name") != name) continue;
+            if (c.tag == "rgb" || c.tag == "srgb" || c.tag == "spectrum") {
+                if (c.attr("filename")) throw std::runtime_error("<spectrum filename=...> is not supported");
+                parseColour(c.tag, sub(c.get("value")), rgb);
+                return;
+            }
+            if (c.tag == "texture" || c.tag == "ref") throw std::runtime_error("textured '" + name + "' is not supported (SURVEY.md §8 f1)");
+        }
+        rgb[0] = rgb[1] = rgb[2] = dflt;
+    }
+    bool hasChildNamed(const XmlNode &e, const std::string &name) const {
+        for (auto &c : e.children) if (c.get("name") == name) return true;
+        return false;
+    }
+    Mat4 transform(const XmlNode &e) const {
+        Mat4 m = Mat4::identity();
+        for (auto &c : e.children) {
+            auto g = [&](const char *k, float d) { auto *a = c.attr(k); return a ? std::stof(sub(*a)) : d; };
+            Mat4 t = Mat4::identity();
+            if (c.tag == "translate") { t.m[3] = g("x", 0); t.m[7] = g("y", 0); t.m[11] = g("z", 0); }
+            else if (c.tag == "scale") {
+                if (c.attr("value")) { t.m[0] = t.m[5] = t.m[10] = g("value", 1); }
+                else { t.m[0] = g("x", 1); t.m[5] = g("y", 1); t.m[10] = g("z", 1); }
+            } else if (c.tag == "rotate") {  // Transform::rotate, transform.cpp:65-97
+                V3 a = normalized(V3{g("x", 0), g("y", 0), g("z", 0)});
+                const float th = g("angle", 0) * (float)(3.14159265358979323846 / 180.0), s = std::sin(th), co = std::cos(th);
+                t.m[0] = a.x * a.x + (1 - a.x * a.x) * co; t.m[1] = a.x * a.y * (1 - co) - a.z * s; t.m[2] = a.x * a.z * (1 - co) + a.y * s;
+                t.m[4] = a.x * a.y * (1 - co) + a.z * s; t.m[5] = a.y * a.y + (1 - a.y * a.y) * co; t.m[6] = a.y * a.z * (1 - co) - a.x * s;
+                t.m[8] = a.x * a.z * (1 - co) - a.y * s; t.m[9] = a.y * a.z * (1 - co) + a.x * s; t.m[10] = a.z * a.z + (1 - a.z * a.z) * co;
+            } else if (c.tag == "lookAt" || c.tag == "lookat") {  // Transform::lookAt, transform.cpp:191-214
+                auto o = parseFloats(sub(c.get("origin"))), tg = parseFloats(sub(c.get("target")));
+                std::vector<double> up = c.attr("up") ? parseFloats(sub(c.get("up"))) : std::vector<double>();
+                if (o.size() != 3 || tg.size() != 3) throw std::runtime_error("<lookAt> needs origin and target");
+                V3 p{(float)o[0], (float)o[1], (float)o[2]}, d = normalized(V3{(float)tg[0], (float)tg[1], (float)tg[2]} - p);
+                V3 u = up.size() == 3 ? V3{(float)up[0], (float)up[1], (float)up[2]} : cross(d, std::fabs(d.x) < std::fabs(d.y) ? V3{1, 0, 0} : V3{0, 1, 0});
+                V3 left = normalized(cross(u, d)), nu = cross(d, left);
+                t.m[0] = left.x; t.m[4] = left.y; t.m[8] = left.z; t.m[1] = nu.x; t.m[5] = nu.y; t.m[9] = nu.z;
+                t.m[2] = d.x; t.m[6] = d.y; t.m[10] = d.z; t.m[3] = p.x; t.m[7] = p.y; t.m[11] = p.z;
+            } else if (c.tag == "matrix") {
+                auto v = parseFloats(sub(c.get("value")));
+                if (v.size() != 16) throw std::runtime_error("<matrix> needs 16 values");
+                for (int i = 0; i < 16; ++i) t.m[i] = (float)v[i];
+            } else {
+                throw std::runtime_error("unsupported transform element <" + c.tag + ">");
+            }
+            m = t * m;  // later elements are applied after earlier ones
+        }
+        return m;
+    }
+    static Mesh rectangle(const Mat4 &toWorld, bool flip) {  // shapes/rectangle.cpp:170-203
+        Mat4 m = toWorld;
+        if (flip) { Mat4 s = Mat4::identity(); s.m[10] = -1; m = m * s; }
+        Mesh r;
+        const V3 c[4] = {{-1, -1, 0}, {1, -1, 0}, {1, 1, 0}, {-1, 1, 0}};
+        double nm[9];
+        normalMatrix(m, nm);
+        V3 n = normalized(xfNormal(nm, V3{0, 0, 1}));
+        for (const V3 &p : c) { r.positions.push_back(xfPoint(m, p)); r.normals.push_back(n); }
+        r.indices = {0, 1, 2, 2, 3, 0};
+        return r;
+    }
+    static void makeCamera(ppg_camera &cam, const Mat4 &c2w, double fov, const std::string &axisIn, double nearC, double farC, int W, int H) {
+        // sensor.cpp:239-264, 301-305; perspective.cpp:150-164 (m_sampleToCamera), inverted in closed form
+        const double aspect = (double)W / H, PI = 3.14159265358979323846;
+        std::string axis = axisIn;
+        if (axis == "smaller") axis = aspect > 1 ? "y" : "x";
+        else if (axis == "larger") axis = aspect > 1 ? "x" : "y";
+        double xfov;
+        if (axis == "x") xfov = fov;
+        else if (axis == "y") xfov = 2 * std::atan(std::tan(0.5 * fov * PI / 180) * aspect) * 180 / PI;
+        else if (axis == "diagonal") { double diag = 2 * std::tan(0.5 * fov * PI / 180), w = diag / std::sqrt(1 + 1 / (aspect * aspect)); xfov = 2 * std::atan(w * 0.5) * 180 / PI; }
+        else throw std::runtime_error("fovAxis '" + axisIn + "' not supported");
+        const double cot = 1 / std::tan(xfov / 2 * PI / 180);
+        double inv[16] = {0};
+        inv[0] = -2 / cot; inv[3] = 1 / cot;
+        inv[5] = -2 / (aspect * cot); inv[7] = 1 / (aspect * cot);
+        inv[11] = 1;
+        inv[14] = -(farC - nearC) / (nearC * farC); inv[15] = 1 / nearC;
+        for (int i = 0; i < 16; ++i) { cam.sample_to_camera[i] = (float)inv[i]; cam.camera_to_world[i] = c2w.m[i]; }
+        cam.near_clip = (float)nearC; cam.far_clip = (float)farC; cam.width = W; cam.height = H;
+    }
+    static void defaults(ppg_material &m) {  // what ppg_host.bindings.Material.from_dict fills in
+        for (int k = 0; k < 3; ++k) { m.specular[k] = 1.0f; m.k[k] = 1.0f; }
+        m.alpha = 0.1f;
+        const bool cond = m.type == PPG_BSDF_MIRROR || m.type == PPG_BSDF_CONDUCTOR || m.type == PPG_BSDF_ROUGHCONDUCTOR;
+        for (int k = 0; k < 3; ++k) m.eta[k] = cond ? 0.0f : 1.5046f;
+    }
+    double lookupIOR(const std::map<std::string, std::string> &p, const std::string &name, const std::string &dflt) const {  // ior.h:95-111
+        static const std::map<std::string, double> ior = {{"vacuum", 1.0}, {"air", 1.000277}, {"water", 1.3330}, {"polypropylene", 1.49}, {"bk7", 1.5046}, {"diamond", 2.419}};
+        std::string v = p.count(name) ? p.at(name) : dflt;
+        char *end = nullptr;
+        double d = std::strtod(v.c_str(), &end);
+        if (end && *end == '\0' && end != v.c_str()) return d;
+        std::transform(v.begin(), v.end(), v.begin(), ::tolower);
+        auto it = ior.find(v);
+        if (it == ior.end()) throw std::runtime_error("IOR name '" + v + "' is not in the built-in list; give a number");
+        return it->second;
+    }
+    void conductorIOR(const XmlNode &e, const std::map<std::string, std::string> &p, const std::string &what, ppg_material &m) const {
+        const float ext = (float)lookupIOR(p, "extEta", "air");
+        std::string mat = p.count("material") ? p.at("material") : "Cu";
+        std::transform(mat.begin(), mat.end(), mat.begin(), ::tolower);
+        float eta[3] = {0, 0, 0}, k[3] = {1, 1, 1};
+        if (mat != "none") {
+            if (!hasChildNamed(e, "eta") || !hasChildNamed(e, "k"))
+                throw std::runtime_error(what + "(material=" + (p.count("material") ? p.at("material") : "Cu") + "): measured IOR spectra (data/ior/*.spd) are not bundled; give eta and k");
+            colour(e, "eta", 0.0f, eta); colour(e, "k", 1.0f, k);
+        }
+        for (int c = 0; c < 3; ++c) { m.eta[c] = eta[c] / ext; m.k[c] = k[c] / ext; }
+    }
+    ppg_material makeBsdf(const XmlNode &e, bool allowWrap, LoadedScene &out) const {
+        std::string t = e.get("type");
+        auto p = props(e);
+        ppg_material m{};
+        auto inner = [&]() { std::vector<const XmlNode *> v; for (auto &c : e.children) if (c.tag == "bsdf") v.push_back(&c); return v; };
+        if (t == "diffuse") { m.type = PPG_BSDF_DIFFUSE; defaults(m); colour(e, "reflectance", 0.5f, m.reflectance); return m; }
+        if (t == "twosided" && allowWrap) {
+            auto in = inner();
+            if (in.size() == 1) {
+                m = makeBsdf(*in[0], false, out);
+                if (m.type == PPG_BSDF_DIELECTRIC || m.type == PPG_BSDF_THINDIELECTRIC) throw std::runtime_error("twosided(dielectric): only BRDFs can be two-sided (twosided.cpp:84-88)");
+                if (m.type == PPG_BSDF_DIFFUSE && !(m.flags & PPG_MAT_MASK)) { m.type = PPG_BSDF_TWOSIDED_DIFFUSE; return m; }
+                m.flags |= PPG_MAT_TWOSIDED;
+                return m;
+            }
+            t = "twosided(...)";
+        } else if (t == "mask" && allowWrap) {
+            auto in = inner();
+            if (in.size() == 1) {
+                m = makeBsdf(*in[0], true, out);
+                if (m.flags & PPG_MAT_MASK) throw std::runtime_error("mask(mask(...)) is not supported");
+                if (m.type == PPG_BSDF_TWOSIDED_DIFFUSE) { m.type = PPG_BSDF_DIFFUSE; m.flags |= PPG_MAT_TWOSIDED; }
+                m.flags |= PPG_MAT_MASK;
+                colour(e, "opacity", 0.5f, m.opacity);
+                return m;
+            }
+            t = "mask(...)";
+        } else if (t == "conductor") {
+            std::string mat = p.count("material") ? p["material"] : "Cu";
+            std::transform(mat.begin(), mat.end(), mat.begin(), ::tolower);
+            m.type = mat == "none" ? PPG_BSDF_MIRROR : PPG_BSDF_CONDUCTOR;
+            defaults(m);
+            colour(e, "specularReflectance", 1.0f, m.reflectance);
+            if (mat != "none") conductorIOR(e, p, t, m);
+            return m;
+        } else if (t == "roughconductor") {
+            m.type = PPG_BSDF_ROUGHCONDUCTOR; defaults(m);
+            colour(e, "specularReflectance", 1.0f, m.reflectance);
+            conductorIOR(e, p, t, m);
+            std::string distr = p.count("distribution") ? p["distribution"] : "beckmann";
+            std::transform(distr.begin(), distr.end(), distr.begin(), ::tolower);
+            if (distr != "ggx") throw std::runtime_error(t + ": distribution '" + distr + "' is not supported (ggx only)");
+            if (p.count("alphaU") || p.count("alphaV")) {
+                if (!p.count("alphaU") || !p.count("alphaV") || std::stof(p["alphaU"]) != std::stof(p["alphaV"])) throw std::runtime_error(t + ": anisotropic roughness is not supported");
+                m.alpha = std::stof(p["alphaU"]);
+            } else m.alpha = p.count("alpha") ? std::stof(p["alpha"]) : 0.1f;
+            if (p.count("sampleVisible") && !flag(p, "sampleVisible", true)) throw std::runtime_error(t + ": sampleVisible=false is not supported");
+            return m;
+        } else if (t == "plastic" || t == "dielectric" || t == "thindielectric") {
+            m.type = t == "plastic" ? PPG_BSDF_PLASTIC : (t == "dielectric" ? PPG_BSDF_DIELECTRIC : PPG_BSDF_THINDIELECTRIC);
+            defaults(m);
+            const float eta = (float)(lookupIOR(p, "intIOR", t == "plastic" ? "polypropylene" : "bk7") / lookupIOR(p, "extIOR", "air"));
+            m.eta[0] = m.eta[1] = m.eta[2] = eta;
+            if (t == "plastic") {
+                colour(e, "diffuseReflectance", 0.5f, m.reflectance); colour(e, "specularReflectance", 1.0f, m.specular);
+                if (flag(p, "nonlinear", false)) m.flags |= PPG_MAT_NONLINEAR;
+            } else {
+                colour(e, "specularReflectance", 1.0f, m.reflectance); colour(e, "specularTransmittance", 1.0f, m.specular);
+            }
+            return m;
+        }
+        if (m_strict) throw std::runtime_error("bsdf type '" + t + "' is not supported yet (diffuse, conductor, roughconductor(ggx), plastic, dielectric, thindielectric, mask, twosided; SURVEY.md §8 f1)");
+        out.warnings.push_back("bsdf '" + t + "' replaced by diffuse(0.5)");
+        m = ppg_material{}; m.type = PPG_BSDF_DIFFUSE; defaults(m);
+        m.reflectance[0] = m.reflectance[1] = m.reflectance[2] = 0.5f;
+        return m;
+    }
+    uint32_t intern(const ppg_material &m, LoadedScene &out) {
+        std::string key((const char *)&m, sizeof m);
+        for (size_t i = 0; i < m_matKeys.size(); ++i) if (m_matKeys[i] == key) return (uint32_t)i;
+        m_matKeys.push_back(key);
+        out.scene.materials.push_back(m);
+        return (uint32_t)m_matKeys.size() - 1;
+    }
+};
+
+}  // namespace ppg

@@ -24,4 +24,10 @@ if __name__ == "__main__":
     assert len(wl) == 471 and wl[0] == 360 and wl[-1] == 830 and np.all(np.diff(wl) == 1)
     xyz = np.stack([table(src, n) for n in ("CIE_X_entries", "CIE_Y_entries", "CIE_Z_entries")], 1)
     np.save(OUT, xyz.astype(np.float64))
+    inc = os.path.join(os.path.dirname(os.path.dirname(OUT)), "..", "host", "cie1931_xyz_1nm.inc")
+    with open(inc, "w") as f:  # the same numbers for the C++ scene loader (host/scene_xml.h)
+        f.write("// CIE 1931 2-degree standard observer, 360..830 nm in 1 nm steps: x-bar, y-bar, z-bar (data; written by tools/make_cie_table.py\n"
+                "// from the same table as ppg_host/data/cie1931_xyz_1nm.npy)\n")
+        for row in xyz:
+            f.write("{%r, %r, %r},\n" % tuple(float(v) for v in row))
     print(OUT, xyz.shape, xyz.sum(0))
