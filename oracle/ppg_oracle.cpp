@@ -25,7 +25,8 @@
  *     (2) the reference's own shipped render logs and pixels (tests/golden/ref_logs.json,
  *         ref_cbox_images.npz, mined by tools/make_ref_fixtures.py): iteration schedules exactly,
  *         iteration-0/1 SD-tree statistics, average path length, variance sequence and the CBOX
- *         image statistically                                   tests/test_oracle_reference_pins.py
+ *         image statistically, for the default and the "improved" configuration
+ *                                                               tests/test_oracle_reference_pins.py
  *     (3) next-event estimation (no reference log uses it): the analytic irradiance under a small lamp
  *         (within 1 %) and agreement of nee = never / kickstart / always on CBOX
  *                                                               tests/test_oracle_known_answers.py
