@@ -79,7 +79,7 @@ enum {
     PPG_BSDF_MIRROR = 2,           /* conductor.cpp:220-290 with material "none" (eta = 0, k = 1: Fresnel = 1): ideal specular
                                       reflection, reflectance = specularReflectance; a delta BSDF — never guided (GP:1942-1944, 1654) */
     PPG_BSDF_CONDUCTOR = 3,        /* conductor.cpp:220-290: smooth conductor, fresnelConductorExact(eta, k) (util.cpp:739-761) */
-    PPG_BSDF_ROUGHCONDUCTOR = 4,   /* roughconductor.cpp:247-415 with the isotropic GGX distribution and visible-normal
+    PPG_BSDF_ROUGHCONDUCTOR = 4,   /* roughconductor.cpp:247-415 with an isotropic GGX (or, PPG_MAT_BECKMANN, Beckmann) distribution and visible-normal
                                       sampling (microfacet.h:191-276, 425-540, 645-690): glossy ⇒ smooth ⇒ guided */
     PPG_BSDF_PLASTIC = 5,          /* plastic.cpp:247-455: delta specular coat over a diffuse base — the mixed delta/smooth
                                       case of sampleMat (GP:1672-1676) */
@@ -92,6 +92,8 @@ enum {
 enum {
     PPG_MAT_TWOSIDED = 1,          /* wrap the (one-sided) BRDF in twosided.cpp:100-180, same BRDF on both sides */
     PPG_MAT_NONLINEAR = 2,         /* plastic: nonlinear = true (plastic.cpp:164) */
+    PPG_MAT_BECKMANN = 8,          /* roughconductor: Beckmann distribution (Mitsuba's default) instead of GGX — microfacet.h:199-205,
+                                      487-498, 565-642 (visible-normal sampling by numerical inversion), math.cpp:25-72 (erf, erfinv) */
     PPG_MAT_MASK = 4               /* wrap the BSDF (outside a two-sided adapter, if any) in mask.cpp:108-214 with constant `opacity`: a
                                       smooth/null hybrid — its sampled pass-through is recorded for the sampling-fraction optimiser
                                       (GP:2047-2068) */

@@ -82,12 +82,12 @@ PPG_HD float ppg_atan2(float y, float x) {
     return a;
 }
 
-/* exp(x) for |x| <= 80, Cephes expf scheme. */
 /* acos / tan for the visible-normal sampling of microfacet.h:425-470, 645-690 — via the routines above so that CPU and
    GPU agree to the bit: acos(x) = atan2(sqrt((1 - x)(1 + x)), x), tan(x) = sin / cos */
 PPG_HD float ppg_acos(float x) { return ppg_atan2(__builtin_sqrtf(ppg_max(0.0f, (1.0f - x) * (1.0f + x))), x); }
 PPG_HD float ppg_tan(float x) { float s, c; ppg_sincos(x, &s, &c); return s / c; }
 
+/* exp(x) for |x| <= 80, Cephes expf scheme. */
 PPG_HD float ppg_exp(float x) {
     if (x > 80.0f) x = 80.0f;
     if (x < -80.0f) x = -80.0f;
@@ -104,6 +104,26 @@ PPG_HD float ppg_exp(float x) {
 }
 
 /* b^n for integer n >= 0 by binary exponentiation (stands in for std::pow(beta, iter), GP:100). */
+/* log(x) for normal x > 0 (log(0) = -inf, x < 0 → NaN), Cephes logf scheme; pow(x, y) = exp(y log x) for x > 0.
+   Used by the Beckmann microfacet code (microfacet.h: fastlog / fastexp / std::pow, math.cpp:25-72 erf / erfinv). */
+PPG_HD float ppg_log(float x) {
+    if (!(x > 0.0f)) return x == 0.0f ? -__builtin_inff() : __builtin_nanf("");
+    uint32_t u = ppg_f2u(x);
+    int e = (int)(u >> 23) - 126;                            /* frexp: x = m 2^e, m in [0.5, 1) */
+    float m = ppg_u2f((u & 0x007fffffu) | 0x3f000000u);
+    if (m < 0.707106781186547524f) { e -= 1; m = m + m - 1.0f; } else m = m - 1.0f;
+    float z = m * m;
+    float y = ((((((((7.0376836292e-2f * m - 1.1514610310e-1f) * m + 1.1676998740e-1f) * m - 1.2420140846e-1f) * m + 1.4249322787e-1f) * m
+                  - 1.6668057665e-1f) * m + 2.0000714765e-1f) * m - 2.4999993993e-1f) * m + 3.3333331174e-1f) * m * z;
+    const float fe = (float)e;
+    if (e) y += -2.12194440e-4f * fe;
+    y += -0.5f * z;
+    z = m + y;
+    if (e) z += 0.693359375f * fe;
+    return z;
+}
+PPG_HD float ppg_pow(float x, float y) { return ppg_exp(y * ppg_log(x)); }
+
 PPG_HD float ppg_powi(float b, int n) {
     float r = 1.0f;
     while (n > 0) {

@@ -1404,15 +1404,60 @@ struct Conductor {
     }
 };
 
-// MicrofacetDistribution, isotropic GGX with visible-normal sampling (microfacet.h)
+// math.cpp:25-72
+inline Float mtsErfinv(Float x) {
+    Float w = -ppg_log(((Float)1 - x) * ((Float)1 + x));
+    Float p;
+    if (w < (Float)5) {
+        w = w - (Float)2.5;
+        p = (Float)2.81022636e-08;
+        p = (Float)3.43273939e-07 + p * w;
+        p = (Float)-3.5233877e-06 + p * w;
+        p = (Float)-4.39150654e-06 + p * w;
+        p = (Float)0.00021858087 + p * w;
+        p = (Float)-0.00125372503 + p * w;
+        p = (Float)-0.00417768164 + p * w;
+        p = (Float)0.246640727 + p * w;
+        p = (Float)1.50140941 + p * w;
+    } else {
+        w = std::sqrt(w) - (Float)3;
+        p = (Float)-0.000200214257;
+        p = (Float)0.000100950558 + p * w;
+        p = (Float)0.00134934322 + p * w;
+        p = (Float)-0.00367342844 + p * w;
+        p = (Float)0.00573950773 + p * w;
+        p = (Float)-0.0076224613 + p * w;
+        p = (Float)0.00943887047 + p * w;
+        p = (Float)1.00167406 + p * w;
+        p = (Float)2.83297682 + p * w;
+    }
+    return p * x;
+}
+inline Float mtsErf(Float x) {
+    Float a1 = (Float)0.254829592, a2 = (Float)-0.284496736, a3 = (Float)1.421413741, a4 = (Float)-1.453152027, a5 = (Float)1.061405429;
+    Float p = (Float)0.3275911;
+    Float sign = (ppg_f2u(x) >> 31) ? -1.0f : 1.0f;  // math::signum: the FP sign, never zero
+    x = ppg_abs(x);
+    Float t = (Float)1.0 / ((Float)1.0 + p * x);
+    Float y = (Float)1.0 - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * ppg_exp(-x * x);
+    return sign * y;
+}
+
+// MicrofacetDistribution, isotropic GGX or Beckmann with visible-normal sampling (microfacet.h)
 struct GGX {
     Float alpha;
+    bool beckmann = false;
     Float eval(const Vec &m) const {  // microfacet.h:191-237
         if (m.z <= 0) return 0.0f;
         Float cosTheta2 = m.z * m.z;
         Float beckmannExponent = ((m.x * m.x) / (alpha * alpha) + (m.y * m.y) / (alpha * alpha)) / cosTheta2;
-        Float root = ((Float)1 + beckmannExponent) * cosTheta2;
-        Float result = (Float)1 / (PPG_PI_F * alpha * alpha * root * root);
+        Float result;
+        if (beckmann) {
+            result = ppg_exp(-beckmannExponent) / (PPG_PI_F * alpha * alpha * cosTheta2 * cosTheta2);
+        } else {
+            Float root = ((Float)1 + beckmannExponent) * cosTheta2;
+            result = (Float)1 / (PPG_PI_F * alpha * alpha * root * root);
+        }
         if (result * m.z < 1e-20f) result = 0;
         return result;
     }
@@ -1428,6 +1473,12 @@ struct GGX {
         Float temp = 1 - v.z * v.z;
         Float tanTheta = temp <= 0.0f ? 0.0f : ppg_abs(std::sqrt(temp) / v.z);  // |Frame::tanTheta(v)|, frame.h:122-127
         if (tanTheta == 0.0f) return 1.0f;
+        if (beckmann) {
+            Float a = 1.0f / (alpha * tanTheta);
+            if (a >= 1.6f) return 1.0f;
+            Float aSqr = a * a;
+            return (3.535f * a + 2.181f * aSqr) / (1.0f + 2.276f * a + 2.577f * aSqr);
+        }
         Float root = alpha * tanTheta;  // projectRoughness: isotropic ⇒ alpha
         return 2.0f / (1.0f + hypot2(1.0f, root));
     }
@@ -1435,6 +1486,36 @@ struct GGX {
     Float pdfVisible(const Vec &wi, const Vec &m) const {  // microfacet.h:462-466
         if (wi.z == 0) return 0.0f;
         return smithG1(wi, m) * ppg_abs(dot(wi, m)) * eval(m) / ppg_abs(wi.z);
+    }
+    static void sampleVisible11Beckmann(Float thetaI, Point2 sample, Float &sx, Float &sy) {  // microfacet.h:565-642
+        const Float SQRT_PI_INV = 1 / std::sqrt(PPG_PI_F);
+        if (thetaI < 1e-4f) {
+            Float sinPhi, cosPhi;
+            Float r = std::sqrt(-ppg_log(1.0f - sample.x));
+            ppg_sincos(2 * PPG_PI_F * sample.y, &sinPhi, &cosPhi);
+            sx = r * cosPhi; sy = r * sinPhi;
+            return;
+        }
+        Float tanThetaI = ppg_tan(thetaI);
+        Float cotThetaI = 1 / tanThetaI;
+        Float a = -1, c = mtsErf(cotThetaI);
+        Float sample_x = ppg_max(sample.x, (Float)1e-6f);
+        Float fit = 1 + thetaI * (-0.876f + thetaI * (0.4265f - 0.0594f * thetaI));
+        Float b = c - (1 + c) * ppg_pow(1 - sample_x, fit);
+        Float normalization = 1 / (1 + c + SQRT_PI_INV * tanThetaI * ppg_exp(-cotThetaI * cotThetaI));
+        int it = 0;
+        while (++it < 10) {
+            if (!(b >= a && b <= c)) b = 0.5f * (a + c);
+            Float invErf = mtsErfinv(b);
+            Float value = normalization * (1 + b + SQRT_PI_INV * tanThetaI * ppg_exp(-invErf * invErf)) - sample_x;
+            Float derivative = normalization * (1 - invErf * tanThetaI);
+            if (ppg_abs(value) < 1e-5f) break;
+            if (value > 0) c = b;
+            else a = b;
+            b -= value / derivative;
+        }
+        sx = mtsErfinv(b);
+        sy = mtsErfinv(2.0f * ppg_max(sample.y, (Float)1e-6f) - 1.0f);
     }
     static void sampleVisible11(Float thetaI, Point2 sample, Float &sx, Float &sy) {  // microfacet.h:645-690
         if (thetaI < 1e-4f) {
@@ -1474,7 +1555,8 @@ struct GGX {
         Float sinPhi, cosPhi;
         ppg_sincos(phi, &sinPhi, &cosPhi);
         Float sx, sy;
-        sampleVisible11(theta, sample, sx, sy);
+        if (beckmann) sampleVisible11Beckmann(theta, sample, sx, sy);
+        else sampleVisible11(theta, sample, sx, sy);
         Float rx = cosPhi * sx - sinPhi * sy, ry = sinPhi * sx + cosPhi * sy;
         rx *= alpha; ry *= alpha;
         Float normalization = (Float)1 / std::sqrt(rx * rx + ry * ry + (Float)1.0);
@@ -1488,7 +1570,7 @@ struct RoughConductor {
     static Spectrum eval(const Material &mt, const BRec &b) {
         if (b.wi.z <= 0 || b.wo.z <= 0) return Spectrum(0.0f);
         Vec H = normalize(b.wo + b.wi);
-        GGX distr{mt.alpha};
+        GGX distr{mt.alpha, (mt.flags & PPG_MAT_BECKMANN) != 0};
         const Float D = distr.eval(H);
         if (D == 0) return Spectrum(0.0f);
         const Spectrum F = mul(fresnelConductorExact(dot(b.wi, H), mt.Eta(), mt.K()), mt.R());
@@ -1499,13 +1581,13 @@ struct RoughConductor {
     static Float pdf(const Material &mt, const BRec &b) {
         if (b.wi.z <= 0 || b.wo.z <= 0) return 0.0f;
         Vec H = normalize(b.wo + b.wi);
-        GGX distr{mt.alpha};
+        GGX distr{mt.alpha, (mt.flags & PPG_MAT_BECKMANN) != 0};
         return distr.eval(H) * distr.smithG1(b.wi, H) / (4.0f * b.wi.z);
     }
     static Spectrum sample(const Material &mt, BRec &b, Float &pdf, const Point2 &sample) {
         pdf = 0;
         if (b.wi.z < 0) return Spectrum(0.0f);
-        GGX distr{mt.alpha};
+        GGX distr{mt.alpha, (mt.flags & PPG_MAT_BECKMANN) != 0};
         Vec m = distr.sampleVisible(b.wi, sample);
         pdf = distr.pdfVisible(b.wi, m);
         if (pdf == 0) return Spectrum(0.0f);
@@ -2711,6 +2793,8 @@ int ppgo_math_eval(int32_t op, uint32_t n, const float *a, const float *b, float
             case 3: out0[i] = ppg_from_fixed(ppg_to_fixed(a[i])); break;
             case 4: out0[i] = ppg_rand((uint32_t)i * 2654435761u + 17u, (uint32_t)b[i]); break;
             case 5: out0[i] = ppg_powi(a[i], (int)b[i]); break;
+            case 6: out0[i] = ppg_log(a[i]); break;
+            case 7: out0[i] = ppg_pow(a[i], b[i]); break;
             default: return PPG_ERR_INVALID;
         }
     }

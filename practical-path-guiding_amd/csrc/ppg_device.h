@@ -639,13 +639,58 @@ D F3 fresnel_conductor_exact(float cosThetaI, F3 eta, F3 k) {
     return (Rp2 + Rs2) * 0.5f;
 }
 
-// MicrofacetDistribution, isotropic GGX, visible-normal sampling (microfacet.h:191-237, 425-540, 645-690)
-D float ggx_eval(float alpha, F3 m) {
+// math.cpp:25-72
+D float mts_erfinv(float x) {
+    float w = -ppg_log((1.0f - x) * (1.0f + x));
+    float p;
+    if (w < 5.0f) {
+        w = w - 2.5f;
+        p = 2.81022636e-08f;
+        p = 3.43273939e-07f + p * w;
+        p = -3.5233877e-06f + p * w;
+        p = -4.39150654e-06f + p * w;
+        p = 0.00021858087f + p * w;
+        p = -0.00125372503f + p * w;
+        p = -0.00417768164f + p * w;
+        p = 0.246640727f + p * w;
+        p = 1.50140941f + p * w;
+    } else {
+        w = __builtin_sqrtf(w) - 3.0f;
+        p = -0.000200214257f;
+        p = 0.000100950558f + p * w;
+        p = 0.00134934322f + p * w;
+        p = -0.00367342844f + p * w;
+        p = 0.00573950773f + p * w;
+        p = -0.0076224613f + p * w;
+        p = 0.00943887047f + p * w;
+        p = 1.00167406f + p * w;
+        p = 2.83297682f + p * w;
+    }
+    return p * x;
+}
+D float mts_erf(float x) {
+    const float a1 = 0.254829592f, a2 = -0.284496736f, a3 = 1.421413741f, a4 = -1.453152027f, a5 = 1.061405429f, p = 0.3275911f;
+    const float sign = (ppg_f2u(x) >> 31) ? -1.0f : 1.0f;
+    x = ppg_abs(x);
+    float t = 1.0f / (1.0f + p * x);
+    float y = 1.0f - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * ppg_exp(-x * x);
+    return sign * y;
+}
+
+// MicrofacetDistribution, isotropic GGX or Beckmann, visible-normal sampling (microfacet.h:191-237, 425-540, 565-690)
+struct Mfd { float alpha; bool beckmann; };
+D float ggx_eval(Mfd d, F3 m) {
+    const float alpha = d.alpha;
     if (m.z <= 0) return 0.0f;
     float cosTheta2 = m.z * m.z;
     float beckmannExponent = ((m.x * m.x) / (alpha * alpha) + (m.y * m.y) / (alpha * alpha)) / cosTheta2;
-    float root = (1.0f + beckmannExponent) * cosTheta2;
-    float result = 1.0f / (PPG_PI_F * alpha * alpha * root * root);
+    float result;
+    if (d.beckmann) {
+        result = ppg_exp(-beckmannExponent) / (PPG_PI_F * alpha * alpha * cosTheta2 * cosTheta2);
+    } else {
+        float root = (1.0f + beckmannExponent) * cosTheta2;
+        result = 1.0f / (PPG_PI_F * alpha * alpha * root * root);
+    }
     if (result * m.z < 1e-20f) result = 0;
     return result;
 }
@@ -656,17 +701,53 @@ D float hypot2f(float a, float b) {  // math.cpp:74-86
     else r = 0.0f;
     return r;
 }
-D float ggx_smith_g1(float alpha, F3 v, F3 m) {
+D float ggx_smith_g1(Mfd d, F3 v, F3 m) {
     if (dot3(v, m) * v.z <= 0) return 0.0f;
     float temp = 1 - v.z * v.z;
     float tanTheta = temp <= 0.0f ? 0.0f : ppg_abs(__builtin_sqrtf(temp) / v.z);
     if (tanTheta == 0.0f) return 1.0f;
-    float root = alpha * tanTheta;
+    if (d.beckmann) {
+        float a = 1.0f / (d.alpha * tanTheta);
+        if (a >= 1.6f) return 1.0f;
+        float aSqr = a * a;
+        return (3.535f * a + 2.181f * aSqr) / (1.0f + 2.276f * a + 2.577f * aSqr);
+    }
+    float root = d.alpha * tanTheta;
     return 2.0f / (1.0f + hypot2f(1.0f, root));
 }
-D float ggx_pdf_visible(float alpha, F3 wi, F3 m) {
+D float ggx_pdf_visible(Mfd d, F3 wi, F3 m) {
     if (wi.z == 0) return 0.0f;
-    return ggx_smith_g1(alpha, wi, m) * ppg_abs(dot3(wi, m)) * ggx_eval(alpha, m) / ppg_abs(wi.z);
+    return ggx_smith_g1(d, wi, m) * ppg_abs(dot3(wi, m)) * ggx_eval(d, m) / ppg_abs(wi.z);
+}
+D void beckmann_sample_visible11(float thetaI, float u, float v, float &sx, float &sy) {  // microfacet.h:565-642
+    const float SQRT_PI_INV = 1 / __builtin_sqrtf(PPG_PI_F);
+    if (thetaI < 1e-4f) {
+        float sinPhi, cosPhi;
+        float r = __builtin_sqrtf(-ppg_log(1.0f - u));
+        ppg_sincos(2 * PPG_PI_F * v, &sinPhi, &cosPhi);
+        sx = r * cosPhi; sy = r * sinPhi;
+        return;
+    }
+    float tanThetaI = ppg_tan(thetaI);
+    float cotThetaI = 1 / tanThetaI;
+    float a = -1, c = mts_erf(cotThetaI);
+    float sample_x = ppg_max(u, 1e-6f);
+    float fit = 1 + thetaI * (-0.876f + thetaI * (0.4265f - 0.0594f * thetaI));
+    float b = c - (1 + c) * ppg_pow(1 - sample_x, fit);
+    float normalization = 1 / (1 + c + SQRT_PI_INV * tanThetaI * ppg_exp(-cotThetaI * cotThetaI));
+    int it = 0;
+    while (++it < 10) {
+        if (!(b >= a && b <= c)) b = 0.5f * (a + c);
+        float invErf = mts_erfinv(b);
+        float value = normalization * (1 + b + SQRT_PI_INV * tanThetaI * ppg_exp(-invErf * invErf)) - sample_x;
+        float derivative = normalization * (1 - invErf * tanThetaI);
+        if (ppg_abs(value) < 1e-5f) break;
+        if (value > 0) c = b;
+        else a = b;
+        b -= value / derivative;
+    }
+    sx = mts_erfinv(b);
+    sy = mts_erfinv(2.0f * ppg_max(v, 1e-6f) - 1.0f);
 }
 D void ggx_sample_visible11(float thetaI, float u, float v, float &sx, float &sy) {
     if (thetaI < 1e-4f) {
@@ -694,7 +775,8 @@ D void ggx_sample_visible11(float thetaI, float u, float v, float &sx, float &sy
               (v * (v * (v * (v * 0.169507819808272f - 0.397203533833404f) - 0.232500544458471f) + 1.0f) - 0.539825872510702f);
     sy = S * z * __builtin_sqrtf(1.0f + sx * sx);
 }
-D F3 ggx_sample_visible(float alpha, F3 _wi, float u, float v) {
+D F3 ggx_sample_visible(Mfd d, F3 _wi, float u, float v) {
+    const float alpha = d.alpha;
     F3 wi = norm3(f3(alpha * _wi.x, alpha * _wi.y, _wi.z));
     float theta = 0, phi = 0;
     if (wi.z < 0.99999f) {
@@ -704,7 +786,8 @@ D F3 ggx_sample_visible(float alpha, F3 _wi, float u, float v) {
     float sinPhi, cosPhi;
     ppg_sincos(phi, &sinPhi, &cosPhi);
     float sx, sy;
-    ggx_sample_visible11(theta, u, v, sx, sy);
+    if (d.beckmann) beckmann_sample_visible11(theta, u, v, sx, sy);
+    else ggx_sample_visible11(theta, u, v, sx, sy);
     float rx = cosPhi * sx - sinPhi * sy, ry = sinPhi * sx + cosPhi * sy;
     rx *= alpha; ry *= alpha;
     float normalization = 1.0f / __builtin_sqrtf(rx * rx + ry * ry + 1.0f);
@@ -740,10 +823,11 @@ D F3 mat_eval_one(const Mat &M, F3 wi, F3 wo) {
     if (M.type == PPG_BSDF_ROUGHCONDUCTOR) {  // roughconductor.cpp:247-282
         if (wi.z <= 0 || wo.z <= 0) return f3s(0.0f);
         F3 H = norm3(wo + wi);
-        const float Dm = ggx_eval(M.alpha, H);
+        const Mfd distr{M.alpha, (M.flags & PPG_MAT_BECKMANN) != 0};
+        const float Dm = ggx_eval(distr, H);
         if (Dm == 0) return f3s(0.0f);
         const F3 F = mul3(fresnel_conductor_exact(dot3(wi, H), M.eta, M.k), M.refl);
-        const float G = ggx_smith_g1(M.alpha, wi, H) * ggx_smith_g1(M.alpha, wo, H);
+        const float G = ggx_smith_g1(distr, wi, H) * ggx_smith_g1(distr, wo, H);
         float model = Dm * G / (4.0f * wi.z);
         return F * model;
     }
@@ -761,7 +845,8 @@ D float mat_pdf_one(const Mat &M, F3 wi, F3 wo) {
     if (M.type == PPG_BSDF_ROUGHCONDUCTOR) {  // roughconductor.cpp:284-307
         if (wi.z <= 0 || wo.z <= 0) return 0.0f;
         F3 H = norm3(wo + wi);
-        return ggx_eval(M.alpha, H) * ggx_smith_g1(M.alpha, wi, H) / (4.0f * wi.z);
+        const Mfd distr{M.alpha, (M.flags & PPG_MAT_BECKMANN) != 0};
+        return ggx_eval(distr, H) * ggx_smith_g1(distr, wi, H) / (4.0f * wi.z);
     }
     if (M.type == PPG_BSDF_PLASTIC) {  // plastic.cpp:283-311
         if (wo.z <= 0 || wi.z <= 0) return 0.0f;
@@ -787,13 +872,14 @@ D F3 mat_sample_one(const Mat &M, F3 wi, float sx, float sy, F3 &wo, float &pdf,
             return mul3(M.refl, fresnel_conductor_exact(wi.z, M.eta, M.k));
         case PPG_BSDF_ROUGHCONDUCTOR: {  // roughconductor.cpp:367-415
             if (wi.z < 0) return f3s(0.0f);
-            F3 m = ggx_sample_visible(M.alpha, wi, sx, sy);
-            pdf = ggx_pdf_visible(M.alpha, wi, m);
+            const Mfd distr{M.alpha, (M.flags & PPG_MAT_BECKMANN) != 0};
+            F3 m = ggx_sample_visible(distr, wi, sx, sy);
+            pdf = ggx_pdf_visible(distr, wi, m);
             if (pdf == 0) return f3s(0.0f);
             wo = m * (2 * dot3(wi, m)) - wi;
             if (wo.z <= 0) return f3s(0.0f);
             F3 F = mul3(fresnel_conductor_exact(dot3(wi, m), M.eta, M.k), M.refl);
-            float weight = ggx_smith_g1(M.alpha, wo, m);
+            float weight = ggx_smith_g1(distr, wo, m);
             pdf /= 4.0f * dot3(wo, m);
             return F * weight;
         }

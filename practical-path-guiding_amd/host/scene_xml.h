@@ -5,7 +5,7 @@
  *   integrator  guided_path (properties of guided_path.cpp:1014-1085 and integrator.cpp:192-218)
  *   sensor      perspective (fov, fovAxis, nearClip, farClip, toWorld), film hdrfilm (width, height; rfilter box)
  *   shapes      obj (filename, toWorld, faceNormals, flipNormals, flipTexCoords, collapse), rectangle (toWorld, flipNormals)
- *   bsdfs       diffuse, conductor, roughconductor (ggx, isotropic), plastic, dielectric, thindielectric, mask (constant opacity),
+ *   bsdfs       diffuse, conductor, roughconductor (ggx / beckmann, isotropic), plastic, dielectric, thindielectric, mask (constant opacity),
  *               twosided(BRDF) — top level with id, nested, or <ref id>
  *   emitters    area (nested in a shape), constant (environment)
  *   values      <spectrum>, <rgb>, <srgb>; <transform> of translate / rotate / scale / lookAt / matrix; <default> and $name
@@ -703,7 +703,8 @@ private:
             conductorIOR(e, p, t, m);
             std::string distr = p.count("distribution") ? p["distribution"] : "beckmann";
             std::transform(distr.begin(), distr.end(), distr.begin(), ::tolower);
-            if (distr != "ggx") throw std::runtime_error(t + ": distribution '" + distr + "' is not supported (ggx only)");
+            if (distr != "ggx" && distr != "beckmann") throw std::runtime_error(t + ": distribution '" + distr + "' is not supported (ggx, beckmann)");
+            if (distr == "beckmann") m.flags |= PPG_MAT_BECKMANN;  // Mitsuba's default (microfacet.h:99)
             if (p.count("alphaU") || p.count("alphaV")) {
                 if (!p.count("alphaU") || !p.count("alphaV") || std::stof(p["alphaU"]) != std::stof(p["alphaV"])) throw std::runtime_error(t + ": anisotropic roughness is not supported");
                 m.alpha = std::stof(p["alphaU"]);
@@ -723,7 +724,7 @@ private:
             }
             return m;
         }
-        if (m_strict) throw std::runtime_error("bsdf type '" + t + "' is not supported yet (diffuse, conductor, roughconductor(ggx), plastic, dielectric, thindielectric, mask, twosided; SURVEY.md §8 f1)");
+        if (m_strict) throw std::runtime_error("bsdf type '" + t + "' is not supported yet (diffuse, conductor, roughconductor, plastic, dielectric, thindielectric, mask, twosided; SURVEY.md §8 f1)");
         out.warnings.push_back("bsdf '" + t + "' replaced by diffuse(0.5)");
         m = ppg_material{}; m.type = PPG_BSDF_DIFFUSE; defaults(m);
         m.reflectance[0] = m.reflectance[1] = m.reflectance[2] = 0.5f;

@@ -62,7 +62,7 @@ class Config(C.Structure):
 
 class Material(C.Structure):
     """ppg_material (include/ppg.h).  Scene descriptions carry materials as dicts: type, reflectance and — by type —
-    specular, alpha, eta (3 values, or one number for plastic / dielectric), k, twosided, nonlinear, opacity (a mask adapter)."""
+    specular, alpha, eta (3 values, or one number for plastic / dielectric), k, twosided, nonlinear, opacity (a mask adapter), distribution ("ggx" | "beckmann")."""
     _fields_ = [("type", C.c_int32), ("reflectance", C.c_float * 3), ("specular", C.c_float * 3), ("alpha", C.c_float),
                 ("eta", C.c_float * 3), ("k", C.c_float * 3), ("flags", C.c_int32), ("_reserved", C.c_int32),
                 ("opacity", C.c_float * 3), ("_pad", C.c_float)]
@@ -83,7 +83,8 @@ class Material(C.Structure):
         o.alpha = float(m.get("alpha", 0.1))
         o.eta[:] = three(m.get("eta"), 0.0 if o.type in (2, 3, 4) else 1.5046)  # dielectric / plastic default: bk7 / polypropylene-ish
         o.k[:] = three(m.get("k"), 1.0)
-        o.flags = (1 if m.get("twosided") else 0) | (2 if m.get("nonlinear") else 0) | (4 if m.get("opacity") is not None else 0)
+        o.flags = ((1 if m.get("twosided") else 0) | (2 if m.get("nonlinear") else 0) | (4 if m.get("opacity") is not None else 0)
+                   | (8 if m.get("distribution", "ggx") == "beckmann" else 0))
         o.opacity[:] = three(m.get("opacity"), 0.0)
         return o
 

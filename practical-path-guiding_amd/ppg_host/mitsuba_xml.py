@@ -5,7 +5,7 @@
               nested sampler (independent; sampleCount / seed do not steer guided_path, GP:1342-1374) and
               film hdrfilm (width, height; rfilter box)
   shapes      obj (filename, toWorld, faceNormals, flipNormals, flipTexCoords, collapse), rectangle (toWorld, flipNormals)
-  bsdfs       diffuse, conductor (material none, or explicit eta / k), roughconductor (ggx, isotropic), plastic, dielectric, thindielectric,
+  bsdfs       diffuse, conductor (material none, or explicit eta / k), roughconductor (ggx / beckmann, isotropic), plastic, dielectric, thindielectric,
               mask (constant opacity), twosided(any of the BRDFs) — top level with id, nested, or <ref id>
   emitters    area (nested in a shape), constant (environment)
   values      <spectrum>, <rgb>, <srgb> (spectrum.py), <transform> of translate / rotate / scale / lookAt / matrix,
@@ -381,8 +381,8 @@ def load_scene(path, defines=None, strict=True, width=None, height=None):
         return IOR[str(v).lower()]
 
     def microfacet_alpha(p, what):  # MicrofacetDistribution(props), microfacet.h:99-145
-        if str(p.get("distribution", "beckmann")).lower() != "ggx":
-            raise SceneError("%s: distribution %r is not supported (ggx only)" % (what, p.get("distribution", "beckmann")))
+        if str(p.get("distribution", "beckmann")).lower() not in ("ggx", "beckmann"):
+            raise SceneError("%s: distribution %r is not supported (ggx, beckmann)" % (what, p.get("distribution", "beckmann")))
         if "alphaU" in p or "alphaV" in p:
             if p.get("alphaU") != p.get("alphaV"):
                 raise SceneError("%s: anisotropic roughness is not supported" % what)
@@ -436,7 +436,10 @@ def load_scene(path, defines=None, strict=True, width=None, height=None):
             return dict(type=3, reflectance=rgb("specularReflectance", 1.0), eta=eta, k=k)
         elif t == "roughconductor":
             eta, k = conductor_ior(elem, p, t)
-            return dict(type=4, reflectance=rgb("specularReflectance", 1.0), eta=eta, k=k, alpha=microfacet_alpha(p, t))
+            m = dict(type=4, reflectance=rgb("specularReflectance", 1.0), eta=eta, k=k, alpha=microfacet_alpha(p, t))
+            if str(p.get("distribution", "beckmann")).lower() == "beckmann":  # Mitsuba's default (microfacet.h:99)
+                m["distribution"] = "beckmann"
+            return m
         elif t == "plastic":
             eta = lookup_ior(p, "intIOR", "polypropylene") / lookup_ior(p, "extIOR", "air")
             return dict(type=5, reflectance=rgb("diffuseReflectance", 0.5), specular=rgb("specularReflectance", 1.0), eta=float(f32(eta)),
@@ -448,7 +451,7 @@ def load_scene(path, defines=None, strict=True, width=None, height=None):
             eta = lookup_ior(p, "intIOR", "bk7") / lookup_ior(p, "extIOR", "air")
             return dict(type=7, reflectance=rgb("specularReflectance", 1.0), specular=rgb("specularTransmittance", 1.0), eta=float(f32(eta)))
         if strict:
-            raise SceneError("bsdf type %r is not supported yet (diffuse, conductor, roughconductor(ggx), plastic, dielectric, thindielectric, twosided(...); "
+            raise SceneError("bsdf type %r is not supported yet (diffuse, conductor, roughconductor, plastic, dielectric, thindielectric, twosided(...); "
                              "SURVEY.md §8 f1)" % t)
         warnings.append("bsdf %r replaced by diffuse(0.5)" % t)
         return dict(type=0, reflectance=(0.5, 0.5, 0.5), _substituted=True)
@@ -589,8 +592,9 @@ def save_scene_xml(desc, props, directory, name="scene"):
             2: '<bsdf type="conductor"%%s><string name="material" value="none"/><rgb name="specularReflectance" value="%s"/></bsdf>' % R,
             3: '<bsdf type="conductor"%%s><float name="extEta" value="1.0"/><rgb name="eta" value="%s"/><rgb name="k" value="%s"/>'
                '<rgb name="specularReflectance" value="%s"/></bsdf>' % (E, K, R),
-            4: '<bsdf type="roughconductor"%%s><string name="distribution" value="ggx"/><float name="alpha" value="%r"/><float name="extEta" value="1.0"/>'
-               '<rgb name="eta" value="%s"/><rgb name="k" value="%s"/><rgb name="specularReflectance" value="%s"/></bsdf>' % (float(M.alpha), E, K, R),
+            4: '<bsdf type="roughconductor"%%s><string name="distribution" value="%s"/><float name="alpha" value="%r"/><float name="extEta" value="1.0"/>'
+               '<rgb name="eta" value="%s"/><rgb name="k" value="%s"/><rgb name="specularReflectance" value="%s"/></bsdf>'
+               % ("beckmann" if M.flags & 8 else "ggx", float(M.alpha), E, K, R),
             5: '<bsdf type="plastic"%%s>%s<rgb name="diffuseReflectance" value="%s"/><rgb name="specularReflectance" value="%s"/>'
                '<boolean name="nonlinear" value="%s"/></bsdf>' % (one, R, S, "true" if M.flags & 2 else "false"),
             6: '<bsdf type="dielectric"%%s>%s<rgb name="specularReflectance" value="%s"/><rgb name="specularTransmittance" value="%s"/></bsdf>' % (one, R, S),

@@ -59,6 +59,9 @@ SMOOTH = [
     ("ggx-0.25", GOLD),
     ("ggx-0.05", dict(GOLD, alpha=0.05)),
     ("ggx-0.6-twosided", dict(GOLD, alpha=0.6, twosided=True)),
+    ("ggx-beckmann-0.25", dict(GOLD, distribution="beckmann")),
+    ("ggx-beckmann-0.08", dict(GOLD, alpha=0.08, distribution="beckmann")),
+    ("ggx-beckmann-0.5", dict(GOLD, alpha=0.5, distribution="beckmann")),
     ("plastic", dict(type="plastic", reflectance=(0.6, 0.3, 0.1), specular=(1, 1, 1), eta=1.49)),
     ("plastic-nonlinear", dict(type="plastic", reflectance=(0.6, 0.3, 0.1), specular=(0.8, 0.8, 0.8), eta=1.9, nonlinear=True)),
 ]

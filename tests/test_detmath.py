@@ -60,3 +60,17 @@ def test_rng_uniform(oracle_lib):
     assert abs(u.mean() - 0.5) < 2e-3 and abs(u.var() - 1 / 12) < 1e-3
     per_dim = u.reshape(-1, 8)
     assert np.abs(np.corrcoef(per_dim.T) - np.eye(8)).max() < 0.02  # dimensions are decorrelated
+
+
+def test_log_and_pow(oracle_lib):
+    x = np.exp(np.linspace(-30, 30, 200001)).astype(np.float32)
+    l, _ = _eval(oracle_lib, 6, x)
+    ref = np.log(x.astype(np.float64))
+    assert np.abs(l - ref).max() < 2.5e-6 and (np.abs(l - ref) / np.maximum(np.abs(ref), 1e-3)).max() < 3e-7 * 40  # <= 2 ulp of the result
+    l, _ = _eval(oracle_lib, 6, np.array([1.0, 0.0, -1.0], np.float32))
+    assert l[0] == 0.0 and l[1] == -np.inf and np.isnan(l[2])
+    rng = np.random.RandomState(2)
+    a = rng.uniform(1e-6, 1.0, 100000).astype(np.float32); b = rng.uniform(0.3, 1.1, 100000).astype(np.float32)  # pow(1 - u, fit), microfacet.h:596
+    p, _ = _eval(oracle_lib, 7, a, b)
+    ref = a.astype(np.float64) ** b.astype(np.float64)
+    assert (np.abs(p - ref) / ref).max() < 2e-6

@@ -441,7 +441,8 @@ def _full_materials_scene(res):
         dict(type="conductor", eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14), reflectance=(0.95, 0.95, 0.95)),                         # +1 back wall
         dict(type="plastic", reflectance=(0.2, 0.35, 0.7), specular=(1, 1, 1), eta=1.49),                                           # +2 short box
         dict(type="dielectric", eta=1.5, reflectance=(1, 1, 1), specular=(0.98, 0.99, 0.98)),                                       # +3 tall box
-        dict(type="roughconductor", alpha=0.45, eta=(1.66, 0.88, 0.52), k=(9.2, 6.3, 4.8), reflectance=(0.9, 0.9, 0.9), twosided=True),  # +4 ceiling
+        dict(type="roughconductor", alpha=0.45, eta=(1.66, 0.88, 0.52), k=(9.2, 6.3, 4.8), reflectance=(0.9, 0.9, 0.9), twosided=True,
+             distribution="beckmann"),                                                                                              # +4 ceiling
     ]
     tm = scene.tri_material.copy()
     tm[2:4] = base + 0      # floor

@@ -247,12 +247,13 @@ def test_glossy_plugins_parse_like_their_constructors(tmp_path):
     air = np.float32(1.000277)
     assert m[0] == dict(type=4, reflectance=f(1, 1, 1), eta=f(0, 0, 0), k=tuple(float(np.float32(1) / air) for _ in range(3)), alpha=0.15)
     assert m[1]["twosided"] and m[1]["type"] == 4 and m[1]["alpha"] == 0.1 and m[1]["reflectance"] == f(0.5, 0.6, 0.7)  # alpha default, microfacet.h:99-100
+    assert "distribution" not in m[1] and "distribution" not in m[0]                                                     # both ask for ggx
     assert np.allclose(m[1]["eta"], np.float32([0.2, 0.9, 1.1]) / air, rtol=1e-7)  # divided by extEta = air (roughconductor.cpp:183-186)
     assert m[2] == dict(type=5, reflectance=f(0.1, 0.2, 0.3), specular=f(1, 1, 1), eta=float(np.float32(1.49 / 1.000277)), nonlinear=True)  # polypropylene / air
     assert m[3] == dict(type=6, reflectance=f(1, 1, 1), specular=f(1, 1, 1), eta=float(np.float32(1.333)))
     assert m[4] == dict(type=3, reflectance=f(1, 1, 1), eta=f(0.5, 0.5, 0.5), k=f(1.5, 1.5, 1.5))
     for bad, needle in (('<bsdf type="roughconductor"><string name="distribution" value="ggx"/></bsdf>', "data/ior"),
-                        ('<bsdf type="roughconductor"><string name="material" value="none"/></bsdf>', "beckmann"),
+                        ('<bsdf type="roughconductor"><string name="material" value="none"/><string name="distribution" value="phong"/></bsdf>', "phong"),
                         ('<bsdf type="roughconductor"><string name="material" value="none"/><string name="distribution" value="ggx"/>'
                          '<float name="alphaU" value="0.1"/><float name="alphaV" value="0.3"/></bsdf>', "anisotropic"),
                         ('<bsdf type="dielectric"><string name="intIOR" value="unobtainium"/></bsdf>', "unobtainium"),
@@ -272,8 +273,9 @@ def test_full_material_set_survives_the_xml_round_trip(tmp_path):
         dict(type="mirror", reflectance=(0.7, 0.8, 0.9)), dict(type=1, reflectance=(0.3, 0.3, 0.3)),
         dict(type="thindielectric", eta=1.33, reflectance=(1, 1, 1), specular=(0.9, 0.9, 1.0)),
         dict(type="diffuse", reflectance=(0.2, 0.3, 0.4), twosided=True, opacity=(0.5, 0.6, 0.7)),
-        dict(type="plastic", reflectance=(0.2, 0.3, 0.4), eta=1.4, opacity=(0.25, 0.25, 0.25))]
-    tm = scene.tri_material.copy(); tm[2:20:2] = np.arange(5, 14); scene.tri_material = tm
+        dict(type="plastic", reflectance=(0.2, 0.3, 0.4), eta=1.4, opacity=(0.25, 0.25, 0.25)),
+        dict(type="roughconductor", alpha=0.3, eta=(0.2, 0.9, 1.1), k=(3.9, 2.4, 2.1), reflectance=(1, 1, 1), distribution="beckmann")]
+    tm = scene.tri_material.copy(); tm[2:22:2] = np.arange(5, 15); scene.tri_material = tm
     back, _, info = ppg_host.load_scene(ppg_host.save_scene_xml(scene, dict(budgetType="spp", budget=8.0), str(tmp_path)))
     assert not info["warnings"]
     per_tri = lambda s: sorted((tuple(np.sort(t.reshape(-1))), bytes(Material.from_dict(s.materials[m])))  # noqa: E731
