@@ -87,8 +87,11 @@ enum {
     PPG_BSDF_THINDIELECTRIC = 7    /* thindielectric.cpp:152-252: delta reflection + a NULL (pass-through) component — exercises Li's
                                       null branch (GP:2045-2075) and the look-through of rayIntersectAndLookForEmitter /
                                       evalTransmittance (GP:2184-2245, scene.cpp:619-679) */
+    ,
+    PPG_BSDF_ROUGHDIELECTRIC = 8   /* roughdielectric.cpp:268-606: microfacet reflection + refraction (GGX / Beckmann, visible normals) — a smooth,
+                                      TRANSMISSIVE BSDF: guided on both sides; its sample() draws one extra number from the path's sampler */
 };
-#define PPG_BSDF_LAST PPG_BSDF_THINDIELECTRIC
+#define PPG_BSDF_LAST PPG_BSDF_ROUGHDIELECTRIC
 enum {
     PPG_MAT_TWOSIDED = 1,          /* wrap the (one-sided) BRDF in twosided.cpp:100-180, same BRDF on both sides */
     PPG_MAT_NONLINEAR = 2,         /* plastic: nonlinear = true (plastic.cpp:164) */
@@ -104,9 +107,9 @@ typedef struct ppg_material {
     float reflectance[3]; /* linear RGB (SPECTRUM_SAMPLES=3 build of the reference): diffuse `reflectance`; plastic
                              `diffuseReflectance`; conductors and dielectric `specularReflectance` */
     float specular[3];    /* plastic `specularReflectance`; dielectric / thindielectric `specularTransmittance` */
-    float alpha;          /* roughconductor: GGX roughness `alpha` (clamped to >= 1e-4 like microfacet.h:135) */
+    float alpha;          /* roughconductor / roughdielectric: roughness `alpha` (clamped to >= 1e-4 like microfacet.h:135) */
     float eta[3];         /* conductors: eta per channel (already divided by extEta, roughconductor.cpp:185-186);
-                             plastic / dielectric / thindielectric: eta[0] = intIOR / extIOR */
+                             plastic / (rough / thin) dielectric: eta[0] = intIOR / extIOR */
     float k[3];           /* conductors: k per channel */
     int32_t flags;        /* PPG_MAT_* */
     int32_t _reserved;

@@ -815,7 +815,7 @@ struct Material : ppg_material {
     void configure() {
         if (type == PPG_BSDF_TWOSIDED_DIFFUSE) { type = PPG_BSDF_DIFFUSE; flags |= PPG_MAT_TWOSIDED; }
         if (type == PPG_BSDF_MIRROR) { for (int i = 0; i < 3; ++i) { eta[i] = 0.0f; k[i] = 1.0f; } }  // material "none", conductor.cpp:171-173
-        if (type == PPG_BSDF_ROUGHCONDUCTOR) alpha = ppg_max(alpha, 1e-4f);  // microfacet.h:135
+        if (type == PPG_BSDF_ROUGHCONDUCTOR || type == PPG_BSDF_ROUGHDIELECTRIC) alpha = ppg_max(alpha, 1e-4f);  // microfacet.h:135
         if (type == PPG_BSDF_PLASTIC) {
             fdrInt = ppg_fresnel_diffuse_reflectance(1 / eta[0]);
             Float dAvg = luminance(R()), sAvg = luminance(S());
@@ -1665,6 +1665,97 @@ struct Dielectric {
     }
 };
 
+// RoughDielectric roughdielectric.cpp:268-606 (sampleVisible = true, ERadiance)
+struct RoughDielectric {
+    static Float signum(Float v) { return (ppg_f2u(v) >> 31) ? -1.0f : 1.0f; }  // math::signum: never zero
+    static Spectrum eval(const Material &mt, const BRec &b) {
+        if (b.wi.z == 0) return Spectrum(0.0f);
+        const Float m_eta = mt.eta[0], m_invEta = 1 / m_eta;
+        bool reflect = b.wi.z * b.wo.z > 0;
+        Vec H;
+        if (reflect) H = normalize(b.wo + b.wi);
+        else {
+            Float eta = b.wi.z > 0 ? m_eta : m_invEta;
+            H = normalize(b.wi + b.wo * eta);
+        }
+        H = H * signum(H.z);
+        GGX distr{mt.alpha, (mt.flags & PPG_MAT_BECKMANN) != 0};
+        const Float D = distr.eval(H);
+        if (D == 0) return Spectrum(0.0f);
+        const Float F = fresnelDielectricExt(dot(b.wi, H), m_eta);
+        const Float G = distr.G(b.wi, b.wo, H);
+        if (reflect) {
+            Float value = F * D * G / (4.0f * ppg_abs(b.wi.z));
+            return mt.R() * value;
+        }
+        Float eta = b.wi.z > 0.0f ? m_eta : m_invEta;
+        Float sqrtDenom = dot(b.wi, H) + eta * dot(b.wo, H);
+        Float value = ((1 - F) * D * G * eta * eta * dot(b.wi, H) * dot(b.wo, H)) / (b.wi.z * sqrtDenom * sqrtDenom);
+        Float factor = b.wi.z > 0 ? m_invEta : m_eta;
+        return mt.S() * ppg_abs(value * factor * factor);
+    }
+    static Float pdf(const Material &mt, const BRec &b) {
+        const Float m_eta = mt.eta[0], m_invEta = 1 / m_eta;
+        bool reflect = b.wi.z * b.wo.z > 0;
+        Vec H;
+        Float dwh_dwo;
+        if (reflect) {
+            H = normalize(b.wo + b.wi);
+            dwh_dwo = 1.0f / (4.0f * dot(b.wo, H));
+        } else {
+            Float eta = b.wi.z > 0 ? m_eta : m_invEta;
+            H = normalize(b.wi + b.wo * eta);
+            Float sqrtDenom = dot(b.wi, H) + eta * dot(b.wo, H);
+            dwh_dwo = (eta * eta * dot(b.wo, H)) / (sqrtDenom * sqrtDenom);
+        }
+        H = H * signum(H.z);
+        GGX distr{mt.alpha, (mt.flags & PPG_MAT_BECKMANN) != 0};
+        Float prob = distr.pdfVisible(b.wi * signum(b.wi.z), H);
+        Float F = fresnelDielectricExt(dot(b.wi, H), m_eta);
+        prob *= reflect ? F : (1 - F);
+        return ppg_abs(prob * dwh_dwo);
+    }
+    static Spectrum sample(const Material &mt, BRec &b, Float &pdf, const Point2 &sample, Sampler *sampler) {
+        const Float m_eta = mt.eta[0], m_invEta = 1 / m_eta;
+        GGX distr{mt.alpha, (mt.flags & PPG_MAT_BECKMANN) != 0};
+        pdf = 0;
+        b.sampledDelta = false;
+        const Vec wis = b.wi * signum(b.wi.z);
+        const Vec m = distr.sampleVisible(wis, sample);
+        Float microfacetPDF = distr.pdfVisible(wis, m);
+        if (microfacetPDF == 0) return Spectrum(0.0f);
+        pdf = microfacetPDF;
+        Float cosThetaT;
+        Float F = fresnelDielectricExt(dot(b.wi, m), cosThetaT, m_eta);
+        Spectrum weight(1.0f);
+        bool sampleReflection = true;
+        if (sampler->next1D() > F) { sampleReflection = false; pdf *= 1 - F; }
+        else pdf *= F;
+        Float dwh_dwo;
+        if (sampleReflection) {
+            b.wo = m * (2 * dot(b.wi, m)) - b.wi;  // reflect(wi, m), util.cpp:763-765
+            b.eta = 1.0f;
+            if (b.wi.z * b.wo.z <= 0) return Spectrum(0.0f);
+            weight = mul(weight, mt.R());
+            dwh_dwo = 1.0f / (4.0f * dot(b.wo, m));
+        } else {
+            if (cosThetaT == 0) return Spectrum(0.0f);
+            Float eta = m_eta;  // refract(wi, m, eta, cosThetaT), util.cpp:767-772
+            if (cosThetaT < 0) eta = 1 / eta;
+            b.wo = m * (dot(b.wi, m) * eta + cosThetaT) - b.wi * eta;
+            b.eta = cosThetaT < 0 ? m_eta : m_invEta;
+            if (b.wi.z * b.wo.z >= 0) return Spectrum(0.0f);
+            Float factor = cosThetaT < 0 ? m_invEta : m_eta;
+            weight = mul(weight, mt.S() * (factor * factor));
+            Float sqrtDenom = dot(b.wi, m) + b.eta * dot(b.wo, m);
+            dwh_dwo = (b.eta * b.eta * dot(b.wo, m)) / (sqrtDenom * sqrtDenom);
+        }
+        weight = weight * distr.smithG1(b.wo, m);
+        pdf *= ppg_abs(dwh_dwo);
+        return weight;
+    }
+};
+
 // ThinDielectric thindielectric.cpp:152-252
 struct ThinDielectric {
     static Float R(const Material &m, Float cosThetaI) {  // incl. internal reflections: R' = R + TRT + TR^3T + ..
@@ -1694,12 +1785,13 @@ struct ThinDielectric {
 // BSDF dispatch: getType / eval / pdf / sample (solid-angle measure) of the supported plugins, incl. the TwoSided adapter
 struct BSDF {
     static bool isSmooth(const Material &m) {  // getType() & ESmooth (diffuse or glossy components)
-        return m.type == PPG_BSDF_DIFFUSE || m.type == PPG_BSDF_ROUGHCONDUCTOR || m.type == PPG_BSDF_PLASTIC;
+        return m.type == PPG_BSDF_DIFFUSE || m.type == PPG_BSDF_ROUGHCONDUCTOR || m.type == PPG_BSDF_PLASTIC || m.type == PPG_BSDF_ROUGHDIELECTRIC;
     }
     static bool allDelta(const Material &m) { return !isSmooth(m); }  // (type & EDelta) == (type & EAll)
     // getType() & (ETransmission | EBackSide): twosided sets EBackSide (twosided.cpp:97-101), the dielectric both
     static bool hasBackSideOrTransmission(const Material &m) {
-        return (m.flags & (PPG_MAT_TWOSIDED | PPG_MAT_MASK)) || m.type == PPG_BSDF_DIELECTRIC || m.type == PPG_BSDF_THINDIELECTRIC;  // mask: mask.cpp:103
+        return (m.flags & (PPG_MAT_TWOSIDED | PPG_MAT_MASK)) || m.type == PPG_BSDF_DIELECTRIC || m.type == PPG_BSDF_THINDIELECTRIC ||
+               m.type == PPG_BSDF_ROUGHDIELECTRIC;  // mask: mask.cpp:103
     }
     static bool hasNull(const Material &m) { return m.masked() || m.type == PPG_BSDF_THINDIELECTRIC; }  // getType() & ENull
     static Spectrum evalNull(const Material &m, Float cosThetaI) {  // eval(bRec(its, -wo, wo), EDiscrete), typeMask = ENull
@@ -1712,6 +1804,7 @@ struct BSDF {
             case PPG_BSDF_DIFFUSE: return Diffuse::eval(m, b);
             case PPG_BSDF_ROUGHCONDUCTOR: return RoughConductor::eval(m, b);
             case PPG_BSDF_PLASTIC: return Plastic::eval(m, b);
+            case PPG_BSDF_ROUGHDIELECTRIC: return RoughDielectric::eval(m, b);
             default: return Spectrum(0.0f);  // delta components are zero for the solid-angle measure (conductor.cpp:222-237)
         }
     }
@@ -1720,10 +1813,11 @@ struct BSDF {
             case PPG_BSDF_DIFFUSE: return Diffuse::pdf(m, b);
             case PPG_BSDF_ROUGHCONDUCTOR: return RoughConductor::pdf(m, b);
             case PPG_BSDF_PLASTIC: return Plastic::pdf(m, b);
+            case PPG_BSDF_ROUGHDIELECTRIC: return RoughDielectric::pdf(m, b);
             default: return 0.0f;
         }
     }
-    static Spectrum sampleOne(const Material &m, BRec &b, Float &pdf, const Point2 &sample) {
+    static Spectrum sampleOne(const Material &m, BRec &b, Float &pdf, const Point2 &sample, Sampler *sampler) {
         switch (m.type) {
             case PPG_BSDF_DIFFUSE: return Diffuse::sample(m, b, pdf, sample);
             case PPG_BSDF_MIRROR:
@@ -1732,10 +1826,13 @@ struct BSDF {
             case PPG_BSDF_PLASTIC: return Plastic::sample(m, b, pdf, sample);
             case PPG_BSDF_DIELECTRIC: return Dielectric::sample(m, b, pdf, sample);
             case PPG_BSDF_THINDIELECTRIC: return ThinDielectric::sample(m, b, pdf, sample);
+            case PPG_BSDF_ROUGHDIELECTRIC: return RoughDielectric::sample(m, b, pdf, sample, sampler);
             default: pdf = 0; return Spectrum(0.0f);
         }
     }
-    static bool twoSided(const Material &m) { return (m.flags & PPG_MAT_TWOSIDED) && m.type != PPG_BSDF_DIELECTRIC && m.type != PPG_BSDF_THINDIELECTRIC; }
+    static bool twoSided(const Material &m) {
+        return (m.flags & PPG_MAT_TWOSIDED) && m.type != PPG_BSDF_DIELECTRIC && m.type != PPG_BSDF_THINDIELECTRIC && m.type != PPG_BSDF_ROUGHDIELECTRIC;
+    }
 
     static Spectrum evalTS(const Material &m, const BRec &b) {
         if (!twoSided(m) || b.wi.z > 0) return evalOne(m, b);
@@ -1758,14 +1855,14 @@ struct BSDF {
         Float r = pdfTS(m, b);
         return m.masked() ? r * luminance(m.Opacity()) : r;
     }
-    static Spectrum sample(const Material &m, BRec &b, Float &pdf, const Point2 &_sample) {
-        if (!m.masked()) return sampleTS(m, b, pdf, _sample);
+    static Spectrum sample(const Material &m, BRec &b, Float &pdf, const Point2 &_sample, Sampler *sampler) {
+        if (!m.masked()) return sampleTS(m, b, pdf, _sample, sampler);
         Point2 sample(_sample);
         Spectrum opacity = m.Opacity();
         Float prob = luminance(opacity);
         if (sample.x < prob) {
             sample.x /= prob;
-            Spectrum result = mul(sampleTS(m, b, pdf, sample), opacity) / prob;
+            Spectrum result = mul(sampleTS(m, b, pdf, sample, sampler), opacity) / prob;
             pdf *= prob;
             return result;
         }
@@ -1776,11 +1873,11 @@ struct BSDF {
         pdf = 1 - prob;
         return (Spectrum(1.0f) - opacity) / pdf;
     }
-    static Spectrum sampleTS(const Material &m, BRec &b, Float &pdf, const Point2 &sample) {
-        if (!twoSided(m)) return sampleOne(m, b, pdf, sample);
+    static Spectrum sampleTS(const Material &m, BRec &b, Float &pdf, const Point2 &sample, Sampler *sampler) {
+        if (!twoSided(m)) return sampleOne(m, b, pdf, sample, sampler);
         bool flipped = false;  // twosided.cpp:160-180
         if (b.wi.z < 0) { b.wi.z *= -1; flipped = true; }
-        Spectrum result = sampleOne(m, b, pdf, sample);
+        Spectrum result = sampleOne(m, b, pdf, sample, sampler);
         if (flipped) {
             b.wi.z *= -1;
             if (!isZero(result) && pdf != 0) b.wo.z *= -1;
@@ -2047,7 +2144,7 @@ public:
                        Float bsdfSamplingFraction, Sampler &sampler, const DTreeWrapper *dTree) const {
         Point2 sample = sampler.next2D();
         if (!m_isBuilt || !dTree || BSDF::allDelta(bsdf)) {
-            Spectrum result = BSDF::sample(bsdf, bRec, bsdfPdf, sample);
+            Spectrum result = BSDF::sample(bsdf, bRec, bsdfPdf, sample, &sampler);
             woPdf = bsdfPdf;
             dTreePdf = 0;
             return result;
@@ -2055,7 +2152,7 @@ public:
         Spectrum result;
         if (sample.x < bsdfSamplingFraction) {
             sample.x /= bsdfSamplingFraction;
-            result = BSDF::sample(bsdf, bRec, bsdfPdf, sample);
+            result = BSDF::sample(bsdf, bRec, bsdfPdf, sample, &sampler);
             if (isZero(result)) {
                 woPdf = bsdfPdf = dTreePdf = 0;
                 return Spectrum(0.0f);
@@ -2533,7 +2630,7 @@ int ppgo_set_scene(ppgo_ctx *ctx, const ppg_scene *s) {
         Material m;
         static_cast<ppg_material &>(m) = s->materials[i];
         if (m.type < 0 || m.type > PPG_BSDF_LAST) { ctx->gpt.error = "unsupported BSDF type"; return PPG_ERR_INVALID; }
-        if ((m.type == PPG_BSDF_PLASTIC || m.type == PPG_BSDF_DIELECTRIC || m.type == PPG_BSDF_THINDIELECTRIC) && !(m.eta[0] > 0)) { ctx->gpt.error = "plastic / dielectric need eta[0] = intIOR / extIOR > 0"; return PPG_ERR_INVALID; }
+        if ((m.type == PPG_BSDF_PLASTIC || m.type == PPG_BSDF_DIELECTRIC || m.type == PPG_BSDF_THINDIELECTRIC || m.type == PPG_BSDF_ROUGHDIELECTRIC) && !(m.eta[0] > 0)) { ctx->gpt.error = "plastic / dielectric need eta[0] = intIOR / extIOR > 0"; return PPG_ERR_INVALID; }
         m.configure();
         sc.materials.push_back(m);
     }
@@ -2852,7 +2949,8 @@ int ppgo_bsdf_sample(const ppg_material *mat, uint32_t n, const float *wi, const
     for (uint32_t i = 0; i < n; ++i) {
         BRec b; b.wi = Vec(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]);
         Float pdf = 0;
-        Spectrum w = BSDF::sample(m, b, pdf, Point2{sample_xy[2 * i], sample_xy[2 * i + 1]});
+        Sampler smp{ppg_path_key(77, i, 0), 0};  // the extra draw of roughdielectric::sample (roughdielectric.cpp:553)
+        Spectrum w = BSDF::sample(m, b, pdf, Point2{sample_xy[2 * i], sample_xy[2 * i + 1]}, &smp);
         wo_out[3 * i] = b.wo.x; wo_out[3 * i + 1] = b.wo.y; wo_out[3 * i + 2] = b.wo.z;
         weight_out[3 * i] = w.x; weight_out[3 * i + 1] = w.y; weight_out[3 * i + 2] = w.z;
         pdf_out[i] = pdf; eta_out[i] = b.eta; delta_out[i] = b.sampledDelta ? 1 : 0;

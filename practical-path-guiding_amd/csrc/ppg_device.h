@@ -600,17 +600,23 @@ D Mat load_material(const DevScene &S, int id) {
     M.opacity = f3(e.x, e.y, e.z);
     return M;
 }
-D bool mat_is_smooth(const Mat &M) { return M.type == PPG_BSDF_DIFFUSE || M.type == PPG_BSDF_ROUGHCONDUCTOR || M.type == PPG_BSDF_PLASTIC; }
-D bool mat_two_sided(const Mat &M) { return (M.flags & PPG_MAT_TWOSIDED) && M.type != PPG_BSDF_DIELECTRIC && M.type != PPG_BSDF_THINDIELECTRIC; }
+D bool mat_is_smooth(const Mat &M) {
+    return M.type == PPG_BSDF_DIFFUSE || M.type == PPG_BSDF_ROUGHCONDUCTOR || M.type == PPG_BSDF_PLASTIC || M.type == PPG_BSDF_ROUGHDIELECTRIC;
+}
+D bool mat_two_sided(const Mat &M) {
+    return (M.flags & PPG_MAT_TWOSIDED) && M.type != PPG_BSDF_DIELECTRIC && M.type != PPG_BSDF_THINDIELECTRIC && M.type != PPG_BSDF_ROUGHDIELECTRIC;
+}
 D bool mat_masked(const Mat &M) { return (M.flags & PPG_MAT_MASK) != 0; }
 D bool mat_backside_or_transmission(const Mat &M) {
-    return (M.flags & (PPG_MAT_TWOSIDED | PPG_MAT_MASK)) || M.type == PPG_BSDF_DIELECTRIC || M.type == PPG_BSDF_THINDIELECTRIC;
+    return (M.flags & (PPG_MAT_TWOSIDED | PPG_MAT_MASK)) || M.type == PPG_BSDF_DIELECTRIC || M.type == PPG_BSDF_THINDIELECTRIC ||
+           M.type == PPG_BSDF_ROUGHDIELECTRIC;
 }
 D bool mat_has_null(const Mat &M) { return mat_masked(M) || M.type == PPG_BSDF_THINDIELECTRIC; }  // getType() & ENull
 
 D F3 cdiv3(F3 a, F3 b) { return f3(a.x / b.x, a.y / b.y, a.z / b.z); }
 D F3 safe_sqrt3(F3 s) { return f3(__builtin_sqrtf(ppg_max(0.0f, s.x)), __builtin_sqrtf(ppg_max(0.0f, s.y)), __builtin_sqrtf(ppg_max(0.0f, s.z))); }
 D float lum3(F3 s) { return s.x * 0.212671f + s.y * 0.715160f + s.z * 0.072169f; }
+D float fsignum(float v) { return (ppg_f2u(v) >> 31) ? -1.0f : 1.0f; }  // math::signum: the FP sign, never zero
 
 // util.cpp:651-681
 D float fresnel_dielectric_ext(float cosThetaI_, float &cosThetaT_, float eta) {
@@ -831,6 +837,32 @@ D F3 mat_eval_one(const Mat &M, F3 wi, F3 wo) {
         float model = Dm * G / (4.0f * wi.z);
         return F * model;
     }
+    if (M.type == PPG_BSDF_ROUGHDIELECTRIC) {  // roughdielectric.cpp:268-340
+        if (wi.z == 0) return f3s(0.0f);
+        const float m_eta = M.eta.x, m_invEta = 1 / m_eta;
+        const bool reflect = wi.z * wo.z > 0;
+        F3 H;
+        if (reflect) H = norm3(wo + wi);
+        else {
+            float eta = wi.z > 0 ? m_eta : m_invEta;
+            H = norm3(wi + wo * eta);
+        }
+        H = H * fsignum(H.z);
+        const Mfd distr{M.alpha, (M.flags & PPG_MAT_BECKMANN) != 0};
+        const float Dm = ggx_eval(distr, H);
+        if (Dm == 0) return f3s(0.0f);
+        const float F = fresnel_dielectric_ext(dot3(wi, H), m_eta);
+        const float G = ggx_smith_g1(distr, wi, H) * ggx_smith_g1(distr, wo, H);
+        if (reflect) {
+            float value = F * Dm * G / (4.0f * ppg_abs(wi.z));
+            return M.refl * value;
+        }
+        float eta = wi.z > 0.0f ? m_eta : m_invEta;
+        float sqrtDenom = dot3(wi, H) + eta * dot3(wo, H);
+        float value = ((1 - F) * Dm * G * eta * eta * dot3(wi, H) * dot3(wo, H)) / (wi.z * sqrtDenom * sqrtDenom);
+        float factor = wi.z > 0 ? m_invEta : m_eta;
+        return M.spec * ppg_abs(value * factor * factor);
+    }
     if (M.type == PPG_BSDF_PLASTIC) {  // plastic.cpp:247-281, diffuse component
         if (wo.z <= 0 || wi.z <= 0) return f3s(0.0f);
         float Fi = fresnel_dielectric_ext(wi.z, M.eta.x);
@@ -848,6 +880,27 @@ D float mat_pdf_one(const Mat &M, F3 wi, F3 wo) {
         const Mfd distr{M.alpha, (M.flags & PPG_MAT_BECKMANN) != 0};
         return ggx_eval(distr, H) * ggx_smith_g1(distr, wi, H) / (4.0f * wi.z);
     }
+    if (M.type == PPG_BSDF_ROUGHDIELECTRIC) {  // roughdielectric.cpp:342-418
+        const float m_eta = M.eta.x, m_invEta = 1 / m_eta;
+        const bool reflect = wi.z * wo.z > 0;
+        F3 H;
+        float dwh_dwo;
+        if (reflect) {
+            H = norm3(wo + wi);
+            dwh_dwo = 1.0f / (4.0f * dot3(wo, H));
+        } else {
+            float eta = wi.z > 0 ? m_eta : m_invEta;
+            H = norm3(wi + wo * eta);
+            float sqrtDenom = dot3(wi, H) + eta * dot3(wo, H);
+            dwh_dwo = (eta * eta * dot3(wo, H)) / (sqrtDenom * sqrtDenom);
+        }
+        H = H * fsignum(H.z);
+        const Mfd distr{M.alpha, (M.flags & PPG_MAT_BECKMANN) != 0};
+        float prob = ggx_pdf_visible(distr, wi * fsignum(wi.z), H);
+        float F = fresnel_dielectric_ext(dot3(wi, H), m_eta);
+        prob *= reflect ? F : (1 - F);
+        return ppg_abs(prob * dwh_dwo);
+    }
     if (M.type == PPG_BSDF_PLASTIC) {  // plastic.cpp:283-311
         if (wo.z <= 0 || wi.z <= 0) return 0.0f;
         float Fi = fresnel_dielectric_ext(wi.z, M.eta.x);
@@ -855,7 +908,8 @@ D float mat_pdf_one(const Mat &M, F3 wi, F3 wo) {
     }
     return 0.0f;
 }
-D F3 mat_sample_one(const Mat &M, F3 wi, float sx, float sy, F3 &wo, float &pdf, bool &delta, float &eta, bool &isnull) {
+D F3 mat_sample_one(const Mat &M, F3 wi, float sx, float sy, F3 &wo, float &pdf, bool &delta, float &eta, bool &isnull, unsigned int key,
+                    unsigned int &dim) {
     delta = false; eta = 1.0f; pdf = 0.0f; wo = f3s(0.0f); isnull = false;
     switch (M.type) {
         case PPG_BSDF_DIFFUSE:
@@ -916,6 +970,42 @@ D F3 mat_sample_one(const Mat &M, F3 wi, float sx, float sy, F3 &wo, float &pdf,
             float factor = cosThetaT < 0 ? invEta : e;
             return M.spec * (factor * factor);
         }
+        case PPG_BSDF_ROUGHDIELECTRIC: {  // roughdielectric.cpp:514-606
+            const float m_eta = M.eta.x, m_invEta = 1 / m_eta;
+            const Mfd distr{M.alpha, (M.flags & PPG_MAT_BECKMANN) != 0};
+            const F3 wis = wi * fsignum(wi.z);
+            const F3 m = ggx_sample_visible(distr, wis, sx, sy);
+            const float microfacetPDF = ggx_pdf_visible(distr, wis, m);
+            if (microfacetPDF == 0) return f3s(0.0f);
+            pdf = microfacetPDF;
+            float cosThetaT;
+            const float F = fresnel_dielectric_ext(dot3(wi, m), cosThetaT, m_eta);
+            F3 weight = f3s(1.0f);
+            bool sampleReflection = true;
+            if (ppg_rand(key, dim++) > F) { sampleReflection = false; pdf *= 1 - F; }  // bRec.sampler->next1D(), roughdielectric.cpp:553
+            else pdf *= F;
+            float dwh_dwo;
+            if (sampleReflection) {
+                wo = m * (2 * dot3(wi, m)) - wi;
+                if (wi.z * wo.z <= 0) return f3s(0.0f);
+                weight = mul3(weight, M.refl);
+                dwh_dwo = 1.0f / (4.0f * dot3(wo, m));
+            } else {
+                if (cosThetaT == 0) return f3s(0.0f);
+                float e2 = m_eta;  // refract(wi, m, eta, cosThetaT), util.cpp:767-772
+                if (cosThetaT < 0) e2 = 1 / e2;
+                wo = m * (dot3(wi, m) * e2 + cosThetaT) - wi * e2;
+                eta = cosThetaT < 0 ? m_eta : m_invEta;
+                if (wi.z * wo.z >= 0) return f3s(0.0f);
+                float factor = cosThetaT < 0 ? m_invEta : m_eta;
+                weight = mul3(weight, M.spec * (factor * factor));
+                float sqrtDenom = dot3(wi, m) + eta * dot3(wo, m);
+                dwh_dwo = (eta * eta * dot3(wo, m)) / (sqrtDenom * sqrtDenom);
+            }
+            weight = weight * ggx_smith_g1(distr, wo, m);
+            pdf *= ppg_abs(dwh_dwo);
+            return weight;
+        }
         case PPG_BSDF_THINDIELECTRIC: {  // thindielectric.cpp:203-232
             const float Rr = thin_R(M, wi.z);
             delta = true;
@@ -943,13 +1033,16 @@ D float mat_pdf(const Mat &M, F3 wi, F3 wo) {
     float r = mat_pdf_one(M, wi, wo);
     return mat_masked(M) ? r * lum3(M.opacity) : r;
 }
-D F3 mat_sample_ts(const Mat &M, F3 wi, float sx, float sy, F3 &wo, float &pdf, bool &delta, float &eta, bool &isnull);
-D F3 mat_sample(const Mat &M, F3 wi, float sx, float sy, F3 &wo, float &pdf, bool &delta, float &eta, bool &isnull) {
-    if (!mat_masked(M)) return mat_sample_ts(M, wi, sx, sy, wo, pdf, delta, eta, isnull);
+D F3 mat_sample_ts(const Mat &M, F3 wi, float sx, float sy, F3 &wo, float &pdf, bool &delta, float &eta, bool &isnull, unsigned int key,
+                   unsigned int &dim);
+// key / dim: the path's sampler, for plug-ins whose sample() draws from it (roughdielectric)
+D F3 mat_sample(const Mat &M, F3 wi, float sx, float sy, F3 &wo, float &pdf, bool &delta, float &eta, bool &isnull, unsigned int key,
+                unsigned int &dim) {
+    if (!mat_masked(M)) return mat_sample_ts(M, wi, sx, sy, wo, pdf, delta, eta, isnull, key, dim);
     const float prob = lum3(M.opacity);
     if (sx < prob) {
         sx /= prob;
-        F3 result = div3(mul3(mat_sample_ts(M, wi, sx, sy, wo, pdf, delta, eta, isnull), M.opacity), prob);
+        F3 result = div3(mul3(mat_sample_ts(M, wi, sx, sy, wo, pdf, delta, eta, isnull, key, dim), M.opacity), prob);
         pdf *= prob;
         return result;
     }
@@ -960,10 +1053,11 @@ D F3 mat_sample(const Mat &M, F3 wi, float sx, float sy, F3 &wo, float &pdf, boo
     pdf = 1 - prob;
     return div3(f3s(1.0f) - M.opacity, pdf);
 }
-D F3 mat_sample_ts(const Mat &M, F3 wi, float sx, float sy, F3 &wo, float &pdf, bool &delta, float &eta, bool &isnull) {
+D F3 mat_sample_ts(const Mat &M, F3 wi, float sx, float sy, F3 &wo, float &pdf, bool &delta, float &eta, bool &isnull, unsigned int key,
+                   unsigned int &dim) {
     bool flipped = false;
     if (mat_two_sided(M) && wi.z < 0) { wi.z *= -1; flipped = true; }
-    F3 result = mat_sample_one(M, wi, sx, sy, wo, pdf, delta, eta, isnull);
+    F3 result = mat_sample_one(M, wi, sx, sy, wo, pdf, delta, eta, isnull, key, dim);
     if (flipped && !iszero3(result) && pdf != 0) wo.z *= -1;
     return result;
 }

@@ -1174,8 +1174,8 @@ int ppg_set_scene(ppg_ctx *ctx, const ppg_scene *s) {
         if (m.type == PPG_BSDF_DIFFUSE && m.flags == PPG_MAT_TWOSIDED) { m.type = PPG_BSDF_TWOSIDED_DIFFUSE; m.flags = 0; }
         if (m.type == PPG_BSDF_TWOSIDED_DIFFUSE) m.flags &= ~PPG_MAT_TWOSIDED;
         if (m.type == PPG_BSDF_MIRROR) for (int c = 0; c < 3; ++c) { m.eta[c] = 0.0f; m.k[c] = 1.0f; }
-        if (m.type == PPG_BSDF_ROUGHCONDUCTOR) m.alpha = ppg_max(m.alpha, 1e-4f);
-        if ((m.type == PPG_BSDF_PLASTIC || m.type == PPG_BSDF_DIELECTRIC || m.type == PPG_BSDF_THINDIELECTRIC) && !(m.eta[0] > 0)) { ctx->error = "plastic / dielectric need eta[0] = intIOR / extIOR > 0"; return PPG_ERR_INVALID; }
+        if (m.type == PPG_BSDF_ROUGHCONDUCTOR || m.type == PPG_BSDF_ROUGHDIELECTRIC) m.alpha = ppg_max(m.alpha, 1e-4f);
+        if ((m.type == PPG_BSDF_PLASTIC || m.type == PPG_BSDF_DIELECTRIC || m.type == PPG_BSDF_THINDIELECTRIC || m.type == PPG_BSDF_ROUGHDIELECTRIC) && !(m.eta[0] > 0)) { ctx->error = "plastic / dielectric need eta[0] = intIOR / extIOR > 0"; return PPG_ERR_INVALID; }
         const float fdrInt = m.type == PPG_BSDF_PLASTIC ? ppg_fresnel_diffuse_reflectance(1 / m.eta[0]) : 0.0f;
         if (m.type > PPG_BSDF_MIRROR || m.flags != 0) ctx->fullMaterials = true;
         if (m.type == PPG_BSDF_THINDIELECTRIC || (m.flags & PPG_MAT_MASK)) hasNull = true;

@@ -820,7 +820,7 @@ D void shade_slice(const PathState &P, const DevScene &S, const DevTree &T, cons
                 float sampledEta = 1.0f;
                 bool sampledNull = false;
                 auto b_sample = [&](float u_, float v_, F3 &wo_, float &pdf_, bool &delta_) {
-                    return FULL ? mat_sample(M, I.wi, u_, v_, wo_, pdf_, delta_, sampledEta, sampledNull)
+                    return FULL ? mat_sample(M, I.wi, u_, v_, wo_, pdf_, delta_, sampledEta, sampledNull, key, dim)
                                 : bsdf_sample(M.type, M.refl, I.wi, u_, v_, wo_, pdf_, delta_);
                 };
                 F3 vox = f3s(0.0f);

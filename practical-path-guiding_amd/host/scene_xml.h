@@ -5,7 +5,7 @@
  *   integrator  guided_path (properties of guided_path.cpp:1014-1085 and integrator.cpp:192-218)
  *   sensor      perspective (fov, fovAxis, nearClip, farClip, toWorld), film hdrfilm (width, height; rfilter box)
  *   shapes      obj (filename, toWorld, faceNormals, flipNormals, flipTexCoords, collapse), rectangle (toWorld, flipNormals)
- *   bsdfs       diffuse, conductor, roughconductor (ggx / beckmann, isotropic), plastic, dielectric, thindielectric, mask (constant opacity),
+ *   bsdfs       diffuse, conductor, roughconductor / roughdielectric (ggx / beckmann, isotropic), plastic, dielectric, thindielectric, mask (constant opacity),
  *               twosided(BRDF) — top level with id, nested, or <ref id>
  *   emitters    area (nested in a shape), constant (environment)
  *   values      <spectrum>, <rgb>, <srgb>; <transform> of translate / rotate / scale / lookAt / matrix; <default> and $name
@@ -672,7 +672,7 @@ private:
             auto in = inner();
             if (in.size() == 1) {
                 m = makeBsdf(*in[0], false, out);
-                if (m.type == PPG_BSDF_DIELECTRIC || m.type == PPG_BSDF_THINDIELECTRIC) throw std::runtime_error("twosided(dielectric): only BRDFs can be two-sided (twosided.cpp:84-88)");
+                if (m.type == PPG_BSDF_DIELECTRIC || m.type == PPG_BSDF_THINDIELECTRIC || m.type == PPG_BSDF_ROUGHDIELECTRIC) throw std::runtime_error("twosided(dielectric): only BRDFs can be two-sided (twosided.cpp:84-88)");
                 if (m.type == PPG_BSDF_DIFFUSE && !(m.flags & PPG_MAT_MASK)) { m.type = PPG_BSDF_TWOSIDED_DIFFUSE; return m; }
                 m.flags |= PPG_MAT_TWOSIDED;
                 return m;
@@ -697,10 +697,18 @@ private:
             colour(e, "specularReflectance", 1.0f, m.reflectance);
             if (mat != "none") conductorIOR(e, p, t, m);
             return m;
-        } else if (t == "roughconductor") {
-            m.type = PPG_BSDF_ROUGHCONDUCTOR; defaults(m);
-            colour(e, "specularReflectance", 1.0f, m.reflectance);
-            conductorIOR(e, p, t, m);
+        } else if (t == "roughconductor" || t == "roughdielectric") {
+            if (t == "roughconductor") {
+                m.type = PPG_BSDF_ROUGHCONDUCTOR; defaults(m);
+                colour(e, "specularReflectance", 1.0f, m.reflectance);
+                conductorIOR(e, p, t, m);
+            } else {  // roughdielectric.cpp:183-211
+                m.type = PPG_BSDF_ROUGHDIELECTRIC; defaults(m);
+                colour(e, "specularReflectance", 1.0f, m.reflectance); colour(e, "specularTransmittance", 1.0f, m.specular);
+                const double intIOR = lookupIOR(p, "intIOR", "bk7"), extIOR = lookupIOR(p, "extIOR", "air");
+                if (intIOR < 0 || extIOR < 0 || intIOR == extIOR) throw std::runtime_error(t + ": the interior and exterior indices of refraction must be positive and differ");
+                m.eta[0] = m.eta[1] = m.eta[2] = (float)(intIOR / extIOR);
+            }
             std::string distr = p.count("distribution") ? p["distribution"] : "beckmann";
             std::transform(distr.begin(), distr.end(), distr.begin(), ::tolower);
             if (distr != "ggx" && distr != "beckmann") throw std::runtime_error(t + ": distribution '" + distr + "' is not supported (ggx, beckmann)");
@@ -724,7 +732,7 @@ private:
             }
             return m;
         }
-        if (m_strict) throw std::runtime_error("bsdf type '" + t + "' is not supported yet (diffuse, conductor, roughconductor, plastic, dielectric, thindielectric, mask, twosided; SURVEY.md §8 f1)");
+        if (m_strict) throw std::runtime_error("bsdf type '" + t + "' is not supported yet (diffuse, conductor, roughconductor, plastic, dielectric, thindielectric, roughdielectric, mask, twosided; SURVEY.md §8 f1)");
         out.warnings.push_back("bsdf '" + t + "' replaced by diffuse(0.5)");
         m = ppg_material{}; m.type = PPG_BSDF_DIFFUSE; defaults(m);
         m.reflectance[0] = m.reflectance[1] = m.reflectance[2] = 0.5f;

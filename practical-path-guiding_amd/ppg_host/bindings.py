@@ -67,7 +67,7 @@ class Material(C.Structure):
                 ("eta", C.c_float * 3), ("k", C.c_float * 3), ("flags", C.c_int32), ("_reserved", C.c_int32),
                 ("opacity", C.c_float * 3), ("_pad", C.c_float)]
 
-    BSDF = dict(diffuse=0, twosided_diffuse=1, mirror=2, conductor=3, roughconductor=4, plastic=5, dielectric=6, thindielectric=7)
+    BSDF = dict(diffuse=0, twosided_diffuse=1, mirror=2, conductor=3, roughconductor=4, plastic=5, dielectric=6, thindielectric=7, roughdielectric=8)
 
     @classmethod
     def from_dict(cls, m):

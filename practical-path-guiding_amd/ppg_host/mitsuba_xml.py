@@ -5,7 +5,7 @@
               nested sampler (independent; sampleCount / seed do not steer guided_path, GP:1342-1374) and
               film hdrfilm (width, height; rfilter box)
   shapes      obj (filename, toWorld, faceNormals, flipNormals, flipTexCoords, collapse), rectangle (toWorld, flipNormals)
-  bsdfs       diffuse, conductor (material none, or explicit eta / k), roughconductor (ggx / beckmann, isotropic), plastic, dielectric, thindielectric,
+  bsdfs       diffuse, conductor (material none, or explicit eta / k), roughconductor / roughdielectric (ggx / beckmann, isotropic), plastic, dielectric, thindielectric,
               mask (constant opacity), twosided(any of the BRDFs) — top level with id, nested, or <ref id>
   emitters    area (nested in a shape), constant (environment)
   values      <spectrum>, <rgb>, <srgb> (spectrum.py), <transform> of translate / rotate / scale / lookAt / matrix,
@@ -413,7 +413,7 @@ def load_scene(path, defines=None, strict=True, width=None, height=None):
             inner = [c for c in elem if c.tag == "bsdf"]
             if len(inner) == 1:
                 m = make_bsdf(inner[0], allow_twosided=False)
-                if m["type"] in (6, 7):
+                if m["type"] in (6, 7, 8):
                     raise SceneError("twosided(dielectric): only BRDFs can be two-sided (twosided.cpp:84-88)")
                 if m["type"] == 0 and not m.get("_substituted"):
                     return dict(type=1, reflectance=m["reflectance"])
@@ -450,8 +450,18 @@ def load_scene(path, defines=None, strict=True, width=None, height=None):
         elif t == "thindielectric":
             eta = lookup_ior(p, "intIOR", "bk7") / lookup_ior(p, "extIOR", "air")
             return dict(type=7, reflectance=rgb("specularReflectance", 1.0), specular=rgb("specularTransmittance", 1.0), eta=float(f32(eta)))
+        elif t == "roughdielectric":  # roughdielectric.cpp:183-211
+            int_ior, ext_ior = lookup_ior(p, "intIOR", "bk7"), lookup_ior(p, "extIOR", "air")
+            if int_ior < 0 or ext_ior < 0 or int_ior == ext_ior:
+                raise SceneError("roughdielectric: the interior and exterior indices of refraction must be positive and differ")
+            m = dict(type=8, reflectance=rgb("specularReflectance", 1.0), specular=rgb("specularTransmittance", 1.0), eta=float(f32(int_ior / ext_ior)),
+                     alpha=microfacet_alpha(p, t))
+            if str(p.get("distribution", "beckmann")).lower() == "beckmann":
+                m["distribution"] = "beckmann"
+            return m
         if strict:
-            raise SceneError("bsdf type %r is not supported yet (diffuse, conductor, roughconductor, plastic, dielectric, thindielectric, twosided(...); "
+            raise SceneError("bsdf type %r is not supported yet (diffuse, conductor, roughconductor, plastic, dielectric, thindielectric, roughdielectric, "
+                             "mask(...), twosided(...); "
                              "SURVEY.md §8 f1)" % t)
         warnings.append("bsdf %r replaced by diffuse(0.5)" % t)
         return dict(type=0, reflectance=(0.5, 0.5, 0.5), _substituted=True)
@@ -599,8 +609,11 @@ def save_scene_xml(desc, props, directory, name="scene"):
                '<boolean name="nonlinear" value="%s"/></bsdf>' % (one, R, S, "true" if M.flags & 2 else "false"),
             6: '<bsdf type="dielectric"%%s>%s<rgb name="specularReflectance" value="%s"/><rgb name="specularTransmittance" value="%s"/></bsdf>' % (one, R, S),
             7: '<bsdf type="thindielectric"%%s>%s<rgb name="specularReflectance" value="%s"/><rgb name="specularTransmittance" value="%s"/></bsdf>' % (one, R, S),
+            8: '<bsdf type="roughdielectric"%%s><string name="distribution" value="%s"/><float name="alpha" value="%r"/>%s'
+               '<rgb name="specularReflectance" value="%s"/><rgb name="specularTransmittance" value="%s"/></bsdf>'
+               % ("beckmann" if M.flags & 8 else "ggx", float(M.alpha), one, R, S),
         }[t]
-        twos = t == 1 or (M.flags & 1 and t not in (6, 7))
+        twos = t == 1 or (M.flags & 1 and t not in (6, 7, 8))
         if M.flags & 4:
             inner = ('<bsdf type="twosided">%s</bsdf>' % (body % "")) if twos else body % ""
             out.append('\t<bsdf type="mask" id="mat%d"><rgb name="opacity" value="%s"/>%s</bsdf>' % (i, c(M.opacity), inner))

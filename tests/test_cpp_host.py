@@ -160,6 +160,8 @@ def test_cpp_scene_xml_loader_equals_the_python_loader(ppg_render, tmp_path):
     <shape type="rectangle"><bsdf type="plastic"><spectrum name="diffuseReflectance" value="400:0.1, 500:0.5, 600:0.3, 700:0.2"/></bsdf></shape>
     <shape type="rectangle"><bsdf type="dielectric"><string name="intIOR" value="water"/></bsdf></shape>
     <shape type="rectangle"><bsdf type="thindielectric"/></shape>
+    <shape type="rectangle"><bsdf type="roughdielectric"><string name="intIOR" value="diamond"/><float name="alpha" value="0.05"/></bsdf></shape>
+    <shape type="rectangle"><bsdf type="roughdielectric"><string name="distribution" value="ggx"/><rgb name="specularTransmittance" value="0.9, 0.8, 0.7"/></bsdf></shape>
     <shape type="rectangle"><bsdf type="conductor"><rgb name="eta" value="0.2, 0.9, 1.1"/><rgb name="k" value="3.9, 2.4, 2.1"/></bsdf></shape>
     <shape type="obj"><string name="filename" value="meshes/cube.obj"/><transform name="toWorld"><rotate x="1" y="1" angle="33"/><translate x="3"/></transform></shape>
     <emitter type="constant"><srgb name="radiance" value="0.5, 0.6, 0.7"/></emitter>

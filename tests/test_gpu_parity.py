@@ -476,6 +476,37 @@ def test_glossy_plastic_and_glass_materials_against_oracle(oracle_lib, extra):
     assert np.nanmean(np.abs(ig - plain)) > 5e-3
 
 
+@pytest.mark.parametrize("extra", [{}, dict(nee="always", **IMPROVED), dict(maxDepth=-1, rrDepth=3, strictNormals=0, nee="kickstart")],
+                         ids=["default", "nee-always-improved", "unbounded-kickstart"])
+def test_rough_dielectric_against_oracle(oracle_lib, extra):
+    """roughdielectric (roughdielectric.cpp:268-606): a smooth ⇒ guided BSDF that transmits — guided directions below the surface,
+    eta carried for Russian roulette, and sample() drawing its reflect/refract choice from the path's sampler (one extra
+    dimension per BSDF sample), which shifts every later dimension of the path."""
+    import ppg_host
+    scene = ppg_host.cbox_scene(64, 64)
+    base = len(scene.materials)
+    scene.materials = list(scene.materials) + [
+        dict(type="roughdielectric", alpha=0.2, eta=1.5, reflectance=(1, 1, 1), specular=(0.95, 0.98, 0.95)),                         # tall box: frosted glass
+        dict(type="roughdielectric", alpha=0.08, eta=1.33, reflectance=(0.9, 0.9, 1), specular=(1, 1, 1), distribution="beckmann")]   # short box
+    tm = scene.tri_material.copy()
+    tm[12:24] = base + 1
+    tm[24:36] = base + 0
+    scene.tri_material = tm
+    props = dict(CBOX_PROPS, budget=60, seed=33)
+    props.update(maxDepth=12, rrDepth=5)
+    props.update(extra)
+    g, o = hip(**props), make_oracle(oracle_lib, threads=os.cpu_count() or 8, **props)
+    gg, go = ppg_host.GuidedPathTracer(engine=g), ppg_host.GuidedPathTracer(engine=o)
+    ig, io = gg.render(scene), go.render(scene)
+    assert _stats(gg) == _stats(go)
+    assert np.array_equal(ig, io, equal_nan=True)
+    assert_tree_equal(g.read_sdtree(), o.read_sdtree())
+    glass = ppg_host.cbox_scene(64, 64)
+    glass.materials = list(glass.materials) + [dict(type="dielectric", eta=1.5, reflectance=(1, 1, 1), specular=(0.95, 0.98, 0.95))]
+    tmg = glass.tri_material.copy(); tmg[24:36] = base; glass.tri_material = tmg
+    assert np.nanmean(np.abs(ig - ppg_host.GuidedPathTracer(engine=hip(**props)).render(glass))) > 5e-3
+
+
 def _pane_scene(res):
     """CBOX + two thin-dielectric panes: a horizontal one between the (upward-facing) luminaire and the ceiling and a vertical
     "window" across the room — most paths cross a null component, emitters are found through one or two panes."""

@@ -257,7 +257,9 @@ def test_glossy_plugins_parse_like_their_constructors(tmp_path):
                         ('<bsdf type="roughconductor"><string name="material" value="none"/><string name="distribution" value="ggx"/>'
                          '<float name="alphaU" value="0.1"/><float name="alphaV" value="0.3"/></bsdf>', "anisotropic"),
                         ('<bsdf type="dielectric"><string name="intIOR" value="unobtainium"/></bsdf>', "unobtainium"),
-                        ('<bsdf type="twosided"><bsdf type="dielectric"/></bsdf>', "two-sided")):
+                        ('<bsdf type="twosided"><bsdf type="dielectric"/></bsdf>', "two-sided"),
+                        ('<bsdf type="twosided"><bsdf type="roughdielectric"/></bsdf>', "two-sided"),
+                        ('<bsdf type="roughdielectric"><float name="intIOR" value="1.0"/><float name="extIOR" value="1.0"/></bsdf>', "differ")):
         with pytest.raises(mitsuba_xml.SceneError, match=needle):
             ppg_host.load_scene(_write(tmp_path, '<shape type="rectangle">%s</shape>' % bad), defines=dict(nee="never"))
 
@@ -274,8 +276,10 @@ def test_full_material_set_survives_the_xml_round_trip(tmp_path):
         dict(type="thindielectric", eta=1.33, reflectance=(1, 1, 1), specular=(0.9, 0.9, 1.0)),
         dict(type="diffuse", reflectance=(0.2, 0.3, 0.4), twosided=True, opacity=(0.5, 0.6, 0.7)),
         dict(type="plastic", reflectance=(0.2, 0.3, 0.4), eta=1.4, opacity=(0.25, 0.25, 0.25)),
-        dict(type="roughconductor", alpha=0.3, eta=(0.2, 0.9, 1.1), k=(3.9, 2.4, 2.1), reflectance=(1, 1, 1), distribution="beckmann")]
-    tm = scene.tri_material.copy(); tm[2:22:2] = np.arange(5, 15); scene.tri_material = tm
+        dict(type="roughconductor", alpha=0.3, eta=(0.2, 0.9, 1.1), k=(3.9, 2.4, 2.1), reflectance=(1, 1, 1), distribution="beckmann"),
+        dict(type="roughdielectric", alpha=0.25, eta=1.5, reflectance=(1, 1, 1), specular=(0.9, 0.95, 1.0)),
+        dict(type="roughdielectric", alpha=0.1, eta=1.33, reflectance=(0.9, 0.9, 0.9), specular=(1, 1, 1), distribution="beckmann", opacity=(0.5, 0.5, 0.5))]
+    tm = scene.tri_material.copy(); tm[2:26:2] = np.arange(5, 17); scene.tri_material = tm
     back, _, info = ppg_host.load_scene(ppg_host.save_scene_xml(scene, dict(budgetType="spp", budget=8.0), str(tmp_path)))
     assert not info["warnings"]
     per_tri = lambda s: sorted((tuple(np.sort(t.reshape(-1))), bytes(Material.from_dict(s.materials[m])))  # noqa: E731
