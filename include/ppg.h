@@ -89,9 +89,12 @@ enum {
                                       evalTransmittance (GP:2184-2245, scene.cpp:619-679) */
     ,
     PPG_BSDF_ROUGHDIELECTRIC = 8   /* roughdielectric.cpp:268-606: microfacet reflection + refraction (GGX / Beckmann, visible normals) — a smooth,
-                                      TRANSMISSIVE BSDF: guided on both sides; its sample() draws one extra number from the path's sampler */
+                                      TRANSMISSIVE BSDF: guided on both sides; its sample() draws one extra number from the path's sampler */,
+    PPG_BSDF_ROUGHPLASTIC = 9      /* roughplastic.cpp:330-501: rough dielectric coating (GGX / Beckmann, visible normals) over a diffuse base; the
+                                      energy balance between the two comes from Mitsuba's precomputed rough-transmittance tables
+                                      (data/microfacet/{ggx,beckmann}.dat, rtrans.h), handed over as the per-material slice `ppg_scene.rtrans[material.rtrans]` */
 };
-#define PPG_BSDF_LAST PPG_BSDF_ROUGHDIELECTRIC
+#define PPG_BSDF_LAST PPG_BSDF_ROUGHPLASTIC
 enum {
     PPG_MAT_TWOSIDED = 1,          /* wrap the (one-sided) BRDF in twosided.cpp:100-180, same BRDF on both sides */
     PPG_MAT_NONLINEAR = 2,         /* plastic: nonlinear = true (plastic.cpp:164) */
@@ -112,7 +115,7 @@ typedef struct ppg_material {
                              plastic / (rough / thin) dielectric: eta[0] = intIOR / extIOR */
     float k[3];           /* conductors: k per channel */
     int32_t flags;        /* PPG_MAT_* */
-    int32_t _reserved;
+    int32_t rtrans;       /* roughplastic: index of this material's slice in ppg_scene.rtrans; otherwise 0 */
     float opacity[3];     /* PPG_MAT_MASK: opacity (mask.cpp, default 0.5) */
     float _pad;
 } ppg_material;           /* 80 bytes */
@@ -146,6 +149,15 @@ typedef struct ppg_scene {
     ppg_camera camera;
     const float *environment;     /* NULL, or float[3]: radiance of a constant environment emitter (emitters/constant.cpp) — what rays
                                      that leave the scene see (GP:1902-1914, 2236-2243) and one more emitter for luminaire sampling */
+    /* Rough-transmittance slices for PPG_BSDF_ROUGHPLASTIC (0 / 0 / NULL without such materials).  One slice per (distribution, alpha,
+       eta) = what RoughPlastic::configure() (roughplastic.cpp:285-305) leaves in its two RoughTransmittance objects:
+         [0 .. rtrans_samples)  m_externalRoughTransmittance after setEta(eta), setAlpha(alpha) (rtrans.h:299-400): transmittance over
+                                the warped incident cosine |cos|^(1/4) in [0, 1], read by eval() through evalCubicInterp1D;
+         [rtrans_samples]       m_internalRoughTransmittance->evalDiffuse(alpha) after setEta(1/eta) (the diffuse transmittance from
+                                inside: 1 - Fdr, roughplastic.cpp:372). */
+    uint32_t n_rtrans;
+    uint32_t rtrans_samples;      /* thetaSamples of the data file (100 in Mitsuba's tables), >= 2 */
+    const float *rtrans;          /* [n_rtrans * (rtrans_samples + 1)] */
 } ppg_scene;
 
 /* ------------------------------------------------------------------------------------------------

@@ -806,6 +806,8 @@ struct BRec {
 // A BSDF instance: the ABI record plus what the plugin's configure() precomputes
 struct Material : ppg_material {
     Float fdrInt = 0, specularSamplingWeight = 0, invEta2 = 0;  // plastic.cpp:191-204
+    const Float *rt = nullptr;  // roughplastic: this material's rough-transmittance slice (ppg_scene.rtrans), rtN samples + 1
+    uint32_t rtN = 0;
     Spectrum R() const { return Spectrum(reflectance[0], reflectance[1], reflectance[2]); }
     Spectrum S() const { return Spectrum(specular[0], specular[1], specular[2]); }
     Spectrum Eta() const { return Spectrum(eta[0], eta[1], eta[2]); }
@@ -815,7 +817,13 @@ struct Material : ppg_material {
     void configure() {
         if (type == PPG_BSDF_TWOSIDED_DIFFUSE) { type = PPG_BSDF_DIFFUSE; flags |= PPG_MAT_TWOSIDED; }
         if (type == PPG_BSDF_MIRROR) { for (int i = 0; i < 3; ++i) { eta[i] = 0.0f; k[i] = 1.0f; } }  // material "none", conductor.cpp:171-173
-        if (type == PPG_BSDF_ROUGHCONDUCTOR || type == PPG_BSDF_ROUGHDIELECTRIC) alpha = ppg_max(alpha, 1e-4f);  // microfacet.h:135
+        if (type == PPG_BSDF_ROUGHCONDUCTOR || type == PPG_BSDF_ROUGHDIELECTRIC || type == PPG_BSDF_ROUGHPLASTIC) alpha = ppg_max(alpha, 1e-4f);  // microfacet.h:135
+        if (type == PPG_BSDF_ROUGHPLASTIC) {  // roughplastic.cpp:277-283 (Fdr comes from the slice, :372)
+            Float dAvg = luminance(R()), sAvg = luminance(S());
+            specularSamplingWeight = sAvg / (dAvg + sAvg);
+            invEta2 = 1.0f / (eta[0] * eta[0]);
+            fdrInt = rt ? 1 - rt[rtN] : 0.0f;
+        }
         if (type == PPG_BSDF_PLASTIC) {
             fdrInt = ppg_fresnel_diffuse_reflectance(1 / eta[0]);
             Float dAvg = luminance(R()), sAvg = luminance(S());
@@ -898,6 +906,7 @@ struct Scene {
     std::vector<uint32_t> idx, triMat;
     std::vector<int32_t> triEmitter;
     std::vector<Material> materials;
+    std::vector<Float> rtrans;  // ppg_scene.rtrans (roughplastic slices)
     std::vector<ppg_emitter> emitters;
     ppg_camera cam;
     AABB aabb;  // what Scene::getAABB() returns: the kd-tree's enlarged box (gkdtree.h:1213-1220)
@@ -1756,6 +1765,85 @@ struct RoughDielectric {
     }
 };
 
+// evalCubicInterp1D (spline.cpp:23-60) on [min, max] = [0, 1], extrapolate = false
+inline Float evalCubicInterp1D(Float x, const Float *values, size_t size) {
+    if (!(x >= 0.0f && x <= 1.0f)) return 0.0f;
+    Float t = ((x - 0.0f) * (Float)(size - 1)) / (1.0f - 0.0f);
+    size_t k = std::max((size_t)0, std::min((size_t)t, size - 2));
+    Float f0 = values[k], f1 = values[k + 1], d0, d1;
+    if (k > 0) d0 = 0.5f * (values[k + 1] - values[k - 1]);
+    else d0 = values[k + 1] - values[k];
+    if (k + 2 < size) d1 = 0.5f * (values[k + 2] - values[k]);
+    else d1 = values[k + 1] - values[k];
+    t = t - (Float)k;
+    Float t2 = t * t, t3 = t2 * t;
+    return (2 * t3 - 3 * t2 + 1) * f0 + (-2 * t3 + 3 * t2) * f1 + (t3 - 2 * t2 + t) * d0 + (t3 - t2) * d1;
+}
+
+// RoughPlastic roughplastic.cpp:330-501 (constant alpha, sampleVisible = true, both components requested)
+struct RoughPlastic {
+    // m_externalRoughTransmittance->eval(cosTheta, alpha) with eta and alpha fixed (rtrans.h:185-196, 233)
+    static Float T(const Material &m, Float cosTheta) {
+        Float warpedCosTheta = ppg_pow(ppg_abs(cosTheta), 0.25f);
+        if (!(cosTheta >= 0)) return 0.0f;
+        Float result = evalCubicInterp1D(warpedCosTheta, m.rt, m.rtN);
+        return ppg_min(1.0f, ppg_max(0.0f, result));
+    }
+    static Float probSpecular(const Material &m, Float cosThetaI) {  // roughplastic.cpp:406-412
+        Float probSpecular = 1 - T(m, cosThetaI);
+        return (probSpecular * m.specularSamplingWeight) / (probSpecular * m.specularSamplingWeight + (1 - probSpecular) * (1 - m.specularSamplingWeight));
+    }
+    static Spectrum eval(const Material &mt, const BRec &b) {
+        if (b.wi.z <= 0 || b.wo.z <= 0) return Spectrum(0.0f);
+        GGX distr{mt.alpha, (mt.flags & PPG_MAT_BECKMANN) != 0};
+        const Vec H = normalize(b.wo + b.wi);
+        const Float D = distr.eval(H);
+        const Float F = fresnelDielectricExt(dot(b.wi, H), mt.eta[0]);
+        const Float G = distr.G(b.wi, b.wo, H);
+        Float value = F * D * G / (4.0f * b.wi.z);
+        Spectrum result = mt.S() * value;
+        Spectrum diff = mt.R();
+        Float T12 = T(mt, b.wi.z), T21 = T(mt, b.wo.z);
+        Float Fdr = mt.fdrInt;  // 1 - m_internalRoughTransmittance->evalDiffuse(alpha)
+        if (mt.flags & PPG_MAT_NONLINEAR) diff = cdiv(diff, Spectrum(1.0f) - diff * Fdr);
+        else diff = diff / (1 - Fdr);
+        return result + diff * (PPG_INV_PI_F * b.wo.z * T12 * T21 * mt.invEta2);
+    }
+    static Float pdf(const Material &mt, const BRec &b) {
+        if (b.wi.z <= 0 || b.wo.z <= 0) return 0.0f;
+        GGX distr{mt.alpha, (mt.flags & PPG_MAT_BECKMANN) != 0};
+        const Vec H = normalize(b.wo + b.wi);
+        Float pS = probSpecular(mt, b.wi.z), pD = 1 - pS;
+        const Float dwh_dwo = 1.0f / (4.0f * dot(b.wo, H));
+        const Float prob = distr.pdfVisible(b.wi, H);
+        Float result = prob * dwh_dwo * pS;
+        result += pD * squareToCosineHemispherePdf(b.wo);
+        return result;
+    }
+    static Spectrum sample(const Material &mt, BRec &b, Float &pdf_, const Point2 &sample_) {
+        pdf_ = 0;
+        if (b.wi.z <= 0) return Spectrum(0.0f);
+        Point2 sample = sample_;
+        GGX distr{mt.alpha, (mt.flags & PPG_MAT_BECKMANN) != 0};
+        bool choseSpecular = true;
+        Float pS = probSpecular(mt, b.wi.z);
+        if (sample.y < pS) sample.y /= pS;
+        else { sample.y = (sample.y - pS) / (1 - pS); choseSpecular = false; }
+        b.sampledDelta = false;
+        if (choseSpecular) {
+            Vec m = distr.sampleVisible(b.wi, sample);
+            b.wo = RoughConductor::reflect(b.wi, m);
+            if (b.wo.z <= 0) return Spectrum(0.0f);
+        } else {
+            b.wo = squareToCosineHemisphere(sample);
+        }
+        b.eta = 1.0f;
+        pdf_ = pdf(mt, b);
+        if (pdf_ == 0) return Spectrum(0.0f);
+        return eval(mt, b) / pdf_;
+    }
+};
+
 // ThinDielectric thindielectric.cpp:152-252
 struct ThinDielectric {
     static Float R(const Material &m, Float cosThetaI) {  // incl. internal reflections: R' = R + TRT + TR^3T + ..
@@ -1785,7 +1873,8 @@ struct ThinDielectric {
 // BSDF dispatch: getType / eval / pdf / sample (solid-angle measure) of the supported plugins, incl. the TwoSided adapter
 struct BSDF {
     static bool isSmooth(const Material &m) {  // getType() & ESmooth (diffuse or glossy components)
-        return m.type == PPG_BSDF_DIFFUSE || m.type == PPG_BSDF_ROUGHCONDUCTOR || m.type == PPG_BSDF_PLASTIC || m.type == PPG_BSDF_ROUGHDIELECTRIC;
+        return m.type == PPG_BSDF_DIFFUSE || m.type == PPG_BSDF_ROUGHCONDUCTOR || m.type == PPG_BSDF_PLASTIC || m.type == PPG_BSDF_ROUGHDIELECTRIC ||
+               m.type == PPG_BSDF_ROUGHPLASTIC;
     }
     static bool allDelta(const Material &m) { return !isSmooth(m); }  // (type & EDelta) == (type & EAll)
     // getType() & (ETransmission | EBackSide): twosided sets EBackSide (twosided.cpp:97-101), the dielectric both
@@ -1804,6 +1893,7 @@ struct BSDF {
             case PPG_BSDF_DIFFUSE: return Diffuse::eval(m, b);
             case PPG_BSDF_ROUGHCONDUCTOR: return RoughConductor::eval(m, b);
             case PPG_BSDF_PLASTIC: return Plastic::eval(m, b);
+            case PPG_BSDF_ROUGHPLASTIC: return RoughPlastic::eval(m, b);
             case PPG_BSDF_ROUGHDIELECTRIC: return RoughDielectric::eval(m, b);
             default: return Spectrum(0.0f);  // delta components are zero for the solid-angle measure (conductor.cpp:222-237)
         }
@@ -1813,6 +1903,7 @@ struct BSDF {
             case PPG_BSDF_DIFFUSE: return Diffuse::pdf(m, b);
             case PPG_BSDF_ROUGHCONDUCTOR: return RoughConductor::pdf(m, b);
             case PPG_BSDF_PLASTIC: return Plastic::pdf(m, b);
+            case PPG_BSDF_ROUGHPLASTIC: return RoughPlastic::pdf(m, b);
             case PPG_BSDF_ROUGHDIELECTRIC: return RoughDielectric::pdf(m, b);
             default: return 0.0f;
         }
@@ -1824,6 +1915,7 @@ struct BSDF {
             case PPG_BSDF_CONDUCTOR: return Conductor::sample(m, b, pdf, sample);
             case PPG_BSDF_ROUGHCONDUCTOR: return RoughConductor::sample(m, b, pdf, sample);
             case PPG_BSDF_PLASTIC: return Plastic::sample(m, b, pdf, sample);
+            case PPG_BSDF_ROUGHPLASTIC: return RoughPlastic::sample(m, b, pdf, sample);
             case PPG_BSDF_DIELECTRIC: return Dielectric::sample(m, b, pdf, sample);
             case PPG_BSDF_THINDIELECTRIC: return ThinDielectric::sample(m, b, pdf, sample);
             case PPG_BSDF_ROUGHDIELECTRIC: return RoughDielectric::sample(m, b, pdf, sample, sampler);
@@ -2626,10 +2718,20 @@ int ppgo_set_scene(ppgo_ctx *ctx, const ppg_scene *s) {
     sc.hasEnv = s->environment != nullptr;
     if (sc.hasEnv) sc.envRadiance = Spectrum(s->environment[0], s->environment[1], s->environment[2]);
     sc.materials.clear();
+    if (s->n_rtrans) {
+        if (!s->rtrans || s->rtrans_samples < 2) { ctx->gpt.error = "rtrans: need the slices and rtrans_samples >= 2"; return PPG_ERR_INVALID; }
+        sc.rtrans.assign(s->rtrans, s->rtrans + (size_t)s->n_rtrans * (s->rtrans_samples + 1));
+    }
     for (uint32_t i = 0; i < s->n_materials; ++i) {
         Material m;
         static_cast<ppg_material &>(m) = s->materials[i];
         if (m.type < 0 || m.type > PPG_BSDF_LAST) { ctx->gpt.error = "unsupported BSDF type"; return PPG_ERR_INVALID; }
+        if (m.type == PPG_BSDF_ROUGHPLASTIC) {
+            if (m.rtrans < 0 || (uint32_t)m.rtrans >= s->n_rtrans) { ctx->gpt.error = "roughplastic: material.rtrans is not a slice of scene.rtrans"; return PPG_ERR_INVALID; }
+            if (!(m.eta[0] > 0)) { ctx->gpt.error = "plastic / dielectric need eta[0] = intIOR / extIOR > 0"; return PPG_ERR_INVALID; }
+            m.rt = sc.rtrans.data() + (size_t)m.rtrans * (s->rtrans_samples + 1);
+            m.rtN = s->rtrans_samples;
+        }
         if ((m.type == PPG_BSDF_PLASTIC || m.type == PPG_BSDF_DIELECTRIC || m.type == PPG_BSDF_THINDIELECTRIC || m.type == PPG_BSDF_ROUGHDIELECTRIC) && !(m.eta[0] > 0)) { ctx->gpt.error = "plastic / dielectric need eta[0] = intIOR / extIOR > 0"; return PPG_ERR_INVALID; }
         m.configure();
         sc.materials.push_back(m);
@@ -2929,9 +3031,20 @@ int ppgo_dtree_exercise(int32_t acc_mode, int32_t directional_filter, float rho,
 
 // BSDF plug-in interface of the supported materials, element-wise (tests/test_bsdfs.py: the chi-square-style checks the
 // reference applies to its BSDFs, M/src/tests/test_chisquare.cpp).  wi / wo are in the local shading frame.
+static std::vector<float> g_testRtrans;  // the slice ppgo_bsdf_* give a roughplastic material (tests only)
+int ppgo_bsdf_set_rtrans(const float *slice, uint32_t samples) {
+    g_testRtrans.assign(slice, slice + samples + 1);
+    return PPG_OK;
+}
+static bool testSlice(Material &m) {
+    if (m.type != PPG_BSDF_ROUGHPLASTIC) return true;
+    if (g_testRtrans.size() < 3) return false;
+    m.rt = g_testRtrans.data(); m.rtN = (uint32_t)g_testRtrans.size() - 1;
+    return true;
+}
 int ppgo_bsdf_eval(const ppg_material *mat, uint32_t n, const float *wi, const float *wo, float *f_out, float *pdf_out) {
     Material m; static_cast<ppg_material &>(m) = *mat;
-    if (m.type < 0 || m.type > PPG_BSDF_LAST) return PPG_ERR_INVALID;
+    if (m.type < 0 || m.type > PPG_BSDF_LAST || !testSlice(m)) return PPG_ERR_INVALID;
     m.configure();
     for (uint32_t i = 0; i < n; ++i) {
         BRec b; b.wi = Vec(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]); b.wo = Vec(wo[3 * i], wo[3 * i + 1], wo[3 * i + 2]);
@@ -2944,7 +3057,7 @@ int ppgo_bsdf_eval(const ppg_material *mat, uint32_t n, const float *wi, const f
 int ppgo_bsdf_sample(const ppg_material *mat, uint32_t n, const float *wi, const float *sample_xy, float *wo_out, float *weight_out,
                      float *pdf_out, float *eta_out, int32_t *delta_out) {
     Material m; static_cast<ppg_material &>(m) = *mat;
-    if (m.type < 0 || m.type > PPG_BSDF_LAST) return PPG_ERR_INVALID;
+    if (m.type < 0 || m.type > PPG_BSDF_LAST || !testSlice(m)) return PPG_ERR_INVALID;
     m.configure();
     for (uint32_t i = 0; i < n; ++i) {
         BRec b; b.wi = Vec(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]);
@@ -2959,6 +3072,7 @@ int ppgo_bsdf_sample(const ppg_material *mat, uint32_t n, const float *wi, const
 }
 int ppgo_bsdf_flags(const ppg_material *mat, int32_t *is_smooth, int32_t *all_delta, int32_t *backside_or_transmission) {
     Material m; static_cast<ppg_material &>(m) = *mat;
+    testSlice(m);
     m.configure();
     *is_smooth = BSDF::isSmooth(m); *all_delta = BSDF::allDelta(m); *backside_or_transmission = BSDF::hasBackSideOrTransmission(m);
     return PPG_OK;

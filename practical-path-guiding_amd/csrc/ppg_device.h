@@ -98,6 +98,8 @@ struct DevScene {
     const float *em_area_cdf;  // per emitter: count + 1 entries (TriMesh::prepareSamplingTable)
     const float4 *em_tris;     // 3 per emitter triangle: positions
     const float4 *em_normals;  // 3 per emitter triangle or nullptr
+    const float *rtrans;       // roughplastic: rough-transmittance slices, rtrans_n + 1 floats each (ppg_scene.rtrans)
+    int rtrans_n;
 };
 
 struct Hit {
@@ -586,8 +588,10 @@ struct Mat {
     int type, flags;          // type normalised: TWOSIDED_DIFFUSE → DIFFUSE + PPG_MAT_TWOSIDED
     F3 refl, spec, eta, k, opacity;
     float alpha, fdr_int;
+    const float *rt;          // roughplastic: its rough-transmittance slice, rt_n samples
+    int rt_n;
 };
-#define PPG_MAT_STRIDE 5  // float4 per material: (reflectance, type) (specular, alpha) (eta, flags) (k, fdrInt) (opacity, -)
+#define PPG_MAT_STRIDE 5  // float4 per material: (reflectance, type) (specular, alpha) (eta, flags) (k, fdrInt) (opacity, rtrans slice)
 D Mat load_material(const DevScene &S, int id) {
     const float4 *m = S.materials + PPG_MAT_STRIDE * (size_t)id;
     const float4 a = m[0], b = m[1], c = m[2], d = m[3];
@@ -598,10 +602,13 @@ D Mat load_material(const DevScene &S, int id) {
     M.refl = f3(a.x, a.y, a.z); M.spec = f3(b.x, b.y, b.z); M.eta = f3(c.x, c.y, c.z); M.k = f3(d.x, d.y, d.z);
     M.alpha = b.w; M.fdr_int = d.w;
     M.opacity = f3(e.x, e.y, e.z);
+    M.rt_n = S.rtrans_n;
+    M.rt = S.rtrans + (size_t)__float_as_int(e.w) * (size_t)(S.rtrans_n + 1);
     return M;
 }
 D bool mat_is_smooth(const Mat &M) {
-    return M.type == PPG_BSDF_DIFFUSE || M.type == PPG_BSDF_ROUGHCONDUCTOR || M.type == PPG_BSDF_PLASTIC || M.type == PPG_BSDF_ROUGHDIELECTRIC;
+    return M.type == PPG_BSDF_DIFFUSE || M.type == PPG_BSDF_ROUGHCONDUCTOR || M.type == PPG_BSDF_PLASTIC || M.type == PPG_BSDF_ROUGHDIELECTRIC ||
+           M.type == PPG_BSDF_ROUGHPLASTIC;
 }
 D bool mat_two_sided(const Mat &M) {
     return (M.flags & PPG_MAT_TWOSIDED) && M.type != PPG_BSDF_DIELECTRIC && M.type != PPG_BSDF_THINDIELECTRIC && M.type != PPG_BSDF_ROUGHDIELECTRIC;
@@ -811,6 +818,36 @@ D F3 plastic_diff_term(const Mat &M) {
     return div3(M.refl, 1 - M.fdr_int);
 }
 
+// evalCubicInterp1D (spline.cpp:23-60) on [0, 1], no extrapolation
+D float cubic_interp_1d(float x, const float *values, int size) {
+    if (!(x >= 0.0f && x <= 1.0f)) return 0.0f;
+    float t = ((x - 0.0f) * (float)(size - 1)) / (1.0f - 0.0f);
+    int k = (int)t;
+    k = k < size - 2 ? k : size - 2;
+    k = k > 0 ? k : 0;
+    const float f0 = values[k], f1 = values[k + 1];
+    float d0, d1;
+    if (k > 0) d0 = 0.5f * (values[k + 1] - values[k - 1]);
+    else d0 = values[k + 1] - values[k];
+    if (k + 2 < size) d1 = 0.5f * (values[k + 2] - values[k]);
+    else d1 = values[k + 1] - values[k];
+    t = t - (float)k;
+    const float t2 = t * t, t3 = t2 * t;
+    return (2 * t3 - 3 * t2 + 1) * f0 + (-2 * t3 + 3 * t2) * f1 + (t3 - 2 * t2 + t) * d0 + (t3 - t2) * d1;
+}
+// roughplastic: m_externalRoughTransmittance->eval(cosTheta, alpha), eta and alpha fixed (rtrans.h:185-196, 233)
+D float rough_T(const Mat &M, float cosTheta) {
+    const float warped = ppg_pow(ppg_abs(cosTheta), 0.25f);
+    if (!(cosTheta >= 0)) return 0.0f;
+    return ppg_min(1.0f, ppg_max(0.0f, cubic_interp_1d(warped, M.rt, M.rt_n)));
+}
+D float roughplastic_prob_specular(const Mat &M, float cosThetaI) {  // roughplastic.cpp:406-412
+    const float dAvg = lum3(M.refl), sAvg = lum3(M.spec);
+    const float w = sAvg / (dAvg + sAvg);
+    const float pS = 1 - rough_T(M, cosThetaI);
+    return (pS * w) / (pS * w + (1 - pS) * (1 - w));
+}
+
 // thindielectric.cpp:160-164: slab reflectance incl. internal reflections R' = R + TRT + TR^3T + ..
 D float thin_R(const Mat &M, float cosThetaI) {
     float Rr = fresnel_dielectric_ext(ppg_abs(cosThetaI), M.eta.x), Tt = 1 - Rr;
@@ -863,6 +900,19 @@ D F3 mat_eval_one(const Mat &M, F3 wi, F3 wo) {
         float factor = wi.z > 0 ? m_invEta : m_eta;
         return M.spec * ppg_abs(value * factor * factor);
     }
+    if (M.type == PPG_BSDF_ROUGHPLASTIC) {  // roughplastic.cpp:330-384
+        if (wi.z <= 0 || wo.z <= 0) return f3s(0.0f);
+        const Mfd distr{M.alpha, (M.flags & PPG_MAT_BECKMANN) != 0};
+        const F3 H = norm3(wo + wi);
+        const float Dm = ggx_eval(distr, H);
+        const float F = fresnel_dielectric_ext(dot3(wi, H), M.eta.x);
+        const float G = ggx_smith_g1(distr, wi, H) * ggx_smith_g1(distr, wo, H);
+        const float value = F * Dm * G / (4.0f * wi.z);
+        const F3 result = M.spec * value;
+        const float T12 = rough_T(M, wi.z), T21 = rough_T(M, wo.z);
+        const float invEta2 = 1.0f / (M.eta.x * M.eta.x);
+        return result + plastic_diff_term(M) * (PPG_INV_PI_F * wo.z * T12 * T21 * invEta2);
+    }
     if (M.type == PPG_BSDF_PLASTIC) {  // plastic.cpp:247-281, diffuse component
         if (wo.z <= 0 || wi.z <= 0) return f3s(0.0f);
         float Fi = fresnel_dielectric_ext(wi.z, M.eta.x);
@@ -901,6 +951,17 @@ D float mat_pdf_one(const Mat &M, F3 wi, F3 wo) {
         prob *= reflect ? F : (1 - F);
         return ppg_abs(prob * dwh_dwo);
     }
+    if (M.type == PPG_BSDF_ROUGHPLASTIC) {  // roughplastic.cpp:386-437
+        if (wi.z <= 0 || wo.z <= 0) return 0.0f;
+        const Mfd distr{M.alpha, (M.flags & PPG_MAT_BECKMANN) != 0};
+        const F3 H = norm3(wo + wi);
+        const float pS = roughplastic_prob_specular(M, wi.z), pD = 1 - pS;
+        const float dwh_dwo = 1.0f / (4.0f * dot3(wo, H));
+        const float prob = ggx_pdf_visible(distr, wi, H);
+        float result = prob * dwh_dwo * pS;
+        result += pD * (PPG_INV_PI_F * wo.z);
+        return result;
+    }
     if (M.type == PPG_BSDF_PLASTIC) {  // plastic.cpp:283-311
         if (wo.z <= 0 || wi.z <= 0) return 0.0f;
         float Fi = fresnel_dielectric_ext(wi.z, M.eta.x);
@@ -936,6 +997,23 @@ D F3 mat_sample_one(const Mat &M, F3 wi, float sx, float sy, F3 &wo, float &pdf,
             float weight = ggx_smith_g1(distr, wo, m);
             pdf /= 4.0f * dot3(wo, m);
             return F * weight;
+        }
+        case PPG_BSDF_ROUGHPLASTIC: {  // roughplastic.cpp:439-501
+            if (wi.z <= 0) return f3s(0.0f);
+            const Mfd distr{M.alpha, (M.flags & PPG_MAT_BECKMANN) != 0};
+            const float pS = roughplastic_prob_specular(M, wi.z);
+            if (sy < pS) {
+                sy /= pS;
+                const F3 m = ggx_sample_visible(distr, wi, sx, sy);
+                wo = m * (2 * dot3(wi, m)) - wi;
+                if (wo.z <= 0) return f3s(0.0f);
+            } else {
+                sy = (sy - pS) / (1 - pS);
+                wo = cosine_hemisphere(sx, sy);
+            }
+            pdf = mat_pdf_one(M, wi, wo);
+            if (pdf == 0) return f3s(0.0f);
+            return div3(mat_eval_one(M, wi, wo), pdf);
         }
         case PPG_BSDF_PLASTIC: {  // plastic.cpp:368-425
             if (wi.z <= 0) return f3s(0.0f);

@@ -257,6 +257,7 @@ struct ppg_ctx {
     bool haveScene = false;
     bool fullMaterials = false;
     DevBuf<float4> d_tris, d_accel, d_accelSmall, d_normals, d_materials, d_emitters, d_emTris, d_emNrm;
+    DevBuf<float> d_rtrans;  // ppg_scene.rtrans (roughplastic slices)
     DevBuf<float> d_emSel, d_emArea, d_neeCos;
     DevBuf<int4> d_emInfo;
     DevBuf<BvhNode> d_bvh;
@@ -1163,7 +1164,7 @@ int ppg_set_scene(ppg_ctx *ctx, const ppg_scene *s) {
             if (s->normals) { const float *n = s->normals + 3 * s->indices[3 * t + v]; nrm[3 * k + v] = make_float4(n[0], n[1], n[2], 0); }
         }
     }
-    // material table: 4 x float4 per BSDF = (reflectance, type) (specular, alpha) (eta, flags) (k, fdrInt); the lean kernels read
+    // material table: 4 x float4 per BSDF = (reflectance, type) (specular, alpha) (eta, flags) (k, fdrInt) (opacity, rtrans slice); the lean kernels read
     // only the first.  configure()-time normalisation as in the plugins: "none" conductor = (eta 0, k 1) (conductor.cpp:171-173),
     // GGX alpha clamped (microfacet.h:135), plastic's internal diffuse Fresnel reflectance (plastic.cpp:191-193)
     std::vector<float4> mats(PPG_MAT_STRIDE * (size_t)s->n_materials), ems(std::max<uint32_t>(1, s->n_emitters));
@@ -1174,16 +1175,21 @@ int ppg_set_scene(ppg_ctx *ctx, const ppg_scene *s) {
         if (m.type == PPG_BSDF_DIFFUSE && m.flags == PPG_MAT_TWOSIDED) { m.type = PPG_BSDF_TWOSIDED_DIFFUSE; m.flags = 0; }
         if (m.type == PPG_BSDF_TWOSIDED_DIFFUSE) m.flags &= ~PPG_MAT_TWOSIDED;
         if (m.type == PPG_BSDF_MIRROR) for (int c = 0; c < 3; ++c) { m.eta[c] = 0.0f; m.k[c] = 1.0f; }
-        if (m.type == PPG_BSDF_ROUGHCONDUCTOR || m.type == PPG_BSDF_ROUGHDIELECTRIC) m.alpha = ppg_max(m.alpha, 1e-4f);
+        if (m.type == PPG_BSDF_ROUGHCONDUCTOR || m.type == PPG_BSDF_ROUGHDIELECTRIC || m.type == PPG_BSDF_ROUGHPLASTIC) m.alpha = ppg_max(m.alpha, 1e-4f);
         if ((m.type == PPG_BSDF_PLASTIC || m.type == PPG_BSDF_DIELECTRIC || m.type == PPG_BSDF_THINDIELECTRIC || m.type == PPG_BSDF_ROUGHDIELECTRIC) && !(m.eta[0] > 0)) { ctx->error = "plastic / dielectric need eta[0] = intIOR / extIOR > 0"; return PPG_ERR_INVALID; }
-        const float fdrInt = m.type == PPG_BSDF_PLASTIC ? ppg_fresnel_diffuse_reflectance(1 / m.eta[0]) : 0.0f;
+        float fdrInt = m.type == PPG_BSDF_PLASTIC ? ppg_fresnel_diffuse_reflectance(1 / m.eta[0]) : 0.0f;
+        if (m.type == PPG_BSDF_ROUGHPLASTIC) {  // Fdr = 1 - internal diffuse transmittance, the last entry of the slice (roughplastic.cpp:372)
+            if (m.rtrans < 0 || (uint32_t)m.rtrans >= s->n_rtrans || !s->rtrans || s->rtrans_samples < 2) { ctx->error = "roughplastic: material.rtrans is not a slice of scene.rtrans"; return PPG_ERR_INVALID; }
+            if (!(m.eta[0] > 0)) { ctx->error = "plastic / dielectric need eta[0] = intIOR / extIOR > 0"; return PPG_ERR_INVALID; }
+            fdrInt = 1 - s->rtrans[(size_t)m.rtrans * (s->rtrans_samples + 1) + s->rtrans_samples];
+        } else m.rtrans = 0;
         if (m.type > PPG_BSDF_MIRROR || m.flags != 0) ctx->fullMaterials = true;
         if (m.type == PPG_BSDF_THINDIELECTRIC || (m.flags & PPG_MAT_MASK)) hasNull = true;
         mats[PPG_MAT_STRIDE * i + 0] = make_float4(m.reflectance[0], m.reflectance[1], m.reflectance[2], (float)m.type);
         mats[PPG_MAT_STRIDE * i + 1] = make_float4(m.specular[0], m.specular[1], m.specular[2], m.alpha);
         mats[PPG_MAT_STRIDE * i + 2] = make_float4(m.eta[0], m.eta[1], m.eta[2], __builtin_bit_cast(float, m.flags));
         mats[PPG_MAT_STRIDE * i + 3] = make_float4(m.k[0], m.k[1], m.k[2], fdrInt);
-        mats[PPG_MAT_STRIDE * i + 4] = make_float4(m.opacity[0], m.opacity[1], m.opacity[2], 0.0f);
+        mats[PPG_MAT_STRIDE * i + 4] = make_float4(m.opacity[0], m.opacity[1], m.opacity[2], __builtin_bit_cast(float, m.rtrans));
     }
     for (uint32_t i = 0; i < s->n_emitters; ++i) ems[i] = make_float4(s->emitters[i].radiance[0], s->emitters[i].radiance[1], s->emitters[i].radiance[2], 0);
     HIP_CHECK(ctx->d_tris.reserve(tris.size()));
@@ -1214,6 +1220,11 @@ int ppg_set_scene(ppg_ctx *ctx, const ppg_scene *s) {
     HIP_CHECK(hipMemcpy(ctx->d_bvh.p, bb.nodes.data(), bb.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice));
     HIP_CHECK(ctx->d_bvh4.reserve(bb.nodes4.size()));
     HIP_CHECK(hipMemcpy(ctx->d_bvh4.p, bb.nodes4.data(), bb.nodes4.size() * sizeof(Bvh4Node), hipMemcpyHostToDevice));
+    if (s->n_rtrans && s->rtrans) {
+        const size_t n = (size_t)s->n_rtrans * (s->rtrans_samples + 1);
+        HIP_CHECK(ctx->d_rtrans.reserve(n));
+        HIP_CHECK(hipMemcpy(ctx->d_rtrans.p, s->rtrans, n * sizeof(float), hipMemcpyHostToDevice));
+    }
     HIP_CHECK(ctx->d_materials.reserve(mats.size()));
     HIP_CHECK(hipMemcpy(ctx->d_materials.p, mats.data(), mats.size() * sizeof(float4), hipMemcpyHostToDevice));
     HIP_CHECK(ctx->d_emitters.reserve(ems.size()));
@@ -1286,6 +1297,7 @@ int ppg_set_scene(ppg_ctx *ctx, const ppg_scene *s) {
     DevScene &S = ctx->scene;
     S.tris = ctx->d_tris.p; S.accel = ctx->d_accel.p; S.normals = s->normals ? ctx->d_normals.p : nullptr; S.bvh = ctx->d_bvh.p; S.bvh4 = ctx->d_bvh4.p;
     S.materials = ctx->d_materials.p; S.emitters = ctx->d_emitters.p; S.n_tris = (int)s->n_triangles; S.has_null = hasNull ? 1 : 0;
+    S.rtrans = s->n_rtrans ? ctx->d_rtrans.p : nullptr; S.rtrans_n = (int)s->rtrans_samples;
     memcpy(S.cam.s2c, s->camera.sample_to_camera, 64); memcpy(S.cam.c2w, s->camera.camera_to_world, 64);
     S.cam.near_clip = s->camera.near_clip; S.cam.far_clip = s->camera.far_clip;
     S.cam.width = s->camera.width; S.cam.height = s->camera.height;

@@ -39,6 +39,8 @@ struct SceneData {
     ppg_camera camera{};
     bool hasEnvironment = false;  // constant environment emitter
     float environment[3] = {0, 0, 0};
+    std::vector<float> rtrans;    // rough-transmittance slices of the roughplastic materials, rtransSamples + 1 floats each
+    uint32_t rtransSamples = 0;
 
     ppg_scene view() const {
         ppg_scene s{};
@@ -50,6 +52,7 @@ struct SceneData {
         s.n_emitters = (uint32_t)emitters.size(); s.emitters = emitters.data();
         s.camera = camera;
         s.environment = hasEnvironment ? environment : nullptr;
+        if (rtransSamples && !rtrans.empty()) { s.n_rtrans = (uint32_t)(rtrans.size() / (rtransSamples + 1)); s.rtrans_samples = rtransSamples; s.rtrans = rtrans.data(); }
         return s;
     }
 };

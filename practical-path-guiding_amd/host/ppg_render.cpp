@@ -37,8 +37,15 @@ static bool loadScene(const char *path, SceneData &s) {
     s.materials.resize(nm); f.read((char *)s.materials.data(), (size_t)nm * sizeof(ppg_material));
     s.emitters.resize(ne); f.read((char *)s.emitters.data(), (size_t)ne * sizeof(ppg_emitter));
     f.read((char *)&s.camera, sizeof(ppg_camera));
-    s.hasEnvironment = hdr[5] != 0;
+    s.hasEnvironment = (hdr[5] & 1) != 0;  // hdr[5]: optional blocks, bit 0 environment, bit 1 rtrans
     if (s.hasEnvironment) f.read((char *)s.environment, 12);
+    if (hdr[5] & 2) {
+        uint32_t rt[2];
+        f.read((char *)rt, 8);
+        if (!f || rt[1] < 2) return false;
+        s.rtransSamples = rt[1];
+        s.rtrans.resize((size_t)rt[0] * (rt[1] + 1)); f.read((char *)s.rtrans.data(), s.rtrans.size() * 4);
+    }
     return (bool)f;
 }
 
@@ -107,7 +114,7 @@ static void writePFM(const char *path, const std::vector<float> &rgb, int w, int
 static bool saveScene(const char *path, const SceneData &s) {
     std::ofstream f(path, std::ios::binary);
     const uint32_t hdr[6] = {(uint32_t)(s.positions.size() / 3), (uint32_t)(s.indices.size() / 3), (uint32_t)s.materials.size(), (uint32_t)s.emitters.size(),
-                             s.normals.empty() ? 0u : 1u, s.hasEnvironment ? 1u : 0u};
+                             s.normals.empty() ? 0u : 1u, (s.hasEnvironment ? 1u : 0u) | (s.rtrans.empty() ? 0u : 2u)};
     f.write("PPGS", 4); f.write((const char *)hdr, sizeof hdr);
     f.write((const char *)s.positions.data(), s.positions.size() * 4);
     if (!s.normals.empty()) f.write((const char *)s.normals.data(), s.normals.size() * 4);
@@ -118,6 +125,10 @@ static bool saveScene(const char *path, const SceneData &s) {
     f.write((const char *)s.emitters.data(), s.emitters.size() * sizeof(ppg_emitter));
     f.write((const char *)&s.camera, sizeof(ppg_camera));
     if (s.hasEnvironment) f.write((const char *)s.environment, 12);
+    if (!s.rtrans.empty()) {
+        const uint32_t rt[2] = {(uint32_t)(s.rtrans.size() / (s.rtransSamples + 1)), s.rtransSamples};
+        f.write((const char *)rt, 8); f.write((const char *)s.rtrans.data(), s.rtrans.size() * 4);
+    }
     return (bool)f;
 }
 
@@ -125,6 +136,7 @@ int main(int argc, char **argv) {
     Properties props;
     std::string out = "out.pfm", scenePath, dumpScene;
     bool quiet = false, lenient = false;
+    std::string dataDir;  // `data` directory of a Mitsuba tree (roughplastic: data/microfacet/*.dat); default $PPG_MITSUBA_DATA
     int cw = 0, ch = 0, sw = 0, sh = 0;
     std::map<std::string, std::string> defines;
     for (int i = 1; i < argc; ++i) {
@@ -138,10 +150,11 @@ int main(int argc, char **argv) {
         } else if (a == "-o" && i + 1 < argc) out = argv[++i];
         else if (a == "--ppgs" && i + 1 < argc) dumpScene = argv[++i];
         else if (a == "--lenient") lenient = true;
+        else if (a == "--data-dir" && i + 1 < argc) dataDir = argv[++i];
         else if (a == "--size" && i + 1 < argc) { if (sscanf(argv[++i], "%dx%d", &sw, &sh) != 2) { std::cerr << "--size WxH\n"; return 2; } }
         else if (a == "-q") quiet = true;
         else if (a == "--cbox" && i + 1 < argc) { if (sscanf(argv[++i], "%dx%d", &cw, &ch) != 2) { std::cerr << "--cbox WxH\n"; return 2; } }
-        else if (a == "-h" || a == "--help") { std::cout << "usage: ppg_render [-D key=value]... [-o out.pfm] [-q] [--size WxH] [--lenient] [--ppgs flat-scene-out] (scene.xml | scene.ppgs | --cbox WxH)\n"; return 0; }
+        else if (a == "-h" || a == "--help") { std::cout << "usage: ppg_render [-D key=value]... [-o out.pfm] [-q] [--size WxH] [--lenient] [--data-dir mitsuba/data] [--ppgs flat-scene-out] (scene.xml | scene.ppgs | --cbox WxH)\n"; return 0; }
         else scenePath = a;
     }
     // scene.ppgs.props (written next to the flat scene by `python -m ppg_host scene.xml --ppgs scene.ppgs`): the XML's
@@ -163,7 +176,7 @@ int main(int argc, char **argv) {
     if (cw > 0) cboxScene(cw, ch, scene);
     else if (isXml) {
         try {
-            LoadedScene ls = SceneXmlLoader(scenePath, defines, !lenient, sw, sh).load();
+            LoadedScene ls = SceneXmlLoader(scenePath, defines, !lenient, sw, sh, dataDir).load();
             for (auto &w : ls.warnings) if (!quiet) std::cerr << "warning: " << w << std::endl;
             scene = std::move(ls.scene);
             for (auto &kv : ls.integrator.values) if (!props.values.count(kv.first)) props.values[kv.first] = kv.second;  // -D on the command line wins

@@ -5,7 +5,7 @@
  *   integrator  guided_path (properties of guided_path.cpp:1014-1085 and integrator.cpp:192-218)
  *   sensor      perspective (fov, fovAxis, nearClip, farClip, toWorld), film hdrfilm (width, height; rfilter box)
  *   shapes      obj (filename, toWorld, faceNormals, flipNormals, flipTexCoords, collapse), rectangle (toWorld, flipNormals)
- *   bsdfs       diffuse, conductor, roughconductor / roughdielectric (ggx / beckmann, isotropic), plastic, dielectric, thindielectric, mask (constant opacity),
+ *   bsdfs       diffuse, conductor, roughconductor / roughdielectric / roughplastic (ggx / beckmann, isotropic; roughplastic reads Mitsuba's data/microfacet tables), plastic, dielectric, thindielectric, mask (constant opacity),
  *               twosided(BRDF) — top level with id, nested, or <ref id>
  *   emitters    area (nested in a shape), constant (environment)
  *   values      <spectrum>, <rgb>, <srgb>; <transform> of translate / rotate / scale / lookAt / matrix; <default> and $name
@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "guided_path_hip.h"
+#include "rough_transmittance.h"
 
 namespace ppg {
 
@@ -378,8 +379,9 @@ struct LoadedScene {
 
 class SceneXmlLoader {
 public:
-    SceneXmlLoader(const std::string &path, const std::map<std::string, std::string> &defines, bool strict = true, int width = 0, int height = 0)
-        : m_path(path), m_params(defines), m_strict(strict), m_w(width), m_h(height) {}
+    SceneXmlLoader(const std::string &path, const std::map<std::string, std::string> &defines, bool strict = true, int width = 0, int height = 0,
+                   const std::string &dataDir = "")
+        : m_path(path), m_params(defines), m_strict(strict), m_w(width), m_h(height), m_dataDir(dataDir) {}
 
     LoadedScene load() {
         std::ifstream f(m_path, std::ios::binary);
@@ -515,6 +517,8 @@ private:
     std::map<std::string, std::string> m_params;
     bool m_strict;
     int m_w, m_h;
+    std::string m_dataDir;  // Mitsuba `data` directory (roughplastic)
+    mutable std::map<std::string, int> m_rtIndex;  // (distribution, alpha, eta) → slice of out.scene.rtrans
     std::map<std::string, uint32_t> m_byId;
     std::vector<std::string> m_matKeys;
 
@@ -639,6 +643,19 @@ private:
         const bool cond = m.type == PPG_BSDF_MIRROR || m.type == PPG_BSDF_CONDUCTOR || m.type == PPG_BSDF_ROUGHCONDUCTOR;
         for (int k = 0; k < 3; ++k) m.eta[k] = cond ? 0.0f : 1.5046f;
     }
+    // MicrofacetDistribution(props), microfacet.h:99-145: distribution name (flag set on m), isotropic alpha
+    std::string microfacet(std::map<std::string, std::string> &p, const std::string &t, ppg_material &m) const {
+        std::string distr = p.count("distribution") ? p["distribution"] : "beckmann";
+        std::transform(distr.begin(), distr.end(), distr.begin(), ::tolower);
+        if (distr != "ggx" && distr != "beckmann") throw std::runtime_error(t + ": distribution '" + distr + "' is not supported (ggx, beckmann)");
+        if (distr == "beckmann") m.flags |= PPG_MAT_BECKMANN;  // Mitsuba's default (microfacet.h:99)
+        if (p.count("alphaU") || p.count("alphaV")) {
+            if (!p.count("alphaU") || !p.count("alphaV") || std::stof(p["alphaU"]) != std::stof(p["alphaV"])) throw std::runtime_error(t + ": anisotropic roughness is not supported");
+            m.alpha = std::stof(p["alphaU"]);
+        } else m.alpha = p.count("alpha") ? std::stof(p["alpha"]) : 0.1f;
+        if (p.count("sampleVisible") && !flag(p, "sampleVisible", true)) throw std::runtime_error(t + ": sampleVisible=false is not supported");
+        return distr;
+    }
     double lookupIOR(const std::map<std::string, std::string> &p, const std::string &name, const std::string &dflt) const {  // ior.h:95-111
         static const std::map<std::string, double> ior = {{"vacuum", 1.0}, {"air", 1.000277}, {"water", 1.3330}, {"polypropylene", 1.49}, {"bk7", 1.5046}, {"diamond", 2.419}};
         std::string v = p.count(name) ? p.at(name) : dflt;
@@ -709,15 +726,28 @@ private:
                 if (intIOR < 0 || extIOR < 0 || intIOR == extIOR) throw std::runtime_error(t + ": the interior and exterior indices of refraction must be positive and differ");
                 m.eta[0] = m.eta[1] = m.eta[2] = (float)(intIOR / extIOR);
             }
-            std::string distr = p.count("distribution") ? p["distribution"] : "beckmann";
-            std::transform(distr.begin(), distr.end(), distr.begin(), ::tolower);
-            if (distr != "ggx" && distr != "beckmann") throw std::runtime_error(t + ": distribution '" + distr + "' is not supported (ggx, beckmann)");
-            if (distr == "beckmann") m.flags |= PPG_MAT_BECKMANN;  // Mitsuba's default (microfacet.h:99)
-            if (p.count("alphaU") || p.count("alphaV")) {
-                if (!p.count("alphaU") || !p.count("alphaV") || std::stof(p["alphaU"]) != std::stof(p["alphaV"])) throw std::runtime_error(t + ": anisotropic roughness is not supported");
-                m.alpha = std::stof(p["alphaU"]);
-            } else m.alpha = p.count("alpha") ? std::stof(p["alpha"]) : 0.1f;
-            if (p.count("sampleVisible") && !flag(p, "sampleVisible", true)) throw std::runtime_error(t + ": sampleVisible=false is not supported");
+            microfacet(p, t, m);
+            return m;
+        } else if (t == "roughplastic") {  // roughplastic.cpp:197-227, 285-305
+            m.type = PPG_BSDF_ROUGHPLASTIC; defaults(m);
+            colour(e, "diffuseReflectance", 0.5f, m.reflectance); colour(e, "specularReflectance", 1.0f, m.specular);
+            const double intIOR = lookupIOR(p, "intIOR", "polypropylene"), extIOR = lookupIOR(p, "extIOR", "air");
+            if (intIOR < 0 || extIOR < 0 || intIOR == extIOR) throw std::runtime_error(t + ": the interior and exterior indices of refraction must be positive and differ");
+            m.eta[0] = m.eta[1] = m.eta[2] = (float)(intIOR / extIOR);
+            if (flag(p, "nonlinear", false)) m.flags |= PPG_MAT_NONLINEAR;
+            const std::string distr = microfacet(p, t, m);
+            char key[96];
+            snprintf(key, sizeof key, "%s/%.9g/%.9g", distr.c_str(), m.alpha, m.eta[0]);
+            auto it = m_rtIndex.find(key);
+            if (it == m_rtIndex.end()) {
+                std::vector<float> slice;
+                try { slice = roughplasticSlice(distr, m.alpha, m.eta[0], m_dataDir); }
+                catch (const std::exception &ex) { throw std::runtime_error(t + ": " + ex.what()); }
+                out.scene.rtransSamples = (uint32_t)slice.size() - 1;
+                it = m_rtIndex.emplace(key, (int)(out.scene.rtrans.size() / slice.size())).first;
+                out.scene.rtrans.insert(out.scene.rtrans.end(), slice.begin(), slice.end());
+            }
+            m.rtrans = it->second;
             return m;
         } else if (t == "plastic" || t == "dielectric" || t == "thindielectric") {
             m.type = t == "plastic" ? PPG_BSDF_PLASTIC : (t == "dielectric" ? PPG_BSDF_DIELECTRIC : PPG_BSDF_THINDIELECTRIC);
@@ -732,7 +762,7 @@ private:
             }
             return m;
         }
-        if (m_strict) throw std::runtime_error("bsdf type '" + t + "' is not supported yet (diffuse, conductor, roughconductor, plastic, dielectric, thindielectric, roughdielectric, mask, twosided; SURVEY.md §8 f1)");
+        if (m_strict) throw std::runtime_error("bsdf type '" + t + "' is not supported yet (diffuse, conductor, roughconductor, plastic, roughplastic, dielectric, thindielectric, roughdielectric, mask, twosided; SURVEY.md §8 f1)");
         out.warnings.push_back("bsdf '" + t + "' replaced by diffuse(0.5)");
         m = ppg_material{}; m.type = PPG_BSDF_DIFFUSE; defaults(m);
         m.reflectance[0] = m.reflectance[1] = m.reflectance[2] = 0.5f;

@@ -62,12 +62,12 @@ class Config(C.Structure):
 
 class Material(C.Structure):
     """ppg_material (include/ppg.h).  Scene descriptions carry materials as dicts: type, reflectance and — by type —
-    specular, alpha, eta (3 values, or one number for plastic / dielectric), k, twosided, nonlinear, opacity (a mask adapter), distribution ("ggx" | "beckmann")."""
+    specular, alpha, eta (3 values, or one number for plastic / dielectric), k, twosided, nonlinear, opacity (a mask adapter), distribution ("ggx" | "beckmann"), rtrans (roughplastic: row of SceneDesc.rtrans)."""
     _fields_ = [("type", C.c_int32), ("reflectance", C.c_float * 3), ("specular", C.c_float * 3), ("alpha", C.c_float),
-                ("eta", C.c_float * 3), ("k", C.c_float * 3), ("flags", C.c_int32), ("_reserved", C.c_int32),
+                ("eta", C.c_float * 3), ("k", C.c_float * 3), ("flags", C.c_int32), ("rtrans", C.c_int32),
                 ("opacity", C.c_float * 3), ("_pad", C.c_float)]
 
-    BSDF = dict(diffuse=0, twosided_diffuse=1, mirror=2, conductor=3, roughconductor=4, plastic=5, dielectric=6, thindielectric=7, roughdielectric=8)
+    BSDF = dict(diffuse=0, twosided_diffuse=1, mirror=2, conductor=3, roughconductor=4, plastic=5, dielectric=6, thindielectric=7, roughdielectric=8, roughplastic=9)
 
     @classmethod
     def from_dict(cls, m):
@@ -78,7 +78,7 @@ class Material(C.Structure):
         o = cls()
         t = m.get("type", 0)
         o.type = cls.BSDF[t] if isinstance(t, str) else int(t)
-        o.reflectance[:] = three(m.get("reflectance"), 0.5 if o.type in (0, 1, 5) else 1.0)
+        o.reflectance[:] = three(m.get("reflectance"), 0.5 if o.type in (0, 1, 5, 9) else 1.0)
         o.specular[:] = three(m.get("specular"), 1.0)
         o.alpha = float(m.get("alpha", 0.1))
         o.eta[:] = three(m.get("eta"), 0.0 if o.type in (2, 3, 4) else 1.5046)  # dielectric / plastic default: bk7 / polypropylene-ish
@@ -86,6 +86,7 @@ class Material(C.Structure):
         o.flags = ((1 if m.get("twosided") else 0) | (2 if m.get("nonlinear") else 0) | (4 if m.get("opacity") is not None else 0)
                    | (8 if m.get("distribution", "ggx") == "beckmann" else 0))
         o.opacity[:] = three(m.get("opacity"), 0.0)
+        o.rtrans = int(m.get("rtrans", 0))
         return o
 
 
@@ -102,7 +103,8 @@ class Scene(C.Structure):
     _fields_ = [("n_vertices", C.c_uint32), ("positions", C.POINTER(C.c_float)), ("normals", C.POINTER(C.c_float)),
                 ("n_triangles", C.c_uint32), ("indices", C.POINTER(C.c_uint32)), ("tri_material", C.POINTER(C.c_uint32)),
                 ("tri_emitter", C.POINTER(C.c_int32)), ("n_materials", C.c_uint32), ("materials", C.POINTER(Material)),
-                ("n_emitters", C.c_uint32), ("emitters", C.POINTER(Emitter)), ("camera", Camera), ("environment", C.POINTER(C.c_float))]
+                ("n_emitters", C.c_uint32), ("emitters", C.POINTER(Emitter)), ("camera", Camera), ("environment", C.POINTER(C.c_float)),
+                ("n_rtrans", C.c_uint32), ("rtrans_samples", C.c_uint32), ("rtrans", C.POINTER(C.c_float))]
 
 
 class _StatsMixin:
@@ -217,12 +219,16 @@ class Engine:
         if env is not None:
             env_arr = (C.c_float * 3)(*[float(v) for v in env])
             s.environment = C.cast(env_arr, C.POINTER(C.c_float))
+        rt = getattr(desc, "rtrans", None)
+        if rt is not None and len(rt):
+            rt = np.ascontiguousarray(rt, np.float32)
+            s.n_rtrans, s.rtrans_samples, s.rtrans = rt.shape[0], rt.shape[1] - 1, _fp(rt)
         cam = desc.camera
         s.camera.sample_to_camera[:] = [float(v) for v in np.asarray(cam["sample_to_camera"], np.float32).reshape(-1)]
         s.camera.camera_to_world[:] = [float(v) for v in np.asarray(cam["camera_to_world"], np.float32).reshape(-1)]
         s.camera.near_clip, s.camera.far_clip = cam["near_clip"], cam["far_clip"]
         s.camera.width, s.camera.height = cam["width"], cam["height"]
-        self._scene_keep = (pos, idx, tm, te, nrm, mats, ems)
+        self._scene_keep = (pos, idx, tm, te, nrm, mats, ems, rt)
         self._call("set_scene", C.byref(s))
         self.width, self.height = cam["width"], cam["height"]
 

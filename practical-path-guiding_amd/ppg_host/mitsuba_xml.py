@@ -5,7 +5,8 @@
               nested sampler (independent; sampleCount / seed do not steer guided_path, GP:1342-1374) and
               film hdrfilm (width, height; rfilter box)
   shapes      obj (filename, toWorld, faceNormals, flipNormals, flipTexCoords, collapse), rectangle (toWorld, flipNormals)
-  bsdfs       diffuse, conductor (material none, or explicit eta / k), roughconductor / roughdielectric (ggx / beckmann, isotropic), plastic, dielectric, thindielectric,
+  bsdfs       diffuse, conductor (material none, or explicit eta / k), roughconductor / roughdielectric / roughplastic (ggx / beckmann, isotropic; roughplastic reads Mitsuba's data/microfacet tables),
+              plastic, dielectric, thindielectric,
               mask (constant opacity), twosided(any of the BRDFs) — top level with id, nested, or <ref id>
   emitters    area (nested in a shape), constant (environment)
   values      <spectrum>, <rgb>, <srgb> (spectrum.py), <transform> of translate / rotate / scale / lookAt / matrix,
@@ -296,10 +297,11 @@ def _props(elem, sub):
     return out
 
 
-def load_scene(path, defines=None, strict=True, width=None, height=None):
+def load_scene(path, defines=None, strict=True, width=None, height=None, data_dir=None):
     """Parse `path` → (SceneDesc, integrator properties for ppg_create, info dict).
 
-    defines: {"name": "value"} like `mitsuba -D name=value`; width/height override the film size."""
+    defines: {"name": "value"} like `mitsuba -D name=value`; width/height override the film size; data_dir: the `data` directory of
+    a Mitsuba tree (default $PPG_MITSUBA_DATA) — only `roughplastic` needs it, for data/microfacet/*.dat."""
     root = ET.parse(path).getroot()
     if root.tag != "scene":
         raise SceneError("%s: root element is <%s>, expected <scene>" % (path, root.tag))
@@ -403,6 +405,8 @@ def load_scene(path, defines=None, strict=True, width=None, height=None):
             eta, k = colour(elem, "eta", 0.0), colour(elem, "k", 1.0)
         return tuple(float(v) for v in (eta / f32(ext))), tuple(float(v) for v in (k / f32(ext)))  # roughconductor.cpp:185-186
 
+    rt_slices, rt_index = [], {}
+
     def make_bsdf(elem, allow_twosided=True):
         t = elem.get("type")
         p = _props(elem, sub)
@@ -450,6 +454,25 @@ def load_scene(path, defines=None, strict=True, width=None, height=None):
         elif t == "thindielectric":
             eta = lookup_ior(p, "intIOR", "bk7") / lookup_ior(p, "extIOR", "air")
             return dict(type=7, reflectance=rgb("specularReflectance", 1.0), specular=rgb("specularTransmittance", 1.0), eta=float(f32(eta)))
+        elif t == "roughplastic":  # roughplastic.cpp:197-227, 285-305
+            from . import rtrans as _rt
+            int_ior, ext_ior = lookup_ior(p, "intIOR", "polypropylene"), lookup_ior(p, "extIOR", "air")
+            if int_ior < 0 or ext_ior < 0 or int_ior == ext_ior:
+                raise SceneError("roughplastic: the interior and exterior indices of refraction must be positive and differ")
+            alpha, eta = microfacet_alpha(p, t), float(f32(int_ior / ext_ior))
+            distr = str(p.get("distribution", "beckmann")).lower()
+            key = (distr, float(f32(alpha)), eta)
+            if key not in rt_index:
+                try:
+                    rt_slices.append(_rt.roughplastic_slice(distr, alpha, eta, data_dir))
+                except _rt.RoughTransmittanceError as e:
+                    raise SceneError("roughplastic: %s" % e)
+                rt_index[key] = len(rt_slices) - 1
+            m = dict(type=9, reflectance=rgb("diffuseReflectance", 0.5), specular=rgb("specularReflectance", 1.0), eta=eta, alpha=alpha,
+                     nonlinear=bool(p.get("nonlinear", False)), rtrans=rt_index[key])
+            if distr == "beckmann":
+                m["distribution"] = "beckmann"
+            return m
         elif t == "roughdielectric":  # roughdielectric.cpp:183-211
             int_ior, ext_ior = lookup_ior(p, "intIOR", "bk7"), lookup_ior(p, "extIOR", "air")
             if int_ior < 0 or ext_ior < 0 or int_ior == ext_ior:
@@ -460,7 +483,7 @@ def load_scene(path, defines=None, strict=True, width=None, height=None):
                 m["distribution"] = "beckmann"
             return m
         if strict:
-            raise SceneError("bsdf type %r is not supported yet (diffuse, conductor, roughconductor, plastic, dielectric, thindielectric, roughdielectric, "
+            raise SceneError("bsdf type %r is not supported yet (diffuse, conductor, roughconductor, plastic, roughplastic, dielectric, thindielectric, roughdielectric, "
                              "mask(...), twosided(...); "
                              "SURVEY.md §8 f1)" % t)
         warnings.append("bsdf %r replaced by diffuse(0.5)" % t)
@@ -557,7 +580,7 @@ def load_scene(path, defines=None, strict=True, width=None, height=None):
         tmat.append(np.full(T, mat, np.uint32)); tem.append(np.full(T, em, np.int32))
     normals = np.concatenate(nrm).astype(f32) if any_normals else None
     desc = SceneDesc(np.concatenate(pos).astype(f32), np.concatenate(idx).astype(np.uint32), np.concatenate(tmat), np.concatenate(tem),
-                     materials, emitters, camera, normals, environment)
+                     materials, emitters, camera, normals, environment, np.stack(rt_slices).astype(f32) if rt_slices else None)
     info["warnings"] = warnings
     return desc, props, info
 
@@ -612,6 +635,9 @@ def save_scene_xml(desc, props, directory, name="scene"):
             8: '<bsdf type="roughdielectric"%%s><string name="distribution" value="%s"/><float name="alpha" value="%r"/>%s'
                '<rgb name="specularReflectance" value="%s"/><rgb name="specularTransmittance" value="%s"/></bsdf>'
                % ("beckmann" if M.flags & 8 else "ggx", float(M.alpha), one, R, S),
+            9: '<bsdf type="roughplastic"%%s><string name="distribution" value="%s"/><float name="alpha" value="%r"/>%s'
+               '<rgb name="diffuseReflectance" value="%s"/><rgb name="specularReflectance" value="%s"/><boolean name="nonlinear" value="%s"/></bsdf>'
+               % ("beckmann" if M.flags & 8 else "ggx", float(M.alpha), one, R, S, "true" if M.flags & 2 else "false"),
         }[t]
         twos = t == 1 or (M.flags & 1 and t not in (6, 7, 8))
         if M.flags & 4:

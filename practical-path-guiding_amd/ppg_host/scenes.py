@@ -16,11 +16,12 @@ import numpy as np
 
 
 class SceneDesc:
-    def __init__(self, positions, indices, tri_material, tri_emitter, materials, emitters, camera, normals=None, environment=None):
+    def __init__(self, positions, indices, tri_material, tri_emitter, materials, emitters, camera, normals=None, environment=None, rtrans=None):
         self.positions, self.indices = positions, indices
         self.tri_material, self.tri_emitter = tri_material, tri_emitter
         self.materials, self.emitters, self.camera, self.normals = materials, emitters, camera, normals
         self.environment = environment  # None or (r, g, b): constant environment emitter
+        self.rtrans = rtrans            # None or float32 [n_slices, samples + 1]: rough-transmittance slices of the roughplastic materials
 
     @property
     def n_triangles(self):
@@ -29,16 +30,19 @@ class SceneDesc:
 
 def save_scene(desc, path):
     """Write the flat binary scene read by host/ppg_render.cpp: "PPGS", 6 x uint32 {n_vertices, n_triangles, n_materials,
-    n_emitters, has_normals, has_environment}, then positions, [normals], indices, tri_material, tri_emitter, materials
-    (ppg_material, 80 bytes each), emitters (4 floats), camera (ppg_camera), [environment radiance: 3 floats]."""
+    n_emitters, has_normals, blocks (bit 0: environment, bit 1: rtrans)}, then positions, [normals], indices, tri_material,
+    tri_emitter, materials (ppg_material, 80 bytes each), emitters (4 floats), camera (ppg_camera), [environment radiance:
+    3 floats], [rtrans: 2 x uint32 {n_slices, samples}, then n_slices x (samples + 1) floats]."""
     import struct
     pos = np.ascontiguousarray(desc.positions, np.float32)
     idx = np.ascontiguousarray(desc.indices, np.uint32)
     with open(path, "wb") as f:
         f.write(b"PPGS")
         env = getattr(desc, "environment", None)
+        rt = getattr(desc, "rtrans", None)
+        rt = None if rt is None or not len(rt) else np.ascontiguousarray(rt, np.float32)
         f.write(struct.pack("<6I", pos.shape[0], idx.shape[0], len(desc.materials), len(desc.emitters), 0 if desc.normals is None else 1,
-                            0 if env is None else 1))
+                            (0 if env is None else 1) | (0 if rt is None else 2)))
         f.write(pos.tobytes())
         if desc.normals is not None:
             f.write(np.ascontiguousarray(desc.normals, np.float32).tobytes())
@@ -56,6 +60,9 @@ def save_scene(desc, path):
         f.write(struct.pack("<2f2i", c["near_clip"], c["far_clip"], c["width"], c["height"]))
         if env is not None:
             f.write(struct.pack("<3f", *[float(np.float32(v)) for v in env]))
+        if rt is not None:
+            f.write(struct.pack("<2I", rt.shape[0], rt.shape[1] - 1))
+            f.write(rt.tobytes())
 
 
 def _sample_to_camera(fov_deg, fov_axis, near, far, width, height):

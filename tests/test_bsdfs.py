@@ -19,7 +19,28 @@ def _fp(a):
     return a.ctypes.data_as(FP)
 
 
+def _slice(lib, mat):
+    """roughplastic: hand the oracle's element-wise BSDF interface the material's rough-transmittance slice (tests/golden/rtrans_slices.npz)."""
+    if "slice" in mat:
+        sl = np.ascontiguousarray(mat["slice"], np.float32)
+        assert lib.ppgo_bsdf_set_rtrans(_fp(sl), len(sl) - 1) == 0
+
+
+def rtrans_slice(distribution, alpha, eta):
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "rtrans_slices.npz"))
+    for i, (d, a, e) in enumerate(g["cases"]):
+        if (str(d), float(a), float(e)) == (distribution, alpha, eta):
+            return g["slice%d" % i]
+    raise KeyError((distribution, alpha, eta))
+
+
+def roughplastic(distribution, alpha, eta, **kw):
+    return dict(type="roughplastic", alpha=alpha, eta=eta, distribution=distribution, slice=rtrans_slice(distribution, alpha, eta), **kw)
+
+
 def bsdf_eval(lib, mat, wi, wo):
+    _slice(lib, mat)
     m = Material.from_dict(mat)
     wi = np.ascontiguousarray(np.broadcast_to(wi, wo.shape), np.float32); wo = np.ascontiguousarray(wo, np.float32)
     f = np.zeros_like(wo); pdf = np.zeros(len(wo), np.float32)
@@ -28,6 +49,7 @@ def bsdf_eval(lib, mat, wi, wo):
 
 
 def bsdf_sample(lib, mat, wi, xy):
+    _slice(lib, mat)
     m = Material.from_dict(mat)
     n = len(xy)
     wi = np.ascontiguousarray(np.broadcast_to(wi, (n, 3)), np.float32); xy = np.ascontiguousarray(xy, np.float32)
@@ -64,6 +86,9 @@ SMOOTH = [
     ("ggx-beckmann-0.5", dict(GOLD, alpha=0.5, distribution="beckmann")),
     ("ggx-roughdielectric-0.3", dict(type="roughdielectric", alpha=0.3, eta=1.5, reflectance=(1, 1, 1), specular=(0.9, 0.95, 1.0))),
     ("ggx-roughdielectric-beckmann-0.15", dict(type="roughdielectric", alpha=0.15, eta=1.33, reflectance=(1, 1, 1), specular=(1, 1, 1), distribution="beckmann")),
+    ("ggx-roughplastic-0.1", roughplastic("ggx", 0.1, 1.5, reflectance=(0.6, 0.3, 0.1), specular=(1, 1, 1))),
+    ("ggx-roughplastic-beckmann-0.2-nonlinear-twosided", roughplastic("beckmann", 0.2, 1.49, reflectance=(0.2, 0.5, 0.7), specular=(0.8, 0.9, 1.0),
+                                                                    nonlinear=True, twosided=True)),
     ("plastic", dict(type="plastic", reflectance=(0.6, 0.3, 0.1), specular=(1, 1, 1), eta=1.49)),
     ("plastic-nonlinear", dict(type="plastic", reflectance=(0.6, 0.3, 0.1), specular=(0.8, 0.8, 0.8), eta=1.9, nonlinear=True)),
 ]
@@ -221,6 +246,25 @@ def test_flags(oracle_lib):
     assert flags(dict(type="diffuse")) == (1, 0, 0) and flags(dict(type=1)) == (1, 0, 1)
     assert flags(dict(type="mirror")) == (0, 1, 0) and flags(dict(type="conductor", twosided=True)) == (0, 1, 1)
     assert flags(GOLD) == (1, 0, 0) and flags(dict(type="plastic")) == (1, 0, 0) and flags(dict(type="dielectric")) == (0, 1, 1)
+
+
+def test_roughplastic_tends_to_smooth_plastic(oracle_lib):
+    """roughplastic.cpp:330-501 with a small alpha is plastic.cpp with its delta lobe widened a little: the two albedos agree (the
+    diffuse base sees the rough-transmittance table where the smooth plug-in sees 1 - Fresnel), and no more energy leaves than arrives."""
+    rng = np.random.RandomState(11)
+    xy = rng.rand(400000, 2).astype(np.float32)
+    rough = roughplastic("ggx", 0.05, 1.9, reflectance=(0.6, 0.3, 0.1), specular=(1, 1, 1))
+    smooth = dict(type="plastic", reflectance=(0.6, 0.3, 0.1), specular=(1, 1, 1), eta=1.9)
+    for wi in (unit((0, 0, 1)), unit((0.6, 0.2, 0.5)), unit((0.9, 0, 0.3))):
+        _, wr, pr, _, dr = bsdf_sample(oracle_lib, rough, wi, xy)
+        _, ws, ps, _, _ = bsdf_sample(oracle_lib, smooth, wi, xy)
+        ar, asm = wr.astype(np.float64).mean(0), ws.astype(np.float64).mean(0)
+        assert np.all(dr == 0) and np.all(ar < 1.0) and np.allclose(ar, asm, rtol=0.03, atol=0.012), (ar, asm)
+    m = Material.from_dict(rough)
+    a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+    _slice(oracle_lib, rough)
+    oracle_lib.ppgo_bsdf_flags(C.byref(m), C.byref(a), C.byref(b), C.byref(c))
+    assert (a.value, b.value, c.value) == (1, 0, 0)  # glossy + diffuse, one-sided
 
 
 def test_thindielectric_null_component(oracle_lib):

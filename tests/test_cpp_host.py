@@ -121,7 +121,8 @@ def _read_ppgs(path):
     import struct
     buf = open(path, "rb").read()
     assert buf[:4] == b"PPGS"
-    nv, nt, nm, ne, has_n, has_env = struct.unpack_from("<6I", buf, 4)
+    nv, nt, nm, ne, has_n, blocks = struct.unpack_from("<6I", buf, 4)
+    has_env, has_rt = blocks & 1, blocks & 2
     off = 28
     def take(dtype, count):
         nonlocal off
@@ -136,6 +137,10 @@ def _read_ppgs(path):
     out["s2c"] = take(np.float32, 16); out["c2w"] = take(np.float32, 16)
     out["clip"] = take(np.float32, 2); out["size"] = take(np.int32, 2)
     out["env"] = take(np.float32, 3) if has_env else None
+    out["rtrans"] = None
+    if has_rt:
+        n, samples = take(np.uint32, 2)
+        out["rtrans"] = take(np.float32, int(n) * (int(samples) + 1)).reshape(int(n), int(samples) + 1)
     assert off == len(buf)
     return out
 
@@ -191,15 +196,45 @@ def test_cpp_scene_xml_loader_equals_the_python_loader(ppg_render, tmp_path):
     assert got == {k: ("true" if v is True else str(v)) if not isinstance(v, float) else got[k] for k, v in dict(props, strictNormals="true").items()} and float(got["budget"]) == 12.0
 
 
+@pytest.mark.skipif(not os.path.exists("/root/reference/mitsuba/data/microfacet/ggx.dat"), reason="Mitsuba data tables not mounted")
+def test_cpp_roughplastic_slices_equal_the_python_loader(ppg_render, tmp_path):
+    """host/rough_transmittance.h against ppg_host/rtrans.py: same table, same reduction, same float arithmetic ⇒ the same bits."""
+    import ppg_host
+    from test_mitsuba_xml import _write
+    data = "/root/reference/mitsuba/data"
+    xml = _write(tmp_path, """
+    <shape type="rectangle"><bsdf type="roughplastic"><string name="distribution" value="ggx"/><float name="alpha" value="0.13"/>
+        <string name="intIOR" value="water"/><rgb name="diffuseReflectance" value="0.1, 0.2, 0.3"/><boolean name="nonlinear" value="true"/></bsdf></shape>
+    <shape type="rectangle"><bsdf type="twosided"><bsdf type="roughplastic"><float name="alpha" value="0.35"/></bsdf></bsdf></shape>
+    <shape type="rectangle"><bsdf type="roughplastic"><string name="distribution" value="ggx"/><float name="alpha" value="0.13"/>
+        <string name="intIOR" value="water"/></bsdf></shape>""")
+    r, c = _cpp_load(ppg_render, xml, tmp_path, "-D", "nee=never", "--data-dir", data)
+    assert r.returncode == 0, r.stderr
+    desc, _, _ = ppg_host.load_scene(xml, defines=dict(nee="never"), data_dir=data)
+    assert c["rtrans"].shape == desc.rtrans.shape == (2, 101) and np.array_equal(c["rtrans"], desc.rtrans)
+    from ppg_host.bindings import Material
+    for a, m in zip(c["materials"], desc.materials):
+        b = bytes(Material.from_dict(m))
+        assert np.frombuffer(a, np.int32)[[0, 14, 15]].tolist() == np.frombuffer(b, np.int32)[[0, 14, 15]].tolist()   # type, flags, rtrans slice
+        assert np.allclose(np.frombuffer(a, np.float32)[1:11], np.frombuffer(b, np.float32)[1:11], rtol=2e-6)
+    env = dict(os.environ); env.pop("PPG_MITSUBA_DATA", None)
+    r = subprocess.run([ppg_render, "--ppgs", str(tmp_path / "x.ppgs"), "-q", "-D", "nee=never", xml], capture_output=True, text=True, env=env)
+    assert r.returncode == 2 and "data/microfacet" in r.stderr
+    # the flat file carries the slices: ppg_render reads back what it wrote
+    r2 = subprocess.run([ppg_render, "--ppgs", str(tmp_path / "again.ppgs"), "-q", str(tmp_path / "cpp.ppgs")], capture_output=True, text=True)
+    assert r2.returncode == 0, r2.stderr
+    assert open(str(tmp_path / "again.ppgs"), "rb").read() == open(str(tmp_path / "cpp.ppgs"), "rb").read()
+
+
 def test_cpp_scene_xml_loader_errors(ppg_render, tmp_path):
     from test_mitsuba_xml import _write
-    for extra, needle in (('<shape type="sphere"/>', "sphere"), ('<shape type="rectangle"><bsdf type="roughplastic"/></shape>', "roughplastic"),
+    for extra, needle in (('<shape type="sphere"/>', "sphere"), ('<shape type="rectangle"><bsdf type="ward"/></shape>', "ward"),
                           ('<emitter type="sunsky"/>', "sunsky"), ('<shape type="obj"><string name="filename" value="meshes/missing.obj"/></shape>', "not found")):
         r, _ = _cpp_load(ppg_render, _write(tmp_path, extra), tmp_path, "-D", "nee=never")
         assert r.returncode == 2 and needle in r.stderr, r.stderr
     r, _ = _cpp_load(ppg_render, _write(tmp_path), tmp_path)
     assert r.returncode == 2 and "$nee" in r.stderr          # undefined parameter
-    r, c = _cpp_load(ppg_render, _write(tmp_path, '<shape type="rectangle"><bsdf type="roughplastic"/></shape>'), tmp_path, "-D", "nee=never", "--lenient")
+    r, c = _cpp_load(ppg_render, _write(tmp_path, '<shape type="rectangle"><bsdf type="ward"/></shape>'), tmp_path, "-D", "nee=never", "--lenient")
     assert r.returncode == 0 and len(c["indices"]) == 9
 
 

@@ -507,6 +507,49 @@ def test_rough_dielectric_against_oracle(oracle_lib, extra):
     assert np.nanmean(np.abs(ig - ppg_host.GuidedPathTracer(engine=hip(**props)).render(glass))) > 5e-3
 
 
+def _roughplastic_scene(res):
+    import ppg_host
+    from test_bsdfs import rtrans_slice
+    scene = ppg_host.cbox_scene(*res)
+    base = len(scene.materials)
+    scene.rtrans = np.stack([rtrans_slice("ggx", 0.1, 1.5), rtrans_slice("beckmann", 0.2, 1.49), rtrans_slice("ggx", 0.3, 1.49)]).astype(np.float32)
+    scene.materials = list(scene.materials) + [
+        dict(type="roughplastic", alpha=0.1, eta=1.5, reflectance=(0.45, 0.3, 0.15), specular=(1, 1, 1), rtrans=0),                                  # floor: varnished wood
+        dict(type="roughplastic", alpha=0.2, eta=1.49, reflectance=(0.2, 0.5, 0.7), specular=(0.8, 0.9, 1.0), distribution="beckmann", nonlinear=True,
+             twosided=True, rtrans=1),                                                                                                             # short box
+        dict(type="roughplastic", alpha=0.3, eta=1.49, reflectance=(0.7, 0.7, 0.7), specular=(1, 1, 1), rtrans=2)]                                   # tall box
+    tm = scene.tri_material.copy()
+    tm[2:4] = base + 0
+    tm[12:24] = base + 1
+    tm[24:36] = base + 2
+    scene.tri_material = tm
+    return scene
+
+
+@pytest.mark.parametrize("extra", [{}, dict(nee="always", **IMPROVED)], ids=["default", "nee-always-improved"])
+def test_rough_plastic_against_oracle(oracle_lib, extra):
+    """roughplastic (roughplastic.cpp:330-501): glossy coating + diffuse base, both guided; the energy split comes from the material's
+    rough-transmittance slice (ppg_scene.rtrans — cut from Mitsuba's data/microfacet tables, committed as tests/golden/rtrans_slices.npz),
+    read through the reference's cubic interpolation on the warped cosine."""
+    import ppg_host
+    scene = _roughplastic_scene((64, 64))
+    props = dict(CBOX_PROPS, budget=60, seed=41)
+    props.update(maxDepth=10, rrDepth=5)
+    props.update(extra)
+    g, o = hip(**props), make_oracle(oracle_lib, threads=os.cpu_count() or 8, **props)
+    gg, go = ppg_host.GuidedPathTracer(engine=g), ppg_host.GuidedPathTracer(engine=o)
+    ig, io = gg.render(scene), go.render(scene)
+    assert _stats(gg) == _stats(go)
+    assert np.array_equal(ig, io, equal_nan=True)
+    assert_tree_equal(g.read_sdtree(), o.read_sdtree())
+    plain = ppg_host.GuidedPathTracer(engine=hip(**props)).render(ppg_host.cbox_scene(64, 64))
+    assert np.nanmean(np.abs(ig - plain)) > 5e-3
+    bad = _roughplastic_scene((16, 16))
+    bad.materials[-1]["rtrans"] = 7
+    with pytest.raises(ppg_host.PPGError, match="rtrans"):
+        ppg_host.GuidedPathTracer(engine=hip(**props)).render(bad)
+
+
 def _pane_scene(res):
     """CBOX + two thin-dielectric panes: a horizontal one between the (upward-facing) luminaire and the ceiling and a vertical
     "window" across the room — most paths cross a null component, emitters are found through one or two panes."""

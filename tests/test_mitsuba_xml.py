@@ -151,7 +151,7 @@ def test_loader_subset_semantics(tmp_path):
 
 @pytest.mark.parametrize("extra,needle", [
     ('<shape type="sphere"/>', "sphere"),
-    ('<shape type="rectangle"><bsdf type="roughplastic"/></shape>', "roughplastic"),
+    ('<shape type="rectangle"><bsdf type="ward"/></shape>', "ward"),
     ('<shape type="rectangle"><bsdf type="conductor"><string name="material" value="Au"/></bsdf></shape>', "Au"),
     ('<emitter type="sunsky"/>', "sunsky"),
     ('<shape type="rectangle"><bsdf type="diffuse"><texture name="reflectance" type="bitmap"/></bsdf></shape>', "textured"),
@@ -163,9 +163,9 @@ def test_unsupported_plugins_are_named(tmp_path, extra, needle):
 
 
 def test_lenient_mode_and_wrong_integrator(tmp_path):
-    p = _write(tmp_path, '<shape type="rectangle"><bsdf type="roughplastic"/></shape>')
+    p = _write(tmp_path, '<shape type="rectangle"><bsdf type="ward"/></shape>')
     desc, _, info = ppg_host.load_scene(p, defines=dict(nee="never"), strict=False)
-    assert any("roughplastic" in w for w in info["warnings"]) and desc.n_triangles == 9
+    assert any("ward" in w for w in info["warnings"]) and desc.n_triangles == 9
     q = tmp_path / "pt.xml"
     q.write_text(open(p).read().replace('type="guided_path"', 'type="path"'))
     with pytest.raises(mitsuba_xml.SceneError, match="guided_path"):
