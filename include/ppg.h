@@ -125,6 +125,19 @@ typedef struct ppg_emitter {
     float _pad;
 } ppg_emitter;
 
+typedef struct ppg_sphere {
+    /* An analytic sphere (shapes/sphere.cpp:106-372): double-precision quadratic for the ray test (:164-189), intersection record and
+       (theta, phi) tangent frame of :213-263, Shirley et al. cone sampling / uniform area sampling for next-event estimation
+       (:291-378).  Spheres are primitives number n_triangles, n_triangles + 1, .. for the closest-hit tie rule. */
+    float center[3];
+    float radius;         /* > 0 (sphere.cpp:129-130); the scale of `toWorld` is folded in (:113-121) */
+    float to_world[9];    /* row-major rotation left of `toWorld` once its scale is removed (m_objectToWorld's linear part, :116-120);
+                             identity for an untransformed sphere.  The inverse is taken as the transpose. */
+    uint32_t material;    /* index into materials */
+    int32_t emitter;      /* index into emitters, -1 = none; an emitter id carried by a sphere must not be used by any other shape */
+    int32_t flip_normals; /* sphere.cpp:124, 256-257, 351-352 */
+} ppg_sphere;             /* 64 bytes */
+
 typedef struct ppg_camera {
     /* row-major 4x4, exactly the matrices of mitsuba/src/sensors/perspective.cpp:150-164 (m_sampleToCamera)
        and the sensor's world transform; rays follow perspective.cpp:271-298 */
@@ -158,6 +171,8 @@ typedef struct ppg_scene {
     uint32_t n_rtrans;
     uint32_t rtrans_samples;      /* thetaSamples of the data file (100 in Mitsuba's tables), >= 2 */
     const float *rtrans;          /* [n_rtrans * (rtrans_samples + 1)] */
+    uint32_t n_spheres;
+    const ppg_sphere *spheres;    /* [n_spheres] or NULL */
 } ppg_scene;
 
 /* ------------------------------------------------------------------------------------------------

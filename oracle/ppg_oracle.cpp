@@ -907,6 +907,8 @@ struct Scene {
     std::vector<int32_t> triEmitter;
     std::vector<Material> materials;
     std::vector<Float> rtrans;  // ppg_scene.rtrans (roughplastic slices)
+    std::vector<ppg_sphere> spheres;   // analytic spheres (shapes/sphere.cpp), primitives nTris(), nTris() + 1, ..
+    std::vector<int> emitterSphere;    // per emitter: the sphere carrying it, or -1 (a triangle emitter)
     std::vector<ppg_emitter> emitters;
     ppg_camera cam;
     AABB aabb;  // what Scene::getAABB() returns: the kd-tree's enlarged box (gkdtree.h:1213-1220)
@@ -924,6 +926,8 @@ struct Scene {
             const Point &p = P[idx[t]];
             for (int a = 0; a < 3; ++a) { mn[a] = ppg_min(mn[a], p[a]); mx[a] = ppg_max(mx[a], p[a]); }
         }
+        for (const ppg_sphere &sp : spheres)  // Sphere::getAABB, sphere.cpp:152-157
+            for (int a = 0; a < 3; ++a) { mn[a] = ppg_min(mn[a], sp.center[a] - sp.radius); mx[a] = ppg_max(mx[a], sp.center[a] + sp.radius); }
         const Float eps = 1e-3f;  // MTS_KD_AABB_EPSILON
         aabb.min = mn - ((mx - mn) * eps + Vec(eps));
         aabb.max = mx + ((mx - aabb.min) * eps + Vec(eps));
@@ -940,6 +944,9 @@ struct Scene {
         // TriMesh::prepareSamplingTable (trimesh.cpp:388-403) per emitter; Scene::configure's emitter pmf
         // (scene.cpp:375-380, samplingWeight = 1)
         emMesh.assign(emitters.size(), EmitterMesh());
+        emitterSphere.assign(emitters.size(), -1);
+        for (size_t k = 0; k < spheres.size(); ++k)
+            if (spheres[k].emitter >= 0) emitterSphere[spheres[k].emitter] = (int)k;
         for (uint32_t t = 0; t < nTris(); ++t)
             if (triEmitter[t] >= 0) emMesh[triEmitter[t]].tris.push_back(t);
         emitterPDF = Pmf();
@@ -960,6 +967,136 @@ struct Scene {
             bsRadius = ppg_max(PPG_EPSILON, length(bsCenter - aabb.max) * 1.5f);
         }
         if (!emMesh.empty() || hasEnv) emitterPDF.normalize();
+    }
+
+    // solveQuadratic (util.cpp:447-485)
+    static bool solveQuadratic(Float a, Float b, Float c, Float &x0, Float &x1) {
+        if (a == 0) {
+            if (b != 0) { x0 = x1 = -c / b; return true; }
+            return false;
+        }
+        Float discrim = b * b - 4.0f * a * c;
+        if (discrim < 0) return false;
+        Float temp, sqrtDiscrim = std::sqrt(discrim);
+        if (b < 0) temp = -0.5f * (b - sqrtDiscrim);
+        else temp = -0.5f * (b + sqrtDiscrim);
+        x0 = temp / a;
+        x1 = c / temp;
+        if (x0 > x1) std::swap(x0, x1);
+        return true;
+    }
+    // Sphere::rayIntersect (sphere.cpp:164-189) with solveQuadraticDouble (util.cpp:487-525)
+    static bool sphereRayIntersect(const ppg_sphere &sp, const Point &ro, const Vec &rd, Float mint, Float maxt, Float &t) {
+        const double ox = (double)ro.x - (double)sp.center[0], oy = (double)ro.y - (double)sp.center[1], oz = (double)ro.z - (double)sp.center[2];
+        const double dx = rd.x, dy = rd.y, dz = rd.z;
+        const double A = dx * dx + dy * dy + dz * dz;
+        const double B = 2 * (ox * dx + oy * dy + oz * dz);
+        const double C = (ox * ox + oy * oy + oz * oz) - sp.radius * sp.radius;  // m_radius * m_radius is a Float product
+        double nearT, farT;
+        if (A == 0) {
+            if (B != 0) nearT = farT = -C / B;
+            else return false;
+        } else {
+            const double discrim = B * B - 4.0f * A * C;
+            if (discrim < 0) return false;
+            double temp, sqrtDiscrim = std::sqrt(discrim);
+            if (B < 0) temp = -0.5f * (B - sqrtDiscrim);
+            else temp = -0.5f * (B + sqrtDiscrim);
+            nearT = temp / A;
+            farT = C / temp;
+            if (nearT > farT) std::swap(nearT, farT);
+        }
+        if (!(nearT <= maxt && farT >= mint)) return false;
+        if (nearT < mint) {
+            if (farT > maxt) return false;
+            t = (Float)farT;
+        } else {
+            t = (Float)nearT;
+        }
+        return true;
+    }
+    // Sphere::fillIntersectionRecord (sphere.cpp:213-263): position re-projected onto the sphere, normal, dpdu of the (theta, phi)
+    // parameterisation (the shading frame's tangent, skdtree.h:427); worldToObject of a vector taken as the transposed rotation
+    static void sphereFill(const ppg_sphere &sp, const Point &ro, const Vec &rd, Float t, Point &p, Vec &n, Vec &dpdu) {
+        const Point c(sp.center[0], sp.center[1], sp.center[2]);
+        p = ro + rd * t;
+        p = c + normalize(p - c) * sp.radius;
+        const Vec v = p - c;
+        const float *R = sp.to_world;
+        const Vec local(R[0] * v.x + R[3] * v.y + R[6] * v.z, R[1] * v.x + R[4] * v.y + R[7] * v.z, R[2] * v.x + R[5] * v.y + R[8] * v.z);
+        const Vec du = Vec(-local.y, local.x, 0.0f) * (2 * PPG_PI_F);
+        dpdu = Vec(R[0] * du.x + R[1] * du.y + R[2] * du.z, R[3] * du.x + R[4] * du.y + R[5] * du.z, R[6] * du.x + R[7] * du.y + R[8] * du.z);
+        n = normalize(p - c);
+        if (sp.flip_normals) n = n * -1.0f;
+    }
+    // Sphere::sampleDirect (sphere.cpp:291-355), solid-angle measure
+    static void sphereSampleDirect(const ppg_sphere &sp, DRec &dRec, const Point2 &sample) {
+        const Point c(sp.center[0], sp.center[1], sp.center[2]);
+        const Float invSurfaceArea = 1 / (4 * PPG_PI_F * sp.radius * sp.radius);
+        const Vec refToCenter = c - dRec.ref;
+        const Float refDist2 = dot(refToCenter, refToCenter);
+        const Float invRefDist = 1.0f / std::sqrt(refDist2);
+        const Float sinAlpha = sp.radius * invRefDist;
+        if (sinAlpha < 1 - PPG_EPSILON) {  // outside: the cone subtended by the sphere
+            Float cosAlpha = std::sqrt(ppg_max(0.0f, 1.0f - sinAlpha * sinAlpha));
+            // warp::squareToUniformCone (warp.cpp:54-63) in Frame(refToCenter * invRefDist) (coordinateSystem, util.cpp:592-601)
+            Float cosTheta = (1 - sample.x) + sample.x * cosAlpha;
+            Float sinTheta = std::sqrt(ppg_max(0.0f, 1.0f - cosTheta * cosTheta));
+            Float sinPhi, cosPhi;
+            ppg_sincos(2.0f * PPG_PI_F * sample.y, &sinPhi, &cosPhi);
+            const Vec lv(cosPhi * sinTheta, sinPhi * sinTheta, cosTheta);
+            const Vec a = refToCenter * invRefDist;
+            Vec sF, tF;
+            if (ppg_abs(a.x) > ppg_abs(a.y)) {
+                Float invLen = 1.0f / std::sqrt(a.x * a.x + a.z * a.z);
+                tF = Vec(a.z * invLen, 0.0f, -a.x * invLen);
+            } else {
+                Float invLen = 1.0f / std::sqrt(a.y * a.y + a.z * a.z);
+                tF = Vec(0.0f, a.z * invLen, -a.y * invLen);
+            }
+            sF = cross(tF, a);
+            dRec.d = sF * lv.x + tF * lv.y + a * lv.z;
+            dRec.pdf = (PPG_INV_PI_F * 0.5f) / (1 - cosAlpha);  // squareToUniformConePdf, warp.h:74-76
+            const Float projDist = dot(refToCenter, dRec.d);
+            const Float baseT = refDist2 / projDist;
+            const Point query = dRec.ref + dRec.d * baseT;
+            const Vec queryToCenter = c - query;
+            const Float queryDist2 = dot(queryToCenter, queryToCenter);
+            const Float queryProjDist = dot(queryToCenter, dRec.d);
+            Float A = 1.0f, B = -2 * queryProjDist, C = queryDist2 - sp.radius * sp.radius;
+            Float nearT, farT;
+            if (!solveQuadratic(A, B, C, nearT, farT)) nearT = queryProjDist;
+            dRec.dist = baseT + nearT;
+            dRec.n = normalize(dRec.d * nearT - queryToCenter);
+            dRec.p = c + dRec.n * sp.radius;
+        } else {  // inside: uniform over the sphere
+            Float z = 1.0f - 2.0f * sample.y;  // warp::squareToUniformSphere, warp.cpp:25-31
+            Float r = std::sqrt(ppg_max(0.0f, 1.0f - z * z));
+            Float sinPhi, cosPhi;
+            ppg_sincos(2.0f * PPG_PI_F * sample.x, &sinPhi, &cosPhi);
+            const Vec d(r * cosPhi, r * sinPhi, z);
+            dRec.p = c + d * sp.radius;
+            dRec.n = d;
+            dRec.d = dRec.p - dRec.ref;
+            Float dist2 = dot(dRec.d, dRec.d);
+            dRec.dist = std::sqrt(dist2);
+            dRec.d = dRec.d / dRec.dist;
+            dRec.pdf = invSurfaceArea * dist2 / ppg_abs(dot(dRec.d, dRec.n));
+        }
+        if (sp.flip_normals) dRec.n = dRec.n * -1.0f;
+    }
+    // Sphere::pdfDirect (sphere.cpp:357-378), solid-angle measure
+    static Float spherePdfDirect(const ppg_sphere &sp, const DRec &dRec) {
+        const Point c(sp.center[0], sp.center[1], sp.center[2]);
+        const Vec refToCenter = c - dRec.ref;
+        const Float invRefDist = 1.0f / length(refToCenter);
+        const Float sinAlpha = sp.radius * invRefDist;
+        if (sinAlpha < 1 - PPG_EPSILON) {
+            Float cosAlpha = std::sqrt(ppg_max(0.0f, 1 - sinAlpha * sinAlpha));
+            return (PPG_INV_PI_F * 0.5f) / (1 - cosAlpha);
+        }
+        const Float invSurfaceArea = 1 / (4 * PPG_PI_F * sp.radius * sp.radius);
+        return invSurfaceArea * dRec.dist * dRec.dist / ppg_abs(dot(dRec.d, dRec.n));
     }
 
     // BSphere::rayIntersect (bsphere.h:88-95) + solveQuadratic (util.cpp:447-485)
@@ -1077,6 +1214,14 @@ struct Scene {
         const bool isEnv = hasEnv && (int)index == envIndex();
         if (isEnv) {
             value = envSampleDirect(dRec, sample);
+        } else if (emitterSphere[index] >= 0) {  // AreaLight::sampleDirect (area.cpp:158-173) on a sphere
+            sphereSampleDirect(spheres[emitterSphere[index]], dRec, sample);
+            if (!(dot(dRec.d, dRec.refN) >= 0 && dot(dRec.d, dRec.n) < 0 && dRec.pdf != 0)) {
+                dRec.pdf = 0.0f;
+                return Spectrum(0.0f);
+            }
+            const float *r = emitters[index].radiance;
+            value = Spectrum(r[0], r[1], r[2]) / dRec.pdf;
         } else {
             const EmitterMesh &m = emMesh[index];
             if (m.tris.empty()) return Spectrum(0.0f);
@@ -1124,8 +1269,10 @@ struct Scene {
         if (hasEnv && dRec.emitter == envIndex()) {  // ConstantBackgroundEmitter::pdfDirect, constant.cpp:216-231 (solid angle)
             const bool hasRefN = !(dRec.refN.x == 0 && dRec.refN.y == 0 && dRec.refN.z == 0);
             pdf = hasRefN ? PPG_INV_PI_F * ppg_max(0.0f, dot(dRec.d, dRec.refN)) : PPG_INV_PI_F * 0.25f;
-        } else if (dot(dRec.d, dRec.refN) >= 0 && dot(dRec.d, dRec.n) < 0)
-            pdf = emMesh[dRec.emitter].invSurfaceArea * (dRec.dist * dRec.dist) / ppg_abs(dot(dRec.d, dRec.n));
+        } else if (dot(dRec.d, dRec.refN) >= 0 && dot(dRec.d, dRec.n) < 0) {
+            if (emitterSphere[dRec.emitter] >= 0) pdf = spherePdfDirect(spheres[emitterSphere[dRec.emitter]], dRec);
+            else pdf = emMesh[dRec.emitter].invSurfaceArea * (dRec.dist * dRec.dist) / ppg_abs(dot(dRec.d, dRec.n));
+        }
         return pdf * (1.0f * emitterPDF.normalization);  // pdfEmitterDiscrete, scene.h:848-850
     }
 
@@ -1272,7 +1419,27 @@ struct Scene {
         Float t, u, v; int prim;
         its.valid = false;
         its.t = std::numeric_limits<Float>::infinity();
-        if (!closest(o, d, rayMinT, rayMaxt, t, u, v, prim)) return false;
+        bool found = closest(o, d, rayMinT, rayMaxt, t, u, v, prim);
+        int sph = -1;  // spheres: primitives after the triangles; a tie in t keeps the smaller index
+        for (size_t k = 0; k < spheres.size(); ++k) {
+            Float ts;
+            if (sphereRayIntersect(spheres[k], o, d, rayMinT, found ? ppg_min(rayMaxt, t) : rayMaxt, ts) && (!found || ts < t)) { found = true; t = ts; sph = (int)k; }
+        }
+        if (!found) return false;
+        if (sph >= 0) {
+            const ppg_sphere &sp = spheres[sph];
+            its.valid = true; its.t = t; its.prim = (int)nTris() + sph;
+            Vec n, dpdu;
+            sphereFill(sp, o, d, t, its.p, n, dpdu);
+            its.geoN = n;
+            its.shFrame.n = n;
+            its.shFrame.s = normalize(dpdu - n * dot(n, dpdu));  // computeShadingFrame, util.cpp:603-608
+            its.shFrame.t = cross(n, its.shFrame.s);
+            its.wi = its.shFrame.toLocal(-d);
+            its.material = sp.material;
+            its.emitter = sp.emitter;
+            return true;
+        }
         its.valid = true; its.t = t; its.prim = prim;
         const uint32_t i0 = idx[3 * prim], i1 = idx[3 * prim + 1], i2 = idx[3 * prim + 2];
         const Point &p0 = P[i0], &p1 = P[i1], &p2 = P[i2];
@@ -2737,6 +2904,17 @@ int ppgo_set_scene(ppgo_ctx *ctx, const ppg_scene *s) {
         sc.materials.push_back(m);
     }
     if (s->n_emitters) sc.emitters.assign(s->emitters, s->emitters + s->n_emitters);
+    if (s->n_spheres) {
+        if (!s->spheres) { ctx->gpt.error = "spheres: n_spheres > 0 but no array"; return PPG_ERR_INVALID; }
+        sc.spheres.assign(s->spheres, s->spheres + s->n_spheres);
+        std::vector<int> users(s->n_emitters, 0);
+        for (uint32_t t = 0; t < s->n_triangles; ++t) if (s->tri_emitter[t] >= 0 && s->tri_emitter[t] < (int32_t)s->n_emitters) users[s->tri_emitter[t]] = 1;
+        for (const ppg_sphere &sp : sc.spheres) {
+            if (!(sp.radius > 0)) { ctx->gpt.error = "sphere: radius must be > 0"; return PPG_ERR_INVALID; }
+            if (sp.material >= s->n_materials || sp.emitter >= (int32_t)s->n_emitters) { ctx->gpt.error = "index out of range"; return PPG_ERR_INVALID; }
+            if (sp.emitter >= 0 && users[sp.emitter]++) { ctx->gpt.error = "sphere: its emitter is shared with another shape"; return PPG_ERR_INVALID; }
+        }
+    }
     for (uint32_t t = 0; t < s->n_triangles; ++t) {
         if (sc.triMat[t] >= s->n_materials || sc.triEmitter[t] >= (int32_t)s->n_emitters) { ctx->gpt.error = "index out of range"; return PPG_ERR_INVALID; }
         for (int k = 0; k < 3; ++k) if (sc.idx[3 * t + k] >= s->n_vertices) { ctx->gpt.error = "vertex index out of range"; return PPG_ERR_INVALID; }

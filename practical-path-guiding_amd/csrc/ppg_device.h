@@ -100,6 +100,10 @@ struct DevScene {
     const float4 *em_normals;  // 3 per emitter triangle or nullptr
     const float *rtrans;       // roughplastic: rough-transmittance slices, rtrans_n + 1 floats each (ppg_scene.rtrans)
     int rtrans_n;
+    // analytic spheres (FULL kernels, BVH path only): 4 float4 each = (centre, radius) (R row 0, material) (R row 1, emitter)
+    // (R row 2, flip normals); primitive numbers n_tris, n_tris + 1, ..
+    const float4 *spheres;
+    int n_spheres;
 };
 
 struct Hit {
@@ -230,9 +234,52 @@ struct TStack {
     D int pop() { --sp; return sp < PPG_LDS_STACK ? lds[sp * stride] : over[sp - PPG_LDS_STACK]; }
 };
 
+// Sphere::rayIntersect (sphere.cpp:164-189) with solveQuadraticDouble (util.cpp:487-525): double precision, like the reference
+D bool sphere_hit(const float4 c, F3 ro, F3 rd, float mint, float maxt, float &t) {
+    const double ox = (double)ro.x - (double)c.x, oy = (double)ro.y - (double)c.y, oz = (double)ro.z - (double)c.z;
+    const double dx = rd.x, dy = rd.y, dz = rd.z;
+    const double A = dx * dx + dy * dy + dz * dz;
+    const double B = 2 * (ox * dx + oy * dy + oz * dz);
+    const double C = (ox * ox + oy * oy + oz * oz) - c.w * c.w;  // m_radius * m_radius is a float product
+    double nearT, farT;
+    if (A == 0) {
+        if (B != 0) nearT = farT = -C / B;
+        else return false;
+    } else {
+        const double discrim = B * B - 4.0f * A * C;
+        if (discrim < 0) return false;
+        double temp;
+        const double sqrtDiscrim = __builtin_sqrt(discrim);
+        if (B < 0) temp = -0.5f * (B - sqrtDiscrim);
+        else temp = -0.5f * (B + sqrtDiscrim);
+        nearT = temp / A;
+        farT = C / temp;
+        if (nearT > farT) { const double sw = nearT; nearT = farT; farT = sw; }
+    }
+    if (!(nearT <= maxt && farT >= mint)) return false;
+    if (nearT < mint) {
+        if (farT > maxt) return false;
+        t = (float)farT;
+    } else {
+        t = (float)nearT;
+    }
+    return true;
+}
+// the spheres after the triangles: a sphere wins only with a strictly smaller t (its primitive number is larger)
+template <bool ANY>
+D void sphere_pass(const DevScene &S, F3 o, F3 d, float mint, float maxt, Hit &best) {
+    for (int k = 0; k < S.n_spheres; ++k) {
+        float ts;
+        if (sphere_hit(S.spheres[4 * k], o, d, mint, best.prim >= 0 ? fminf(maxt, best.t) : maxt, ts) && (best.prim < 0 || ts < best.t)) {
+            best.t = ts; best.u = 0; best.v = 0; best.prim = S.n_tris + k;
+            if (ANY) return;
+        }
+    }
+}
+
 // Closest hit by (t, original primitive index) through the BVH4 — equals brute force (conservative culling).
 // ANY: return at the first triangle hit (shadow rays; only prim >= 0 is meaningful then).
-template <bool ANY = false>
+template <bool ANY = false, bool SPH = false>
 D Hit trace_closest4(const DevScene &S, int *lds_stack_col, int stride, F3 o, F3 d, float mint, float maxt) {
     Hit best;
     best.t = __builtin_inff(); best.u = 0; best.v = 0; best.prim = -1;
@@ -303,6 +350,7 @@ D Hit trace_closest4(const DevScene &S, int *lds_stack_col, int stride, F3 o, F3
             cur = st.pop();
         }
     }
+    if (SPH && S.n_spheres) sphere_pass<ANY>(S, o, d, mint, maxt, best);
     return best;
 }
 
@@ -314,6 +362,27 @@ struct Isect {
 D F3 to_local(const Isect &I, F3 v) { return f3(dot3(v, I.s), dot3(v, I.t), dot3(v, I.n)); }
 D F3 to_world(const Isect &I, F3 v) { return I.s * v.x + I.t * v.y + I.n * v.z; }
 
+// Sphere::fillIntersectionRecord (sphere.cpp:213-263): position re-projected onto the sphere, its normal, dpdu of the (theta, phi)
+// parameterisation as the tangent; worldToObject of a vector taken as the transposed rotation.  `o` = the ray origin.
+D void fill_isect_sphere(const DevScene &S, const Hit &h, F3 o, F3 d, Isect &I) {
+    const float4 *Q = S.spheres + 4 * (h.prim - S.n_tris);
+    const float4 c4 = Q[0], r0 = Q[1], r1 = Q[2], r2 = Q[3];
+    const F3 c = f3(c4.x, c4.y, c4.z);
+    F3 p = o + d * h.t;
+    p = c + norm3(p - c) * c4.w;
+    const F3 v = p - c;
+    const F3 local = f3(r0.x * v.x + r1.x * v.y + r2.x * v.z, r0.y * v.x + r1.y * v.y + r2.y * v.z, r0.z * v.x + r1.z * v.y + r2.z * v.z);
+    const F3 du = f3(-local.y, local.x, 0.0f) * (2 * PPG_PI_F);
+    const F3 dpdu = f3(r0.x * du.x + r0.y * du.y + r0.z * du.z, r1.x * du.x + r1.y * du.y + r1.z * du.z, r2.x * du.x + r2.y * du.y + r2.z * du.z);
+    F3 n = norm3(p - c);
+    if (__float_as_int(r2.w)) n = n * -1.0f;
+    I.p = p; I.geoN = n; I.n = n;
+    I.s = norm3(dpdu - n * dot3(n, dpdu));
+    I.t = cross3(n, I.s);
+    I.wi = to_local(I, -d);
+    I.material = __float_as_int(r0.w);
+    I.emitter = __float_as_int(r1.w);
+}
 D void fill_isect(const DevScene &S, const Hit &h, F3 d, Isect &I) {
     const float4 *T = S.tris + 3 * h.prim;
     float4 q0 = T[0], q1 = T[1];
@@ -444,6 +513,87 @@ D F3 env_sample_direct(const DevScene &S, F3 ref, F3 refN, float sx, float sy, D
     if (hasRefN && dot3(ds.d, refN) <= 0) return f3s(0.0f);
     return div3(f3(S.env.x, S.env.y, S.env.z), pdf);
 }
+// Sphere::sampleDirect (sphere.cpp:291-355) and pdfDirect (:357-378), solid-angle measure
+D void sphere_sample_direct(const float4 *Q, F3 ref, float sx, float sy, DirectSample &ds) {
+    const float4 c4 = Q[0];
+    const F3 c = f3(c4.x, c4.y, c4.z);
+    const float radius = c4.w;
+    const float invSurfaceArea = 1 / (4 * PPG_PI_F * radius * radius);
+    const F3 refToCenter = c - ref;
+    const float refDist2 = dot3(refToCenter, refToCenter);
+    const float invRefDist = 1.0f / __builtin_sqrtf(refDist2);
+    const float sinAlpha = radius * invRefDist;
+    if (sinAlpha < 1 - PPG_EPSILON) {  // outside: the cone subtended by the sphere
+        const float cosAlpha = __builtin_sqrtf(ppg_max(0.0f, 1.0f - sinAlpha * sinAlpha));
+        const float cosTheta = (1 - sx) + sx * cosAlpha;  // warp::squareToUniformCone, warp.cpp:54-63
+        const float sinTheta = __builtin_sqrtf(ppg_max(0.0f, 1.0f - cosTheta * cosTheta));
+        float sinPhi, cosPhi;
+        ppg_sincos(2.0f * PPG_PI_F * sy, &sinPhi, &cosPhi);
+        const F3 lv = f3(cosPhi * sinTheta, sinPhi * sinTheta, cosTheta);
+        const F3 a = refToCenter * invRefDist;  // Frame(a): coordinateSystem, util.cpp:592-601
+        F3 sF, tF;
+        if (ppg_abs(a.x) > ppg_abs(a.y)) {
+            const float invLen = 1.0f / __builtin_sqrtf(a.x * a.x + a.z * a.z);
+            tF = f3(a.z * invLen, 0.0f, -a.x * invLen);
+        } else {
+            const float invLen = 1.0f / __builtin_sqrtf(a.y * a.y + a.z * a.z);
+            tF = f3(0.0f, a.z * invLen, -a.y * invLen);
+        }
+        sF = cross3(tF, a);
+        ds.d = sF * lv.x + tF * lv.y + a * lv.z;
+        ds.pdf = (PPG_INV_PI_F * 0.5f) / (1 - cosAlpha);  // squareToUniformConePdf, warp.h:74-76
+        const float projDist = dot3(refToCenter, ds.d);
+        const float baseT = refDist2 / projDist;
+        const F3 query = ref + ds.d * baseT;
+        const F3 queryToCenter = c - query;
+        const float queryDist2 = dot3(queryToCenter, queryToCenter);
+        const float queryProjDist = dot3(queryToCenter, ds.d);
+        const float B = -2 * queryProjDist, Cq = queryDist2 - radius * radius;  // solveQuadratic(1, B, C), util.cpp:447-485
+        float nearT;
+        const float discrim = B * B - 4.0f * 1.0f * Cq;
+        if (discrim < 0) nearT = queryProjDist;
+        else {
+            const float sqrtDiscrim = __builtin_sqrtf(discrim);
+            float temp;
+            if (B < 0) temp = -0.5f * (B - sqrtDiscrim);
+            else temp = -0.5f * (B + sqrtDiscrim);
+            const float x0 = temp / 1.0f, x1 = Cq / temp;
+            nearT = x0 > x1 ? x1 : x0;
+        }
+        ds.dist = baseT + nearT;
+        ds.n = norm3(ds.d * nearT - queryToCenter);
+        const F3 pd = (c + ds.n * radius) - ref;  // the shadow ray goes to dRec.p (scene.cpp:889-893), not along dRec.d
+        ds.sdist = len3(pd);
+        ds.sd = div3(pd, ds.sdist);
+    } else {  // inside: uniform over the sphere (warp::squareToUniformSphere, warp.cpp:25-31)
+        const float z = 1.0f - 2.0f * sy;
+        const float r = __builtin_sqrtf(ppg_max(0.0f, 1.0f - z * z));
+        float sinPhi, cosPhi;
+        ppg_sincos(2.0f * PPG_PI_F * sx, &sinPhi, &cosPhi);
+        const F3 dv = f3(r * cosPhi, r * sinPhi, z);
+        const F3 p = c + dv * radius;
+        ds.n = dv;
+        F3 dd = p - ref;
+        const float dist2 = dot3(dd, dd);
+        ds.dist = __builtin_sqrtf(dist2);
+        ds.d = div3(dd, ds.dist);
+        ds.pdf = invSurfaceArea * dist2 / ppg_abs(dot3(ds.d, ds.n));
+        ds.sd = ds.d; ds.sdist = ds.dist;
+    }
+    if (__float_as_int(Q[3].w)) ds.n = ds.n * -1.0f;
+}
+D float sphere_pdf_direct(const float4 *Q, F3 ref, F3 d, F3 n, float dist) {
+    const float4 c4 = Q[0];
+    const F3 refToCenter = f3(c4.x, c4.y, c4.z) - ref;
+    const float invRefDist = 1.0f / len3(refToCenter);
+    const float sinAlpha = c4.w * invRefDist;
+    if (sinAlpha < 1 - PPG_EPSILON) {
+        const float cosAlpha = __builtin_sqrtf(ppg_max(0.0f, 1 - sinAlpha * sinAlpha));
+        return (PPG_INV_PI_F * 0.5f) / (1 - cosAlpha);
+    }
+    const float invSurfaceArea = 1 / (4 * PPG_PI_F * c4.w * c4.w);
+    return invSurfaceArea * dist * dist / ppg_abs(dot3(d, n));
+}
 D F3 emitter_sample_direct(const DevScene &S, F3 ref, F3 refN, float sx, float sy, DirectSample &ds) {
     ds.pdf = 0; ds.em_pdf = 0; ds.dist = 0; ds.n = f3s(0.0f); ds.d = f3s(0.0f); ds.is_env = false; ds.sd = f3s(0.0f); ds.sdist = 0;
     const int n_sel = S.n_emitters + (S.env.w != 0 ? 1 : 0);
@@ -458,6 +608,15 @@ D F3 emitter_sample_direct(const DevScene &S, F3 ref, F3 refN, float sx, float s
     }
     const int4 info = S.em_info[e];
     if (info.y == 0) return f3s(0.0f);
+    if (info.y < 0) {  // the emitter is an analytic sphere: AreaLight::sampleDirect (area.cpp:158-173) on Sphere::sampleDirect
+        sphere_sample_direct(S.spheres + 4 * (-info.y - 1), ref, sx, sy, ds);
+        if (!(dot3(ds.d, refN) >= 0 && dot3(ds.d, ds.n) < 0 && ds.pdf != 0)) {
+            ds.pdf = 0.0f;
+            return f3s(0.0f);
+        }
+        const float4 r = S.emitters[e];
+        return div3(f3(r.x, r.y, r.z), ds.pdf);
+    }
     const float *acdf = S.em_area_cdf + info.z;
     const int ti = pmf_sample(acdf, info.y + 1, sy);
     const float a0 = acdf[ti], a1 = acdf[ti + 1];

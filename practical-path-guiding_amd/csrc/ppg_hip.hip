@@ -258,6 +258,7 @@ struct ppg_ctx {
     bool fullMaterials = false;
     DevBuf<float4> d_tris, d_accel, d_accelSmall, d_normals, d_materials, d_emitters, d_emTris, d_emNrm;
     DevBuf<float> d_rtrans;  // ppg_scene.rtrans (roughplastic slices)
+    DevBuf<float4> d_spheres;  // 4 float4 per analytic sphere (DevScene::spheres)
     DevBuf<float> d_emSel, d_emArea, d_neeCos;
     DevBuf<int4> d_emInfo;
     DevBuf<BvhNode> d_bvh;
@@ -607,7 +608,7 @@ int renderBatch(ppg_ctx *ctx, int batch) {
     const int grid = ctx->nBlocks;
     const int gridAll = gridFor(P.n_paths);
     hipStream_t s = ctx->stream;
-    const bool smallScene = ctx->scene.n_tris <= 64 && ctx->ldsTris == ctx->scene.n_tris && !getenv("PPG_FORCE_BVH");
+    const bool smallScene = ctx->scene.n_tris <= 64 && ctx->ldsTris == ctx->scene.n_tris && ctx->scene.n_spheres == 0 && !getenv("PPG_FORCE_BVH");
     // Tracing inside k_generate / k_shade (no k_trace launch, no ray/hit round trip) was measured SLOWER on MI355X
     // (cbox-720p, 63 passes: 184 ms vs 172 ms for generate+trace+shade): the fused kernel needs 142 VGPRs (3 waves/SIMD)
     // and only the surviving lanes trace.  Kept selectable for re-measurement on other scenes.
@@ -1114,10 +1115,26 @@ int ppg_set_scene(ppg_ctx *ctx, const ppg_scene *s) {
         if (s->materials[s->tri_material[t]].type < 0 || s->materials[s->tri_material[t]].type > PPG_BSDF_LAST) { ctx->error = "unsupported BSDF type"; return PPG_ERR_INVALID; }
         for (int k = 0; k < 3; ++k) if (s->indices[3 * t + k] >= s->n_vertices) { ctx->error = "vertex index out of range"; return PPG_ERR_INVALID; }
     }
+    std::vector<int> emitterSphere(s->n_emitters, -1);  // per emitter: the analytic sphere carrying it
+    if (s->n_spheres) {
+        if (!s->spheres) { ctx->error = "spheres: n_spheres > 0 but no array"; return PPG_ERR_INVALID; }
+        std::vector<int> users(s->n_emitters, 0);
+        for (uint32_t t = 0; t < s->n_triangles; ++t) if (s->tri_emitter[t] >= 0) users[s->tri_emitter[t]] = 1;
+        for (uint32_t k = 0; k < s->n_spheres; ++k) {
+            const ppg_sphere &sp = s->spheres[k];
+            if (!(sp.radius > 0)) { ctx->error = "sphere: radius must be > 0"; return PPG_ERR_INVALID; }
+            if (sp.material >= s->n_materials || sp.emitter >= (int32_t)s->n_emitters) { ctx->error = "index out of range"; return PPG_ERR_INVALID; }
+            if (s->materials[sp.material].type < 0 || s->materials[sp.material].type > PPG_BSDF_LAST) { ctx->error = "unsupported BSDF type"; return PPG_ERR_INVALID; }
+            if (sp.emitter >= 0 && users[sp.emitter]++) { ctx->error = "sphere: its emitter is shared with another shape"; return PPG_ERR_INVALID; }
+            if (sp.emitter >= 0) emitterSphere[sp.emitter] = (int)k;
+        }
+    }
     // Scene::getAABB(): kd-tree box enlarged by MTS_KD_AABB_EPSILON (gkdtree.h:1213-1220) + sensor position (scene.cpp:386-414)
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (size_t t = 0; t < 3 * (size_t)s->n_triangles; ++t)
         for (int a = 0; a < 3; ++a) { float v = s->positions[3 * s->indices[t] + a]; mn[a] = ppg_min(mn[a], v); mx[a] = ppg_max(mx[a], v); }
+    for (uint32_t k = 0; k < s->n_spheres; ++k)  // Sphere::getAABB, sphere.cpp:152-157
+        for (int a = 0; a < 3; ++a) { mn[a] = ppg_min(mn[a], s->spheres[k].center[a] - s->spheres[k].radius); mx[a] = ppg_max(mx[a], s->spheres[k].center[a] + s->spheres[k].radius); }
     const float eps = 1e-3f;
     for (int a = 0; a < 3; ++a) {
         ctx->aabbMin[a] = mn[a] - ((mx[a] - mn[a]) * eps + eps);
@@ -1267,6 +1284,7 @@ int ppg_set_scene(ppg_ctx *ctx, const ppg_scene *s) {
             float area = 0, inv = -1;
             if (!emTris[e].empty()) { normalize(areaCdf, first, emTris[e].size() + 1, area); inv = 1.0f / area; }
             info[e] = make_int4(firstTri, (int)emTris[e].size(), (int)first, __builtin_bit_cast(int, inv));
+            if (emitterSphere[e] >= 0) info[e].y = -(emitterSphere[e] + 1);  // sampled analytically (sphere_sample_direct)
             selCdf.push_back(selCdf.back() + 1.0f);
         }
         if (s->environment) selCdf.push_back(selCdf.back() + 1.0f);  // the environment emitter is the last one
@@ -1298,6 +1316,21 @@ int ppg_set_scene(ppg_ctx *ctx, const ppg_scene *s) {
     S.tris = ctx->d_tris.p; S.accel = ctx->d_accel.p; S.normals = s->normals ? ctx->d_normals.p : nullptr; S.bvh = ctx->d_bvh.p; S.bvh4 = ctx->d_bvh4.p;
     S.materials = ctx->d_materials.p; S.emitters = ctx->d_emitters.p; S.n_tris = (int)s->n_triangles; S.has_null = hasNull ? 1 : 0;
     S.rtrans = s->n_rtrans ? ctx->d_rtrans.p : nullptr; S.rtrans_n = (int)s->rtrans_samples;
+    S.spheres = nullptr; S.n_spheres = (int)s->n_spheres;
+    if (s->n_spheres) {
+        std::vector<float4> sph(4 * (size_t)s->n_spheres);
+        for (uint32_t k = 0; k < s->n_spheres; ++k) {
+            const ppg_sphere &sp = s->spheres[k];
+            sph[4 * k + 0] = make_float4(sp.center[0], sp.center[1], sp.center[2], sp.radius);
+            sph[4 * k + 1] = make_float4(sp.to_world[0], sp.to_world[1], sp.to_world[2], __builtin_bit_cast(float, (int)sp.material));
+            sph[4 * k + 2] = make_float4(sp.to_world[3], sp.to_world[4], sp.to_world[5], __builtin_bit_cast(float, sp.emitter));
+            sph[4 * k + 3] = make_float4(sp.to_world[6], sp.to_world[7], sp.to_world[8], __builtin_bit_cast(float, sp.flip_normals ? 1 : 0));
+        }
+        HIP_CHECK(ctx->d_spheres.reserve(sph.size()));
+        HIP_CHECK(hipMemcpy(ctx->d_spheres.p, sph.data(), sph.size() * sizeof(float4), hipMemcpyHostToDevice));
+        S.spheres = ctx->d_spheres.p;
+        ctx->fullMaterials = true;  // the sphere code lives in the FULL kernel variants, on the BVH path
+    }
     memcpy(S.cam.s2c, s->camera.sample_to_camera, 64); memcpy(S.cam.c2w, s->camera.camera_to_world, 64);
     S.cam.near_clip = s->camera.near_clip; S.cam.far_clip = s->camera.far_clip;
     S.cam.width = s->camera.width; S.cam.height = s->camera.height;

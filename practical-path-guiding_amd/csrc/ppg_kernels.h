@@ -336,6 +336,7 @@ D void trace_slice_bvh4(const PathState &P, const DevScene &S, int *lds_stack, u
         } else if (st.sp > 0) {
             cur = st.pop();
         } else {
+            if (S.n_spheres) sphere_pass<false>(S, o, d, mint, maxt, best);
             P.hit[i] = make_float4(best.t, best.u, best.v, __int_as_float(best.prim));
             ++traced;
             have = false;
@@ -596,19 +597,26 @@ D void commit_single(const DevTree &T, int sfilter, int dfilter, int loss, int l
 // Shadow-ray test of Scene::evalTransmittance (scene.cpp:619-679) without media / null BSDFs: true = occluded.
 // small_tris != nullptr: the whole scene is staged in LDS (brute force); otherwise BVH4 any-hit with this lane's
 // LDS stack column.
+// SPH: the scene may hold analytic spheres (FULL kernels; such scenes never take the LDS brute-force path).
+template <bool SPH = false>
 D bool shadow_occluded(const DevScene &S, const float4 *small_tris, int *stack_col, F3 o, F3 d, float maxt) {
     if (small_tris) return trace_small(small_tris, S, o, d, PPG_EPSILON, maxt).prim >= 0;
     float rayMinT = PPG_EPSILON;  // adaptive ray epsilon, skdtree.cpp:125-129
     rayMinT *= ppg_max(ppg_max(ppg_max(ppg_abs(o.x), ppg_abs(o.y)), ppg_abs(o.z)), PPG_EPSILON);
-    return trace_closest4<true>(S, stack_col, PPG_BLOCK, o, d, rayMinT, maxt).prim >= 0;
+    return trace_closest4<true, SPH>(S, stack_col, PPG_BLOCK, o, d, rayMinT, maxt).prim >= 0;
 }
 
 // closest hit for rays traced inside k_shade (look-through / transmittance loops): LDS brute force or BVH4 with the lane's stack column
-D Hit trace_inline(const DevScene &S, const float4 *small_tris, int *stack_col, F3 o, F3 d, float maxt) {
+D Hit trace_inline(const DevScene &S, const float4 *small_tris, int *stack_col, F3 o, F3 d, float maxt) {  // FULL kernels only
     if (small_tris) return trace_small(small_tris, S, o, d, PPG_EPSILON, maxt);
     float rayMinT = PPG_EPSILON;  // adaptive ray epsilon, skdtree.cpp:125-129
     rayMinT *= ppg_max(ppg_max(ppg_max(ppg_abs(o.x), ppg_abs(o.y)), ppg_abs(o.z)), PPG_EPSILON);
-    return trace_closest4<false>(S, stack_col, PPG_BLOCK, o, d, rayMinT, maxt);
+    return trace_closest4<false, true>(S, stack_col, PPG_BLOCK, o, d, rayMinT, maxt);
+}
+// intersection record of a hit found by trace_inline / k_trace in a FULL kernel: triangle or sphere (`o` = that ray's origin)
+D void fill_isect_full(const DevScene &S, const Hit &h, F3 o, F3 d, Isect &I) {
+    if (h.prim >= S.n_tris) fill_isect_sphere(S, h, o, d, I);
+    else fill_isect(S, h, d, I);
 }
 
 // Scene::evalTransmittance (scene.cpp:619-679), surfaces only, for scenes with null-component BSDFs: zero behind an occluder,
@@ -625,7 +633,7 @@ D F3 shadow_transmittance(const DevScene &S, const float4 *small_tris, int *stac
         const bool surface = h.prim >= 0;
         Mat M;
         Isect I;
-        if (surface) { fill_isect(S, h, d, I); M = load_material(S, I.material); }
+        if (surface) { fill_isect_full(S, h, o, d, I); M = load_material(S, I.material); }
         if (surface && (interactions == maxInteractions || !mat_has_null(M))) return f3s(0.0f);
         if (!surface || iszero3(transmittance)) break;
         const float cosThetaI = dot3(I.geoN, -d);
@@ -678,7 +686,12 @@ D void shade_slice(const PathState &P, const DevScene &S, const DevTree &T, cons
             h.t = h4.x; h.u = h4.y; h.v = h4.z; h.prim = __float_as_int(h4.w);
             const bool valid = h.prim >= 0;
             Isect I;
-            if (valid) fill_isect(S, h, d, I);
+            if (valid) {
+                if (FULL && h.prim >= S.n_tris) {
+                    const float4 ro4 = P.ray_o[i];
+                    fill_isect_sphere(S, h, f3(ro4.x, ro4.y, ro4.z), d, I);
+                } else fill_isect(S, h, d, I);
+            }
             bool go = true;
 
             if (FULL && (flags & FL_PENDING) && (flags & FL_PEND_NULL)) {
@@ -722,7 +735,7 @@ D void shade_slice(const PathState &P, const DevScene &S, const DevTree &T, cons
                             hc = trace_inline(S, nee.small_tris, nee.stack_col, ro, d, __builtin_inff());
                             ++traced;
                             if (hc.prim < 0) { surface = false; break; }
-                            fill_isect(S, hc, d, Ic);
+                            fill_isect_full(S, hc, ro, d, Ic);
                             Mc = load_material(S, Ic.material);
                         }
                         if (!abandoned && surface && Ic.emitter >= 0) {
@@ -743,8 +756,13 @@ D void shade_slice(const PathState &P, const DevScene &S, const DevTree &T, cons
                     const float dn = dot3(d, em_n);
                     if (FULL && em_id == S.n_emitters) {
                         pdfDirect = env_pdf_direct(P.nee_cos[i]);
-                    } else if ((flags & FL_PEND_REFN) && dn < 0)
-                        pdfDirect = __int_as_float(S.em_info[em_id].w) * (em_dist * em_dist) / ppg_abs(dn);
+                    } else if ((flags & FL_PEND_REFN) && dn < 0) {
+                        const int4 info = S.em_info[em_id];
+                        if (FULL && info.y < 0) {  // Sphere::pdfDirect needs dRec.ref = the previous vertex = this ray's origin
+                            const float4 ro4 = P.ray_o[i];
+                            pdfDirect = sphere_pdf_direct(S.spheres + 4 * (-info.y - 1), f3(ro4.x, ro4.y, ro4.z), d, em_n, em_dist);
+                        } else pdfDirect = __int_as_float(info.w) * (em_dist * em_dist) / ppg_abs(dn);
+                    }
                     emitterPdf = pdfDirect * (1.0f * S.em_sel_norm);
                 }
                 float pa = woPdf * woPdf, pb = emitterPdf * emitterPdf;  // miWeight(woPdf, emitterPdf), GP:2247-2250
@@ -901,7 +919,7 @@ D void shade_slice(const PathState &P, const DevScene &S, const DevTree &T, cons
                             else { value = div3(mul3(value, tr), ds.em_pdf); ds.pdf *= ds.em_pdf; }
                         } else {
                             ++traced;
-                            if (shadow_occluded(S, nee.small_tris, nee.stack_col, I.p, ds.sd, ds.sdist * ((FULL && ds.is_env) ? 1.0f : 1 - PPG_SHADOW_EPSILON))) {
+                            if (shadow_occluded<FULL>(S, nee.small_tris, nee.stack_col, I.p, ds.sd, ds.sdist * ((FULL && ds.is_env) ? 1.0f : 1 - PPG_SHADOW_EPSILON))) {
                                 value = f3s(0.0f);
                             } else {
                                 value = div3(value, ds.em_pdf);

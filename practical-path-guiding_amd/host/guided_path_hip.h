@@ -41,6 +41,7 @@ struct SceneData {
     float environment[3] = {0, 0, 0};
     std::vector<float> rtrans;    // rough-transmittance slices of the roughplastic materials, rtransSamples + 1 floats each
     uint32_t rtransSamples = 0;
+    std::vector<ppg_sphere> spheres;  // analytic spheres
 
     ppg_scene view() const {
         ppg_scene s{};
@@ -52,6 +53,7 @@ struct SceneData {
         s.n_emitters = (uint32_t)emitters.size(); s.emitters = emitters.data();
         s.camera = camera;
         s.environment = hasEnvironment ? environment : nullptr;
+        if (!spheres.empty()) { s.n_spheres = (uint32_t)spheres.size(); s.spheres = spheres.data(); }
         if (rtransSamples && !rtrans.empty()) { s.n_rtrans = (uint32_t)(rtrans.size() / (rtransSamples + 1)); s.rtrans_samples = rtransSamples; s.rtrans = rtrans.data(); }
         return s;
     }

@@ -37,7 +37,7 @@ static bool loadScene(const char *path, SceneData &s) {
     s.materials.resize(nm); f.read((char *)s.materials.data(), (size_t)nm * sizeof(ppg_material));
     s.emitters.resize(ne); f.read((char *)s.emitters.data(), (size_t)ne * sizeof(ppg_emitter));
     f.read((char *)&s.camera, sizeof(ppg_camera));
-    s.hasEnvironment = (hdr[5] & 1) != 0;  // hdr[5]: optional blocks, bit 0 environment, bit 1 rtrans
+    s.hasEnvironment = (hdr[5] & 1) != 0;  // hdr[5]: optional blocks, bit 0 environment, bit 1 rtrans, bit 2 spheres
     if (s.hasEnvironment) f.read((char *)s.environment, 12);
     if (hdr[5] & 2) {
         uint32_t rt[2];
@@ -45,6 +45,12 @@ static bool loadScene(const char *path, SceneData &s) {
         if (!f || rt[1] < 2) return false;
         s.rtransSamples = rt[1];
         s.rtrans.resize((size_t)rt[0] * (rt[1] + 1)); f.read((char *)s.rtrans.data(), s.rtrans.size() * 4);
+    }
+    if (hdr[5] & 4) {
+        uint32_t n = 0;
+        f.read((char *)&n, 4);
+        if (!f) return false;
+        s.spheres.resize(n); f.read((char *)s.spheres.data(), (size_t)n * sizeof(ppg_sphere));
     }
     return (bool)f;
 }
@@ -114,7 +120,7 @@ static void writePFM(const char *path, const std::vector<float> &rgb, int w, int
 static bool saveScene(const char *path, const SceneData &s) {
     std::ofstream f(path, std::ios::binary);
     const uint32_t hdr[6] = {(uint32_t)(s.positions.size() / 3), (uint32_t)(s.indices.size() / 3), (uint32_t)s.materials.size(), (uint32_t)s.emitters.size(),
-                             s.normals.empty() ? 0u : 1u, (s.hasEnvironment ? 1u : 0u) | (s.rtrans.empty() ? 0u : 2u)};
+                             s.normals.empty() ? 0u : 1u, (s.hasEnvironment ? 1u : 0u) | (s.rtrans.empty() ? 0u : 2u) | (s.spheres.empty() ? 0u : 4u)};
     f.write("PPGS", 4); f.write((const char *)hdr, sizeof hdr);
     f.write((const char *)s.positions.data(), s.positions.size() * 4);
     if (!s.normals.empty()) f.write((const char *)s.normals.data(), s.normals.size() * 4);
@@ -128,6 +134,10 @@ static bool saveScene(const char *path, const SceneData &s) {
     if (!s.rtrans.empty()) {
         const uint32_t rt[2] = {(uint32_t)(s.rtrans.size() / (s.rtransSamples + 1)), s.rtransSamples};
         f.write((const char *)rt, 8); f.write((const char *)s.rtrans.data(), s.rtrans.size() * 4);
+    }
+    if (!s.spheres.empty()) {
+        const uint32_t n = (uint32_t)s.spheres.size();
+        f.write((const char *)&n, 4); f.write((const char *)s.spheres.data(), (size_t)n * sizeof(ppg_sphere));
     }
     return (bool)f;
 }

@@ -4,7 +4,7 @@
  *
  *   integrator  guided_path (properties of guided_path.cpp:1014-1085 and integrator.cpp:192-218)
  *   sensor      perspective (fov, fovAxis, nearClip, farClip, toWorld), film hdrfilm (width, height; rfilter box)
- *   shapes      obj (filename, toWorld, faceNormals, flipNormals, flipTexCoords, collapse), rectangle (toWorld, flipNormals)
+ *   shapes      sphere (center, radius, toWorld = rotation x uniform scale, flipNormals; analytic), obj (filename, toWorld, faceNormals, flipNormals, flipTexCoords, collapse), rectangle (toWorld, flipNormals)
  *   bsdfs       diffuse, conductor, roughconductor / roughdielectric / roughplastic (ggx / beckmann, isotropic; roughplastic reads Mitsuba's data/microfacet tables), plastic, dielectric, thindielectric, mask (constant opacity),
  *               twosided(BRDF) — top level with id, nested, or <ref id>
  *   emitters    area (nested in a shape), constant (environment)
@@ -449,16 +449,41 @@ public:
             Mat4 m = Mat4::identity();
             if (const XmlNode *tw = sh.child("transform")) m = transform(*tw);
             std::vector<Mesh> meshes;
+            ppg_sphere sphere{};
+            bool isSphere = false;
             if (t == "obj") {
                 if (!pr.count("filename")) throw std::runtime_error("obj shape without filename");
                 if (pr.count("maxSmoothAngle") || pr.count("shapeIndex")) throw std::runtime_error("obj: maxSmoothAngle / shapeIndex are not supported");
                 std::string fn = pr["filename"];
                 if (fn.empty() || fn[0] != '/') fn = m_base + "/" + fn;
+                if (!m_strict && !std::ifstream(fn)) { out.warnings.push_back("shape skipped: Wavefront OBJ file '" + fn + "' not found"); continue; }
                 meshes = loadOBJ(fn, m, flag(pr, "faceNormals", false), flag(pr, "flipNormals", false), flag(pr, "flipTexCoords", true), flag(pr, "collapse", false));
             } else if (t == "rectangle") {
                 meshes.push_back(rectangle(m, flag(pr, "flipNormals", false)));
+            } else if (t == "sphere") {  // Sphere::Sphere, sphere.cpp:108-131: the scale of toWorld goes into the radius, the rest stays a rotation
+                float c[3] = {0, 0, 0};
+                for (auto &pc : sh.children)
+                    if (pc.tag == "point" && pc.get("name") == "center") {
+                        const char *ax[3] = {"x", "y", "z"};
+                        for (int a = 0; a < 3; ++a) if (pc.attr(ax[a])) c[a] = std::stof(sub(pc.get(ax[a])));
+                    }
+                Mat4 o2w = Mat4::identity();
+                o2w.m[3] = c[0]; o2w.m[7] = c[1]; o2w.m[11] = c[2];
+                sphere = ppg_sphere{};
+                sphere.radius = pr.count("radius") ? std::stof(pr["radius"]) : 1.0f;
+                if (sh.child("transform")) {
+                    const float scale = std::sqrt(m.m[0] * m.m[0] + m.m[4] * m.m[4] + m.m[8] * m.m[8]);  // objectToWorld(Vector(1, 0, 0)).length()
+                    Mat4 sc = Mat4::identity();
+                    sc.m[0] = sc.m[5] = sc.m[10] = 1 / scale;
+                    o2w = (m * sc) * o2w;
+                    sphere.radius *= scale;
+                }
+                if (!(sphere.radius > 0)) throw std::runtime_error("Cannot create spheres of radius <= 0");
+                for (int a = 0; a < 3; ++a) { sphere.center[a] = o2w.m[4 * a + 3]; for (int b = 0; b < 3; ++b) sphere.to_world[3 * a + b] = o2w.m[4 * a + b]; }
+                sphere.flip_normals = flag(pr, "flipNormals", false) ? 1 : 0;
+                isSphere = true;
             } else {
-                throw std::runtime_error("shape type '" + t + "' is not supported (obj, rectangle)");
+                throw std::runtime_error("shape type '" + t + "' is not supported (obj, rectangle, sphere)");
             }
             int mat = -1;
             for (auto &c : sh.children) {
@@ -483,6 +508,7 @@ public:
                 out.scene.emitters.push_back(pe);
             }
             for (auto &mm : meshes) parts.push_back(Part{std::move(mm), (uint32_t)mat, em});
+            if (isSphere) { sphere.material = (uint32_t)mat; sphere.emitter = em; out.scene.spheres.push_back(sphere); }
         }
         if (parts.empty()) throw std::runtime_error("scene without shapes");
         bool anyNormals = false;

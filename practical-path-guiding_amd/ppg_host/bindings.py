@@ -90,6 +90,22 @@ class Material(C.Structure):
         return o
 
 
+class Sphere(C.Structure):
+    """ppg_sphere (include/ppg.h).  Scene descriptions carry spheres as dicts: center, radius, material, emitter (-1), flip_normals,
+    to_world (9 floats, row-major rotation; identity by default)."""
+    _fields_ = [("center", C.c_float * 3), ("radius", C.c_float), ("to_world", C.c_float * 9), ("material", C.c_uint32),
+                ("emitter", C.c_int32), ("flip_normals", C.c_int32)]
+
+    @classmethod
+    def from_dict(cls, d):
+        o = cls()
+        o.center[:] = [float(np.float32(v)) for v in d["center"]]
+        o.radius = float(np.float32(d["radius"]))
+        o.to_world[:] = [float(np.float32(v)) for v in np.asarray(d.get("to_world", np.eye(3)), np.float32).reshape(-1)]
+        o.material, o.emitter, o.flip_normals = int(d.get("material", 0)), int(d.get("emitter", -1)), 1 if d.get("flip_normals") else 0
+        return o
+
+
 class Emitter(C.Structure):
     _fields_ = [("radiance", C.c_float * 3), ("_pad", C.c_float)]
 
@@ -104,7 +120,8 @@ class Scene(C.Structure):
                 ("n_triangles", C.c_uint32), ("indices", C.POINTER(C.c_uint32)), ("tri_material", C.POINTER(C.c_uint32)),
                 ("tri_emitter", C.POINTER(C.c_int32)), ("n_materials", C.c_uint32), ("materials", C.POINTER(Material)),
                 ("n_emitters", C.c_uint32), ("emitters", C.POINTER(Emitter)), ("camera", Camera), ("environment", C.POINTER(C.c_float)),
-                ("n_rtrans", C.c_uint32), ("rtrans_samples", C.c_uint32), ("rtrans", C.POINTER(C.c_float))]
+                ("n_rtrans", C.c_uint32), ("rtrans_samples", C.c_uint32), ("rtrans", C.POINTER(C.c_float)),
+                ("n_spheres", C.c_uint32), ("spheres", C.POINTER(Sphere))]
 
 
 class _StatsMixin:
@@ -223,12 +240,18 @@ class Engine:
         if rt is not None and len(rt):
             rt = np.ascontiguousarray(rt, np.float32)
             s.n_rtrans, s.rtrans_samples, s.rtrans = rt.shape[0], rt.shape[1] - 1, _fp(rt)
+        sph = getattr(desc, "spheres", None) or []
+        sph_arr = (Sphere * max(1, len(sph)))()
+        for i, d in enumerate(sph):
+            sph_arr[i] = Sphere.from_dict(d)
+        if sph:
+            s.n_spheres, s.spheres = len(sph), sph_arr
         cam = desc.camera
         s.camera.sample_to_camera[:] = [float(v) for v in np.asarray(cam["sample_to_camera"], np.float32).reshape(-1)]
         s.camera.camera_to_world[:] = [float(v) for v in np.asarray(cam["camera_to_world"], np.float32).reshape(-1)]
         s.camera.near_clip, s.camera.far_clip = cam["near_clip"], cam["far_clip"]
         s.camera.width, s.camera.height = cam["width"], cam["height"]
-        self._scene_keep = (pos, idx, tm, te, nrm, mats, ems, rt)
+        self._scene_keep = (pos, idx, tm, te, nrm, mats, ems, rt, sph_arr)
         self._call("set_scene", C.byref(s))
         self.width, self.height = cam["width"], cam["height"]
 

@@ -4,7 +4,8 @@
   sensor      perspective (fov, fovAxis, nearClip, farClip, toWorld; focusDistance ignored: pinhole),
               nested sampler (independent; sampleCount / seed do not steer guided_path, GP:1342-1374) and
               film hdrfilm (width, height; rfilter box)
-  shapes      obj (filename, toWorld, faceNormals, flipNormals, flipTexCoords, collapse), rectangle (toWorld, flipNormals)
+  shapes      obj (filename, toWorld, faceNormals, flipNormals, flipTexCoords, collapse), rectangle (toWorld, flipNormals),
+              sphere (center, radius, toWorld = rotation x uniform scale, flipNormals) — analytic, not tessellated
   bsdfs       diffuse, conductor (material none, or explicit eta / k), roughconductor / roughdielectric / roughplastic (ggx / beckmann, isotropic; roughplastic reads Mitsuba's data/microfacet tables),
               plastic, dielectric, thindielectric,
               mask (constant opacity), twosided(any of the BRDFs) — top level with id, nested, or <ref id>
@@ -294,6 +295,8 @@ def _props(elem, sub):
             out[n] = float(sub(c.get("value")))
         elif c.tag == "string":
             out[n] = sub(c.get("value"))
+        elif c.tag == "point":
+            out[n] = tuple(float(sub(c.get(k, "0"))) for k in "xyz")
     return out
 
 
@@ -510,7 +513,7 @@ def load_scene(path, defines=None, strict=True, width=None, height=None, data_di
         raise SceneError("emitter type %r is not supported (area emitters on shapes and one `constant` environment emitter; SURVEY.md §8 f2)" % em.get("type"))
 
     # ---- shapes
-    collected, emitters = [], []
+    collected, emitters, spheres = [], [], []
     default_mat = None
     for sh in root.findall("shape"):
         t = sh.get("type")
@@ -525,13 +528,30 @@ def load_scene(path, defines=None, strict=True, width=None, height=None, data_di
                 raise SceneError("obj: maxSmoothAngle / shapeIndex are not supported")
             full = fn if os.path.isabs(fn) else os.path.join(base, fn)
             if not os.path.exists(full):
-                raise SceneError("Wavefront OBJ file '%s' not found!" % full)  # obj.cpp:230
+                if strict:
+                    raise SceneError("Wavefront OBJ file '%s' not found!" % full)  # obj.cpp:230
+                warnings.append("shape skipped: Wavefront OBJ file '%s' not found" % full)
+                continue
             meshes = load_obj(full, m, bool(sprops.get("faceNormals", False)), bool(sprops.get("flipNormals", False)),
                               bool(sprops.get("flipTexCoords", True)), bool(sprops.get("collapse", False)))
         elif t == "rectangle":
             meshes = [rectangle_mesh(m, bool(sprops.get("flipNormals", False)))]
+        elif t == "sphere":  # Sphere::Sphere, sphere.cpp:108-131: the scale of toWorld goes into the radius, the rest stays a rotation
+            meshes = []
+            c = np.asarray(sprops.get("center", (0.0, 0.0, 0.0)), f32)
+            o2w = _translate(*[float(v) for v in c])
+            radius = f32(sprops.get("radius", 1.0))
+            if tw is not None:
+                scale = np.sqrt(np.sum(m[:3, 0] * m[:3, 0], dtype=f32), dtype=f32)  # objectToWorld(Vector(1, 0, 0)).length()
+                o2w = (m @ _scale(*[float(f32(1) / scale)] * 3)).astype(f32) @ o2w
+                o2w = o2w.astype(f32)
+                radius = f32(radius * scale)
+            if not radius > 0:
+                raise SceneError("Cannot create spheres of radius <= 0")
+            sphere = dict(center=tuple(float(v) for v in o2w[:3, 3]), radius=float(radius), to_world=[float(v) for v in o2w[:3, :3].reshape(-1)],
+                          flip_normals=bool(sprops.get("flipNormals", False)))
         else:
-            raise SceneError("shape type %r is not supported (obj, rectangle)" % t)
+            raise SceneError("shape type %r is not supported (obj, rectangle, sphere)" % t)
         # material: nested <bsdf> or <ref id>; Mitsuba's default is diffuse(0.5)
         mat = None
         for c in sh:
@@ -553,10 +573,14 @@ def load_scene(path, defines=None, strict=True, width=None, height=None, data_di
                 raise SceneError("emitter type %r on a shape is not supported (area only)" % e.get("type"))
             if len(meshes) > 1:
                 raise SceneError("Cannot attach an emitter to an OBJ file containing multiple objects!")  # obj.cpp:757-759
+            if t == "obj" and not meshes:
+                continue
             em = len(emitters)
             emitters.append(dict(radiance=tuple(float(v) for v in colour(e, "radiance", 1.0))))
         for mesh in meshes:
             collected.append((mesh, mat, em))
+        if t == "sphere":
+            spheres.append(dict(sphere, material=mat, emitter=em))
     if not collected:
         raise SceneError("scene without shapes")
     # one vertex-normal array for the whole scene: a faceNormals mesh living next to smooth ones gets its vertices
@@ -580,7 +604,7 @@ def load_scene(path, defines=None, strict=True, width=None, height=None, data_di
         tmat.append(np.full(T, mat, np.uint32)); tem.append(np.full(T, em, np.int32))
     normals = np.concatenate(nrm).astype(f32) if any_normals else None
     desc = SceneDesc(np.concatenate(pos).astype(f32), np.concatenate(idx).astype(np.uint32), np.concatenate(tmat), np.concatenate(tem),
-                     materials, emitters, camera, normals, environment, np.stack(rt_slices).astype(f32) if rt_slices else None)
+                     materials, emitters, camera, normals, environment, np.stack(rt_slices).astype(f32) if rt_slices else None, spheres)
     info["warnings"] = warnings
     return desc, props, info
 
@@ -650,7 +674,28 @@ def save_scene_xml(desc, props, directory, name="scene"):
     tm, te = np.asarray(desc.tri_material), np.asarray(desc.tri_emitter)
     idx, pos = np.asarray(desc.indices), np.asarray(desc.positions)
     groups = sorted({(int(a), int(b)) for a, b in zip(tm, te)}, key=lambda g: (g[1] < 0, g[1], g[0]))  # emitters first, in emitter order
-    for gi, (mat, em) in enumerate(groups):
+    # shapes in emitter order (the loader numbers emitters in shape order), shapes without an emitter last
+    shapes = [("mesh", g) for g in groups] + [("sphere", sp) for sp in (getattr(desc, "spheres", None) or [])]
+    em_of = lambda rec: rec[1][1] if rec[0] == "mesh" else int(rec[1].get("emitter", -1))  # noqa: E731
+    shapes.sort(key=lambda rec: (em_of(rec) < 0, em_of(rec)))
+    for gi, (kind, rec) in enumerate(shapes):
+        if kind == "sphere":
+            out.append('\t<shape type="sphere">')
+            R = np.asarray(rec.get("to_world", np.eye(3)), np.float32).reshape(3, 3)
+            if np.array_equal(R, np.eye(3, dtype=np.float32)):
+                out.append('\t\t<point name="center" x="%r" y="%r" z="%r"/>' % tuple(float(np.float32(v)) for v in rec["center"]))
+            else:
+                M4 = np.eye(4, dtype=np.float32); M4[:3, :3] = R; M4[:3, 3] = rec["center"]
+                out.append('\t\t<transform name="toWorld"><matrix value="%s"/></transform>' % " ".join(repr(float(x)) for x in M4.reshape(-1)))
+            out.append('\t\t<float name="radius" value="%r"/>' % float(np.float32(rec["radius"])))
+            if rec.get("flip_normals"):
+                out.append('\t\t<boolean name="flipNormals" value="true"/>')
+            out.append('\t\t<ref id="mat%d"/>' % int(rec.get("material", 0)))
+            if int(rec.get("emitter", -1)) >= 0:
+                out.append('\t\t<emitter type="area"><rgb name="radiance" value="%s"/></emitter>' % c(desc.emitters[int(rec["emitter"])]["radiance"]))
+            out.append('\t</shape>')
+            continue
+        mat, em = rec
         sel = np.nonzero((tm == mat) & (te == em))[0]
         fn = "meshes/%s_%03d.obj" % (name, gi)
         with open(os.path.join(directory, fn), "w") as f:

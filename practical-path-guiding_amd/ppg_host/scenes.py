@@ -16,12 +16,13 @@ import numpy as np
 
 
 class SceneDesc:
-    def __init__(self, positions, indices, tri_material, tri_emitter, materials, emitters, camera, normals=None, environment=None, rtrans=None):
+    def __init__(self, positions, indices, tri_material, tri_emitter, materials, emitters, camera, normals=None, environment=None, rtrans=None, spheres=None):
         self.positions, self.indices = positions, indices
         self.tri_material, self.tri_emitter = tri_material, tri_emitter
         self.materials, self.emitters, self.camera, self.normals = materials, emitters, camera, normals
         self.environment = environment  # None or (r, g, b): constant environment emitter
         self.rtrans = rtrans            # None or float32 [n_slices, samples + 1]: rough-transmittance slices of the roughplastic materials
+        self.spheres = spheres or []    # analytic spheres: dicts {center, radius, material, emitter, flip_normals, to_world} (bindings.Sphere)
 
     @property
     def n_triangles(self):
@@ -30,9 +31,10 @@ class SceneDesc:
 
 def save_scene(desc, path):
     """Write the flat binary scene read by host/ppg_render.cpp: "PPGS", 6 x uint32 {n_vertices, n_triangles, n_materials,
-    n_emitters, has_normals, blocks (bit 0: environment, bit 1: rtrans)}, then positions, [normals], indices, tri_material,
+    n_emitters, has_normals, blocks (bit 0: environment, bit 1: rtrans, bit 2: spheres)}, then positions, [normals], indices, tri_material,
     tri_emitter, materials (ppg_material, 80 bytes each), emitters (4 floats), camera (ppg_camera), [environment radiance:
-    3 floats], [rtrans: 2 x uint32 {n_slices, samples}, then n_slices x (samples + 1) floats]."""
+    3 floats], [rtrans: 2 x uint32 {n_slices, samples}, then n_slices x (samples + 1) floats], [spheres: uint32 n, then n x ppg_sphere
+    (64 bytes)]."""
     import struct
     pos = np.ascontiguousarray(desc.positions, np.float32)
     idx = np.ascontiguousarray(desc.indices, np.uint32)
@@ -42,7 +44,7 @@ def save_scene(desc, path):
         rt = getattr(desc, "rtrans", None)
         rt = None if rt is None or not len(rt) else np.ascontiguousarray(rt, np.float32)
         f.write(struct.pack("<6I", pos.shape[0], idx.shape[0], len(desc.materials), len(desc.emitters), 0 if desc.normals is None else 1,
-                            (0 if env is None else 1) | (0 if rt is None else 2)))
+                            (0 if env is None else 1) | (0 if rt is None else 2) | (4 if getattr(desc, "spheres", None) else 0)))
         f.write(pos.tobytes())
         if desc.normals is not None:
             f.write(np.ascontiguousarray(desc.normals, np.float32).tobytes())
@@ -63,6 +65,11 @@ def save_scene(desc, path):
         if rt is not None:
             f.write(struct.pack("<2I", rt.shape[0], rt.shape[1] - 1))
             f.write(rt.tobytes())
+        if getattr(desc, "spheres", None):
+            from .bindings import Sphere
+            f.write(struct.pack("<I", len(desc.spheres)))
+            for d in desc.spheres:
+                f.write(bytes(Sphere.from_dict(d)))
 
 
 def _sample_to_camera(fov_deg, fov_axis, near, far, width, height):

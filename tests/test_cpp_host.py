@@ -137,10 +137,17 @@ def _read_ppgs(path):
     out["s2c"] = take(np.float32, 16); out["c2w"] = take(np.float32, 16)
     out["clip"] = take(np.float32, 2); out["size"] = take(np.int32, 2)
     out["env"] = take(np.float32, 3) if has_env else None
+    has_sph = blocks & 4
     out["rtrans"] = None
     if has_rt:
         n, samples = take(np.uint32, 2)
         out["rtrans"] = take(np.float32, int(n) * (int(samples) + 1)).reshape(int(n), int(samples) + 1)
+    out["spheres"] = []
+    if has_sph:
+        (n,) = take(np.uint32, 1)
+        for _ in range(int(n)):
+            f = take(np.float32, 13); i = take(np.int32, 3)
+            out["spheres"].append(dict(center=tuple(f[:3]), radius=float(f[3]), to_world=f[4:13].copy(), material=int(i[0]), emitter=int(i[1]), flip_normals=int(i[2])))
     assert off == len(buf)
     return out
 
@@ -170,6 +177,10 @@ def test_cpp_scene_xml_loader_equals_the_python_loader(ppg_render, tmp_path):
     <shape type="rectangle"><bsdf type="conductor"><rgb name="eta" value="0.2, 0.9, 1.1"/><rgb name="k" value="3.9, 2.4, 2.1"/></bsdf></shape>
     <shape type="obj"><string name="filename" value="meshes/cube.obj"/><transform name="toWorld"><rotate x="1" y="1" angle="33"/><translate x="3"/></transform></shape>
     <emitter type="constant"><srgb name="radiance" value="0.5, 0.6, 0.7"/></emitter>
+    <shape type="sphere"><point name="center" x="1" y="2" z="3"/><float name="radius" value="0.5"/><ref id="m1"/></shape>
+    <shape type="sphere"><boolean name="flipNormals" value="true"/><float name="radius" value="2"/>
+        <transform name="toWorld"><rotate x="1" y="1" angle="33"/><scale value="3"/><translate x="5" y="6" z="7"/></transform>
+        <emitter type="area"><rgb name="radiance" value="0.3, 0.4, 0.5"/></emitter></shape>
     """
     xml = _write(tmp_path, extra)
     # a cube with shared vertices and no normals: TriMesh::computeNormals generates them
@@ -181,6 +192,10 @@ def test_cpp_scene_xml_loader_equals_the_python_loader(ppg_render, tmp_path):
     desc, props, _ = ppg_host.load_scene(xml, defines=dict(nee="kickstart"))
     assert np.array_equal(c["indices"], desc.indices) and np.array_equal(c["tri_material"], desc.tri_material) and np.array_equal(c["tri_emitter"], desc.tri_emitter)
     assert np.allclose(c["positions"], desc.positions, rtol=1e-6, atol=1e-6) and np.allclose(c["normals"], desc.normals, rtol=1e-5, atol=1e-6)
+    assert len(c["spheres"]) == len(desc.spheres) == 2
+    for a, b in zip(c["spheres"], desc.spheres):
+        assert np.allclose(a["center"], b["center"], rtol=1e-6) and abs(a["radius"] - b["radius"]) < 1e-5 * b["radius"] and np.allclose(a["to_world"], b["to_world"], atol=1e-6)
+        assert (a["material"], a["emitter"], a["flip_normals"]) == (b["material"], b["emitter"], int(b["flip_normals"]))
     py_mats = [bytes(Material.from_dict(m)) for m in desc.materials]
     assert len(c["materials"]) == len(py_mats)
     for a, b in zip(c["materials"], py_mats):
@@ -228,7 +243,7 @@ def test_cpp_roughplastic_slices_equal_the_python_loader(ppg_render, tmp_path):
 
 def test_cpp_scene_xml_loader_errors(ppg_render, tmp_path):
     from test_mitsuba_xml import _write
-    for extra, needle in (('<shape type="sphere"/>', "sphere"), ('<shape type="rectangle"><bsdf type="ward"/></shape>', "ward"),
+    for extra, needle in (('<shape type="cylinder"/>', "cylinder"), ('<shape type="rectangle"><bsdf type="ward"/></shape>', "ward"),
                           ('<emitter type="sunsky"/>', "sunsky"), ('<shape type="obj"><string name="filename" value="meshes/missing.obj"/></shape>', "not found")):
         r, _ = _cpp_load(ppg_render, _write(tmp_path, extra), tmp_path, "-D", "nee=never")
         assert r.returncode == 2 and needle in r.stderr, r.stderr

@@ -550,6 +550,61 @@ def test_rough_plastic_against_oracle(oracle_lib, extra):
         ppg_host.GuidedPathTracer(engine=hip(**props)).render(bad)
 
 
+def _sphere_scene(res, sky=False):
+    """CBOX whose tall box is replaced by nothing and which gains three analytic spheres (shapes/sphere.cpp): a glass ball, a rotated
+    rough-gold ball (its (theta, phi) tangent frame steers the microfacet sampling) and a small sphere LAMP; `sky`: everything sits
+    inside a large emitting sphere with flipped normals, the sky dome of the reference's SPACESHIP scene."""
+    import ppg_host
+    scene = ppg_host.cbox_scene(*res)
+    base = len(scene.materials)
+    scene.materials = list(scene.materials) + [
+        dict(type="dielectric", eta=1.5, reflectance=(1, 1, 1), specular=(1, 1, 1)),
+        dict(type="roughconductor", alpha=0.15, eta=(0.143, 0.375, 1.442), k=(3.983, 2.386, 1.603), reflectance=(1, 1, 1)),
+        dict(type="diffuse", reflectance=(0.5, 0.5, 0.5))]
+    scene.emitters = list(scene.emitters) + [dict(radiance=(40.0, 30.0, 20.0))]
+    a = np.float32(0.6)
+    rot = [float(np.cos(a)), 0.0, float(np.sin(a)), 0.0, 1.0, 0.0, float(-np.sin(a)), 0.0, float(np.cos(a))]
+    scene.spheres = [dict(center=(370.0, 90.0, 200.0), radius=90.0, material=base + 0),
+                     dict(center=(150.0, 250.0, 320.0), radius=70.0, material=base + 1, to_world=rot),
+                     dict(center=(420.0, 400.0, 380.0), radius=25.0, material=base + 2, emitter=1)]
+    keep = np.ones(len(scene.indices), bool); keep[24:36] = False          # drop the tall box (the glass ball stands there)
+    scene.indices, scene.tri_material, scene.tri_emitter = scene.indices[keep], scene.tri_material[keep], scene.tri_emitter[keep]
+    if sky:
+        scene.emitters = scene.emitters + [dict(radiance=(0.3, 0.3, 0.35))]
+        scene.spheres.append(dict(center=(278.0, 273.0, 280.0), radius=3000.0, material=base + 2, emitter=2, flip_normals=True))
+        keep = np.ones(len(scene.indices), bool); keep[4:6] = False        # open the ceiling towards the dome
+        scene.indices, scene.tri_material, scene.tri_emitter = scene.indices[keep], scene.tri_material[keep], scene.tri_emitter[keep]
+    return scene
+
+
+@pytest.mark.parametrize("extra,sky", [({}, False), (dict(nee="always", **IMPROVED), False), (dict(nee="kickstart", bsdfSamplingFractionLoss="kl"), True),
+                                       (dict(maxDepth=-1, rrDepth=3, strictNormals=0), True)],
+                         ids=["default", "nee-always-improved", "sky-dome-kickstart", "sky-dome-unbounded"])
+def test_analytic_spheres_against_oracle(oracle_lib, extra, sky):
+    """shapes/sphere.cpp as a primitive next to the triangles: the reference's double-precision quadratic (sphere.cpp:164-189) after the
+    BVH's closest triangle, intersection records re-projected onto the sphere with the (theta, phi) tangent (:213-263), sphere emitters
+    sampled by cone (outside) or area (inside) with the matching pdfDirect in the MIS weights (:291-378), and a scene box / S-tree
+    that now spans the dome."""
+    import ppg_host
+    scene = _sphere_scene((64, 64), sky)
+    props = dict(CBOX_PROPS, budget=60, seed=52)
+    props.update(maxDepth=10, rrDepth=5)
+    props.update(extra)
+    g, o = hip(**props), make_oracle(oracle_lib, threads=os.cpu_count() or 8, **props)
+    gg, go = ppg_host.GuidedPathTracer(engine=g), ppg_host.GuidedPathTracer(engine=o)
+    ig, io = gg.render(scene), go.render(scene)
+    assert _stats(gg) == _stats(go)
+    assert np.array_equal(ig, io, equal_nan=True)
+    assert_tree_equal(g.read_sdtree(), o.read_sdtree())
+    plain = ppg_host.GuidedPathTracer(engine=hip(**props)).render(ppg_host.cbox_scene(64, 64))
+    assert np.nanmean(np.abs(ig - plain)) > 5e-3
+    if not sky:
+        bad = _sphere_scene((16, 16))
+        bad.spheres[2]["emitter"] = 0                                      # the ceiling lamp's emitter
+        with pytest.raises(ppg_host.PPGError, match="shared"):
+            ppg_host.GuidedPathTracer(engine=hip(**props)).render(bad)
+
+
 def _pane_scene(res):
     """CBOX + two thin-dielectric panes: a horizontal one between the (upward-facing) luminaire and the ceiling and a vertical
     "window" across the room — most paths cross a null component, emitters are found through one or two panes."""

@@ -150,7 +150,7 @@ def test_loader_subset_semantics(tmp_path):
 
 
 @pytest.mark.parametrize("extra,needle", [
-    ('<shape type="sphere"/>', "sphere"),
+    ('<shape type="cylinder"/>', "cylinder"),
     ('<shape type="rectangle"><bsdf type="ward"/></shape>', "ward"),
     ('<shape type="rectangle"><bsdf type="conductor"><string name="material" value="Au"/></bsdf></shape>', "Au"),
     ('<emitter type="sunsky"/>', "sunsky"),
@@ -299,3 +299,53 @@ def test_environment_emitter_in_xml_and_flat_file(tmp_path):
     assert struct.unpack_from("<6I", raw, 4)[5] == 1 and struct.unpack_from("<3f", raw, len(raw) - 12) == (0.25, 0.5, 1.0)
     with pytest.raises(mitsuba_xml.SceneError, match="envmap"):
         ppg_host.load_scene(_write(tmp_path, '<emitter type="envmap"/>'), defines=dict(nee="never"))
+
+
+def test_sphere_shapes_follow_the_reference_constructor(tmp_path):
+    """Sphere::Sphere (sphere.cpp:108-131): `center` / `radius`, and a toWorld whose (uniform) scale is moved into the radius while
+    rotation and translation stay in the object-to-world transform — the rotation orients the (theta, phi) tangent frame."""
+    import struct
+    xml = _write(tmp_path, """
+    <shape type="sphere"><point name="center" x="1" y="2" z="3"/><float name="radius" value="0.5"/></shape>
+    <shape type="sphere"><boolean name="flipNormals" value="true"/><transform name="toWorld"><scale x="100" y="100" z="100"/></transform>
+        <emitter type="area"><rgb name="radiance" value="0.3, 0.3, 0.3"/></emitter></shape>
+    <shape type="sphere"><float name="radius" value="2"/><transform name="toWorld"><rotate y="1" angle="90"/><scale value="3"/><translate x="5" y="6" z="7"/></transform>
+        <bsdf type="dielectric"/></shape>""")
+    desc, _, info = ppg_host.load_scene(xml, defines=dict(nee="never"))
+    a, b, c = desc.spheres
+    assert a["center"] == (1.0, 2.0, 3.0) and a["radius"] == 0.5 and not a["flip_normals"] and a["emitter"] == -1
+    assert np.array_equal(np.reshape(a["to_world"], (3, 3)), np.eye(3))
+    assert b["center"] == (0.0, 0.0, 0.0) and abs(b["radius"] - 100.0) < 1e-4 and b["flip_normals"]
+    assert np.allclose(np.reshape(b["to_world"], (3, 3)), np.eye(3), atol=1e-6)
+    assert desc.emitters[b["emitter"]]["radiance"] == pytest.approx((0.3, 0.3, 0.3)) and b["emitter"] == len(desc.emitters) - 1
+    assert desc.materials[b["material"]]["type"] == 0                       # Mitsuba's default BSDF: diffuse(0.5)
+    assert np.allclose(c["center"], (5, 6, 7)) and abs(c["radius"] - 6.0) < 1e-5 and desc.materials[c["material"]]["type"] == 6
+    R = np.reshape(c["to_world"], (3, 3))                                   # rotate 90 deg about y: x -> -z, z -> x
+    assert np.allclose(R, [[0, 0, 1], [0, 1, 0], [-1, 0, 0]], atol=1e-6)
+    # flat file: block bit 2, then ppg_sphere records of 64 bytes
+    p = str(tmp_path / "s.ppgs")
+    ppg_host.save_scene(desc, p)
+    raw = open(p, "rb").read()
+    assert struct.unpack_from("<6I", raw, 4)[5] & 4
+    n = struct.unpack_from("<I", raw, len(raw) - 4 - 3 * 64)[0]
+    rec = struct.unpack_from("<4f9fIii", raw, len(raw) - 64)
+    assert n == 3 and rec[:4] == pytest.approx((5, 6, 7, 6.0)) and rec[13:] == (c["material"], -1, 0)
+    # XML round trip keeps spheres and the emitter numbering
+    back, _, _ = ppg_host.load_scene(ppg_host.save_scene_xml(desc, dict(budgetType="spp", budget=8.0), str(tmp_path / "rt")))
+    key = lambda sp: tuple(np.round(sp["center"], 3))  # noqa: E731
+    for sp in desc.spheres:
+        (q,) = [x for x in back.spheres if key(x) == key(sp)]
+        assert abs(q["radius"] - sp["radius"]) < 1e-4 and bool(q["flip_normals"]) == bool(sp["flip_normals"]) and np.allclose(q["to_world"], sp["to_world"], atol=1e-6)
+        assert (q["emitter"] < 0) == (sp["emitter"] < 0)
+        if sp["emitter"] >= 0:
+            assert back.emitters[q["emitter"]]["radiance"] == pytest.approx(desc.emitters[sp["emitter"]]["radiance"])
+    with pytest.raises(mitsuba_xml.SceneError, match="radius"):
+        ppg_host.load_scene(_write(tmp_path, '<shape type="sphere"><float name="radius" value="0"/></shape>'), defines=dict(nee="never"))
+
+
+def test_lenient_loading_skips_missing_meshes(tmp_path):
+    xml = _write(tmp_path, '<shape type="obj"><string name="filename" value="meshes/not-there.obj"/></shape>')
+    with pytest.raises(mitsuba_xml.SceneError, match="not found"):
+        ppg_host.load_scene(xml, defines=dict(nee="never"))
+    desc, _, info = ppg_host.load_scene(xml, defines=dict(nee="never"), strict=False)
+    assert any("not-there.obj" in w for w in info["warnings"]) and desc.n_triangles > 0

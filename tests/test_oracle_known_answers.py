@@ -233,3 +233,43 @@ def test_constant_environment_emitter_furnace_and_mis(oracle_lib):
         e = make_oracle(oracle_lib, threads=4, budgetType="spp", budget=4, maxDepth=3, nee="never", seed=2, hideEmitters=hide)
         img = ppg_host.GuidedPathTracer(engine=e).render(scene)
         assert np.allclose(img.reshape(-1, 3), want)
+
+
+def test_analytic_sphere_lamp_and_sky_sphere(oracle_lib):
+    """shapes/sphere.cpp as an area emitter.  (1) A sphere lamp (radius r, radiance L) at height 1 over a diffuse floor: the irradiance
+    from a uniform sphere is exactly pi L (r / D)^2 cos(theta), so with direct light only the floor shows rho L r^2 cos / D^2 — for
+    BSDF sampling (the double-precision ray test, sphere.cpp:164-189, and Sphere::pdfDirect in the MIS weight) and for luminaire
+    sampling (the cone of Sphere::sampleDirect, sphere.cpp:291-334).  (2) The camera INSIDE an emitting sphere with flipped normals
+    and the default diffuse(0.5) BSDF — the sky dome of the reference's SPACESHIP scene: a furnace, every pixel L / (1 - 0.5); with
+    next-event estimation the inside branch of sampleDirect (uniform area sampling, sphere.cpp:335-349) takes part."""
+    import ppg_host
+    from conftest import make_oracle
+    res = 24
+    scene = _floor_and_lamp(res)
+    scene.indices, scene.tri_material, scene.tri_emitter = scene.indices[:2], scene.tri_material[:2], scene.tri_emitter[:2]  # floor only
+    r = 0.1
+    scene.spheres = [dict(center=(0.0, 1.0, 0.0), radius=r, material=1, emitter=0)]
+    half = 30.0 * np.tan(np.radians(2.0))
+    xs = (np.arange(res) + 0.5) / res * 2 * half - half
+    X, Z = np.meshgrid(xs, xs)
+    D2 = X ** 2 + Z ** 2 + 1.0
+    analytic = 0.5 * 100.0 * r * r / D2 / np.sqrt(D2)
+    outside = (np.abs(X) > 0.2) | (np.abs(Z) > 0.2)  # the lamp itself hides the centre
+    for nee, budget, tol in (("always", 64, 0.01), ("never", 1024, 0.04)):
+        e = make_oracle(oracle_lib, threads=16, budgetType="spp", budget=budget, maxDepth=2, rrDepth=10, nee=nee, seed=3)
+        img = ppg_host.GuidedPathTracer(engine=e).render(scene)[..., 0]
+        assert abs(img[outside].mean() / analytic[outside].mean() - 1) < tol, (nee, img[outside].mean(), analytic[outside].mean())
+        if nee == "always":
+            assert np.abs(img - analytic.T)[outside].mean() / analytic[outside].mean() < 0.03
+            assert img[res // 2, res // 2] > 50.0     # the camera sees the lamp itself in the centre
+    # (2) the sky dome: one far-away triangle (the C-ABI wants a mesh), the camera at the dome's centre
+    sky = _floor_and_lamp(8)
+    sky.indices, sky.tri_material, sky.tri_emitter = sky.indices[:1], sky.tri_material[:1], sky.tri_emitter[:1]
+    sky.positions = (sky.positions * np.float32(1e-3)).astype(np.float32); sky.positions[:, 1] -= 50.0
+    sky.materials = list(sky.materials) + [dict(type="diffuse", reflectance=(0.5, 0.5, 0.5))]
+    sky.emitters = [dict(radiance=(1.0, 2.0, 3.0))]
+    sky.spheres = [dict(center=(0.0, 30.0, 0.0), radius=100.0, material=2, emitter=0, flip_normals=True)]
+    for nee in ("never", "always"):
+        e = make_oracle(oracle_lib, threads=16, budgetType="spp", budget=60, maxDepth=-1, rrDepth=100, nee=nee, seed=5)
+        img = ppg_host.GuidedPathTracer(engine=e).render(sky)
+        assert np.allclose(img.reshape(-1, 3).mean(0), [2.0, 4.0, 6.0], rtol=0.02), (nee, img.reshape(-1, 3).mean(0))
