@@ -494,9 +494,14 @@ public:
                     mat = (int)it->second;
                 }
             }
-            if (mat < 0) {
-                if (defaultMat < 0) { ppg_material d{}; d.type = PPG_BSDF_DIFFUSE; d.reflectance[0] = d.reflectance[1] = d.reflectance[2] = 0.5f; defaults(d); defaultMat = (int)intern(d, out); }
-                mat = defaultMat;
+            if (mat < 0) {  // Shape::configure (shape.cpp:48-72): all-absorbing under an emitter, otherwise a 0.5 Lambertian "for convenience"
+                if (sh.child("emitter")) {
+                    ppg_material d{}; d.type = PPG_BSDF_DIFFUSE; defaults(d); d.reflectance[0] = d.reflectance[1] = d.reflectance[2] = 0.0f;
+                    mat = (int)intern(d, out);
+                } else {
+                    if (defaultMat < 0) { ppg_material d{}; d.type = PPG_BSDF_DIFFUSE; d.reflectance[0] = d.reflectance[1] = d.reflectance[2] = 0.5f; defaults(d); defaultMat = (int)intern(d, out); }
+                    mat = defaultMat;
+                }
             }
             int em = -1;
             if (const XmlNode *e = sh.child("emitter")) {

@@ -552,7 +552,7 @@ def load_scene(path, defines=None, strict=True, width=None, height=None, data_di
                           flip_normals=bool(sprops.get("flipNormals", False)))
         else:
             raise SceneError("shape type %r is not supported (obj, rectangle, sphere)" % t)
-        # material: nested <bsdf> or <ref id>; Mitsuba's default is diffuse(0.5)
+        # material: nested <bsdf> or <ref id>
         mat = None
         for c in sh:
             if c.tag == "bsdf":
@@ -562,10 +562,13 @@ def load_scene(path, defines=None, strict=True, width=None, height=None, data_di
                 if rid not in by_id:
                     raise SceneError("<ref id=%r>: no such bsdf" % rid)
                 mat = by_id[rid]
-        if mat is None:
-            if default_mat is None:
-                default_mat = intern(dict(type=0, reflectance=(0.5, 0.5, 0.5)))
-            mat = default_mat
+        if mat is None:  # Shape::configure (shape.cpp:48-72): all-absorbing under an emitter, otherwise a 0.5 Lambertian "for convenience"
+            if sh.find("emitter") is not None:
+                mat = intern(dict(type=0, reflectance=(0.0, 0.0, 0.0)))
+            else:
+                if default_mat is None:
+                    default_mat = intern(dict(type=0, reflectance=(0.5, 0.5, 0.5)))
+                mat = default_mat
         em = -1
         e = sh.find("emitter")
         if e is not None:

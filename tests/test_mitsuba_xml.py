@@ -318,7 +318,8 @@ def test_sphere_shapes_follow_the_reference_constructor(tmp_path):
     assert b["center"] == (0.0, 0.0, 0.0) and abs(b["radius"] - 100.0) < 1e-4 and b["flip_normals"]
     assert np.allclose(np.reshape(b["to_world"], (3, 3)), np.eye(3), atol=1e-6)
     assert desc.emitters[b["emitter"]]["radiance"] == pytest.approx((0.3, 0.3, 0.3)) and b["emitter"] == len(desc.emitters) - 1
-    assert desc.materials[b["material"]]["type"] == 0                       # Mitsuba's default BSDF: diffuse(0.5)
+    assert desc.materials[b["material"]] == dict(type=0, reflectance=(0.0, 0.0, 0.0))   # under an emitter: all-absorbing (shape.cpp:51-56)
+    assert desc.materials[a["material"]] == dict(type=0, reflectance=(0.5, 0.5, 0.5))   # otherwise Mitsuba's 0.5 Lambertian (shape.cpp:57-64)
     assert np.allclose(c["center"], (5, 6, 7)) and abs(c["radius"] - 6.0) < 1e-5 and desc.materials[c["material"]]["type"] == 6
     R = np.reshape(c["to_world"], (3, 3))                                   # rotate 90 deg about y: x -> -z, z -> x
     assert np.allclose(R, [[0, 0, 1], [0, 1, 0], [-1, 0, 0]], atol=1e-6)

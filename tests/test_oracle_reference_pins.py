@@ -127,3 +127,34 @@ def test_cbox_improved_preset_matches_reference_log(oracle_lib, ref_logs):
     rmse = np.sqrt(((blocks - gold["cbox_improved_block8"]) ** 2).mean())
     noise_floor = np.sqrt(((gold["cbox_improved_block8"] - gold["cbox_block8"]) ** 2).mean())
     assert rmse < 1.6 * noise_floor, (rmse, noise_floor)
+
+
+SPACESHIP = "/root/reference/scenes/spaceship/spaceship.xml"
+
+
+@pytest.mark.skipif(not os.path.exists(SPACESHIP), reason="reference scenes not mounted (development container only)")
+def test_spaceship_scene_matches_the_reference_render(oracle_lib):
+    """The reference's bundled SPACESHIP scene end to end: its XML through ppg_host.load_scene (86 OBJ meshes — two are missing from the
+    checkout and skipped —, twosided rough conductors, rough plastic cut from Mitsuba's data/microfacet tables, a rough dielectric canopy,
+    four area lights and the emitting sky sphere with flipped normals), rendered by the oracle at the scene's 640 x 360 with 63 spp,
+    against the pixels of the reference's own 1023-spp render (scenes/spaceship/spaceship.exr).  Region means agree to Monte-Carlo
+    noise: 0.0188 on the backdrop is (sky 0.3 x albedo 0.1) x visibility — it was 0.033 while the loader still gave the emitting dome
+    Mitsuba's 0.5 "convenience" BSDF instead of the all-absorbing one of Shape::configure (shape.cpp:48-72)."""
+    import sys
+    import ppg_host
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
+    import exr_min
+    _, ch = exr_min.read_exr(os.path.join(os.path.dirname(SPACESHIP), "spaceship.exr"))
+    ref = np.stack([ch[k] for k in ("R", "G", "B")], -1)
+    desc, props, info = ppg_host.load_scene(SPACESHIP, strict=False, data_dir="/root/reference/mitsuba/data")
+    assert len(info["warnings"]) == 2 and all("not found" in w for w in info["warnings"])
+    assert desc.n_triangles == 257486 and len(desc.spheres) == 1 and len(desc.emitters) == 5 and desc.rtrans.shape == (3, 101)
+    assert props == dict(strictNormals=1, maxDepth=10, rrDepth=10, budgetType="spp", budget=1023.0)
+    e = make_oracle(oracle_lib, threads=os.cpu_count() or 8, **dict(props, budget=63.0))
+    img = ppg_host.GuidedPathTracer(engine=e).render(desc)
+    assert img.shape == ref.shape == (360, 640, 3)
+    regions = dict(backdrop=(0, 80, 0, 200, 0.01), floor=(300, 360, 0, 640, 0.01), right=(100, 200, 560, 640, 0.02), ship=(100, 260, 200, 500, 0.04),
+                   whole=(0, 360, 0, 640, 0.02))
+    for name, (y0, y1, x0, x1, tol) in regions.items():
+        a, b = np.nanmean(img[y0:y1, x0:x1].reshape(-1, 3), 0), ref[y0:y1, x0:x1].reshape(-1, 3).mean(0)
+        assert np.allclose(a, b, rtol=tol), (name, a, b)
