@@ -72,6 +72,54 @@ def save_scene(desc, path):
                 f.write(bytes(Sphere.from_dict(d)))
 
 
+def load_scene_file(path):
+    """Read a flat scene written by save_scene() / `ppg_render --ppgs` back into a SceneDesc."""
+    import struct
+    from .bindings import Material, Sphere
+    buf = open(path, "rb").read()
+    if buf[:4] != b"PPGS":
+        raise ValueError("%s: not a flat scene file" % path)
+    nv, nt, nm, ne, has_n, blocks = struct.unpack_from("<6I", buf, 4)
+    off = [28]
+
+    def take(dtype, count):
+        a = np.frombuffer(buf, dtype, count, off[0])
+        off[0] += a.nbytes
+        return a
+    pos = take(np.float32, 3 * nv).reshape(-1, 3).copy()
+    nrm = take(np.float32, 3 * nv).reshape(-1, 3).copy() if has_n else None
+    idx = take(np.uint32, 3 * nt).reshape(-1, 3).copy()
+    tm, te = take(np.uint32, nt).copy(), take(np.int32, nt).copy()
+    mats = []
+    for _ in range(nm):
+        m = Material.from_buffer_copy(bytes(take(np.uint8, 80)))
+        d = dict(type=int(m.type), reflectance=tuple(m.reflectance), specular=tuple(m.specular), alpha=float(m.alpha), eta=tuple(m.eta), k=tuple(m.k),
+                 twosided=bool(m.flags & 1), nonlinear=bool(m.flags & 2), rtrans=int(m.rtrans))
+        if m.flags & 4:
+            d["opacity"] = tuple(m.opacity)
+        if m.flags & 8:
+            d["distribution"] = "beckmann"
+        mats.append(d)
+    ems = [dict(radiance=tuple(float(v) for v in take(np.float32, 4)[:3])) for _ in range(ne)]
+    cam = dict(sample_to_camera=take(np.float32, 16).reshape(4, 4).copy(), camera_to_world=take(np.float32, 16).reshape(4, 4).copy())
+    cam["near_clip"], cam["far_clip"] = (float(v) for v in take(np.float32, 2))
+    cam["width"], cam["height"] = (int(v) for v in take(np.int32, 2))
+    env = tuple(float(v) for v in take(np.float32, 3)) if blocks & 1 else None
+    rt = None
+    if blocks & 2:
+        n, samples = (int(v) for v in take(np.uint32, 2))
+        rt = take(np.float32, n * (samples + 1)).reshape(n, samples + 1).copy()
+    spheres = []
+    if blocks & 4:
+        for _ in range(int(take(np.uint32, 1)[0])):
+            sp = Sphere.from_buffer_copy(bytes(take(np.uint8, 64)))
+            spheres.append(dict(center=tuple(sp.center), radius=float(sp.radius), to_world=list(sp.to_world), material=int(sp.material), emitter=int(sp.emitter),
+                                flip_normals=bool(sp.flip_normals)))
+    if off[0] != len(buf):
+        raise ValueError("%s: trailing bytes" % path)
+    return SceneDesc(pos, idx, tm, te, mats, ems, cam, nrm, env, rt, spheres)
+
+
 def _sample_to_camera(fov_deg, fov_axis, near, far, width, height):
     """m_sampleToCamera of sensors/perspective.cpp:150-164; fov-axis handling of sensor.cpp:239-264.  Computed in
     double, stored as float32 (an input to both the HIP path and the oracle, not part of either)."""
