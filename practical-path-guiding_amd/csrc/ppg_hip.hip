@@ -1146,7 +1146,11 @@ int ppg_set_scene(ppg_ctx *ctx, const ppg_scene *s) {
     float ext = 0;
     for (int a = 0; a < 3; ++a) ext = std::max(ext, mx[a] - mn[a]);
     BvhBuilder bb;
-    bb.run(s->positions, s->indices, s->n_triangles, 1e-4f * ext + 1e-30f);
+    // Box padding: the BVH must return what brute force returns.  A slab test carries a few ulps of error in t, i.e. up to
+    // ~4 * 2^-24 * (distance travelled) in position; 2e-6 * (scene extent) leaves an 8x margin.  (1e-4 * extent, the first
+    // choice, made the leaf boxes of a finely tessellated model under a 100 m sky dome several triangles thick: 4x slower.)
+    const float padRel = getenv("PPG_BVH_PAD") ? (float)atof(getenv("PPG_BVH_PAD")) : 2e-6f;
+    bb.run(s->positions, s->indices, s->n_triangles, padRel * ext + 1e-30f);
     std::vector<float4> tris(3 * (size_t)s->n_triangles), nrm, accel(3 * (size_t)s->n_triangles);
     if (s->normals) nrm.resize(tris.size());
     for (uint32_t k = 0; k < s->n_triangles; ++k) {
