@@ -130,26 +130,30 @@ def test_cbox_improved_preset_matches_reference_log(oracle_lib, ref_logs):
 
 
 SPACESHIP = "/root/reference/scenes/spaceship/spaceship.xml"
+IMPROVED_PRESET = dict(sampleCombination="inversevar", bsdfSamplingFractionLoss="kl", spatialFilter="stochastic", directionalFilter="box",
+                       sTreeThreshold=4000, sppPerPass=1)
 
 
 @pytest.mark.skipif(not os.path.exists(SPACESHIP), reason="reference scenes not mounted (development container only)")
-def test_spaceship_scene_matches_the_reference_render(oracle_lib):
+@pytest.mark.parametrize("variant", ["spaceship", "spaceship-improved"])
+def test_spaceship_scene_matches_the_reference_render(oracle_lib, variant):
     """The reference's bundled SPACESHIP scene end to end: its XML through ppg_host.load_scene (86 OBJ meshes — two are missing from the
     checkout and skipped —, twosided rough conductors, rough plastic cut from Mitsuba's data/microfacet tables, a rough dielectric canopy,
     four area lights and the emitting sky sphere with flipped normals), rendered by the oracle at the scene's 640 x 360 with 63 spp,
-    against the pixels of the reference's own 1023-spp render (scenes/spaceship/spaceship.exr).  Region means agree to Monte-Carlo
+    against the pixels of the reference's own 1023-spp render (scenes/spaceship/spaceship.exr; likewise spaceship-improved.xml / .exr, the README's improved preset).  Region means agree to Monte-Carlo
     noise: 0.0188 on the backdrop is (sky 0.3 x albedo 0.1) x visibility — it was 0.033 while the loader still gave the emitting dome
     Mitsuba's 0.5 "convenience" BSDF instead of the all-absorbing one of Shape::configure (shape.cpp:48-72)."""
     import sys
     import ppg_host
     sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
     import exr_min
-    _, ch = exr_min.read_exr(os.path.join(os.path.dirname(SPACESHIP), "spaceship.exr"))
+    _, ch = exr_min.read_exr(os.path.join(os.path.dirname(SPACESHIP), variant + ".exr"))
     ref = np.stack([ch[k] for k in ("R", "G", "B")], -1)
-    desc, props, info = ppg_host.load_scene(SPACESHIP, strict=False, data_dir="/root/reference/mitsuba/data")
+    desc, props, info = ppg_host.load_scene(os.path.join(os.path.dirname(SPACESHIP), variant + ".xml"), strict=False, data_dir="/root/reference/mitsuba/data")
     assert len(info["warnings"]) == 2 and all("not found" in w for w in info["warnings"])
     assert desc.n_triangles == 257486 and len(desc.spheres) == 1 and len(desc.emitters) == 5 and desc.rtrans.shape == (3, 101)
-    assert props == dict(strictNormals=1, maxDepth=10, rrDepth=10, budgetType="spp", budget=1023.0)
+    base = dict(strictNormals=1, maxDepth=10, rrDepth=10, budgetType="spp", budget=1023.0)
+    assert props == (base if variant == "spaceship" else dict(base, **IMPROVED_PRESET))  # spaceship-improved.xml = README.md:30-37
     e = make_oracle(oracle_lib, threads=os.cpu_count() or 8, **dict(props, budget=63.0))
     img = ppg_host.GuidedPathTracer(engine=e).render(desc)
     assert img.shape == ref.shape == (360, 640, 3)
