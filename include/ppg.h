@@ -138,6 +138,18 @@ typedef struct ppg_sphere {
     int32_t flip_normals; /* sphere.cpp:124, 256-257, 351-352 */
 } ppg_sphere;             /* 64 bytes */
 
+typedef struct ppg_envmap {
+    /* Image-based environment emitter (emitters/envmap.cpp): a latitude-longitude radiance map, bilinearly interpolated
+       (mipmap.h:575-596, repeat in u / clamp in v), importance-sampled by luminance x sin(theta) with the tent-filtered pixel
+       sampling of envmap.cpp:557-595 and its pdf (:598-633); the bounding sphere / emitter numbering of the constant emitter.
+       Deviation: a camera ray that leaves the scene is looked up bilinearly at level 0 as well (the reference filters it with
+       EWA over the ray differentials, envmap.cpp:389-404) — this only smooths the directly visible background. */
+    uint32_t width, height;   /* <= 65535 */
+    const float *rgb;         /* [height * width * 3] linear RGB, row 0 = +y (theta = 0), column 0 = -z turning towards +x */
+    float scale;              /* envmap.cpp:189 */
+    float to_world[9];        /* row-major rotation of the emitter's toWorld (inverse taken as transpose); identity if none */
+} ppg_envmap;
+
 typedef struct ppg_camera {
     /* row-major 4x4, exactly the matrices of mitsuba/src/sensors/perspective.cpp:150-164 (m_sampleToCamera)
        and the sensor's world transform; rays follow perspective.cpp:271-298 */
@@ -173,6 +185,7 @@ typedef struct ppg_scene {
     const float *rtrans;          /* [n_rtrans * (rtrans_samples + 1)] */
     uint32_t n_spheres;
     const ppg_sphere *spheres;    /* [n_spheres] or NULL */
+    const ppg_envmap *envmap;     /* NULL, or the image-based environment emitter (not together with `environment`) */
 } ppg_scene;
 
 /* ------------------------------------------------------------------------------------------------

@@ -889,14 +889,124 @@ struct DRec {
 
 inline Vec squareToCosineHemisphere(const Point2 &sample);  // warp.cpp:43-52, defined below
 
+// EnvironmentMap (emitters/envmap.cpp): latitude-longitude map, level-0 bilinear lookups (mipmap.h:503-596, u repeats, v clamps),
+// luminance x sin(theta) importance sampling with tent-filtered pixel positions and the matching solid-angle density
+struct EnvMap {
+    int w = 0, h = 0;
+    std::vector<Spectrum> texel;
+    Float scale = 1;
+    float R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};  // toWorld rotation; inverse = transpose
+    std::vector<float> cdfRows, cdfCols;
+    std::vector<Float> rowWeights;
+    Float normalization = 0, pixelSizeX = 0, pixelSizeY = 0;
+
+    static int floorToInt(Float v) { return (int)std::floor(v); }
+    Vec toWorld(const Vec &v) const { return Vec(R[0] * v.x + R[1] * v.y + R[2] * v.z, R[3] * v.x + R[4] * v.y + R[5] * v.z, R[6] * v.x + R[7] * v.y + R[8] * v.z); }
+    Vec toLocal(const Vec &v) const { return Vec(R[0] * v.x + R[3] * v.y + R[6] * v.z, R[1] * v.x + R[4] * v.y + R[7] * v.z, R[2] * v.x + R[5] * v.y + R[8] * v.z); }
+    Spectrum evalTexel(int x, int y) const {  // mipmap.h:503-570: ERepeat in u, EClamp in v
+        if (x < 0 || x >= w) { x %= w; if (x < 0) x += w; }  // math::modulo, math.h:67-70
+        if (y < 0 || y >= h) y = y < 0 ? 0 : h - 1;
+        return texel[(size_t)y * w + x];
+    }
+    void configure() {  // envmap.cpp:255-322
+        cdfCols.assign((size_t)(w + 1) * h, 0.0f);
+        cdfRows.assign(h + 1, 0.0f);
+        rowWeights.assign(h, 0.0f);
+        size_t colPos = 0, rowPos = 0;
+        Float rowSum = 0.0f;
+        cdfRows[rowPos++] = 0;
+        for (int y = 0; y < h; ++y) {
+            Float colSum = 0;
+            cdfCols[colPos++] = 0;
+            for (int x = 0; x < w; ++x) {
+                colSum += luminance(texel[(size_t)y * w + x]);
+                cdfCols[colPos++] = (float)colSum;
+            }
+            float normalization = 1.0f / (float)colSum;
+            for (int x = 1; x < w; ++x) cdfCols[colPos - x - 1] *= normalization;
+            cdfCols[colPos - 1] = 1.0f;
+            Float weight, cosUnused;
+            ppg_sincos((y + 0.5f) * PPG_PI_F / h, &weight, &cosUnused);  // std::sin in the reference
+            rowWeights[y] = weight;
+            rowSum += colSum * weight;
+            cdfRows[rowPos++] = (float)rowSum;
+        }
+        float norm = 1.0f / (float)rowSum;
+        for (int y = 1; y < h; ++y) cdfRows[rowPos - y - 1] *= norm;
+        cdfRows[rowPos - 1] = 1.0f;
+        normalization = 1.0f / (rowSum * (2 * PPG_PI_F / w) * (PPG_PI_F / h));
+        pixelSizeX = 2 * PPG_PI_F / w; pixelSizeY = PPG_PI_F / h;
+        valid = rowSum > 0 && std::isfinite(rowSum);
+    }
+    bool valid = false;
+    // evalEnvironment (envmap.cpp:381-407) for a ray without differentials: `d` is the world direction the ray travels in
+    Spectrum eval(const Vec &dWorld) const {
+        const Vec v = toLocal(dWorld);
+        const Point2 uv{ppg_atan2(v.x, -v.z) * (PPG_INV_PI_F * 0.5f), ppg_acos(v.y) * PPG_INV_PI_F};
+        if (!std::isfinite(uv.x) || !std::isfinite(uv.y)) return Spectrum(0.0f);
+        const Float u = uv.x * w - 0.5f, vv = uv.y * h - 0.5f;  // mipmap.h:585-595
+        const int xPos = floorToInt(u), yPos = floorToInt(vv);
+        const Float dx1 = u - xPos, dx2 = 1.0f - dx1, dy1 = vv - yPos, dy2 = 1.0f - dy1;
+        const Spectrum value = evalTexel(xPos, yPos) * dx2 * dy2 + evalTexel(xPos, yPos + 1) * dx2 * dy1 + evalTexel(xPos + 1, yPos) * dx1 * dy2 +
+                               evalTexel(xPos + 1, yPos + 1) * dx1 * dy1;
+        return value * scale;
+    }
+    static uint32_t sampleReuse(const float *cdf, uint32_t size, Float &sample) {  // envmap.cpp:659-664
+        const float *entry = std::lower_bound(cdf, cdf + size + 1, (float)sample);
+        uint32_t index = std::min((uint32_t)std::max((ptrdiff_t)0, entry - cdf - 1), size - 1);
+        sample = (sample - (Float)cdf[index]) / (Float)(cdf[index + 1] - cdf[index]);
+        return index;
+    }
+    static Float intervalToTent(Float sample) {  // warp.cpp:143-155
+        Float sign;
+        if (sample < 0.5f) { sign = 1; sample *= 2; }
+        else { sign = -1; sample = 2 * (sample - 0.5f); }
+        return sign * (1 - std::sqrt(sample));
+    }
+    int clampRow(int y) const { return y < 0 ? 0 : (y > h - 1 ? h - 1 : y); }
+    // internalSampleDirection (envmap.cpp:557-595): d in the emitter's frame
+    void sampleDirection(Point2 sample, Vec &d, Spectrum &value, Float &pdf) const {
+        uint32_t row = sampleReuse(cdfRows.data(), (uint32_t)h, sample.y);
+        uint32_t col = sampleReuse(cdfCols.data() + (size_t)row * (w + 1), (uint32_t)w, sample.x);
+        const Float posX = (Float)col + intervalToTent(sample.x), posY = (Float)row + intervalToTent(sample.y);
+        const int xPos = floorToInt(posX), yPos = floorToInt(posY);
+        const Float dx1 = posX - xPos, dx2 = 1.0f - dx1, dy1 = posY - yPos, dy2 = 1.0f - dy1;
+        const Spectrum value1 = evalTexel(xPos, yPos) * dx2 * dy2 + evalTexel(xPos + 1, yPos) * dx1 * dy2;
+        const Spectrum value2 = evalTexel(xPos, yPos + 1) * dx2 * dy1 + evalTexel(xPos + 1, yPos + 1) * dx1 * dy1;
+        value = (value1 + value2) * scale;
+        pdf = (luminance(value1) * rowWeights[clampRow(yPos)] + luminance(value2) * rowWeights[clampRow(yPos + 1)]) * normalization;
+        Float sinPhi, cosPhi, sinTheta, cosTheta;
+        ppg_sincos(pixelSizeX * (posX + 0.5f), &sinPhi, &cosPhi);
+        ppg_sincos(pixelSizeY * (posY + 0.5f), &sinTheta, &cosTheta);
+        d = Vec(sinPhi * sinTheta, cosTheta, -cosPhi * sinTheta);
+        pdf /= ppg_max(ppg_abs(sinTheta), PPG_EPSILON);
+    }
+    // internalPdfDirection (envmap.cpp:598-633): d in the emitter's frame
+    Float pdfDirection(const Vec &d) const {
+        const Point2 uv{ppg_atan2(d.x, -d.z) * (PPG_INV_PI_F * 0.5f), ppg_acos(d.y) * PPG_INV_PI_F};
+        if (!std::isfinite(uv.x) || !std::isfinite(uv.y)) return 0.0f;
+        const Float u = uv.x * w - 0.5f, v = uv.y * h - 0.5f;
+        const int xPos = floorToInt(u), yPos = floorToInt(v);
+        const Float dx1 = u - xPos, dx2 = 1.0f - dx1, dy1 = v - yPos, dy2 = 1.0f - dy1;
+        const Spectrum value1 = evalTexel(xPos, yPos) * dx2 * dy2 + evalTexel(xPos + 1, yPos) * dx1 * dy2;
+        const Spectrum value2 = evalTexel(xPos, yPos + 1) * dx2 * dy1 + evalTexel(xPos + 1, yPos + 1) * dx1 * dy1;
+        const Float sinTheta = std::sqrt(ppg_max(0.0f, 1 - d.y * d.y));
+        return (luminance(value1) * rowWeights[clampRow(yPos)] + luminance(value2) * rowWeights[clampRow(yPos + 1)]) * normalization /
+               ppg_max(ppg_abs(sinTheta), PPG_EPSILON);
+    }
+};
+
 struct Scene {
     // one area emitter = the triangles carrying its id, in index order (area.cpp: one emitter per shape)
     struct EmitterMesh { std::vector<uint32_t> tris; Pmf areaDistr; Float surfaceArea = -1, invSurfaceArea = -1; };
     std::vector<EmitterMesh> emMesh;
     Pmf emitterPDF;
     // ConstantBackgroundEmitter (constant.cpp): the last entry of the emitter list; bounding sphere of createShape() (constant.cpp:67-78)
-    bool hasEnv = false;
+    bool hasEnv = false;       // an environment emitter: constant (envRadiance) or image based (envMap.valid)
     Spectrum envRadiance;
+    EnvMap envMap;
+    // Scene::evalEnvironment for a ray travelling along d that left the scene
+    Spectrum envEval(const Vec &d) const { return envMap.valid ? envMap.eval(d) : envRadiance; }
     Point bsCenter;
     Float bsRadius = 0;
     int envIndex() const { return (int)emMesh.size(); }
@@ -1130,6 +1240,22 @@ struct Scene {
     }
     // ConstantBackgroundEmitter::sampleDirect (constant.cpp:176-214)
     Spectrum envSampleDirect(DRec &dRec, const Point2 &sample) const {
+        if (envMap.valid) {  // EnvironmentMap::sampleDirect, envmap.cpp:510-538
+            Spectrum value; Vec dl; Float pdfM;
+            envMap.sampleDirection(sample, dl, value, pdfM);
+            const Vec dw = envMap.toWorld(dl);
+            Float nearT, farT;
+            if (isZero(value) || pdfM == 0 || !bsphereIntersect(dRec.ref, dw, nearT, farT) || nearT >= 0 || farT <= 0) {
+                dRec.pdf = 0.0f;
+                return Spectrum(0.0f);
+            }
+            dRec.pdf = pdfM;
+            dRec.p = dRec.ref + dw * farT;
+            dRec.n = normalize(bsCenter - dRec.p);
+            dRec.dist = farT;
+            dRec.d = dw;
+            return value / pdfM;
+        }
         Vec d;
         Float pdf;
         const bool hasRefN = !(dRec.refN.x == 0 && dRec.refN.y == 0 && dRec.refN.z == 0);
@@ -1266,7 +1392,9 @@ struct Scene {
     Float pdfEmitterDirect(const DRec &dRec) const {
         if (dRec.emitter < 0) return 0.0f;
         Float pdf = 0.0f;
-        if (hasEnv && dRec.emitter == envIndex()) {  // ConstantBackgroundEmitter::pdfDirect, constant.cpp:216-231 (solid angle)
+        if (hasEnv && dRec.emitter == envIndex() && envMap.valid) {  // EnvironmentMap::pdfDirect, envmap.cpp:540-552 (solid angle)
+            pdf = envMap.pdfDirection(envMap.toLocal(dRec.d));
+        } else if (hasEnv && dRec.emitter == envIndex()) {  // ConstantBackgroundEmitter::pdfDirect, constant.cpp:216-231 (solid angle)
             const bool hasRefN = !(dRec.refN.x == 0 && dRec.refN.y == 0 && dRec.refN.z == 0);
             pdf = hasRefN ? PPG_INV_PI_F * ppg_max(0.0f, dot(dRec.d, dRec.refN)) : PPG_INV_PI_F * 0.25f;
         } else if (dot(dRec.d, dRec.refN) >= 0 && dot(dRec.d, dRec.n) < 0) {
@@ -2523,7 +2651,7 @@ public:
 
         while (depth <= m_maxDepth || m_maxDepth < 0) {
             if (!its.valid) {  // GP:1902-1914: radiance from a background luminaire
-                if (emittedAllowed && (!m_hideEmitters || scattered) && scene.hasEnv) recordRadiance(mul(throughput, scene.envRadiance));
+                if (emittedAllowed && (!m_hideEmitters || scattered) && scene.hasEnv) recordRadiance(mul(throughput, scene.envEval(d)));
                 break;
             }
             if (its.emitter >= 0 && emittedAllowed && (!m_hideEmitters || scattered))
@@ -2634,7 +2762,7 @@ public:
                     dRec.p = cur->p; dRec.n = cur->shFrame.n; dRec.d = d; dRec.dist = cur->t; dRec.emitter = cur->emitter;
                     value = mul(transmittance, scene.Le(*cur, -d));
                 } else if (!abandoned && !surface && scene.hasEnv && scene.envFillDirectSamplingRecord(dRec, ro, d)) {  // GP:2236-2243
-                    value = mul(transmittance, scene.envRadiance);
+                    value = mul(transmittance, scene.envEval(d));
                     dRec.dist = std::numeric_limits<Float>::infinity();
                 }
             }
@@ -2884,6 +3012,19 @@ int ppgo_set_scene(ppgo_ctx *ctx, const ppg_scene *s) {
     sc.triEmitter.assign(s->tri_emitter, s->tri_emitter + s->n_triangles);
     sc.hasEnv = s->environment != nullptr;
     if (sc.hasEnv) sc.envRadiance = Spectrum(s->environment[0], s->environment[1], s->environment[2]);
+    if (s->envmap) {
+        const ppg_envmap &em = *s->envmap;
+        if (sc.hasEnv) { ctx->gpt.error = "envmap: a scene has one environment emitter (`environment` is set as well)"; return PPG_ERR_INVALID; }
+        if (!em.rgb || em.width == 0 || em.height == 0 || em.width > 0xFFFF || em.height > 0xFFFF) { ctx->gpt.error = "envmap: needs pixels and 0 < width, height < 65536"; return PPG_ERR_INVALID; }
+        EnvMap &m = sc.envMap;
+        m.w = (int)em.width; m.h = (int)em.height; m.scale = em.scale;
+        memcpy(m.R, em.to_world, sizeof m.R);
+        m.texel.resize((size_t)m.w * m.h);
+        for (size_t k = 0; k < m.texel.size(); ++k) m.texel[k] = Spectrum(em.rgb[3 * k], em.rgb[3 * k + 1], em.rgb[3 * k + 2]);
+        m.configure();
+        if (!m.valid) { ctx->gpt.error = "envmap: the environment map is completely black or holds nan / inf (envmap.cpp:308-312)"; return PPG_ERR_INVALID; }
+        sc.hasEnv = true;
+    }
     sc.materials.clear();
     if (s->n_rtrans) {
         if (!s->rtrans || s->rtrans_samples < 2) { ctx->gpt.error = "rtrans: need the slices and rtrans_samples >= 2"; return PPG_ERR_INVALID; }
@@ -3245,6 +3386,41 @@ int ppgo_bsdf_sample(const ppg_material *mat, uint32_t n, const float *wi, const
         wo_out[3 * i] = b.wo.x; wo_out[3 * i + 1] = b.wo.y; wo_out[3 * i + 2] = b.wo.z;
         weight_out[3 * i] = w.x; weight_out[3 * i + 1] = w.y; weight_out[3 * i + 2] = w.z;
         pdf_out[i] = pdf; eta_out[i] = b.eta; delta_out[i] = b.sampledDelta ? 1 : 0;
+    }
+    return PPG_OK;
+}
+// EnvironmentMap, element-wise (tests): radiance and solid-angle density for world directions; sampled directions with value / pdf
+static bool loadEnvMap(const ppg_envmap *em, EnvMap &m) {
+    if (!em || !em->rgb || em->width == 0 || em->height == 0) return false;
+    m.w = (int)em->width; m.h = (int)em->height; m.scale = em->scale;
+    memcpy(m.R, em->to_world, sizeof m.R);
+    m.texel.resize((size_t)m.w * m.h);
+    for (size_t k = 0; k < m.texel.size(); ++k) m.texel[k] = Spectrum(em->rgb[3 * k], em->rgb[3 * k + 1], em->rgb[3 * k + 2]);
+    m.configure();
+    return m.valid;
+}
+int ppgo_envmap_eval(const ppg_envmap *em, uint32_t n, const float *dirs, float *rgb_out, float *pdf_out) {
+    EnvMap m;
+    if (!loadEnvMap(em, m)) return PPG_ERR_INVALID;
+    for (uint32_t i = 0; i < n; ++i) {
+        const Vec d(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]);
+        const Spectrum v = m.eval(d);
+        rgb_out[3 * i] = v.x; rgb_out[3 * i + 1] = v.y; rgb_out[3 * i + 2] = v.z;
+        pdf_out[i] = m.pdfDirection(m.toLocal(d));
+    }
+    return PPG_OK;
+}
+int ppgo_envmap_sample(const ppg_envmap *em, uint32_t n, const float *sample_xy, float *dir_out, float *weight_out, float *pdf_out) {
+    EnvMap m;
+    if (!loadEnvMap(em, m)) return PPG_ERR_INVALID;
+    for (uint32_t i = 0; i < n; ++i) {
+        Vec dl; Spectrum value; Float pdf;
+        m.sampleDirection(Point2{sample_xy[2 * i], sample_xy[2 * i + 1]}, dl, value, pdf);
+        const Vec d = m.toWorld(dl);
+        const Spectrum wgt = pdf > 0 ? value / pdf : Spectrum(0.0f);
+        dir_out[3 * i] = d.x; dir_out[3 * i + 1] = d.y; dir_out[3 * i + 2] = d.z;
+        weight_out[3 * i] = wgt.x; weight_out[3 * i + 1] = wgt.y; weight_out[3 * i + 2] = wgt.z;
+        pdf_out[i] = pdf;
     }
     return PPG_OK;
 }

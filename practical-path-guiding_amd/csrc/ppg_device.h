@@ -104,6 +104,13 @@ struct DevScene {
     // (R row 2, flip normals); primitive numbers n_tris, n_tris + 1, ..
     const float4 *spheres;
     int n_spheres;
+    // image-based environment emitter (envmap.cpp), env.w == 2: texels (rgb, -), the row / column cdfs and sin(theta) row weights
+    // of EnvironmentMap::configure, m_normalization, m_scale, the pixel size in spherical coordinates, toWorld's rotation
+    const float4 *em_texels;
+    const float *em_cdf_rows, *em_cdf_cols, *em_row_weights;
+    int em_w, em_h;
+    float em_norm, em_scale, em_px, em_py;
+    float em_R[9];
 };
 
 struct Hit {
@@ -472,8 +479,106 @@ D bool env_fill_direct(const DevScene &S, F3 o, F3 d) {
 }
 // ConstantBackgroundEmitter::pdfDirect (constant.cpp:216-231), solid angle; cos_refn = dot(d, refN), or < -1.5 when refN = 0
 D float env_pdf_direct(float cos_refn) { return cos_refn < -1.5f ? PPG_INV_PI_F * 0.25f : PPG_INV_PI_F * ppg_max(0.0f, cos_refn); }
+D float lum3(F3 s);  // defined below
+// ---- EnvironmentMap (emitters/envmap.cpp), level-0 bilinear lookups (mipmap.h:503-596: u repeats, v clamps) ----
+D F3 envmap_to_world(const DevScene &S, F3 v) {
+    return f3(S.em_R[0] * v.x + S.em_R[1] * v.y + S.em_R[2] * v.z, S.em_R[3] * v.x + S.em_R[4] * v.y + S.em_R[5] * v.z, S.em_R[6] * v.x + S.em_R[7] * v.y + S.em_R[8] * v.z);
+}
+D F3 envmap_to_local(const DevScene &S, F3 v) {
+    return f3(S.em_R[0] * v.x + S.em_R[3] * v.y + S.em_R[6] * v.z, S.em_R[1] * v.x + S.em_R[4] * v.y + S.em_R[7] * v.z, S.em_R[2] * v.x + S.em_R[5] * v.y + S.em_R[8] * v.z);
+}
+D F3 envmap_texel(const DevScene &S, int x, int y) {
+    if (x < 0 || x >= S.em_w) { x %= S.em_w; if (x < 0) x += S.em_w; }
+    if (y < 0 || y >= S.em_h) y = y < 0 ? 0 : S.em_h - 1;
+    const float4 t = S.em_texels[(size_t)y * S.em_w + x];
+    return f3(t.x, t.y, t.z);
+}
+D int envmap_clamp_row(const DevScene &S, int y) { return y < 0 ? 0 : (y > S.em_h - 1 ? S.em_h - 1 : y); }
+D bool finitef(float v) { return (ppg_f2u(v) & 0x7f800000u) != 0x7f800000u; }
+// evalEnvironment (envmap.cpp:381-407) of a ray without differentials travelling along the world direction d
+D F3 envmap_eval(const DevScene &S, F3 dWorld) {
+    const F3 v = envmap_to_local(S, dWorld);
+    const float uvx = ppg_atan2(v.x, -v.z) * (PPG_INV_PI_F * 0.5f), uvy = ppg_acos(v.y) * PPG_INV_PI_F;
+    if (!finitef(uvx) || !finitef(uvy)) return f3s(0.0f);
+    const float u = uvx * S.em_w - 0.5f, vv = uvy * S.em_h - 0.5f;
+    const int xPos = (int)__builtin_floorf(u), yPos = (int)__builtin_floorf(vv);
+    const float dx1 = u - xPos, dx2 = 1.0f - dx1, dy1 = vv - yPos, dy2 = 1.0f - dy1;
+    const F3 value = envmap_texel(S, xPos, yPos) * dx2 * dy2 + envmap_texel(S, xPos, yPos + 1) * dx2 * dy1 + envmap_texel(S, xPos + 1, yPos) * dx1 * dy2 +
+                     envmap_texel(S, xPos + 1, yPos + 1) * dx1 * dy1;
+    return value * S.em_scale;
+}
+// the radiance a ray travelling along d sees once it has left the scene: constant or image-based environment emitter
+D F3 env_radiance(const DevScene &S, F3 d) { return S.env.w == 2.0f ? envmap_eval(S, d) : f3(S.env.x, S.env.y, S.env.z); }
+// sampleReuse (envmap.cpp:659-664): std::lower_bound over size + 1 floats
+D int envmap_sample_reuse(const float *cdf, int size, float &sample) {
+    int lo = 0, n = size + 1;
+    while (n > 0) {
+        const int half = n >> 1;
+        if (cdf[lo + half] < sample) { lo += half + 1; n -= half + 1; }
+        else n = half;
+    }
+    int index = lo - 1;
+    index = index < 0 ? 0 : index;
+    index = index > size - 1 ? size - 1 : index;
+    sample = (sample - cdf[index]) / (cdf[index + 1] - cdf[index]);
+    return index;
+}
+D float interval_to_tent(float sample) {  // warp.cpp:143-155
+    float sign;
+    if (sample < 0.5f) { sign = 1; sample *= 2; }
+    else { sign = -1; sample = 2 * (sample - 0.5f); }
+    return sign * (1 - __builtin_sqrtf(sample));
+}
+// internalSampleDirection (envmap.cpp:557-595): direction in the emitter's frame
+D void envmap_sample_direction(const DevScene &S, float sx, float sy, F3 &d, F3 &value, float &pdf) {
+    const int row = envmap_sample_reuse(S.em_cdf_rows, S.em_h, sy);
+    const int col = envmap_sample_reuse(S.em_cdf_cols + (size_t)row * (S.em_w + 1), S.em_w, sx);
+    const float posX = (float)col + interval_to_tent(sx), posY = (float)row + interval_to_tent(sy);
+    const int xPos = (int)__builtin_floorf(posX), yPos = (int)__builtin_floorf(posY);
+    const float dx1 = posX - xPos, dx2 = 1.0f - dx1, dy1 = posY - yPos, dy2 = 1.0f - dy1;
+    const F3 value1 = envmap_texel(S, xPos, yPos) * dx2 * dy2 + envmap_texel(S, xPos + 1, yPos) * dx1 * dy2;
+    const F3 value2 = envmap_texel(S, xPos, yPos + 1) * dx2 * dy1 + envmap_texel(S, xPos + 1, yPos + 1) * dx1 * dy1;
+    value = (value1 + value2) * S.em_scale;
+    pdf = (lum3(value1) * S.em_row_weights[envmap_clamp_row(S, yPos)] + lum3(value2) * S.em_row_weights[envmap_clamp_row(S, yPos + 1)]) * S.em_norm;
+    float sinPhi, cosPhi, sinTheta, cosTheta;
+    ppg_sincos(S.em_px * (posX + 0.5f), &sinPhi, &cosPhi);
+    ppg_sincos(S.em_py * (posY + 0.5f), &sinTheta, &cosTheta);
+    d = f3(sinPhi * sinTheta, cosTheta, -cosPhi * sinTheta);
+    pdf /= ppg_max(ppg_abs(sinTheta), PPG_EPSILON);
+}
+// internalPdfDirection (envmap.cpp:598-633): direction in the emitter's frame
+D float envmap_pdf_direction(const DevScene &S, F3 d) {
+    const float uvx = ppg_atan2(d.x, -d.z) * (PPG_INV_PI_F * 0.5f), uvy = ppg_acos(d.y) * PPG_INV_PI_F;
+    if (!finitef(uvx) || !finitef(uvy)) return 0.0f;
+    const float u = uvx * S.em_w - 0.5f, v = uvy * S.em_h - 0.5f;
+    const int xPos = (int)__builtin_floorf(u), yPos = (int)__builtin_floorf(v);
+    const float dx1 = u - xPos, dx2 = 1.0f - dx1, dy1 = v - yPos, dy2 = 1.0f - dy1;
+    const F3 value1 = envmap_texel(S, xPos, yPos) * dx2 * dy2 + envmap_texel(S, xPos + 1, yPos) * dx1 * dy2;
+    const F3 value2 = envmap_texel(S, xPos, yPos + 1) * dx2 * dy1 + envmap_texel(S, xPos + 1, yPos + 1) * dx1 * dy1;
+    const float sinTheta = __builtin_sqrtf(ppg_max(0.0f, 1 - d.y * d.y));
+    return (lum3(value1) * S.em_row_weights[envmap_clamp_row(S, yPos)] + lum3(value2) * S.em_row_weights[envmap_clamp_row(S, yPos + 1)]) * S.em_norm /
+           ppg_max(ppg_abs(sinTheta), PPG_EPSILON);
+}
 // ConstantBackgroundEmitter::sampleDirect (constant.cpp:176-214)
 D F3 env_sample_direct(const DevScene &S, F3 ref, F3 refN, float sx, float sy, DirectSample &ds) {
+    if (S.env.w == 2.0f) {  // EnvironmentMap::sampleDirect, envmap.cpp:510-538
+        F3 dl, value;
+        float pdfM;
+        envmap_sample_direction(S, sx, sy, dl, value, pdfM);
+        const F3 dw = envmap_to_world(S, dl);
+        float nearT, farT;
+        ds.pdf = 0.0f;
+        if (iszero3(value) || pdfM == 0 || !bsphere_intersect(S, ref, dw, nearT, farT) || nearT >= 0 || farT <= 0) return f3s(0.0f);
+        ds.pdf = pdfM;
+        const F3 p = ref + dw * farT;
+        ds.n = norm3(f3(S.bsphere.x, S.bsphere.y, S.bsphere.z) - p);
+        ds.dist = farT;
+        ds.d = dw;
+        const F3 pd = p - ref;
+        ds.sdist = len3(pd);
+        ds.sd = div3(pd, ds.sdist);
+        return div3(value, pdfM);
+    }
     F3 d;
     float pdf;
     const bool hasRefN = !(refN.x == 0 && refN.y == 0 && refN.z == 0);

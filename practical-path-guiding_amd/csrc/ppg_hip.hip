@@ -259,6 +259,8 @@ struct ppg_ctx {
     DevBuf<float4> d_tris, d_accel, d_accelSmall, d_normals, d_materials, d_emitters, d_emTris, d_emNrm;
     DevBuf<float> d_rtrans;  // ppg_scene.rtrans (roughplastic slices)
     DevBuf<float4> d_spheres;  // 4 float4 per analytic sphere (DevScene::spheres)
+    DevBuf<float4> d_emTexels;  // image-based environment emitter: texels, cdfs, row weights
+    DevBuf<float> d_emCdfRows, d_emCdfCols, d_emRowWeights;
     DevBuf<float> d_emSel, d_emArea, d_neeCos;
     DevBuf<int4> d_emInfo;
     DevBuf<BvhNode> d_bvh;
@@ -1250,6 +1252,50 @@ int ppg_set_scene(ppg_ctx *ctx, const ppg_scene *s) {
     HIP_CHECK(hipMemcpy(ctx->d_materials.p, mats.data(), mats.size() * sizeof(float4), hipMemcpyHostToDevice));
     HIP_CHECK(ctx->d_emitters.reserve(ems.size()));
     HIP_CHECK(hipMemcpy(ctx->d_emitters.p, ems.data(), ems.size() * sizeof(float4), hipMemcpyHostToDevice));
+    ctx->scene.em_texels = nullptr; ctx->scene.em_w = ctx->scene.em_h = 0;
+    if (s->envmap) {  // EnvironmentMap::configure (envmap.cpp:255-322): the same float running sums as the oracle's
+        const ppg_envmap &em = *s->envmap;
+        if (s->environment) { ctx->error = "envmap: a scene has one environment emitter (`environment` is set as well)"; return PPG_ERR_INVALID; }
+        if (!em.rgb || em.width == 0 || em.height == 0 || em.width > 0xFFFF || em.height > 0xFFFF) { ctx->error = "envmap: needs pixels and 0 < width, height < 65536"; return PPG_ERR_INVALID; }
+        const int w = (int)em.width, h = (int)em.height;
+        std::vector<float4> tex((size_t)w * h);
+        std::vector<float> cdfCols((size_t)(w + 1) * h, 0.0f), cdfRows(h + 1, 0.0f), rowWeights(h, 0.0f);
+        size_t colPos = 0, rowPos = 0;
+        float rowSum = 0.0f;
+        cdfRows[rowPos++] = 0;
+        for (int y = 0; y < h; ++y) {
+            float colSum = 0;
+            cdfCols[colPos++] = 0;
+            for (int x = 0; x < w; ++x) {
+                const float *px = em.rgb + 3 * ((size_t)y * w + x);
+                tex[(size_t)y * w + x] = make_float4(px[0], px[1], px[2], 0.0f);
+                colSum += px[0] * 0.212671f + px[1] * 0.715160f + px[2] * 0.072169f;
+                cdfCols[colPos++] = colSum;
+            }
+            const float normalization = 1.0f / colSum;
+            for (int x = 1; x < w; ++x) cdfCols[colPos - x - 1] *= normalization;
+            cdfCols[colPos - 1] = 1.0f;
+            float weight, cosUnused;
+            ppg_sincos((y + 0.5f) * PPG_PI_F / h, &weight, &cosUnused);
+            rowWeights[y] = weight;
+            rowSum += colSum * weight;
+            cdfRows[rowPos++] = rowSum;
+        }
+        const float norm = 1.0f / rowSum;
+        for (int y = 1; y < h; ++y) cdfRows[rowPos - y - 1] *= norm;
+        cdfRows[rowPos - 1] = 1.0f;
+        if (!(rowSum > 0) || !std::isfinite(rowSum)) { ctx->error = "envmap: the environment map is completely black or holds nan / inf (envmap.cpp:308-312)"; return PPG_ERR_INVALID; }
+        HIP_CHECK(ctx->d_emTexels.reserve(tex.size())); HIP_CHECK(hipMemcpy(ctx->d_emTexels.p, tex.data(), tex.size() * sizeof(float4), hipMemcpyHostToDevice));
+        HIP_CHECK(ctx->d_emCdfRows.reserve(cdfRows.size())); HIP_CHECK(hipMemcpy(ctx->d_emCdfRows.p, cdfRows.data(), cdfRows.size() * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(ctx->d_emCdfCols.reserve(cdfCols.size())); HIP_CHECK(hipMemcpy(ctx->d_emCdfCols.p, cdfCols.data(), cdfCols.size() * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(ctx->d_emRowWeights.reserve(rowWeights.size())); HIP_CHECK(hipMemcpy(ctx->d_emRowWeights.p, rowWeights.data(), rowWeights.size() * 4, hipMemcpyHostToDevice));
+        DevScene &E = ctx->scene;
+        E.em_texels = ctx->d_emTexels.p; E.em_cdf_rows = ctx->d_emCdfRows.p; E.em_cdf_cols = ctx->d_emCdfCols.p; E.em_row_weights = ctx->d_emRowWeights.p;
+        E.em_w = w; E.em_h = h; E.em_scale = em.scale;
+        E.em_norm = 1.0f / (rowSum * (2 * PPG_PI_F / w) * (PPG_PI_F / h));
+        E.em_px = 2 * PPG_PI_F / w; E.em_py = PPG_PI_F / h;
+        memcpy(E.em_R, em.to_world, sizeof E.em_R);
+    }
     {   // luminaire sampling tables: TriMesh::prepareSamplingTable (trimesh.cpp:388-403) per emitter (= the triangles
         // carrying its id, in index order) and Scene::configure's emitter pmf (scene.cpp:375-380, samplingWeight = 1);
         // float running sums and DiscreteDistribution::normalize() (pmf.h:101-114) exactly as the oracle builds them
@@ -1291,7 +1337,7 @@ int ppg_set_scene(ppg_ctx *ctx, const ppg_scene *s) {
             if (emitterSphere[e] >= 0) info[e].y = -(emitterSphere[e] + 1);  // sampled analytically (sphere_sample_direct)
             selCdf.push_back(selCdf.back() + 1.0f);
         }
-        if (s->environment) selCdf.push_back(selCdf.back() + 1.0f);  // the environment emitter is the last one
+        if (s->environment || s->envmap) selCdf.push_back(selCdf.back() + 1.0f);  // the environment emitter is the last one
         float selSum = 0, selNorm = 0;
         if (selCdf.size() > 1) selNorm = normalize(selCdf, 0, selCdf.size(), selSum);
         if (etris.empty()) etris.push_back(make_float4(0, 0, 0, 0));
@@ -1302,12 +1348,13 @@ int ppg_set_scene(ppg_ctx *ctx, const ppg_scene *s) {
         HIP_CHECK(ctx->d_emTris.reserve(etris.size())); HIP_CHECK(hipMemcpy(ctx->d_emTris.p, etris.data(), etris.size() * sizeof(float4), hipMemcpyHostToDevice));
         if (!enrm.empty()) { HIP_CHECK(ctx->d_emNrm.reserve(enrm.size())); HIP_CHECK(hipMemcpy(ctx->d_emNrm.p, enrm.data(), enrm.size() * sizeof(float4), hipMemcpyHostToDevice)); }
         DevScene &S = ctx->scene;
-        if (s->environment) {  // ConstantBackgroundEmitter: bounding sphere of createShape() (constant.cpp:67-78) around Scene::getAABB()
+        if (s->environment || s->envmap) {  // Constant / EnvironmentMap: bounding sphere of createShape() (constant.cpp:67-78, envmap.cpp:330-355) around Scene::getAABB()
             float c[3], r2 = 0;
             for (int a = 0; a < 3; ++a) { c[a] = (ctx->aabbMax[a] + ctx->aabbMin[a]) * 0.5f; }
             const float dx = c[0] - ctx->aabbMax[0], dy = c[1] - ctx->aabbMax[1], dz = c[2] - ctx->aabbMax[2];
             r2 = dx * dx + dy * dy + dz * dz;
-            S.env = make_float4(s->environment[0], s->environment[1], s->environment[2], 1.0f);
+            if (s->environment) S.env = make_float4(s->environment[0], s->environment[1], s->environment[2], 1.0f);
+            else S.env = make_float4(0, 0, 0, 2.0f);  // image based: DevScene::em_*
             S.bsphere = make_float4(c[0], c[1], c[2], ppg_max(PPG_EPSILON, std::sqrt(r2) * 1.5f));
             ctx->fullMaterials = true;  // the environment code lives in the FULL kernel variants
         } else {

@@ -710,7 +710,7 @@ D void shade_slice(const PathState &P, const DevScene &S, const DevTree &T, cons
                 int em_id = I.emitter;
                 if (FULL && !valid && S.env.w != 0) {  // GP:2236-2243: the ray left the scene
                     const float4 ro4 = P.ray_o[i];
-                    if (env_fill_direct(S, f3(ro4.x, ro4.y, ro4.z), d)) { value = f3(S.env.x, S.env.y, S.env.z); em_id = S.n_emitters; }
+                    if (env_fill_direct(S, f3(ro4.x, ro4.y, ro4.z), d)) { value = env_radiance(S, d); em_id = S.n_emitters; }
                 }
                 if (FULL && S.has_null && valid && I.emitter < 0) {
                     // rayIntersectAndLookForEmitter GP:2184-2245: the path continues from THIS hit, but the search for an emitter
@@ -742,7 +742,7 @@ D void shade_slice(const PathState &P, const DevScene &S, const DevTree &T, cons
                             value = mul3(transmittance, eval_Le(S, Ic, -d));
                             em_n = Ic.n; em_dist = hc.t; em_id = Ic.emitter;  // dist from the LAST ray origin, as in the reference
                         } else if (!abandoned && !surface && S.env.w != 0 && env_fill_direct(S, ro, d)) {
-                            value = mul3(transmittance, f3(S.env.x, S.env.y, S.env.z));
+                            value = mul3(transmittance, env_radiance(S, d));
                             em_id = S.n_emitters;
                         }
                     }
@@ -755,7 +755,7 @@ D void shade_slice(const PathState &P, const DevScene &S, const DevTree &T, cons
                     float pdfDirect = 0.0f;
                     const float dn = dot3(d, em_n);
                     if (FULL && em_id == S.n_emitters) {
-                        pdfDirect = env_pdf_direct(P.nee_cos[i]);
+                        pdfDirect = S.env.w == 2.0f ? envmap_pdf_direction(S, envmap_to_local(S, d)) : env_pdf_direct(P.nee_cos[i]);
                     } else if ((flags & FL_PEND_REFN) && dn < 0) {
                         const int4 info = S.em_info[em_id];
                         if (FULL && info.y < 0) {  // Sphere::pdfDirect needs dRec.ref = the previous vertex = this ray's origin
@@ -812,7 +812,7 @@ D void shade_slice(const PathState &P, const DevScene &S, const DevTree &T, cons
             // ---- first half of this bounce: GP:1902-2040 ----
             if (go && !valid) {  // GP:1902-1914: possibly radiance from a background luminaire, then the path ends
                 if (FULL && S.env.w != 0 && (flags & FL_EMITTED_OK) && (!R.hide_emitters || (flags & FL_SCATTERED)))
-                    Li = Li + mul3(thr, f3(S.env.x, S.env.y, S.env.z));  // (nVertices == 0 whenever emission is still enabled)
+                    Li = Li + mul3(thr, env_radiance(S, d));  // (nVertices == 0 whenever emission is still enabled)
                 go = false;
             }
             if (go) {

@@ -42,6 +42,9 @@ struct SceneData {
     std::vector<float> rtrans;    // rough-transmittance slices of the roughplastic materials, rtransSamples + 1 floats each
     uint32_t rtransSamples = 0;
     std::vector<ppg_sphere> spheres;  // analytic spheres
+    bool hasEnvmap = false;           // image-based environment emitter: envmap (pixels in envmapRgb)
+    mutable ppg_envmap envmap{};
+    std::vector<float> envmapRgb;
 
     ppg_scene view() const {
         ppg_scene s{};
@@ -53,6 +56,7 @@ struct SceneData {
         s.n_emitters = (uint32_t)emitters.size(); s.emitters = emitters.data();
         s.camera = camera;
         s.environment = hasEnvironment ? environment : nullptr;
+        if (hasEnvmap) { envmap.rgb = envmapRgb.data(); s.envmap = &envmap; }
         if (!spheres.empty()) { s.n_spheres = (uint32_t)spheres.size(); s.spheres = spheres.data(); }
         if (rtransSamples && !rtrans.empty()) { s.n_rtrans = (uint32_t)(rtrans.size() / (rtransSamples + 1)); s.rtrans_samples = rtransSamples; s.rtrans = rtrans.data(); }
         return s;

@@ -37,7 +37,7 @@ static bool loadScene(const char *path, SceneData &s) {
     s.materials.resize(nm); f.read((char *)s.materials.data(), (size_t)nm * sizeof(ppg_material));
     s.emitters.resize(ne); f.read((char *)s.emitters.data(), (size_t)ne * sizeof(ppg_emitter));
     f.read((char *)&s.camera, sizeof(ppg_camera));
-    s.hasEnvironment = (hdr[5] & 1) != 0;  // hdr[5]: optional blocks, bit 0 environment, bit 1 rtrans, bit 2 spheres
+    s.hasEnvironment = (hdr[5] & 1) != 0;  // hdr[5]: optional blocks, bit 0 environment, bit 1 rtrans, bit 2 spheres, bit 3 envmap
     if (s.hasEnvironment) f.read((char *)s.environment, 12);
     if (hdr[5] & 2) {
         uint32_t rt[2];
@@ -51,6 +51,13 @@ static bool loadScene(const char *path, SceneData &s) {
         f.read((char *)&n, 4);
         if (!f) return false;
         s.spheres.resize(n); f.read((char *)s.spheres.data(), (size_t)n * sizeof(ppg_sphere));
+    }
+    if (hdr[5] & 8) {
+        uint32_t wh[2];
+        f.read((char *)wh, 8); f.read((char *)&s.envmap.scale, 4); f.read((char *)s.envmap.to_world, 36);
+        if (!f) return false;
+        s.envmap.width = wh[0]; s.envmap.height = wh[1]; s.hasEnvmap = true;
+        s.envmapRgb.resize((size_t)wh[0] * wh[1] * 3); f.read((char *)s.envmapRgb.data(), s.envmapRgb.size() * 4);
     }
     return (bool)f;
 }
@@ -120,7 +127,7 @@ static void writePFM(const char *path, const std::vector<float> &rgb, int w, int
 static bool saveScene(const char *path, const SceneData &s) {
     std::ofstream f(path, std::ios::binary);
     const uint32_t hdr[6] = {(uint32_t)(s.positions.size() / 3), (uint32_t)(s.indices.size() / 3), (uint32_t)s.materials.size(), (uint32_t)s.emitters.size(),
-                             s.normals.empty() ? 0u : 1u, (s.hasEnvironment ? 1u : 0u) | (s.rtrans.empty() ? 0u : 2u) | (s.spheres.empty() ? 0u : 4u)};
+                             s.normals.empty() ? 0u : 1u, (s.hasEnvironment ? 1u : 0u) | (s.rtrans.empty() ? 0u : 2u) | (s.spheres.empty() ? 0u : 4u) | (s.hasEnvmap ? 8u : 0u)};
     f.write("PPGS", 4); f.write((const char *)hdr, sizeof hdr);
     f.write((const char *)s.positions.data(), s.positions.size() * 4);
     if (!s.normals.empty()) f.write((const char *)s.normals.data(), s.normals.size() * 4);
@@ -138,6 +145,11 @@ static bool saveScene(const char *path, const SceneData &s) {
     if (!s.spheres.empty()) {
         const uint32_t n = (uint32_t)s.spheres.size();
         f.write((const char *)&n, 4); f.write((const char *)s.spheres.data(), (size_t)n * sizeof(ppg_sphere));
+    }
+    if (s.hasEnvmap) {
+        const uint32_t wh[2] = {s.envmap.width, s.envmap.height};
+        f.write((const char *)wh, 8); f.write((const char *)&s.envmap.scale, 4); f.write((const char *)s.envmap.to_world, 36);
+        f.write((const char *)s.envmapRgb.data(), s.envmapRgb.size() * 4);
     }
     return (bool)f;
 }

@@ -7,7 +7,7 @@
  *   shapes      sphere (center, radius, toWorld = rotation x uniform scale, flipNormals; analytic), obj (filename, toWorld, faceNormals, flipNormals, flipTexCoords, collapse), rectangle (toWorld, flipNormals)
  *   bsdfs       diffuse, conductor, roughconductor / roughdielectric / roughplastic (ggx / beckmann, isotropic; roughplastic reads Mitsuba's data/microfacet tables), plastic, dielectric, thindielectric, mask (constant opacity),
  *               twosided(BRDF) — top level with id, nested, or <ref id>
- *   emitters    area (nested in a shape), constant (environment)
+ *   emitters    area (nested in a shape), constant (environment), envmap (latitude-longitude .exr / .pfm / .hdr; filename, scale, toWorld = rotation)
  *   values      <spectrum>, <rgb>, <srgb>; <transform> of translate / rotate / scale / lookAt / matrix; <default> and $name
  *
  * Anything else throws std::runtime_error naming the plugin.  Same semantics as ppg_host/mitsuba_xml.py (the two are tested against each
@@ -26,6 +26,7 @@
 
 #include "guided_path_hip.h"
 #include "rough_transmittance.h"
+#include "hdr_image.h"
 
 namespace ppg {
 
@@ -435,8 +436,29 @@ public:
         for (auto &b : root.children) if (b.tag == "bsdf" && b.attr("id")) m_byId[b.get("id")] = intern(makeBsdf(b, true, out), out);
         for (auto &e : root.children) {
             if (e.tag != "emitter") continue;
-            if (e.get("type") == "constant" && !out.scene.hasEnvironment) { out.scene.hasEnvironment = true; colour(e, "radiance", 1.0f, out.scene.environment); continue; }
-            throw std::runtime_error("emitter type '" + e.get("type") + "' is not supported (area emitters on shapes and one `constant` environment emitter; SURVEY.md §8 f2)");
+            if (e.get("type") == "constant" && !out.scene.hasEnvironment && !out.scene.hasEnvmap) { out.scene.hasEnvironment = true; colour(e, "radiance", 1.0f, out.scene.environment); continue; }
+            if (e.get("type") == "envmap" && !out.scene.hasEnvironment && !out.scene.hasEnvmap) {  // EnvironmentMap::EnvironmentMap, envmap.cpp:100-190
+                auto ep = props(e);
+                if (!ep.count("filename")) throw std::runtime_error("envmap emitter without filename");
+                std::string fn = ep["filename"];
+                if (fn.empty() || fn[0] != '/') fn = m_base + "/" + fn;
+                HdrImage img = readHdrImage(fn);
+                Mat4 m = Mat4::identity();
+                if (const XmlNode *tw = e.child("transform")) m = transform(*tw);
+                for (int a = 0; a < 3; ++a)
+                    for (int b = 0; b < 3; ++b) {
+                        float d = 0;
+                        for (int k = 0; k < 3; ++k) d += m.m[4 * a + k] * m.m[4 * b + k];
+                        if (std::fabs(d - (a == b ? 1.0f : 0.0f)) > 1e-4f) throw std::runtime_error("envmap: toWorld must be a rotation");
+                        out.scene.envmap.to_world[3 * a + b] = m.m[4 * a + b];
+                    }
+                out.scene.envmap.width = (uint32_t)img.width; out.scene.envmap.height = (uint32_t)img.height;
+                out.scene.envmap.scale = ep.count("scale") ? std::stof(ep["scale"]) : 1.0f;
+                out.scene.envmapRgb.swap(img.rgb);
+                out.scene.hasEnvmap = true;
+                continue;
+            }
+            throw std::runtime_error("emitter type '" + e.get("type") + "' is not supported (area emitters on shapes and one `constant` or `envmap` environment emitter; SURVEY.md §8 f2)");
         }
         // shapes
         struct Part { Mesh mesh; uint32_t mat; int em; };

@@ -106,6 +106,23 @@ class Sphere(C.Structure):
         return o
 
 
+class EnvMap(C.Structure):
+    """ppg_envmap (include/ppg.h).  Scene descriptions carry it as a dict: rgb (float32 [height, width, 3]), scale, to_world (9 floats)."""
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("rgb", C.POINTER(C.c_float)), ("scale", C.c_float), ("to_world", C.c_float * 9)]
+
+    @classmethod
+    def from_dict(cls, d):
+        o = cls()
+        rgb = np.ascontiguousarray(d["rgb"], np.float32)
+        assert rgb.ndim == 3 and rgb.shape[2] == 3
+        o.height, o.width = rgb.shape[0], rgb.shape[1]
+        o.rgb = rgb.ctypes.data_as(C.POINTER(C.c_float))
+        o.scale = float(np.float32(d.get("scale", 1.0)))
+        o.to_world[:] = [float(np.float32(v)) for v in np.asarray(d.get("to_world", np.eye(3)), np.float32).reshape(-1)]
+        o._keep = rgb
+        return o
+
+
 class Emitter(C.Structure):
     _fields_ = [("radiance", C.c_float * 3), ("_pad", C.c_float)]
 
@@ -121,7 +138,7 @@ class Scene(C.Structure):
                 ("tri_emitter", C.POINTER(C.c_int32)), ("n_materials", C.c_uint32), ("materials", C.POINTER(Material)),
                 ("n_emitters", C.c_uint32), ("emitters", C.POINTER(Emitter)), ("camera", Camera), ("environment", C.POINTER(C.c_float)),
                 ("n_rtrans", C.c_uint32), ("rtrans_samples", C.c_uint32), ("rtrans", C.POINTER(C.c_float)),
-                ("n_spheres", C.c_uint32), ("spheres", C.POINTER(Sphere))]
+                ("n_spheres", C.c_uint32), ("spheres", C.POINTER(Sphere)), ("envmap", C.POINTER(EnvMap))]
 
 
 class _StatsMixin:
@@ -246,12 +263,16 @@ class Engine:
             sph_arr[i] = Sphere.from_dict(d)
         if sph:
             s.n_spheres, s.spheres = len(sph), sph_arr
+        envmap = None
+        if getattr(desc, "envmap", None) is not None:
+            envmap = EnvMap.from_dict(desc.envmap)
+            s.envmap = C.pointer(envmap)
         cam = desc.camera
         s.camera.sample_to_camera[:] = [float(v) for v in np.asarray(cam["sample_to_camera"], np.float32).reshape(-1)]
         s.camera.camera_to_world[:] = [float(v) for v in np.asarray(cam["camera_to_world"], np.float32).reshape(-1)]
         s.camera.near_clip, s.camera.far_clip = cam["near_clip"], cam["far_clip"]
         s.camera.width, s.camera.height = cam["width"], cam["height"]
-        self._scene_keep = (pos, idx, tm, te, nrm, mats, ems, rt, sph_arr)
+        self._scene_keep = (pos, idx, tm, te, nrm, mats, ems, rt, sph_arr, envmap)
         self._call("set_scene", C.byref(s))
         self.width, self.height = cam["width"], cam["height"]
 

@@ -9,7 +9,7 @@
   bsdfs       diffuse, conductor (material none, or explicit eta / k), roughconductor / roughdielectric / roughplastic (ggx / beckmann, isotropic; roughplastic reads Mitsuba's data/microfacet tables),
               plastic, dielectric, thindielectric,
               mask (constant opacity), twosided(any of the BRDFs) — top level with id, nested, or <ref id>
-  emitters    area (nested in a shape), constant (environment)
+  emitters    area (nested in a shape), constant (environment), envmap (latitude-longitude .exr / .pfm / .hdr; filename, scale, toWorld = rotation)
   values      <spectrum>, <rgb>, <srgb> (spectrum.py), <transform> of translate / rotate / scale / lookAt / matrix,
               <default name value> and $name substitution (mitsuba -D, mitsuba.cpp:58-87)
 
@@ -505,12 +505,32 @@ def load_scene(path, defines=None, strict=True, width=None, height=None, data_di
             by_id[b.get("id")] = intern(make_bsdf(b))
     for tex in root.findall("texture"):
         warnings.append("top-level texture %r ignored" % tex.get("id"))
-    environment = None
+    environment = envmap = None
     for em in root.findall("emitter"):
-        if em.get("type") == "constant" and environment is None:
+        if em.get("type") == "constant" and environment is None and envmap is None:
             environment = tuple(float(v) for v in colour(em, "radiance", 1.0))
             continue
-        raise SceneError("emitter type %r is not supported (area emitters on shapes and one `constant` environment emitter; SURVEY.md §8 f2)" % em.get("type"))
+        if em.get("type") == "envmap" and environment is None and envmap is None:  # EnvironmentMap::EnvironmentMap, envmap.cpp:100-190
+            from . import imageio
+            ep = _props(em, sub)
+            fn = ep.get("filename")
+            if not fn:
+                raise SceneError("envmap emitter without filename")
+            full = fn if os.path.isabs(fn) else os.path.join(base, fn)
+            if not os.path.exists(full):
+                raise SceneError("envmap: file '%s' not found" % full)
+            try:
+                rgb = imageio.read_image(full)
+            except (ValueError, AssertionError) as e:
+                raise SceneError("envmap: %s" % e)
+            tw = em.find("transform")
+            R = (_transform(tw, sub) if tw is not None else np.eye(4, dtype=f32))[:3, :3].astype(f32)
+            if not np.allclose(R @ R.T, np.eye(3), atol=1e-4):
+                raise SceneError("envmap: toWorld must be a rotation")
+            envmap = dict(rgb=rgb, scale=float(ep.get("scale", 1.0)), to_world=[float(v) for v in R.reshape(-1)])
+            continue
+        raise SceneError("emitter type %r is not supported (area emitters on shapes and one `constant` or `envmap` environment emitter; "
+                         "SURVEY.md §8 f2)" % em.get("type"))
 
     # ---- shapes
     collected, emitters, spheres = [], [], []
@@ -607,7 +627,7 @@ def load_scene(path, defines=None, strict=True, width=None, height=None, data_di
         tmat.append(np.full(T, mat, np.uint32)); tem.append(np.full(T, em, np.int32))
     normals = np.concatenate(nrm).astype(f32) if any_normals else None
     desc = SceneDesc(np.concatenate(pos).astype(f32), np.concatenate(idx).astype(np.uint32), np.concatenate(tmat), np.concatenate(tem),
-                     materials, emitters, camera, normals, environment, np.stack(rt_slices).astype(f32) if rt_slices else None, spheres)
+                     materials, emitters, camera, normals, environment, np.stack(rt_slices).astype(f32) if rt_slices else None, spheres, envmap)
     info["warnings"] = warnings
     return desc, props, info
 
@@ -721,6 +741,13 @@ def save_scene_xml(desc, props, directory, name="scene"):
         out.append('\t</shape>')
     if getattr(desc, "environment", None) is not None:
         out.append('\t<emitter type="constant"><rgb name="radiance" value="%s"/></emitter>' % c(desc.environment))
+    if getattr(desc, "envmap", None) is not None:
+        from . import imageio
+        imageio.write_pfm(os.path.join(directory, name + "_envmap.pfm"), desc.envmap["rgb"])
+        M4 = np.eye(4, dtype=np.float32); M4[:3, :3] = np.asarray(desc.envmap.get("to_world", np.eye(3)), np.float32).reshape(3, 3)
+        out.append('\t<emitter type="envmap"><string name="filename" value="%s_envmap.pfm"/><float name="scale" value="%r"/>'
+                   '<transform name="toWorld"><matrix value="%s"/></transform></emitter>'
+                   % (name, float(desc.envmap.get("scale", 1.0)), " ".join(repr(float(x)) for x in M4.reshape(-1))))
     out.append('</scene>')
     path = os.path.join(directory, name + ".xml")
     with open(path, "w") as f:

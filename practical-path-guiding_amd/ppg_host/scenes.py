@@ -16,12 +16,13 @@ import numpy as np
 
 
 class SceneDesc:
-    def __init__(self, positions, indices, tri_material, tri_emitter, materials, emitters, camera, normals=None, environment=None, rtrans=None, spheres=None):
+    def __init__(self, positions, indices, tri_material, tri_emitter, materials, emitters, camera, normals=None, environment=None, rtrans=None, spheres=None, envmap=None):
         self.positions, self.indices = positions, indices
         self.tri_material, self.tri_emitter = tri_material, tri_emitter
         self.materials, self.emitters, self.camera, self.normals = materials, emitters, camera, normals
         self.environment = environment  # None or (r, g, b): constant environment emitter
         self.rtrans = rtrans            # None or float32 [n_slices, samples + 1]: rough-transmittance slices of the roughplastic materials
+        self.envmap = envmap            # None or dict(rgb=float32 [h, w, 3], scale, to_world): image-based environment emitter (bindings.EnvMap)
         self.spheres = spheres or []    # analytic spheres: dicts {center, radius, material, emitter, flip_normals, to_world} (bindings.Sphere)
 
     @property
@@ -31,10 +32,10 @@ class SceneDesc:
 
 def save_scene(desc, path):
     """Write the flat binary scene read by host/ppg_render.cpp: "PPGS", 6 x uint32 {n_vertices, n_triangles, n_materials,
-    n_emitters, has_normals, blocks (bit 0: environment, bit 1: rtrans, bit 2: spheres)}, then positions, [normals], indices, tri_material,
+    n_emitters, has_normals, blocks (bit 0: environment, bit 1: rtrans, bit 2: spheres, bit 3: envmap)}, then positions, [normals], indices, tri_material,
     tri_emitter, materials (ppg_material, 80 bytes each), emitters (4 floats), camera (ppg_camera), [environment radiance:
     3 floats], [rtrans: 2 x uint32 {n_slices, samples}, then n_slices x (samples + 1) floats], [spheres: uint32 n, then n x ppg_sphere
-    (64 bytes)]."""
+    (64 bytes)], [envmap: 2 x uint32 {width, height}, float scale, 9 floats to_world, then height x width x 3 floats]."""
     import struct
     pos = np.ascontiguousarray(desc.positions, np.float32)
     idx = np.ascontiguousarray(desc.indices, np.uint32)
@@ -44,7 +45,7 @@ def save_scene(desc, path):
         rt = getattr(desc, "rtrans", None)
         rt = None if rt is None or not len(rt) else np.ascontiguousarray(rt, np.float32)
         f.write(struct.pack("<6I", pos.shape[0], idx.shape[0], len(desc.materials), len(desc.emitters), 0 if desc.normals is None else 1,
-                            (0 if env is None else 1) | (0 if rt is None else 2) | (4 if getattr(desc, "spheres", None) else 0)))
+                            (0 if env is None else 1) | (0 if rt is None else 2) | (4 if getattr(desc, "spheres", None) else 0) | (8 if getattr(desc, "envmap", None) is not None else 0)))
         f.write(pos.tobytes())
         if desc.normals is not None:
             f.write(np.ascontiguousarray(desc.normals, np.float32).tobytes())
@@ -70,6 +71,12 @@ def save_scene(desc, path):
             f.write(struct.pack("<I", len(desc.spheres)))
             for d in desc.spheres:
                 f.write(bytes(Sphere.from_dict(d)))
+        if getattr(desc, "envmap", None) is not None:
+            em = desc.envmap
+            rgb = np.ascontiguousarray(em["rgb"], np.float32)
+            f.write(struct.pack("<2If9f", rgb.shape[1], rgb.shape[0], float(np.float32(em.get("scale", 1.0))),
+                                *[float(np.float32(v)) for v in np.asarray(em.get("to_world", np.eye(3)), np.float32).reshape(-1)]))
+            f.write(rgb.tobytes())
 
 
 def load_scene_file(path):
@@ -115,9 +122,15 @@ def load_scene_file(path):
             sp = Sphere.from_buffer_copy(bytes(take(np.uint8, 64)))
             spheres.append(dict(center=tuple(sp.center), radius=float(sp.radius), to_world=list(sp.to_world), material=int(sp.material), emitter=int(sp.emitter),
                                 flip_normals=bool(sp.flip_normals)))
+    envmap = None
+    if blocks & 8:
+        w, h = (int(v) for v in take(np.uint32, 2))
+        scale = float(take(np.float32, 1)[0])
+        R = [float(v) for v in take(np.float32, 9)]
+        envmap = dict(rgb=take(np.float32, w * h * 3).reshape(h, w, 3).copy(), scale=scale, to_world=R)
     if off[0] != len(buf):
         raise ValueError("%s: trailing bytes" % path)
-    return SceneDesc(pos, idx, tm, te, mats, ems, cam, nrm, env, rt, spheres)
+    return SceneDesc(pos, idx, tm, te, mats, ems, cam, nrm, env, rt, spheres, envmap)
 
 
 def _sample_to_camera(fov_deg, fov_axis, near, far, width, height):

@@ -81,12 +81,13 @@ def test_ctypes_mirrors_have_the_layout_of_the_header(tmp_path):
     import subprocess
     from ppg_host import bindings as b
     src = tmp_path / "layout.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "ppg.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", '
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "ppg.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", '
                    'sizeof(ppg_material), sizeof(ppg_sphere), sizeof(ppg_emitter), sizeof(ppg_camera), sizeof(ppg_scene), offsetof(ppg_material, rtrans), '
-                   'offsetof(ppg_scene, environment), offsetof(ppg_scene, rtrans), offsetof(ppg_scene, spheres), offsetof(ppg_sphere, material)); return 0; }\n')
+                   'offsetof(ppg_scene, environment), offsetof(ppg_scene, rtrans), offsetof(ppg_scene, spheres), offsetof(ppg_sphere, material), sizeof(ppg_envmap), offsetof(ppg_envmap, scale), offsetof(ppg_scene, envmap)); return 0; }\n')
     exe = str(tmp_path / "layout")
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-o", exe, str(src)], check=True)
     got = [int(v) for v in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
     want = [C.sizeof(b.Material), C.sizeof(b.Sphere), C.sizeof(b.Emitter), C.sizeof(b.Camera), C.sizeof(b.Scene), b.Material.rtrans.offset,
-            b.Scene.environment.offset, b.Scene.rtrans.offset, b.Scene.spheres.offset, b.Sphere.material.offset]
+            b.Scene.environment.offset, b.Scene.rtrans.offset, b.Scene.spheres.offset, b.Sphere.material.offset, C.sizeof(b.EnvMap), b.EnvMap.scale.offset,
+            b.Scene.envmap.offset]
     assert got == want and got[:2] == [80, 64]

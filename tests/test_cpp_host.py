@@ -137,7 +137,7 @@ def _read_ppgs(path):
     out["s2c"] = take(np.float32, 16); out["c2w"] = take(np.float32, 16)
     out["clip"] = take(np.float32, 2); out["size"] = take(np.int32, 2)
     out["env"] = take(np.float32, 3) if has_env else None
-    has_sph = blocks & 4
+    has_sph, has_em = blocks & 4, blocks & 8
     out["rtrans"] = None
     if has_rt:
         n, samples = take(np.uint32, 2)
@@ -148,6 +148,11 @@ def _read_ppgs(path):
         for _ in range(int(n)):
             f = take(np.float32, 13); i = take(np.int32, 3)
             out["spheres"].append(dict(center=tuple(f[:3]), radius=float(f[3]), to_world=f[4:13].copy(), material=int(i[0]), emitter=int(i[1]), flip_normals=int(i[2])))
+    out["envmap"] = None
+    if has_em:
+        w, h = (int(v) for v in take(np.uint32, 2))
+        scale = float(take(np.float32, 1)[0]); R = take(np.float32, 9).copy()
+        out["envmap"] = dict(rgb=take(np.float32, w * h * 3).reshape(h, w, 3), scale=scale, to_world=R)
     assert off == len(buf)
     return out
 
@@ -239,6 +244,35 @@ def test_cpp_roughplastic_slices_equal_the_python_loader(ppg_render, tmp_path):
     r2 = subprocess.run([ppg_render, "--ppgs", str(tmp_path / "again.ppgs"), "-q", str(tmp_path / "cpp.ppgs")], capture_output=True, text=True)
     assert r2.returncode == 0, r2.stderr
     assert open(str(tmp_path / "again.ppgs"), "rb").read() == open(str(tmp_path / "cpp.ppgs"), "rb").read()
+
+
+def test_cpp_envmap_readers_equal_the_python_loader(ppg_render, tmp_path):
+    """host/hdr_image.h against ppg_host/imageio.py: PFM, Radiance RGBE (flat and run-length encoded), uncompressed EXR and — where
+    the reference tree is mounted — one of its ZIP-compressed half-float EXR files, all through <emitter type="envmap">."""
+    import ppg_host
+    from ppg_host import imageio
+    from test_envmap import _write_hdr
+    from test_mitsuba_xml import _write
+    rng = np.random.RandomState(5)
+    img = (rng.rand(6, 40, 3) ** 3 * 50).astype(np.float32)
+    img[2, 5:30] = img[2, 5]
+    (tmp_path / "meshes").mkdir(exist_ok=True)
+    imageio.write_pfm(str(tmp_path / "m.pfm"), img); imageio.write_exr(str(tmp_path / "m.exr"), img)
+    _write_hdr(str(tmp_path / "flat.hdr"), img, False); _write_hdr(str(tmp_path / "rle.hdr"), img, True)
+    files = ["m.pfm", "m.exr", "flat.hdr", "rle.hdr"]
+    ref_exr = "/root/reference/scenes/cbox/cbox.exr"
+    if os.path.exists(ref_exr):
+        files.append(ref_exr)
+    for fn in files:
+        xml = _write(tmp_path, '<emitter type="envmap"><string name="filename" value="%s"/><float name="scale" value="1.5"/>'
+                               '<transform name="toWorld"><rotate x="1" y="2" z="3" angle="40"/></transform></emitter>' % fn)
+        r, c = _cpp_load(ppg_render, xml, tmp_path, "-D", "nee=never")
+        assert r.returncode == 0, r.stderr
+        desc, _, _ = ppg_host.load_scene(xml, defines=dict(nee="never"))
+        assert np.array_equal(c["envmap"]["rgb"], desc.envmap["rgb"]), fn
+        assert c["envmap"]["scale"] == desc.envmap["scale"] == 1.5 and np.allclose(c["envmap"]["to_world"], desc.envmap["to_world"], atol=1e-6)
+    r, _ = _cpp_load(ppg_render, _write(tmp_path, '<emitter type="envmap"><string name="filename" value="nope.hdr"/></emitter>'), tmp_path, "-D", "nee=never")
+    assert r.returncode == 2 and "not found" in r.stderr
 
 
 def test_cpp_scene_xml_loader_errors(ppg_render, tmp_path):

@@ -605,6 +605,55 @@ def test_analytic_spheres_against_oracle(oracle_lib, extra, sky):
             ppg_host.GuidedPathTracer(engine=hip(**props)).render(bad)
 
 
+def _envmap_scene(res, pane=False):
+    """CBOX without its ceiling and lamp under an image-based sky (a noisy map with a small, 60x brighter "sun", rotated about an oblique
+    axis); `pane`: a thin-dielectric pane closes the opening, so the sky is found THROUGH a null surface."""
+    import ppg_host
+    from test_envmap import _sun_map
+    scene = ppg_host.cbox_scene(*res)
+    keep = np.ones(len(scene.indices), bool); keep[0:2] = False; keep[4:6] = False     # the luminaire and the ceiling
+    scene.indices, scene.tri_material, scene.tri_emitter = scene.indices[keep], scene.tri_material[keep], scene.tri_emitter[keep]
+    scene.emitters = []
+    ax = np.float64([1, 2, 3]) / np.sqrt(14.0); a = 0.7
+    K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    R = np.eye(3) + np.sin(a) * K + (1 - np.cos(a)) * K @ K
+    scene.envmap = dict(rgb=_sun_map(), scale=0.5, to_world=R.astype(np.float32).reshape(-1))
+    if pane:
+        base_v = len(scene.positions)
+        quad = np.array([(0, 548, 0), (556, 548, 0), (556, 548, 559), (0, 548, 559)], np.float32)
+        scene.positions = np.vstack([scene.positions, quad]).astype(np.float32)
+        scene.indices = np.vstack([scene.indices, [[base_v, base_v + 1, base_v + 2], [base_v, base_v + 2, base_v + 3]]]).astype(np.uint32)
+        scene.materials = list(scene.materials) + [dict(type="thindielectric", eta=1.5, reflectance=(1, 1, 1), specular=(0.95, 0.97, 0.95))]
+        scene.tri_material = np.concatenate([scene.tri_material, np.full(2, len(scene.materials) - 1)]).astype(np.uint32)
+        scene.tri_emitter = np.concatenate([scene.tri_emitter, np.full(2, -1)]).astype(np.int32)
+    return scene
+
+
+@pytest.mark.parametrize("extra,pane", [({}, False), (dict(nee="always", **IMPROVED), False), (dict(nee="kickstart", maxDepth=-1, rrDepth=3, strictNormals=0), True),
+                                        (dict(nee="always", maxDepth=6), True)],
+                         ids=["default", "nee-always-improved", "pane-kickstart-unbounded", "pane-nee-always"])
+def test_environment_map_against_oracle(oracle_lib, extra, pane):
+    """emitters/envmap.cpp: level-0 bilinear lookups for rays that leave the scene (also through null surfaces, GP:2236-2243), luminance x
+    sin(theta) importance sampling with tent-filtered pixel positions (envmap.cpp:557-595) for next-event estimation, its solid-angle
+    density in the MIS weights (:598-633), the emitter's rotation; the cdfs are built on the host in the oracle's float operations."""
+    import ppg_host
+    scene = _envmap_scene((64, 64), pane)
+    props = dict(CBOX_PROPS, budget=60, seed=63)
+    props.update(maxDepth=10, rrDepth=5)
+    props.update(extra)
+    g, o = hip(**props), make_oracle(oracle_lib, threads=os.cpu_count() or 8, **props)
+    gg, go = ppg_host.GuidedPathTracer(engine=g), ppg_host.GuidedPathTracer(engine=o)
+    ig, io = gg.render(scene), go.render(scene)
+    assert _stats(gg) == _stats(go)
+    assert np.array_equal(ig, io, equal_nan=True)
+    assert_tree_equal(g.read_sdtree(), o.read_sdtree())
+    assert np.nanmean(ig) > 0.02
+    if not pane:
+        scene.environment = (1.0, 1.0, 1.0)
+        with pytest.raises(ppg_host.PPGError, match="one environment emitter"):
+            ppg_host.GuidedPathTracer(engine=hip(**props)).render(scene)
+
+
 def _pane_scene(res):
     """CBOX + two thin-dielectric panes: a horizontal one between the (upward-facing) luminaire and the ceiling and a vertical
     "window" across the room — most paths cross a null component, emitters are found through one or two panes."""
