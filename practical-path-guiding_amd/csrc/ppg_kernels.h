@@ -295,7 +295,8 @@ D void trace_slice_bvh4(const PathState &P, const DevScene &S, int *lds_stack, u
             float ay = (lys[k] - o.y) * id.y, by = (hys[k] - o.y) * id.y;
             float az = (lzs[k] - o.z) * id.z, bz = (hzs[k] - o.z) * id.z;
             float n = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), mint));
-            float f = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tlim));
+            // exit distance widened by 1 + 2 gamma_3 (3 roundings in the slab arithmetic): the test stays conservative whatever the box padding
+            float f = fminf(fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000008f, tlim);
             tn[k] = n;
             hit[k] = (n <= f) && chs[k] != PPG_BVH4_EMPTY;
         }
