@@ -18,12 +18,23 @@ import ppg_host
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--scene", default="cbox", choices=["cbox", "room"])
+ap.add_argument("--scene-file", help="flat scene file (e.g. scratch/spaceship.ppgs) with its .props instead of a procedural scene")
 ap.add_argument("--width", type=int, default=1280); ap.add_argument("--height", type=int, default=720)
 ap.add_argument("--ref-spp", type=int, default=8188); ap.add_argument("--cpu-spp", type=int, default=60)
 args = ap.parse_args()
 
 props = dict(budgetType="spp", maxDepth=10, rrDepth=10, strictNormals=1)
-if args.scene == "cbox":
+if args.scene_file:
+    scene = ppg_host.load_scene_file(args.scene_file)
+    args.width, args.height = scene.camera["width"], scene.camera["height"]
+    args.scene = os.path.splitext(os.path.basename(args.scene_file))[0]
+    props = dict(budgetType="spp")
+    for line in open(args.scene_file + ".props"):
+        if "=" in line:
+            k, v = line.strip().split("=", 1)
+            if k not in ("budget", "budgetType"):
+                props[k] = int(v) if v.lstrip("-").isdigit() else (float(v) if v.replace(".", "", 1).replace("-", "", 1).isdigit() else v)
+elif args.scene == "cbox":
     scene = ppg_host.cbox_scene(args.width, args.height)
 else:
     scene = ppg_host.room_scene(args.width, args.height, n_boxes=1820, tess=8)
