@@ -231,7 +231,9 @@ D Hit trace_closest(const DevScene &S, const LdsScene &L, F3 o, F3 d, float mint
 
 // Traversal stack: the first PPG_LDS_STACK entries of every lane live in an LDS column (conflict-free, no
 // scratch traffic), deeper entries — rare — in a small private array.
+#ifndef PPG_LDS_STACK
 #define PPG_LDS_STACK 24
+#endif
 struct TStack {
     int *lds;      // this lane's column, stride blockDim.x
     int stride;

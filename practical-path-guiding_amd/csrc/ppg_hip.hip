@@ -83,6 +83,7 @@ struct BvhBuilder {
     std::vector<float> bmin, bmax, cent;  // per tri
     std::vector<BvhNode> nodes;
     float pad;
+    int maxLeaf = 4;  // triangles per leaf (the BVH4 child code holds up to 8)
 
     struct Box { float lo[3], hi[3]; };
     static Box empty() { Box b; for (int a = 0; a < 3; ++a) { b.lo[a] = INFINITY; b.hi[a] = -INFINITY; } return b; }
@@ -98,7 +99,7 @@ struct BvhBuilder {
     // returns (ref, n): n > 0 leaf [ref, ref+n), n == 0 interior node ref
     void build(int first, int count, int &ref, int &n, Box &box) {
         box = boundsOf(first, count);
-        if (count <= 4) { ref = first; n = count; return; }
+        if (count <= maxLeaf) { ref = first; n = count; return; }
         Box cb = empty();
         for (int i = first; i < first + count; ++i) grow(cb, &cent[3 * order[i]], &cent[3 * order[i]]);
         int bestAxis = -1, bestSplit = -1; float bestCost = INFINITY;
@@ -1152,6 +1153,7 @@ int ppg_set_scene(ppg_ctx *ctx, const ppg_scene *s) {
     // ~4 * 2^-24 * (distance travelled) in position; 2e-6 * (scene extent) leaves an 8x margin.  (1e-4 * extent, the first
     // choice, made the leaf boxes of a finely tessellated model under a 100 m sky dome several triangles thick: 4x slower.)
     const float padRel = getenv("PPG_BVH_PAD") ? (float)atof(getenv("PPG_BVH_PAD")) : 2e-6f;
+    if (const char *e = getenv("PPG_BVH_LEAF")) bb.maxLeaf = std::max(1, std::min(8, atoi(e)));
     bb.run(s->positions, s->indices, s->n_triangles, padRel * ext + 1e-30f);
     std::vector<float4> tris(3 * (size_t)s->n_triangles), nrm, accel(3 * (size_t)s->n_triangles);
     if (s->normals) nrm.resize(tris.size());

@@ -367,6 +367,9 @@ D void trace_slice(const PathState &P, const DevScene &S, const LdsScene &L, int
 
 // SMALL: the whole scene (<= 64 triangles) is tested from LDS without a BVH.
 template <bool SMALL>
+#ifdef PPG_TRACE_WAVES
+__attribute__((amdgpu_waves_per_eu(PPG_TRACE_WAVES, PPG_TRACE_WAVES)))
+#endif
 __global__ __launch_bounds__(PPG_BLOCK) void k_trace(PathState P, DevScene S, Queues Q, int qin, int lds_nodes, int lds_tris) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __shared__ unsigned long long acc;
