@@ -162,17 +162,6 @@ D bool tri_hit_axis(const float4 *A, float o_u, float o_v, float o_k, float d_u,
 
 D float safe_inv(float d) { return d == 0.0f ? 1e30f : 1.0f / d; }
 
-// conservative slab test against a (padded) box; returns entry distance in tn
-D bool box_hit(const float *lo, const float *hi, F3 o, F3 id, float t0, float t1, float &tn) {
-    float ax = (lo[0] - o.x) * id.x, bx = (hi[0] - o.x) * id.x;
-    float ay = (lo[1] - o.y) * id.y, by = (hi[1] - o.y) * id.y;
-    float az = (lo[2] - o.z) * id.z, bz = (hi[2] - o.z) * id.z;
-    float n = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), t0));
-    float f = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), t1));
-    tn = n;
-    return n <= f;
-}
-
 // Scene cache in LDS: the first `n_nodes` BVH nodes and (if they all fit) the triangles.  Small scenes such
 // as CBOX live there entirely; for large ones the top of the tree, which every ray visits, does.
 struct LdsScene {
@@ -180,54 +169,6 @@ struct LdsScene {
     const float4 *tris;
     int n_nodes, n_tris;
 };
-
-// Closest hit by (t, original primitive index) — order independent, equals brute force.
-D Hit trace_closest(const DevScene &S, const LdsScene &L, F3 o, F3 d, float mint, float maxt) {
-    Hit best;
-    best.t = __builtin_inff(); best.u = 0; best.v = 0; best.prim = -1;
-    int bestOrig = 0x7fffffff;
-    F3 id = f3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
-    int stack[48];
-    int sp = 0;
-    int cur = 0;
-    for (;;) {
-        const BvhNode nd = cur < L.n_nodes ? L.nodes[cur] : S.bvh[cur];
-        float tlim = fminf(maxt, best.t);
-        float tn0, tn1;
-        bool h0 = nd.n0 >= 0 && box_hit(nd.lo0, nd.hi0, o, id, mint, tlim, tn0);
-        bool h1 = nd.n1 >= 0 && box_hit(nd.lo1, nd.hi1, o, id, mint, tlim, tn1);
-        int next0 = -1, next1 = -1;
-#pragma unroll
-        for (int side = 0; side < 2; ++side) {
-            bool h = side ? h1 : h0;
-            int n = side ? nd.n1 : nd.n0, c = side ? nd.c1 : nd.c0;
-            if (!h) continue;
-            if (n > 0) {
-                for (int k = c; k < c + n; ++k) {
-                    float tt, uu, vv;
-                    const float4 *T = (k < L.n_tris ? L.tris : S.accel) + 3 * k;
-                    if (tri_hit(T, o, d, mint, fminf(maxt, best.t), tt, uu, vv)) {
-                        int orig = __float_as_int(T[2].w);
-                        if (tt < best.t || (tt == best.t && orig < bestOrig)) {
-                            best.t = tt; best.u = uu; best.v = vv; best.prim = k; bestOrig = orig;
-                        }
-                    }
-                }
-            } else if (side == 0) next0 = c; else next1 = c;
-        }
-        if (next0 >= 0 && next1 >= 0) {
-            if (tn1 < tn0) { int t = next0; next0 = next1; next1 = t; }
-            stack[sp++] = next1;
-            cur = next0;
-        } else if (next0 >= 0) cur = next0;
-        else if (next1 >= 0) cur = next1;
-        else {
-            if (sp == 0) break;
-            cur = stack[--sp];
-        }
-    }
-    return best;
-}
 
 // Traversal stack: the first PPG_LDS_STACK entries of every lane live in an LDS column (conflict-free, no
 // scratch traffic), deeper entries — rare — in a small private array.
