@@ -102,6 +102,16 @@ def run(args):
         spp = int(props.get("sppPerPass", spp))
         workload = "%s (%d triangles, %d spheres), %dx%d, %d spp/pass, %d passes, the scene file's integrator settings" % (
             os.path.basename(args.scene_file), scene.n_triangles, len(scene.spheres), args.width, args.height, spp, args.steps)
+    elif args.scene == "torus":
+        # BASELINE.json configs[4] "TORUS (SDS caustics), 1920x1080, sppPerPass=1, sTreeThreshold=4000": the paper's scene is not bundled with
+        # the reference — the labelled procedural stand-in of SURVEY.md §8(d) S5 (diffuse torus in a glass cube, one small emitter)
+        if (args.width, args.height) == (1280, 720):
+            args.width, args.height = 1920, 1080
+        spp = 1
+        scene = ppg_host.torus_scene(args.width, args.height)
+        props.update(sppPerPass=1, sTreeThreshold=4000, maxDepth=-1, rrDepth=5, strictNormals=0)
+        workload = "torus-1080p (torus-class STAND-IN: diffuse torus in a glass cube, %d triangles), %dx%d, 1 spp/pass, %d passes, sTreeThreshold 4000" % (
+            scene.n_triangles, args.width, args.height, args.steps)
     elif args.scene == "cbox":
         scene = ppg_host.cbox_scene(args.width, args.height)
     else:
@@ -225,7 +235,7 @@ def main():
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--spp", type=int, default=4)
-    ap.add_argument("--scene", choices=["cbox", "room"], default="cbox", help="room = kitchen-class procedural stand-in, improved preset")
+    ap.add_argument("--scene", choices=["cbox", "room", "torus"], default="cbox", help="room = kitchen-class procedural stand-in, improved preset; torus = torus-class stand-in (SDS caustics)")
     ap.add_argument("--scene-file", help="flat scene file (ppg_host.save_scene / `python -m ppg_host scene.xml --ppgs`) instead of a procedural scene")
     ap.add_argument("--room-boxes", type=int, default=1820, help="boxes of the room scene (768 triangles each)")
     ap.add_argument("--glossy", action="store_true", help="room scene with the S3 material mix (GGX alpha 0.1 metal, plastic) instead of Lambertian only")

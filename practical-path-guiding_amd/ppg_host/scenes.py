@@ -313,3 +313,46 @@ def room_scene(width=1280, height=720, n_boxes=2000, tess=4, seed=1234, glossy=F
     emitters = [dict(radiance=(60.0, 55.0, 45.0))]
     cam = perspective_camera((2.0, 1.5, 0.15), (2.0, 1.2, 3.0), (0, 1, 0), 70.0, "x", 0.05, 100.0, width, height)
     return SceneDesc(positions, indices, tri_mat.astype(np.uint32), tri_em.astype(np.int32), materials, emitters, cam)
+
+
+def torus_scene(width=1920, height=1080, n_major=96, n_minor=48):
+    """Torus-class stand-in (the paper's TORUS scene is not bundled with the reference): a diffuse torus inside a
+    glass cube (dielectric, eta 1.5) on a diffuse floor in a closed room, lit by one small area emitter — every path that reaches the
+    torus is specular-diffuse-specular.  2 * n_major * n_minor + 12 (cube) + 12 (room) + 2 (lamp) triangles, deterministic."""
+    P, I, M, E = [], [], [], []
+
+    def quad(a, b, c, d, mat, em=-1):
+        k = len(P)
+        P.extend([a, b, c, d]); I.extend([(k, k + 1, k + 2), (k, k + 2, k + 3)]); M.extend([mat, mat]); E.extend([em, em])
+
+    def box(lo, hi, mat, inward):
+        x0, y0, z0 = lo; x1, y1, z1 = hi
+        faces = [((x0, y0, z0), (x1, y0, z0), (x1, y0, z1), (x0, y0, z1)),   # bottom (normal -y when outward)
+                 ((x0, y1, z0), (x0, y1, z1), (x1, y1, z1), (x1, y1, z0)),   # top
+                 ((x0, y0, z0), (x0, y0, z1), (x0, y1, z1), (x0, y1, z0)),   # -x
+                 ((x1, y0, z0), (x1, y1, z0), (x1, y1, z1), (x1, y0, z1)),   # +x
+                 ((x0, y0, z0), (x0, y1, z0), (x1, y1, z0), (x1, y0, z0)),   # -z
+                 ((x0, y0, z1), (x1, y0, z1), (x1, y1, z1), (x0, y1, z1))]   # +z
+        for f in faces:
+            quad(*(f[::-1] if inward else f), mat)
+    box((-4.0, 0.0, -4.0), (4.0, 4.0, 4.0), 0, True)            # the room, normals inward
+    box((-1.0, 0.002, -1.0), (1.0, 1.2, 1.0), 1, False)         # the glass cube (a hair above the floor)
+    R, r, cy = 0.55, 0.2, 0.45                                  # the torus, axis +y
+    base = len(P)
+    for a in range(n_major):
+        ua = 2 * math.pi * a / n_major
+        for b in range(n_minor):
+            vb = 2 * math.pi * b / n_minor
+            rr = R + r * math.cos(vb)
+            P.append((rr * math.cos(ua), cy + r * math.sin(vb), rr * math.sin(ua)))
+    for a in range(n_major):
+        for b in range(n_minor):
+            i00 = base + a * n_minor + b; i01 = base + a * n_minor + (b + 1) % n_minor
+            i10 = base + ((a + 1) % n_major) * n_minor + b; i11 = base + ((a + 1) % n_major) * n_minor + (b + 1) % n_minor
+            I.extend([(i00, i01, i11), (i00, i11, i10)]); M.extend([2, 2]); E.extend([-1, -1])
+    quad((-0.15, 3.6, -0.15), (0.15, 3.6, -0.15), (0.15, 3.6, 0.15), (-0.15, 3.6, 0.15), 3, 0)   # the lamp, facing down
+    materials = [dict(type=0, reflectance=(0.6, 0.6, 0.6)), dict(type="dielectric", eta=1.5, reflectance=(1, 1, 1), specular=(1, 1, 1)),
+                 dict(type=0, reflectance=(0.8, 0.35, 0.15)), dict(type=0, reflectance=(0, 0, 0))]
+    cam = perspective_camera((3.3, 2.5, -3.6), (0.0, 0.5, 0.0), (0, 1, 0), 46.0, "x", 0.01, 100.0, width, height)
+    return SceneDesc(np.array(P, np.float32), np.array(I, np.uint32), np.array(M, np.uint32), np.array(E, np.int32), materials,
+                     [dict(radiance=(400.0, 400.0, 400.0))], cam)
