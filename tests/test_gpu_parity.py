@@ -654,6 +654,20 @@ def test_environment_map_against_oracle(oracle_lib, extra, pane):
             ppg_host.GuidedPathTracer(engine=hip(**props)).render(scene)
 
 
+def test_torus_class_stand_in_against_oracle(oracle_lib):
+    """ppg_host.torus_scene (bench.py --scene torus, BASELINE configs[4] stand-in): unbounded specular chains inside the glass cube, the
+    k_tail path, 1 spp per pass."""
+    import ppg_host
+    scene = ppg_host.torus_scene(64, 36, n_major=24, n_minor=12)
+    props = dict(budgetType="spp", budget=31, sppPerPass=1, sTreeThreshold=4000, maxDepth=-1, rrDepth=5, seed=7)
+    g, o = hip(**props), make_oracle(oracle_lib, threads=os.cpu_count() or 8, **props)
+    gg, go = ppg_host.GuidedPathTracer(engine=g), ppg_host.GuidedPathTracer(engine=o)
+    ig, io = gg.render(scene), go.render(scene)
+    assert _stats(gg) == _stats(go)
+    assert np.array_equal(ig, io, equal_nan=True) and np.isfinite(ig).all() and ig.mean() > 0.05
+    assert_tree_equal(g.read_sdtree(), o.read_sdtree())
+
+
 def _pane_scene(res):
     """CBOX + two thin-dielectric panes: a horizontal one between the (upward-facing) luminaire and the ceiling and a vertical
     "window" across the room — most paths cross a null component, emitters are found through one or two panes."""

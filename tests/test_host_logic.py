@@ -198,3 +198,21 @@ def test_automatic_sdt_dumps_and_memory_cap(oracle_lib, tmp_path):
     free = make_oracle(oracle_lib, budget=124, seed=2, sTreeThreshold=200, **CBOX_PROPS); free.set_scene(scene); free.render()
     capped = make_oracle(oracle_lib, budget=124, seed=2, sTreeThreshold=200, sdTreeMaxMemory=0, **CBOX_PROPS); capped.set_scene(scene); capped.render()
     assert capped.read_sdtree()["n_leaves"] == 1 < free.read_sdtree()["n_leaves"]  # footprint / 1e6 >= 0 always: never refined
+
+
+def test_torus_scene_is_closed_and_deterministic():
+    """The torus-class stand-in: triangle count by formula, every edge of the torus and of the cube shared by exactly two triangles
+    (closed surfaces — the glass cube must be watertight for the dielectric's inside / outside bookkeeping), one emitter."""
+    import ppg_host
+    a, b = ppg_host.torus_scene(64, 36, n_major=24, n_minor=12), ppg_host.torus_scene(64, 36, n_major=24, n_minor=12)
+    assert a.n_triangles == 2 * 24 * 12 + 12 + 12 + 2 and np.array_equal(a.positions, b.positions) and np.array_equal(a.indices, b.indices)
+    assert (a.tri_emitter >= 0).sum() == 2 and len(a.emitters) == 1
+    for mat in (1, 2):                                     # glass cube, torus
+        tris = a.indices[a.tri_material == mat]
+        pos = np.round(a.positions[tris], 5)
+        edges = {}
+        for t in pos:
+            for k in range(3):
+                e = tuple(sorted([tuple(t[k]), tuple(t[(k + 1) % 3])]))
+                edges[e] = edges.get(e, 0) + 1
+        assert set(edges.values()) == {2}, mat
