@@ -108,11 +108,14 @@ if sys.argv[4] == "inversevar":
     props.update(sampleCombination="inversevar", spatialFilter="stochastic", directionalFilter="box", sTreeThreshold=2000)
 if sys.argv[4] == "improved":
     props.update(sampleCombination="inversevar", bsdfSamplingFractionLoss="kl", spatialFilter="stochastic", directionalFilter="box", sTreeThreshold=2000, sppPerPass=1)
-if sys.argv[4] == "nee":
+if sys.argv[4] in ("nee", "full-scene"):
     props.update(nee="kickstart", bsdfSamplingFractionLoss="var", spatialFilter="box", sTreeThreshold=2000)
 e = ppg_host.Engine(lib, "ppgo_", **props)
 lib.ppgo_set_modes(e.ctx, 0, 0, 2)
 scene = ppg_host.cbox_scene(64, 48)
+if sys.argv[4] == "full-scene":
+    from test_gpu_parity import _sphere_scene
+    scene = _sphere_scene((64, 48), sky=True)
 e.set_scene(scene); e.set_shard(rank, world, 16)
 img = ppg_host.GuidedPathTracer(engine=e, reducer=HostReducer(dist)).render()
 t = e.read_sdtree()
@@ -121,7 +124,7 @@ dist.barrier(); dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("mode", ["default", "inversevar", "improved", "nee"])
+@pytest.mark.parametrize("mode", ["default", "inversevar", "improved", "nee", "full-scene"])
 def test_sharded_render_over_gloo_equals_single_rank(oracle_lib, tmp_path, mode):
     """world_size 2, gloo: tiles sharded, SD-tree statistics all-reduced as int64 → the merged render is
     bit-identical to the unsharded one on every rank."""
@@ -139,10 +142,14 @@ def test_sharded_render_over_gloo_equals_single_rank(oracle_lib, tmp_path, mode)
     if mode == "improved":  # learned BSDF sampling fraction: the per-pass Adam sums are all-reduced through the pass hook
         props.update(sampleCombination="inversevar", bsdfSamplingFractionLoss="kl", spatialFilter="stochastic", directionalFilter="box",
                      sTreeThreshold=2000, sppPerPass=1)
-    if mode == "nee":  # direct-light vertices are committed inside Li's loop on whichever rank owns the pixel
+    if mode in ("nee", "full-scene"):  # direct-light vertices are committed inside Li's loop on whichever rank owns the pixel
         props.update(nee="kickstart", bsdfSamplingFractionLoss="var", spatialFilter="box", sTreeThreshold=2000)
+    scene = ppg_host.cbox_scene(64, 48)
+    if mode == "full-scene":  # analytic spheres (glass, rough gold, lamp) under an emitting sky dome: the S-tree spans the dome
+        from test_gpu_parity import _sphere_scene
+        scene = _sphere_scene((64, 48), sky=True)
     e = make_oracle(oracle_lib, threads=4, **props)
-    e.set_scene(ppg_host.cbox_scene(64, 48)); e.render()
+    e.set_scene(scene); e.render()
     ref_img, ref_t = e.read_film(), e.read_sdtree()
     for r in range(2):
         got = np.load(tmp_path / ("rank%d.npz" % r))
