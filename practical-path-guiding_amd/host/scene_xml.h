@@ -279,7 +279,58 @@ inline void computeNormals(Mesh &m, bool flip) {  // TriMesh::computeNormals, sm
     }
 }
 
-inline std::vector<Mesh> loadOBJ(const std::string &path, const Mat4 &toWorld, bool faceNormals, bool flipNormals, bool flipTexCoords, bool collapse) {
+/* TriMesh::rebuildTopology (trimesh.cpp:468-608): vertices re-merged on (position[, uv]); around each, the incident triangles are
+ * clustered greedily by face normal (one new vertex per cluster of faces within maxAngle degrees of the cluster's first face), so that
+ * the smooth normals computed afterwards stop at creases.  New vertices are numbered in the reference's order. */
+inline void rebuildTopology(Mesh &m, const std::vector<std::pair<float, float>> *uvs, float maxAngle) {
+    const float dpThresh = std::cos(maxAngle * (float)(M_PI / 180.0));
+    const size_t nt = m.indices.size() / 3;
+    std::vector<V3> fn(nt);
+    for (size_t t = 0; t < nt; ++t) {
+        const V3 v0 = m.positions[m.indices[3 * t]], v1 = m.positions[m.indices[3 * t + 1]], v2 = m.positions[m.indices[3 * t + 2]];
+        V3 n = cross(v1 - v0, v2 - v0);
+        const float l = std::sqrt(dot(n, n));
+        fn[t] = l > 2.93873587705571876e-39f ? V3{n.x / l, n.y / l, n.z / l} : V3{0, 0, 0};  // RCPOVERFLOW_FLT
+    }
+    struct Key { float v[5]; int n; bool operator<(const Key &o) const { return std::lexicographical_compare(v, v + n, o.v, o.v + o.n); } };
+    std::multimap<Key, std::pair<uint32_t, bool>> vertexToFace;  // equal keys keep their insertion order (triangle, corner)
+    for (size_t t = 0; t < nt; ++t)
+        for (int j = 0; j < 3; ++j) {
+            const uint32_t v = m.indices[3 * t + j];
+            Key k{{m.positions[v].x, m.positions[v].y, m.positions[v].z, uvs ? (*uvs)[v].first : 0.0f, uvs ? (*uvs)[v].second : 0.0f}, uvs ? 5 : 3};
+            vertexToFace.insert({k, {(uint32_t)t, false}});
+        }
+    std::vector<V3> newPositions;
+    std::vector<uint32_t> newIndices(m.indices.size(), 0xFFFFFFFFu);
+    for (auto it = vertexToFace.begin(); it != vertexToFace.end();) {
+        auto end = vertexToFace.upper_bound(it->first);
+        const V3 p{it->first.v[0], it->first.v[1], it->first.v[2]};
+        for (auto it2 = it; it2 != end; ++it2) {
+            if (it2->second.second) continue;
+            const V3 n1 = fn[it2->second.first];
+            const uint32_t vertexIdx = (uint32_t)newPositions.size();
+            newPositions.push_back(p);
+            for (auto it3 = it2; it3 != end; ++it3) {
+                if (it3->second.second) continue;
+                const V3 n2 = fn[it3->second.first];
+                if ((n1.x == n2.x && n1.y == n2.y && n1.z == n2.z) || dot(n1, n2) > dpThresh) {
+                    for (int i = 0; i < 3; ++i) {
+                        const V3 q = m.positions[m.indices[3 * it3->second.first + i]];
+                        if (q.x == p.x && q.y == p.y && q.z == p.z) newIndices[3 * it3->second.first + i] = vertexIdx;
+                    }
+                    it3->second.second = true;
+                }
+            }
+        }
+        it = end;
+    }
+    m.positions.swap(newPositions);
+    m.indices.swap(newIndices);
+    m.normals.clear();
+}
+
+inline std::vector<Mesh> loadOBJ(const std::string &path, const Mat4 &toWorld, bool faceNormals, bool flipNormals, bool flipTexCoords, bool collapse,
+                                 float maxSmoothAngle = -1.0f) {
     std::ifstream is(path);
     if (!is) throw std::runtime_error("Wavefront OBJ file '" + path + "' not found!");
     std::vector<V3> V, N;
@@ -302,7 +353,8 @@ inline std::vector<Mesh> loadOBJ(const std::string &path, const Mat4 &toWorld, b
         std::map<Key, uint32_t> vmap;
         Mesh m;
         std::vector<V3> vn;
-        bool hasNormals = false;
+        std::vector<std::pair<float, float>> vuv;
+        bool hasNormals = false, hasUVs = false;
         for (const Corner &c : tris) {
             int p = c.p, n = c.n, uv = c.uv;
             if (p < 0) p += (int)V.size() + 1;
@@ -312,14 +364,16 @@ inline std::vector<Mesh> loadOBJ(const std::string &path, const Mat4 &toWorld, b
             if (n > (int)N.size() || uv > (int)UV.size()) throw std::runtime_error(path + ": normal / uv index out of bounds");
             V3 pn = n ? nw[n - 1] : V3{0, 0, 0};
             hasNormals |= n != 0;
+            hasUVs |= uv != 0;
             std::pair<float, float> puv = uv ? UV[uv - 1] : std::make_pair(0.0f, 0.0f);
             Key k{{pw[p - 1].x, pw[p - 1].y, pw[p - 1].z, pn.x, pn.y, pn.z, puv.first, puv.second}};
             auto it = vmap.find(k);
             uint32_t id;
-            if (it == vmap.end()) { id = (uint32_t)m.positions.size(); vmap[k] = id; m.positions.push_back(pw[p - 1]); vn.push_back(pn); }
+            if (it == vmap.end()) { id = (uint32_t)m.positions.size(); vmap[k] = id; m.positions.push_back(pw[p - 1]); vn.push_back(pn); vuv.push_back(puv); }
             else id = it->second;
             m.indices.push_back(id);
         }
+        if (maxSmoothAngle >= 0) { rebuildTopology(m, hasUVs ? &vuv : nullptr, maxSmoothAngle); hasNormals = false; }  // obj.cpp:336-343
         if (faceNormals) {
             if (flipNormals) for (size_t t = 0; t + 2 < m.indices.size(); t += 3) std::swap(m.indices[t], m.indices[t + 1]);
         } else if (hasNormals) {
@@ -475,11 +529,13 @@ public:
             bool isSphere = false;
             if (t == "obj") {
                 if (!pr.count("filename")) throw std::runtime_error("obj shape without filename");
-                if (pr.count("maxSmoothAngle") || pr.count("shapeIndex")) throw std::runtime_error("obj: maxSmoothAngle / shapeIndex are not supported");
+                if (pr.count("shapeIndex")) throw std::runtime_error("obj: shapeIndex is not supported");
+                if (pr.count("maxSmoothAngle") && flag(pr, "faceNormals", false)) throw std::runtime_error("The properties 'maxSmoothAngle' and 'faceNormals' can't be specified at the same time!");
                 std::string fn = pr["filename"];
                 if (fn.empty() || fn[0] != '/') fn = m_base + "/" + fn;
                 if (!m_strict && !std::ifstream(fn)) { out.warnings.push_back("shape skipped: Wavefront OBJ file '" + fn + "' not found"); continue; }
-                meshes = loadOBJ(fn, m, flag(pr, "faceNormals", false), flag(pr, "flipNormals", false), flag(pr, "flipTexCoords", true), flag(pr, "collapse", false));
+                meshes = loadOBJ(fn, m, flag(pr, "faceNormals", false), flag(pr, "flipNormals", false), flag(pr, "flipTexCoords", true), flag(pr, "collapse", false),
+                                 pr.count("maxSmoothAngle") ? std::stof(pr["maxSmoothAngle"]) : -1.0f);
             } else if (t == "rectangle") {
                 meshes.push_back(rectangle(m, flag(pr, "flipNormals", false)));
             } else if (t == "sphere") {  // Sphere::Sphere, sphere.cpp:108-131: the scale of toWorld goes into the radius, the rest stays a rotation

@@ -4,7 +4,7 @@
   sensor      perspective (fov, fovAxis, nearClip, farClip, toWorld; focusDistance ignored: pinhole),
               nested sampler (independent; sampleCount / seed do not steer guided_path, GP:1342-1374) and
               film hdrfilm (width, height; rfilter box)
-  shapes      obj (filename, toWorld, faceNormals, flipNormals, flipTexCoords, collapse), rectangle (toWorld, flipNormals),
+  shapes      obj (filename, toWorld, faceNormals, maxSmoothAngle, flipNormals, flipTexCoords, collapse), rectangle (toWorld, flipNormals),
               sphere (center, radius, toWorld = rotation x uniform scale, flipNormals) — analytic, not tessellated
   bsdfs       diffuse, conductor (material none, or explicit eta / k), roughconductor / roughdielectric / roughplastic (ggx / beckmann, isotropic; roughplastic reads Mitsuba's data/microfacet tables),
               plastic, dielectric, thindielectric,
@@ -176,7 +176,69 @@ def compute_normals(pos, tris, flip=False):
     return n
 
 
-def load_obj(path, to_world=None, face_normals=False, flip_normals=False, flip_tex_coords=True, collapse=False):
+def _cosf(x):
+    """cosf of the C library (the crease threshold of rebuild_topology must not depend on numpy's float32 cosine)."""
+    import ctypes
+    import ctypes.util
+    global _libm_cos
+    try:
+        _libm_cos
+    except NameError:
+        _libm_cos = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+        _libm_cos.cosf.restype, _libm_cos.cosf.argtypes = ctypes.c_float, [ctypes.c_float]
+    return f32(_libm_cos.cosf(float(f32(x))))
+
+
+def rebuild_topology(pos, uvs, idx, max_angle):
+    """TriMesh::rebuildTopology (trimesh.cpp:468-608): vertices are re-merged on (position, uv) and, around every such vertex, the
+    incident triangles are greedily clustered by face normal — a new vertex per cluster of faces whose normals differ by less than
+    `max_angle` degrees from the cluster's first face — so that the smooth normals computed afterwards stop at creases.
+    Returns (positions, uvs or None, indices); new vertices are numbered in the reference's order (sorted by position, then uv;
+    clusters in triangle order)."""
+    pos = np.asarray(pos, f32); idx = np.asarray(idx, np.int64)
+    dp_thresh = _cosf(f32(max_angle) * f32(math.pi / 180.0))  # std::cos(degToRad(maxAngle))
+    v0, v1, v2 = pos[idx[:, 0]], pos[idx[:, 1]], pos[idx[:, 2]]
+    n = np.cross(v1 - v0, v2 - v0).astype(f32)
+    ln = np.sqrt(np.sum(n * n, 1, dtype=f32), dtype=f32)
+    ok = ln > f32(2.93873587705571876e-39)  # RCPOVERFLOW_FLT
+    fn = np.zeros_like(n)
+    fn[ok] = n[ok] / ln[ok, None]
+    # the multimap<Vertex, TopoData>: key order (p.x, p.y, p.z[, uv.x, uv.y]), equal keys in insertion order (triangle, corner)
+    groups = {}
+    for t in range(len(idx)):
+        for j in range(3):
+            v = int(idx[t, j])
+            key = tuple(float(c) for c in pos[v]) + (tuple(float(c) for c in uvs[v]) if uvs is not None else ())
+            groups.setdefault(key, []).append(t)
+    new_pos, new_uv = [], []
+    new_idx = np.full(idx.shape, -1, np.int64)
+    for key in sorted(groups):
+        entries = groups[key]
+        p = np.asarray(key[:3], f32)
+        clustered = [False] * len(entries)
+        for a, t1 in enumerate(entries):
+            if clustered[a]:
+                continue
+            n1 = fn[t1]
+            vertex = len(new_pos)
+            new_pos.append(key[:3])
+            if uvs is not None:
+                new_uv.append(key[3:])
+            for b in range(a, len(entries)):
+                if clustered[b]:
+                    continue
+                n2 = fn[entries[b]]
+                if np.array_equal(n1, n2) or f32(f32(n1[0] * n2[0]) + f32(n1[1] * n2[1])) + f32(n1[2] * n2[2]) > dp_thresh:
+                    for i in range(3):
+                        if np.array_equal(pos[idx[entries[b], i]], p):
+                            new_idx[entries[b], i] = vertex
+                    clustered[b] = True
+    assert (new_idx >= 0).all()
+    return (np.asarray(new_pos, f32).reshape(-1, 3), np.asarray(new_uv, f32).reshape(-1, 2) if uvs is not None else None,
+            new_idx.astype(np.uint32))
+
+
+def load_obj(path, to_world=None, face_normals=False, flip_normals=False, flip_tex_coords=True, collapse=False, max_smooth_angle=None):
     """→ list of meshes dict(name, material, positions (V,3), normals (V,3) or None, indices (T,3)) in world space."""
     to_world = np.eye(4, dtype=f32) if to_world is None else to_world
     V, N, UV = [], [], []
@@ -205,8 +267,8 @@ def load_obj(path, to_world=None, face_normals=False, flip_normals=False, flip_t
             nz = ln != 0
             nrm_w[nz] = nrm_w[nz] / ln[nz, None]
         uvs = np.asarray(UV, f32).reshape(-1, 2) if UV else np.zeros((0, 2), f32)
-        vmap, vp, vn, idx = {}, [], [], []
-        has_normals = False
+        vmap, vp, vn, vuv, idx = {}, [], [], [], []
+        has_normals = has_uvs = False
         for t in tris:
             tri = []
             for (p, uv, n) in t:
@@ -219,17 +281,21 @@ def load_obj(path, to_world=None, face_normals=False, flip_normals=False, flip_t
                     raise SceneError("%s: normal / uv index out of bounds" % path)
                 pn = tuple(nrm_w[n - 1]) if n else (0.0, 0.0, 0.0)
                 has_normals |= bool(n)
+                has_uvs |= bool(uv)
                 puv = tuple(uvs[uv - 1]) if uv else (0.0, 0.0)
                 key = (tuple(pos_w[p - 1]), pn, puv)
                 k = vmap.get(key)
                 if k is None:
                     k = vmap[key] = len(vp)
-                    vp.append(key[0]); vn.append(pn)
+                    vp.append(key[0]); vn.append(pn); vuv.append(puv)
                 tri.append(k)
             idx.append(tri)
         pos = np.asarray(vp, f32).reshape(-1, 3)
         idx = np.asarray(idx, np.uint32).reshape(-1, 3)
         normals = np.asarray(vn, f32).reshape(-1, 3) if has_normals else None
+        if max_smooth_angle is not None:  # obj.cpp:336-343: the file's normals are discarded, creases found from the dihedral angles
+            pos, _, idx = rebuild_topology(pos, np.asarray(vuv, f32).reshape(-1, 2) if has_uvs else None, idx, max_smooth_angle)
+            normals = None
         # TriMesh::computeNormals (trimesh.cpp:608-676)
         if face_normals:
             normals = None
@@ -544,8 +610,10 @@ def load_scene(path, defines=None, strict=True, width=None, height=None, data_di
             fn = sprops.get("filename")
             if not fn:
                 raise SceneError("obj shape without filename")
-            if "maxSmoothAngle" in sprops or "shapeIndex" in sprops:
-                raise SceneError("obj: maxSmoothAngle / shapeIndex are not supported")
+            if "shapeIndex" in sprops:
+                raise SceneError("obj: shapeIndex is not supported")
+            if "maxSmoothAngle" in sprops and sprops.get("faceNormals", False):
+                raise SceneError("The properties 'maxSmoothAngle' and 'faceNormals' can't be specified at the same time!")  # obj.cpp:337-339
             full = fn if os.path.isabs(fn) else os.path.join(base, fn)
             if not os.path.exists(full):
                 if strict:
@@ -553,7 +621,7 @@ def load_scene(path, defines=None, strict=True, width=None, height=None, data_di
                 warnings.append("shape skipped: Wavefront OBJ file '%s' not found" % full)
                 continue
             meshes = load_obj(full, m, bool(sprops.get("faceNormals", False)), bool(sprops.get("flipNormals", False)),
-                              bool(sprops.get("flipTexCoords", True)), bool(sprops.get("collapse", False)))
+                              bool(sprops.get("flipTexCoords", True)), bool(sprops.get("collapse", False)), sprops.get("maxSmoothAngle"))
         elif t == "rectangle":
             meshes = [rectangle_mesh(m, bool(sprops.get("flipNormals", False)))]
         elif t == "sphere":  # Sphere::Sphere, sphere.cpp:108-131: the scale of toWorld goes into the radius, the rest stays a rotation

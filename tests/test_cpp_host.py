@@ -275,6 +275,41 @@ def test_cpp_envmap_readers_equal_the_python_loader(ppg_render, tmp_path):
     assert r.returncode == 2 and "not found" in r.stderr
 
 
+def test_cpp_max_smooth_angle_equals_the_python_loader(ppg_render, tmp_path):
+    """rebuildTopology in host/scene_xml.h against ppg_host/mitsuba_xml.py: a bumpy height field with texture coordinates and a sharp ridge,
+    thresholds on both sides of its dihedral angles — same vertex numbering, same generated normals."""
+    import ppg_host
+    from test_mitsuba_xml import _write
+    rng = np.random.RandomState(6)
+    n = 7
+    h = rng.rand(n, n) * 0.15
+    h[:, n // 2] += 0.8                                           # the ridge
+    lines = []
+    for i in range(n):
+        for j in range(n):
+            lines.append("v %r %r %r" % (float(i), float(h[i, j]), float(j)))
+    for i in range(n):
+        for j in range(n):
+            lines.append("vt %r %r" % (i / (n - 1), j / (n - 1)))
+    for i in range(n - 1):
+        for j in range(n - 1):
+            a, b, c, d = i * n + j + 1, (i + 1) * n + j + 1, (i + 1) * n + j + 2, i * n + j + 2
+            lines.append("f %d/%d %d/%d %d/%d %d/%d" % (a, a, b, b, c, c, d, d))
+    (tmp_path / "meshes").mkdir(exist_ok=True)
+    (tmp_path / "meshes" / "field.obj").write_text("\n".join(lines) + "\n")
+    for angle in (5, 25, 60, 179):
+        xml = _write(tmp_path, '<shape type="obj"><string name="filename" value="meshes/field.obj"/><float name="maxSmoothAngle" value="%d"/>'
+                               '<transform name="toWorld"><rotate x="1" angle="20"/><scale value="0.5"/></transform></shape>' % angle)
+        r, c = _cpp_load(ppg_render, xml, tmp_path, "-D", "nee=never")
+        assert r.returncode == 0, r.stderr
+        desc, _, _ = ppg_host.load_scene(xml, defines=dict(nee="never"))
+        assert np.array_equal(c["indices"], desc.indices), angle
+        assert np.allclose(c["positions"], desc.positions, rtol=1e-6, atol=1e-6) and np.allclose(c["normals"], desc.normals, rtol=1e-5, atol=2e-6)
+    n5 = len(ppg_host.mitsuba_xml.load_obj(str(tmp_path / "meshes" / "field.obj"), max_smooth_angle=5.0)[0]["positions"])
+    n179 = len(ppg_host.mitsuba_xml.load_obj(str(tmp_path / "meshes" / "field.obj"), max_smooth_angle=179.0)[0]["positions"])
+    assert n179 == n * n and n5 > 2 * n * n                     # everything smooth vs. most vertices split
+
+
 def test_cpp_scene_xml_loader_errors(ppg_render, tmp_path):
     from test_mitsuba_xml import _write
     for extra, needle in (('<shape type="cylinder"/>', "cylinder"), ('<shape type="rectangle"><bsdf type="ward"/></shape>', "ward"),

@@ -350,3 +350,28 @@ def test_lenient_loading_skips_missing_meshes(tmp_path):
         ppg_host.load_scene(xml, defines=dict(nee="never"))
     desc, _, info = ppg_host.load_scene(xml, defines=dict(nee="never"), strict=False)
     assert any("not-there.obj" in w for w in info["warnings"]) and desc.n_triangles > 0
+
+
+def test_max_smooth_angle_rebuilds_the_topology(tmp_path):
+    """obj.cpp:336-343 → TriMesh::rebuildTopology (trimesh.cpp:468-608): the file's normals are dropped, vertices re-merged, and smooth
+    normals stop at creases sharper than the angle.  A cube with shared corners: 30 deg → every face gets its own four vertices and a
+    flat normal; 100 deg (more than the cube's 90) → the eight corners stay shared and their normals are the diagonals."""
+    v = [(x, y, z) for x in (0, 1) for y in (0, 1) for z in (0, 1)]
+    quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+    (tmp_path / "meshes").mkdir(exist_ok=True)
+    (tmp_path / "meshes" / "cube.obj").write_text("".join("v %d %d %d\n" % q for q in v) + "vn 0 0 1\n" + "".join("f " + " ".join("%d//1" % (i + 1) for i in q) + "\n" for q in quads))
+    p = str(tmp_path / "meshes" / "cube.obj")
+    flat, smooth = mitsuba_xml.load_obj(p, max_smooth_angle=30.0)[0], mitsuba_xml.load_obj(p, max_smooth_angle=100.0)[0]
+    assert len(flat["positions"]) == 24 and len(smooth["positions"]) == 8 and len(flat["indices"]) == len(smooth["indices"]) == 12
+    P, I = flat["positions"], flat["indices"]
+    fn = np.cross(P[I[:, 1]] - P[I[:, 0]], P[I[:, 2]] - P[I[:, 0]]); fn /= np.linalg.norm(fn, axis=1, keepdims=True)
+    for k in range(3):
+        assert np.allclose(flat["normals"][I[:, k]], fn, atol=1e-6)                    # flat per face (the file's bogus "vn 0 0 1" is gone)
+    assert np.allclose(np.abs(smooth["normals"]), 1 / np.sqrt(3), atol=1e-5)            # corner diagonals
+    xml = _write(tmp_path, '<shape type="obj"><string name="filename" value="meshes/cube.obj"/><float name="maxSmoothAngle" value="30"/></shape>')
+    desc, _, _ = ppg_host.load_scene(xml, defines=dict(nee="never"))
+    base, _, _ = ppg_host.load_scene(_write(tmp_path), defines=dict(nee="never"))
+    assert desc.n_triangles == base.n_triangles + 12
+    with pytest.raises(mitsuba_xml.SceneError, match="same time"):
+        ppg_host.load_scene(_write(tmp_path, '<shape type="obj"><string name="filename" value="meshes/cube.obj"/><float name="maxSmoothAngle" value="30"/>'
+                                             '<boolean name="faceNormals" value="true"/></shape>'), defines=dict(nee="never"))
