@@ -538,6 +538,8 @@ public:
                                  pr.count("maxSmoothAngle") ? std::stof(pr["maxSmoothAngle"]) : -1.0f);
             } else if (t == "rectangle") {
                 meshes.push_back(rectangle(m, flag(pr, "flipNormals", false)));
+            } else if (t == "cube") {
+                meshes.push_back(cube(m, flag(pr, "flipNormals", false)));
             } else if (t == "sphere") {  // Sphere::Sphere, sphere.cpp:108-131: the scale of toWorld goes into the radius, the rest stays a rotation
                 float c[3] = {0, 0, 0};
                 for (auto &pc : sh.children)
@@ -561,7 +563,7 @@ public:
                 sphere.flip_normals = flag(pr, "flipNormals", false) ? 1 : 0;
                 isSphere = true;
             } else {
-                throw std::runtime_error("shape type '" + t + "' is not supported (obj, rectangle, sphere)");
+                throw std::runtime_error("shape type '" + t + "' is not supported (obj, rectangle, cube, sphere)");
             }
             int mat = -1;
             for (auto &c : sh.children) {
@@ -724,6 +726,29 @@ private:
         V3 n = normalized(xfNormal(nm, V3{0, 0, 1}));
         for (const V3 &p : c) { r.positions.push_back(xfPoint(m, p)); r.normals.push_back(n); }
         r.indices = {0, 1, 2, 2, 3, 0};
+        return r;
+    }
+    // shapes/cube.cpp:24-30, 73-103: [-1, 1]^3 as 6 faces x 4 vertices with their own normals; face order -y, +y, +x, +z, -x, -z, corners
+    // from the start corner counter-clockwise about the normal, triangles (0, 1, 2), (3, 0, 2) per face
+    static Mesh cube(const Mat4 &toWorld, bool flip) {
+        static const int faces[6][6] = {{0, -1, 0, 1, -1, -1}, {0, 1, 0, 1, 1, -1}, {1, 0, 0, 1, -1, -1}, {0, 0, 1, 1, -1, 1}, {-1, 0, 0, -1, -1, 1}, {0, 0, -1, 1, 1, -1}};
+        Mesh r;
+        double nm[9];
+        normalMatrix(toWorld, nm);
+        for (int f = 0; f < 6; ++f) {
+            const V3 n{(float)faces[f][0], (float)faces[f][1], (float)faces[f][2]};
+            V3 p{(float)faces[f][3], (float)faces[f][4], (float)faces[f][5]};
+            V3 nw = normalized(xfNormal(nm, n));
+            if (flip) nw = {-nw.x, -nw.y, -nw.z};
+            for (int k = 0; k < 4; ++k) {
+                r.positions.push_back(xfPoint(toWorld, p)); r.normals.push_back(nw);
+                const V3 c = cross(n, p);
+                const float d = dot(n, p);
+                p = {c.x + d * n.x, c.y + d * n.y, c.z + d * n.z};  // a quarter turn about the normal
+            }
+            const uint32_t b = 4 * (uint32_t)f;
+            for (uint32_t id : {b, b + 1, b + 2, b + 3, b, b + 2}) r.indices.push_back(id);
+        }
         return r;
     }
     static void makeCamera(ppg_camera &cam, const Mat4 &c2w, double fov, const std::string &axisIn, double nearC, double farC, int W, int H) {

@@ -4,7 +4,7 @@
   sensor      perspective (fov, fovAxis, nearClip, farClip, toWorld; focusDistance ignored: pinhole),
               nested sampler (independent; sampleCount / seed do not steer guided_path, GP:1342-1374) and
               film hdrfilm (width, height; rfilter box)
-  shapes      obj (filename, toWorld, faceNormals, maxSmoothAngle, flipNormals, flipTexCoords, collapse), rectangle (toWorld, flipNormals),
+  shapes      obj (filename, toWorld, faceNormals, maxSmoothAngle, flipNormals, flipTexCoords, collapse), rectangle / cube (toWorld, flipNormals),
               sphere (center, radius, toWorld = rotation x uniform scale, flipNormals) — analytic, not tessellated
   bsdfs       diffuse, conductor (material none, or explicit eta / k), roughconductor / roughdielectric / roughplastic (ggx / beckmann, isotropic; roughplastic reads Mitsuba's data/microfacet tables),
               plastic, dielectric, thindielectric,
@@ -349,6 +349,27 @@ def rectangle_mesh(to_world, flip_normals=False):
 
 
 # ---------------------------------------------------------------------------------------------- scene
+def cube_mesh(to_world, flip_normals=False):
+    """shapes/cube.cpp:24-30, 73-103: the cube [-1, 1]^3 as 6 faces x 4 vertices (own normals per face) and 12 triangles.  Face order
+    -y, +y, +x, +z, -x, -z; a face's corners start at the corner given below and turn counter-clockwise about the face normal;
+    triangles (0, 1, 2), (3, 0, 2) per face — the layout of the reference's vertex table."""
+    faces = [((0, -1, 0), (1, -1, -1)), ((0, 1, 0), (1, 1, -1)), ((1, 0, 0), (1, -1, -1)), ((0, 0, 1), (1, -1, 1)), ((-1, 0, 0), (-1, -1, 1)),
+             ((0, 0, -1), (1, 1, -1))]
+    P, N, I = [], [], []
+    for f, (n, start) in enumerate(faces):
+        n, p = np.array(n, np.float64), np.array(start, np.float64)
+        for _ in range(4):
+            P.append(p); N.append(n)
+            p = np.cross(n, p) + np.dot(n, p) * n          # a quarter turn about the normal
+        I += [(4 * f, 4 * f + 1, 4 * f + 2), (4 * f + 3, 4 * f, 4 * f + 2)]
+    pos = _xf_points(to_world, np.asarray(P, f32))
+    nrm = _xf_normals(to_world, np.asarray(N, f32))
+    nrm = (nrm / np.sqrt(np.sum(nrm * nrm, 1, dtype=f32), dtype=f32)[:, None]).astype(f32)
+    if flip_normals:  # TriMesh::computeNormals with existing normals (trimesh.cpp:612-618)
+        nrm = -nrm
+    return dict(name="cube", material="", positions=pos, normals=nrm, indices=np.asarray(I, np.uint32))
+
+
 def _props(elem, sub):
     out = {}
     for c in elem:
@@ -624,6 +645,8 @@ def load_scene(path, defines=None, strict=True, width=None, height=None, data_di
                               bool(sprops.get("flipTexCoords", True)), bool(sprops.get("collapse", False)), sprops.get("maxSmoothAngle"))
         elif t == "rectangle":
             meshes = [rectangle_mesh(m, bool(sprops.get("flipNormals", False)))]
+        elif t == "cube":
+            meshes = [cube_mesh(m, bool(sprops.get("flipNormals", False)))]
         elif t == "sphere":  # Sphere::Sphere, sphere.cpp:108-131: the scale of toWorld goes into the radius, the rest stays a rotation
             meshes = []
             c = np.asarray(sprops.get("center", (0.0, 0.0, 0.0)), f32)
@@ -639,7 +662,7 @@ def load_scene(path, defines=None, strict=True, width=None, height=None, data_di
             sphere = dict(center=tuple(float(v) for v in o2w[:3, 3]), radius=float(radius), to_world=[float(v) for v in o2w[:3, :3].reshape(-1)],
                           flip_normals=bool(sprops.get("flipNormals", False)))
         else:
-            raise SceneError("shape type %r is not supported (obj, rectangle, sphere)" % t)
+            raise SceneError("shape type %r is not supported (obj, rectangle, cube, sphere)" % t)
         # material: nested <bsdf> or <ref id>
         mat = None
         for c in sh:

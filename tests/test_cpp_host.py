@@ -183,6 +183,7 @@ def test_cpp_scene_xml_loader_equals_the_python_loader(ppg_render, tmp_path):
     <shape type="obj"><string name="filename" value="meshes/cube.obj"/><transform name="toWorld"><rotate x="1" y="1" angle="33"/><translate x="3"/></transform></shape>
     <emitter type="constant"><srgb name="radiance" value="0.5, 0.6, 0.7"/></emitter>
     <shape type="sphere"><point name="center" x="1" y="2" z="3"/><float name="radius" value="0.5"/><ref id="m1"/></shape>
+    <shape type="cube"><boolean name="flipNormals" value="true"/><transform name="toWorld"><scale x="2" y="0.5" z="1"/><rotate y="1" angle="30"/><translate x="-4"/></transform></shape>
     <shape type="sphere"><boolean name="flipNormals" value="true"/><float name="radius" value="2"/>
         <transform name="toWorld"><rotate x="1" y="1" angle="33"/><scale value="3"/><translate x="5" y="6" z="7"/></transform>
         <emitter type="area"><rgb name="radiance" value="0.3, 0.4, 0.5"/></emitter></shape>

@@ -375,3 +375,24 @@ def test_max_smooth_angle_rebuilds_the_topology(tmp_path):
     with pytest.raises(mitsuba_xml.SceneError, match="same time"):
         ppg_host.load_scene(_write(tmp_path, '<shape type="obj"><string name="filename" value="meshes/cube.obj"/><float name="maxSmoothAngle" value="30"/>'
                                              '<boolean name="faceNormals" value="true"/></shape>'), defines=dict(nee="never"))
+
+
+def test_cube_shape(tmp_path):
+    """shapes/cube.cpp: 24 vertices (each face its own four, so the normals are flat), 12 triangles wound outward; toWorld may stretch it
+    (normals through the inverse transpose); flipNormals negates the normals and leaves the winding."""
+    xml = _write(tmp_path, '<shape type="cube"><transform name="toWorld"><scale x="2" y="0.5" z="1"/><translate x="10"/></transform></shape>')
+    desc, _, _ = ppg_host.load_scene(xml, defines=dict(nee="never"))
+    base, _, _ = ppg_host.load_scene(_write(tmp_path), defines=dict(nee="never"))
+    assert desc.n_triangles == base.n_triangles + 12
+    tri = desc.indices[-12:]
+    P, N = desc.positions, desc.normals
+    assert P[tri].reshape(-1, 3).min(0).tolist() == [8.0, -0.5, -1.0] and P[tri].reshape(-1, 3).max(0).tolist() == [12.0, 0.5, 1.0]
+    fn = np.cross(P[tri[:, 1]] - P[tri[:, 0]], P[tri[:, 2]] - P[tri[:, 0]]); fn /= np.linalg.norm(fn, axis=1, keepdims=True)
+    centre = np.float32([10, 0, 0])
+    assert np.all(np.sum(fn * (P[tri].mean(1) - centre), 1) > 0)                       # wound outward
+    for k in range(3):
+        assert np.allclose(N[tri[:, k]], fn, atol=1e-6)                                  # flat normals = the geometric ones, also when stretched
+    flipped, _, _ = ppg_host.load_scene(_write(tmp_path, '<shape type="cube"><boolean name="flipNormals" value="true"/></shape>'), defines=dict(nee="never"))
+    t2 = flipped.indices[-12:]
+    f2 = np.cross(flipped.positions[t2[:, 1]] - flipped.positions[t2[:, 0]], flipped.positions[t2[:, 2]] - flipped.positions[t2[:, 0]])
+    assert np.all(np.sum(f2 * flipped.normals[t2[:, 0]], 1) < 0)
