@@ -425,6 +425,102 @@ inline std::vector<Mesh> loadOBJ(const std::string &path, const Mat4 &toWorld, b
     return meshes;
 }
 
+/* shapes/serialized.cpp:148-212 + TriMesh::loadCompressed (trimesh.cpp:175-295): Mitsuba's binary mesh format — header 0x041C, version 3 or
+ * 4, then a zlib stream {flags, [name], vertex count, triangle count, positions, [normals], [texcoords], [colours], indices}; several
+ * meshes per file are addressed through the offset table at the end (shapeIndex). */
+inline Mesh loadSerialized(const std::string &path, const Mat4 &toWorld, int shapeIndex, bool faceNormals, bool flipNormals, float maxSmoothAngle) {
+    const std::vector<unsigned char> buf = slurp(path, "serialized");
+    auto header = [&](size_t off) {
+        uint16_t h[2];
+        if (off + 4 > buf.size()) throw std::runtime_error(path + ": encountered an invalid file format!");
+        memcpy(h, &buf[off], 4);
+        if (h[0] != 0x041C) throw std::runtime_error(path + ": encountered an invalid file format!");
+        if (h[1] != 3 && h[1] != 4) throw std::runtime_error(path + ": encountered an incompatible file version!");
+        return (int)h[1];
+    };
+    const int version = header(0);
+    size_t start = 0;
+    if (shapeIndex != 0) {
+        uint32_t count;
+        memcpy(&count, &buf[buf.size() - 4], 4);
+        if (shapeIndex < 0 || shapeIndex > (int)count) throw std::runtime_error(path + ": shape index is out of range!");
+        if (version == 4) { uint64_t o; memcpy(&o, &buf[buf.size() - 8 * (size_t)(count - shapeIndex) - 4], 8); start = (size_t)o; }
+        else { uint32_t o; memcpy(&o, &buf[buf.size() - 4 * (size_t)(count - shapeIndex + 1)], 4); start = o; }
+        header(start);
+    }
+    std::vector<unsigned char> data;
+    {
+        z_stream zs{};
+        if (inflateInit(&zs) != Z_OK) throw std::runtime_error(path + ": zlib failure");
+        zs.next_in = const_cast<unsigned char *>(&buf[start + 4]);
+        zs.avail_in = (uInt)(buf.size() - start - 4);
+        unsigned char chunk[1 << 16];
+        int rc;
+        do {
+            zs.next_out = chunk; zs.avail_out = sizeof chunk;
+            rc = inflate(&zs, Z_NO_FLUSH);
+            if (rc != Z_OK && rc != Z_STREAM_END) { inflateEnd(&zs); throw std::runtime_error(path + ": corrupt zlib stream"); }
+            data.insert(data.end(), chunk, chunk + (sizeof chunk - zs.avail_out));
+        } while (rc != Z_STREAM_END);
+        inflateEnd(&zs);
+    }
+    size_t off = 0;
+    auto need = [&](size_t n) { if (off + n > data.size()) throw std::runtime_error(path + ": truncated mesh data"); };
+    uint32_t flags;
+    need(4); memcpy(&flags, &data[off], 4); off += 4;
+    if (version == 4) { while (off < data.size() && data[off]) ++off; ++off; }
+    uint64_t nv, nt;
+    need(16); memcpy(&nv, &data[off], 8); memcpy(&nt, &data[off + 8], 8); off += 16;
+    const bool dbl = (flags & 0x2000) != 0;
+    auto take = [&](int comps, std::vector<float> &out) {
+        const size_t n = (size_t)nv * comps;
+        need(n * (dbl ? 8 : 4));
+        out.resize(n);
+        for (size_t k = 0; k < n; ++k) {
+            if (dbl) { double v; memcpy(&v, &data[off + 8 * k], 8); out[k] = (float)v; }
+            else memcpy(&out[k], &data[off + 4 * k], 4);
+        }
+        off += n * (dbl ? 8 : 4);
+    };
+    std::vector<float> P, N, UVs, C;
+    take(3, P);
+    if (flags & 0x0001) take(3, N);
+    if (flags & 0x0002) take(2, UVs);
+    if (flags & 0x0008) take(3, C);
+    need((size_t)nt * 12);
+    Mesh m;
+    m.indices.resize((size_t)nt * 3);
+    memcpy(m.indices.data(), &data[off], (size_t)nt * 12);
+    for (uint32_t id : m.indices) if (id >= nv) throw std::runtime_error(path + ": vertex index out of bounds");
+    bool identity = true;
+    for (int k = 0; k < 16; ++k) identity &= toWorld.m[k] == Mat4::identity().m[k];
+    double nm[9];
+    normalMatrix(toWorld, nm);
+    for (size_t i = 0; i < nv; ++i) {
+        const V3 p{P[3 * i], P[3 * i + 1], P[3 * i + 2]};
+        m.positions.push_back(identity ? p : xfPoint(toWorld, p));
+        if (!N.empty()) {
+            const V3 n{N[3 * i], N[3 * i + 1], N[3 * i + 2]};
+            m.normals.push_back(identity ? n : normalized(xfNormal(nm, n)));
+        }
+    }
+    const double a = toWorld.m[0], b = toWorld.m[1], c = toWorld.m[2], d = toWorld.m[4], e = toWorld.m[5], f = toWorld.m[6], g = toWorld.m[8], h = toWorld.m[9], i9 = toWorld.m[10];
+    if (a * (e * i9 - f * h) - b * (d * i9 - f * g) + c * (d * h - e * g) < 0)
+        for (size_t t = 0; t + 2 < m.indices.size(); t += 3) std::swap(m.indices[t], m.indices[t + 1]);
+    std::vector<std::pair<float, float>> vuv;
+    for (size_t i = 0; i + 1 < UVs.size(); i += 2) vuv.emplace_back(UVs[i], UVs[i + 1]);
+    if (maxSmoothAngle >= 0) rebuildTopology(m, UVs.empty() ? nullptr : &vuv, maxSmoothAngle);
+    if (faceNormals) {
+        m.normals.clear();
+        if (flipNormals) for (size_t t = 0; t + 2 < m.indices.size(); t += 3) std::swap(m.indices[t], m.indices[t + 1]);
+    } else if (!m.normals.empty()) {
+        if (flipNormals) for (V3 &n : m.normals) n = {-n.x, -n.y, -n.z};
+    } else {
+        computeNormals(m, flipNormals);
+    }
+    return m;
+}
+
 // ------------------------------------------------------------------------------------------------ the scene
 struct LoadedScene {
     SceneData scene;
@@ -536,6 +632,18 @@ public:
                 if (!m_strict && !std::ifstream(fn)) { out.warnings.push_back("shape skipped: Wavefront OBJ file '" + fn + "' not found"); continue; }
                 meshes = loadOBJ(fn, m, flag(pr, "faceNormals", false), flag(pr, "flipNormals", false), flag(pr, "flipTexCoords", true), flag(pr, "collapse", false),
                                  pr.count("maxSmoothAngle") ? std::stof(pr["maxSmoothAngle"]) : -1.0f);
+            } else if (t == "serialized") {
+                if (!pr.count("filename")) throw std::runtime_error("serialized shape without filename");
+                std::string fn = pr["filename"];
+                if (fn.empty() || fn[0] != '/') fn = m_base + "/" + fn;
+                if (!std::ifstream(fn)) {
+                    if (m_strict) throw std::runtime_error("serialized mesh file '" + fn + "' not found");
+                    out.warnings.push_back("shape skipped: serialized mesh file '" + fn + "' not found");
+                    continue;
+                }
+                if (pr.count("maxSmoothAngle") && flag(pr, "faceNormals", false)) throw std::runtime_error("The properties 'maxSmoothAngle' and 'faceNormals' can't be specified at the same time!");
+                meshes.push_back(loadSerialized(fn, m, pr.count("shapeIndex") ? std::stoi(pr["shapeIndex"]) : 0, flag(pr, "faceNormals", false), flag(pr, "flipNormals", false),
+                                                pr.count("maxSmoothAngle") ? std::stof(pr["maxSmoothAngle"]) : -1.0f));
             } else if (t == "rectangle") {
                 meshes.push_back(rectangle(m, flag(pr, "flipNormals", false)));
             } else if (t == "cube") {
@@ -563,7 +671,7 @@ public:
                 sphere.flip_normals = flag(pr, "flipNormals", false) ? 1 : 0;
                 isSphere = true;
             } else {
-                throw std::runtime_error("shape type '" + t + "' is not supported (obj, rectangle, cube, sphere)");
+                throw std::runtime_error("shape type '" + t + "' is not supported (obj, serialized, rectangle, cube, sphere)");
             }
             int mat = -1;
             for (auto &c : sh.children) {

@@ -4,7 +4,8 @@
   sensor      perspective (fov, fovAxis, nearClip, farClip, toWorld; focusDistance ignored: pinhole),
               nested sampler (independent; sampleCount / seed do not steer guided_path, GP:1342-1374) and
               film hdrfilm (width, height; rfilter box)
-  shapes      obj (filename, toWorld, faceNormals, maxSmoothAngle, flipNormals, flipTexCoords, collapse), rectangle / cube (toWorld, flipNormals),
+  shapes      obj (filename, toWorld, faceNormals, maxSmoothAngle, flipNormals, flipTexCoords, collapse),
+              serialized (filename, shapeIndex, toWorld, faceNormals, maxSmoothAngle, flipNormals), rectangle / cube (toWorld, flipNormals),
               sphere (center, radius, toWorld = rotation x uniform scale, flipNormals) — analytic, not tessellated
   bsdfs       diffuse, conductor (material none, or explicit eta / k), roughconductor / roughdielectric / roughplastic (ggx / beckmann, isotropic; roughplastic reads Mitsuba's data/microfacet tables),
               plastic, dielectric, thindielectric,
@@ -296,16 +297,7 @@ def load_obj(path, to_world=None, face_normals=False, flip_normals=False, flip_t
         if max_smooth_angle is not None:  # obj.cpp:336-343: the file's normals are discarded, creases found from the dihedral angles
             pos, _, idx = rebuild_topology(pos, np.asarray(vuv, f32).reshape(-1, 2) if has_uvs else None, idx, max_smooth_angle)
             normals = None
-        # TriMesh::computeNormals (trimesh.cpp:608-676)
-        if face_normals:
-            normals = None
-            if flip_normals:
-                idx = idx[:, [1, 0, 2]]
-        elif normals is not None:
-            if flip_normals:
-                normals = -normals
-        else:
-            normals = compute_normals(pos, idx, flip_normals)
+        normals, idx = _finish_normals(pos, normals, idx, face_normals, flip_normals)
         meshes.append(dict(name=mesh_name, material=material, positions=pos, normals=normals, indices=idx))
         tris = []
 
@@ -349,6 +341,85 @@ def rectangle_mesh(to_world, flip_normals=False):
 
 
 # ---------------------------------------------------------------------------------------------- scene
+def _finish_normals(pos, normals, idx, face_normals, flip_normals):
+    """TriMesh::computeNormals (trimesh.cpp:608-676) as configure() applies it to a freshly loaded mesh."""
+    if face_normals:
+        normals = None
+        if flip_normals:
+            idx = idx[:, [1, 0, 2]]
+    elif normals is not None:
+        if flip_normals:
+            normals = -normals
+    else:
+        normals = compute_normals(pos, idx, flip_normals)
+    return normals, idx
+
+
+def load_serialized(path, to_world=None, shape_index=0, face_normals=False, flip_normals=False, max_smooth_angle=None):
+    """shapes/serialized.cpp:148-212 + TriMesh::loadCompressed (trimesh.cpp:175-295): Mitsuba's binary mesh format — header 0x041C,
+    version 3 or 4, then a zlib stream {flags, [name], vertex count, triangle count, positions, [normals], [texcoords], [colours],
+    indices}; several meshes per file are addressed through the offset table at the end (`shapeIndex`)."""
+    import struct
+    import zlib
+    to_world = np.eye(4, dtype=f32) if to_world is None else to_world
+    buf = open(path, "rb").read()
+
+    def header(off):
+        fmt, version = struct.unpack_from("<HH", buf, off)
+        if fmt != 0x041C:
+            raise SceneError("%s: encountered an invalid file format!" % path)
+        if version not in (3, 4):
+            raise SceneError("%s: encountered an incompatible file version!" % path)
+        return version
+    version = header(0)
+    start = 0
+    if shape_index != 0:  # readOffset, trimesh.cpp:272-295
+        count = struct.unpack_from("<I", buf, len(buf) - 4)[0]
+        if shape_index < 0 or shape_index > count:
+            raise SceneError("%s: shape index is out of range! (requested %d out of 0..%d)" % (path, shape_index, count - 1))
+        if version == 4:
+            start = struct.unpack_from("<Q", buf, len(buf) - 8 * (count - shape_index) - 4)[0]
+        else:
+            start = struct.unpack_from("<I", buf, len(buf) - 4 * (count - shape_index + 1))[0]
+        header(start)
+    try:
+        data = zlib.decompressobj().decompress(buf[start + 4:])
+    except zlib.error as e:
+        raise SceneError("%s: %s" % (path, e))
+    off = 0
+    flags = struct.unpack_from("<I", data, off)[0]; off += 4
+    if version == 4:
+        off = data.index(b"\0", off) + 1
+    nv, nt = struct.unpack_from("<QQ", data, off); off += 16
+    dt = "<f8" if flags & 0x2000 else "<f4"
+
+    def take(n_comp):
+        nonlocal off
+        a = np.frombuffer(data, dt, nv * n_comp, off).reshape(nv, n_comp).astype(f32)
+        off += a.shape[0] * n_comp * (8 if flags & 0x2000 else 4)
+        return a
+    pos = take(3)
+    normals = take(3) if flags & 0x0001 else None
+    uvs = take(2) if flags & 0x0002 else None
+    if flags & 0x0008:
+        take(3)  # vertex colours: not used
+    idx = np.frombuffer(data, "<u4", nt * 3, off).reshape(nt, 3).astype(np.uint32)
+    if idx.size and idx.max() >= nv:
+        raise SceneError("%s: vertex index out of bounds" % path)
+    if not np.array_equal(to_world, np.eye(4, dtype=f32)):
+        pos = _xf_points(to_world, pos)
+        if normals is not None:
+            normals = _xf_normals(to_world, normals)
+            normals = (normals / np.sqrt(np.sum(normals * normals, 1, dtype=f32), dtype=f32)[:, None]).astype(f32)
+    if np.linalg.det(to_world[:3, :3].astype(np.float64)) < 0:
+        idx = idx[:, [1, 0, 2]]
+    if max_smooth_angle is not None:
+        pos, uvs, idx = rebuild_topology(pos, uvs, idx, max_smooth_angle)
+        normals = None
+    normals, idx = _finish_normals(pos, normals, idx, face_normals, flip_normals)
+    return dict(name=os.path.splitext(os.path.basename(path))[0], material="", positions=pos, normals=normals, indices=idx)
+
+
 def cube_mesh(to_world, flip_normals=False):
     """shapes/cube.cpp:24-30, 73-103: the cube [-1, 1]^3 as 6 faces x 4 vertices (own normals per face) and 12 triangles.  Face order
     -y, +y, +x, +z, -x, -z; a face's corners start at the corner given below and turn counter-clockwise about the face normal;
@@ -643,6 +714,20 @@ def load_scene(path, defines=None, strict=True, width=None, height=None, data_di
                 continue
             meshes = load_obj(full, m, bool(sprops.get("faceNormals", False)), bool(sprops.get("flipNormals", False)),
                               bool(sprops.get("flipTexCoords", True)), bool(sprops.get("collapse", False)), sprops.get("maxSmoothAngle"))
+        elif t == "serialized":
+            fn = sprops.get("filename")
+            if not fn:
+                raise SceneError("serialized shape without filename")
+            full = fn if os.path.isabs(fn) else os.path.join(base, fn)
+            if not os.path.exists(full):
+                if strict:
+                    raise SceneError("serialized mesh file '%s' not found" % full)
+                warnings.append("shape skipped: serialized mesh file '%s' not found" % full)
+                continue
+            if "maxSmoothAngle" in sprops and sprops.get("faceNormals", False):
+                raise SceneError("The properties 'maxSmoothAngle' and 'faceNormals' can't be specified at the same time!")
+            meshes = [load_serialized(full, m, int(sprops.get("shapeIndex", 0)), bool(sprops.get("faceNormals", False)), bool(sprops.get("flipNormals", False)),
+                                      sprops.get("maxSmoothAngle"))]
         elif t == "rectangle":
             meshes = [rectangle_mesh(m, bool(sprops.get("flipNormals", False)))]
         elif t == "cube":
@@ -662,7 +747,7 @@ def load_scene(path, defines=None, strict=True, width=None, height=None, data_di
             sphere = dict(center=tuple(float(v) for v in o2w[:3, 3]), radius=float(radius), to_world=[float(v) for v in o2w[:3, :3].reshape(-1)],
                           flip_normals=bool(sprops.get("flipNormals", False)))
         else:
-            raise SceneError("shape type %r is not supported (obj, rectangle, cube, sphere)" % t)
+            raise SceneError("shape type %r is not supported (obj, serialized, rectangle, cube, sphere)" % t)
         # material: nested <bsdf> or <ref id>
         mat = None
         for c in sh:

@@ -311,6 +311,26 @@ def test_cpp_max_smooth_angle_equals_the_python_loader(ppg_render, tmp_path):
     assert n179 == n * n and n5 > 2 * n * n                     # everything smooth vs. most vertices split
 
 
+def test_cpp_serialized_loader_equals_the_python_loader(ppg_render, tmp_path):
+    import ppg_host
+    from test_mitsuba_xml import _two_meshes, _write, write_serialized
+    (tmp_path / "meshes").mkdir(exist_ok=True)
+    for version in (3, 4):
+        write_serialized(str(tmp_path / "meshes" / "two.serialized"), list(_two_meshes()), version)
+        xml = _write(tmp_path, '<shape type="serialized"><string name="filename" value="meshes/two.serialized"/><boolean name="flipNormals" value="true"/>'
+                               '<transform name="toWorld"><scale x="-1"/><rotate y="1" angle="25"/></transform></shape>'
+                               '<shape type="serialized"><string name="filename" value="meshes/two.serialized"/><integer name="shapeIndex" value="1"/>'
+                               '<float name="maxSmoothAngle" value="20"/></shape>')
+        r, c = _cpp_load(ppg_render, xml, tmp_path, "-D", "nee=never")
+        assert r.returncode == 0, r.stderr
+        desc, _, _ = ppg_host.load_scene(xml, defines=dict(nee="never"))
+        assert np.array_equal(c["indices"], desc.indices) and np.allclose(c["positions"], desc.positions, rtol=1e-6, atol=1e-6)
+        assert np.allclose(c["normals"], desc.normals, rtol=1e-5, atol=2e-6)
+    r, _ = _cpp_load(ppg_render, _write(tmp_path, '<shape type="serialized"><string name="filename" value="meshes/two.serialized"/><integer name="shapeIndex" value="7"/></shape>'),
+                     tmp_path, "-D", "nee=never")
+    assert r.returncode == 2 and "out of range" in r.stderr
+
+
 def test_cpp_scene_xml_loader_errors(ppg_render, tmp_path):
     from test_mitsuba_xml import _write
     for extra, needle in (('<shape type="cylinder"/>', "cylinder"), ('<shape type="rectangle"><bsdf type="ward"/></shape>', "ward"),

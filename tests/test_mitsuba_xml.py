@@ -396,3 +396,67 @@ def test_cube_shape(tmp_path):
     t2 = flipped.indices[-12:]
     f2 = np.cross(flipped.positions[t2[:, 1]] - flipped.positions[t2[:, 0]], flipped.positions[t2[:, 2]] - flipped.positions[t2[:, 0]])
     assert np.all(np.sum(f2 * flipped.normals[t2[:, 0]], 1) < 0)
+
+
+def write_serialized(path, meshes, version=4):
+    """Mitsuba's .serialized container (trimesh.cpp:1130-1190): per mesh {u16 0x041C, u16 version, zlib{flags, [name\\0], u64 nv, u64 nt,
+    positions, [normals], [uvs], indices}}, then the offset table and the mesh count."""
+    import struct
+    import zlib
+    out, offsets = b"", []
+    for m in meshes:
+        dbl = m.get("double", False)
+        dt = "<f8" if dbl else "<f4"
+        flags = (0x2000 if dbl else 0x1000) | (1 if m.get("normals") is not None else 0) | (2 if m.get("uvs") is not None else 0)
+        body = struct.pack("<I", flags) + ((m.get("name", "mesh").encode() + b"\0") if version == 4 else b"")
+        body += struct.pack("<QQ", len(m["positions"]), len(m["indices"]))
+        body += np.asarray(m["positions"], dt).tobytes()
+        if m.get("normals") is not None:
+            body += np.asarray(m["normals"], dt).tobytes()
+        if m.get("uvs") is not None:
+            body += np.asarray(m["uvs"], dt).tobytes()
+        body += np.asarray(m["indices"], "<u4").tobytes()
+        offsets.append(len(out))
+        out += struct.pack("<HH", 0x041C, version) + zlib.compress(body)
+    out += b"".join(struct.pack("<Q" if version == 4 else "<I", o) for o in offsets) + struct.pack("<I", len(meshes))
+    open(path, "wb").write(out)
+
+
+def _two_meshes():
+    rng = np.random.RandomState(8)
+    quad = dict(name="quad", positions=np.float32([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]]), indices=np.uint32([[0, 1, 2], [0, 2, 3]]),
+                normals=np.float32([[0, 0, 1]] * 4), uvs=np.float32([[0, 0], [1, 0], [1, 1], [0, 1]]))
+    P = rng.rand(9, 3).astype(np.float32)
+    fan = dict(name="fan", positions=P, indices=np.uint32([[0, k, k + 1] for k in range(1, 8)]), double=True)
+    return quad, fan
+
+
+@pytest.mark.parametrize("version", [3, 4])
+def test_serialized_meshes(tmp_path, version):
+    """shapes/serialized.cpp + TriMesh::loadCompressed: both format versions, float and double payloads, the offset table (shapeIndex),
+    stored normals kept / generated when absent, toWorld with a mirror (winding swapped, serialized.cpp:197-202), flipNormals."""
+    quad, fan = _two_meshes()
+    (tmp_path / "meshes").mkdir(exist_ok=True)
+    p = str(tmp_path / "meshes" / "two.serialized")
+    write_serialized(p, [quad, fan], version)
+    a = mitsuba_xml.load_serialized(p)
+    assert np.array_equal(a["positions"], quad["positions"]) and np.array_equal(a["indices"], quad["indices"]) and np.array_equal(a["normals"], quad["normals"])
+    b = mitsuba_xml.load_serialized(p, shape_index=1)
+    assert np.array_equal(b["positions"], fan["positions"]) and np.array_equal(b["indices"], fan["indices"])
+    assert np.array_equal(b["normals"], mitsuba_xml.compute_normals(fan["positions"], fan["indices"], False))     # none stored: generated
+    mirror = np.diag(np.float32([-1, 1, 1, 1]))
+    c = mitsuba_xml.load_serialized(p, mirror)
+    assert np.array_equal(c["indices"], quad["indices"][:, [1, 0, 2]]) and np.array_equal(c["positions"][:, 0], -quad["positions"][:, 0])
+    d = mitsuba_xml.load_serialized(p, flip_normals=True)
+    assert np.array_equal(d["normals"], -quad["normals"])
+    e = mitsuba_xml.load_serialized(p, shape_index=1, face_normals=True)
+    assert e["normals"] is None
+    xml = _write(tmp_path, '<shape type="serialized"><string name="filename" value="meshes/two.serialized"/><integer name="shapeIndex" value="1"/>'
+                           '<transform name="toWorld"><scale value="2"/></transform><bsdf type="conductor"><string name="material" value="none"/></bsdf></shape>')
+    desc, _, _ = ppg_host.load_scene(xml, defines=dict(nee="never"))
+    assert np.allclose(desc.positions[-9:], 2 * fan["positions"]) and desc.materials[desc.tri_material[-1]]["type"] == 2
+    with pytest.raises(mitsuba_xml.SceneError, match="out of range"):
+        mitsuba_xml.load_serialized(p, shape_index=5)
+    open(str(tmp_path / "bad.serialized"), "wb").write(b"\x00\x01\x02\x03rubbish")
+    with pytest.raises(mitsuba_xml.SceneError, match="invalid file format"):
+        mitsuba_xml.load_serialized(str(tmp_path / "bad.serialized"))
