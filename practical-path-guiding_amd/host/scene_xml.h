@@ -521,6 +521,109 @@ inline Mesh loadSerialized(const std::string &path, const Mat4 &toWorld, int sha
     return m;
 }
 
+/* shapes/ply.cpp: Stanford PLY (ascii / binary little / big endian), vertex x y z [nx ny nz], faces of 3 or 4 indices (a quad becomes
+ * (0, 1, 2), (3, 0, 2), ply.cpp:299-311); positions and normals go through toWorld as they are read (:229-233). */
+inline Mesh loadPLY(const std::string &path, const Mat4 &toWorld, bool faceNormals, bool flipNormals, float maxSmoothAngle) {
+    const std::vector<unsigned char> buf = slurp(path, "ply");
+    const std::string all(buf.begin(), buf.end());
+    const size_t end = all.find("end_header");
+    if (all.compare(0, 3, "ply") != 0 || end == std::string::npos) throw std::runtime_error(path + ": not a PLY file");
+    size_t off = all.find('\n', end) + 1;
+    struct Prop { std::string name; bool list; std::string t0, t1; };
+    struct Elem { std::string name; size_t count; std::vector<Prop> props; };
+    std::vector<Elem> elems;
+    std::string fmt;
+    {
+        std::istringstream hs(all.substr(0, end));
+        std::string line;
+        std::getline(hs, line);
+        while (std::getline(hs, line)) {
+            std::istringstream ls(line);
+            std::string tok;
+            if (!(ls >> tok) || tok == "comment" || tok == "obj_info") continue;
+            if (tok == "format") ls >> fmt;
+            else if (tok == "element") { Elem e; ls >> e.name >> e.count; elems.push_back(e); }
+            else if (tok == "property" && !elems.empty()) {
+                Prop p; std::string a;
+                ls >> a;
+                if (a == "list") { p.list = true; ls >> p.t0 >> p.t1 >> p.name; }
+                else { p.list = false; p.t0 = a; ls >> p.name; }
+                elems.back().props.push_back(p);
+            }
+        }
+    }
+    if (fmt != "ascii" && fmt != "binary_little_endian" && fmt != "binary_big_endian") throw std::runtime_error(path + ": unknown PLY format '" + fmt + "'");
+    auto sizeOf = [&](const std::string &t) -> int {
+        if (t == "char" || t == "int8" || t == "uchar" || t == "uint8") return 1;
+        if (t == "short" || t == "int16" || t == "ushort" || t == "uint16") return 2;
+        if (t == "int" || t == "int32" || t == "uint" || t == "uint32" || t == "float" || t == "float32") return 4;
+        if (t == "double" || t == "float64") return 8;
+        throw std::runtime_error(path + ": unknown PLY type '" + t + "'");
+    };
+    std::istringstream ascii(fmt == "ascii" ? all.substr(off) : std::string());
+    const bool big = fmt == "binary_big_endian";
+    auto next = [&](const std::string &t) -> double {
+        if (fmt == "ascii") { double v; if (!(ascii >> v)) throw std::runtime_error(path + ": truncated PLY data"); return v; }
+        const int n = sizeOf(t);
+        if (off + n > buf.size()) throw std::runtime_error(path + ": truncated PLY data");
+        unsigned char b[8];
+        for (int k = 0; k < n; ++k) b[k] = buf[off + (big ? n - 1 - k : k)];
+        off += n;
+        if (t == "float" || t == "float32") { float v; memcpy(&v, b, 4); return v; }
+        if (t == "double" || t == "float64") { double v; memcpy(&v, b, 8); return v; }
+        if (t == "char" || t == "int8") return (signed char)b[0];
+        if (t == "uchar" || t == "uint8") return b[0];
+        if (t == "short" || t == "int16") { int16_t v; memcpy(&v, b, 2); return v; }
+        if (t == "ushort" || t == "uint16") { uint16_t v; memcpy(&v, b, 2); return v; }
+        if (t == "int" || t == "int32") { int32_t v; memcpy(&v, b, 4); return v; }
+        uint32_t v; memcpy(&v, b, 4); return v;
+    };
+    std::map<std::string, std::vector<float>> cols;
+    Mesh m;
+    size_t nVerts = 0;
+    for (const Elem &e : elems)
+        for (size_t r = 0; r < e.count; ++r)
+            for (const Prop &p : e.props) {
+                if (p.list) {
+                    const int n = (int)next(p.t0);
+                    uint32_t v[4] = {0, 0, 0, 0};
+                    const bool faceList = e.name == "face" && (p.name == "vertex_indices" || p.name == "vertex_index");
+                    if (faceList && n != 3 && n != 4) throw std::runtime_error(path + ": only triangle and quad-based PLY meshes are supported");
+                    for (int k = 0; k < n; ++k) { const double d = next(p.t1); if (k < 4) v[k] = (uint32_t)d; }
+                    if (faceList) {
+                        for (uint32_t id : {v[0], v[1], v[2]}) m.indices.push_back(id);
+                        if (n == 4) for (uint32_t id : {v[3], v[0], v[2]}) m.indices.push_back(id);
+                    }
+                } else {
+                    const double d = next(p.t0);
+                    if (e.name == "vertex") { cols[p.name].push_back((float)d); if (p.name == "x") ++nVerts; }
+                }
+            }
+    if (m.indices.empty() || nVerts == 0) throw std::runtime_error("Unable to load \"" + path + "\" (no triangles or vertices found)!");
+    for (uint32_t id : m.indices) if (id >= nVerts) throw std::runtime_error(path + ": vertex index out of bounds");
+    const bool hasN = cols.count("nx") && cols.count("ny") && cols.count("nz");
+    double nm[9];
+    normalMatrix(toWorld, nm);
+    for (size_t i = 0; i < nVerts; ++i) {
+        m.positions.push_back(xfPoint(toWorld, V3{cols["x"][i], cols["y"][i], cols["z"][i]}));
+        if (hasN) m.normals.push_back(normalized(xfNormal(nm, V3{cols["nx"][i], cols["ny"][i], cols["nz"][i]})));
+    }
+    std::vector<std::pair<float, float>> vuv;
+    const char *uvNames[2][2] = {{"u", "v"}, {"s", "t"}};
+    for (auto &nmz : uvNames)
+        if (cols.count(nmz[0]) && cols.count(nmz[1])) { vuv.clear(); for (size_t i = 0; i < nVerts; ++i) vuv.emplace_back(cols[nmz[0]][i], cols[nmz[1]][i]); }
+    if (maxSmoothAngle >= 0) rebuildTopology(m, vuv.empty() ? nullptr : &vuv, maxSmoothAngle);
+    if (faceNormals) {
+        m.normals.clear();
+        if (flipNormals) for (size_t t = 0; t + 2 < m.indices.size(); t += 3) std::swap(m.indices[t], m.indices[t + 1]);
+    } else if (!m.normals.empty()) {
+        if (flipNormals) for (V3 &n : m.normals) n = {-n.x, -n.y, -n.z};
+    } else {
+        computeNormals(m, flipNormals);
+    }
+    return m;
+}
+
 // ------------------------------------------------------------------------------------------------ the scene
 struct LoadedScene {
     SceneData scene;
@@ -632,6 +735,17 @@ public:
                 if (!m_strict && !std::ifstream(fn)) { out.warnings.push_back("shape skipped: Wavefront OBJ file '" + fn + "' not found"); continue; }
                 meshes = loadOBJ(fn, m, flag(pr, "faceNormals", false), flag(pr, "flipNormals", false), flag(pr, "flipTexCoords", true), flag(pr, "collapse", false),
                                  pr.count("maxSmoothAngle") ? std::stof(pr["maxSmoothAngle"]) : -1.0f);
+            } else if (t == "ply") {
+                if (!pr.count("filename")) throw std::runtime_error("ply shape without filename");
+                std::string fn = pr["filename"];
+                if (fn.empty() || fn[0] != '/') fn = m_base + "/" + fn;
+                if (!std::ifstream(fn)) {
+                    if (m_strict) throw std::runtime_error("PLY file '" + fn + "' not found");
+                    out.warnings.push_back("shape skipped: PLY file '" + fn + "' not found");
+                    continue;
+                }
+                if (pr.count("maxSmoothAngle") && flag(pr, "faceNormals", false)) throw std::runtime_error("The properties 'maxSmoothAngle' and 'faceNormals' can't be specified at the same time!");
+                meshes.push_back(loadPLY(fn, m, flag(pr, "faceNormals", false), flag(pr, "flipNormals", false), pr.count("maxSmoothAngle") ? std::stof(pr["maxSmoothAngle"]) : -1.0f));
             } else if (t == "serialized") {
                 if (!pr.count("filename")) throw std::runtime_error("serialized shape without filename");
                 std::string fn = pr["filename"];
@@ -671,7 +785,7 @@ public:
                 sphere.flip_normals = flag(pr, "flipNormals", false) ? 1 : 0;
                 isSphere = true;
             } else {
-                throw std::runtime_error("shape type '" + t + "' is not supported (obj, serialized, rectangle, cube, sphere)");
+                throw std::runtime_error("shape type '" + t + "' is not supported (obj, ply, serialized, rectangle, cube, sphere)");
             }
             int mat = -1;
             for (auto &c : sh.children) {

@@ -5,7 +5,7 @@
               nested sampler (independent; sampleCount / seed do not steer guided_path, GP:1342-1374) and
               film hdrfilm (width, height; rfilter box)
   shapes      obj (filename, toWorld, faceNormals, maxSmoothAngle, flipNormals, flipTexCoords, collapse),
-              serialized (filename, shapeIndex, toWorld, faceNormals, maxSmoothAngle, flipNormals), rectangle / cube (toWorld, flipNormals),
+              serialized (filename, shapeIndex, toWorld, faceNormals, maxSmoothAngle, flipNormals), ply (filename, toWorld, faceNormals, maxSmoothAngle, flipNormals), rectangle / cube (toWorld, flipNormals),
               sphere (center, radius, toWorld = rotation x uniform scale, flipNormals) — analytic, not tessellated
   bsdfs       diffuse, conductor (material none, or explicit eta / k), roughconductor / roughdielectric / roughplastic (ggx / beckmann, isotropic; roughplastic reads Mitsuba's data/microfacet tables),
               plastic, dielectric, thindielectric,
@@ -420,6 +420,88 @@ def load_serialized(path, to_world=None, shape_index=0, face_normals=False, flip
     return dict(name=os.path.splitext(os.path.basename(path))[0], material="", positions=pos, normals=normals, indices=idx)
 
 
+_PLY_TYPES = {"char": "i1", "int8": "i1", "uchar": "u1", "uint8": "u1", "short": "i2", "int16": "i2", "ushort": "u2", "uint16": "u2", "int": "i4", "int32": "i4",
+              "uint": "u4", "uint32": "u4", "float": "f4", "float32": "f4", "double": "f8", "float64": "f8"}
+
+
+def load_ply(path, to_world=None, face_normals=False, flip_normals=False, max_smooth_angle=None):
+    """shapes/ply.cpp: Stanford PLY (ascii / binary little / big endian) with vertex x y z [nx ny nz] [u v | s t] and faces of 3 or 4 indices
+    (a quad becomes (0, 1, 2), (3, 0, 2), ply.cpp:299-311); positions and normals go through toWorld as they are read (:229-233)."""
+    to_world = np.eye(4, dtype=f32) if to_world is None else to_world
+    buf = open(path, "rb").read()
+    end = buf.find(b"end_header")
+    if not buf.startswith(b"ply") or end < 0:
+        raise SceneError("%s: not a PLY file" % path)
+    head = buf[:end].decode("latin1").splitlines()
+    data_off = buf.index(b"\n", end) + 1
+    fmt, elements = None, []
+    for line in head[1:]:
+        tok = line.split()
+        if not tok or tok[0] in ("comment", "obj_info"):
+            continue
+        if tok[0] == "format":
+            fmt = tok[1]
+        elif tok[0] == "element":
+            elements.append([tok[1], int(tok[2]), []])
+        elif tok[0] == "property":
+            elements[-1][2].append((tok[-1], tok[1:-1]))
+    if fmt not in ("ascii", "binary_little_endian", "binary_big_endian"):
+        raise SceneError("%s: unknown PLY format %r" % (path, fmt))
+    verts, faces = {}, []
+    if fmt == "ascii":
+        tokens = iter(buf[data_off:].split())
+        nxt = lambda typ: (float if _PLY_TYPES[typ][0] == "f" else int)(next(tokens))  # noqa: E731
+    else:
+        bo = "<" if fmt == "binary_little_endian" else ">"
+        pos = [data_off]
+
+        def nxt(typ):
+            dt = np.dtype(bo + _PLY_TYPES[typ])
+            v = np.frombuffer(buf, dt, 1, pos[0])[0]
+            pos[0] += dt.itemsize
+            return v
+    for name, count, props in elements:
+        cols = {pn: [] for pn, _ in props} if name == "vertex" else None
+        for _ in range(count):
+            for pn, ptype in props:
+                if ptype[0] == "list":
+                    n = int(nxt(ptype[1]))
+                    vals = [int(nxt(ptype[2])) for _ in range(n)]
+                    if name == "face" and pn in ("vertex_indices", "vertex_index"):
+                        if n not in (3, 4):
+                            raise SceneError("%s: only triangle and quad-based PLY meshes are supported" % path)
+                        faces.append((vals[0], vals[1], vals[2]))
+                        if n == 4:
+                            faces.append((vals[3], vals[0], vals[2]))
+                else:
+                    v = nxt(ptype[0])
+                    if cols is not None:
+                        cols[pn].append(v)
+        if name == "vertex":
+            verts = cols
+    if not faces or not verts or "x" not in verts:
+        raise SceneError("Unable to load \"%s\" (no triangles or vertices found)!" % path)
+    P = np.stack([np.asarray(verts[k], f32) for k in "xyz"], 1)
+    N = np.stack([np.asarray(verts[k], f32) for k in ("nx", "ny", "nz")], 1) if all(k in verts for k in ("nx", "ny", "nz")) else None
+    uvs = None
+    for a, b in (("u", "v"), ("s", "t")):
+        if a in verts and b in verts:
+            uvs = np.stack([np.asarray(verts[a], f32), np.asarray(verts[b], f32)], 1)
+    idx = np.asarray(faces, np.uint32)
+    if idx.max() >= len(P):
+        raise SceneError("%s: vertex index out of bounds" % path)
+    pos_w = _xf_points(to_world, P)
+    nrm_w = None
+    if N is not None:
+        nrm_w = _xf_normals(to_world, N)
+        nrm_w = (nrm_w / np.sqrt(np.sum(nrm_w * nrm_w, 1, dtype=f32), dtype=f32)[:, None]).astype(f32)
+    if max_smooth_angle is not None:
+        pos_w, uvs, idx = rebuild_topology(pos_w, uvs, idx, max_smooth_angle)
+        nrm_w = None
+    nrm_w, idx = _finish_normals(pos_w, nrm_w, idx, face_normals, flip_normals)
+    return dict(name=os.path.splitext(os.path.basename(path))[0], material="", positions=pos_w, normals=nrm_w, indices=idx)
+
+
 def cube_mesh(to_world, flip_normals=False):
     """shapes/cube.cpp:24-30, 73-103: the cube [-1, 1]^3 as 6 faces x 4 vertices (own normals per face) and 12 triangles.  Face order
     -y, +y, +x, +z, -x, -z; a face's corners start at the corner given below and turn counter-clockwise about the face normal;
@@ -714,6 +796,19 @@ def load_scene(path, defines=None, strict=True, width=None, height=None, data_di
                 continue
             meshes = load_obj(full, m, bool(sprops.get("faceNormals", False)), bool(sprops.get("flipNormals", False)),
                               bool(sprops.get("flipTexCoords", True)), bool(sprops.get("collapse", False)), sprops.get("maxSmoothAngle"))
+        elif t == "ply":
+            fn = sprops.get("filename")
+            if not fn:
+                raise SceneError("ply shape without filename")
+            full = fn if os.path.isabs(fn) else os.path.join(base, fn)
+            if not os.path.exists(full):
+                if strict:
+                    raise SceneError("PLY file '%s' not found" % full)
+                warnings.append("shape skipped: PLY file '%s' not found" % full)
+                continue
+            if "maxSmoothAngle" in sprops and sprops.get("faceNormals", False):
+                raise SceneError("The properties 'maxSmoothAngle' and 'faceNormals' can't be specified at the same time!")
+            meshes = [load_ply(full, m, bool(sprops.get("faceNormals", False)), bool(sprops.get("flipNormals", False)), sprops.get("maxSmoothAngle"))]
         elif t == "serialized":
             fn = sprops.get("filename")
             if not fn:
@@ -747,7 +842,7 @@ def load_scene(path, defines=None, strict=True, width=None, height=None, data_di
             sphere = dict(center=tuple(float(v) for v in o2w[:3, 3]), radius=float(radius), to_world=[float(v) for v in o2w[:3, :3].reshape(-1)],
                           flip_normals=bool(sprops.get("flipNormals", False)))
         else:
-            raise SceneError("shape type %r is not supported (obj, serialized, rectangle, cube, sphere)" % t)
+            raise SceneError("shape type %r is not supported (obj, ply, serialized, rectangle, cube, sphere)" % t)
         # material: nested <bsdf> or <ref id>
         mat = None
         for c in sh:

@@ -331,6 +331,24 @@ def test_cpp_serialized_loader_equals_the_python_loader(ppg_render, tmp_path):
     assert r.returncode == 2 and "out of range" in r.stderr
 
 
+def test_cpp_ply_loader_equals_the_python_loader(ppg_render, tmp_path):
+    import ppg_host
+    from test_mitsuba_xml import _write, write_ply
+    rng = np.random.RandomState(9)
+    P = rng.rand(12, 3).astype(np.float32)
+    faces = [(0, 1, 2, 3), (4, 5, 6), (7, 8, 9, 10), (1, 5, 11), (2, 6, 10, 11)]
+    (tmp_path / "meshes").mkdir(exist_ok=True)
+    for fmt, normals, double in (("ascii", None, False), ("binary_little_endian", rng.randn(12, 3).astype(np.float32), False), ("binary_big_endian", None, True)):
+        write_ply(str(tmp_path / "meshes" / "m.ply"), P, faces, fmt, normals, double)
+        xml = _write(tmp_path, '<shape type="ply"><string name="filename" value="meshes/m.ply"/><transform name="toWorld"><rotate x="1" angle="35"/><scale x="2" y="1" z="0.5"/></transform></shape>'
+                               '<shape type="ply"><string name="filename" value="meshes/m.ply"/><float name="maxSmoothAngle" value="40"/><boolean name="flipNormals" value="true"/></shape>')
+        r, c = _cpp_load(ppg_render, xml, tmp_path, "-D", "nee=never")
+        assert r.returncode == 0, r.stderr
+        desc, _, _ = ppg_host.load_scene(xml, defines=dict(nee="never"))
+        assert np.array_equal(c["indices"], desc.indices) and np.allclose(c["positions"], desc.positions, rtol=1e-6, atol=1e-6)
+        assert np.allclose(c["normals"], desc.normals, rtol=1e-5, atol=2e-6), fmt
+
+
 def test_cpp_scene_xml_loader_errors(ppg_render, tmp_path):
     from test_mitsuba_xml import _write
     for extra, needle in (('<shape type="cylinder"/>', "cylinder"), ('<shape type="rectangle"><bsdf type="ward"/></shape>', "ward"),

@@ -460,3 +460,47 @@ def test_serialized_meshes(tmp_path, version):
     open(str(tmp_path / "bad.serialized"), "wb").write(b"\x00\x01\x02\x03rubbish")
     with pytest.raises(mitsuba_xml.SceneError, match="invalid file format"):
         mitsuba_xml.load_serialized(str(tmp_path / "bad.serialized"))
+
+
+def write_ply(path, P, faces, fmt="ascii", normals=None, double=False):
+    import struct
+    props = [("x", 0), ("y", 1), ("z", 2)] + ([("nx", 3), ("ny", 4), ("nz", 5)] if normals is not None else [])
+    V = np.hstack([P, normals]) if normals is not None else np.asarray(P)
+    head = "ply\nformat %s 1.0\ncomment written by the test\nelement vertex %d\n" % (fmt, len(V))
+    head += "".join("property %s %s\n" % ("double" if double else "float", n) for n, _ in props) + "property uchar red\n"
+    head += "element face %d\nproperty list uchar int vertex_indices\nend_header\n" % len(faces)
+    with open(path, "wb") as f:
+        f.write(head.encode())
+        if fmt == "ascii":
+            for v in V:
+                f.write((" ".join(repr(float(x)) for x in v) + " 200\n").encode())
+            for fc in faces:
+                f.write(("%d %s\n" % (len(fc), " ".join(str(i) for i in fc))).encode())
+        else:
+            bo = "<" if fmt == "binary_little_endian" else ">"
+            for v in V:
+                f.write(struct.pack(bo + "%d%sB" % (len(v), "d" if double else "f"), *[float(x) for x in v], 200))
+            for fc in faces:
+                f.write(struct.pack(bo + "B%di" % len(fc), len(fc), *fc))
+
+
+@pytest.mark.parametrize("fmt", ["ascii", "binary_little_endian", "binary_big_endian"])
+def test_ply_meshes(tmp_path, fmt):
+    """shapes/ply.cpp: the three encodings, extra properties skipped, quads split as (0, 1, 2), (3, 0, 2), normals kept or generated."""
+    P = np.float32([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [0.5, 0.5, 1]])
+    faces = [(0, 1, 2, 3), (0, 1, 4), (1, 2, 4)]
+    (tmp_path / "meshes").mkdir(exist_ok=True)
+    p = str(tmp_path / "meshes" / "m.ply")
+    write_ply(p, P, faces, fmt, double=(fmt == "binary_big_endian"))
+    m = mitsuba_xml.load_ply(p)
+    assert m["indices"].tolist() == [[0, 1, 2], [3, 0, 2], [0, 1, 4], [1, 2, 4]] and np.array_equal(m["positions"], P)
+    assert np.array_equal(m["normals"], mitsuba_xml.compute_normals(P, m["indices"], False))
+    N = np.float32([[0, 0, 1]] * 5)
+    write_ply(p, P, faces, fmt, normals=N)
+    assert np.array_equal(mitsuba_xml.load_ply(p, flip_normals=True)["normals"], -N)
+    xml = _write(tmp_path, '<shape type="ply"><string name="filename" value="meshes/m.ply"/><transform name="toWorld"><translate z="5"/></transform></shape>')
+    desc, _, _ = ppg_host.load_scene(xml, defines=dict(nee="never"))
+    assert np.allclose(desc.positions[-5:], P + np.float32([0, 0, 5]))
+    write_ply(p, P, [(0, 1, 2, 3, 4)], fmt)
+    with pytest.raises(mitsuba_xml.SceneError, match="triangle and quad"):
+        mitsuba_xml.load_ply(p)
