@@ -199,6 +199,31 @@ inline void interpolatedToRGB(std::vector<double> lam, std::vector<double> val, 
     rgb[0] = (float)std::max(r, 0.0); rgb[1] = (float)std::max(gg, 0.0); rgb[2] = (float)std::max(b, 0.0);
 }
 
+// <blackbody temperature=".." scale=".."/> (scenehandler.cpp:534-547): Planck's law (BlackBodySpectrum::eval, spectrum.cpp:483-495) through
+// Spectrum::fromContinuousSpectrum, clamped, times scale
+inline void blackbodyToRGB(double temperature, double scale, float rgb[3]) {
+    using namespace detail;
+    std::vector<double> wl(471), cx(471), cy(471), cz(471);
+    for (int i = 0; i < 471; ++i) { wl[i] = 360.0 + i; cx[i] = kCIE[i][0]; cy[i] = kCIE[i][1]; cz[i] = kCIE[i][2]; }
+    const double step = 0.00731, cc = 299792458.0, k = 1.3806488e-23, h = 6.62606957e-34;
+    double X = 0, Y = 0, Z = 0, N = 0, pg = 0, ps[4] = {0, 0, 0, 0};
+    bool first = true;
+    for (long n = 0;; ++n) {
+        const double g = 360.0 + n * step;
+        if (!(g < 830.0)) break;
+        const double lambda = g * 1e-9;
+        const double s = (2 * h * cc * cc) * std::pow(lambda, -5.0) / ((std::exp((h / k) * cc / (lambda * temperature)) - 1.0) * 1e9);
+        const double x = evalInterp(wl, cx, g), y = evalInterp(wl, cy, g), z = evalInterp(wl, cz, g);
+        const double cur[4] = {s * x, s * y, s * z, y};
+        if (!first) { const double hh = 0.5 * (g - pg); X += hh * (cur[0] + ps[0]); Y += hh * (cur[1] + ps[1]); Z += hh * (cur[2] + ps[2]); N += hh * (cur[3] + ps[3]); }
+        first = false; pg = g;
+        for (int c = 0; c < 4; ++c) ps[c] = cur[c];
+    }
+    X /= N; Y /= N; Z /= N;
+    const double r = 3.240479 * X - 1.537150 * Y - 0.498535 * Z, gg = -0.969256 * X + 1.875991 * Y + 0.041556 * Z, b = 0.055648 * X - 0.204043 * Y + 1.057311 * Z;
+    rgb[0] = (float)std::max(r, 0.0) * (float)scale; rgb[1] = (float)std::max(gg, 0.0) * (float)scale; rgb[2] = (float)std::max(b, 0.0) * (float)scale;
+}
+
 inline std::vector<double> parseFloats(std::string t) {
     for (char &c : t) if (c == ',') c = ' ';
     std::istringstream is(t);
@@ -891,8 +916,34 @@ private:
         for (auto &c : e.children) {
             if (c.get("name") != name) continue;
             if (c.tag == "rgb" || c.tag == "srgb" || c.tag == "spectrum") {
-                if (c.attr("filename")) throw std::runtime_error("<spectrum filename=...> is not supported");
+                if (c.attr("filename")) {  // InterpolatedSpectrum(path) (spectrum.cpp:575-600): "wavelength value" lines, # comments
+                    std::string fn = sub(c.get("filename"));
+                    if (fn.empty() || fn[0] != '/') fn = m_base + "/" + fn;
+                    std::ifstream sf(fn);
+                    if (c.tag != "spectrum" || c.attr("value")) throw std::runtime_error("<" + c.tag + " filename>: please provide one of 'value' or 'filename'");
+                    if (!sf) throw std::runtime_error("<spectrum filename=\"" + c.get("filename") + "\">: file not found");
+                    std::vector<double> lam, val;
+                    std::string line;
+                    while (std::getline(sf, line)) {
+                        size_t a = line.find_first_not_of(" \t\r\n");
+                        if (a == std::string::npos || line[a] == '#') continue;
+                        std::istringstream ls(line);
+                        double l, v;
+                        if (!(ls >> l >> v)) break;
+                        lam.push_back(l); val.push_back(v);
+                    }
+                    if (lam.size() < 2) throw std::runtime_error("<spectrum filename>: fewer than two samples");
+                    interpolatedToRGB(lam, val, rgb);
+                    return;
+                }
                 parseColour(c.tag, sub(c.get("value")), rgb);
+                return;
+            }
+            if (c.tag == "blackbody") {
+                std::string t = sub(c.get("temperature"));
+                while (!t.empty() && isspace((unsigned char)t.back())) t.pop_back();
+                if (!t.empty() && (t.back() == 'K' || t.back() == 'k')) t.pop_back();
+                blackbodyToRGB(std::stod(t), c.attr("scale") ? std::stod(sub(c.get("scale"))) : 1.0, rgb);
                 return;
             }
             if (c.tag == "texture" || c.tag == "ref") throw std::runtime_error("textured '" + name + "' is not supported (SURVEY.md §8 f1)");

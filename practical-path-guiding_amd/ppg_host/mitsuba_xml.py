@@ -11,7 +11,7 @@
               plastic, dielectric, thindielectric,
               mask (constant opacity), twosided(any of the BRDFs) — top level with id, nested, or <ref id>
   emitters    area (nested in a shape), constant (environment), envmap (latitude-longitude .exr / .pfm / .hdr; filename, scale, toWorld = rotation)
-  values      <spectrum>, <rgb>, <srgb> (spectrum.py), <transform> of translate / rotate / scale / lookAt / matrix,
+  values      <spectrum>, <rgb>, <srgb>, <blackbody> (spectrum.py), <transform> of translate / rotate / scale / lookAt / matrix,
               <default name value> and $name substitution (mitsuba -D, mitsuba.cpp:58-87)
 
 Anything else raises SceneError naming the plugin (Mitsuba would load it; this path cannot render it yet —
@@ -608,9 +608,29 @@ def load_scene(path, defines=None, strict=True, width=None, height=None, data_di
         for c in elem:
             if c.get("name") == name:
                 if c.tag in ("rgb", "srgb", "spectrum"):
-                    if c.get("filename"):
-                        raise SceneError("<spectrum filename=...> is not supported")
+                    if c.get("filename"):  # InterpolatedSpectrum(path) (spectrum.cpp:575-600): "wavelength value" lines, # comments
+                        fn = sub(c.get("filename"))
+                        full = fn if os.path.isabs(fn) else os.path.join(base, fn)
+                        if c.tag != "spectrum" or c.get("value") is not None or not os.path.exists(full):
+                            raise SceneError("<%s filename=%r>: %s" % (c.tag, fn, "file not found" if c.tag == "spectrum" and c.get("value") is None
+                                                                         else "please provide one of 'value' or 'filename'"))
+                        pairs = []
+                        for line in open(full):
+                            line = line.strip()
+                            if not line or line.startswith("#"):
+                                continue
+                            tok = line.split()
+                            try:
+                                pairs.append((float(tok[0]), float(tok[1])))
+                            except (ValueError, IndexError):
+                                break
+                        if len(pairs) < 2:
+                            raise SceneError("<spectrum filename=%r>: fewer than two samples" % fn)
+                        return spectrum.interpolated_to_rgb(pairs)
                     return spectrum.parse(c.tag, sub(c.get("value")))
+                if c.tag == "blackbody":
+                    t = sub(c.get("temperature", "")).strip()
+                    return spectrum.blackbody_to_rgb(float(t[:-1] if t[-1:] in "kK" else t), float(sub(c.get("scale", "1"))))
                 if c.tag == "texture" or c.tag == "ref":
                     raise SceneError("textured %r is not supported (SURVEY.md §8 f1)" % name)
         return np.full(3, default, f32)

@@ -67,6 +67,17 @@ def interpolated_to_rgb(pairs):
     return np.maximum(_XYZ_TO_RGB @ xyz, 0.0).astype(np.float32)
 
 
+def blackbody_to_rgb(temperature, scale=1.0):
+    """<blackbody temperature="5000K" scale=".."/> (scenehandler.cpp:534-547): Planck's law in W m^-2 nm^-1 sr^-1 (BlackBodySpectrum::eval,
+    spectrum.cpp:483-495) through Spectrum::fromContinuousSpectrum like any other continuous spectrum, clamped, times `scale`."""
+    grid, c, ynorm = _cie()
+    lam = grid * 1e-9
+    cc, k, h = 299792458.0, 1.3806488e-23, 6.62606957e-34
+    s = (2 * h * cc * cc) * np.power(lam, -5.0) / ((np.exp((h / k) * cc / (lam * float(temperature))) - 1.0) * 1e9)
+    xyz = np.array([np.trapezoid(s * ck, grid) for ck in c]) / ynorm
+    return (np.maximum(_XYZ_TO_RGB @ xyz, 0.0).astype(np.float32) * np.float32(scale)).astype(np.float32)
+
+
 def srgb_to_linear(v):
     v = np.asarray(v, np.float64)
     return np.where(v <= 0.04045, v / 12.92, ((v + 0.055) / 1.055) ** 2.4).astype(np.float32)

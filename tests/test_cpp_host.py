@@ -182,6 +182,8 @@ def test_cpp_scene_xml_loader_equals_the_python_loader(ppg_render, tmp_path):
     <shape type="rectangle"><bsdf type="conductor"><rgb name="eta" value="0.2, 0.9, 1.1"/><rgb name="k" value="3.9, 2.4, 2.1"/></bsdf></shape>
     <shape type="obj"><string name="filename" value="meshes/cube.obj"/><transform name="toWorld"><rotate x="1" y="1" angle="33"/><translate x="3"/></transform></shape>
     <emitter type="constant"><srgb name="radiance" value="0.5, 0.6, 0.7"/></emitter>
+    <shape type="rectangle"><emitter type="area"><blackbody name="radiance" temperature="4500K" scale="0.001"/></emitter></shape>
+    <shape type="rectangle"><bsdf type="diffuse"><spectrum name="reflectance" filename="meshes/paint.spd"/></bsdf></shape>
     <shape type="sphere"><point name="center" x="1" y="2" z="3"/><float name="radius" value="0.5"/><ref id="m1"/></shape>
     <shape type="cube"><boolean name="flipNormals" value="true"/><transform name="toWorld"><scale x="2" y="0.5" z="1"/><rotate y="1" angle="30"/><translate x="-4"/></transform></shape>
     <shape type="sphere"><boolean name="flipNormals" value="true"/><float name="radius" value="2"/>
@@ -193,12 +195,13 @@ def test_cpp_scene_xml_loader_equals_the_python_loader(ppg_render, tmp_path):
     v = [(x, y, z) for x in (0, 1) for y in (0, 1) for z in (0, 1)]
     quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
     (tmp_path / "meshes" / "cube.obj").write_text("".join("v %d %d %d\n" % p for p in v) + "".join("f %d %d %d %d\n" % tuple(i + 1 for i in q) for q in quads))
+    (tmp_path / "meshes" / "paint.spd").write_text("# measured\n400 0.1\n500 0.8\n600 0.5\n700 0.2\n")
     r, c = _cpp_load(ppg_render, xml, tmp_path, "-D", "nee=kickstart")
     assert r.returncode == 0, r.stderr
     desc, props, _ = ppg_host.load_scene(xml, defines=dict(nee="kickstart"))
     assert np.array_equal(c["indices"], desc.indices) and np.array_equal(c["tri_material"], desc.tri_material) and np.array_equal(c["tri_emitter"], desc.tri_emitter)
     assert np.allclose(c["positions"], desc.positions, rtol=1e-6, atol=1e-6) and np.allclose(c["normals"], desc.normals, rtol=1e-5, atol=1e-6)
-    assert len(c["spheres"]) == len(desc.spheres) == 2
+    assert len(c["spheres"]) == len(desc.spheres) == 2 and len(desc.emitters) >= 3
     for a, b in zip(c["spheres"], desc.spheres):
         assert np.allclose(a["center"], b["center"], rtol=1e-6) and abs(a["radius"] - b["radius"]) < 1e-5 * b["radius"] and np.allclose(a["to_world"], b["to_world"], atol=1e-6)
         assert (a["material"], a["emitter"], a["flip_normals"]) == (b["material"], b["emitter"], int(b["flip_normals"]))

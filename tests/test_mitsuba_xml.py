@@ -504,3 +504,33 @@ def test_ply_meshes(tmp_path, fmt):
     write_ply(p, P, [(0, 1, 2, 3, 4)], fmt)
     with pytest.raises(mitsuba_xml.SceneError, match="triangle and quad"):
         mitsuba_xml.load_ply(p)
+
+
+def test_blackbody_spectra(tmp_path):
+    """<blackbody> (scenehandler.cpp:534-547, spectrum.cpp:483-495): Planck's law through the CIE matching functions.  The chromaticities
+    land on the published Planckian locus (6500 K: x 0.3135, y 0.3237; 5000 K: 0.3451, 0.3516; 3000 K: 0.4369, 0.4041); the magnitude is
+    spectral radiance in W m^-2 nm^-1 sr^-1 weighted by y-bar, `scale` multiplies it."""
+    from ppg_host import spectrum
+    M = np.linalg.inv(spectrum._XYZ_TO_RGB)
+    for T, xy in ((6500, (0.3135, 0.3237)), (5000, (0.3451, 0.3516)), (3000, (0.4369, 0.4041))):
+        XYZ = M @ spectrum.blackbody_to_rgb(T).astype(np.float64)
+        assert abs(XYZ[0] / XYZ.sum() - xy[0]) < 3e-4 and abs(XYZ[1] / XYZ.sum() - xy[1]) < 3e-4
+    assert np.allclose(spectrum.blackbody_to_rgb(5000, 1e-4), spectrum.blackbody_to_rgb(5000) * np.float32(1e-4), rtol=1e-6)
+    xml = _write(tmp_path, '<shape type="rectangle"><emitter type="area"><blackbody name="radiance" temperature="4500K" scale="0.001"/></emitter></shape>')
+    desc, _, _ = ppg_host.load_scene(xml, defines=dict(nee="never"))
+    assert np.allclose(desc.emitters[-1]["radiance"], spectrum.blackbody_to_rgb(4500, 0.001), rtol=1e-6)
+    r, g, b = desc.emitters[-1]["radiance"]
+    assert r > g > b > 0                                    # a warm white
+
+
+def test_spectrum_from_a_file(tmp_path):
+    """<spectrum filename="x.spd"/> (scenehandler.cpp:557-567): the file's "wavelength value" samples go the same way as an inline list."""
+    from ppg_host import spectrum
+    pairs = [(400, 0.1), (500, 0.8), (600, 0.5), (700, 0.2)]
+    (tmp_path / "meshes").mkdir(exist_ok=True)
+    (tmp_path / "meshes" / "paint.spd").write_text("# measured\n" + "".join("%g %g\n" % p for p in pairs) + "\n")
+    xml = _write(tmp_path, '<shape type="rectangle"><bsdf type="diffuse"><spectrum name="reflectance" filename="meshes/paint.spd"/></bsdf></shape>')
+    desc, _, _ = ppg_host.load_scene(xml, defines=dict(nee="never"))
+    assert np.allclose(desc.materials[desc.tri_material[-1]]["reflectance"], spectrum.interpolated_to_rgb(pairs), rtol=1e-6)
+    with pytest.raises(mitsuba_xml.SceneError, match="not found"):
+        ppg_host.load_scene(_write(tmp_path, '<shape type="rectangle"><bsdf type="diffuse"><spectrum name="reflectance" filename="nope.spd"/></bsdf></shape>'), defines=dict(nee="never"))
