@@ -175,11 +175,12 @@ inline double evalInterp(const std::vector<double> &lam, const std::vector<doubl
 }
 }  // namespace detail
 
-inline void interpolatedToRGB(std::vector<double> lam, std::vector<double> val, float rgb[3]) {
+// scene-file spectra are zero-extended and clamped (scenehandler.cpp:563-566); the conductor plug-ins read data/ior/*.spd without either
+inline void interpolatedToRGB(std::vector<double> lam, std::vector<double> val, float rgb[3], bool zeroExtend = true, bool clamp = true) {
     using namespace detail;
     const double spacing = (lam.back() - lam.front()) / (lam.size() - 1);  // zeroExtend, spectrum.cpp:630-648
-    if (val.front() != 0) { lam.insert(lam.begin(), lam.front() - spacing); val.insert(val.begin(), 0.0); }
-    if (val.back() != 0) { lam.push_back(lam.back() + spacing); val.push_back(0.0); }
+    if (zeroExtend && val.front() != 0) { lam.insert(lam.begin(), lam.front() - spacing); val.insert(val.begin(), 0.0); }
+    if (zeroExtend && val.back() != 0) { lam.push_back(lam.back() + spacing); val.push_back(0.0); }
     std::vector<double> wl(471), cx(471), cy(471), cz(471);
     for (int i = 0; i < 471; ++i) { wl[i] = 360.0 + i; cx[i] = kCIE[i][0]; cy[i] = kCIE[i][1]; cz[i] = kCIE[i][2]; }
     const double step = 0.00731;  // off-node sampling: exact hits have measure zero
@@ -196,7 +197,23 @@ inline void interpolatedToRGB(std::vector<double> lam, std::vector<double> val, 
     }
     X /= N; Y /= N; Z /= N;
     const double r = 3.240479 * X - 1.537150 * Y - 0.498535 * Z, gg = -0.969256 * X + 1.875991 * Y + 0.041556 * Z, b = 0.055648 * X - 0.204043 * Y + 1.057311 * Z;
-    rgb[0] = (float)std::max(r, 0.0); rgb[1] = (float)std::max(gg, 0.0); rgb[2] = (float)std::max(b, 0.0);
+    rgb[0] = (float)(clamp ? std::max(r, 0.0) : r); rgb[1] = (float)(clamp ? std::max(gg, 0.0) : gg); rgb[2] = (float)(clamp ? std::max(b, 0.0) : b);
+}
+
+// InterpolatedSpectrum(path), spectrum.cpp:575-600: "wavelength value" lines, # comments; stops at the first malformed line
+inline bool readSPD(const std::string &path, std::vector<double> &lam, std::vector<double> &val) {
+    std::ifstream sf(path);
+    if (!sf) return false;
+    std::string line;
+    while (std::getline(sf, line)) {
+        const size_t a = line.find_first_not_of(" \t\r\n");
+        if (a == std::string::npos || line[a] == '#') continue;
+        std::istringstream ls(line);
+        double l, v;
+        if (!(ls >> l >> v)) break;
+        lam.push_back(l); val.push_back(v);
+    }
+    return true;
 }
 
 // <blackbody temperature=".." scale=".."/> (scenehandler.cpp:534-547): Planck's law (BlackBodySpectrum::eval, spectrum.cpp:483-495) through
@@ -919,19 +936,9 @@ private:
                 if (c.attr("filename")) {  // InterpolatedSpectrum(path) (spectrum.cpp:575-600): "wavelength value" lines, # comments
                     std::string fn = sub(c.get("filename"));
                     if (fn.empty() || fn[0] != '/') fn = m_base + "/" + fn;
-                    std::ifstream sf(fn);
                     if (c.tag != "spectrum" || c.attr("value")) throw std::runtime_error("<" + c.tag + " filename>: please provide one of 'value' or 'filename'");
-                    if (!sf) throw std::runtime_error("<spectrum filename=\"" + c.get("filename") + "\">: file not found");
                     std::vector<double> lam, val;
-                    std::string line;
-                    while (std::getline(sf, line)) {
-                        size_t a = line.find_first_not_of(" \t\r\n");
-                        if (a == std::string::npos || line[a] == '#') continue;
-                        std::istringstream ls(line);
-                        double l, v;
-                        if (!(ls >> l >> v)) break;
-                        lam.push_back(l); val.push_back(v);
-                    }
+                    if (!readSPD(fn, lam, val)) throw std::runtime_error("<spectrum filename=\"" + c.get("filename") + "\">: file not found");
                     if (lam.size() < 2) throw std::runtime_error("<spectrum filename>: fewer than two samples");
                     interpolatedToRGB(lam, val, rgb);
                     return;
@@ -1080,9 +1087,18 @@ private:
         std::transform(mat.begin(), mat.end(), mat.begin(), ::tolower);
         float eta[3] = {0, 0, 0}, k[3] = {1, 1, 1};
         if (mat != "none") {
-            if (!hasChildNamed(e, "eta") || !hasChildNamed(e, "k"))
-                throw std::runtime_error(what + "(material=" + (p.count("material") ? p.at("material") : "Cu") + "): measured IOR spectra (data/ior/*.spd) are not bundled; give eta and k");
-            colour(e, "eta", 0.0f, eta); colour(e, "k", 1.0f, k);
+            const std::string name = p.count("material") ? p.at("material") : "Cu";
+            if (!hasChildNamed(e, "eta") || !hasChildNamed(e, "k")) {  // the measured spectra ship with Mitsuba (data/ior/<name>.{eta,k}.spd)
+                std::string dir = m_dataDir;
+                if (dir.empty()) { const char *ev = std::getenv("PPG_MITSUBA_DATA"); if (ev) dir = ev; }
+                std::vector<double> le, ve, lk, vk;
+                if (dir.empty() || !readSPD(dir + "/ior/" + name + ".eta.spd", le, ve) || !readSPD(dir + "/ior/" + name + ".k.spd", lk, vk) || le.size() < 2 || lk.size() < 2)
+                    throw std::runtime_error(what + "(material=" + name + "): the measured IOR spectra data/ior/" + name + ".{eta,k}.spd come with Mitsuba: pass --data-dir / PPG_MITSUBA_DATA, or give eta and k");
+                interpolatedToRGB(le, ve, eta, false, false);
+                interpolatedToRGB(lk, vk, k, false, false);
+            }
+            if (hasChildNamed(e, "eta")) colour(e, "eta", 0.0f, eta);
+            if (hasChildNamed(e, "k")) colour(e, "k", 1.0f, k);
         }
         for (int c = 0; c < 3; ++c) { m.eta[c] = eta[c] / ext; m.k[c] = k[c] / ext; }
     }

@@ -7,7 +7,7 @@
   shapes      obj (filename, toWorld, faceNormals, maxSmoothAngle, flipNormals, flipTexCoords, collapse),
               serialized (filename, shapeIndex, toWorld, faceNormals, maxSmoothAngle, flipNormals), ply (filename, toWorld, faceNormals, maxSmoothAngle, flipNormals), rectangle / cube (toWorld, flipNormals),
               sphere (center, radius, toWorld = rotation x uniform scale, flipNormals) — analytic, not tessellated
-  bsdfs       diffuse, conductor (material none, or explicit eta / k), roughconductor / roughdielectric / roughplastic (ggx / beckmann, isotropic; roughplastic reads Mitsuba's data/microfacet tables),
+  bsdfs       diffuse, conductor (material none, explicit eta / k, or a named material read from Mitsuba's data/ior), roughconductor / roughdielectric / roughplastic (ggx / beckmann, isotropic; roughplastic reads Mitsuba's data/microfacet tables),
               plastic, dielectric, thindielectric,
               mask (constant opacity), twosided(any of the BRDFs) — top level with id, nested, or <ref id>
   emitters    area (nested in a shape), constant (environment), envmap (latitude-longitude .exr / .pfm / .hdr; filename, scale, toWorld = rotation)
@@ -614,16 +614,7 @@ def load_scene(path, defines=None, strict=True, width=None, height=None, data_di
                         if c.tag != "spectrum" or c.get("value") is not None or not os.path.exists(full):
                             raise SceneError("<%s filename=%r>: %s" % (c.tag, fn, "file not found" if c.tag == "spectrum" and c.get("value") is None
                                                                          else "please provide one of 'value' or 'filename'"))
-                        pairs = []
-                        for line in open(full):
-                            line = line.strip()
-                            if not line or line.startswith("#"):
-                                continue
-                            tok = line.split()
-                            try:
-                                pairs.append((float(tok[0]), float(tok[1])))
-                            except (ValueError, IndexError):
-                                break
+                        pairs = spectrum.read_spd(full)
                         if len(pairs) < 2:
                             raise SceneError("<spectrum filename=%r>: fewer than two samples" % fn)
                         return spectrum.interpolated_to_rgb(pairs)
@@ -656,16 +647,23 @@ def load_scene(path, defines=None, strict=True, width=None, height=None, data_di
             raise SceneError("%s: sampleVisible=false is not supported" % what)
         return float(p.get("alpha", 0.1))
 
-    def conductor_ior(elem, p, what):
+    def conductor_ior(elem, p, what):  # conductor.cpp:160-186 / roughconductor.cpp:174-186
         ext = lookup_ior(p, "extEta", "air")
-        if str(p.get("material", "Cu")).lower() == "none":
-            eta, k = np.zeros(3, f32), np.ones(3, f32)
+        name = str(p.get("material", "Cu"))
+        if name.lower() == "none":
+            int_eta, int_k = np.zeros(3, f32), np.ones(3, f32)
         else:
             have = {c.get("name") for c in elem}
-            if not ({"eta", "k"} <= have):
-                raise SceneError("%s(material=%s): measured IOR spectra (data/ior/*.spd) are not bundled; give <spectrum|rgb name=\"eta\"> and \"k\""
-                                 % (what, p.get("material", "Cu")))
-            eta, k = colour(elem, "eta", 0.0), colour(elem, "k", 1.0)
+            int_eta = int_k = None
+            if not ({"eta", "k"} <= have):  # the measured spectra ship with Mitsuba (data/ior/<name>.{eta,k}.spd), not with this repository
+                ddir = data_dir or os.environ.get("PPG_MITSUBA_DATA")
+                files = [os.path.join(ddir, "ior", "%s.%s.spd" % (name, part)) for part in ("eta", "k")] if ddir else []
+                if not ddir or not all(os.path.exists(f) for f in files):
+                    raise SceneError("%s(material=%s): the measured IOR spectra data/ior/%s.{eta,k}.spd come with Mitsuba: pass data_dir (--data-dir) / "
+                                     "PPG_MITSUBA_DATA, or give <spectrum|rgb name=\"eta\"> and \"k\"" % (what, name, name))
+                int_eta, int_k = (spectrum.interpolated_to_rgb(spectrum.read_spd(f), zero_extend=False, clamp=False) for f in files)
+        eta = colour(elem, "eta", 0.0) if any(c.get("name") == "eta" for c in elem) else int_eta
+        k = colour(elem, "k", 1.0) if any(c.get("name") == "k" for c in elem) else int_k
         return tuple(float(v) for v in (eta / f32(ext))), tuple(float(v) for v in (k / f32(ext)))  # roughconductor.cpp:185-186
 
     rt_slices, rt_index = [], {}

@@ -58,13 +58,30 @@ def _cie():
     return _cache["cie"]
 
 
-def interpolated_to_rgb(pairs):
-    """[(lambda_nm, value), ...] → float32 RGB (Spectrum::fromContinuousSpectrum of the RGB build)."""
+def interpolated_to_rgb(pairs, zero_extend=True, clamp=True):
+    """[(lambda_nm, value), ...] → float32 RGB (Spectrum::fromContinuousSpectrum of the RGB build).  Scene-file spectra are zero-extended and
+    clamped (scenehandler.cpp:563-566); the conductor plug-ins read data/ior/*.spd without either (roughconductor.cpp:179-183)."""
     grid, c, ynorm = _cie()
-    lam, val = _zero_extend(*zip(*pairs))
+    lam, val = _zero_extend(*zip(*pairs)) if zero_extend else zip(*pairs)
     s = _eval_interp(lam, val, grid)
     xyz = np.array([np.trapezoid(s * ck, grid) for ck in c]) / ynorm
-    return np.maximum(_XYZ_TO_RGB @ xyz, 0.0).astype(np.float32)
+    rgb = _XYZ_TO_RGB @ xyz
+    return (np.maximum(rgb, 0.0) if clamp else rgb).astype(np.float32)
+
+
+def read_spd(path):
+    """InterpolatedSpectrum(path), spectrum.cpp:575-600: "wavelength value" lines, # comments; stops at the first malformed line."""
+    pairs = []
+    for line in open(path, errors="replace"):
+        line = line.strip()
+        if not line or line.startswith("#"):
+            continue
+        tok = line.split()
+        try:
+            pairs.append((float(tok[0]), float(tok[1])))
+        except (ValueError, IndexError):
+            break
+    return pairs
 
 
 def blackbody_to_rgb(temperature, scale=1.0):

@@ -375,6 +375,28 @@ def test_cpp_loader_on_the_reference_spaceship_scene(ppg_render, tmp_path):
     assert np.allclose(c["c2w"], np.asarray(desc.camera["camera_to_world"]).reshape(-1), atol=1e-6) and list(c["size"]) == [640, 360]
 
 
+@pytest.mark.skipif(not os.path.exists("/root/reference/mitsuba/data/ior/Au.eta.spd"), reason="Mitsuba data tables not mounted")
+def test_cpp_named_conductors_equal_the_python_loader(ppg_render, tmp_path):
+    import ppg_host
+    from ppg_host.bindings import Material
+    from test_mitsuba_xml import _write
+    data = "/root/reference/mitsuba/data"
+    xml = _write(tmp_path, '<shape type="rectangle"><bsdf type="conductor"><string name="material" value="Au"/></bsdf></shape>'
+                           '<shape type="rectangle"><bsdf type="roughconductor"><float name="extEta" value="1.33"/></bsdf></shape>'
+                           '<shape type="rectangle"><bsdf type="conductor"><string name="material" value="W"/><rgb name="k" value="1, 2, 3"/></bsdf></shape>')
+    r, c = _cpp_load(ppg_render, xml, tmp_path, "-D", "nee=never", "--data-dir", data)
+    assert r.returncode == 0, r.stderr
+    desc, _, _ = ppg_host.load_scene(xml, defines=dict(nee="never"), data_dir=data)
+    assert len(c["materials"]) == len(desc.materials)
+    for a, m in zip(c["materials"], desc.materials):
+        b = bytes(Material.from_dict(m))
+        assert np.frombuffer(a, np.int32)[0] == np.frombuffer(b, np.int32)[0]
+        assert np.allclose(np.frombuffer(a, np.float32)[1:14], np.frombuffer(b, np.float32)[1:14], rtol=1e-5)
+    env = dict(os.environ); env.pop("PPG_MITSUBA_DATA", None)
+    r = subprocess.run([ppg_render, "--ppgs", str(tmp_path / "x.ppgs"), "-q", "-D", "nee=never", xml], capture_output=True, text=True, env=env)
+    assert r.returncode == 2 and "data/ior" in r.stderr
+
+
 def test_cpp_scene_xml_loader_errors(ppg_render, tmp_path):
     from test_mitsuba_xml import _write
     for extra, needle in (('<shape type="cylinder"/>', "cylinder"), ('<shape type="rectangle"><bsdf type="ward"/></shape>', "ward"),

@@ -534,3 +534,22 @@ def test_spectrum_from_a_file(tmp_path):
     assert np.allclose(desc.materials[desc.tri_material[-1]]["reflectance"], spectrum.interpolated_to_rgb(pairs), rtol=1e-6)
     with pytest.raises(mitsuba_xml.SceneError, match="not found"):
         ppg_host.load_scene(_write(tmp_path, '<shape type="rectangle"><bsdf type="diffuse"><spectrum name="reflectance" filename="nope.spd"/></bsdf></shape>'), defines=dict(nee="never"))
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/mitsuba/data/ior/Au.eta.spd"), reason="Mitsuba data tables not mounted")
+def test_named_conductor_materials_come_from_the_mitsuba_data_directory(tmp_path):
+    """conductor.cpp:160-186 / roughconductor.cpp:174-186: `material` names data/ior/<name>.{eta,k}.spd, integrated against the CIE curves
+    without zero extension or clamping; Mitsuba's default is copper.  Gold gives the familiar (0.143, 0.375, 1.442) / (3.98, 2.39, 1.60)."""
+    data = "/root/reference/mitsuba/data"
+    xml = _write(tmp_path, '<shape type="rectangle"><bsdf type="roughconductor"><string name="material" value="Au"/><string name="distribution" value="ggx"/></bsdf></shape>'
+                           '<shape type="rectangle"><bsdf type="conductor"/></shape>'
+                           '<shape type="rectangle"><bsdf type="conductor"><string name="material" value="Ag"/><float name="extEta" value="1.33"/></bsdf></shape>')
+    desc, _, _ = ppg_host.load_scene(xml, defines=dict(nee="never"), data_dir=data)
+    au, cu, ag = desc.materials[-3:]
+    assert np.allclose(au["eta"], (0.143, 0.375, 1.442), atol=5e-3) and np.allclose(au["k"], (3.983, 2.386, 1.603), atol=5e-3)
+    assert np.allclose(cu["eta"], (0.2, 0.92, 1.1), atol=2e-2) and np.allclose(cu["k"], (3.9, 2.45, 2.14), atol=3e-2)
+    plain, _, _ = ppg_host.load_scene(_write(tmp_path, '<shape type="rectangle"><bsdf type="conductor"><string name="material" value="Ag"/></bsdf></shape>'),
+                                      defines=dict(nee="never"), data_dir=data)
+    assert np.allclose(np.float32(ag["eta"]) * np.float32(1.33), np.float32(plain.materials[-1]["eta"]) * np.float32(1.000277), rtol=1e-5)
+    with pytest.raises(mitsuba_xml.SceneError, match="data/ior"):
+        ppg_host.load_scene(xml, defines=dict(nee="never"), data_dir=str(tmp_path))
