@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstring>
 #include <fstream>
+#include <functional>
 #include <map>
 #include <sstream>
 #include <stdexcept>
@@ -729,6 +730,16 @@ public:
                    sp.count("farClip") ? std::stod(sp["farClip"]) : 1e4, W, H);
         // bsdfs
         for (auto &b : root.children) if (b.tag == "bsdf" && b.attr("id")) m_byId[b.get("id")] = intern(makeBsdf(b, true, out), out);
+        {   // an id may also sit on a NESTED bsdf (KITCHEN references the twosided element inside a bumpmap): every element with an id is a named object
+            std::function<void(const XmlNode &)> walk = [&](const XmlNode &n) {
+                for (auto &c : n.children) {
+                    if (c.tag != "bsdf") continue;
+                    if (c.attr("id") && !m_byId.count(c.get("id"))) m_byId[c.get("id")] = intern(makeBsdf(c, true, out), out);
+                    walk(c);
+                }
+            };
+            for (auto &b : root.children) if (b.tag == "bsdf") walk(b);
+        }
         for (auto &e : root.children) {
             if (e.tag != "emitter") continue;
             if (e.get("type") == "constant" && !out.scene.hasEnvironment && !out.scene.hasEnvmap) { out.scene.hasEnvironment = true; colour(e, "radiance", 1.0f, out.scene.environment); continue; }
@@ -753,6 +764,7 @@ public:
                 out.scene.hasEnvmap = true;
                 continue;
             }
+            if (!m_strict) { out.warnings.push_back("emitter '" + e.get("type") + "' skipped (not supported)"); continue; }
             throw std::runtime_error("emitter type '" + e.get("type") + "' is not supported (area emitters on shapes and one `constant` or `envmap` environment emitter; SURVEY.md §8 f2)");
         }
         // shapes
@@ -884,6 +896,7 @@ public:
             for (uint32_t id : m.indices) S.indices.push_back(base + id);
             for (size_t t = 0; t < m.indices.size() / 3; ++t) { S.triMaterial.push_back(p.mat); S.triEmitter.push_back(p.em); }
         }
+        out.warnings.insert(out.warnings.end(), m_lenientNotes.begin(), m_lenientNotes.end());
         return out;
     }
 
@@ -893,7 +906,8 @@ private:
     bool m_strict;
     int m_w, m_h;
     std::string m_dataDir;  // Mitsuba `data` directory (roughplastic)
-    mutable std::map<std::string, int> m_rtIndex;  // (distribution, alpha, eta) → slice of out.scene.rtrans
+    mutable std::map<std::string, int> m_rtIndex;
+    mutable std::vector<std::string> m_lenientNotes;  // warnings raised inside const helpers  // (distribution, alpha, eta) → slice of out.scene.rtrans
     std::map<std::string, uint32_t> m_byId;
     std::vector<std::string> m_matKeys;
 
@@ -953,7 +967,11 @@ private:
                 blackbodyToRGB(std::stod(t), c.attr("scale") ? std::stod(sub(c.get("scale"))) : 1.0, rgb);
                 return;
             }
-            if (c.tag == "texture" || c.tag == "ref") throw std::runtime_error("textured '" + name + "' is not supported (SURVEY.md §8 f1)");
+            if (c.tag == "texture" || c.tag == "ref") {
+                if (m_strict) throw std::runtime_error("textured '" + name + "' is not supported (SURVEY.md §8 f1)");
+                m_lenientNotes.push_back("texture on '" + name + "' ignored: the plug-in's default value is used");
+                break;
+            }
         }
         rgb[0] = rgb[1] = rgb[2] = dflt;
     }
@@ -1184,6 +1202,10 @@ private:
                 colour(e, "specularReflectance", 1.0f, m.reflectance); colour(e, "specularTransmittance", 1.0f, m.specular);
             }
             return m;
+        }
+        if (!m_strict && (t == "bumpmap" || t == "coating" || t == "roughcoating" || t == "normalmap")) {  // adapters around one nested BSDF: render the nested one
+            auto in = inner();
+            if (in.size() == 1) { out.warnings.push_back("bsdf '" + t + "' dropped around its nested bsdf"); return makeBsdf(*in[0], allowWrap, out); }
         }
         if (m_strict) throw std::runtime_error("bsdf type '" + t + "' is not supported yet (diffuse, conductor, roughconductor, plastic, roughplastic, dielectric, thindielectric, roughdielectric, mask, twosided; SURVEY.md §8 f1)");
         out.warnings.push_back("bsdf '" + t + "' replaced by diffuse(0.5)");

@@ -623,7 +623,10 @@ def load_scene(path, defines=None, strict=True, width=None, height=None, data_di
                     t = sub(c.get("temperature", "")).strip()
                     return spectrum.blackbody_to_rgb(float(t[:-1] if t[-1:] in "kK" else t), float(sub(c.get("scale", "1"))))
                 if c.tag == "texture" or c.tag == "ref":
-                    raise SceneError("textured %r is not supported (SURVEY.md §8 f1)" % name)
+                    if strict:
+                        raise SceneError("textured %r is not supported (SURVEY.md §8 f1)" % name)
+                    warnings.append("texture on %r ignored: the plug-in's default value is used" % name)
+                    break
         return np.full(3, default, f32)
 
     IOR = {"vacuum": 1.0, "air": 1.000277, "water": 1.3330, "polypropylene": 1.49, "bk7": 1.5046, "diamond": 2.419}  # well-known constants (cf. ior.h)
@@ -743,6 +746,11 @@ def load_scene(path, defines=None, strict=True, width=None, height=None, data_di
             if str(p.get("distribution", "beckmann")).lower() == "beckmann":
                 m["distribution"] = "beckmann"
             return m
+        if not strict and t in ("bumpmap", "coating", "roughcoating", "normalmap"):  # adapters around one nested BSDF: render the nested one
+            inner = [c for c in elem if c.tag == "bsdf"]
+            if len(inner) == 1:
+                warnings.append("bsdf %r dropped around its nested bsdf" % t)
+                return make_bsdf(inner[0], allow_twosided)
         if strict:
             raise SceneError("bsdf type %r is not supported yet (diffuse, conductor, roughconductor, plastic, roughplastic, dielectric, thindielectric, roughdielectric, "
                              "mask(...), twosided(...); "
@@ -761,6 +769,12 @@ def load_scene(path, defines=None, strict=True, width=None, height=None, data_di
     for b in root.findall("bsdf"):
         if b.get("id"):
             by_id[b.get("id")] = intern(make_bsdf(b))
+    # an id may also sit on a NESTED bsdf (KITCHEN references the twosided element inside a bumpmap): every element with an id is a named
+    # object in Mitsuba (scenehandler.cpp: namedObjects)
+    for top in root.findall("bsdf"):
+        for b in top.iter("bsdf"):
+            if b is not top and b.get("id") and b.get("id") not in by_id:
+                by_id[b.get("id")] = intern(make_bsdf(b))
     for tex in root.findall("texture"):
         warnings.append("top-level texture %r ignored" % tex.get("id"))
     environment = envmap = None
@@ -786,6 +800,9 @@ def load_scene(path, defines=None, strict=True, width=None, height=None, data_di
             if not np.allclose(R @ R.T, np.eye(3), atol=1e-4):
                 raise SceneError("envmap: toWorld must be a rotation")
             envmap = dict(rgb=rgb, scale=float(ep.get("scale", 1.0)), to_world=[float(v) for v in R.reshape(-1)])
+            continue
+        if not strict:
+            warnings.append("emitter %r skipped (not supported)" % em.get("type"))
             continue
         raise SceneError("emitter type %r is not supported (area emitters on shapes and one `constant` or `envmap` environment emitter; "
                          "SURVEY.md §8 f2)" % em.get("type"))

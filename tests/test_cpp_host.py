@@ -397,6 +397,23 @@ def test_cpp_named_conductors_equal_the_python_loader(ppg_render, tmp_path):
     assert r.returncode == 2 and "data/ior" in r.stderr
 
 
+def test_cpp_lenient_loading_equals_the_python_loader(ppg_render, tmp_path):
+    import ppg_host
+    from ppg_host.bindings import Material
+    from test_mitsuba_xml import LENIENT_EXTRA, _write
+    xml = _write(tmp_path, LENIENT_EXTRA)
+    r, _ = _cpp_load(ppg_render, xml, tmp_path, "-D", "nee=never")
+    assert r.returncode == 2 and ("bumpmap" in r.stderr or "textured" in r.stderr or "sunsky" in r.stderr)
+    r, c = _cpp_load(ppg_render, xml, tmp_path, "-D", "nee=never", "--lenient")
+    assert r.returncode == 0, r.stderr
+    desc, _, info = ppg_host.load_scene(xml, defines=dict(nee="never"), strict=False)
+    assert np.array_equal(c["tri_material"], desc.tri_material) and len(c["materials"]) == len(desc.materials)
+    for a, m in zip(c["materials"], desc.materials):
+        b = bytes(Material.from_dict(m))
+        assert np.frombuffer(a, np.int32)[[0, 14]].tolist() == np.frombuffer(b, np.int32)[[0, 14]].tolist()
+        assert np.allclose(np.frombuffer(a, np.float32)[1:14], np.frombuffer(b, np.float32)[1:14], rtol=2e-6)
+
+
 def test_cpp_scene_xml_loader_errors(ppg_render, tmp_path):
     from test_mitsuba_xml import _write
     for extra, needle in (('<shape type="cylinder"/>', "cylinder"), ('<shape type="rectangle"><bsdf type="ward"/></shape>', "ward"),

@@ -553,3 +553,28 @@ def test_named_conductor_materials_come_from_the_mitsuba_data_directory(tmp_path
     assert np.allclose(np.float32(ag["eta"]) * np.float32(1.33), np.float32(plain.materials[-1]["eta"]) * np.float32(1.000277), rtol=1e-5)
     with pytest.raises(mitsuba_xml.SceneError, match="data/ior"):
         ppg_host.load_scene(xml, defines=dict(nee="never"), data_dir=str(tmp_path))
+
+
+LENIENT_EXTRA = """
+    <bsdf type="bumpmap"><texture type="scale"><float name="scale" value="0.01"/></texture>
+        <bsdf type="twosided" id="inner"><bsdf type="diffuse"><texture name="reflectance" type="bitmap"><string name="filename" value="t.jpg"/></texture></bsdf></bsdf></bsdf>
+    <shape type="rectangle"><ref id="inner"/></shape>
+    <shape type="rectangle"><bsdf type="bumpmap"><texture type="bitmap"><string name="filename" value="b.png"/></texture>
+        <bsdf type="roughconductor"><string name="material" value="none"/><string name="distribution" value="ggx"/></bsdf></bsdf></shape>
+    <emitter type="sunsky"><float name="hour" value="9"/></emitter>
+"""
+
+
+def test_lenient_loading_of_kitchen_style_constructs(tmp_path):
+    """What the reference's KITCHEN scene needs from a lenient load: an id on a bsdf NESTED in a bumpmap is a named object of its own
+    (the shapes reference the inner twosided, not the bump adapter); textures fall back to the plug-in's default value; bumpmap is dropped
+    around its nested bsdf; the sunsky emitter is skipped — each with a warning.  Strict loading names the first unsupported construct."""
+    xml = _write(tmp_path, LENIENT_EXTRA)
+    with pytest.raises(mitsuba_xml.SceneError, match="bumpmap|textured|sunsky"):
+        ppg_host.load_scene(xml, defines=dict(nee="never"))
+    desc, _, info = ppg_host.load_scene(xml, defines=dict(nee="never"), strict=False)
+    w = "\n".join(info["warnings"])
+    assert "texture on 'reflectance' ignored" in w and "bsdf 'bumpmap' dropped" in w and "emitter 'sunsky' skipped" in w
+    a, b = desc.materials[desc.tri_material[-4]], desc.materials[desc.tri_material[-1]]
+    assert a["type"] == 1 and tuple(a["reflectance"]) == (0.5, 0.5, 0.5)          # the inner twosided diffuse with diffuse's default reflectance
+    assert b["type"] == 4 and b.get("distribution") is None

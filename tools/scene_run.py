@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--parity-spp", type=float, default=31)  # >= 5 iterations: with 1 spp/pass the first iteration has no variance estimate and
     # inverse-variance combination over the last 4 iterations would make a 15-spp image NaN everywhere (in the reference too)
     ap.add_argument("--cpu-spp", type=float, default=31, help="oracle timing at the first size (0: skip)")
+    ap.add_argument("--constant-env", help="R,G,B: add a constant environment emitter (STAND-IN lighting for a scene whose own emitter was skipped)")
     ap.add_argument("-P", dest="props", action="append", default=[])
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out"))
     a = ap.parse_args()
@@ -37,6 +38,8 @@ def main():
     import ppg_host
     from conftest import ORACLE_SO, make_oracle
     desc = ppg_host.load_scene_file(a.scene)
+    if a.constant_env:
+        desc.environment = tuple(float(v) for v in a.constant_env.split(","))
     props = {}
     pf = a.scene + ".props"
     if os.path.exists(pf):
@@ -58,7 +61,7 @@ def main():
                     props[k] = {"true": 1, "false": 0}.get(v, v)
     os.makedirs(a.out, exist_ok=True)
     name = os.path.splitext(os.path.basename(a.scene))[0]
-    summary = dict(scene=name, triangles=desc.n_triangles, spheres=len(desc.spheres), materials=len(desc.materials), props=props, runs=[])
+    summary = dict(scene=name, stand_in_environment=a.constant_env, triangles=desc.n_triangles, spheres=len(desc.spheres), materials=len(desc.materials), props=props, runs=[])
 
     def sized(wh):
         w, h = (int(v) for v in wh.split("x"))
