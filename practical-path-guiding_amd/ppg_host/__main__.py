@@ -21,6 +21,7 @@ def main(argv=None):
     ap.add_argument("--ppgs", metavar="FILE", help="write the flattened scene for bin/ppg_render and exit")
     ap.add_argument("--lenient", action="store_true", help="replace unsupported BSDFs by diffuse(0.5) instead of failing")
     ap.add_argument("--data-dir", help="`data` directory of a Mitsuba tree (roughplastic reads data/microfacet/*.dat); default $PPG_MITSUBA_DATA")
+    ap.add_argument("--constant-env", metavar="R,G,B", help="add a constant environment emitter (stand-in lighting when --lenient skipped the scene's own, e.g. sunsky)")
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("-q", "--quiet", action="store_true")
     a = ap.parse_args(argv)
@@ -35,6 +36,10 @@ def main(argv=None):
     if a.size:
         w, h = (int(v) for v in a.size.lower().split("x"))
     desc, props, info = load_scene(a.scene, defines, strict=not a.lenient, width=w, height=h, data_dir=a.data_dir)
+    if a.constant_env:
+        if desc.environment is not None or desc.envmap is not None:
+            ap.error("--constant-env: the scene already has an environment emitter")
+        desc.environment = tuple(float(v) for v in a.constant_env.split(","))
     for kv in a.props:
         k, v = kv.split("=", 1)
         if k not in GUIDED_PATH_PROPS:
