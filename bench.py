@@ -92,6 +92,10 @@ def run(args):
         # a converted scene (python -m ppg_host scene.xml --ppgs FILE, e.g. the reference's SPACESHIP): its own integrator settings
         # (FILE.props) and film size; extra bench line, not the headline configuration
         scene = ppg_host.load_scene_file(args.scene_file)
+        if args.size_override:
+            scene.camera = dict(scene.camera, width=args.width, height=args.height)
+        if args.constant_env:
+            scene.environment = tuple(float(v) for v in args.constant_env.split(","))
         args.width, args.height = scene.camera["width"], scene.camera["height"]
         if os.path.exists(args.scene_file + ".props"):
             for line in open(args.scene_file + ".props"):
@@ -237,6 +241,8 @@ def main():
     ap.add_argument("--spp", type=int, default=4)
     ap.add_argument("--scene", choices=["cbox", "room", "torus"], default="cbox", help="room = kitchen-class procedural stand-in, improved preset; torus = torus-class stand-in (SDS caustics)")
     ap.add_argument("--scene-file", help="flat scene file (ppg_host.save_scene / `python -m ppg_host scene.xml --ppgs`) instead of a procedural scene")
+    ap.add_argument("--size-override", action="store_true", help="with --scene-file: render at --width x --height instead of the file's film size")
+    ap.add_argument("--constant-env", help="with --scene-file: R,G,B of a constant environment emitter (STAND-IN lighting)")
     ap.add_argument("--room-boxes", type=int, default=1820, help="boxes of the room scene (768 triangles each)")
     ap.add_argument("--glossy", action="store_true", help="room scene with the S3 material mix (GGX alpha 0.1 metal, plastic) instead of Lambertian only")
     ap.add_argument("--cpu-passes", type=int, default=7, help="passes timed on the CPU baseline (bounded sample)")

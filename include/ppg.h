@@ -306,13 +306,56 @@ int ppg_image_buffers(ppg_ctx *ctx, void **dev_image /* float[h*w*3] */, void **
 int ppg_render_passes_nostat(ppg_ctx *ctx, int32_t n_passes); /* GP:1217-1286 only */
 int ppg_finish_passes(ppg_ctx *ctx, ppg_pass_stats *stats);   /* GP:1288-1328 only */
 
-/* Per-pass hook for multi-GPU learning of the BSDF sampling fraction: called after the records of a pass were
-   accumulated and before the per-pass Adam step, i.e. where the reference would have taken its
-   steps under the spin-lock (GP:672-697).  The hook all-reduces the buffers of ppg_adam_buffers (int64 / uint64
-   fixed-point sums, PPG_ADAM_BATCHES per S-tree node) so that every rank takes the identical step.  Return non-zero to abort. */
+/* ------------------------------------------------------------------------------------------------
+ * Learning the BSDF sampling fraction (bsdfSamplingFractionLoss = "kl" | "var"; AdamOptimizer GP:69-133,
+ * DTreeWrapper::optimizeBsdfSamplingFraction GP:672-697).
+ *
+ * The reference calls optimizeBsdfSamplingFraction() for every committed record under a per-D-tree spin-lock, in the order
+ * in which its worker threads happen to arrive: AdamOptimizer::append() accumulates gradient * weight and takes one step
+ * whenever the accumulated weight exceeds batchSize = 1 (GP:85-95), the gradient being evaluated at the variable's value at
+ * that moment.  That order is not reproducible (not even between two runs of the reference).  This build keeps the rule and
+ * fixes the order:
+ *   - the n passes of a ppg_render_passes() call (= the training passes of an iteration) are rendered in ROUNDS of
+ *     ppg_adam_round_passes(.., n) consecutive passes — at least two rounds per iteration from the second iteration on, so that
+ *     the fractions learned from the first half already steer the second (measured on cbox-improved: variance of iterations
+ *     2..6 within noise of the literal rule).  All paths of a round are sampled with the fractions in effect
+ *     at its start;
+ *   - at the end of the round every record that reached DTreeWrapper::record with product > 0 is applied to its D-tree with
+ *     exactly the reference's arithmetic (float, gradient at the current variable, append(), step()), D-tree by D-tree, in
+ *     ascending order of the 64-bit key
+ *         leaf << PPG_ADAM_LEAF_SHIFT | path << PPG_ADAM_CODE_BITS | code
+ *     leaf = S-tree node of the D-tree; path = (sample index within the round) * width * height + pixel index;
+ *     code = PPG_ADAM_CODE_VERTEX + i for path vertex i (Vertex::commit, GP:2150-2154), min(rRec.depth, PPG_ADAM_CODE_VERTEX - 1)
+ *     for the direct-light vertex of next-event estimation (GP:1994-2010).  Keys are unique, so the order is total: a valid
+ *     serialisation of the reference's critical sections that does not depend on wave scheduling, thread or GPU count.
+ * AdamOptimizer::State (incl. the partial batch) survives rounds, iterations and STree subdivision (GP:890) as in the reference.
+ * Limits: width * height * sppPerPass <= 2^PPG_ADAM_PATH_BITS and at most 2^24 S-tree nodes while a loss is set.
+ * ---------------------------------------------------------------------------------------------- */
+#define PPG_ADAM_ROUND_MAX_PASSES 16
+#define PPG_ADAM_ROUND_MAX_PATHS (1u << 24)
+#define PPG_ADAM_CODE_BITS 13
+#define PPG_ADAM_PATH_BITS 27
+#define PPG_ADAM_LEAF_SHIFT (PPG_ADAM_CODE_BITS + PPG_ADAM_PATH_BITS)
+#define PPG_ADAM_CODE_VERTEX 4096
+/* passes per round for a call that renders n_passes: the largest power of two <= min(PPG_ADAM_ROUND_MAX_PASSES, n_passes / 2)
+   whose paths (passes * sppPerPass * pixels of the whole image, not of a shard) stay within PPG_ADAM_ROUND_MAX_PATHS; at least 1 */
+int32_t ppg_adam_round_passes(int32_t spp_per_pass, int32_t width, int32_t height, int32_t n_passes);
+
+typedef struct ppg_adam_record { /* one deferred optimizeBsdfSamplingFraction() call: DTreeRecord's fields it reads (GP:562-568) */
+    uint64_t key;
+    float product, wo_pdf, bsdf_pdf, dtree_pdf, statistical_weight, _pad;
+} ppg_adam_record;             /* 32 bytes */
+
+/* Round hook for multi-GPU rendering: called at the end of every round after this rank's records were collected and before
+   they are applied.  The hook gathers the records of all ranks (ppg_adam_records → exchange → ppg_adam_records_replace) so that
+   every rank applies the identical sequence and the learned fractions stay bit-identical across ranks — and equal to a
+   single-GPU render, because the key order does not depend on the sharding.  Return non-zero to abort. */
 typedef int (*ppg_pass_hook)(void *user);
 int ppg_set_pass_hook(ppg_ctx *ctx, ppg_pass_hook hook, void *user);
-int ppg_adam_buffers(ppg_ctx *ctx, void **dev_grad, void **dev_weight, uint64_t *n);
+/* Valid inside the hook only.  dev_records: this rank's records (device memory, unspecified order). */
+int ppg_adam_records(ppg_ctx *ctx, void **dev_records /* ppg_adam_record[n] */, uint64_t *n);
+/* Valid inside the hook only: the records to apply instead (device pointer, copied). */
+int ppg_adam_records_replace(ppg_ctx *ctx, const void *dev_records, uint64_t n);
 
 /* Batched queries against the current *sampling* SD-tree (what Li does per vertex):
    pdf  = DTreeWrapper::pdf(dir) of the leaf containing p        (GP:623-625, 897-905)
@@ -326,7 +369,6 @@ typedef struct ppg_kernel_time { const char *name; double ms; uint64_t launches;
 int ppg_kernel_times(ppg_ctx *ctx, ppg_kernel_time *out, uint32_t cap, uint32_t *n);
 int ppg_enable_kernel_timing(ppg_ctx *ctx, int32_t enable);
 
-#define PPG_ADAM_BATCHES 64 /* mini-batches per D-tree and render pass of the deterministic Adam rule */
 #define PPG_FIXED_SHIFT 24 /* building sums / weights are accumulated as round(x * 2^24) in uint64 */
 
 #ifdef __cplusplus

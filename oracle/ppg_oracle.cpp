@@ -39,8 +39,9 @@
  *   - SD-tree statistics are accumulated in 2^-24 fixed point (order independent) when
  *     acc_mode = FIXED (default); acc_mode = FLOAT is the reference's sequential float adds
  *     (GP:59-62) and is what pin (1) exercises;
- *   - Adam: adam_mode = SEQUENTIAL is GP:672-697 literally (single thread); adam_mode = PER_PASS
- *     (default) takes one step per D-tree and render pass from exact fixed-point gradient sums.
+ *   - Adam: adam_mode = SEQUENTIAL is GP:672-697 literally (single thread, every record applied the moment its path
+ *     commits it); adam_mode = ROUND (default, the product's rule) applies the same calls with the same arithmetic at the end
+ *     of every round of render passes in a fixed key order (include/ppg.h "Learning the BSDF sampling fraction").
  */
 #include "../include/ppg.h"
 #include "../include/ppg_detmath.h"
@@ -151,9 +152,20 @@ enum EDirectionalFilter { EDNearest, EDBox };
 enum ELoss { ENone, EKL, EVariance };
 enum EBudget { ESpp, ESeconds };
 
+struct DTreeWrapper;
+// One call of optimizeBsdfSamplingFraction deferred to the end of the round (adam_mode = ROUND): its inputs and its place in
+// the canonical order (S-tree leaf, path of the round, record code) — see include/ppg.h "Learning the BSDF sampling fraction".
+struct AdamRecord {
+    DTreeWrapper *dTree;
+    uint32_t path, code;
+    float product, woPdf, bsdfPdf, dTreePdf, weight;
+};
 struct Modes {
     int acc = PPGO_ACC_FIXED;
-    int adam = PPGO_ADAM_PER_PASS;
+    int adam = PPGO_ADAM_ROUND;
+    // ROUND mode, per worker thread: where the records of the path being committed go, and that path's / vertex's identity
+    std::vector<AdamRecord> *sink = nullptr;
+    uint32_t path = 0, code = 0;
 };
 
 inline Float logistic(Float x) { return 1 / (1 + ppg_exp(-x)); }  // GP:64-66
@@ -193,25 +205,6 @@ public:
     }
 
     Float variable() const { return m_state.variable; }
-
-    // PER_PASS mode: exact integer sums of gradient*weight (2^-20) and weight (2^-24), see header.
-    // Records are dealt to PPG_ADAM_BATCHES mini-batches by a hash of (path key, vertex slot); at the end of a pass
-    // every mini-batch whose weight exceeds batchSize takes one step (in index order) with its mean gradient — all
-    // gradients of a pass are evaluated at the fraction the pass started with.  A mini-batch that is still too
-    // light keeps accumulating (like append(), GP:85-95, it never drops a record).
-    int64_t passGradient[PPG_ADAM_BATCHES] = {};
-    uint64_t passWeight[PPG_ADAM_BATCHES] = {};
-    void endPass() {
-        for (int k = 0; k < PPG_ADAM_BATCHES; ++k) {
-            if (passWeight[k] == 0) continue;
-            Float w = ppg_from_fixed(passWeight[k]);
-            if (w > (Float)m_hparams.batchSize) {
-                step(ppg_from_sfixed(passGradient[k]) / w);
-                passGradient[k] = 0;
-                passWeight[k] = 0;
-            }
-        }
-    }
 
 private:
     struct State {
@@ -520,7 +513,6 @@ struct DTreeRecord {
     Float woPdf, bsdfPdf, dTreePdf;
     Float statisticalWeight;
     bool isDelta;
-    int adamBatch = 0;  // mini-batch of the per-pass Adam rule (PER_PASS mode only)
 };
 
 struct DTreeWrapper {
@@ -576,23 +568,23 @@ public:
     Float bsdfSamplingFraction() const { return bsdfSamplingFraction(bsdfSamplingFractionOptimizer.variable()); }
 
     void optimizeBsdfSamplingFraction(const DTreeRecord &rec, Float ratioPower, const Modes &modes) {  // GP:672-697
+        if (modes.adam == PPGO_ADAM_ROUND) {  // deferred to the end of the round, applied in canonical order by applyAdamRound()
+            modes.sink->push_back(AdamRecord{this, modes.path, modes.code, rec.product, rec.woPdf, rec.bsdfPdf, rec.dTreePdf, rec.statisticalWeight});
+            return;
+        }
+        optimizeBsdfSamplingFraction(rec.product, rec.woPdf, rec.bsdfPdf, rec.dTreePdf, rec.statisticalWeight, ratioPower);
+    }
+    void optimizeBsdfSamplingFraction(Float product, Float woPdf, Float bsdfPdf, Float dTreePdf, Float statisticalWeight, Float ratioPower) {
         Float variable = bsdfSamplingFractionOptimizer.variable();
         Float samplingFraction = bsdfSamplingFraction(variable);
-        Float mixPdf = samplingFraction * rec.bsdfPdf + (1 - samplingFraction) * rec.dTreePdf;
-        Float r = rec.product / mixPdf;
+        Float mixPdf = samplingFraction * bsdfPdf + (1 - samplingFraction) * dTreePdf;
+        Float r = product / mixPdf;
         Float ratio = ratioPower == 1.0f ? r : r * r;  // std::pow(x, 1 | 2)
-        Float dLoss_dSamplingFraction = -ratio / rec.woPdf * (rec.bsdfPdf - rec.dTreePdf);
+        Float dLoss_dSamplingFraction = -ratio / woPdf * (bsdfPdf - dTreePdf);
         Float dLoss_dVariable = dLoss_dSamplingFraction * dBsdfSamplingFraction_dVariable(variable);
         Float l2RegGradient = 0.01f * variable;
         Float lossGradient = l2RegGradient + dLoss_dVariable;
-        if (modes.adam == PPGO_ADAM_SEQUENTIAL) {
-            bsdfSamplingFractionOptimizer.append(lossGradient, rec.statisticalWeight);
-        } else {
-            __atomic_fetch_add(&bsdfSamplingFractionOptimizer.passGradient[rec.adamBatch],
-                               ppg_to_sfixed(lossGradient * rec.statisticalWeight), __ATOMIC_RELAXED);
-            __atomic_fetch_add(&bsdfSamplingFractionOptimizer.passWeight[rec.adamBatch], ppg_to_fixed(rec.statisticalWeight),
-                               __ATOMIC_RELAXED);
-        }
+        bsdfSamplingFractionOptimizer.append(lossGradient, statisticalWeight);
     }
 
     void dump(FILE *f, const Point &p, const Vec &size) const {  // GP:699-711
@@ -671,7 +663,7 @@ struct STreeNode {
         if (w > 0) {
             if (isLeaf) {
                 dTree.record({rec.d, rec.radiance, rec.product, rec.woPdf, rec.bsdfPdf, rec.dTreePdf,
-                              rec.statisticalWeight * w, rec.isDelta, rec.adamBatch},
+                              rec.statisticalWeight * w, rec.isDelta},
                              directionalFilter, loss, modes);
             } else {
                 size2[axis] /= 2;
@@ -2318,6 +2310,7 @@ public:
     int m_passesLocal = 0;
     PathCounters m_counters;
     uint64_t m_work[CNT_N] = {};
+    uint64_t m_lenHist[PPGO_LEN_HIST] = {};  // paths by final rRec.depth (last bin: that or longer) — sizes the GPU's tail phase
     volatile bool cancelled = false;
     ppg_pass_hook passHook = nullptr;
     void *passHookUser = nullptr;
@@ -2337,11 +2330,7 @@ public:
         // std::pow(2, m_iter) is a double power; the whole expression is double, then truncated to size_t
         double thr = std::sqrt(std::ldexp(1.0, m_iter) * m_sppPerPass / 4) * m_sTreeThreshold;
         m_sdTree->refine((size_t)thr, m_sdTreeMaxMemory);
-        m_sdTree->forEachDTreeWrapper([this](DTreeWrapper *dTree) {
-            dTree->reset(20, m_dTreeThreshold);
-            // PER_PASS Adam: mini-batches that stayed below batchSize are dropped at the iteration boundary
-            for (int k = 0; k < PPG_ADAM_BATCHES; ++k) { dTree->bsdfSamplingFractionOptimizer.passGradient[k] = 0; dTree->bsdfSamplingFractionOptimizer.passWeight[k] = 0; }
-        });
+        m_sdTree->forEachDTreeWrapper([this](DTreeWrapper *dTree) { dTree->reset(20, m_dTreeThreshold); });
     }
 
     void buildSDTree(ppg_tree_stats *st) {  // GP:1115-1189
@@ -2410,12 +2399,60 @@ public:
         m_passStart = std::chrono::steady_clock::now();
         m_passesLocal = 0;
         m_counters = PathCounters();
-        for (int i = 0; i < numPasses; ++i) {
+        // ROUND mode: the passes are rendered in rounds of ppg_adam_round_passes() passes; the sampling fractions are frozen during
+        // a round and its records are applied afterwards (applyAdamRound).  The time budget is checked once per round then
+        // (the reference checks after every finished pass of a batch of up to 128 scheduled ones, GP:1235-1266).
+        const bool rounds = m_bsdfSamplingFractionLoss != ENone && modes.adam == PPGO_ADAM_ROUND && m_isBuilt && !m_isFinalIter;
+        const int roundPasses = rounds ? adamRoundPasses(numPasses) : 1;
+        for (int i = 0; i < numPasses;) {
             if (cancelled) break;
-            renderOnePass();
-            ++m_passesRendered; ++m_passesRenderedThisIter; ++m_passesLocal;
+            const int n = std::min(roundPasses, numPasses - i);
+            m_roundStartPass = m_passesRendered;
+            for (int k = 0; k < n; ++k) {
+                renderOnePass();
+                ++m_passesRendered; ++m_passesRenderedThisIter; ++m_passesLocal;
+            }
+            i += n;
+            if (rounds) applyAdamRound();
             if (m_budgetType == ESeconds && (int)computeElapsedSeconds(m_startTime) > m_budget) break;  // GP:1259-1262: whole seconds
         }
+    }
+
+    // passes per round (include/ppg.h, ppg_adam_round_passes): doubled while it stays within 16 passes, half the call's passes and
+    // 2^24 paths of the whole image
+    int adamRoundPasses(int numPasses) const {
+        const uint64_t perPass = (uint64_t)m_sppPerPass * (uint64_t)W() * (uint64_t)H();
+        int r = 1;
+        for (;;) {
+            const int next = 2 * r;
+            if (next > PPG_ADAM_ROUND_MAX_PASSES || 2 * next > numPasses || (uint64_t)next * perPass > PPG_ADAM_ROUND_MAX_PATHS) break;
+            r = next;
+        }
+        return r;
+    }
+
+    // ---- the deferred Adam steps of one round (adam_mode = ROUND; include/ppg.h "Learning the BSDF sampling fraction") ----
+    int m_roundStartPass = 0;
+    std::vector<std::vector<AdamRecord>> m_blockSinks;  // one per image block: filled by whichever thread renders the block
+    struct PackedAdamRecord { uint64_t key; float product, woPdf, bsdfPdf, dTreePdf, weight, pad; };  // = ppg_adam_record
+    std::vector<PackedAdamRecord> m_adamRecords;
+    void applyAdamRound() {
+        auto &nodes = m_sdTree->nodes();
+        m_adamRecords.clear();
+        for (auto &sink : m_blockSinks) {
+            for (const AdamRecord &r : sink) {
+                const uint64_t leaf = (uint64_t)(((const char *)r.dTree - (const char *)&nodes[0].dTree) / sizeof(STreeNode));
+                m_adamRecords.push_back(PackedAdamRecord{(leaf << PPG_ADAM_LEAF_SHIFT) | ((uint64_t)r.path << PPG_ADAM_CODE_BITS) | r.code,
+                                                         r.product, r.woPdf, r.bsdfPdf, r.dTreePdf, r.weight, 0.0f});
+            }
+            sink.clear();
+        }
+        if (passHook) passHook(passHookUser);  // sharded rendering: the driver replaces the records by the union over all ranks
+        std::sort(m_adamRecords.begin(), m_adamRecords.end(), [](const PackedAdamRecord &a, const PackedAdamRecord &b) { return a.key < b.key; });
+        const Float ratioPower = m_bsdfSamplingFractionLoss == EKL ? 1.0f : 2.0f;
+        for (const PackedAdamRecord &r : m_adamRecords)
+            nodes[(size_t)(r.key >> PPG_ADAM_LEAF_SHIFT)].dTree.optimizeBsdfSamplingFraction(r.product, r.woPdf, r.bsdfPdf, r.dTreePdf, r.weight, ratioPower);
+        m_adamRecords.clear();
     }
 
     void finishPasses(ppg_pass_stats *st) {  // GP:1288-1328
@@ -2467,12 +2504,16 @@ public:
         const int bs = 32;  // scene->getBlockSize()
         const int bx = (w + bs - 1) / bs, by = (h + bs - 1) / bs;
         const uint32_t passIndex = (uint32_t)m_passesRendered;
+        const uint32_t sampleInRound0 = (uint32_t)(m_passesRendered - m_roundStartPass) * (uint32_t)m_sppPerPass;
+        if (m_blockSinks.size() != (size_t)bx * by) m_blockSinks.assign((size_t)bx * by, std::vector<AdamRecord>());
         uint64_t rays = 0, plen = 0, comm = 0;
 #ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads) reduction(+ : rays, plen, comm)
 #endif
         for (int b = 0; b < bx * by; ++b) {
             PathCounters pc;
+            Modes tm = modes;
+            tm.sink = &m_blockSinks[b];
             uint64_t cnt0[CNT_N];
             memcpy(cnt0, t_cnt, sizeof cnt0);
             int x0 = (b % bx) * bs, y0 = (b / bx) * bs;
@@ -2486,7 +2527,8 @@ public:
                         Point2 samplePos{(Float)x + s2.x, (Float)y + s2.y};  // GP:1620
                         Point o; Vec d; Float mint, maxt;
                         sampleRay(samplePos, o, d, mint, maxt);
-                        Spectrum spec = Li(o, d, mint, maxt, sampler, pc);  // GP:1632 (sensor weight is 1)
+                        tm.path = (sampleInRound0 + (uint32_t)j) * (uint32_t)(w * h) + pixel;
+                        Spectrum spec = Li(o, d, mint, maxt, sampler, pc, tm);  // GP:1632 (sensor weight is 1)
                         // block->put / squaredBlock->put with the box filter: own pixel, weight 1 (SURVEY App. A "Film")
                         for (int c = 0; c < 3; ++c) {
                             m_image[3 * pixel + c] += spec[c];
@@ -2501,16 +2543,6 @@ public:
             for (int k = 0; k < CNT_N; ++k) __atomic_fetch_add(&m_work[k], t_cnt[k] - cnt0[k], __ATOMIC_RELAXED);
         }
         m_counters.rays += rays; m_counters.pathLen += plen; m_counters.committed += comm;
-        if (m_bsdfSamplingFractionLoss != ENone && modes.adam == PPGO_ADAM_PER_PASS && m_isBuilt && !m_isFinalIter) {
-            if (passHook) passHook(passHookUser);  // sharded rendering: the driver all-reduces the per-pass sums here
-            m_sdTree->forEachDTreeWrapper([](DTreeWrapper *d) { d->bsdfSamplingFractionOptimizer.endPass(); });
-            // sharded: the hook summed the mini-batch sums over all ranks; what is carried to the next pass must
-            // exist once, so only rank 0 keeps it
-            if (shardWorld > 1 && shardRank != 0)
-                m_sdTree->forEachDTreeWrapper([](DTreeWrapper *d) {
-                    for (int k = 0; k < PPG_ADAM_BATCHES; ++k) { d->bsdfSamplingFractionOptimizer.passGradient[k] = 0; d->bsdfSamplingFractionOptimizer.passWeight[k] = 0; }
-                });
-        }
     }
 
     // PerspectiveCamera::sampleRayDifferential perspective.cpp:271-298
@@ -2596,15 +2628,15 @@ public:
         void record(const Spectrum &r) { radiance = radiance + r; }
 
         bool commit(STree &sdTree, Float statisticalWeight, ESpatialFilter spatialFilter, EDirectionalFilter directionalFilter,
-                    ELoss loss, Sampler *sampler, const Modes &modes, int slot) {
+                    ELoss loss, Sampler *sampler, Modes &modes, uint32_t code) {
             if (!(woPdf > 0) || !isValid(radiance) || !isValid(bsdfVal)) return false;
             Spectrum localRadiance(0.0f);
             if (throughput[0] * woPdf > PPG_EPSILON) localRadiance[0] = radiance[0] / throughput[0];
             if (throughput[1] * woPdf > PPG_EPSILON) localRadiance[1] = radiance[1] / throughput[1];
             if (throughput[2] * woPdf > PPG_EPSILON) localRadiance[2] = radiance[2] / throughput[2];
             Spectrum product = mul(localRadiance, bsdfVal);
-            DTreeRecord rec{rayD, average(localRadiance), average(product), woPdf, bsdfPdf, dTreePdf, statisticalWeight, isDelta,
-                            (int)(ppg_hash32(sampler->key ^ (0x9e3779b9u * (uint32_t)(slot + 1))) & (PPG_ADAM_BATCHES - 1))};
+            DTreeRecord rec{rayD, average(localRadiance), average(product), woPdf, bsdfPdf, dTreePdf, statisticalWeight, isDelta};
+            modes.code = code;  // place of this vertex's records in the round's canonical order
             switch (spatialFilter) {
                 case ESNearest:
                     dTree->record(rec, directionalFilter, loss, modes);
@@ -2628,7 +2660,7 @@ public:
     };
 
     // Li GP:1712-2157, surface branch
-    Spectrum Li(Point o, Vec d, Float rayMint, Float rayMaxt, Sampler &sampler, PathCounters &pc) {
+    Spectrum Li(Point o, Vec d, Float rayMint, Float rayMaxt, Sampler &sampler, PathCounters &pc, Modes &modes) {
         static const int MAX_NUM_VERTICES = 32;
         std::array<Vertex, MAX_NUM_VERTICES> vertices;
         Intersection its;
@@ -2700,7 +2732,7 @@ public:
                                          dRec.pdf, bsdfPdfE, dTreePdfE, false};
                                 Sampler cs{sampler.key, PPG_DIM_NEE_COMMIT + 3u * (uint32_t)depth};  // sampler contract, ppg_rng.h
                                 if (v.commit(*m_sdTree, 0.5f, m_spatialFilter, m_directionalFilter,
-                                             m_isBuilt ? m_bsdfSamplingFractionLoss : ENone, &cs, modes, (int)PPG_SLOT_NEE + depth))
+                                             m_isBuilt ? m_bsdfSamplingFractionLoss : ENone, &cs, modes, (uint32_t)std::min(depth, PPG_ADAM_CODE_VERTEX - 1)))
                                     pc.committed++;
                             }
                         }
@@ -2797,13 +2829,14 @@ public:
             scattered = true;
         }
         pc.pathLen += (uint64_t)depth;  // avgPathLength += rRec.depth, GP:2147-2148
+        __atomic_fetch_add(&m_lenHist[std::min(depth, (int)PPGO_LEN_HIST - 1)], (uint64_t)1, __ATOMIC_RELAXED);
 
         if (nVertices > 0 && !m_isFinalIter) {  // GP:2150-2154
             const uint32_t dimEnd = sampler.dim;
             for (int i = 0; i < nVertices; ++i) {
                 sampler.dim = dimEnd + 3u * (uint32_t)i;  // sampler contract: the commit draws of vertex i (ppg_rng.h)
                 bool ok = vertices[i].commit(*m_sdTree, m_nee == EKickstart && m_doNee ? 0.5f : 1.0f, m_spatialFilter,
-                                             m_directionalFilter, m_isBuilt ? m_bsdfSamplingFractionLoss : ENone, &sampler, modes, i);
+                                             m_directionalFilter, m_isBuilt ? m_bsdfSamplingFractionLoss : ENone, &sampler, modes, (uint32_t)(PPG_ADAM_CODE_VERTEX + i));
                 if (ok) pc.committed++;
             }
         }
@@ -3211,27 +3244,16 @@ int ppgo_stat_import(ppgo_ctx *ctx, const uint64_t *sums, uint64_t n_sums, const
     return PPG_OK;
 }
 int ppgo_work_counters(ppgo_ctx *ctx, uint64_t *out8) { memcpy(out8, ctx->gpt.m_work, sizeof ctx->gpt.m_work); return PPG_OK; }
+int ppgo_path_length_histogram(ppgo_ctx *ctx, uint64_t *out) { memcpy(out, ctx->gpt.m_lenHist, sizeof ctx->gpt.m_lenHist); return PPG_OK; }
 int ppgo_set_pass_hook(ppgo_ctx *ctx, ppg_pass_hook hook, void *user) { ctx->gpt.passHook = hook; ctx->gpt.passHookUser = user; return PPG_OK; }
-int ppgo_adam_export(ppgo_ctx *ctx, int64_t *grad, uint64_t *weight, uint64_t n) {
-    NEED_TREE
-    auto &nodes = ctx->gpt.m_sdTree->nodes();
-    if (n != nodes.size() * PPG_ADAM_BATCHES) return PPG_ERR_INVALID;
-    for (size_t i = 0; i < nodes.size(); ++i)
-        for (int k = 0; k < PPG_ADAM_BATCHES; ++k) {
-            grad[i * PPG_ADAM_BATCHES + k] = nodes[i].dTree.bsdfSamplingFractionOptimizer.passGradient[k];
-            weight[i * PPG_ADAM_BATCHES + k] = nodes[i].dTree.bsdfSamplingFractionOptimizer.passWeight[k];
-        }
+int ppgo_adam_records(ppgo_ctx *ctx, void **records, uint64_t *n) {
+    *records = ctx->gpt.m_adamRecords.data(); *n = ctx->gpt.m_adamRecords.size();
     return PPG_OK;
 }
-int ppgo_adam_import(ppgo_ctx *ctx, const int64_t *grad, const uint64_t *weight, uint64_t n) {
-    NEED_TREE
-    auto &nodes = ctx->gpt.m_sdTree->nodes();
-    if (n != nodes.size() * PPG_ADAM_BATCHES) return PPG_ERR_INVALID;
-    for (size_t i = 0; i < nodes.size(); ++i)
-        for (int k = 0; k < PPG_ADAM_BATCHES; ++k) {
-            nodes[i].dTree.bsdfSamplingFractionOptimizer.passGradient[k] = grad[i * PPG_ADAM_BATCHES + k];
-            nodes[i].dTree.bsdfSamplingFractionOptimizer.passWeight[k] = weight[i * PPG_ADAM_BATCHES + k];
-        }
+int ppgo_adam_records_replace(ppgo_ctx *ctx, const void *records, uint64_t n) {
+    const auto *r = (const GuidedPathTracer::PackedAdamRecord *)records;
+    std::vector<GuidedPathTracer::PackedAdamRecord> v(r, r + n);  // `records` may alias the current array
+    ctx->gpt.m_adamRecords.swap(v);
     return PPG_OK;
 }
 int ppgo_film_ptrs(ppgo_ctx *ctx, float **rgb_sum, float **weight) {
@@ -3287,7 +3309,7 @@ int ppgo_ka_refine(float Wt, uint64_t thr, uint32_t *n_leaves, uint32_t *n_nodes
 int ppgo_ka_adam(int32_t n, float product, float wo_pdf, float bsdf_pdf, float dtree_pdf, float weight, int32_t loss, float *fraction) {
     DTreeWrapper w;
     Modes m; m.acc = PPGO_ACC_FLOAT; m.adam = PPGO_ADAM_SEQUENTIAL;
-    DTreeRecord rec{Vec(0, 0, 1), 1.0f, product, wo_pdf, bsdf_pdf, dtree_pdf, weight, true /* isDelta: only the Adam half */, 0};
+    DTreeRecord rec{Vec(0, 0, 1), 1.0f, product, wo_pdf, bsdf_pdf, dtree_pdf, weight, true /* isDelta: only the Adam half */};
     for (int i = 0; i < n; ++i) w.record(rec, EDNearest, loss == 1 ? EKL : EVariance, m);
     *fraction = w.bsdfSamplingFraction();
     return PPG_OK;

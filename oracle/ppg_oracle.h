@@ -17,7 +17,9 @@ extern "C" {
 typedef struct ppgo_ctx ppgo_ctx;
 
 enum { PPGO_ACC_FIXED = 0, PPGO_ACC_FLOAT = 1 };
-enum { PPGO_ADAM_PER_PASS = 0, PPGO_ADAM_SEQUENTIAL = 1 };
+/* ROUND: the product's rule (include/ppg.h "Learning the BSDF sampling fraction": records applied at the end of every round in
+   key order).  SEQUENTIAL: GP:672-697 literally — every record is applied the moment its path commits it (single thread). */
+enum { PPGO_ADAM_ROUND = 0, PPGO_ADAM_SEQUENTIAL = 1 };
 
 int ppgo_create(const ppg_config *cfg, ppgo_ctx **out);
 void ppgo_destroy(ppgo_ctx *ctx);
@@ -58,9 +60,13 @@ int ppgo_stat_import(ppgo_ctx *ctx, const uint64_t *sums, uint64_t n_sums, const
 int ppgo_stat_sizes(ppgo_ctx *ctx, uint64_t *n_sums, uint64_t *n_weights);
 /* levels visited since create: {S-tree levels, lookups, D-tree sample levels, calls, pdf levels, calls, record levels, calls} */
 int ppgo_work_counters(ppgo_ctx *ctx, uint64_t *out8);
+/* number of paths by final depth since create, PPGO_LEN_HIST bins (the last one collects everything longer) */
+#define PPGO_LEN_HIST 4096
+int ppgo_path_length_histogram(ppgo_ctx *ctx, uint64_t *out);
 int ppgo_set_pass_hook(ppgo_ctx *ctx, ppg_pass_hook hook, void *user);
-int ppgo_adam_export(ppgo_ctx *ctx, int64_t *grad, uint64_t *weight, uint64_t n);
-int ppgo_adam_import(ppgo_ctx *ctx, const int64_t *grad, const uint64_t *weight, uint64_t n);
+/* host-memory counterparts of ppg_adam_records / ppg_adam_records_replace (valid inside the round hook) */
+int ppgo_adam_records(ppgo_ctx *ctx, void **records, uint64_t *n);
+int ppgo_adam_records_replace(ppgo_ctx *ctx, const void *records, uint64_t n);
 int ppgo_film_ptrs(ppgo_ctx *ctx, float **rgb_sum, float **weight);
 int ppgo_image_ptrs(ppgo_ctx *ctx, float **image, float **sq_image);
 int ppgo_image_weight_ptr(ppgo_ctx *ctx, float **w);

@@ -1366,7 +1366,14 @@ struct __attribute__((aligned(16))) LeafHdr {  // one per S-tree node, 64 B
     int adam_iter;
     float adam_m, adam_v;
     float b_statw;               // statisticalWeightBuilding() as float (valid after build; halved by refine)
-    unsigned int pad[3];
+    float adam_bg, adam_ba;      // AdamOptimizer::State::batchGradient / batchAccumulation (GP:121-122): the partial batch of append()
+    unsigned int pad;
+};
+
+// One deferred DTreeWrapper::optimizeBsdfSamplingFraction call (= ppg_adam_record of include/ppg.h)
+struct __attribute__((aligned(16))) AdamRec {
+    unsigned long long key;  // leaf << PPG_ADAM_LEAF_SHIFT | path << PPG_ADAM_CODE_BITS | code
+    float product, woPdf, bsdfPdf, dTreePdf, weight, pad;
 };
 
 struct DevTree {
@@ -1376,8 +1383,15 @@ struct DevTree {
     const ushort4 *bchild;        // building pool topology
     unsigned long long *bacc;     // building pool accumulators [node*4 + slot], 2^-24 fixed point
     unsigned long long *bweight;  // per S-tree node: building statistical weight accumulator (folded, see *_rep)
-    long long *adam_grad;         // [node * PPG_ADAM_BATCHES + k]: Σ gradient·weight of mini-batch k (2^-20)
-    unsigned long long *adam_w;   // [node * PPG_ADAM_BATCHES + k]: Σ weight (2^-24)
+    // Records of the round for the sampling-fraction optimiser (include/ppg.h "Learning the BSDF sampling fraction"): written at
+    // position adam_base[path] + vertex when adam_base != nullptr (every record's place is known in advance: nearest / stochastic
+    // spatial filter without next-event estimation — the buffer is then already ordered by (path, code) and only a stable sort
+    // by leaf remains), otherwise appended through adam_count[0] (adam_count[1] = overflow flag) and sorted by the whole key.
+    unsigned long long *adam_keys;
+    AdamRec *adam_recs;
+    unsigned int *adam_count;
+    const unsigned int *adam_base;
+    unsigned int adam_cap;
     // Replicated accumulation targets [node * PPG_REPLICAS + r]: a popular S-tree leaf receives several percent of all
     // records of a pass and one address sustains only ~90 atomics/µs; workgroups spread over the replicas,
     // k_fold_replicas adds them into the compact arrays above (integer sums: exact).

@@ -9,6 +9,10 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <cstring>  // rocprim's texture iterator calls memset from host code
+
+#include <rocprim/rocprim.hpp>
+
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -305,8 +309,29 @@ struct ppg_ctx {
     int cur = 0;  // d_snodes[cur] = sampling pool
     size_t nSamplingNodes = 0, nBuildingNodes = 0;
     DevBuf<ushort4> d_bchild;
-    DevBuf<unsigned long long> d_bacc, d_bweight, d_adamW, d_total, d_bweightRep;
-    DevBuf<long long> d_adamGrad;
+    DevBuf<unsigned long long> d_bacc, d_bweight, d_total, d_bweightRep;
+    // sampling-fraction optimiser: the records of the current round (include/ppg.h "Learning the BSDF sampling fraction")
+    DevBuf<unsigned long long> d_adamKeys[2];
+    DevBuf<unsigned int> d_adamIdx[2], d_adamNv, d_adamBase, d_adamCount;
+    DevBuf<AdamRec> d_adamRecs, d_adamRecsOut;
+    DevBuf<unsigned char> d_sortTemp;
+    size_t adamIota = 0;          // d_adamIdx[0][0 .. adamIota) holds the identity permutation
+    bool adamFast = false;        // record positions known in advance (DevTree::adam_base)
+    bool adamActive = false;      // a round of the optimiser is being rendered
+    bool inHook = false, hookReplaced = false;
+    uint64_t hookCount = 0;
+    // unbounded paths: live paths after each bulk bounce of the last batch → how many bulk bounces the next batch runs before k_tail
+    DevBuf<unsigned int> d_bounceCounts, d_ticket;
+    unsigned int *h_round = nullptr;  // pinned: [0..63] bounce counts, [64] Adam record count / overflow, [65] Σ nV
+    int bulkBounces = 8;
+    // Tuning switches, read ONCE from the environment by ppg_create (DESIGN.md "Tuning switches"); none of them changes a result.
+    unsigned int tailThreshold = 0;   // PPG_TAIL_THRESHOLD: live paths below which k_tail takes over (0 = automatic)
+    size_t tuneBatchPaths = 0;        // PPG_BATCH_PATHS: paths in flight per batch of passes (0 = automatic)
+    int tuneBlocks = 0;               // PPG_BLOCKS: persistent workgroups of the path kernels (0 = 2048)
+    bool tuneForceBvh = false;        // PPG_FORCE_BVH: trace small scenes through the BVH as well
+    bool tuneFuse = false;            // PPG_FUSE: trace small scenes inside k_generate / k_shade
+    int tuneBvhLeaf = 4;              // PPG_BVH_LEAF: triangles per BVH leaf (1..8)
+    float tuneBvhPad = 2e-6f;         // PPG_BVH_PAD: box padding relative to the scene extent
     DevBuf<unsigned int> d_leaves, d_counts, d_offsets, d_grid;
     DevBuf<unsigned int> d_dfs[2], d_refEv, d_refLv, d_refEvOff, d_refLvOff;  // S-tree refine: leaves in the reference's (right-first) visiting order
     int dfsCur = 0;
@@ -320,15 +345,17 @@ struct ppg_ctx {
     float lastVariance = 0;
     ppg_pass_stats lastStats{};
     KernelTimer timer;
-    std::vector<unsigned int> tailCounts;
     ppg_pass_hook passHook = nullptr;
     void *passHookUser = nullptr;
 
     DevTree devTree() {
         DevTree T{};
         T.stree = d_stree.p; T.hdr = d_hdr.p; T.snodes = d_snodes[cur].p; T.bchild = d_bchild.p; T.bacc = d_bacc.p;
-        T.bweight = d_bweight.p; T.adam_grad = d_adamGrad.p; T.adam_w = d_adamW.p;
+        T.bweight = d_bweight.p;
         T.bweight_rep = d_bweightRep.p;
+        T.adam_keys = adamActive ? d_adamKeys[0].p : nullptr; T.adam_recs = adamActive ? d_adamRecs.p : nullptr;
+        T.adam_count = d_adamCount.p; T.adam_base = (adamActive && adamFast) ? d_adamBase.p : nullptr;
+        T.adam_cap = adamActive ? (unsigned int)std::min<size_t>(d_adamRecs.cap, 0xfffffff0u) : 0u;
         for (int a = 0; a < 3; ++a) { T.aabb_min[a] = treeMin[a]; T.aabb_ext[a] = treeExt[a]; T.aabb_max[a] = treeMax[a]; }
         T.is_built = isBuilt ? 1 : 0;
         T.grid = d_grid.p;
@@ -340,7 +367,7 @@ struct ppg_ctx {
         R.bsdf_sampling_fraction = bsdfSamplingFraction; R.rr_depth = rrDepth; R.max_depth = maxDepth;
         R.strict_normals = strictNormals; R.hide_emitters = hideEmitters; R.spp = sppPerPass;
         R.is_final_iter = isFinalIter; R.do_nee = doNee; R.seed = seed; R.pass_index = (unsigned int)passesRendered;
-        R.max_vertices = maxVertices;
+        R.max_vertices = maxVertices; R.img_pixels = (unsigned int)W * (unsigned int)H;
         return R;
     }
 };
@@ -386,13 +413,6 @@ int uploadTree(ppg_ctx *ctx, bool nodes) {
     HIP_CHECK(hipMemcpyAsync(ctx->d_leaves.p, ctx->leaves.data(), ctx->leaves.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     HIP_CHECK(ctx->d_bweight.reserve(n));
     HIP_CHECK(hipMemsetAsync(ctx->d_bweight.p, 0, n * 8, ctx->stream));
-    {   // Adam mini-batch sums; what stayed below batchSize is dropped at the iteration boundary
-        const size_t na = ctx->loss != LOSS_NONE ? n * PPG_ADAM_BATCHES : 1;
-        HIP_CHECK(ctx->d_adamW.reserve(na));
-        HIP_CHECK(ctx->d_adamGrad.reserve(na));
-        HIP_CHECK(hipMemsetAsync(ctx->d_adamW.p, 0, na * 8, ctx->stream));
-        HIP_CHECK(hipMemsetAsync(ctx->d_adamGrad.p, 0, na * 8, ctx->stream));
-    }
     HIP_CHECK(ctx->d_bweightRep.reserve(n * PPG_REPLICAS));
     HIP_CHECK(hipMemsetAsync(ctx->d_bweightRep.p, 0, n * PPG_REPLICAS * 8, ctx->stream));
     if (n >= (1u << 27)) { ctx->error = "S-tree exceeds 2^27 nodes"; return PPG_ERR_NOMEM; }
@@ -553,8 +573,10 @@ int allocPaths(ppg_ctx *ctx) {
     // Pass batching: the passes of an iteration are independent (frozen sampling tree, accumulate-only building
     // tree), so up to maxBatch of them run as ONE set of launches over nPix * spp * batch paths.  Sample indices,
     // per-pixel accumulation order and all integer statistics are unchanged, i.e. results are bit-identical; what
-    // changes is that small images / tile shards (multi-GPU strong scaling) still fill the GPU.  Not used when the
-    // BSDF sampling fraction is learned (one Adam step per pass) or with a time budget (checked after every pass).
+    // changes is that small images / tile shards (multi-GPU strong scaling) still fill the GPU and that the serial
+    // tail of unbounded paths is paid once per batch.  When the BSDF sampling fraction is learned, a batch is one
+    // ROUND of the optimiser (include/ppg.h: ppg_adam_round_passes — part of the algorithm, not a tuning knob).
+    // With a time budget and no rounds the clock is checked after every pass, as in the reference (GP:1259-1262).
     {
         const size_t perPass = std::max<size_t>(1, (size_t)ctx->nPix * ctx->sppPerPass);
         size_t target = 16u << 20;  // ~16 M paths in flight (measured on cbox-720p: 4 M 996, 8 M 1007, 16 M 1034, 32 M 1041 Msamples/s)
@@ -564,8 +586,12 @@ int allocPaths(ppg_ctx *ctx) {
             const size_t perPath = (size_t)slots * (ctx->spatialFilter != SF_NEAREST ? 96 : 64) + 96;
             target = std::min<size_t>(target, (size_t)24e9 / perPath);
         }
-        if (const char *e = getenv("PPG_BATCH_PATHS")) target = (size_t)std::max(1ll, atoll(e));
-        ctx->maxBatch = (ctx->loss != LOSS_NONE || ctx->budgetType == 1) ? 1 : (int)std::max<size_t>(1, std::min<size_t>(64, target / perPass));
+        if (ctx->tuneBatchPaths) target = ctx->tuneBatchPaths;
+        ctx->maxBatch = ctx->budgetType == 1 ? 1 : (int)std::max<size_t>(1, std::min<size_t>(64, target / perPass));
+        if (ctx->loss != LOSS_NONE) {
+            if ((uint64_t)ctx->W * ctx->H * ctx->sppPerPass > (1ull << PPG_ADAM_PATH_BITS)) { ctx->error = "width * height * sppPerPass exceeds 2^27 with a bsdfSamplingFractionLoss"; return PPG_ERR_INVALID; }
+            ctx->maxBatch = std::max(ctx->maxBatch, (int)ppg_adam_round_passes(ctx->sppPerPass, ctx->W, ctx->H, 1 << 30));
+        }
     }
     size_t n = (size_t)ctx->nPix * ctx->sppPerPass * (size_t)ctx->maxBatch;
     if (n > 0xfffffff0ull) { ctx->error = "too many paths per pass"; return PPG_ERR_INVALID; }
@@ -574,12 +600,15 @@ int allocPaths(ppg_ctx *ctx) {
     if (ctx->maxDepth > 0) ctx->maxVertices = std::max(1, std::min(PPG_MAX_VERTICES, ctx->maxDepth - 1));
     HIP_CHECK(ctx->d_ray_o.reserve(nn)); HIP_CHECK(ctx->d_ray_d.reserve(nn)); HIP_CHECK(ctx->d_thr.reserve(nn));
     HIP_CHECK(ctx->d_li.reserve(nn)); HIP_CHECK(ctx->d_hit.reserve(nn)); HIP_CHECK(ctx->d_misc.reserve(nn));
-    if (const char *nbEnv = getenv("PPG_BLOCKS")) ctx->nBlocks = std::max(1, atoi(nbEnv));
+    if (ctx->tuneBlocks) ctx->nBlocks = ctx->tuneBlocks;
     const size_t nb = (size_t)ctx->nBlocks;
     const size_t chunks = (nn + PPG_CHUNK - 1) / PPG_CHUNK;
     const size_t cap = ((chunks + nb - 1) / nb) * PPG_CHUNK;
     for (int k = 0; k < 2; ++k) { HIP_CHECK(ctx->d_queue[k].reserve(cap * nb)); HIP_CHECK(ctx->d_qcount[k].reserve(nb)); }
     HIP_CHECK(ctx->d_stats.reserve(nb)); HIP_CHECK(ctx->d_qtotal.reserve(1));
+    HIP_CHECK(ctx->d_bounceCounts.reserve(64)); HIP_CHECK(ctx->d_ticket.reserve(1)); HIP_CHECK(ctx->d_total.reserve(2)); HIP_CHECK(ctx->d_offsets.reserve(nb));
+    HIP_CHECK(ctx->d_adamCount.reserve(2));
+    if (!ctx->h_round) HIP_CHECK(hipHostMalloc((void **)&ctx->h_round, 68 * sizeof(unsigned int), hipHostMallocDefault));
     ctx->queues.items[0] = ctx->d_queue[0].p; ctx->queues.items[1] = ctx->d_queue[1].p;
     ctx->queues.count[0] = ctx->d_qcount[0].p; ctx->queues.count[1] = ctx->d_qcount[1].p;
     ctx->queues.cap = (unsigned int)cap; ctx->queues.stats = ctx->d_stats.p; ctx->queues.n_blocks = (unsigned int)nb;
@@ -597,11 +626,84 @@ int allocPaths(ppg_ctx *ctx) {
     return PPG_OK;
 }
 
-// `batch` BlockedRenderProcesses (GP:1087-1106 / renderBlock GP:1587-1641) over all owned pixels in one set of launches
-int renderBatch(ppg_ctx *ctx, int batch) {
+// stable LSD radix sort of the round's (key, record index) pairs on bits [beginBit, endBit); result in d_adamKeys[1] / d_adamIdx[1]
+int sortAdamRecords(ppg_ctx *ctx, size_t n, unsigned int beginBit, unsigned int endBit) {
+    hipStream_t s = ctx->stream;
+    HIP_CHECK(ctx->d_adamKeys[1].reserve(n)); HIP_CHECK(ctx->d_adamIdx[1].reserve(n)); HIP_CHECK(ctx->d_adamIdx[0].reserve(n));
+    if (ctx->adamIota < ctx->d_adamIdx[0].cap) {
+        const unsigned int m = (unsigned int)ctx->d_adamIdx[0].cap;
+        hipLaunchKernelGGL(k_iota, dim3((m + 255) / 256), dim3(256), 0, s, ctx->d_adamIdx[0].p, m);
+        ctx->adamIota = m;
+    }
+    size_t bytes = 0;
+    HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, ctx->d_adamKeys[0].p, ctx->d_adamKeys[1].p, ctx->d_adamIdx[0].p, ctx->d_adamIdx[1].p, n, beginBit, endBit, s));
+    HIP_CHECK(ctx->d_sortTemp.reserve(std::max<size_t>(bytes, 16)));
+    HIP_CHECK(rocprim::radix_sort_pairs((void *)ctx->d_sortTemp.p, bytes, ctx->d_adamKeys[0].p, ctx->d_adamKeys[1].p, ctx->d_adamIdx[0].p, ctx->d_adamIdx[1].p, n, beginBit, endBit, s));
+    return PPG_OK;
+}
+
+// The deferred optimizeBsdfSamplingFraction calls of the round just rendered: sort by key, (multi-GPU: exchange through the round
+// hook), apply leaf by leaf (k_adam_apply).  nRecords = positions used in d_adamKeys[0] / d_adamRecs (holes carry key ~0).
+int applyAdamRound(ppg_ctx *ctx, size_t nRecords) {
+    hipStream_t s = ctx->stream;
+    const unsigned int nNodes = (unsigned int)ctx->snodes.size();
+    if (nNodes >= (1u << 24)) { ctx->error = "S-tree exceeds 2^24 nodes with a bsdfSamplingFractionLoss"; return PPG_ERR_NOMEM; }
+    unsigned int leafBits = 1;
+    while ((1u << leafBits) <= nNodes) ++leafBits;  // every leaf index is below the all-ones pattern of a hole
+    const unsigned int endBit = PPG_ADAM_LEAF_SHIFT + leafBits;
+    size_t n = nRecords;
+    if (n > 0) { int rc = sortAdamRecords(ctx, n, ctx->adamFast ? PPG_ADAM_LEAF_SHIFT : 0u, endBit); if (rc) return rc; }
+    if (ctx->passHook) {
+        // hand the valid records over in key order, compact
+        unsigned int nValid = 0;
+        if (n > 0) {
+            hipLaunchKernelGGL(k_count_valid, dim3(1), dim3(1), 0, s, ctx->d_adamKeys[1].p, (unsigned int)n, ctx->d_adamCount.p);
+            HIP_CHECK(hipMemcpyAsync(&nValid, ctx->d_adamCount.p, 4, hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+            HIP_CHECK(ctx->d_adamRecsOut.reserve(std::max<size_t>(1, nValid)));
+            if (nValid) hipLaunchKernelGGL(k_gather_records, dim3((nValid + 255) / 256), dim3(256), 0, s, ctx->d_adamRecs.p, ctx->d_adamIdx[1].p, ctx->d_adamRecsOut.p, nValid);
+        } else HIP_CHECK(ctx->d_adamRecsOut.reserve(1));
+        HIP_CHECK(hipStreamSynchronize(s));
+        ctx->inHook = true; ctx->hookReplaced = false; ctx->hookCount = nValid;
+        const int hrc = ctx->passHook(ctx->passHookUser);
+        ctx->inHook = false;
+        if (hrc != 0) { ctx->error = "round hook failed"; return PPG_ERR_INVALID; }
+        if (ctx->hookReplaced) {  // the union over all ranks, in d_adamRecs: sort it by the whole key
+            n = (size_t)ctx->hookCount;
+            if (n > 0) {
+                HIP_CHECK(ctx->d_adamKeys[0].reserve(n));
+                hipLaunchKernelGGL(k_record_keys, dim3((unsigned int)((n + 255) / 256)), dim3(256), 0, s, ctx->d_adamRecs.p, ctx->d_adamKeys[0].p, (unsigned int)n);
+                int rc = sortAdamRecords(ctx, n, 0u, endBit);
+                if (rc) return rc;
+            }
+        }
+    }
+    if (n == 0) return PPG_OK;
+    const unsigned int nl = (unsigned int)ctx->leaves.size();
+    timedLaunch(ctx, "k_adam_apply", n, [&] {
+        hipLaunchKernelGGL(k_adam_apply, dim3((nl * 64u + 255u) / 256u), dim3(256), 0, s, ctx->d_hdr.p, ctx->d_leaves.p, nl, ctx->d_adamKeys[1].p, ctx->d_adamIdx[1].p,
+                           ctx->d_adamRecs.p, (unsigned int)n, ctx->loss);
+    });
+    HIP_CHECK(hipGetLastError());
+    return PPG_OK;
+}
+
+// `batch` BlockedRenderProcesses (GP:1087-1106 / renderBlock GP:1587-1641) over all owned pixels in one set of launches.
+// adamRound: this batch is one round of the sampling-fraction optimiser.
+int renderBatch(ppg_ctx *ctx, int batch, bool adamRound) {
     PathState P = ctx->paths;
     P.n_paths = (unsigned int)((size_t)ctx->nPix * ctx->sppPerPass * (size_t)batch);
-    if (P.n_paths == 0) return PPG_OK;
+    if (P.n_paths == 0 && !(adamRound && ctx->passHook)) return PPG_OK;
+    hipStream_t s = ctx->stream;
+    // Adam records: positions are known in advance unless one vertex can make several records (box spatial filter) or records are made
+    // while the paths are still being traced (the direct-light vertex of nee = kickstart)
+    ctx->adamActive = adamRound;
+    ctx->adamFast = adamRound && ctx->spatialFilter != SF_BOX && !(ctx->doNee && ctx->nee == NEE_KICKSTART);
+    if (adamRound && !ctx->adamFast) {
+        const size_t cap = std::max<size_t>((size_t)1 << 16, std::min<size_t>((size_t)48 * P.n_paths, 0xfffffff0u));
+        HIP_CHECK(ctx->d_adamKeys[0].reserve(cap)); HIP_CHECK(ctx->d_adamRecs.reserve(cap));
+        HIP_CHECK(hipMemsetAsync(ctx->d_adamCount.p, 0, 8, s));
+    }
     DevScene S = ctx->scene;
     DevTree T = ctx->devTree();
     RenderParams R = ctx->params();
@@ -610,24 +712,31 @@ int renderBatch(ppg_ctx *ctx, int batch) {
     Queues Q = ctx->queues;
     const int grid = ctx->nBlocks;
     const int gridAll = gridFor(P.n_paths);
-    hipStream_t s = ctx->stream;
-    const bool smallScene = ctx->scene.n_tris <= 64 && ctx->ldsTris == ctx->scene.n_tris && ctx->scene.n_spheres == 0 && !getenv("PPG_FORCE_BVH");
+    const bool smallScene = ctx->scene.n_tris <= 64 && ctx->ldsTris == ctx->scene.n_tris && ctx->scene.n_spheres == 0 && !ctx->tuneForceBvh;
     // Tracing inside k_generate / k_shade (no k_trace launch, no ray/hit round trip) was measured SLOWER on MI355X
     // (cbox-720p, 63 passes: 184 ms vs 172 ms for generate+trace+shade): the fused kernel needs 142 VGPRs (3 waves/SIMD)
     // and only the surviving lanes trace.  Kept selectable for re-measurement on other scenes.
-    const bool fused = smallScene && getenv("PPG_FUSE");
+    const bool fused = smallScene && ctx->tuneFuse;
     const bool neeOn = ctx->doNee;  // m_doNee of this iteration (doNeeWithSpp, GP:1331-1340)
     const bool fullMats = ctx->fullMaterials;  // any BSDF beyond diffuse / two-sided diffuse / mirror: the FULL kernel variants
     const size_t triBytes = (size_t)ctx->scene.n_tris * 48;
+    const bool unbounded = ctx->maxDepth < 0;
+    int bouncesRun = 0;
+    if (P.n_paths > 0) {
     timedLaunch(ctx, "k_generate", P.n_paths, [&] {
         if (fused) hipLaunchKernelGGL(k_generate<true>, dim3(gridAll), dim3(PPG_BLOCK), triBytes, s, P, S, R, Q);
         else hipLaunchKernelGGL(k_generate<false>, dim3(gridAll), dim3(PPG_BLOCK), 0, s, P, S, R, Q);
     });
-    // bounce 1 works on all paths (no queue); afterwards the two queue sets alternate
+    // bounce 1 works on all paths (no queue); afterwards the two queue sets alternate.  Bounded paths (maxDepth > 0) run a fixed
+    // schedule of maxDepth bounces.  Unbounded paths run `bulkBounces` wavefront bounces over the whole GPU — as many as the previous
+    // batch needed to thin the queues out — and hand the survivors to the persistent-thread tail (k_tail); nothing is read back in
+    // between, the host synchronises once per batch.
     int qin = -1;
-    const int maxBounces = ctx->maxDepth > 0 ? ctx->maxDepth : 1 << 20;
+    const int maxBounces = unbounded ? (fused ? 1 << 20 : std::max(1, std::min(64, ctx->bulkBounces))) : ctx->maxDepth;
     unsigned int hostCount = P.n_paths;
     const size_t ldsBytes = smallScene ? (size_t)ctx->ldsTris * 48 : (size_t)PPG_LDS_STACK * PPG_BLOCK * 4;
+    const bool liveCount = ctx->timer.enabled || (unbounded && fused);  // kernel timing wants the units of every launch
+    if (unbounded) HIP_CHECK(hipMemsetAsync(ctx->d_bounceCounts.p, 0, 64 * 4, s));
     for (int b = 0; b < maxBounces; ++b) {
         int qout = b & 1;
         if (!fused)
@@ -655,48 +764,69 @@ int renderBatch(ppg_ctx *ctx, int batch) {
 #undef PPG_SHADE
         });
         qin = qout;
-        // unbounded paths (maxDepth < 0) and kernel timing need the live count; bounded paths run a fixed schedule without a sync
-        if (ctx->maxDepth < 0 || ctx->timer.enabled) {
-            hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(256), 0, s, Q.count[qin], (unsigned int)grid, ctx->d_qtotal.p);
-            HIP_CHECK(hipMemcpyAsync(&hostCount, ctx->d_qtotal.p, 4, hipMemcpyDeviceToHost, s));
+        ++bouncesRun;
+        if (unbounded || liveCount)
+            hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(256), 0, s, Q.count[qin], (unsigned int)grid, unbounded ? ctx->d_bounceCounts.p + std::min(b, 63) : ctx->d_qtotal.p);
+        if (liveCount) {
+            HIP_CHECK(hipMemcpyAsync(&hostCount, unbounded ? ctx->d_bounceCounts.p + std::min(b, 63) : ctx->d_qtotal.p, 4, hipMemcpyDeviceToHost, s));
             HIP_CHECK(hipStreamSynchronize(s));
             if (hostCount == 0) break;
-            // unbounded paths: hand the thin tail to the per-workgroup bounce loop (one launch, no more host round trips)
-            if (ctx->maxDepth < 0 && !fused && hostCount < std::max<unsigned int>(P.n_paths / 4, 1u) && !getenv("PPG_NO_TAIL")) {
-                // re-deal the survivors densely to fewer workgroups (the slices have thinned to a few dozen paths each)
-                const unsigned int nbTail = std::max(64u, std::min((unsigned int)grid, hostCount / 768u + 1u));
-                const unsigned int capTail = (hostCount + nbTail - 1) / nbTail;
-                HIP_CHECK(ctx->d_offsets.reserve((size_t)grid));
-                hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, s, Q.count[qin], ctx->d_offsets.p, (unsigned int)grid, ctx->d_total.p);
-                hipLaunchKernelGGL(k_gather_slices, dim3(grid), dim3(PPG_BLOCK), 0, s, Q.items[qin], Q.count[qin], ctx->d_offsets.p, Q.cap, Q.items[qin ^ 1]);
-                ctx->tailCounts.assign((size_t)grid, 0u);
-                for (unsigned int t = 0; t < nbTail; ++t) ctx->tailCounts[t] = std::min(capTail, hostCount - std::min(hostCount, t * capTail));
-                HIP_CHECK(hipMemcpyAsync(Q.count[qin ^ 1], ctx->tailCounts.data(), (size_t)grid * 4, hipMemcpyHostToDevice, s));
-                Queues Qt = Q;
-                Qt.items[0] = Q.items[qin ^ 1]; Qt.items[1] = Q.items[qin];
-                Qt.count[0] = Q.count[qin ^ 1]; Qt.count[1] = Q.count[qin];
-                Qt.cap = capTail; Qt.n_blocks = nbTail;
-                timedLaunch(ctx, "k_tail", hostCount, [&] {
-#define PPG_TAIL(SM, N, M) hipLaunchKernelGGL((k_tail<SM, N, M>), dim3(nbTail), dim3(PPG_BLOCK), ldsBytes, s, P, S, T, R, Qt, 0, (SM) ? 0 : ctx->ldsNodes, ctx->ldsTris)
-                    switch ((smallScene ? 4 : 0) | (neeOn ? 2 : 0) | (fullMats ? 1 : 0)) {
-                        case 0: PPG_TAIL(false, false, false); break;
-                        case 1: PPG_TAIL(false, false, true); break;
-                        case 2: PPG_TAIL(false, true, false); break;
-                        case 3: PPG_TAIL(false, true, true); break;
-                        case 4: PPG_TAIL(true, false, false); break;
-                        case 5: PPG_TAIL(true, false, true); break;
-                        case 6: PPG_TAIL(true, true, false); break;
-                        default: PPG_TAIL(true, true, true); break;
-                    }
-#undef PPG_TAIL
-                });
-                HIP_CHECK(hipStreamSynchronize(s));  // tailCounts is reused by the next pass
-                break;
-            }
         }
     }
     // the last shade of a bounded schedule terminates every path (depth >= maxDepth), no trailing trace needed
-    if (!ctx->isFinalIter) {
+    if (unbounded && !fused) {
+        // the survivors of all workgroups in one dense list, then persistent threads until the last path has ended
+        hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, s, Q.count[qin], ctx->d_offsets.p, (unsigned int)grid, ctx->d_total.p);
+        hipLaunchKernelGGL(k_gather_slices, dim3(grid), dim3(PPG_BLOCK), 0, s, Q.items[qin], Q.count[qin], ctx->d_offsets.p, Q.cap, Q.items[qin ^ 1]);
+        HIP_CHECK(hipMemsetAsync(ctx->d_ticket.p, 0, 4, s));
+        timedLaunch(ctx, "k_tail", hostCount, [&] {
+#define PPG_TAIL(SM, N, M) hipLaunchKernelGGL((k_tail<SM, N, M>), dim3(grid), dim3(PPG_BLOCK), ldsBytes, s, P, S, T, R, Q.items[qin ^ 1], ctx->d_total.p, ctx->d_ticket.p, Q.stats, ctx->ldsTris)
+            switch ((smallScene ? 4 : 0) | (neeOn ? 2 : 0) | (fullMats ? 1 : 0)) {
+                case 0: PPG_TAIL(false, false, false); break;
+                case 1: PPG_TAIL(false, false, true); break;
+                case 2: PPG_TAIL(false, true, false); break;
+                case 3: PPG_TAIL(false, true, true); break;
+                case 4: PPG_TAIL(true, false, false); break;
+                case 5: PPG_TAIL(true, false, true); break;
+                case 6: PPG_TAIL(true, true, false); break;
+                default: PPG_TAIL(true, true, true); break;
+            }
+#undef PPG_TAIL
+        });
+    }
+    }
+    size_t nRecords = 0;
+    if (adamRound && ctx->adamFast && P.n_paths > 0) {
+        // position of path i's records = exclusive scan of the vertex counts
+        HIP_CHECK(ctx->d_adamNv.reserve(P.n_paths)); HIP_CHECK(ctx->d_adamBase.reserve(P.n_paths));
+        hipLaunchKernelGGL(k_path_nv, dim3((P.n_paths + 255) / 256), dim3(256), 0, s, P, ctx->d_adamNv.p);
+        size_t bytes = 0;
+        HIP_CHECK(rocprim::exclusive_scan(nullptr, bytes, ctx->d_adamNv.p, ctx->d_adamBase.p, 0u, (size_t)P.n_paths, rocprim::plus<unsigned int>(), s));
+        HIP_CHECK(ctx->d_sortTemp.reserve(std::max<size_t>(bytes, 16)));
+        HIP_CHECK(rocprim::exclusive_scan((void *)ctx->d_sortTemp.p, bytes, ctx->d_adamNv.p, ctx->d_adamBase.p, 0u, (size_t)P.n_paths, rocprim::plus<unsigned int>(), s));
+        HIP_CHECK(hipMemcpyAsync(ctx->h_round + 65, ctx->d_adamBase.p + (P.n_paths - 1), 4, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipMemcpyAsync(ctx->h_round + 66, ctx->d_adamNv.p + (P.n_paths - 1), 4, hipMemcpyDeviceToHost, s));
+    }
+    if (P.n_paths > 0 && ((unbounded && !fused) || (adamRound && ctx->adamFast))) {
+        if (unbounded) HIP_CHECK(hipMemcpyAsync(ctx->h_round, ctx->d_bounceCounts.p, 64 * 4, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));  // the one host round trip of a batch of unbounded paths / of a round
+        if (unbounded && !fused) {
+            // next batch: wavefront bounces until fewer paths are left than the persistent-thread tail handles just as well
+            const unsigned int thr = ctx->tailThreshold ? ctx->tailThreshold : std::max(131072u, P.n_paths / 16u);
+            int nb = bouncesRun;
+            for (int b = 0; b < bouncesRun; ++b) if (ctx->h_round[b] < thr) { nb = b + 1; break; }
+            if (nb == bouncesRun && ctx->h_round[bouncesRun - 1] >= thr) nb = std::min(64, bouncesRun + 4);
+            ctx->bulkBounces = std::max(1, nb);
+        }
+        if (adamRound && ctx->adamFast) {
+            nRecords = (size_t)ctx->h_round[65] + ctx->h_round[66];
+            if (nRecords > 0xfffffff0ull) { ctx->error = "too many Adam records in one round"; return PPG_ERR_NOMEM; }
+            HIP_CHECK(ctx->d_adamKeys[0].reserve(std::max<size_t>(1, nRecords))); HIP_CHECK(ctx->d_adamRecs.reserve(std::max<size_t>(1, nRecords)));
+            if (nRecords) HIP_CHECK(hipMemsetAsync(ctx->d_adamKeys[0].p, 0xff, nRecords * 8, s));
+            T = ctx->devTree();
+        }
+    }
+    if (!ctx->isFinalIter && P.n_paths > 0) {
         timedLaunch(ctx, "k_commit", P.n_paths, [&] {
 #define PPG_COMMIT(SFV, DFV) hipLaunchKernelGGL((k_commit<SFV, DFV>), dim3(grid), dim3(PPG_BLOCK), 0, s, P, T, R, Q)
             const int sf = ctx->spatialFilter, df = ctx->directionalFilter;
@@ -708,20 +838,19 @@ int renderBatch(ppg_ctx *ctx, int batch) {
             else PPG_COMMIT(SF_BOX, DF_BOX);
 #undef PPG_COMMIT
         });
-        if (ctx->loss != LOSS_NONE && ctx->isBuilt) {
-            unsigned int nn = (unsigned int)ctx->snodes.size();
-            if (ctx->passHook) {  // multi-GPU: the driver all-reduces the per-pass sums here
-                HIP_CHECK(hipStreamSynchronize(s));
-                if (ctx->passHook(ctx->passHookUser) != 0) { ctx->error = "pass hook failed"; return PPG_ERR_INVALID; }
-            }
-            hipLaunchKernelGGL(k_adam_step, dim3((nn + 255) / 256), dim3(256), 0, s, T, nn);
-            if (ctx->shardWorld > 1 && ctx->shardRank != 0) {
-                // sharded: the hook summed the mini-batch sums over all ranks; the part carried to the next pass must exist once
-                HIP_CHECK(hipMemsetAsync(ctx->d_adamW.p, 0, (size_t)nn * PPG_ADAM_BATCHES * 8, s));
-                HIP_CHECK(hipMemsetAsync(ctx->d_adamGrad.p, 0, (size_t)nn * PPG_ADAM_BATCHES * 8, s));
-            }
-        }
     }
+    if (adamRound) {
+        if (!ctx->adamFast) {
+            HIP_CHECK(hipMemcpyAsync(ctx->h_round + 64, ctx->d_adamCount.p, 8, hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+            if (ctx->h_round[65]) { ctx->error = "Adam record buffer overflow (box spatial filter / next-event estimation with a bsdfSamplingFractionLoss)"; return PPG_ERR_NOMEM; }
+            nRecords = ctx->h_round[64];
+        }
+        int rc = applyAdamRound(ctx, nRecords);
+        ctx->adamActive = false;
+        if (rc) return rc;
+    }
+    if (P.n_paths > 0)
     timedLaunch(ctx, "k_film", P.n_pix, [&] {
         hipLaunchKernelGGL(k_film, dim3((P.n_pix + 255) / 256), dim3(256), 0, s, P, ctx->sppPerPass * batch, ctx->d_image.p, ctx->d_sq.p, ctx->d_imageW.p,
                            ctx->d_film.p, ctx->d_filmW.p);
@@ -738,10 +867,13 @@ int renderPassesNoStat(ppg_ctx *ctx, int numPasses) {  // GP:1217-1286
     HIP_CHECK(hipMemsetAsync(ctx->d_stats.p, 0, sizeof(BlockStats) * (size_t)ctx->nBlocks, ctx->stream));
     ctx->passStart = std::chrono::steady_clock::now();
     ctx->passesLocal = 0;
+    // rounds of the sampling-fraction optimiser (include/ppg.h): fractions frozen during a round, its records applied afterwards
+    const bool rounds = ctx->loss != LOSS_NONE && ctx->isBuilt && !ctx->isFinalIter;
+    const int roundPasses = rounds ? (int)ppg_adam_round_passes(ctx->sppPerPass, ctx->W, ctx->H, numPasses) : ctx->maxBatch;
     for (int i = 0; i < numPasses;) {
         if (ctx->cancelled.load()) break;
-        const int batch = std::min(ctx->maxBatch, numPasses - i);
-        int rc = renderBatch(ctx, batch);
+        const int batch = std::min(roundPasses, numPasses - i);
+        int rc = renderBatch(ctx, batch, rounds);
         if (rc) return rc;
         ctx->passesRendered += batch; ctx->passesRenderedThisIter += batch; ctx->passesLocal += batch;
         i += batch;
@@ -1062,6 +1194,13 @@ void ppg_config_default(ppg_config *cfg) {
 
 const char *ppg_description(void) { return "Guided path tracer"; }
 
+int32_t ppg_adam_round_passes(int32_t spp_per_pass, int32_t width, int32_t height, int32_t n_passes) {
+    const uint64_t perPass = (uint64_t)std::max(1, spp_per_pass) * (uint64_t)std::max(1, width) * (uint64_t)std::max(1, height);
+    int32_t r = 1;
+    while (r * 2 <= PPG_ADAM_ROUND_MAX_PASSES && r * 4 <= n_passes && (uint64_t)(r * 2) * perPass <= PPG_ADAM_ROUND_MAX_PATHS) r *= 2;
+    return r;
+}
+
 int ppg_create(const ppg_config *cfg, ppg_ctx **out) {
     if (!cfg || !out) { g_createError = "null argument"; return PPG_ERR_INVALID; }
     std::unique_ptr<ppg_ctx> c(new ppg_ctx());
@@ -1080,6 +1219,15 @@ int ppg_create(const ppg_config *cfg, ppg_ctx **out) {
     c->dumpSDTree = cfg->dumpSDTree != 0; c->rrDepth = cfg->rrDepth; c->maxDepth = cfg->maxDepth;
     c->strictNormals = cfg->strictNormals != 0; c->hideEmitters = cfg->hideEmitters != 0; c->seed = cfg->seed; c->device = cfg->device;
     if (cfg->dumpPrefix) c->dumpPrefix = cfg->dumpPrefix;
+    {   // tuning switches (performance experiments only; results do not depend on them)
+        if (const char *e = getenv("PPG_TAIL_THRESHOLD")) c->tailThreshold = (unsigned int)std::max(0ll, atoll(e));
+        if (const char *e = getenv("PPG_BATCH_PATHS")) c->tuneBatchPaths = (size_t)std::max(1ll, atoll(e));
+        if (const char *e = getenv("PPG_BLOCKS")) c->tuneBlocks = std::max(1, atoi(e));
+        c->tuneForceBvh = getenv("PPG_FORCE_BVH") != nullptr;
+        c->tuneFuse = getenv("PPG_FUSE") != nullptr;
+        if (const char *e = getenv("PPG_BVH_LEAF")) c->tuneBvhLeaf = std::max(1, std::min(8, atoi(e)));
+        if (const char *e = getenv("PPG_BVH_PAD")) c->tuneBvhPad = (float)atof(e);
+    }
     if (c->sppPerPass <= 0) { g_createError = "sppPerPass must be > 0"; return PPG_ERR_INVALID; }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -1100,6 +1248,7 @@ void ppg_destroy(ppg_ctx *ctx) {
     ctx->timer.resolve();
     for (auto e : ctx->timer.pool) (void)hipEventDestroy(e);
     if (ctx->h_lum) (void)hipHostFree(ctx->h_lum);
+    if (ctx->h_round) (void)hipHostFree(ctx->h_round);
     hipStream_t s = ctx->stream;
     delete ctx;
     if (s) (void)hipStreamDestroy(s);
@@ -1152,8 +1301,8 @@ int ppg_set_scene(ppg_ctx *ctx, const ppg_scene *s) {
     // Box padding: the BVH must return what brute force returns.  A slab test carries a few ulps of error in t, i.e. up to
     // ~4 * 2^-24 * (distance travelled) in position; 2e-6 * (scene extent) leaves an 8x margin.  (1e-4 * extent, the first
     // choice, made the leaf boxes of a finely tessellated model under a 100 m sky dome several triangles thick: 4x slower.)
-    const float padRel = getenv("PPG_BVH_PAD") ? (float)atof(getenv("PPG_BVH_PAD")) : 2e-6f;
-    if (const char *e = getenv("PPG_BVH_LEAF")) bb.maxLeaf = std::max(1, std::min(8, atoi(e)));
+    const float padRel = ctx->tuneBvhPad;
+    bb.maxLeaf = ctx->tuneBvhLeaf;
     bb.run(s->positions, s->indices, s->n_triangles, padRel * ext + 1e-30f);
     std::vector<float4> tris(3 * (size_t)s->n_triangles), nrm, accel(3 * (size_t)s->n_triangles);
     if (s->normals) nrm.resize(tris.size());
@@ -1554,10 +1703,22 @@ int ppg_image_buffers(ppg_ctx *ctx, void **dev_image, void **dev_sq_image, void 
 }
 
 int ppg_set_pass_hook(ppg_ctx *ctx, ppg_pass_hook hook, void *user) { ctx->passHook = hook; ctx->passHookUser = user; return PPG_OK; }
-int ppg_adam_buffers(ppg_ctx *ctx, void **dev_grad, void **dev_weight, uint64_t *n) {
+int ppg_adam_records(ppg_ctx *ctx, void **dev_records, uint64_t *n) {
     NEED_TREE
-    *dev_grad = ctx->d_adamGrad.p; *dev_weight = ctx->d_adamW.p;
-    *n = ctx->loss != LOSS_NONE ? ctx->snodes.size() * PPG_ADAM_BATCHES : 0;
+    if (!ctx->inHook) { ctx->error = "ppg_adam_records: only valid inside the round hook"; return PPG_ERR_STATE; }
+    *dev_records = ctx->hookReplaced ? (void *)ctx->d_adamRecs.p : (void *)ctx->d_adamRecsOut.p;
+    *n = ctx->hookCount;
+    return PPG_OK;
+}
+int ppg_adam_records_replace(ppg_ctx *ctx, const void *dev_records, uint64_t n) {
+    NEED_TREE
+    if (!ctx->inHook) { ctx->error = "ppg_adam_records_replace: only valid inside the round hook"; return PPG_ERR_STATE; }
+    if (n > 0xfffffff0ull) { ctx->error = "too many Adam records in one round"; return PPG_ERR_NOMEM; }
+    if (n && dev_records == (const void *)ctx->d_adamRecs.p) { ctx->error = "ppg_adam_records_replace: source aliases the destination"; return PPG_ERR_INVALID; }
+    HIP_CHECK(ctx->d_adamRecs.reserve(std::max<size_t>(1, (size_t)n)));
+    if (n) HIP_CHECK(hipMemcpyAsync(ctx->d_adamRecs.p, dev_records, (size_t)n * sizeof(AdamRec), hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->hookReplaced = true; ctx->hookCount = n;
     return PPG_OK;
 }
 

@@ -2,7 +2,7 @@
  * ppg_kernels.h — wavefront kernels of the guided path tracer (included by ppg_hip.hip).
  *
  * One render pass (= one BlockedRenderProcess of the reference, GP:1087-1106) is
- *     k_generate → [k_trace → k_shade]* → k_commit → (k_adam_step) → k_film
+ *     k_generate → [k_trace → k_shade]* → (k_tail) → k_commit → k_film, and per round of passes (sort →) k_adam_apply
  * over SoA path state.  Path i = j * n_pix + k is sample j of the k-th owned pixel, so a wave holds 64
  * neighbouring pixels.  Queues are arrays of path indices compacted with one wave-aggregated atomic;
  * all accumulation into shared state is integer (fixed point), so results do not depend on the order
@@ -47,6 +47,7 @@ struct RenderParams {
     unsigned int pass_index;  // m_passesRendered at the start of this pass
     unsigned int pass_index_spp;  // sample index of the batch's first sample = pass_index * sppPerPass
     int max_vertices;         // vertex slots allocated per path
+    unsigned int img_pixels;  // width * height of the whole image (path ids of the Adam records)
 };
 
 struct PathState {
@@ -473,8 +474,15 @@ struct Rec {  // DTreeRecord, GP:562-568
     F3 d;
     float radiance, product, woPdf, bsdfPdf, dTreePdf, statisticalWeight;
     bool isDelta;
-    int adamBatch;  // mini-batch of the per-pass Adam rule: hash(path key, vertex slot) & (PPG_ADAM_BATCHES - 1)
+    // place of this record's optimizeBsdfSamplingFraction call in the round's canonical order (include/ppg.h): path id, record code,
+    // and its position in the record buffer (0xffffffff: append)
+    unsigned int adamPath, adamCode, adamPos;
 };
+
+// path id of the Adam records: (sample index within the round) * (pixels of the whole image) + pixel index
+D unsigned int adam_path_id(const PathState &P, const RenderParams &R, unsigned int i) {
+    return (i / P.n_pix) * R.img_pixels + P.pixels[i % P.n_pix];
+}
 
 // DTreeWrapper::record (GP:575-584) incl. the gradient of optimizeBsdfSamplingFraction (GP:672-697);
 // the Adam step itself is taken once per pass by k_adam_step from the exact sums accumulated here.
@@ -494,28 +502,19 @@ D void wrapper_record(const DevTree &T, int leaf, const Rec &rec, int dfilter, i
     else if (wOk) atomicAdd(&T.bweight_rep[(size_t)leaf * PPG_REPLICAS + (blockIdx.x & (PPG_REPLICAS - 1))], wf);
     if (wOk) dtree_record(T, leaf, px, py, irradiance, rec.statisticalWeight, dfilter);
 
-    const bool adam = active && loss != LOSS_NONE && rec.product > 0;
-    if (loss != LOSS_NONE) {
-        unsigned long long g = 0, w = 0;
-        if (adam) {
-            float variable = T.hdr[leaf].theta;
-            float samplingFraction = logistic(variable);
-            float mixPdf = samplingFraction * rec.bsdfPdf + (1 - samplingFraction) * rec.dTreePdf;
-            float r = rec.product / mixPdf;
-            float ratio = (loss == LOSS_KL) ? r : r * r;
-            float dLoss_dSamplingFraction = -ratio / rec.woPdf * (rec.bsdfPdf - rec.dTreePdf);
-            float dLoss_dVariable = dLoss_dSamplingFraction * (samplingFraction * (1 - samplingFraction));
-            float l2RegGradient = 0.01f * variable;
-            float lossGradient = l2RegGradient + dLoss_dVariable;
-            g = (unsigned long long)ppg_to_sfixed(lossGradient * rec.statisticalWeight);
-            w = ppg_to_fixed(rec.statisticalWeight);
+    // if (bsdfSamplingFractionLoss != ENone && rec.product > 0) optimizeBsdfSamplingFraction(rec, ...), GP:581-583: deferred to the end
+    // of the round (k_adam_apply), here only written down
+    if (active && loss != LOSS_NONE && rec.product > 0) {
+        unsigned int pos = rec.adamPos;
+        if (pos == 0xffffffffu) {
+            pos = atomicAdd(T.adam_count, 1u);
+            if (pos >= T.adam_cap) { T.adam_count[1] = 1u; return; }  // reported as an error by the host
         }
-        // 64 mini-batches per D-tree already spread a popular leaf's records over 64 addresses: plain atomics
-        if (adam) {
-            const size_t ak = (size_t)leaf * PPG_ADAM_BATCHES + (size_t)rec.adamBatch;
-            atomicAdd((unsigned long long *)&T.adam_grad[ak], g);
-            atomicAdd(&T.adam_w[ak], w);
-        }
+        AdamRec a;
+        a.key = ((unsigned long long)(unsigned int)leaf << PPG_ADAM_LEAF_SHIFT) | ((unsigned long long)rec.adamPath << PPG_ADAM_CODE_BITS) | rec.adamCode;
+        a.product = rec.product; a.woPdf = rec.woPdf; a.bsdfPdf = rec.bsdfPdf; a.dTreePdf = rec.dTreePdf; a.weight = rec.statisticalWeight; a.pad = 0.0f;
+        T.adam_keys[pos] = a.key;
+        T.adam_recs[pos] = a;
     }
 }
 
@@ -554,7 +553,7 @@ D void stree_record_box(const DevTree &T, F3 p, F3 vox, Rec rec, int dfilter, in
 
 // Vertex::commit up to the spatial-filter dispatch (GP:1730-1744): false = the vertex is dropped
 D bool vertex_to_rec(F3 radiance, F3 bsdfVal, F3 throughput, float woPdf, float bsdfPdf, float dTreePdf, F3 d, bool isDelta,
-                     unsigned int key, unsigned int slot, float statisticalWeight, Rec &rec) {
+                     float statisticalWeight, Rec &rec) {
     if (!(woPdf > 0) || !isvalid3(radiance) || !isvalid3(bsdfVal)) return false;
     F3 localRadiance = f3s(0.0f);
     if (throughput.x * woPdf > PPG_EPSILON) localRadiance.x = radiance.x / throughput.x;
@@ -566,7 +565,6 @@ D bool vertex_to_rec(F3 radiance, F3 bsdfVal, F3 throughput, float woPdf, float 
     rec.woPdf = woPdf; rec.bsdfPdf = bsdfPdf; rec.dTreePdf = dTreePdf;
     rec.statisticalWeight = statisticalWeight;
     rec.isDelta = isDelta;
-    rec.adamBatch = (int)(ppg_hash32(key ^ (0x9e3779b9u * (slot + 1u))) & (PPG_ADAM_BATCHES - 1));
     return true;
 }
 
@@ -660,6 +658,368 @@ struct NeeLds {
 // NEE: the variant with luminaire sampling (GP:1962-2021) and MIS against it (GP:2083-2088); the shadow ray is
 // traced and the direct-light vertex committed in place, as in the reference's loop.
 // FULL: the complete material set (ppg_device.h "Full material set"); otherwise only diffuse / two-sided diffuse / mirror.
+// Li's loop body for ONE path: returns whether the path goes on (a new ray was written).  Free of cross-lane operations, so
+// it may be called under divergence (k_tail).  plen receives rRec.depth when the path ends here.
+template <bool FUSED, bool NEE, bool FULL>
+D bool shade_one(const PathState &P, const DevScene &S, const DevTree &T, const RenderParams &R, const unsigned int i, const LdsColumn &fcol,
+                 const float4 *lds_tris, unsigned long long &plen, unsigned int &traced, const NeeLds &nee, unsigned long long &committed) {
+    bool alive = false;
+    {
+    uint4 m = P.misc[i];
+    unsigned int key = m.x, dim = m.y, flags = m.z;
+    unsigned int depth = flags & FL_DEPTH_MASK;
+    unsigned int nV = (flags & FL_NV_MASK) >> FL_NV_SHIFT;
+    float4 t4 = P.thr[i], l4 = P.li[i], h4 = P.hit[i], d4 = P.ray_d[i];
+    F3 thr = f3(t4.x, t4.y, t4.z);
+    float eta = t4.w;
+    F3 Li = f3(l4.x, l4.y, l4.z);
+    F3 d = f3(d4.x, d4.y, d4.z);
+    Hit h;
+    h.t = h4.x; h.u = h4.y; h.v = h4.z; h.prim = __float_as_int(h4.w);
+    const bool valid = h.prim >= 0;
+    Isect I;
+    if (valid) {
+        if (FULL && h.prim >= S.n_tris) {
+            const float4 ro4 = P.ray_o[i];
+            fill_isect_sphere(S, h, f3(ro4.x, ro4.y, ro4.z), d, I);
+        } else fill_isect(S, h, d, I);
+    }
+    bool go = true;
+
+    if (FULL && (flags & FL_PENDING) && (flags & FL_PEND_NULL)) {
+        // ---- the previous bounce passed straight through a null component, GP:2045-2075: no emitter lookup, no MIS,
+        // no Russian roulette; rRec.type = scattered ? ERadianceNoEmission : ERadiance; rRec.depth++; continue ----
+        if (flags & FL_SCATTERED) flags &= ~FL_EMITTED_OK; else flags |= FL_EMITTED_OK;
+        ++depth;
+        if (!((int)depth <= R.max_depth || R.max_depth < 0)) go = false;
+        flags &= ~(FL_PENDING | FL_PEND_TREE | FL_PEND_DELTA | FL_PEND_REFN | FL_PEND_NULL);
+    } else if (flags & FL_PENDING) {
+        // ---- second half of the previous bounce: GP:2078-2145 ----
+        F3 value = valid ? eval_Le(S, I, -d) : f3s(0.0f);  // rayIntersectAndLookForEmitter, GP:2229-2234
+        // dRec.setQuery(ray, its) of the emitter that was found (records.inl:170-178)
+        F3 em_n = I.n;
+        float em_dist = h.t;
+        int em_id = I.emitter;
+        if (FULL && !valid && S.env.w != 0) {  // GP:2236-2243: the ray left the scene
+            const float4 ro4 = P.ray_o[i];
+            if (env_fill_direct(S, f3(ro4.x, ro4.y, ro4.z), d)) { value = env_radiance(S, d); em_id = S.n_emitters; }
+        }
+        if (FULL && S.has_null && valid && I.emitter < 0) {
+            // rayIntersectAndLookForEmitter GP:2184-2245: the path continues from THIS hit, but the search for an emitter
+            // goes on through surfaces that have a null component (traced in place)
+            Mat Mc = load_material(S, I.material);
+            if (mat_has_null(Mc)) {
+                const float4 ro4 = P.ray_o[i];
+                F3 ro = f3(ro4.x, ro4.y, ro4.z);
+                F3 transmittance = f3s(1.0f);
+                const int maxInteractions = R.max_depth - (int)depth - 1;
+                int interactions = 0;
+                bool abandoned = false, surface = true;
+                Hit hc = h;
+                Isect Ic = I;
+                for (;;) {
+                    if (interactions == maxInteractions || !mat_has_null(Mc) || Ic.emitter >= 0) break;
+                    if (iszero3(transmittance)) { abandoned = true; break; }
+                    const float cosThetaI = -to_local(Ic, d).z;  // bRec(its, -wo, wo) in the shading frame
+                    transmittance = mul3(transmittance, mat_eval_null(Mc, cosThetaI));
+                    ro = ro + d * hc.t;
+                    if (++interactions > 100) { abandoned = true; break; }
+                    hc = trace_inline(S, nee.small_tris, nee.stack_col, ro, d, __builtin_inff());
+                    ++traced;
+                    if (hc.prim < 0) { surface = false; break; }
+                    fill_isect_full(S, hc, ro, d, Ic);
+                    Mc = load_material(S, Ic.material);
+                }
+                if (!abandoned && surface && Ic.emitter >= 0) {
+                    value = mul3(transmittance, eval_Le(S, Ic, -d));
+                    em_n = Ic.n; em_dist = hc.t; em_id = Ic.emitter;  // dist from the LAST ray origin, as in the reference
+                } else if (!abandoned && !surface && S.env.w != 0 && env_fill_direct(S, ro, d)) {
+                    value = mul3(transmittance, env_radiance(S, d));
+                    em_id = S.n_emitters;
+                }
+            }
+        }
+        const float woPdf = l4.w;
+        const bool isDelta = (flags & FL_PEND_DELTA) != 0;
+        const bool hasTree = (flags & FL_PEND_TREE) != 0;
+        float emitterPdf = 0.0f;  // GP:2085: scene->pdfEmitterDirect(dRec) (scene.cpp:949-952, area.cpp:175-183, shape.cpp:117-126)
+        if (NEE && R.do_nee && !isDelta && !iszero3(value)) {
+            float pdfDirect = 0.0f;
+            const float dn = dot3(d, em_n);
+            if (FULL && em_id == S.n_emitters) {
+                pdfDirect = S.env.w == 2.0f ? envmap_pdf_direction(S, envmap_to_local(S, d)) : env_pdf_direct(P.nee_cos[i]);
+            } else if ((flags & FL_PEND_REFN) && dn < 0) {
+                const int4 info = S.em_info[em_id];
+                if (FULL && info.y < 0) {  // Sphere::pdfDirect needs dRec.ref = the previous vertex = this ray's origin
+                    const float4 ro4 = P.ray_o[i];
+                    pdfDirect = sphere_pdf_direct(S.spheres + 4 * (-info.y - 1), f3(ro4.x, ro4.y, ro4.z), d, em_n, em_dist);
+                } else pdfDirect = __int_as_float(info.w) * (em_dist * em_dist) / ppg_abs(dn);
+            }
+            emitterPdf = pdfDirect * (1.0f * S.em_sel_norm);
+        }
+        float pa = woPdf * woPdf, pb = emitterPdf * emitterPdf;  // miWeight(woPdf, emitterPdf), GP:2247-2250
+        const float weight = pa / (pa + pb);
+        F3 L = mul3(thr, value) * weight;
+        if (!iszero3(L)) {  // recordRadiance, GP:1791-1796
+            Li = Li + L;
+            for (unsigned int v0 = 0; v0 < nV; v0 += 4) {  // 4 independent loads in flight, then 4 stores
+                float4 rr[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (v0 + k < nV) rr[k] = P.v_rad[(size_t)(v0 + k) * P.n_paths + i];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (v0 + k < nV) {
+                        rr[k].x += L.x; rr[k].y += L.y; rr[k].z += L.z;
+                        P.v_rad[(size_t)(v0 + k) * P.n_paths + i] = rr[k];
+                    }
+            }
+        }
+        if ((!isDelta || R.loss != LOSS_NONE) && hasTree && nV < PPG_MAX_VERTICES && nV < (unsigned int)R.max_vertices &&
+            !R.is_final_iter) {
+            if (1 / woPdf > 0) {  // the other vertex fields were written when the bounce was sampled
+                F3 rad = (R.nee == NEE_ALWAYS) ? f3s(0.0f) : L;
+                unsigned int bits = m.w | (isDelta ? 0x80000000u : 0u);
+                P.v_rad[(size_t)nV * P.n_paths + i] = make_float4(rad.x, rad.y, rad.z, __uint_as_float(bits));
+                ++nV;
+            }
+        }
+        flags &= ~FL_EMITTED_OK;  // rRec.type = ERadianceNoEmission
+        if (depth++ >= (unsigned int)R.rr_depth) {  // Russian roulette, GP:2124-2142
+            float successProb = 1.0f;
+            if (hasTree && !isDelta) {
+                if (!T.is_built) successProb = max3(thr) * eta * eta;
+                successProb = ppg_max(0.1f, ppg_min(successProb, 0.99f));
+            }
+            if (ppg_rand(key, dim++) >= successProb) go = false;
+            else thr = div3(thr, successProb);
+        }
+        if (go) {
+            flags |= FL_SCATTERED;
+            if (!((int)depth <= R.max_depth || R.max_depth < 0)) go = false;
+        }
+        flags &= ~(FL_PENDING | FL_PEND_TREE | FL_PEND_DELTA | FL_PEND_REFN);
+    }
+
+    // ---- first half of this bounce: GP:1902-2040 ----
+    if (go && !valid) {  // GP:1902-1914: possibly radiance from a background luminaire, then the path ends
+        if (FULL && S.env.w != 0 && (flags & FL_EMITTED_OK) && (!R.hide_emitters || (flags & FL_SCATTERED)))
+            Li = Li + mul3(thr, env_radiance(S, d));  // (nVertices == 0 whenever emission is still enabled)
+        go = false;
+    }
+    if (go) {
+        if (I.emitter >= 0 && (flags & FL_EMITTED_OK) && (!R.hide_emitters || (flags & FL_SCATTERED)))
+            Li = Li + mul3(thr, eval_Le(S, I, -d));  // GP:1917-1919 (nVertices == 0 here)
+        if ((int)depth >= R.max_depth && R.max_depth != -1) go = false;
+    }
+    if (go) {
+        float wiDotGeoN = -dot3(I.geoN, d), wiDotShN = I.wi.z;
+        if (wiDotGeoN * wiDotShN < 0 && R.strict_normals) go = false;
+    }
+    if (go) {
+        Mat M;
+        if (FULL) {
+            M = load_material(S, I.material);
+        } else {
+            const float4 mat = S.materials[PPG_MAT_STRIDE * (size_t)I.material];
+            M.type = (int)mat.w; M.flags = 0; M.refl = f3(mat.x, mat.y, mat.z);
+        }
+        const bool smooth = FULL ? mat_is_smooth(M) : bsdf_is_smooth(M.type);  // bsdf->getType() & ESmooth: only those are guided
+        auto b_eval = [&](F3 wi_, F3 wo_) { return FULL ? mat_eval(M, wi_, wo_) : bsdf_eval(M.type, M.refl, wi_, wo_); };
+        auto b_pdf = [&](F3 wi_, F3 wo_) { return FULL ? mat_pdf(M, wi_, wo_) : bsdf_pdf(M.type, wi_, wo_); };
+        float sampledEta = 1.0f;
+        bool sampledNull = false;
+        auto b_sample = [&](float u_, float v_, F3 &wo_, float &pdf_, bool &delta_) {
+            return FULL ? mat_sample(M, I.wi, u_, v_, wo_, pdf_, delta_, sampledEta, sampledNull, key, dim)
+                        : bsdf_sample(M.type, M.refl, I.wi, u_, v_, wo_, pdf_, delta_);
+        };
+        F3 vox = f3s(0.0f);
+        int leaf = 0;
+        DTreeRef hd;
+        hd.s_base = 0; hd.s_sum = 0; hd.s_statw = 0;
+        float frac = R.bsdf_sampling_fraction;  // GP:1946-1949
+        if (smooth) {
+            leaf = stree_lookup(T, I.p, vox);  // GP:1942-1944
+            const float4 h4 = *reinterpret_cast<const float4 *>(&T.hdr[leaf]);  // {s_base, s_num, s_sum, s_statw}
+            hd.s_base = __float_as_uint(h4.x); hd.s_sum = h4.z; hd.s_statw = h4.w;
+            if (R.loss != LOSS_NONE) frac = logistic(T.hdr[leaf].theta);
+        }
+
+        // sampleMat, GP:1650-1691
+        float sx = ppg_rand(key, dim++);
+        float sy = ppg_rand(key, dim++);
+        F3 wo_l, bsdfWeight;
+        float woPdf, bsdfPdf, dTreePdf;
+        bool sampledDelta = false;
+        if (!T.is_built || !smooth) {  // !m_isBuilt || !dTree || all components are delta
+            bsdfWeight = b_sample(sx, sy, wo_l, bsdfPdf, sampledDelta);
+            woPdf = bsdfPdf;
+            dTreePdf = 0;
+        } else {
+            F3 result;
+            bool zero = false, deltaEarly = false;
+            if (sx < frac) {
+                sx /= frac;
+                result = b_sample(sx, sy, wo_l, bsdfPdf, sampledDelta);
+                if (iszero3(result)) zero = true;
+                else if (FULL && sampledDelta) deltaEarly = true;  // GP:1672-1676: a delta lobe of a mixed BSDF
+                else result = result * bsdfPdf;
+            } else {
+                // sample.x is remapped but unused on this branch (GP:1680-1682)
+                float cx, cy;
+                dtree_sample(T, hd, key, dim, cx, cy);
+                wo_l = to_local(I, canonical_to_dir(cx, cy));
+                sampledEta = 1.0f; sampledNull = false;
+                result = b_eval(I.wi, wo_l);
+            }
+            if (zero) {
+                woPdf = bsdfPdf = dTreePdf = 0;
+                bsdfWeight = f3s(0.0f);
+                wo_l = f3s(0.0f);
+            } else if (deltaEarly) {
+                dTreePdf = 0;
+                woPdf = bsdfPdf * frac;
+                bsdfWeight = div3(result, frac);
+            } else {
+                // pdfMat, GP:1693-1710
+                dTreePdf = 0;
+                bsdfPdf = b_pdf(I.wi, wo_l);
+                if (!ppg_isfinite(bsdfPdf)) {
+                    woPdf = 0;
+                } else {
+                    float cx, cy;
+                    dir_to_canonical(to_world(I, wo_l), cx, cy);
+                    dTreePdf = dtree_pdf(T, hd, cx, cy, fcol);
+                    woPdf = frac * bsdfPdf + (1 - frac) * dTreePdf;
+                }
+                bsdfWeight = (woPdf == 0) ? f3s(0.0f) : div3(result, woPdf);
+            }
+        }
+        // Luminaire sampling, GP:1962-2021
+        const bool noRefN = FULL ? mat_backside_or_transmission(M) : (M.type == PPG_BSDF_TWOSIDED_DIFFUSE);
+        const F3 refN = noRefN ? f3s(0.0f) : I.n;  // DirectSamplingRecord(its), records.inl:160-164
+        if (NEE && R.do_nee && smooth) {
+            const float ex = ppg_rand(key, dim++);
+            const float ey = ppg_rand(key, dim++);
+            DirectSample ds;
+            F3 value = emitter_sample_direct(S, I.p, refN, ex, ey, ds);
+            if (ds.pdf != 0) {
+                if (FULL && S.has_null) {  // value *= evalTransmittance(...) / emPdf, scene.cpp:887-889
+                    const F3 tr = shadow_transmittance(S, nee.small_tris, nee.stack_col, I.p, ds.sd, ds.sdist, ds.is_env ? 1.0f : 1 - PPG_SHADOW_EPSILON,
+                                                       R.max_depth - (int)depth - 1, traced);
+                    if (iszero3(tr)) value = f3s(0.0f);
+                    else { value = div3(mul3(value, tr), ds.em_pdf); ds.pdf *= ds.em_pdf; }
+                } else {
+                    ++traced;
+                    if (shadow_occluded<FULL>(S, nee.small_tris, nee.stack_col, I.p, ds.sd, ds.sdist * ((FULL && ds.is_env) ? 1.0f : 1 - PPG_SHADOW_EPSILON))) {
+                        value = f3s(0.0f);
+                    } else {
+                        value = div3(value, ds.em_pdf);
+                        ds.pdf *= ds.em_pdf;
+                    }
+                }
+            }
+            if (!iszero3(value)) {
+                const F3 wo_e = to_local(I, ds.d);
+                const float woDotGeoNE = dot3(I.geoN, ds.d);
+                if (!R.strict_normals || woDotGeoNE * wo_e.z > 0) {
+                    const F3 bsdfVal = b_eval(I.wi, wo_e);
+                    float woPdfE = 0, bsdfPdfE = 0, dTreePdfE = 0;  // pdfMat, GP:1693-1710
+                    if (!T.is_built) {
+                        woPdfE = bsdfPdfE = b_pdf(I.wi, wo_e);
+                    } else {
+                        bsdfPdfE = b_pdf(I.wi, wo_e);
+                        if (ppg_isfinite(bsdfPdfE)) {
+                            float cx, cy;
+                            dir_to_canonical(to_world(I, wo_e), cx, cy);
+                            dTreePdfE = dtree_pdf(T, hd, cx, cy, fcol);
+                            woPdfE = frac * bsdfPdfE + (1 - frac) * dTreePdfE;
+                        }
+                    }
+                    const float qa = ds.pdf * ds.pdf, qb = woPdfE * woPdfE;
+                    const float weightE = qa / (qa + qb);
+                    value = mul3(value, bsdfVal);
+                    const F3 L = mul3(thr, value) * weightE;
+                    if (!R.is_final_iter && R.nee != NEE_ALWAYS) {  // the direct-light vertex, GP:1994-2010
+                        Rec rec;
+                        if (vertex_to_rec(L, bsdfVal, div3(mul3(thr, bsdfVal), ds.pdf), ds.pdf, bsdfPdfE, dTreePdfE, ds.d, false, 0.5f, rec)) {
+                            rec.adamPath = adam_path_id(P, R, i);
+                            rec.adamCode = depth < (unsigned int)PPG_ADAM_CODE_VERTEX ? depth : (unsigned int)PPG_ADAM_CODE_VERTEX - 1u;
+                            rec.adamPos = 0xffffffffu;
+                            commit_single(T, R.spatial_filter, R.directional_filter, T.is_built ? R.loss : LOSS_NONE, leaf, I.p, vox, rec,
+                                          key, PPG_DIM_NEE_COMMIT + 3u * depth);
+                            ++committed;
+                        }
+                    }
+                    if (!iszero3(L)) {  // recordRadiance, GP:1791-1796
+                        Li = Li + L;
+                        for (unsigned int v0 = 0; v0 < nV; ++v0) {
+                            float4 rr = P.v_rad[(size_t)v0 * P.n_paths + i];
+                            rr.x += L.x; rr.y += L.y; rr.z += L.z;
+                            P.v_rad[(size_t)v0 * P.n_paths + i] = rr;
+                        }
+                    }
+                }
+            }
+        }
+        if (iszero3(bsdfWeight)) go = false;  // GP:2024-2025
+        if (go) {
+            const F3 wo = to_world(I, wo_l);
+            float woDotGeoN = dot3(I.geoN, wo);
+            if (woDotGeoN * wo_l.z <= 0 && R.strict_normals) go = false;  // GP:2031-2032
+            if (go) {
+                thr = mul3(thr, bsdfWeight);  // GP:2039-2040
+                if (FULL) eta *= sampledEta;
+                d = wo;
+                if (FUSED) {
+                    Hit hn = trace_small(lds_tris, S, I.p, wo, PPG_EPSILON, __builtin_inff());
+                    P.hit[i] = make_float4(hn.t, hn.u, hn.v, __int_as_float(hn.prim));
+                    ++traced;
+                } else {
+                    P.ray_o[i] = make_float4(I.p.x, I.p.y, I.p.z, PPG_EPSILON);
+                }
+                P.ray_d[i] = make_float4(wo.x, wo.y, wo.z, __builtin_inff());
+                if (smooth && nV < PPG_MAX_VERTICES && nV < (unsigned int)R.max_vertices && !R.is_final_iter) {
+                    size_t vi = (size_t)nV * P.n_paths + i;
+                    F3 bv = bsdfWeight * woPdf;
+                    P.v_d[vi] = make_float4(wo.x, wo.y, wo.z, woPdf);
+                    P.v_thr[vi] = make_float4(thr.x, thr.y, thr.z, bsdfPdf);
+                    P.v_bsdf[vi] = make_float4(bv.x, bv.y, bv.z, dTreePdf);
+                    if (P.v_o) {
+                        P.v_o[vi] = make_float4(I.p.x, I.p.y, I.p.z, 0.0f);
+                        P.v_vox[vi] = make_float4(vox.x, vox.y, vox.z, 0.0f);
+                    }
+                }
+                flags |= FL_PENDING | (smooth ? FL_PEND_TREE : 0u) | (sampledDelta ? FL_PEND_DELTA : 0u);
+                if (NEE && dot3(wo, refN) >= 0) flags |= FL_PEND_REFN;
+                if (NEE && FULL && P.nee_cos) P.nee_cos[i] = noRefN ? -2.0f : dot3(wo, refN);
+                if (FULL && sampledNull) {
+                    // GP:2045-2075: a sampled null interaction.  Smooth/null hybrids (mask) record it for the sampling-fraction
+                    // optimiser (GP:2047-2068): the slot's d / throughput / bsdfVal were written just above; radiance stays 0, delta.
+                    flags |= FL_PEND_NULL;
+                    if (R.loss != LOSS_NONE && smooth && nV < PPG_MAX_VERTICES && nV < (unsigned int)R.max_vertices && !R.is_final_iter) {
+                        if (1 / woPdf > 0) {
+                            P.v_rad[(size_t)nV * P.n_paths + i] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float((unsigned int)leaf | 0x80000000u));
+                            ++nV;
+                        }
+                    }
+                }
+                m.w = (unsigned int)leaf;
+                l4.w = woPdf;
+                alive = true;
+            }
+        }
+    }
+    flags = (flags & ~(FL_DEPTH_MASK | FL_NV_MASK)) | (depth & FL_DEPTH_MASK) | (nV << FL_NV_SHIFT);
+    P.misc[i] = make_uint4(key, dim, flags, m.w);
+    P.li[i] = make_float4(Li.x, Li.y, Li.z, l4.w);
+    if (alive) P.thr[i] = make_float4(thr.x, thr.y, thr.z, eta);
+    else plen = depth;  // avgPathLength += rRec.depth, GP:2147-2148
+    }
+    return alive;
+}
+
+// One queue slice through Li's loop body.
 template <bool FUSED, bool NEE, bool FULL>
 D void shade_slice(const PathState &P, const DevScene &S, const DevTree &T, const RenderParams &R, const unsigned int *items, unsigned int count,
                    unsigned int b, unsigned int nb, unsigned int *out_items, unsigned int *out_count, const LdsColumn &fcol,
@@ -677,354 +1037,7 @@ D void shade_slice(const PathState &P, const DevScene &S, const DevTree &T, cons
             active = i < P.n_paths;
         }
         if (active) {
-            uint4 m = P.misc[i];
-            unsigned int key = m.x, dim = m.y, flags = m.z;
-            unsigned int depth = flags & FL_DEPTH_MASK;
-            unsigned int nV = (flags & FL_NV_MASK) >> FL_NV_SHIFT;
-            float4 t4 = P.thr[i], l4 = P.li[i], h4 = P.hit[i], d4 = P.ray_d[i];
-            F3 thr = f3(t4.x, t4.y, t4.z);
-            float eta = t4.w;
-            F3 Li = f3(l4.x, l4.y, l4.z);
-            F3 d = f3(d4.x, d4.y, d4.z);
-            Hit h;
-            h.t = h4.x; h.u = h4.y; h.v = h4.z; h.prim = __float_as_int(h4.w);
-            const bool valid = h.prim >= 0;
-            Isect I;
-            if (valid) {
-                if (FULL && h.prim >= S.n_tris) {
-                    const float4 ro4 = P.ray_o[i];
-                    fill_isect_sphere(S, h, f3(ro4.x, ro4.y, ro4.z), d, I);
-                } else fill_isect(S, h, d, I);
-            }
-            bool go = true;
-
-            if (FULL && (flags & FL_PENDING) && (flags & FL_PEND_NULL)) {
-                // ---- the previous bounce passed straight through a null component, GP:2045-2075: no emitter lookup, no MIS,
-                // no Russian roulette; rRec.type = scattered ? ERadianceNoEmission : ERadiance; rRec.depth++; continue ----
-                if (flags & FL_SCATTERED) flags &= ~FL_EMITTED_OK; else flags |= FL_EMITTED_OK;
-                ++depth;
-                if (!((int)depth <= R.max_depth || R.max_depth < 0)) go = false;
-                flags &= ~(FL_PENDING | FL_PEND_TREE | FL_PEND_DELTA | FL_PEND_REFN | FL_PEND_NULL);
-            } else if (flags & FL_PENDING) {
-                // ---- second half of the previous bounce: GP:2078-2145 ----
-                F3 value = valid ? eval_Le(S, I, -d) : f3s(0.0f);  // rayIntersectAndLookForEmitter, GP:2229-2234
-                // dRec.setQuery(ray, its) of the emitter that was found (records.inl:170-178)
-                F3 em_n = I.n;
-                float em_dist = h.t;
-                int em_id = I.emitter;
-                if (FULL && !valid && S.env.w != 0) {  // GP:2236-2243: the ray left the scene
-                    const float4 ro4 = P.ray_o[i];
-                    if (env_fill_direct(S, f3(ro4.x, ro4.y, ro4.z), d)) { value = env_radiance(S, d); em_id = S.n_emitters; }
-                }
-                if (FULL && S.has_null && valid && I.emitter < 0) {
-                    // rayIntersectAndLookForEmitter GP:2184-2245: the path continues from THIS hit, but the search for an emitter
-                    // goes on through surfaces that have a null component (traced in place)
-                    Mat Mc = load_material(S, I.material);
-                    if (mat_has_null(Mc)) {
-                        const float4 ro4 = P.ray_o[i];
-                        F3 ro = f3(ro4.x, ro4.y, ro4.z);
-                        F3 transmittance = f3s(1.0f);
-                        const int maxInteractions = R.max_depth - (int)depth - 1;
-                        int interactions = 0;
-                        bool abandoned = false, surface = true;
-                        Hit hc = h;
-                        Isect Ic = I;
-                        for (;;) {
-                            if (interactions == maxInteractions || !mat_has_null(Mc) || Ic.emitter >= 0) break;
-                            if (iszero3(transmittance)) { abandoned = true; break; }
-                            const float cosThetaI = -to_local(Ic, d).z;  // bRec(its, -wo, wo) in the shading frame
-                            transmittance = mul3(transmittance, mat_eval_null(Mc, cosThetaI));
-                            ro = ro + d * hc.t;
-                            if (++interactions > 100) { abandoned = true; break; }
-                            hc = trace_inline(S, nee.small_tris, nee.stack_col, ro, d, __builtin_inff());
-                            ++traced;
-                            if (hc.prim < 0) { surface = false; break; }
-                            fill_isect_full(S, hc, ro, d, Ic);
-                            Mc = load_material(S, Ic.material);
-                        }
-                        if (!abandoned && surface && Ic.emitter >= 0) {
-                            value = mul3(transmittance, eval_Le(S, Ic, -d));
-                            em_n = Ic.n; em_dist = hc.t; em_id = Ic.emitter;  // dist from the LAST ray origin, as in the reference
-                        } else if (!abandoned && !surface && S.env.w != 0 && env_fill_direct(S, ro, d)) {
-                            value = mul3(transmittance, env_radiance(S, d));
-                            em_id = S.n_emitters;
-                        }
-                    }
-                }
-                const float woPdf = l4.w;
-                const bool isDelta = (flags & FL_PEND_DELTA) != 0;
-                const bool hasTree = (flags & FL_PEND_TREE) != 0;
-                float emitterPdf = 0.0f;  // GP:2085: scene->pdfEmitterDirect(dRec) (scene.cpp:949-952, area.cpp:175-183, shape.cpp:117-126)
-                if (NEE && R.do_nee && !isDelta && !iszero3(value)) {
-                    float pdfDirect = 0.0f;
-                    const float dn = dot3(d, em_n);
-                    if (FULL && em_id == S.n_emitters) {
-                        pdfDirect = S.env.w == 2.0f ? envmap_pdf_direction(S, envmap_to_local(S, d)) : env_pdf_direct(P.nee_cos[i]);
-                    } else if ((flags & FL_PEND_REFN) && dn < 0) {
-                        const int4 info = S.em_info[em_id];
-                        if (FULL && info.y < 0) {  // Sphere::pdfDirect needs dRec.ref = the previous vertex = this ray's origin
-                            const float4 ro4 = P.ray_o[i];
-                            pdfDirect = sphere_pdf_direct(S.spheres + 4 * (-info.y - 1), f3(ro4.x, ro4.y, ro4.z), d, em_n, em_dist);
-                        } else pdfDirect = __int_as_float(info.w) * (em_dist * em_dist) / ppg_abs(dn);
-                    }
-                    emitterPdf = pdfDirect * (1.0f * S.em_sel_norm);
-                }
-                float pa = woPdf * woPdf, pb = emitterPdf * emitterPdf;  // miWeight(woPdf, emitterPdf), GP:2247-2250
-                const float weight = pa / (pa + pb);
-                F3 L = mul3(thr, value) * weight;
-                if (!iszero3(L)) {  // recordRadiance, GP:1791-1796
-                    Li = Li + L;
-                    for (unsigned int v0 = 0; v0 < nV; v0 += 4) {  // 4 independent loads in flight, then 4 stores
-                        float4 rr[4];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            if (v0 + k < nV) rr[k] = P.v_rad[(size_t)(v0 + k) * P.n_paths + i];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            if (v0 + k < nV) {
-                                rr[k].x += L.x; rr[k].y += L.y; rr[k].z += L.z;
-                                P.v_rad[(size_t)(v0 + k) * P.n_paths + i] = rr[k];
-                            }
-                    }
-                }
-                if ((!isDelta || R.loss != LOSS_NONE) && hasTree && nV < PPG_MAX_VERTICES && nV < (unsigned int)R.max_vertices &&
-                    !R.is_final_iter) {
-                    if (1 / woPdf > 0) {  // the other vertex fields were written when the bounce was sampled
-                        F3 rad = (R.nee == NEE_ALWAYS) ? f3s(0.0f) : L;
-                        unsigned int bits = m.w | (isDelta ? 0x80000000u : 0u);
-                        P.v_rad[(size_t)nV * P.n_paths + i] = make_float4(rad.x, rad.y, rad.z, __uint_as_float(bits));
-                        ++nV;
-                    }
-                }
-                flags &= ~FL_EMITTED_OK;  // rRec.type = ERadianceNoEmission
-                if (depth++ >= (unsigned int)R.rr_depth) {  // Russian roulette, GP:2124-2142
-                    float successProb = 1.0f;
-                    if (hasTree && !isDelta) {
-                        if (!T.is_built) successProb = max3(thr) * eta * eta;
-                        successProb = ppg_max(0.1f, ppg_min(successProb, 0.99f));
-                    }
-                    if (ppg_rand(key, dim++) >= successProb) go = false;
-                    else thr = div3(thr, successProb);
-                }
-                if (go) {
-                    flags |= FL_SCATTERED;
-                    if (!((int)depth <= R.max_depth || R.max_depth < 0)) go = false;
-                }
-                flags &= ~(FL_PENDING | FL_PEND_TREE | FL_PEND_DELTA | FL_PEND_REFN);
-            }
-
-            // ---- first half of this bounce: GP:1902-2040 ----
-            if (go && !valid) {  // GP:1902-1914: possibly radiance from a background luminaire, then the path ends
-                if (FULL && S.env.w != 0 && (flags & FL_EMITTED_OK) && (!R.hide_emitters || (flags & FL_SCATTERED)))
-                    Li = Li + mul3(thr, env_radiance(S, d));  // (nVertices == 0 whenever emission is still enabled)
-                go = false;
-            }
-            if (go) {
-                if (I.emitter >= 0 && (flags & FL_EMITTED_OK) && (!R.hide_emitters || (flags & FL_SCATTERED)))
-                    Li = Li + mul3(thr, eval_Le(S, I, -d));  // GP:1917-1919 (nVertices == 0 here)
-                if ((int)depth >= R.max_depth && R.max_depth != -1) go = false;
-            }
-            if (go) {
-                float wiDotGeoN = -dot3(I.geoN, d), wiDotShN = I.wi.z;
-                if (wiDotGeoN * wiDotShN < 0 && R.strict_normals) go = false;
-            }
-            if (go) {
-                Mat M;
-                if (FULL) {
-                    M = load_material(S, I.material);
-                } else {
-                    const float4 mat = S.materials[PPG_MAT_STRIDE * (size_t)I.material];
-                    M.type = (int)mat.w; M.flags = 0; M.refl = f3(mat.x, mat.y, mat.z);
-                }
-                const bool smooth = FULL ? mat_is_smooth(M) : bsdf_is_smooth(M.type);  // bsdf->getType() & ESmooth: only those are guided
-                auto b_eval = [&](F3 wi_, F3 wo_) { return FULL ? mat_eval(M, wi_, wo_) : bsdf_eval(M.type, M.refl, wi_, wo_); };
-                auto b_pdf = [&](F3 wi_, F3 wo_) { return FULL ? mat_pdf(M, wi_, wo_) : bsdf_pdf(M.type, wi_, wo_); };
-                float sampledEta = 1.0f;
-                bool sampledNull = false;
-                auto b_sample = [&](float u_, float v_, F3 &wo_, float &pdf_, bool &delta_) {
-                    return FULL ? mat_sample(M, I.wi, u_, v_, wo_, pdf_, delta_, sampledEta, sampledNull, key, dim)
-                                : bsdf_sample(M.type, M.refl, I.wi, u_, v_, wo_, pdf_, delta_);
-                };
-                F3 vox = f3s(0.0f);
-                int leaf = 0;
-                DTreeRef hd;
-                hd.s_base = 0; hd.s_sum = 0; hd.s_statw = 0;
-                float frac = R.bsdf_sampling_fraction;  // GP:1946-1949
-                if (smooth) {
-                    leaf = stree_lookup(T, I.p, vox);  // GP:1942-1944
-                    const float4 h4 = *reinterpret_cast<const float4 *>(&T.hdr[leaf]);  // {s_base, s_num, s_sum, s_statw}
-                    hd.s_base = __float_as_uint(h4.x); hd.s_sum = h4.z; hd.s_statw = h4.w;
-                    if (R.loss != LOSS_NONE) frac = logistic(T.hdr[leaf].theta);
-                }
-
-                // sampleMat, GP:1650-1691
-                float sx = ppg_rand(key, dim++);
-                float sy = ppg_rand(key, dim++);
-                F3 wo_l, bsdfWeight;
-                float woPdf, bsdfPdf, dTreePdf;
-                bool sampledDelta = false;
-                if (!T.is_built || !smooth) {  // !m_isBuilt || !dTree || all components are delta
-                    bsdfWeight = b_sample(sx, sy, wo_l, bsdfPdf, sampledDelta);
-                    woPdf = bsdfPdf;
-                    dTreePdf = 0;
-                } else {
-                    F3 result;
-                    bool zero = false, deltaEarly = false;
-                    if (sx < frac) {
-                        sx /= frac;
-                        result = b_sample(sx, sy, wo_l, bsdfPdf, sampledDelta);
-                        if (iszero3(result)) zero = true;
-                        else if (FULL && sampledDelta) deltaEarly = true;  // GP:1672-1676: a delta lobe of a mixed BSDF
-                        else result = result * bsdfPdf;
-                    } else {
-                        // sample.x is remapped but unused on this branch (GP:1680-1682)
-                        float cx, cy;
-                        dtree_sample(T, hd, key, dim, cx, cy);
-                        wo_l = to_local(I, canonical_to_dir(cx, cy));
-                        sampledEta = 1.0f; sampledNull = false;
-                        result = b_eval(I.wi, wo_l);
-                    }
-                    if (zero) {
-                        woPdf = bsdfPdf = dTreePdf = 0;
-                        bsdfWeight = f3s(0.0f);
-                        wo_l = f3s(0.0f);
-                    } else if (deltaEarly) {
-                        dTreePdf = 0;
-                        woPdf = bsdfPdf * frac;
-                        bsdfWeight = div3(result, frac);
-                    } else {
-                        // pdfMat, GP:1693-1710
-                        dTreePdf = 0;
-                        bsdfPdf = b_pdf(I.wi, wo_l);
-                        if (!ppg_isfinite(bsdfPdf)) {
-                            woPdf = 0;
-                        } else {
-                            float cx, cy;
-                            dir_to_canonical(to_world(I, wo_l), cx, cy);
-                            dTreePdf = dtree_pdf(T, hd, cx, cy, fcol);
-                            woPdf = frac * bsdfPdf + (1 - frac) * dTreePdf;
-                        }
-                        bsdfWeight = (woPdf == 0) ? f3s(0.0f) : div3(result, woPdf);
-                    }
-                }
-                // Luminaire sampling, GP:1962-2021
-                const bool noRefN = FULL ? mat_backside_or_transmission(M) : (M.type == PPG_BSDF_TWOSIDED_DIFFUSE);
-                const F3 refN = noRefN ? f3s(0.0f) : I.n;  // DirectSamplingRecord(its), records.inl:160-164
-                if (NEE && R.do_nee && smooth) {
-                    const float ex = ppg_rand(key, dim++);
-                    const float ey = ppg_rand(key, dim++);
-                    DirectSample ds;
-                    F3 value = emitter_sample_direct(S, I.p, refN, ex, ey, ds);
-                    if (ds.pdf != 0) {
-                        if (FULL && S.has_null) {  // value *= evalTransmittance(...) / emPdf, scene.cpp:887-889
-                            const F3 tr = shadow_transmittance(S, nee.small_tris, nee.stack_col, I.p, ds.sd, ds.sdist, ds.is_env ? 1.0f : 1 - PPG_SHADOW_EPSILON,
-                                                               R.max_depth - (int)depth - 1, traced);
-                            if (iszero3(tr)) value = f3s(0.0f);
-                            else { value = div3(mul3(value, tr), ds.em_pdf); ds.pdf *= ds.em_pdf; }
-                        } else {
-                            ++traced;
-                            if (shadow_occluded<FULL>(S, nee.small_tris, nee.stack_col, I.p, ds.sd, ds.sdist * ((FULL && ds.is_env) ? 1.0f : 1 - PPG_SHADOW_EPSILON))) {
-                                value = f3s(0.0f);
-                            } else {
-                                value = div3(value, ds.em_pdf);
-                                ds.pdf *= ds.em_pdf;
-                            }
-                        }
-                    }
-                    if (!iszero3(value)) {
-                        const F3 wo_e = to_local(I, ds.d);
-                        const float woDotGeoNE = dot3(I.geoN, ds.d);
-                        if (!R.strict_normals || woDotGeoNE * wo_e.z > 0) {
-                            const F3 bsdfVal = b_eval(I.wi, wo_e);
-                            float woPdfE = 0, bsdfPdfE = 0, dTreePdfE = 0;  // pdfMat, GP:1693-1710
-                            if (!T.is_built) {
-                                woPdfE = bsdfPdfE = b_pdf(I.wi, wo_e);
-                            } else {
-                                bsdfPdfE = b_pdf(I.wi, wo_e);
-                                if (ppg_isfinite(bsdfPdfE)) {
-                                    float cx, cy;
-                                    dir_to_canonical(to_world(I, wo_e), cx, cy);
-                                    dTreePdfE = dtree_pdf(T, hd, cx, cy, fcol);
-                                    woPdfE = frac * bsdfPdfE + (1 - frac) * dTreePdfE;
-                                }
-                            }
-                            const float qa = ds.pdf * ds.pdf, qb = woPdfE * woPdfE;
-                            const float weightE = qa / (qa + qb);
-                            value = mul3(value, bsdfVal);
-                            const F3 L = mul3(thr, value) * weightE;
-                            if (!R.is_final_iter && R.nee != NEE_ALWAYS) {  // the direct-light vertex, GP:1994-2010
-                                Rec rec;
-                                if (vertex_to_rec(L, bsdfVal, div3(mul3(thr, bsdfVal), ds.pdf), ds.pdf, bsdfPdfE, dTreePdfE, ds.d, false, key,
-                                                  PPG_SLOT_NEE + depth, 0.5f, rec)) {
-                                    commit_single(T, R.spatial_filter, R.directional_filter, T.is_built ? R.loss : LOSS_NONE, leaf, I.p, vox, rec,
-                                                  key, PPG_DIM_NEE_COMMIT + 3u * depth);
-                                    ++committed;
-                                }
-                            }
-                            if (!iszero3(L)) {  // recordRadiance, GP:1791-1796
-                                Li = Li + L;
-                                for (unsigned int v0 = 0; v0 < nV; ++v0) {
-                                    float4 rr = P.v_rad[(size_t)v0 * P.n_paths + i];
-                                    rr.x += L.x; rr.y += L.y; rr.z += L.z;
-                                    P.v_rad[(size_t)v0 * P.n_paths + i] = rr;
-                                }
-                            }
-                        }
-                    }
-                }
-                if (iszero3(bsdfWeight)) go = false;  // GP:2024-2025
-                if (go) {
-                    const F3 wo = to_world(I, wo_l);
-                    float woDotGeoN = dot3(I.geoN, wo);
-                    if (woDotGeoN * wo_l.z <= 0 && R.strict_normals) go = false;  // GP:2031-2032
-                    if (go) {
-                        thr = mul3(thr, bsdfWeight);  // GP:2039-2040
-                        if (FULL) eta *= sampledEta;
-                        d = wo;
-                        if (FUSED) {
-                            Hit hn = trace_small(lds_tris, S, I.p, wo, PPG_EPSILON, __builtin_inff());
-                            P.hit[i] = make_float4(hn.t, hn.u, hn.v, __int_as_float(hn.prim));
-                            ++traced;
-                        } else {
-                            P.ray_o[i] = make_float4(I.p.x, I.p.y, I.p.z, PPG_EPSILON);
-                        }
-                        P.ray_d[i] = make_float4(wo.x, wo.y, wo.z, __builtin_inff());
-                        if (smooth && nV < PPG_MAX_VERTICES && nV < (unsigned int)R.max_vertices && !R.is_final_iter) {
-                            size_t vi = (size_t)nV * P.n_paths + i;
-                            F3 bv = bsdfWeight * woPdf;
-                            P.v_d[vi] = make_float4(wo.x, wo.y, wo.z, woPdf);
-                            P.v_thr[vi] = make_float4(thr.x, thr.y, thr.z, bsdfPdf);
-                            P.v_bsdf[vi] = make_float4(bv.x, bv.y, bv.z, dTreePdf);
-                            if (P.v_o) {
-                                P.v_o[vi] = make_float4(I.p.x, I.p.y, I.p.z, 0.0f);
-                                P.v_vox[vi] = make_float4(vox.x, vox.y, vox.z, 0.0f);
-                            }
-                        }
-                        flags |= FL_PENDING | (smooth ? FL_PEND_TREE : 0u) | (sampledDelta ? FL_PEND_DELTA : 0u);
-                        if (NEE && dot3(wo, refN) >= 0) flags |= FL_PEND_REFN;
-                        if (NEE && FULL && P.nee_cos) P.nee_cos[i] = noRefN ? -2.0f : dot3(wo, refN);
-                        if (FULL && sampledNull) {
-                            // GP:2045-2075: a sampled null interaction.  Smooth/null hybrids (mask) record it for the sampling-fraction
-                            // optimiser (GP:2047-2068): the slot's d / throughput / bsdfVal were written just above; radiance stays 0, delta.
-                            flags |= FL_PEND_NULL;
-                            if (R.loss != LOSS_NONE && smooth && nV < PPG_MAX_VERTICES && nV < (unsigned int)R.max_vertices && !R.is_final_iter) {
-                                if (1 / woPdf > 0) {
-                                    P.v_rad[(size_t)nV * P.n_paths + i] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float((unsigned int)leaf | 0x80000000u));
-                                    ++nV;
-                                }
-                            }
-                        }
-                        m.w = (unsigned int)leaf;
-                        l4.w = woPdf;
-                        alive = true;
-                    }
-                }
-            }
-            flags = (flags & ~(FL_DEPTH_MASK | FL_NV_MASK)) | (depth & FL_DEPTH_MASK) | (nV << FL_NV_SHIFT);
-            P.misc[i] = make_uint4(key, dim, flags, m.w);
-            P.li[i] = make_float4(Li.x, Li.y, Li.z, l4.w);
-            if (alive) P.thr[i] = make_float4(thr.x, thr.y, thr.z, eta);
-            else plen = depth;  // avgPathLength += rRec.depth, GP:2147-2148
+            alive = shade_one<FUSED, NEE, FULL>(P, S, T, R, i, fcol, lds_tris, plen, traced, nee, committed);
         }
         unsigned int slot = queue_append(out_count, alive);
         if (alive) out_items[slot] = i;
@@ -1065,46 +1078,69 @@ __global__ __launch_bounds__(PPG_BLOCK, PPG_SHADE_WAVES) void k_shade(PathState 
     if (NEE) block_add_u64(&acc, &Q.stats[b].committed, committed);
 }
 
-// Tail of unbounded paths (maxDepth < 0): once few paths are left, every workgroup keeps bouncing its own queue
-// slice — trace phase, shade phase, swap — until the slice is empty, inside ONE launch.  The slices are private
-// to a workgroup, so no grid-wide synchronisation (and no host round trip per bounce) is needed.
+// Tail of unbounded paths (maxDepth < 0): persistent threads.  The reference's Russian roulette keeps a guided path alive with
+// probability 0.99 (GP:2125-2137): after the bulk bounces a few per cent of the paths are left, and a handful of them go on for
+// hundreds of bounces.  Every LANE takes one surviving path from the dense list (wave-aggregated global ticket) and carries it
+// through trace → shade → trace → ... until it ends, then takes the next one: no queues, no barriers between bounces, all
+// workgroups share one list (work stealing), and the run time of the launch is the longest path's chain of dependent loads
+// rather than (number of bounces) x (launch + barrier latency).
 template <bool SMALL, bool NEE, bool FULL>
-__global__ __launch_bounds__(PPG_BLOCK, PPG_SHADE_WAVES) void k_tail(PathState P, DevScene S, DevTree T, RenderParams R, Queues Q, int qin,
-                                                                    int lds_nodes, int lds_tris) {
+__global__ __launch_bounds__(PPG_BLOCK, PPG_SHADE_WAVES) void k_tail(PathState P, DevScene S, DevTree T, RenderParams R, const unsigned int *dense,
+                                                                    const unsigned long long *total_ptr, unsigned int *ticket, BlockStats *stats,
+                                                                    int lds_tris) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __shared__ float pdf_factors[20 * PPG_BLOCK];
-    __shared__ unsigned int out_count, ticket;
     __shared__ unsigned long long acc;
     const LdsColumn fcol{pdf_factors + threadIdx.x, PPG_BLOCK};
-    const unsigned int b = blockIdx.x, nb = gridDim.x;
-    unsigned int count = Q.count[qin][b];
-    if (count == 0) return;
+    const unsigned int total = (unsigned int)*total_ptr;
     LdsScene L;
     if (SMALL) L = stage_scene(S, lds_raw, 0, lds_tris);
     else { L.nodes = nullptr; L.tris = nullptr; L.n_nodes = 0; L.n_tris = 0; }
     NeeLds nee;
-    nee.small_tris = SMALL ? L.tris : nullptr;   // SMALL: all triangles are staged
-    nee.stack_col = (int *)lds_raw + threadIdx.x;  // !SMALL: the trace phase's stack columns are idle during the shade phase
+    nee.small_tris = SMALL ? L.tris : nullptr;     // SMALL: all triangles are staged
+    nee.stack_col = (int *)lds_raw + threadIdx.x;  // !SMALL: this lane's BVH stack column (trace and shade never overlap in a lane)
     unsigned long long plen_sum = 0, committed = 0;
-    unsigned int traced = 0, shadow = 0;
-    int cur = qin;
-    while (count > 0) {
-        const unsigned int *items = Q.items[cur] + (size_t)b * Q.cap;
-        trace_slice<SMALL>(P, S, L, (int *)lds_raw, &ticket, items, count, b, nb, traced);
-        __syncthreads();  // hits written by any lane of the workgroup are read by the shade phase
-        if (threadIdx.x == 0) out_count = 0;
-        __syncthreads();
-        shade_slice<false, NEE, FULL>(P, S, T, R, items, count, b, nb, Q.items[cur ^ 1] + (size_t)b * Q.cap, &out_count, fcol, L.tris, plen_sum,
-                                      shadow, nee, committed);
-        __syncthreads();  // queue writes of this workgroup are visible to it after the barrier (same CU, write-through L1)
-        count = out_count;
-        cur ^= 1;
-        __syncthreads();
+    unsigned int traced = 0;
+    const int lane = threadIdx.x & 63;
+    bool have = false, drained = false;
+    unsigned int i = 0;
+    for (;;) {
+        const unsigned long long need = __ballot(!have && !drained);
+        if (need) {
+            const int leader = __ffsll((long long)need) - 1;
+            unsigned int base = 0;
+            if (lane == leader) base = atomicAdd(ticket, (unsigned int)__popcll(need));
+            base = __shfl(base, leader);
+            if (!have && !drained) {
+                const unsigned int k = base + (unsigned int)__popcll(need & ((1ull << lane) - 1ull));
+                if (k < total) { i = dense[k]; have = true; }
+                else drained = true;
+            }
+        }
+        if (!__any(have)) break;
+        if (have) {
+            const float4 ro = P.ray_o[i], rd = P.ray_d[i];
+            const F3 o = f3(ro.x, ro.y, ro.z), d = f3(rd.x, rd.y, rd.z);
+            Hit h;
+            if (SMALL) {
+                h = trace_small(L.tris, S, o, d, ro.w, rd.w);
+            } else {
+                float mint = ro.w;
+                if (mint == PPG_EPSILON)  // adaptive ray epsilon, skdtree.cpp:125-129
+                    mint *= ppg_max(ppg_max(ppg_max(ppg_abs(o.x), ppg_abs(o.y)), ppg_abs(o.z)), PPG_EPSILON);
+                h = trace_closest4<false, true>(S, nee.stack_col, PPG_BLOCK, o, d, mint, rd.w);
+            }
+            P.hit[i] = make_float4(h.t, h.u, h.v, __int_as_float(h.prim));
+            ++traced;
+            unsigned long long plen = 0;
+            const bool alive = shade_one<false, NEE, FULL>(P, S, T, R, i, fcol, L.tris, plen, traced, nee, committed);
+            plen_sum += plen;
+            if (!alive) have = false;
+        }
     }
-    if (threadIdx.x == 0) { Q.count[0][b] = 0; Q.count[1][b] = 0; }
-    block_add_u64(&acc, &Q.stats[b].path_len, plen_sum);
-    block_add_u64(&acc, &Q.stats[b].rays, traced + ((NEE || FULL) ? shadow : 0u));
-    if (NEE) block_add_u64(&acc, &Q.stats[b].committed, committed);
+    block_add_u64(&acc, &stats[blockIdx.x].path_len, plen_sum);
+    block_add_u64(&acc, &stats[blockIdx.x].rays, traced);
+    if (NEE) block_add_u64(&acc, &stats[blockIdx.x].committed, committed);
 }
 
 // copy every workgroup's queue slice into one dense array (offsets = exclusive scan of the slice counts)
@@ -1154,7 +1190,7 @@ __global__ __launch_bounds__(PPG_BLOCK) void k_commit(PathState P, DevTree T, Re
         if (!__any(act)) continue;
         Rec rec;
         rec.d = f3s(0.0f); rec.radiance = rec.product = rec.woPdf = rec.bsdfPdf = rec.dTreePdf = 0; rec.statisticalWeight = statisticalWeight;
-        rec.isDelta = false; rec.adamBatch = 0;
+        rec.isDelta = false; rec.adamPath = 0; rec.adamCode = 0; rec.adamPos = 0xffffffffu;
         int leaf = 0;
         const size_t vi = (size_t)v * P.n_paths + i;
         if (act) {
@@ -1163,11 +1199,16 @@ __global__ __launch_bounds__(PPG_BLOCK) void k_commit(PathState P, DevTree T, Re
             F3 radiance = f3(e.x, e.y, e.z), bsdfVal = f3(c.x, c.y, c.z), throughput = f3(b.x, b.y, b.z);
             unsigned int bits = __float_as_uint(e.w);
             const bool isDelta = (bits & 0x80000000u) != 0;
-            if (!vertex_to_rec(radiance, bsdfVal, throughput, woPdf, bsdfPdf, dTreePdf, f3(a.x, a.y, a.z), isDelta, key, v, statisticalWeight, rec)) {
+            if (!vertex_to_rec(radiance, bsdfVal, throughput, woPdf, bsdfPdf, dTreePdf, f3(a.x, a.y, a.z), isDelta, statisticalWeight, rec)) {
                 act = false;
             } else {
                 leaf = (int)(bits & 0x7fffffffu);
                 ++committed_sum;
+                if (loss != LOSS_NONE) {
+                    rec.adamPath = adam_path_id(P, R, i);
+                    rec.adamCode = (unsigned int)PPG_ADAM_CODE_VERTEX + v;
+                    rec.adamPos = T.adam_base ? T.adam_base[i] + v : 0xffffffffu;
+                }
             }
         }
         if (SF == SF_BOX) {
@@ -1187,7 +1228,7 @@ __global__ __launch_bounds__(PPG_BLOCK) void k_commit(PathState P, DevTree T, Re
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_adam_step — one AdamOptimizer::step (GP:97-109) per D-tree and pass from the exact per-pass sums
+// Per-round application of the sampling-fraction optimiser's records
 // ------------------------------------------------------------------------------------------------
 // compact[i] += Σ_r rep[i][r]; rep = 0.  Idempotent (a second call adds zeros).
 __global__ void k_fold_replicas(unsigned long long *compact, unsigned long long *rep, unsigned int n_nodes) {
@@ -1201,31 +1242,96 @@ __global__ void k_fold_replicas(unsigned long long *compact, unsigned long long 
     if (s) compact[i] += s;
 }
 
-// AdamOptimizer::step (GP:97-109) for every mini-batch of every D-tree whose accumulated weight exceeds batchSize
-// (= 1), in mini-batch order; lighter mini-batches keep accumulating (append(), GP:85-95).
-__global__ void k_adam_step(DevTree T, unsigned int n_nodes) {
+// nv[i] = number of vertices path i recorded = the number of positions it owns in the Adam record buffer (fast mode)
+__global__ void k_path_nv(PathState P, unsigned int *nv) {
     unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_nodes) return;
-    LeafHdr h = T.hdr[i];
-    bool stepped = false;
-    for (int k = 0; k < PPG_ADAM_BATCHES; ++k) {
-        const size_t ak = (size_t)i * PPG_ADAM_BATCHES + k;
-        unsigned long long wacc = T.adam_w[ak];
-        if (wacc == 0) continue;
-        float w = ppg_from_fixed(wacc);
-        if (!(w > 1.0f)) continue;  // batchAccumulation > batchSize
-        float gradient = ppg_from_sfixed(T.adam_grad[ak]) / w;
-        ++h.adam_iter;
-        float lr = 0.01f * __builtin_sqrtf(1 - ppg_powi(0.999f, h.adam_iter)) / (1 - ppg_powi(0.9f, h.adam_iter));
-        h.adam_m = 0.9f * h.adam_m + (1 - 0.9f) * gradient;
-        h.adam_v = 0.999f * h.adam_v + (1 - 0.999f) * gradient * gradient;
-        h.theta -= lr * h.adam_m / (__builtin_sqrtf(h.adam_v) + 1e-08f);
-        h.theta = ppg_min(ppg_max(h.theta, -20.0f), 20.0f);
-        T.adam_grad[ak] = 0;
-        T.adam_w[ak] = 0;
-        stepped = true;
+    if (i < P.n_paths) nv[i] = (P.misc[i].z & FL_NV_MASK) >> FL_NV_SHIFT;
+}
+__global__ void k_iota(unsigned int *a, unsigned int n) {
+    unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = i;
+}
+__global__ void k_record_keys(const AdamRec *recs, unsigned long long *keys, unsigned int n) {
+    unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keys[i] = recs[i].key;
+}
+// out[k] = recs[idx[k]] for the first n_valid sorted records (what the round hook hands to the other ranks)
+__global__ void k_gather_records(const AdamRec *recs, const unsigned int *idx, AdamRec *out, unsigned int n) {
+    unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = recs[idx[i]];
+}
+// first position whose key is >= bound
+D unsigned int adam_lower_bound(const unsigned long long *keys, unsigned int n, unsigned long long bound) {
+    unsigned int lo = 0, hi = n;
+    while (lo < hi) {
+        const unsigned int mid = lo + ((hi - lo) >> 1);
+        if (keys[mid] < bound) lo = mid + 1; else hi = mid;
     }
-    if (stepped) T.hdr[i] = h;
+    return lo;
+}
+__global__ void k_count_valid(const unsigned long long *keys, unsigned int n, unsigned int *out) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *out = adam_lower_bound(keys, n, ~0ull);
+}
+
+// The deferred optimizeBsdfSamplingFraction calls of one round (include/ppg.h "Learning the BSDF sampling fraction"): one WAVE
+// per S-tree leaf walks that leaf's records in key order — 64 records are fetched at once, then applied one after the other with
+// the reference's arithmetic: the gradient at the current variable (GP:672-691), AdamOptimizer::append (GP:85-95) and step
+// (GP:97-109).  Every lane computes the same (scalar) sequence; lane 0 writes the state back.
+__global__ __launch_bounds__(256) void k_adam_apply(LeafHdr *hdr, const unsigned int *leaves, unsigned int n_leaves, const unsigned long long *keys,
+                                                    const unsigned int *idx, const AdamRec *recs, unsigned int n, int loss) {
+    const unsigned int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const unsigned int lane = threadIdx.x & 63u;
+    if (w >= n_leaves) return;
+    const unsigned int leaf = leaves[w];
+    const unsigned int lo = adam_lower_bound(keys, n, (unsigned long long)leaf << PPG_ADAM_LEAF_SHIFT);
+    const unsigned int hi = adam_lower_bound(keys, n, (unsigned long long)(leaf + 1u) << PPG_ADAM_LEAF_SHIFT);
+    if (lo == hi) return;
+    const LeafHdr h = hdr[leaf];
+    float variable = h.theta, firstMoment = h.adam_m, secondMoment = h.adam_v, batchGradient = h.adam_bg, batchAccumulation = h.adam_ba;
+    int iter = h.adam_iter;
+    for (unsigned int base = lo; base < hi; base += 64u) {
+        float4 pay = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        float wgt = 0.0f;
+        if (base + lane < hi) {
+            const AdamRec *r = recs + idx[base + lane];
+            const float4 a = reinterpret_cast<const float4 *>(r)[0], b = reinterpret_cast<const float4 *>(r)[1];
+            pay = make_float4(a.z, a.w, b.x, b.y);  // product, woPdf, bsdfPdf, dTreePdf
+            wgt = b.z;
+        }
+        const unsigned int cnt = (hi - base) < 64u ? (hi - base) : 64u;
+        for (unsigned int t = 0; t < cnt; ++t) {
+            const float product = __shfl(pay.x, (int)t), woPdf = __shfl(pay.y, (int)t), bsdfPdf = __shfl(pay.z, (int)t), dTreePdf = __shfl(pay.w, (int)t);
+            const float statisticalWeight = __shfl(wgt, (int)t);
+            // optimizeBsdfSamplingFraction, GP:672-691
+            const float samplingFraction = logistic(variable);
+            const float mixPdf = samplingFraction * bsdfPdf + (1 - samplingFraction) * dTreePdf;
+            const float r = product / mixPdf;
+            const float ratio = (loss == LOSS_KL) ? r : r * r;
+            const float dLoss_dSamplingFraction = -ratio / woPdf * (bsdfPdf - dTreePdf);
+            const float dLoss_dVariable = dLoss_dSamplingFraction * (samplingFraction * (1 - samplingFraction));
+            const float l2RegGradient = 0.01f * variable;
+            const float lossGradient = l2RegGradient + dLoss_dVariable;
+            // AdamOptimizer::append, GP:85-95 (batchSize = 1)
+            batchGradient += lossGradient * statisticalWeight;
+            batchAccumulation += statisticalWeight;
+            if (batchAccumulation > 1.0f) {
+                const float gradient = batchGradient / batchAccumulation;  // step(), GP:97-109
+                ++iter;
+                const float lr = 0.01f * __builtin_sqrtf(1 - ppg_powi(0.999f, iter)) / (1 - ppg_powi(0.9f, iter));
+                firstMoment = 0.9f * firstMoment + (1 - 0.9f) * gradient;
+                secondMoment = 0.999f * secondMoment + (1 - 0.999f) * gradient * gradient;
+                variable -= lr * firstMoment / (__builtin_sqrtf(secondMoment) + 1e-08f);
+                variable = ppg_min(ppg_max(variable, -20.0f), 20.0f);
+                batchGradient = 0;
+                batchAccumulation = 0;
+            }
+        }
+    }
+    if (lane == 0) {
+        LeafHdr o = h;
+        o.theta = variable; o.adam_iter = iter; o.adam_m = firstMoment; o.adam_v = secondMoment; o.adam_bg = batchGradient; o.adam_ba = batchAccumulation;
+        hdr[leaf] = o;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

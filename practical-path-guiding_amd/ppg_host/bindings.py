@@ -405,13 +405,20 @@ class Engine:
         self.image_buffers()
         return self._image_w
 
-    def adam_buffers(self):
-        g, w, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
-        self._call("adam_buffers", C.byref(g), C.byref(w), C.byref(n))
-        return g.value, w.value, n.value
+    def adam_records(self):
+        """Inside the round hook: (pointer, count) of this rank's 32-byte ppg_adam_record array (device memory for the HIP engine,
+        host memory for the oracle)."""
+        ptr, n = C.c_void_p(), C.c_uint64()
+        self._call("adam_records", C.byref(ptr), C.byref(n))
+        return ptr.value, n.value
+
+    def adam_records_replace(self, ptr, n):
+        """Inside the round hook: the records to apply instead (the union over all ranks)."""
+        self._call("adam_records_replace", C.c_void_p(ptr), C.c_uint64(n))
 
     def set_pass_hook(self, fn):
-        """fn() is called once per render pass between the accumulation of the Adam sums and the Adam step."""
+        """fn() is called at the end of every round of the sampling-fraction optimiser (include/ppg.h), after this rank's records
+        were collected and before they are applied."""
         HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p)
 
         def tramp(_user):

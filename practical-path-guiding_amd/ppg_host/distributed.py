@@ -6,6 +6,7 @@ t % world == rank for all passes and the only exchange per iteration is
     all_reduce(SUM) of the building tree's fixed-point leaf sums   (uint64 as int64, exact, order independent)
     all_reduce(SUM) of the per-D-tree statistical weights           (same)
     all_reduce(SUM) of image / squared image of the iteration       (disjoint supports → exact)
+plus, when the BSDF sampling fraction is learned, one all_gather per ROUND of the optimiser's records (include/ppg.h);
 after which refine/reset/build are deterministic functions of identical data on every rank: the SD-tree
 topology stays bit-identical across ranks and equal to a single-GPU render.  torch is plumbing here
 (device-pointer views + the collective); all compute is in libppg_hip.so.
@@ -52,11 +53,27 @@ class TorchReducer:
         self.torch.cuda.synchronize()
 
     def reduce_adam(self, e):
-        g, w, n = e.adam_buffers()
+        """Round hook of the sampling-fraction optimiser: every rank applies the records of ALL ranks (in key order, which does
+        not depend on the sharding), so the learned fractions stay identical everywhere and equal to a single-GPU render.
+        The records travel as int64 quadruples (32 bytes each); ranks contribute different counts, so the gather is padded."""
+        torch, dist = self.torch, self.dist
+        ptr, n = e.adam_records()
+        world = dist.get_world_size()
+        counts = torch.zeros(world, dtype=torch.int64, device=self.device)
+        counts[dist.get_rank()] = n
+        dist.all_reduce(counts)
+        counts = [int(c) for c in counts.tolist()]
+        most = max(counts)
+        if most == 0:
+            return
+        mine = torch.zeros(4 * most, dtype=torch.int64, device=self.device)
         if n:
-            self.dist.all_reduce(_view(self.torch, g, n, "<i8", self.device))
-            self.dist.all_reduce(_view(self.torch, w, n, "<i8", self.device))
-            self.torch.cuda.synchronize()
+            mine[:4 * n] = _view(torch, ptr, 4 * n, "<i8", self.device)
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        union = torch.cat([p[:4 * c] for p, c in zip(parts, counts)])
+        torch.cuda.synchronize()
+        e.adam_records_replace(union.data_ptr(), sum(counts))
 
     def reduce_film(self, e, inverse_variance=False):
         if inverse_variance:
@@ -106,13 +123,23 @@ class HostReducer:
         self._allreduce_np(np.ctypeslib.as_array(w, shape=(n,)))
 
     def reduce_adam(self, e):
-        n = int(e.sdtree_info().n_stree_nodes) * 64  # PPG_ADAM_BATCHES mini-batches per node
-        g = np.zeros(n, np.int64)
-        w = np.zeros(n, np.int64)
-        e._call("adam_export", g.ctypes.data_as(C.POINTER(C.c_int64)), w.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_uint64(n))
-        self._allreduce_np(g)
-        self._allreduce_np(w)
-        e._call("adam_import", g.ctypes.data_as(C.POINTER(C.c_int64)), w.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_uint64(n))
+        torch, dist = self.torch, self.dist
+        ptr, n = e.adam_records()
+        world = dist.get_world_size()
+        counts = torch.zeros(world, dtype=torch.int64)
+        counts[dist.get_rank()] = n
+        dist.all_reduce(counts)
+        counts = [int(c) for c in counts.tolist()]
+        most = max(counts)
+        if most == 0:
+            return
+        mine = np.zeros(4 * most, np.int64)
+        if n:
+            mine[:4 * n] = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int64)), shape=(4 * n,))
+        parts = [torch.empty(4 * most, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(parts, torch.from_numpy(mine))
+        union = np.ascontiguousarray(np.concatenate([p.numpy()[:4 * c] for p, c in zip(parts, counts)]))
+        e.adam_records_replace(union.ctypes.data, sum(counts))
 
     def reduce_film(self, e, inverse_variance=False):
         if inverse_variance:

@@ -43,8 +43,12 @@ class GuidedPathTracer:
         if scene is not None:
             e.set_scene(scene)
         e.begin_render()
+        if self.reducer is not None and p["budgetType"] != "spp":
+            # every control decision of renderTime() (guided_path.cpp:1434-1514) reads a rank-local clock: ranks would render
+            # different numbers of passes and iterations and their collectives would no longer match
+            raise ValueError("sharded rendering needs budgetType='spp' (a time budget is decided by rank-local clocks)")
         if self.reducer is not None and p["bsdfSamplingFractionLoss"] != "none":
-            e.set_pass_hook(lambda: self.reducer.reduce_adam(e))  # every rank takes the same per-pass Adam step
+            e.set_pass_hook(lambda: self.reducer.reduce_adam(e))  # every rank applies the records of all ranks, round by round
         self.iterations = []
         spp = p["sppPerPass"]
         automatic = p["sampleCombination"] == "automatic"

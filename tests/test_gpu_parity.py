@@ -316,9 +316,10 @@ def test_sdt_dump_equals_oracle_bytes(oracle_lib, tmp_path):
     assert open(tmp_path / "g.sdt", "rb").read() == open(tmp_path / "o.sdt", "rb").read()
 
 
-def test_pass_hook_sees_the_per_pass_adam_sums():
-    """The multi-GPU Adam exchange point: the hook runs once per training pass after the sums were folded and
-    before the step; an identity hook must not change anything, and the buffers must hold the pass's sums."""
+def test_round_hook_sees_the_records_of_every_round():
+    """The multi-GPU exchange point of the sampling-fraction optimiser (include/ppg.h): the hook runs once per round after the
+    round's records were collected and before they are applied.  An identity hook must not change anything; a hook that hands the
+    same records back in another order exercises the whole-key sort of the union and must not change anything either."""
     import ppg_host
     import torch
     from ppg_host.distributed import _view
@@ -327,29 +328,113 @@ def test_pass_hook_sees_the_per_pass_adam_sums():
     props = dict(CBOX_PROPS, budget=31, seed=4, **IMPROVED)
     ref = hip(**props)
     ref_img = ppg_host.GuidedPathTracer(engine=ref).render(scene)
-    e = hip(**props)
-    seen = []
+    for shuffle in (False, True):
+        e = hip(**props)
+        seen = []
 
-    def hook():
-        g, w, n = e.adam_buffers()
-        wt = _view(torch, w, n, "<i8", dev)
-        seen.append(int((wt > 0).sum().item()))
+        def hook():
+            ptr, n = e.adam_records()
+            recs = _view(torch, ptr, 4 * n, "<i8", dev).reshape(n, 4)
+            keys = recs[:, 0]
+            assert bool((keys[1:] > keys[:-1]).all())  # handed over in key order, keys unique
+            leaf, path, code = keys >> 40, (keys >> 13) & ((1 << 27) - 1), keys & 8191
+            assert int(leaf.max()) < e.sdtree_info().n_stree_nodes and int(code.min()) >= 4096 and int(code.max()) < 4096 + 32
+            seen.append((n, int(path.max())))
+            if shuffle:
+                perm = torch.randperm(n, device=dev)
+                mixed = recs[perm].contiguous()
+                e.adam_records_replace(mixed.data_ptr(), n)
 
-    e.set_scene(scene)
-    e.begin_render()
-    e.set_pass_hook(hook)
-    e.close_hook = hook
-    gpt = ppg_host.GuidedPathTracer(engine=e)
-    # drive the phases by hand so that begin_render is not repeated
-    passes = [1, 2, 4, 8, 16]
-    for it, p in enumerate(passes):
-        e.begin_iteration(it == len(passes) - 1)
-        e.render_passes(p)
-        e.build_sdtree(); e.end_iteration()
-    e.end_render()
-    assert np.array_equal(e.read_film(), ref_img)
-    assert np.array_equal(e.read_sdtree()["theta"], ref.read_sdtree()["theta"])
-    assert len(seen) == 2 + 4 + 8 and max(seen) > 0  # training passes after the first build; none in the final iteration
+        e.set_scene(scene)
+        e.begin_render()
+        e.set_pass_hook(hook)
+        passes = [1, 2, 4, 8, 16]
+        for it, p in enumerate(passes):
+            e.begin_iteration(it == len(passes) - 1)
+            e.render_passes(p)
+            e.build_sdtree(); e.end_iteration()
+        e.end_render()
+        assert np.array_equal(e.read_film(), ref_img)
+        assert np.array_equal(e.read_sdtree()["theta"], ref.read_sdtree()["theta"])
+        # rounds: none before the first build, 2 x 1 pass, 2 x 2 passes, 2 x 4 passes, none in the final iteration
+        assert len(seen) == 6 and min(n for n, _ in seen) > 0
+        assert [p // (64 * 64) for _, p in seen] == [0, 0, 1, 1, 3, 3]  # path id = sample-in-round * pixels + pixel
+
+
+def test_sharded_contexts_with_learned_fraction_equal_unsharded():
+    """Two tile-sharded contexts on one GPU with the improved preset (KL-learned sampling fraction): the two render threads meet in
+    the round hook, each applies the union of both ranks' records — fractions, SD-tree and image equal the unsharded render."""
+    import threading
+    import ppg_host
+    import torch
+    from ppg_host.distributed import _view
+    dev = torch.device("cuda", 0)
+    scene = ppg_host.cbox_scene(64, 48)
+    props = dict(CBOX_PROPS, budget=31, seed=9, **IMPROVED)
+    ref = hip(**props)
+    ref_img = ppg_host.GuidedPathTracer(engine=ref).render(scene)
+    engines = [hip(**props) for _ in range(2)]
+    barrier = threading.Barrier(2)
+    slots = [None, None]
+
+    def make_hook(r):
+        def hook():
+            ptr, n = engines[r].adam_records()
+            slots[r] = _view(torch, ptr, 4 * n, "<i8", dev).clone() if n else torch.zeros(0, dtype=torch.int64, device=dev)
+            torch.cuda.synchronize()
+            barrier.wait()
+            union = torch.cat(slots).contiguous()
+            torch.cuda.synchronize()
+            engines[r].adam_records_replace(union.data_ptr(), union.numel() // 4)
+            barrier.wait()
+        return hook
+
+    def both(fn):
+        errs = []
+
+        def run(r):
+            try:
+                fn(r)
+            except Exception as ex:  # pragma: no cover
+                errs.append(ex)
+                barrier.abort()
+        ts = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+        [t.start() for t in ts]; [t.join() for t in ts]
+        assert not errs, errs
+
+    def sum_views(views):
+        total = views[0].clone()
+        for v in views[1:]:
+            total += v
+        for v in views:
+            v.copy_(total)
+        torch.cuda.synchronize()
+
+    n = 64 * 48
+    for r, e in enumerate(engines):
+        e.set_scene(scene); e.set_shard(r, 2, 16); e.begin_render(); e.set_pass_hook(make_hook(r))
+    for it, p in enumerate([1, 2, 4, 8, 16]):
+        final = it == 4
+        for e in engines:
+            e.begin_iteration(final)
+        both(lambda r: engines[r].render_passes_nostat(p))
+        for sel in (0, 1):
+            sum_views([_view(torch, e.image_buffers()[sel], 3 * n, "<f4", dev) for e in engines])
+        sum_views([_view(torch, e.image_weight_buffer(), n, "<f4", dev) for e in engines])
+        stats = [e.finish_passes() for e in engines]
+        assert stats[0].variance == stats[1].variance or (np.isnan(stats[0].variance) and np.isnan(stats[1].variance))
+        if not final:
+            bufs = [e.stat_buffers() for e in engines]
+            for k in range(2):
+                if bufs[0][k][1]:
+                    sum_views([_view(torch, b[k][0], b[k][1], "<i8", dev) for b in bufs])
+        for e in engines:
+            e.build_sdtree(); e.end_iteration()
+    for e in engines:
+        e.end_render()
+        assert np.array_equal(e.read_film(), ref_img, equal_nan=True)
+        assert_tree_equal(e.read_sdtree(), ref.read_sdtree())
+        assert np.array_equal(e.read_sdtree()["theta"], ref.read_sdtree()["theta"])
 
 
 def _materials_scene(res):
