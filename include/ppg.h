@@ -104,6 +104,22 @@ enum {
                                       smooth/null hybrid — its sampled pass-through is recorded for the sampling-fraction optimiser
                                       (GP:2047-2068) */
 };
+enum { PPG_WRAP_REPEAT = 0, PPG_WRAP_MIRROR = 1, PPG_WRAP_CLAMP = 2, PPG_WRAP_ZERO = 3, PPG_WRAP_ONE = 4 }; /* ReconstructionFilter::EBoundaryCondition, mipmap.h:503-560 */
+
+typedef struct ppg_texture {
+    /* A bitmap texture as THIS integrator sees it (textures/bitmap.cpp).  Li fetches the BSDF with its.getBSDF() (GP:1934), not
+       getBSDF(ray), so Intersection::computePartials never runs, its.hasUVPartials stays false and Texture2D::eval (texture.cpp:112-121)
+       always takes the unfiltered branch: BitmapTexture::eval(uv) (bitmap.cpp:431-452) = MIPMap::evalBilinear(0, uv) (mipmap.h:575-596)
+       on the full-resolution image — or evalBox for filterType "nearest" — whatever filterType the scene asks for; bump maps read
+       evalGradientBilinear(0, uv) (mipmap.h:601-626).  uv = its.uv * (uscale, vscale) + (uoffset, voffset). */
+    uint32_t width, height;
+    const float *rgb;          /* [height * width * 3] linear RGB: the image after the loader's gamma / sRGB decoding (bitmap.cpp:182-260),
+                                  row 0 = first row of the file; luminance images replicated to three channels */
+    float uv_scale[2], uv_offset[2];
+    int32_t wrap_u, wrap_v;    /* PPG_WRAP_*: wrapModeU / wrapModeV */
+    int32_t nearest;           /* filterType = nearest */
+} ppg_texture;
+
 
 typedef struct ppg_material {
     int32_t type;         /* PPG_BSDF_* */
@@ -117,7 +133,11 @@ typedef struct ppg_material {
     int32_t flags;        /* PPG_MAT_* */
     int32_t rtrans;       /* roughplastic: index of this material's slice in ppg_scene.rtrans; otherwise 0 */
     float opacity[3];     /* PPG_MAT_MASK: opacity (mask.cpp, default 0.5) */
-    float _pad;
+    uint32_t texture;     /* bits 0..15: 1 + index (ppg_scene.textures) of the bitmap on the diffuse reflectance — `reflectance` of diffuse,
+                             `diffuseReflectance` of plastic / roughplastic — in which case reflectance[] holds the texture's average
+                             (Texture::getAverage, used by the plug-ins' configure() for the component sampling weights, plastic.cpp:191-204);
+                             bits 16..31: 1 + index of the displacement texture of a `bumpmap` adapter around this BSDF (bumpmap.cpp:135-219:
+                             shading frame perturbed by the texture's gradient); 0 = none */
 } ppg_material;           /* 80 bytes */
 
 typedef struct ppg_emitter {
@@ -186,6 +206,13 @@ typedef struct ppg_scene {
     uint32_t n_spheres;
     const ppg_sphere *spheres;    /* [n_spheres] or NULL */
     const ppg_envmap *envmap;     /* NULL, or the image-based environment emitter (not together with `environment`) */
+    const float *texcoords;       /* NULL, or [n_vertices * 2] per-vertex texture coordinates (TriMesh::m_texcoords; its.uv is their barycentric
+                                     interpolation, skdtree.h:403-410 — without them its.uv = the barycentrics (b1, b2)).  A triangle whose three
+                                     vertices all carry NaN has no texture coordinates (meshes with and without `vt` share the vertex array).
+                                     Triangles WITH coordinates whose BSDF uses a texture also get the reference's UV tangents as dpdu / dpdv
+                                     (TriMesh::computeUVTangents, trimesh.cpp:683-735; skdtree.h:374-381) */
+    uint32_t n_textures;
+    const ppg_texture *textures;  /* [n_textures] or NULL */
 } ppg_scene;
 
 /* ------------------------------------------------------------------------------------------------

@@ -793,6 +793,9 @@ struct BRec {
     Float eta = 1.0f;
     bool sampledDelta = false;  // sampledType & EDelta (EDelta includes ENull, bsdf.h:280)
     bool sampledNull = false;   // sampledType == ENull
+    // `bumpmap` adapter (bumpmap.cpp:135-219): the intersection's shading frame and the frame perturbed by the displacement
+    // texture's gradient; nullptr = no bump map on this surface
+    const Frame *bumpSh = nullptr, *bumpPert = nullptr;
 };
 
 // A BSDF instance: the ABI record plus what the plugin's configure() precomputes
@@ -838,6 +841,8 @@ struct Intersection {
     int prim = -1;
     int emitter = -1;
     uint32_t material = 0;
+    Point2 uv{0, 0};   // its.uv (skdtree.h:403-410); only filled for surfaces whose BSDF reads a texture
+    Vec dpdu, dpdv;    // its.dpdu / dpdv (skdtree.h:374-381), likewise
 };
 
 // DiscreteDistribution (pmf.h:30-189): float running sums, normalize(), sample()/sampleReuse()
@@ -988,6 +993,65 @@ struct EnvMap {
     }
 };
 
+// BitmapTexture as this integrator sees it (include/ppg.h ppg_texture): Li never computes UV partials, so every lookup is
+// BitmapTexture::eval(uv) (bitmap.cpp:431-452) = MIPMap::evalBilinear(0, uv) / evalBox(0, uv) (mipmap.h:566-596) and bump maps read
+// evalGradientBilinear(0, uv) (mipmap.h:601-626); texel addressing with the boundary conditions of evalTexel (mipmap.h:503-563).
+struct Texture {
+    int w = 0, h = 0;
+    std::vector<Spectrum> texel;
+    Float su = 1, sv = 1, ou = 0, ov = 0;
+    int wrapU = PPG_WRAP_REPEAT, wrapV = PPG_WRAP_REPEAT;
+    bool nearest = false;
+    static int floorToInt(Float v) { return (int)std::floor(v); }
+    static int modulo(int a, int b) { int r = a % b; return (r < 0) ? r + b : r; }  // math.h:67-70
+    Spectrum evalTexel(int x, int y) const {
+        if (x < 0 || x >= w) {
+            switch (wrapU) {
+                case PPG_WRAP_REPEAT: x = modulo(x, w); break;
+                case PPG_WRAP_CLAMP: x = x < 0 ? 0 : w - 1; break;
+                case PPG_WRAP_MIRROR: x = modulo(x, 2 * w); if (x >= w) x = 2 * w - x - 1; break;
+                case PPG_WRAP_ZERO: return Spectrum(0.0f);
+                default: return Spectrum(1.0f);
+            }
+        }
+        if (y < 0 || y >= h) {
+            switch (wrapV) {
+                case PPG_WRAP_REPEAT: y = modulo(y, h); break;
+                case PPG_WRAP_CLAMP: y = y < 0 ? 0 : h - 1; break;
+                case PPG_WRAP_MIRROR: y = modulo(y, 2 * h); if (y >= h) y = 2 * h - y - 1; break;
+                case PPG_WRAP_ZERO: return Spectrum(0.0f);
+                default: return Spectrum(1.0f);
+            }
+        }
+        return texel[(size_t)y * w + x];
+    }
+    Point2 transform(const Point2 &uv) const { return Point2{uv.x * su + ou, uv.y * sv + ov}; }  // Texture2D::eval, texture.cpp:112-113
+    Spectrum eval(const Point2 &itsUv) const {
+        const Point2 uv = transform(itsUv);
+        if (nearest) return evalTexel(floorToInt(uv.x * w), floorToInt(uv.y * h));  // evalBox(0, uv)
+        if (!std::isfinite(uv.x) || !std::isfinite(uv.y)) return Spectrum(0.0f);
+        const Float u = uv.x * w - 0.5f, v = uv.y * h - 0.5f;
+        const int xPos = floorToInt(u), yPos = floorToInt(v);
+        const Float dx1 = u - xPos, dx2 = 1.0f - dx1, dy1 = v - yPos, dy2 = 1.0f - dy1;
+        return evalTexel(xPos, yPos) * dx2 * dy2 + evalTexel(xPos, yPos + 1) * dx2 * dy1 + evalTexel(xPos + 1, yPos) * dx1 * dy2 +
+               evalTexel(xPos + 1, yPos + 1) * dx1 * dy1;
+    }
+    // Texture2D::evalGradient(its) (texture.cpp:123-131) over BitmapTexture::evalGradient(uv) (bitmap.cpp:454-477)
+    void evalGradient(const Point2 &itsUv, Spectrum *gradient) const {
+        const Point2 uv = transform(itsUv);
+        if (nearest || !std::isfinite(uv.x) || !std::isfinite(uv.y)) { gradient[0] = gradient[1] = Spectrum(0.0f); return; }
+        const Float u = uv.x * w - 0.5f, v = uv.y * h - 0.5f;
+        const int xPos = floorToInt(u), yPos = floorToInt(v);
+        const Float dx = u - xPos, dy = v - yPos;
+        const Spectrum p00 = evalTexel(xPos, yPos), p10 = evalTexel(xPos + 1, yPos), p01 = evalTexel(xPos, yPos + 1), p11 = evalTexel(xPos + 1, yPos + 1);
+        const Spectrum tmp = p01 + p10 - p11;
+        gradient[0] = (p10 + p00 * (dy - 1) - tmp * dy) * (Float)w;
+        gradient[1] = (p01 + p00 * (dx - 1) - tmp * dx) * (Float)h;
+        gradient[0] = gradient[0] * su;
+        gradient[1] = gradient[1] * sv;
+    }
+};
+
 struct Scene {
     // one area emitter = the triangles carrying its id, in index order (area.cpp: one emitter per shape)
     struct EmitterMesh { std::vector<uint32_t> tris; Pmf areaDistr; Float surfaceArea = -1, invSurfaceArea = -1; };
@@ -1009,6 +1073,8 @@ struct Scene {
     std::vector<int32_t> triEmitter;
     std::vector<Material> materials;
     std::vector<Float> rtrans;  // ppg_scene.rtrans (roughplastic slices)
+    std::vector<Texture> textures;     // ppg_scene.textures
+    std::vector<Point2> UV;            // ppg_scene.texcoords (per vertex; NaN = none), empty if the scene has none
     std::vector<ppg_sphere> spheres;   // analytic spheres (shapes/sphere.cpp), primitives nTris(), nTris() + 1, ..
     std::vector<int> emitterSphere;    // per emitter: the sphere carrying it, or -1 (a triangle emitter)
     std::vector<ppg_emitter> emitters;
@@ -1577,13 +1643,73 @@ struct Scene {
             shN = faceNormal;
         }
         its.geoN = faceNormal;
-        // computeShadingFrame(n, dpdu = side1)
-        its.shFrame.n = shN;
-        its.shFrame.s = normalize(side1 - shN * dot(shN, side1));
-        its.shFrame.t = cross(shN, its.shFrame.s);
-        its.wi = its.shFrame.toLocal(-d);
         its.material = triMat[prim];
         its.emitter = triEmitter[prim];
+        Vec dpdu = side1;
+        if (materials[its.material].texture != 0) {
+            // a BSDF with a bitmap (usesRayDifferentials): texture coordinates (skdtree.h:403-410) and, on meshes that carry them, the
+            // tangents of TriMesh::computeUVTangents (trimesh.cpp:683-735) instead of the triangle edges (skdtree.h:374-381)
+            its.uv = Point2{b.y, b.z};
+            its.dpdu = side1; its.dpdv = side2;
+            if (!UV.empty() && !std::isnan(UV[i0].x) && !std::isnan(UV[i1].x) && !std::isnan(UV[i2].x)) {
+                const Point2 &t0 = UV[i0], &t1 = UV[i1], &t2 = UV[i2];
+                its.uv = Point2{t0.x * b.x + t1.x * b.y + t2.x * b.z, t0.y * b.x + t1.y * b.y + t2.y * b.z};
+                const Float dUV1x = t1.x - t0.x, dUV1y = t1.y - t0.y, dUV2x = t2.x - t0.x, dUV2y = t2.y - t0.y;
+                const Vec n = cross(side1, side2);
+                const Float nlen = length(n);
+                if (nlen != 0) {
+                    const Float determinant = dUV1x * dUV2y - dUV1y * dUV2x;
+                    if (determinant == 0) {
+                        const Vec a = n / nlen;  // coordinateSystem(n / length, dpdu, dpdv), util.cpp:592-601
+                        if (ppg_abs(a.x) > ppg_abs(a.y)) {
+                            Float invLen = 1.0f / std::sqrt(a.x * a.x + a.z * a.z);
+                            its.dpdv = Vec(a.z * invLen, 0.0f, -a.x * invLen);
+                        } else {
+                            Float invLen = 1.0f / std::sqrt(a.y * a.y + a.z * a.z);
+                            its.dpdv = Vec(0.0f, a.z * invLen, -a.y * invLen);
+                        }
+                        its.dpdu = cross(its.dpdv, a);
+                    } else {
+                        const Float invDet = 1.0f / determinant;
+                        its.dpdu = (side1 * dUV2y - side2 * dUV1y) * invDet;
+                        its.dpdv = (side1 * -dUV2x + side2 * dUV1x) * invDet;
+                    }
+                }
+            }
+            dpdu = its.dpdu;
+        }
+        // computeShadingFrame(n, dpdu)
+        its.shFrame.n = shN;
+        its.shFrame.s = normalize(dpdu - shN * dot(shN, dpdu));
+        its.shFrame.t = cross(shN, its.shFrame.s);
+        its.wi = its.shFrame.toLocal(-d);
+        return true;
+    }
+
+    // The BSDF instance at an intersection: a bitmap on the diffuse reflectance replaces the constant (m_reflectance->eval(bRec.its),
+    // diffuse.cpp:112 / plastic.cpp:258 / roughplastic.cpp:365); the sampling weights of configure() keep the texture's average.
+    Material materialAt(const Intersection &its) const {
+        Material m = materials[its.material];
+        const uint32_t t = m.texture & 0xffffu;
+        if (t) {
+            const Spectrum c = textures[t - 1].eval(its.uv);
+            m.reflectance[0] = c.x; m.reflectance[1] = c.y; m.reflectance[2] = c.z;
+        }
+        return m;
+    }
+    // BumpMap::getFrame (bumpmap.cpp:135-160): false = no bump map on this surface
+    bool bumpFrame(const Intersection &its, Frame &result) const {
+        const uint32_t t = materials[its.material].texture >> 16;
+        if (!t) return false;
+        Spectrum grad[2];
+        textures[t - 1].evalGradient(its.uv, grad);
+        const Float dDispDu = luminance(grad[0]), dDispDv = luminance(grad[1]);
+        const Vec dpdu = its.dpdu + its.shFrame.n * (dDispDu - dot(its.shFrame.n, its.dpdu));
+        const Vec dpdv = its.dpdv + its.shFrame.n * (dDispDv - dot(its.shFrame.n, its.dpdv));
+        result.n = normalize(cross(dpdu, dpdv));
+        result.s = normalize(dpdu - result.n * dot(result.n, dpdu));
+        result.t = cross(result.n, result.s);
+        if (dot(result.n, its.geoN) < 0) result.n = result.n * -1.0f;
         return true;
     }
 
@@ -2225,16 +2351,50 @@ struct BSDF {
         c.wi.z *= -1; c.wo.z *= -1;
         return pdfOne(m, c);
     }
-    // Mask adapter (mask.cpp:108-214), solid-angle measure for eval / pdf
+    // BumpMap adapter (bumpmap.cpp:162-219): the outermost one; queries are re-expressed in the perturbed frame
+    static BRec perturbed(const BRec &b) {
+        BRec q = b;
+        q.bumpSh = q.bumpPert = nullptr;
+        q.wi = b.bumpPert->toLocal(b.bumpSh->toWorld(b.wi));
+        q.wo = b.bumpPert->toLocal(b.bumpSh->toWorld(b.wo));
+        return q;
+    }
     static Spectrum eval(const Material &m, const BRec &b) {
+        if (!b.bumpPert) return evalMask(m, b);
+        const BRec q = perturbed(b);
+        if (b.wo.z * q.wo.z <= 0) return Spectrum(0.0f);
+        return evalMask(m, q);
+    }
+    static Float pdf(const Material &m, const BRec &b) {
+        if (!b.bumpPert) return pdfMask(m, b);
+        const BRec q = perturbed(b);
+        if (b.wo.z * q.wo.z <= 0) return 0;
+        return pdfMask(m, q);
+    }
+    static Spectrum sample(const Material &m, BRec &b, Float &pdf, const Point2 &sample, Sampler *sampler) {
+        if (!b.bumpPert) return sampleMask(m, b, pdf, sample, sampler);
+        BRec q = b;
+        q.bumpSh = q.bumpPert = nullptr;
+        q.wi = b.bumpPert->toLocal(b.bumpSh->toWorld(b.wi));
+        Spectrum result = sampleMask(m, q, pdf, sample, sampler);
+        if (!isZero(result)) {
+            b.sampledDelta = q.sampledDelta; b.sampledNull = q.sampledNull;
+            b.wo = b.bumpSh->toLocal(b.bumpPert->toWorld(q.wo));
+            b.eta = q.eta;
+            if (b.wo.z * q.wo.z <= 0) return Spectrum(0.0f);
+        }
+        return result;
+    }
+    // Mask adapter (mask.cpp:108-214), solid-angle measure for eval / pdf
+    static Spectrum evalMask(const Material &m, const BRec &b) {
         Spectrum r = evalTS(m, b);
         return m.masked() ? mul(r, m.Opacity()) : r;
     }
-    static Float pdf(const Material &m, const BRec &b) {
+    static Float pdfMask(const Material &m, const BRec &b) {
         Float r = pdfTS(m, b);
         return m.masked() ? r * luminance(m.Opacity()) : r;
     }
-    static Spectrum sample(const Material &m, BRec &b, Float &pdf, const Point2 &_sample, Sampler *sampler) {
+    static Spectrum sampleMask(const Material &m, BRec &b, Float &pdf, const Point2 &_sample, Sampler *sampler) {
         if (!m.masked()) return sampleTS(m, b, pdf, _sample, sampler);
         Point2 sample(_sample);
         Spectrum opacity = m.Opacity();
@@ -2694,7 +2854,9 @@ public:
             Float wiDotGeoN = -dot(its.geoN, d), wiDotShN = its.wi.z;  // GP:1929-1932
             if (wiDotGeoN * wiDotShN < 0 && m_strictNormals) break;
 
-            const Material &bsdf = scene.materials[its.material];
+            const Material bsdf = scene.materialAt(its);  // its.getBSDF() with the textures evaluated at its.uv
+            Frame bumpFrame;
+            const bool bumped = scene.bumpFrame(its, bumpFrame);
             Vec dTreeVoxelSize;
             DTreeWrapper *dTree = nullptr;
             if (BSDF::isSmooth(bsdf)) dTree = m_sdTree->dTreeWrapper(its.p, dTreeVoxelSize);  // GP:1942-1944
@@ -2704,6 +2866,7 @@ public:
 
             BRec bRec;
             bRec.wi = its.wi;
+            if (bumped) { bRec.bumpSh = &its.shFrame; bRec.bumpPert = &bumpFrame; }
             Float woPdf, bsdfPdf, dTreePdf;
             Spectrum bsdfWeight = sampleMat(bsdf, bRec, its.shFrame, woPdf, bsdfPdf, dTreePdf, bsdfSamplingFraction, sampler, dTree);
 
@@ -2718,6 +2881,7 @@ public:
                     BRec bRecE;
                     bRecE.wi = its.wi;
                     bRecE.wo = its.shFrame.toLocal(dRec.d);
+                    if (bumped) { bRecE.bumpSh = &its.shFrame; bRecE.bumpPert = &bumpFrame; }
                     Float woDotGeoNE = dot(its.geoN, dRec.d);
                     if (!m_strictNormals || woDotGeoNE * bRecE.wo.z > 0) {
                         const Spectrum bsdfVal = BSDF::eval(bsdf, bRecE);
@@ -3077,6 +3241,28 @@ int ppgo_set_scene(ppgo_ctx *ctx, const ppg_scene *s) {
         m.configure();
         sc.materials.push_back(m);
     }
+    if (s->n_textures) {
+        if (!s->textures) { ctx->gpt.error = "textures: n_textures > 0 but no array"; return PPG_ERR_INVALID; }
+        for (uint32_t i = 0; i < s->n_textures; ++i) {
+            const ppg_texture &t = s->textures[i];
+            if (!t.rgb || t.width == 0 || t.height == 0 || t.width > 0x7fff || t.height > 0x7fff || t.wrap_u < 0 || t.wrap_u > PPG_WRAP_ONE || t.wrap_v < 0 || t.wrap_v > PPG_WRAP_ONE) {
+                ctx->gpt.error = "texture: needs pixels, 0 < width, height < 32768 and valid wrap modes"; return PPG_ERR_INVALID;
+            }
+            Texture x;
+            x.w = (int)t.width; x.h = (int)t.height; x.su = t.uv_scale[0]; x.sv = t.uv_scale[1]; x.ou = t.uv_offset[0]; x.ov = t.uv_offset[1];
+            x.wrapU = t.wrap_u; x.wrapV = t.wrap_v; x.nearest = t.nearest != 0;
+            x.texel.resize((size_t)x.w * x.h);
+            for (size_t k = 0; k < x.texel.size(); ++k) x.texel[k] = Spectrum(t.rgb[3 * k], t.rgb[3 * k + 1], t.rgb[3 * k + 2]);
+            sc.textures.push_back(std::move(x));
+        }
+    }
+    for (const Material &m : sc.materials) {
+        const uint32_t a = m.texture & 0xffffu, b = m.texture >> 16;
+        if (a > s->n_textures || b > s->n_textures) { ctx->gpt.error = "material.texture: index out of range"; return PPG_ERR_INVALID; }
+        if (a && m.type != PPG_BSDF_DIFFUSE && m.type != PPG_BSDF_PLASTIC && m.type != PPG_BSDF_ROUGHPLASTIC) { ctx->gpt.error = "material.texture: only the diffuse reflectance of diffuse / plastic / roughplastic can carry a bitmap"; return PPG_ERR_INVALID; }
+    }
+    if (s->texcoords)
+        for (uint32_t i = 0; i < s->n_vertices; ++i) sc.UV.push_back(Point2{s->texcoords[2 * i], s->texcoords[2 * i + 1]});
     if (s->n_emitters) sc.emitters.assign(s->emitters, s->emitters + s->n_emitters);
     if (s->n_spheres) {
         if (!s->spheres) { ctx->gpt.error = "spheres: n_spheres > 0 but no array"; return PPG_ERR_INVALID; }
@@ -3087,6 +3273,7 @@ int ppgo_set_scene(ppgo_ctx *ctx, const ppg_scene *s) {
             if (!(sp.radius > 0)) { ctx->gpt.error = "sphere: radius must be > 0"; return PPG_ERR_INVALID; }
             if (sp.material >= s->n_materials || sp.emitter >= (int32_t)s->n_emitters) { ctx->gpt.error = "index out of range"; return PPG_ERR_INVALID; }
             if (sp.emitter >= 0 && users[sp.emitter]++) { ctx->gpt.error = "sphere: its emitter is shared with another shape"; return PPG_ERR_INVALID; }
+            if (sc.materials[sp.material].texture) { ctx->gpt.error = "sphere: textured BSDFs are only supported on triangle meshes"; return PPG_ERR_INVALID; }
         }
     }
     for (uint32_t t = 0; t < s->n_triangles; ++t) {
@@ -3335,6 +3522,11 @@ int ppgo_math_eval(int32_t op, uint32_t n, const float *a, const float *b, float
             case 5: out0[i] = ppg_powi(a[i], (int)b[i]); break;
             case 6: out0[i] = ppg_log(a[i]); break;
             case 7: out0[i] = ppg_pow(a[i], b[i]); break;
+            case 8: {  // draw `dim` of the path (seed, pixel, sample index): a = pixel, b = seed << 16 | sample << 4 | dim, as bit patterns
+                const uint32_t pixel = ppg_f2u(a[i]), w = ppg_f2u(b[i]);
+                out0[i] = ppg_rand(ppg_path_key((uint64_t)(w >> 16), pixel, (w >> 4) & 0xfffu), w & 15u);
+                break;
+            }
             default: return PPG_ERR_INVALID;
         }
     }

@@ -85,7 +85,8 @@ int ppgo_ka_adam(int32_t n, float product, float wo_pdf, float bsdf_pdf, float d
 /* canonicalToDir / dirToCanonical (GP:586-608) */
 void ppgo_canonical_to_dir(float x, float y, float *d);
 void ppgo_dir_to_canonical(const float *d, float *xy);
-/* element-wise ppg_detmath.h / ppg_rng.h evaluation: op 0 sincos(a), 1 atan2(a,b), 2 exp(a), 3 fixed round trip, 4 rand, 5 powi */
+/* element-wise ppg_detmath.h / ppg_rng.h evaluation: op 0 sincos(a), 1 atan2(a,b), 2 exp(a), 3 fixed round trip, 4 rand, 5 powi, 6 log, 7 pow,
+   8 draw of a path: ppg_rand(ppg_path_key(seed, pixel, sample), dim) with a = pixel, b = seed << 16 | sample << 4 | dim as bit patterns */
 int ppgo_math_eval(int32_t op, uint32_t n, const float *a, const float *b, float *out0, float *out1);
 int ppgo_bsdf_eval(const ppg_material *mat, uint32_t n, const float *wi, const float *wo, float *f_out, float *pdf_out);
 int ppgo_bsdf_sample(const ppg_material *mat, uint32_t n, const float *wi, const float *sample_xy, float *wo_out, float *weight_out,

@@ -75,6 +75,16 @@ struct DevCamera {
     int width, height;
 };
 
+#define PPG_MAT_STRIDE 6  // float4 per material: (reflectance, type) (specular, alpha) (eta, flags) (k, fdrInt) (opacity, rtrans slice) (texture word, -, -, -)
+
+// ppg_texture on the device: texels as (rgb, -)
+struct DevTex {
+    const float4 *texels;
+    int w, h;
+    float su, sv, ou, ov;
+    int wrap_u, wrap_v, nearest, pad;
+};
+
 struct DevScene {
     const float4 *tris;     // 3 per triangle: positions (.w = material, emitter, original index) — intersection records only
     const float4 *accel;    // 3 per triangle: TriAccel (triaccel.h:36-58), what the traversal reads
@@ -111,6 +121,9 @@ struct DevScene {
     int em_w, em_h;
     float em_norm, em_scale, em_px, em_py;
     float em_R[9];
+    // bitmap textures (FULL kernels): texture coordinates, 3 x float2 per triangle in leaf order (NaN = the mesh has none) or nullptr
+    const float2 *uvs;
+    const DevTex *textures;
 };
 
 struct Hit {
@@ -359,6 +372,141 @@ D void fill_isect(const DevScene &S, const Hit &h, F3 d, Isect &I) {
     I.wi = to_local(I, -d);
     I.material = __float_as_int(q0.w);
     I.emitter = __float_as_int(q1.w);
+}
+
+// ---- bitmap textures (FULL kernels; include/ppg.h ppg_texture) ----
+// What a textured BSDF needs of the intersection besides the frame: its.uv, its.dpdu / dpdv, the material's texture word.
+struct TexInfo {
+    unsigned int tex;
+    float u, v;
+    F3 dpdu, dpdv;
+};
+// fillIntersectionRecord for a triangle whose BSDF may read a bitmap: as fill_isect, plus the texture coordinates (skdtree.h:403-410)
+// and — on meshes that carry them — TriMesh::computeUVTangents' tangents (trimesh.cpp:683-735) as dpdu / dpdv (skdtree.h:374-381),
+// which then also span the shading frame.
+D void fill_isect_tex(const DevScene &S, const Hit &h, F3 d, Isect &I, TexInfo &X) {
+    const float4 *T = S.tris + 3 * h.prim;
+    float4 q0 = T[0], q1 = T[1];
+    F3 p0 = f3(q0.x, q0.y, q0.z), p1 = f3(q1.x, q1.y, q1.z), p2 = ld3(T + 2);
+    F3 b = f3(1 - h.u - h.v, h.u, h.v);
+    I.p = p0 * b.x + p1 * b.y + p2 * b.z;
+    F3 side1 = p1 - p0, side2 = p2 - p0;
+    F3 fn = cross3(side1, side2);
+    float len = len3(fn);
+    const F3 nraw = fn;
+    if (!(fn.x == 0 && fn.y == 0 && fn.z == 0)) fn = div3(fn, len);
+    F3 shN;
+    if (S.normals) {
+        const float4 *Nn = S.normals + 3 * h.prim;
+        shN = norm3(ld3(Nn) * b.x + ld3(Nn + 1) * b.y + ld3(Nn + 2) * b.z);
+        if (dot3(fn, shN) < 0) fn = -fn;
+    } else {
+        shN = fn;
+    }
+    I.geoN = fn;
+    I.n = shN;
+    I.material = __float_as_int(q0.w);
+    I.emitter = __float_as_int(q1.w);
+    X.tex = __float_as_uint(S.materials[PPG_MAT_STRIDE * (size_t)I.material + 5].x);
+    F3 dpdu = side1;
+    if (X.tex) {
+        X.u = b.y; X.v = b.z;
+        X.dpdu = side1; X.dpdv = side2;
+        if (S.uvs) {
+            const float2 t0 = S.uvs[3 * (size_t)h.prim], t1 = S.uvs[3 * (size_t)h.prim + 1], t2 = S.uvs[3 * (size_t)h.prim + 2];
+            if (!(t0.x != t0.x) && !(t1.x != t1.x) && !(t2.x != t2.x)) {
+                X.u = t0.x * b.x + t1.x * b.y + t2.x * b.z;
+                X.v = t0.y * b.x + t1.y * b.y + t2.y * b.z;
+                const float dUV1x = t1.x - t0.x, dUV1y = t1.y - t0.y, dUV2x = t2.x - t0.x, dUV2y = t2.y - t0.y;
+                if (len != 0) {
+                    const float determinant = dUV1x * dUV2y - dUV1y * dUV2x;
+                    if (determinant == 0) {
+                        const F3 a = div3(nraw, len);  // coordinateSystem(n / length, dpdu, dpdv), util.cpp:592-601
+                        if (ppg_abs(a.x) > ppg_abs(a.y)) {
+                            float invLen = 1.0f / __builtin_sqrtf(a.x * a.x + a.z * a.z);
+                            X.dpdv = f3(a.z * invLen, 0.0f, -a.x * invLen);
+                        } else {
+                            float invLen = 1.0f / __builtin_sqrtf(a.y * a.y + a.z * a.z);
+                            X.dpdv = f3(0.0f, a.z * invLen, -a.y * invLen);
+                        }
+                        X.dpdu = cross3(X.dpdv, a);
+                    } else {
+                        const float invDet = 1.0f / determinant;
+                        X.dpdu = (side1 * dUV2y - side2 * dUV1y) * invDet;
+                        X.dpdv = (side1 * -dUV2x + side2 * dUV1x) * invDet;
+                    }
+                }
+            }
+        }
+        dpdu = X.dpdu;
+    }
+    I.s = norm3(dpdu - shN * dot3(shN, dpdu));
+    I.t = cross3(shN, I.s);
+    I.wi = to_local(I, -d);
+}
+
+D int tex_modulo(int a, int b) { int r = a % b; return (r < 0) ? r + b : r; }  // math.h:67-70
+// MIPMap::evalTexel (mipmap.h:503-563) on level 0
+D F3 tex_texel(const DevTex &t, int x, int y) {
+    if (x < 0 || x >= t.w) {
+        switch (t.wrap_u) {
+            case PPG_WRAP_REPEAT: x = tex_modulo(x, t.w); break;
+            case PPG_WRAP_CLAMP: x = x < 0 ? 0 : t.w - 1; break;
+            case PPG_WRAP_MIRROR: x = tex_modulo(x, 2 * t.w); if (x >= t.w) x = 2 * t.w - x - 1; break;
+            case PPG_WRAP_ZERO: return f3s(0.0f);
+            default: return f3s(1.0f);
+        }
+    }
+    if (y < 0 || y >= t.h) {
+        switch (t.wrap_v) {
+            case PPG_WRAP_REPEAT: y = tex_modulo(y, t.h); break;
+            case PPG_WRAP_CLAMP: y = y < 0 ? 0 : t.h - 1; break;
+            case PPG_WRAP_MIRROR: y = tex_modulo(y, 2 * t.h); if (y >= t.h) y = 2 * t.h - y - 1; break;
+            case PPG_WRAP_ZERO: return f3s(0.0f);
+            default: return f3s(1.0f);
+        }
+    }
+    const float4 v = t.texels[(size_t)y * t.w + x];
+    return f3(v.x, v.y, v.z);
+}
+// Texture2D::eval(its) without UV partials (texture.cpp:112-121) → BitmapTexture::eval(uv) (bitmap.cpp:431-452)
+D F3 tex_eval(const DevTex &t, float iu, float iv) {
+    const float ux = iu * t.su + t.ou, uy = iv * t.sv + t.ov;
+    if (t.nearest) return tex_texel(t, (int)__builtin_floorf(ux * t.w), (int)__builtin_floorf(uy * t.h));
+    if (!ppg_isfinite(ux) || !ppg_isfinite(uy)) return f3s(0.0f);
+    const float u = ux * t.w - 0.5f, v = uy * t.h - 0.5f;
+    const int xPos = (int)__builtin_floorf(u), yPos = (int)__builtin_floorf(v);
+    const float dx1 = u - xPos, dx2 = 1.0f - dx1, dy1 = v - yPos, dy2 = 1.0f - dy1;
+    return tex_texel(t, xPos, yPos) * dx2 * dy2 + tex_texel(t, xPos, yPos + 1) * dx2 * dy1 + tex_texel(t, xPos + 1, yPos) * dx1 * dy2 +
+           tex_texel(t, xPos + 1, yPos + 1) * dx1 * dy1;
+}
+// Texture2D::evalGradient(its) (texture.cpp:123-131) over MIPMap::evalGradientBilinear(0, uv) (mipmap.h:601-626): luminance of d/du, d/dv
+D void tex_gradient_lum(const DevTex &t, float iu, float iv, float &gu, float &gv) {
+    const float ux = iu * t.su + t.ou, uy = iv * t.sv + t.ov;
+    gu = 0.0f; gv = 0.0f;
+    if (t.nearest || !ppg_isfinite(ux) || !ppg_isfinite(uy)) return;
+    const float u = ux * t.w - 0.5f, v = uy * t.h - 0.5f;
+    const int xPos = (int)__builtin_floorf(u), yPos = (int)__builtin_floorf(v);
+    const float dx = u - xPos, dy = v - yPos;
+    const F3 p00 = tex_texel(t, xPos, yPos), p10 = tex_texel(t, xPos + 1, yPos), p01 = tex_texel(t, xPos, yPos + 1), p11 = tex_texel(t, xPos + 1, yPos + 1);
+    const F3 tmp = p01 + p10 - p11;
+    F3 g0 = (p10 + p00 * (dy - 1) - tmp * dy) * (float)t.w;
+    F3 g1 = (p01 + p00 * (dx - 1) - tmp * dx) * (float)t.h;
+    g0 = g0 * t.su;
+    g1 = g1 * t.sv;
+    gu = g0.x * 0.212671f + g0.y * 0.715160f + g0.z * 0.072169f;
+    gv = g1.x * 0.212671f + g1.y * 0.715160f + g1.z * 0.072169f;
+}
+// BumpMap::getFrame (bumpmap.cpp:135-160): the perturbed frame (s, t, n)
+D void bump_frame(const DevScene &S, const Isect &I, const TexInfo &X, F3 &ps, F3 &pt, F3 &pn) {
+    float dDispDu, dDispDv;
+    tex_gradient_lum(S.textures[(X.tex >> 16) - 1], X.u, X.v, dDispDu, dDispDv);
+    const F3 dpdu = X.dpdu + I.n * (dDispDu - dot3(I.n, X.dpdu));
+    const F3 dpdv = X.dpdv + I.n * (dDispDv - dot3(I.n, X.dpdv));
+    pn = norm3(cross3(dpdu, dpdv));
+    ps = norm3(dpdu - pn * dot3(pn, dpdu));
+    pt = cross3(pn, ps);
+    if (dot3(pn, I.geoN) < 0) pn = pn * -1.0f;
 }
 
 // AreaLight::eval (area.cpp:104-109)
@@ -798,8 +946,9 @@ struct Mat {
     float alpha, fdr_int;
     const float *rt;          // roughplastic: its rough-transmittance slice, rt_n samples
     int rt_n;
+    float refl_lum;           // luminance of the material record's reflectance = of the texture's average when `refl` was read from a bitmap:
+                              // what the plug-ins' configure() derives the component sampling weights from (plastic.cpp:191-204)
 };
-#define PPG_MAT_STRIDE 5  // float4 per material: (reflectance, type) (specular, alpha) (eta, flags) (k, fdrInt) (opacity, rtrans slice)
 D Mat load_material(const DevScene &S, int id) {
     const float4 *m = S.materials + PPG_MAT_STRIDE * (size_t)id;
     const float4 a = m[0], b = m[1], c = m[2], d = m[3];
@@ -812,6 +961,7 @@ D Mat load_material(const DevScene &S, int id) {
     M.opacity = f3(e.x, e.y, e.z);
     M.rt_n = S.rtrans_n;
     M.rt = S.rtrans + (size_t)__float_as_int(e.w) * (size_t)(S.rtrans_n + 1);
+    M.refl_lum = a.x * 0.212671f + a.y * 0.715160f + a.z * 0.072169f;
     return M;
 }
 D bool mat_is_smooth(const Mat &M) {
@@ -1017,7 +1167,7 @@ D F3 ggx_sample_visible(Mfd d, F3 _wi, float u, float v) {
 
 // plastic.cpp:191-204 (configure) — recomputed per call from the material record, same arithmetic as the oracle's configure()
 D float plastic_prob_specular(const Mat &M, float Fi) {
-    float dAvg = lum3(M.refl), sAvg = lum3(M.spec);
+    float dAvg = M.refl_lum, sAvg = lum3(M.spec);
     float w = sAvg / (dAvg + sAvg);
     return (Fi * w) / (Fi * w + (1 - Fi) * (1 - w));
 }
@@ -1050,7 +1200,7 @@ D float rough_T(const Mat &M, float cosTheta) {
     return ppg_min(1.0f, ppg_max(0.0f, cubic_interp_1d(warped, M.rt, M.rt_n)));
 }
 D float roughplastic_prob_specular(const Mat &M, float cosThetaI) {  // roughplastic.cpp:406-412
-    const float dAvg = lum3(M.refl), sAvg = lum3(M.spec);
+    const float dAvg = M.refl_lum, sAvg = lum3(M.spec);
     const float w = sAvg / (dAvg + sAvg);
     const float pS = 1 - rough_T(M, cosThetaI);
     return (pS * w) / (pS * w + (1 - pS) * (1 - w));

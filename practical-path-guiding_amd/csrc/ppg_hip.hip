@@ -264,6 +264,9 @@ struct ppg_ctx {
     DevBuf<float4> d_tris, d_accel, d_accelSmall, d_normals, d_materials, d_emitters, d_emTris, d_emNrm;
     DevBuf<float> d_rtrans;  // ppg_scene.rtrans (roughplastic slices)
     DevBuf<float4> d_spheres;  // 4 float4 per analytic sphere (DevScene::spheres)
+    DevBuf<float2> d_uvs;  // bitmap textures: per-triangle texture coordinates, the texel arrays, the DevTex table
+    std::vector<DevBuf<float4>> d_texTexels;
+    DevBuf<DevTex> d_textures;
     DevBuf<float4> d_emTexels;  // image-based environment emitter: texels, cdfs, row weights
     DevBuf<float> d_emCdfRows, d_emCdfCols, d_emRowWeights;
     DevBuf<float> d_emSel, d_emArea, d_neeCos;
@@ -1364,6 +1367,51 @@ int ppg_set_scene(ppg_ctx *ctx, const ppg_scene *s) {
         mats[PPG_MAT_STRIDE * i + 2] = make_float4(m.eta[0], m.eta[1], m.eta[2], __builtin_bit_cast(float, m.flags));
         mats[PPG_MAT_STRIDE * i + 3] = make_float4(m.k[0], m.k[1], m.k[2], fdrInt);
         mats[PPG_MAT_STRIDE * i + 4] = make_float4(m.opacity[0], m.opacity[1], m.opacity[2], __builtin_bit_cast(float, m.rtrans));
+        {   // bitmap on the diffuse reflectance / bump map around the BSDF
+            const uint32_t ta = m.texture & 0xffffu, tb = m.texture >> 16;
+            if (ta > s->n_textures || tb > s->n_textures || (m.texture && !s->textures)) { ctx->error = "material.texture: index out of range"; return PPG_ERR_INVALID; }
+            if (ta && m.type != PPG_BSDF_DIFFUSE && m.type != PPG_BSDF_TWOSIDED_DIFFUSE && m.type != PPG_BSDF_PLASTIC && m.type != PPG_BSDF_ROUGHPLASTIC) {
+                ctx->error = "material.texture: only the diffuse reflectance of diffuse / plastic / roughplastic can carry a bitmap"; return PPG_ERR_INVALID;
+            }
+            if (m.texture) ctx->fullMaterials = true;  // the texture code lives in the FULL kernel variants
+            mats[PPG_MAT_STRIDE * i + 5] = make_float4(__builtin_bit_cast(float, m.texture), 0.0f, 0.0f, 0.0f);
+        }
+    }
+    for (uint32_t k = 0; k < s->n_spheres; ++k)
+        if (s->materials[s->spheres[k].material].texture) { ctx->error = "sphere: textured BSDFs are only supported on triangle meshes"; return PPG_ERR_INVALID; }
+    ctx->scene.uvs = nullptr; ctx->scene.textures = nullptr;
+    if (s->texcoords) {
+        std::vector<float2> uv(3 * (size_t)s->n_triangles);
+        for (uint32_t k = 0; k < s->n_triangles; ++k) {
+            const uint32_t t = bb.order[k];
+            for (int v = 0; v < 3; ++v) { const float *q = s->texcoords + 2 * (size_t)s->indices[3 * t + v]; uv[3 * (size_t)k + v] = make_float2(q[0], q[1]); }
+        }
+        HIP_CHECK(ctx->d_uvs.reserve(uv.size()));
+        HIP_CHECK(hipMemcpy(ctx->d_uvs.p, uv.data(), uv.size() * sizeof(float2), hipMemcpyHostToDevice));
+        ctx->scene.uvs = ctx->d_uvs.p;
+    }
+    ctx->d_texTexels.clear();
+    if (s->n_textures) {
+        if (!s->textures) { ctx->error = "textures: n_textures > 0 but no array"; return PPG_ERR_INVALID; }
+        std::vector<DevTex> table(s->n_textures);
+        ctx->d_texTexels.resize(s->n_textures);
+        for (uint32_t i = 0; i < s->n_textures; ++i) {
+            const ppg_texture &t = s->textures[i];
+            if (!t.rgb || t.width == 0 || t.height == 0 || t.width > 0x7fff || t.height > 0x7fff || t.wrap_u < 0 || t.wrap_u > PPG_WRAP_ONE || t.wrap_v < 0 || t.wrap_v > PPG_WRAP_ONE) {
+                ctx->error = "texture: needs pixels, 0 < width, height < 32768 and valid wrap modes"; return PPG_ERR_INVALID;
+            }
+            const size_t n = (size_t)t.width * t.height;
+            std::vector<float4> px(n);
+            for (size_t k = 0; k < n; ++k) px[k] = make_float4(t.rgb[3 * k], t.rgb[3 * k + 1], t.rgb[3 * k + 2], 0.0f);
+            HIP_CHECK(ctx->d_texTexels[i].reserve(n));
+            HIP_CHECK(hipMemcpy(ctx->d_texTexels[i].p, px.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+            DevTex &d = table[i];
+            d.texels = ctx->d_texTexels[i].p; d.w = (int)t.width; d.h = (int)t.height; d.su = t.uv_scale[0]; d.sv = t.uv_scale[1]; d.ou = t.uv_offset[0]; d.ov = t.uv_offset[1];
+            d.wrap_u = t.wrap_u; d.wrap_v = t.wrap_v; d.nearest = t.nearest != 0; d.pad = 0;
+        }
+        HIP_CHECK(ctx->d_textures.reserve(table.size()));
+        HIP_CHECK(hipMemcpy(ctx->d_textures.p, table.data(), table.size() * sizeof(DevTex), hipMemcpyHostToDevice));
+        ctx->scene.textures = ctx->d_textures.p;
     }
     for (uint32_t i = 0; i < s->n_emitters; ++i) ems[i] = make_float4(s->emitters[i].radiance[0], s->emitters[i].radiance[1], s->emitters[i].radiance[2], 0);
     HIP_CHECK(ctx->d_tris.reserve(tris.size()));

@@ -678,11 +678,14 @@ D bool shade_one(const PathState &P, const DevScene &S, const DevTree &T, const 
     h.t = h4.x; h.u = h4.y; h.v = h4.z; h.prim = __float_as_int(h4.w);
     const bool valid = h.prim >= 0;
     Isect I;
+    TexInfo X;
+    X.tex = 0u;
     if (valid) {
         if (FULL && h.prim >= S.n_tris) {
             const float4 ro4 = P.ray_o[i];
             fill_isect_sphere(S, h, f3(ro4.x, ro4.y, ro4.z), d, I);
-        } else fill_isect(S, h, d, I);
+        } else if (FULL) fill_isect_tex(S, h, d, I, X);
+        else fill_isect(S, h, d, I);
     }
     bool go = true;
 
@@ -825,11 +828,43 @@ D bool shade_one(const PathState &P, const DevScene &S, const DevTree &T, const 
             M.type = (int)mat.w; M.flags = 0; M.refl = f3(mat.x, mat.y, mat.z);
         }
         const bool smooth = FULL ? mat_is_smooth(M) : bsdf_is_smooth(M.type);  // bsdf->getType() & ESmooth: only those are guided
-        auto b_eval = [&](F3 wi_, F3 wo_) { return FULL ? mat_eval(M, wi_, wo_) : bsdf_eval(M.type, M.refl, wi_, wo_); };
-        auto b_pdf = [&](F3 wi_, F3 wo_) { return FULL ? mat_pdf(M, wi_, wo_) : bsdf_pdf(M.type, wi_, wo_); };
+        // bitmap on the diffuse reflectance (m_reflectance->eval(bRec.its)); `bumpmap` adapter: the frame perturbed by the displacement
+        // texture's gradient, in which the nested BSDF is queried (bumpmap.cpp:162-219)
+        bool bumped = false;
+        F3 ps = f3s(0.0f), pt = f3s(0.0f), pn = f3s(0.0f);
+        if (FULL && X.tex) {
+            if (X.tex & 0xffffu) M.refl = tex_eval(S.textures[(X.tex & 0xffffu) - 1u], X.u, X.v);
+            if (X.tex >> 16) { bump_frame(S, I, X, ps, pt, pn); bumped = true; }
+        }
+        auto to_pert = [&](F3 v_) { const F3 w_ = to_world(I, v_); return f3(dot3(w_, ps), dot3(w_, pt), dot3(w_, pn)); };
+        auto b_eval = [&](F3 wi_, F3 wo_) {
+            if (FULL && bumped) {
+                const F3 wip = to_pert(wi_), wop = to_pert(wo_);
+                if (wo_.z * wop.z <= 0) return f3s(0.0f);
+                return mat_eval(M, wip, wop);
+            }
+            return FULL ? mat_eval(M, wi_, wo_) : bsdf_eval(M.type, M.refl, wi_, wo_);
+        };
+        auto b_pdf = [&](F3 wi_, F3 wo_) {
+            if (FULL && bumped) {
+                const F3 wip = to_pert(wi_), wop = to_pert(wo_);
+                if (wo_.z * wop.z <= 0) return 0.0f;
+                return mat_pdf(M, wip, wop);
+            }
+            return FULL ? mat_pdf(M, wi_, wo_) : bsdf_pdf(M.type, wi_, wo_);
+        };
         float sampledEta = 1.0f;
         bool sampledNull = false;
         auto b_sample = [&](float u_, float v_, F3 &wo_, float &pdf_, bool &delta_) {
+            if (FULL && bumped) {
+                F3 wop = f3s(0.0f);
+                F3 result = mat_sample(M, to_pert(I.wi), u_, v_, wop, pdf_, delta_, sampledEta, sampledNull, key, dim);
+                if (!iszero3(result)) {
+                    wo_ = to_local(I, ps * wop.x + pt * wop.y + pn * wop.z);
+                    if (wo_.z * wop.z <= 0) result = f3s(0.0f);
+                }
+                return result;
+            }
             return FULL ? mat_sample(M, I.wi, u_, v_, wo_, pdf_, delta_, sampledEta, sampledNull, key, dim)
                         : bsdf_sample(M.type, M.refl, I.wi, u_, v_, wo_, pdf_, delta_);
         };

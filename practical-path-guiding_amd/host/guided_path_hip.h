@@ -45,6 +45,9 @@ struct SceneData {
     bool hasEnvmap = false;           // image-based environment emitter: envmap (pixels in envmapRgb)
     mutable ppg_envmap envmap{};
     std::vector<float> envmapRgb;
+    std::vector<float> texcoords;                  // per-vertex texture coordinates (NaN rows: none) or empty
+    mutable std::vector<ppg_texture> textures;     // bitmap textures; their pixels in texturePixels
+    std::vector<std::vector<float>> texturePixels;
 
     ppg_scene view() const {
         ppg_scene s{};
@@ -59,6 +62,9 @@ struct SceneData {
         if (hasEnvmap) { envmap.rgb = envmapRgb.data(); s.envmap = &envmap; }
         if (!spheres.empty()) { s.n_spheres = (uint32_t)spheres.size(); s.spheres = spheres.data(); }
         if (rtransSamples && !rtrans.empty()) { s.n_rtrans = (uint32_t)(rtrans.size() / (rtransSamples + 1)); s.rtrans_samples = rtransSamples; s.rtrans = rtrans.data(); }
+        s.texcoords = texcoords.empty() ? nullptr : texcoords.data();
+        for (size_t i = 0; i < textures.size(); ++i) textures[i].rgb = texturePixels[i].data();
+        if (!textures.empty()) { s.n_textures = (uint32_t)textures.size(); s.textures = textures.data(); }
         return s;
     }
 };

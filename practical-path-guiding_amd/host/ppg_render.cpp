@@ -59,6 +59,29 @@ static bool loadScene(const char *path, SceneData &s) {
         s.envmap.width = wh[0]; s.envmap.height = wh[1]; s.hasEnvmap = true;
         s.envmapRgb.resize((size_t)wh[0] * wh[1] * 3); f.read((char *)s.envmapRgb.data(), s.envmapRgb.size() * 4);
     }
+    if (hdr[5] & 16) { s.texcoords.resize(2 * (size_t)nv); f.read((char *)s.texcoords.data(), s.texcoords.size() * 4); }  // bit 4: texture coordinates
+    if (hdr[5] & 32) {  // bit 5: bitmap textures (pixels as float32 RGB, or as the 8-bit sRGB source decoded through the conversion's 256-entry table)
+        uint32_t n = 0;
+        f.read((char *)&n, 4);
+        if (!f) return false;
+        float srgb[256];
+        for (int i = 0; i < 256; ++i) { const double v = i / 255.0; srgb[i] = (float)(v <= 0.04045 ? v / 12.92 : std::pow((v + 0.055) / 1.055, 2.4)); }
+        for (uint32_t k = 0; k < n; ++k) {
+            uint32_t wh[2], storage = 0; float sc[4]; int32_t wr[3];
+            f.read((char *)wh, 8); f.read((char *)sc, 16); f.read((char *)wr, 12); f.read((char *)&storage, 4);
+            if (!f) return false;
+            ppg_texture t{};
+            t.width = wh[0]; t.height = wh[1]; t.uv_scale[0] = sc[0]; t.uv_scale[1] = sc[1]; t.uv_offset[0] = sc[2]; t.uv_offset[1] = sc[3];
+            t.wrap_u = wr[0]; t.wrap_v = wr[1]; t.nearest = wr[2];
+            std::vector<float> px((size_t)wh[0] * wh[1] * 3);
+            if (storage == 1) {
+                std::vector<unsigned char> raw(px.size());
+                f.read((char *)raw.data(), raw.size());
+                for (size_t i = 0; i < px.size(); ++i) px[i] = srgb[raw[i]];
+            } else f.read((char *)px.data(), px.size() * 4);
+            s.textures.push_back(t); s.texturePixels.push_back(std::move(px));
+        }
+    }
     return (bool)f;
 }
 
@@ -127,7 +150,8 @@ static void writePFM(const char *path, const std::vector<float> &rgb, int w, int
 static bool saveScene(const char *path, const SceneData &s) {
     std::ofstream f(path, std::ios::binary);
     const uint32_t hdr[6] = {(uint32_t)(s.positions.size() / 3), (uint32_t)(s.indices.size() / 3), (uint32_t)s.materials.size(), (uint32_t)s.emitters.size(),
-                             s.normals.empty() ? 0u : 1u, (s.hasEnvironment ? 1u : 0u) | (s.rtrans.empty() ? 0u : 2u) | (s.spheres.empty() ? 0u : 4u) | (s.hasEnvmap ? 8u : 0u)};
+                             s.normals.empty() ? 0u : 1u, (s.hasEnvironment ? 1u : 0u) | (s.rtrans.empty() ? 0u : 2u) | (s.spheres.empty() ? 0u : 4u) | (s.hasEnvmap ? 8u : 0u) |
+                                 (s.texcoords.empty() ? 0u : 16u) | (s.textures.empty() ? 0u : 32u)};
     f.write("PPGS", 4); f.write((const char *)hdr, sizeof hdr);
     f.write((const char *)s.positions.data(), s.positions.size() * 4);
     if (!s.normals.empty()) f.write((const char *)s.normals.data(), s.normals.size() * 4);
@@ -150,6 +174,19 @@ static bool saveScene(const char *path, const SceneData &s) {
         const uint32_t wh[2] = {s.envmap.width, s.envmap.height};
         f.write((const char *)wh, 8); f.write((const char *)&s.envmap.scale, 4); f.write((const char *)s.envmap.to_world, 36);
         f.write((const char *)s.envmapRgb.data(), s.envmapRgb.size() * 4);
+    }
+    if (!s.texcoords.empty()) f.write((const char *)s.texcoords.data(), s.texcoords.size() * 4);
+    if (!s.textures.empty()) {
+        const uint32_t n = (uint32_t)s.textures.size();
+        f.write((const char *)&n, 4);
+        for (uint32_t k = 0; k < n; ++k) {
+            const ppg_texture &t = s.textures[k];
+            const uint32_t wh[2] = {t.width, t.height}, storage = 0;
+            const float sc[4] = {t.uv_scale[0], t.uv_scale[1], t.uv_offset[0], t.uv_offset[1]};
+            const int32_t wr[3] = {t.wrap_u, t.wrap_v, t.nearest};
+            f.write((const char *)wh, 8); f.write((const char *)sc, 16); f.write((const char *)wr, 12); f.write((const char *)&storage, 4);
+            f.write((const char *)s.texturePixels[k].data(), s.texturePixels[k].size() * 4);
+        }
     }
     return (bool)f;
 }

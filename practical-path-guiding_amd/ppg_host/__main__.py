@@ -73,6 +73,9 @@ def main(argv=None):
                                                      t["avg_stat_weight"], t["max_stat_weight"]))
         log_lines.append(line); say(line)
 
+    out = a.output or os.path.splitext(a.scene)[0] + ".exr"
+    if props.get("dumpSDTree") and not props.get("dumpPrefix"):
+        props["dumpPrefix"] = os.path.splitext(out)[0]  # "<dest>-%02d.sdt", GP:1192-1195
     gpt = GuidedPathTracer(log=log, device=a.device, **props)
     t0 = time.monotonic()
     img = gpt.render(desc)
@@ -80,7 +83,6 @@ def main(argv=None):
     spp = sum(s["samples"] for it in gpt.iterations for s in it["stats"]) / float(info["width"] * info["height"])
     line = "Render time: %.3f s (%.1f spp, %.2f Msamples/s)" % (dt, spp, spp * info["width"] * info["height"] / dt / 1e6)
     log_lines.append(line); say(line)
-    out = a.output or os.path.splitext(a.scene)[0] + ".exr"
     if out.lower().endswith(".pfm"):
         write_pfm(out, img)
     else:

@@ -65,7 +65,7 @@ class Material(C.Structure):
     specular, alpha, eta (3 values, or one number for plastic / dielectric), k, twosided, nonlinear, opacity (a mask adapter), distribution ("ggx" | "beckmann"), rtrans (roughplastic: row of SceneDesc.rtrans)."""
     _fields_ = [("type", C.c_int32), ("reflectance", C.c_float * 3), ("specular", C.c_float * 3), ("alpha", C.c_float),
                 ("eta", C.c_float * 3), ("k", C.c_float * 3), ("flags", C.c_int32), ("rtrans", C.c_int32),
-                ("opacity", C.c_float * 3), ("_pad", C.c_float)]
+                ("opacity", C.c_float * 3), ("texture", C.c_uint32)]
 
     BSDF = dict(diffuse=0, twosided_diffuse=1, mirror=2, conductor=3, roughconductor=4, plastic=5, dielectric=6, thindielectric=7, roughdielectric=8, roughplastic=9)
 
@@ -87,6 +87,9 @@ class Material(C.Structure):
                    | (8 if m.get("distribution", "ggx") == "beckmann" else 0))
         o.opacity[:] = three(m.get("opacity"), 0.0)
         o.rtrans = int(m.get("rtrans", 0))
+        # texture: index into SceneDesc.textures of the bitmap on the diffuse reflectance; bump: of a bumpmap adapter's displacement texture
+        tex, bump = m.get("texture"), m.get("bump")
+        o.texture = (0 if tex is None else int(tex) + 1) | ((0 if bump is None else int(bump) + 1) << 16)
         return o
 
 
@@ -123,6 +126,30 @@ class EnvMap(C.Structure):
         return o
 
 
+class Texture(C.Structure):
+    """ppg_texture (include/ppg.h).  Scene descriptions carry textures as dicts: rgb (float32 [height, width, 3], linear), uv_scale, uv_offset,
+    wrap_u / wrap_v ("repeat" | "mirror" | "clamp" | "zero" | "one"), nearest."""
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("rgb", C.POINTER(C.c_float)), ("uv_scale", C.c_float * 2), ("uv_offset", C.c_float * 2),
+                ("wrap_u", C.c_int32), ("wrap_v", C.c_int32), ("nearest", C.c_int32)]
+    WRAP = dict(repeat=0, mirror=1, clamp=2, zero=3, one=4)
+
+    @classmethod
+    def from_dict(cls, d):
+        o = cls()
+        rgb = np.ascontiguousarray(d["rgb"], np.float32)
+        assert rgb.ndim == 3 and rgb.shape[2] == 3
+        o.height, o.width = rgb.shape[0], rgb.shape[1]
+        o.rgb = rgb.ctypes.data_as(C.POINTER(C.c_float))
+        o.uv_scale[:] = [float(np.float32(v)) for v in d.get("uv_scale", (1.0, 1.0))]
+        o.uv_offset[:] = [float(np.float32(v)) for v in d.get("uv_offset", (0.0, 0.0))]
+        wu, wv = d.get("wrap_u", "repeat"), d.get("wrap_v", "repeat")
+        o.wrap_u = cls.WRAP[wu] if isinstance(wu, str) else int(wu)
+        o.wrap_v = cls.WRAP[wv] if isinstance(wv, str) else int(wv)
+        o.nearest = 1 if d.get("nearest") else 0
+        o._keep = rgb
+        return o
+
+
 class Emitter(C.Structure):
     _fields_ = [("radiance", C.c_float * 3), ("_pad", C.c_float)]
 
@@ -138,7 +165,8 @@ class Scene(C.Structure):
                 ("tri_emitter", C.POINTER(C.c_int32)), ("n_materials", C.c_uint32), ("materials", C.POINTER(Material)),
                 ("n_emitters", C.c_uint32), ("emitters", C.POINTER(Emitter)), ("camera", Camera), ("environment", C.POINTER(C.c_float)),
                 ("n_rtrans", C.c_uint32), ("rtrans_samples", C.c_uint32), ("rtrans", C.POINTER(C.c_float)),
-                ("n_spheres", C.c_uint32), ("spheres", C.POINTER(Sphere)), ("envmap", C.POINTER(EnvMap))]
+                ("n_spheres", C.c_uint32), ("spheres", C.POINTER(Sphere)), ("envmap", C.POINTER(EnvMap)),
+                ("texcoords", C.POINTER(C.c_float)), ("n_textures", C.c_uint32), ("textures", C.POINTER(Texture))]
 
 
 class _StatsMixin:
@@ -267,12 +295,26 @@ class Engine:
         if getattr(desc, "envmap", None) is not None:
             envmap = EnvMap.from_dict(desc.envmap)
             s.envmap = C.pointer(envmap)
+        uvs = getattr(desc, "texcoords", None)
+        if uvs is not None:
+            uvs = np.ascontiguousarray(uvs, np.float32)
+            assert uvs.shape == (pos.shape[0], 2)
+            s.texcoords = _fp(uvs)
+        texs = getattr(desc, "textures", None) or []
+        tex_arr = (Texture * max(1, len(texs)))()
+        tex_keep = []
+        for i, d in enumerate(texs):
+            t = Texture.from_dict(d)
+            tex_keep.append(t._keep)
+            tex_arr[i] = t
+        if texs:
+            s.n_textures, s.textures = len(texs), tex_arr
         cam = desc.camera
         s.camera.sample_to_camera[:] = [float(v) for v in np.asarray(cam["sample_to_camera"], np.float32).reshape(-1)]
         s.camera.camera_to_world[:] = [float(v) for v in np.asarray(cam["camera_to_world"], np.float32).reshape(-1)]
         s.camera.near_clip, s.camera.far_clip = cam["near_clip"], cam["far_clip"]
         s.camera.width, s.camera.height = cam["width"], cam["height"]
-        self._scene_keep = (pos, idx, tm, te, nrm, mats, ems, rt, sph_arr, envmap)
+        self._scene_keep = (pos, idx, tm, te, nrm, mats, ems, rt, sph_arr, envmap, uvs, tex_arr, tex_keep)
         self._call("set_scene", C.byref(s))
         self.width, self.height = cam["width"], cam["height"]
 

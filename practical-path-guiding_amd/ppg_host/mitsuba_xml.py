@@ -294,11 +294,12 @@ def load_obj(path, to_world=None, face_normals=False, flip_normals=False, flip_t
         pos = np.asarray(vp, f32).reshape(-1, 3)
         idx = np.asarray(idx, np.uint32).reshape(-1, 3)
         normals = np.asarray(vn, f32).reshape(-1, 3) if has_normals else None
+        muv = np.asarray(vuv, f32).reshape(-1, 2) if has_uvs else None
         if max_smooth_angle is not None:  # obj.cpp:336-343: the file's normals are discarded, creases found from the dihedral angles
-            pos, _, idx = rebuild_topology(pos, np.asarray(vuv, f32).reshape(-1, 2) if has_uvs else None, idx, max_smooth_angle)
+            pos, muv, idx = rebuild_topology(pos, muv, idx, max_smooth_angle)
             normals = None
         normals, idx = _finish_normals(pos, normals, idx, face_normals, flip_normals)
-        meshes.append(dict(name=mesh_name, material=material, positions=pos, normals=normals, indices=idx))
+        meshes.append(dict(name=mesh_name, material=material, positions=pos, normals=normals, indices=idx, uvs=muv))
         tris = []
 
     for line in _fetch_lines(path):
@@ -540,7 +541,7 @@ def _props(elem, sub):
     return out
 
 
-def load_scene(path, defines=None, strict=True, width=None, height=None, data_dir=None):
+def load_scene(path, defines=None, strict=True, width=None, height=None, data_dir=None, mitsuba_src=None):
     """Parse `path` → (SceneDesc, integrator properties for ppg_create, info dict).
 
     defines: {"name": "value"} like `mitsuba -D name=value`; width/height override the film size; data_dir: the `data` directory of
@@ -603,6 +604,7 @@ def load_scene(path, defines=None, strict=True, width=None, height=None, data_di
 
     # ---- bsdfs
     materials, mat_index, by_id = [], {}, {}
+    tex_by_id = {t.get("id"): t for t in root.findall("texture") if t.get("id")}
 
     def colour(elem, name, default):
         for c in elem:
@@ -624,10 +626,91 @@ def load_scene(path, defines=None, strict=True, width=None, height=None, data_di
                     return spectrum.blackbody_to_rgb(float(t[:-1] if t[-1:] in "kK" else t), float(sub(c.get("scale", "1"))))
                 if c.tag == "texture" or c.tag == "ref":
                     if strict:
-                        raise SceneError("textured %r is not supported (SURVEY.md §8 f1)" % name)
+                        raise SceneError("a texture on %r is not supported (bitmaps on diffuse reflectances and bump maps are)" % name)
                     warnings.append("texture on %r ignored: the plug-in's default value is used" % name)
                     break
         return np.full(3, default, f32)
+
+    textures, tex_index = [], {}
+
+    def bitmap_texture(elem, what):
+        """<texture type="bitmap"> (textures/bitmap.cpp:90-330) → index into `textures`.  The image is decoded here — 8-bit files through the
+        sRGB curve unless `gamma` says otherwise (bitmap.cpp:182-204), luminance replicated to RGB — because the integrator only ever
+        reads level 0 of the MIP map (include/ppg.h ppg_texture)."""
+        if elem.tag == "ref":
+            target = tex_by_id.get(elem.get("id"))
+            if target is None:
+                raise SceneError("<ref id=%r>: no such texture" % elem.get("id"))
+            elem = target
+        if elem.get("type") != "bitmap":
+            raise SceneError("texture type %r on %s is not supported (bitmap only)" % (elem.get("type"), what))
+        tp = _props(elem, sub)
+        fn = tp.get("filename")
+        if not fn:
+            raise SceneError("bitmap texture without filename")
+        full = fn if os.path.isabs(fn) else os.path.join(base, fn)
+        wrap = str(tp.get("wrapMode", "repeat")).lower()
+        wu, wv = str(tp.get("wrapModeU", wrap)).lower(), str(tp.get("wrapModeV", wrap)).lower()
+        for wm in (wu, wv):
+            if wm not in ("repeat", "mirror", "clamp", "zero", "one"):
+                raise SceneError("bitmap: invalid wrap mode %r" % wm)  # bitmap.cpp:113-127
+        filt = str(tp.get("filterType", "ewa")).lower()
+        if filt not in ("ewa", "trilinear", "nearest", "bilinear"):
+            raise SceneError("bitmap: invalid filter type %r" % filt)
+        gamma = float(tp.get("gamma", 0.0))
+        key = (full, wu, wv, filt == "nearest", gamma, float(tp.get("uscale", 1.0)), float(tp.get("vscale", 1.0)), float(tp.get("uoffset", 0.0)), float(tp.get("voffset", 0.0)),
+               str(tp.get("channel", "")))
+        if key in tex_index:
+            return tex_index[key]
+        if not os.path.exists(full):
+            raise SceneError("bitmap: file '%s' not found" % full)
+        if tp.get("channel"):
+            raise SceneError("bitmap: the `channel` parameter is not supported")
+        from . import imageio
+        from .scenes import srgb8_table
+        t = dict(uv_scale=(float(tp.get("uscale", 1.0)), float(tp.get("vscale", 1.0))), uv_offset=(float(tp.get("uoffset", 0.0)), float(tp.get("voffset", 0.0))),
+                 wrap_u=wu, wrap_v=wv, nearest=filt == "nearest", source=os.path.basename(full))
+        ext = os.path.splitext(full)[1].lower()
+        if ext in (".exr", ".pfm", ".hdr", ".rgbe"):
+            t["rgb"] = np.ascontiguousarray(imageio.read_image(full), f32)  # floating point data is linear (bitmap.cpp:190-192)
+        else:
+            try:
+                from PIL import Image
+            except ImportError:
+                raise SceneError("bitmap: decoding '%s' needs PIL (scene conversion only)" % full)
+            im = Image.open(full)
+            if im.mode in ("P", "RGBA", "LA", "CMYK", "1", "I;16", "I"):  # alpha is dropped for a spectrum texture (bitmap.cpp:218-236: EAuto → RGB / luminance)
+                im = im.convert("RGB" if im.mode != "LA" else "L")
+            a = np.asarray(im)
+            if a.dtype != np.uint8:
+                raise SceneError("bitmap: '%s': only 8-bit images are decoded here" % full)
+            if a.ndim == 2:
+                a = np.repeat(a[:, :, None], 3, 2)
+            a = np.ascontiguousarray(a[:, :, :3])
+            if gamma == 0.0 or gamma == -1.0:  # the file's own encoding: sRGB for 8-bit images
+                t["srgb8"] = a
+                t["rgb"] = srgb8_table()[a]
+            else:  # an explicit gamma (bump maps ask for 1.0, bumpmap.cpp:121-126): value^gamma on value / 255
+                t["rgb"] = np.power(a.astype(np.float64) / 255.0, gamma).astype(f32)
+        # Texture::getAverage: the mean of the full-resolution image (the MIP map's 1x1 level; exact for power-of-two sizes)
+        t["average"] = [float(v) for v in t["rgb"].reshape(-1, 3).mean(0, dtype=np.float64)]
+        tex_index[key] = len(textures)
+        textures.append(t)
+        return tex_index[key]
+
+    def colour_or_texture(elem, name, default):
+        """(rgb, texture index or None) of a reflectance that may be a bitmap; rgb is then the bitmap's average."""
+        for c in elem:
+            if c.get("name") == name and c.tag in ("texture", "ref") and (c.tag == "texture" or c.get("id") in tex_by_id):
+                try:
+                    ti = bitmap_texture(c, name)
+                except SceneError as e:
+                    if strict:
+                        raise
+                    warnings.append("texture on %r ignored (%s): the plug-in's default value is used" % (name, e))
+                    return np.full(3, default, f32), None
+                return np.asarray(textures[ti]["average"], f32), ti
+        return colour(elem, name, default), None
 
     IOR = {"vacuum": 1.0, "air": 1.000277, "water": 1.3330, "polypropylene": 1.49, "bk7": 1.5046, "diamond": 2.419}  # well-known constants (cf. ior.h)
 
@@ -675,8 +758,14 @@ def load_scene(path, defines=None, strict=True, width=None, height=None, data_di
         t = elem.get("type")
         p = _props(elem, sub)
         rgb = lambda name, d: tuple(float(v) for v in colour(elem, name, d))  # noqa: E731
+        def textured(m, name, d):  # a bitmap on the diffuse reflectance: constant = its average, plus the texture index
+            c, ti = colour_or_texture(elem, name, d)
+            m["reflectance"] = tuple(float(v) for v in c)
+            if ti is not None:
+                m["texture"] = ti
+            return m
         if t == "diffuse":
-            return dict(type=0, reflectance=rgb("reflectance", 0.5))
+            return textured(dict(type=0), "reflectance", 0.5)
         if t == "twosided" and allow_twosided:
             inner = [c for c in elem if c.tag == "bsdf"]
             if len(inner) == 1:
@@ -684,7 +773,7 @@ def load_scene(path, defines=None, strict=True, width=None, height=None, data_di
                 if m["type"] in (6, 7, 8):
                     raise SceneError("twosided(dielectric): only BRDFs can be two-sided (twosided.cpp:84-88)")
                 if m["type"] == 0 and not m.get("_substituted"):
-                    return dict(type=1, reflectance=m["reflectance"])
+                    return dict({k: v for k, v in m.items() if k in ("texture", "bump")}, type=1, reflectance=m["reflectance"])
                 return dict(m, twosided=True)
             t = "twosided(%s)" % ",".join(c.get("type", "?") for c in inner)
         elif t == "mask" and allow_twosided:
@@ -694,7 +783,7 @@ def load_scene(path, defines=None, strict=True, width=None, height=None, data_di
                 if "opacity" in m:
                     raise SceneError("mask(mask(...)) is not supported")
                 if m["type"] == 1:
-                    m = dict(type=0, reflectance=m["reflectance"], twosided=True)
+                    m = dict({k: v for k, v in m.items() if k in ("texture", "bump")}, type=0, reflectance=m["reflectance"], twosided=True)
                 return dict(m, opacity=rgb("opacity", 0.5))
             t = "mask(%s)" % ",".join(c.get("type", "?") for c in inner)
         elif t == "conductor":
@@ -710,8 +799,8 @@ def load_scene(path, defines=None, strict=True, width=None, height=None, data_di
             return m
         elif t == "plastic":
             eta = lookup_ior(p, "intIOR", "polypropylene") / lookup_ior(p, "extIOR", "air")
-            return dict(type=5, reflectance=rgb("diffuseReflectance", 0.5), specular=rgb("specularReflectance", 1.0), eta=float(f32(eta)),
-                        nonlinear=bool(p.get("nonlinear", False)))
+            return textured(dict(type=5, specular=rgb("specularReflectance", 1.0), eta=float(f32(eta)), nonlinear=bool(p.get("nonlinear", False))),
+                            "diffuseReflectance", 0.5)
         elif t == "dielectric":
             eta = lookup_ior(p, "intIOR", "bk7") / lookup_ior(p, "extIOR", "air")
             return dict(type=6, reflectance=rgb("specularReflectance", 1.0), specular=rgb("specularTransmittance", 1.0), eta=float(f32(eta)))
@@ -732,8 +821,8 @@ def load_scene(path, defines=None, strict=True, width=None, height=None, data_di
                 except _rt.RoughTransmittanceError as e:
                     raise SceneError("roughplastic: %s" % e)
                 rt_index[key] = len(rt_slices) - 1
-            m = dict(type=9, reflectance=rgb("diffuseReflectance", 0.5), specular=rgb("specularReflectance", 1.0), eta=eta, alpha=alpha,
-                     nonlinear=bool(p.get("nonlinear", False)), rtrans=rt_index[key])
+            m = textured(dict(type=9, specular=rgb("specularReflectance", 1.0), eta=eta, alpha=alpha, nonlinear=bool(p.get("nonlinear", False)), rtrans=rt_index[key]),
+                         "diffuseReflectance", 0.5)
             if distr == "beckmann":
                 m["distribution"] = "beckmann"
             return m
@@ -746,6 +835,22 @@ def load_scene(path, defines=None, strict=True, width=None, height=None, data_di
             if str(p.get("distribution", "beckmann")).lower() == "beckmann":
                 m["distribution"] = "beckmann"
             return m
+        if t == "bumpmap":  # BumpMap (bumpmap.cpp:60-133): one nested BSDF + one displacement texture, the outermost adapter
+            inner = [c for c in elem if c.tag == "bsdf"]
+            disp = [c for c in elem if c.tag in ("texture", "ref") and (c.tag == "texture" or c.get("id") in tex_by_id)]
+            if len(inner) == 1 and len(disp) == 1:
+                m = make_bsdf(inner[0], allow_twosided)
+                try:
+                    if "bump" in m:
+                        raise SceneError("bumpmap(bumpmap(...)) is not supported")
+                    if disp[0].tag == "texture" and disp[0].get("type") == "bitmap" and "gamma" not in _props(disp[0], sub):
+                        raise SceneError("When using a bitmap texture as a bump map, please explicitly specify the 'gamma' parameter of the bitmap plugin")  # bumpmap.cpp:121-126
+                    return dict(m, bump=bitmap_texture(disp[0], "bumpmap"))
+                except SceneError as e:
+                    if strict:
+                        raise
+                    warnings.append("bump map dropped around its nested bsdf (%s)" % e)
+                    return m
         if not strict and t in ("bumpmap", "coating", "roughcoating", "normalmap"):  # adapters around one nested BSDF: render the nested one
             inner = [c for c in elem if c.tag == "bsdf"]
             if len(inner) == 1:
@@ -775,8 +880,6 @@ def load_scene(path, defines=None, strict=True, width=None, height=None, data_di
         for b in top.iter("bsdf"):
             if b is not top and b.get("id") and b.get("id") not in by_id:
                 by_id[b.get("id")] = intern(make_bsdf(b))
-    for tex in root.findall("texture"):
-        warnings.append("top-level texture %r ignored" % tex.get("id"))
     environment = envmap = None
     for em in root.findall("emitter"):
         if em.get("type") == "constant" and environment is None and envmap is None:
@@ -801,10 +904,36 @@ def load_scene(path, defines=None, strict=True, width=None, height=None, data_di
                 raise SceneError("envmap: toWorld must be a rotation")
             envmap = dict(rgb=rgb, scale=float(ep.get("scale", 1.0)), to_world=[float(v) for v in R.reshape(-1)])
             continue
+        if em.get("type") == "sunsky" and environment is None and envmap is None:
+            # SunSkyEmitter (sunsky.cpp:100-235) bakes sun + sky into a radiance map and instantiates `envmap` on it: same bake here
+            # (ppg_host/sunsky.py); the Hosek-Wilkie / Preetham tables are read from the operator's Mitsuba source tree
+            from . import sunsky
+            ddir = data_dir or os.environ.get("PPG_MITSUBA_DATA")
+            src = mitsuba_src or os.environ.get("PPG_MITSUBA_SRC") or (os.path.dirname(os.path.abspath(ddir)) if ddir else None)
+            if not src or not os.path.exists(os.path.join(src, "src", "emitters", "sunsky", "skymodeldata.h")):
+                if strict:
+                    raise SceneError("sunsky: the sky model's coefficient tables (src/emitters/sunsky/skymodeldata.h, sunmodel.h) come with Mitsuba's "
+                                     "source tree: pass mitsuba_src / --data-dir <tree>/data / PPG_MITSUBA_SRC")
+                warnings.append("emitter 'sunsky' skipped (no Mitsuba source tree for the sky model's tables)")
+                continue
+            ep = _props(em, sub)
+            for c in em:
+                if c.get("name") == "albedo" and c.tag in ("rgb", "srgb", "spectrum"):
+                    ep["albedo"] = [float(v) for v in spectrum.parse(c.tag, sub(c.get("value")))]
+            try:
+                rgb, _ = sunsky.bake(ep, src)
+            except (ValueError, NotImplementedError) as e:
+                raise SceneError("sunsky: %s" % e)
+            tw = em.find("transform")
+            R = (_transform(tw, sub) if tw is not None else np.eye(4, dtype=f32))[:3, :3].astype(f32)
+            if not np.allclose(R @ R.T, np.eye(3), atol=1e-4):
+                raise SceneError("sunsky: toWorld must be a rotation")
+            envmap = dict(rgb=rgb, scale=1.0, to_world=[float(v) for v in R.reshape(-1)])
+            continue
         if not strict:
             warnings.append("emitter %r skipped (not supported)" % em.get("type"))
             continue
-        raise SceneError("emitter type %r is not supported (area emitters on shapes and one `constant` or `envmap` environment emitter; "
+        raise SceneError("emitter type %r is not supported (area emitters on shapes and one `constant`, `envmap` or `sunsky` environment emitter; "
                          "SURVEY.md §8 f2)" % em.get("type"))
 
     # ---- shapes
@@ -915,11 +1044,17 @@ def load_scene(path, defines=None, strict=True, width=None, height=None, data_di
     # one vertex-normal array for the whole scene: a faceNormals mesh living next to smooth ones gets its vertices
     # un-shared and its face normals written out (same shading frame as "no normals": skdtree.h:388-401)
     any_normals = any(m["normals"] is not None for m, _, _ in collected)
+    # texture coordinates only matter on meshes whose BSDF reads a bitmap; the others get NaN rows (= none)
+    any_uvs = any(m.get("uvs") is not None and ("texture" in materials[mat] or "bump" in materials[mat]) for m, mat, _ in collected)
+    uvl = []
     pos, nrm, idx, tmat, tem = [], [], [], [], []
     nv = 0
     for mesh, mat, em in collected:
         p, i, n = mesh["positions"], mesh["indices"], mesh["normals"]
+        uv = mesh.get("uvs") if ("texture" in materials[mat] or "bump" in materials[mat]) else None
         if any_normals and n is None:
+            if uv is not None:
+                uv = uv[i.reshape(-1)]
             p = p[i.reshape(-1)]
             a, b = p[1::3] - p[0::3], p[2::3] - p[0::3]
             fnrm = np.cross(a, b).astype(f32)
@@ -929,11 +1064,13 @@ def load_scene(path, defines=None, strict=True, width=None, height=None, data_di
             i = np.arange(p.shape[0], dtype=np.uint32).reshape(-1, 3)
         T = i.shape[0]
         pos.append(p); idx.append(i + np.uint32(nv)); nrm.append(n)
+        uvl.append(uv.astype(f32) if uv is not None else np.full((p.shape[0], 2), np.nan, f32))
         nv += p.shape[0]
         tmat.append(np.full(T, mat, np.uint32)); tem.append(np.full(T, em, np.int32))
     normals = np.concatenate(nrm).astype(f32) if any_normals else None
     desc = SceneDesc(np.concatenate(pos).astype(f32), np.concatenate(idx).astype(np.uint32), np.concatenate(tmat), np.concatenate(tem),
-                     materials, emitters, camera, normals, environment, np.stack(rt_slices).astype(f32) if rt_slices else None, spheres, envmap)
+                     materials, emitters, camera, normals, environment, np.stack(rt_slices).astype(f32) if rt_slices else None, spheres, envmap,
+                     np.concatenate(uvl).astype(f32) if any_uvs else None, textures)
     info["warnings"] = warnings
     return desc, props, info
 

@@ -16,7 +16,8 @@ import numpy as np
 
 
 class SceneDesc:
-    def __init__(self, positions, indices, tri_material, tri_emitter, materials, emitters, camera, normals=None, environment=None, rtrans=None, spheres=None, envmap=None):
+    def __init__(self, positions, indices, tri_material, tri_emitter, materials, emitters, camera, normals=None, environment=None, rtrans=None, spheres=None, envmap=None,
+                 texcoords=None, textures=None):
         self.positions, self.indices = positions, indices
         self.tri_material, self.tri_emitter = tri_material, tri_emitter
         self.materials, self.emitters, self.camera, self.normals = materials, emitters, camera, normals
@@ -24,6 +25,9 @@ class SceneDesc:
         self.rtrans = rtrans            # None or float32 [n_slices, samples + 1]: rough-transmittance slices of the roughplastic materials
         self.envmap = envmap            # None or dict(rgb=float32 [h, w, 3], scale, to_world): image-based environment emitter (bindings.EnvMap)
         self.spheres = spheres or []    # analytic spheres: dicts {center, radius, material, emitter, flip_normals, to_world} (bindings.Sphere)
+        self.texcoords = texcoords      # None or float32 [n_vertices, 2] (NaN rows: vertices of meshes without texture coordinates)
+        self.textures = textures or []  # bitmap textures: dicts {rgb, uv_scale, uv_offset, wrap_u, wrap_v, nearest} (bindings.Texture); materials refer
+                                        # to them by index: material["texture"] (diffuse reflectance), material["bump"] (bumpmap displacement)
 
     @property
     def n_triangles(self):
@@ -32,10 +36,12 @@ class SceneDesc:
 
 def save_scene(desc, path):
     """Write the flat binary scene read by host/ppg_render.cpp: "PPGS", 6 x uint32 {n_vertices, n_triangles, n_materials,
-    n_emitters, has_normals, blocks (bit 0: environment, bit 1: rtrans, bit 2: spheres, bit 3: envmap)}, then positions, [normals], indices, tri_material,
+    n_emitters, has_normals, blocks (bit 0: environment, bit 1: rtrans, bit 2: spheres, bit 3: envmap, bit 4: texcoords, bit 5: textures)}, then positions, [normals], indices, tri_material,
     tri_emitter, materials (ppg_material, 80 bytes each), emitters (4 floats), camera (ppg_camera), [environment radiance:
     3 floats], [rtrans: 2 x uint32 {n_slices, samples}, then n_slices x (samples + 1) floats], [spheres: uint32 n, then n x ppg_sphere
-    (64 bytes)], [envmap: 2 x uint32 {width, height}, float scale, 9 floats to_world, then height x width x 3 floats]."""
+    (64 bytes)], [envmap: 2 x uint32 {width, height}, float scale, 9 floats to_world, then height x width x 3 floats], [texcoords: n_vertices x 2
+    floats], [textures: uint32 n, then per texture 2 x uint32 {width, height}, 4 floats uv scale / offset, 3 x int32 {wrap_u, wrap_v, nearest}, uint32
+    storage (0: float32 RGB, 1: uint8 sRGB-encoded RGB — decoded on load with the exact 256-entry table of the 8-bit → float conversion), pixels]."""
     import struct
     pos = np.ascontiguousarray(desc.positions, np.float32)
     idx = np.ascontiguousarray(desc.indices, np.uint32)
@@ -45,7 +51,8 @@ def save_scene(desc, path):
         rt = getattr(desc, "rtrans", None)
         rt = None if rt is None or not len(rt) else np.ascontiguousarray(rt, np.float32)
         f.write(struct.pack("<6I", pos.shape[0], idx.shape[0], len(desc.materials), len(desc.emitters), 0 if desc.normals is None else 1,
-                            (0 if env is None else 1) | (0 if rt is None else 2) | (4 if getattr(desc, "spheres", None) else 0) | (8 if getattr(desc, "envmap", None) is not None else 0)))
+                            (0 if env is None else 1) | (0 if rt is None else 2) | (4 if getattr(desc, "spheres", None) else 0) | (8 if getattr(desc, "envmap", None) is not None else 0)
+                            | (16 if getattr(desc, "texcoords", None) is not None else 0) | (32 if getattr(desc, "textures", None) else 0)))
         f.write(pos.tobytes())
         if desc.normals is not None:
             f.write(np.ascontiguousarray(desc.normals, np.float32).tobytes())
@@ -77,6 +84,25 @@ def save_scene(desc, path):
             f.write(struct.pack("<2If9f", rgb.shape[1], rgb.shape[0], float(np.float32(em.get("scale", 1.0))),
                                 *[float(np.float32(v)) for v in np.asarray(em.get("to_world", np.eye(3)), np.float32).reshape(-1)]))
             f.write(rgb.tobytes())
+        if getattr(desc, "texcoords", None) is not None:
+            f.write(np.ascontiguousarray(desc.texcoords, np.float32).tobytes())
+        if getattr(desc, "textures", None):
+            from .bindings import Texture
+            f.write(struct.pack("<I", len(desc.textures)))
+            for t in desc.textures:
+                rgb = np.ascontiguousarray(t["rgb"], np.float32)
+                wu, wv = t.get("wrap_u", "repeat"), t.get("wrap_v", "repeat")
+                src8 = t.get("srgb8")  # the 8-bit source of an sRGB-decoded image: stored instead of the floats (4x smaller)
+                f.write(struct.pack("<2I4f3iI", rgb.shape[1], rgb.shape[0], *[float(np.float32(v)) for v in t.get("uv_scale", (1, 1))],
+                                    *[float(np.float32(v)) for v in t.get("uv_offset", (0, 0))], Texture.WRAP[wu] if isinstance(wu, str) else int(wu),
+                                    Texture.WRAP[wv] if isinstance(wv, str) else int(wv), 1 if t.get("nearest") else 0, 0 if src8 is None else 1))
+                f.write(rgb.tobytes() if src8 is None else np.ascontiguousarray(src8, np.uint8).tobytes())
+
+
+def srgb8_table():
+    """uint8 sRGB → linear float32, the table of the 8-bit → float conversion (bitmap.cpp / fmtconv.cpp: value / 255 through the sRGB curve)."""
+    v = np.arange(256, dtype=np.float64) / 255.0
+    return np.where(v <= 0.04045, v / 12.92, ((v + 0.055) / 1.055) ** 2.4).astype(np.float32)
 
 
 def load_scene_file(path):
@@ -106,6 +132,10 @@ def load_scene_file(path):
             d["opacity"] = tuple(m.opacity)
         if m.flags & 8:
             d["distribution"] = "beckmann"
+        if m.texture & 0xffff:
+            d["texture"] = (m.texture & 0xffff) - 1
+        if m.texture >> 16:
+            d["bump"] = (m.texture >> 16) - 1
         mats.append(d)
     ems = [dict(radiance=tuple(float(v) for v in take(np.float32, 4)[:3])) for _ in range(ne)]
     cam = dict(sample_to_camera=take(np.float32, 16).reshape(4, 4).copy(), camera_to_world=take(np.float32, 16).reshape(4, 4).copy())
@@ -128,9 +158,25 @@ def load_scene_file(path):
         scale = float(take(np.float32, 1)[0])
         R = [float(v) for v in take(np.float32, 9)]
         envmap = dict(rgb=take(np.float32, w * h * 3).reshape(h, w, 3).copy(), scale=scale, to_world=R)
+    uvs = take(np.float32, 2 * nv).reshape(-1, 2).copy() if blocks & 16 else None
+    textures = []
+    if blocks & 32:
+        names = ["repeat", "mirror", "clamp", "zero", "one"]
+        for _ in range(int(take(np.uint32, 1)[0])):
+            w, h = (int(v) for v in take(np.uint32, 2))
+            sc = [float(v) for v in take(np.float32, 4)]
+            wu, wv, nearest = (int(v) for v in take(np.int32, 3))
+            storage = int(take(np.uint32, 1)[0])
+            t = dict(uv_scale=tuple(sc[:2]), uv_offset=tuple(sc[2:]), wrap_u=names[wu], wrap_v=names[wv], nearest=bool(nearest))
+            if storage == 1:
+                t["srgb8"] = take(np.uint8, w * h * 3).reshape(h, w, 3).copy()
+                t["rgb"] = srgb8_table()[t["srgb8"]]
+            else:
+                t["rgb"] = take(np.float32, w * h * 3).reshape(h, w, 3).copy()
+            textures.append(t)
     if off[0] != len(buf):
         raise ValueError("%s: trailing bytes" % path)
-    return SceneDesc(pos, idx, tm, te, mats, ems, cam, nrm, env, rt, spheres, envmap)
+    return SceneDesc(pos, idx, tm, te, mats, ems, cam, nrm, env, rt, spheres, envmap, uvs, textures)
 
 
 def _sample_to_camera(fov_deg, fov_axis, near, far, width, height):

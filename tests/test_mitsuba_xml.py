@@ -154,7 +154,9 @@ def test_loader_subset_semantics(tmp_path):
     ('<shape type="rectangle"><bsdf type="ward"/></shape>', "ward"),
     ('<shape type="rectangle"><bsdf type="conductor"><string name="material" value="Au"/></bsdf></shape>', "Au"),
     ('<emitter type="sunsky"/>', "sunsky"),
-    ('<shape type="rectangle"><bsdf type="diffuse"><texture name="reflectance" type="bitmap"/></bsdf></shape>', "textured"),
+    ('<shape type="rectangle"><bsdf type="diffuse"><texture name="reflectance" type="checkerboard"/></bsdf></shape>', "checkerboard"),
+    ('<shape type="rectangle"><bsdf type="diffuse"><texture name="reflectance" type="bitmap"/></bsdf></shape>', "without filename"),
+    ('<shape type="rectangle"><bsdf type="dielectric"><texture name="specularReflectance" type="bitmap"/></bsdf></shape>', "texture on"),
     ('<shape type="obj"><string name="filename" value="meshes/missing.obj"/></shape>', "not found"),
 ])
 def test_unsupported_plugins_are_named(tmp_path, extra, needle):
@@ -567,14 +569,15 @@ LENIENT_EXTRA = """
 
 def test_lenient_loading_of_kitchen_style_constructs(tmp_path):
     """What the reference's KITCHEN scene needs from a lenient load: an id on a bsdf NESTED in a bumpmap is a named object of its own
-    (the shapes reference the inner twosided, not the bump adapter); textures fall back to the plug-in's default value; bumpmap is dropped
-    around its nested bsdf; the sunsky emitter is skipped — each with a warning.  Strict loading names the first unsupported construct."""
+    (the shapes reference the inner twosided, not the bump adapter); textures whose files are missing fall back to the plug-in's default
+    value; a bump map that cannot be loaded is dropped around its nested bsdf; the sunsky emitter is skipped without a Mitsuba source tree
+    for the sky model's tables — each with a warning.  Strict loading names the first unsupported construct."""
     xml = _write(tmp_path, LENIENT_EXTRA)
-    with pytest.raises(mitsuba_xml.SceneError, match="bumpmap|textured|sunsky"):
+    with pytest.raises(mitsuba_xml.SceneError, match="bumpmap|texture|bitmap|sunsky"):
         ppg_host.load_scene(xml, defines=dict(nee="never"))
     desc, _, info = ppg_host.load_scene(xml, defines=dict(nee="never"), strict=False)
     w = "\n".join(info["warnings"])
-    assert "texture on 'reflectance' ignored" in w and "bsdf 'bumpmap' dropped" in w and "emitter 'sunsky' skipped" in w
+    assert "texture on 'reflectance' ignored" in w and "bump map dropped" in w and "emitter 'sunsky' skipped" in w
     a, b = desc.materials[desc.tri_material[-4]], desc.materials[desc.tri_material[-1]]
     assert a["type"] == 1 and tuple(a["reflectance"]) == (0.5, 0.5, 0.5)          # the inner twosided diffuse with diffuse's default reflectance
     assert b["type"] == 4 and b.get("distribution") is None
