@@ -1,25 +1,34 @@
 #!/usr/bin/env python3
-"""bench.py — Msamples/s of the guided path tracer hot path on MI355X.
+"""bench.py — Msamples/s (+ time to target RMSE) of the guided path tracer hot path on MI355X.
 
-Workload (BASELINE.json configs[1]): procedural CBOX (= scenes/cbox/cbox.xml, 36 triangles) at 1280x720,
-4 spp per pass, default SD-tree parameters (sTreeThreshold 12000, dTreeThreshold 0.01,
-bsdfSamplingFraction 0.5, nearest filters, sampleCombination automatic), maxDepth 10 / rrDepth 10 /
-strictNormals as in the scene file, budgetType = spp.
+Default workload = BASELINE.json configs[2], the configuration the metric is quoted on: the reference's bundled KITCHEN scene
+(scenes/kitchen/kitchen-improved.xml: the README's "improved" preset — inverse-variance combination, KL-learned BSDF sampling
+fraction, stochastic + box filters, sTreeThreshold 4000, 1 spp per pass, unbounded path depth) at 1280x720.  The scene is read from
+scratch/kitchen-improved.ppgs, the flat conversion of the XML made in the development container (`python -m ppg_host
+kitchen-improved.xml --lenient --data-dir <mitsuba>/data --size 1280x720 --ppgs ...`: 283 of its 289 meshes — six are missing from
+the reference checkout —, its eleven bitmap textures, its sunsky emitter baked into a radiance map).  If that file is absent the
+labelled procedural stand-in `room` (1.4 M Lambertian triangles, same preset) is rendered instead and `config.workload` says so.
+`--scene cbox` is configs[1] (procedural CBOX, 4 spp per pass, default parameters), `--scene torus` the configs[4] stand-in.
 
-A "step" is one render pass = one BlockedRenderProcess of the reference: every pixel x sppPerPass paths
-through Li, splatted into the SD-tree, accumulated into the film.  The timed region is a complete
-GuidedPathTracer::render() of K passes (budget = K x 4 spp) following the reference's iteration schedule
-1, 2, 4, ... (guided_path.cpp:1342-1426), so SD-tree refine / reset / build between iterations ARE inside
-the timed region and scene upload / BVH build are not.  Warm-up = one throw-away
-render of W passes.  value = pixels x spp x K / seconds, whole job over all GPUs.
+A "step" is one render pass = one BlockedRenderProcess of the reference: every pixel x sppPerPass paths through Li, recorded into
+the SD-tree, accumulated into the film.  The timed region is a complete GuidedPathTracer::render() of K passes following the
+reference's iteration schedule 1, 2, 4, ... (guided_path.cpp:1342-1426): SD-tree refine / reset / build between iterations and the
+rounds of the sampling-fraction optimiser ARE inside the timed region; scene upload and BVH build are not.
+Warm-up = one throw-away render of W passes.  value = pixels x spp x K / seconds, whole job over all GPUs.
 
-Multi-GPU (`torchrun ... bench.py --gpus N`): the fixed image is sharded by 32x32 tiles over the ranks
-(strong scaling); per iteration the building SD-tree statistics are all-reduced over RCCL
+Multi-GPU (`torchrun ... bench.py --gpus N`): the fixed image is sharded by 32x32 tiles over the ranks (strong scaling); per
+iteration the building SD-tree statistics are all-reduced over RCCL, per round the optimiser's records are gathered
 (ppg_host/distributed.py).
 
-Adds to the JSON line: `roofline` for the dominant kernel (HIP-event durations measured in-process on
-the kernel's own stream; algorithmic bytes per DESIGN.md) and, on rank 0 at N = 1, `cpu_baseline` = the
-oracle restatement timed on the host cores on a bounded sample of the same workload.
+Added to the JSON line (rank 0):
+  roofline      the kernel with the largest accumulated time of an instrumented render of the same K passes: HIP-event durations on
+                the kernels' own stream, algorithmic bytes per DESIGN.md §3 — for k_trace on a BVH scene 48 B per ray + 128 B per
+                BVH4 node visited + 48 B per triangle tested, the visits counted by the kernel itself in that run
+  cpu_baseline  the oracle restatement timed on the host cores on the first passes of the same render (N = 1 only)
+  time_to_rmse  seconds until the image reaches the RMSE the reference's own KITCHEN render has against its converged render
+                (0.2065 for kitchen-improved.exr, 2400 spp, 500.9 s on 16 CPU cores), measured against a converged
+                render of this build (N = 1 only; --no-rmse skips it)
+  secondary     cbox-720p (configs[1]) Msamples/s, for the record (N = 1 only; --no-secondary skips it)
 """
 import argparse
 import json
@@ -31,17 +40,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "practical-path-guiding_amd"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+KITCHEN_FILE = os.path.join(ROOT, "scratch", "kitchen-improved.ppgs")
+IMPROVED = dict(sampleCombination="inversevar", bsdfSamplingFractionLoss="kl", spatialFilter="stochastic", directionalFilter="box", sTreeThreshold=4000, sppPerPass=1)
+REF_KITCHEN_RMSE, REF_KITCHEN_SECONDS = 0.2065, 500.9  # kitchen-improved.exr vs kitchen-reference.exr; its log's render time
 
 
-def algorithmic_bytes(work=None, rays=None):
-    """ALGORITHMIC bytes per unit of each path kernel: bytes the kernel's algorithm touches per
-    unit, cache-oblivious, from the data layout of ppg_kernels.h and the operation counts measured by the CPU
-    restatement on the same workload (`work` = ppgo_work_counters, `rays` = rays traced in that run).
-    Without counters the a-priori CBOX values of a 63-pass run are used."""
+def algorithmic_bytes(work=None, rays=None, bvh=None):
+    """ALGORITHMIC bytes per unit of each path kernel: bytes the kernel's algorithm touches per unit, cache-oblivious,
+    from the data layout of ppg_kernels.h and operation counts of the same workload: `work` = ppgo_work_counters of the CPU restatement
+    with `rays` rays traced (S-tree lookups, D-tree levels), `bvh` = (nodes visited, triangles tested, rays) counted by k_trace itself."""
     if work and rays:
-        lookups = work[1] / rays                       # S-tree lookups (= bounces sampled) per traced ray
-        ds = work[2] / rays                            # D-tree levels descended while sampling, per ray
-        dp = work[4] / rays                            # ... while evaluating the pdf, per ray
+        lookups, ds, dp = work[1] / rays, work[2] / rays, work[4] / rays
     else:
         lookups, ds, dp = 0.70, 1.31, 2.48
     state_rd = 4 + 5 * 16                              # queue entry, ray_d, thr, li, hit, misc
@@ -50,21 +59,44 @@ def algorithmic_bytes(work=None, rays=None):
              + lookups * (4 + 64)                      # grid cell + leaf header
              + (ds + dp) * 32                          # sampling-tree nodes
              + lookups * 64)                           # speculative vertex record (4 float4)
-    return {"k_shade": shade,
-            "k_trace": 32 + 16,                        # small scene: ray in, hit out (triangles are LDS resident)
-            "k_commit": 16 + 64 + 5 * 8 + 16,          # per recorded vertex: misc, vertex, descent, 2 atomics
-            "k_generate": 80, "k_film": 4 * 16 + 88,
-            "detail": {"lookups_per_ray": lookups, "dtree_sample_levels_per_ray": ds, "dtree_pdf_levels_per_ray": dp}}
+    trace = 32 + 16                                    # ray in, hit out (small scenes: the triangles are LDS resident)
+    detail = {"lookups_per_ray": lookups, "dtree_sample_levels_per_ray": ds, "dtree_pdf_levels_per_ray": dp}
+    if bvh and bvh[2]:
+        n_bar, t_bar = bvh[0] / bvh[2], bvh[1] / bvh[2]
+        trace += n_bar * 128 + t_bar * 48              # BVH4 node = 128 B, TriAccel record = 48 B
+        detail.update(bvh4_nodes_per_ray=n_bar, triangles_tested_per_ray=t_bar)
+    return {"k_shade": shade, "k_trace": trace, "k_tail": trace + shade, "k_commit": 16 + 64 + 5 * 8 + 16, "k_generate": 80, "k_film": 4 * 16 + 88, "detail": detail}
 
 
-def measured_traffic():
-    """HBM bytes per unit from profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes,
-    calibrated as MI355X_MICROARCH.md prescribes; written by tools/collect_profiles.py on the GPU box)."""
-    p = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    try:
-        return json.load(open(p))
-    except Exception:
-        return None
+def measured_traffic(tag):
+    """HBM bytes per unit from profiles/<tag>_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, calibrated as
+    MI355X_MICROARCH.md prescribes; written by tools/collect_profiles.py on the GPU box) — a STORED calibration, not measured in this run."""
+    for name in ("r02_pmc_traffic_%s.json" % tag, "r01_pmc_traffic.json" if tag == "cbox" else ""):
+        p = os.path.join(ROOT, "profiles", name)
+        if name and os.path.exists(p):
+            try:
+                return json.load(open(p)), name
+            except Exception:
+                pass
+    return None, None
+
+
+def scene_props(path, base):
+    props = dict(base)
+    pf = path + ".props"
+    if os.path.exists(pf):
+        for line in open(pf):
+            if "=" in line:
+                k, v = line.strip().split("=", 1)
+                if k not in ("budget", "budgetType"):
+                    props[k] = int(v) if v.lstrip("-").isdigit() else (float(v) if v.replace(".", "", 1).replace("-", "", 1).isdigit() else v)
+    return props
+
+
+def rmse(a, b):
+    import numpy as np
+    d = (np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2
+    return float(np.sqrt(np.nanmean(d)))
 
 
 def run(args):
@@ -84,53 +116,63 @@ def run(args):
         world = dist.get_world_size()
     import torch  # noqa: F811  (device sync + barrier plumbing only)
 
-    spp = args.spp
-    props = dict(budgetType="spp", sppPerPass=spp, maxDepth=10, rrDepth=10, strictNormals=1, seed=1234, device=local_rank)
-    workload = "cbox-720p: procedural CBOX (36 tris), %dx%d, %d spp/pass, %d passes, default SD-tree params, maxDepth 10" % (
-        args.width, args.height, spp, args.steps)
+    base = dict(budgetType="spp", seed=1234, device=local_rank)
+    scene_name = args.scene
     if args.scene_file:
-        # a converted scene (python -m ppg_host scene.xml --ppgs FILE, e.g. the reference's SPACESHIP): its own integrator settings
-        # (FILE.props) and film size; extra bench line, not the headline configuration
-        scene = ppg_host.load_scene_file(args.scene_file)
+        scene_name = "file"
+    elif scene_name == "kitchen" and not os.path.exists(KITCHEN_FILE):
+        scene_name = "room"
+    traffic_tag = "cbox" if scene_name == "cbox" else "kitchen"
+    if scene_name in ("kitchen", "file"):
+        path = args.scene_file or KITCHEN_FILE
+        scene = ppg_host.load_scene_file(path)
         if args.size_override:
             scene.camera = dict(scene.camera, width=args.width, height=args.height)
         if args.constant_env:
             scene.environment = tuple(float(v) for v in args.constant_env.split(","))
         args.width, args.height = scene.camera["width"], scene.camera["height"]
-        if os.path.exists(args.scene_file + ".props"):
-            for line in open(args.scene_file + ".props"):
-                if "=" in line:
-                    k, v = line.strip().split("=", 1)
-                    if k not in ("budget", "budgetType"):
-                        props[k] = int(v) if v.lstrip("-").isdigit() else (float(v) if v.replace(".", "", 1).replace("-", "", 1).isdigit() else v)
-        spp = int(props.get("sppPerPass", spp))
-        workload = "%s (%d triangles, %d spheres), %dx%d, %d spp/pass, %d passes, the scene file's integrator settings" % (
-            os.path.basename(args.scene_file), scene.n_triangles, len(scene.spheres), args.width, args.height, spp, args.steps)
-    elif args.scene == "torus":
+        props = scene_props(path, base)
+        spp = int(props.get("sppPerPass", 4))
+        if scene_name == "kitchen":
+            workload = ("kitchen-improved-720p: the reference's scenes/kitchen/kitchen-improved.xml converted in the development container (%d triangles: 283 of its 289 "
+                        "meshes, six are missing from the reference checkout; %d BSDFs, %d bitmap textures, sunsky baked into a %dx%d radiance map), %dx%d, "
+                        "improved preset (inversevar, kl, stochastic + box filters, sTreeThreshold 4000), %d spp/pass, maxDepth %d, %d passes"
+                        % (scene.n_triangles, len(scene.materials), len(scene.textures), scene.envmap["rgb"].shape[1] if scene.envmap else 0,
+                           scene.envmap["rgb"].shape[0] if scene.envmap else 0, args.width, args.height, spp, int(props.get("maxDepth", -1)), args.steps))
+        else:
+            workload = "%s (%d triangles, %d spheres), %dx%d, %d spp/pass, %d passes, the scene file's integrator settings" % (
+                os.path.basename(path), scene.n_triangles, len(scene.spheres), args.width, args.height, spp, args.steps)
+    elif scene_name == "torus":
         # BASELINE.json configs[4] "TORUS (SDS caustics), 1920x1080, sppPerPass=1, sTreeThreshold=4000": the paper's scene is not bundled with
         # the reference — the labelled procedural stand-in of SURVEY.md §8(d) S5 (diffuse torus in a glass cube, one small emitter)
         if (args.width, args.height) == (1280, 720):
             args.width, args.height = 1920, 1080
         spp = 1
         scene = ppg_host.torus_scene(args.width, args.height)
-        props.update(sppPerPass=1, sTreeThreshold=4000, maxDepth=-1, rrDepth=5, strictNormals=0)
+        props = dict(base, sppPerPass=1, sTreeThreshold=4000, maxDepth=-1, rrDepth=5, strictNormals=0)
         workload = "torus-1080p (torus-class STAND-IN: diffuse torus in a glass cube, %d triangles), %dx%d, 1 spp/pass, %d passes, sTreeThreshold 4000" % (
             scene.n_triangles, args.width, args.height, args.steps)
-    elif args.scene == "cbox":
+    elif scene_name == "cbox":
+        spp = args.spp or 4
         scene = ppg_host.cbox_scene(args.width, args.height)
+        props = dict(base, sppPerPass=spp, maxDepth=10, rrDepth=10, strictNormals=1)
+        workload = "cbox-720p: procedural CBOX (36 tris), %dx%d, %d spp/pass, %d passes, default SD-tree params, maxDepth 10" % (args.width, args.height, spp, args.steps)
     else:
-        # BASELINE.json configs[2] "kitchen-class improved": the bundled KITCHEN lacks 6 meshes and cannot travel to the GPU
-        # box, so this is the labelled procedural stand-in of SURVEY.md §8(d) S3 (Lambertian only) with the README's
-        # "improved" preset; maxDepth -1 / rrDepth 5 as in kitchen-improved.xml.
+        # the bundled KITCHEN cannot be read here (no scratch/kitchen-improved.ppgs): labelled procedural stand-in of SURVEY.md §8(d) S3 with the
+        # README's "improved" preset; maxDepth -1 / rrDepth 5 as in kitchen-improved.xml
+        spp = args.spp or 1
         scene = ppg_host.room_scene(args.width, args.height, n_boxes=args.room_boxes, tess=8, glossy=args.glossy)
-        props.update(sampleCombination="inversevar", bsdfSamplingFractionLoss="kl", spatialFilter="stochastic", directionalFilter="box",
-                     sTreeThreshold=4000, maxDepth=-1, rrDepth=5, strictNormals=0)
-        workload = "room-720p (kitchen-class STAND-IN, %d %s triangles), %dx%d, %d spp/pass, %d passes, improved preset" % (
+        props = dict(base, **IMPROVED)
+        props.update(sppPerPass=spp, maxDepth=-1, rrDepth=5, strictNormals=0)
+        workload = "room-720p (kitchen-class STAND-IN for the KITCHEN scene, %d %s triangles), %dx%d, %d spp/pass, %d passes, improved preset" % (
             scene.n_triangles, "Lambertian / GGX(0.1) / plastic" if args.glossy else "Lambertian", args.width, args.height, spp, args.steps)
 
-    def make(budget_passes, timing=False):
-        e = ppg_host.Engine.hip(budget=float(budget_passes * spp), **props)
-        e.set_scene(scene)
+    def make(budget_passes, timing=False, the_scene=scene, the_props=props, the_spp=None, seed=None):
+        p = dict(the_props)
+        if seed is not None:
+            p["seed"] = seed
+        e = ppg_host.Engine.hip(budget=float(budget_passes * (the_spp or spp)), **p)
+        e.set_scene(the_scene)
         if world > 1:
             e.set_shard(rank, world, 32)
         if timing:
@@ -147,21 +189,26 @@ def run(args):
             dist.barrier()
             torch.cuda.synchronize()
 
+    def timed_render(gpt):
+        sync()
+        t0 = time.perf_counter()
+        img = gpt.render()
+        sync()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return img, dt
+
     if args.warmup > 0:
         make(args.warmup).render()
     gpt = make(args.steps)
-    sync()
-    t0 = time.perf_counter()
-    gpt.render()
-    sync()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    _, dt = timed_render(gpt)
     samples = args.width * args.height * spp * args.steps
     rays = sum(s["rays"] for it in gpt.iterations for s in it["stats"])
     own_samples = sum(s["samples"] for it in gpt.iterations for s in it["stats"])
+    plen = sum(s["path_length_sum"] for it in gpt.iterations for s in it["stats"])
     var_last = gpt.iterations[-1]["stats"][-1]["variance"]
     out = {
         "metric": "Msamples/s", "value": samples / dt / 1e6, "unit": "Msamples/s", "n_gpus": args.gpus, "steps": args.steps,
@@ -169,13 +216,14 @@ def run(args):
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload,
                    "iterations": [it["passes"] for it in gpt.iterations], "parallelism": "tiles%d" % args.gpus,
-                   "rays_per_sample": rays / max(1, own_samples), "variance_last_iteration": var_last},
+                   "rays_per_sample": rays / max(1, own_samples), "avg_path_length": plen / max(1, own_samples), "variance_last_iteration": var_last},
     }
+    del gpt
 
     work = rays_cpu = None
     if rank == 0 and args.gpus == 1 and not args.no_cpu:
         # CPU baseline: the oracle (a port, not the reference binary) on the host cores, bounded sample:
-        # the same scene/resolution/settings, the first `cpu_passes` passes of the same schedule.
+        # the same scene / resolution / settings, the first `cpu_passes` passes of the same schedule.
         import ctypes
         cores = os.cpu_count() or 1
         lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "libppg_oracle.so"))
@@ -194,6 +242,7 @@ def run(args):
         out["cpu_baseline"] = {"value": args.width * args.height * spp * cp / dtc / 1e6, "unit": "Msamples/s", "cores": cores,
                                "kind": "port", "sample": "first %d passes (%d spp) of the same render(), oracle restatement, OpenMP over 32x32 blocks"
                                % (cp, cp * spp), "seconds": dtc}
+        del og, o
 
     times = None
     if not args.no_roofline:
@@ -203,25 +252,57 @@ def run(args):
         g2.render()
         times = g2.engine.kernel_times()
         sync()
+        del g2
     if rank == 0 and times:
+        counts = {k["name"]: k["units"] for k in times if k["launches"] == 0}
+        times = [k for k in times if k["launches"] > 0]
         dom = max(times, key=lambda k: k["ms"])
-        alg = algorithmic_bytes(work, rays_cpu)
         name = dom["name"].split("<")[0]
+        trace_rays = sum(k["units"] for k in times if k["name"] == "k_trace")
+        bvh = (counts.get("bvh_nodes_visited", 0), counts.get("bvh_triangles_tested", 0), trace_rays) if counts else None
+        alg = algorithmic_bytes(work, rays_cpu, bvh)
         bytes_per_unit = alg.get(name, alg["k_shade"])
         avg_units = dom["units"] / max(1, dom["launches"])
         avg_ms = dom["ms"] / max(1, dom["launches"])
         achieved = bytes_per_unit * avg_units / (avg_ms * 1e-3) / 1e9
-        tr = measured_traffic()
+        tr, tr_file = measured_traffic(traffic_tag)
         traffic = None
         if tr and name in tr.get("bytes_per_unit", {}):
             traffic = tr["bytes_per_unit"][name] * avg_units
         out["roofline"] = {"bound": "hbm", "kernel": dom["name"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": avg_ms, "launches": dom["launches"],
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                           "traffic_source": ("stored calibration profiles/%s (PMC bytes per unit of an earlier run) x this run's units" % tr_file) if traffic is not None else None,
+                           "avg_launch_ms": avg_ms, "launches": dom["launches"],
                            "algorithmic_bytes_per_unit": bytes_per_unit, "avg_units_per_launch": avg_units, "unit_of_work": "traced ray",
                            "operation_counts": alg["detail"], "kernels_ms": {k["name"]: round(k["ms"], 3) for k in times},
-                           "note": "tree/scene bytes are cache resident: `traffic` (PMC) is what actually reaches HBM"
-                                   + ("; k_trace on a BVH scene: the algorithmic count holds only the ray read and the hit written (48 B), node and "
-                                      "triangle reads are not counted" if name == "k_trace" and scene.n_triangles > 64 else "")}
+                           "note": "the BVH and the SD-tree are L2 / Infinity-Cache resident: the algorithmic bytes are what the kernel must read per ray "
+                                   "(cache-oblivious), `traffic` what reaches HBM"}
+
+    if rank == 0 and args.gpus == 1 and not args.no_rmse and scene_name in ("kitchen", "room"):
+        # time to target RMSE.  Reference image: a converged render of this build (another seed); target: the RMSE the reference's own
+        # kitchen-improved.exr (2400 spp, 500.9 s on 16 CPU cores) has against the reference's converged kitchen-reference.exr.
+        ref_img, ref_dt = timed_render(make(args.rmse_reference_spp // spp, seed=987654321))
+        trials, hit = [], None
+        for n in (15, 31, 63, 127, 255, 511, 1023, 2047):
+            img, t = timed_render(make(n))
+            r = rmse(img, ref_img)
+            trials.append({"passes": n, "spp": n * spp, "seconds": t, "rmse": r})
+            if r <= REF_KITCHEN_RMSE:
+                hit = trials[-1]
+                break
+        out["time_to_rmse"] = {"target_rmse": REF_KITCHEN_RMSE, "target_source": "BASELINE.md: RMSE(kitchen-improved.exr, kitchen-reference.exr), the reference's 2400-spp render, 500.9 s on 16 CPU cores",
+                               "reference_image": "this build, %d spp, another seed (%.2f s)" % (args.rmse_reference_spp, ref_dt),
+                               "seconds": hit["seconds"] if hit else None, "spp": hit["spp"] if hit else None, "rmse": hit["rmse"] if hit else None,
+                               "speedup_vs_reference_log": (REF_KITCHEN_SECONDS / hit["seconds"]) if hit else None, "trials": trials,
+                               "note": "RMSE per pixel over RGB of the full-size image; the reference's figure is for its 700x400 render of the complete scene"}
+
+    if rank == 0 and args.gpus == 1 and not args.no_secondary and scene_name != "cbox":
+        cb = ppg_host.cbox_scene(1280, 720)
+        cprops = dict(base, sppPerPass=4, maxDepth=10, rrDepth=10, strictNormals=1)
+        make(3, the_scene=cb, the_props=cprops, the_spp=4).render()
+        _, t = timed_render(make(args.secondary_passes, the_scene=cb, the_props=cprops, the_spp=4))
+        out["secondary"] = {"workload": "cbox-720p (BASELINE.json configs[1]): procedural CBOX, 1280x720, 4 spp/pass, %d passes, default SD-tree params, maxDepth 10" % args.secondary_passes,
+                            "value": 1280 * 720 * 4 * args.secondary_passes / t / 1e6, "unit": "Msamples/s"}
 
     if dist is not None:
         dist.barrier()
@@ -234,20 +315,26 @@ def run(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=255, help="render passes in the timed render() (budget = steps * spp)")
+    ap.add_argument("--steps", type=int, default=127, help="render passes in the timed render() (budget = steps * spp)")
     ap.add_argument("--warmup", type=int, default=3, help="passes of the throw-away warm-up render")
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=720)
-    ap.add_argument("--spp", type=int, default=4)
-    ap.add_argument("--scene", choices=["cbox", "room", "torus"], default="cbox", help="room = kitchen-class procedural stand-in, improved preset; torus = torus-class stand-in (SDS caustics)")
-    ap.add_argument("--scene-file", help="flat scene file (ppg_host.save_scene / `python -m ppg_host scene.xml --ppgs`) instead of a procedural scene")
-    ap.add_argument("--size-override", action="store_true", help="with --scene-file: render at --width x --height instead of the file's film size")
-    ap.add_argument("--constant-env", help="with --scene-file: R,G,B of a constant environment emitter (STAND-IN lighting)")
+    ap.add_argument("--spp", type=int, default=0, help="samples per pixel and pass of the procedural scenes (default: 4 cbox, 1 room / torus); scene files carry their own")
+    ap.add_argument("--scene", choices=["kitchen", "cbox", "room", "torus"], default="kitchen",
+                    help="kitchen = the reference's KITCHEN scene, improved preset (scratch/kitchen-improved.ppgs; falls back to `room`); room = kitchen-class procedural "
+                         "stand-in, improved preset; cbox = BASELINE configs[1]; torus = torus-class stand-in (SDS caustics)")
+    ap.add_argument("--scene-file", help="flat scene file (ppg_host.save_scene / `python -m ppg_host scene.xml --ppgs`) instead of a named scene")
+    ap.add_argument("--size-override", action="store_true", help="with a scene file: render at --width x --height instead of the file's film size")
+    ap.add_argument("--constant-env", help="with a scene file: R,G,B of a constant environment emitter (STAND-IN lighting)")
     ap.add_argument("--room-boxes", type=int, default=1820, help="boxes of the room scene (768 triangles each)")
     ap.add_argument("--glossy", action="store_true", help="room scene with the S3 material mix (GGX alpha 0.1 metal, plastic) instead of Lambertian only")
-    ap.add_argument("--cpu-passes", type=int, default=7, help="passes timed on the CPU baseline (bounded sample)")
+    ap.add_argument("--cpu-passes", type=int, default=15, help="passes timed on the CPU baseline (bounded sample)")
+    ap.add_argument("--rmse-reference-spp", type=int, default=4095, help="spp of the converged render the time-to-RMSE block compares against")
+    ap.add_argument("--secondary-passes", type=int, default=63)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-rmse", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the reducer even with one rank (plumbing check)")
     run(ap.parse_args())
 

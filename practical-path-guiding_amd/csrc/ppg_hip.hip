@@ -348,6 +348,7 @@ struct ppg_ctx {
     float lastVariance = 0;
     ppg_pass_stats lastStats{};
     KernelTimer timer;
+    uint64_t bvhNodesVisited = 0, bvhTrisTested = 0;  // by k_trace while kernel timing is on (the roofline's node / triangle counts)
     ppg_pass_hook passHook = nullptr;
     void *passHookUser = nullptr;
 
@@ -744,8 +745,9 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound) {
         int qout = b & 1;
         if (!fused)
             timedLaunch(ctx, "k_trace", hostCount, [&] {
-                if (smallScene) hipLaunchKernelGGL(k_trace<true>, dim3(grid), dim3(PPG_BLOCK), ldsBytes, s, P, S, Q, qin, 0, ctx->ldsTris);
-                else hipLaunchKernelGGL(k_trace<false>, dim3(grid), dim3(PPG_BLOCK), ldsBytes, s, P, S, Q, qin, ctx->ldsNodes, ctx->ldsTris);
+                if (smallScene) hipLaunchKernelGGL((k_trace<true, false>), dim3(grid), dim3(PPG_BLOCK), ldsBytes, s, P, S, Q, qin, 0, ctx->ldsTris);
+                else if (ctx->timer.enabled) hipLaunchKernelGGL((k_trace<false, true>), dim3(grid), dim3(PPG_BLOCK), ldsBytes, s, P, S, Q, qin, ctx->ldsNodes, ctx->ldsTris);
+                else hipLaunchKernelGGL((k_trace<false, false>), dim3(grid), dim3(PPG_BLOCK), ldsBytes, s, P, S, Q, qin, ctx->ldsNodes, ctx->ldsTris);
             });
         timedLaunch(ctx, fused ? "k_shade<fused>" : (neeOn ? "k_shade<nee>" : (fullMats ? "k_shade<full>" : "k_shade")), hostCount, [&] {
             const int small = smallScene ? 1 : 0;
@@ -905,7 +907,8 @@ int finishPasses(ppg_ctx *ctx, ppg_pass_stats *st) {  // GP:1288-1328
     HIP_CHECK(hipMemcpyAsync(bs.data(), ctx->d_stats.p, bs.size() * sizeof(BlockStats), hipMemcpyDeviceToHost, ctx->stream));
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
     BlockStats c{};
-    for (const BlockStats &x : bs) { c.rays += x.rays; c.path_len += x.path_len; c.committed += x.committed; }
+    for (const BlockStats &x : bs) { c.rays += x.rays; c.path_len += x.path_len; c.committed += x.committed; c.bvh_nodes += x.bvh_nodes; c.bvh_tris += x.bvh_tris; }
+    ctx->bvhNodesVisited += c.bvh_nodes; ctx->bvhTrisTested += c.bvh_tris;
     float variance = 0;  // summed in the reference's x-major order (GP:1303-1311)
     for (int k = 0; k < n; ++k) variance += lum[k];  // k = x * H + y
     variance /= (float)ctx->W * ctx->H * (N - 1);
@@ -1796,6 +1799,7 @@ int ppg_query_sample(ppg_ctx *ctx, uint32_t n, const float *positions, uint64_t 
 
 int ppg_enable_kernel_timing(ppg_ctx *ctx, int32_t enable) {
     ctx->timer.reset();
+    ctx->bvhNodesVisited = ctx->bvhTrisTested = 0;
     ctx->timer.enabled = enable != 0;
     return PPG_OK;
 }
@@ -1804,6 +1808,11 @@ int ppg_kernel_times(ppg_ctx *ctx, ppg_kernel_time *out, uint32_t cap, uint32_t 
     uint32_t k = 0;
     for (size_t i = 0; i < ctx->timer.names.size() && k < cap; ++i, ++k) {
         out[k].name = ctx->timer.names[i].c_str(); out[k].ms = ctx->timer.ms[i]; out[k].launches = ctx->timer.launches[i]; out[k].units = ctx->timer.units[i];
+    }
+    // two pseudo entries for the roofline of k_trace on BVH scenes: `units` = BVH4 nodes visited / triangles tested by its launches
+    if (k + 2 <= cap && ctx->bvhNodesVisited) {
+        out[k].name = "bvh_nodes_visited"; out[k].ms = 0; out[k].launches = 0; out[k].units = ctx->bvhNodesVisited; ++k;
+        out[k].name = "bvh_triangles_tested"; out[k].ms = 0; out[k].launches = 0; out[k].units = ctx->bvhTrisTested; ++k;
     }
     *n = k;
     return PPG_OK;

@@ -76,6 +76,7 @@ struct PathState {
 // k_shade's run time — so every persistent workgroup owns a private record and a private slice of the queues.
 struct BlockStats {
     unsigned long long rays, path_len, committed;
+    unsigned long long bvh_nodes, bvh_tris;  // k_trace<.., COUNT>: BVH4 nodes visited / triangles tested (kernel timing runs only: the roofline's n, t)
 };
 
 // Queues: workgroup b owns entries [b * cap, b * cap + count[b]).  Paths are dealt to workgroups in chunks of
@@ -251,8 +252,9 @@ D LdsScene stage_scene(const DevScene &S, unsigned char *lds_raw, int lds_nodes,
 // BVH4 traversal of one queue slice with ray replacement: a lane whose ray is finished immediately takes the next
 // entry of the slice (LDS ticket), so a wave stays full until the slice is empty instead of idling until its
 // longest ray is done — secondary rays are incoherent and their traversal lengths differ by an order of magnitude.
+template <bool COUNT>
 D void trace_slice_bvh4(const PathState &P, const DevScene &S, int *lds_stack, unsigned int *ticket, const unsigned int *items,
-                        unsigned int count, unsigned int b, unsigned int nb, unsigned int &traced) {
+                        unsigned int count, unsigned int b, unsigned int nb, unsigned int &traced, unsigned long long &n_nodes, unsigned long long &n_tris) {
     if (threadIdx.x == 0) *ticket = 0;
     __syncthreads();
     TStack st;
@@ -281,6 +283,7 @@ D void trace_slice_bvh4(const PathState &P, const DevScene &S, int *lds_stack, u
             have = true;
         }
         // ---- one node ----
+        if (COUNT) ++n_nodes;
         const float4 *nd = reinterpret_cast<const float4 *>(S.bvh4 + cur);
         const float4 lx = nd[0], ly = nd[1], lz = nd[2], hx = nd[3], hy = nd[4], hz = nd[5];
         const int4 ch = *reinterpret_cast<const int4 *>(nd + 6);
@@ -306,6 +309,7 @@ D void trace_slice_bvh4(const PathState &P, const DevScene &S, int *lds_stack, u
             if (hit[k] && chs[k] < 0) {  // leaves first: they can only shorten the ray
                 const int code = ~chs[k];
                 const int first = code >> 3, cnt = (code & 7) + 1;
+                if (COUNT) n_tris += (unsigned long long)cnt;
                 for (int q = first; q < first + cnt; ++q) {
                     float tt, uu, vv;
                     const float4 *T = S.accel + 3 * q;
@@ -348,11 +352,11 @@ D void trace_slice_bvh4(const PathState &P, const DevScene &S, int *lds_stack, u
 }
 
 // trace the rays of one queue slice
-template <bool SMALL>
+template <bool SMALL, bool COUNT>
 D void trace_slice(const PathState &P, const DevScene &S, const LdsScene &L, int *lds_stack, unsigned int *ticket, const unsigned int *items,
-                   unsigned int count, unsigned int b, unsigned int nb, unsigned int &traced) {
+                   unsigned int count, unsigned int b, unsigned int nb, unsigned int &traced, unsigned long long &n_nodes, unsigned long long &n_tris) {
     if (!SMALL) {
-        trace_slice_bvh4(P, S, lds_stack, ticket, items, count, b, nb, traced);
+        trace_slice_bvh4<COUNT>(P, S, lds_stack, ticket, items, count, b, nb, traced, n_nodes, n_tris);
         return;
     }
     for (unsigned int k = threadIdx.x; k < count; k += blockDim.x) {
@@ -367,7 +371,7 @@ D void trace_slice(const PathState &P, const DevScene &S, const LdsScene &L, int
 }
 
 // SMALL: the whole scene (<= 64 triangles) is tested from LDS without a BVH.
-template <bool SMALL>
+template <bool SMALL, bool COUNT = false>
 #ifdef PPG_TRACE_WAVES
 __attribute__((amdgpu_waves_per_eu(PPG_TRACE_WAVES, PPG_TRACE_WAVES)))
 #endif
@@ -384,8 +388,10 @@ __global__ __launch_bounds__(PPG_BLOCK) void k_trace(PathState P, DevScene S, Qu
     else { L.nodes = nullptr; L.tris = nullptr; L.n_nodes = 0; L.n_tris = 0; }
     const unsigned int *items = qin >= 0 ? Q.items[qin] + (size_t)b * Q.cap : nullptr;
     unsigned int traced = 0;
-    trace_slice<SMALL>(P, S, L, (int *)lds_raw, &ticket, items, count, b, nb, traced);
+    unsigned long long n_nodes = 0, n_tris = 0;
+    trace_slice<SMALL, COUNT>(P, S, L, (int *)lds_raw, &ticket, items, count, b, nb, traced, n_nodes, n_tris);
     block_add_u64(&acc, &Q.stats[b].rays, traced);
+    if (COUNT) { block_add_u64(&acc, &Q.stats[b].bvh_nodes, n_nodes); block_add_u64(&acc, &Q.stats[b].bvh_tris, n_tris); }
 }
 
 // grid[cell] for stree_lookup: descend at most PPG_GRID_LEVELS levels along the cell's coordinate bits
@@ -1324,6 +1330,10 @@ __global__ __launch_bounds__(256) void k_adam_apply(LeafHdr *hdr, const unsigned
     const LeafHdr h = hdr[leaf];
     float variable = h.theta, firstMoment = h.adam_m, secondMoment = h.adam_v, batchGradient = h.adam_bg, batchAccumulation = h.adam_ba;
     int iter = h.adam_iter;
+    // functions of the variable alone, refreshed after every step (the reference re-evaluates them per record: same values)
+    float samplingFraction = logistic(variable);
+    float dFraction = samplingFraction * (1 - samplingFraction);
+    float l2RegGradient = 0.01f * variable;
     for (unsigned int base = lo; base < hi; base += 64u) {
         float4 pay = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         float wgt = 0.0f;
@@ -1334,17 +1344,31 @@ __global__ __launch_bounds__(256) void k_adam_apply(LeafHdr *hdr, const unsigned
             wgt = b.z;
         }
         const unsigned int cnt = (hi - base) < 64u ? (hi - base) : 64u;
+        // Which records complete a batch depends on the weights only (append(), GP:85-95: batchAccumulation += weight; step once it
+        // exceeds batchSize = 1) — so the steps' iteration numbers are known before any gradient is: the lanes work out the learning
+        // rates of "their" steps (the two pow() of GP:100 are the longest dependency chain of a step) in parallel, off the serial path.
+        unsigned long long stepMask = 0ull;
+        {
+            float ba = batchAccumulation;
+            for (unsigned int t = 0; t < cnt; ++t) {
+                ba += __shfl(wgt, (int)t);
+                if (ba > 1.0f) { stepMask |= 1ull << t; ba = 0; }
+            }
+        }
+        float myLr = 0.0f;
+        if ((stepMask >> lane) & 1ull) {
+            const int it = iter + (int)__popcll(stepMask & ((2ull << lane) - 1ull));
+            myLr = 0.01f * __builtin_sqrtf(1 - ppg_powi(0.999f, it)) / (1 - ppg_powi(0.9f, it));
+        }
         for (unsigned int t = 0; t < cnt; ++t) {
             const float product = __shfl(pay.x, (int)t), woPdf = __shfl(pay.y, (int)t), bsdfPdf = __shfl(pay.z, (int)t), dTreePdf = __shfl(pay.w, (int)t);
             const float statisticalWeight = __shfl(wgt, (int)t);
             // optimizeBsdfSamplingFraction, GP:672-691
-            const float samplingFraction = logistic(variable);
             const float mixPdf = samplingFraction * bsdfPdf + (1 - samplingFraction) * dTreePdf;
             const float r = product / mixPdf;
             const float ratio = (loss == LOSS_KL) ? r : r * r;
             const float dLoss_dSamplingFraction = -ratio / woPdf * (bsdfPdf - dTreePdf);
-            const float dLoss_dVariable = dLoss_dSamplingFraction * (samplingFraction * (1 - samplingFraction));
-            const float l2RegGradient = 0.01f * variable;
+            const float dLoss_dVariable = dLoss_dSamplingFraction * dFraction;
             const float lossGradient = l2RegGradient + dLoss_dVariable;
             // AdamOptimizer::append, GP:85-95 (batchSize = 1)
             batchGradient += lossGradient * statisticalWeight;
@@ -1352,13 +1376,16 @@ __global__ __launch_bounds__(256) void k_adam_apply(LeafHdr *hdr, const unsigned
             if (batchAccumulation > 1.0f) {
                 const float gradient = batchGradient / batchAccumulation;  // step(), GP:97-109
                 ++iter;
-                const float lr = 0.01f * __builtin_sqrtf(1 - ppg_powi(0.999f, iter)) / (1 - ppg_powi(0.9f, iter));
+                const float lr = __shfl(myLr, (int)t);
                 firstMoment = 0.9f * firstMoment + (1 - 0.9f) * gradient;
                 secondMoment = 0.999f * secondMoment + (1 - 0.999f) * gradient * gradient;
                 variable -= lr * firstMoment / (__builtin_sqrtf(secondMoment) + 1e-08f);
                 variable = ppg_min(ppg_max(variable, -20.0f), 20.0f);
                 batchGradient = 0;
                 batchAccumulation = 0;
+                samplingFraction = logistic(variable);
+                dFraction = samplingFraction * (1 - samplingFraction);
+                l2RegGradient = 0.01f * variable;
             }
         }
     }
