@@ -131,6 +131,8 @@ def run(args):
         if args.constant_env:
             scene.environment = tuple(float(v) for v in args.constant_env.split(","))
         args.width, args.height = scene.camera["width"], scene.camera["height"]
+        if args.all_diffuse:  # experiment: what the BSDF mix costs — every surface a grey two-sided Lambertian, no textures
+            scene.materials = [dict(type=1, reflectance=(0.5, 0.5, 0.5)) for _ in scene.materials]
         props = scene_props(path, base)
         spp = int(props.get("sppPerPass", 4))
         if scene_name == "kitchen":
@@ -335,6 +337,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-rmse", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--all-diffuse", action="store_true", help="experiment: replace every BSDF of a scene file by a grey two-sided Lambertian")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the reducer even with one rank (plumbing check)")
     run(ap.parse_args())
 

@@ -287,7 +287,9 @@ struct ppg_ctx {
     // path state
     DevBuf<float4> d_ray_o, d_ray_d, d_thr, d_li, d_hit, d_vd, d_vthr, d_vbsdf, d_vrad, d_vo, d_vvox;
     DevBuf<uint4> d_misc;
-    DevBuf<unsigned int> d_queue[2], d_qcount[2], d_qtotal;
+    DevBuf<unsigned int> d_queue[2], d_qcount[2], d_qtotal, d_queueSorted;
+    DevBuf<unsigned char> d_sortKeys;
+    int maxBatchFinal = 1;  // passes per batch in the final iteration (nothing is recorded: no vertex slots needed)
     DevBuf<BlockStats> d_stats;
     Queues queues{};
     int nBlocks = 2048;  // persistent workgroups of the path kernels (8 per CU)
@@ -333,6 +335,7 @@ struct ppg_ctx {
     int tuneBlocks = 0;               // PPG_BLOCKS: persistent workgroups of the path kernels (0 = 2048)
     bool tuneForceBvh = false;        // PPG_FORCE_BVH: trace small scenes through the BVH as well
     bool tuneFuse = false;            // PPG_FUSE: trace small scenes inside k_generate / k_shade
+    bool tuneNoSort = false;          // PPG_NO_SORT: do not sort the queue slices by BSDF type before k_shade<FULL>
     int tuneBvhLeaf = 4;              // PPG_BVH_LEAF: triangles per BVH leaf (1..8)
     float tuneBvhPad = 2e-6f;         // PPG_BVH_PAD: box padding relative to the scene extent
     DevBuf<unsigned int> d_leaves, d_counts, d_offsets, d_grid;
@@ -597,9 +600,17 @@ int allocPaths(ppg_ctx *ctx) {
             ctx->maxBatch = std::max(ctx->maxBatch, (int)ppg_adam_round_passes(ctx->sppPerPass, ctx->W, ctx->H, 1 << 30));
         }
     }
+    {   // the final iteration records nothing: its batches need path state only (96 B per path), so they can be larger — the serial tail of
+        // unbounded paths is then paid once per 64 passes
+        const size_t perPass = std::max<size_t>(1, (size_t)ctx->nPix * ctx->sppPerPass);
+        ctx->maxBatchFinal = ctx->budgetType == 1 ? 1 : (int)std::max<size_t>((size_t)ctx->maxBatch, std::min<size_t>(64, ((size_t)1 << 26) / perPass));
+        if (ctx->tuneBatchPaths) ctx->maxBatchFinal = ctx->maxBatch;
+    }
     size_t n = (size_t)ctx->nPix * ctx->sppPerPass * (size_t)ctx->maxBatch;
-    if (n > 0xfffffff0ull) { ctx->error = "too many paths per pass"; return PPG_ERR_INVALID; }
-    size_t nn = std::max<size_t>(1, n);
+    const size_t nFinal = (size_t)ctx->nPix * ctx->sppPerPass * (size_t)ctx->maxBatchFinal;
+    if (n > 0xfffffff0ull || nFinal > 0xfffffff0ull) { ctx->error = "too many paths per pass"; return PPG_ERR_INVALID; }
+    const size_t nTrain = std::max<size_t>(1, n);  // vertex slots: training batches only
+    size_t nn = std::max<size_t>(1, std::max(n, nFinal));
     ctx->maxVertices = PPG_MAX_VERTICES;
     if (ctx->maxDepth > 0) ctx->maxVertices = std::max(1, std::min(PPG_MAX_VERTICES, ctx->maxDepth - 1));
     HIP_CHECK(ctx->d_ray_o.reserve(nn)); HIP_CHECK(ctx->d_ray_d.reserve(nn)); HIP_CHECK(ctx->d_thr.reserve(nn));
@@ -616,7 +627,8 @@ int allocPaths(ppg_ctx *ctx) {
     ctx->queues.items[0] = ctx->d_queue[0].p; ctx->queues.items[1] = ctx->d_queue[1].p;
     ctx->queues.count[0] = ctx->d_qcount[0].p; ctx->queues.count[1] = ctx->d_qcount[1].p;
     ctx->queues.cap = (unsigned int)cap; ctx->queues.stats = ctx->d_stats.p; ctx->queues.n_blocks = (unsigned int)nb;
-    size_t nv = nn * (size_t)ctx->maxVertices;
+    if (ctx->fullMaterials && !ctx->tuneNoSort) { HIP_CHECK(ctx->d_queueSorted.reserve(cap * nb)); HIP_CHECK(ctx->d_sortKeys.reserve(cap * nb)); }
+    size_t nv = nTrain * (size_t)ctx->maxVertices;
     HIP_CHECK(ctx->d_vd.reserve(nv)); HIP_CHECK(ctx->d_vthr.reserve(nv)); HIP_CHECK(ctx->d_vbsdf.reserve(nv)); HIP_CHECK(ctx->d_vrad.reserve(nv));
     if (ctx->spatialFilter != SF_NEAREST) { HIP_CHECK(ctx->d_vo.reserve(nv)); HIP_CHECK(ctx->d_vvox.reserve(nv)); }
     PathState &P = ctx->paths;
@@ -749,12 +761,19 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound) {
                 else if (ctx->timer.enabled) hipLaunchKernelGGL((k_trace<false, true>), dim3(grid), dim3(PPG_BLOCK), ldsBytes, s, P, S, Q, qin, ctx->ldsNodes, ctx->ldsTris);
                 else hipLaunchKernelGGL((k_trace<false, false>), dim3(grid), dim3(PPG_BLOCK), ldsBytes, s, P, S, Q, qin, ctx->ldsNodes, ctx->ldsTris);
             });
+        const unsigned int *sortedItems = nullptr;
+        if (fullMats && !fused && qin >= 0 && ctx->d_queueSorted.p) {
+            timedLaunch(ctx, "k_sort_slices", hostCount, [&] {
+                hipLaunchKernelGGL(k_sort_slices, dim3(grid), dim3(PPG_BLOCK), 0, s, P, S, Q, qin, ctx->d_queueSorted.p, ctx->d_sortKeys.p);
+            });
+            sortedItems = ctx->d_queueSorted.p;
+        }
         timedLaunch(ctx, fused ? "k_shade<fused>" : (neeOn ? "k_shade<nee>" : (fullMats ? "k_shade<full>" : "k_shade")), hostCount, [&] {
             const int small = smallScene ? 1 : 0;
             // dynamic LDS: the staged triangles (fused, or luminaire sampling on a small scene) or the shadow rays' BVH stack columns
             const size_t neeBytes = smallScene ? triBytes : (size_t)PPG_LDS_STACK * PPG_BLOCK * 4;
             const size_t lds = fused ? triBytes : ((neeOn || ctx->scene.has_null) ? neeBytes : 0);
-#define PPG_SHADE(F, N, M) hipLaunchKernelGGL((k_shade<F, N, M>), dim3(grid), dim3(PPG_BLOCK), lds, s, P, S, T, R, Q, qin, qout, small)
+#define PPG_SHADE(F, N, M) hipLaunchKernelGGL((k_shade<F, N, M>), dim3(grid), dim3(PPG_BLOCK), lds, s, P, S, T, R, Q, qin, qout, small, sortedItems)
             const int variant = (fused ? 4 : 0) | (neeOn ? 2 : 0) | (fullMats ? 1 : 0);
             switch (variant) {
                 case 0: PPG_SHADE(false, false, false); break;
@@ -874,7 +893,7 @@ int renderPassesNoStat(ppg_ctx *ctx, int numPasses) {  // GP:1217-1286
     ctx->passesLocal = 0;
     // rounds of the sampling-fraction optimiser (include/ppg.h): fractions frozen during a round, its records applied afterwards
     const bool rounds = ctx->loss != LOSS_NONE && ctx->isBuilt && !ctx->isFinalIter;
-    const int roundPasses = rounds ? (int)ppg_adam_round_passes(ctx->sppPerPass, ctx->W, ctx->H, numPasses) : ctx->maxBatch;
+    const int roundPasses = rounds ? (int)ppg_adam_round_passes(ctx->sppPerPass, ctx->W, ctx->H, numPasses) : (ctx->isFinalIter ? ctx->maxBatchFinal : ctx->maxBatch);
     for (int i = 0; i < numPasses;) {
         if (ctx->cancelled.load()) break;
         const int batch = std::min(roundPasses, numPasses - i);
@@ -1231,6 +1250,7 @@ int ppg_create(const ppg_config *cfg, ppg_ctx **out) {
         if (const char *e = getenv("PPG_BLOCKS")) c->tuneBlocks = std::max(1, atoi(e));
         c->tuneForceBvh = getenv("PPG_FORCE_BVH") != nullptr;
         c->tuneFuse = getenv("PPG_FUSE") != nullptr;
+        c->tuneNoSort = getenv("PPG_NO_SORT") != nullptr;
         if (const char *e = getenv("PPG_BVH_LEAF")) c->tuneBvhLeaf = std::max(1, std::min(8, atoi(e)));
         if (const char *e = getenv("PPG_BVH_PAD")) c->tuneBvhPad = (float)atof(e);
     }

@@ -1088,7 +1088,7 @@ D void shade_slice(const PathState &P, const DevScene &S, const DevTree &T, cons
 
 template <bool FUSED, bool NEE, bool FULL>
 __global__ __launch_bounds__(PPG_BLOCK, PPG_SHADE_WAVES) void k_shade(PathState P, DevScene S, DevTree T, RenderParams R, Queues Q, int qin, int qout,
-                                                                     int small_scene) {
+                                                                     int small_scene, const unsigned int *sorted_items) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __shared__ float pdf_factors[20 * PPG_BLOCK];  // QuadTreeNode::pdf's per-level factors (tree depth <= 20, GP:1112)
     __shared__ unsigned int out_count;
@@ -1105,7 +1105,8 @@ __global__ __launch_bounds__(PPG_BLOCK, PPG_SHADE_WAVES) void k_shade(PathState 
     const LdsColumn fcol{pdf_factors + threadIdx.x, PPG_BLOCK};
     const unsigned int b = blockIdx.x, nb = gridDim.x;
     const unsigned int count = qin >= 0 ? Q.count[qin][b] : first_share(P.n_paths, b, nb);
-    const unsigned int *items = qin >= 0 ? Q.items[qin] + (size_t)b * Q.cap : nullptr;
+    // sorted_items: this bounce's slice re-ordered by the BSDF type at the new hit (k_sort_slices); same items, other order
+    const unsigned int *items = qin >= 0 ? (sorted_items ? sorted_items : Q.items[qin]) + (size_t)b * Q.cap : nullptr;
     if (threadIdx.x == 0) out_count = 0;
     __syncthreads();
     unsigned long long plen_sum = 0, committed = 0;
@@ -1182,6 +1183,46 @@ __global__ __launch_bounds__(PPG_BLOCK, PPG_SHADE_WAVES) void k_tail(PathState P
     block_add_u64(&acc, &stats[blockIdx.x].path_len, plen_sum);
     block_add_u64(&acc, &stats[blockIdx.x].rays, traced);
     if (NEE) block_add_u64(&acc, &stats[blockIdx.x].committed, committed);
+}
+
+// Scenes with many BSDF types (k_shade<FULL>): after the first bounce the rays of a wave hit unrelated surfaces, and a wave executes the
+// union of its lanes' BSDF branches (rough plastic, rough conductor, glass, ...).  Every workgroup therefore counting-sorts its queue
+// slice by the BSDF type at the new hit (16 bins; rays that left the scene last, so that the lanes of their waves finish together).
+// The order of a slice has no influence on any result: per-path random numbers, integer accumulation.
+__global__ __launch_bounds__(PPG_BLOCK) void k_sort_slices(PathState P, DevScene S, Queues Q, int qin, unsigned int *sorted, unsigned char *keys) {
+    __shared__ unsigned int hist[16], offs[16];
+    const unsigned int b = blockIdx.x;
+    const unsigned int count = Q.count[qin][b];
+    if (count == 0) return;
+    const unsigned int *items = Q.items[qin] + (size_t)b * Q.cap;
+    unsigned int *out = sorted + (size_t)b * Q.cap;
+    unsigned char *kk = keys + (size_t)b * Q.cap;
+    if (threadIdx.x < 16) hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (unsigned int k = threadIdx.x; k < count; k += blockDim.x) {
+        const unsigned int i = items[k];
+        const int prim = __float_as_int(P.hit[i].w);
+        unsigned int key = 15u;
+        if (prim >= 0) {
+            if (prim >= S.n_tris) key = 14u;
+            else {
+                const int m = __float_as_int(S.tris[3 * (size_t)prim].w);
+                key = (unsigned int)(int)S.materials[PPG_MAT_STRIDE * (size_t)m].w & 15u;
+            }
+        }
+        kk[k] = (unsigned char)key;
+        atomicAdd(&hist[key], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int acc = 0;
+        for (int j = 0; j < 16; ++j) { offs[j] = acc; acc += hist[j]; }
+    }
+    __syncthreads();
+    for (unsigned int k = threadIdx.x; k < count; k += blockDim.x) {
+        const unsigned int pos = atomicAdd(&offs[kk[k]], 1u);
+        out[pos] = items[k];
+    }
 }
 
 // copy every workgroup's queue slice into one dense array (offsets = exclusive scan of the slice counts)
