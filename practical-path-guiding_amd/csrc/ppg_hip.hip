@@ -189,6 +189,51 @@ struct BvhBuilder {
         return me;
     }
 
+    // quantise the child boxes of every BVH4 node (Bvh4QNode, ppg_device.h); conservativeness is verified in the device's arithmetic
+    std::vector<Bvh4QNode> nodes4q;
+    static float scaleOf(unsigned int e) { const uint32_t bits = e << 23; float f; memcpy(&f, &bits, 4); return f; }
+    void quantise() {
+        nodes4q.resize(nodes4.size());
+        for (size_t i = 0; i < nodes4.size(); ++i) {
+            const Bvh4Node &nd = nodes4[i];
+            Bvh4QNode q{};
+            const float *lo[3] = {nd.lox, nd.loy, nd.loz}, *hi[3] = {nd.hix, nd.hiy, nd.hiz};
+            float org[3];
+            unsigned int ex[3], qlo[3] = {0, 0, 0}, qhi[3] = {0, 0, 0};
+            for (int a = 0; a < 3; ++a) {
+                float mn = INFINITY, mx = -INFINITY;
+                for (int k = 0; k < 4; ++k) if (nd.child[k] != PPG_BVH4_EMPTY) { mn = std::min(mn, lo[a][k]); mx = std::max(mx, hi[a][k]); }
+                if (!(mn <= mx)) { mn = 0; mx = 0; }
+                org[a] = mn;
+                int x = 0;
+                (void)std::frexp((double)(mx - mn) / 255.0, &x);  // value = m 2^x, m in [0.5, 1): 2^x >= value
+                int e = std::max(1, std::min(254, x + 127));
+                for (;;) {  // find a cell size for which all four boxes fit into 0..255 conservatively
+                    const float s = scaleOf((unsigned int)e);
+                    bool ok = true;
+                    unsigned int wl = 0, wh = 0;
+                    for (int k = 0; k < 4 && ok; ++k) {
+                        if (nd.child[k] == PPG_BVH4_EMPTY) { wl |= 255u << (8 * k); continue; }  // inverted box: never entered
+                        long ql = (long)std::floor(((double)lo[a][k] - (double)mn) / (double)s), qh = (long)std::ceil(((double)hi[a][k] - (double)mn) / (double)s);
+                        ql = std::max(0l, std::min(255l, ql)); qh = std::max(0l, qh);
+                        while (ql > 0 && !(mn + (float)ql * s <= lo[a][k])) --ql;   // the float decode must not cut into the box
+                        while (qh <= 255 && !(mn + (float)qh * s >= hi[a][k])) ++qh;
+                        if (qh > 255 || !(mn + (float)ql * s <= lo[a][k])) { ok = false; break; }
+                        wl |= (unsigned int)ql << (8 * k); wh |= (unsigned int)qh << (8 * k);
+                    }
+                    if (ok) { qlo[a] = wl; qhi[a] = wh; break; }
+                    if (++e > 254) { e = 254; qlo[a] = 0; qhi[a] = 0xffffffffu; break; }
+                }
+                ex[a] = (unsigned int)e;
+            }
+            q.ox = org[0]; q.oy = org[1]; q.oz = org[2];
+            q.exps = ex[0] | (ex[1] << 8) | (ex[2] << 16);
+            q.qlox = qlo[0]; q.qloy = qlo[1]; q.qloz = qlo[2]; q.qhix = qhi[0]; q.qhiy = qhi[1]; q.qhiz = qhi[2];
+            for (int k = 0; k < 4; ++k) q.child[k] = nd.child[k];
+            nodes4q[i] = q;
+        }
+    }
+
     void run(const float *positions, const uint32_t *indices, uint32_t nTris, float padAbs) {
         pos = positions; idx = indices; pad = padAbs;
         order.resize(nTris); bmin.resize(3 * (size_t)nTris); bmax.resize(3 * (size_t)nTris); cent.resize(3 * (size_t)nTris);
@@ -209,13 +254,14 @@ struct BvhBuilder {
             Box bb = boundsOf(0, (int)nTris);
             for (int a = 0; a < 3; ++a) { nd.lo0[a] = bb.lo[a] - pad; nd.hi0[a] = bb.hi[a] + pad; nd.lo1[a] = 0; nd.hi1[a] = 0; }
             nd.c0 = 0; nd.n0 = (int)nTris; nd.c1 = 0; nd.n1 = -1;
-            nodes4.clear(); make4(0);
+            nodes4.clear(); make4(0); quantise();
             return;
         }
         nodes.pop_back();
         build(0, (int)nTris, ref, n, b);  // nTris > 4 ⇒ root is interior and lands at index 0
         nodes4.clear(); nodes4.reserve(nodes.size() / 2 + 1);
         make4(0);
+        quantise();
     }
 };
 
@@ -272,7 +318,7 @@ struct ppg_ctx {
     DevBuf<float> d_emSel, d_emArea, d_neeCos;
     DevBuf<int4> d_emInfo;
     DevBuf<BvhNode> d_bvh;
-    DevBuf<Bvh4Node> d_bvh4;
+    DevBuf<Bvh4QNode> d_bvh4;
     DevScene scene{};
     float aabbMin[3], aabbMax[3];  // Scene::getAABB()
     int W = 0, H = 0;
@@ -292,7 +338,7 @@ struct ppg_ctx {
     int maxBatchFinal = 1;  // passes per batch in the final iteration (nothing is recorded: no vertex slots needed)
     DevBuf<BlockStats> d_stats;
     Queues queues{};
-    int nBlocks = 2048;  // persistent workgroups of the path kernels (8 per CU)
+    int nBlocks = 4096;  // persistent workgroups of the path kernels (16 per CU; KITCHEN 720p: 2048 → 76.5, 4096 → 81.3, 8192 → 75.0 Msamples/s)
     PathState paths{};
     int maxVertices = 0;
 
@@ -332,7 +378,7 @@ struct ppg_ctx {
     // Tuning switches, read ONCE from the environment by ppg_create (DESIGN.md "Tuning switches"); none of them changes a result.
     unsigned int tailThreshold = 0;   // PPG_TAIL_THRESHOLD: live paths below which k_tail takes over (0 = automatic)
     size_t tuneBatchPaths = 0;        // PPG_BATCH_PATHS: paths in flight per batch of passes (0 = automatic)
-    int tuneBlocks = 0;               // PPG_BLOCKS: persistent workgroups of the path kernels (0 = 2048)
+    int tuneBlocks = 0;               // PPG_BLOCKS: persistent workgroups of the path kernels (0 = 4096)
     bool tuneForceBvh = false;        // PPG_FORCE_BVH: trace small scenes through the BVH as well
     bool tuneFuse = false;            // PPG_FUSE: trace small scenes inside k_generate / k_shade
     bool tuneNoSort = false;          // PPG_NO_SORT: do not sort the queue slices by BSDF type before k_shade<FULL>
@@ -1463,8 +1509,8 @@ int ppg_set_scene(ppg_ctx *ctx, const ppg_scene *s) {
     if (s->normals) { HIP_CHECK(ctx->d_normals.reserve(nrm.size())); HIP_CHECK(hipMemcpy(ctx->d_normals.p, nrm.data(), nrm.size() * sizeof(float4), hipMemcpyHostToDevice)); }
     HIP_CHECK(ctx->d_bvh.reserve(bb.nodes.size()));
     HIP_CHECK(hipMemcpy(ctx->d_bvh.p, bb.nodes.data(), bb.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice));
-    HIP_CHECK(ctx->d_bvh4.reserve(bb.nodes4.size()));
-    HIP_CHECK(hipMemcpy(ctx->d_bvh4.p, bb.nodes4.data(), bb.nodes4.size() * sizeof(Bvh4Node), hipMemcpyHostToDevice));
+    HIP_CHECK(ctx->d_bvh4.reserve(bb.nodes4q.size()));
+    HIP_CHECK(hipMemcpy(ctx->d_bvh4.p, bb.nodes4q.data(), bb.nodes4q.size() * sizeof(Bvh4QNode), hipMemcpyHostToDevice));
     if (s->n_rtrans && s->rtrans) {
         const size_t n = (size_t)s->n_rtrans * (s->rtrans_samples + 1);
         HIP_CHECK(ctx->d_rtrans.reserve(n));

@@ -19,6 +19,10 @@
 #ifndef PPG_SHADE_WAVES
 #define PPG_SHADE_WAVES 4  // waves per SIMD requested for k_shade: 128 VGPRs without spilling (5 or 6 spill and are slower, 2-3 waste occupancy)
 #endif
+#ifndef PPG_SHADE_WAVES_FULL
+#define PPG_SHADE_WAVES_FULL 3  // ... for the FULL material set (k_shade<.., FULL>, k_tail<.., FULL>), whose BSDF code needs more registers: at 128 VGPRs it
+                                // spills 257 of them (KITCHEN 720p: 4 waves 76.5, 3 waves 81.3, 2 waves 79.6 Msamples/s)
+#endif
 
 enum { NEE_NEVER = 0, NEE_KICKSTART = 1, NEE_ALWAYS = 2 };
 enum { SF_NEAREST = 0, SF_STOCHASTIC = 1, SF_BOX = 2 };
@@ -284,15 +288,12 @@ D void trace_slice_bvh4(const PathState &P, const DevScene &S, int *lds_stack, u
         }
         // ---- one node ----
         if (COUNT) ++n_nodes;
-        const float4 *nd = reinterpret_cast<const float4 *>(S.bvh4 + cur);
-        const float4 lx = nd[0], ly = nd[1], lz = nd[2], hx = nd[3], hy = nd[4], hz = nd[5];
-        const int4 ch = *reinterpret_cast<const int4 *>(nd + 6);
+        float lxs[4], lys[4], lzs[4], hxs[4], hys[4], hzs[4];
+        int chs[4];
+        bvh4q_load(S.bvh4 + cur, lxs, lys, lzs, hxs, hys, hzs, chs);
         const float tlim = fminf(maxt, best.t);
         float tn[4];
         bool hit[4];
-        const float lxs[4] = {lx.x, lx.y, lx.z, lx.w}, lys[4] = {ly.x, ly.y, ly.z, ly.w}, lzs[4] = {lz.x, lz.y, lz.z, lz.w};
-        const float hxs[4] = {hx.x, hx.y, hx.z, hx.w}, hys[4] = {hy.x, hy.y, hy.z, hy.w}, hzs[4] = {hz.x, hz.y, hz.z, hz.w};
-        const int chs[4] = {ch.x, ch.y, ch.z, ch.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float ax = (lxs[k] - o.x) * id.x, bx = (hxs[k] - o.x) * id.x;
@@ -1087,7 +1088,7 @@ D void shade_slice(const PathState &P, const DevScene &S, const DevTree &T, cons
 }
 
 template <bool FUSED, bool NEE, bool FULL>
-__global__ __launch_bounds__(PPG_BLOCK, PPG_SHADE_WAVES) void k_shade(PathState P, DevScene S, DevTree T, RenderParams R, Queues Q, int qin, int qout,
+__global__ __launch_bounds__(PPG_BLOCK, (FULL ? PPG_SHADE_WAVES_FULL : PPG_SHADE_WAVES)) void k_shade(PathState P, DevScene S, DevTree T, RenderParams R, Queues Q, int qin, int qout,
                                                                      int small_scene, const unsigned int *sorted_items) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __shared__ float pdf_factors[20 * PPG_BLOCK];  // QuadTreeNode::pdf's per-level factors (tree depth <= 20, GP:1112)
@@ -1127,7 +1128,7 @@ __global__ __launch_bounds__(PPG_BLOCK, PPG_SHADE_WAVES) void k_shade(PathState 
 // workgroups share one list (work stealing), and the run time of the launch is the longest path's chain of dependent loads
 // rather than (number of bounces) x (launch + barrier latency).
 template <bool SMALL, bool NEE, bool FULL>
-__global__ __launch_bounds__(PPG_BLOCK, PPG_SHADE_WAVES) void k_tail(PathState P, DevScene S, DevTree T, RenderParams R, const unsigned int *dense,
+__global__ __launch_bounds__(PPG_BLOCK, (FULL ? PPG_SHADE_WAVES_FULL : PPG_SHADE_WAVES)) void k_tail(PathState P, DevScene S, DevTree T, RenderParams R, const unsigned int *dense,
                                                                     const unsigned long long *total_ptr, unsigned int *ticket, BlockStats *stats,
                                                                     int lds_tris) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
