@@ -22,7 +22,7 @@ iteration the building SD-tree statistics are all-reduced over RCCL, per round t
 
 Added to the JSON line (rank 0):
   roofline      the kernel with the largest accumulated time of an instrumented render of the same K passes: HIP-event durations on
-                the kernels' own stream, algorithmic bytes per DESIGN.md §3 — for k_trace on a BVH scene 48 B per ray + 128 B per
+                the kernels' own stream, algorithmic bytes per DESIGN.md §3 — for k_trace on a BVH scene 48 B per ray + 64 B per
                 BVH4 node visited + 48 B per triangle tested, the visits counted by the kernel itself in that run
   cpu_baseline  the oracle restatement timed on the host cores on the first passes of the same render (N = 1 only)
   time_to_rmse  seconds until the image reaches the RMSE the reference's own KITCHEN render has against its converged render
@@ -63,7 +63,7 @@ def algorithmic_bytes(work=None, rays=None, bvh=None):
     detail = {"lookups_per_ray": lookups, "dtree_sample_levels_per_ray": ds, "dtree_pdf_levels_per_ray": dp}
     if bvh and bvh[2]:
         n_bar, t_bar = bvh[0] / bvh[2], bvh[1] / bvh[2]
-        trace += n_bar * 128 + t_bar * 48              # BVH4 node = 128 B, TriAccel record = 48 B
+        trace += n_bar * 64 + t_bar * 48               # quantised BVH4 node = 64 B, TriAccel record = 48 B
         detail.update(bvh4_nodes_per_ray=n_bar, triangles_tested_per_ray=t_bar)
     return {"k_shade": shade, "k_trace": trace, "k_tail": trace + shade, "k_commit": 16 + 64 + 5 * 8 + 16, "k_generate": 80, "k_film": 4 * 16 + 88, "detail": detail}
 

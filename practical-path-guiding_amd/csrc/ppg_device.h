@@ -280,62 +280,52 @@ D Hit trace_closest4(const DevScene &S, int *lds_stack_col, int stride, F3 o, F3
     TStack st;
     st.lds = lds_stack_col; st.stride = stride; st.sp = 0;
     int cur = 0;
-    for (;;) {
-        float lxs[4], lys[4], lzs[4], hxs[4], hys[4], hzs[4];
-        int chs[4];
-        bvh4q_load(S.bvh4 + cur, lxs, lys, lzs, hxs, hys, hzs, chs);
-        const float tlim = fminf(maxt, best.t);
-        float tn[4];
-        bool hit[4];
+    for (;;) {  // one step per iteration: an interior node or a leaf popped from the stack (see trace_slice_bvh4)
+        if (cur >= 0) {
+            float lxs[4], lys[4], lzs[4], hxs[4], hys[4], hzs[4];
+            int chs[4];
+            bvh4q_load(S.bvh4 + cur, lxs, lys, lzs, hxs, hys, hzs, chs);
+            const float tlim = fminf(maxt, best.t);
+            int cn[4];
+            float ct[4];
+            int m = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float ax = (lxs[k] - o.x) * id.x, bx = (hxs[k] - o.x) * id.x;
-            float ay = (lys[k] - o.y) * id.y, by = (hys[k] - o.y) * id.y;
-            float az = (lzs[k] - o.z) * id.z, bz = (hzs[k] - o.z) * id.z;
-            float n = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), mint));
-            // exit distance widened by 1 + 2 gamma_3 (3 roundings in the slab arithmetic): the test stays conservative whatever the box padding
-            float f = fminf(fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000008f, tlim);
-            tn[k] = n;
-            hit[k] = (n <= f) && chs[k] != PPG_BVH4_EMPTY;
-        }
-        // leaves first (they can only shorten the ray), then the interior children nearest-first
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (hit[k] && chs[k] < 0) {
-                const int code = ~chs[k];
-                const int first = code >> 3, cnt = (code & 7) + 1;
-                for (int q = first; q < first + cnt; ++q) {
-                    float tt, uu, vv;
-                    const float4 *T = S.accel + 3 * q;
-                    if (tri_hit(T, o, d, mint, fminf(maxt, best.t), tt, uu, vv)) {
-                        if (ANY) { best.t = tt; best.prim = q; return best; }
-                        int orig = __float_as_int(T[2].w);
-                        if (tt < best.t || (tt == best.t && orig < bestOrig)) { best.t = tt; best.u = uu; best.v = vv; best.prim = q; bestOrig = orig; }
+            for (int k = 0; k < 4; ++k) {
+                float ax = (lxs[k] - o.x) * id.x, bx = (hxs[k] - o.x) * id.x;
+                float ay = (lys[k] - o.y) * id.y, by = (hys[k] - o.y) * id.y;
+                float az = (lzs[k] - o.z) * id.z, bz = (hzs[k] - o.z) * id.z;
+                float n = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), mint));
+                // exit distance widened by 1 + 2 gamma_3 (3 roundings in the slab arithmetic): the test stays conservative whatever the box padding
+                float f = fminf(fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000008f, tlim);
+                if ((n <= f) && chs[k] != PPG_BVH4_EMPTY) {
+                    int j = m++;
+                    cn[j] = chs[k]; ct[j] = n;
+                    while (j > 0 && ct[j - 1] > ct[j]) {
+                        float tf = ct[j]; ct[j] = ct[j - 1]; ct[j - 1] = tf;
+                        int tc = cn[j]; cn[j] = cn[j - 1]; cn[j - 1] = tc;
+                        --j;
                     }
                 }
-                hit[k] = false;
             }
-        }
-        // collect interior hits, order by entry distance (insertion sort of <= 4)
-        int cn[4];
-        float ct[4];
-        int m = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (hit[k] && tn[k] <= best.t) {
-                int j = m++;
-                cn[j] = chs[k]; ct[j] = tn[k];
-                while (j > 0 && ct[j - 1] > ct[j]) {
-                    float tf = ct[j]; ct[j] = ct[j - 1]; ct[j - 1] = tf;
-                    int tc = cn[j]; cn[j] = cn[j - 1]; cn[j - 1] = tc;
-                    --j;
+            if (m > 0) {
+                for (int j = m - 1; j >= 1; --j) st.push(cn[j]);
+                cur = cn[0];
+            } else {
+                if (st.sp == 0) break;
+                cur = st.pop();
+            }
+        } else {
+            const int code = ~cur;
+            const int first = code >> 3, cnt = (code & 7) + 1;
+            for (int q = first; q < first + cnt; ++q) {
+                float tt, uu, vv;
+                const float4 *T = S.accel + 3 * q;
+                if (tri_hit(T, o, d, mint, fminf(maxt, best.t), tt, uu, vv)) {
+                    if (ANY) { best.t = tt; best.prim = q; return best; }
+                    int orig = __float_as_int(T[2].w);
+                    if (tt < best.t || (tt == best.t && orig < bestOrig)) { best.t = tt; best.u = uu; best.v = vv; best.prim = q; bestOrig = orig; }
                 }
             }
-        }
-        if (m > 0) {
-            for (int j = m - 1; j >= 1; --j) st.push(cn[j]);
-            cur = cn[0];
-        } else {
             if (st.sp == 0) break;
             cur = st.pop();
         }

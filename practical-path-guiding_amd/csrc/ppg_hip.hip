@@ -714,7 +714,11 @@ int applyAdamRound(ppg_ctx *ctx, size_t nRecords) {
     while ((1u << leafBits) <= nNodes) ++leafBits;  // every leaf index is below the all-ones pattern of a hole
     const unsigned int endBit = PPG_ADAM_LEAF_SHIFT + leafBits;
     size_t n = nRecords;
-    if (n > 0) { int rc = sortAdamRecords(ctx, n, ctx->adamFast ? PPG_ADAM_LEAF_SHIFT : 0u, endBit); if (rc) return rc; }
+    if (n > 0) {
+        int rc = PPG_OK;
+        timedLaunch(ctx, "adam_sort(rocprim)", n, [&] { rc = sortAdamRecords(ctx, n, ctx->adamFast ? PPG_ADAM_LEAF_SHIFT : 0u, endBit); });
+        if (rc) return rc;
+    }
     if (ctx->passHook) {
         // hand the valid records over in key order, compact
         unsigned int nValid = 0;

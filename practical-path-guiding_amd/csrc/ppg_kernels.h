@@ -286,63 +286,57 @@ D void trace_slice_bvh4(const PathState &P, const DevScene &S, int *lds_stack, u
             bestOrig = 0x7fffffff; cur = 0; st.sp = 0;
             have = true;
         }
-        // ---- one node ----
-        if (COUNT) ++n_nodes;
-        float lxs[4], lys[4], lzs[4], hxs[4], hys[4], hzs[4];
-        int chs[4];
-        bvh4q_load(S.bvh4 + cur, lxs, lys, lzs, hxs, hys, hzs, chs);
-        const float tlim = fminf(maxt, best.t);
-        float tn[4];
-        bool hit[4];
+        // One step per iteration and lane: either an interior node (test its four child boxes, continue with the nearest child, push the
+        // others) or a leaf popped from the stack (test its triangles).  Leaves are NOT tested inside the node step: a wave executes the
+        // union of its lanes' branches, and with the triangle loops nested in the node step almost every iteration ran up to four
+        // divergent triangle loops for the few lanes that had a leaf child (measured on KITCHEN: the traversal was bound by issue slots,
+        // not by bytes — 64-byte nodes alone changed nothing).
+        if (cur >= 0) {
+            if (COUNT) ++n_nodes;
+            float lxs[4], lys[4], lzs[4], hxs[4], hys[4], hzs[4];
+            int chs[4];
+            bvh4q_load(S.bvh4 + cur, lxs, lys, lzs, hxs, hys, hzs, chs);
+            const float tlim = fminf(maxt, best.t);
+            int cn[4];
+            float ct[4];
+            int m = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float ax = (lxs[k] - o.x) * id.x, bx = (hxs[k] - o.x) * id.x;
-            float ay = (lys[k] - o.y) * id.y, by = (hys[k] - o.y) * id.y;
-            float az = (lzs[k] - o.z) * id.z, bz = (hzs[k] - o.z) * id.z;
-            float n = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), mint));
-            // exit distance widened by 1 + 2 gamma_3 (3 roundings in the slab arithmetic): the test stays conservative whatever the box padding
-            float f = fminf(fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000008f, tlim);
-            tn[k] = n;
-            hit[k] = (n <= f) && chs[k] != PPG_BVH4_EMPTY;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (hit[k] && chs[k] < 0) {  // leaves first: they can only shorten the ray
-                const int code = ~chs[k];
-                const int first = code >> 3, cnt = (code & 7) + 1;
-                if (COUNT) n_tris += (unsigned long long)cnt;
-                for (int q = first; q < first + cnt; ++q) {
-                    float tt, uu, vv;
-                    const float4 *T = S.accel + 3 * q;
-                    if (tri_hit(T, o, d, mint, fminf(maxt, best.t), tt, uu, vv)) {
-                        int orig = __float_as_int(T[2].w);
-                        if (tt < best.t || (tt == best.t && orig < bestOrig)) { best.t = tt; best.u = uu; best.v = vv; best.prim = q; bestOrig = orig; }
+            for (int k = 0; k < 4; ++k) {
+                float ax = (lxs[k] - o.x) * id.x, bx = (hxs[k] - o.x) * id.x;
+                float ay = (lys[k] - o.y) * id.y, by = (hys[k] - o.y) * id.y;
+                float az = (lzs[k] - o.z) * id.z, bz = (hzs[k] - o.z) * id.z;
+                float n = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), mint));
+                // exit distance widened by 1 + 2 gamma_3 (3 roundings in the slab arithmetic): the test stays conservative whatever the box padding
+                float f = fminf(fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000008f, tlim);
+                if ((n <= f) && chs[k] != PPG_BVH4_EMPTY) {  // children (interior or leaf) nearest first
+                    int j = m++;
+                    cn[j] = chs[k]; ct[j] = n;
+                    while (j > 0 && ct[j - 1] > ct[j]) {
+                        float tf = ct[j]; ct[j] = ct[j - 1]; ct[j - 1] = tf;
+                        int tc = cn[j]; cn[j] = cn[j - 1]; cn[j - 1] = tc;
+                        --j;
                     }
                 }
-                hit[k] = false;
             }
-        }
-        int cn[4];
-        float ct[4];
-        int m = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (hit[k] && tn[k] <= best.t) {  // interior children, nearest first
-                int j = m++;
-                cn[j] = chs[k]; ct[j] = tn[k];
-                while (j > 0 && ct[j - 1] > ct[j]) {
-                    float tf = ct[j]; ct[j] = ct[j - 1]; ct[j - 1] = tf;
-                    int tc = cn[j]; cn[j] = cn[j - 1]; cn[j - 1] = tc;
-                    --j;
+            if (m > 0) {
+                for (int j = m - 1; j >= 1; --j) st.push(cn[j]);
+                cur = cn[0];
+            } else cur = st.sp > 0 ? st.pop() : PPG_BVH4_EMPTY;
+        } else {
+            const int code = ~cur;
+            const int first = code >> 3, cnt = (code & 7) + 1;
+            if (COUNT) n_tris += (unsigned long long)cnt;
+            for (int q = first; q < first + cnt; ++q) {
+                float tt, uu, vv;
+                const float4 *T = S.accel + 3 * q;
+                if (tri_hit(T, o, d, mint, fminf(maxt, best.t), tt, uu, vv)) {
+                    int orig = __float_as_int(T[2].w);
+                    if (tt < best.t || (tt == best.t && orig < bestOrig)) { best.t = tt; best.u = uu; best.v = vv; best.prim = q; bestOrig = orig; }
                 }
             }
+            cur = st.sp > 0 ? st.pop() : PPG_BVH4_EMPTY;
         }
-        if (m > 0) {
-            for (int j = m - 1; j >= 1; --j) st.push(cn[j]);
-            cur = cn[0];
-        } else if (st.sp > 0) {
-            cur = st.pop();
-        } else {
+        if (cur == PPG_BVH4_EMPTY) {  // stack empty: this ray is done
             if (S.n_spheres) sphere_pass<false>(S, o, d, mint, maxt, best);
             P.hit[i] = make_float4(best.t, best.u, best.v, __int_as_float(best.prim));
             ++traced;
