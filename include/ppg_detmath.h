@@ -135,10 +135,13 @@ PPG_HD float ppg_powi(float b, int n) {
 }
 
 /* Fixed-point accumulation of SD-tree statistics: round-to-nearest-even of x * 2^24 as uint64.
-   Caller guarantees x finite and >= 0; values >= 2^39 saturate (never reached by radiance data). */
+   Supported range of ONE contribution: [2^-25, 2^26) — smaller values round to 0, larger ones (and +inf) are clamped to 2^26 = 2^50
+   fixed-point units, NaN contributes nothing.  A bin can therefore absorb 2^13 maximal contributions (or 2^39 of unit size) before the
+   64-bit sum could wrap; radiance x weight / pdf records of a render stay orders of magnitude below the clamp. */
 PPG_HD uint64_t ppg_to_fixed(float x) {
     float v = x * 16777216.0f;
-    if (!(v < 9.2233720368547758e18f)) return 0x7fffffffffffffffull;
+    if (v != v) return 0ull;
+    if (!(v < 1125899906842624.0f)) return 1ull << 50;
     return (uint64_t)__builtin_rintf(v); /* exactly specified: nearest-even (v_rndne_f32 / rintf) */
 }
 PPG_HD float ppg_from_fixed(uint64_t a) { return (float)a * 5.9604644775390625e-8f; /* 2^-24 */ }

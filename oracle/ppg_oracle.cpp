@@ -3196,7 +3196,8 @@ int ppgo_set_modes(ppgo_ctx *ctx, int32_t acc_mode, int32_t adam_mode, int32_t t
 int ppgo_set_scene(ppgo_ctx *ctx, const ppg_scene *s) {
     Scene &sc = ctx->gpt.scene;
     sc = Scene();
-    if (!s || !s->positions || !s->indices || !s->tri_material || !s->tri_emitter || !s->materials || s->n_triangles == 0) {
+    if (!s || !s->materials || (s->n_triangles == 0 && s->n_spheres == 0) ||
+        (s->n_triangles > 0 && (!s->positions || !s->indices || !s->tri_material || !s->tri_emitter))) {
         ctx->gpt.error = "incomplete scene";
         return PPG_ERR_INVALID;
     }
@@ -3204,9 +3205,11 @@ int ppgo_set_scene(ppgo_ctx *ctx, const ppg_scene *s) {
     sc.hasNormals = s->normals != nullptr;
     if (sc.hasNormals)
         for (uint32_t i = 0; i < s->n_vertices; ++i) sc.N.push_back(Vec(s->normals[3 * i], s->normals[3 * i + 1], s->normals[3 * i + 2]));
-    sc.idx.assign(s->indices, s->indices + 3 * (size_t)s->n_triangles);
-    sc.triMat.assign(s->tri_material, s->tri_material + s->n_triangles);
-    sc.triEmitter.assign(s->tri_emitter, s->tri_emitter + s->n_triangles);
+    if (s->n_triangles) {
+        sc.idx.assign(s->indices, s->indices + 3 * (size_t)s->n_triangles);
+        sc.triMat.assign(s->tri_material, s->tri_material + s->n_triangles);
+        sc.triEmitter.assign(s->tri_emitter, s->tri_emitter + s->n_triangles);
+    }
     sc.hasEnv = s->environment != nullptr;
     if (sc.hasEnv) sc.envRadiance = Spectrum(s->environment[0], s->environment[1], s->environment[2]);
     if (s->envmap) {

@@ -249,6 +249,12 @@ struct BvhBuilder {
         nodes.reserve(nTris);
         int ref, n; Box b;
         nodes.emplace_back();  // root placeholder, must be an interior node
+        if (nTris == 0) {  // spheres only: one node without children
+            nodes4.assign(1, Bvh4Node{});
+            for (int k = 0; k < 4; ++k) nodes4[0].child[k] = PPG_BVH4_EMPTY;
+            quantise();
+            return;
+        }
         if (nTris <= 4) {
             BvhNode &nd = nodes[0];
             Box bb = boundsOf(0, (int)nTris);
@@ -1333,7 +1339,9 @@ void ppg_destroy(ppg_ctx *ctx) {
 const char *ppg_last_error(const ppg_ctx *ctx) { return ctx ? ctx->error.c_str() : g_createError.c_str(); }
 
 int ppg_set_scene(ppg_ctx *ctx, const ppg_scene *s) {
-    if (!s || !s->positions || !s->indices || !s->tri_material || !s->tri_emitter || !s->materials || s->n_triangles == 0) {
+    // a scene needs materials and at least one primitive; triangle arrays may be absent when it consists of analytic spheres only
+    if (!s || !s->materials || (s->n_triangles == 0 && s->n_spheres == 0) ||
+        (s->n_triangles > 0 && (!s->positions || !s->indices || !s->tri_material || !s->tri_emitter))) {
         ctx->error = "incomplete scene";
         return PPG_ERR_INVALID;
     }
@@ -1487,9 +1495,9 @@ int ppg_set_scene(ppg_ctx *ctx, const ppg_scene *s) {
         ctx->scene.textures = ctx->d_textures.p;
     }
     for (uint32_t i = 0; i < s->n_emitters; ++i) ems[i] = make_float4(s->emitters[i].radiance[0], s->emitters[i].radiance[1], s->emitters[i].radiance[2], 0);
-    HIP_CHECK(ctx->d_tris.reserve(tris.size()));
+    HIP_CHECK(ctx->d_tris.reserve(std::max<size_t>(tris.size(), 3)));
     HIP_CHECK(hipMemcpy(ctx->d_tris.p, tris.data(), tris.size() * sizeof(float4), hipMemcpyHostToDevice));
-    HIP_CHECK(ctx->d_accel.reserve(accel.size()));
+    HIP_CHECK(ctx->d_accel.reserve(std::max<size_t>(accel.size(), 3)));
     HIP_CHECK(hipMemcpy(ctx->d_accel.p, accel.data(), accel.size() * sizeof(float4), hipMemcpyHostToDevice));
     {   // small scenes are traced by brute force from LDS: the same records grouped by projection axis (degenerate ones dropped,
         // the rest padded with never-hit records so that n_tris records can always be staged), leaf-order index in record[2].z
@@ -1505,13 +1513,13 @@ int ppg_set_scene(ppg_ctx *ctx, const ppg_scene *s) {
                         ++w; ++n[axis];
                     }
         }
-        HIP_CHECK(ctx->d_accelSmall.reserve(small.size()));
+        HIP_CHECK(ctx->d_accelSmall.reserve(std::max<size_t>(small.size(), 3)));
         HIP_CHECK(hipMemcpy(ctx->d_accelSmall.p, small.data(), small.size() * sizeof(float4), hipMemcpyHostToDevice));
         for (int axis = 0; axis < 3; ++axis) ctx->scene.small_n[axis] = n[axis];
         ctx->scene.accel_small = ctx->d_accelSmall.p;
     }
     if (s->normals) { HIP_CHECK(ctx->d_normals.reserve(nrm.size())); HIP_CHECK(hipMemcpy(ctx->d_normals.p, nrm.data(), nrm.size() * sizeof(float4), hipMemcpyHostToDevice)); }
-    HIP_CHECK(ctx->d_bvh.reserve(bb.nodes.size()));
+    HIP_CHECK(ctx->d_bvh.reserve(std::max<size_t>(bb.nodes.size(), 1)));
     HIP_CHECK(hipMemcpy(ctx->d_bvh.p, bb.nodes.data(), bb.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice));
     HIP_CHECK(ctx->d_bvh4.reserve(bb.nodes4q.size()));
     HIP_CHECK(hipMemcpy(ctx->d_bvh4.p, bb.nodes4q.data(), bb.nodes4q.size() * sizeof(Bvh4QNode), hipMemcpyHostToDevice));

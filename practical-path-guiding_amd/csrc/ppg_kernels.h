@@ -19,6 +19,10 @@
 #ifndef PPG_SHADE_WAVES
 #define PPG_SHADE_WAVES 4  // waves per SIMD requested for k_shade: 128 VGPRs without spilling (5 or 6 spill and are slower, 2-3 waste occupancy)
 #endif
+#ifndef PPG_LEAF_VOTE
+#define PPG_LEAF_VOTE 16  // k_trace: lanes holding a leaf wait until this many lanes of the wave do (0 = test leaves at once).  KITCHEN 720p,
+                          // k_trace over 127 passes: 0 → 486 ms, 8 → 412, 16 → 387, 32 → 390
+#endif
 #ifndef PPG_SHADE_WAVES_FULL
 #define PPG_SHADE_WAVES_FULL 3  // ... for the FULL material set (k_shade<.., FULL>, k_tail<.., FULL>), whose BSDF code needs more registers: at 128 VGPRs it
                                 // spills 257 of them (KITCHEN 720p: 4 waves 76.5, 3 waves 81.3, 2 waves 79.6 Msamples/s)
@@ -291,6 +295,14 @@ D void trace_slice_bvh4(const PathState &P, const DevScene &S, int *lds_stack, u
         // union of its lanes' branches, and with the triangle loops nested in the node step almost every iteration ran up to four
         // divergent triangle loops for the few lanes that had a leaf child (measured on KITCHEN: the traversal was bound by issue slots,
         // not by bytes — 64-byte nodes alone changed nothing).
+#if PPG_LEAF_VOTE > 0
+        // leaves wait until PPG_LEAF_VOTE lanes of the wave have one (or no lane has an interior node left): the triangle code then runs
+        // for many lanes at once instead of in almost every iteration for one or two of them
+        const unsigned long long leafLanes = __ballot(cur < 0), nodeLanes = __ballot(cur >= 0 && cur != PPG_BVH4_EMPTY);
+        const bool doLeaves = __popcll(leafLanes) >= PPG_LEAF_VOTE || nodeLanes == 0ull;
+#else
+        const bool doLeaves = true;
+#endif
         if (cur >= 0) {
             if (COUNT) ++n_nodes;
             float lxs[4], lys[4], lzs[4], hxs[4], hys[4], hzs[4];
@@ -322,7 +334,7 @@ D void trace_slice_bvh4(const PathState &P, const DevScene &S, int *lds_stack, u
                 for (int j = m - 1; j >= 1; --j) st.push(cn[j]);
                 cur = cn[0];
             } else cur = st.sp > 0 ? st.pop() : PPG_BVH4_EMPTY;
-        } else {
+        } else if (doLeaves) {
             const int code = ~cur;
             const int first = code >> 3, cnt = (code & 7) + 1;
             if (COUNT) n_tris += (unsigned long long)cnt;

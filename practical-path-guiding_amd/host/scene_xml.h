@@ -484,11 +484,17 @@ inline Mesh loadSerialized(const std::string &path, const Mat4 &toWorld, int sha
     const int version = header(0);
     size_t start = 0;
     if (shapeIndex != 0) {
+        // the offset table at the end of the file (readOffset, trimesh.cpp:272-295); every size comes from the file: check it against the buffer
+        // (the reference accepts shapeIndex == count and then reads past the table — an error here)
+        if (buf.size() < 8) throw std::runtime_error(path + ": truncated file");
         uint32_t count;
         memcpy(&count, &buf[buf.size() - 4], 4);
-        if (shapeIndex < 0 || shapeIndex > (int)count) throw std::runtime_error(path + ": shape index is out of range!");
-        if (version == 4) { uint64_t o; memcpy(&o, &buf[buf.size() - 8 * (size_t)(count - shapeIndex) - 4], 8); start = (size_t)o; }
-        else { uint32_t o; memcpy(&o, &buf[buf.size() - 4 * (size_t)(count - shapeIndex + 1)], 4); start = o; }
+        if (shapeIndex < 0 || (uint64_t)shapeIndex >= (uint64_t)count) throw std::runtime_error(path + ": shape index is out of range!");
+        const uint64_t entry = version == 4 ? 8 : 4, back = entry * (uint64_t)(count - shapeIndex) + 4;
+        if (back > buf.size()) throw std::runtime_error(path + ": corrupt offset table");
+        if (version == 4) { uint64_t o; memcpy(&o, &buf[buf.size() - back], 8); if (o > buf.size()) throw std::runtime_error(path + ": corrupt offset table"); start = (size_t)o; }
+        else { uint32_t o; memcpy(&o, &buf[buf.size() - back], 4); start = o; }
+        if (start + 4 > buf.size()) throw std::runtime_error(path + ": corrupt offset table");
         header(start);
     }
     std::vector<unsigned char> data;
@@ -515,6 +521,7 @@ inline Mesh loadSerialized(const std::string &path, const Mat4 &toWorld, int sha
     uint64_t nv, nt;
     need(16); memcpy(&nv, &data[off], 8); memcpy(&nt, &data[off + 8], 8); off += 16;
     const bool dbl = (flags & 0x2000) != 0;
+    if (nv > data.size() || nt > data.size()) throw std::runtime_error(path + ": truncated mesh data");  // every vertex / triangle takes > 1 byte: no overflow below
     auto take = [&](int comps, std::vector<float> &out) {
         const size_t n = (size_t)nv * comps;
         need(n * (dbl ? 8 : 4));

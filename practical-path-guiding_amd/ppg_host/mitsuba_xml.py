@@ -375,13 +375,17 @@ def load_serialized(path, to_world=None, shape_index=0, face_normals=False, flip
     version = header(0)
     start = 0
     if shape_index != 0:  # readOffset, trimesh.cpp:272-295
+        if len(buf) < 8:
+            raise SceneError("%s: truncated file" % path)
         count = struct.unpack_from("<I", buf, len(buf) - 4)[0]
-        if shape_index < 0 or shape_index > count:
+        if shape_index < 0 or shape_index >= count:  # (the reference accepts shapeIndex == count and then reads past the offset table)
             raise SceneError("%s: shape index is out of range! (requested %d out of 0..%d)" % (path, shape_index, count - 1))
-        if version == 4:
-            start = struct.unpack_from("<Q", buf, len(buf) - 8 * (count - shape_index) - 4)[0]
-        else:
-            start = struct.unpack_from("<I", buf, len(buf) - 4 * (count - shape_index + 1))[0]
+        back = (8 if version == 4 else 4) * (count - shape_index) + 4
+        if back > len(buf):
+            raise SceneError("%s: corrupt offset table" % path)
+        start = struct.unpack_from("<Q" if version == 4 else "<I", buf, len(buf) - back)[0]
+        if start + 4 > len(buf):
+            raise SceneError("%s: corrupt offset table" % path)
         header(start)
     try:
         data = zlib.decompressobj().decompress(buf[start + 4:])
@@ -391,11 +395,17 @@ def load_serialized(path, to_world=None, shape_index=0, face_normals=False, flip
     flags = struct.unpack_from("<I", data, off)[0]; off += 4
     if version == 4:
         off = data.index(b"\0", off) + 1
+    if off + 16 > len(data):
+        raise SceneError("%s: truncated mesh data" % path)
     nv, nt = struct.unpack_from("<QQ", data, off); off += 16
+    if nv > len(data) or nt > len(data):
+        raise SceneError("%s: truncated mesh data" % path)
     dt = "<f8" if flags & 0x2000 else "<f4"
 
     def take(n_comp):
         nonlocal off
+        if off + nv * n_comp * (8 if flags & 0x2000 else 4) > len(data):
+            raise SceneError("%s: truncated mesh data" % path)
         a = np.frombuffer(data, dt, nv * n_comp, off).reshape(nv, n_comp).astype(f32)
         off += a.shape[0] * n_comp * (8 if flags & 0x2000 else 4)
         return a
@@ -404,6 +414,8 @@ def load_serialized(path, to_world=None, shape_index=0, face_normals=False, flip
     uvs = take(2) if flags & 0x0002 else None
     if flags & 0x0008:
         take(3)  # vertex colours: not used
+    if off + nt * 12 > len(data):
+        raise SceneError("%s: truncated mesh data" % path)
     idx = np.frombuffer(data, "<u4", nt * 3, off).reshape(nt, 3).astype(np.uint32)
     if idx.size and idx.max() >= nv:
         raise SceneError("%s: vertex index out of bounds" % path)
@@ -1039,7 +1051,7 @@ def load_scene(path, defines=None, strict=True, width=None, height=None, data_di
             collected.append((mesh, mat, em))
         if t == "sphere":
             spheres.append(dict(sphere, material=mat, emitter=em))
-    if not collected:
+    if not collected and not spheres:
         raise SceneError("scene without shapes")
     # one vertex-normal array for the whole scene: a faceNormals mesh living next to smooth ones gets its vertices
     # un-shared and its face normals written out (same shading frame as "no normals": skdtree.h:388-401)
@@ -1068,6 +1080,8 @@ def load_scene(path, defines=None, strict=True, width=None, height=None, data_di
         nv += p.shape[0]
         tmat.append(np.full(T, mat, np.uint32)); tem.append(np.full(T, em, np.int32))
     normals = np.concatenate(nrm).astype(f32) if any_normals else None
+    if not collected:  # analytic spheres only
+        pos, idx, tmat, tem = [np.zeros((0, 3), f32)], [np.zeros((0, 3), np.uint32)], [np.zeros(0, np.uint32)], [np.zeros(0, np.int32)]
     desc = SceneDesc(np.concatenate(pos).astype(f32), np.concatenate(idx).astype(np.uint32), np.concatenate(tmat), np.concatenate(tem),
                      materials, emitters, camera, normals, environment, np.stack(rt_slices).astype(f32) if rt_slices else None, spheres, envmap,
                      np.concatenate(uvl).astype(f32) if any_uvs else None, textures)

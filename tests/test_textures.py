@@ -211,3 +211,30 @@ def test_textured_floor_on_the_gpu_equals_the_oracle(oracle_lib):
         g = hip(**props); g.set_scene(scene); g.render()
         o = make_oracle(oracle_lib, threads=4, **props); o.set_scene(scene); o.render()
         assert np.array_equal(g.read_film(), o.read_film()), kw
+
+
+def _sphere_only_scene(res):
+    """No triangle at all: one diffuse analytic sphere under a uniform sky (a convex body: every reflected ray leaves the scene)."""
+    cam = ppg_host.scenes.perspective_camera((0, 0, 4), (0, 0, 0), (0, 1, 0), 30.0, "x", 0.01, 100.0, res, res)
+    return ppg_host.SceneDesc(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.int32),
+                              [dict(type=0, reflectance=(0.25, 0.5, 0.75))], [], cam, environment=(2.0, 2.0, 2.0),
+                              spheres=[dict(center=(0, 0, 0), radius=1.0, material=0, emitter=-1)])
+
+
+def test_scene_of_analytic_spheres_only(oracle_lib):
+    """A scene Mitsuba renders must not be refused because it holds no triangle mesh: the furnace identity on a convex diffuse sphere."""
+    e = make_oracle(oracle_lib, threads=2, budgetType="spp", budget=8, sppPerPass=4, maxDepth=4, rrDepth=10, seed=2)
+    e.set_scene(_sphere_only_scene(24)); e.render()
+    img = e.read_film()
+    assert np.allclose(img[10:14, 10:14], np.array([0.25, 0.5, 0.75]) * 2.0, rtol=1e-5)   # on the sphere: albedo x L, sample by sample
+    assert np.allclose(img[0, 0], 2.0)                                                      # beside it: the sky
+
+
+@pytest.mark.gpu
+def test_scene_of_analytic_spheres_only_on_the_gpu(oracle_lib):
+    from test_gpu_parity import hip
+    props = dict(budgetType="spp", budget=28, sppPerPass=4, maxDepth=6, rrDepth=3, seed=2)
+    scene = _sphere_only_scene(48)
+    g = hip(**props); g.set_scene(scene); g.render()
+    o = make_oracle(oracle_lib, threads=4, **props); o.set_scene(scene); o.render()
+    assert np.array_equal(g.read_film(), o.read_film())
