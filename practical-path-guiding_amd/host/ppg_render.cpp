@@ -193,7 +193,7 @@ static bool saveScene(const char *path, const SceneData &s) {
 
 int main(int argc, char **argv) {
     Properties props;
-    std::string out = "out.pfm", scenePath, dumpScene;
+    std::string out = "out.pfm", scenePath, dumpScene, bsdfId;
     bool quiet = false, lenient = false;
     std::string dataDir;  // `data` directory of a Mitsuba tree (roughplastic: data/microfacet/*.dat); default $PPG_MITSUBA_DATA
     int cw = 0, ch = 0, sw = 0, sh = 0;
@@ -208,6 +208,7 @@ int main(int argc, char **argv) {
             defines[kv.substr(0, eq)] = kv.substr(eq + 1);  // also a $name for a scene XML, like mitsuba -D (mitsuba.cpp:58-87)
         } else if (a == "-o" && i + 1 < argc) out = argv[++i];
         else if (a == "--ppgs" && i + 1 < argc) dumpScene = argv[++i];
+        else if (a == "--bsdf-id" && i + 1 < argc) bsdfId = argv[++i];  // print the ppg_material of <bsdf id=...> (what the Mitsuba plug-in shim asks for) and exit
         else if (a == "--lenient") lenient = true;
         else if (a == "--data-dir" && i + 1 < argc) dataDir = argv[++i];
         else if (a == "--size" && i + 1 < argc) { if (sscanf(argv[++i], "%dx%d", &sw, &sh) != 2) { std::cerr << "--size WxH\n"; return 2; } }
@@ -232,6 +233,15 @@ int main(int argc, char **argv) {
     }
     SceneData scene;
     const bool isXml = scenePath.size() > 4 && scenePath.compare(scenePath.size() - 4, 4, ".xml") == 0;
+    if (!bsdfId.empty()) {
+        ppg_material m{};
+        std::string why;
+        if (!isXml || !xml::bsdfById(scenePath, bsdfId, dataDir, scene, m, why)) { std::cerr << "no bsdf '" << bsdfId << "': " << why << std::endl; return 2; }
+        std::cout << "{\"type\": " << m.type << ", \"flags\": " << m.flags << ", \"reflectance\": [" << m.reflectance[0] << ", " << m.reflectance[1] << ", " << m.reflectance[2]
+                  << "], \"alpha\": " << m.alpha << ", \"eta\": " << m.eta[0] << ", \"rtrans\": " << m.rtrans << ", \"rtrans_slices\": "
+                  << (scene.rtransSamples ? scene.rtrans.size() / (scene.rtransSamples + 1) : 0) << "}" << std::endl;
+        return 0;
+    }
     if (cw > 0) cboxScene(cw, ch, scene);
     else if (isXml) {
         try {

@@ -1220,6 +1220,32 @@ private:
         m.reflectance[0] = m.reflectance[1] = m.reflectance[2] = 0.5f;
         return m;
     }
+public:
+    // The <bsdf> element carrying `id` (at any nesting depth: every element with an id is a named object in Mitsuba) as a ppg_material;
+    // rough-transmittance slices it needs are appended to out.scene.rtrans.  Used by the Mitsuba plug-in shim
+    // (mitsuba_plugin/guided_path_hip.cpp), which cannot reach the nested BSDF of an adapter through Mitsuba's API.
+    bool bsdfById(const std::string &id, LoadedScene &out, ppg_material &m) {
+        std::ifstream f(m_path, std::ios::binary);
+        if (!f) throw std::runtime_error("cannot open '" + m_path + "'");
+        std::stringstream ss; ss << f.rdbuf();
+        const std::string text = ss.str();
+        XmlNode root = XmlParser(text).parseDocument();
+        size_t slash = m_path.find_last_of('/');
+        m_base = slash == std::string::npos ? "." : m_path.substr(0, slash);
+        collectDefaults(root);
+        const XmlNode *found = nullptr;
+        std::function<void(const XmlNode &)> walk = [&](const XmlNode &n) {
+            for (auto &c : n.children) {
+                if (!found && c.tag == "bsdf" && c.attr("id") && c.get("id") == id) found = &c;
+                if (!found) walk(c);
+            }
+        };
+        walk(root);
+        if (!found) return false;
+        m = makeBsdf(*found, true, out);
+        return true;
+    }
+private:
     uint32_t intern(const ppg_material &m, LoadedScene &out) {
         std::string key((const char *)&m, sizeof m);
         for (size_t i = 0; i < m_matKeys.size(); ++i) if (m_matKeys[i] == key) return (uint32_t)i;
@@ -1228,5 +1254,27 @@ private:
         return (uint32_t)m_matKeys.size() - 1;
     }
 };
+
+namespace xml {
+// one <bsdf id="..."> of a scene file as a ppg_material appended to `data` (its rough-transmittance slice, if any, to data.rtrans)
+inline bool bsdfById(const std::string &scenePath, const std::string &id, const std::string &dataDir, SceneData &data, ppg_material &m, std::string &why) {
+    try {
+        SceneXmlLoader loader(scenePath, {}, true, 0, 0, dataDir);
+        LoadedScene tmp;
+        if (!loader.bsdfById(id, tmp, m)) return false;
+        if (!tmp.scene.rtrans.empty()) {
+            if (data.rtransSamples && data.rtransSamples != tmp.scene.rtransSamples) { why = "rough-transmittance tables of different resolutions"; return false; }
+            const uint32_t have = data.rtransSamples ? (uint32_t)(data.rtrans.size() / (data.rtransSamples + 1)) : 0u;
+            data.rtransSamples = tmp.scene.rtransSamples;
+            data.rtrans.insert(data.rtrans.end(), tmp.scene.rtrans.begin(), tmp.scene.rtrans.end());
+            if (m.type == PPG_BSDF_ROUGHPLASTIC) m.rtrans += (int32_t)have;
+        }
+        return true;
+    } catch (const std::exception &e) {
+        why = e.what();
+        return false;
+    }
+}
+}  // namespace xml
 
 }  // namespace ppg

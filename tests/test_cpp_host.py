@@ -437,3 +437,24 @@ def test_cpp_loader_reads_the_reference_cbox(ppg_render, tmp_path):
     mats = np.array([np.frombuffer(m, np.float32)[1:4] for m in c["materials"]])
     assert np.allclose(mats, [m["reflectance"] for m in desc.materials], rtol=5e-6)   # spectrum → RGB, incl. the reversed interpolation
     assert np.allclose(c["emitters"][0, :3], desc.emitters[0]["radiance"], rtol=5e-6)
+
+
+def test_bsdf_by_id_for_the_mitsuba_plugin_shim(tmp_path):
+    """mitsuba_plugin/guided_path_hip.cpp cannot reach the nested BSDF of a twosided / mask / bumpmap adapter through Mitsuba's API; it asks
+    host/scene_xml.h for the <bsdf> element with the object's id (ppg::xml::bsdfById, exposed as `ppg_render --bsdf-id`): ids on nested
+    elements are named objects of their own, unknown ids are reported."""
+    import json
+    xml = tmp_path / "s.xml"
+    xml.write_text("""<scene version="0.5.0"><integrator type="guided_path"/><sensor type="perspective"><float name="fov" value="40"/>
+        <film type="hdrfilm"><rfilter type="box"/></film></sensor>
+        <bsdf type="bumpmap"><texture type="scale"/><bsdf type="twosided" id="inner"><bsdf type="diffuse"><rgb name="reflectance" value="0.2,0.3,0.4"/></bsdf></bsdf></bsdf>
+        <bsdf type="mask" id="holes"><rgb name="opacity" value="0.25"/><bsdf type="roughconductor"><string name="material" value="none"/><float name="alpha" value="0.2"/>
+            <string name="distribution" value="ggx"/></bsdf></bsdf>
+        <shape type="rectangle"><ref id="inner"/></shape></scene>""")
+    exe = os.path.join(ROOT, "practical-path-guiding_amd", "bin", "ppg_render")
+    a = json.loads(subprocess.run([exe, str(xml), "--bsdf-id", "inner"], check=True, capture_output=True, text=True).stdout)
+    assert a["type"] == 1 and np.allclose(a["reflectance"], [0.2, 0.3, 0.4])
+    b = json.loads(subprocess.run([exe, str(xml), "--bsdf-id", "holes"], check=True, capture_output=True, text=True).stdout)
+    assert b["type"] == 4 and b["flags"] & 4 and abs(b["alpha"] - 0.2) < 1e-6
+    r = subprocess.run([exe, str(xml), "--bsdf-id", "nope"], capture_output=True, text=True)
+    assert r.returncode == 2 and "no bsdf 'nope'" in r.stderr
