@@ -83,6 +83,19 @@ public:
     }
 };
 
+// The exchange points of a tile-sharded multi-GPU render (one process per GPU): what render() calls between the phases of an iteration.
+// host/rccl_reducer.h implements it over RCCL.
+class Reducer {
+public:
+    virtual ~Reducer() {}
+    virtual void reduceImages(ppg_ctx *ctx, int width, int height) = 0;   // before the variance estimate of performRenderPasses (GP:1288-1313)
+    virtual void reduceSDTree(ppg_ctx *ctx) = 0;                          // before buildSDTree (GP:1115)
+    virtual void reduceAdamRecords(ppg_ctx *ctx) = 0;                     // round hook of the sampling-fraction optimiser (include/ppg.h)
+    virtual void reduceFilm(ppg_ctx *ctx, int width, int height) = 0;     // before the film is read (not with inverse-variance combination)
+    virtual int rank() const = 0;
+    virtual int world() const = 0;
+};
+
 class GuidedPathTracerHIP {
 public:
     typedef std::function<void(const std::string &)> Log;
@@ -117,15 +130,22 @@ public:
 
     void cancel() { ppg_cancel(m_ctx); }  // GP:1643-1648
 
-    // render(): GP:1516-1585.  Returns false when cancelled, throws on errors.
-    bool render(const SceneData &scene, const Log &log = Log()) {
+    // render(): GP:1516-1585.  Returns false when cancelled, throws on errors.  With a reducer the image is sharded by 32x32 tiles over
+    // reducer->world() ranks (every rank calls render() on the same scene) and the film is complete on every rank afterwards.
+    bool render(const SceneData &scene, const Log &log = Log(), Reducer *reducer = nullptr) {
+        m_reducer = reducer;
+        const bool spp = std::string(m_cfg.budgetType) == "spp";
+        if (reducer && !spp)  // every control decision of renderTime (GP:1434-1514) reads a rank-local clock: the ranks' collectives would stop matching
+            throw std::runtime_error("sharded rendering needs budgetType = spp (a time budget is decided by rank-local clocks)");
         ppg_scene sv = scene.view();
         check(ppg_set_scene(m_ctx, &sv), "ppg_set_scene");
+        if (reducer) check(ppg_set_shard(m_ctx, reducer->rank(), reducer->world(), 32), "ppg_set_shard");
         m_w = scene.camera.width; m_h = scene.camera.height;
         check(ppg_begin_render(m_ctx), "ppg_begin_render");
-        say(log, fmt("Starting render job (%ix%i, MI355X) ..", m_w, m_h));
-        const bool spp = std::string(m_cfg.budgetType) == "spp";
+        if (reducer && std::string(m_cfg.bsdfSamplingFractionLoss) != "none") check(ppg_set_pass_hook(m_ctx, &GuidedPathTracerHIP::roundHook, this), "ppg_set_pass_hook");
+        say(log, fmt("Starting render job (%ix%i, MI355X%s) ..", m_w, m_h, reducer ? fmt(", rank %d of %d", reducer->rank(), reducer->world()).c_str() : ""));
         bool ok = spp ? renderSPP(log) : renderTime(log);
+        if (ok && reducer && std::string(m_cfg.sampleCombination) != "inversevar") reducer->reduceFilm(m_ctx, m_w, m_h);
         if (ok) check(ppg_end_render(m_ctx), "ppg_end_render");
         return ok;
     }
@@ -144,19 +164,32 @@ private:
         return buf;
     }
     static void say(const Log &log, const std::string &s) { if (log) log(s); }
-    void check(int rc, const char *what) { if (rc != PPG_OK && rc != PPG_ERR_CANCELLED) throw std::runtime_error(std::string(what) + ": " + ppg_last_error(m_ctx)); }
+    void check(int rc, const char *what) {
+        rethrowHookError();
+        if (rc != PPG_OK && rc != PPG_ERR_CANCELLED) throw std::runtime_error(std::string(what) + ": " + ppg_last_error(m_ctx));
+    }
 
     // performRenderPasses, GP:1210-1329
     bool passes(int n, ppg_pass_stats &st, const Log &log) {
         say(log, fmt("Rendering %d render passes.", n));
-        int rc = ppg_render_passes(m_ctx, n, &st);
-        check(rc, "ppg_render_passes");
+        int rc;
+        if (!m_reducer) {
+            rc = ppg_render_passes(m_ctx, n, &st);
+            check(rc, "ppg_render_passes");
+        } else {  // the ranks' image tiles are summed before the variance is estimated from them
+            rc = ppg_render_passes_nostat(m_ctx, n);
+            check(rc, "ppg_render_passes_nostat");
+            try { m_reducer->reduceImages(m_ctx, m_w, m_h); } catch (...) { m_hookError = std::current_exception(); }
+            rethrowHookError();
+            check(ppg_finish_passes(m_ctx, &st), "ppg_finish_passes");
+        }
         const float ttuv = (float)st.seconds * st.variance, stuv = st.passes_rendered_local * m_cfg.sppPerPass * st.variance;
         say(log, fmt("%.2f seconds, Total passes: %d, Var: %f, TTUV: %f, STUV: %f.", st.seconds, st.passes_rendered_total, st.variance, ttuv, stuv));
         m_passesRendered = st.passes_rendered_total;
         return rc == PPG_OK;
     }
-    void build(const Log &log) {  // buildSDTree, GP:1115-1189
+    void build(const Log &log, bool final = false) {  // buildSDTree, GP:1115-1189
+        if (m_reducer && !final) m_reducer->reduceSDTree(m_ctx);  // (the final iteration records nothing)
         say(log, "Building distributions for sampling.");
         ppg_tree_stats t;
         check(ppg_build_sdtree(m_ctx, &t), "ppg_build_sdtree");
@@ -186,7 +219,8 @@ private:
             if (remainingPasses - passesThisIteration < 2 * passesThisIteration) passesThisIteration = remainingPasses;
             say(log, fmt("ITERATION %d, %d passes", iter, passesThisIteration));
             say(log, "Resetting distributions for sampling.");
-            check(ppg_begin_iteration(m_ctx, passesThisIteration >= remainingPasses), "ppg_begin_iteration");
+            bool isFinal = passesThisIteration >= remainingPasses;
+            check(ppg_begin_iteration(m_ctx, isFinal), "ppg_begin_iteration");
             ppg_pass_stats st;
             if (!passes(passesThisIteration, st, log)) return false;
             const float lastVarAtEnd = currentVarAtEnd;
@@ -196,9 +230,10 @@ private:
             if (automatic && remainingPasses > 0 && (remainingPasses < passesThisIteration || (sppRendered > 256 && currentVarAtEnd > lastVarAtEnd))) {
                 say(log, fmt("FINAL %d passes", remainingPasses));
                 ppg_set_final(m_ctx, 1);
+                isFinal = true;
                 if (!passes(remainingPasses, st, log)) return false;
             }
-            build(log);
+            build(log, isFinal);
             check(ppg_end_iteration(m_ctx), "ppg_end_iteration");
             ++iter;
         }
@@ -246,6 +281,14 @@ private:
         return true;
     }
 
+    static int roundHook(void *self) {  // C callback: no exception may cross the C-ABI
+        GuidedPathTracerHIP *g = static_cast<GuidedPathTracerHIP *>(self);
+        try { g->m_reducer->reduceAdamRecords(g->m_ctx); return 0; } catch (...) { g->m_hookError = std::current_exception(); return 1; }
+    }
+    void rethrowHookError() { if (m_hookError) { std::exception_ptr e = m_hookError; m_hookError = nullptr; std::rethrow_exception(e); } }
+
+    Reducer *m_reducer = nullptr;
+    std::exception_ptr m_hookError;
     ppg_config m_cfg;
     ppg_ctx *m_ctx = nullptr;
     std::string m_str[7];

@@ -16,9 +16,11 @@
 #include <cstdarg>
 #include <cstring>
 #include <fstream>
+#include <memory>
 #include <iostream>
 
 #include "guided_path_hip.h"
+#include "rccl_reducer.h"
 #include "scene_xml.h"
 
 using namespace ppg;
@@ -193,7 +195,8 @@ static bool saveScene(const char *path, const SceneData &s) {
 
 int main(int argc, char **argv) {
     Properties props;
-    std::string out = "out.pfm", scenePath, dumpScene, bsdfId;
+    std::string out = "out.pfm", scenePath, dumpScene, bsdfId, ncclIdFile;
+    int rank = 0, world = 1;
     bool quiet = false, lenient = false;
     std::string dataDir;  // `data` directory of a Mitsuba tree (roughplastic: data/microfacet/*.dat); default $PPG_MITSUBA_DATA
     int cw = 0, ch = 0, sw = 0, sh = 0;
@@ -209,6 +212,9 @@ int main(int argc, char **argv) {
         } else if (a == "-o" && i + 1 < argc) out = argv[++i];
         else if (a == "--ppgs" && i + 1 < argc) dumpScene = argv[++i];
         else if (a == "--bsdf-id" && i + 1 < argc) bsdfId = argv[++i];  // print the ppg_material of <bsdf id=...> (what the Mitsuba plug-in shim asks for) and exit
+        else if (a == "--rank" && i + 1 < argc) rank = atoi(argv[++i]);       // multi-GPU: one process per GPU, image tiles sharded over `--world` ranks,
+        else if (a == "--world" && i + 1 < argc) world = atoi(argv[++i]);     // RCCL communicator bootstrapped through the file `--nccl-id` (rank 0 writes it);
+        else if (a == "--nccl-id" && i + 1 < argc) ncclIdFile = argv[++i];    // host/rccl_reducer.h
         else if (a == "--lenient") lenient = true;
         else if (a == "--data-dir" && i + 1 < argc) dataDir = argv[++i];
         else if (a == "--size" && i + 1 < argc) { if (sscanf(argv[++i], "%dx%d", &sw, &sh) != 2) { std::cerr << "--size WxH\n"; return 2; } }
@@ -261,12 +267,23 @@ int main(int argc, char **argv) {
         return 0;
     }
     try {
+        std::unique_ptr<RcclReducer> reducer;
+        if (!ncclIdFile.empty()) {
+            if (world < 1 || rank < 0 || rank >= world) { std::cerr << "--rank / --world out of range\n"; return 2; }
+            if (!props.values.count("device")) props.values["device"] = std::to_string(rank);  // one GPU per rank of the node
+            const auto t0 = std::chrono::steady_clock::now();
+            reducer.reset(new RcclReducer(rank, world, std::stoi(props.values["device"]), ncclIdFile));
+            if (!quiet) std::cout << "RCCL communicator: rank " << rank << " of " << world << " ready after "
+                                  << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << " s" << std::endl;
+        }
         GuidedPathTracerHIP gpt(props);
         const auto t0 = std::chrono::steady_clock::now();
-        bool ok = gpt.render(scene, quiet ? GuidedPathTracerHIP::Log() : [](const std::string &s) { std::cout << s << std::endl; });
+        const bool talk = !quiet && rank == 0;
+        bool ok = gpt.render(scene, talk ? [](const std::string &s) { std::cout << s << std::endl; } : GuidedPathTracerHIP::Log(), reducer.get());
         const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        if (!quiet) std::cout << "Render time: " << sec << "s" << (ok ? "" : " (cancelled)") << std::endl;
-        writePFM(out.c_str(), gpt.film(), scene.camera.width, scene.camera.height);
+        if (talk) std::cout << "Render time: " << sec << "s" << (ok ? "" : " (cancelled)") << std::endl;
+        if (reducer && talk) std::cout << "RCCL: " << reducer->collectives() << " collectives, " << reducer->bytes() / 1e6 << " MB staged" << std::endl;
+        if (rank == 0) writePFM(out.c_str(), gpt.film(), scene.camera.width, scene.camera.height);
         return ok ? 0 : 1;
     } catch (const std::exception &e) {
         std::cerr << "error: " << e.what() << std::endl;

@@ -87,6 +87,34 @@ def test_cpp_driver_equals_python_path(ppg_render, tmp_path):
 
 
 @pytest.mark.gpu
+def test_cpp_rccl_reducer_single_rank(ppg_render, tmp_path):
+    """`ppg_render --rank 0 --world 1 --nccl-id FILE`: the C++ RCCL reducer with a real communicator (ncclCommInitRank, packed all-reduces
+    of images / SD-tree sums / film, all-gather of the optimiser records).  On one rank every sum is the identity, so the picture must
+    equal the un-sharded render bit for bit — for both film combinations and with the sampling-fraction optimiser on."""
+    import ppg_host
+    scene = ppg_host.cbox_scene(96, 64)
+    path = str(tmp_path / "cbox.ppgs")
+    ppg_host.save_scene(scene, path)
+    for extra in ({}, dict(sampleCombination="inversevar", bsdfSamplingFractionLoss="kl", directionalFilter="box")):
+        props = dict(CBOX_PROPS, budget=60, seed=9, **extra)
+        defs = sum([["-D", "%s=%s" % kv] for kv in props.items()], [])
+        a, b = str(tmp_path / "a.pfm"), str(tmp_path / "b.pfm")
+        r = subprocess.run([ppg_render, "-q", "-o", a] + defs + [path], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        r = subprocess.run([ppg_render, "-o", b, "--rank", "0", "--world", "1", "--nccl-id", str(tmp_path / "id")] + defs + [path],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        assert "RCCL communicator: rank 0 of 1" in r.stdout
+        n = int(re.search(r"RCCL: (\d+) collectives", r.stdout).group(1))
+        assert n >= 2 * len(re.findall(r"ITERATION", r.stdout))
+        assert np.array_equal(read_pfm(a), read_pfm(b))
+    # wall-clock budgets cannot be sharded (ranks would disagree on the number of passes): refused, not deadlocked
+    r = subprocess.run([ppg_render, "-q", "-o", a, "--rank", "0", "--world", "1", "--nccl-id", str(tmp_path / "id2"), "-D", "budgetType=seconds",
+                        "-D", "budget=1", path], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "spp" in r.stderr
+
+
+@pytest.mark.gpu
 def test_scene_xml_through_both_drivers(ppg_render, tmp_path):
     """Mitsuba scene XML → (a) `python -m ppg_host` → EXR with the render log attached, (b) --ppgs + .props → the C++
     driver; both equal a direct render of the loaded scene."""
