@@ -25,13 +25,14 @@ Added to the JSON line (rank 0):
                 the kernels' own stream, algorithmic bytes per DESIGN.md §3 — for k_trace on a BVH scene 48 B per ray + 64 B per
                 BVH4 node visited + 48 B per triangle tested, the visits counted by the kernel itself in that run
   cpu_baseline  the oracle restatement timed on the host cores on the first passes of the same render (N = 1 only)
-  time_to_rmse  seconds until the image reaches the RMSE the reference's own KITCHEN render has against its converged render
-                (0.2065 for kitchen-improved.exr, 2400 spp, 500.9 s on 16 CPU cores), measured against a converged
-                render of this build (N = 1 only; --no-rmse skips it)
+  time_to_rmse  seconds until this build's KITCHEN picture (at the reference's 700x400) is as close to the reference's converged
+                kitchen-reference.exr as the reference's own guided render kitchen-improved.exr is (2400 spp, 500.9 s on 16 CPU
+                cores): MAPE and RMSE over the pixels not affected by the six missing meshes (N = 1 only; --no-rmse skips it)
   secondary     cbox-720p (configs[1]) Msamples/s, for the record (N = 1 only; --no-secondary skips it)
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -42,7 +43,8 @@ sys.path.insert(0, os.path.join(ROOT, "practical-path-guiding_amd"))
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 KITCHEN_FILE = os.path.join(ROOT, "scratch", "kitchen-improved.ppgs")
 IMPROVED = dict(sampleCombination="inversevar", bsdfSamplingFractionLoss="kl", spatialFilter="stochastic", directionalFilter="box", sTreeThreshold=4000, sppPerPass=1)
-REF_KITCHEN_RMSE, REF_KITCHEN_SECONDS = 0.2065, 500.9  # kitchen-improved.exr vs kitchen-reference.exr; its log's render time
+REF_KITCHEN_SECONDS = 500.9  # render time in the log embedded in kitchen-improved.exr (2400 spp, 700x400, 16 CPU cores)
+KITCHEN_REFERENCE = os.path.join(ROOT, "tests", "golden", "ref_kitchen_reference.npz")
 
 
 def algorithmic_bytes(work=None, rays=None, bvh=None):
@@ -111,6 +113,9 @@ def run(args):
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
+        if args.force_dist and args.gpus == 1:  # stand-alone plumbing check: a one-rank communicator without a launcher
+            for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533")):
+                os.environ.setdefault(k, v)
         dist.init_process_group("nccl")
         assert dist.get_world_size() == args.gpus, "launch with --nproc-per-node == --gpus"
         world = dist.get_world_size()
@@ -127,7 +132,7 @@ def run(args):
         path = args.scene_file or KITCHEN_FILE
         scene = ppg_host.load_scene_file(path)
         if args.size_override:
-            scene.camera = dict(scene.camera, width=args.width, height=args.height)
+            scene.camera = ppg_host.resize_camera(scene.camera, args.width, args.height)  # keeps the horizontal field of view
         if args.constant_env:
             scene.environment = tuple(float(v) for v in args.constant_env.split(","))
         args.width, args.height = scene.camera["width"], scene.camera["height"]
@@ -280,23 +285,52 @@ def run(args):
                            "note": "the BVH and the SD-tree are L2 / Infinity-Cache resident: the algorithmic bytes are what the kernel must read per ray "
                                    "(cache-oblivious), `traffic` what reaches HBM"}
 
-    if rank == 0 and args.gpus == 1 and not args.no_rmse and scene_name in ("kitchen", "room"):
-        # time to target RMSE.  Reference image: a converged render of this build (another seed); target: the RMSE the reference's own
-        # kitchen-improved.exr (2400 spp, 500.9 s on 16 CPU cores) has against the reference's converged kitchen-reference.exr.
-        ref_img, ref_dt = timed_render(make(args.rmse_reference_spp // spp, seed=987654321))
-        trials, hit = [], None
-        for n in (15, 31, 63, 127, 255, 511, 1023, 2047):
-            img, t = timed_render(make(n))
-            r = rmse(img, ref_img)
-            trials.append({"passes": n, "spp": n * spp, "seconds": t, "rmse": r})
-            if r <= REF_KITCHEN_RMSE:
-                hit = trials[-1]
+    if rank == 0 and args.gpus == 1 and not args.no_rmse and scene_name == "kitchen" and os.path.exists(KITCHEN_REFERENCE):
+        # Time to equal error.  The yardstick is the reference's own converged picture, scenes/kitchen/kitchen-reference.exr (committed as
+        # a fixture: pixels are data), so the scene is rendered at the reference's film size, 700x400.  Target: the error of the
+        # reference's own guided render kitchen-improved.exr (2400 spp, 500.9 s on 16 CPU cores) against that picture, over the pixels
+        # outside the footprint of the six meshes missing from the reference checkout (tools/make_kitchen_mask.py; 21 % masked).
+        import copy
+        fx = np.load(KITCHEN_REFERENCE)
+        ref = fx["rgb"].astype(np.float64)
+        blk = int(fx["mask_block"])
+        keep = ~np.kron(fx["mask_blocks"], np.ones((blk, blk), np.uint8)).astype(bool)
+        target_mape, target_rmse = float(fx["kitchen_improved_mape_unmasked"]), float(fx["kitchen_improved_rmse_unmasked"])
+        small = copy.copy(scene)
+        small.camera = ppg_host.resize_camera(scene.camera, ref.shape[1], ref.shape[0])
+        make(3, the_scene=small).render()
+        trials = []
+
+        def trial(n):
+            img, t = timed_render(make(n, the_scene=small, seed=4321))
+            d = (np.asarray(img, np.float64) - ref)[keep]
+            trials.append({"spp": n * spp, "seconds": t, "mape": float((np.abs(d) / (ref[keep] + 0.01)).mean()), "rmse": float(np.sqrt((d * d).mean()))})
+            return trials[-1]
+
+        a, b = trial(255), trial(1023)
+        # error ~ spp^-slope between the two; aim 4 % under the target, confirm by rendering that budget (and once more if it misses)
+        slope = max(0.2, math.log(a["mape"] / b["mape"]) / math.log(b["spp"] / a["spp"]))
+        n = b["spp"]
+        for _ in range(2):
+            if trials[-1]["mape"] <= target_mape:
                 break
-        out["time_to_rmse"] = {"target_rmse": REF_KITCHEN_RMSE, "target_source": "BASELINE.md: RMSE(kitchen-improved.exr, kitchen-reference.exr), the reference's 2400-spp render, 500.9 s on 16 CPU cores",
-                               "reference_image": "this build, %d spp, another seed (%.2f s)" % (args.rmse_reference_spp, ref_dt),
-                               "seconds": hit["seconds"] if hit else None, "spp": hit["spp"] if hit else None, "rmse": hit["rmse"] if hit else None,
-                               "speedup_vs_reference_log": (REF_KITCHEN_SECONDS / hit["seconds"]) if hit else None, "trials": trials,
-                               "note": "RMSE per pixel over RGB of the full-size image; the reference's figure is for its 700x400 render of the complete scene"}
+            n = int(min(4800, max(n + 1, n * (trials[-1]["mape"] / (0.96 * target_mape)) ** (1.0 / slope))))
+            trial(-(-n // spp))
+        hit_mape = min((t for t in trials if t["mape"] <= target_mape), key=lambda t: t["seconds"], default=None)
+        hit_rmse = min((t for t in trials if t["rmse"] <= target_rmse), key=lambda t: t["seconds"], default=None)
+        out["time_to_rmse"] = {
+            "reference_image": "scenes/kitchen/kitchen-reference.exr of the reference (tests/golden/ref_kitchen_reference.npz), 700x400; %.0f %% of the film "
+                               "masked: footprint of the 6 meshes missing from the reference checkout" % (100 * (1 - keep.mean())),
+            "target_source": "error of the reference's own kitchen-improved.exr (2400 spp, 500.9 s on 16 CPU cores, its embedded log) against the same picture, same pixels",
+            "target_mape": target_mape, "target_rmse": target_rmse,
+            "seconds_to_mape": hit_mape["seconds"] if hit_mape else None, "spp_to_mape": hit_mape["spp"] if hit_mape else None,
+            "seconds_to_rmse": hit_rmse["seconds"] if hit_rmse else None, "spp_to_rmse": hit_rmse["spp"] if hit_rmse else None,
+            "speedup_vs_reference_log_mape": (REF_KITCHEN_SECONDS / hit_mape["seconds"]) if hit_mape else None,
+            "speedup_vs_reference_log_rmse": (REF_KITCHEN_SECONDS / hit_rmse["seconds"]) if hit_rmse else None,
+            "trials": trials,
+            "note": "MAPE = mean |x - ref| / (ref + 0.01) is the meaningful figure: the reference render's RMSE is a handful of fireflies (max pixel 119), "
+                    "which this build's render of equal spp does not have, so the RMSE target is met at a tenth of the samples.  Seconds = render() "
+                    "of the 700x400 film, scene upload and BVH build excluded like the reference's kd-tree build"}
 
     if rank == 0 and args.gpus == 1 and not args.no_secondary and scene_name != "cbox":
         cb = ppg_host.cbox_scene(1280, 720)
@@ -331,7 +365,6 @@ def main():
     ap.add_argument("--room-boxes", type=int, default=1820, help="boxes of the room scene (768 triangles each)")
     ap.add_argument("--glossy", action="store_true", help="room scene with the S3 material mix (GGX alpha 0.1 metal, plastic) instead of Lambertian only")
     ap.add_argument("--cpu-passes", type=int, default=15, help="passes timed on the CPU baseline (bounded sample)")
-    ap.add_argument("--rmse-reference-spp", type=int, default=4095, help="spp of the converged render the time-to-RMSE block compares against")
     ap.add_argument("--secondary-passes", type=int, default=63)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")

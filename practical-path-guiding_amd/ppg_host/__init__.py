@@ -8,6 +8,6 @@
 `distributed` tile-sharded multi-GPU driver (one process per GPU, RCCL all-reduce of SD-tree statistics)
 """
 from .bindings import Engine, PPGError, Config, PassStats, TreeStats, hip_library_path  # noqa: F401
-from .scenes import SceneDesc, cbox_scene, perspective_camera, perspective_camera_from_matrix, room_scene, torus_scene, save_scene, load_scene_file  # noqa: F401
+from .scenes import SceneDesc, cbox_scene, perspective_camera, perspective_camera_from_matrix, resize_camera, room_scene, torus_scene, save_scene, load_scene_file  # noqa: F401
 from .mitsuba_xml import load_scene, load_obj, save_scene_xml, SceneError  # noqa: F401
 from .integrator import GuidedPathTracer  # noqa: F401,E402

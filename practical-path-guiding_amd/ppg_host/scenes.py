@@ -221,6 +221,15 @@ def perspective_camera_from_matrix(camera_to_world, fov_deg, fov_axis, near, far
                 width=int(width), height=int(height), fov=float(fov_deg), fov_axis=str(fov_axis))
 
 
+def resize_camera(camera, width, height):
+    """The same perspective camera with another film size, keeping its HORIZONTAL field of view (fovAxis = x, Mitsuba's default and
+    what the reference's bundled scenes use): the x-fov is read back from the projection (sample_to_camera^-1 [0][0] = -cot / 2)."""
+    cam_to_sample = np.linalg.inv(np.asarray(camera["sample_to_camera"], np.float64).reshape(4, 4))
+    xfov = math.degrees(2.0 * math.atan(1.0 / (-2.0 * cam_to_sample[0, 0])))
+    return dict(camera, sample_to_camera=_sample_to_camera(xfov, "x", camera["near_clip"], camera["far_clip"], width, height),
+                width=int(width), height=int(height))
+
+
 def perspective_camera(origin, target, up, fov_deg, fov_axis, near, far, width, height):
     """Transform::lookAt (transform.cpp:191-214) + the projection above."""
     p, t, u = (np.asarray(v, np.float64) for v in (origin, target, up))

@@ -192,6 +192,89 @@ def test_large_scene_bvh_against_oracle(oracle_lib):
     assert_tree_equal(g.read_sdtree(), o.read_sdtree())
 
 
+def test_room_stand_in_improved_unbounded_against_oracle(oracle_lib):
+    """BASELINE configs[2] class (KITCHEN scene-improved: inverse-variance film, stochastic/box filters, KL-learned sampling fraction,
+    unbounded depth) on the full-geometry room stand-in — 384k triangles, one rough-metal and two plastic materials, all light
+    indirect — at a film size the oracle covers."""
+    import ppg_host
+    scene = ppg_host.room_scene(128, 72, glossy=True)
+    assert scene.n_triangles == 384024
+    props = dict(budgetType="spp", budget=31, maxDepth=-1, rrDepth=5, strictNormals=1, seed=17, **IMPROVED)
+    g, o = hip(**props), make_oracle(oracle_lib, threads=os.cpu_count() or 8, **props)
+    gg, go = ppg_host.GuidedPathTracer(engine=g), ppg_host.GuidedPathTracer(engine=o)
+    ig, io = gg.render(scene), go.render(scene)
+    assert _stats(gg) == _stats(go) and [i["passes"] for i in gg.iterations] == [1, 2, 4, 8, 16]
+    assert np.array_equal(ig, io, equal_nan=True) and np.isfinite(ig).all() and ig.mean() > 1e-3
+    assert_tree_equal(g.read_sdtree(), o.read_sdtree())
+
+
+def spaceship_class_scene(width, height, n_boxes=1400):
+    """BASELINE configs[3] class stand-in (the reference's SPACESHIP: 257k triangles, one sphere — the emitting sky dome with flipped
+    normals —, rough conductor / plastic / glass / diffuse): the room's boxes (268,824 triangles with n_boxes = 1400) with a third of
+    them glass, the ceiling and its lamp removed, under a dome."""
+    import ppg_host
+    scene = ppg_host.room_scene(width, height, n_boxes=n_boxes, glossy=True)
+    scene.materials = list(scene.materials)
+    scene.materials[7] = dict(type="dielectric", eta=1.5, reflectance=(1, 1, 1), specular=(1, 1, 1))            # "b2"
+    scene.materials.append(dict(type="diffuse", reflectance=(0.5, 0.5, 0.5)))
+    keep = np.ones(len(scene.indices), bool); keep[10:24] = False                                           # ceiling, lamp, lamp housing
+    scene.indices, scene.tri_material, scene.tri_emitter = scene.indices[keep], scene.tri_material[keep], scene.tri_emitter[keep]
+    scene.emitters = [dict(radiance=(1.2, 1.3, 1.5))]
+    scene.spheres = [dict(center=(2.0, 1.5, 2.5), radius=60.0, material=len(scene.materials) - 1, emitter=0, flip_normals=True)]
+    return scene
+
+
+def test_spaceship_class_improved_against_oracle(oracle_lib):
+    """>= 250k triangles + 1 sphere with the SPACESHIP material mix, improved preset with the scene's own depth settings
+    (spaceship-improved.xml: maxDepth 10, rrDepth 10)."""
+    import ppg_host
+    scene = spaceship_class_scene(160, 90)
+    assert scene.n_triangles == 268810 and len(scene.spheres) == 1
+    props = dict(budgetType="spp", budget=31, maxDepth=10, rrDepth=10, strictNormals=1, seed=23, **IMPROVED)
+    g, o = hip(**props), make_oracle(oracle_lib, threads=os.cpu_count() or 8, **props)
+    gg, go = ppg_host.GuidedPathTracer(engine=g), ppg_host.GuidedPathTracer(engine=o)
+    ig, io = gg.render(scene), go.render(scene)
+    assert _stats(gg) == _stats(go)
+    assert np.array_equal(ig, io, equal_nan=True) and np.isfinite(ig).all() and ig.mean() > 1e-2
+    assert_tree_equal(g.read_sdtree(), o.read_sdtree())
+
+
+@pytest.mark.parametrize("which", ["room-720p", "spaceship-class-1080p"])
+def test_full_size_invariants_improved_configs(which):
+    """Properties that need no oracle, at the real film sizes of BASELINE configs[2] / configs[3] with the improved preset: run-to-run
+    determinism of film and SD-tree (atomics are fixed point, the optimiser's records are applied in key order), sample / ray
+    bookkeeping, a finite film, every guiding pdf integrating to one."""
+    import ppg_host
+    if which == "room-720p":
+        scene, spp = ppg_host.room_scene(1280, 720, glossy=True), 1280 * 720
+        props = dict(budgetType="spp", budget=15, maxDepth=-1, rrDepth=5, strictNormals=1, seed=5, **IMPROVED)
+    else:
+        scene, spp = spaceship_class_scene(1920, 1080), 1920 * 1080
+        props = dict(budgetType="spp", budget=15, maxDepth=10, rrDepth=10, strictNormals=1, seed=5, **IMPROVED)
+    runs = []
+    for _ in range(2):
+        e = hip(**props)
+        gpt = ppg_host.GuidedPathTracer(engine=e)
+        img = gpt.render(scene)
+        assert [i["passes"] for i in gpt.iterations] == [1, 2, 4, 8]
+        for i in gpt.iterations:
+            st = i["stats"][0]
+            assert st["samples"] == spp * i["passes"] and st["rays"] == st["path_length_sum"]
+            assert (st["vertices_committed"] > 0) == (i is not gpt.iterations[-1])      # the last iteration only renders (GP:1524, isFinalIter)
+        assert np.isfinite(img).all() and img.mean() > 1e-3
+        runs.append((img, e.read_sdtree(), e))
+    assert np.array_equal(runs[0][0], runs[1][0])
+    assert_tree_equal(runs[0][1], runs[1][1])
+    e = runs[0][2]
+    rng = np.random.RandomState(1)
+    u = rng.rand(100000, 2)
+    z = 2 * u[:, 0] - 1; phi = 2 * np.pi * u[:, 1]; r = np.sqrt(1 - z * z)
+    dirs = np.stack([r * np.cos(phi), r * np.sin(phi), z], -1).astype(np.float32)
+    for p in np.array([[2.0, 0.02, 2.5], [0.02, 1.5, 3.0], [2.0, 1.5, 0.5]], np.float32):
+        pdf = e.query_pdf(np.repeat(p[None], len(dirs), 0), dirs)
+        assert abs(pdf.mean() * 4 * np.pi - 1) < 0.03
+
+
 def test_edge_cases(oracle_lib):
     import ppg_host
     # 1x1 film; 1 spp and a single pass (N - 1 = 0 → non-finite variance like the reference's "-1.#INF"); maxDepth = 1

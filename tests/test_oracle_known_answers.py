@@ -99,8 +99,27 @@ def test_dtree_box_filter_conserves_interior_energy(oracle_lib):
     q = rng.rand(10, 2)
     near, box = _exercise(oracle_lib, 0, 0, xy, irr, w, q), _exercise(oracle_lib, 0, 1, xy, irr, w, q)
     assert abs(box["total"] - near["total"]) < 2e-3 * near["total"]
-    edge = _exercise(oracle_lib, 0, 1, np.full((100, 2), 0.001), np.ones(100), np.ones(100), q)
-    assert 20 < edge["total"] < 75  # energy outside [0,1]^2 is lost, as in the reference
+    # Near the border the part of the footprint outside [0,1]^2 is dropped (GP:403-409: a square of side 0.5^depthAt(p) centred on p,
+    # density irradiance / side^2, recorded into the tree from its origin p - side / 2).  The exact loss follows from the depth of the
+    # leaf quadrant that holds p, read off the returned topology: kept = (clipped side / side)^2 per axis.
+    def depth_at(children, x, y):
+        node, d = 0, 0
+        while True:
+            d += 1
+            i = (1 if x >= 0.5 else 0) | (2 if y >= 0.5 else 0)
+            x, y = (x * 2 if x < 0.5 else (x - 0.5) * 2), (y * 2 if y < 0.5 else (y - 0.5) * 2)
+            if children[node, i] == 0:
+                return d
+            node = children[node, i]
+    for px, py in ((0.001, 0.001), (0.0005, 0.4), (0.9995, 0.9999), (0.01, 0.01)):
+        for acc in (0, 1):
+            edge = _exercise(oracle_lib, acc, 1, np.tile(np.float32([px, py]), (100, 1)), np.ones(100), np.ones(100), q)
+            side = 0.5 ** depth_at(edge["children"], np.float32(px), np.float32(py))
+            kept = 1.0
+            for c in (np.float32(px), np.float32(py)):
+                kept *= (min(float(c) + side / 2, 1.0) - max(float(c) - side / 2, 0.0)) / side
+            assert edge["statw"] == 100 and abs(edge["total"] - 100 * kept) < 2e-4 * 100, (px, py, acc, side, edge["total"], 100 * kept)
+    assert abs(_exercise(oracle_lib, 0, 1, np.full((100, 2), 0.001), np.ones(100), np.ones(100), q)["total"] - 57.1536) < 1e-3   # side 1/256
 
 
 def _floor_and_lamp(res, lamp_half=0.05, lamp_h=1.0):

@@ -6,6 +6,9 @@ Writes tests/golden/ref_logs.json       parsed per-iteration log lines embedded 
                                         (written by mitsuba/src/films/hdrfilm.cpp:527-534; the lines
                                         themselves are printed by guided_path.cpp:1176-1186, 1325, 1376)
        tests/golden/ref_cbox_images.npz 64x64 block-averaged RGB of cbox.exr / cbox-improved.exr + mean RGB
+       tests/golden/ref_kitchen_reference.npz  the pixels of kitchen-reference.exr (the reference's converged 700x400 KITCHEN render,
+                                        half precision) + RMSE / MAPE of the reference's own kitchen.exr and kitchen-improved.exr
+                                        against it: the "equal error" target of bench.py's time_to_rmse block
 
 These are the only outputs of the reference integrator that exist for this path (SURVEY.md §4, §6,
 §8(c)); the oracle is pinned against them statistically (tests/test_oracle_reference_pins.py).
@@ -95,6 +98,29 @@ def main():
         imgs[key + "_mean_rgb"] = rgb.mean((0, 1)).astype(np.float32)
     np.savez_compressed(os.path.join(OUT, "ref_cbox_images.npz"), **imgs)
     print({k: (v.shape, v.mean()) for k, v in imgs.items()})
+    rgb = {}
+    for n in ("kitchen-reference", "kitchen", "kitchen-improved"):
+        _, ch = read_exr(os.path.join(REF, "kitchen", n + ".exr"))
+        rgb[n] = np.stack([ch["R"], ch["G"], ch["B"]], -1).astype(np.float64)
+    ref = rgb["kitchen-reference"]
+    err = {}
+    for n in ("kitchen", "kitchen-improved"):
+        d = rgb[n] - ref
+        err[n.replace("-", "_") + "_rmse"] = np.float64(np.sqrt((d * d).mean()))
+        err[n.replace("-", "_") + "_mape"] = np.float64((np.abs(d) / (ref + 0.01)).mean())
+    # the same errors over the pixels where this build's picture can be compared at all: six of the scene's 289 meshes are missing from
+    # the reference checkout; tools/make_kitchen_mask.py located their footprint (20x20-pixel blocks)
+    mpath = os.path.join(OUT, "kitchen_missing_mesh_mask.npz")
+    if os.path.exists(mpath):
+        mk = np.load(mpath)
+        keep = ~np.kron(mk["mask_blocks"], np.ones((int(mk["block"]), int(mk["block"]), ), np.uint8)).astype(bool)
+        err["mask_blocks"], err["mask_block"] = mk["mask_blocks"], mk["block"]
+        for n in ("kitchen", "kitchen-improved"):
+            d = (rgb[n] - ref)[keep]
+            err[n.replace("-", "_") + "_rmse_unmasked"] = np.float64(np.sqrt((d * d).mean()))
+            err[n.replace("-", "_") + "_mape_unmasked"] = np.float64((np.abs(d) / (ref[keep] + 0.01)).mean())
+    np.savez_compressed(os.path.join(OUT, "ref_kitchen_reference.npz"), rgb=ref.astype(np.float16), mean_rgb=ref.mean((0, 1)), **err)
+    print("kitchen-reference", ref.shape, ref.mean((0, 1)), float(ref.max()), {k: v for k, v in err.items() if np.ndim(v) == 0})
     for k, v in logs.items():
         print(k, [(i["iter"], i["passes"]) for i in v["iterations"]], v.get("avg_path_length"))
 
