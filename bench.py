@@ -329,7 +329,7 @@ def run(args):
             "speedup_vs_reference_log_rmse": (REF_KITCHEN_SECONDS / hit_rmse["seconds"]) if hit_rmse else None,
             "trials": trials,
             "note": "MAPE = mean |x - ref| / (ref + 0.01) is the meaningful figure: the reference render's RMSE is a handful of fireflies (max pixel 119), "
-                    "which this build's render of equal spp does not have, so the RMSE target is met at a tenth of the samples.  Seconds = render() "
+                    "which this build's renders of equal spp do not show to that extent (seed dependent), so the RMSE target is met at well under half the samples.  Seconds = render() "
                     "of the 700x400 film, scene upload and BVH build excluded like the reference's kd-tree build"}
 
     if rank == 0 and args.gpus == 1 and not args.no_secondary and scene_name != "cbox":

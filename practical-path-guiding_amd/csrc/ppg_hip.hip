@@ -309,6 +309,9 @@ struct ppg_ctx {
     int device = 0;
     std::string dumpPrefix, error;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;    // k_commit of the finished paths runs here while k_tail finishes the stragglers on `stream`
+    hipEvent_t evFork = nullptr, evJoin = nullptr;
+    DevBuf<unsigned char> d_straggler;  // [path] 1 = still alive when the persistent-thread tail took over
 
     // scene
     bool haveScene = false;
@@ -339,6 +342,9 @@ struct ppg_ctx {
     // path state
     DevBuf<float4> d_ray_o, d_ray_d, d_thr, d_li, d_hit, d_vd, d_vthr, d_vbsdf, d_vrad, d_vo, d_vvox;
     DevBuf<uint4> d_misc;
+    DevBuf<float4> d_pathRec, d_vertexRec;  // interleaved layout (PathState Field, ppg_kernels.h): 8 float4 per path, 4 / 6 per vertex slot
+    DevBuf<uint4> d_miscCompact;
+    bool aosPaths = false;
     DevBuf<unsigned int> d_queue[2], d_qcount[2], d_qtotal, d_queueSorted;
     DevBuf<unsigned char> d_sortKeys;
     int maxBatchFinal = 1;  // passes per batch in the final iteration (nothing is recorded: no vertex slots needed)
@@ -388,6 +394,9 @@ struct ppg_ctx {
     bool tuneForceBvh = false;        // PPG_FORCE_BVH: trace small scenes through the BVH as well
     bool tuneFuse = false;            // PPG_FUSE: trace small scenes inside k_generate / k_shade
     bool tuneNoSort = false;          // PPG_NO_SORT: do not sort the queue slices by BSDF type before k_shade<FULL>
+    bool tuneNoOverlap = false;       // PPG_NO_OVERLAP: k_commit after k_tail on one stream instead of beside it
+    int tuneTailBlocks = 0;           // PPG_TAIL_BLOCKS: workgroups of k_tail when k_commit runs beside it (0 = automatic)
+    int tunePathLayout = 0;           // PPG_PATH_LAYOUT = aos: per-path state interleaved in 128-byte records instead of one array per field
     int tuneBvhLeaf = 4;              // PPG_BVH_LEAF: triangles per BVH leaf (1..8)
     float tuneBvhPad = 2e-6f;         // PPG_BVH_PAD: box padding relative to the scene extent
     DevBuf<unsigned int> d_leaves, d_counts, d_offsets, d_grid;
@@ -665,8 +674,15 @@ int allocPaths(ppg_ctx *ctx) {
     size_t nn = std::max<size_t>(1, std::max(n, nFinal));
     ctx->maxVertices = PPG_MAX_VERTICES;
     if (ctx->maxDepth > 0) ctx->maxVertices = std::max(1, std::min(PPG_MAX_VERTICES, ctx->maxDepth - 1));
-    HIP_CHECK(ctx->d_ray_o.reserve(nn)); HIP_CHECK(ctx->d_ray_d.reserve(nn)); HIP_CHECK(ctx->d_thr.reserve(nn));
-    HIP_CHECK(ctx->d_li.reserve(nn)); HIP_CHECK(ctx->d_hit.reserve(nn)); HIP_CHECK(ctx->d_misc.reserve(nn));
+    // layout of the per-path state: one array per field, or (PPG_PATH_LAYOUT=aos) interleaved 128-byte records.  Measured on MI355X:
+    // interleaving helps the late, scattered bounces (KITCHEN k_shade<FULL> 380 -> 340 ms per 127 passes) and hurts the early, coalesced
+    // ones (k_trace 387 -> 404 ms, k_sort_slices, k_generate): KITCHEN +1 %, SPACESHIP 1080p -10 %, cbox-720p -19 %.  Off by default.
+    ctx->aosPaths = ctx->tunePathLayout == 2;
+    if (ctx->aosPaths) { HIP_CHECK(ctx->d_pathRec.reserve(nn * 8)); HIP_CHECK(ctx->d_miscCompact.reserve(nn)); }
+    else {
+        HIP_CHECK(ctx->d_ray_o.reserve(nn)); HIP_CHECK(ctx->d_ray_d.reserve(nn)); HIP_CHECK(ctx->d_thr.reserve(nn));
+        HIP_CHECK(ctx->d_li.reserve(nn)); HIP_CHECK(ctx->d_hit.reserve(nn)); HIP_CHECK(ctx->d_misc.reserve(nn));
+    }
     if (ctx->tuneBlocks) ctx->nBlocks = ctx->tuneBlocks;
     const size_t nb = (size_t)ctx->nBlocks;
     const size_t chunks = (nn + PPG_CHUNK - 1) / PPG_CHUNK;
@@ -681,14 +697,24 @@ int allocPaths(ppg_ctx *ctx) {
     ctx->queues.cap = (unsigned int)cap; ctx->queues.stats = ctx->d_stats.p; ctx->queues.n_blocks = (unsigned int)nb;
     if (ctx->fullMaterials && !ctx->tuneNoSort) { HIP_CHECK(ctx->d_queueSorted.reserve(cap * nb)); HIP_CHECK(ctx->d_sortKeys.reserve(cap * nb)); }
     size_t nv = nTrain * (size_t)ctx->maxVertices;
-    HIP_CHECK(ctx->d_vd.reserve(nv)); HIP_CHECK(ctx->d_vthr.reserve(nv)); HIP_CHECK(ctx->d_vbsdf.reserve(nv)); HIP_CHECK(ctx->d_vrad.reserve(nv));
-    if (ctx->spatialFilter != SF_NEAREST) { HIP_CHECK(ctx->d_vo.reserve(nv)); HIP_CHECK(ctx->d_vvox.reserve(nv)); }
+    const bool filtered = ctx->spatialFilter != SF_NEAREST;
     PathState &P = ctx->paths;
     P.n_paths = (unsigned int)n; P.n_pix = ctx->nPix; P.pixels = ctx->d_pixels.p;
-    P.ray_o = ctx->d_ray_o.p; P.ray_d = ctx->d_ray_d.p; P.thr = ctx->d_thr.p; P.li = ctx->d_li.p; P.hit = ctx->d_hit.p; P.misc = ctx->d_misc.p;
-    P.v_d = ctx->d_vd.p; P.v_thr = ctx->d_vthr.p; P.v_bsdf = ctx->d_vbsdf.p; P.v_rad = ctx->d_vrad.p;
-    P.v_o = ctx->spatialFilter != SF_NEAREST ? ctx->d_vo.p : nullptr;
-    P.v_vox = ctx->spatialFilter != SF_NEAREST ? ctx->d_vvox.p : nullptr;
+    if (ctx->aosPaths) {
+        const unsigned int vs = filtered ? 6u : 4u;
+        HIP_CHECK(ctx->d_vertexRec.reserve(nv * vs));
+        float4 *r = ctx->d_pathRec.p, *v = ctx->d_vertexRec.p;
+        P.ray_o = {r, 8}; P.ray_d = {r + 1, 8}; P.thr = {r + 2, 8}; P.li = {r + 3, 8}; P.hit = {r + 4, 8}; P.misc = {reinterpret_cast<uint4 *>(r + 5), 8};
+        P.v_d = {v, vs}; P.v_thr = {v + 1, vs}; P.v_bsdf = {v + 2, vs}; P.v_rad = {v + 3, vs};
+        P.v_o = {filtered ? v + 4 : nullptr, vs}; P.v_vox = {filtered ? v + 5 : nullptr, vs};
+    } else {
+        HIP_CHECK(ctx->d_vd.reserve(nv)); HIP_CHECK(ctx->d_vthr.reserve(nv)); HIP_CHECK(ctx->d_vbsdf.reserve(nv)); HIP_CHECK(ctx->d_vrad.reserve(nv));
+        if (filtered) { HIP_CHECK(ctx->d_vo.reserve(nv)); HIP_CHECK(ctx->d_vvox.reserve(nv)); }
+        P.ray_o = {ctx->d_ray_o.p, 1}; P.ray_d = {ctx->d_ray_d.p, 1}; P.thr = {ctx->d_thr.p, 1}; P.li = {ctx->d_li.p, 1}; P.hit = {ctx->d_hit.p, 1};
+        P.misc = {ctx->d_misc.p, 1};
+        P.v_d = {ctx->d_vd.p, 1}; P.v_thr = {ctx->d_vthr.p, 1}; P.v_bsdf = {ctx->d_vbsdf.p, 1}; P.v_rad = {ctx->d_vrad.p, 1};
+        P.v_o = {filtered ? ctx->d_vo.p : nullptr, 1}; P.v_vox = {filtered ? ctx->d_vvox.p : nullptr, 1};
+    }
     P.nee_cos = nullptr;
     if (ctx->scene.env.w != 0 && ctx->nee != NEE_NEVER) { HIP_CHECK(ctx->d_neeCos.reserve(nn)); P.nee_cos = ctx->d_neeCos.p; }
     return PPG_OK;
@@ -794,6 +820,9 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound) {
     const size_t triBytes = (size_t)ctx->scene.n_tris * 48;
     const bool unbounded = ctx->maxDepth < 0;
     int bouncesRun = 0;
+    int qin = -1;
+    unsigned int hostCount = P.n_paths;
+    const size_t ldsBytes = smallScene ? (size_t)ctx->ldsTris * 48 : (size_t)PPG_LDS_STACK * PPG_BLOCK * 4;
     if (P.n_paths > 0) {
     timedLaunch(ctx, "k_generate", P.n_paths, [&] {
         if (fused) hipLaunchKernelGGL(k_generate<true>, dim3(gridAll), dim3(PPG_BLOCK), triBytes, s, P, S, R, Q);
@@ -803,10 +832,7 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound) {
     // schedule of maxDepth bounces.  Unbounded paths run `bulkBounces` wavefront bounces over the whole GPU — as many as the previous
     // batch needed to thin the queues out — and hand the survivors to the persistent-thread tail (k_tail); nothing is read back in
     // between, the host synchronises once per batch.
-    int qin = -1;
     const int maxBounces = unbounded ? (fused ? 1 << 20 : std::max(1, std::min(64, ctx->bulkBounces))) : ctx->maxDepth;
-    unsigned int hostCount = P.n_paths;
-    const size_t ldsBytes = smallScene ? (size_t)ctx->ldsTris * 48 : (size_t)PPG_LDS_STACK * PPG_BLOCK * 4;
     const bool liveCount = ctx->timer.enabled || (unbounded && fused);  // kernel timing wants the units of every launch
     if (unbounded) HIP_CHECK(hipMemsetAsync(ctx->d_bounceCounts.p, 0, 64 * 4, s));
     for (int b = 0; b < maxBounces; ++b) {
@@ -853,14 +879,25 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound) {
             if (hostCount == 0) break;
         }
     }
-    // the last shade of a bounded schedule terminates every path (depth >= maxDepth), no trailing trace needed
-    if (unbounded && !fused) {
-        // the survivors of all workgroups in one dense list, then persistent threads until the last path has ended
-        hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, s, Q.count[qin], ctx->d_offsets.p, (unsigned int)grid, ctx->d_total.p);
-        hipLaunchKernelGGL(k_gather_slices, dim3(grid), dim3(PPG_BLOCK), 0, s, Q.items[qin], Q.count[qin], ctx->d_offsets.p, Q.cap, Q.items[qin ^ 1]);
+    }
+    // What follows the wavefront bounces of a batch:
+    //   unbounded paths   the survivors of all workgroups go into one dense list and persistent threads finish them (k_tail) — a phase
+    //                     bounded by the latency of the longest path (hundreds of dependent bounces), during which most CUs idle;
+    //   training batches  k_commit splats every recorded vertex into the building tree.
+    // With both, k_commit for the paths that HAVE ended runs on a second stream beside k_tail, and a second, small k_commit takes the
+    // stragglers afterwards.  Integer accumulation makes the split invisible in the result.  In a round of the optimiser, the record
+    // positions must then be known before the tail has run: a straggler reserves max_vertices positions (unused ones stay holes).
+    const bool tail = unbounded && !fused && P.n_paths > 0;
+    const bool commit = !ctx->isFinalIter && P.n_paths > 0;
+    const bool overlap = tail && commit && !ctx->timer.enabled && !ctx->tuneNoOverlap;
+    const bool fastRound = adamRound && ctx->adamFast && P.n_paths > 0;
+    size_t nRecords = 0;
+    // beside k_commit the tail leaves room on every CU: its persistent workgroups hold their registers until their last path has ended
+    const int tailGrid = overlap ? std::min(grid, ctx->tuneTailBlocks ? ctx->tuneTailBlocks : grid) : grid;
+    auto launchTail = [&] {
         HIP_CHECK(hipMemsetAsync(ctx->d_ticket.p, 0, 4, s));
         timedLaunch(ctx, "k_tail", hostCount, [&] {
-#define PPG_TAIL(SM, N, M) hipLaunchKernelGGL((k_tail<SM, N, M>), dim3(grid), dim3(PPG_BLOCK), ldsBytes, s, P, S, T, R, Q.items[qin ^ 1], ctx->d_total.p, ctx->d_ticket.p, Q.stats, ctx->ldsTris)
+#define PPG_TAIL(SM, N, M) hipLaunchKernelGGL((k_tail<SM, N, M>), dim3(tailGrid), dim3(PPG_BLOCK), ldsBytes, s, P, S, T, R, Q.items[qin ^ 1], ctx->d_total.p, ctx->d_ticket.p, Q.stats, ctx->ldsTris)
             switch ((smallScene ? 4 : 0) | (neeOn ? 2 : 0) | (fullMats ? 1 : 0)) {
                 case 0: PPG_TAIL(false, false, false); break;
                 case 1: PPG_TAIL(false, false, true); break;
@@ -873,13 +910,50 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound) {
             }
 #undef PPG_TAIL
         });
+        return PPG_OK;
+    };
+    // interleaved path records: k_commit and k_path_nv sweep the per-path word once per (slot, path) item — from a contiguous copy
+    PathState Pc = P;
+    bool miscCopied = false;
+    auto copyMisc = [&] {
+        if (!ctx->aosPaths || miscCopied || P.n_paths == 0) return;
+        hipLaunchKernelGGL(k_copy_misc, dim3((P.n_paths + 255) / 256), dim3(256), 0, s, P, ctx->d_miscCompact.p);
+        Pc.misc = {ctx->d_miscCompact.p, 1};
+        miscCopied = true;
+    };
+    // mode 0: every path; 1: paths not flagged as stragglers; 2: the paths of the dense list
+    auto launchCommit = [&](hipStream_t st, int mode) {
+        const unsigned char *skip = mode == 1 ? ctx->d_straggler.p : nullptr;
+        const unsigned int *list = mode == 2 ? Q.items[qin ^ 1] : nullptr;
+        const unsigned long long *listN = mode == 2 ? ctx->d_total.p : nullptr;
+        const PathState &PP = mode == 2 ? P : Pc;  // the stragglers' words changed in the tail: read them in place
+#define PPG_COMMIT(SFV, DFV) hipLaunchKernelGGL((k_commit<SFV, DFV>), dim3(grid), dim3(PPG_BLOCK), 0, st, PP, T, R, Q, skip, list, listN)
+        const int sf = ctx->spatialFilter, df = ctx->directionalFilter;
+        if (sf == SF_NEAREST && df == DF_NEAREST) PPG_COMMIT(SF_NEAREST, DF_NEAREST);
+        else if (sf == SF_NEAREST) PPG_COMMIT(SF_NEAREST, DF_BOX);
+        else if (sf == SF_STOCHASTIC && df == DF_NEAREST) PPG_COMMIT(SF_STOCHASTIC, DF_NEAREST);
+        else if (sf == SF_STOCHASTIC) PPG_COMMIT(SF_STOCHASTIC, DF_BOX);
+        else if (df == DF_NEAREST) PPG_COMMIT(SF_BOX, DF_NEAREST);
+        else PPG_COMMIT(SF_BOX, DF_BOX);
+#undef PPG_COMMIT
+    };
+    if (tail) {
+        hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, s, Q.count[qin], ctx->d_offsets.p, (unsigned int)grid, ctx->d_total.p);
+        hipLaunchKernelGGL(k_gather_slices, dim3(grid), dim3(PPG_BLOCK), 0, s, Q.items[qin], Q.count[qin], ctx->d_offsets.p, Q.cap, Q.items[qin ^ 1]);
+        if (overlap) {
+            HIP_CHECK(ctx->d_straggler.reserve(P.n_paths));
+            HIP_CHECK(hipMemsetAsync(ctx->d_straggler.p, 0, P.n_paths, s));
+            hipLaunchKernelGGL(k_mark_list, dim3(grid), dim3(PPG_BLOCK), 0, s, Q.items[qin ^ 1], ctx->d_total.p, ctx->d_straggler.p);
+        } else {
+            int rc = launchTail();
+            if (rc) return rc;
+        }
     }
-    }
-    size_t nRecords = 0;
-    if (adamRound && ctx->adamFast && P.n_paths > 0) {
+    if (fastRound) {
         // position of path i's records = exclusive scan of the vertex counts
         HIP_CHECK(ctx->d_adamNv.reserve(P.n_paths)); HIP_CHECK(ctx->d_adamBase.reserve(P.n_paths));
-        hipLaunchKernelGGL(k_path_nv, dim3((P.n_paths + 255) / 256), dim3(256), 0, s, P, ctx->d_adamNv.p);
+        copyMisc();
+        hipLaunchKernelGGL(k_path_nv, dim3((P.n_paths + 255) / 256), dim3(256), 0, s, Pc, ctx->d_adamNv.p, overlap ? ctx->d_straggler.p : nullptr, (unsigned int)ctx->maxVertices);
         size_t bytes = 0;
         HIP_CHECK(rocprim::exclusive_scan(nullptr, bytes, ctx->d_adamNv.p, ctx->d_adamBase.p, 0u, (size_t)P.n_paths, rocprim::plus<unsigned int>(), s));
         HIP_CHECK(ctx->d_sortTemp.reserve(std::max<size_t>(bytes, 16)));
@@ -887,10 +961,10 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound) {
         HIP_CHECK(hipMemcpyAsync(ctx->h_round + 65, ctx->d_adamBase.p + (P.n_paths - 1), 4, hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipMemcpyAsync(ctx->h_round + 66, ctx->d_adamNv.p + (P.n_paths - 1), 4, hipMemcpyDeviceToHost, s));
     }
-    if (P.n_paths > 0 && ((unbounded && !fused) || (adamRound && ctx->adamFast))) {
+    if (tail || fastRound) {
         if (unbounded) HIP_CHECK(hipMemcpyAsync(ctx->h_round, ctx->d_bounceCounts.p, 64 * 4, hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));  // the one host round trip of a batch of unbounded paths / of a round
-        if (unbounded && !fused) {
+        if (tail) {
             // next batch: wavefront bounces until fewer paths are left than the persistent-thread tail handles just as well
             const unsigned int thr = ctx->tailThreshold ? ctx->tailThreshold : std::max(131072u, P.n_paths / 16u);
             int nb = bouncesRun;
@@ -898,7 +972,7 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound) {
             if (nb == bouncesRun && ctx->h_round[bouncesRun - 1] >= thr) nb = std::min(64, bouncesRun + 4);
             ctx->bulkBounces = std::max(1, nb);
         }
-        if (adamRound && ctx->adamFast) {
+        if (fastRound) {
             nRecords = (size_t)ctx->h_round[65] + ctx->h_round[66];
             if (nRecords > 0xfffffff0ull) { ctx->error = "too many Adam records in one round"; return PPG_ERR_NOMEM; }
             HIP_CHECK(ctx->d_adamKeys[0].reserve(std::max<size_t>(1, nRecords))); HIP_CHECK(ctx->d_adamRecs.reserve(std::max<size_t>(1, nRecords)));
@@ -906,18 +980,18 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound) {
             T = ctx->devTree();
         }
     }
-    if (!ctx->isFinalIter && P.n_paths > 0) {
-        timedLaunch(ctx, "k_commit", P.n_paths, [&] {
-#define PPG_COMMIT(SFV, DFV) hipLaunchKernelGGL((k_commit<SFV, DFV>), dim3(grid), dim3(PPG_BLOCK), 0, s, P, T, R, Q)
-            const int sf = ctx->spatialFilter, df = ctx->directionalFilter;
-            if (sf == SF_NEAREST && df == DF_NEAREST) PPG_COMMIT(SF_NEAREST, DF_NEAREST);
-            else if (sf == SF_NEAREST) PPG_COMMIT(SF_NEAREST, DF_BOX);
-            else if (sf == SF_STOCHASTIC && df == DF_NEAREST) PPG_COMMIT(SF_STOCHASTIC, DF_NEAREST);
-            else if (sf == SF_STOCHASTIC) PPG_COMMIT(SF_STOCHASTIC, DF_BOX);
-            else if (df == DF_NEAREST) PPG_COMMIT(SF_BOX, DF_NEAREST);
-            else PPG_COMMIT(SF_BOX, DF_BOX);
-#undef PPG_COMMIT
-        });
+    if (commit) copyMisc();
+    if (overlap) {
+        HIP_CHECK(hipEventRecord(ctx->evFork, s));
+        int rc = launchTail();
+        if (rc) return rc;
+        HIP_CHECK(hipStreamWaitEvent(ctx->stream2, ctx->evFork, 0));
+        launchCommit(ctx->stream2, 1);
+        HIP_CHECK(hipEventRecord(ctx->evJoin, ctx->stream2));
+        HIP_CHECK(hipStreamWaitEvent(s, ctx->evJoin, 0));
+        launchCommit(s, 2);
+    } else if (commit) {
+        timedLaunch(ctx, "k_commit", P.n_paths, [&] { launchCommit(s, 0); });
     }
     if (adamRound) {
         if (!ctx->adamFast) {
@@ -1307,6 +1381,9 @@ int ppg_create(const ppg_config *cfg, ppg_ctx **out) {
         c->tuneForceBvh = getenv("PPG_FORCE_BVH") != nullptr;
         c->tuneFuse = getenv("PPG_FUSE") != nullptr;
         c->tuneNoSort = getenv("PPG_NO_SORT") != nullptr;
+        c->tuneNoOverlap = getenv("PPG_NO_OVERLAP") != nullptr;
+        if (const char *e = getenv("PPG_TAIL_BLOCKS")) c->tuneTailBlocks = std::max(1, atoi(e));
+        if (const char *e = getenv("PPG_PATH_LAYOUT")) c->tunePathLayout = !strcmp(e, "aos") ? 2 : (!strcmp(e, "soa") ? 1 : 0);
         if (const char *e = getenv("PPG_BVH_LEAF")) c->tuneBvhLeaf = std::max(1, std::min(8, atoi(e)));
         if (const char *e = getenv("PPG_BVH_PAD")) c->tuneBvhPad = (float)atof(e);
     }
@@ -1315,7 +1392,8 @@ int ppg_create(const ppg_config *cfg, ppg_ctx **out) {
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) { g_createError = std::string("no HIP device available: ") + hipGetErrorString(e); return PPG_ERR_DEVICE; }
     if (c->device < 0 || c->device >= ndev) { g_createError = "device ordinal out of range"; return PPG_ERR_INVALID; }
-    if ((e = hipSetDevice(c->device)) != hipSuccess || (e = hipStreamCreate(&c->stream)) != hipSuccess) {
+    if ((e = hipSetDevice(c->device)) != hipSuccess || (e = hipStreamCreate(&c->stream)) != hipSuccess || (e = hipStreamCreate(&c->stream2)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming)) != hipSuccess) {
         g_createError = std::string("HIP init failed: ") + hipGetErrorString(e);
         return PPG_ERR_DEVICE;
     }
@@ -1327,6 +1405,9 @@ void ppg_destroy(ppg_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); }
+    if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
+    if (ctx->evFork) (void)hipEventDestroy(ctx->evFork);
+    if (ctx->evJoin) (void)hipEventDestroy(ctx->evJoin);
     ctx->timer.resolve();
     for (auto e : ctx->timer.pool) (void)hipEventDestroy(e);
     if (ctx->h_lum) (void)hipHostFree(ctx->h_lum);

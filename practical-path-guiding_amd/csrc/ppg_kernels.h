@@ -58,23 +58,36 @@ struct RenderParams {
     unsigned int img_pixels;  // width * height of the whole image (path ids of the Adam records)
 };
 
+// A field of the per-path (or per-vertex-slot) state: element i lives at base[i * stride].  stride 1 = one array per field (SoA, the
+// default: a wave of NEIGHBOURING paths reads full lines — the first bounces, where most of the rays are); PPG_PATH_LAYOUT=aos interleaves
+// the fields of one path in one 128-byte record (stride 8; 4 / 6 for vertex slots), which suits the late bounces — slices compacted and
+// sorted by BSDF type, lane k holds an arbitrary path, six 16-byte accesses cost six sectors in six lines (KITCHEN: k_shade moves
+// 970 + 642 B per ray through HBM, profiles/r02_pmc_traffic_kitchen.json) — and costs the early ones as much as it gains.
+template <typename T>
+struct Field {
+    T *base;
+    unsigned int stride;
+    D T &operator[](size_t i) const { return base[i * stride]; }
+    D explicit operator bool() const { return base != nullptr; }
+};
+
 struct PathState {
     unsigned int n_paths;  // n_pix * spp
     unsigned int n_pix;    // owned pixels
     const unsigned int *pixels;  // owned pixel list (row-major pixel indices)
-    float4 *ray_o;   // (o, mint)
-    float4 *ray_d;   // (d, maxt)
-    float4 *thr;     // (throughput, eta)
-    float4 *li;      // (Li, woPdf of the pending bounce)
-    float4 *hit;     // (t, u, v, prim)
-    uint4 *misc;     // (key, dim, flags, leaf of the pending bounce)
+    Field<float4> ray_o;   // (o, mint)
+    Field<float4> ray_d;   // (d, maxt)
+    Field<float4> thr;     // (throughput, eta)
+    Field<float4> li;      // (Li, woPdf of the pending bounce)
+    Field<float4> hit;     // (t, u, v, prim)
+    Field<uint4> misc;     // (key, dim, flags, leaf of the pending bounce)
     // vertex slots, index = slot * n_paths + path
-    float4 *v_d;     // (ray.d, woPdf)
-    float4 *v_thr;   // (throughput, bsdfPdf)
-    float4 *v_bsdf;  // (bsdfVal, dTreePdf)
-    float4 *v_rad;   // (radiance, leaf | delta << 31)
-    float4 *v_o;     // (ray.o, -)        only if spatial filter != nearest
-    float4 *v_vox;   // (voxel size, -)   only if spatial filter != nearest
+    Field<float4> v_d;     // (ray.d, woPdf)
+    Field<float4> v_thr;   // (throughput, bsdfPdf)
+    Field<float4> v_bsdf;  // (bsdfVal, dTreePdf)
+    Field<float4> v_rad;   // (radiance, leaf | delta << 31)
+    Field<float4> v_o;     // (ray.o, -)        only if spatial filter != nearest
+    Field<float4> v_vox;   // (voxel size, -)   only if spatial filter != nearest
     float *nee_cos;  // dot(ray.d, dRec.refN) of the pending bounce (-2 when refN = 0): ConstantBackgroundEmitter::pdfDirect needs the
                      // value, not just its sign; only allocated for scenes with an environment emitter
 };
@@ -117,7 +130,7 @@ D void block_add_u64(unsigned long long *lds_acc, unsigned long long *dst, unsig
     __syncthreads();
     if ((threadIdx.x & 63) == 0 && v) atomicAdd(lds_acc, v);
     __syncthreads();
-    if (threadIdx.x == 0) *dst += *lds_acc;
+    if (threadIdx.x == 0 && *lds_acc) atomicAdd(dst, *lds_acc);  // atomic: k_tail and k_commit may run side by side on two streams
 }
 
 // number of paths workgroup b handles at the first bounce and its k-th path (chunks dealt round-robin)
@@ -1258,23 +1271,31 @@ __global__ void k_sum_counts(const unsigned int *count, unsigned int nb, unsigne
 // vertices tend to lie in the same S-tree leaf (so the per-leaf counters combine) and whose loads coalesce.
 // The stochastic filter's three draws for slot v use sampler dimensions dim_end + 3v .. +2 (dim_end = the
 // path's dimension counter when Li returned) — the same rule as the oracle.
+// Which paths: all of them; or (skip) those not flagged — the paths that had ended when the persistent-thread tail took over, committed
+// on a second stream while k_tail runs —; or (list) the flagged ones afterwards.
 template <int SF, int DF>
-__global__ __launch_bounds__(PPG_BLOCK) void k_commit(PathState P, DevTree T, RenderParams R, Queues Q) {
+__global__ __launch_bounds__(PPG_BLOCK) void k_commit(PathState P, DevTree T, RenderParams R, Queues Q, const unsigned char *skip,
+                                                      const unsigned int *list, const unsigned long long *list_n) {
     __shared__ unsigned long long acc;
     unsigned long long committed_sum = 0;
     const float statisticalWeight = (R.nee == NEE_KICKSTART && R.do_nee) ? 0.5f : 1.0f;
     const int loss = T.is_built ? R.loss : LOSS_NONE;
-    const unsigned long long items = (unsigned long long)R.max_vertices * P.n_paths;
+    const unsigned int n_sel = list ? (unsigned int)*list_n : P.n_paths;
+    const unsigned long long items = (unsigned long long)R.max_vertices * n_sel;
     const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
     for (unsigned long long w0 = (unsigned long long)blockIdx.x * blockDim.x; w0 < items; w0 += stride) {
         const unsigned long long w = w0 + threadIdx.x;
         bool act = w < items;
         unsigned int v = 0, i = 0, key = 0, dim = 0;
         if (act) {
-            v = (unsigned int)(w / P.n_paths); i = (unsigned int)(w % P.n_paths);
-            uint4 m = P.misc[i];
-            key = m.x; dim = m.y + 3u * v;
-            act = v < ((m.z & FL_NV_MASK) >> FL_NV_SHIFT);
+            v = (unsigned int)(w / n_sel); i = (unsigned int)(w % n_sel);
+            if (list) i = list[i];
+            if (skip && skip[i]) act = false;
+            else {
+                uint4 m = P.misc[i];
+                key = m.x; dim = m.y + 3u * v;
+                act = v < ((m.z & FL_NV_MASK) >> FL_NV_SHIFT);
+            }
         }
         if (!__any(act)) continue;
         Rec rec;
@@ -1332,9 +1353,20 @@ __global__ void k_fold_replicas(unsigned long long *compact, unsigned long long 
 }
 
 // nv[i] = number of vertices path i recorded = the number of positions it owns in the Adam record buffer (fast mode)
-__global__ void k_path_nv(PathState P, unsigned int *nv) {
+// (a path still alive when the tail takes over — `straggler` — reserves the maximum; what it does not use stays a hole)
+__global__ void k_path_nv(PathState P, unsigned int *nv, const unsigned char *straggler, unsigned int max_vertices) {
     unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < P.n_paths) nv[i] = (P.misc[i].z & FL_NV_MASK) >> FL_NV_SHIFT;
+    if (i < P.n_paths) nv[i] = (straggler && straggler[i]) ? max_vertices : (P.misc[i].z & FL_NV_MASK) >> FL_NV_SHIFT;
+}
+// contiguous copy of the per-path word (key, dim, flags, leaf): k_commit tests it once per (slot, path) item
+__global__ void k_copy_misc(PathState P, uint4 *out) {
+    unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < P.n_paths) out[i] = P.misc[i];
+}
+// flag[list[k]] = 1 for the n = *list_n entries of a dense path list
+__global__ void k_mark_list(const unsigned int *list, const unsigned long long *list_n, unsigned char *flag) {
+    const unsigned int n = (unsigned int)*list_n;
+    for (unsigned int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) flag[list[k]] = 1;
 }
 __global__ void k_iota(unsigned int *a, unsigned int n) {
     unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -3,9 +3,8 @@
 Pixels are independent inside an iteration (the sampling SD-tree is frozen; the building tree only
 accumulates — guided_path.cpp:610-613, 308, 332, 397), so every rank renders the 32x32 tiles t with
 t % world == rank for all passes and the only exchange per iteration is
-    all_reduce(SUM) of the building tree's fixed-point leaf sums   (uint64 as int64, exact, order independent)
-    all_reduce(SUM) of the per-D-tree statistical weights           (same)
-    all_reduce(SUM) of image / squared image of the iteration       (disjoint supports → exact)
+    one all_reduce(SUM) of the building tree's fixed-point leaf sums + the per-D-tree statistical weights (uint64 as int64: exact, order independent)
+    one all_reduce(SUM) of image / squared image / weights of the iteration (disjoint supports → exact)
 plus, when the BSDF sampling fraction is learned, one all_gather per ROUND of the optimiser's records (include/ppg.h);
 after which refine/reset/build are deterministic functions of identical data on every rank: the SD-tree
 topology stays bit-identical across ranks and equal to a single-GPU render.  torch is plumbing here
@@ -36,21 +35,32 @@ class TorchReducer:
         import torch
         self.torch, self.dist, self.device = torch, dist, device
 
+    def _all_reduce_fused(self, views):
+        """ONE collective per exchange: the arrays are separate allocations of the context, so they are packed into a staging tensor,
+        reduced together and copied back — the xGMI ring is latency bound at these sizes (a few MB to ~100 MB), fewer and larger
+        calls win (the C++ twin: host/rccl_reducer.h)."""
+        views = [v for v in views if v.numel()]
+        if len(views) == 1:
+            self.dist.all_reduce(views[0])
+        elif views:
+            flat = self.torch.cat(views)
+            self.dist.all_reduce(flat)
+            off = 0
+            for v in views:
+                v.copy_(flat[off:off + v.numel()])
+                off += v.numel()
+        self.torch.cuda.synchronize()
+
     def reduce_sdtree(self, e):
         (ps, ns), (pw, nw) = e.stat_buffers()
-        for ptr, n in ((ps, ns), (pw, nw)):
-            if n:
-                self.dist.all_reduce(_view(self.torch, ptr, n, "<i8", self.device))
-        self.torch.cuda.synchronize()
+        self._all_reduce_fused([_view(self.torch, ptr, n, "<i8", self.device) for ptr, n in ((ps, ns), (pw, nw)) if n])
 
     def reduce_images(self, e):
         n = e.width * e.height
         a, b = e.image_buffers()
-        for ptr in (a, b):
-            self.dist.all_reduce(_view(self.torch, ptr, 3 * n, "<f4", self.device))
         w = e.image_weight_buffer()
-        self.dist.all_reduce(_view(self.torch, w, n, "<f4", self.device))
-        self.torch.cuda.synchronize()
+        self._all_reduce_fused([_view(self.torch, a, 3 * n, "<f4", self.device), _view(self.torch, b, 3 * n, "<f4", self.device),
+                                _view(self.torch, w, n, "<f4", self.device)])
 
     def reduce_adam(self, e):
         """Round hook of the sampling-fraction optimiser: every rank applies the records of ALL ranks (in key order, which does
@@ -80,9 +90,7 @@ class TorchReducer:
             return  # the retained iteration images were already reduced by reduce_images
         n = e.width * e.height
         a, w = e.film_buffers()
-        self.dist.all_reduce(_view(self.torch, a, 3 * n, "<f4", self.device))
-        self.dist.all_reduce(_view(self.torch, w, n, "<f4", self.device))
-        self.torch.cuda.synchronize()
+        self._all_reduce_fused([_view(self.torch, a, 3 * n, "<f4", self.device), _view(self.torch, w, n, "<f4", self.device)])
 
 
 class HostReducer:

@@ -129,6 +129,38 @@ def test_cbox_improved_preset_matches_reference_log(oracle_lib, ref_logs):
     assert rmse < 1.6 * noise_floor, (rmse, noise_floor)
 
 
+def test_sampling_fraction_rules_against_the_reference_log_seed_averaged(oracle_lib, ref_logs):
+    """The learned BSDF sampling fraction shows in the variance estimates of cbox-improved.exr's log.  The reference's numbers are one
+    draw each; the oracle's need not be — averaged over seeds their spread (2-3 % per run) drops below the effect measured here.
+
+    (1) PPGO_ADAM_SEQUENTIAL, the reference's literal rule (a step after every ~2 records, in arrival order — single-threaded here so the
+        order is defined): iteration 1, the first guided passes and the ones most sensitive to the optimiser, reproduces the log's 4.713.
+    (2) The product's rule (PPGO_ADAM_ROUND: the same append()/step() arithmetic applied at the end of each round of passes in key order,
+        fractions frozen within a round — include/ppg.h) starts every pass of iteration 1 from the untrained fraction 0.5: +19 % there,
+        a lag that is gone two iterations later.  That deviation is what this test measures; DESIGN.md §4.4 quotes it."""
+    import ppg_host
+    from conftest import IMPROVED
+    ref = [r["var"][0] for r in ref_logs["cbox-improved"]["iterations"]]
+    assert abs(ref[1] - 4.713) < 1e-3 and abs(ref[3] - 0.297) < 1e-3
+    scene = ppg_host.cbox_scene(512, 512)
+
+    def variances(adam, budget, seeds):
+        rows = []
+        for seed in seeds:
+            e = make_oracle(oracle_lib, threads=os.cpu_count() or 8, adam=adam, budget=budget, seed=seed, **dict(CBOX_PROPS, **IMPROVED))
+            gpt = ppg_host.GuidedPathTracer(engine=e)
+            gpt.render(scene)
+            rows.append([i["stats"][0]["variance"] for i in gpt.iterations])
+        return np.mean(np.array(rows)[:, 1:], axis=0)
+
+    seq = variances(1, 7, (1000, 1001, 1002, 1003))              # iterations 0-2 (the last one does not train: 7, not 3, passes)
+    assert abs(seq[0] / ref[1] - 1) < 0.05, seq                   # measured 4.757 +- 0.04 (six seeds) vs 4.713
+    rnd = variances(0, 31, (1000, 1001, 1002))                    # iterations 0-4
+    assert 1.08 < rnd[0] / ref[1] < 1.32, rnd                     # measured 5.63: the documented lag of the round rule
+    assert abs(rnd[1] / ref[2] - 1) < 0.20, rnd                   # 1.071 vs 0.922 (the literal rule: 0.976)
+    assert abs(rnd[2] / ref[3] - 1) < 0.07 and abs(rnd[3] / ref[4] - 1) < 0.09, rnd   # 0.290 vs 0.297, 0.0881 vs 0.0834: converged
+
+
 SPACESHIP = "/root/reference/scenes/spaceship/spaceship.xml"
 IMPROVED_PRESET = dict(sampleCombination="inversevar", bsdfSamplingFractionLoss="kl", spatialFilter="stochastic", directionalFilter="box",
                        sTreeThreshold=4000, sppPerPass=1)
