@@ -217,10 +217,12 @@ struct LdsScene {
 #ifndef PPG_LDS_STACK
 #define PPG_LDS_STACK 24
 #endif
+// (the overflow array is a separate object: as a member it kept the whole struct — stack pointer included — in scratch memory, and
+// every push / pop went through a scratch load and store)
 struct TStack {
     int *lds;      // this lane's column, stride blockDim.x
     int stride;
-    int over[24];
+    int *over;     // int[24] of the caller
     int sp;
     D void push(int v) { if (sp < PPG_LDS_STACK) lds[sp * stride] = v; else over[sp - PPG_LDS_STACK] = v; ++sp; }
     D int pop() { --sp; return sp < PPG_LDS_STACK ? lds[sp * stride] : over[sp - PPG_LDS_STACK]; }
@@ -269,6 +271,38 @@ D void sphere_pass(const DevScene &S, F3 o, F3 d, float mint, float maxt, Hit &b
     }
 }
 
+// The four children of a node after the slab tests, nearest first, WITHOUT indexed local arrays (a dynamically indexed array lives in
+// scratch memory: the insertion sort that stood here cost k_trace 120 B of scratch traffic per lane and step).  Children that were
+// missed carry t = +inf and sort to the end; a 5-comparator network on registers.  Equal distances may swap — the closest hit does not
+// depend on the visiting order (ties are broken by (t, original triangle index)).
+#define PPG_CSWAP(ta, ca, tb, cb) { const bool sw_ = (ta) > (tb); const float t0_ = sw_ ? (tb) : (ta), t1_ = sw_ ? (ta) : (tb); \
+                                    const int c0_ = sw_ ? (cb) : (ca), c1_ = sw_ ? (ca) : (cb); ta = t0_; tb = t1_; ca = c0_; cb = c1_; }
+struct Bvh4Hits { int c0, c1, c2, c3, m; };
+D Bvh4Hits bvh4_children(const Bvh4QNode *node, F3 o, F3 id, float mint, float tlim) {
+    float lxs[4], lys[4], lzs[4], hxs[4], hys[4], hzs[4];
+    int chs[4];
+    bvh4q_load(node, lxs, lys, lzs, hxs, hys, hzs, chs);
+    float ts[4];
+    int m = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float ax = (lxs[k] - o.x) * id.x, bx = (hxs[k] - o.x) * id.x;
+        float ay = (lys[k] - o.y) * id.y, by = (hys[k] - o.y) * id.y;
+        float az = (lzs[k] - o.z) * id.z, bz = (hzs[k] - o.z) * id.z;
+        float n = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), mint));
+        // exit distance widened by 1 + 2 gamma_3 (3 roundings in the slab arithmetic): the test stays conservative whatever the box padding
+        float f = fminf(fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000008f, tlim);
+        const bool hit = (n <= f) && chs[k] != PPG_BVH4_EMPTY;
+        ts[k] = hit ? n : __builtin_inff();
+        m += hit ? 1 : 0;
+    }
+    float t0 = ts[0], t1 = ts[1], t2 = ts[2], t3 = ts[3];
+    int c0 = chs[0], c1 = chs[1], c2 = chs[2], c3 = chs[3];
+    PPG_CSWAP(t0, c0, t1, c1) PPG_CSWAP(t2, c2, t3, c3) PPG_CSWAP(t0, c0, t2, c2) PPG_CSWAP(t1, c1, t3, c3) PPG_CSWAP(t1, c1, t2, c2)
+    Bvh4Hits r; r.c0 = c0; r.c1 = c1; r.c2 = c2; r.c3 = c3; r.m = m;
+    return r;
+}
+
 // Closest hit by (t, original primitive index) through the BVH4 — equals brute force (conservative culling).
 // ANY: return at the first triangle hit (shadow rays; only prim >= 0 is meaningful then).
 template <bool ANY = false, bool SPH = false>
@@ -278,38 +312,18 @@ D Hit trace_closest4(const DevScene &S, int *lds_stack_col, int stride, F3 o, F3
     int bestOrig = 0x7fffffff;
     const F3 id = f3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
     TStack st;
+    int st_over[24];
+    st.over = st_over;
     st.lds = lds_stack_col; st.stride = stride; st.sp = 0;
     int cur = 0;
     for (;;) {  // one step per iteration: an interior node or a leaf popped from the stack (see trace_slice_bvh4)
         if (cur >= 0) {
-            float lxs[4], lys[4], lzs[4], hxs[4], hys[4], hzs[4];
-            int chs[4];
-            bvh4q_load(S.bvh4 + cur, lxs, lys, lzs, hxs, hys, hzs, chs);
-            const float tlim = fminf(maxt, best.t);
-            int cn[4];
-            float ct[4];
-            int m = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float ax = (lxs[k] - o.x) * id.x, bx = (hxs[k] - o.x) * id.x;
-                float ay = (lys[k] - o.y) * id.y, by = (hys[k] - o.y) * id.y;
-                float az = (lzs[k] - o.z) * id.z, bz = (hzs[k] - o.z) * id.z;
-                float n = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), mint));
-                // exit distance widened by 1 + 2 gamma_3 (3 roundings in the slab arithmetic): the test stays conservative whatever the box padding
-                float f = fminf(fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000008f, tlim);
-                if ((n <= f) && chs[k] != PPG_BVH4_EMPTY) {
-                    int j = m++;
-                    cn[j] = chs[k]; ct[j] = n;
-                    while (j > 0 && ct[j - 1] > ct[j]) {
-                        float tf = ct[j]; ct[j] = ct[j - 1]; ct[j - 1] = tf;
-                        int tc = cn[j]; cn[j] = cn[j - 1]; cn[j - 1] = tc;
-                        --j;
-                    }
-                }
-            }
-            if (m > 0) {
-                for (int j = m - 1; j >= 1; --j) st.push(cn[j]);
-                cur = cn[0];
+            const Bvh4Hits hc = bvh4_children(S.bvh4 + cur, o, id, mint, fminf(maxt, best.t));
+            if (hc.m > 0) {
+                if (hc.m > 3) st.push(hc.c3);
+                if (hc.m > 2) st.push(hc.c2);
+                if (hc.m > 1) st.push(hc.c1);
+                cur = hc.c0;
             } else {
                 if (st.sp == 0) break;
                 cur = st.pop();

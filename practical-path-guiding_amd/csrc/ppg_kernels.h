@@ -279,6 +279,8 @@ D void trace_slice_bvh4(const PathState &P, const DevScene &S, int *lds_stack, u
     if (threadIdx.x == 0) *ticket = 0;
     __syncthreads();
     TStack st;
+    int st_over[24];
+    st.over = st_over;
     st.lds = lds_stack + threadIdx.x; st.stride = PPG_BLOCK; st.sp = 0;
     bool have = false;
     unsigned int i = 0;
@@ -318,34 +320,12 @@ D void trace_slice_bvh4(const PathState &P, const DevScene &S, int *lds_stack, u
 #endif
         if (cur >= 0) {
             if (COUNT) ++n_nodes;
-            float lxs[4], lys[4], lzs[4], hxs[4], hys[4], hzs[4];
-            int chs[4];
-            bvh4q_load(S.bvh4 + cur, lxs, lys, lzs, hxs, hys, hzs, chs);
-            const float tlim = fminf(maxt, best.t);
-            int cn[4];
-            float ct[4];
-            int m = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float ax = (lxs[k] - o.x) * id.x, bx = (hxs[k] - o.x) * id.x;
-                float ay = (lys[k] - o.y) * id.y, by = (hys[k] - o.y) * id.y;
-                float az = (lzs[k] - o.z) * id.z, bz = (hzs[k] - o.z) * id.z;
-                float n = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), mint));
-                // exit distance widened by 1 + 2 gamma_3 (3 roundings in the slab arithmetic): the test stays conservative whatever the box padding
-                float f = fminf(fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000008f, tlim);
-                if ((n <= f) && chs[k] != PPG_BVH4_EMPTY) {  // children (interior or leaf) nearest first
-                    int j = m++;
-                    cn[j] = chs[k]; ct[j] = n;
-                    while (j > 0 && ct[j - 1] > ct[j]) {
-                        float tf = ct[j]; ct[j] = ct[j - 1]; ct[j - 1] = tf;
-                        int tc = cn[j]; cn[j] = cn[j - 1]; cn[j - 1] = tc;
-                        --j;
-                    }
-                }
-            }
-            if (m > 0) {
-                for (int j = m - 1; j >= 1; --j) st.push(cn[j]);
-                cur = cn[0];
+            const Bvh4Hits hc = bvh4_children(S.bvh4 + cur, o, id, mint, fminf(maxt, best.t));
+            if (hc.m > 0) {
+                if (hc.m > 3) st.push(hc.c3);
+                if (hc.m > 2) st.push(hc.c2);
+                if (hc.m > 1) st.push(hc.c1);
+                cur = hc.c0;
             } else cur = st.sp > 0 ? st.pop() : PPG_BVH4_EMPTY;
         } else if (doLeaves) {
             const int code = ~cur;
@@ -912,16 +892,24 @@ D bool shade_one(const PathState &P, const DevScene &S, const DevTree &T, const 
         F3 wo_l, bsdfWeight;
         float woPdf, bsdfPdf, dTreePdf;
         bool sampledDelta = false;
-        if (!T.is_built || !smooth) {  // !m_isBuilt || !dTree || all components are delta
-            bsdfWeight = b_sample(sx, sy, wo_l, bsdfPdf, sampledDelta);
+        // ONE call site for the BSDF's sample(): called from two places the lambda is not inlined, and everything it captures by
+        // reference (intersection record, material, texture info) then lives in scratch memory
+        const bool unguided = !T.is_built || !smooth;  // !m_isBuilt || !dTree || all components are delta
+        const bool viaBsdf = unguided || sx < frac;
+        F3 sampled = f3s(0.0f);
+        if (viaBsdf) {
+            if (!unguided) sx /= frac;
+            sampled = b_sample(sx, sy, wo_l, bsdfPdf, sampledDelta);
+        }
+        if (unguided) {
+            bsdfWeight = sampled;
             woPdf = bsdfPdf;
             dTreePdf = 0;
         } else {
             F3 result;
             bool zero = false, deltaEarly = false;
-            if (sx < frac) {
-                sx /= frac;
-                result = b_sample(sx, sy, wo_l, bsdfPdf, sampledDelta);
+            if (viaBsdf) {
+                result = sampled;
                 if (iszero3(result)) zero = true;
                 else if (FULL && sampledDelta) deltaEarly = true;  // GP:1672-1676: a delta lobe of a mixed BSDF
                 else result = result * bsdfPdf;
