@@ -342,10 +342,11 @@ def run(args):
 
     if dist is not None:
         dist.barrier()
-        dist.destroy_process_group()
     if rank == 0:  # the one JSON line is the last thing written
         sys.stdout.flush(); sys.stderr.flush()
         print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 def main():
