@@ -11,9 +11,9 @@
  * stream in vertex order, skipping invalid vertices; any fixed assignment is statistically equivalent and
  * this one lets vertices be committed independently).
  * With next-event estimation the direct-light vertex of GP:1994-2010 is committed inside the loop; its three
- * stochastic-filter draws use dimensions PPG_DIM_NEE_COMMIT + 3·depth (depth = rRec.depth at that vertex), its
- * Adam mini-batch slot is PPG_SLOT_NEE + depth — a separate range, so the main stream's positions do not
- * depend on whether or where such a vertex is committed.
+ * stochastic-filter draws use dimensions PPG_DIM_NEE_COMMIT + 3·depth (depth = rRec.depth at that vertex) — a separate
+ * range, so the main stream's positions do not depend on whether or where such a vertex is committed (its place in the
+ * order of the sampling-fraction optimiser's records: include/ppg.h, record code = depth).
  * Floats are built from 23 random mantissa bits like random.cpp:630-639.
  */
 #ifndef PPG_RNG_H
@@ -22,7 +22,6 @@
 #include "ppg_detmath.h"
 
 #define PPG_DIM_NEE_COMMIT 0x40000000u
-#define PPG_SLOT_NEE 0x100u
 
 PPG_HD uint32_t ppg_hash32(uint32_t x) { /* "lowbias32" integer finaliser */
     x ^= x >> 16; x *= 0x7feb352du;

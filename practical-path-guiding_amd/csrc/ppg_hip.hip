@@ -388,7 +388,8 @@ struct ppg_ctx {
     unsigned int *h_round = nullptr;  // pinned: [0..63] bounce counts, [64] Adam record count / overflow, [65] Σ nV
     int bulkBounces = 8;
     // Tuning switches, read ONCE from the environment by ppg_create (DESIGN.md "Tuning switches"); none of them changes a result.
-    unsigned int tailThreshold = 0;   // PPG_TAIL_THRESHOLD: live paths below which k_tail takes over (0 = automatic)
+    unsigned int tailThreshold = 0;   // PPG_TAIL_THRESHOLD: live paths below which k_tail takes over (0 = automatic: max(tailMin, paths / tailDiv))
+    unsigned int tailMin = 786432, tailDiv = 12;  // PPG_TAIL_MIN, PPG_TAIL_DIV (KITCHEN 720p: 131072 / 16 -> 786432 / 12: +1.5 % at 127 passes, +5 % at 20)
     size_t tuneBatchPaths = 0;        // PPG_BATCH_PATHS: paths in flight per batch of passes (0 = automatic)
     int tuneBlocks = 0;               // PPG_BLOCKS: persistent workgroups of the path kernels (0 = 4096)
     bool tuneForceBvh = false;        // PPG_FORCE_BVH: trace small scenes through the BVH as well
@@ -966,7 +967,7 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound) {
         HIP_CHECK(hipStreamSynchronize(s));  // the one host round trip of a batch of unbounded paths / of a round
         if (tail) {
             // next batch: wavefront bounces until fewer paths are left than the persistent-thread tail handles just as well
-            const unsigned int thr = ctx->tailThreshold ? ctx->tailThreshold : std::max(131072u, P.n_paths / 16u);
+            const unsigned int thr = ctx->tailThreshold ? ctx->tailThreshold : std::max(ctx->tailMin, P.n_paths / ctx->tailDiv);
             int nb = bouncesRun;
             for (int b = 0; b < bouncesRun; ++b) if (ctx->h_round[b] < thr) { nb = b + 1; break; }
             if (nb == bouncesRun && ctx->h_round[bouncesRun - 1] >= thr) nb = std::min(64, bouncesRun + 4);
@@ -1376,6 +1377,8 @@ int ppg_create(const ppg_config *cfg, ppg_ctx **out) {
     if (cfg->dumpPrefix) c->dumpPrefix = cfg->dumpPrefix;
     {   // tuning switches (performance experiments only; results do not depend on them)
         if (const char *e = getenv("PPG_TAIL_THRESHOLD")) c->tailThreshold = (unsigned int)std::max(0ll, atoll(e));
+        if (const char *e = getenv("PPG_TAIL_MIN")) c->tailMin = (unsigned int)std::max(1ll, atoll(e));
+        if (const char *e = getenv("PPG_TAIL_DIV")) c->tailDiv = (unsigned int)std::max(1ll, atoll(e));
         if (const char *e = getenv("PPG_BATCH_PATHS")) c->tuneBatchPaths = (size_t)std::max(1ll, atoll(e));
         if (const char *e = getenv("PPG_BLOCKS")) c->tuneBlocks = std::max(1, atoi(e));
         c->tuneForceBvh = getenv("PPG_FORCE_BVH") != nullptr;

@@ -416,7 +416,11 @@ __global__ void k_build_grid(const int4 *stree, unsigned int *grid) {
 // Splatting: DTree::recordIrradiance (GP:395-413) into the building tree of one S-tree leaf
 // ------------------------------------------------------------------------------------------------
 // (the `statisticalWeight += w` half of recordIrradiance is done by the caller, wave-combined)
-D void dtree_record(const DevTree &T, int leaf, float px, float py, float irradiance, float w, int dfilter) {
+#ifndef PPG_BOX_STACK
+#define PPG_BOX_STACK 8
+#endif
+D void dtree_record(const DevTree &T, int leaf, float px, float py, float irradiance, float w, int dfilter, unsigned long long *box_stack = nullptr,
+                    int box_stride = 0) {
     if (!(ppg_isfinite(w) && w > 0)) return;
     if (!(ppg_isfinite(irradiance) && irradiance > 0)) return;
     const unsigned int base = T.hdr[leaf].b_base;
@@ -450,26 +454,43 @@ D void dtree_record(const DevTree &T, int leaf, float px, float py, float irradi
         const float size = ppg_exp2i(-depth);
         const float ox = px - size / 2, oy = py - size / 2;
         const float value = irradiance * w / (size * size);
-        struct E { unsigned int node; float x, y, s; };
-        E st[64];
+        // Explicit stack of (node, cell) pairs.  A cell of level l is [ix, ix + 1) x [iy, iy + 1) * 2^-l — dyadic, so its float corner
+        // ix * 2^-l is exactly what the reference's running `origin + childSize` additions produce — and an entry packs into 64 bits:
+        // node (16) | level (5) | ix (21) | iy (21).  With `box_stack` (k_commit: an LDS column per lane) the first PPG_BOX_STACK entries
+        // never leave the CU; a 64-entry array in scratch memory — 1 KB per lane, far beyond L1 — was the whole stack before.
+        unsigned long long over[64];
         int sp = 0;
-        st[sp++] = E{0u, 0.0f, 0.0f, 1.0f};
+        auto push = [&](unsigned long long v) {
+            if (box_stack && sp < PPG_BOX_STACK) box_stack[sp * box_stride] = v; else over[box_stack ? sp - PPG_BOX_STACK : sp] = v;
+            ++sp;
+        };
+        auto pop = [&]() -> unsigned long long {
+            --sp;
+            return (box_stack && sp < PPG_BOX_STACK) ? box_stack[sp * box_stride] : over[box_stack ? sp - PPG_BOX_STACK : sp];
+        };
+        push(0ull);
         while (sp) {
-            E e = st[--sp];
-            float childSize = e.s / 2;
-            ushort4 ch = T.bchild[base + e.node];
+            const unsigned long long e = pop();
+            const unsigned int enode = (unsigned int)(e & 0xffffu), level = (unsigned int)(e >> 16) & 31u;
+            const unsigned int ix = (unsigned int)(e >> 21) & 0x1fffffu, iy = (unsigned int)(e >> 42) & 0x1fffffu;
+            const float es = ppg_exp2i(-(int)level);
+            const float ex = (float)ix * es, ey = (float)iy * es;
+            float childSize = es / 2;
+            ushort4 ch = T.bchild[base + enode];
             const unsigned short cc[4] = {ch.x, ch.y, ch.z, ch.w};
             // the reference recurses depth-first in child order; contributions to distinct leaf slots commute (integer adds)
+#pragma unroll
             for (int i = 0; i < 4; ++i) {
-                float cx = e.x, cy = e.y;
+                float cx = ex, cy = ey;
                 if (i & 1) cx += childSize;
                 if (i & 2) cy += childSize;
                 float lx = ppg_max(ppg_min(ox + size, cx + childSize) - ppg_max(ox, cx), 0.0f);
                 float ly = ppg_max(ppg_min(oy + size, cy + childSize) - ppg_max(oy, cy), 0.0f);
                 float ww = lx * ly;
                 if (ww > 0.0f) {
-                    if (cc[i] == 0) atomicAdd(&T.bacc[(size_t)(base + e.node) * 4 + i], ppg_to_fixed(value * ww));
-                    else st[sp++] = E{cc[i], cx, cy, childSize};
+                    if (cc[i] == 0) atomicAdd(&T.bacc[(size_t)(base + enode) * 4 + i], ppg_to_fixed(value * ww));
+                    else push((unsigned long long)cc[i] | ((unsigned long long)(level + 1) << 16) | ((unsigned long long)(2 * ix + (i & 1)) << 21) |
+                              ((unsigned long long)(2 * iy + ((i >> 1) & 1)) << 42));
                 }
             }
         }
@@ -495,7 +516,8 @@ D unsigned int adam_path_id(const PathState &P, const RenderParams &R, unsigned 
 // COMBINE: called by all lanes of a wave (inactive lanes pass active = false); the per-D-tree counters
 // are then pre-combined across the wave.
 template <bool COMBINE>
-D void wrapper_record(const DevTree &T, int leaf, const Rec &rec, int dfilter, int loss, bool active) {
+D void wrapper_record(const DevTree &T, int leaf, const Rec &rec, int dfilter, int loss, bool active, unsigned long long *box_stack = nullptr,
+                      int box_stride = 0) {
     const bool irr = active && !rec.isDelta;
     float irradiance = 0, px = 0, py = 0;
     if (irr) {
@@ -506,7 +528,7 @@ D void wrapper_record(const DevTree &T, int leaf, const Rec &rec, int dfilter, i
     const unsigned long long wf = wOk ? ppg_to_fixed(rec.statisticalWeight) : 0ull;
     if (COMBINE) wave_key_add<3>(T.bweight_rep, (unsigned int)leaf * PPG_REPLICAS + (blockIdx.x & (PPG_REPLICAS - 1)), wf, wOk);
     else if (wOk) atomicAdd(&T.bweight_rep[(size_t)leaf * PPG_REPLICAS + (blockIdx.x & (PPG_REPLICAS - 1))], wf);
-    if (wOk) dtree_record(T, leaf, px, py, irradiance, rec.statisticalWeight, dfilter);
+    if (wOk) dtree_record(T, leaf, px, py, irradiance, rec.statisticalWeight, dfilter, box_stack, box_stride);
 
     // if (bsdfSamplingFractionLoss != ENone && rec.product > 0) optimizeBsdfSamplingFraction(rec, ...), GP:581-583: deferred to the end
     // of the round (k_adam_apply), here only written down
@@ -1265,6 +1287,7 @@ template <int SF, int DF>
 __global__ __launch_bounds__(PPG_BLOCK) void k_commit(PathState P, DevTree T, RenderParams R, Queues Q, const unsigned char *skip,
                                                       const unsigned int *list, const unsigned long long *list_n) {
     __shared__ unsigned long long acc;
+    __shared__ unsigned long long box_lds[DF == DF_BOX ? PPG_BOX_STACK * PPG_BLOCK : 1];  // the box splat's stack, one column per lane
     unsigned long long committed_sum = 0;
     const float statisticalWeight = (R.nee == NEE_KICKSTART && R.do_nee) ? 0.5f : 1.0f;
     const int loss = T.is_built ? R.loss : LOSS_NONE;
@@ -1319,7 +1342,7 @@ __global__ __launch_bounds__(PPG_BLOCK) void k_commit(PathState P, DevTree T, Re
                 float4 o4 = P.v_o[vi], x4 = P.v_vox[vi];
                 leaf = stochastic_leaf(T, f3(o4.x, o4.y, o4.z), f3(x4.x, x4.y, x4.z), key, dim);
             }
-            wrapper_record<true>(T, leaf, rec, DF, loss, act);
+            wrapper_record<true>(T, leaf, rec, DF, loss, act, DF == DF_BOX ? box_lds + threadIdx.x : nullptr, PPG_BLOCK);
         }
     }
     block_add_u64(&acc, &Q.stats[blockIdx.x].committed, committed_sum);
