@@ -217,6 +217,9 @@ struct LdsScene {
 #ifndef PPG_LDS_STACK
 #define PPG_LDS_STACK 24
 #endif
+#ifndef PPG_LEAF_VOTE_TAIL
+#define PPG_LEAF_VOTE_TAIL 8  // leaf vote of trace_closest4<.., VOTE> (k_tail: waves are sparsely populated there)
+#endif
 // (the overflow array is a separate object: as a member it kept the whole struct — stack pointer included — in scratch memory, and
 // every push / pop went through a scratch load and store)
 struct TStack {
@@ -305,7 +308,9 @@ D Bvh4Hits bvh4_children(const Bvh4QNode *node, F3 o, F3 id, float mint, float t
 
 // Closest hit by (t, original primitive index) through the BVH4 — equals brute force (conservative culling).
 // ANY: return at the first triangle hit (shadow rays; only prim >= 0 is meaningful then).
-template <bool ANY = false, bool SPH = false>
+// VOTE: as in k_trace, lanes holding a leaf wait until PPG_LEAF_VOTE lanes of the wave do (or none has an interior node left) — for callers
+// whose whole wave traverses at once (k_tail); lanes that are done have left the loop and do not count.
+template <bool ANY = false, bool SPH = false, bool VOTE = false>
 D Hit trace_closest4(const DevScene &S, int *lds_stack_col, int stride, F3 o, F3 d, float mint, float maxt) {
     Hit best;
     best.t = __builtin_inff(); best.u = 0; best.v = 0; best.prim = -1;
@@ -317,6 +322,11 @@ D Hit trace_closest4(const DevScene &S, int *lds_stack_col, int stride, F3 o, F3
     st.lds = lds_stack_col; st.stride = stride; st.sp = 0;
     int cur = 0;
     for (;;) {  // one step per iteration: an interior node or a leaf popped from the stack (see trace_slice_bvh4)
+        bool doLeaves = true;
+        if (VOTE) {
+            const unsigned long long leafLanes = __ballot(cur < 0), nodeLanes = __ballot(cur >= 0);
+            doLeaves = __popcll(leafLanes) >= PPG_LEAF_VOTE_TAIL || nodeLanes == 0ull;
+        }
         if (cur >= 0) {
             const Bvh4Hits hc = bvh4_children(S.bvh4 + cur, o, id, mint, fminf(maxt, best.t));
             if (hc.m > 0) {
@@ -328,7 +338,7 @@ D Hit trace_closest4(const DevScene &S, int *lds_stack_col, int stride, F3 o, F3
                 if (st.sp == 0) break;
                 cur = st.pop();
             }
-        } else {
+        } else if (doLeaves) {
             const int code = ~cur;
             const int first = code >> 3, cnt = (code & 7) + 1;
             for (int q = first; q < first + cnt; ++q) {

@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>  // rocprim's texture iterator calls memset from host code
+#include <map>
+#include <mutex>
 
 #include <rocprim/rocprim.hpp>
 
@@ -41,23 +43,64 @@ thread_local std::string g_createError;
         }                                                                                           \
     } while (0)
 
+// Device memory blocks outlive the contexts that used them: a context's buffers grow while it renders (path state at begin_render, the
+// optimiser's records with the first large round, sort scratch ...), and hipMalloc / hipFree of hundreds of megabytes are synchronous,
+// millisecond-scale calls — rocprofv3 showed a 17 ms hole in a 190 ms KITCHEN render where one round's record buffers were grown.  Released
+// blocks therefore go to a process-wide cache (per device, keyed by size) and the next reserve() — of this context or of the next one, e.g.
+// the render after a warm-up render — takes a fitting block from it.  Blocks come back with stale contents, like fresh hipMalloc memory.
+// Ordering: a block is released only by reserve() / the destructor on the host; everything that used it was enqueued earlier on the
+// context's in-order stream (the second stream is joined back before the host continues past a batch), and its next user is enqueued later.
+struct BlockCache {
+    std::mutex m;
+    std::map<int, std::multimap<size_t, void *>> blocks;
+    size_t held = 0;
+    static constexpr size_t kMaxHeld = (size_t)96 << 30;
+    static constexpr size_t kGranule = (size_t)2 << 20;
+    static size_t roundUp(size_t bytes) { return (bytes + kGranule - 1) / kGranule * kGranule; }
+    void *take(size_t bytes, size_t &got) {
+        int dev = 0; (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> g(m);
+        auto &mm = blocks[dev];
+        auto it = mm.lower_bound(bytes);
+        if (it == mm.end() || it->first > std::max(2 * bytes, bytes + ((size_t)64 << 20))) return nullptr;
+        void *p = it->second; got = it->first;
+        held -= got; mm.erase(it);
+        return p;
+    }
+    void give(void *p, size_t bytes) {
+        int dev = 0; (void)hipGetDevice(&dev);
+        {
+            std::lock_guard<std::mutex> g(m);
+            if (held + bytes <= kMaxHeld) { blocks[dev].emplace(bytes, p); held += bytes; return; }
+        }
+        (void)hipFree(p);
+    }
+};
+static BlockCache g_blockCache;
+
 template <typename T> struct DevBuf {
     T *p = nullptr;
     size_t cap = 0;
+    size_t bytes = 0;  // size of the block behind p
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
-    DevBuf(DevBuf &&o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    DevBuf(DevBuf &&o) noexcept : p(o.p), cap(o.cap), bytes(o.bytes) { o.p = nullptr; o.cap = 0; o.bytes = 0; }
+    ~DevBuf() { if (p) g_blockCache.give(p, bytes); }
     hipError_t reserve(size_t n, bool keep = false) {
         if (n <= cap) return hipSuccess;
-        size_t ncap = std::max(n, cap + cap / 2);
-        T *np = nullptr;
-        hipError_t e = hipMalloc(&np, ncap * sizeof(T));
-        if (e != hipSuccess) return e;
+        const size_t want = BlockCache::roundUp(std::max(n, cap + cap / 2) * sizeof(T));
+        size_t got = 0;
+        T *np = (T *)g_blockCache.take(want, got);
+        hipError_t e = hipSuccess;
+        if (!np) {
+            e = hipMalloc(&np, want);
+            if (e != hipSuccess) return e;
+            got = want;
+        }
         if (keep && p && cap) e = hipMemcpy(np, p, cap * sizeof(T), hipMemcpyDeviceToDevice);
-        if (p) (void)hipFree(p);
-        p = np; cap = ncap;
+        if (p) g_blockCache.give(p, bytes);
+        p = np; bytes = got; cap = got / sizeof(T);
         return e;
     }
 };

@@ -1200,7 +1200,7 @@ __global__ __launch_bounds__(PPG_BLOCK, (FULL ? PPG_SHADE_WAVES_FULL : PPG_SHADE
                 float mint = ro.w;
                 if (mint == PPG_EPSILON)  // adaptive ray epsilon, skdtree.cpp:125-129
                     mint *= ppg_max(ppg_max(ppg_max(ppg_abs(o.x), ppg_abs(o.y)), ppg_abs(o.z)), PPG_EPSILON);
-                h = trace_closest4<false, true>(S, nee.stack_col, PPG_BLOCK, o, d, mint, rd.w);
+                h = trace_closest4<false, true, true>(S, nee.stack_col, PPG_BLOCK, o, d, mint, rd.w);
             }
             P.hit[i] = make_float4(h.t, h.u, h.v, __int_as_float(h.prim));
             ++traced;
