@@ -258,32 +258,49 @@ def run(args):
         g2 = make(args.steps, timing=True)
         g2.render()
         times = g2.engine.kernel_times()
+        rays2 = sum(s["rays"] for it in g2.iterations for s in it["stats"])
         sync()
         del g2
     if rank == 0 and times:
         counts = {k["name"]: k["units"] for k in times if k["launches"] == 0}
         times = [k for k in times if k["launches"] > 0]
-        dom = max(times, key=lambda k: k["ms"])
-        name = dom["name"].split("<")[0]
         trace_rays = sum(k["units"] for k in times if k["name"] == "k_trace")
         bvh = (counts.get("bvh_nodes_visited", 0), counts.get("bvh_triangles_tested", 0), trace_rays) if counts else None
         alg = algorithmic_bytes(work, rays_cpu, bvh)
-        bytes_per_unit = alg.get(name, alg["k_shade"])
-        avg_units = dom["units"] / max(1, dom["launches"])
-        avg_ms = dom["ms"] / max(1, dom["launches"])
-        achieved = bytes_per_unit * avg_units / (avg_ms * 1e-3) / 1e9
         tr, tr_file = measured_traffic(traffic_tag)
-        traffic = None
-        if tr and name in tr.get("bytes_per_unit", {}):
-            traffic = tr["bytes_per_unit"][name] * avg_units
-        out["roofline"] = {"bound": "hbm", "kernel": dom["name"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                           "traffic_source": ("stored calibration profiles/%s (PMC bytes per unit of an earlier run) x this run's units" % tr_file) if traffic is not None else None,
-                           "avg_launch_ms": avg_ms, "launches": dom["launches"],
-                           "algorithmic_bytes_per_unit": bytes_per_unit, "avg_units_per_launch": avg_units, "unit_of_work": "traced ray",
+
+        def entry(k):
+            name = k["name"].split("<")[0]
+            units = k["units"]
+            if name == "k_tail":  # the persistent-thread tail traces AND shades: its unit is a ray it traced = all rays - those k_trace traced
+                units = max(0, rays2 - trace_rays)
+            bpu = alg.get(name)
+            if bpu is None or not units:
+                return None
+            avg_units, avg_ms = units / k["launches"], k["ms"] / k["launches"]
+            achieved = bpu * avg_units / (avg_ms * 1e-3) / 1e9
+            traffic = None
+            if tr and name in tr.get("bytes_per_unit", {}):  # the stored calibration is per unit as the kernel timer counts them (k_tail: paths handed over)
+                traffic = tr["bytes_per_unit"][name] * k["units"] / k["launches"]
+            return {"kernel": k["name"], "ms": round(k["ms"], 3), "launches": k["launches"], "avg_launch_ms": avg_ms, "avg_units_per_launch": avg_units,
+                    "algorithmic_bytes_per_unit": bpu, "achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "traffic": traffic}
+
+        per = {k["name"]: entry(k) for k in times}
+        per = {n: e for n, e in per.items() if e}
+        dom = max(per.values(), key=lambda e: e["ms"])
+        name = dom["kernel"].split("<")[0]
+        out["roofline"] = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": dom["frac"], "traffic": dom["traffic"],
+                           "traffic_source": ("stored calibration profiles/%s (PMC bytes per unit of an earlier run) x this run's units" % tr_file) if dom["traffic"] is not None else None,
+                           "avg_launch_ms": dom["avg_launch_ms"], "launches": dom["launches"],
+                           "algorithmic_bytes_per_unit": dom["algorithmic_bytes_per_unit"], "avg_units_per_launch": dom["avg_units_per_launch"],
+                           "unit_of_work": "ray traced and shaded inside the persistent-thread tail" if name == "k_tail" else ("traced ray" if name in ("k_trace", "k_shade") else "unit of " + name),
                            "operation_counts": alg["detail"], "kernels_ms": {k["name"]: round(k["ms"], 3) for k in times},
+                           "per_kernel": {n: {q: (round(v, 4) if isinstance(v, float) else v) for q, v in e.items() if q != "kernel"} for n, e in per.items()
+                                          if n.split("<")[0] in ("k_trace", "k_shade", "k_tail", "k_commit")},
                            "note": "the BVH and the SD-tree are L2 / Infinity-Cache resident: the algorithmic bytes are what the kernel must read per ray "
-                                   "(cache-oblivious), `traffic` what reaches HBM"}
+                                   "(cache-oblivious), `traffic` what reaches HBM.  k_tail finishes the paths still alive after the wavefront bounces, one lane per "
+                                   "path: it is bound by the latency of the longest path, not by bandwidth (DESIGN.md §7)"}
 
     if rank == 0 and args.gpus == 1 and not args.no_rmse and scene_name == "kitchen" and os.path.exists(KITCHEN_REFERENCE):
         # Time to equal error.  The yardstick is the reference's own converged picture, scenes/kitchen/kitchen-reference.exr (committed as
