@@ -275,6 +275,30 @@ def test_full_size_invariants_improved_configs(which):
         assert abs(pdf.mean() * 4 * np.pi - 1) < 0.03
 
 
+def test_tuning_switches_do_not_change_results(monkeypatch):
+    """DESIGN.md "Tuning switches": the environment switches ppg_create reads select schedules and layouts, never results.  A BVH scene
+    with the full material set, improved preset, unbounded depth (tail + commit on two streams, BSDF-type sort, optimiser rounds)."""
+    import ppg_host
+    scene = ppg_host.room_scene(96, 54, n_boxes=60, tess=2, glossy=True)
+    props = dict(budgetType="spp", budget=31, maxDepth=-1, rrDepth=5, strictNormals=1, seed=3, **IMPROVED)
+
+    def run():
+        e = hip(**props)
+        img = ppg_host.GuidedPathTracer(engine=e).render(scene)
+        return img, e.read_sdtree()
+
+    base_img, base_tree = run()
+    assert np.isfinite(base_img).all() and base_img.mean() > 1e-3
+    for env in (dict(PPG_PATH_LAYOUT="aos"), dict(PPG_NO_OVERLAP="1"), dict(PPG_NO_SORT="1"), dict(PPG_TAIL_MIN="1", PPG_TAIL_DIV="1000000"),
+                dict(PPG_TAIL_THRESHOLD="100000000"), dict(PPG_BLOCKS="512"), dict(PPG_BATCH_PATHS="20000"), dict(PPG_TAIL_BLOCKS="64")):
+        with monkeypatch.context() as m:
+            for k, v in env.items():
+                m.setenv(k, v)
+            img, tree = run()
+        assert np.array_equal(img, base_img), env
+        assert_tree_equal(tree, base_tree)
+
+
 def test_edge_cases(oracle_lib):
     import ppg_host
     # 1x1 film; 1 spp and a single pass (N - 1 = 0 → non-finite variance like the reference's "-1.#INF"); maxDepth = 1
