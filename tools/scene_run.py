@@ -65,7 +65,7 @@ def main():
 
     def sized(wh):
         w, h = (int(v) for v in wh.split("x"))
-        desc.camera = dict(desc.camera, width=w, height=h)
+        desc.camera = ppg_host.resize_camera(desc.camera, w, h)  # keeps the horizontal field of view
         return w, h
     if a.parity:
         w, h = sized(a.parity)
