@@ -439,7 +439,7 @@ struct ppg_ctx {
     bool tuneFuse = false;            // PPG_FUSE: trace small scenes inside k_generate / k_shade
     bool tuneNoSort = false;          // PPG_NO_SORT: do not sort the queue slices by BSDF type before k_shade<FULL>
     bool tuneNoOverlap = false;       // PPG_NO_OVERLAP: k_commit after k_tail on one stream instead of beside it
-    int tuneFinalBatch = 0;           // PPG_FINAL_BATCH: passes per batch of the final iteration (0 = 256)
+    int tuneFinalBatch = 0;           // PPG_FINAL_BATCH: passes per batch of the final iteration (0 = 64)
     int tuneTailBlocks = 0;           // PPG_TAIL_BLOCKS: workgroups of k_tail when k_commit runs beside it (0 = automatic)
     int tunePathLayout = 0;           // PPG_PATH_LAYOUT = aos: per-path state interleaved in 128-byte records instead of one array per field
     int tuneBvhLeaf = 4;              // PPG_BVH_LEAF: triangles per BVH leaf (1..8)
@@ -707,10 +707,12 @@ int allocPaths(ppg_ctx *ctx) {
         }
     }
     {   // the final iteration records nothing: its batches need path state only (96 B per path), so they can be larger — the serial tail of
-        // unbounded paths is then paid once per 256 passes
+        // unbounded paths is then paid once per 64 passes
         const size_t perPass = std::max<size_t>(1, (size_t)ctx->nPix * ctx->sppPerPass);
-        // (64 passes / 2^26 paths -> 256 / 2^28: KITCHEN 700x400 at 2400 spp 5.2 -> 4.9 s, 720p at 511 passes 169 -> 175 Msamples/s)
-        const size_t capPasses = ctx->tuneFinalBatch ? (size_t)ctx->tuneFinalBatch : 256, capPaths = (size_t)1 << (capPasses > 64 ? 28 : 26);
+        // PPG_FINAL_BATCH=256 (2^28 paths): KITCHEN 700x400 at 2400 spp 5.2 -> 4.9 s, 720p at 511 passes 169 -> 175 Msamples/s — but the 23 GB of
+        // path state it sizes cost the FIRST process on a freshly booted GPU box 20 % of a 20-pass render (86 vs 110 Msamples/s; the second
+        // process is at par), so the default stays at 64 passes.
+        const size_t capPasses = ctx->tuneFinalBatch ? (size_t)ctx->tuneFinalBatch : 64, capPaths = (size_t)1 << (capPasses > 64 ? 28 : 26);
         ctx->maxBatchFinal = ctx->budgetType == 1 ? 1 : (int)std::max<size_t>((size_t)ctx->maxBatch, std::min<size_t>(capPasses, capPaths / perPass));
         if (ctx->tuneBatchPaths) ctx->maxBatchFinal = ctx->maxBatch;
     }
