@@ -511,8 +511,8 @@ D unsigned int adam_path_id(const PathState &P, const RenderParams &R, unsigned 
     return (i / P.n_pix) * R.img_pixels + P.pixels[i % P.n_pix];
 }
 
-// DTreeWrapper::record (GP:575-584) incl. the gradient of optimizeBsdfSamplingFraction (GP:672-697);
-// the Adam step itself is taken once per pass by k_adam_step from the exact sums accumulated here.
+// DTreeWrapper::record (GP:575-584); of optimizeBsdfSamplingFraction (GP:672-697)
+// the optimiser's record is only WRITTEN here (position known in advance, or appended); it is applied at the end of the round by k_adam_apply.
 // COMBINE: called by all lanes of a wave (inactive lanes pass active = false); the per-D-tree counters
 // are then pre-combined across the wave.
 template <bool COMBINE>
