@@ -51,6 +51,26 @@ D float max3(F3 s) { return ppg_max(ppg_max(s.x, s.y), s.z); }
 D F3 ld3(const float4 *p) { float4 v = *p; return f3(v.x, v.y, v.z); }
 
 // ------------------------------------------------------------------------------------------------
+// include/ppg_detmath.h on the device: ONE out-of-line copy of each transcendental per kernel module instead of one inlined copy per
+// call site.  Pure register-in / register-out functions (no pointers: nothing is forced into scratch memory); the arithmetic is the
+// header's, so results are unchanged.  Inlined everywhere they were 4 400 of k_tail<FULL>'s 25 000 instructions — a kernel of 135 KB
+// (330 KB before the BSDF call sites were merged) against a 64 KB instruction cache.  -DPPG_INLINE_MATH restores the inlined calls.
+// ------------------------------------------------------------------------------------------------
+#ifdef PPG_INLINE_MATH
+#define DM_ATTR __device__ __forceinline__
+#else
+#define DM_ATTR static __device__ __attribute__((noinline))
+#endif
+DM_ATTR float2 dm_sincos(float x) { float s_, c_; ppg_sincos(x, &s_, &c_); return make_float2(s_, c_); }
+DM_ATTR float dm_atan2(float y, float x) { return ppg_atan2(y, x); }
+DM_ATTR float dm_exp(float x) { return ppg_exp(x); }
+DM_ATTR float dm_log(float x) { return ppg_log(x); }
+D void dm_sincos(float x, float *s, float *c) { const float2 r = dm_sincos(x); *s = r.x; *c = r.y; }
+D float dm_acos(float x) { return dm_atan2(__builtin_sqrtf(ppg_max(0.0f, (1.0f - x) * (1.0f + x))), x); }  // = ppg_acos
+D float dm_tan(float x) { const float2 r = dm_sincos(x); return r.x / r.y; }                                 // = ppg_tan
+D float dm_pow(float x, float y) { return dm_exp(y * dm_log(x)); }                                            // = ppg_pow
+
+// ------------------------------------------------------------------------------------------------
 // Scene
 // ------------------------------------------------------------------------------------------------
 struct BvhNode {  // 64 B
@@ -306,6 +326,17 @@ D Bvh4Hits bvh4_children(const Bvh4QNode *node, F3 o, F3 id, float mint, float t
     return r;
 }
 
+// PPG_PREFETCH: when a node step pushes children, the one that will be popped first (the nearest of the pushed ones) is touched right
+// away — one dword of its node / of its first triangle record, consumed a step later, when it has long arrived — so that the pop finds
+// its line in L2 instead of waiting for HBM / Infinity Cache behind the dependent chain of the subtree visited in between.
+#ifndef PPG_PREFETCH
+#define PPG_PREFETCH 0
+#endif
+D unsigned int bvh4_touch(const DevScene &S, int c) {
+    const unsigned int *pa = c >= 0 ? reinterpret_cast<const unsigned int *>(S.bvh4 + c) : reinterpret_cast<const unsigned int *>(S.accel + 3 * ((~c) >> 3));
+    return *pa;
+}
+
 // Closest hit by (t, original primitive index) through the BVH4 — equals brute force (conservative culling).
 // ANY: return at the first triangle hit (shadow rays; only prim >= 0 is meaningful then).
 // VOTE: as in k_trace, lanes holding a leaf wait until PPG_LEAF_VOTE lanes of the wave do (or none has an interior node left) — for callers
@@ -321,6 +352,9 @@ D Hit trace_closest4(const DevScene &S, int *lds_stack_col, int stride, F3 o, F3
     st.over = st_over;
     st.lds = lds_stack_col; st.stride = stride; st.sp = 0;
     int cur = 0;
+#if PPG_PREFETCH
+    unsigned int pf_acc = 0, pf_pending = 0;
+#endif
     for (;;) {  // one step per iteration: an interior node or a leaf popped from the stack (see trace_slice_bvh4)
         bool doLeaves = true;
         if (VOTE) {
@@ -329,6 +363,10 @@ D Hit trace_closest4(const DevScene &S, int *lds_stack_col, int stride, F3 o, F3
         }
         if (cur >= 0) {
             const Bvh4Hits hc = bvh4_children(S.bvh4 + cur, o, id, mint, fminf(maxt, best.t));
+#if PPG_PREFETCH
+            pf_acc ^= pf_pending; pf_pending = 0;
+            if (hc.m > 1) pf_pending = bvh4_touch(S, hc.c1);
+#endif
             if (hc.m > 0) {
                 if (hc.m > 3) st.push(hc.c3);
                 if (hc.m > 2) st.push(hc.c2);
@@ -354,6 +392,10 @@ D Hit trace_closest4(const DevScene &S, int *lds_stack_col, int stride, F3 o, F3
             cur = st.pop();
         }
     }
+#if PPG_PREFETCH
+    pf_acc ^= pf_pending;
+    asm volatile("" ::"v"(pf_acc));
+#endif
     if (SPH && S.n_spheres) sphere_pass<ANY>(S, o, d, mint, maxt, best);
     return best;
 }
@@ -630,7 +672,7 @@ D bool finitef(float v) { return (ppg_f2u(v) & 0x7f800000u) != 0x7f800000u; }
 // evalEnvironment (envmap.cpp:381-407) of a ray without differentials travelling along the world direction d
 D F3 envmap_eval(const DevScene &S, F3 dWorld) {
     const F3 v = envmap_to_local(S, dWorld);
-    const float uvx = ppg_atan2(v.x, -v.z) * (PPG_INV_PI_F * 0.5f), uvy = ppg_acos(v.y) * PPG_INV_PI_F;
+    const float uvx = dm_atan2(v.x, -v.z) * (PPG_INV_PI_F * 0.5f), uvy = dm_acos(v.y) * PPG_INV_PI_F;
     if (!finitef(uvx) || !finitef(uvy)) return f3s(0.0f);
     const float u = uvx * S.em_w - 0.5f, vv = uvy * S.em_h - 0.5f;
     const int xPos = (int)__builtin_floorf(u), yPos = (int)__builtin_floorf(vv);
@@ -673,14 +715,14 @@ D void envmap_sample_direction(const DevScene &S, float sx, float sy, F3 &d, F3 
     value = (value1 + value2) * S.em_scale;
     pdf = (lum3(value1) * S.em_row_weights[envmap_clamp_row(S, yPos)] + lum3(value2) * S.em_row_weights[envmap_clamp_row(S, yPos + 1)]) * S.em_norm;
     float sinPhi, cosPhi, sinTheta, cosTheta;
-    ppg_sincos(S.em_px * (posX + 0.5f), &sinPhi, &cosPhi);
-    ppg_sincos(S.em_py * (posY + 0.5f), &sinTheta, &cosTheta);
+    dm_sincos(S.em_px * (posX + 0.5f), &sinPhi, &cosPhi);
+    dm_sincos(S.em_py * (posY + 0.5f), &sinTheta, &cosTheta);
     d = f3(sinPhi * sinTheta, cosTheta, -cosPhi * sinTheta);
     pdf /= ppg_max(ppg_abs(sinTheta), PPG_EPSILON);
 }
 // internalPdfDirection (envmap.cpp:598-633): direction in the emitter's frame
 D float envmap_pdf_direction(const DevScene &S, F3 d) {
-    const float uvx = ppg_atan2(d.x, -d.z) * (PPG_INV_PI_F * 0.5f), uvy = ppg_acos(d.y) * PPG_INV_PI_F;
+    const float uvx = dm_atan2(d.x, -d.z) * (PPG_INV_PI_F * 0.5f), uvy = dm_acos(d.y) * PPG_INV_PI_F;
     if (!finitef(uvx) || !finitef(uvy)) return 0.0f;
     const float u = uvx * S.em_w - 0.5f, v = uvy * S.em_h - 0.5f;
     const int xPos = (int)__builtin_floorf(u), yPos = (int)__builtin_floorf(v);
@@ -731,7 +773,7 @@ D F3 env_sample_direct(const DevScene &S, F3 ref, F3 refN, float sx, float sy, D
         float z = 1.0f - 2.0f * sy;  // warp::squareToUniformSphere, warp.cpp:25-31
         float r = __builtin_sqrtf(ppg_max(0.0f, 1.0f - z * z));
         float sinPhi, cosPhi;
-        ppg_sincos(2.0f * PPG_PI_F * sx, &sinPhi, &cosPhi);
+        dm_sincos(2.0f * PPG_PI_F * sx, &sinPhi, &cosPhi);
         d = f3(r * cosPhi, r * sinPhi, z);
         pdf = PPG_INV_PI_F * 0.25f;
     }
@@ -765,7 +807,7 @@ D void sphere_sample_direct(const float4 *Q, F3 ref, float sx, float sy, DirectS
         const float cosTheta = (1 - sx) + sx * cosAlpha;  // warp::squareToUniformCone, warp.cpp:54-63
         const float sinTheta = __builtin_sqrtf(ppg_max(0.0f, 1.0f - cosTheta * cosTheta));
         float sinPhi, cosPhi;
-        ppg_sincos(2.0f * PPG_PI_F * sy, &sinPhi, &cosPhi);
+        dm_sincos(2.0f * PPG_PI_F * sy, &sinPhi, &cosPhi);
         const F3 lv = f3(cosPhi * sinTheta, sinPhi * sinTheta, cosTheta);
         const F3 a = refToCenter * invRefDist;  // Frame(a): coordinateSystem, util.cpp:592-601
         F3 sF, tF;
@@ -806,7 +848,7 @@ D void sphere_sample_direct(const float4 *Q, F3 ref, float sx, float sy, DirectS
         const float z = 1.0f - 2.0f * sy;
         const float r = __builtin_sqrtf(ppg_max(0.0f, 1.0f - z * z));
         float sinPhi, cosPhi;
-        ppg_sincos(2.0f * PPG_PI_F * sx, &sinPhi, &cosPhi);
+        dm_sincos(2.0f * PPG_PI_F * sx, &sinPhi, &cosPhi);
         const F3 dv = f3(r * cosPhi, r * sinPhi, z);
         const F3 p = c + dv * radius;
         ds.n = dv;
@@ -914,7 +956,7 @@ D void disk_concentric(float sx, float sy, float &px, float &py) {
         phi = (PPG_PI_F / 2.0f) - (r1 / r2) * (PPG_PI_F / 4.0f);
     }
     float c, s;
-    ppg_sincos(phi, &s, &c);
+    dm_sincos(phi, &s, &c);
     px = r * c; py = r * s;
 }
 D F3 cosine_hemisphere(float sx, float sy) {
@@ -1052,7 +1094,7 @@ D F3 fresnel_conductor_exact(float cosThetaI, F3 eta, F3 k) {
 
 // math.cpp:25-72
 D float mts_erfinv(float x) {
-    float w = -ppg_log((1.0f - x) * (1.0f + x));
+    float w = -dm_log((1.0f - x) * (1.0f + x));
     float p;
     if (w < 5.0f) {
         w = w - 2.5f;
@@ -1084,7 +1126,7 @@ D float mts_erf(float x) {
     const float sign = (ppg_f2u(x) >> 31) ? -1.0f : 1.0f;
     x = ppg_abs(x);
     float t = 1.0f / (1.0f + p * x);
-    float y = 1.0f - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * ppg_exp(-x * x);
+    float y = 1.0f - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * dm_exp(-x * x);
     return sign * y;
 }
 
@@ -1097,7 +1139,7 @@ D float ggx_eval(Mfd d, F3 m) {
     float beckmannExponent = ((m.x * m.x) / (alpha * alpha) + (m.y * m.y) / (alpha * alpha)) / cosTheta2;
     float result;
     if (d.beckmann) {
-        result = ppg_exp(-beckmannExponent) / (PPG_PI_F * alpha * alpha * cosTheta2 * cosTheta2);
+        result = dm_exp(-beckmannExponent) / (PPG_PI_F * alpha * alpha * cosTheta2 * cosTheta2);
     } else {
         float root = (1.0f + beckmannExponent) * cosTheta2;
         result = 1.0f / (PPG_PI_F * alpha * alpha * root * root);
@@ -1134,23 +1176,23 @@ D void beckmann_sample_visible11(float thetaI, float u, float v, float &sx, floa
     const float SQRT_PI_INV = 1 / __builtin_sqrtf(PPG_PI_F);
     if (thetaI < 1e-4f) {
         float sinPhi, cosPhi;
-        float r = __builtin_sqrtf(-ppg_log(1.0f - u));
-        ppg_sincos(2 * PPG_PI_F * v, &sinPhi, &cosPhi);
+        float r = __builtin_sqrtf(-dm_log(1.0f - u));
+        dm_sincos(2 * PPG_PI_F * v, &sinPhi, &cosPhi);
         sx = r * cosPhi; sy = r * sinPhi;
         return;
     }
-    float tanThetaI = ppg_tan(thetaI);
+    float tanThetaI = dm_tan(thetaI);
     float cotThetaI = 1 / tanThetaI;
     float a = -1, c = mts_erf(cotThetaI);
     float sample_x = ppg_max(u, 1e-6f);
     float fit = 1 + thetaI * (-0.876f + thetaI * (0.4265f - 0.0594f * thetaI));
-    float b = c - (1 + c) * ppg_pow(1 - sample_x, fit);
-    float normalization = 1 / (1 + c + SQRT_PI_INV * tanThetaI * ppg_exp(-cotThetaI * cotThetaI));
+    float b = c - (1 + c) * dm_pow(1 - sample_x, fit);
+    float normalization = 1 / (1 + c + SQRT_PI_INV * tanThetaI * dm_exp(-cotThetaI * cotThetaI));
     int it = 0;
     while (++it < 10) {
         if (!(b >= a && b <= c)) b = 0.5f * (a + c);
         float invErf = mts_erfinv(b);
-        float value = normalization * (1 + b + SQRT_PI_INV * tanThetaI * ppg_exp(-invErf * invErf)) - sample_x;
+        float value = normalization * (1 + b + SQRT_PI_INV * tanThetaI * dm_exp(-invErf * invErf)) - sample_x;
         float derivative = normalization * (1 - invErf * tanThetaI);
         if (ppg_abs(value) < 1e-5f) break;
         if (value > 0) c = b;
@@ -1164,11 +1206,11 @@ D void ggx_sample_visible11(float thetaI, float u, float v, float &sx, float &sy
     if (thetaI < 1e-4f) {
         float sinPhi, cosPhi;
         float r = __builtin_sqrtf(ppg_max(0.0f, u / (1 - u)));
-        ppg_sincos(2 * PPG_PI_F * v, &sinPhi, &cosPhi);
+        dm_sincos(2 * PPG_PI_F * v, &sinPhi, &cosPhi);
         sx = r * cosPhi; sy = r * sinPhi;
         return;
     }
-    float tanThetaI = ppg_tan(thetaI);
+    float tanThetaI = dm_tan(thetaI);
     float a = 1 / tanThetaI;
     float G1 = 2.0f / (1.0f + __builtin_sqrtf(ppg_max(0.0f, 1.0f + 1.0f / (a * a))));
     float A = 2.0f * u / G1 - 1.0f;
@@ -1191,11 +1233,11 @@ D F3 ggx_sample_visible(Mfd d, F3 _wi, float u, float v) {
     F3 wi = norm3(f3(alpha * _wi.x, alpha * _wi.y, _wi.z));
     float theta = 0, phi = 0;
     if (wi.z < 0.99999f) {
-        theta = ppg_acos(wi.z);
-        phi = ppg_atan2(wi.y, wi.x);
+        theta = dm_acos(wi.z);
+        phi = dm_atan2(wi.y, wi.x);
     }
     float sinPhi, cosPhi;
-    ppg_sincos(phi, &sinPhi, &cosPhi);
+    dm_sincos(phi, &sinPhi, &cosPhi);
     float sx, sy;
     if (d.beckmann) beckmann_sample_visible11(theta, u, v, sx, sy);
     else ggx_sample_visible11(theta, u, v, sx, sy);
@@ -1235,7 +1277,7 @@ D float cubic_interp_1d(float x, const float *values, int size) {
 }
 // roughplastic: m_externalRoughTransmittance->eval(cosTheta, alpha), eta and alpha fixed (rtrans.h:185-196, 233)
 D float rough_T(const Mat &M, float cosTheta) {
-    const float warped = ppg_pow(ppg_abs(cosTheta), 0.25f);
+    const float warped = dm_pow(ppg_abs(cosTheta), 0.25f);
     if (!(cosTheta >= 0)) return 0.0f;
     return ppg_min(1.0f, ppg_max(0.0f, cubic_interp_1d(warped, M.rt, M.rt_n)));
 }
@@ -1514,20 +1556,24 @@ D F3 mat_sample_ts(const Mat &M, F3 wi, float sx, float sy, F3 &wo, float &pdf, 
 // key / dim: the path's sampler, for plug-ins whose sample() draws from it (roughdielectric)
 D F3 mat_sample(const Mat &M, F3 wi, float sx, float sy, F3 &wo, float &pdf, bool &delta, float &eta, bool &isnull, unsigned int key,
                 unsigned int &dim) {
-    if (!mat_masked(M)) return mat_sample_ts(M, wi, sx, sy, wo, pdf, delta, eta, isnull, key, dim);
-    const float prob = lum3(M.opacity);
-    if (sx < prob) {
-        sx /= prob;
-        F3 result = div3(mul3(mat_sample_ts(M, wi, sx, sy, wo, pdf, delta, eta, isnull, key, dim), M.opacity), prob);
-        pdf *= prob;
-        return result;
+    // (ONE call of the nested BSDF's sample(): see the note on code size in shade_one)
+    const bool masked = mat_masked(M);
+    const float prob = masked ? lum3(M.opacity) : 1.0f;
+    if (masked && !(sx < prob)) {
+        wo = -wi;
+        eta = 1.0f;
+        delta = true;
+        isnull = true;
+        pdf = 1 - prob;
+        return div3(f3s(1.0f) - M.opacity, pdf);
     }
-    wo = -wi;
-    eta = 1.0f;
-    delta = true;
-    isnull = true;
-    pdf = 1 - prob;
-    return div3(f3s(1.0f) - M.opacity, pdf);
+    if (masked) sx /= prob;
+    F3 result = mat_sample_ts(M, wi, sx, sy, wo, pdf, delta, eta, isnull, key, dim);
+    if (masked) {
+        result = div3(mul3(result, M.opacity), prob);
+        pdf *= prob;
+    }
+    return result;
 }
 D F3 mat_sample_ts(const Mat &M, F3 wi, float sx, float sy, F3 &wo, float &pdf, bool &delta, float &eta, bool &isnull, unsigned int key,
                    unsigned int &dim) {
@@ -1648,13 +1694,13 @@ D F3 canonical_to_dir(float px, float py) {
     const float phi = 2 * PPG_PI_F * py;
     const float sinTheta = __builtin_sqrtf(1 - cosTheta * cosTheta);
     float sinPhi, cosPhi;
-    ppg_sincos(phi, &sinPhi, &cosPhi);
+    dm_sincos(phi, &sinPhi, &cosPhi);
     return f3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
 }
 D void dir_to_canonical(F3 d, float &px, float &py) {
     if (!ppg_isfinite(d.x) || !ppg_isfinite(d.y) || !ppg_isfinite(d.z)) { px = 0; py = 0; return; }
     const float cosTheta = ppg_min(ppg_max(d.z, -1.0f), 1.0f);
-    float phi = ppg_atan2(d.y, d.x);
+    float phi = dm_atan2(d.y, d.x);
     while (phi < 0) phi = (float)((double)phi + 2.0 * (double)PPG_PI_F);
     px = (cosTheta + 1) / 2;
     py = phi / (2 * PPG_PI_F);
@@ -1799,6 +1845,6 @@ struct RegColumn {
     D float &operator[](int i) { return v[i]; }
 };
 
-D float logistic(float x) { return 1 / (1 + ppg_exp(-x)); }  // GP:64-66
+D float logistic(float x) { return 1 / (1 + dm_exp(-x)); }  // GP:64-66
 
 #endif

@@ -73,6 +73,9 @@ struct Field {
 
 struct PathState {
     unsigned int n_paths;  // n_pix * spp
+    // A batch may run as several SUB-BATCHES one after the other (paths [first, first + n_sub)): the persistent-thread tail of one
+    // sub-batch then runs on a stream of its own beside the wavefront bounces of the next ones (ppg_hip.hip renderBatch).
+    unsigned int first, n_sub;
     unsigned int n_pix;    // owned pixels
     const unsigned int *pixels;  // owned pixel list (row-major pixel indices)
     Field<float4> ray_o;   // (o, mint)
@@ -98,18 +101,32 @@ struct PathState {
 struct BlockStats {
     unsigned long long rays, path_len, committed;
     unsigned long long bvh_nodes, bvh_tris;  // k_trace<.., COUNT>: BVH4 nodes visited / triangles tested (kernel timing runs only: the roofline's n, t)
+    unsigned long long max_len;              // longest path finished by k_tail (diagnostics: PPG_DEBUG_BATCH)
 };
 
-// Queues: workgroup b owns entries [b * cap, b * cap + count[b]).  Paths are dealt to workgroups in chunks of
-// PPG_CHUNK consecutive indices at the first bounce and stay with their workgroup, so compaction needs
-// only an LDS counter and queue reads/writes stay coalesced.
+// Queues.  Every wavefront bounce reads the DENSE list of live paths (items[1], dense_n entries), dealt to the persistent workgroups in
+// chunks of PPG_DCHUNK, and k_shade appends the survivors to its workgroup's own slice of items[0] (entries [b * cap, b * cap + count[0][b]):
+// compaction needs only an LDS counter, no global atomics).  k_scan_counts + k_gather_slices then rebuild the dense list — two tiny launches
+// per bounce.  (Until round 3 a workgroup kept its slice for the whole batch; once fewer paths are alive than the GPU has lanes, every one
+// of the 4096 workgroups then still holds a few paths and every launch costs several rounds of almost empty workgroups — KITCHEN 720p, one pass
+// in flight: k_trace took 0.5 ms per bounce whether 920 k or 300 k rays were left.)
 struct Queues {
-    unsigned int *items[2];
-    unsigned int *count[2];  // [n_blocks]
-    unsigned int cap;        // entries per workgroup
+    unsigned int *items[2];  // [0]: k_shade's output slices; [1]: the dense list
+    unsigned int *count[2];  // [0][b]: entries of output slice b; [1][b]: entries of workgroup b's slice of the sorted list (k_sort_slices)
+    unsigned int cap;        // entries per workgroup slice
     unsigned int n_blocks;
     BlockStats *stats;       // [n_blocks]
+    const unsigned long long *dense_n;  // entries of the dense list
+    const unsigned int *stop;           // != 0: the batch has gone to the persistent threads (k_tail); wavefront kernels launched after that return at once
 };
+
+// what a wavefront kernel reads (its `qin` argument)
+#define QIN_FIRST (-1)   // bounce 1: every path of the batch, dealt in chunks of PPG_CHUNK (a wave = 64 neighbouring pixels)
+#define QIN_DENSE (-2)   // the dense list, dealt in chunks of PPG_DCHUNK
+#define QIN_SORTED (-3)  // k_shade after k_sort_slices: the workgroup's share of the dense list, re-ordered, in its slice of `sorted_items`
+#ifndef PPG_DCHUNK
+#define PPG_DCHUNK 256
+#endif
 
 // wave-aggregated append to the workgroup's queue slice: one LDS atomic per wave
 D unsigned int queue_append(unsigned int *lds_counter, bool pred) {
@@ -144,6 +161,41 @@ D unsigned int first_share(unsigned int n_paths, unsigned int b, unsigned int nb
 }
 D unsigned int first_path(unsigned int k, unsigned int b, unsigned int nb) { return ((k / PPG_CHUNK) * nb + b) * PPG_CHUNK + (k % PPG_CHUNK); }
 
+
+// the same dealing of the dense list, in chunks of PPG_DCHUNK (one workgroup's worth: with fewer live paths than lanes the busy workgroups
+// are full and the others return at once)
+D unsigned int dense_share(unsigned int n, unsigned int b, unsigned int nb) {  // exact: the last chunk of the list may be partial
+    const unsigned int chunks = (n + PPG_DCHUNK - 1) / PPG_DCHUNK;
+    const unsigned int mine = chunks > b ? (chunks - b + nb - 1) / nb : 0;
+    if (mine == 0) return 0;
+    const unsigned int last = (mine - 1) * nb + b;  // this workgroup's last chunk
+    const unsigned int tail = n - last * PPG_DCHUNK;
+    return (mine - 1) * PPG_DCHUNK + (tail < PPG_DCHUNK ? tail : PPG_DCHUNK);
+}
+D unsigned int dense_index(unsigned int k, unsigned int b, unsigned int nb) { return ((k / PPG_DCHUNK) * nb + b) * PPG_DCHUNK + (k % PPG_DCHUNK); }
+
+// The work of workgroup b in a wavefront kernel: `count` positions, position k holds path work_item(k).
+struct Work {
+    const unsigned int *items;
+    unsigned int count;
+    unsigned int first, n_sub;  // mode 0: the sub-batch's range of paths
+    int mode;  // 0: first bounce (work_item returns ~0 beyond the sub-batch: the last chunk may be partial), 1: items[k], 2: items[dense_index(k)]
+};
+D Work work_of(const PathState &P, const Queues &Q, int qin, const unsigned int *sorted_items, unsigned int b, unsigned int nb) {
+    Work w;
+    w.first = P.first; w.n_sub = P.n_sub;
+    if (qin == QIN_FIRST) { w.items = nullptr; w.count = first_share(P.n_sub, b, nb); w.mode = 0; }
+    else if (qin == QIN_SORTED && sorted_items) { w.items = sorted_items + (size_t)b * Q.cap; w.count = Q.count[1][b]; w.mode = 1; }
+    else { w.items = Q.items[1]; w.count = dense_share((unsigned int)*Q.dense_n, b, nb); w.mode = 2; }
+    return w;
+}
+D unsigned int work_item(const Work &w, unsigned int k, unsigned int b, unsigned int nb) {
+    if (w.mode == 0) {
+        const unsigned int idx = first_path(k, b, nb);
+        return idx < w.n_sub ? w.first + idx : 0xffffffffu;
+    }
+    return w.items[w.mode == 2 ? dense_index(k, b, nb) : k];
+}
 
 // Keyed accumulation with wave-level pre-combination: lanes of a wave that add to the same key are summed
 // in registers and issue ONE atomic (up to ROUNDS distinct keys are combined, the rest go out directly).
@@ -222,7 +274,8 @@ __global__ __launch_bounds__(PPG_BLOCK) void k_generate(PathState P, DevScene S,
         __syncthreads();
     }
     unsigned int traced = 0;
-    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < P.n_paths; i += gridDim.x * blockDim.x) {
+    for (unsigned int i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < P.n_sub; i0 += gridDim.x * blockDim.x) {
+        const unsigned int i = P.first + i0;
         unsigned int k = i % P.n_pix, j = i / P.n_pix;
         unsigned int pixel = P.pixels[k];
         unsigned int key = ppg_path_key(R.seed, pixel, R.pass_index_spp + j);
@@ -274,8 +327,9 @@ D LdsScene stage_scene(const DevScene &S, unsigned char *lds_raw, int lds_nodes,
 // entry of the slice (LDS ticket), so a wave stays full until the slice is empty instead of idling until its
 // longest ray is done — secondary rays are incoherent and their traversal lengths differ by an order of magnitude.
 template <bool COUNT>
-D void trace_slice_bvh4(const PathState &P, const DevScene &S, int *lds_stack, unsigned int *ticket, const unsigned int *items,
-                        unsigned int count, unsigned int b, unsigned int nb, unsigned int &traced, unsigned long long &n_nodes, unsigned long long &n_tris) {
+D void trace_slice_bvh4(const PathState &P, const DevScene &S, int *lds_stack, unsigned int *ticket, const Work &work,
+                        unsigned int b, unsigned int nb, unsigned int &traced, unsigned long long &n_nodes, unsigned long long &n_tris) {
+    const unsigned int count = work.count;
     if (threadIdx.x == 0) *ticket = 0;
     __syncthreads();
     TStack st;
@@ -289,11 +343,14 @@ D void trace_slice_bvh4(const PathState &P, const DevScene &S, int *lds_stack, u
     Hit best;
     best.t = 0; best.u = 0; best.v = 0; best.prim = -1;
     int bestOrig = 0, cur = 0;
+#if PPG_PREFETCH
+    unsigned int pf_acc = 0, pf_pending = 0;
+#endif
     for (;;) {
         if (!have) {
             unsigned int k = atomicAdd(ticket, 1u);
             if (k >= count) break;
-            i = items ? items[k] : first_path(k, b, nb);
+            i = work_item(work, k, b, nb);
             if (i >= P.n_paths) continue;
             float4 ro = P.ray_o[i], rd = P.ray_d[i];
             o = f3(ro.x, ro.y, ro.z); d = f3(rd.x, rd.y, rd.z);
@@ -321,6 +378,10 @@ D void trace_slice_bvh4(const PathState &P, const DevScene &S, int *lds_stack, u
         if (cur >= 0) {
             if (COUNT) ++n_nodes;
             const Bvh4Hits hc = bvh4_children(S.bvh4 + cur, o, id, mint, fminf(maxt, best.t));
+#if PPG_PREFETCH
+            pf_acc ^= pf_pending; pf_pending = 0;
+            if (hc.m > 1) pf_pending = bvh4_touch(S, hc.c1);
+#endif
             if (hc.m > 0) {
                 if (hc.m > 3) st.push(hc.c3);
                 if (hc.m > 2) st.push(hc.c2);
@@ -348,19 +409,28 @@ D void trace_slice_bvh4(const PathState &P, const DevScene &S, int *lds_stack, u
             have = false;
         }
     }
+#if PPG_PREFETCH
+    pf_acc ^= pf_pending;
+    asm volatile("" ::"v"(pf_acc));
+#endif
     __syncthreads();
 }
 
 // trace the rays of one queue slice
 template <bool SMALL, bool COUNT>
-D void trace_slice(const PathState &P, const DevScene &S, const LdsScene &L, int *lds_stack, unsigned int *ticket, const unsigned int *items,
-                   unsigned int count, unsigned int b, unsigned int nb, unsigned int &traced, unsigned long long &n_nodes, unsigned long long &n_tris) {
+D void trace_slice(const PathState &P, const DevScene &S, const LdsScene &L, int *lds_stack, unsigned int *ticket, const Work &work,
+                   unsigned int b, unsigned int nb, unsigned int &traced, unsigned long long &n_nodes, unsigned long long &n_tris) {
     if (!SMALL) {
-        trace_slice_bvh4<COUNT>(P, S, lds_stack, ticket, items, count, b, nb, traced, n_nodes, n_tris);
+        trace_slice_bvh4<COUNT>(P, S, lds_stack, ticket, work, b, nb, traced, n_nodes, n_tris);
         return;
     }
+    const unsigned int *items = work.items;
+    const unsigned int count = work.count;
+    const bool dense = work.mode == 2;
     for (unsigned int k = threadIdx.x; k < count; k += blockDim.x) {
-        unsigned int i = items ? items[k] : first_path(k, b, nb);
+        unsigned int i;
+        if (items) i = items[dense ? dense_index(k, b, nb) : k];
+        else { const unsigned int idx = first_path(k, b, nb); i = idx < work.n_sub ? work.first + idx : 0xffffffffu; }
         if (i >= P.n_paths) continue;
         float4 ro = P.ray_o[i], rd = P.ray_d[i];
         F3 o = f3(ro.x, ro.y, ro.z), d = f3(rd.x, rd.y, rd.z);
@@ -380,22 +450,23 @@ __global__ __launch_bounds__(PPG_BLOCK) void k_trace(PathState P, DevScene S, Qu
     __shared__ unsigned long long acc;
     __shared__ unsigned int ticket;
     const unsigned int b = blockIdx.x, nb = gridDim.x;
-    const unsigned int count = qin >= 0 ? Q.count[qin][b] : first_share(P.n_paths, b, nb);
-    if (count == 0) return;  // (uniform per workgroup)
+    const bool stopped = Q.stop && *Q.stop;
+    Work work = work_of(P, Q, qin, nullptr, b, nb);
+    if (stopped) work.count = 0;
+    if (work.count == 0) return;  // (uniform per workgroup)
     // dynamic LDS: SMALL → the triangles; otherwise the traversal stacks [PPG_LDS_STACK][PPG_BLOCK]
     LdsScene L;
     if (SMALL) L = stage_scene(S, lds_raw, 0, lds_tris);
     else { L.nodes = nullptr; L.tris = nullptr; L.n_nodes = 0; L.n_tris = 0; }
-    const unsigned int *items = qin >= 0 ? Q.items[qin] + (size_t)b * Q.cap : nullptr;
     unsigned int traced = 0;
     unsigned long long n_nodes = 0, n_tris = 0;
-    trace_slice<SMALL, COUNT>(P, S, L, (int *)lds_raw, &ticket, items, count, b, nb, traced, n_nodes, n_tris);
+    trace_slice<SMALL, COUNT>(P, S, L, (int *)lds_raw, &ticket, work, b, nb, traced, n_nodes, n_tris);
     block_add_u64(&acc, &Q.stats[b].rays, traced);
     if (COUNT) { block_add_u64(&acc, &Q.stats[b].bvh_nodes, n_nodes); block_add_u64(&acc, &Q.stats[b].bvh_tris, n_tris); }
 }
 
 // grid[cell] for stree_lookup: descend at most PPG_GRID_LEVELS levels along the cell's coordinate bits
-__global__ void k_build_grid(const int4 *stree, unsigned int *grid) {
+static __global__ void k_build_grid(const int4 *stree, unsigned int *grid) {
     unsigned int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= PPG_GRID_DIM * PPG_GRID_DIM * PPG_GRID_DIM) return;
     unsigned int coord[3] = {c % PPG_GRID_DIM, (c / PPG_GRID_DIM) % PPG_GRID_DIM, c / (PPG_GRID_DIM * PPG_GRID_DIM)};
@@ -864,37 +935,40 @@ D bool shade_one(const PathState &P, const DevScene &S, const DevTree &T, const 
             if (X.tex & 0xffffu) M.refl = tex_eval(S.textures[(X.tex & 0xffffu) - 1u], X.u, X.v);
             if (X.tex >> 16) { bump_frame(S, I, X, ps, pt, pn); bumped = true; }
         }
+        // (one call site per BSDF function: the bumped variant only transforms the arguments first — two inlined copies of the whole
+        // material switch per function made the FULL kernels 330 KB of code, five times the instruction cache)
         auto to_pert = [&](F3 v_) { const F3 w_ = to_world(I, v_); return f3(dot3(w_, ps), dot3(w_, pt), dot3(w_, pn)); };
         auto b_eval = [&](F3 wi_, F3 wo_) {
-            if (FULL && bumped) {
-                const F3 wip = to_pert(wi_), wop = to_pert(wo_);
-                if (wo_.z * wop.z <= 0) return f3s(0.0f);
-                return mat_eval(M, wip, wop);
+            if (!FULL) return bsdf_eval(M.type, M.refl, wi_, wo_);
+            F3 wia = wi_, woa = wo_;
+            if (bumped) {
+                wia = to_pert(wi_); woa = to_pert(wo_);
+                if (wo_.z * woa.z <= 0) return f3s(0.0f);
             }
-            return FULL ? mat_eval(M, wi_, wo_) : bsdf_eval(M.type, M.refl, wi_, wo_);
+            return mat_eval(M, wia, woa);
         };
         auto b_pdf = [&](F3 wi_, F3 wo_) {
-            if (FULL && bumped) {
-                const F3 wip = to_pert(wi_), wop = to_pert(wo_);
-                if (wo_.z * wop.z <= 0) return 0.0f;
-                return mat_pdf(M, wip, wop);
+            if (!FULL) return bsdf_pdf(M.type, wi_, wo_);
+            F3 wia = wi_, woa = wo_;
+            if (bumped) {
+                wia = to_pert(wi_); woa = to_pert(wo_);
+                if (wo_.z * woa.z <= 0) return 0.0f;
             }
-            return FULL ? mat_pdf(M, wi_, wo_) : bsdf_pdf(M.type, wi_, wo_);
+            return mat_pdf(M, wia, woa);
         };
         float sampledEta = 1.0f;
         bool sampledNull = false;
         auto b_sample = [&](float u_, float v_, F3 &wo_, float &pdf_, bool &delta_) {
-            if (FULL && bumped) {
-                F3 wop = f3s(0.0f);
-                F3 result = mat_sample(M, to_pert(I.wi), u_, v_, wop, pdf_, delta_, sampledEta, sampledNull, key, dim);
+            if (!FULL) return bsdf_sample(M.type, M.refl, I.wi, u_, v_, wo_, pdf_, delta_);
+            F3 wop = f3s(0.0f);
+            F3 result = mat_sample(M, bumped ? to_pert(I.wi) : I.wi, u_, v_, wop, pdf_, delta_, sampledEta, sampledNull, key, dim);
+            if (bumped) {
                 if (!iszero3(result)) {
                     wo_ = to_local(I, ps * wop.x + pt * wop.y + pn * wop.z);
                     if (wo_.z * wop.z <= 0) result = f3s(0.0f);
                 }
-                return result;
-            }
-            return FULL ? mat_sample(M, I.wi, u_, v_, wo_, pdf_, delta_, sampledEta, sampledNull, key, dim)
-                        : bsdf_sample(M.type, M.refl, I.wi, u_, v_, wo_, pdf_, delta_);
+            } else wo_ = wop;
+            return result;
         };
         F3 vox = f3s(0.0f);
         int leaf = 0;
@@ -1092,19 +1166,19 @@ D bool shade_one(const PathState &P, const DevScene &S, const DevTree &T, const 
 
 // One queue slice through Li's loop body.
 template <bool FUSED, bool NEE, bool FULL>
-D void shade_slice(const PathState &P, const DevScene &S, const DevTree &T, const RenderParams &R, const unsigned int *items, unsigned int count,
+D void shade_slice(const PathState &P, const DevScene &S, const DevTree &T, const RenderParams &R, const Work &work,
                    unsigned int b, unsigned int nb, unsigned int *out_items, unsigned int *out_count, const LdsColumn &fcol,
                    const float4 *lds_tris, unsigned long long &plen_sum, unsigned int &traced, const NeeLds &nee,
                    unsigned long long &committed) {
-    const unsigned int rounds = (count + PPG_BLOCK - 1) / PPG_BLOCK;
+    const unsigned int rounds = (work.count + PPG_BLOCK - 1) / PPG_BLOCK;
     for (unsigned int r = 0; r < rounds; ++r) {
         unsigned int q = r * PPG_BLOCK + threadIdx.x;
-        bool active = q < count;
+        bool active = q < work.count;
         bool alive = false;
         unsigned long long plen = 0;
         unsigned int i = 0;
         if (active) {
-            i = items ? items[q] : first_path(q, b, nb);
+            i = work_item(work, q, b, nb);
             active = i < P.n_paths;
         }
         if (active) {
@@ -1117,7 +1191,7 @@ D void shade_slice(const PathState &P, const DevScene &S, const DevTree &T, cons
 }
 
 template <bool FUSED, bool NEE, bool FULL>
-__global__ __launch_bounds__(PPG_BLOCK, (FULL ? PPG_SHADE_WAVES_FULL : PPG_SHADE_WAVES)) void k_shade(PathState P, DevScene S, DevTree T, RenderParams R, Queues Q, int qin, int qout,
+__global__ __launch_bounds__(PPG_BLOCK, (FULL ? PPG_SHADE_WAVES_FULL : PPG_SHADE_WAVES)) void k_shade(PathState P, DevScene S, DevTree T, RenderParams R, Queues Q, int qin,
                                                                      int small_scene, const unsigned int *sorted_items) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __shared__ float pdf_factors[20 * PPG_BLOCK];  // QuadTreeNode::pdf's per-level factors (tree depth <= 20, GP:1112)
@@ -1134,17 +1208,17 @@ __global__ __launch_bounds__(PPG_BLOCK, (FULL ? PPG_SHADE_WAVES_FULL : PPG_SHADE
     nee.stack_col = (int *)lds_raw + threadIdx.x;
     const LdsColumn fcol{pdf_factors + threadIdx.x, PPG_BLOCK};
     const unsigned int b = blockIdx.x, nb = gridDim.x;
-    const unsigned int count = qin >= 0 ? Q.count[qin][b] : first_share(P.n_paths, b, nb);
-    // sorted_items: this bounce's slice re-ordered by the BSDF type at the new hit (k_sort_slices); same items, other order
-    const unsigned int *items = qin >= 0 ? (sorted_items ? sorted_items : Q.items[qin]) + (size_t)b * Q.cap : nullptr;
+    if (Q.stop && *Q.stop) return;
+    // QIN_SORTED: the workgroup's share of the dense list re-ordered by the BSDF type at the new hit (k_sort_slices); same paths, other order
+    const Work work = work_of(P, Q, qin, sorted_items, b, nb);
     if (threadIdx.x == 0) out_count = 0;
     __syncthreads();
     unsigned long long plen_sum = 0, committed = 0;
     unsigned int traced = 0;
-    shade_slice<FUSED, NEE, FULL>(P, S, T, R, items, count, b, nb, Q.items[qout] + (size_t)b * Q.cap, &out_count, fcol, lds_tris, plen_sum, traced,
+    shade_slice<FUSED, NEE, FULL>(P, S, T, R, work, b, nb, Q.items[0] + (size_t)b * Q.cap, &out_count, fcol, lds_tris, plen_sum, traced,
                                   nee, committed);
     __syncthreads();
-    if (threadIdx.x == 0) Q.count[qout][b] = out_count;
+    if (threadIdx.x == 0) Q.count[0][b] = out_count;
     block_add_u64(&acc, &Q.stats[b].path_len, plen_sum);
     if (FUSED || NEE || FULL) block_add_u64(&acc, &Q.stats[b].rays, traced);
     if (NEE) block_add_u64(&acc, &Q.stats[b].committed, committed);
@@ -1159,7 +1233,8 @@ __global__ __launch_bounds__(PPG_BLOCK, (FULL ? PPG_SHADE_WAVES_FULL : PPG_SHADE
 template <bool SMALL, bool NEE, bool FULL>
 __global__ __launch_bounds__(PPG_BLOCK, (FULL ? PPG_SHADE_WAVES_FULL : PPG_SHADE_WAVES)) void k_tail(PathState P, DevScene S, DevTree T, RenderParams R, const unsigned int *dense,
                                                                     const unsigned long long *total_ptr, unsigned int *ticket, BlockStats *stats,
-                                                                    int lds_tris) {
+                                                                    int lds_tris, unsigned int max_bounces, unsigned int *out_list,
+                                                                    unsigned long long *out_count, int use_prio) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __shared__ float pdf_factors[20 * PPG_BLOCK];
     __shared__ unsigned long long acc;
@@ -1171,12 +1246,17 @@ __global__ __launch_bounds__(PPG_BLOCK, (FULL ? PPG_SHADE_WAVES_FULL : PPG_SHADE
     NeeLds nee;
     nee.small_tris = SMALL ? L.tris : nullptr;     // SMALL: all triangles are staged
     nee.stack_col = (int *)lds_raw + threadIdx.x;  // !SMALL: this lane's BVH stack column (trace and shade never overlap in a lane)
-    unsigned long long plen_sum = 0, committed = 0;
+    unsigned long long plen_sum = 0, committed = 0, plen_max = 0;
     unsigned int traced = 0;
     const int lane = threadIdx.x & 63;
     bool have = false, drained = false;
-    unsigned int i = 0;
+    unsigned int i = 0, bounces = 0;  // bounces this lane's current path has spent in this kernel
+    int prio = 0;
     for (;;) {
+        // A path that has been here for long is one of the few that decide when the launch ends (hundreds of dependent bounces): its wave
+        // gets issue priority over the waves that still work through the crowd of short paths.
+        const int want = (use_prio && __any(have && bounces > 24u)) ? 3 : 0;
+        if (want != prio) { if (want) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); prio = want; }
         const unsigned long long need = __ballot(!have && !drained);
         if (need) {
             const int leader = __ffsll((long long)need) - 1;
@@ -1185,7 +1265,7 @@ __global__ __launch_bounds__(PPG_BLOCK, (FULL ? PPG_SHADE_WAVES_FULL : PPG_SHADE
             base = __shfl(base, leader);
             if (!have && !drained) {
                 const unsigned int k = base + (unsigned int)__popcll(need & ((1ull << lane) - 1ull));
-                if (k < total) { i = dense[k]; have = true; }
+                if (k < total) { i = dense[k]; have = true; bounces = 0; }
                 else drained = true;
             }
         }
@@ -1207,9 +1287,30 @@ __global__ __launch_bounds__(PPG_BLOCK, (FULL ? PPG_SHADE_WAVES_FULL : PPG_SHADE
             unsigned long long plen = 0;
             const bool alive = shade_one<false, NEE, FULL>(P, S, T, R, i, fcol, L.tris, plen, traced, nee, committed);
             plen_sum += plen;
+            if (plen > plen_max) plen_max = plen;
+            ++bounces;
             if (!alive) have = false;
         }
+        // GENERATIONS: a path that has spent max_bounces bounces in this launch is handed to the next launch (a smaller grid): the
+        // persistent workgroups of a launch hold their registers and LDS until their last path is done, and the few paths that go on for
+        // hundreds of bounces must not hold a GPU-sized grid while they do — the wavefront bounces of the next sub-batch run beside them.
+        if (max_bounces) {
+            const bool hand = have && bounces >= max_bounces;
+            const unsigned long long hm = __ballot(hand);
+            if (hm) {
+                const int leader = __ffsll((long long)hm) - 1;
+                unsigned long long base = 0;
+                if (lane == leader) base = atomicAdd(out_count, (unsigned long long)__popcll(hm));
+                base = __shfl(base, leader);
+                if (hand) {
+                    out_list[base + (unsigned long long)__popcll(hm & ((1ull << lane) - 1ull))] = i;
+                    have = false;
+                }
+            }
+        }
     }
+    for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_down(plen_max, off); if (o > plen_max) plen_max = o; }
+    if (lane == 0 && plen_max) atomicMax(&stats[blockIdx.x].max_len, plen_max);
     block_add_u64(&acc, &stats[blockIdx.x].path_len, plen_sum);
     block_add_u64(&acc, &stats[blockIdx.x].rays, traced);
     if (NEE) block_add_u64(&acc, &stats[blockIdx.x].committed, committed);
@@ -1219,59 +1320,88 @@ __global__ __launch_bounds__(PPG_BLOCK, (FULL ? PPG_SHADE_WAVES_FULL : PPG_SHADE
 // union of its lanes' BSDF branches (rough plastic, rough conductor, glass, ...).  Every workgroup therefore counting-sorts its queue
 // slice by the BSDF type at the new hit (16 bins; rays that left the scene last, so that the lanes of their waves finish together).
 // The order of a slice has no influence on any result: per-path random numbers, integer accumulation.
-__global__ __launch_bounds__(PPG_BLOCK) void k_sort_slices(PathState P, DevScene S, Queues Q, int qin, unsigned int *sorted, unsigned char *keys) {
+static __global__ __launch_bounds__(PPG_BLOCK) void k_sort_slices(PathState P, DevScene S, Queues Q, unsigned int *sorted, unsigned char *keys) {
     __shared__ unsigned int hist[16], offs[16];
-    const unsigned int b = blockIdx.x;
-    const unsigned int count = Q.count[qin][b];
-    if (count == 0) return;
-    const unsigned int *items = Q.items[qin] + (size_t)b * Q.cap;
+    const unsigned int b = blockIdx.x, nb = gridDim.x;
+    if (Q.stop && *Q.stop) return;
+    const Work work = work_of(P, Q, QIN_DENSE, nullptr, b, nb);
+    if (work.count == 0) { if (threadIdx.x == 0) Q.count[1][b] = 0; return; }
     unsigned int *out = sorted + (size_t)b * Q.cap;
     unsigned char *kk = keys + (size_t)b * Q.cap;
     if (threadIdx.x < 16) hist[threadIdx.x] = 0;
     __syncthreads();
-    for (unsigned int k = threadIdx.x; k < count; k += blockDim.x) {
-        const unsigned int i = items[k];
-        const int prim = __float_as_int(P.hit[i].w);
-        unsigned int key = 15u;
-        if (prim >= 0) {
-            if (prim >= S.n_tris) key = 14u;
-            else {
-                const int m = __float_as_int(S.tris[3 * (size_t)prim].w);
-                key = (unsigned int)(int)S.materials[PPG_MAT_STRIDE * (size_t)m].w & 15u;
+    for (unsigned int k = threadIdx.x; k < work.count; k += blockDim.x) {
+        const unsigned int i = work_item(work, k, b, nb);
+        unsigned int key = 255u;  // no path at this position (partial last chunk)
+        if (i < P.n_paths) {
+            const int prim = __float_as_int(P.hit[i].w);
+            key = 15u;
+            if (prim >= 0) {
+                if (prim >= S.n_tris) key = 14u;
+                else {
+                    const int m = __float_as_int(S.tris[3 * (size_t)prim].w);
+                    key = (unsigned int)(int)S.materials[PPG_MAT_STRIDE * (size_t)m].w & 15u;
+                }
             }
+            atomicAdd(&hist[key], 1u);
         }
         kk[k] = (unsigned char)key;
-        atomicAdd(&hist[key], 1u);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned int acc = 0;
         for (int j = 0; j < 16; ++j) { offs[j] = acc; acc += hist[j]; }
+        Q.count[1][b] = acc;
     }
     __syncthreads();
-    for (unsigned int k = threadIdx.x; k < count; k += blockDim.x) {
-        const unsigned int pos = atomicAdd(&offs[kk[k]], 1u);
-        out[pos] = items[k];
+    for (unsigned int k = threadIdx.x; k < work.count; k += blockDim.x) {
+        const unsigned int key = kk[k];
+        if (key == 255u) continue;
+        const unsigned int pos = atomicAdd(&offs[key], 1u);
+        out[pos] = work_item(work, k, b, nb);
     }
 }
 
 // copy every workgroup's queue slice into one dense array (offsets = exclusive scan of the slice counts)
-__global__ void k_gather_slices(const unsigned int *items, const unsigned int *count, const unsigned int *offsets, unsigned int cap,
+static __global__ void k_gather_slices(const unsigned int *items, const unsigned int *count, const unsigned int *offsets, unsigned int cap,
                                 unsigned int *dense) {
     const unsigned int b = blockIdx.x, n = count[b], off = offsets[b];
     for (unsigned int k = threadIdx.x; k < n; k += blockDim.x) dense[off + k] = items[(size_t)b * cap + k];
 }
 
-// sum of count[b] (the host needs it only for unbounded paths and for kernel timing)
-__global__ void k_sum_counts(const unsigned int *count, unsigned int nb, unsigned int *total) {
-    __shared__ unsigned int acc;
-    if (threadIdx.x == 0) acc = 0;
+// After a bounce: offsets[b] = exclusive scan of the output slice counts (k_gather_slices builds the dense list from them), *total_out =
+// the number of live paths, also recorded per bounce for the host (which sizes the next batch's schedule by it).  When fewer than
+// `stop_below` paths are left, *stop is set: the wavefront kernels of the bounces that were launched beyond this one return at once and
+// the persistent threads (k_tail) take the dense list as it is now.  One workgroup of 1024 threads.
+static __global__ __launch_bounds__(1024) void k_scan_counts(const unsigned int *counts, unsigned int *offsets, unsigned int n, unsigned long long *total_out,
+                                                      unsigned int *bounce_count, unsigned int *stop, unsigned int stop_below) {
+    __shared__ unsigned long long part[1024];
+    __shared__ unsigned long long carry;
+    const bool stopped = stop && *stop;  // (read by every thread before thread 0 may write it)
+    if (threadIdx.x == 0) carry = 0;
     __syncthreads();
-    unsigned int v = 0;
-    for (unsigned int k = threadIdx.x; k < nb; k += blockDim.x) v += count[k];
-    atomicAdd(&acc, v);
-    __syncthreads();
-    if (threadIdx.x == 0) *total = acc;
+    if (stopped) return;
+    for (unsigned int start = 0; start < n; start += 1024) {
+        unsigned int i = start + threadIdx.x;
+        unsigned long long v = i < n ? counts[i] : 0;
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (unsigned int off = 1; off < 1024; off <<= 1) {
+            unsigned long long t = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+            __syncthreads();
+            part[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < n) offsets[i] = (unsigned int)(carry + part[threadIdx.x] - v);
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += part[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        *total_out = carry;
+        if (bounce_count) *bounce_count = (unsigned int)carry;
+        if (stop && carry < (unsigned long long)stop_below) *stop = 1u;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1352,7 +1482,7 @@ __global__ __launch_bounds__(PPG_BLOCK) void k_commit(PathState P, DevTree T, Re
 // Per-round application of the sampling-fraction optimiser's records
 // ------------------------------------------------------------------------------------------------
 // compact[i] += Σ_r rep[i][r]; rep = 0.  Idempotent (a second call adds zeros).
-__global__ void k_fold_replicas(unsigned long long *compact, unsigned long long *rep, unsigned int n_nodes) {
+static __global__ void k_fold_replicas(unsigned long long *compact, unsigned long long *rep, unsigned int n_nodes) {
     unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_nodes) return;
     unsigned long long s = 0;
@@ -1365,30 +1495,42 @@ __global__ void k_fold_replicas(unsigned long long *compact, unsigned long long 
 
 // nv[i] = number of vertices path i recorded = the number of positions it owns in the Adam record buffer (fast mode)
 // (a path still alive when the tail takes over — `straggler` — reserves the maximum; what it does not use stays a hole)
-__global__ void k_path_nv(PathState P, unsigned int *nv, const unsigned char *straggler, unsigned int max_vertices) {
+static __global__ void k_path_nv(PathState P, unsigned int *nv, const unsigned char *straggler, unsigned int max_vertices) {
     unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < P.n_paths) nv[i] = (straggler && straggler[i]) ? max_vertices : (P.misc[i].z & FL_NV_MASK) >> FL_NV_SHIFT;
 }
 // contiguous copy of the per-path word (key, dim, flags, leaf): k_commit tests it once per (slot, path) item
-__global__ void k_copy_misc(PathState P, uint4 *out) {
+static __global__ void k_copy_misc(PathState P, uint4 *out) {
     unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < P.n_paths) out[i] = P.misc[i];
 }
 // flag[list[k]] = 1 for the n = *list_n entries of a dense path list
-__global__ void k_mark_list(const unsigned int *list, const unsigned long long *list_n, unsigned char *flag) {
+static __global__ void k_mark_list(const unsigned int *list, const unsigned long long *list_n, unsigned char *flag) {
     const unsigned int n = (unsigned int)*list_n;
     for (unsigned int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) flag[list[k]] = 1;
 }
-__global__ void k_iota(unsigned int *a, unsigned int n) {
+// a[i] = i, *total = n (the dense list of a batch that goes to the persistent threads without a wavefront bounce)
+static __global__ void k_iota_total(unsigned int *a, unsigned int first, unsigned int n, unsigned long long *total) {
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) a[i] = first + i;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *total = n;
+}
+// the dense list of a sub-batch after its last wavefront bounce -> the work list of its persistent-thread tail (the next sub-batch
+// reuses the dense list while that tail runs)
+static __global__ void k_copy_list(const unsigned int *src, const unsigned long long *n_src, unsigned int *dst, unsigned long long *n_dst) {
+    const unsigned int n = (unsigned int)*n_src;
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = src[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *n_dst = n;
+}
+static __global__ void k_iota(unsigned int *a, unsigned int n) {
     unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) a[i] = i;
 }
-__global__ void k_record_keys(const AdamRec *recs, unsigned long long *keys, unsigned int n) {
+static __global__ void k_record_keys(const AdamRec *recs, unsigned long long *keys, unsigned int n) {
     unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) keys[i] = recs[i].key;
 }
 // out[k] = recs[idx[k]] for the first n_valid sorted records (what the round hook hands to the other ranks)
-__global__ void k_gather_records(const AdamRec *recs, const unsigned int *idx, AdamRec *out, unsigned int n) {
+static __global__ void k_gather_records(const AdamRec *recs, const unsigned int *idx, AdamRec *out, unsigned int n) {
     unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = recs[idx[i]];
 }
@@ -1401,7 +1543,7 @@ D unsigned int adam_lower_bound(const unsigned long long *keys, unsigned int n, 
     }
     return lo;
 }
-__global__ void k_count_valid(const unsigned long long *keys, unsigned int n, unsigned int *out) {
+static __global__ void k_count_valid(const unsigned long long *keys, unsigned int n, unsigned int *out) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *out = adam_lower_bound(keys, n, ~0ull);
 }
 
@@ -1409,7 +1551,7 @@ __global__ void k_count_valid(const unsigned long long *keys, unsigned int n, un
 // per S-tree leaf walks that leaf's records in key order — 64 records are fetched at once, then applied one after the other with
 // the reference's arithmetic: the gradient at the current variable (GP:672-691), AdamOptimizer::append (GP:85-95) and step
 // (GP:97-109).  Every lane computes the same (scalar) sequence; lane 0 writes the state back.
-__global__ __launch_bounds__(256) void k_adam_apply(LeafHdr *hdr, const unsigned int *leaves, unsigned int n_leaves, const unsigned long long *keys,
+static __global__ __launch_bounds__(256) void k_adam_apply(LeafHdr *hdr, const unsigned int *leaves, unsigned int n_leaves, const unsigned long long *keys,
                                                     const unsigned int *idx, const AdamRec *recs, unsigned int n, int loss) {
     const unsigned int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const unsigned int lane = threadIdx.x & 63u;
@@ -1491,7 +1633,7 @@ __global__ __launch_bounds__(256) void k_adam_apply(LeafHdr *hdr, const unsigned
 // k_film — block->put / squaredBlock->put / film->put for the spp samples of each owned pixel
 // (GP:1633-1640; box filter ⇒ own pixel, unit weight)
 // ------------------------------------------------------------------------------------------------
-__global__ void k_film(PathState P, int spp, float *image, float *sq_image, float *image_w, float *film, float *film_w) {
+static __global__ void k_film(PathState P, int spp, float *image, float *sq_image, float *image_w, float *film, float *film_w) {
     unsigned int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= P.n_pix) return;
     unsigned int pixel = P.pixels[k];
@@ -1514,7 +1656,7 @@ __global__ void k_film(PathState P, int spp, float *image, float *sq_image, floa
 
 // per-pixel variance estimate of performRenderPasses (GP:1300-1311); the clamped luminance goes to `lum`, stored x-major
 // (index x * H + y) — the order the reference's serial loop sums it in, so the host adds a contiguous array
-__global__ void k_variance(int n, int W, int N, const float *image, const float *sq_image, const float *image_w, float *var_rgb, float *lum) {
+static __global__ void k_variance(int n, int W, int N, const float *image, const float *sq_image, const float *image_w, float *var_rgb, float *lum) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float w = image_w[i];
@@ -1528,7 +1670,7 @@ __global__ void k_variance(int n, int W, int N, const float *image, const float 
     lum[(size_t)x * H + y] = ppg_min(l, 10000.0f);
 }
 
-__global__ void k_normalise(int n, const float *rgb_sum, const float *w, float *out) {
+static __global__ void k_normalise(int n, const float *rgb_sum, const float *w, float *out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float ww = w[i];
@@ -1536,7 +1678,7 @@ __global__ void k_normalise(int n, const float *rgb_sum, const float *w, float *
     out[3 * i] = rgb_sum[3 * i] * iw; out[3 * i + 1] = rgb_sum[3 * i + 1] * iw; out[3 * i + 2] = rgb_sum[3 * i + 2] * iw;
 }
 
-__global__ void k_axpy(int n, float a, const float *x, float *y) {
+static __global__ void k_axpy(int n, float a, const float *x, float *y) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] += x[i] * a;
 }
@@ -1591,7 +1733,7 @@ __global__ void k_dtree_reset(DevTree T, const unsigned int *leaves, unsigned in
 
 // DTree::build (GP:520-533, 346-366) + `sampling = building` (GP:610-613): children always have larger
 // indices than their parent, so one backwards sweep evaluates the recursion's post-order.
-__global__ void k_dtree_build(DevTree T, const unsigned int *leaves, unsigned int n_leaves, SNode *snodes_out) {
+static __global__ void k_dtree_build(DevTree T, const unsigned int *leaves, unsigned int n_leaves, SNode *snodes_out) {
     unsigned int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_leaves) return;
     const unsigned int leaf = leaves[k];
@@ -1637,7 +1779,7 @@ __global__ void k_dtree_build(DevTree T, const unsigned int *leaves, unsigned in
 //   first new node of old leaf j      = n_old + 2 * (number of subdivisions of the leaves before j)      (exclusive scan)
 //   children of subdivision e of leaf j = base_j + 2 e, base_j + 2 e + 1                                   (e = preorder index)
 // so every subdivision of every leaf can be written independently.  Results are identical to the serial loop, node for node.
-__global__ void k_refine_count(const LeafHdr *hdr, const unsigned int *dfs, unsigned int n_leaves, float threshold, unsigned int *events,
+static __global__ void k_refine_count(const LeafHdr *hdr, const unsigned int *dfs, unsigned int n_leaves, float threshold, unsigned int *events,
                                unsigned int *new_leaves) {
     unsigned int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_leaves) return;
@@ -1649,7 +1791,7 @@ __global__ void k_refine_count(const LeafHdr *hdr, const unsigned int *dfs, unsi
 }
 
 // one workgroup per old leaf; thread e handles subdivision e of that leaf's subtree
-__global__ void k_refine_fill(int4 *stree, LeafHdr *hdr, const unsigned int *dfs, unsigned int n_leaves, unsigned int n_old,
+static __global__ void k_refine_fill(int4 *stree, LeafHdr *hdr, const unsigned int *dfs, unsigned int n_leaves, unsigned int n_old,
                               const unsigned int *events, const unsigned int *ev_off, const unsigned int *lv_off, unsigned int *dfs_out) {
     const unsigned int j = blockIdx.x;
     if (j >= n_leaves) return;
@@ -1700,7 +1842,7 @@ __global__ void k_refine_fill(int4 *stree, LeafHdr *hdr, const unsigned int *dfs
 }
 
 // exclusive scan of `counts` (n small: one S-tree leaf each) by a single workgroup; total → *total_out
-__global__ void k_scan_exclusive(const unsigned int *counts, unsigned int *offsets, unsigned int n, unsigned long long *total_out) {
+static __global__ void k_scan_exclusive(const unsigned int *counts, unsigned int *offsets, unsigned int n, unsigned long long *total_out) {
     __shared__ unsigned long long part[1024];
     __shared__ unsigned long long carry;
     if (threadIdx.x == 0) carry = 0;
@@ -1724,7 +1866,7 @@ __global__ void k_scan_exclusive(const unsigned int *counts, unsigned int *offse
     if (threadIdx.x == 0) *total_out = carry;
 }
 
-__global__ void k_assign_blocks(DevTree T, const unsigned int *leaves, unsigned int n_leaves, const unsigned int *counts,
+static __global__ void k_assign_blocks(DevTree T, const unsigned int *leaves, unsigned int n_leaves, const unsigned int *counts,
                                 const unsigned int *offsets) {
     unsigned int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_leaves) return;
@@ -1733,7 +1875,7 @@ __global__ void k_assign_blocks(DevTree T, const unsigned int *leaves, unsigned 
 }
 
 // batched queries (ppg_query_pdf / ppg_query_sample)
-__global__ void k_query_pdf(DevTree T, unsigned int n, const float *pos, const float *dirs, float *out) {
+static __global__ void k_query_pdf(DevTree T, unsigned int n, const float *pos, const float *dirs, float *out) {
     unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     F3 vox;
@@ -1743,7 +1885,7 @@ __global__ void k_query_pdf(DevTree T, unsigned int n, const float *pos, const f
     RegColumn col;
     out[i] = dtree_pdf<RegColumn &>(T, dtree_ref(T.hdr[leaf]), cx, cy, col);
 }
-__global__ void k_query_sample(DevTree T, unsigned int n, const float *pos, unsigned long long seed, float *out) {
+static __global__ void k_query_sample(DevTree T, unsigned int n, const float *pos, unsigned long long seed, float *out) {
     unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     F3 vox;

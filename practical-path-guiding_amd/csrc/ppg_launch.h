@@ -1,0 +1,60 @@
+/*
+ * ppg_launch.h — launchers of the large path kernels.  k_shade and k_tail exist in eight instantiations each (FUSED / SMALL x NEE x FULL)
+ * and k_commit in six (spatial x directional filter); each pair of instantiations is its own translation unit (ppg_inst.hip compiled with
+ * -DPPG_INST=n), so the library builds in parallel instead of in one 2.5-minute compile.  No device code crosses a translation unit.
+ */
+#ifndef PPG_LAUNCH_H
+#define PPG_LAUNCH_H
+
+#include "ppg_kernels.h"
+
+struct ShadeLaunch {
+    int grid;
+    size_t lds;
+    hipStream_t stream;
+    PathState P; DevScene S; DevTree T; RenderParams R; Queues Q;
+    int qin, small_scene;
+    const unsigned int *sorted_items;
+};
+struct TailLaunch {
+    int grid;
+    size_t lds;
+    hipStream_t stream;
+    PathState P; DevScene S; DevTree T; RenderParams R;
+    const unsigned int *dense;
+    const unsigned long long *total;
+    unsigned int *ticket;
+    BlockStats *stats;
+    int lds_tris;
+    unsigned int max_bounces;     // bounces per path in this launch (0 = until the path ends); survivors go to out_list
+    unsigned int *out_list;
+    unsigned long long *out_count;
+    int use_prio;                 // raise the issue priority of waves that carry a long path
+};
+struct CommitLaunch {
+    int grid;
+    hipStream_t stream;
+    PathState P; DevTree T; RenderParams R; Queues Q;
+    const unsigned char *skip;
+    const unsigned int *list;
+    const unsigned long long *list_n;
+};
+
+// variant = (FUSED ? 4 : 0) | (NEE ? 2 : 0) | (FULL ? 1 : 0)
+void ppg_launch_shade(int variant, const ShadeLaunch &a);
+// variant = (SMALL ? 4 : 0) | (NEE ? 2 : 0) | (FULL ? 1 : 0)
+void ppg_launch_tail(int variant, const TailLaunch &a);
+void ppg_launch_commit(int spatial_filter, int directional_filter, const CommitLaunch &a);
+
+// one function per translation unit (pair = variant >> 1)
+void ppg_launch_shade_pair0(int variant, const ShadeLaunch &a);
+void ppg_launch_shade_pair1(int variant, const ShadeLaunch &a);
+void ppg_launch_shade_pair2(int variant, const ShadeLaunch &a);
+void ppg_launch_shade_pair3(int variant, const ShadeLaunch &a);
+void ppg_launch_tail_pair0(int variant, const TailLaunch &a);
+void ppg_launch_tail_pair1(int variant, const TailLaunch &a);
+void ppg_launch_tail_pair2(int variant, const TailLaunch &a);
+void ppg_launch_tail_pair3(int variant, const TailLaunch &a);
+void ppg_launch_commit_all(int spatial_filter, int directional_filter, const CommitLaunch &a);
+
+#endif
