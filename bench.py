@@ -25,9 +25,14 @@ Added to the JSON line (rank 0):
                 the kernels' own stream, algorithmic bytes per DESIGN.md §3 — for k_trace on a BVH scene 48 B per ray + 64 B per
                 BVH4 node visited + 48 B per triangle tested, the visits counted by the kernel itself in that run
   cpu_baseline  the oracle restatement timed on the host cores on the first passes of the same render (N = 1 only)
+  reference_log the reference's OWN run of this configuration (its embedded render log: 1.34 Msamples/s on 16 CPU cores, the complete scene)
+                and vs_reference_log = value / that — the honest denominator; the triangle ratio of the checkout's scene is stated
+  single_call   the same render through ppg_render(), the ONE C-ABI call a host in any language makes (no Python between the phases)
+  tuning_env    every PPG_* variable set in the environment (none = the defaults the library ships with)
   time_to_rmse  seconds until this build's KITCHEN picture (at the reference's 700x400) is as close to the reference's converged
                 kitchen-reference.exr as the reference's own guided render kitchen-improved.exr is (2400 spp, 500.9 s on 16 CPU
-                cores): MAPE and RMSE over the pixels not affected by the six missing meshes (N = 1 only; --no-rmse skips it)
+                cores): MAPE and RMSE over the pixels not affected by the six missing meshes; the render that meets the target is
+                repeated with three seeds and the spread reported (N = 1 only; --no-rmse skips it)
   secondary     cbox-720p (configs[1]) Msamples/s, for the record (N = 1 only; --no-secondary skips it)
 """
 import argparse
@@ -44,6 +49,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 KITCHEN_FILE = os.path.join(ROOT, "scratch", "kitchen-improved.ppgs")
 IMPROVED = dict(sampleCombination="inversevar", bsdfSamplingFractionLoss="kl", spatialFilter="stochastic", directionalFilter="box", sTreeThreshold=4000, sppPerPass=1)
 REF_KITCHEN_SECONDS = 500.9  # render time in the log embedded in kitchen-improved.exr (2400 spp, 700x400, 16 CPU cores)
+# The reference's own run of this configuration (the log embedded in scenes/kitchen/kitchen-improved.exr): the honest
+# denominator — the reference BINARY on the COMPLETE scene — next to cpu_baseline, which times this repository's CPU restatement.
+REF_KITCHEN_LOG = {"msamples_per_s": 1.34, "seconds": 500.9, "samples": 672.00e6, "rays": 4.327e9, "cores": 16, "os": "Windows", "film": "700x400",
+                   "spp": 2400, "primitives": 1414390, "source": "scenes/kitchen/kitchen-improved.exr, log attribute (BASELINE.md §1)"}
 KITCHEN_REFERENCE = os.path.join(ROOT, "tests", "golden", "ref_kitchen_reference.npz")
 
 
@@ -224,8 +233,25 @@ def run(args):
         "config": {"workload": workload,
                    "iterations": [it["passes"] for it in gpt.iterations], "parallelism": "tiles%d" % args.gpus,
                    "rays_per_sample": rays / max(1, own_samples), "avg_path_length": plen / max(1, own_samples), "variance_last_iteration": var_last},
+        "tuning_env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("PPG_")},
     }
     del gpt
+    if scene_name == "kitchen":
+        out["reference_log"] = dict(REF_KITCHEN_LOG, triangle_ratio_of_this_scene=scene.n_triangles / REF_KITCHEN_LOG["primitives"],
+                                    note="the reference binary on the complete scene (1 414 390 primitives) at 700x400; this run renders the %d triangles of the "
+                                         "checkout (six meshes are missing from it) at %dx%d" % (scene.n_triangles, args.width, args.height))
+        out["vs_reference_log"] = out["value"] / REF_KITCHEN_LOG["msamples_per_s"]
+    if rank == 0 and args.gpus == 1 and not args.no_single_call:
+        # the same render through ppg_render(): one C-ABI call, the iteration loop in the library (what the C++ host / the plug-in make)
+        e1 = ppg_host.Engine.hip(budget=float(args.steps * spp), **props)
+        e1.set_scene(scene)
+        sync()
+        t1 = time.perf_counter()
+        e1.render()
+        sync()
+        dt1 = time.perf_counter() - t1
+        out["single_call"] = {"entry_point": "ppg_render()", "value": samples / dt1 / 1e6, "unit": "Msamples/s", "seconds": dt1}
+        del e1
 
     work = rays_cpu = None
     if rank == 0 and args.gpus == 1 and not args.no_cpu:
@@ -248,7 +274,9 @@ def run(args):
         rays_cpu = sum(s["rays"] for it in og.iterations for s in it["stats"])
         out["cpu_baseline"] = {"value": args.width * args.height * spp * cp / dtc / 1e6, "unit": "Msamples/s", "cores": cores,
                                "kind": "port", "sample": "first %d passes (%d spp) of the same render(), oracle restatement, OpenMP over 32x32 blocks"
-                               % (cp, cp * spp), "seconds": dtc}
+                               % (cp, cp * spp), "seconds": dtc,
+                               "note": "a PORT on this box's host cores (brute-force / median-split BVH, software libm: slower than the reference binary was on 16 "
+                                       "cores) — a reported baseline, not the yardstick; the reference's own figure is `reference_log`"}
         del og, o
 
     times = None
@@ -335,6 +363,16 @@ def run(args):
             trial(-(-n // spp))
         hit_mape = min((t for t in trials if t["mape"] <= target_mape), key=lambda t: t["seconds"], default=None)
         hit_rmse = min((t for t in trials if t["rmse"] <= target_rmse), key=lambda t: t["seconds"], default=None)
+        # the budget that met the MAPE target, again with other seeds: how much of the figure is one seed's luck
+        seeds = []
+        if hit_mape:
+            for sd in (4321, 99, 20260927):
+                if sd == 4321:
+                    seeds.append({"seed": sd, "seconds": hit_mape["seconds"], "mape": hit_mape["mape"], "rmse": hit_mape["rmse"]})
+                    continue
+                img, t = timed_render(make(-(-hit_mape["spp"] // spp), the_scene=small, seed=sd))
+                d = (np.asarray(img, np.float64) - ref)[keep]
+                seeds.append({"seed": sd, "seconds": t, "mape": float((np.abs(d) / (ref[keep] + 0.01)).mean()), "rmse": float(np.sqrt((d * d).mean()))})
         out["time_to_rmse"] = {
             "reference_image": "scenes/kitchen/kitchen-reference.exr of the reference (tests/golden/ref_kitchen_reference.npz), 700x400; %.0f %% of the film "
                                "masked: footprint of the 6 meshes missing from the reference checkout" % (100 * (1 - keep.mean())),
@@ -344,6 +382,10 @@ def run(args):
             "seconds_to_rmse": hit_rmse["seconds"] if hit_rmse else None, "spp_to_rmse": hit_rmse["spp"] if hit_rmse else None,
             "speedup_vs_reference_log_mape": (REF_KITCHEN_SECONDS / hit_mape["seconds"]) if hit_mape else None,
             "speedup_vs_reference_log_rmse": (REF_KITCHEN_SECONDS / hit_rmse["seconds"]) if hit_rmse else None,
+            "seeds_at_spp_to_mape": seeds,
+            "seconds_to_mape_min_max": [min(s_["seconds"] for s_ in seeds), max(s_["seconds"] for s_ in seeds)] if seeds else None,
+            "mape_min_max": [min(s_["mape"] for s_ in seeds), max(s_["mape"] for s_ in seeds)] if seeds else None,
+            "seeds_meeting_target": sum(1 for s_ in seeds if s_["mape"] <= target_mape) if seeds else None,
             "trials": trials,
             "note": "MAPE = mean |x - ref| / (ref + 0.01) is the meaningful figure: the reference render's RMSE is a handful of fireflies (max pixel 119), "
                     "which this build's renders of equal spp do not show to that extent (seed dependent), so the RMSE target is met at well under half the samples.  Seconds = render() "
@@ -388,6 +430,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-rmse", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--no-single-call", action="store_true", help="skip the extra render through ppg_render() (the single C-ABI call)")
     ap.add_argument("--all-diffuse", action="store_true", help="experiment: replace every BSDF of a scene file by a grey two-sided Lambertian")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the reducer even with one rank (plumbing check)")
     run(ap.parse_args())

@@ -277,6 +277,11 @@ int ppg_end_render(ppg_ctx *ctx);                         /* GP:1567-1582: inver
 /* Integrator::cancel() (IH:84, GP:1643-1648).  Thread-safe; the running ppg_render / ppg_render_passes
    call returns PPG_ERR_CANCELLED. */
 int ppg_cancel(ppg_ctx *ctx);
+/* Device blocks released by contexts (buffer growth, ppg_destroy) are kept by the library — at most a third of the device's memory —
+   and handed to the next allocation that fits, of this or another context (hipMalloc / hipFree of hundreds of MB are synchronous,
+   millisecond-scale calls).  This gives the kept blocks of `device` back to the driver; the library also does so by itself when an
+   allocation fails. */
+int ppg_release_cached_memory(int32_t device);
 
 /* Film read-back: weight-normalised RGB, row-major [height][width][3] (hdrfilm develop, fmtconv.cpp:1036-1044). */
 int ppg_read_film(ppg_ctx *ctx, float *rgb);
@@ -383,6 +388,23 @@ int ppg_set_pass_hook(ppg_ctx *ctx, ppg_pass_hook hook, void *user);
 int ppg_adam_records(ppg_ctx *ctx, void **dev_records /* ppg_adam_record[n] */, uint64_t *n);
 /* Valid inside the hook only: the records to apply instead (device pointer, copied). */
 int ppg_adam_records_replace(ppg_ctx *ctx, const void *dev_records, uint64_t n);
+
+/* Sharded optimiser: ONE OWNER PER D-TREE.  The reference serialises the Adam steps per D-tree (its spin-lock, GP:719-737), so the
+   D-trees can be dealt to the ranks: S-tree node `leaf` belongs to rank leaf / segment, segment = ceil(n_stree_nodes / world) —
+   contiguous node ranges, so with the records in key order every owner's records are one contiguous run.  The hook is then called
+   TWICE per round:
+     phase 0  before the records are applied: ppg_adam_records_by_owner → all-to-all (every rank keeps 1 / world of the records
+              instead of gathering all of them) → ppg_adam_records_replace with what this rank owns; it then sorts and applies only those;
+     phase 1  after they were applied (only if phase 0 called ppg_adam_records_by_owner): ppg_adam_state → all-gather of the
+              owners' segments, in place → ppg_adam_state_commit.
+   Same records in the same key order at the owner as in the union ⇒ the same bits as the gather-everything scheme and as one GPU. */
+int ppg_hook_phase(ppg_ctx *ctx, int32_t *phase);
+/* phase 0: this rank's records in key order (device memory) and how many of them each of the `world` owners gets */
+int ppg_adam_records_by_owner(ppg_ctx *ctx, int32_t world, void **dev_records /* ppg_adam_record[sum(counts)] */, uint64_t *counts /* [world] */);
+/* phase 1: the optimiser's state of every S-tree node, 24 bytes each (theta, iter, m, v, batchGradient, batchAccumulation; GP:116-124),
+   packed into a device array of world * segment entries; rank r's segment [r * segment, (r + 1) * segment) holds what it computed */
+int ppg_adam_state(ppg_ctx *ctx, int32_t world, void **dev_state, uint64_t *segment);
+int ppg_adam_state_commit(ppg_ctx *ctx); /* take the (gathered) array back into the tree */
 
 /* Batched queries against the current *sampling* SD-tree (what Li does per vertex):
    pdf  = DTreeWrapper::pdf(dir) of the leaf containing p        (GP:623-625, 897-905)

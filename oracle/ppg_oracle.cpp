@@ -206,6 +206,17 @@ public:
 
     Float variable() const { return m_state.variable; }
 
+    // the complete state as six 32-bit words (theta, iter, m, v, batchGradient, batchAccumulation): what the owner of a D-tree hands to the
+    // other ranks of a sharded render (include/ppg.h "Sharded optimiser")
+    void exportState(uint32_t out[6]) const {
+        memcpy(out + 0, &m_state.variable, 4); memcpy(out + 1, &m_state.iter, 4); memcpy(out + 2, &m_state.firstMoment, 4);
+        memcpy(out + 3, &m_state.secondMoment, 4); memcpy(out + 4, &m_state.batchGradient, 4); memcpy(out + 5, &m_state.batchAccumulation, 4);
+    }
+    void importState(const uint32_t in[6]) {
+        memcpy(&m_state.variable, in + 0, 4); memcpy(&m_state.iter, in + 1, 4); memcpy(&m_state.firstMoment, in + 2, 4);
+        memcpy(&m_state.secondMoment, in + 3, 4); memcpy(&m_state.batchGradient, in + 4, 4); memcpy(&m_state.batchAccumulation, in + 5, 4);
+    }
+
 private:
     struct State {
         int iter = 0;
@@ -2607,13 +2618,20 @@ public:
             }
             sink.clear();
         }
-        if (passHook) passHook(passHookUser);  // sharded rendering: the driver replaces the records by the union over all ranks
+        // sharded rendering: the driver replaces the records by the union over all ranks — or, with one owner per D-tree
+        // (ppgo_adam_records_by_owner), by the records of the D-trees this rank owns
+        hookPhase = 0; ownerMode = false;
+        if (passHook) passHook(passHookUser);
         std::sort(m_adamRecords.begin(), m_adamRecords.end(), [](const PackedAdamRecord &a, const PackedAdamRecord &b) { return a.key < b.key; });
         const Float ratioPower = m_bsdfSamplingFractionLoss == EKL ? 1.0f : 2.0f;
         for (const PackedAdamRecord &r : m_adamRecords)
             nodes[(size_t)(r.key >> PPG_ADAM_LEAF_SHIFT)].dTree.optimizeBsdfSamplingFraction(r.product, r.woPdf, r.bsdfPdf, r.dTreePdf, r.weight, ratioPower);
         m_adamRecords.clear();
+        if (passHook && ownerMode) { hookPhase = 1; passHook(passHookUser); hookPhase = 0; }  // the owners publish the state they computed
     }
+    int hookPhase = 0;
+    bool ownerMode = false;
+    std::vector<uint32_t> m_adamState;  // [world * segment][6]
 
     void finishPasses(ppg_pass_stats *st) {  // GP:1288-1328
         Float variance = 0;
@@ -3444,6 +3462,38 @@ int ppgo_adam_records_replace(ppgo_ctx *ctx, const void *records, uint64_t n) {
     const auto *r = (const GuidedPathTracer::PackedAdamRecord *)records;
     std::vector<GuidedPathTracer::PackedAdamRecord> v(r, r + n);  // `records` may alias the current array
     ctx->gpt.m_adamRecords.swap(v);
+    return PPG_OK;
+}
+int ppgo_hook_phase(ppgo_ctx *ctx, int32_t *phase) { *phase = ctx->gpt.hookPhase; return PPG_OK; }
+int ppgo_adam_records_by_owner(ppgo_ctx *ctx, int32_t world, void **records, uint64_t *counts) {
+    NEED_TREE
+    auto &g = ctx->gpt;
+    if (world < 1 || g.hookPhase != 0) { g.error = "ppg_adam_records_by_owner: only valid in phase 0 of the round hook"; return PPG_ERR_STATE; }
+    std::sort(g.m_adamRecords.begin(), g.m_adamRecords.end(), [](const GuidedPathTracer::PackedAdamRecord &a, const GuidedPathTracer::PackedAdamRecord &b) { return a.key < b.key; });
+    const uint64_t nNodes = g.m_sdTree->nodes().size(), seg = (nNodes + world - 1) / world;
+    for (int32_t r = 0; r < world; ++r) counts[r] = 0;
+    for (const auto &rec : g.m_adamRecords) counts[(rec.key >> PPG_ADAM_LEAF_SHIFT) / seg]++;
+    *records = g.m_adamRecords.data();
+    g.ownerMode = true;
+    return PPG_OK;
+}
+int ppgo_adam_state(ppgo_ctx *ctx, int32_t world, void **state, uint64_t *segment) {
+    NEED_TREE
+    auto &g = ctx->gpt;
+    if (world < 1 || g.hookPhase != 1) { g.error = "ppg_adam_state: only valid in phase 1 of the round hook"; return PPG_ERR_STATE; }
+    auto &nodes = g.m_sdTree->nodes();
+    const uint64_t seg = (nodes.size() + world - 1) / world;
+    g.m_adamState.assign((size_t)world * seg * 6, 0u);
+    for (size_t i = 0; i < nodes.size(); ++i) nodes[i].dTree.bsdfSamplingFractionOptimizer.exportState(&g.m_adamState[6 * i]);
+    *state = g.m_adamState.data(); *segment = seg;
+    return PPG_OK;
+}
+int ppgo_adam_state_commit(ppgo_ctx *ctx) {
+    NEED_TREE
+    auto &g = ctx->gpt;
+    auto &nodes = g.m_sdTree->nodes();
+    if (g.hookPhase != 1 || g.m_adamState.size() < 6 * nodes.size()) { g.error = "ppg_adam_state_commit: call ppg_adam_state first"; return PPG_ERR_STATE; }
+    for (size_t i = 0; i < nodes.size(); ++i) nodes[i].dTree.bsdfSamplingFractionOptimizer.importState(&g.m_adamState[6 * i]);
     return PPG_OK;
 }
 int ppgo_film_ptrs(ppgo_ctx *ctx, float **rgb_sum, float **weight) {

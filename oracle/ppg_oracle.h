@@ -67,6 +67,11 @@ int ppgo_set_pass_hook(ppgo_ctx *ctx, ppg_pass_hook hook, void *user);
 /* host-memory counterparts of ppg_adam_records / ppg_adam_records_replace (valid inside the round hook) */
 int ppgo_adam_records(ppgo_ctx *ctx, void **records, uint64_t *n);
 int ppgo_adam_records_replace(ppgo_ctx *ctx, const void *records, uint64_t n);
+/* one owner per D-tree (include/ppg.h "Sharded optimiser"): same calls as the product, on host memory */
+int ppgo_hook_phase(ppgo_ctx *ctx, int32_t *phase);
+int ppgo_adam_records_by_owner(ppgo_ctx *ctx, int32_t world, void **records, uint64_t *counts);
+int ppgo_adam_state(ppgo_ctx *ctx, int32_t world, void **state, uint64_t *segment);
+int ppgo_adam_state_commit(ppgo_ctx *ctx);
 int ppgo_film_ptrs(ppgo_ctx *ctx, float **rgb_sum, float **weight);
 int ppgo_image_ptrs(ppgo_ctx *ctx, float **image, float **sq_image);
 int ppgo_image_weight_ptr(ppgo_ctx *ctx, float **w);

@@ -326,17 +326,6 @@ D Bvh4Hits bvh4_children(const Bvh4QNode *node, F3 o, F3 id, float mint, float t
     return r;
 }
 
-// PPG_PREFETCH: when a node step pushes children, the one that will be popped first (the nearest of the pushed ones) is touched right
-// away — one dword of its node / of its first triangle record, consumed a step later, when it has long arrived — so that the pop finds
-// its line in L2 instead of waiting for HBM / Infinity Cache behind the dependent chain of the subtree visited in between.
-#ifndef PPG_PREFETCH
-#define PPG_PREFETCH 0
-#endif
-D unsigned int bvh4_touch(const DevScene &S, int c) {
-    const unsigned int *pa = c >= 0 ? reinterpret_cast<const unsigned int *>(S.bvh4 + c) : reinterpret_cast<const unsigned int *>(S.accel + 3 * ((~c) >> 3));
-    return *pa;
-}
-
 // Closest hit by (t, original primitive index) through the BVH4 — equals brute force (conservative culling).
 // ANY: return at the first triangle hit (shadow rays; only prim >= 0 is meaningful then).
 // VOTE: as in k_trace, lanes holding a leaf wait until PPG_LEAF_VOTE lanes of the wave do (or none has an interior node left) — for callers
@@ -352,9 +341,6 @@ D Hit trace_closest4(const DevScene &S, int *lds_stack_col, int stride, F3 o, F3
     st.over = st_over;
     st.lds = lds_stack_col; st.stride = stride; st.sp = 0;
     int cur = 0;
-#if PPG_PREFETCH
-    unsigned int pf_acc = 0, pf_pending = 0;
-#endif
     for (;;) {  // one step per iteration: an interior node or a leaf popped from the stack (see trace_slice_bvh4)
         bool doLeaves = true;
         if (VOTE) {
@@ -363,10 +349,6 @@ D Hit trace_closest4(const DevScene &S, int *lds_stack_col, int stride, F3 o, F3
         }
         if (cur >= 0) {
             const Bvh4Hits hc = bvh4_children(S.bvh4 + cur, o, id, mint, fminf(maxt, best.t));
-#if PPG_PREFETCH
-            pf_acc ^= pf_pending; pf_pending = 0;
-            if (hc.m > 1) pf_pending = bvh4_touch(S, hc.c1);
-#endif
             if (hc.m > 0) {
                 if (hc.m > 3) st.push(hc.c3);
                 if (hc.m > 2) st.push(hc.c2);
@@ -392,10 +374,6 @@ D Hit trace_closest4(const DevScene &S, int *lds_stack_col, int stride, F3 o, F3
             cur = st.pop();
         }
     }
-#if PPG_PREFETCH
-    pf_acc ^= pf_pending;
-    asm volatile("" ::"v"(pf_acc));
-#endif
     if (SPH && S.n_spheres) sphere_pass<ANY>(S, o, d, mint, maxt, best);
     return best;
 }

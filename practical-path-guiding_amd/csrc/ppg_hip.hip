@@ -51,30 +51,77 @@ thread_local std::string g_createError;
 // the render after a warm-up render — takes a fitting block from it.  Blocks come back with stale contents, like fresh hipMalloc memory.
 // Ordering: a block is released only by reserve() / the destructor on the host; everything that used it was enqueued earlier on the
 // context's in-order stream (the second stream is joined back before the host continues past a batch), and its next user is enqueued later.
+// The stream the calling thread's context works on (set by the C-ABI entry points that render): fresh blocks are touched on it and the
+// hand-over of a released block is ordered behind it — not behind the legacy null stream, which would serialise every stream of the
+// process.  Outside those entry points (scene set-up, destruction) it is null and the null stream's conservative ordering applies.
+thread_local hipStream_t g_ctxStream = nullptr;
+struct StreamScope {
+    hipStream_t prev;
+    explicit StreamScope(hipStream_t s) : prev(g_ctxStream) { g_ctxStream = s; }
+    ~StreamScope() { g_ctxStream = prev; }
+};
+
 struct BlockCache {
+    struct Block { void *p; hipEvent_t ready; };  // `ready`: recorded when the block was released, behind everything its last owner had enqueued
     std::mutex m;
-    std::map<int, std::multimap<size_t, void *>> blocks;
+    std::map<int, std::multimap<size_t, Block>> blocks;
     size_t held = 0;
-    static constexpr size_t kMaxHeld = (size_t)96 << 30;
+    size_t maxHeld = 0;  // a third of the device's memory (set on first use): the cache must not starve other processes of the GPU
     static constexpr size_t kGranule = (size_t)2 << 20;
     static size_t roundUp(size_t bytes) { return (bytes + kGranule - 1) / kGranule * kGranule; }
     void *take(size_t bytes, size_t &got) {
         int dev = 0; (void)hipGetDevice(&dev);
-        std::lock_guard<std::mutex> g(m);
-        auto &mm = blocks[dev];
-        auto it = mm.lower_bound(bytes);
-        if (it == mm.end() || it->first > std::max(2 * bytes, bytes + ((size_t)64 << 20))) return nullptr;
-        void *p = it->second; got = it->first;
-        held -= got; mm.erase(it);
-        return p;
+        Block b{nullptr, nullptr};
+        {
+            std::lock_guard<std::mutex> g(m);
+            auto &mm = blocks[dev];
+            auto it = mm.lower_bound(bytes);
+            if (it == mm.end() || it->first > std::max(2 * bytes, bytes + ((size_t)64 << 20))) return nullptr;
+            b = it->second; got = it->first;
+            held -= got; mm.erase(it);
+        }
+        // the previous owner may be another context on another stream: its work on the block must be over before the new owner touches it
+        if (b.ready) { (void)hipEventSynchronize(b.ready); (void)hipEventDestroy(b.ready); }
+        return b.p;
     }
     void give(void *p, size_t bytes) {
         int dev = 0; (void)hipGetDevice(&dev);
         {
             std::lock_guard<std::mutex> g(m);
-            if (held + bytes <= kMaxHeld) { blocks[dev].emplace(bytes, p); held += bytes; return; }
+            if (!maxHeld) { size_t fr = 0, tot = 0; maxHeld = hipMemGetInfo(&fr, &tot) == hipSuccess ? tot / 3 : ((size_t)32 << 30); }
+            if (held + bytes <= maxHeld) {
+                Block b{p, nullptr};
+                if (hipEventCreateWithFlags(&b.ready, hipEventDisableTiming) == hipSuccess) (void)hipEventRecord(b.ready, g_ctxStream);
+                else b.ready = nullptr;
+                if (!b.ready) (void)hipDeviceSynchronize();
+                blocks[dev].emplace(bytes, b); held += bytes;
+                return;
+            }
         }
         (void)hipFree(p);
+    }
+    // Before a context's streams are destroyed: the `ready` events of cached blocks may have been recorded on them, and the runtime
+    // dereferences an event's stream when the event is waited for (seen as a spurious "operation not permitted when stream is
+    // capturing" from hipEventSynchronize after the stream was gone).  The streams have been synchronised: the events are complete.
+    void settle() {
+        int dev = 0; (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> g(m);
+        for (auto &kv : blocks[dev])
+            if (kv.second.ready) { (void)hipEventSynchronize(kv.second.ready); (void)hipEventDestroy(kv.second.ready); kv.second.ready = nullptr; }
+    }
+    // give every cached block of the current device back to the driver (ppg_release_cached_memory; also when hipMalloc fails)
+    void trim() {
+        int dev = 0; (void)hipGetDevice(&dev);
+        std::vector<Block> out;
+        {
+            std::lock_guard<std::mutex> g(m);
+            for (auto &kv : blocks[dev]) { out.push_back(kv.second); held -= kv.first; }
+            blocks[dev].clear();
+        }
+        for (Block &b : out) {
+            if (b.ready) { (void)hipEventSynchronize(b.ready); (void)hipEventDestroy(b.ready); }
+            (void)hipFree(b.p);
+        }
     }
 };
 static BlockCache g_blockCache;
@@ -96,14 +143,20 @@ template <typename T> struct DevBuf {
         hipError_t e = hipSuccess;
         if (!np) {
             e = hipMalloc(&np, want);
-            if (e != hipSuccess) return e;
+            if (e != hipSuccess) {  // memory parked in the cache is memory the driver cannot hand out: release it and try once more
+                (void)hipGetLastError();
+                g_blockCache.trim();
+                e = hipMalloc(&np, want);
+                if (e != hipSuccess) return e;
+            }
             got = want;
-            // touch fresh device memory once, here (scene set-up), so that whatever the driver does lazily for a new allocation is not
-            // paid inside the first render that reaches it: the first process on a freshly booted box sometimes ran a 20-pass render
-            // 20-30 % slower than the second
-            (void)hipMemsetAsync(np, 0, want, nullptr);
+            // touch fresh device memory once, where it is allocated (normally scene set-up), so that whatever the driver does lazily for a new
+            // allocation is not paid inside the first render that reaches it: the first process on a freshly booted box sometimes ran a
+            // 20-pass render 20-30 % slower than the second.  On the context's own stream when a render is under way.
+            (void)hipMemsetAsync(np, 0, want, g_ctxStream);
         }
-        if (keep && p && cap) e = hipMemcpy(np, p, cap * sizeof(T), hipMemcpyDeviceToDevice);
+        if (keep && p && cap) e = hipMemcpyAsync(np, p, cap * sizeof(T), hipMemcpyDeviceToDevice, g_ctxStream);
+        if (keep && p && cap && !g_ctxStream) (void)hipStreamSynchronize(nullptr);
         if (p) g_blockCache.give(p, bytes);
         p = np; bytes = got; cap = got / sizeof(T);
         return e;
@@ -445,6 +498,10 @@ struct ppg_ctx {
     bool adamActive = false;      // a round of the optimiser is being rendered
     bool inHook = false, hookReplaced = false;
     uint64_t hookCount = 0;
+    int hookPhase = 0;            // 0: before the round's records are applied, 1: after (sharded optimiser, include/ppg.h)
+    bool ownerMode = false;       // phase 0 asked for the records by owner: phase 1 follows
+    DevBuf<unsigned int> d_adamState;             // [world * segment][6] (ppg_adam_state)
+    DevBuf<unsigned long long> d_ownerBounds;     // [world + 1] first record of every owner
     // unbounded paths: live paths after each bulk bounce of the last batch → how many bulk bounces the next batch runs before k_tail
     DevBuf<unsigned int> d_bounceCounts, d_ticket;
     unsigned int *h_round = nullptr;  // pinned: [0..63] bounce counts, [64] Adam record count / overflow, [65] Σ nV
@@ -493,7 +550,7 @@ struct ppg_ctx {
         T.bweight_rep = d_bweightRep.p;
         T.adam_keys = adamActive ? d_adamKeys[0].p : nullptr; T.adam_recs = adamActive ? d_adamRecs.p : nullptr;
         T.adam_count = d_adamCount.p; T.adam_base = (adamActive && adamFast) ? d_adamBase.p : nullptr;
-        T.adam_cap = adamActive ? (unsigned int)std::min<size_t>(d_adamRecs.cap, 0xfffffff0u) : 0u;
+        T.adam_cap = adamActive ? (unsigned int)std::min<size_t>(std::min(d_adamRecs.cap, d_adamKeys[0].cap), 0xfffffff0u) : 0u;  // (both are written at the same position)
         for (int a = 0; a < 3; ++a) { T.aabb_min[a] = treeMin[a]; T.aabb_ext[a] = treeExt[a]; T.aabb_max[a] = treeMax[a]; }
         T.is_built = isBuilt ? 1 : 0;
         T.grid = d_grid.p;
@@ -857,7 +914,7 @@ int applyAdamRound(ppg_ctx *ctx, size_t nRecords) {
             if (nValid) hipLaunchKernelGGL(k_gather_records, dim3((nValid + 255) / 256), dim3(256), 0, s, ctx->d_adamRecs.p, ctx->d_adamIdx[1].p, ctx->d_adamRecsOut.p, nValid);
         } else HIP_CHECK(ctx->d_adamRecsOut.reserve(1));
         HIP_CHECK(hipStreamSynchronize(s));
-        ctx->inHook = true; ctx->hookReplaced = false; ctx->hookCount = nValid;
+        ctx->inHook = true; ctx->hookReplaced = false; ctx->hookCount = nValid; ctx->hookPhase = 0; ctx->ownerMode = false;
         const int hrc = ctx->passHook(ctx->passHookUser);
         ctx->inHook = false;
         if (hrc != 0) { ctx->error = "round hook failed"; return PPG_ERR_INVALID; }
@@ -871,13 +928,21 @@ int applyAdamRound(ppg_ctx *ctx, size_t nRecords) {
             }
         }
     }
-    if (n == 0) return PPG_OK;
-    const unsigned int nl = (unsigned int)ctx->leaves.size();
-    timedLaunch(ctx, "k_adam_apply", n, [&] {
-        hipLaunchKernelGGL(k_adam_apply, dim3((nl * 64u + 255u) / 256u), dim3(256), 0, s, ctx->d_hdr.p, ctx->d_leaves.p, nl, ctx->d_adamKeys[1].p, ctx->d_adamIdx[1].p,
-                           ctx->d_adamRecs.p, (unsigned int)n, ctx->loss);
-    });
-    HIP_CHECK(hipGetLastError());
+    if (n > 0) {
+        const unsigned int nl = (unsigned int)ctx->leaves.size();
+        timedLaunch(ctx, "k_adam_apply", n, [&] {
+            hipLaunchKernelGGL(k_adam_apply, dim3((nl * 64u + 255u) / 256u), dim3(256), 0, s, ctx->d_hdr.p, ctx->d_leaves.p, nl, ctx->d_adamKeys[1].p, ctx->d_adamIdx[1].p,
+                               ctx->d_adamRecs.p, (unsigned int)n, ctx->loss);
+        });
+        HIP_CHECK(hipGetLastError());
+    }
+    if (ctx->passHook && ctx->ownerMode) {  // one owner per D-tree: the owners publish the state they computed
+        HIP_CHECK(hipStreamSynchronize(s));
+        ctx->inHook = true; ctx->hookPhase = 1;
+        const int hrc = ctx->passHook(ctx->passHookUser);
+        ctx->inHook = false; ctx->hookPhase = 0; ctx->ownerMode = false;
+        if (hrc != 0) { ctx->error = "round hook failed"; return PPG_ERR_INVALID; }
+    }
     return PPG_OK;
 }
 
@@ -1589,6 +1654,7 @@ void ppg_destroy(ppg_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); }
+    g_blockCache.settle();
     if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
     if (ctx->evFork) (void)hipEventDestroy(ctx->evFork);
     if (ctx->evJoin) (void)hipEventDestroy(ctx->evJoin);
@@ -1969,8 +2035,9 @@ int ppg_set_shard(ppg_ctx *ctx, int32_t rank, int32_t world, int32_t tile_size) 
 }
 
 // every entry point re-selects the context's device: the caller (torch / RCCL in a multi-GPU process) may have changed it
-#define NEED_SCENE (void)hipSetDevice(ctx->device); if (!ctx->haveScene) { ctx->error = "no scene"; return PPG_ERR_STATE; }
-#define NEED_TREE (void)hipSetDevice(ctx->device); if (!ctx->treeAlive) { ctx->error = "render not begun"; return PPG_ERR_STATE; }
+// ... and names the context's stream as the one buffer growth is ordered on (StreamScope)
+#define NEED_SCENE (void)hipSetDevice(ctx->device); StreamScope scope_(ctx->stream); if (!ctx->haveScene) { ctx->error = "no scene"; return PPG_ERR_STATE; }
+#define NEED_TREE (void)hipSetDevice(ctx->device); StreamScope scope_(ctx->stream); if (!ctx->treeAlive) { ctx->error = "render not begun"; return PPG_ERR_STATE; }
 
 int ppg_begin_render(ppg_ctx *ctx) { NEED_SCENE return beginRender(ctx); }
 int ppg_begin_iteration(ppg_ctx *ctx, int32_t is_final) { NEED_TREE return beginIteration(ctx, is_final != 0); }
@@ -1989,6 +2056,14 @@ int ppg_build_sdtree(ppg_ctx *ctx, ppg_tree_stats *st) { NEED_TREE return buildS
 int ppg_end_iteration(ppg_ctx *ctx) { NEED_TREE return endIteration(ctx); }
 int ppg_end_render(ppg_ctx *ctx) { NEED_TREE return endRender(ctx); }
 int ppg_cancel(ppg_ctx *ctx) { ctx->cancelled.store(true); return PPG_OK; }
+int ppg_release_cached_memory(int32_t device) {
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    if (hipSetDevice(device) != hipSuccess) return PPG_ERR_DEVICE;
+    g_blockCache.trim();
+    (void)hipSetDevice(prev);
+    return PPG_OK;
+}
 
 int ppg_render(ppg_ctx *ctx) {  // GP:1516-1585
     NEED_SCENE
@@ -2106,6 +2181,53 @@ int ppg_adam_records(ppg_ctx *ctx, void **dev_records, uint64_t *n) {
     if (!ctx->inHook) { ctx->error = "ppg_adam_records: only valid inside the round hook"; return PPG_ERR_STATE; }
     *dev_records = ctx->hookReplaced ? (void *)ctx->d_adamRecs.p : (void *)ctx->d_adamRecsOut.p;
     *n = ctx->hookCount;
+    return PPG_OK;
+}
+int ppg_hook_phase(ppg_ctx *ctx, int32_t *phase) {
+    if (!ctx || !phase) return PPG_ERR_INVALID;
+    *phase = ctx->hookPhase;
+    return PPG_OK;
+}
+int ppg_adam_records_by_owner(ppg_ctx *ctx, int32_t world, void **dev_records, uint64_t *counts) {
+    if (!ctx || !dev_records || !counts || world < 1) return PPG_ERR_INVALID;
+    if (!ctx->inHook || ctx->hookPhase != 0) { ctx->error = "ppg_adam_records_by_owner: only valid in phase 0 of the round hook"; return PPG_ERR_STATE; }
+    HIP_CHECK(hipSetDevice(ctx->device));
+    const unsigned int nNodes = (unsigned int)ctx->snodes.size();
+    const unsigned int seg = (nNodes + (unsigned int)world - 1u) / (unsigned int)world;
+    const unsigned int n = (unsigned int)ctx->hookCount;  // the valid records, in key order: d_adamKeys[1] / d_adamRecsOut
+    HIP_CHECK(ctx->d_ownerBounds.reserve((size_t)world + 1));
+    std::vector<unsigned long long> b((size_t)world + 1, 0ull);
+    if (n) {
+        hipLaunchKernelGGL(k_owner_bounds, dim3(((unsigned int)world + 1u + 63u) / 64u), dim3(64), 0, ctx->stream, ctx->d_adamKeys[1].p, n, seg, (unsigned int)world, ctx->d_ownerBounds.p);
+        HIP_CHECK(hipMemcpyAsync(b.data(), ctx->d_ownerBounds.p, b.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
+    for (int32_t r = 0; r < world; ++r) counts[r] = b[(size_t)r + 1] - b[(size_t)r];
+    *dev_records = ctx->d_adamRecsOut.p;
+    ctx->ownerMode = true;
+    return PPG_OK;
+}
+int ppg_adam_state(ppg_ctx *ctx, int32_t world, void **dev_state, uint64_t *segment) {
+    if (!ctx || !dev_state || !segment || world < 1) return PPG_ERR_INVALID;
+    if (!ctx->inHook || ctx->hookPhase != 1) { ctx->error = "ppg_adam_state: only valid in phase 1 of the round hook"; return PPG_ERR_STATE; }
+    HIP_CHECK(hipSetDevice(ctx->device));
+    const unsigned int nNodes = (unsigned int)ctx->snodes.size();
+    const size_t seg = ((size_t)nNodes + (size_t)world - 1) / (size_t)world;
+    const size_t words = (size_t)world * seg * 6;
+    HIP_CHECK(ctx->d_adamState.reserve(std::max<size_t>(words, 6)));
+    HIP_CHECK(hipMemsetAsync(ctx->d_adamState.p, 0, words * 4, ctx->stream));
+    hipLaunchKernelGGL((k_adam_state<false>), dim3((nNodes + 255u) / 256u), dim3(256), 0, ctx->stream, ctx->d_hdr.p, nNodes, ctx->d_adamState.p);
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    *dev_state = ctx->d_adamState.p; *segment = seg;
+    return PPG_OK;
+}
+int ppg_adam_state_commit(ppg_ctx *ctx) {
+    if (!ctx) return PPG_ERR_INVALID;
+    if (!ctx->inHook || ctx->hookPhase != 1 || !ctx->d_adamState.p) { ctx->error = "ppg_adam_state_commit: call ppg_adam_state first"; return PPG_ERR_STATE; }
+    HIP_CHECK(hipSetDevice(ctx->device));
+    const unsigned int nNodes = (unsigned int)ctx->snodes.size();
+    hipLaunchKernelGGL((k_adam_state<true>), dim3((nNodes + 255u) / 256u), dim3(256), 0, ctx->stream, ctx->d_hdr.p, nNodes, ctx->d_adamState.p);
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return PPG_OK;
 }
 int ppg_adam_records_replace(ppg_ctx *ctx, const void *dev_records, uint64_t n) {

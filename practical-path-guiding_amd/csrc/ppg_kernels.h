@@ -343,9 +343,6 @@ D void trace_slice_bvh4(const PathState &P, const DevScene &S, int *lds_stack, u
     Hit best;
     best.t = 0; best.u = 0; best.v = 0; best.prim = -1;
     int bestOrig = 0, cur = 0;
-#if PPG_PREFETCH
-    unsigned int pf_acc = 0, pf_pending = 0;
-#endif
     for (;;) {
         if (!have) {
             unsigned int k = atomicAdd(ticket, 1u);
@@ -378,10 +375,6 @@ D void trace_slice_bvh4(const PathState &P, const DevScene &S, int *lds_stack, u
         if (cur >= 0) {
             if (COUNT) ++n_nodes;
             const Bvh4Hits hc = bvh4_children(S.bvh4 + cur, o, id, mint, fminf(maxt, best.t));
-#if PPG_PREFETCH
-            pf_acc ^= pf_pending; pf_pending = 0;
-            if (hc.m > 1) pf_pending = bvh4_touch(S, hc.c1);
-#endif
             if (hc.m > 0) {
                 if (hc.m > 3) st.push(hc.c3);
                 if (hc.m > 2) st.push(hc.c2);
@@ -409,10 +402,6 @@ D void trace_slice_bvh4(const PathState &P, const DevScene &S, int *lds_stack, u
             have = false;
         }
     }
-#if PPG_PREFETCH
-    pf_acc ^= pf_pending;
-    asm volatile("" ::"v"(pf_acc));
-#endif
     __syncthreads();
 }
 
@@ -1542,6 +1531,28 @@ D unsigned int adam_lower_bound(const unsigned long long *keys, unsigned int n, 
         if (keys[mid] < bound) lo = mid + 1; else hi = mid;
     }
     return lo;
+}
+// Sharded optimiser (include/ppg.h): bounds[r] = first record (in key order) of owner r = first key >= (r * segment) << LEAF_SHIFT
+static __global__ void k_owner_bounds(const unsigned long long *keys, unsigned int n, unsigned int segment, unsigned int world, unsigned long long *bounds) {
+    const unsigned int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > world) return;
+    bounds[r] = r == world ? (unsigned long long)adam_lower_bound(keys, n, ~0ull)
+                           : (unsigned long long)adam_lower_bound(keys, n, (unsigned long long)((unsigned long long)r * segment) << PPG_ADAM_LEAF_SHIFT);
+}
+// AdamOptimizer::State of every S-tree node <-> six 32-bit words per node (theta, iter, m, v, batchGradient, batchAccumulation)
+template <bool IMPORT>
+__global__ void k_adam_state(LeafHdr *hdr, unsigned int n_nodes, unsigned int *state) {
+    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    unsigned int *w = state + 6 * (size_t)i;
+    LeafHdr &h = hdr[i];
+    if (IMPORT) {
+        h.theta = __uint_as_float(w[0]); h.adam_iter = (int)w[1]; h.adam_m = __uint_as_float(w[2]); h.adam_v = __uint_as_float(w[3]);
+        h.adam_bg = __uint_as_float(w[4]); h.adam_ba = __uint_as_float(w[5]);
+    } else {
+        w[0] = __float_as_uint(h.theta); w[1] = (unsigned int)h.adam_iter; w[2] = __float_as_uint(h.adam_m); w[3] = __float_as_uint(h.adam_v);
+        w[4] = __float_as_uint(h.adam_bg); w[5] = __float_as_uint(h.adam_ba);
+    }
 }
 static __global__ void k_count_valid(const unsigned long long *keys, unsigned int n, unsigned int *out) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *out = adam_lower_bound(keys, n, ~0ull);

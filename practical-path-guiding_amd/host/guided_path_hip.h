@@ -92,6 +92,7 @@ public:
     virtual void reduceSDTree(ppg_ctx *ctx) = 0;                          // before buildSDTree (GP:1115)
     virtual void reduceAdamRecords(ppg_ctx *ctx) = 0;                     // round hook of the sampling-fraction optimiser (include/ppg.h)
     virtual void reduceFilm(ppg_ctx *ctx, int width, int height) = 0;     // before the film is read (not with inverse-variance combination)
+    virtual void setLocalStatus(int status) { (void)status; }             // != 0: this rank was cancelled / failed — announced to the others in the next exchange
     virtual int rank() const = 0;
     virtual int world() const = 0;
 };
@@ -178,8 +179,11 @@ private:
             check(rc, "ppg_render_passes");
         } else {  // the ranks' image tiles are summed before the variance is estimated from them
             rc = ppg_render_passes_nostat(m_ctx, n);
+            // cancelled or failed here: the other ranks must not wait for this one in their next collective — tell them in it
+            if (rc != PPG_OK || m_hookError) m_reducer->setLocalStatus(1);
+            try { m_reducer->reduceImages(m_ctx, m_w, m_h); } catch (...) { if (!m_hookError) m_hookError = std::current_exception(); }
+            if (rc == PPG_ERR_CANCELLED) { m_hookError = nullptr; return false; }  // (the exchange above told the others; they leave with an error)
             check(rc, "ppg_render_passes_nostat");
-            try { m_reducer->reduceImages(m_ctx, m_w, m_h); } catch (...) { m_hookError = std::current_exception(); }
             rethrowHookError();
             check(ppg_finish_passes(m_ctx, &st), "ppg_finish_passes");
         }

@@ -25,12 +25,23 @@
 
 using namespace ppg;
 
+static bool loadSceneChecked(const char *path, SceneData &s);
+// a corrupt or truncated file is "cannot load scene", never an allocation of whatever size its header claims
 static bool loadScene(const char *path, SceneData &s) {
+    try { return loadSceneChecked(path, s); } catch (const std::exception &) { return false; }
+}
+static bool loadSceneChecked(const char *path, SceneData &s) {
     std::ifstream f(path, std::ios::binary);
+    f.seekg(0, std::ios::end);
+    const uint64_t fileSize = f ? (uint64_t)f.tellg() : 0;
+    f.seekg(0);
+    // every count read from the file is checked against what is left of it before anything is sized by it
+    auto fits = [&](uint64_t bytes) { const std::streamoff p = f.tellg(); return p >= 0 && bytes <= fileSize - (uint64_t)p; };
     char magic[4];
     uint32_t hdr[6];
     if (!f.read(magic, 4) || memcmp(magic, "PPGS", 4) != 0 || !f.read((char *)hdr, sizeof hdr)) return false;
     const uint32_t nv = hdr[0], nt = hdr[1], nm = hdr[2], ne = hdr[3], hasN = hdr[4];
+    if (!fits((uint64_t)nv * 12 * (hasN ? 2 : 1) + (uint64_t)nt * 20 + (uint64_t)nm * sizeof(ppg_material) + (uint64_t)ne * sizeof(ppg_emitter) + sizeof(ppg_camera))) return false;
     s.positions.resize(3 * (size_t)nv); f.read((char *)s.positions.data(), s.positions.size() * 4);
     if (hasN) { s.normals.resize(3 * (size_t)nv); f.read((char *)s.normals.data(), s.normals.size() * 4); }
     s.indices.resize(3 * (size_t)nt); f.read((char *)s.indices.data(), s.indices.size() * 4);
@@ -44,23 +55,24 @@ static bool loadScene(const char *path, SceneData &s) {
     if (hdr[5] & 2) {
         uint32_t rt[2];
         f.read((char *)rt, 8);
-        if (!f || rt[1] < 2) return false;
+        if (!f || rt[1] < 2 || !fits((uint64_t)rt[0] * ((uint64_t)rt[1] + 1) * 4)) return false;
         s.rtransSamples = rt[1];
         s.rtrans.resize((size_t)rt[0] * (rt[1] + 1)); f.read((char *)s.rtrans.data(), s.rtrans.size() * 4);
     }
     if (hdr[5] & 4) {
         uint32_t n = 0;
         f.read((char *)&n, 4);
-        if (!f) return false;
+        if (!f || !fits((uint64_t)n * sizeof(ppg_sphere))) return false;
         s.spheres.resize(n); f.read((char *)s.spheres.data(), (size_t)n * sizeof(ppg_sphere));
     }
     if (hdr[5] & 8) {
         uint32_t wh[2];
         f.read((char *)wh, 8); f.read((char *)&s.envmap.scale, 4); f.read((char *)s.envmap.to_world, 36);
-        if (!f) return false;
+        if (!f || wh[0] == 0 || wh[1] == 0 || wh[0] > 0x7fffu || wh[1] > 0x7fffu || !fits((uint64_t)wh[0] * wh[1] * 12)) return false;
         s.envmap.width = wh[0]; s.envmap.height = wh[1]; s.hasEnvmap = true;
         s.envmapRgb.resize((size_t)wh[0] * wh[1] * 3); f.read((char *)s.envmapRgb.data(), s.envmapRgb.size() * 4);
     }
+    if ((hdr[5] & 16) && !fits((uint64_t)nv * 8)) return false;
     if (hdr[5] & 16) { s.texcoords.resize(2 * (size_t)nv); f.read((char *)s.texcoords.data(), s.texcoords.size() * 4); }  // bit 4: texture coordinates
     if (hdr[5] & 32) {  // bit 5: bitmap textures (pixels as float32 RGB, or as the 8-bit sRGB source decoded through the conversion's 256-entry table)
         uint32_t n = 0;
@@ -71,7 +83,8 @@ static bool loadScene(const char *path, SceneData &s) {
         for (uint32_t k = 0; k < n; ++k) {
             uint32_t wh[2], storage = 0; float sc[4]; int32_t wr[3];
             f.read((char *)wh, 8); f.read((char *)sc, 16); f.read((char *)wr, 12); f.read((char *)&storage, 4);
-            if (!f) return false;
+            // (ppg_set_scene accepts textures below 32768 x 32768)
+            if (!f || wh[0] == 0 || wh[1] == 0 || wh[0] > 0x7fffu || wh[1] > 0x7fffu || !fits((uint64_t)wh[0] * wh[1] * 3 * (storage == 1 ? 1 : 4))) return false;
             ppg_texture t{};
             t.width = wh[0]; t.height = wh[1]; t.uv_scale[0] = sc[0]; t.uv_scale[1] = sc[1]; t.uv_offset[0] = sc[2]; t.uv_offset[1] = sc[3];
             t.wrap_u = wr[0]; t.wrap_v = wr[1]; t.nearest = wr[2];
@@ -195,7 +208,7 @@ static bool saveScene(const char *path, const SceneData &s) {
 
 int main(int argc, char **argv) {
     Properties props;
-    std::string out = "out.pfm", scenePath, dumpScene, bsdfId, ncclIdFile;
+    std::string out = "out.pfm", scenePath, dumpScene, bsdfId, ncclIdFile, runTag;
     int rank = 0, world = 1;
     bool quiet = false, lenient = false;
     std::string dataDir;  // `data` directory of a Mitsuba tree (roughplastic: data/microfacet/*.dat); default $PPG_MITSUBA_DATA
@@ -215,6 +228,7 @@ int main(int argc, char **argv) {
         else if (a == "--rank" && i + 1 < argc) rank = atoi(argv[++i]);       // multi-GPU: one process per GPU, image tiles sharded over `--world` ranks,
         else if (a == "--world" && i + 1 < argc) world = atoi(argv[++i]);     // RCCL communicator bootstrapped through the file `--nccl-id` (rank 0 writes it);
         else if (a == "--nccl-id" && i + 1 < argc) ncclIdFile = argv[++i];    // host/rccl_reducer.h
+        else if (a == "--run-tag" && i + 1 < argc) runTag = argv[++i];        // the same string on all ranks of one run: a stale id file of an earlier run is ignored
         else if (a == "--lenient") lenient = true;
         else if (a == "--data-dir" && i + 1 < argc) dataDir = argv[++i];
         else if (a == "--size" && i + 1 < argc) { if (sscanf(argv[++i], "%dx%d", &sw, &sh) != 2) { std::cerr << "--size WxH\n"; return 2; } }
@@ -272,7 +286,8 @@ int main(int argc, char **argv) {
             if (world < 1 || rank < 0 || rank >= world) { std::cerr << "--rank / --world out of range\n"; return 2; }
             if (!props.values.count("device")) props.values["device"] = std::to_string(rank);  // one GPU per rank of the node
             const auto t0 = std::chrono::steady_clock::now();
-            reducer.reset(new RcclReducer(rank, world, std::stoi(props.values["device"]), ncclIdFile));
+            if (runTag.empty() && getenv("PPG_RUN_TAG")) runTag = getenv("PPG_RUN_TAG");
+            reducer.reset(new RcclReducer(rank, world, std::stoi(props.values["device"]), ncclIdFile, runTag));
             if (!quiet) std::cout << "RCCL communicator: rank " << rank << " of " << world << " ready after "
                                   << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << " s" << std::endl;
         }

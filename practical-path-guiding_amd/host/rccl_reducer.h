@@ -7,12 +7,20 @@
  *   per iteration, before the variance estimate   image + squared image + weights of the iteration: disjoint supports, float sums are exact
  *   per iteration, before buildSDTree             the building tree's fixed-point leaf sums and per-D-tree statistical weights (uint64 as int64:
  *                                                 integer sums are exact and order independent → refine / reset / build stay identical on all ranks)
- *   per round of the sampling-fraction optimiser  its records (include/ppg.h): every rank applies the union in key order
+ *   per round of the sampling-fraction optimiser  ONE OWNER PER D-TREE (include/ppg.h "Sharded optimiser"; the reference serialises Adam per D-tree, GP:719-737):
+ *                                                 phase 0 — every record goes to the owner of its D-tree (grouped ncclSend / ncclRecv = all-to-all-v, a rank
+ *                                                 receives 1 / world of the records), which sorts and applies them in key order; phase 1 — the owners'
+ *                                                 optimiser state (24 B per S-tree node) is all-gathered in place.  Same key order at the owner ⇒ same bits
  *   at the end                                    the film (not with inverse-variance combination: the retained iteration images were reduced)
  *
  * Each exchange is ONE collective: the arrays of an exchange are packed into a staging buffer on the device (they are separate allocations of
  * the context), all-reduced / all-gathered in place, and unpacked — xGMI rings are latency bound for these sizes (a few MB to ~100 MB), so
- * fewer, larger calls beat one call per array.  The communicator is bootstrapped through a file holding the ncclUniqueId (rank 0 writes it).
+ * fewer, larger calls beat one call per array.  The communicator is bootstrapped through a file holding the ncclUniqueId: rank 0 removes
+ * what a previous run may have left, writes {run tag, id} under a temporary name and renames it; the other ranks accept the file only if
+ * it carries THEIR run tag (`--run-tag` / PPG_RUN_TAG: any string the launcher gives to all ranks of one run), and rank 0 removes the file again
+ * once the communicator exists.
+ * Every exchange also carries one status word per rank (0 = fine): a rank that was cancelled or failed says so in the next exchange, all
+ * ranks see the same sum and leave together instead of waiting for each other in a collective that will never complete.
  */
 #ifndef PPG_RCCL_REDUCER_H
 #define PPG_RCCL_REDUCER_H
@@ -36,24 +44,31 @@ namespace ppg {
 
 class RcclReducer : public Reducer {
 public:
-    RcclReducer(int rank, int world, int device, const std::string &idFile) : m_rank(rank), m_world(world) {
+    RcclReducer(int rank, int world, int device, const std::string &idFile, const std::string &runTag = std::string()) : m_rank(rank), m_world(world) {
         hip(hipSetDevice(device), "hipSetDevice");
         ncclUniqueId id;
+        char tag[64];
+        memset(tag, 0, sizeof tag);
+        strncpy(tag, runTag.c_str(), sizeof tag - 1);
         if (rank == 0) {
+            (void)std::remove(idFile.c_str());  // whatever an earlier run left behind
             nccl(ncclGetUniqueId(&id), "ncclGetUniqueId");
             std::ofstream f(idFile + ".tmp", std::ios::binary);
+            f.write(tag, sizeof tag);
             f.write((const char *)&id, sizeof id);
             f.close();
-            if (std::rename((idFile + ".tmp").c_str(), idFile.c_str()) != 0) throw std::runtime_error("cannot write " + idFile);
+            if (!f || std::rename((idFile + ".tmp").c_str(), idFile.c_str()) != 0) throw std::runtime_error("cannot write " + idFile);
         } else {
             for (int tries = 0;; ++tries) {
                 std::ifstream f(idFile, std::ios::binary);
-                if (f && f.read((char *)&id, sizeof id)) break;
-                if (tries > 6000) throw std::runtime_error("timed out waiting for " + idFile);
+                char got[64];
+                if (f && f.read(got, sizeof got) && f.read((char *)&id, sizeof id) && memcmp(got, tag, sizeof tag) == 0) break;  // (a stale file carries another tag)
+                if (tries > 6000) throw std::runtime_error("timed out waiting for " + idFile + " with this run's tag");
                 std::this_thread::sleep_for(std::chrono::milliseconds(10));
             }
         }
         nccl(ncclCommInitRank(&m_comm, world, id, rank), "ncclCommInitRank");
+        if (rank == 0) (void)std::remove(idFile.c_str());  // every rank has read it: ncclCommInitRank returns when all have joined
         hip(hipStreamCreate(&m_stream), "hipStreamCreate");
     }
     ~RcclReducer() {
@@ -88,35 +103,57 @@ public:
         Piece p[2] = {{rgb, 3 * n * 4}, {w, n * 4}};
         allReduce(p, 2, ncclFloat);
     }
-    // every rank applies the records of all ranks: counts first, then one padded all-gather, then the pieces packed back to back
+    // a rank that was cancelled or failed announces it in the next exchange (status word, see the header comment)
+    void setLocalStatus(int status) override { m_status = status; }
+
+    // round hook of the sampling-fraction optimiser, called twice per round (include/ppg.h "Sharded optimiser")
     void reduceAdamRecords(ppg_ctx *ctx) override {
-        void *recs;
-        uint64_t n;
-        check(ctx, ppg_adam_records(ctx, &recs, &n), "ppg_adam_records");
-        if (!m_counts) hip(hipMalloc(&m_counts, (size_t)m_world * sizeof(unsigned long long)), "hipMalloc");
-        std::vector<unsigned long long> counts((size_t)m_world, 0ull);
-        unsigned long long mine = n;
-        hip(hipMemcpyAsync((unsigned long long *)m_counts + m_rank, &mine, 8, hipMemcpyHostToDevice, m_stream), "hipMemcpyAsync");
-        nccl(ncclAllGather((unsigned long long *)m_counts + m_rank, m_counts, 1, ncclUint64, m_comm, m_stream), "ncclAllGather(counts)");
-        hip(hipMemcpyAsync(counts.data(), m_counts, (size_t)m_world * 8, hipMemcpyDeviceToHost, m_stream), "hipMemcpyAsync");
-        hip(hipStreamSynchronize(m_stream), "hipStreamSynchronize");
-        ++m_collectives;
-        unsigned long long most = 0, total = 0;
-        for (unsigned long long c : counts) { most = std::max(most, c); total += c; }
-        if (most == 0) return;
-        const size_t rec = sizeof(ppg_adam_record), slot = (size_t)most * rec;
-        reserve(slot * (size_t)m_world + (size_t)total * rec);
-        char *gather = (char *)m_stage, *packed = gather + slot * (size_t)m_world;
-        if (n) hip(hipMemcpyAsync(gather + slot * (size_t)m_rank, recs, (size_t)n * rec, hipMemcpyDeviceToDevice, m_stream), "hipMemcpyAsync");
-        nccl(ncclAllGather(gather + slot * (size_t)m_rank, gather, slot, ncclChar, m_comm, m_stream), "ncclAllGather(records)");
-        size_t off = 0;
-        for (int r = 0; r < m_world; ++r) {
-            if (counts[r]) hip(hipMemcpyAsync(packed + off, gather + slot * (size_t)r, (size_t)counts[r] * rec, hipMemcpyDeviceToDevice, m_stream), "hipMemcpyAsync");
-            off += (size_t)counts[r] * rec;
+        int32_t phase = 0;
+        check(ctx, ppg_hook_phase(ctx, &phase), "ppg_hook_phase");
+        const size_t rec = sizeof(ppg_adam_record), W = (size_t)m_world;
+        if (phase == 0) {
+            // who gets how many of my records: one all-gather of a (world + 1)-vector per rank — counts per owner + my status
+            void *recs;
+            std::vector<uint64_t> send(W, 0);
+            check(ctx, ppg_adam_records_by_owner(ctx, m_world, &recs, send.data()), "ppg_adam_records_by_owner");
+            const size_t row = W + 1;
+            if (!m_counts) hip(hipMalloc(&m_counts, W * row * 8), "hipMalloc");
+            std::vector<unsigned long long> mine(row, 0ull), all(W * row, 0ull);
+            for (size_t r = 0; r < W; ++r) mine[r] = send[r];
+            mine[W] = (unsigned long long)m_status;
+            unsigned long long *dc = (unsigned long long *)m_counts;
+            hip(hipMemcpyAsync(dc + (size_t)m_rank * row, mine.data(), row * 8, hipMemcpyHostToDevice, m_stream), "hipMemcpyAsync");
+            nccl(ncclAllGather(dc + (size_t)m_rank * row, dc, row, ncclUint64, m_comm, m_stream), "ncclAllGather(counts)");
+            hip(hipMemcpyAsync(all.data(), dc, W * row * 8, hipMemcpyDeviceToHost, m_stream), "hipMemcpyAsync");
+            hip(hipStreamSynchronize(m_stream), "hipStreamSynchronize");
+            ++m_collectives;
+            unsigned long long bad = 0, total = 0;
+            std::vector<unsigned long long> recv(W, 0ull);
+            for (size_t r = 0; r < W; ++r) { bad += all[r * row + W]; recv[r] = all[r * row + (size_t)m_rank]; total += recv[r]; }
+            if (bad) throw std::runtime_error("render aborted: a rank reported a failure or a cancellation");
+            // all-to-all-v: grouped point-to-point, one message per pair of ranks that has records for each other
+            reserve(std::max<size_t>((size_t)total * rec, 64));
+            nccl(ncclGroupStart(), "ncclGroupStart");
+            size_t soff = 0, roff = 0;
+            for (size_t r = 0; r < W; ++r) {
+                if (send[r]) nccl(ncclSend((const char *)recs + soff, (size_t)send[r] * rec, ncclChar, (int)r, m_comm, m_stream), "ncclSend");
+                if (recv[r]) nccl(ncclRecv((char *)m_stage + roff, (size_t)recv[r] * rec, ncclChar, (int)r, m_comm, m_stream), "ncclRecv");
+                soff += (size_t)send[r] * rec; roff += (size_t)recv[r] * rec;
+            }
+            nccl(ncclGroupEnd(), "ncclGroupEnd");
+            hip(hipStreamSynchronize(m_stream), "hipStreamSynchronize");
+            ++m_collectives; m_bytes += (size_t)total * rec;
+            check(ctx, ppg_adam_records_replace(ctx, m_stage, total), "ppg_adam_records_replace");
+        } else {
+            void *state;
+            uint64_t seg = 0;
+            check(ctx, ppg_adam_state(ctx, m_world, &state, &seg), "ppg_adam_state");
+            const size_t bytes = (size_t)seg * 24;
+            if (bytes) nccl(ncclAllGather((const char *)state + (size_t)m_rank * bytes, state, bytes, ncclChar, m_comm, m_stream), "ncclAllGather(state)");
+            hip(hipStreamSynchronize(m_stream), "hipStreamSynchronize");
+            ++m_collectives; m_bytes += bytes * W;
+            check(ctx, ppg_adam_state_commit(ctx), "ppg_adam_state_commit");
         }
-        hip(hipStreamSynchronize(m_stream), "hipStreamSynchronize");
-        ++m_collectives; m_bytes += slot * (size_t)m_world;
-        check(ctx, ppg_adam_records_replace(ctx, packed, total), "ppg_adam_records_replace");
     }
 
 private:
@@ -131,16 +168,20 @@ private:
     void allReduce(const Piece *p, int count, ncclDataType_t type) {
         size_t total = 0;
         for (int i = 0; i < count; ++i) total += p[i].bytes;
-        if (total == 0) return;
-        reserve(total);
+        const size_t elem = type == ncclFloat ? 4 : 8;
+        reserve(total + elem);  // + the status word (summed like the data: > 0 means some rank gave up)
         size_t off = 0;
         for (int i = 0; i < count; ++i) { if (p[i].bytes) hip(hipMemcpyAsync((char *)m_stage + off, p[i].dev, p[i].bytes, hipMemcpyDeviceToDevice, m_stream), "hipMemcpyAsync"); off += p[i].bytes; }
-        const size_t elem = type == ncclFloat ? 4 : 8;
-        nccl(ncclAllReduce(m_stage, m_stage, total / elem, type, ncclSum, m_comm, m_stream), "ncclAllReduce");
+        const float sf = (float)m_status; const long long si = (long long)m_status;
+        hip(hipMemcpyAsync((char *)m_stage + total, type == ncclFloat ? (const void *)&sf : (const void *)&si, elem, hipMemcpyHostToDevice, m_stream), "hipMemcpyAsync");
+        nccl(ncclAllReduce(m_stage, m_stage, total / elem + 1, type, ncclSum, m_comm, m_stream), "ncclAllReduce");
+        float rf = 0; long long ri = 0;
+        hip(hipMemcpyAsync(type == ncclFloat ? (void *)&rf : (void *)&ri, (char *)m_stage + total, elem, hipMemcpyDeviceToHost, m_stream), "hipMemcpyAsync");
         off = 0;
         for (int i = 0; i < count; ++i) { if (p[i].bytes) hip(hipMemcpyAsync(p[i].dev, (char *)m_stage + off, p[i].bytes, hipMemcpyDeviceToDevice, m_stream), "hipMemcpyAsync"); off += p[i].bytes; }
         hip(hipStreamSynchronize(m_stream), "hipStreamSynchronize");
         ++m_collectives; m_bytes += total;
+        if (rf != 0 || ri != 0) throw std::runtime_error("render aborted: a rank reported a failure or a cancellation");
     }
     static void hip(hipError_t e, const char *what) { if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e)); }
     static void nccl(ncclResult_t r, const char *what) { if (r != ncclSuccess) throw std::runtime_error(std::string(what) + ": " + ncclGetErrorString(r)); }
@@ -151,6 +192,7 @@ private:
     hipStream_t m_stream = nullptr;
     void *m_stage = nullptr, *m_counts = nullptr;
     size_t m_stageBytes = 0, m_collectives = 0, m_bytes = 0;
+    int m_status = 0;
 };
 
 }  // namespace ppg

@@ -7,7 +7,8 @@
  *   shapes      sphere (center, radius, toWorld = rotation x uniform scale, flipNormals; analytic), obj (filename, toWorld, faceNormals, flipNormals, flipTexCoords, collapse), rectangle (toWorld, flipNormals)
  *   bsdfs       diffuse, conductor, roughconductor / roughdielectric / roughplastic (ggx / beckmann, isotropic; roughplastic reads Mitsuba's data/microfacet tables), plastic, dielectric, thindielectric, mask (constant opacity),
  *               twosided(BRDF) — top level with id, nested, or <ref id>
- *   emitters    area (nested in a shape), constant (environment), envmap (latitude-longitude .exr / .pfm / .hdr; filename, scale, toWorld = rotation)
+ *   emitters    area (nested in a shape), constant (environment), envmap (latitude-longitude .exr / .pfm / .hdr; filename, scale, toWorld = rotation),
+ *               sunsky (baked into an envmap at load time, host/sunsky.h; its tables are parsed from the operator's Mitsuba source tree)
  *   values      <spectrum>, <rgb>, <srgb>; <transform> of translate / rotate / scale / lookAt / matrix; <default> and $name
  *
  * Anything else throws std::runtime_error naming the plugin.  Same semantics as ppg_host/mitsuba_xml.py (the two are tested against each
@@ -241,6 +242,10 @@ inline void blackbodyToRGB(double temperature, double scale, float rgb[3]) {
     const double r = 3.240479 * X - 1.537150 * Y - 0.498535 * Z, gg = -0.969256 * X + 1.875991 * Y + 0.041556 * Z, b = 0.055648 * X - 0.204043 * Y + 1.057311 * Z;
     rgb[0] = (float)std::max(r, 0.0) * (float)scale; rgb[1] = (float)std::max(gg, 0.0) * (float)scale; rgb[2] = (float)std::max(b, 0.0) * (float)scale;
 }
+
+}  // namespace ppg
+#include "sunsky.h"
+namespace ppg {
 
 inline std::vector<double> parseFloats(std::string t) {
     for (char &c : t) if (c == ',') c = ' ';
@@ -771,8 +776,49 @@ public:
                 out.scene.hasEnvmap = true;
                 continue;
             }
+            if (e.get("type") == "sunsky" && !out.scene.hasEnvironment && !out.scene.hasEnvmap) {
+                // SunSkyEmitter (sunsky.cpp:100-235) bakes sun + sky into a radiance map and instantiates `envmap` on it: the same bake here
+                // (host/sunsky.h); the Hosek-Wilkie / Preetham tables are read from the operator's Mitsuba source tree (the parent of --data-dir,
+                // or PPG_MITSUBA_SRC)
+                std::string src = getenv("PPG_MITSUBA_SRC") ? getenv("PPG_MITSUBA_SRC") : "";
+                if (src.empty() && !m_dataDir.empty()) { std::string dd = m_dataDir; while (dd.size() > 1 && dd.back() == '/') dd.pop_back(); const size_t sl = dd.find_last_of('/'); src = sl == std::string::npos ? "." : dd.substr(0, sl); }
+                std::ifstream probe(src + "/src/emitters/sunsky/skymodeldata.h");
+                if (src.empty() || !probe) {
+                    if (!m_strict) { out.warnings.push_back("emitter 'sunsky' skipped (no Mitsuba source tree for the sky model's tables)"); continue; }
+                    throw std::runtime_error("sunsky: the sky model's coefficient tables (src/emitters/sunsky/skymodeldata.h, sunmodel.h) come with Mitsuba's source tree: "
+                                             "pass --data-dir <tree>/data or set PPG_MITSUBA_SRC");
+                }
+                auto ep = props(e);
+                for (const char *k : {"sunDirection", "extend"}) if (ep.count(k) && ep[k] != "false") throw std::runtime_error(std::string("sunsky: ") + k + " is not supported");
+                sunsky::Params sp;
+                auto num = [&](const char *k, double &v) { if (ep.count(k)) v = std::stod(ep[k]); };
+                auto inum = [&](const char *k, int &v) { if (ep.count(k)) v = std::stoi(ep[k]); };
+                num("latitude", sp.latitude); num("longitude", sp.longitude); num("timezone", sp.timezone); num("hour", sp.hour); num("minute", sp.minute); num("second", sp.second);
+                inum("year", sp.year); inum("month", sp.month); inum("day", sp.day); inum("resolution", sp.resolution);
+                num("scale", sp.scale); num("sunScale", sp.sunScale); num("skyScale", sp.skyScale); num("sunRadiusScale", sp.sunRadiusScale);
+                num("turbidity", sp.turbidity); num("stretch", sp.stretch);
+                for (auto &c : e.children)
+                    if (c.attr("name") && c.get("name") == "albedo" && (c.tag == "rgb" || c.tag == "srgb" || c.tag == "spectrum")) {
+                        float a3[3]; colour(e, "albedo", 0.2f, a3);
+                        for (int k = 0; k < 3; ++k) sp.albedo[k] = a3[k];
+                    }
+                int ew = 0, eh = 0;
+                sunsky::bake(sp, src, out.scene.envmapRgb, ew, eh);
+                Mat4 m = Mat4::identity();
+                if (const XmlNode *tw = e.child("transform")) m = transform(*tw);
+                for (int a = 0; a < 3; ++a)
+                    for (int b = 0; b < 3; ++b) {
+                        float d = 0;
+                        for (int k = 0; k < 3; ++k) d += m.m[4 * a + k] * m.m[4 * b + k];
+                        if (std::fabs(d - (a == b ? 1.0f : 0.0f)) > 1e-4f) throw std::runtime_error("sunsky: toWorld must be a rotation");
+                        out.scene.envmap.to_world[3 * a + b] = m.m[4 * a + b];
+                    }
+                out.scene.envmap.width = (uint32_t)ew; out.scene.envmap.height = (uint32_t)eh; out.scene.envmap.scale = 1.0f;
+                out.scene.hasEnvmap = true;
+                continue;
+            }
             if (!m_strict) { out.warnings.push_back("emitter '" + e.get("type") + "' skipped (not supported)"); continue; }
-            throw std::runtime_error("emitter type '" + e.get("type") + "' is not supported (area emitters on shapes and one `constant` or `envmap` environment emitter; SURVEY.md §8 f2)");
+            throw std::runtime_error("emitter type '" + e.get("type") + "' is not supported (area emitters on shapes and one `constant`, `envmap` or `sunsky` environment emitter; SURVEY.md §8 f2)");
         }
         // shapes
         struct Part { Mesh mesh; uint32_t mat; int em; };

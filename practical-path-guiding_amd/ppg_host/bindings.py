@@ -458,6 +458,29 @@ class Engine:
         """Inside the round hook: the records to apply instead (the union over all ranks)."""
         self._call("adam_records_replace", C.c_void_p(ptr), C.c_uint64(n))
 
+    # ---- one owner per D-tree (include/ppg.h "Sharded optimiser") ----
+    def hook_phase(self):
+        """Inside the round hook: 0 before the round's records are applied, 1 after (only if phase 0 asked for the records by owner)."""
+        ph = C.c_int32()
+        self._call("hook_phase", C.byref(ph))
+        return ph.value
+
+    def adam_records_by_owner(self, world):
+        """Phase 0: (pointer to this rank's records in key order, [count for owner 0, ..., owner world-1])."""
+        ptr = C.c_void_p()
+        counts = (C.c_uint64 * world)()
+        self._call("adam_records_by_owner", C.c_int32(world), C.byref(ptr), counts)
+        return ptr.value, [int(c) for c in counts]
+
+    def adam_state(self, world):
+        """Phase 1: (pointer to the packed optimiser state, 24 bytes per S-tree node, world * segment entries; segment)."""
+        ptr, seg = C.c_void_p(), C.c_uint64()
+        self._call("adam_state", C.c_int32(world), C.byref(ptr), C.byref(seg))
+        return ptr.value, seg.value
+
+    def adam_state_commit(self):
+        self._call("adam_state_commit")
+
     def set_pass_hook(self, fn):
         """fn() is called at the end of every round of the sampling-fraction optimiser (include/ppg.h), after this rank's records
         were collected and before they are applied."""

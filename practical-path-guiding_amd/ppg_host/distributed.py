@@ -5,8 +5,10 @@ accumulates — guided_path.cpp:610-613, 308, 332, 397), so every rank renders t
 t % world == rank for all passes and the only exchange per iteration is
     one all_reduce(SUM) of the building tree's fixed-point leaf sums + the per-D-tree statistical weights (uint64 as int64: exact, order independent)
     one all_reduce(SUM) of image / squared image / weights of the iteration (disjoint supports → exact)
-plus, when the BSDF sampling fraction is learned, one all_gather per ROUND of the optimiser's records (include/ppg.h);
-after which refine/reset/build are deterministic functions of identical data on every rank: the SD-tree
+plus, when the BSDF sampling fraction is learned, per ROUND of the optimiser (include/ppg.h "Sharded optimiser") one all-to-all of
+its records — every D-tree has ONE owner, rank = S-tree node / ceil(nodes / world), which sorts and applies that D-tree's records of
+all ranks — and one all-gather of the 24-byte optimiser state per S-tree node (`gather_all=True` restores round 2's scheme: every
+rank gathers and applies everything); after which refine/reset/build are deterministic functions of identical data on every rank: the SD-tree
 topology stays bit-identical across ranks and equal to a single-GPU render.  torch is plumbing here
 (device-pointer views + the collective); all compute is in libppg_hip.so.
 
@@ -31,9 +33,9 @@ def _view(torch, ptr, n, typestr, device):
 
 
 class TorchReducer:
-    def __init__(self, dist, device):
+    def __init__(self, dist, device, gather_all=False):
         import torch
-        self.torch, self.dist, self.device = torch, dist, device
+        self.torch, self.dist, self.device, self.gather_all = torch, dist, device, gather_all
 
     def _all_reduce_fused(self, views):
         """ONE collective per exchange: the arrays are separate allocations of the context, so they are packed into a staging tensor,
@@ -63,9 +65,37 @@ class TorchReducer:
                                 _view(self.torch, w, n, "<f4", self.device)])
 
     def reduce_adam(self, e):
-        """Round hook of the sampling-fraction optimiser: every rank applies the records of ALL ranks (in key order, which does
-        not depend on the sharding), so the learned fractions stay identical everywhere and equal to a single-GPU render.
-        The records travel as int64 quadruples (32 bytes each); ranks contribute different counts, so the gather is padded."""
+        """Round hook of the sampling-fraction optimiser (called twice per round, include/ppg.h "Sharded optimiser").
+        Phase 0: this rank's records, in key order, are split by OWNER of their D-tree and exchanged with ONE all-to-all (32-byte records
+        as int64 quadruples): a rank receives — and then sorts and applies — only the records of the D-trees it owns, 1 / world of the
+        total instead of all of them.  Phase 1: the owners' results, 24 bytes of optimiser state per S-tree node, are all-gathered in
+        place.  Same records in the same key order at the owner ⇒ the fractions stay bit-identical to a single-GPU render."""
+        torch, dist = self.torch, self.dist
+        world = dist.get_world_size()
+        if self.gather_all:
+            return self._reduce_adam_gather_all(e)
+        if e.hook_phase() == 0:
+            ptr, send = e.adam_records_by_owner(world)
+            sc = torch.tensor(send, dtype=torch.int64, device=self.device)
+            rc = torch.empty_like(sc)
+            dist.all_to_all_single(rc, sc)                       # how many records every rank will send me
+            recv = [int(c) for c in rc.tolist()]
+            n_send, n_recv = sum(send), sum(recv)
+            src = _view(torch, ptr, 4 * n_send, "<i8", self.device) if n_send else torch.empty(0, dtype=torch.int64, device=self.device)
+            self._adam_recv = torch.empty(4 * max(n_recv, 1), dtype=torch.int64, device=self.device)
+            dist.all_to_all_single(self._adam_recv[:4 * n_recv], src, [4 * c for c in recv], [4 * c for c in send])
+            torch.cuda.synchronize()
+            e.adam_records_replace(self._adam_recv.data_ptr(), n_recv)
+        else:
+            ptr, seg = e.adam_state(world)
+            state = _view(torch, ptr, 3 * seg * world, "<i8", self.device)      # 24 bytes per node = three int64
+            mine = state[3 * seg * dist.get_rank():3 * seg * (dist.get_rank() + 1)].clone()
+            dist.all_gather_into_tensor(state, mine)
+            torch.cuda.synchronize()
+            e.adam_state_commit()
+
+    def _reduce_adam_gather_all(self, e):
+        """Round 2's scheme, kept for comparison: every rank gathers the records of ALL ranks and applies the union."""
         torch, dist = self.torch, self.dist
         ptr, n = e.adam_records()
         world = dist.get_world_size()
@@ -96,9 +126,9 @@ class TorchReducer:
 class HostReducer:
     """Same exchange for an oracle engine (host memory, gloo)."""
 
-    def __init__(self, dist):
+    def __init__(self, dist, gather_all=False):
         import torch
-        self.torch, self.dist = torch, dist
+        self.torch, self.dist, self.gather_all = torch, dist, gather_all
 
     def _allreduce_np(self, arr):
         t = self.torch.from_numpy(arr)
@@ -131,6 +161,32 @@ class HostReducer:
         self._allreduce_np(np.ctypeslib.as_array(w, shape=(n,)))
 
     def reduce_adam(self, e):
+        """The same two-phase exchange as TorchReducer.reduce_adam, on host arrays."""
+        torch, dist = self.torch, self.dist
+        world, rank = dist.get_world_size(), dist.get_rank()
+        if self.gather_all:
+            return self._reduce_adam_gather_all(e)
+        if e.hook_phase() == 0:
+            ptr, send = e.adam_records_by_owner(world)
+            rc = torch.empty(world, dtype=torch.int64)
+            dist.all_to_all_single(rc, torch.tensor(send, dtype=torch.int64))
+            recv = [int(c) for c in rc.tolist()]
+            n_send, n_recv = sum(send), sum(recv)
+            src = torch.from_numpy(np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int64)), shape=(4 * n_send,)).copy()) if n_send else torch.empty(0, dtype=torch.int64)
+            got = torch.empty(4 * n_recv, dtype=torch.int64)
+            dist.all_to_all_single(got, src, [4 * c for c in recv], [4 * c for c in send])
+            self._adam_recv = np.ascontiguousarray(got.numpy())
+            e.adam_records_replace(self._adam_recv.ctypes.data if n_recv else 0, n_recv)
+        else:
+            ptr, seg = e.adam_state(world)
+            state = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int64)), shape=(3 * seg * world,))
+            parts = [torch.empty(3 * seg, dtype=torch.int64) for _ in range(world)]
+            dist.all_gather(parts, torch.from_numpy(state[3 * seg * rank:3 * seg * (rank + 1)].copy()))
+            for r, part in enumerate(parts):
+                state[3 * seg * r:3 * seg * (r + 1)] = part.numpy()
+            e.adam_state_commit()
+
+    def _reduce_adam_gather_all(self, e):
         torch, dist = self.torch, self.dist
         ptr, n = e.adam_records()
         world = dist.get_world_size()

@@ -48,7 +48,7 @@ class GuidedPathTracer:
             # different numbers of passes and iterations and their collectives would no longer match
             raise ValueError("sharded rendering needs budgetType='spp' (a time budget is decided by rank-local clocks)")
         if self.reducer is not None and p["bsdfSamplingFractionLoss"] != "none":
-            e.set_pass_hook(lambda: self.reducer.reduce_adam(e))  # every rank applies the records of all ranks, round by round
+            e.set_pass_hook(lambda: self.reducer.reduce_adam(e))  # per round: records to the owners of their D-trees, the owners' state back to all
         self.iterations = []
         spp = p["sppPerPass"]
         automatic = p["sampleCombination"] == "automatic"

@@ -116,9 +116,20 @@ def load_scene_file(path):
     off = [28]
 
     def take(dtype, count):
+        # every count comes from the file: checked against what is left of it (a corrupt or truncated file is a ValueError, not an
+        # allocation of whatever size its header claims)
+        need = int(count) * np.dtype(dtype).itemsize
+        if count < 0 or need > len(buf) - off[0]:
+            raise ValueError("%s: truncated or corrupt flat scene file" % path)
         a = np.frombuffer(buf, dtype, count, off[0])
         off[0] += a.nbytes
         return a
+
+    def image_size():
+        w, h = (int(v) for v in take(np.uint32, 2))
+        if not (0 < w < 0x8000 and 0 < h < 0x8000):  # what ppg_set_scene accepts
+            raise ValueError("%s: image of %d x %d pixels" % (path, w, h))
+        return w, h
     pos = take(np.float32, 3 * nv).reshape(-1, 3).copy()
     nrm = take(np.float32, 3 * nv).reshape(-1, 3).copy() if has_n else None
     idx = take(np.uint32, 3 * nt).reshape(-1, 3).copy()
@@ -154,7 +165,7 @@ def load_scene_file(path):
                                 flip_normals=bool(sp.flip_normals)))
     envmap = None
     if blocks & 8:
-        w, h = (int(v) for v in take(np.uint32, 2))
+        w, h = image_size()
         scale = float(take(np.float32, 1)[0])
         R = [float(v) for v in take(np.float32, 9)]
         envmap = dict(rgb=take(np.float32, w * h * 3).reshape(h, w, 3).copy(), scale=scale, to_world=R)
@@ -163,7 +174,7 @@ def load_scene_file(path):
     if blocks & 32:
         names = ["repeat", "mirror", "clamp", "zero", "one"]
         for _ in range(int(take(np.uint32, 1)[0])):
-            w, h = (int(v) for v in take(np.uint32, 2))
+            w, h = image_size()
             sc = [float(v) for v in take(np.float32, 4)]
             wu, wv, nearest = (int(v) for v in take(np.int32, 3))
             storage = int(take(np.uint32, 1)[0])

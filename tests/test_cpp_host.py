@@ -37,6 +37,32 @@ def test_driver_builds_and_rejects_bad_input(ppg_render, tmp_path):
     assert r.returncode == 3 and ("spatialFilter" in r.stderr or "HIP device" in r.stderr)  # unknown enum value / no GPU here
 
 
+def test_truncated_and_corrupt_scene_files_are_refused(ppg_render, tmp_path):
+    """A flat scene file whose header or texture block claims more than the file holds (truncated download, corrupt sizes): both
+    readers refuse it — "cannot load scene" / ValueError — instead of sizing an allocation by the claim."""
+    import struct
+    import ppg_host
+    s = ppg_host.cbox_scene(16, 16)
+    s.textures = [dict(rgb=np.full((4, 4, 3), 0.5, np.float32))]
+    s.texcoords = np.zeros((len(s.positions), 2), np.float32)
+    good = tmp_path / "good.ppgs"
+    ppg_host.save_scene(s, str(good))
+    buf = good.read_bytes()
+    assert len(ppg_host.load_scene_file(str(good)).textures) == 1
+    cases = {"cut.ppgs": buf[:len(buf) // 2], "short-texture.ppgs": buf[:-7],
+             "huge-count.ppgs": buf[:4] + struct.pack("<I", 0x7fffffff) + buf[8:]}
+    tex_hdr = len(buf) - (8 + 16 + 12 + 4 + 4 * 4 * 3 * 4)            # width, height of the one texture
+    cases["huge-texture.ppgs"] = buf[:tex_hdr] + struct.pack("<2I", 0x7fff, 0x7fff) + buf[tex_hdr + 8:]
+    cases["zero-texture.ppgs"] = buf[:tex_hdr] + struct.pack("<2I", 0, 4) + buf[tex_hdr + 8:]
+    for name, data in cases.items():
+        p = tmp_path / name
+        p.write_bytes(data)
+        with pytest.raises(ValueError):
+            ppg_host.load_scene_file(str(p))
+        r = subprocess.run([ppg_render, str(p)], capture_output=True, text=True)
+        assert r.returncode == 2 and "cannot load scene" in r.stderr, (name, r.returncode, r.stderr)
+
+
 def test_scene_file_round_trip(tmp_path):
     import struct
     import ppg_host
@@ -89,8 +115,10 @@ def test_cpp_driver_equals_python_path(ppg_render, tmp_path):
 @pytest.mark.gpu
 def test_cpp_rccl_reducer_single_rank(ppg_render, tmp_path):
     """`ppg_render --rank 0 --world 1 --nccl-id FILE`: the C++ RCCL reducer with a real communicator (ncclCommInitRank, packed all-reduces
-    of images / SD-tree sums / film, all-gather of the optimiser records).  On one rank every sum is the identity, so the picture must
-    equal the un-sharded render bit for bit — for both film combinations and with the sampling-fraction optimiser on."""
+    of images / SD-tree sums / film each with its status word; per round of the optimiser the records sent to the owners of their D-trees
+    by grouped ncclSend / ncclRecv and the owners' state all-gathered — include/ppg.h "Sharded optimiser").  On one rank every exchange is
+    the identity, so the picture must equal the un-sharded render bit for bit — for both film combinations and with the sampling-fraction
+    optimiser on.  The id file carries the run's tag and is gone once the communicator exists."""
     import ppg_host
     scene = ppg_host.cbox_scene(96, 64)
     path = str(tmp_path / "cbox.ppgs")
@@ -101,9 +129,11 @@ def test_cpp_rccl_reducer_single_rank(ppg_render, tmp_path):
         a, b = str(tmp_path / "a.pfm"), str(tmp_path / "b.pfm")
         r = subprocess.run([ppg_render, "-q", "-o", a] + defs + [path], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr
-        r = subprocess.run([ppg_render, "-o", b, "--rank", "0", "--world", "1", "--nccl-id", str(tmp_path / "id")] + defs + [path],
+        (tmp_path / "id").write_bytes(b"stale file of an earlier run")
+        r = subprocess.run([ppg_render, "-o", b, "--rank", "0", "--world", "1", "--nccl-id", str(tmp_path / "id"), "--run-tag", "run-%d" % len(extra)] + defs + [path],
                            capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr
+        assert not (tmp_path / "id").exists()
         assert "RCCL communicator: rank 0 of 1" in r.stdout
         n = int(re.search(r"RCCL: (\d+) collectives", r.stdout).group(1))
         assert n >= 2 * len(re.findall(r"ITERATION", r.stdout))
@@ -423,6 +453,30 @@ def test_cpp_named_conductors_equal_the_python_loader(ppg_render, tmp_path):
     env = dict(os.environ); env.pop("PPG_MITSUBA_DATA", None)
     r = subprocess.run([ppg_render, "--ppgs", str(tmp_path / "x.ppgs"), "-q", "-D", "nee=never", xml], capture_output=True, text=True, env=env)
     assert r.returncode == 2 and "data/ior" in r.stderr
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/mitsuba/src/emitters/sunsky/skymodeldata.h"), reason="Mitsuba source tree not mounted (development container only)")
+def test_cpp_sunsky_bake_equals_the_python_loader(ppg_render, tmp_path):
+    """`sunsky` in the C++ host (host/sunsky.h): the same bake as ppg_host/sunsky.py — Hosek-Wilkie sky + Preetham sun rasterised into the
+    latitude-longitude radiance map the envmap emitter takes, tables parsed from the operator's Mitsuba tree — for the plug-in's defaults
+    and for KITCHEN's settings (kitchen-improved.xml: its own sun position, scale, turbidity)."""
+    import ppg_host
+    from test_mitsuba_xml import _write
+    for extra in ('<emitter type="sunsky"/>',
+                  '<emitter type="sunsky"><float name="hour" value="9.5"/><float name="turbidity" value="4.5"/><float name="scale" value="2"/>'
+                  '<integer name="resolution" value="128"/><float name="sunRadiusScale" value="3"/><rgb name="albedo" value="0.1, 0.3, 0.5"/>'
+                  '<transform name="toWorld"><rotate y="1" angle="40"/></transform></emitter>'):
+        xml = _write(tmp_path, extra)
+        r, c = _cpp_load(ppg_render, xml, tmp_path, "-D", "nee=never", "--data-dir", "/root/reference/mitsuba/data")
+        assert r.returncode == 0, r.stderr
+        desc, _, _ = ppg_host.load_scene(xml, defines=dict(nee="never"), data_dir="/root/reference/mitsuba/data")
+        a, b = c["envmap"]["rgb"], np.asarray(desc.envmap["rgb"])
+        assert a.shape == b.shape and b.shape[1] == 2 * b.shape[0]
+        assert np.allclose(c["envmap"]["to_world"], desc.envmap["to_world"], atol=1e-6) and c["envmap"]["scale"] == 1.0
+        sun = b.max(-1) > 50 * np.median(b.max(-1)[: b.shape[0] // 2])                       # the pixels of the sun's disc
+        assert 1 <= sun.sum() < 400 and np.array_equal(sun, a.max(-1) > 50 * np.median(a.max(-1)[: a.shape[0] // 2]))
+        assert np.allclose(a, b, rtol=2e-5, atol=1e-7)                                       # libm vs numpy transcendentals: a few ulp
+        assert abs(a.sum() / b.sum() - 1) < 1e-6
 
 
 def test_cpp_lenient_loading_equals_the_python_loader(ppg_render, tmp_path):

@@ -290,7 +290,10 @@ def test_tuning_switches_do_not_change_results(monkeypatch):
     base_img, base_tree = run()
     assert np.isfinite(base_img).all() and base_img.mean() > 1e-3
     for env in (dict(PPG_PATH_LAYOUT="aos"), dict(PPG_NO_OVERLAP="1"), dict(PPG_NO_SORT="1"), dict(PPG_TAIL_MIN="1", PPG_TAIL_DIV="1000000"),
-                dict(PPG_TAIL_THRESHOLD="100000000"), dict(PPG_BLOCKS="512"), dict(PPG_BATCH_PATHS="20000"), dict(PPG_TAIL_BLOCKS="64")):
+                dict(PPG_TAIL_THRESHOLD="100000000"), dict(PPG_BLOCKS="512"), dict(PPG_BATCH_PATHS="20000"), dict(PPG_TAIL_BLOCKS="64"),
+                dict(PPG_BULK_BOUNCES="0"), dict(PPG_BULK_BOUNCES="3", PPG_TAIL_GENS="3", PPG_TAIL_GEN="4"), dict(PPG_BOUNCE_MARGIN="0"),
+                dict(PPG_SIDE_TAILS="1", PPG_SUB_PATHS="1500", PPG_TAIL_MIN="200", PPG_TAIL_DIV="1000000"),
+                dict(PPG_SIDE_TAILS="1", PPG_SUB_PATHS="1000", PPG_TAIL_PRIO="1", PPG_TAIL_GENS="2", PPG_TAIL_GEN="8", PPG_TAIL_SETPRIO="1")):
         with monkeypatch.context() as m:
             for k, v in env.items():
                 m.setenv(k, v)
@@ -468,9 +471,12 @@ def test_round_hook_sees_the_records_of_every_round():
         assert [p // (64 * 64) for _, p in seen] == [0, 0, 1, 1, 3, 3]  # path id = sample-in-round * pixels + pixel
 
 
-def test_sharded_contexts_with_learned_fraction_equal_unsharded():
+@pytest.mark.parametrize("scheme", ["owner", "gather"])
+def test_sharded_contexts_with_learned_fraction_equal_unsharded(scheme):
     """Two tile-sharded contexts on one GPU with the improved preset (KL-learned sampling fraction): the two render threads meet in
-    the round hook, each applies the union of both ranks' records — fractions, SD-tree and image equal the unsharded render."""
+    the round hook.  "owner" (include/ppg.h "Sharded optimiser"): every D-tree has one owner; phase 0 sends each record to the owner of
+    its D-tree, which sorts and applies only those, phase 1 copies the owners' optimiser state to the other context.  "gather": each
+    context applies the union of both ranks' records.  Fractions, SD-tree and image equal the unsharded render either way."""
     import threading
     import ppg_host
     import torch
@@ -484,7 +490,41 @@ def test_sharded_contexts_with_learned_fraction_equal_unsharded():
     barrier = threading.Barrier(2)
     slots = [None, None]
 
+    def make_owner_hook(r):
+        e = engines[r]
+
+        def hook():
+            if e.hook_phase() == 0:
+                ptr, counts = e.adam_records_by_owner(2)
+                recs = _view(torch, ptr, 4 * sum(counts), "<i8", dev).reshape(-1, 4) if sum(counts) else torch.zeros((0, 4), dtype=torch.int64, device=dev)
+                seg = (e.sdtree_info().n_stree_nodes + 1) // 2
+                assert bool(((recs[:counts[0], 0] >> 40) < seg).all()) and bool(((recs[counts[0]:, 0] >> 40) >= seg).all())
+                slots[r] = (recs[:counts[0]].clone(), recs[counts[0]:].clone())
+                torch.cuda.synchronize()
+                barrier.wait()
+                mine = torch.cat([slots[0][r], slots[1][r]]).contiguous()
+                keep.append(mine)
+                torch.cuda.synchronize()
+                e.adam_records_replace(mine.data_ptr(), mine.shape[0])
+                barrier.wait()
+            else:
+                ptr, seg = e.adam_state(2)
+                state = _view(torch, ptr, 3 * seg * 2, "<i8", dev)
+                slots[r] = state[3 * seg * r:3 * seg * (r + 1)].clone()
+                torch.cuda.synchronize()
+                barrier.wait()
+                o = 1 - r
+                state[3 * seg * o:3 * seg * (o + 1)] = slots[o]
+                torch.cuda.synchronize()
+                e.adam_state_commit()
+                barrier.wait()
+        return hook
+    keep = []
+
     def make_hook(r):
+        if scheme == "owner":
+            return make_owner_hook(r)
+
         def hook():
             ptr, n = engines[r].adam_records()
             slots[r] = _view(torch, ptr, 4 * n, "<i8", dev).clone() if n else torch.zeros(0, dtype=torch.int64, device=dev)

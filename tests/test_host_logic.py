@@ -117,24 +117,26 @@ if sys.argv[4] == "full-scene":
     from test_gpu_parity import _sphere_scene
     scene = _sphere_scene((64, 48), sky=True)
 e.set_scene(scene); e.set_shard(rank, world, 16)
-img = ppg_host.GuidedPathTracer(engine=e, reducer=HostReducer(dist)).render()
+img = ppg_host.GuidedPathTracer(engine=e, reducer=HostReducer(dist, gather_all=(sys.argv[5] == "gather"))).render()
 t = e.read_sdtree()
 np.savez(os.path.join(sys.argv[3], "rank%d.npz" % rank), film=img, children=t["children"], dch=t["sampling"]["node_children"], dsum=t["sampling"]["node_sums"], theta=t["theta"])
 dist.barrier(); dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("mode", ["default", "inversevar", "improved", "nee", "full-scene"])
-def test_sharded_render_over_gloo_equals_single_rank(oracle_lib, tmp_path, mode):
-    """world_size 2, gloo: tiles sharded, SD-tree statistics all-reduced as int64 → the merged render is
-    bit-identical to the unsharded one on every rank (SURVEY.md §8(e))."""
+@pytest.mark.parametrize("mode,world,scheme", [("default", 2, "owner"), ("inversevar", 2, "owner"), ("improved", 2, "owner"), ("nee", 2, "owner"),
+                                               ("full-scene", 2, "owner"), ("improved", 4, "owner"), ("nee", 4, "owner"), ("improved", 2, "gather")])
+def test_sharded_render_over_gloo_equals_single_rank(oracle_lib, tmp_path, mode, world, scheme):
+    """world_size 2 and 4, gloo: tiles sharded, SD-tree statistics all-reduced as int64, the optimiser's records sent to the OWNER of
+    their D-tree (all-to-all) and the owners' optimiser state all-gathered ("owner"; "gather": round 2's gather-everything scheme) →
+    the merged render, the SD-tree and the learned fractions are bit-identical to the unsharded ones on every rank (SURVEY.md §8(e))."""
     import ppg_host
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + os.getpid() % 2000), OMP_NUM_THREADS="2")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
            "--master-port", env["MASTER_PORT"], str(script), os.path.join(ROOT, "practical-path-guiding_amd"),
-           os.path.join(ROOT, "oracle", "libppg_oracle.so"), str(tmp_path), mode]
+           os.path.join(ROOT, "oracle", "libppg_oracle.so"), str(tmp_path), mode, scheme]
     subprocess.run(cmd, check=True, env=env, timeout=600, capture_output=True)
     props = dict(CBOX_PROPS, budget=60, seed=17)
     if mode == "inversevar":
@@ -151,7 +153,7 @@ def test_sharded_render_over_gloo_equals_single_rank(oracle_lib, tmp_path, mode)
     e = make_oracle(oracle_lib, threads=4, **props)
     e.set_scene(scene); e.render()
     ref_img, ref_t = e.read_film(), e.read_sdtree()
-    for r in range(2):
+    for r in range(world):
         got = np.load(tmp_path / ("rank%d.npz" % r))
         assert np.array_equal(got["children"], ref_t["children"])
         assert np.array_equal(got["dch"], ref_t["sampling"]["node_children"]) and np.array_equal(got["dsum"], ref_t["sampling"]["node_sums"])
