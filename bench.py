@@ -82,7 +82,7 @@ def algorithmic_bytes(work=None, rays=None, bvh=None):
 def measured_traffic(tag):
     """HBM bytes per unit from profiles/<tag>_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, calibrated as
     MI355X_MICROARCH.md prescribes; written by tools/collect_profiles.py on the GPU box) — a STORED calibration, not measured in this run."""
-    for name in ("r02_pmc_traffic_%s.json" % tag, "r01_pmc_traffic.json" if tag == "cbox" else ""):
+    for name in ("r03_pmc_traffic_%s.json" % tag, "r02_pmc_traffic_%s.json" % tag, "r01_pmc_traffic.json" if tag == "cbox" else ""):
         p = os.path.join(ROOT, "profiles", name)
         if name and os.path.exists(p):
             try:
@@ -308,8 +308,9 @@ def run(args):
             avg_units, avg_ms = units / k["launches"], k["ms"] / k["launches"]
             achieved = bpu * avg_units / (avg_ms * 1e-3) / 1e9
             traffic = None
-            if tr and name in tr.get("bytes_per_unit", {}):  # the stored calibration is per unit as the kernel timer counts them (k_tail: paths handed over)
-                traffic = tr["bytes_per_unit"][name] * k["units"] / k["launches"]
+            if tr and name in tr.get("bytes_per_unit", {}):  # the stored calibration's unit (r03: the roofline's own unit for every kernel; r02: k_tail per path handed over)
+                per_ray = "unit_of_work" in tr
+                traffic = tr["bytes_per_unit"][name] * (units if (per_ray or name != "k_tail") else k["units"]) / k["launches"]
             return {"kernel": k["name"], "ms": round(k["ms"], 3), "launches": k["launches"], "avg_launch_ms": avg_ms, "avg_units_per_launch": avg_units,
                     "algorithmic_bytes_per_unit": bpu, "achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "traffic": traffic}
 
@@ -323,12 +324,18 @@ def run(args):
                            "avg_launch_ms": dom["avg_launch_ms"], "launches": dom["launches"],
                            "algorithmic_bytes_per_unit": dom["algorithmic_bytes_per_unit"], "avg_units_per_launch": dom["avg_units_per_launch"],
                            "unit_of_work": "ray traced and shaded inside the persistent-thread tail" if name == "k_tail" else ("traced ray" if name in ("k_trace", "k_shade") else "unit of " + name),
+                           "tail_critical_path": ({"longest_paths_sum_bounces": counts["tail_longest_paths_sum"], "k_tail_ms": next((k["ms"] for k in times if k["name"] == "k_tail"), None),
+                                                   "us_per_bounce_of_the_longest_path": 1e3 * next((k["ms"] for k in times if k["name"] == "k_tail"), 0.0) / counts["tail_longest_paths_sum"],
+                                                   "note": "a launch of k_tail cannot end before its longest path has: the sum over the iterations of the longest path each tail "
+                                                           "finished (bounces; per iteration the longest of its launches) against k_tail's total time — a LOWER bound of the time per "
+                                                           "bounce of that one lane.  k_tail is bound by this chain of dependent bounces (DESIGN.md section 7), not by bandwidth"}
+                                                  if counts.get("tail_longest_paths_sum") else None),
                            "operation_counts": alg["detail"], "kernels_ms": {k["name"]: round(k["ms"], 3) for k in times},
                            "per_kernel": {n: {q: (round(v, 4) if isinstance(v, float) else v) for q, v in e.items() if q != "kernel"} for n, e in per.items()
                                           if n.split("<")[0] in ("k_trace", "k_shade", "k_tail", "k_commit")},
                            "note": "the BVH and the SD-tree are L2 / Infinity-Cache resident: the algorithmic bytes are what the kernel must read per ray "
                                    "(cache-oblivious), `traffic` what reaches HBM.  k_tail finishes the paths still alive after the wavefront bounces, one lane per "
-                                   "path: it is bound by the latency of the longest path, not by bandwidth (DESIGN.md §7)"}
+                                   "path: it is bound by the chain of dependent bounces of its longest path (`tail_critical_path`), not by bandwidth (DESIGN.md §7)"}
 
     if rank == 0 and args.gpus == 1 and not args.no_rmse and scene_name == "kitchen" and os.path.exists(KITCHEN_REFERENCE):
         # Time to equal error.  The yardstick is the reference's own converged picture, scenes/kitchen/kitchen-reference.exr (committed as

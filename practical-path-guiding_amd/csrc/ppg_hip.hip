@@ -412,20 +412,6 @@ struct ppg_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;    // k_commit of the finished paths runs here while k_tail finishes the stragglers on `stream`
     hipEvent_t evFork = nullptr, evJoin = nullptr;
-#define PPG_MAX_SUB 16      // sub-batches per batch (renderBatch)
-#define PPG_TAIL_STREAMS 4  // side streams their persistent-thread tails are dealt to
-    hipStream_t tailStreams[PPG_TAIL_STREAMS] = {};
-    hipEvent_t evBulk[PPG_MAX_SUB] = {}, evTail[PPG_MAX_SUB] = {};
-#define PPG_MAX_GENS 32     // launches of one tail (generations)
-    DevBuf<unsigned int> d_tailList;            // [path slot] work lists of the tails, sub-batch k's at k * (sub-batch size)
-    DevBuf<unsigned long long> d_tailTotal;     // [PPG_MAX_SUB] their lengths
-    DevBuf<unsigned int> d_tailListA, d_tailListB, d_genTicket;  // what one generation of a tail hands to the next (ping-pong), tickets per launch
-    DevBuf<unsigned long long> d_genTotal;      // [PPG_MAX_SUB][PPG_MAX_GENS]
-    int tailGen = 32, tailGens = 0;             // PPG_TAIL_GEN: bounces per path and launch; PPG_TAIL_GENS: launches before the unlimited one (0: one launch)
-    bool tuneSideTails = false;                 // PPG_SIDE_TAILS: the tails run on side streams beside the next sub-batch's wavefront
-    bool tuneTailSetprio = false;               // PPG_TAIL_SETPRIO: waves of k_tail that carry a long path raise their issue priority
-    bool tuneTailPrio = false;                  // PPG_TAIL_PRIO: ... of the highest stream priority
-    hipStream_t tailStreamsLo[PPG_TAIL_STREAMS] = {};
     DevBuf<unsigned char> d_straggler;  // [path] 1 = still alive when the persistent-thread tail took over
 
     // scene
@@ -518,7 +504,6 @@ struct ppg_ctx {
     bool tuneFuse = false;            // PPG_FUSE: trace small scenes inside k_generate / k_shade
     bool tuneNoSort = false;          // PPG_NO_SORT: do not sort the queue slices by BSDF type before k_shade<FULL>
     bool tuneNoOverlap = false;       // PPG_NO_OVERLAP: k_commit after k_tail on one stream instead of beside it
-    size_t tuneSubPaths = 0;          // PPG_SUB_PATHS: paths per sub-batch (0 = 2 M)
     int tuneBulkBounces = -1;         // PPG_BULK_BOUNCES: fixed number of wavefront bounces before k_tail takes over (-1 = adaptive)
     bool debugBatch = false;          // PPG_DEBUG_BATCH: one line per batch on stderr (paths, live paths after every bulk bounce, tail time)
     int tuneFinalBatch = 0;           // PPG_FINAL_BATCH: passes per batch of the final iteration (0 = 64)
@@ -539,6 +524,7 @@ struct ppg_ctx {
     float lastVariance = 0;
     ppg_pass_stats lastStats{};
     KernelTimer timer;
+    uint64_t tailLongestSum = 0;  // sum over the performRenderPasses calls of the longest path their tails finished (bounces): the tails' critical path
     uint64_t bvhNodesVisited = 0, bvhTrisTested = 0;  // by k_trace while kernel timing is on (the roofline's node / triangle counts)
     ppg_pass_hook passHook = nullptr;
     void *passHookUser = nullptr;
@@ -840,8 +826,7 @@ int allocPaths(ppg_ctx *ctx) {
     const size_t cap = ((chunks + nb - 1) / nb) * PPG_DCHUNK;
     for (int k = 0; k < 2; ++k) { HIP_CHECK(ctx->d_queue[k].reserve(cap * nb)); HIP_CHECK(ctx->d_qcount[k].reserve(nb)); }
     HIP_CHECK(ctx->d_stats.reserve(nb)); HIP_CHECK(ctx->d_qtotal.reserve(1));
-    HIP_CHECK(ctx->d_bounceCounts.reserve(72 * PPG_MAX_SUB)); HIP_CHECK(ctx->d_ticket.reserve(PPG_MAX_SUB)); HIP_CHECK(ctx->d_tailTotal.reserve(PPG_MAX_SUB)); HIP_CHECK(ctx->d_tailList.reserve(nn + PPG_MAX_SUB * PPG_DCHUNK)); HIP_CHECK(ctx->d_tailListA.reserve(nn + PPG_MAX_SUB * PPG_DCHUNK)); HIP_CHECK(ctx->d_tailListB.reserve(nn + PPG_MAX_SUB * PPG_DCHUNK));
-    HIP_CHECK(ctx->d_genTotal.reserve(PPG_MAX_SUB * PPG_MAX_GENS)); HIP_CHECK(ctx->d_genTicket.reserve(PPG_MAX_SUB * (PPG_MAX_GENS + 1))); HIP_CHECK(ctx->d_total.reserve(2)); HIP_CHECK(ctx->d_offsets.reserve(nb));
+    HIP_CHECK(ctx->d_bounceCounts.reserve(72)); HIP_CHECK(ctx->d_ticket.reserve(1));
     HIP_CHECK(ctx->d_adamCount.reserve(2));
     if (!ctx->h_round) HIP_CHECK(hipHostMalloc((void **)&ctx->h_round, 68 * sizeof(unsigned int), hipHostMallocDefault));
     ctx->queues.items[0] = ctx->d_queue[0].p; ctx->queues.items[1] = ctx->d_queue[1].p;
@@ -951,7 +936,6 @@ int applyAdamRound(ppg_ctx *ctx, size_t nRecords) {
 int renderBatch(ppg_ctx *ctx, int batch, bool adamRound) {
     PathState P = ctx->paths;
     P.n_paths = (unsigned int)((size_t)ctx->nPix * ctx->sppPerPass * (size_t)batch);
-    P.first = 0; P.n_sub = P.n_paths;
     if (P.n_paths == 0 && !(adamRound && ctx->passHook)) return PPG_OK;
     hipStream_t s = ctx->stream;
     // Adam records: positions are known in advance unless one vertex can make several records (box spatial filter) or records are made
@@ -970,6 +954,7 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound) {
     R.pass_index_spp = (unsigned int)ctx->passesRendered * (unsigned int)ctx->sppPerPass;
     Queues Q = ctx->queues;
     const int grid = ctx->nBlocks;
+    const int gridAll = gridFor(P.n_paths);
     const bool smallScene = ctx->scene.n_tris <= 64 && ctx->ldsTris == ctx->scene.n_tris && ctx->scene.n_spheres == 0 && !ctx->tuneForceBvh;
     // Tracing inside k_generate / k_shade (no k_trace launch, no ray/hit round trip) was measured SLOWER on MI355X
     // (cbox-720p, 63 passes: 184 ms vs 172 ms for generate+trace+shade): the fused kernel needs 142 VGPRs (3 waves/SIMD)
@@ -980,113 +965,31 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound) {
     const size_t triBytes = (size_t)ctx->scene.n_tris * 48;
     const bool unbounded = ctx->maxDepth < 0;
     const size_t ldsBytes = smallScene ? (size_t)ctx->ldsTris * 48 : (size_t)PPG_LDS_STACK * PPG_BLOCK * 4;
-    // What follows the wavefront bounces:
-    //   unbounded paths   persistent threads finish the survivors (k_tail): a launch whose length is set by its LONGEST path — on KITCHEN
-    //                     880 dependent bounces among the 12 M paths of a final-iteration batch, tens of milliseconds during which almost
-    //                     every CU idles;
-    //   training batches  k_commit splats every recorded vertex into the building tree.
-    // Two things hide that latency.  (1) SUB-BATCHES: the paths of a batch are independent, so a large batch runs as a sequence of
-    // sub-batches whose wavefront bounces follow one another on the main stream while each sub-batch's tail runs on a side stream,
-    // beside the bounces of the sub-batches after it; only the tail of the last sub-batch is exposed.  (2) k_commit for the paths
-    // that had ended when their tail took over runs on a second stream beside the tails, a small k_commit per sub-batch takes the
-    // stragglers afterwards.  Integer accumulation, per-path random numbers and the key-ordered optimiser make all of this invisible
-    // in every result.  In a round of the optimiser the record positions must be known before the tails have run: a straggler
-    // reserves max_vertices positions (unused ones stay holes).
-    const bool tail = unbounded && !fused && P.n_paths > 0;
-    const bool commit = !ctx->isFinalIter && P.n_paths > 0;
-    const bool sideStreams = tail && ctx->tuneSideTails && !ctx->timer.enabled && !ctx->tuneNoOverlap;
-    const bool overlap = tail && commit && !ctx->timer.enabled && !ctx->tuneNoOverlap;
-    const bool fastRound = adamRound && ctx->adamFast && P.n_paths > 0;
-    int nSub = 1;
-    if (sideStreams) {
-        const size_t subPaths = ctx->tuneSubPaths ? ctx->tuneSubPaths : ((size_t)1 << 30);
-        nSub = (int)std::max<size_t>(1, std::min<size_t>(PPG_MAX_SUB, (P.n_paths + subPaths - 1) / subPaths));
-    }
-    const unsigned int subSize = (unsigned int)((((size_t)P.n_paths + nSub - 1) / nSub + PPG_DCHUNK - 1) / PPG_DCHUNK * PPG_DCHUNK);
-    // live paths below which the wavefront of a sub-batch stops (unbounded paths: k_tail takes over; bounded paths: nothing is left)
-    const unsigned int stopBelow = unbounded ? (ctx->tailThreshold ? ctx->tailThreshold : std::max(ctx->tailMin, std::min(subSize, P.n_paths) / ctx->tailDiv)) : 1u;
+    // live paths below which the wavefront stops (unbounded paths: k_tail takes over; bounded paths: nothing is left)
+    const unsigned int stopBelow = unbounded ? (ctx->tailThreshold ? ctx->tailThreshold : std::max(ctx->tailMin, P.n_paths / ctx->tailDiv)) : 1u;
     unsigned int hostCount = P.n_paths;
-    int bouncesRun0 = 0;
-    unsigned int paths0 = 0;
-    if (overlap) {
-        HIP_CHECK(ctx->d_straggler.reserve(P.n_paths));
-        HIP_CHECK(hipMemsetAsync(ctx->d_straggler.p, 0, P.n_paths, s));
-    }
-    if (tail) {
-        HIP_CHECK(hipMemsetAsync(ctx->d_genTotal.p, 0, sizeof(unsigned long long) * PPG_MAX_SUB * PPG_MAX_GENS, s));
-        HIP_CHECK(hipMemsetAsync(ctx->d_genTicket.p, 0, 4 * PPG_MAX_SUB * (PPG_MAX_GENS + 1), s));
-    }
-    // The persistent-thread tail of sub-batch `sub` (work list d_tailList + first, d_tailTotal[sub] entries).  With side streams it is
-    // launched right after the sub-batch's wavefront bounces, on a stream of its own; otherwise after the batch's one host round trip on the
-    // main stream, k_commit of the finished paths beside it on the second stream.
-    auto launchTails = [&](int sub, unsigned int first) -> int {
-        const unsigned int *tailList = ctx->d_tailList.p + first;
-        const unsigned long long *tailTotal = ctx->d_tailTotal.p + sub;
-        hipStream_t ts = s;
-        if (sideStreams) {
-            ts = (ctx->tuneTailPrio ? ctx->tailStreams : ctx->tailStreamsLo)[sub % PPG_TAIL_STREAMS];
-            HIP_CHECK(hipEventRecord(ctx->evBulk[sub], s));
-            HIP_CHECK(hipStreamWaitEvent(ts, ctx->evBulk[sub], 0));
-        }
-        // The tail runs as GENERATIONS (k_tail): launch g carries every path for at most tailGen bounces and hands the survivors to
-        // launch g + 1, whose grid is a quarter of the size; the last launch has no limit.  The persistent workgroups of a launch hold
-        // their registers and LDS until their last path is done — the hundreds of dependent bounces of the longest paths are then
-        // spent in a handful of workgroups, and the rest of the GPU belongs to the next sub-batch's wavefront.
-        const int gens = ctx->timer.enabled ? 0 : ctx->tailGens;
-        // (the persistent workgroups of k_tail hold their registers until their last path has ended: no more of them than fit the GPU at once)
-        int tailGrid = std::min(grid, ctx->tuneTailBlocks ? ctx->tuneTailBlocks : 1024);
-        unsigned int *lists[2] = {ctx->d_tailListA.p + first, ctx->d_tailListB.p + first};
-        const unsigned int *inList = tailList;
-        const unsigned long long *inTotal = tailTotal;
-        for (int g = 0; g <= gens; ++g) {
-            const bool last = g == gens;
-            unsigned long long *outTotal = ctx->d_genTotal.p + (size_t)sub * PPG_MAX_GENS + g;
-            unsigned int *tick = ctx->d_genTicket.p + (size_t)sub * (PPG_MAX_GENS + 1) + g;
-            auto launch = [&] {
-                TailLaunch a{tailGrid, ldsBytes, ts, P, S, T, R, inList, inTotal, tick, Q.stats, ctx->ldsTris,
-                             last ? 0u : (unsigned int)ctx->tailGen, last ? nullptr : lists[g & 1], last ? nullptr : outTotal, ctx->tuneTailSetprio ? 1 : 0};
-                ppg_launch_tail((smallScene ? 4 : 0) | (neeOn ? 2 : 0) | (fullMats ? 1 : 0), a);
-            };
-            if (ctx->timer.enabled) timedLaunch(ctx, "k_tail", hostCount, launch); else launch();
-            inList = lists[g & 1]; inTotal = outTotal;
-            tailGrid = std::max(16, tailGrid / 4);
-        }
-        if (sideStreams) HIP_CHECK(hipEventRecord(ctx->evTail[sub], ts));
-        return PPG_OK;
-    };
-    int nSubRun = 0;
-    for (int sub = 0; sub < nSub && P.n_paths > 0; ++sub) {
-        PathState Ps = P;
-        Ps.first = (unsigned int)std::min<size_t>((size_t)sub * subSize, P.n_paths);
-        Ps.n_sub = std::min(subSize, P.n_paths - Ps.first);
-        if (Ps.n_sub == 0) break;
-        ++nSubRun;
-        const int gridAll = gridFor(Ps.n_sub);
-        unsigned int *counts = ctx->d_bounceCounts.p + 72 * sub;  // [0..63] live paths after bounce b, [64] the stop flag
-        unsigned long long *tailTotal = ctx->d_tailTotal.p + sub;
-        unsigned int *tailList = ctx->d_tailList.p + Ps.first;
-        int bouncesRun = 0;
+    int bouncesRun = 0;
+    if (P.n_paths > 0) {
         int qin = QIN_FIRST;
-        hostCount = Ps.n_sub;
-        timedLaunch(ctx, "k_generate", Ps.n_sub, [&] {
-            if (fused) hipLaunchKernelGGL(k_generate<true>, dim3(gridAll), dim3(PPG_BLOCK), triBytes, s, Ps, S, R, Q);
-            else hipLaunchKernelGGL(k_generate<false>, dim3(gridAll), dim3(PPG_BLOCK), 0, s, Ps, S, R, Q);
+        timedLaunch(ctx, "k_generate", P.n_paths, [&] {
+            if (fused) hipLaunchKernelGGL(k_generate<true>, dim3(gridAll), dim3(PPG_BLOCK), triBytes, s, P, S, R, Q);
+            else hipLaunchKernelGGL(k_generate<false>, dim3(gridAll), dim3(PPG_BLOCK), 0, s, P, S, R, Q);
         });
-        // Bounce 1 works on all paths of the sub-batch; every later bounce on the dense list of live paths that k_scan_counts +
-        // k_gather_slices rebuild from k_shade's output slices (ppg_kernels.h "Queues").  Bounded paths (maxDepth > 0) run maxDepth
-        // bounces.  Unbounded paths run wavefront bounces until fewer than `stopBelow` paths are alive.  Nothing is read back in
-        // between: the host launches as many bounces as the previous batch's survival curve says are needed (plus a margin); the
-        // device raises a stop flag when the live count has fallen below the threshold, and the kernels of the bounces launched beyond
-        // that point return at once.  The host synchronises once per batch.
+        // Bounce 1 works on all paths of the batch; every later bounce on the dense list of live paths that k_scan_counts + k_gather_slices
+        // rebuild from k_shade's output slices (ppg_kernels.h "Queues").  Bounded paths (maxDepth > 0) run maxDepth bounces.  Unbounded
+        // paths run wavefront bounces until fewer than `stopBelow` paths are alive and hand those to the persistent-thread tail (k_tail).
+        // Nothing is read back in between: the host launches as many bounces as the previous batch's survival curve says this batch needs
+        // (plus a margin); the device raises a stop flag when the live count has fallen below the threshold, and the kernels of the
+        // bounces launched beyond that point return at once.  The host synchronises once per batch.
         int maxBounces = ctx->maxDepth;
         if (unbounded) {
             if (fused) maxBounces = 1 << 20;
             else if (ctx->tuneBulkBounces >= 0) maxBounces = std::min(64, ctx->tuneBulkBounces);
             else {
-                // live(b) of this sub-batch ~ (live(b) / paths of the observed one) * paths of this one; beyond what was observed, the last ratio
+                // live(b) of this batch ~ (live(b) / paths of the previous batch) * paths of this one; beyond what was observed, the last ratio
                 int need = 8;
                 if (ctx->prevBounces > 0 && ctx->prevPaths > 0) {
-                    const double scale = (double)Ps.n_sub / (double)ctx->prevPaths;
+                    const double scale = (double)P.n_paths / (double)ctx->prevPaths;
                     need = -1;
                     for (int b = 0; b < ctx->prevBounces; ++b) if (ctx->prevLive[b] * scale < stopBelow) { need = b + 1; break; }
                     if (need < 0) {
@@ -1101,20 +1004,21 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound) {
             }
         }
         const bool liveCount = ctx->timer.enabled || (unbounded && fused);  // kernel timing wants the units of every launch
+        unsigned int *counts = ctx->d_bounceCounts.p;  // [0..63] live paths after bounce b, [64] the stop flag
         HIP_CHECK(hipMemsetAsync(counts, 0, 72 * 4, s));
         Q.stop = counts + 64;
         Q.dense_n = ctx->d_total.p;
         for (int b = 0; b < maxBounces; ++b) {
             if (!fused)
                 timedLaunch(ctx, "k_trace", hostCount, [&] {
-                    if (smallScene) hipLaunchKernelGGL((k_trace<true, false>), dim3(grid), dim3(PPG_BLOCK), ldsBytes, s, Ps, S, Q, qin, 0, ctx->ldsTris);
-                    else if (ctx->timer.enabled) hipLaunchKernelGGL((k_trace<false, true>), dim3(grid), dim3(PPG_BLOCK), ldsBytes, s, Ps, S, Q, qin, ctx->ldsNodes, ctx->ldsTris);
-                    else hipLaunchKernelGGL((k_trace<false, false>), dim3(grid), dim3(PPG_BLOCK), ldsBytes, s, Ps, S, Q, qin, ctx->ldsNodes, ctx->ldsTris);
+                    if (smallScene) hipLaunchKernelGGL((k_trace<true, false>), dim3(grid), dim3(PPG_BLOCK), ldsBytes, s, P, S, Q, qin, 0, ctx->ldsTris);
+                    else if (ctx->timer.enabled) hipLaunchKernelGGL((k_trace<false, true>), dim3(grid), dim3(PPG_BLOCK), ldsBytes, s, P, S, Q, qin, ctx->ldsNodes, ctx->ldsTris);
+                    else hipLaunchKernelGGL((k_trace<false, false>), dim3(grid), dim3(PPG_BLOCK), ldsBytes, s, P, S, Q, qin, ctx->ldsNodes, ctx->ldsTris);
                 });
             int shadeIn = qin;
             if (fullMats && !fused && qin == QIN_DENSE && ctx->d_queueSorted.p) {
                 timedLaunch(ctx, "k_sort_slices", hostCount, [&] {
-                    hipLaunchKernelGGL(k_sort_slices, dim3(grid), dim3(PPG_BLOCK), 0, s, Ps, S, Q, ctx->d_queueSorted.p, ctx->d_sortKeys.p);
+                    hipLaunchKernelGGL(k_sort_slices, dim3(grid), dim3(PPG_BLOCK), 0, s, P, S, Q, ctx->d_queueSorted.p, ctx->d_sortKeys.p);
                 });
                 shadeIn = QIN_SORTED;
             }
@@ -1124,7 +1028,7 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound) {
                 const size_t neeBytes = smallScene ? triBytes : (size_t)PPG_LDS_STACK * PPG_BLOCK * 4;
                 const size_t lds = fused ? triBytes : ((neeOn || ctx->scene.has_null) ? neeBytes : 0);
                 const int variant = (fused ? 4 : 0) | (neeOn ? 2 : 0) | (fullMats ? 1 : 0);
-                ShadeLaunch a{grid, lds, s, Ps, S, T, R, Q, shadeIn, small, ctx->d_queueSorted.p};
+                ShadeLaunch a{grid, lds, s, P, S, T, R, Q, shadeIn, small, ctx->d_queueSorted.p};
                 ppg_launch_shade(variant, a);
             });
             qin = QIN_DENSE;
@@ -1138,36 +1042,61 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound) {
                 if (hostCount == 0 || (unbounded && !fused && hostCount < stopBelow)) break;
             }
         }
-        if (sub == 0) { bouncesRun0 = bouncesRun; paths0 = Ps.n_sub; }
-        if (tail) {
-            // this sub-batch's survivors: its tail's work list (the next sub-batch reuses the dense list)
-            if (bouncesRun == 0) hipLaunchKernelGGL(k_iota_total, dim3(gridAll), dim3(PPG_BLOCK), 0, s, tailList, Ps.first, Ps.n_sub, tailTotal);
-            else hipLaunchKernelGGL(k_copy_list, dim3(gridFor(Ps.n_sub)), dim3(PPG_BLOCK), 0, s, Q.items[1], ctx->d_total.p, tailList, tailTotal);
-            if (overlap) hipLaunchKernelGGL(k_mark_list, dim3(grid), dim3(PPG_BLOCK), 0, s, tailList, tailTotal, ctx->d_straggler.p);
-            if (sideStreams) { int rc = launchTails(sub, Ps.first); if (rc) return rc; }
-        }
     }
-    if (tail && !sideStreams && !overlap) { int rc = launchTails(0, 0u); if (rc) return rc; }  // everything on the main stream, in order
+    // What follows the wavefront bounces of a batch:
+    //   unbounded paths   persistent threads finish the survivors (k_tail): ONE launch, every lane carries a path from the dense list until it
+    //                     ends.  Its length is set by the batch's LONGEST path (KITCHEN: 300-900 dependent bounces among 1-12 M paths); the
+    //                     crowd of short paths dies away around it and the wave that holds it speeds up as it empties;
+    //   training batches  k_commit splats every recorded vertex into the building tree.
+    // With both, k_commit for the paths that HAVE ended runs on a second stream beside k_tail, and a second, small k_commit takes the
+    // stragglers afterwards.  Integer accumulation makes the split invisible in the result.  In a round of the optimiser, the record
+    // positions must then be known before the tail has run: a straggler reserves max_vertices positions (unused ones stay holes).
+    const bool tail = unbounded && !fused && P.n_paths > 0;
+    const bool commit = !ctx->isFinalIter && P.n_paths > 0;
+    const bool overlap = tail && commit && !ctx->timer.enabled && !ctx->tuneNoOverlap;
+    const bool fastRound = adamRound && ctx->adamFast && P.n_paths > 0;
+    size_t nRecords = 0;
+    unsigned int *dense = Q.items[1];  // the live paths in one list (k_tail's work list)
+    auto launchTail = [&] {
+        HIP_CHECK(hipMemsetAsync(ctx->d_ticket.p, 0, 4, s));
+        // (the persistent workgroups of k_tail hold their registers until their last path has ended: no more of them than fit the GPU at once)
+        const int tailGrid = std::min(grid, ctx->tuneTailBlocks ? ctx->tuneTailBlocks : 1024);
+        timedLaunch(ctx, "k_tail", hostCount, [&] {
+            TailLaunch a{tailGrid, ldsBytes, s, P, S, T, R, dense, ctx->d_total.p, ctx->d_ticket.p, Q.stats, ctx->ldsTris};
+            ppg_launch_tail((smallScene ? 4 : 0) | (neeOn ? 2 : 0) | (fullMats ? 1 : 0), a);
+        });
+        return PPG_OK;
+    };
     // interleaved path records: k_commit and k_path_nv sweep the per-path word once per (slot, path) item — from a contiguous copy
-    // (only without side streams: the words of paths still in a tail keep changing)
     PathState Pc = P;
     bool miscCopied = false;
     auto copyMisc = [&] {
-        if (!ctx->aosPaths || miscCopied || P.n_paths == 0 || sideStreams) return;
+        if (!ctx->aosPaths || miscCopied || P.n_paths == 0) return;
         hipLaunchKernelGGL(k_copy_misc, dim3((P.n_paths + 255) / 256), dim3(256), 0, s, P, ctx->d_miscCompact.p);
         Pc.misc = {ctx->d_miscCompact.p, 1};
         miscCopied = true;
     };
-    // mode 0: every path; 1: paths not flagged as stragglers; 2: the paths of sub-batch `sub`'s tail list
-    auto launchCommit = [&](hipStream_t st, int mode, int sub) {
+    // mode 0: every path; 1: paths not flagged as stragglers; 2: the paths of the dense list
+    auto launchCommit = [&](hipStream_t st, int mode) {
         const unsigned char *skip = mode == 1 ? ctx->d_straggler.p : nullptr;
-        const unsigned int *list = mode == 2 ? ctx->d_tailList.p + (size_t)sub * subSize : nullptr;
-        const unsigned long long *listN = mode == 2 ? ctx->d_tailTotal.p + sub : nullptr;
+        const unsigned int *list = mode == 2 ? dense : nullptr;
+        const unsigned long long *listN = mode == 2 ? ctx->d_total.p : nullptr;
         const PathState &PP = mode == 2 ? P : Pc;  // the stragglers' words changed in the tail: read them in place
         CommitLaunch a{grid, st, PP, T, R, Q, skip, list, listN};
         ppg_launch_commit(ctx->spatialFilter, ctx->directionalFilter, a);
     };
-    size_t nRecords = 0;
+    if (tail) {
+        if (bouncesRun == 0)  // no wavefront bounce was run: every path of the batch goes to the persistent threads
+            hipLaunchKernelGGL(k_iota_total, dim3(gridAll), dim3(PPG_BLOCK), 0, s, dense, P.n_paths, ctx->d_total.p);
+        if (overlap) {
+            HIP_CHECK(ctx->d_straggler.reserve(P.n_paths));
+            HIP_CHECK(hipMemsetAsync(ctx->d_straggler.p, 0, P.n_paths, s));
+            hipLaunchKernelGGL(k_mark_list, dim3(grid), dim3(PPG_BLOCK), 0, s, dense, ctx->d_total.p, ctx->d_straggler.p);
+        } else {
+            int rc = launchTail();
+            if (rc) return rc;
+        }
+    }
     if (fastRound) {
         // position of path i's records = exclusive scan of the vertex counts
         HIP_CHECK(ctx->d_adamNv.reserve(P.n_paths)); HIP_CHECK(ctx->d_adamBase.reserve(P.n_paths));
@@ -1182,16 +1111,15 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound) {
     }
     if (tail || fastRound) {
         if (unbounded) HIP_CHECK(hipMemcpyAsync(ctx->h_round, ctx->d_bounceCounts.p, 64 * 4, hipMemcpyDeviceToHost, s));
-        HIP_CHECK(hipStreamSynchronize(s));  // the one host round trip of a batch of unbounded paths / of a round (the tails run on)
+        HIP_CHECK(hipStreamSynchronize(s));  // the one host round trip of a batch of unbounded paths / of a round
         if (tail) {
-            // the survival curve of the first sub-batch sizes the schedule of what comes next
-            int ran = bouncesRun0;
-            for (int b = 0; b < bouncesRun0; ++b) if (ctx->h_round[b] < stopBelow) { ran = b + 1; break; }
-            ctx->prevBounces = ran; ctx->prevPaths = paths0;
+            // the survival curve of this batch sizes the schedule of the next one
+            int ran = bouncesRun;
+            for (int b = 0; b < bouncesRun; ++b) if (ctx->h_round[b] < stopBelow) { ran = b + 1; break; }
+            ctx->prevBounces = ran; ctx->prevPaths = P.n_paths;
             for (int b = 0; b < ran; ++b) ctx->prevLive[b] = ctx->h_round[b];
             if (ctx->debugBatch) {
-                fprintf(stderr, "[ppg batch] iter %d paths %u in %d sub-batches, built %d final %d, sub-batch 0: %u paths, launched %d ran %d stop<%u live:", ctx->iter, P.n_paths, nSubRun,
-                        (int)ctx->isBuilt, (int)ctx->isFinalIter, paths0, bouncesRun0, ran, stopBelow);
+                fprintf(stderr, "[ppg batch] iter %d paths %u built %d final %d launched %d ran %d stop<%u live:", ctx->iter, P.n_paths, (int)ctx->isBuilt, (int)ctx->isFinalIter, bouncesRun, ran, stopBelow);
                 for (int b = 0; b < ran; ++b) fprintf(stderr, " %u", ctx->h_round[b]);
                 fprintf(stderr, "\n");
             }
@@ -1205,19 +1133,17 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound) {
         }
     }
     if (commit) copyMisc();
-    if (overlap) HIP_CHECK(hipEventRecord(ctx->evFork, s));
-    if (tail && !sideStreams && overlap) { int rc = launchTails(0, 0u); if (rc) return rc; }  // (one sub-batch; k_commit of the finished paths runs beside it)
     if (overlap) {
+        HIP_CHECK(hipEventRecord(ctx->evFork, s));
+        int rc = launchTail();
+        if (rc) return rc;
         HIP_CHECK(hipStreamWaitEvent(ctx->stream2, ctx->evFork, 0));
-        launchCommit(ctx->stream2, 1, 0);
+        launchCommit(ctx->stream2, 1);
         HIP_CHECK(hipEventRecord(ctx->evJoin, ctx->stream2));
         HIP_CHECK(hipStreamWaitEvent(s, ctx->evJoin, 0));
-    }
-    if (sideStreams) for (int sub = 0; sub < nSubRun; ++sub) HIP_CHECK(hipStreamWaitEvent(s, ctx->evTail[sub], 0));
-    if (overlap) {
-        for (int sub = 0; sub < nSubRun; ++sub) launchCommit(s, 2, sub);
+        launchCommit(s, 2);
     } else if (commit) {
-        timedLaunch(ctx, "k_commit", P.n_paths, [&] { launchCommit(s, 0, 0); });
+        timedLaunch(ctx, "k_commit", P.n_paths, [&] { launchCommit(s, 0); });
     }
     if (adamRound) {
         if (!ctx->adamFast) {
@@ -1284,7 +1210,7 @@ int finishPasses(ppg_ctx *ctx, ppg_pass_stats *st) {  // GP:1288-1328
     BlockStats c{};
     for (const BlockStats &x : bs) { c.rays += x.rays; c.path_len += x.path_len; c.committed += x.committed; c.bvh_nodes += x.bvh_nodes; c.bvh_tris += x.bvh_tris; c.max_len = std::max(c.max_len, x.max_len); }
     if (ctx->debugBatch) fprintf(stderr, "[ppg passes] iter %d passes %d rays %llu path_len_sum %llu longest path finished by k_tail %llu\n", ctx->iter, ctx->passesLocal, (unsigned long long)c.rays, (unsigned long long)c.path_len, (unsigned long long)c.max_len);
-    ctx->bvhNodesVisited += c.bvh_nodes; ctx->bvhTrisTested += c.bvh_tris;
+    ctx->bvhNodesVisited += c.bvh_nodes; ctx->bvhTrisTested += c.bvh_tris; ctx->tailLongestSum += c.max_len;
     float variance = 0;  // summed in the reference's x-major order (GP:1303-1311)
     for (int k = 0; k < n; ++k) variance += lum[k];  // k = x * H + y
     variance /= (float)ctx->W * ctx->H * (N - 1);
@@ -1613,12 +1539,6 @@ int ppg_create(const ppg_config *cfg, ppg_ctx **out) {
         c->tuneNoOverlap = getenv("PPG_NO_OVERLAP") != nullptr;
         if (const char *e = getenv("PPG_BULK_BOUNCES")) c->tuneBulkBounces = std::max(0, atoi(e));
         if (const char *e = getenv("PPG_BOUNCE_MARGIN")) c->bounceMargin = std::max(0, atoi(e));
-        if (const char *e = getenv("PPG_SUB_PATHS")) c->tuneSubPaths = (size_t)std::max(1ll, atoll(e));
-        if (const char *e = getenv("PPG_TAIL_GEN")) c->tailGen = std::max(1, atoi(e));
-        if (const char *e = getenv("PPG_TAIL_GENS")) c->tailGens = std::max(0, std::min(PPG_MAX_GENS - 1, atoi(e)));
-        c->tuneSideTails = getenv("PPG_SIDE_TAILS") != nullptr;
-        c->tuneTailPrio = getenv("PPG_TAIL_PRIO") != nullptr;
-        c->tuneTailSetprio = getenv("PPG_TAIL_SETPRIO") != nullptr;
         c->debugBatch = getenv("PPG_DEBUG_BATCH") != nullptr;
         if (const char *e = getenv("PPG_TAIL_BLOCKS")) c->tuneTailBlocks = std::max(1, atoi(e));
         if (const char *e = getenv("PPG_FINAL_BATCH")) c->tuneFinalBatch = std::max(1, atoi(e));
@@ -1636,16 +1556,6 @@ int ppg_create(const ppg_config *cfg, ppg_ctx **out) {
         g_createError = std::string("HIP init failed: ") + hipGetErrorString(e);
         return PPG_ERR_DEVICE;
     }
-    {   // the tails decide when a batch ends: their streams get the highest priority the device offers
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        for (int k = 0; k < PPG_TAIL_STREAMS; ++k)
-            if ((e = hipStreamCreateWithPriority(&c->tailStreams[k], hipStreamDefault, hi)) != hipSuccess || (e = hipStreamCreate(&c->tailStreamsLo[k])) != hipSuccess) { g_createError = std::string("HIP init failed: ") + hipGetErrorString(e); return PPG_ERR_DEVICE; }
-        for (int k = 0; k < PPG_MAX_SUB; ++k)
-            if ((e = hipEventCreateWithFlags(&c->evBulk[k], hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&c->evTail[k], hipEventDisableTiming)) != hipSuccess) {
-                g_createError = std::string("HIP init failed: ") + hipGetErrorString(e); return PPG_ERR_DEVICE;
-            }
-    }
     *out = c.release();
     return PPG_OK;
 }
@@ -1658,10 +1568,6 @@ void ppg_destroy(ppg_ctx *ctx) {
     if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
     if (ctx->evFork) (void)hipEventDestroy(ctx->evFork);
     if (ctx->evJoin) (void)hipEventDestroy(ctx->evJoin);
-    for (auto &t : ctx->tailStreams) if (t) { (void)hipStreamSynchronize(t); (void)hipStreamDestroy(t); }
-    for (auto &t : ctx->tailStreamsLo) if (t) { (void)hipStreamSynchronize(t); (void)hipStreamDestroy(t); }
-    for (auto &e : ctx->evBulk) if (e) (void)hipEventDestroy(e);
-    for (auto &e : ctx->evTail) if (e) (void)hipEventDestroy(e);
     ctx->timer.resolve();
     for (auto e : ctx->timer.pool) (void)hipEventDestroy(e);
     if (ctx->h_lum) (void)hipHostFree(ctx->h_lum);
@@ -2268,7 +2174,7 @@ int ppg_query_sample(ppg_ctx *ctx, uint32_t n, const float *positions, uint64_t 
 
 int ppg_enable_kernel_timing(ppg_ctx *ctx, int32_t enable) {
     ctx->timer.reset();
-    ctx->bvhNodesVisited = ctx->bvhTrisTested = 0;
+    ctx->bvhNodesVisited = ctx->bvhTrisTested = 0; ctx->tailLongestSum = 0;
     ctx->timer.enabled = enable != 0;
     return PPG_OK;
 }
@@ -2283,6 +2189,9 @@ int ppg_kernel_times(ppg_ctx *ctx, ppg_kernel_time *out, uint32_t cap, uint32_t 
         out[k].name = "bvh_nodes_visited"; out[k].ms = 0; out[k].launches = 0; out[k].units = ctx->bvhNodesVisited; ++k;
         out[k].name = "bvh_triangles_tested"; out[k].ms = 0; out[k].launches = 0; out[k].units = ctx->bvhTrisTested; ++k;
     }
+    // ... and one for k_tail: `units` = sum over the performRenderPasses calls of the longest path (bounces) a tail finished — a launch of
+    // k_tail cannot be shorter than its longest path's chain of dependent bounces
+    if (k + 1 <= cap && ctx->tailLongestSum) { out[k].name = "tail_longest_paths_sum"; out[k].ms = 0; out[k].launches = 0; out[k].units = ctx->tailLongestSum; ++k; }
     *n = k;
     return PPG_OK;
 }

@@ -73,9 +73,6 @@ struct Field {
 
 struct PathState {
     unsigned int n_paths;  // n_pix * spp
-    // A batch may run as several SUB-BATCHES one after the other (paths [first, first + n_sub)): the persistent-thread tail of one
-    // sub-batch then runs on a stream of its own beside the wavefront bounces of the next ones (ppg_hip.hip renderBatch).
-    unsigned int first, n_sub;
     unsigned int n_pix;    // owned pixels
     const unsigned int *pixels;  // owned pixel list (row-major pixel indices)
     Field<float4> ray_o;   // (o, mint)
@@ -178,13 +175,13 @@ D unsigned int dense_index(unsigned int k, unsigned int b, unsigned int nb) { re
 struct Work {
     const unsigned int *items;
     unsigned int count;
-    unsigned int first, n_sub;  // mode 0: the sub-batch's range of paths
-    int mode;  // 0: first bounce (work_item returns ~0 beyond the sub-batch: the last chunk may be partial), 1: items[k], 2: items[dense_index(k)]
+    unsigned int n_paths;  // mode 0: paths of the batch
+    int mode;  // 0: first bounce (work_item returns ~0 beyond the batch: the last chunk may be partial), 1: items[k], 2: items[dense_index(k)]
 };
 D Work work_of(const PathState &P, const Queues &Q, int qin, const unsigned int *sorted_items, unsigned int b, unsigned int nb) {
     Work w;
-    w.first = P.first; w.n_sub = P.n_sub;
-    if (qin == QIN_FIRST) { w.items = nullptr; w.count = first_share(P.n_sub, b, nb); w.mode = 0; }
+    w.n_paths = P.n_paths;
+    if (qin == QIN_FIRST) { w.items = nullptr; w.count = first_share(P.n_paths, b, nb); w.mode = 0; }
     else if (qin == QIN_SORTED && sorted_items) { w.items = sorted_items + (size_t)b * Q.cap; w.count = Q.count[1][b]; w.mode = 1; }
     else { w.items = Q.items[1]; w.count = dense_share((unsigned int)*Q.dense_n, b, nb); w.mode = 2; }
     return w;
@@ -192,7 +189,7 @@ D Work work_of(const PathState &P, const Queues &Q, int qin, const unsigned int 
 D unsigned int work_item(const Work &w, unsigned int k, unsigned int b, unsigned int nb) {
     if (w.mode == 0) {
         const unsigned int idx = first_path(k, b, nb);
-        return idx < w.n_sub ? w.first + idx : 0xffffffffu;
+        return idx < w.n_paths ? idx : 0xffffffffu;
     }
     return w.items[w.mode == 2 ? dense_index(k, b, nb) : k];
 }
@@ -274,8 +271,7 @@ __global__ __launch_bounds__(PPG_BLOCK) void k_generate(PathState P, DevScene S,
         __syncthreads();
     }
     unsigned int traced = 0;
-    for (unsigned int i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < P.n_sub; i0 += gridDim.x * blockDim.x) {
-        const unsigned int i = P.first + i0;
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < P.n_paths; i += gridDim.x * blockDim.x) {
         unsigned int k = i % P.n_pix, j = i / P.n_pix;
         unsigned int pixel = P.pixels[k];
         unsigned int key = ppg_path_key(R.seed, pixel, R.pass_index_spp + j);
@@ -419,7 +415,7 @@ D void trace_slice(const PathState &P, const DevScene &S, const LdsScene &L, int
     for (unsigned int k = threadIdx.x; k < count; k += blockDim.x) {
         unsigned int i;
         if (items) i = items[dense ? dense_index(k, b, nb) : k];
-        else { const unsigned int idx = first_path(k, b, nb); i = idx < work.n_sub ? work.first + idx : 0xffffffffu; }
+        else i = first_path(k, b, nb);
         if (i >= P.n_paths) continue;
         float4 ro = P.ray_o[i], rd = P.ray_d[i];
         F3 o = f3(ro.x, ro.y, ro.z), d = f3(rd.x, rd.y, rd.z);
@@ -1217,13 +1213,16 @@ __global__ __launch_bounds__(PPG_BLOCK, (FULL ? PPG_SHADE_WAVES_FULL : PPG_SHADE
 // probability 0.99 (GP:2125-2137): after the bulk bounces a few per cent of the paths are left, and a handful of them go on for
 // hundreds of bounces.  Every LANE takes one surviving path from the dense list (wave-aggregated global ticket) and carries it
 // through trace → shade → trace → ... until it ends, then takes the next one: no queues, no barriers between bounces, all
-// workgroups share one list (work stealing), and the run time of the launch is the longest path's chain of dependent loads
-// rather than (number of bounces) x (launch + barrier latency).
+// workgroups share one list (work stealing), and the run time of the launch is the longest path's chain of dependent bounces
+// rather than (number of bounces) x (launch + barrier latency).  Measured on KITCHEN 720p (round 3): the longest path of a
+// batch has 300-900 bounces; a wave's bounce takes ~20 us with one live lane and ~120 us with 64 (the union of the lanes' BSDF branches,
+// 64 scattered lines per load), so the wave that holds the long path speeds up as the crowd around it dies — which is why this plain
+// "one lane per path, until it ends" beat every re-compaction of the survivors into dense waves that was tried (generations of launches
+// on shrinking or on full grids, tails on side streams beside the next sub-batch's wavefront: profiles/r03_tail_experiments.json).
 template <bool SMALL, bool NEE, bool FULL>
 __global__ __launch_bounds__(PPG_BLOCK, (FULL ? PPG_SHADE_WAVES_FULL : PPG_SHADE_WAVES)) void k_tail(PathState P, DevScene S, DevTree T, RenderParams R, const unsigned int *dense,
                                                                     const unsigned long long *total_ptr, unsigned int *ticket, BlockStats *stats,
-                                                                    int lds_tris, unsigned int max_bounces, unsigned int *out_list,
-                                                                    unsigned long long *out_count, int use_prio) {
+                                                                    int lds_tris) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __shared__ float pdf_factors[20 * PPG_BLOCK];
     __shared__ unsigned long long acc;
@@ -1239,13 +1238,8 @@ __global__ __launch_bounds__(PPG_BLOCK, (FULL ? PPG_SHADE_WAVES_FULL : PPG_SHADE
     unsigned int traced = 0;
     const int lane = threadIdx.x & 63;
     bool have = false, drained = false;
-    unsigned int i = 0, bounces = 0;  // bounces this lane's current path has spent in this kernel
-    int prio = 0;
+    unsigned int i = 0;
     for (;;) {
-        // A path that has been here for long is one of the few that decide when the launch ends (hundreds of dependent bounces): its wave
-        // gets issue priority over the waves that still work through the crowd of short paths.
-        const int want = (use_prio && __any(have && bounces > 24u)) ? 3 : 0;
-        if (want != prio) { if (want) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); prio = want; }
         const unsigned long long need = __ballot(!have && !drained);
         if (need) {
             const int leader = __ffsll((long long)need) - 1;
@@ -1254,7 +1248,7 @@ __global__ __launch_bounds__(PPG_BLOCK, (FULL ? PPG_SHADE_WAVES_FULL : PPG_SHADE
             base = __shfl(base, leader);
             if (!have && !drained) {
                 const unsigned int k = base + (unsigned int)__popcll(need & ((1ull << lane) - 1ull));
-                if (k < total) { i = dense[k]; have = true; bounces = 0; }
+                if (k < total) { i = dense[k]; have = true; }
                 else drained = true;
             }
         }
@@ -1277,25 +1271,7 @@ __global__ __launch_bounds__(PPG_BLOCK, (FULL ? PPG_SHADE_WAVES_FULL : PPG_SHADE
             const bool alive = shade_one<false, NEE, FULL>(P, S, T, R, i, fcol, L.tris, plen, traced, nee, committed);
             plen_sum += plen;
             if (plen > plen_max) plen_max = plen;
-            ++bounces;
             if (!alive) have = false;
-        }
-        // GENERATIONS: a path that has spent max_bounces bounces in this launch is handed to the next launch (a smaller grid): the
-        // persistent workgroups of a launch hold their registers and LDS until their last path is done, and the few paths that go on for
-        // hundreds of bounces must not hold a GPU-sized grid while they do — the wavefront bounces of the next sub-batch run beside them.
-        if (max_bounces) {
-            const bool hand = have && bounces >= max_bounces;
-            const unsigned long long hm = __ballot(hand);
-            if (hm) {
-                const int leader = __ffsll((long long)hm) - 1;
-                unsigned long long base = 0;
-                if (lane == leader) base = atomicAdd(out_count, (unsigned long long)__popcll(hm));
-                base = __shfl(base, leader);
-                if (hand) {
-                    out_list[base + (unsigned long long)__popcll(hm & ((1ull << lane) - 1ull))] = i;
-                    have = false;
-                }
-            }
         }
     }
     for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_down(plen_max, off); if (o > plen_max) plen_max = o; }
@@ -1499,16 +1475,9 @@ static __global__ void k_mark_list(const unsigned int *list, const unsigned long
     for (unsigned int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) flag[list[k]] = 1;
 }
 // a[i] = i, *total = n (the dense list of a batch that goes to the persistent threads without a wavefront bounce)
-static __global__ void k_iota_total(unsigned int *a, unsigned int first, unsigned int n, unsigned long long *total) {
-    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) a[i] = first + i;
+static __global__ void k_iota_total(unsigned int *a, unsigned int n, unsigned long long *total) {
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) a[i] = i;
     if (blockIdx.x == 0 && threadIdx.x == 0) *total = n;
-}
-// the dense list of a sub-batch after its last wavefront bounce -> the work list of its persistent-thread tail (the next sub-batch
-// reuses the dense list while that tail runs)
-static __global__ void k_copy_list(const unsigned int *src, const unsigned long long *n_src, unsigned int *dst, unsigned long long *n_dst) {
-    const unsigned int n = (unsigned int)*n_src;
-    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = src[i];
-    if (blockIdx.x == 0 && threadIdx.x == 0) *n_dst = n;
 }
 static __global__ void k_iota(unsigned int *a, unsigned int n) {
     unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;

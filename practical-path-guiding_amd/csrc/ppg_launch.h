@@ -26,10 +26,6 @@ struct TailLaunch {
     unsigned int *ticket;
     BlockStats *stats;
     int lds_tris;
-    unsigned int max_bounces;     // bounces per path in this launch (0 = until the path ends); survivors go to out_list
-    unsigned int *out_list;
-    unsigned long long *out_count;
-    int use_prio;                 // raise the issue priority of waves that carry a long path
 };
 struct CommitLaunch {
     int grid;

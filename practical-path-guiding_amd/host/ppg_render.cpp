@@ -208,7 +208,8 @@ static bool saveScene(const char *path, const SceneData &s) {
 
 int main(int argc, char **argv) {
     Properties props;
-    std::string out = "out.pfm", scenePath, dumpScene, bsdfId, ncclIdFile, runTag;
+    std::string out = "out.pfm", scenePath, dumpScene, bsdfId, bsdfPlugin, ncclIdFile, runTag;
+    std::vector<xml::BsdfParam> bsdfParams;
     int rank = 0, world = 1;
     bool quiet = false, lenient = false;
     std::string dataDir;  // `data` directory of a Mitsuba tree (roughplastic: data/microfacet/*.dat); default $PPG_MITSUBA_DATA
@@ -224,6 +225,13 @@ int main(int argc, char **argv) {
             defines[kv.substr(0, eq)] = kv.substr(eq + 1);  // also a $name for a scene XML, like mitsuba -D (mitsuba.cpp:58-87)
         } else if (a == "-o" && i + 1 < argc) out = argv[++i];
         else if (a == "--ppgs" && i + 1 < argc) dumpScene = argv[++i];
+        else if (a == "--bsdf-plugin" && i + 1 < argc) bsdfPlugin = argv[++i];  // ... of a flat plug-in given by --bsdf-param name:tag:value (what the shim makes of a BSDF without an id)
+        else if (a == "--bsdf-param" && i + 1 < argc) {
+            const std::string v = argv[++i];
+            const size_t c1 = v.find(':'), c2 = v.find(':', c1 + 1);
+            if (c1 == std::string::npos || c2 == std::string::npos) { std::cerr << "--bsdf-param name:tag:value" << std::endl; return 2; }
+            bsdfParams.push_back({v.substr(0, c1), v.substr(c1 + 1, c2 - c1 - 1), v.substr(c2 + 1)});
+        }
         else if (a == "--bsdf-id" && i + 1 < argc) bsdfId = argv[++i];  // print the ppg_material of <bsdf id=...> (what the Mitsuba plug-in shim asks for) and exit
         else if (a == "--rank" && i + 1 < argc) rank = atoi(argv[++i]);       // multi-GPU: one process per GPU, image tiles sharded over `--world` ranks,
         else if (a == "--world" && i + 1 < argc) world = atoi(argv[++i]);     // RCCL communicator bootstrapped through the file `--nccl-id` (rank 0 writes it);
@@ -253,10 +261,12 @@ int main(int argc, char **argv) {
     }
     SceneData scene;
     const bool isXml = scenePath.size() > 4 && scenePath.compare(scenePath.size() - 4, 4, ".xml") == 0;
-    if (!bsdfId.empty()) {
+    if (!bsdfId.empty() || !bsdfPlugin.empty()) {
         ppg_material m{};
         std::string why;
-        if (!isXml || !xml::bsdfById(scenePath, bsdfId, dataDir, scene, m, why)) { std::cerr << "no bsdf '" << bsdfId << "': " << why << std::endl; return 2; }
+        if (!bsdfPlugin.empty()) {
+            if (!xml::bsdfFromProperties(bsdfPlugin, bsdfParams, dataDir, scene, m, why)) { std::cerr << "bsdf plug-in '" << bsdfPlugin << "': " << why << std::endl; return 2; }
+        } else if (!isXml || !xml::bsdfById(scenePath, bsdfId, dataDir, scene, m, why)) { std::cerr << "no bsdf '" << bsdfId << "': " << why << std::endl; return 2; }
         std::cout << "{\"type\": " << m.type << ", \"flags\": " << m.flags << ", \"reflectance\": [" << m.reflectance[0] << ", " << m.reflectance[1] << ", " << m.reflectance[2]
                   << "], \"alpha\": " << m.alpha << ", \"eta\": " << m.eta[0] << ", \"rtrans\": " << m.rtrans << ", \"rtrans_slices\": "
                   << (scene.rtransSamples ? scene.rtrans.size() / (scene.rtransSamples + 1) : 0) << "}" << std::endl;

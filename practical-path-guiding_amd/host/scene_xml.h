@@ -1291,6 +1291,12 @@ public:
         m = makeBsdf(*found, true, out);
         return true;
     }
+    // The ppg_material of a <bsdf> element that is not in a file: the plug-in shim builds one from a flat plug-in's Properties (a BSDF
+    // without an id cannot be looked up in the scene file) and gets exactly what the scene loader makes of the same parameters.
+    ppg_material bsdfFromElement(const XmlNode &e, LoadedScene &out) {
+        m_base = ".";
+        return makeBsdf(e, true, out);
+    }
 private:
     uint32_t intern(const ppg_material &m, LoadedScene &out) {
         std::string key((const char *)&m, sizeof m);
@@ -1303,11 +1309,42 @@ private:
 
 namespace xml {
 // one <bsdf id="..."> of a scene file as a ppg_material appended to `data` (its rough-transmittance slice, if any, to data.rtrans)
+// (name, tag, value) triples of a flat BSDF plug-in's parameters → its ppg_material, through the scene loader's own <bsdf> handling:
+// tag = float | integer | boolean | string | rgb, value as it would stand in the scene file ("0.1, 0.2, 0.3" for rgb)
+struct BsdfParam { std::string name, tag, value; };
+inline bool bsdfFromProperties(const std::string &plugin, const std::vector<BsdfParam> &params, const std::string &dataDir, SceneData &data, ppg_material &m, std::string &why);
+
 inline bool bsdfById(const std::string &scenePath, const std::string &id, const std::string &dataDir, SceneData &data, ppg_material &m, std::string &why) {
     try {
         SceneXmlLoader loader(scenePath, {}, true, 0, 0, dataDir);
         LoadedScene tmp;
         if (!loader.bsdfById(id, tmp, m)) return false;
+        if (!tmp.scene.rtrans.empty()) {
+            if (data.rtransSamples && data.rtransSamples != tmp.scene.rtransSamples) { why = "rough-transmittance tables of different resolutions"; return false; }
+            const uint32_t have = data.rtransSamples ? (uint32_t)(data.rtrans.size() / (data.rtransSamples + 1)) : 0u;
+            data.rtransSamples = tmp.scene.rtransSamples;
+            data.rtrans.insert(data.rtrans.end(), tmp.scene.rtrans.begin(), tmp.scene.rtrans.end());
+            if (m.type == PPG_BSDF_ROUGHPLASTIC) m.rtrans += (int32_t)have;
+        }
+        return true;
+    } catch (const std::exception &e) {
+        why = e.what();
+        return false;
+    }
+}
+
+inline bool bsdfFromProperties(const std::string &plugin, const std::vector<BsdfParam> &params, const std::string &dataDir, SceneData &data, ppg_material &m, std::string &why) {
+    try {
+        SceneXmlLoader loader("", {}, true, 0, 0, dataDir);
+        LoadedScene tmp;
+        XmlNode e;
+        e.tag = "bsdf"; e.attrs.push_back({"type", plugin});
+        for (const BsdfParam &p : params) {
+            XmlNode c;
+            c.tag = p.tag; c.attrs.push_back({"name", p.name}); c.attrs.push_back({"value", p.value});
+            e.children.push_back(c);
+        }
+        m = loader.bsdfFromElement(e, tmp);
         if (!tmp.scene.rtrans.empty()) {
             if (data.rtransSamples && data.rtransSamples != tmp.scene.rtransSamples) { why = "rough-transmittance tables of different resolutions"; return false; }
             const uint32_t have = data.rtransSamples ? (uint32_t)(data.rtrans.size() / (data.rtransSamples + 1)) : 0u;

@@ -75,13 +75,7 @@ public:
             Log(EError, "guided_path_hip: %s", ppg_last_error(NULL));   /* unknown enum strings: where GP:1023.. Assert(false) */
     }
 
-    GuidedPathTracerHIP(Stream *stream, InstanceManager *manager) : Integrator(stream, manager), m_ctx(NULL) {
-        Log(EError, "guided_path_hip cannot be used over the network (like guided_path: its SD-tree is process-local state, GP:2421)");
-    }
-
     virtual ~GuidedPathTracerHIP() { if (m_ctx) ppg_destroy(m_ctx); }
-
-    void serialize(Stream *stream, InstanceManager *manager) const { Integrator::serialize(stream, manager); }
 
     bool preprocess(const Scene *, RenderQueue *, const RenderJob *, int, int, int) { return true; }
 
@@ -147,24 +141,35 @@ private:
             ok = ppg::xml::bsdfById(scene->getSourceFile().string(), p.getID(), m_dataDir(), data, m, why);
         }
         if (!ok) {
-            Spectrum s;
-            Float r, g, b;
-            if (plugin == "diffuse") {
-                m.type = PPG_BSDF_DIFFUSE;
-                s = p.getSpectrum("reflectance", Spectrum(0.5f)); s.toLinearRGB(r, g, b);
-                m.reflectance[0] = r; m.reflectance[1] = g; m.reflectance[2] = b;
-                ok = true;
-            } else if (plugin == "dielectric" || plugin == "thindielectric" || plugin == "plastic") {
-                m.type = plugin == "dielectric" ? PPG_BSDF_DIELECTRIC : (plugin == "plastic" ? PPG_BSDF_PLASTIC : PPG_BSDF_THINDIELECTRIC);
-                const Float intIOR = lookupIOR(p, "intIOR", plugin == "plastic" ? "polypropylene" : "bk7"), extIOR = lookupIOR(p, "extIOR", "air");
-                m.eta[0] = intIOR / extIOR;
-                s = p.getSpectrum(plugin == "plastic" ? "diffuseReflectance" : "specularReflectance", Spectrum(plugin == "plastic" ? 0.5f : 1.0f)); s.toLinearRGB(r, g, b);
-                m.reflectance[0] = r; m.reflectance[1] = g; m.reflectance[2] = b;
-                s = p.getSpectrum(plugin == "plastic" ? "specularReflectance" : "specularTransmittance", Spectrum(1.0f)); s.toLinearRGB(r, g, b);
-                m.specular[0] = r; m.specular[1] = g; m.specular[2] = b;
-                if (plugin == "plastic" && p.getBoolean("nonlinear", false)) m.flags |= PPG_MAT_NONLINEAR;
-                ok = true;
+            /* A flat plug-in without an id: its Properties are the parameters the scene file gave it.  They are handed to the scene loader's own
+               <bsdf> handling as the element they came from (ppg::xml::bsdfFromProperties) — one code path for every plug-in the HIP path
+               knows (diffuse, conductor, roughconductor, plastic, roughplastic, dielectric, thindielectric, roughdielectric), named materials,
+               IOR names and rough-transmittance slices included.  Spectra arrive as linear RGB (this is an RGB build of Mitsuba). */
+            std::vector<ppg::xml::BsdfParam> params;
+            std::vector<std::string> names;
+            p.putPropertyNames(names);
+            for (size_t k = 0; k < names.size(); ++k) {
+                const std::string &n = names[k];
+                ppg::xml::BsdfParam q;
+                q.name = n;
+                switch (p.getType(n)) {
+                    case Properties::EBoolean: q.tag = "boolean"; q.value = p.getBoolean(n) ? "true" : "false"; break;
+                    case Properties::EInteger: q.tag = "integer"; q.value = formatString("%i", p.getInteger(n)); break;
+                    case Properties::EFloat: q.tag = "float"; q.value = formatString("%.9g", (double) p.getFloat(n)); break;
+                    case Properties::EString: q.tag = "string"; q.value = p.getString(n); break;
+                    case Properties::ESpectrum: {
+                        Float r, g, b;
+                        p.getSpectrum(n).toLinearRGB(r, g, b);
+                        q.tag = "rgb"; q.value = formatString("%.9g, %.9g, %.9g", (double) r, (double) g, (double) b);
+                        break;
+                    }
+                    default: continue;   /* transforms, points: no BSDF parameter of the supported plug-ins */
+                }
+                params.push_back(q);
             }
+            std::string why2;
+            ok = ppg::xml::bsdfFromProperties(plugin, params, m_dataDir(), data, m, why2);
+            if (!ok && why.empty()) why = why2;
         }
         if (!ok) {
             if (why.empty()) why = "BSDF plug-in '" + plugin + "' (id '" + p.getID() + "') is not supported by the HIP path";
@@ -320,6 +325,7 @@ private:
     std::string m_s[6], m_dump;
 };
 
-MTS_IMPLEMENT_CLASS_S(GuidedPathTracerHIP, false, Integrator)
+/* not serialisable, like the reference's integrator (guided_path.cpp:2421: MTS_IMPLEMENT_CLASS, no stream constructor) */
+MTS_IMPLEMENT_CLASS(GuidedPathTracerHIP, false, Integrator)
 MTS_EXPORT_PLUGIN(GuidedPathTracerHIP, "Guided path tracer (MI355X, libppg_hip.so)");
 MTS_NAMESPACE_END

@@ -540,3 +540,18 @@ def test_bsdf_by_id_for_the_mitsuba_plugin_shim(tmp_path):
     assert b["type"] == 4 and b["flags"] & 4 and abs(b["alpha"] - 0.2) < 1e-6
     r = subprocess.run([exe, str(xml), "--bsdf-id", "nope"], capture_output=True, text=True)
     assert r.returncode == 2 and "no bsdf 'nope'" in r.stderr
+    # a flat plug-in WITHOUT an id: the shim hands its Properties to the loader as the <bsdf> element they came from
+    # (ppg::xml::bsdfFromProperties, `--bsdf-plugin` / `--bsdf-param name:tag:value`) — same material as the same element in a scene file
+    xml2 = tmp_path / "s2.xml"
+    xml2.write_text(xml.read_text().replace('<shape type="rectangle">', '<bsdf type="roughconductor" id="flat"><string name="material" value="none"/>'
+                                            '<float name="alpha" value="0.15"/><string name="distribution" value="ggx"/><rgb name="specularReflectance" value="0.9, 0.8, 0.7"/></bsdf>'
+                                            '<shape type="rectangle">', 1))
+    want = json.loads(subprocess.run([exe, str(xml2), "--bsdf-id", "flat"], check=True, capture_output=True, text=True).stdout)
+    got = json.loads(subprocess.run([exe, "--bsdf-plugin", "roughconductor", "--bsdf-param", "material:string:none", "--bsdf-param", "alpha:float:0.15",
+                                     "--bsdf-param", "distribution:string:ggx", "--bsdf-param", "specularReflectance:rgb:0.9, 0.8, 0.7"],
+                                    check=True, capture_output=True, text=True).stdout)
+    assert got == want and got["type"] == 4 and abs(got["alpha"] - 0.15) < 1e-6 and np.allclose(got["reflectance"], [0.9, 0.8, 0.7])
+    d = json.loads(subprocess.run([exe, "--bsdf-plugin", "dielectric", "--bsdf-param", "intIOR:string:water"], check=True, capture_output=True, text=True).stdout)
+    assert abs(d["eta"] - 1.3330 / 1.000277) < 1e-5
+    r = subprocess.run([exe, "--bsdf-plugin", "ward"], capture_output=True, text=True)
+    assert r.returncode == 2 and "ward" in r.stderr
