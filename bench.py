@@ -326,9 +326,10 @@ def run(args):
                            "unit_of_work": "ray traced and shaded inside the persistent-thread tail" if name == "k_tail" else ("traced ray" if name in ("k_trace", "k_shade") else "unit of " + name),
                            "tail_critical_path": ({"longest_paths_sum_bounces": counts["tail_longest_paths_sum"], "k_tail_ms": next((k["ms"] for k in times if k["name"] == "k_tail"), None),
                                                    "us_per_bounce_of_the_longest_path": 1e3 * next((k["ms"] for k in times if k["name"] == "k_tail"), 0.0) / counts["tail_longest_paths_sum"],
-                                                   "note": "a launch of k_tail cannot end before its longest path has: the sum over the iterations of the longest path each tail "
-                                                           "finished (bounces; per iteration the longest of its launches) against k_tail's total time — a LOWER bound of the time per "
-                                                           "bounce of that one lane.  k_tail is bound by this chain of dependent bounces (DESIGN.md section 7), not by bandwidth"}
+                                                   "note": "a launch of k_tail cannot end before its longest path has: the sum over its launches of the longest path each finished "
+                                                           "(bounces, counted from the camera: the first ones ran in the wavefront) against k_tail's total time — the average time per "
+                                                           "bounce of the lane that decides when a launch ends, crowd phase included.  k_tail is bound by this chain of dependent "
+                                                           "bounces (DESIGN.md section 7), not by bandwidth"}
                                                   if counts.get("tail_longest_paths_sum") else None),
                            "operation_counts": alg["detail"], "kernels_ms": {k["name"]: round(k["ms"], 3) for k in times},
                            "per_kernel": {n: {q: (round(v, 4) if isinstance(v, float) else v) for q, v in e.items() if q != "kernel"} for n, e in per.items()

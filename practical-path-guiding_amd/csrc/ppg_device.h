@@ -378,6 +378,82 @@ D Hit trace_closest4(const DevScene &S, int *lds_stack_col, int stride, F3 o, F3
     return best;
 }
 
+// ONE ray traversed by a whole WAVE (k_tail, when a wave carries only a handful of live paths).  A lone lane's traversal is a chain of
+// ~17 dependent node / leaf fetches, almost every one an L2 miss (the BVH and the triangle records are 70 MB against 4 MB of L2 per XCD):
+// measured 36 k cycles of a lone path's 54 k-cycle bounce.  Here the wave works on up to 16 stack entries at once — four lanes
+// per entry, one child box or one triangle each — so the dependent chain is as long as the tree is deep, not as the traversal is long,
+// and all fetches of a level are in flight together.  Entries are node indices / leaf codes on a wave-wide stack laid over the wave's 64
+// LDS stack columns (entry k = row k / 64, column k % 64).  No front-to-back order is kept: more nodes are visited than by the ordered
+// per-lane walk, which costs nothing in a wave that would otherwise idle.  Same box arithmetic, same triangle test, same (t, original
+// index) minimum as trace_closest4, so the hit is the same bit for bit.  Must be called by all 64 lanes with identical arguments.
+#ifndef PPG_COOP_MAX
+#define PPG_COOP_MAX 6  // live lanes of a wave up to which k_tail traces cooperatively (measured per-iteration cycles, §7: 1 lane 36 k per-lane vs ~14 k)
+#endif
+D Hit trace_closest4_wave(const DevScene &S, int *wave_stack /* this wave's column 0 */, int stride, F3 o, F3 d, float mint, float maxt) {
+    const int lane = threadIdx.x & 63, g = lane >> 2, c = lane & 3;
+    Hit best;
+    best.t = __builtin_inff(); best.u = 0; best.v = 0; best.prim = -1;
+    int bestOrig = 0x7fffffff;
+    const F3 id = f3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
+    auto slot = [&](int k) -> int & { return wave_stack[(k >> 6) * stride + (k & 63)]; };
+    int count = 1;
+    if (lane == 0) slot(0) = 0;
+    for (;;) {
+        if (count == 0) break;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the entries other lanes pushed in the previous step (LDS, wave-synchronous)
+        const int take = count < 16 ? count : 16, base = count - take;
+        const int entry = g < take ? slot(base + g) : PPG_BVH4_EMPTY;
+        count = base;
+        const float tlim = fminf(maxt, best.t);
+        int push = PPG_BVH4_EMPTY;
+        float tt = __builtin_inff(), uu = 0, vv = 0;
+        int tq = -1, torig = 0x7fffffff;
+        if (entry >= 0 && entry != PPG_BVH4_EMPTY) {  // interior node: this lane tests child c (the arithmetic of bvh4q_load / bvh4_children)
+            const uint4 *q = reinterpret_cast<const uint4 *>(S.bvh4 + entry);
+            const uint4 a = q[0], b = q[1], cc = q[2], dd = q[3];
+            const float ox = __uint_as_float(a.x), oy = __uint_as_float(a.y), oz = __uint_as_float(a.z);
+            const float sx = __uint_as_float((a.w & 255u) << 23), sy = __uint_as_float(((a.w >> 8) & 255u) << 23), sz = __uint_as_float(((a.w >> 16) & 255u) << 23);
+            const int sh = 8 * c;
+            const float lx = ox + (float)((b.x >> sh) & 255u) * sx, ly = oy + (float)((b.y >> sh) & 255u) * sy, lz = oz + (float)((b.z >> sh) & 255u) * sz;
+            const float hx = ox + (float)((b.w >> sh) & 255u) * sx, hy = oy + (float)((cc.x >> sh) & 255u) * sy, hz = oz + (float)((cc.y >> sh) & 255u) * sz;
+            const int ch = c == 0 ? (int)cc.z : (c == 1 ? (int)cc.w : (c == 2 ? (int)dd.x : (int)dd.y));
+            const float ax = (lx - o.x) * id.x, bx = (hx - o.x) * id.x;
+            const float ay = (ly - o.y) * id.y, by = (hy - o.y) * id.y;
+            const float az = (lz - o.z) * id.z, bz = (hz - o.z) * id.z;
+            const float n = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), mint));
+            const float f = fminf(fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000008f, tlim);
+            if (n <= f && ch != PPG_BVH4_EMPTY) push = ch;
+        } else if (entry != PPG_BVH4_EMPTY) {  // leaf: this lane tests triangle c (and c + 4 of a leaf of more than four)
+            const int code = ~entry, first = code >> 3, cnt = (code & 7) + 1;
+            for (int k = c; k < cnt; k += 4) {
+                const float4 *T = S.accel + 3 * (first + k);
+                float t1, u1, v1;
+                if (tri_hit(T, o, d, mint, tlim, t1, u1, v1)) {
+                    const int orig = __float_as_int(T[2].w);
+                    if (t1 < tt || (t1 == tt && orig < torig)) { tt = t1; uu = u1; vv = v1; tq = first + k; torig = orig; }
+                }
+            }
+        }
+        // children that were hit go onto the stack (any order)
+        const unsigned long long pm = __ballot(push != PPG_BVH4_EMPTY);
+        if (push != PPG_BVH4_EMPTY) slot(count + (int)__popcll(pm & ((1ull << lane) - 1ull))) = push;
+        count += (int)__popcll(pm);
+        // the closest triangle hit of this step by (t, original index)
+        if (__any(tq >= 0)) {
+            float tm = tt;
+            for (int off = 32; off > 0; off >>= 1) tm = fminf(tm, __shfl_xor(tm, off));
+            int om = tt == tm ? torig : 0x7fffffff;
+            for (int off = 32; off > 0; off >>= 1) { const int x = __shfl_xor(om, off); om = x < om ? x : om; }
+            const int win = __ffsll((long long)__ballot(tq >= 0 && tt == tm && torig == om)) - 1;
+            const float wu = __shfl(uu, win), wv = __shfl(vv, win);
+            const int wq = __shfl(tq, win);
+            if (tm < best.t || (tm == best.t && om < bestOrig)) { best.t = tm; best.u = wu; best.v = wv; best.prim = wq; bestOrig = om; }
+        }
+    }
+    if (S.n_spheres) sphere_pass<false>(S, o, d, mint, maxt, best);
+    return best;
+}
+
 // Intersection record: fillIntersectionRecord (skdtree.h:343-430) + computeShadingFrame (util.cpp:603-608)
 struct Isect {
     F3 p, geoN, s, t, n, wi;

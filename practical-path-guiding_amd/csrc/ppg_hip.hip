@@ -524,7 +524,10 @@ struct ppg_ctx {
     float lastVariance = 0;
     ppg_pass_stats lastStats{};
     KernelTimer timer;
-    uint64_t tailLongestSum = 0;  // sum over the performRenderPasses calls of the longest path their tails finished (bounces): the tails' critical path
+#define PPG_TAIL_LOG 256
+    DevBuf<unsigned int> d_tailLongest;  // [PPG_TAIL_LOG] longest path (bounces) finished by each k_tail launch of the current performRenderPasses
+    unsigned int tailLaunches = 0;
+    uint64_t tailLongestSum = 0;  // sum over all k_tail launches of the longest path each finished (bounces): the tails' critical path
     uint64_t bvhNodesVisited = 0, bvhTrisTested = 0;  // by k_trace while kernel timing is on (the roofline's node / triangle counts)
     ppg_pass_hook passHook = nullptr;
     void *passHookUser = nullptr;
@@ -1062,7 +1065,8 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound) {
         // (the persistent workgroups of k_tail hold their registers until their last path has ended: no more of them than fit the GPU at once)
         const int tailGrid = std::min(grid, ctx->tuneTailBlocks ? ctx->tuneTailBlocks : 1024);
         timedLaunch(ctx, "k_tail", hostCount, [&] {
-            TailLaunch a{tailGrid, ldsBytes, s, P, S, T, R, dense, ctx->d_total.p, ctx->d_ticket.p, Q.stats, ctx->ldsTris};
+            TailLaunch a{tailGrid, ldsBytes, s, P, S, T, R, dense, ctx->d_total.p, ctx->d_ticket.p, Q.stats, ctx->ldsTris,
+                         ctx->d_tailLongest.p + (ctx->tailLaunches++ % PPG_TAIL_LOG)};
             ppg_launch_tail((smallScene ? 4 : 0) | (neeOn ? 2 : 0) | (fullMats ? 1 : 0), a);
         });
         return PPG_OK;
@@ -1171,6 +1175,9 @@ int renderPassesNoStat(ppg_ctx *ctx, int numPasses) {  // GP:1217-1286
     HIP_CHECK(hipMemsetAsync(ctx->d_sq.p, 0, 3 * n * 4, ctx->stream));
     HIP_CHECK(hipMemsetAsync(ctx->d_imageW.p, 0, n * 4, ctx->stream));
     HIP_CHECK(hipMemsetAsync(ctx->d_stats.p, 0, sizeof(BlockStats) * (size_t)ctx->nBlocks, ctx->stream));
+    HIP_CHECK(ctx->d_tailLongest.reserve(PPG_TAIL_LOG));
+    HIP_CHECK(hipMemsetAsync(ctx->d_tailLongest.p, 0, PPG_TAIL_LOG * 4, ctx->stream));
+    ctx->tailLaunches = 0;
     ctx->passStart = std::chrono::steady_clock::now();
     ctx->passesLocal = 0;
     // rounds of the sampling-fraction optimiser (include/ppg.h): fractions frozen during a round, its records applied afterwards
@@ -1206,11 +1213,15 @@ int finishPasses(ppg_ctx *ctx, ppg_pass_stats *st) {  // GP:1288-1328
     std::vector<BlockStats> bs((size_t)ctx->nBlocks);
     HIP_CHECK(hipMemcpyAsync(lum, ctx->d_lum.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_CHECK(hipMemcpyAsync(bs.data(), ctx->d_stats.p, bs.size() * sizeof(BlockStats), hipMemcpyDeviceToHost, ctx->stream));
+    unsigned int tailLongest[PPG_TAIL_LOG];
+    const unsigned int nTails = std::min<unsigned int>(ctx->tailLaunches, PPG_TAIL_LOG);
+    if (nTails) HIP_CHECK(hipMemcpyAsync(tailLongest, ctx->d_tailLongest.p, nTails * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
     BlockStats c{};
     for (const BlockStats &x : bs) { c.rays += x.rays; c.path_len += x.path_len; c.committed += x.committed; c.bvh_nodes += x.bvh_nodes; c.bvh_tris += x.bvh_tris; c.max_len = std::max(c.max_len, x.max_len); }
     if (ctx->debugBatch) fprintf(stderr, "[ppg passes] iter %d passes %d rays %llu path_len_sum %llu longest path finished by k_tail %llu\n", ctx->iter, ctx->passesLocal, (unsigned long long)c.rays, (unsigned long long)c.path_len, (unsigned long long)c.max_len);
-    ctx->bvhNodesVisited += c.bvh_nodes; ctx->bvhTrisTested += c.bvh_tris; ctx->tailLongestSum += c.max_len;
+    ctx->bvhNodesVisited += c.bvh_nodes; ctx->bvhTrisTested += c.bvh_tris;
+    for (unsigned int k = 0; k < nTails; ++k) ctx->tailLongestSum += tailLongest[k];
     float variance = 0;  // summed in the reference's x-major order (GP:1303-1311)
     for (int k = 0; k < n; ++k) variance += lum[k];  // k = x * H + y
     variance /= (float)ctx->W * ctx->H * (N - 1);
@@ -2189,8 +2200,8 @@ int ppg_kernel_times(ppg_ctx *ctx, ppg_kernel_time *out, uint32_t cap, uint32_t 
         out[k].name = "bvh_nodes_visited"; out[k].ms = 0; out[k].launches = 0; out[k].units = ctx->bvhNodesVisited; ++k;
         out[k].name = "bvh_triangles_tested"; out[k].ms = 0; out[k].launches = 0; out[k].units = ctx->bvhTrisTested; ++k;
     }
-    // ... and one for k_tail: `units` = sum over the performRenderPasses calls of the longest path (bounces) a tail finished — a launch of
-    // k_tail cannot be shorter than its longest path's chain of dependent bounces
+    // ... and one for k_tail: `units` = sum over its launches of the longest path (bounces) each finished — a launch of k_tail cannot be
+    // shorter than its longest path's chain of dependent bounces
     if (k + 1 <= cap && ctx->tailLongestSum) { out[k].name = "tail_longest_paths_sum"; out[k].ms = 0; out[k].launches = 0; out[k].units = ctx->tailLongestSum; ++k; }
     *n = k;
     return PPG_OK;

@@ -35,9 +35,9 @@ void PPG_CAT(ppg_launch_shade_pair, PPG_INST)(int variant, const ShadeLaunch &a)
 #endif
 void PPG_TAIL_FN(int variant, const TailLaunch &a) {
     if (variant & 1)
-        hipLaunchKernelGGL((k_tail<PAIR_S, PAIR_N, true>), dim3(a.grid), dim3(PPG_BLOCK), a.lds, a.stream, a.P, a.S, a.T, a.R, a.dense, a.total, a.ticket, a.stats, a.lds_tris);
+        hipLaunchKernelGGL((k_tail<PAIR_S, PAIR_N, true>), dim3(a.grid), dim3(PPG_BLOCK), a.lds, a.stream, a.P, a.S, a.T, a.R, a.dense, a.total, a.ticket, a.stats, a.lds_tris, a.longest);
     else
-        hipLaunchKernelGGL((k_tail<PAIR_S, PAIR_N, false>), dim3(a.grid), dim3(PPG_BLOCK), a.lds, a.stream, a.P, a.S, a.T, a.R, a.dense, a.total, a.ticket, a.stats, a.lds_tris);
+        hipLaunchKernelGGL((k_tail<PAIR_S, PAIR_N, false>), dim3(a.grid), dim3(PPG_BLOCK), a.lds, a.stream, a.P, a.S, a.T, a.R, a.dense, a.total, a.ticket, a.stats, a.lds_tris, a.longest);
 }
 #else
 void ppg_launch_commit_all(int sf, int df, const CommitLaunch &a) {

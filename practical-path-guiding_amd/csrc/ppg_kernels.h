@@ -1222,7 +1222,7 @@ __global__ __launch_bounds__(PPG_BLOCK, (FULL ? PPG_SHADE_WAVES_FULL : PPG_SHADE
 template <bool SMALL, bool NEE, bool FULL>
 __global__ __launch_bounds__(PPG_BLOCK, (FULL ? PPG_SHADE_WAVES_FULL : PPG_SHADE_WAVES)) void k_tail(PathState P, DevScene S, DevTree T, RenderParams R, const unsigned int *dense,
                                                                     const unsigned long long *total_ptr, unsigned int *ticket, BlockStats *stats,
-                                                                    int lds_tris) {
+                                                                    int lds_tris, unsigned int *longest) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __shared__ float pdf_factors[20 * PPG_BLOCK];
     __shared__ unsigned long long acc;
@@ -1252,12 +1252,31 @@ __global__ __launch_bounds__(PPG_BLOCK, (FULL ? PPG_SHADE_WAVES_FULL : PPG_SHADE
                 else drained = true;
             }
         }
-        if (!__any(have)) break;
+        const unsigned long long live = __ballot(have);
+        if (!live) break;
+        bool traced_coop = false;
+        if (!SMALL && __popcll(live) <= PPG_COOP_MAX) {
+            // a handful of live paths in this wave: each of their rays is traversed by the WHOLE wave (trace_closest4_wave)
+            for (unsigned long long todo = live; todo; todo &= todo - 1ull) {
+                const int src = __ffsll((long long)todo) - 1;
+                const unsigned int is = __shfl(i, src);
+                const float4 ro = P.ray_o[is], rd = P.ray_d[is];
+                const F3 o = f3(ro.x, ro.y, ro.z), d = f3(rd.x, rd.y, rd.z);
+                float mint = ro.w;
+                if (mint == PPG_EPSILON)  // adaptive ray epsilon, skdtree.cpp:125-129
+                    mint *= ppg_max(ppg_max(ppg_max(ppg_abs(o.x), ppg_abs(o.y)), ppg_abs(o.z)), PPG_EPSILON);
+                const Hit h = trace_closest4_wave(S, (int *)lds_raw + (threadIdx.x & ~63), PPG_BLOCK, o, d, mint, rd.w);
+                if (lane == src) { P.hit[i] = make_float4(h.t, h.u, h.v, __int_as_float(h.prim)); ++traced; }
+            }
+            traced_coop = true;
+        }
         if (have) {
             const float4 ro = P.ray_o[i], rd = P.ray_d[i];
             const F3 o = f3(ro.x, ro.y, ro.z), d = f3(rd.x, rd.y, rd.z);
             Hit h;
-            if (SMALL) {
+            if (traced_coop) {
+                h.t = 0; h.u = 0; h.v = 0; h.prim = -1;  // (written above)
+            } else if (SMALL) {
                 h = trace_small(L.tris, S, o, d, ro.w, rd.w);
             } else {
                 float mint = ro.w;
@@ -1265,8 +1284,7 @@ __global__ __launch_bounds__(PPG_BLOCK, (FULL ? PPG_SHADE_WAVES_FULL : PPG_SHADE
                     mint *= ppg_max(ppg_max(ppg_max(ppg_abs(o.x), ppg_abs(o.y)), ppg_abs(o.z)), PPG_EPSILON);
                 h = trace_closest4<false, true, true>(S, nee.stack_col, PPG_BLOCK, o, d, mint, rd.w);
             }
-            P.hit[i] = make_float4(h.t, h.u, h.v, __int_as_float(h.prim));
-            ++traced;
+            if (!traced_coop) { P.hit[i] = make_float4(h.t, h.u, h.v, __int_as_float(h.prim)); ++traced; }
             unsigned long long plen = 0;
             const bool alive = shade_one<false, NEE, FULL>(P, S, T, R, i, fcol, L.tris, plen, traced, nee, committed);
             plen_sum += plen;
@@ -1275,7 +1293,7 @@ __global__ __launch_bounds__(PPG_BLOCK, (FULL ? PPG_SHADE_WAVES_FULL : PPG_SHADE
         }
     }
     for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_down(plen_max, off); if (o > plen_max) plen_max = o; }
-    if (lane == 0 && plen_max) atomicMax(&stats[blockIdx.x].max_len, plen_max);
+    if (lane == 0 && plen_max) { atomicMax(&stats[blockIdx.x].max_len, plen_max); atomicMax(longest, (unsigned int)plen_max); }  // *longest: this launch's longest path
     block_add_u64(&acc, &stats[blockIdx.x].path_len, plen_sum);
     block_add_u64(&acc, &stats[blockIdx.x].rays, traced);
     if (NEE) block_add_u64(&acc, &stats[blockIdx.x].committed, committed);

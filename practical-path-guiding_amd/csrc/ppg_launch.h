@@ -26,6 +26,7 @@ struct TailLaunch {
     unsigned int *ticket;
     BlockStats *stats;
     int lds_tris;
+    unsigned int *longest;   // the longest path (bounces) this launch finishes: what its duration is made of
 };
 struct CommitLaunch {
     int grid;
