@@ -301,20 +301,42 @@ D void sphere_pass(const DevScene &S, F3 o, F3 d, float mint, float maxt, Hit &b
 #define PPG_CSWAP(ta, ca, tb, cb) { const bool sw_ = (ta) > (tb); const float t0_ = sw_ ? (tb) : (ta), t1_ = sw_ ? (ta) : (tb); \
                                     const int c0_ = sw_ ? (cb) : (ca), c1_ = sw_ ? (ca) : (cb); ta = t0_; tb = t1_; ca = c0_; cb = c1_; }
 struct Bvh4Hits { int c0, c1, c2, c3, m; };
+// Slab tests of a node's four child boxes.  The traversal is bound by VALU issue slots (k_trace: 73 % of all SIMD cycles issue a vector
+// instruction, profiles/r03_pmc_wait_cycles.json), and decoding the boxes to world space first — 24 x (convert, scale, add origin), then
+// 24 x (subtract ray origin, multiply) — was half of a node step.  Instead the RAY is taken to the node's grid: the cell sizes are powers
+// of two, so  o' = (o - origin) / cell  and  1/d' = (1/d) * cell  are exact scalings, and a plane distance is
+//     t = (q - o') * (1/d')                  q = the plane's byte
+// — one convert, one subtract and one multiply per plane, the two planes of an axis in one packed instruction each (v_pk_add_f32 /
+// v_pk_mul_f32).  Which plane of an axis is the near one follows from the sign of 1/d: selected once per axis and node on the packed
+// bytes instead of min / max per child.  Against the exact plane  origin + q * cell  the computed t carries the rounding of (o - origin)
+// — a shift of at most 2^-24 |o - origin| along that axis, which matters only where it is not small against the plane distance, i.e. for
+// ray origins within the node's own extent: 6e-8 of the node's size, 3 % of the builder's box padding — and two further roundings, covered by
+// the factor on the exit distance as before.  The builder checks the exact planes (in double) as well as the float decode that
+// trace_closest4_wave still uses.
+typedef float ppg_v2f __attribute__((ext_vector_type(2)));
 D Bvh4Hits bvh4_children(const Bvh4QNode *node, F3 o, F3 id, float mint, float tlim) {
-    float lxs[4], lys[4], lzs[4], hxs[4], hys[4], hzs[4];
-    int chs[4];
-    bvh4q_load(node, lxs, lys, lzs, hxs, hys, hzs, chs);
+    const uint4 *q = reinterpret_cast<const uint4 *>(node);
+    const uint4 a = q[0], b = q[1], c = q[2], d = q[3];
+    const unsigned int ex = a.w & 255u, ey = (a.w >> 8) & 255u, ez = (a.w >> 16) & 255u;  // 64..154 (BvhBuilder::quantise): no overflow below
+    const float osx = (o.x - __uint_as_float(a.x)) * __uint_as_float((254u - ex) << 23), idx = id.x * __uint_as_float(ex << 23);
+    const float osy = (o.y - __uint_as_float(a.y)) * __uint_as_float((254u - ey) << 23), idy = id.y * __uint_as_float(ey << 23);
+    const float osz = (o.z - __uint_as_float(a.z)) * __uint_as_float((254u - ez) << 23), idz = id.z * __uint_as_float(ez << 23);
+    const bool nx = id.x < 0, ny = id.y < 0, nz = id.z < 0;  // (1/d is never -0, NaN or infinite: safe_inv)
+    const unsigned int nearx = nx ? b.w : b.x, farx = nx ? b.x : b.w;
+    const unsigned int neary = ny ? c.x : b.y, fary = ny ? b.y : c.x;
+    const unsigned int nearz = nz ? c.y : b.z, farz = nz ? b.z : c.y;
+    const int chs[4] = {(int)c.z, (int)c.w, (int)d.x, (int)d.y};
     float ts[4];
     int m = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        float ax = (lxs[k] - o.x) * id.x, bx = (hxs[k] - o.x) * id.x;
-        float ay = (lys[k] - o.y) * id.y, by = (hys[k] - o.y) * id.y;
-        float az = (lzs[k] - o.z) * id.z, bz = (hzs[k] - o.z) * id.z;
-        float n = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), mint));
-        // exit distance widened by 1 + 2 gamma_3 (3 roundings in the slab arithmetic): the test stays conservative whatever the box padding
-        float f = fminf(fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000008f, tlim);
+        ppg_v2f px = {(float)((nearx >> (8 * k)) & 255u), (float)((farx >> (8 * k)) & 255u)};
+        ppg_v2f py = {(float)((neary >> (8 * k)) & 255u), (float)((fary >> (8 * k)) & 255u)};
+        ppg_v2f pz = {(float)((nearz >> (8 * k)) & 255u), (float)((farz >> (8 * k)) & 255u)};
+        px = (px - osx) * idx; py = (py - osy) * idy; pz = (pz - osz) * idz;
+        const float n = fmaxf(fmaxf(px.x, py.x), fmaxf(pz.x, mint));
+        // exit distance widened by 1 + 2 gamma_3: the test stays conservative whatever the box padding
+        const float f = fminf(fminf(fminf(px.y, py.y), pz.y) * 1.0000008f, tlim);
         const bool hit = (n <= f) && chs[k] != PPG_BVH4_EMPTY;
         ts[k] = hit ? n : __builtin_inff();
         m += hit ? 1 : 0;

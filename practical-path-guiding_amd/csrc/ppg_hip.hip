@@ -308,7 +308,9 @@ struct BvhBuilder {
                 org[a] = mn;
                 int x = 0;
                 (void)std::frexp((double)(mx - mn) / 255.0, &x);  // value = m 2^x, m in [0.5, 1): 2^x >= value
-                int e = std::max(1, std::min(254, x + 127));
+                // exponent range: bvh4_children scales the ray by 2^-e and 1/d (up to 1e30, safe_inv) by 2^e — both stay finite within 64..154
+                // (cells of 1e-19 .. 1.3e8 scene units; ppg_set_scene refuses scenes of more than 1e9 units)
+                int e = std::max(64, std::min(154, x + 127));
                 for (;;) {  // find a cell size for which all four boxes fit into 0..255 conservatively
                     const float s = scaleOf((unsigned int)e);
                     bool ok = true;
@@ -317,13 +319,16 @@ struct BvhBuilder {
                         if (nd.child[k] == PPG_BVH4_EMPTY) { wl |= 255u << (8 * k); continue; }  // inverted box: never entered
                         long ql = (long)std::floor(((double)lo[a][k] - (double)mn) / (double)s), qh = (long)std::ceil(((double)hi[a][k] - (double)mn) / (double)s);
                         ql = std::max(0l, std::min(255l, ql)); qh = std::max(0l, qh);
-                        while (ql > 0 && !(mn + (float)ql * s <= lo[a][k])) --ql;   // the float decode must not cut into the box
-                        while (qh <= 255 && !(mn + (float)qh * s >= hi[a][k])) ++qh;
-                        if (qh > 255 || !(mn + (float)ql * s <= lo[a][k])) { ok = false; break; }
+                        // neither the float decode (trace_closest4_wave) nor the exact plane (bvh4_children) may cut into the box
+                        auto below = [&](long qq) { return mn + (float)qq * s <= lo[a][k] && (double)mn + (double)qq * (double)s <= (double)lo[a][k]; };
+                        auto above = [&](long qq) { return mn + (float)qq * s >= hi[a][k] && (double)mn + (double)qq * (double)s >= (double)hi[a][k]; };
+                        while (ql > 0 && !below(ql)) --ql;
+                        while (qh <= 255 && !above(qh)) ++qh;
+                        if (qh > 255 || !below(ql)) { ok = false; break; }
                         wl |= (unsigned int)ql << (8 * k); wh |= (unsigned int)qh << (8 * k);
                     }
                     if (ok) { qlo[a] = wl; qhi[a] = wh; break; }
-                    if (++e > 254) { e = 254; qlo[a] = 0; qhi[a] = 0xffffffffu; break; }
+                    if (++e > 154) { e = 154; qlo[a] = 0; qhi[a] = 0xffffffffu; break; }  // (unreachable below 1e9 scene units)
                 }
                 ex[a] = (unsigned int)e;
             }
@@ -459,6 +464,8 @@ struct ppg_ctx {
     DevBuf<float> d_image, d_sq, d_imageW, d_film, d_filmW, d_var, d_lum, d_tmp;
     float *h_lum = nullptr;  // pinned staging of d_lum (variance sum on the host, finishPasses)
     size_t h_lumCap = 0;
+    BlockStats *h_stats = nullptr;  // pinned staging of d_stats
+    size_t h_statsCap = 0;
     std::vector<DevBuf<float>> images;  // inverse-variance copies (weight-normalised)
     std::vector<float> variances;
 
@@ -1210,15 +1217,21 @@ int finishPasses(ppg_ctx *ctx, ppg_pass_stats *st) {  // GP:1288-1328
     }
     hipLaunchKernelGGL(k_variance, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, ctx->W, N, ctx->d_image.p, ctx->d_sq.p, ctx->d_imageW.p, ctx->d_var.p, ctx->d_lum.p);
     float *lum = ctx->h_lum;  // pinned
-    std::vector<BlockStats> bs((size_t)ctx->nBlocks);
+    if (ctx->h_statsCap < (size_t)ctx->nBlocks) {
+        if (ctx->h_stats) (void)hipHostFree(ctx->h_stats);
+        ctx->h_stats = nullptr; ctx->h_statsCap = 0;
+        HIP_CHECK(hipHostMalloc((void **)&ctx->h_stats, (size_t)ctx->nBlocks * sizeof(BlockStats), hipHostMallocDefault));
+        ctx->h_statsCap = (size_t)ctx->nBlocks;
+    }
+    BlockStats *bs = ctx->h_stats;
     HIP_CHECK(hipMemcpyAsync(lum, ctx->d_lum.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_CHECK(hipMemcpyAsync(bs.data(), ctx->d_stats.p, bs.size() * sizeof(BlockStats), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipMemcpyAsync(bs, ctx->d_stats.p, (size_t)ctx->nBlocks * sizeof(BlockStats), hipMemcpyDeviceToHost, ctx->stream));
     unsigned int tailLongest[PPG_TAIL_LOG];
     const unsigned int nTails = std::min<unsigned int>(ctx->tailLaunches, PPG_TAIL_LOG);
     if (nTails) HIP_CHECK(hipMemcpyAsync(tailLongest, ctx->d_tailLongest.p, nTails * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
     BlockStats c{};
-    for (const BlockStats &x : bs) { c.rays += x.rays; c.path_len += x.path_len; c.committed += x.committed; c.bvh_nodes += x.bvh_nodes; c.bvh_tris += x.bvh_tris; c.max_len = std::max(c.max_len, x.max_len); }
+    for (int k = 0; k < ctx->nBlocks; ++k) { const BlockStats &x = bs[k]; c.rays += x.rays; c.path_len += x.path_len; c.committed += x.committed; c.bvh_nodes += x.bvh_nodes; c.bvh_tris += x.bvh_tris; c.max_len = std::max(c.max_len, x.max_len); }
     if (ctx->debugBatch) fprintf(stderr, "[ppg passes] iter %d passes %d rays %llu path_len_sum %llu longest path finished by k_tail %llu\n", ctx->iter, ctx->passesLocal, (unsigned long long)c.rays, (unsigned long long)c.path_len, (unsigned long long)c.max_len);
     ctx->bvhNodesVisited += c.bvh_nodes; ctx->bvhTrisTested += c.bvh_tris;
     for (unsigned int k = 0; k < nTails; ++k) ctx->tailLongestSum += tailLongest[k];
@@ -1582,6 +1595,7 @@ void ppg_destroy(ppg_ctx *ctx) {
     ctx->timer.resolve();
     for (auto e : ctx->timer.pool) (void)hipEventDestroy(e);
     if (ctx->h_lum) (void)hipHostFree(ctx->h_lum);
+    if (ctx->h_stats) (void)hipHostFree(ctx->h_stats);
     if (ctx->h_round) (void)hipHostFree(ctx->h_round);
     hipStream_t s = ctx->stream;
     delete ctx;
@@ -1633,6 +1647,7 @@ int ppg_set_scene(ppg_ctx *ctx, const ppg_scene *s) {
     }
     float ext = 0;
     for (int a = 0; a < 3; ++a) ext = std::max(ext, mx[a] - mn[a]);
+    if (!(ext < 1e9f)) { ctx->error = "scene extent of 1e9 units or more (or not finite)"; return PPG_ERR_INVALID; }  // BvhBuilder::quantise
     BvhBuilder bb;
     // Box padding: the BVH must return what brute force returns.  A slab test carries a few ulps of error in t, i.e. up to
     // ~4 * 2^-24 * (distance travelled) in position; 2e-6 * (scene extent) leaves an 8x margin.  (1e-4 * extent, the first
