@@ -187,10 +187,11 @@ D bool tri_hit(const float4 *A, F3 o, F3 d, float mint, float maxt, float &tt, f
     const float4 a0 = A[0];
     const int k = __float_as_int(a0.w);
     float o_u, o_v, o_k, d_u, d_v, d_k;
-    if (k == 0) { o_u = o.y; o_v = o.z; o_k = o.x; d_u = d.y; d_v = d.z; d_k = d.x; }
-    else if (k == 1) { o_u = o.z; o_v = o.x; o_k = o.y; d_u = d.z; d_v = d.x; d_k = d.y; }
-    else if (k == 2) { o_u = o.x; o_v = o.y; o_k = o.z; d_u = d.x; d_v = d.y; d_k = d.z; }
-    else return false;
+    // (selects, not three divergent blocks of moves: the lanes of a wave test unrelated triangles; measured equal on KITCHEN, less code)
+    if ((unsigned int)k > 2u) return false;
+    const bool k0 = k == 0, k1 = k == 1;
+    o_u = k0 ? o.y : (k1 ? o.z : o.x); o_v = k0 ? o.z : (k1 ? o.x : o.y); o_k = k0 ? o.x : (k1 ? o.y : o.z);
+    d_u = k0 ? d.y : (k1 ? d.z : d.x); d_v = k0 ? d.z : (k1 ? d.x : d.y); d_k = k0 ? d.x : (k1 ? d.y : d.z);
     const float t = (a0.z - o_u * a0.x - o_v * a0.y - o_k) / (d_u * a0.x + d_v * a0.y + d_k);
     if (t < mint || t > maxt) return false;
     const float4 a1 = A[1];
@@ -249,6 +250,20 @@ struct TStack {
     int sp;
     D void push(int v) { if (sp < PPG_LDS_STACK) lds[sp * stride] = v; else over[sp - PPG_LDS_STACK] = v; ++sp; }
     D int pop() { --sp; return sp < PPG_LDS_STACK ? lds[sp * stride] : over[sp - PPG_LDS_STACK]; }
+    // the children of a node that were hit, farthest first (c1 ends on top): one range check for all three instead of one per push
+    D void push_children(int m, int c1, int c2, int c3) {
+        if (sp + 3 <= PPG_LDS_STACK) {
+            int *q = lds + sp * stride;
+            if (m > 3) { *q = c3; q += stride; }
+            if (m > 2) { *q = c2; q += stride; }
+            if (m > 1) *q = c1;
+            sp += m - 1;
+            return;
+        }
+        if (m > 3) push(c3);
+        if (m > 2) push(c2);
+        if (m > 1) push(c1);
+    }
 };
 
 // Sphere::rayIntersect (sphere.cpp:164-189) with solveQuadraticDouble (util.cpp:487-525): double precision, like the reference
@@ -372,9 +387,7 @@ D Hit trace_closest4(const DevScene &S, int *lds_stack_col, int stride, F3 o, F3
         if (cur >= 0) {
             const Bvh4Hits hc = bvh4_children(S.bvh4 + cur, o, id, mint, fminf(maxt, best.t));
             if (hc.m > 0) {
-                if (hc.m > 3) st.push(hc.c3);
-                if (hc.m > 2) st.push(hc.c2);
-                if (hc.m > 1) st.push(hc.c1);
+                st.push_children(hc.m, hc.c1, hc.c2, hc.c3);
                 cur = hc.c0;
             } else {
                 if (st.sp == 0) break;

@@ -372,9 +372,7 @@ D void trace_slice_bvh4(const PathState &P, const DevScene &S, int *lds_stack, u
             if (COUNT) ++n_nodes;
             const Bvh4Hits hc = bvh4_children(S.bvh4 + cur, o, id, mint, fminf(maxt, best.t));
             if (hc.m > 0) {
-                if (hc.m > 3) st.push(hc.c3);
-                if (hc.m > 2) st.push(hc.c2);
-                if (hc.m > 1) st.push(hc.c1);
+                st.push_children(hc.m, hc.c1, hc.c2, hc.c3);
                 cur = hc.c0;
             } else cur = st.sp > 0 ? st.pop() : PPG_BVH4_EMPTY;
         } else if (doLeaves) {
@@ -744,16 +742,24 @@ struct NeeLds {
 // FULL: the complete material set (ppg_device.h "Full material set"); otherwise only diffuse / two-sided diffuse / mirror.
 // Li's loop body for ONE path: returns whether the path goes on (a new ray was written).  Free of cross-lane operations, so
 // it may be called under divergence (k_tail).  plen receives rRec.depth when the path ends here.
-template <bool FUSED, bool NEE, bool FULL>
+// CARRY (k_tail): the path's state travels in the lane's registers from bounce to bounce (`cs`) instead of through memory — in the tail a
+// bounce of a lone path is a chain of dependent latencies, and the store -> load round trips of ray, hit and state through L2 were two
+// of its links.  Memory receives the words others read afterwards (misc, li) when the path ends.
+struct Carried { uint4 misc; float4 thr, li, hit, ro, rd; };
+template <bool FUSED, bool NEE, bool FULL, bool CARRY = false>
 D bool shade_one(const PathState &P, const DevScene &S, const DevTree &T, const RenderParams &R, const unsigned int i, const LdsColumn &fcol,
-                 const float4 *lds_tris, unsigned long long &plen, unsigned int &traced, const NeeLds &nee, unsigned long long &committed) {
+                 const float4 *lds_tris, unsigned long long &plen, unsigned int &traced, const NeeLds &nee, unsigned long long &committed,
+                 Carried *cs = nullptr) {
     bool alive = false;
     {
-    uint4 m = P.misc[i];
+    uint4 m = CARRY ? cs->misc : P.misc[i];
     unsigned int key = m.x, dim = m.y, flags = m.z;
     unsigned int depth = flags & FL_DEPTH_MASK;
     unsigned int nV = (flags & FL_NV_MASK) >> FL_NV_SHIFT;
-    float4 t4 = P.thr[i], l4 = P.li[i], h4 = P.hit[i], d4 = P.ray_d[i];
+    float4 t4, l4, h4, d4;
+    if (CARRY) { t4 = cs->thr; l4 = cs->li; h4 = cs->hit; d4 = cs->rd; }
+    else { t4 = P.thr[i]; l4 = P.li[i]; h4 = P.hit[i]; d4 = P.ray_d[i]; }
+    auto ray_origin = [&]() { return CARRY ? cs->ro : P.ray_o[i]; };
     F3 thr = f3(t4.x, t4.y, t4.z);
     float eta = t4.w;
     F3 Li = f3(l4.x, l4.y, l4.z);
@@ -766,7 +772,7 @@ D bool shade_one(const PathState &P, const DevScene &S, const DevTree &T, const 
     X.tex = 0u;
     if (valid) {
         if (FULL && h.prim >= S.n_tris) {
-            const float4 ro4 = P.ray_o[i];
+            const float4 ro4 = ray_origin();
             fill_isect_sphere(S, h, f3(ro4.x, ro4.y, ro4.z), d, I);
         } else if (FULL) fill_isect_tex(S, h, d, I, X);
         else fill_isect(S, h, d, I);
@@ -788,7 +794,7 @@ D bool shade_one(const PathState &P, const DevScene &S, const DevTree &T, const 
         float em_dist = h.t;
         int em_id = I.emitter;
         if (FULL && !valid && S.env.w != 0) {  // GP:2236-2243: the ray left the scene
-            const float4 ro4 = P.ray_o[i];
+            const float4 ro4 = ray_origin();
             if (env_fill_direct(S, f3(ro4.x, ro4.y, ro4.z), d)) { value = env_radiance(S, d); em_id = S.n_emitters; }
         }
         if (FULL && S.has_null && valid && I.emitter < 0) {
@@ -796,7 +802,7 @@ D bool shade_one(const PathState &P, const DevScene &S, const DevTree &T, const 
             // goes on through surfaces that have a null component (traced in place)
             Mat Mc = load_material(S, I.material);
             if (mat_has_null(Mc)) {
-                const float4 ro4 = P.ray_o[i];
+                const float4 ro4 = ray_origin();
                 F3 ro = f3(ro4.x, ro4.y, ro4.z);
                 F3 transmittance = f3s(1.0f);
                 const int maxInteractions = R.max_depth - (int)depth - 1;
@@ -838,7 +844,7 @@ D bool shade_one(const PathState &P, const DevScene &S, const DevTree &T, const 
             } else if ((flags & FL_PEND_REFN) && dn < 0) {
                 const int4 info = S.em_info[em_id];
                 if (FULL && info.y < 0) {  // Sphere::pdfDirect needs dRec.ref = the previous vertex = this ray's origin
-                    const float4 ro4 = P.ray_o[i];
+                    const float4 ro4 = ray_origin();
                     pdfDirect = sphere_pdf_direct(S.spheres + 4 * (-info.y - 1), f3(ro4.x, ro4.y, ro4.z), d, em_n, em_dist);
                 } else pdfDirect = __int_as_float(info.w) * (em_dist * em_dist) / ppg_abs(dn);
             }
@@ -1105,10 +1111,13 @@ D bool shade_one(const PathState &P, const DevScene &S, const DevTree &T, const 
                     Hit hn = trace_small(lds_tris, S, I.p, wo, PPG_EPSILON, __builtin_inff());
                     P.hit[i] = make_float4(hn.t, hn.u, hn.v, __int_as_float(hn.prim));
                     ++traced;
+                } else if (CARRY) {
+                    cs->ro = make_float4(I.p.x, I.p.y, I.p.z, PPG_EPSILON);
                 } else {
                     P.ray_o[i] = make_float4(I.p.x, I.p.y, I.p.z, PPG_EPSILON);
                 }
-                P.ray_d[i] = make_float4(wo.x, wo.y, wo.z, __builtin_inff());
+                if (CARRY) cs->rd = make_float4(wo.x, wo.y, wo.z, __builtin_inff());
+                else P.ray_d[i] = make_float4(wo.x, wo.y, wo.z, __builtin_inff());
                 if (smooth && nV < PPG_MAX_VERTICES && nV < (unsigned int)R.max_vertices && !R.is_final_iter) {
                     size_t vi = (size_t)nV * P.n_paths + i;
                     F3 bv = bsdfWeight * woPdf;
@@ -1141,10 +1150,16 @@ D bool shade_one(const PathState &P, const DevScene &S, const DevTree &T, const 
         }
     }
     flags = (flags & ~(FL_DEPTH_MASK | FL_NV_MASK)) | (depth & FL_DEPTH_MASK) | (nV << FL_NV_SHIFT);
-    P.misc[i] = make_uint4(key, dim, flags, m.w);
-    P.li[i] = make_float4(Li.x, Li.y, Li.z, l4.w);
-    if (alive) P.thr[i] = make_float4(thr.x, thr.y, thr.z, eta);
-    else plen = depth;  // avgPathLength += rRec.depth, GP:2147-2148
+    if (CARRY && alive) {
+        cs->misc = make_uint4(key, dim, flags, m.w);
+        cs->li = make_float4(Li.x, Li.y, Li.z, l4.w);
+        cs->thr = make_float4(thr.x, thr.y, thr.z, eta);
+    } else {
+        P.misc[i] = make_uint4(key, dim, flags, m.w);
+        P.li[i] = make_float4(Li.x, Li.y, Li.z, l4.w);
+        if (alive) P.thr[i] = make_float4(thr.x, thr.y, thr.z, eta);
+    }
+    if (!alive) plen = depth;  // avgPathLength += rRec.depth, GP:2147-2148
     }
     return alive;
 }
@@ -1239,6 +1254,9 @@ __global__ __launch_bounds__(PPG_BLOCK, (FULL ? PPG_SHADE_WAVES_FULL : PPG_SHADE
     const int lane = threadIdx.x & 63;
     bool have = false, drained = false;
     unsigned int i = 0;
+    Carried cs;
+    cs.misc = make_uint4(0u, 0u, 0u, 0u);
+    cs.thr = cs.li = cs.hit = cs.ro = cs.rd = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     for (;;) {
         const unsigned long long need = __ballot(!have && !drained);
         if (need) {
@@ -1248,8 +1266,10 @@ __global__ __launch_bounds__(PPG_BLOCK, (FULL ? PPG_SHADE_WAVES_FULL : PPG_SHADE
             base = __shfl(base, leader);
             if (!have && !drained) {
                 const unsigned int k = base + (unsigned int)__popcll(need & ((1ull << lane) - 1ull));
-                if (k < total) { i = dense[k]; have = true; }
-                else drained = true;
+                if (k < total) {
+                    i = dense[k]; have = true;
+                    cs.misc = P.misc[i]; cs.thr = P.thr[i]; cs.li = P.li[i]; cs.ro = P.ray_o[i]; cs.rd = P.ray_d[i];
+                } else drained = true;
             }
         }
         const unsigned long long live = __ballot(have);
@@ -1259,23 +1279,23 @@ __global__ __launch_bounds__(PPG_BLOCK, (FULL ? PPG_SHADE_WAVES_FULL : PPG_SHADE
             // a handful of live paths in this wave: each of their rays is traversed by the WHOLE wave (trace_closest4_wave)
             for (unsigned long long todo = live; todo; todo &= todo - 1ull) {
                 const int src = __ffsll((long long)todo) - 1;
-                const unsigned int is = __shfl(i, src);
-                const float4 ro = P.ray_o[is], rd = P.ray_d[is];
-                const F3 o = f3(ro.x, ro.y, ro.z), d = f3(rd.x, rd.y, rd.z);
-                float mint = ro.w;
+                const F3 o = f3(__shfl(cs.ro.x, src), __shfl(cs.ro.y, src), __shfl(cs.ro.z, src));
+                const F3 d = f3(__shfl(cs.rd.x, src), __shfl(cs.rd.y, src), __shfl(cs.rd.z, src));
+                float mint = __shfl(cs.ro.w, src);
+                const float maxt = __shfl(cs.rd.w, src);
                 if (mint == PPG_EPSILON)  // adaptive ray epsilon, skdtree.cpp:125-129
                     mint *= ppg_max(ppg_max(ppg_max(ppg_abs(o.x), ppg_abs(o.y)), ppg_abs(o.z)), PPG_EPSILON);
-                const Hit h = trace_closest4_wave(S, (int *)lds_raw + (threadIdx.x & ~63), PPG_BLOCK, o, d, mint, rd.w);
-                if (lane == src) { P.hit[i] = make_float4(h.t, h.u, h.v, __int_as_float(h.prim)); ++traced; }
+                const Hit h = trace_closest4_wave(S, (int *)lds_raw + (threadIdx.x & ~63), PPG_BLOCK, o, d, mint, maxt);
+                if (lane == src) { cs.hit = make_float4(h.t, h.u, h.v, __int_as_float(h.prim)); ++traced; }
             }
             traced_coop = true;
         }
         if (have) {
-            const float4 ro = P.ray_o[i], rd = P.ray_d[i];
+            const float4 ro = cs.ro, rd = cs.rd;
             const F3 o = f3(ro.x, ro.y, ro.z), d = f3(rd.x, rd.y, rd.z);
             Hit h;
             if (traced_coop) {
-                h.t = 0; h.u = 0; h.v = 0; h.prim = -1;  // (written above)
+                h.t = 0; h.u = 0; h.v = 0; h.prim = -1;  // (in cs.hit already)
             } else if (SMALL) {
                 h = trace_small(L.tris, S, o, d, ro.w, rd.w);
             } else {
@@ -1284,9 +1304,9 @@ __global__ __launch_bounds__(PPG_BLOCK, (FULL ? PPG_SHADE_WAVES_FULL : PPG_SHADE
                     mint *= ppg_max(ppg_max(ppg_max(ppg_abs(o.x), ppg_abs(o.y)), ppg_abs(o.z)), PPG_EPSILON);
                 h = trace_closest4<false, true, true>(S, nee.stack_col, PPG_BLOCK, o, d, mint, rd.w);
             }
-            if (!traced_coop) { P.hit[i] = make_float4(h.t, h.u, h.v, __int_as_float(h.prim)); ++traced; }
+            if (!traced_coop) { cs.hit = make_float4(h.t, h.u, h.v, __int_as_float(h.prim)); ++traced; }
             unsigned long long plen = 0;
-            const bool alive = shade_one<false, NEE, FULL>(P, S, T, R, i, fcol, L.tris, plen, traced, nee, committed);
+            const bool alive = shade_one<false, NEE, FULL, true>(P, S, T, R, i, fcol, L.tris, plen, traced, nee, committed, &cs);
             plen_sum += plen;
             if (plen > plen_max) plen_max = plen;
             if (!alive) have = false;
