@@ -504,7 +504,9 @@ struct ppg_ctx {
     int bounceMargin = 3;             // PPG_BOUNCE_MARGIN: bounces launched beyond the predicted need (the device skips what it does not need)
     // Tuning switches, read ONCE from the environment by ppg_create (DESIGN.md "Tuning switches"); none of them changes a result.
     unsigned int tailThreshold = 0;   // PPG_TAIL_THRESHOLD: live paths below which k_tail takes over (0 = automatic: max(tailMin, paths / tailDiv))
-    unsigned int tailMin = 786432, tailDiv = 12;  // PPG_TAIL_MIN, PPG_TAIL_DIV (KITCHEN 720p: 131072 / 16 -> 786432 / 12: +1.5 % at 127 passes, +5 % at 20)
+    // PPG_TAIL_MIN, PPG_TAIL_DIV (KITCHEN 720p: 131072 / 16 -> 786432 / 12: +1.5 % at 127 passes, +5 % at 20; with the tail's state in registers
+    // a plateau from 1.6 M to 4 M: 786432 -> 2 M another +1.5 % at 20 passes, equal at 127)
+    unsigned int tailMin = 2097152, tailDiv = 12;
     size_t tuneBatchPaths = 0;        // PPG_BATCH_PATHS: paths in flight per batch of passes (0 = automatic)
     int tuneBlocks = 0;               // PPG_BLOCKS: persistent workgroups of the path kernels (0 = 4096)
     bool tuneForceBvh = false;        // PPG_FORCE_BVH: trace small scenes through the BVH as well
