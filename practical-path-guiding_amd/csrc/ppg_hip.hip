@@ -169,6 +169,16 @@ struct HostSNode {  // host mirror of one S-tree node (STreeNode, GP:740-845)
     bool isLeaf() const { return child[0] == 0; }
 };
 
+// The stream of the commits that run beside the tail.  PPG_STREAM2_LOW=1: at the device's least priority, so that the tail's crowd phase is
+// served first (experiment).
+static hipError_t createSecondStream(hipStream_t *st) {
+    const char *e = getenv("PPG_STREAM2_LOW");
+    if (!e || !atoi(e)) return hipStreamCreate(st);
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    return hipStreamCreateWithPriority(st, hipStreamDefault, least);
+}
+
 int parseEnum(const char *s, const char *dflt, std::initializer_list<const char *> names) {
     std::string v = s ? s : dflt;
     int i = 0;
@@ -518,7 +528,8 @@ struct ppg_ctx {
     int tuneFinalBatch = 0;           // PPG_FINAL_BATCH: passes per batch of the final iteration (0 = 64)
     int tuneTailBlocks = 0;           // PPG_TAIL_BLOCKS: workgroups of k_tail when k_commit runs beside it (0 = automatic)
     int tunePathLayout = 0;           // PPG_PATH_LAYOUT = aos: per-path state interleaved in 128-byte records instead of one array per field
-    int tuneBvhLeaf = 4;              // PPG_BVH_LEAF: triangles per BVH leaf (1..8)
+    int tuneBvhLeaf = 3;              // PPG_BVH_LEAF: triangles per BVH leaf (1..8).  KITCHEN 720p, driver's command: 4 -> 3 +3.5 % once the node test had become
+                                      // cheap (130.9 -> 135.6, A/B on one box; with the world-space decode 2 / 3 / 4 / 6 / 8 gave 125.8 / 125.9 / 124.5 / 119.6 / 115.2)
     float tuneBvhPad = 2e-6f;         // PPG_BVH_PAD: box padding relative to the scene extent
     DevBuf<unsigned int> d_leaves, d_counts, d_offsets, d_grid;
     DevBuf<unsigned int> d_dfs[2], d_refEv, d_refLv, d_refEvOff, d_refLvOff;  // S-tree refine: leaves in the reference's (right-first) visiting order
@@ -1577,7 +1588,7 @@ int ppg_create(const ppg_config *cfg, ppg_ctx **out) {
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) { g_createError = std::string("no HIP device available: ") + hipGetErrorString(e); return PPG_ERR_DEVICE; }
     if (c->device < 0 || c->device >= ndev) { g_createError = "device ordinal out of range"; return PPG_ERR_INVALID; }
-    if ((e = hipSetDevice(c->device)) != hipSuccess || (e = hipStreamCreate(&c->stream)) != hipSuccess || (e = hipStreamCreate(&c->stream2)) != hipSuccess ||
+    if ((e = hipSetDevice(c->device)) != hipSuccess || (e = hipStreamCreate(&c->stream)) != hipSuccess || (e = createSecondStream(&c->stream2)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming)) != hipSuccess) {
         g_createError = std::string("HIP init failed: ") + hipGetErrorString(e);
         return PPG_ERR_DEVICE;
