@@ -2001,6 +2001,17 @@ int ppg_build_sdtree(ppg_ctx *ctx, ppg_tree_stats *st) { NEED_TREE return buildS
 int ppg_end_iteration(ppg_ctx *ctx) { NEED_TREE return endIteration(ctx); }
 int ppg_end_render(ppg_ctx *ctx) { NEED_TREE return endRender(ctx); }
 int ppg_cancel(ppg_ctx *ctx) { ctx->cancelled.store(true); return PPG_OK; }
+int ppg_debug_build_bvh(const float *positions, const uint32_t *indices, uint32_t n_triangles, float pad_abs, int32_t max_leaf,
+                        void *nodes_out, uint32_t nodes_cap, uint32_t *n_nodes, uint32_t *order_out) {
+    if (!positions || !indices || !n_nodes || n_triangles == 0) return PPG_ERR_INVALID;
+    BvhBuilder bb;
+    bb.maxLeaf = std::max(1, std::min(8, (int)max_leaf));
+    bb.run(positions, indices, n_triangles, pad_abs);
+    *n_nodes = (uint32_t)bb.nodes4q.size();
+    if (nodes_out) memcpy(nodes_out, bb.nodes4q.data(), std::min<size_t>(nodes_cap, bb.nodes4q.size()) * sizeof(Bvh4QNode));
+    if (order_out) memcpy(order_out, bb.order.data(), (size_t)n_triangles * sizeof(uint32_t));
+    return PPG_OK;
+}
 int ppg_release_cached_memory(int32_t device) {
     int prev = 0;
     (void)hipGetDevice(&prev);
