@@ -219,8 +219,17 @@ def run(args):
 
     if args.warmup > 0:
         make(args.warmup).render()
-    gpt = make(args.steps)
-    _, dt = timed_render(gpt)
+    # `value` is the MEDIAN of --repeats complete renders (new context each: nothing carries over but the process-wide block cache); boxes and
+    # individual renders differ by more than a kernel change is worth (DESIGN.md §7 "Boxes differ"), min / max are reported beside it
+    runs = []
+    for _ in range(max(1, args.repeats)):
+        g_ = make(args.steps)
+        _, dt_ = timed_render(g_)
+        runs.append((dt_, g_))
+    order = sorted(range(len(runs)), key=lambda k: runs[k][0])
+    dt, gpt = runs[order[len(order) // 2]]
+    all_dt = [r[0] for r in runs]
+    del runs, g_
     samples = args.width * args.height * spp * args.steps
     rays = sum(s["rays"] for it in gpt.iterations for s in it["stats"])
     own_samples = sum(s["samples"] for it in gpt.iterations for s in it["stats"])
@@ -234,6 +243,8 @@ def run(args):
                    "iterations": [it["passes"] for it in gpt.iterations], "parallelism": "tiles%d" % args.gpus,
                    "rays_per_sample": rays / max(1, own_samples), "avg_path_length": plen / max(1, own_samples), "variance_last_iteration": var_last},
         "tuning_env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("PPG_")},
+        "repeats": {"n": len(all_dt), "value_is": "median", "values": [samples / t / 1e6 for t in all_dt],
+                    "min": samples / max(all_dt) / 1e6, "max": samples / min(all_dt) / 1e6},
     }
     del gpt
     if scene_name == "kitchen":
@@ -434,6 +445,7 @@ def main():
     ap.add_argument("--glossy", action="store_true", help="room scene with the S3 material mix (GGX alpha 0.1 metal, plastic) instead of Lambertian only")
     ap.add_argument("--cpu-passes", type=int, default=15, help="passes timed on the CPU baseline (bounded sample)")
     ap.add_argument("--secondary-passes", type=int, default=63)
+    ap.add_argument("--repeats", type=int, default=3, help="timed renders; value = their median (min / max reported)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-rmse", action="store_true")

@@ -183,26 +183,33 @@ struct Hit {
 // TriAccel::rayIntersect (triaccel.h:99-195) — Wald's pre-projected triangle test, the one Mitsuba's kd-tree leaves run;
 // identical arithmetic to the oracle's.  A = 3 float4: (n_u, n_v, n_d, k) (a_u, a_v, b_nu, b_nv) (c_nu, c_nv, -, original index).
 // Every lane of a wave tests the same triangle in the brute-force loop, so the switch on k is wave-uniform there.
-D bool tri_hit(const float4 *A, F3 o, F3 d, float mint, float maxt, float &tt, float &uu, float &vv) {
-    const float4 a0 = A[0];
+// The test on a record that is in registers; the arithmetic of TriAccel::rayIntersect in its order.
+D bool tri_hit_regs(const float4 a0, const float4 a1, const float4 a2, F3 o, F3 d, float mint, float maxt, float &tt, float &uu, float &vv) {
     const int k = __float_as_int(a0.w);
-    float o_u, o_v, o_k, d_u, d_v, d_k;
     // (selects, not three divergent blocks of moves: the lanes of a wave test unrelated triangles; measured equal on KITCHEN, less code)
     if ((unsigned int)k > 2u) return false;
     const bool k0 = k == 0, k1 = k == 1;
-    o_u = k0 ? o.y : (k1 ? o.z : o.x); o_v = k0 ? o.z : (k1 ? o.x : o.y); o_k = k0 ? o.x : (k1 ? o.y : o.z);
-    d_u = k0 ? d.y : (k1 ? d.z : d.x); d_v = k0 ? d.z : (k1 ? d.x : d.y); d_k = k0 ? d.x : (k1 ? d.y : d.z);
+    const float o_u = k0 ? o.y : (k1 ? o.z : o.x), o_v = k0 ? o.z : (k1 ? o.x : o.y), o_k = k0 ? o.x : (k1 ? o.y : o.z);
+    const float d_u = k0 ? d.y : (k1 ? d.z : d.x), d_v = k0 ? d.z : (k1 ? d.x : d.y), d_k = k0 ? d.x : (k1 ? d.y : d.z);
     const float t = (a0.z - o_u * a0.x - o_v * a0.y - o_k) / (d_u * a0.x + d_v * a0.y + d_k);
     if (t < mint || t > maxt) return false;
-    const float4 a1 = A[1];
     const float hu = o_u + t * d_u - a1.x;
     const float hv = o_v + t * d_v - a1.y;
     const float u = hv * a1.z + hu * a1.w;
-    const float4 a2 = A[2];
     const float v = hu * a2.x + hv * a2.y;
     if (!(u >= 0 && v >= 0 && u + v <= 1.0f)) return false;
     tt = t; uu = u; vv = v;
     return true;
+}
+// The three words of a record are fetched TOGETHER and waited for once: left to itself the compiler sinks each load to its first use
+// behind the test's early-outs, which made a triangle four dependent memory round trips — projection axis, plane equation, edges,
+// original index (ISA of round 3's k_trace; even as L1 hits that is four waits of a wave's slowest lane per leaf).  orig = a2.w.
+#define PPG_PIN4(v) asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w))
+D bool tri_hit(const float4 *A, F3 o, F3 d, float mint, float maxt, float &tt, float &uu, float &vv, int &orig) {
+    float4 a0 = A[0], a1 = A[1], a2 = A[2];
+    PPG_PIN4(a0); PPG_PIN4(a1); PPG_PIN4(a2);
+    orig = __float_as_int(a2.w);
+    return tri_hit_regs(a0, a1, a2, o, d, mint, maxt, tt, uu, vv);
 }
 
 // The same test with the projection axis known at compile time (small scenes: triangles are grouped by axis, so the
@@ -399,9 +406,9 @@ D Hit trace_closest4(const DevScene &S, int *lds_stack_col, int stride, F3 o, F3
             for (int q = first; q < first + cnt; ++q) {
                 float tt, uu, vv;
                 const float4 *T = S.accel + 3 * q;
-                if (tri_hit(T, o, d, mint, fminf(maxt, best.t), tt, uu, vv)) {
+                int orig;
+                if (tri_hit(T, o, d, mint, fminf(maxt, best.t), tt, uu, vv, orig)) {
                     if (ANY) { best.t = tt; best.prim = q; return best; }
-                    int orig = __float_as_int(T[2].w);
                     if (tt < best.t || (tt == best.t && orig < bestOrig)) { best.t = tt; best.u = uu; best.v = vv; best.prim = q; bestOrig = orig; }
                 }
             }
@@ -424,7 +431,8 @@ D Hit trace_closest4(const DevScene &S, int *lds_stack_col, int stride, F3 o, F3
 #ifndef PPG_COOP_MAX
 #define PPG_COOP_MAX 6  // live lanes of a wave up to which k_tail traces cooperatively (measured per-iteration cycles, §7: 1 lane 36 k per-lane vs ~14 k)
 #endif
-D Hit trace_closest4_wave(const DevScene &S, int *wave_stack /* this wave's column 0 */, int stride, F3 o, F3 d, float mint, float maxt) {
+D Hit trace_closest4_wave(const DevScene &S, int *wave_stack /* this wave's column 0 */, int stride, F3 o, F3 d, float mint, float maxt,
+                          int *probe_steps = nullptr) {
     const int lane = threadIdx.x & 63, g = lane >> 2, c = lane & 3;
     Hit best;
     best.t = __builtin_inff(); best.u = 0; best.v = 0; best.prim = -1;
@@ -437,15 +445,21 @@ D Hit trace_closest4_wave(const DevScene &S, int *wave_stack /* this wave's colu
         if (count == 0) break;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the entries other lanes pushed in the previous step (LDS, wave-synchronous)
         const int take = count < 16 ? count : 16, base = count - take;
+        if (probe_steps) ++*probe_steps;
         const int entry = g < take ? slot(base + g) : PPG_BVH4_EMPTY;
         count = base;
         const float tlim = fminf(maxt, best.t);
         int push = PPG_BVH4_EMPTY;
         float tt = __builtin_inff(), uu = 0, vv = 0;
         int tq = -1, torig = 0x7fffffff;
+        // A step is ONE memory round trip for the whole wave: every lane issues all the loads of its entry — the node's four 16-byte words,
+        // or its triangle's three — back to back and waits once (PPG_PIN).  Left to itself the compiler sinks each load to its first use
+        // behind the early-outs of the tests, which made a triangle four dependent round trips (projection axis, t, barycentrics, original
+        // index) and a node up to three: a lone path's traversal, a chain of such steps, spent 2100 cycles per step (cycle probe).
         if (entry >= 0 && entry != PPG_BVH4_EMPTY) {  // interior node: this lane tests child c (the arithmetic of bvh4q_load / bvh4_children)
             const uint4 *q = reinterpret_cast<const uint4 *>(S.bvh4 + entry);
-            const uint4 a = q[0], b = q[1], cc = q[2], dd = q[3];
+            uint4 a = q[0], b = q[1], cc = q[2], dd = q[3];
+            PPG_PIN4(a); PPG_PIN4(b); PPG_PIN4(cc); PPG_PIN4(dd);
             const float ox = __uint_as_float(a.x), oy = __uint_as_float(a.y), oz = __uint_as_float(a.z);
             const float sx = __uint_as_float((a.w & 255u) << 23), sy = __uint_as_float(((a.w >> 8) & 255u) << 23), sz = __uint_as_float(((a.w >> 16) & 255u) << 23);
             const int sh = 8 * c;
@@ -463,26 +477,30 @@ D Hit trace_closest4_wave(const DevScene &S, int *wave_stack /* this wave's colu
             for (int k = c; k < cnt; k += 4) {
                 const float4 *T = S.accel + 3 * (first + k);
                 float t1, u1, v1;
-                if (tri_hit(T, o, d, mint, tlim, t1, u1, v1)) {
-                    const int orig = __float_as_int(T[2].w);
+                int orig;
+                if (tri_hit(T, o, d, mint, tlim, t1, u1, v1, orig)) {
                     if (t1 < tt || (t1 == tt && orig < torig)) { tt = t1; uu = u1; vv = v1; tq = first + k; torig = orig; }
                 }
             }
         }
-        // children that were hit go onto the stack (any order)
+        // children that were hit go onto the stack (any order).  The stack is PPG_LDS_STACK rows of 64: a traversal that would overrun it
+        // (never observed; heavily overlapping boxes could) is abandoned — prim = -2 — and the caller walks that ray with one lane instead.
         const unsigned long long pm = __ballot(push != PPG_BVH4_EMPTY);
+        if (count + (int)__popcll(pm) > PPG_LDS_STACK * 64) { best.prim = -2; return best; }
         if (push != PPG_BVH4_EMPTY) slot(count + (int)__popcll(pm & ((1ull << lane) - 1ull))) = push;
         count += (int)__popcll(pm);
-        // the closest triangle hit of this step by (t, original index)
-        if (__any(tq >= 0)) {
-            float tm = tt;
-            for (int off = 32; off > 0; off >>= 1) tm = fminf(tm, __shfl_xor(tm, off));
-            int om = tt == tm ? torig : 0x7fffffff;
-            for (int off = 32; off > 0; off >>= 1) { const int x = __shfl_xor(om, off); om = x < om ? x : om; }
-            const int win = __ffsll((long long)__ballot(tq >= 0 && tt == tm && torig == om)) - 1;
-            const float wu = __shfl(uu, win), wv = __shfl(vv, win);
-            const int wq = __shfl(tq, win);
-            if (tm < best.t || (tm == best.t && om < bestOrig)) { best.t = tm; best.u = wu; best.v = wv; best.prim = wq; bestOrig = om; }
+        // the triangle hits of this step, folded into the closest hit so far by (t, original index): a step rarely has more than one, so
+        // the lanes that hit are read one after the other (v_readlane, no LDS round trips) instead of two 64-lane shuffle reductions
+        for (unsigned long long hm = __ballot(tq >= 0); hm; hm &= hm - 1ull) {
+            const int src = __ffsll((long long)hm) - 1;
+            const float ts = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tt), src));
+            const int os = __builtin_amdgcn_readlane(torig, src);
+            if (ts < best.t || (ts == best.t && os < bestOrig)) {
+                best.t = ts; bestOrig = os;
+                best.u = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(uu), src));
+                best.v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vv), src));
+                best.prim = __builtin_amdgcn_readlane(tq, src);
+            }
         }
     }
     if (S.n_spheres) sphere_pass<false>(S, o, d, mint, maxt, best);

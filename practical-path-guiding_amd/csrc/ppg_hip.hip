@@ -551,6 +551,9 @@ struct ppg_ctx {
     uint64_t bvhNodesVisited = 0, bvhTrisTested = 0;  // by k_trace while kernel timing is on (the roofline's node / triangle counts)
     ppg_pass_hook passHook = nullptr;
     void *passHookUser = nullptr;
+#ifdef PPG_PROBE
+    DevBuf<unsigned long long> d_probe;  // development builds: cycle sums of the lone path's bounce (ppg_kernels.h PROBE_MARK), printed by endRender
+#endif
 
     DevTree devTree() {
         DevTree T{};
@@ -572,6 +575,9 @@ struct ppg_ctx {
         R.strict_normals = strictNormals; R.hide_emitters = hideEmitters; R.spp = sppPerPass;
         R.is_final_iter = isFinalIter; R.do_nee = doNee; R.seed = seed; R.pass_index = (unsigned int)passesRendered;
         R.max_vertices = maxVertices; R.img_pixels = (unsigned int)W * (unsigned int)H;
+#ifdef PPG_PROBE
+        R.probe = d_probe.p;
+#endif
         return R;
     }
 };
@@ -1323,6 +1329,10 @@ int beginRender(ppg_ctx *ctx) {  // GP:1519-1550
     HIP_CHECK(hipMemsetAsync(ctx->d_sq.p, 0, 3 * n * 4, ctx->stream));
     HIP_CHECK(hipMemsetAsync(ctx->d_imageW.p, 0, n * 4, ctx->stream));
     ctx->images.clear(); ctx->variances.clear();
+#ifdef PPG_PROBE
+    HIP_CHECK(ctx->d_probe.reserve(PPG_PROBE_SLOTS));
+    HIP_CHECK(hipMemsetAsync(ctx->d_probe.p, 0, PPG_PROBE_SLOTS * 8, ctx->stream));
+#endif
     ctx->startTime = std::chrono::steady_clock::now();
     ctx->passesRendered = 0; ctx->passesRenderedThisIter = 0;
     ctx->cancelled.store(false);
@@ -1353,6 +1363,16 @@ int endIteration(ppg_ctx *ctx) {  // GP:1417-1422
 }
 
 int endRender(ppg_ctx *ctx) {  // GP:1567-1582
+#ifdef PPG_PROBE
+    if (ctx->d_probe.p) {
+        unsigned long long h[PPG_PROBE_SLOTS];
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        HIP_CHECK(hipMemcpy(h, ctx->d_probe.p, sizeof h, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[ppg probe] lone_bounces %llu coop_rays %llu coop_steps %llu cycles:", h[20], h[22], h[21]);
+        for (int k = 0; k <= 11; ++k) fprintf(stderr, " s%d=%llu", k, h[k]);
+        fprintf(stderr, "\n");
+    }
+#endif
     if (ctx->sampleCombination == 2 && !ctx->images.empty()) {
         const int n = ctx->W * ctx->H;
         HIP_CHECK(hipMemsetAsync(ctx->d_film.p, 0, 3 * (size_t)n * 4, ctx->stream));

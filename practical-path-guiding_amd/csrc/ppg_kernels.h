@@ -56,7 +56,21 @@ struct RenderParams {
     unsigned int pass_index_spp;  // sample index of the batch's first sample = pass_index * sppPerPass
     int max_vertices;         // vertex slots allocated per path
     unsigned int img_pixels;  // width * height of the whole image (path ids of the Adam records)
+#ifdef PPG_PROBE
+    unsigned long long *probe;  // development builds only (make EXTRA=-DPPG_PROBE): cycle sums per section of a LONE path's bounce in k_tail
+#endif
 };
+
+// Development probe (make EXTRA=-DPPG_PROBE OUT=../lib/libppg_hip_probe.so): where do the cycles of a lone path's bounce go?  k_tail marks
+// the sections of every loop iteration in which its wave holds exactly ONE live path; s_memtime after a full s_waitcnt, differences summed
+// in LDS (fire-and-forget ds_add) and flushed to RenderParams::probe when the workgroup ends.  Not compiled into the product.
+#ifdef PPG_PROBE
+#define PPG_PROBE_SLOTS 24
+#define PROBE_MARK(cs_, seg) do { if ((cs_) && (cs_)->pon) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_ = __builtin_readcyclecounter(); \
+        atomicAdd(&(cs_)->plds[seg], t_ - (cs_)->pt); (cs_)->pt = t_; } } while (0)
+#else
+#define PROBE_MARK(cs_, seg) do { } while (0)
+#endif
 
 // A field of the per-path (or per-vertex-slot) state: element i lives at base[i * stride].  stride 1 = one array per field (SoA, the
 // default: a wave of NEIGHBOURING paths reads full lines — the first bounces, where most of the rays are); PPG_PATH_LAYOUT=aos interleaves
@@ -382,8 +396,8 @@ D void trace_slice_bvh4(const PathState &P, const DevScene &S, int *lds_stack, u
             for (int q = first; q < first + cnt; ++q) {
                 float tt, uu, vv;
                 const float4 *T = S.accel + 3 * q;
-                if (tri_hit(T, o, d, mint, fminf(maxt, best.t), tt, uu, vv)) {
-                    int orig = __float_as_int(T[2].w);
+                int orig;
+                if (tri_hit(T, o, d, mint, fminf(maxt, best.t), tt, uu, vv, orig)) {
                     if (tt < best.t || (tt == best.t && orig < bestOrig)) { best.t = tt; best.u = uu; best.v = vv; best.prim = q; bestOrig = orig; }
                 }
             }
@@ -745,7 +759,12 @@ struct NeeLds {
 // CARRY (k_tail): the path's state travels in the lane's registers from bounce to bounce (`cs`) instead of through memory — in the tail a
 // bounce of a lone path is a chain of dependent latencies, and the store -> load round trips of ray, hit and state through L2 were two
 // of its links.  Memory receives the words others read afterwards (misc, li) when the path ends.
-struct Carried { uint4 misc; float4 thr, li, hit, ro, rd; };
+struct Carried {
+    uint4 misc; float4 thr, li, hit, ro, rd;
+#ifdef PPG_PROBE
+    unsigned long long *plds, pt, prt; bool pon;
+#endif
+};
 template <bool FUSED, bool NEE, bool FULL, bool CARRY = false>
 D bool shade_one(const PathState &P, const DevScene &S, const DevTree &T, const RenderParams &R, const unsigned int i, const LdsColumn &fcol,
                  const float4 *lds_tris, unsigned long long &plen, unsigned int &traced, const NeeLds &nee, unsigned long long &committed,
@@ -777,6 +796,7 @@ D bool shade_one(const PathState &P, const DevScene &S, const DevTree &T, const 
         } else if (FULL) fill_isect_tex(S, h, d, I, X);
         else fill_isect(S, h, d, I);
     }
+    PROBE_MARK(cs, 2);
     bool go = true;
 
     if (FULL && (flags & FL_PENDING) && (flags & FL_PEND_NULL)) {
@@ -894,6 +914,7 @@ D bool shade_one(const PathState &P, const DevScene &S, const DevTree &T, const 
         flags &= ~(FL_PENDING | FL_PEND_TREE | FL_PEND_DELTA | FL_PEND_REFN);
     }
 
+    PROBE_MARK(cs, 3);
     // ---- first half of this bounce: GP:1902-2040 ----
     if (go && !valid) {  // GP:1902-1914: possibly radiance from a background luminaire, then the path ends
         if (FULL && S.env.w != 0 && (flags & FL_EMITTED_OK) && (!R.hide_emitters || (flags & FL_SCATTERED)))
@@ -961,6 +982,7 @@ D bool shade_one(const PathState &P, const DevScene &S, const DevTree &T, const 
             } else wo_ = wop;
             return result;
         };
+        PROBE_MARK(cs, 4);
         F3 vox = f3s(0.0f);
         int leaf = 0;
         DTreeRef hd;
@@ -973,6 +995,7 @@ D bool shade_one(const PathState &P, const DevScene &S, const DevTree &T, const 
             if (R.loss != LOSS_NONE) frac = logistic(T.hdr[leaf].theta);
         }
 
+        PROBE_MARK(cs, 5);
         // sampleMat, GP:1650-1691
         float sx = ppg_rand(key, dim++);
         float sy = ppg_rand(key, dim++);
@@ -1018,8 +1041,10 @@ D bool shade_one(const PathState &P, const DevScene &S, const DevTree &T, const 
                 bsdfWeight = div3(result, frac);
             } else {
                 // pdfMat, GP:1693-1710
+                PROBE_MARK(cs, 6);
                 dTreePdf = 0;
                 bsdfPdf = b_pdf(I.wi, wo_l);
+                PROBE_MARK(cs, 7);
                 if (!ppg_isfinite(bsdfPdf)) {
                     woPdf = 0;
                 } else {
@@ -1028,6 +1053,7 @@ D bool shade_one(const PathState &P, const DevScene &S, const DevTree &T, const 
                     dTreePdf = dtree_pdf(T, hd, cx, cy, fcol);
                     woPdf = frac * bsdfPdf + (1 - frac) * dTreePdf;
                 }
+                PROBE_MARK(cs, 8);
                 bsdfWeight = (woPdf == 0) ? f3s(0.0f) : div3(result, woPdf);
             }
         }
@@ -1160,6 +1186,7 @@ D bool shade_one(const PathState &P, const DevScene &S, const DevTree &T, const 
         if (alive) P.thr[i] = make_float4(thr.x, thr.y, thr.z, eta);
     }
     if (!alive) plen = depth;  // avgPathLength += rRec.depth, GP:2147-2148
+    PROBE_MARK(cs, 9);
     }
     return alive;
 }
@@ -1241,6 +1268,11 @@ __global__ __launch_bounds__(PPG_BLOCK, (FULL ? PPG_SHADE_WAVES_FULL : PPG_SHADE
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __shared__ float pdf_factors[20 * PPG_BLOCK];
     __shared__ unsigned long long acc;
+#ifdef PPG_PROBE
+    __shared__ unsigned long long probe_lds[PPG_PROBE_SLOTS];
+    if (threadIdx.x < PPG_PROBE_SLOTS) probe_lds[threadIdx.x] = 0;
+    __syncthreads();
+#endif
     const LdsColumn fcol{pdf_factors + threadIdx.x, PPG_BLOCK};
     const unsigned int total = (unsigned int)*total_ptr;
     LdsScene L;
@@ -1257,7 +1289,17 @@ __global__ __launch_bounds__(PPG_BLOCK, (FULL ? PPG_SHADE_WAVES_FULL : PPG_SHADE
     Carried cs;
     cs.misc = make_uint4(0u, 0u, 0u, 0u);
     cs.thr = cs.li = cs.hit = cs.ro = cs.rd = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#ifdef PPG_PROBE
+    cs.plds = probe_lds; cs.pt = 0; cs.pon = false;
+#endif
     for (;;) {
+#ifdef PPG_PROBE
+        {   // lone = this wave held exactly one live path when the iteration began (and R.probe is set)
+            const unsigned long long live0 = __ballot(have);
+            cs.pon = R.probe && have && __popcll(live0) == 1;
+            if (cs.pon) { __builtin_amdgcn_s_waitcnt(0); cs.pt = __builtin_readcyclecounter(); cs.prt = __builtin_amdgcn_s_memrealtime(); atomicAdd(&probe_lds[20], 1ull); }
+        }
+#endif
         const unsigned long long need = __ballot(!have && !drained);
         if (need) {
             const int leader = __ffsll((long long)need) - 1;
@@ -1274,6 +1316,7 @@ __global__ __launch_bounds__(PPG_BLOCK, (FULL ? PPG_SHADE_WAVES_FULL : PPG_SHADE
         }
         const unsigned long long live = __ballot(have);
         if (!live) break;
+        PROBE_MARK(&cs, 0);
         bool traced_coop = false;
         if (!SMALL && __popcll(live) <= PPG_COOP_MAX) {
             // a handful of live paths in this wave: each of their rays is traversed by the WHOLE wave (trace_closest4_wave)
@@ -1285,11 +1328,22 @@ __global__ __launch_bounds__(PPG_BLOCK, (FULL ? PPG_SHADE_WAVES_FULL : PPG_SHADE
                 const float maxt = __shfl(cs.rd.w, src);
                 if (mint == PPG_EPSILON)  // adaptive ray epsilon, skdtree.cpp:125-129
                     mint *= ppg_max(ppg_max(ppg_max(ppg_abs(o.x), ppg_abs(o.y)), ppg_abs(o.z)), PPG_EPSILON);
+#ifdef PPG_PROBE
+                int psteps = 0;
+                const Hit h = trace_closest4_wave(S, (int *)lds_raw + (threadIdx.x & ~63), PPG_BLOCK, o, d, mint, maxt, &psteps);
+                if (cs.pon) { atomicAdd(&probe_lds[21], (unsigned long long)psteps); atomicAdd(&probe_lds[22], 1ull); }
+#else
                 const Hit h = trace_closest4_wave(S, (int *)lds_raw + (threadIdx.x & ~63), PPG_BLOCK, o, d, mint, maxt);
-                if (lane == src) { cs.hit = make_float4(h.t, h.u, h.v, __int_as_float(h.prim)); ++traced; }
+#endif
+                if (lane == src) {
+                    Hit hs = h;
+                    if (h.prim == -2) hs = trace_closest4<false, true, false>(S, nee.stack_col, PPG_BLOCK, o, d, mint, maxt);  // wave stack overrun: this lane alone
+                    cs.hit = make_float4(hs.t, hs.u, hs.v, __int_as_float(hs.prim)); ++traced;
+                }
             }
             traced_coop = true;
         }
+        PROBE_MARK(&cs, 1);
         if (have) {
             const float4 ro = cs.ro, rd = cs.rd;
             const F3 o = f3(ro.x, ro.y, ro.z), d = f3(rd.x, rd.y, rd.z);
@@ -1311,7 +1365,15 @@ __global__ __launch_bounds__(PPG_BLOCK, (FULL ? PPG_SHADE_WAVES_FULL : PPG_SHADE
             if (plen > plen_max) plen_max = plen;
             if (!alive) have = false;
         }
+        PROBE_MARK(&cs, 10);
+#ifdef PPG_PROBE
+        if (cs.pon) atomicAdd(&probe_lds[11], __builtin_amdgcn_s_memrealtime() - cs.prt);  // 100 MHz ticks of the lone iterations: cycles / ticks = the clock
+#endif
     }
+#ifdef PPG_PROBE
+    __syncthreads();
+    if (R.probe && threadIdx.x < PPG_PROBE_SLOTS && probe_lds[threadIdx.x]) atomicAdd(&R.probe[threadIdx.x], probe_lds[threadIdx.x]);
+#endif
     for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_down(plen_max, off); if (o > plen_max) plen_max = o; }
     if (lane == 0 && plen_max) { atomicMax(&stats[blockIdx.x].max_len, plen_max); atomicMax(longest, (unsigned int)plen_max); }  // *longest: this launch's longest path
     block_add_u64(&acc, &stats[blockIdx.x].path_len, plen_sum);
