@@ -142,6 +142,8 @@ struct DevScene {
     const float4 *normals;  // 3 per triangle or nullptr
     const BvhNode *bvh;
     const Bvh4QNode *bvh4;    // same tree collapsed to 4-wide nodes with quantised child boxes (generic traversal)
+    const float4 *bvh_top;    // its top cut for trace_closest4_wave: n_top <= 64 subtrees, (lo, child ref) (hi, -) each; n_top == 0: start at the root
+    int n_top;
     const float4 *materials;  // (reflectance rgb, type)
     const float4 *emitters;   // (radiance rgb, -)
     int n_tris;
@@ -440,7 +442,24 @@ D Hit trace_closest4_wave(const DevScene &S, int *wave_stack /* this wave's colu
     const F3 id = f3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
     auto slot = [&](int k) -> int & { return wave_stack[(k >> 6) * stride + (k & 63)]; };
     int count = 1;
-    if (lane == 0) slot(0) = 0;
+    if (S.n_top > 0) {
+        // first step: the tree's top cut — up to 64 subtrees that partition the scene, each with the box its parent's node would decode for
+        // it — tested by one lane each, instead of the first three levels one dependent step after the other
+        int push = PPG_BVH4_EMPTY;
+        if (lane < S.n_top) {
+            float4 lo = S.bvh_top[2 * lane], hi = S.bvh_top[2 * lane + 1];
+            PPG_PIN4(lo); PPG_PIN4(hi);
+            const float ax = (lo.x - o.x) * id.x, bx = (hi.x - o.x) * id.x;
+            const float ay = (lo.y - o.y) * id.y, by = (hi.y - o.y) * id.y;
+            const float az = (lo.z - o.z) * id.z, bz = (hi.z - o.z) * id.z;
+            const float n = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), mint));
+            const float f = fminf(fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000008f, maxt);
+            if (n <= f) push = __float_as_int(lo.w);
+        }
+        const unsigned long long pm = __ballot(push != PPG_BVH4_EMPTY);
+        if (push != PPG_BVH4_EMPTY) slot((int)__popcll(pm & ((1ull << lane) - 1ull))) = push;
+        count = (int)__popcll(pm);
+    } else if (lane == 0) slot(0) = 0;
     for (;;) {
         if (count == 0) break;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the entries other lanes pushed in the previous step (LDS, wave-synchronous)

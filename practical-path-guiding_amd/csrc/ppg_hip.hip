@@ -350,7 +350,58 @@ struct BvhBuilder {
         }
     }
 
+    // The TOP CUT of the tree for trace_closest4_wave (a whole wave walking ONE ray): up to 64 subtrees that partition the scene — the root's
+    // descendants after opening, level by level and then by surface area, as many interior entries as fit —, each with its box exactly as the
+    // traversal would decode it from its parent (float decode of Bvh4QNode) and its child reference.  The wave tests all of them in ONE step,
+    // one lane each, instead of descending the first three levels one dependent step at a time.  Two float4 per entry: (lo, ref) (hi, -).
+    std::vector<float> topCut;
+    void buildTopCut() {
+        struct Ent { float lo[3], hi[3]; int ref; };
+        auto childrenOfQ = [&](int node, Ent out[4]) {
+            const Bvh4QNode &q = nodes4q[(size_t)node];
+            const float sx = scaleOf(q.exps & 255u), sy = scaleOf((q.exps >> 8) & 255u), sz = scaleOf((q.exps >> 16) & 255u);
+            int m = 0;
+            for (int k = 0; k < 4; ++k) {
+                if (q.child[k] == PPG_BVH4_EMPTY) continue;
+                const int sh = 8 * k;
+                Ent e;
+                e.lo[0] = q.ox + (float)((q.qlox >> sh) & 255u) * sx; e.lo[1] = q.oy + (float)((q.qloy >> sh) & 255u) * sy; e.lo[2] = q.oz + (float)((q.qloz >> sh) & 255u) * sz;
+                e.hi[0] = q.ox + (float)((q.qhix >> sh) & 255u) * sx; e.hi[1] = q.oy + (float)((q.qhiy >> sh) & 255u) * sy; e.hi[2] = q.oz + (float)((q.qhiz >> sh) & 255u) * sz;
+                e.ref = q.child[k];
+                out[m++] = e;
+            }
+            return m;
+        };
+        std::vector<Ent> cut;
+        {
+            Ent ch[4];
+            const int m = nodes4q.empty() ? 0 : childrenOfQ(0, ch);
+            for (int k = 0; k < m; ++k) cut.push_back(ch[k]);
+        }
+        auto areaOf = [](const Ent &e) { const float d[3] = {e.hi[0] - e.lo[0], e.hi[1] - e.lo[1], e.hi[2] - e.lo[2]}; return d[0] * d[1] + d[1] * d[2] + d[2] * d[0]; };
+        for (;;) {  // open the interior entry with the largest box while the cut stays within 64 entries
+            int pick = -1; float best = -1;
+            for (size_t k = 0; k < cut.size(); ++k) if (cut[k].ref >= 0 && areaOf(cut[k]) > best) { best = areaOf(cut[k]); pick = (int)k; }
+            if (pick < 0) break;
+            Ent ch[4];
+            const int m = childrenOfQ(cut[(size_t)pick].ref, ch);
+            if (cut.size() - 1 + (size_t)m > 64) break;
+            cut.erase(cut.begin() + pick);
+            for (int k = 0; k < m; ++k) cut.push_back(ch[k]);
+        }
+        topCut.assign(8 * cut.size(), 0.0f);
+        for (size_t k = 0; k < cut.size(); ++k) {
+            float *o = &topCut[8 * k];
+            o[0] = cut[k].lo[0]; o[1] = cut[k].lo[1]; o[2] = cut[k].lo[2]; memcpy(o + 3, &cut[k].ref, 4);
+            o[4] = cut[k].hi[0]; o[5] = cut[k].hi[1]; o[6] = cut[k].hi[2];
+        }
+    }
+
     void run(const float *positions, const uint32_t *indices, uint32_t nTris, float padAbs) {
+        runTree(positions, indices, nTris, padAbs);
+        buildTopCut();
+    }
+    void runTree(const float *positions, const uint32_t *indices, uint32_t nTris, float padAbs) {
         pos = positions; idx = indices; pad = padAbs;
         order.resize(nTris); bmin.resize(3 * (size_t)nTris); bmax.resize(3 * (size_t)nTris); cent.resize(3 * (size_t)nTris);
         for (uint32_t t = 0; t < nTris; ++t) {
@@ -444,6 +495,7 @@ struct ppg_ctx {
     DevBuf<int4> d_emInfo;
     DevBuf<BvhNode> d_bvh;
     DevBuf<Bvh4QNode> d_bvh4;
+    DevBuf<float4> d_bvhTop;  // BvhBuilder::topCut
     DevScene scene{};
     float aabbMin[3], aabbMax[3];  // Scene::getAABB()
     int W = 0, H = 0;
@@ -461,7 +513,7 @@ struct ppg_ctx {
     DevBuf<float4> d_pathRec, d_vertexRec;  // interleaved layout (PathState Field, ppg_kernels.h): 8 float4 per path, 4 / 6 per vertex slot
     DevBuf<uint4> d_miscCompact;
     bool aosPaths = false;
-    DevBuf<unsigned int> d_queue[2], d_qcount[2], d_qtotal, d_queueSorted;
+    DevBuf<unsigned int> d_queue[2], d_qcount[2], d_qtotal, d_queueSorted, d_qcommon;
     DevBuf<unsigned char> d_sortKeys;
     int maxBatchFinal = 1;  // passes per batch in the final iteration (nothing is recorded: no vertex slots needed)
     DevBuf<BlockStats> d_stats;
@@ -522,6 +574,8 @@ struct ppg_ctx {
     bool tuneForceBvh = false;        // PPG_FORCE_BVH: trace small scenes through the BVH as well
     bool tuneFuse = false;            // PPG_FUSE: trace small scenes inside k_generate / k_shade
     bool tuneNoSort = false;          // PPG_NO_SORT: do not sort the queue slices by BSDF type before k_shade<FULL>
+    bool tuneNoSortFirst = false;     // PPG_NO_SORT_FIRST: the first bounce of a batch unsorted through the complete k_shade<FULL>
+    bool tuneNoSplit = false;         // PPG_NO_SPLIT: one k_shade<FULL> over the whole sorted slice instead of k_shade<.., MSET_COMMON> + the rest
     bool tuneNoOverlap = false;       // PPG_NO_OVERLAP: k_commit after k_tail on one stream instead of beside it
     int tuneBulkBounces = -1;         // PPG_BULK_BOUNCES: fixed number of wavefront bounces before k_tail takes over (-1 = adaptive)
     bool debugBatch = false;          // PPG_DEBUG_BATCH: one line per batch on stderr (paths, live paths after every bulk bounce, tail time)
@@ -861,7 +915,11 @@ int allocPaths(ppg_ctx *ctx) {
     ctx->queues.items[0] = ctx->d_queue[0].p; ctx->queues.items[1] = ctx->d_queue[1].p;
     ctx->queues.count[0] = ctx->d_qcount[0].p; ctx->queues.count[1] = ctx->d_qcount[1].p;
     ctx->queues.cap = (unsigned int)cap; ctx->queues.stats = ctx->d_stats.p; ctx->queues.n_blocks = (unsigned int)nb;
-    if (ctx->fullMaterials && !ctx->tuneNoSort) { HIP_CHECK(ctx->d_queueSorted.reserve(cap * nb)); HIP_CHECK(ctx->d_sortKeys.reserve(cap * nb)); }
+    ctx->queues.n_common = nullptr;
+    if (ctx->fullMaterials && !ctx->tuneNoSort) {
+        HIP_CHECK(ctx->d_queueSorted.reserve(cap * nb)); HIP_CHECK(ctx->d_sortKeys.reserve(cap * nb));
+        if (!ctx->tuneNoSplit) { HIP_CHECK(ctx->d_qcommon.reserve(nb)); ctx->queues.n_common = ctx->d_qcommon.p; }
+    }
     size_t nv = nTrain * (size_t)ctx->maxVertices;
     const bool filtered = ctx->spatialFilter != SF_NEAREST;
     PathState &P = ctx->paths;
@@ -1045,13 +1103,23 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound) {
                     else hipLaunchKernelGGL((k_trace<false, false>), dim3(grid), dim3(PPG_BLOCK), ldsBytes, s, P, S, Q, qin, ctx->ldsNodes, ctx->ldsTris);
                 });
             int shadeIn = qin;
-            if (fullMats && !fused && qin == QIN_DENSE && ctx->d_queueSorted.p) {
+            // (the first bounce — every path of the batch, camera rays — is sorted only for the sake of the split into material classes)
+            if (fullMats && !fused && (qin == QIN_DENSE || (Q.n_common && !neeOn && !ctx->tuneNoSortFirst)) && ctx->d_queueSorted.p) {
                 timedLaunch(ctx, "k_sort_slices", hostCount, [&] {
-                    hipLaunchKernelGGL(k_sort_slices, dim3(grid), dim3(PPG_BLOCK), 0, s, P, S, Q, ctx->d_queueSorted.p, ctx->d_sortKeys.p);
+                    hipLaunchKernelGGL(k_sort_slices, dim3(grid), dim3(PPG_BLOCK), 0, s, P, S, Q, qin, ctx->d_queueSorted.p, ctx->d_sortKeys.p);
                 });
                 shadeIn = QIN_SORTED;
             }
-            timedLaunch(ctx, fused ? "k_shade<fused>" : (neeOn ? "k_shade<nee>" : (fullMats ? "k_shade<full>" : "k_shade")), hostCount, [&] {
+            // FULL scene, sorted slice, no luminaire sampling: the common material classes first, in their own leaner kernel (MSET_COMMON)
+            const bool split = shadeIn == QIN_SORTED && Q.n_common && !neeOn;
+            if (split) {
+                timedLaunch(ctx, "k_shade<common>", hostCount, [&] {
+                    ShadeLaunch a{grid, 0, s, P, S, T, R, Q, QIN_SORTED_COMMON, smallScene ? 1 : 0, ctx->d_queueSorted.p};
+                    ppg_launch_shade_common(a);
+                });
+                shadeIn = QIN_SORTED_REST;
+            }
+            timedLaunch(ctx, fused ? "k_shade<fused>" : (neeOn ? "k_shade<nee>" : (fullMats ? (split ? "k_shade<rest>" : "k_shade<full>") : "k_shade")), hostCount, [&] {
                 const int small = smallScene ? 1 : 0;
                 // dynamic LDS: the staged triangles (fused, or luminaire sampling on a small scene) or the shadow rays' BVH stack columns
                 const size_t neeBytes = smallScene ? triBytes : (size_t)PPG_LDS_STACK * PPG_BLOCK * 4;
@@ -1593,6 +1661,8 @@ int ppg_create(const ppg_config *cfg, ppg_ctx **out) {
         c->tuneForceBvh = getenv("PPG_FORCE_BVH") != nullptr;
         c->tuneFuse = getenv("PPG_FUSE") != nullptr;
         c->tuneNoSort = getenv("PPG_NO_SORT") != nullptr;
+        c->tuneNoSplit = getenv("PPG_NO_SPLIT") != nullptr;
+        c->tuneNoSortFirst = getenv("PPG_NO_SORT_FIRST") != nullptr;
         c->tuneNoOverlap = getenv("PPG_NO_OVERLAP") != nullptr;
         if (const char *e = getenv("PPG_BULK_BOUNCES")) c->tuneBulkBounces = std::max(0, atoi(e));
         if (const char *e = getenv("PPG_BOUNCE_MARGIN")) c->bounceMargin = std::max(0, atoi(e));
@@ -1823,6 +1893,9 @@ int ppg_set_scene(ppg_ctx *ctx, const ppg_scene *s) {
     HIP_CHECK(hipMemcpy(ctx->d_bvh.p, bb.nodes.data(), bb.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice));
     HIP_CHECK(ctx->d_bvh4.reserve(bb.nodes4q.size()));
     HIP_CHECK(hipMemcpy(ctx->d_bvh4.p, bb.nodes4q.data(), bb.nodes4q.size() * sizeof(Bvh4QNode), hipMemcpyHostToDevice));
+    HIP_CHECK(ctx->d_bvhTop.reserve(std::max<size_t>(2, bb.topCut.size() / 4)));
+    if (!bb.topCut.empty()) HIP_CHECK(hipMemcpy(ctx->d_bvhTop.p, bb.topCut.data(), bb.topCut.size() * sizeof(float), hipMemcpyHostToDevice));
+    const int nTop = getenv("PPG_NO_TOPCUT") ? 0 : (int)(bb.topCut.size() / 8);
     if (s->n_rtrans && s->rtrans) {
         const size_t n = (size_t)s->n_rtrans * (s->rtrans_samples + 1);
         HIP_CHECK(ctx->d_rtrans.reserve(n));
@@ -1944,7 +2017,7 @@ int ppg_set_scene(ppg_ctx *ctx, const ppg_scene *s) {
         S.em_area_cdf = ctx->d_emArea.p; S.em_tris = ctx->d_emTris.p; S.em_normals = enrm.empty() ? nullptr : ctx->d_emNrm.p;
     }
     DevScene &S = ctx->scene;
-    S.tris = ctx->d_tris.p; S.accel = ctx->d_accel.p; S.normals = s->normals ? ctx->d_normals.p : nullptr; S.bvh = ctx->d_bvh.p; S.bvh4 = ctx->d_bvh4.p;
+    S.tris = ctx->d_tris.p; S.accel = ctx->d_accel.p; S.normals = s->normals ? ctx->d_normals.p : nullptr; S.bvh = ctx->d_bvh.p; S.bvh4 = ctx->d_bvh4.p; S.bvh_top = ctx->d_bvhTop.p; S.n_top = nTop;
     S.materials = ctx->d_materials.p; S.emitters = ctx->d_emitters.p; S.n_tris = (int)s->n_triangles; S.has_null = hasNull ? 1 : 0;
     S.rtrans = s->n_rtrans ? ctx->d_rtrans.p : nullptr; S.rtrans_n = (int)s->rtrans_samples;
     S.spheres = nullptr; S.n_spheres = (int)s->n_spheres;

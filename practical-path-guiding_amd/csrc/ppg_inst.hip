@@ -1,13 +1,14 @@
 /*
  * ppg_inst.hip — one pair of instantiations of a large path kernel per translation unit (ppg_launch.h): compiled with
- * -DPPG_INST=0..3 (k_shade: FUSED x NEE, both FULL settings), 4..7 (k_tail: SMALL x NEE, both FULL settings), 8 (k_commit, all six).
+ * -DPPG_INST=0..3 (k_shade: FUSED x NEE, both FULL settings), 4..7 (k_tail: SMALL x NEE, both FULL settings), 8 (k_commit, all six),
+ * 9 (k_shade<false, false, FULL, MSET_COMMON>: the common material classes of a FULL scene).
  */
 #include <hip/hip_runtime.h>
 
 #include "ppg_launch.h"
 
 #ifndef PPG_INST
-#error "compile with -DPPG_INST=0..8"
+#error "compile with -DPPG_INST=0..9"
 #endif
 
 #if PPG_INST < 4
@@ -38,6 +39,10 @@ void PPG_TAIL_FN(int variant, const TailLaunch &a) {
         hipLaunchKernelGGL((k_tail<PAIR_S, PAIR_N, true>), dim3(a.grid), dim3(PPG_BLOCK), a.lds, a.stream, a.P, a.S, a.T, a.R, a.dense, a.total, a.ticket, a.stats, a.lds_tris, a.longest);
     else
         hipLaunchKernelGGL((k_tail<PAIR_S, PAIR_N, false>), dim3(a.grid), dim3(PPG_BLOCK), a.lds, a.stream, a.P, a.S, a.T, a.R, a.dense, a.total, a.ticket, a.stats, a.lds_tris, a.longest);
+}
+#elif PPG_INST == 9
+void ppg_launch_shade_common(const ShadeLaunch &a) {
+    hipLaunchKernelGGL((k_shade<false, false, true, MSET_COMMON>), dim3(a.grid), dim3(PPG_BLOCK), a.lds, a.stream, a.P, a.S, a.T, a.R, a.Q, a.qin, a.small_scene, a.sorted_items);
 }
 #else
 void ppg_launch_commit_all(int sf, int df, const CommitLaunch &a) {

@@ -28,6 +28,21 @@
                                 // spills 257 of them (KITCHEN 720p: 4 waves 76.5, 3 waves 81.3, 2 waves 79.6 Msamples/s)
 #endif
 
+#ifndef PPG_SHADE_WAVES_COMMON
+#define PPG_SHADE_WAVES_COMMON 3  // ... for k_shade<.., FULL, MSET_COMMON>: the common lobes of a FULL scene (see MSET_COMMON)
+#endif
+
+// Material subsets of the FULL kernels.  A FULL scene's queue slices are counting-sorted by the BSDF at the new hit (k_sort_slices); the
+// COMMON classes — diffuse / two-sided diffuse, smooth and rough conductor, plastic, rough plastic on a triangle, no mask, no bump map —
+// come first and are shaded by k_shade<.., FULL, MSET_COMMON>, a variant from which everything else is compiled out: analytic spheres, rays
+// that left the scene (environment lookup), null components and the look-through trace, glass / thin glass / rough dielectric lobes, the
+// bump-mapped frame.  The rest of the slice goes through the complete kernel (MSET_ALL) in a second launch.  Same arithmetic per path.
+enum { MSET_ALL = 0, MSET_COMMON = 1 };
+D bool mset_common_type(int type) {
+    return type == PPG_BSDF_DIFFUSE || type == PPG_BSDF_TWOSIDED_DIFFUSE || type == PPG_BSDF_MIRROR || type == PPG_BSDF_CONDUCTOR ||
+           type == PPG_BSDF_ROUGHCONDUCTOR || type == PPG_BSDF_PLASTIC || type == PPG_BSDF_ROUGHPLASTIC;
+}
+
 enum { NEE_NEVER = 0, NEE_KICKSTART = 1, NEE_ALWAYS = 2 };
 enum { SF_NEAREST = 0, SF_STOCHASTIC = 1, SF_BOX = 2 };
 enum { DF_NEAREST = 0, DF_BOX = 1 };
@@ -124,6 +139,7 @@ struct BlockStats {
 struct Queues {
     unsigned int *items[2];  // [0]: k_shade's output slices; [1]: the dense list
     unsigned int *count[2];  // [0][b]: entries of output slice b; [1][b]: entries of workgroup b's slice of the sorted list (k_sort_slices)
+    unsigned int *n_common;  // [b]: how many of them, at the front, belong to the COMMON material classes (MSET_COMMON); nullptr: no split
     unsigned int cap;        // entries per workgroup slice
     unsigned int n_blocks;
     BlockStats *stats;       // [n_blocks]
@@ -135,6 +151,8 @@ struct Queues {
 #define QIN_FIRST (-1)   // bounce 1: every path of the batch, dealt in chunks of PPG_CHUNK (a wave = 64 neighbouring pixels)
 #define QIN_DENSE (-2)   // the dense list, dealt in chunks of PPG_DCHUNK
 #define QIN_SORTED (-3)  // k_shade after k_sort_slices: the workgroup's share of the dense list, re-ordered, in its slice of `sorted_items`
+#define QIN_SORTED_COMMON (-4)  // ... its front part: the hits on the common material classes (k_shade<.., MSET_COMMON>)
+#define QIN_SORTED_REST (-5)    // ... the rest of it (the complete k_shade, launched second: it APPENDS to the first launch's output slice)
 #ifndef PPG_DCHUNK
 #define PPG_DCHUNK 256
 #endif
@@ -197,6 +215,8 @@ D Work work_of(const PathState &P, const Queues &Q, int qin, const unsigned int 
     w.n_paths = P.n_paths;
     if (qin == QIN_FIRST) { w.items = nullptr; w.count = first_share(P.n_paths, b, nb); w.mode = 0; }
     else if (qin == QIN_SORTED && sorted_items) { w.items = sorted_items + (size_t)b * Q.cap; w.count = Q.count[1][b]; w.mode = 1; }
+    else if (qin == QIN_SORTED_COMMON && sorted_items) { w.items = sorted_items + (size_t)b * Q.cap; w.count = Q.n_common[b]; w.mode = 1; }
+    else if (qin == QIN_SORTED_REST && sorted_items) { const unsigned int nc = Q.n_common[b]; w.items = sorted_items + (size_t)b * Q.cap + nc; w.count = Q.count[1][b] - nc; w.mode = 1; }
     else { w.items = Q.items[1]; w.count = dense_share((unsigned int)*Q.dense_n, b, nb); w.mode = 2; }
     return w;
 }
@@ -765,7 +785,7 @@ struct Carried {
     unsigned long long *plds, pt, prt; bool pon;
 #endif
 };
-template <bool FUSED, bool NEE, bool FULL, bool CARRY = false>
+template <bool FUSED, bool NEE, bool FULL, bool CARRY = false, int MSET = MSET_ALL>
 D bool shade_one(const PathState &P, const DevScene &S, const DevTree &T, const RenderParams &R, const unsigned int i, const LdsColumn &fcol,
                  const float4 *lds_tris, unsigned long long &plen, unsigned int &traced, const NeeLds &nee, unsigned long long &committed,
                  Carried *cs = nullptr) {
@@ -785,12 +805,13 @@ D bool shade_one(const PathState &P, const DevScene &S, const DevTree &T, const 
     F3 d = f3(d4.x, d4.y, d4.z);
     Hit h;
     h.t = h4.x; h.u = h4.y; h.v = h4.z; h.prim = __float_as_int(h4.w);
-    const bool valid = h.prim >= 0;
+    if (MSET == MSET_COMMON) __builtin_assume(h.prim >= 0);
+    const bool valid = MSET == MSET_COMMON ? true : h.prim >= 0;
     Isect I;
     TexInfo X;
     X.tex = 0u;
     if (valid) {
-        if (FULL && h.prim >= S.n_tris) {
+        if (FULL && MSET != MSET_COMMON && h.prim >= S.n_tris) {
             const float4 ro4 = ray_origin();
             fill_isect_sphere(S, h, f3(ro4.x, ro4.y, ro4.z), d, I);
         } else if (FULL) fill_isect_tex(S, h, d, I, X);
@@ -813,11 +834,11 @@ D bool shade_one(const PathState &P, const DevScene &S, const DevTree &T, const 
         F3 em_n = I.n;
         float em_dist = h.t;
         int em_id = I.emitter;
-        if (FULL && !valid && S.env.w != 0) {  // GP:2236-2243: the ray left the scene
+        if (FULL && MSET != MSET_COMMON && !valid && S.env.w != 0) {  // GP:2236-2243: the ray left the scene
             const float4 ro4 = ray_origin();
             if (env_fill_direct(S, f3(ro4.x, ro4.y, ro4.z), d)) { value = env_radiance(S, d); em_id = S.n_emitters; }
         }
-        if (FULL && S.has_null && valid && I.emitter < 0) {
+        if (FULL && MSET != MSET_COMMON && S.has_null && valid && I.emitter < 0) {
             // rayIntersectAndLookForEmitter GP:2184-2245: the path continues from THIS hit, but the search for an emitter
             // goes on through surfaces that have a null component (traced in place)
             Mat Mc = load_material(S, I.material);
@@ -916,7 +937,7 @@ D bool shade_one(const PathState &P, const DevScene &S, const DevTree &T, const 
 
     PROBE_MARK(cs, 3);
     // ---- first half of this bounce: GP:1902-2040 ----
-    if (go && !valid) {  // GP:1902-1914: possibly radiance from a background luminaire, then the path ends
+    if (MSET != MSET_COMMON && go && !valid) {  // GP:1902-1914: possibly radiance from a background luminaire, then the path ends
         if (FULL && S.env.w != 0 && (flags & FL_EMITTED_OK) && (!R.hide_emitters || (flags & FL_SCATTERED)))
             Li = Li + mul3(thr, env_radiance(S, d));  // (nVertices == 0 whenever emission is still enabled)
         go = false;
@@ -934,6 +955,11 @@ D bool shade_one(const PathState &P, const DevScene &S, const DevTree &T, const 
         Mat M;
         if (FULL) {
             M = load_material(S, I.material);
+            if (MSET == MSET_COMMON) {  // what k_sort_slices put into the common part of the slice
+                if (!(M.type == PPG_BSDF_DIFFUSE || M.type == PPG_BSDF_MIRROR || M.type == PPG_BSDF_CONDUCTOR || M.type == PPG_BSDF_ROUGHCONDUCTOR ||
+                      M.type == PPG_BSDF_PLASTIC || M.type == PPG_BSDF_ROUGHPLASTIC)) __builtin_unreachable();
+                if (M.flags & PPG_MAT_MASK) __builtin_unreachable();
+            }
         } else {
             const float4 mat = S.materials[PPG_MAT_STRIDE * (size_t)I.material];
             M.type = (int)mat.w; M.flags = 0; M.refl = f3(mat.x, mat.y, mat.z);
@@ -945,7 +971,7 @@ D bool shade_one(const PathState &P, const DevScene &S, const DevTree &T, const 
         F3 ps = f3s(0.0f), pt = f3s(0.0f), pn = f3s(0.0f);
         if (FULL && X.tex) {
             if (X.tex & 0xffffu) M.refl = tex_eval(S.textures[(X.tex & 0xffffu) - 1u], X.u, X.v);
-            if (X.tex >> 16) { bump_frame(S, I, X, ps, pt, pn); bumped = true; }
+            if (MSET != MSET_COMMON && (X.tex >> 16)) { bump_frame(S, I, X, ps, pt, pn); bumped = true; }
         }
         // (one call site per BSDF function: the bumped variant only transforms the arguments first — two inlined copies of the whole
         // material switch per function made the FULL kernels 330 KB of code, five times the instruction cache)
@@ -1192,7 +1218,7 @@ D bool shade_one(const PathState &P, const DevScene &S, const DevTree &T, const 
 }
 
 // One queue slice through Li's loop body.
-template <bool FUSED, bool NEE, bool FULL>
+template <bool FUSED, bool NEE, bool FULL, int MSET = MSET_ALL>
 D void shade_slice(const PathState &P, const DevScene &S, const DevTree &T, const RenderParams &R, const Work &work,
                    unsigned int b, unsigned int nb, unsigned int *out_items, unsigned int *out_count, const LdsColumn &fcol,
                    const float4 *lds_tris, unsigned long long &plen_sum, unsigned int &traced, const NeeLds &nee,
@@ -1209,7 +1235,7 @@ D void shade_slice(const PathState &P, const DevScene &S, const DevTree &T, cons
             active = i < P.n_paths;
         }
         if (active) {
-            alive = shade_one<FUSED, NEE, FULL>(P, S, T, R, i, fcol, lds_tris, plen, traced, nee, committed);
+            alive = shade_one<FUSED, NEE, FULL, false, MSET>(P, S, T, R, i, fcol, lds_tris, plen, traced, nee, committed);
         }
         unsigned int slot = queue_append(out_count, alive);
         if (alive) out_items[slot] = i;
@@ -1217,8 +1243,8 @@ D void shade_slice(const PathState &P, const DevScene &S, const DevTree &T, cons
     }
 }
 
-template <bool FUSED, bool NEE, bool FULL>
-__global__ __launch_bounds__(PPG_BLOCK, (FULL ? PPG_SHADE_WAVES_FULL : PPG_SHADE_WAVES)) void k_shade(PathState P, DevScene S, DevTree T, RenderParams R, Queues Q, int qin,
+template <bool FUSED, bool NEE, bool FULL, int MSET = MSET_ALL>
+__global__ __launch_bounds__(PPG_BLOCK, (MSET == MSET_COMMON ? PPG_SHADE_WAVES_COMMON : (FULL ? PPG_SHADE_WAVES_FULL : PPG_SHADE_WAVES))) void k_shade(PathState P, DevScene S, DevTree T, RenderParams R, Queues Q, int qin,
                                                                      int small_scene, const unsigned int *sorted_items) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __shared__ float pdf_factors[20 * PPG_BLOCK];  // QuadTreeNode::pdf's per-level factors (tree depth <= 20, GP:1112)
@@ -1238,12 +1264,12 @@ __global__ __launch_bounds__(PPG_BLOCK, (FULL ? PPG_SHADE_WAVES_FULL : PPG_SHADE
     if (Q.stop && *Q.stop) return;
     // QIN_SORTED: the workgroup's share of the dense list re-ordered by the BSDF type at the new hit (k_sort_slices); same paths, other order
     const Work work = work_of(P, Q, qin, sorted_items, b, nb);
-    if (threadIdx.x == 0) out_count = 0;
+    if (threadIdx.x == 0) out_count = qin == QIN_SORTED_REST ? Q.count[0][b] : 0;  // the second launch over a slice appends to the first one's output
     __syncthreads();
     unsigned long long plen_sum = 0, committed = 0;
     unsigned int traced = 0;
-    shade_slice<FUSED, NEE, FULL>(P, S, T, R, work, b, nb, Q.items[0] + (size_t)b * Q.cap, &out_count, fcol, lds_tris, plen_sum, traced,
-                                  nee, committed);
+    shade_slice<FUSED, NEE, FULL, MSET>(P, S, T, R, work, b, nb, Q.items[0] + (size_t)b * Q.cap, &out_count, fcol, lds_tris, plen_sum, traced,
+                                        nee, committed);
     __syncthreads();
     if (threadIdx.x == 0) Q.count[0][b] = out_count;
     block_add_u64(&acc, &Q.stats[b].path_len, plen_sum);
@@ -1385,12 +1411,12 @@ __global__ __launch_bounds__(PPG_BLOCK, (FULL ? PPG_SHADE_WAVES_FULL : PPG_SHADE
 // union of its lanes' BSDF branches (rough plastic, rough conductor, glass, ...).  Every workgroup therefore counting-sorts its queue
 // slice by the BSDF type at the new hit (16 bins; rays that left the scene last, so that the lanes of their waves finish together).
 // The order of a slice has no influence on any result: per-path random numbers, integer accumulation.
-static __global__ __launch_bounds__(PPG_BLOCK) void k_sort_slices(PathState P, DevScene S, Queues Q, unsigned int *sorted, unsigned char *keys) {
+static __global__ __launch_bounds__(PPG_BLOCK) void k_sort_slices(PathState P, DevScene S, Queues Q, int qin, unsigned int *sorted, unsigned char *keys) {
     __shared__ unsigned int hist[16], offs[16];
     const unsigned int b = blockIdx.x, nb = gridDim.x;
     if (Q.stop && *Q.stop) return;
-    const Work work = work_of(P, Q, QIN_DENSE, nullptr, b, nb);
-    if (work.count == 0) { if (threadIdx.x == 0) Q.count[1][b] = 0; return; }
+    const Work work = work_of(P, Q, qin, nullptr, b, nb);  // QIN_FIRST (every path of the batch) or QIN_DENSE
+    if (work.count == 0) { if (threadIdx.x == 0) { Q.count[1][b] = 0; if (Q.n_common) Q.n_common[b] = 0; } return; }
     unsigned int *out = sorted + (size_t)b * Q.cap;
     unsigned char *kk = keys + (size_t)b * Q.cap;
     if (threadIdx.x < 16) hist[threadIdx.x] = 0;
@@ -1399,13 +1425,20 @@ static __global__ __launch_bounds__(PPG_BLOCK) void k_sort_slices(PathState P, D
         const unsigned int i = work_item(work, k, b, nb);
         unsigned int key = 255u;  // no path at this position (partial last chunk)
         if (i < P.n_paths) {
+            // bins 0..7: the COMMON classes (MSET_COMMON), by BSDF type; 8..15: everything else — by type, then bump-mapped or masked
+            // surfaces, spheres, and last the rays that left the scene
             const int prim = __float_as_int(P.hit[i].w);
             key = 15u;
             if (prim >= 0) {
                 if (prim >= S.n_tris) key = 14u;
                 else {
                     const int m = __float_as_int(S.tris[3 * (size_t)prim].w);
-                    key = (unsigned int)(int)S.materials[PPG_MAT_STRIDE * (size_t)m].w & 15u;
+                    const float4 *mr = S.materials + PPG_MAT_STRIDE * (size_t)m;
+                    const int type = (int)mr[0].w, flags = __float_as_int(mr[2].w);
+                    const unsigned int tex = __float_as_uint(mr[5].x);
+                    if ((flags & PPG_MAT_MASK) || (tex >> 16)) key = 13u;
+                    else if (mset_common_type(type)) key = type == PPG_BSDF_ROUGHPLASTIC ? 6u : (unsigned int)type;  // 0..6
+                    else key = 8u + ((unsigned int)type & 3u);  // dielectric 10, thin dielectric 11, rough dielectric 8
                 }
             }
             atomicAdd(&hist[key], 1u);
@@ -1415,7 +1448,7 @@ static __global__ __launch_bounds__(PPG_BLOCK) void k_sort_slices(PathState P, D
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned int acc = 0;
-        for (int j = 0; j < 16; ++j) { offs[j] = acc; acc += hist[j]; }
+        for (int j = 0; j < 16; ++j) { offs[j] = acc; acc += hist[j]; if (j == 7 && Q.n_common) Q.n_common[b] = acc; }
         Q.count[1][b] = acc;
     }
     __syncthreads();
@@ -1662,9 +1695,11 @@ static __global__ __launch_bounds__(256) void k_adam_apply(LeafHdr *hdr, const u
         // rates of "their" steps (the two pow() of GP:100 are the longest dependency chain of a step) in parallel, off the serial path.
         unsigned long long stepMask = 0ull;
         {
+            // (record t is read with v_readlane — t is uniform —, not with a shuffle through the LDS crossbar: the walk over a D-tree's
+            // records is a serial chain, and five ds_bpermute round trips per record were most of it)
             float ba = batchAccumulation;
             for (unsigned int t = 0; t < cnt; ++t) {
-                ba += __shfl(wgt, (int)t);
+                ba += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wgt), (int)t));
                 if (ba > 1.0f) { stepMask |= 1ull << t; ba = 0; }
             }
         }
@@ -1674,8 +1709,9 @@ static __global__ __launch_bounds__(256) void k_adam_apply(LeafHdr *hdr, const u
             myLr = 0.01f * __builtin_sqrtf(1 - ppg_powi(0.999f, it)) / (1 - ppg_powi(0.9f, it));
         }
         for (unsigned int t = 0; t < cnt; ++t) {
-            const float product = __shfl(pay.x, (int)t), woPdf = __shfl(pay.y, (int)t), bsdfPdf = __shfl(pay.z, (int)t), dTreePdf = __shfl(pay.w, (int)t);
-            const float statisticalWeight = __shfl(wgt, (int)t);
+            const float product = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pay.x), (int)t)), woPdf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pay.y), (int)t));
+            const float bsdfPdf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pay.z), (int)t)), dTreePdf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pay.w), (int)t));
+            const float statisticalWeight = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wgt), (int)t));
             // optimizeBsdfSamplingFraction, GP:672-691
             const float mixPdf = samplingFraction * bsdfPdf + (1 - samplingFraction) * dTreePdf;
             const float r = product / mixPdf;
@@ -1689,7 +1725,7 @@ static __global__ __launch_bounds__(256) void k_adam_apply(LeafHdr *hdr, const u
             if (batchAccumulation > 1.0f) {
                 const float gradient = batchGradient / batchAccumulation;  // step(), GP:97-109
                 ++iter;
-                const float lr = __shfl(myLr, (int)t);
+                const float lr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myLr), (int)t));
                 firstMoment = 0.9f * firstMoment + (1 - 0.9f) * gradient;
                 secondMoment = 0.999f * secondMoment + (1 - 0.999f) * gradient * gradient;
                 variable -= lr * firstMoment / (__builtin_sqrtf(secondMoment) + 1e-08f);

@@ -53,5 +53,7 @@ void ppg_launch_tail_pair1(int variant, const TailLaunch &a);
 void ppg_launch_tail_pair2(int variant, const TailLaunch &a);
 void ppg_launch_tail_pair3(int variant, const TailLaunch &a);
 void ppg_launch_commit_all(int spatial_filter, int directional_filter, const CommitLaunch &a);
+// k_shade<false, false, FULL, MSET_COMMON> over the front part of the sorted slices (a.qin = QIN_SORTED_COMMON)
+void ppg_launch_shade_common(const ShadeLaunch &a);
 
 #endif
