@@ -6,8 +6,8 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=$1; REPS=$2; PASSES=$3; shift 3
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
-cd /tmp; export TMPDIR=/tmp
-B="python $R/bench.py --steps $PASSES --warmup 5 --no-cpu --no-rmse --no-secondary --no-roofline --no-single-call"
+cd /tmp; export TMPDIR=/tmp; ulimit -c 0
+B="timeout 300 python $R/bench.py --steps $PASSES --warmup 5 --no-cpu --no-rmse --no-secondary --no-roofline --no-single-call"
 lib() { if [ "$1" = "-" ] || [ -z "$1" ]; then echo $R/practical-path-guiding_amd/lib/libppg_hip.so; else echo $R/practical-path-guiding_amd/lib/$1; fi; }
 if [ -n "$PPG_AB_TESTS" ]; then
   for v in "$@"; do
