@@ -20,6 +20,7 @@
 #include <iostream>
 
 #include "guided_path_hip.h"
+#include "plugin_core.h"
 #include "rccl_reducer.h"
 #include "scene_xml.h"
 
@@ -211,7 +212,8 @@ int main(int argc, char **argv) {
     std::string out = "out.pfm", scenePath, dumpScene, bsdfId, bsdfPlugin, ncclIdFile, runTag;
     std::vector<xml::BsdfParam> bsdfParams;
     int rank = 0, world = 1;
-    bool quiet = false, lenient = false;
+    bool quiet = false, lenient = false, pluginCore = false;
+    int cancelAfterMs = -1;
     std::string dataDir;  // `data` directory of a Mitsuba tree (roughplastic: data/microfacet/*.dat); default $PPG_MITSUBA_DATA
     int cw = 0, ch = 0, sw = 0, sh = 0;
     std::map<std::string, std::string> defines;
@@ -238,6 +240,9 @@ int main(int argc, char **argv) {
         else if (a == "--nccl-id" && i + 1 < argc) ncclIdFile = argv[++i];    // host/rccl_reducer.h
         else if (a == "--run-tag" && i + 1 < argc) runTag = argv[++i];        // the same string on all ranks of one run: a stale id file of an earlier run is ignored
         else if (a == "--lenient") lenient = true;
+        else if (a == "--plugin-core") pluginCore = true;   // render the way the Mitsuba plug-in does: ppg::PluginCore (host/plugin_core.h), ONE ppg_render() call,
+                                                            // SD-tree dumps (-D dumpSDTree=true) to "<out without extension>-NN.sdt" like scene->getDestinationFile()
+        else if (a == "--cancel-after-ms" && i + 1 < argc) cancelAfterMs = atoi(argv[++i]);  // with --plugin-core: Integrator::cancel() from another thread (0 = before render())
         else if (a == "--data-dir" && i + 1 < argc) dataDir = argv[++i];
         else if (a == "--size" && i + 1 < argc) { if (sscanf(argv[++i], "%dx%d", &sw, &sh) != 2) { std::cerr << "--size WxH\n"; return 2; } }
         else if (a == "-q") quiet = true;
@@ -289,6 +294,29 @@ int main(int argc, char **argv) {
         std::ofstream pf(dumpScene + ".props");
         for (auto &kv : props.values) pf << kv.first << "=" << kv.second << "\n";
         return 0;
+    }
+    if (pluginCore) {
+        PluginCore core;
+        core.configure(props);
+        core.setSeed((uint64_t)std::stoull(props.getString("seed", "0")));
+        std::string dest = out;
+        const size_t dot = dest.find_last_of('.');
+        if (dot != std::string::npos && dest.find('/', dot) == std::string::npos) dest.erase(dot);
+        std::thread canceller;
+        if (cancelAfterMs == 0) core.cancel();
+        else if (cancelAfterMs > 0) canceller = std::thread([&] { std::this_thread::sleep_for(std::chrono::milliseconds(cancelAfterMs)); core.cancel(); });
+        std::string err;
+        const ppg_scene sv = scene.view();
+        const int rc = core.render(sv, dest, err);
+        if (canceller.joinable()) canceller.join();
+        if (rc != PPG_OK && rc != PPG_ERR_CANCELLED) { std::cerr << "error: " << err << std::endl; return 3; }
+        if (rc == PPG_ERR_CANCELLED && !quiet) std::cout << "(cancelled)" << std::endl;
+        if (core.context() && !(rc == PPG_ERR_CANCELLED && cancelAfterMs == 0)) {
+            std::vector<float> rgb((size_t)scene.camera.width * scene.camera.height * 3);
+            if (core.readFilm(rgb.data(), err) != PPG_OK) { std::cerr << "error: " << err << std::endl; return 3; }
+            writePFM(out.c_str(), rgb, scene.camera.width, scene.camera.height);
+        }
+        return rc == PPG_OK ? 0 : 1;
     }
     try {
         std::unique_ptr<RcclReducer> reducer;

@@ -44,38 +44,18 @@
 
 #include "ppg.h"
 #include "guided_path_hip.h"   /* ppg::SceneData (host side of the C-ABI) */
+#include "plugin_core.h"       /* ppg::PluginCore: property mapping + create / scene / render / cancel, shared with the stand-alone driver */
 #include "scene_xml.h"         /* ppg::xml: the <bsdf> parser of the stand-alone driver */
 
 MTS_NAMESPACE_BEGIN
 
 class GuidedPathTracerHIP : public Integrator {
 public:
-    GuidedPathTracerHIP(const Properties &props) : Integrator(props), m_ctx(NULL) {
-        ppg_config_default(&m_cfg);
-        /* same names and defaults as GuidedPathTracer(const Properties &), GP:1015-1084 */
-        m_s[0] = props.getString("nee", "never");                      m_cfg.nee = m_s[0].c_str();
-        m_s[1] = props.getString("sampleCombination", "automatic");    m_cfg.sampleCombination = m_s[1].c_str();
-        m_s[2] = props.getString("spatialFilter", "nearest");          m_cfg.spatialFilter = m_s[2].c_str();
-        m_s[3] = props.getString("directionalFilter", "nearest");      m_cfg.directionalFilter = m_s[3].c_str();
-        m_s[4] = props.getString("bsdfSamplingFractionLoss", "none");  m_cfg.bsdfSamplingFractionLoss = m_s[4].c_str();
-        m_s[5] = props.getString("budgetType", "seconds");             m_cfg.budgetType = m_s[5].c_str();
-        m_cfg.sdTreeMaxMemory = props.getInteger("sdTreeMaxMemory", -1);
-        m_cfg.sTreeThreshold = props.getInteger("sTreeThreshold", 12000);
-        m_cfg.dTreeThreshold = props.getFloat("dTreeThreshold", 0.01f);
-        m_cfg.bsdfSamplingFraction = props.getFloat("bsdfSamplingFraction", 0.5f);
-        m_cfg.sppPerPass = props.getInteger("sppPerPass", 4);
-        m_cfg.budget = props.getFloat("budget", 300.0f);
-        m_cfg.dumpSDTree = props.getBoolean("dumpSDTree", false);
-        m_cfg.rrDepth = props.getInteger("rrDepth", 5);                /* MonteCarloIntegrator, integrator.cpp:192-218 */
-        m_cfg.maxDepth = props.getInteger("maxDepth", -1);
-        m_cfg.strictNormals = props.getBoolean("strictNormals", false);
-        m_cfg.hideEmitters = props.getBoolean("hideEmitters", false);
-        m_cfg.device = props.getInteger("device", 0);
-        if (ppg_create(&m_cfg, &m_ctx) != PPG_OK)
-            Log(EError, "guided_path_hip: %s", ppg_last_error(NULL));   /* unknown enum strings: where GP:1023.. Assert(false) */
-    }
+    /* same names and defaults as GuidedPathTracer(const Properties &), GP:1015-1084: ppg::PluginCore::configure (host/plugin_core.h), which
+       the stand-alone driver runs too.  The context is created in render(), where the destination of the SD-tree dumps is known. */
+    GuidedPathTracerHIP(const Properties &props) : Integrator(props) { m_core.configure(props); }
 
-    virtual ~GuidedPathTracerHIP() { if (m_ctx) ppg_destroy(m_ctx); }
+    virtual ~GuidedPathTracerHIP() { }
 
     bool preprocess(const Scene *, RenderQueue *, const RenderJob *, int, int, int) { return true; }
 
@@ -87,29 +67,29 @@ public:
 
         ppg::SceneData data;
         std::string why;
-        if (!flatten(scene, sensor.get(), film.get(), data, why))
+        if (!flatten(scene, sensor.get(), film.get(), data, why)) {
             Log(EError, "guided_path_hip: %s", why.c_str());
-        const ppg_scene desc = data.view();
-        if (ppg_set_scene(m_ctx, &desc) != PPG_OK)
-            Log(EError, "guided_path_hip: %s", ppg_last_error(m_ctx));
-
-        if (m_cfg.dumpSDTree) {           /* "<dest>-NN.sdt", GP:1192-1195 */
-            m_dump = scene->getDestinationFile().string();
-            m_cfg.dumpPrefix = m_dump.c_str();
+            return false;                 /* (EError normally throws; if it is configured not to, stop here) */
         }
+        const ppg_scene desc = data.view();
         Log(EInfo, "Starting render job (%ix%i, MI355X, %i triangles, %i analytic spheres) ..", film->getCropSize().x, film->getCropSize().y,
             (int) (data.indices.size() / 3), (int) data.spheres.size());
-        const int rc = ppg_render(m_ctx);
-        if (rc != PPG_OK && rc != PPG_ERR_CANCELLED)
-            Log(EError, "guided_path_hip: %s", ppg_last_error(m_ctx));
-
+        /* create → scene → render; SD-tree dumps to "<dest>-NN.sdt" (GP:1192-1195) */
+        const int rc = m_core.render(desc, scene->getDestinationFile().string(), why);
+        if (rc != PPG_OK && rc != PPG_ERR_CANCELLED) {
+            Log(EError, "guided_path_hip: %s", why.c_str());   /* unknown enum strings: where GP:1023.. Assert(false) */
+            return false;
+        }
         ref<Bitmap> out = new Bitmap(Bitmap::ERGB, Bitmap::EFloat32, film->getCropSize());
-        ppg_read_film(m_ctx, out->getFloat32Data());
+        if (m_core.readFilm(out->getFloat32Data(), why) != PPG_OK) {
+            Log(EError, "guided_path_hip: %s", why.c_str());
+            return false;
+        }
         film->setBitmap(out);
         return rc == PPG_OK;              /* false when cancelled, GP:1584 */
     }
 
-    void cancel() { if (m_ctx) ppg_cancel(m_ctx); }   /* Integrator::cancel, integrator.h:84 / GP:1643-1648; thread-safe */
+    void cancel() { m_core.cancel(); }   /* Integrator::cancel, integrator.h:84 / GP:1643-1648; thread-safe, also before render() */
 
     std::string toString() const { return "GuidedPathTracerHIP[libppg_hip.so]"; }
 
@@ -320,9 +300,7 @@ private:
         return true;
     }
 
-    ppg_config m_cfg;
-    ppg_ctx *m_ctx;
-    std::string m_s[6], m_dump;
+    ppg::PluginCore m_core;
 };
 
 /* not serialisable, like the reference's integrator (guided_path.cpp:2421: MTS_IMPLEMENT_CLASS, no stream constructor) */

@@ -112,6 +112,51 @@ def test_cpp_driver_equals_python_path(ppg_render, tmp_path):
     assert abs(a.mean() / b.mean() - 1) < 0.05
 
 
+def test_plugin_core_reports_errors_instead_of_crashing(ppg_render, tmp_path):
+    """ppg::PluginCore (host/plugin_core.h) is what mitsuba_plugin/guided_path_hip.cpp is made of below the Mitsuba types; the stand-alone
+    driver runs it with --plugin-core.  A context that cannot be created (unknown enum value; here also: no GPU) is an error message and a
+    return code — never a NULL context handed on to ppg_set_scene, which is what round 3's shim did when Log(EError) did not throw."""
+    r = subprocess.run([ppg_render, "--cbox", "8x8", "--plugin-core", "-D", "spatialFilter=gauss", "-o", str(tmp_path / "x.pfm")], capture_output=True, text=True)
+    assert r.returncode == 3 and r.stderr.startswith("error: ") and ("spatialFilter" in r.stderr or "HIP device" in r.stderr)
+    assert not (tmp_path / "x.pfm").exists()
+
+
+@pytest.mark.gpu
+def test_plugin_core_control_flow_dumps_and_cancel(ppg_render, tmp_path):
+    """The plug-in's control flow, compiled and run (its source had never been): properties → create → scene → ONE ppg_render()
+    → film equals the phase-by-phase C++ host bit for bit; dumpSDTree through it writes "<dest>-NN.sdt" for every iteration but the last
+    (GP:1191-1195) — byte-equal to what the phase-driven host writes with an explicit prefix —; cancel() before render() and from another
+    thread while it renders both end it with `false` (GP:1584) and without a crash."""
+    props = dict(CBOX_PROPS, budget=60, seed=5, sampleCombination="inversevar", bsdfSamplingFractionLoss="kl", spatialFilter="stochastic",
+                 directionalFilter="box", sTreeThreshold=4000, sppPerPass=1, dumpSDTree="true")
+    defs = sum([["-D", "%s=%s" % kv] for kv in props.items()], [])
+    a, b = tmp_path / "a" / "img.pfm", tmp_path / "b" / "img.pfm"
+    a.parent.mkdir(); b.parent.mkdir()
+    r = subprocess.run([ppg_render, "--cbox", "64x48", "-q", "--plugin-core", "-o", str(a)] + defs, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([ppg_render, "--cbox", "64x48", "-q", "-o", str(b), "-D", "dumpPrefix=%s" % (b.parent / "img")] + defs, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert np.array_equal(read_pfm(str(a)), read_pfm(str(b)))
+    dumps_a = sorted(f.name for f in a.parent.glob("img-*.sdt"))
+    assert dumps_a == ["img-%02d.sdt" % k for k in range(len(dumps_a))] and len(dumps_a) >= 3  # 60 passes: iterations 0..4, the last one is final
+    for name in dumps_a:
+        assert (a.parent / name).read_bytes() == (b.parent / name).read_bytes() and (a.parent / name).stat().st_size > 64
+    # dumpSDTree off: nothing is written
+    c = tmp_path / "c" / "img.pfm"
+    c.parent.mkdir()
+    defs_off = sum([["-D", "%s=%s" % kv] for kv in dict(props, dumpSDTree="false").items()], [])
+    r = subprocess.run([ppg_render, "--cbox", "64x48", "-q", "--plugin-core", "-o", str(c)] + defs_off, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and not list(c.parent.glob("*.sdt")) and np.array_equal(read_pfm(str(c)), read_pfm(str(a)))
+    # Integrator::cancel(): before render() has a context, and in the middle of a long render
+    d = tmp_path / "d.pfm"
+    r = subprocess.run([ppg_render, "--cbox", "64x48", "--plugin-core", "--cancel-after-ms", "0", "-o", str(d)] + defs_off, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1 and "(cancelled)" in r.stdout and not d.exists()
+    long_defs = sum([["-D", "%s=%s" % kv] for kv in dict(props, dumpSDTree="false", budget=200000).items()], [])
+    r = subprocess.run([ppg_render, "--cbox", "256x256", "--plugin-core", "--cancel-after-ms", "400", "-o", str(d)] + long_defs, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1 and "(cancelled)" in r.stdout, (r.returncode, r.stdout, r.stderr)
+    assert read_pfm(str(d)).shape == (256, 256, 3)  # whatever the film held when the render stopped
+
+
 @pytest.mark.gpu
 def test_cpp_rccl_reducer_single_rank(ppg_render, tmp_path):
     """`ppg_render --rank 0 --world 1 --nccl-id FILE`: the C++ RCCL reducer with a real communicator (ncclCommInitRank, packed all-reduces
