@@ -92,6 +92,25 @@ def measured_traffic(tag):
     return None, None
 
 
+def scene_file_check(path):
+    """sha256 of a flat scene file against scratch/SHA256SUMS (tracked; tools/make_scenes.sh regenerates the files from the reference
+    checkout and verifies them): the benchmark's workload is an untracked conversion of the reference's scene data, so the line says
+    which bytes it rendered."""
+    import hashlib
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 22), b""):
+            h.update(chunk)
+    digest, expected = h.hexdigest(), None
+    sums = os.path.join(os.path.dirname(path), "SHA256SUMS")
+    if os.path.exists(sums):
+        for line in open(sums):
+            f_ = line.split()
+            if len(f_) == 2 and f_[1] == os.path.basename(path):
+                expected = f_[0]
+    return {"file": os.path.relpath(path, ROOT), "sha256": digest, "matches_SHA256SUMS": (digest == expected) if expected else None}
+
+
 def scene_props(path, base):
     props = dict(base)
     pf = path + ".props"
@@ -136,10 +155,17 @@ def run(args):
         scene_name = "file"
     elif scene_name == "kitchen" and not os.path.exists(KITCHEN_FILE):
         scene_name = "room"
+        if rank == 0:
+            print("bench.py: scratch/kitchen-improved.ppgs is MISSING (tools/make_scenes.sh makes it from the reference checkout): rendering the "
+                  "procedural stand-in `room` instead - this is NOT the BASELINE.json configuration", file=sys.stderr, flush=True)
+    scene_check = None
     traffic_tag = "cbox" if scene_name == "cbox" else "kitchen"
     if scene_name in ("kitchen", "file"):
         path = args.scene_file or KITCHEN_FILE
         scene = ppg_host.load_scene_file(path)
+        scene_check = scene_file_check(path)
+        if scene_check["matches_SHA256SUMS"] is False:
+            raise SystemExit("bench.py: %s does not match scratch/SHA256SUMS (regenerate it with tools/make_scenes.sh)" % path)
         if args.size_override:
             scene.camera = ppg_host.resize_camera(scene.camera, args.width, args.height)  # keeps the horizontal field of view
         if args.constant_env:
@@ -239,7 +265,7 @@ def run(args):
         "metric": "Msamples/s", "value": samples / dt / 1e6, "unit": "Msamples/s", "n_gpus": args.gpus, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": workload,
+        "config": {"workload": workload, "scene_file": scene_check, "headline_scene": scene_name == "kitchen",
                    "iterations": [it["passes"] for it in gpt.iterations], "parallelism": "tiles%d" % args.gpus,
                    "rays_per_sample": rays / max(1, own_samples), "avg_path_length": plen / max(1, own_samples), "variance_last_iteration": var_last},
         "tuning_env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("PPG_")},
@@ -384,14 +410,29 @@ def run(args):
         hit_rmse = min((t for t in trials if t["rmse"] <= target_rmse), key=lambda t: t["seconds"], default=None)
         # the budget that met the MAPE target, again with other seeds: how much of the figure is one seed's luck
         seeds = []
+        all_seeds = None  # the budget at which EVERY seed meets the target, and its slowest render: the figure that does not depend on one seed's luck
         if hit_mape:
-            for sd in (4321, 99, 20260927):
-                if sd == 4321:
-                    seeds.append({"seed": sd, "seconds": hit_mape["seconds"], "mape": hit_mape["mape"], "rmse": hit_mape["rmse"]})
-                    continue
-                img, t = timed_render(make(-(-hit_mape["spp"] // spp), the_scene=small, seed=sd))
-                d = (np.asarray(img, np.float64) - ref)[keep]
-                seeds.append({"seed": sd, "seconds": t, "mape": float((np.abs(d) / (ref[keep] + 0.01)).mean()), "rmse": float(np.sqrt((d * d).mean()))})
+            def seed_runs(n_spp, first=None):
+                runs_ = []
+                for sd in (4321, 99, 20260927):
+                    if first is not None and sd == 4321:
+                        runs_.append({"seed": sd, "seconds": first["seconds"], "mape": first["mape"], "rmse": first["rmse"]})
+                        continue
+                    img, t = timed_render(make(-(-n_spp // spp), the_scene=small, seed=sd))
+                    d = (np.asarray(img, np.float64) - ref)[keep]
+                    runs_.append({"seed": sd, "seconds": t, "mape": float((np.abs(d) / (ref[keep] + 0.01)).mean()), "rmse": float(np.sqrt((d * d).mean()))})
+                return runs_
+            seeds = seed_runs(hit_mape["spp"], hit_mape)
+            n_all, runs_all = hit_mape["spp"], seeds
+            for _ in range(3):
+                worst = max(r_["mape"] for r_ in runs_all)
+                if worst <= target_mape:
+                    break
+                n_all = int(min(6000, max(n_all + 16, n_all * (worst / (0.97 * target_mape)) ** (1.0 / slope))))
+                runs_all = seed_runs(n_all)
+            if max(r_["mape"] for r_ in runs_all) <= target_mape:
+                all_seeds = {"spp": n_all, "seconds_slowest_seed": max(r_["seconds"] for r_ in runs_all), "runs": runs_all,
+                             "speedup_vs_reference_log": REF_KITCHEN_SECONDS / max(r_["seconds"] for r_ in runs_all)}
         out["time_to_rmse"] = {
             "reference_image": "scenes/kitchen/kitchen-reference.exr of the reference (tests/golden/ref_kitchen_reference.npz), 700x400; %.0f %% of the film "
                                "masked: footprint of the 6 meshes missing from the reference checkout" % (100 * (1 - keep.mean())),
@@ -401,7 +442,7 @@ def run(args):
             "seconds_to_rmse": hit_rmse["seconds"] if hit_rmse else None, "spp_to_rmse": hit_rmse["spp"] if hit_rmse else None,
             "speedup_vs_reference_log_mape": (REF_KITCHEN_SECONDS / hit_mape["seconds"]) if hit_mape else None,
             "speedup_vs_reference_log_rmse": (REF_KITCHEN_SECONDS / hit_rmse["seconds"]) if hit_rmse else None,
-            "seeds_at_spp_to_mape": seeds,
+            "seeds_at_spp_to_mape": seeds, "all_seeds_meet_target": all_seeds,
             "seconds_to_mape_min_max": [min(s_["seconds"] for s_ in seeds), max(s_["seconds"] for s_ in seeds)] if seeds else None,
             "mape_min_max": [min(s_["mape"] for s_ in seeds), max(s_["mape"] for s_ in seeds)] if seeds else None,
             "seeds_meeting_target": sum(1 for s_ in seeds if s_["mape"] <= target_mape) if seeds else None,

@@ -909,6 +909,9 @@ int allocPaths(ppg_ctx *ctx) {
     const size_t cap = ((chunks + nb - 1) / nb) * PPG_DCHUNK;
     for (int k = 0; k < 2; ++k) { HIP_CHECK(ctx->d_queue[k].reserve(cap * nb)); HIP_CHECK(ctx->d_qcount[k].reserve(nb)); }
     HIP_CHECK(ctx->d_stats.reserve(nb)); HIP_CHECK(ctx->d_qtotal.reserve(1));
+    // k_scan_counts / k_gather_slices write one offset per persistent workgroup and the live count: these two buffers are otherwise sized by
+    // the SD-tree code (one entry per S-tree leaf — a single one in the first iteration)
+    HIP_CHECK(ctx->d_offsets.reserve(nb)); HIP_CHECK(ctx->d_total.reserve(2));
     HIP_CHECK(ctx->d_bounceCounts.reserve(72)); HIP_CHECK(ctx->d_ticket.reserve(1));
     HIP_CHECK(ctx->d_adamCount.reserve(2));
     if (!ctx->h_round) HIP_CHECK(hipHostMalloc((void **)&ctx->h_round, 68 * sizeof(unsigned int), hipHostMallocDefault));

@@ -239,7 +239,7 @@ def test_spaceship_class_improved_against_oracle(oracle_lib):
     assert_tree_equal(g.read_sdtree(), o.read_sdtree())
 
 
-@pytest.mark.parametrize("which", ["room-720p", "spaceship-class-1080p"])
+@pytest.mark.parametrize("which", ["room-720p", "spaceship-class-1080p", "torus-1080p"])
 def test_full_size_invariants_improved_configs(which):
     """Properties that need no oracle, at the real film sizes of BASELINE configs[2] / configs[3] with the improved preset: run-to-run
     determinism of film and SD-tree (atomics are fixed point, the optimiser's records are applied in key order), sample / ray
@@ -248,6 +248,11 @@ def test_full_size_invariants_improved_configs(which):
     if which == "room-720p":
         scene, spp = ppg_host.room_scene(1280, 720, glossy=True), 1280 * 720
         props = dict(budgetType="spp", budget=31, maxDepth=-1, rrDepth=5, strictNormals=1, seed=5, **IMPROVED)
+    elif which == "torus-1080p":
+        # BASELINE configs[4] at its size and settings (TORUS itself is a download, not bundled: the labelled stand-in of bench.py --scene torus):
+        # 1920x1080, sppPerPass = 1, sTreeThreshold = 4000, unbounded specular-diffuse-specular chains — the persistent-thread tail at 2 M paths
+        scene, spp = ppg_host.torus_scene(1920, 1080), 1920 * 1080
+        props = dict(budgetType="spp", budget=31, sppPerPass=1, sTreeThreshold=4000, maxDepth=-1, rrDepth=5, strictNormals=0, seed=5)
     else:
         scene, spp = spaceship_class_scene(1920, 1080), 1920 * 1080
         props = dict(budgetType="spp", budget=31, maxDepth=10, rrDepth=10, strictNormals=1, seed=5, **IMPROVED)
@@ -270,7 +275,10 @@ def test_full_size_invariants_improved_configs(which):
     u = rng.rand(100000, 2)
     z = 2 * u[:, 0] - 1; phi = 2 * np.pi * u[:, 1]; r = np.sqrt(1 - z * z)
     dirs = np.stack([r * np.cos(phi), r * np.sin(phi), z], -1).astype(np.float32)
-    for p in np.array([[2.0, 0.02, 2.5], [0.02, 1.5, 3.0], [2.0, 1.5, 0.5]], np.float32):
+    lo, hi = np.asarray(scene.positions).min(0), np.asarray(scene.positions).max(0)
+    pts = (np.array([[2.0, 0.02, 2.5], [0.02, 1.5, 3.0], [2.0, 1.5, 0.5]], np.float32) if which != "torus-1080p"
+           else (lo + (hi - lo) * np.array([[0.5, 0.5, 0.5], [0.3, 0.1, 0.6], [0.7, 0.45, 0.2]])).astype(np.float32))
+    for p in pts:
         pdf = e.query_pdf(np.repeat(p[None], len(dirs), 0), dirs)
         assert abs(pdf.mean() * 4 * np.pi - 1) < 0.03
 
