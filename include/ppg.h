@@ -348,6 +348,40 @@ int ppg_render_passes_nostat(ppg_ctx *ctx, int32_t n_passes); /* GP:1217-1286 on
 int ppg_finish_passes(ppg_ctx *ctx, ppg_pass_stats *stats);   /* GP:1288-1328 only */
 
 /* ------------------------------------------------------------------------------------------------
+ * Final iteration: groups of passes.
+ *
+ * In the final iteration nothing is recorded (GP:2150-2154, !m_isFinalIter) and it holds at least half of a render's samples
+ * (GP:1367-1374); the sampler is keyed by (pixel, sample index), so its passes are independent of each other.  A sharded render therefore
+ * deals them to the ranks WHOLE — all pixels — instead of splitting every pass by tiles: the tail of a batch of unbounded paths lasts as
+ * long as its longest path (a guided path survives a bounce with probability 0.99, GP:2124-2139), a term that does not shrink with the
+ * number of ranks when every rank runs every batch, and does when a rank runs every world-th batch.
+ * So that the film is the same on one GPU and on N, bit for bit, the float sums are given one association:
+ *   - the n passes of a ppg_render_passes() call made with the final flag set (budgetType = spp) form groups of
+ *     ppg_final_group_passes(n) = 16 * ceil(n / 1024) consecutive passes (at most 64 groups);
+ *   - a group's samples are summed per pixel in sample order, from zero, into the group's partial (image, squared image, weight);
+ *   - the call's image / squared image / weights and the iteration's film are the partials added in group order.
+ * Sharded: group g is rendered by rank g % world; between ppg_render_passes_nostat() and ppg_finish_passes() the host all-reduces (sum,
+ * float) the n_floats at `dev` — [film 3 n][film weights n][groups x (image 3 n, squared image 3 n, weights n)], n = pixels; every slot is
+ * non-zero on one rank only and the film head (the tile-sharded training passes an `automatic` render adds to the same iteration, GP:1400-1405)
+ * has disjoint supports, so the sums are exact — and calls ppg_final_partials_commit().  Afterwards image and film are complete on every
+ * rank: no ppg_image_buffers / ppg_film_buffers exchange for this iteration.  n_floats = 0: not a sharded final iteration, exchange the
+ * image buffers as usual.
+ * ---------------------------------------------------------------------------------------------- */
+/* budgetType = seconds in a sharded render: every decision the reference takes by its clock (GP:1259-1262 inside performRenderPasses,
+   GP:1434-1514 in renderTime) must come out the same on all ranks, or they would render different numbers of passes and their collectives
+   would stop matching.  The stop hook is asked after every batch of passes with this rank's own decision (elapsed whole seconds > budget) and
+   returns the one all ranks follow — rank 0's, broadcast.  The host loop does the same with the times it measures. */
+typedef int (*ppg_stop_hook)(void *user, int local_stop);
+int ppg_set_stop_hook(ppg_ctx *ctx, ppg_stop_hook hook, void *user);
+/* The HIP stream (hipStream_t) the context's kernels run on.  A reducer that enqueues its collectives on it needs no host synchronisation
+   between an exchange and the library call that consumes its result: the round hook's all-to-all and all-gather are followed, in stream
+   order, by the sort / apply / commit kernels. */
+int ppg_exchange_stream(ppg_ctx *ctx, void **hip_stream);
+int32_t ppg_final_group_passes(int32_t n_passes);
+int ppg_final_partials(ppg_ctx *ctx, void **dev /* float[n_floats] */, uint64_t *n_floats);
+int ppg_final_partials_commit(ppg_ctx *ctx);
+
+/* ------------------------------------------------------------------------------------------------
  * Learning the BSDF sampling fraction (bsdfSamplingFractionLoss = "kl" | "var"; AdamOptimizer GP:69-133,
  * DTreeWrapper::optimizeBsdfSamplingFraction GP:672-697).
  *

@@ -2485,13 +2485,25 @@ public:
     volatile bool cancelled = false;
     ppg_pass_hook passHook = nullptr;
     void *passHookUser = nullptr;
+    ppg_stop_hook stopHook = nullptr;
+    void *stopHookUser = nullptr;
     std::string error;
 
     int W() const { return scene.cam.width; }
     int H() const { return scene.cam.height; }
 
+    // final iteration in groups of passes (include/ppg.h "Final iteration: groups of passes"): where renderOnePass accumulates, whether it
+    // renders the whole film (a rank's own groups of a sharded render), the slots, the state of their exchange
+    Float *m_accImage = nullptr, *m_accSq = nullptr, *m_accW = nullptr;
+    bool m_allPixels = false;
+    std::vector<Float> m_partials;   // [film 3 n][film weights n][groups x (image 3 n, squared image 3 n, weights n)]
+    bool m_partialsPending = false, m_partialsExported = false;
+    unsigned int m_pendingGroups = 0;
+    uint64_t m_samplesLocal = 0;
+    static int finalGroupPasses(int n) { n = std::max(1, n); return 16 * ((n + 1023) / 1024); }
+
     bool ownsPixel(int x, int y) const {
-        if (shardWorld <= 1) return true;
+        if (shardWorld <= 1 || m_allPixels) return true;
         int tilesX = (W() + tileSize - 1) / tileSize;
         int t = (y / tileSize) * tilesX + (x / tileSize);
         return t % shardWorld == shardRank;
@@ -2570,23 +2582,73 @@ public:
         m_passStart = std::chrono::steady_clock::now();
         m_passesLocal = 0;
         m_counters = PathCounters();
+        m_samplesLocal = 0;
+        m_partialsPending = false; m_partialsExported = false;
+        if (m_isFinalIter && m_budgetType != ESeconds && numPasses > 0) { renderFinalGroups(numPasses); return; }
         // ROUND mode: the passes are rendered in rounds of ppg_adam_round_passes() passes; the sampling fractions are frozen during
         // a round and its records are applied afterwards (applyAdamRound).  The time budget is checked once per round then
         // (the reference checks after every finished pass of a batch of up to 128 scheduled ones, GP:1235-1266).
         const bool rounds = m_bsdfSamplingFractionLoss != ENone && modes.adam == PPGO_ADAM_ROUND && m_isBuilt && !m_isFinalIter;
         const int roundPasses = rounds ? adamRoundPasses(numPasses) : 1;
+        // (cancelled with a round hook installed: the remaining rounds are entered empty, so that this rank stays in step with the hooks of
+        // the others until they have all seen its status — the product's rule, ppg_hip.hip renderPassesNoStat)
+        bool drain = false;
+        m_hookFailed = false;
         for (int i = 0; i < numPasses;) {
-            if (cancelled) break;
+            if (cancelled) { if (rounds && passHook) drain = true; else break; }
             const int n = std::min(roundPasses, numPasses - i);
             m_roundStartPass = m_passesRendered;
             for (int k = 0; k < n; ++k) {
+                if (drain) continue;
                 renderOnePass();
                 ++m_passesRendered; ++m_passesRenderedThisIter; ++m_passesLocal;
+                m_samplesLocal += ownedPixels() * (uint64_t)m_sppPerPass;
             }
             i += n;
             if (rounds) applyAdamRound();
-            if (m_budgetType == ESeconds && (int)computeElapsedSeconds(m_startTime) > m_budget) break;  // GP:1259-1262: whole seconds
+            if (m_hookFailed) break;
+            if (m_budgetType == ESeconds) {  // GP:1259-1262: whole seconds; sharded: rank 0's decision for all (include/ppg.h ppg_set_stop_hook)
+                int stop = (int)computeElapsedSeconds(m_startTime) > m_budget ? 1 : 0;
+                if (stopHook) stop = stopHook(stopHookUser, stop);
+                if (stop) break;
+            }
         }
+    }
+
+    uint64_t ownedPixels() const {
+        uint64_t c = 0;
+        for (int y = 0; y < H(); ++y) for (int x = 0; x < W(); ++x) if (ownsPixel(x, y)) ++c;
+        return c;
+    }
+    // image += slot, squared image += slot, weights += slot, film += slot's image, film weights += slot's weights
+    void addGroup(const Float *slot) {
+        const size_t n = (size_t)W() * H();
+        for (size_t i = 0; i < 3 * n; ++i) { m_image[i] += slot[i]; m_squaredImage[i] += slot[3 * n + i]; m_film[i] += slot[i]; }
+        for (size_t i = 0; i < n; ++i) { m_imageW[i] += slot[6 * n + i]; m_filmW[i] += slot[6 * n + i]; }
+    }
+    // The passes of a final iteration: groups of finalGroupPasses(numPasses) passes, each summed from zero, added in group order; rank r of a
+    // sharded render renders groups r, r + world, ... over the whole film and leaves its slots for the exchange.
+    void renderFinalGroups(int numPasses) {
+        const int G = finalGroupPasses(numPasses), nGroups = (numPasses + G - 1) / G;
+        const size_t n = (size_t)W() * H();
+        m_partials.assign(4 * n + (size_t)nGroups * 7 * n, 0.0f);
+        const int firstPass = m_passesRendered;
+        m_allPixels = shardWorld > 1;
+        for (int g = shardRank; g < nGroups && !cancelled; g += shardWorld) {
+            Float *slot = m_partials.data() + 4 * n + (size_t)g * 7 * n;
+            m_accImage = slot; m_accSq = slot + 3 * n; m_accW = slot + 6 * n;
+            const int cnt = std::min(G, numPasses - g * G);
+            for (int k = 0; k < cnt; ++k) {
+                m_passesRendered = firstPass + g * G + k;
+                renderOnePass();
+                m_samplesLocal += n * (uint64_t)m_sppPerPass;
+            }
+            if (shardWorld <= 1) addGroup(slot);
+        }
+        m_accImage = m_accSq = m_accW = nullptr;
+        m_allPixels = false;
+        m_passesRendered = firstPass + numPasses; m_passesRenderedThisIter += numPasses; m_passesLocal += numPasses;
+        if (shardWorld > 1) { m_partialsPending = true; m_pendingGroups = (unsigned int)nGroups; }
     }
 
     // passes per round (include/ppg.h, ppg_adam_round_passes): doubled while it stays within 16 passes, half the call's passes and
@@ -2621,14 +2683,15 @@ public:
         // sharded rendering: the driver replaces the records by the union over all ranks — or, with one owner per D-tree
         // (ppgo_adam_records_by_owner), by the records of the D-trees this rank owns
         hookPhase = 0; ownerMode = false;
-        if (passHook) passHook(passHookUser);
+        if (passHook && passHook(passHookUser) != 0) { m_hookFailed = true; m_adamRecords.clear(); return; }
         std::sort(m_adamRecords.begin(), m_adamRecords.end(), [](const PackedAdamRecord &a, const PackedAdamRecord &b) { return a.key < b.key; });
         const Float ratioPower = m_bsdfSamplingFractionLoss == EKL ? 1.0f : 2.0f;
         for (const PackedAdamRecord &r : m_adamRecords)
             nodes[(size_t)(r.key >> PPG_ADAM_LEAF_SHIFT)].dTree.optimizeBsdfSamplingFraction(r.product, r.woPdf, r.bsdfPdf, r.dTreePdf, r.weight, ratioPower);
         m_adamRecords.clear();
-        if (passHook && ownerMode) { hookPhase = 1; passHook(passHookUser); hookPhase = 0; }  // the owners publish the state they computed
+        if (passHook && ownerMode) { hookPhase = 1; if (passHook(passHookUser) != 0) m_hookFailed = true; hookPhase = 0; }  // the owners publish the state they computed
     }
+    bool m_hookFailed = false;
     int hookPhase = 0;
     bool ownerMode = false;
     std::vector<uint32_t> m_adamState;  // [world * segment][6]
@@ -2662,9 +2725,7 @@ public:
             st->passes_rendered_total = m_passesRendered;
             st->passes_rendered_local = m_passesLocal;
             st->variance = variance;
-            st->samples = 0;
-            for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) if (ownsPixel(x, y)) st->samples += 1;
-            st->samples *= (uint64_t)m_passesLocal * m_sppPerPass;
+            st->samples = m_samplesLocal;
             st->rays = m_counters.rays; st->path_length_sum = m_counters.pathLen; st->vertices_committed = m_counters.committed;
         }
         m_lastVariance = variance;
@@ -2708,6 +2769,11 @@ public:
                         tm.path = (sampleInRound0 + (uint32_t)j) * (uint32_t)(w * h) + pixel;
                         Spectrum spec = Li(o, d, mint, maxt, sampler, pc, tm);  // GP:1632 (sensor weight is 1)
                         // block->put / squaredBlock->put with the box filter: own pixel, weight 1 (SURVEY App. A "Film")
+                        if (m_accImage) {  // a group of a final iteration: its own partial; image and film receive it whole (addGroup)
+                            for (int c = 0; c < 3; ++c) { m_accImage[3 * pixel + c] += spec[c]; m_accSq[3 * pixel + c] += spec[c] * spec[c]; }
+                            m_accW[pixel] += 1.0f;
+                            continue;
+                        }
                         for (int c = 0; c < 3; ++c) {
                             m_image[3 * pixel + c] += spec[c];
                             m_squaredImage[3 * pixel + c] += spec[c] * spec[c];
@@ -3321,7 +3387,12 @@ int ppgo_begin_render(ppgo_ctx *ctx) { NEED_SCENE ctx->gpt.beginRender(); return
 int ppgo_begin_iteration(ppgo_ctx *ctx, int32_t is_final) { NEED_TREE ctx->gpt.beginIteration(is_final != 0); return PPG_OK; }
 int ppgo_set_final(ppgo_ctx *ctx, int32_t is_final) { ctx->gpt.m_isFinalIter = is_final != 0; return PPG_OK; }
 int ppgo_set_do_nee(ppgo_ctx *ctx, int32_t do_nee) { ctx->gpt.m_doNee = do_nee != 0; return PPG_OK; }
-int ppgo_render_passes_nostat(ppgo_ctx *ctx, int32_t n) { NEED_TREE ctx->gpt.renderPassesNoStat(n); return ctx->gpt.cancelled ? PPG_ERR_CANCELLED : PPG_OK; }
+int ppgo_render_passes_nostat(ppgo_ctx *ctx, int32_t n) {
+    NEED_TREE
+    ctx->gpt.renderPassesNoStat(n);
+    if (ctx->gpt.m_hookFailed) { ctx->gpt.error = "round hook failed"; return PPG_ERR_INVALID; }
+    return ctx->gpt.cancelled ? PPG_ERR_CANCELLED : PPG_OK;
+}
 int ppgo_finish_passes(ppgo_ctx *ctx, ppg_pass_stats *st) { NEED_TREE ctx->gpt.finishPasses(st); return PPG_OK; }
 int ppgo_render_passes(ppgo_ctx *ctx, int32_t n, ppg_pass_stats *st) {
     NEED_TREE
@@ -3453,6 +3524,7 @@ int ppgo_stat_import(ppgo_ctx *ctx, const uint64_t *sums, uint64_t n_sums, const
 }
 int ppgo_work_counters(ppgo_ctx *ctx, uint64_t *out8) { memcpy(out8, ctx->gpt.m_work, sizeof ctx->gpt.m_work); return PPG_OK; }
 int ppgo_path_length_histogram(ppgo_ctx *ctx, uint64_t *out) { memcpy(out, ctx->gpt.m_lenHist, sizeof ctx->gpt.m_lenHist); return PPG_OK; }
+int ppgo_set_stop_hook(ppgo_ctx *ctx, ppg_stop_hook hook, void *user) { ctx->gpt.stopHook = hook; ctx->gpt.stopHookUser = user; return PPG_OK; }
 int ppgo_set_pass_hook(ppgo_ctx *ctx, ppg_pass_hook hook, void *user) { ctx->gpt.passHook = hook; ctx->gpt.passHookUser = user; return PPG_OK; }
 int ppgo_adam_records(ppgo_ctx *ctx, void **records, uint64_t *n) {
     *records = ctx->gpt.m_adamRecords.data(); *n = ctx->gpt.m_adamRecords.size();
@@ -3494,6 +3566,32 @@ int ppgo_adam_state_commit(ppgo_ctx *ctx) {
     auto &nodes = g.m_sdTree->nodes();
     if (g.hookPhase != 1 || g.m_adamState.size() < 6 * nodes.size()) { g.error = "ppg_adam_state_commit: call ppg_adam_state first"; return PPG_ERR_STATE; }
     for (size_t i = 0; i < nodes.size(); ++i) nodes[i].dTree.bsdfSamplingFractionOptimizer.importState(&g.m_adamState[6 * i]);
+    return PPG_OK;
+}
+int32_t ppgo_final_group_passes(int32_t n_passes) { return GuidedPathTracer::finalGroupPasses(n_passes); }
+int ppgo_final_partials(ppgo_ctx *ctx, void **data, uint64_t *n_floats) {
+    NEED_TREE
+    auto &g = ctx->gpt;
+    *data = nullptr; *n_floats = 0;
+    if (!g.m_partialsPending) return PPG_OK;
+    const size_t n = (size_t)g.W() * g.H();
+    if (!g.m_partialsExported) {
+        std::copy(g.m_film.begin(), g.m_film.end(), g.m_partials.begin());
+        std::copy(g.m_filmW.begin(), g.m_filmW.end(), g.m_partials.begin() + 3 * n);
+        g.m_partialsExported = true;
+    }
+    *data = g.m_partials.data(); *n_floats = g.m_partials.size();
+    return PPG_OK;
+}
+int ppgo_final_partials_commit(ppgo_ctx *ctx) {
+    NEED_TREE
+    auto &g = ctx->gpt;
+    if (!g.m_partialsPending || !g.m_partialsExported) { g.error = "ppg_final_partials_commit: nothing to commit"; return PPG_ERR_STATE; }
+    const size_t n = (size_t)g.W() * g.H();
+    std::copy(g.m_partials.begin(), g.m_partials.begin() + 3 * n, g.m_film.begin());
+    std::copy(g.m_partials.begin() + 3 * n, g.m_partials.begin() + 4 * n, g.m_filmW.begin());
+    for (unsigned int k = 0; k < g.m_pendingGroups; ++k) g.addGroup(g.m_partials.data() + 4 * n + (size_t)k * 7 * n);
+    g.m_partialsPending = false; g.m_partialsExported = false;
     return PPG_OK;
 }
 int ppgo_film_ptrs(ppgo_ctx *ctx, float **rgb_sum, float **weight) {

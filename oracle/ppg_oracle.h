@@ -42,6 +42,10 @@ int ppgo_build_sdtree(ppgo_ctx *ctx, ppg_tree_stats *stats);
 int ppgo_end_iteration(ppgo_ctx *ctx);
 int ppgo_end_render(ppgo_ctx *ctx);
 int ppgo_cancel(ppgo_ctx *ctx);
+int ppgo_set_stop_hook(ppgo_ctx *ctx, ppg_stop_hook hook, void *user);
+int32_t ppgo_final_group_passes(int32_t n_passes);  /* include/ppg.h "Final iteration: groups of passes" */
+int ppgo_final_partials(ppgo_ctx *ctx, void **data, uint64_t *n_floats);
+int ppgo_final_partials_commit(ppgo_ctx *ctx);
 int ppgo_read_film(ppgo_ctx *ctx, float *rgb);
 int ppgo_read_variance(ppgo_ctx *ctx, float *rgb);
 int ppgo_dump_sdtree(ppgo_ctx *ctx, const char *path);

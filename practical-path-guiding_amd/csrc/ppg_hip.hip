@@ -506,6 +506,16 @@ struct ppg_ctx {
     int maxBatch = 1;
     DevBuf<unsigned int> d_pixels;
     unsigned int nPix = 0;
+    // final iteration of a sharded render: whole groups of passes over ALL pixels instead of all passes over this rank's tiles
+    // (include/ppg.h "Final iteration: groups of passes")
+    DevBuf<unsigned int> d_pixelsAll;
+    unsigned int nPixAll = 0;
+    DevBuf<float> d_partials;         // group slots (7 floats per pixel each); sharded: preceded by a film head (4 floats per pixel)
+    unsigned int partialSlots = 0;    // slots the buffer holds
+    bool partialsPending = false;     // sharded: this rank's slots wait for the exchange (ppg_final_partials / ppg_final_partials_commit)
+    bool partialsExported = false;
+    unsigned int pendingGroups = 0;
+    uint64_t samplesLocal = 0;        // samples this rank rendered in the current performRenderPasses
 
     // path state
     DevBuf<float4> d_ray_o, d_ray_d, d_thr, d_li, d_hit, d_vd, d_vthr, d_vbsdf, d_vrad, d_vo, d_vvox;
@@ -605,6 +615,8 @@ struct ppg_ctx {
     uint64_t bvhNodesVisited = 0, bvhTrisTested = 0;  // by k_trace while kernel timing is on (the roofline's node / triangle counts)
     ppg_pass_hook passHook = nullptr;
     void *passHookUser = nullptr;
+    ppg_stop_hook stopHook = nullptr;
+    void *stopHookUser = nullptr;
 #ifdef PPG_PROBE
     DevBuf<unsigned long long> d_probe;  // development builds: cycle sums of the lone path's bounce (ppg_kernels.h PROBE_MARK), printed by endRender
 #endif
@@ -854,6 +866,13 @@ int allocPaths(ppg_ctx *ctx) {
     ctx->nPix = (unsigned int)pix.size();
     HIP_CHECK(ctx->d_pixels.reserve(std::max<size_t>(1, pix.size())));
     if (!pix.empty()) HIP_CHECK(hipMemcpy(ctx->d_pixels.p, pix.data(), pix.size() * 4, hipMemcpyHostToDevice));
+    ctx->nPixAll = (unsigned int)((size_t)ctx->W * ctx->H);
+    if (ctx->shardWorld > 1) {  // the final iteration's groups are rendered over the whole film
+        std::vector<unsigned int> all(ctx->nPixAll);
+        for (unsigned int k = 0; k < ctx->nPixAll; ++k) all[k] = k;
+        HIP_CHECK(ctx->d_pixelsAll.reserve(std::max<size_t>(1, all.size())));
+        if (!all.empty()) HIP_CHECK(hipMemcpy(ctx->d_pixelsAll.p, all.data(), all.size() * 4, hipMemcpyHostToDevice));
+    }
     // Pass batching: the passes of an iteration are independent (frozen sampling tree, accumulate-only building
     // tree), so up to maxBatch of them run as ONE set of launches over nPix * spp * batch paths.  Sample indices,
     // per-pixel accumulation order and all integer statistics are unchanged, i.e. results are bit-identical; what
@@ -879,7 +898,7 @@ int allocPaths(ppg_ctx *ctx) {
     }
     {   // the final iteration records nothing: its batches need path state only (96 B per path), so they can be larger — the serial tail of
         // unbounded paths is then paid once per 64 passes
-        const size_t perPass = std::max<size_t>(1, (size_t)ctx->nPix * ctx->sppPerPass);
+        const size_t perPass = std::max<size_t>(1, (size_t)(ctx->shardWorld > 1 ? ctx->nPixAll : ctx->nPix) * ctx->sppPerPass);
         // PPG_FINAL_BATCH=256 (2^28 paths): KITCHEN 700x400 at 2400 spp 5.2 -> 4.9 s, 720p at 511 passes 169 -> 175 Msamples/s — but the 23 GB of
         // path state it sizes cost the FIRST process on a freshly booted GPU box 20 % of a 20-pass render (86 vs 110 Msamples/s; the second
         // process is at par), so the default stays at 64 passes.
@@ -888,7 +907,7 @@ int allocPaths(ppg_ctx *ctx) {
         if (ctx->tuneBatchPaths) ctx->maxBatchFinal = ctx->maxBatch;
     }
     size_t n = (size_t)ctx->nPix * ctx->sppPerPass * (size_t)ctx->maxBatch;
-    const size_t nFinal = (size_t)ctx->nPix * ctx->sppPerPass * (size_t)ctx->maxBatchFinal;
+    const size_t nFinal = (size_t)(ctx->shardWorld > 1 ? ctx->nPixAll : ctx->nPix) * ctx->sppPerPass * (size_t)ctx->maxBatchFinal;
     if (n > 0xfffffff0ull || nFinal > 0xfffffff0ull) { ctx->error = "too many paths per pass"; return PPG_ERR_INVALID; }
     const size_t nTrain = std::max<size_t>(1, n);  // vertex slots: training batches only
     size_t nn = std::max<size_t>(1, std::max(n, nFinal));
@@ -1023,9 +1042,15 @@ int applyAdamRound(ppg_ctx *ctx, size_t nRecords) {
 
 // `batch` BlockedRenderProcesses (GP:1087-1106 / renderBlock GP:1587-1641) over all owned pixels in one set of launches.
 // adamRound: this batch is one round of the sampling-fraction optimiser.
-int renderBatch(ppg_ctx *ctx, int batch, bool adamRound) {
+// A launch of whole groups of a final iteration's passes (include/ppg.h "Final iteration: groups of passes"): `batch` passes = groups of
+// groupPasses passes (the last one may be shorter; or a part of ONE group when groupPasses >= batch), the first starting at pass
+// firstPass of the render, consecutive groups of the launch stridePasses apart; group k accumulates into slot slot0 + k * slotStride.
+struct GroupLaunch { unsigned int firstPass, groupPasses, stridePasses, slot0, slotStride; };
+
+int renderBatch(ppg_ctx *ctx, int batch, bool adamRound, const GroupLaunch *gl = nullptr) {
     PathState P = ctx->paths;
-    P.n_paths = (unsigned int)((size_t)ctx->nPix * ctx->sppPerPass * (size_t)batch);
+    if (gl && ctx->shardWorld > 1) { P.n_pix = ctx->nPixAll; P.pixels = ctx->d_pixelsAll.p; }  // the whole film, not this rank's tiles
+    P.n_paths = (unsigned int)((size_t)P.n_pix * ctx->sppPerPass * (size_t)batch);
     if (P.n_paths == 0 && !(adamRound && ctx->passHook)) return PPG_OK;
     hipStream_t s = ctx->stream;
     // Adam records: positions are known in advance unless one vertex can make several records (box spatial filter) or records are made
@@ -1042,6 +1067,11 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound) {
     RenderParams R = ctx->params();
     R.spp = ctx->sppPerPass * batch;  // sample j of the batch has sample index pass_index * sppPerPass + j, j < spp * batch
     R.pass_index_spp = (unsigned int)ctx->passesRendered * (unsigned int)ctx->sppPerPass;
+    if (gl) {
+        R.pass_index_spp = gl->firstPass * (unsigned int)ctx->sppPerPass;
+        R.group_samples = gl->groupPasses * (unsigned int)ctx->sppPerPass;
+        R.group_stride = gl->stridePasses * (unsigned int)ctx->sppPerPass;
+    }
     Queues Q = ctx->queues;
     const int grid = ctx->nBlocks;
     const int gridAll = gridFor(P.n_paths);
@@ -1259,11 +1289,74 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound) {
     }
     if (P.n_paths > 0)
     timedLaunch(ctx, "k_film", P.n_pix, [&] {
-        hipLaunchKernelGGL(k_film, dim3((P.n_pix + 255) / 256), dim3(256), 0, s, P, ctx->sppPerPass * batch, ctx->d_image.p, ctx->d_sq.p, ctx->d_imageW.p,
+        if (gl) hipLaunchKernelGGL(k_film_groups, dim3((P.n_pix + 255) / 256), dim3(256), 0, s, P, ctx->sppPerPass * batch, gl->groupPasses * (unsigned int)ctx->sppPerPass,
+                                   ctx->d_partials.p + (ctx->shardWorld > 1 ? 4 * (size_t)ctx->nPixAll : 0), gl->slot0, gl->slotStride, ctx->nPixAll);
+        else hipLaunchKernelGGL(k_film, dim3((P.n_pix + 255) / 256), dim3(256), 0, s, P, ctx->sppPerPass * batch, ctx->d_image.p, ctx->d_sq.p, ctx->d_imageW.p,
                            ctx->d_film.p, ctx->d_filmW.p);
     });
     HIP_CHECK(hipGetLastError());
     return PPG_OK;
+}
+
+// The passes of a FINAL iteration (spp budget), include/ppg.h "Final iteration: groups of passes": groups of ppg_final_group_passes(numPasses)
+// passes, each summed on its own (k_film_groups) and added to image / film in group order (k_add_groups).  One GPU renders them all, several
+// groups per launch; rank r of a sharded render renders groups r, r + world, ... over the WHOLE film — nothing is recorded in a final
+// iteration (GP:2150-2154) and the sampler is keyed by (pixel, sample index), so the groups are independent, and a rank then pays 1 / world of
+// the iteration's tails instead of all of them on its tiles — and leaves its slots for the exchange (ppg_final_partials).
+int addGroups(ppg_ctx *ctx, unsigned int first, unsigned int count) {
+    const unsigned int n = ctx->nPixAll;
+    hipLaunchKernelGGL(k_add_groups, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, ctx->d_partials.p + (ctx->shardWorld > 1 ? 4 * (size_t)n : 0), first, count,
+                       ctx->d_image.p, ctx->d_sq.p, ctx->d_imageW.p, ctx->d_film.p, ctx->d_filmW.p);
+    return PPG_OK;
+}
+int renderFinalGroups(ppg_ctx *ctx, int numPasses) {
+    const unsigned int G = (unsigned int)ppg_final_group_passes(numPasses), nGroups = ((unsigned int)numPasses + G - 1) / G;
+    const unsigned int world = (unsigned int)ctx->shardWorld, rank = (unsigned int)ctx->shardRank;
+    const size_t n = ctx->nPixAll;
+    const unsigned int perLaunch = std::max(1u, (unsigned int)ctx->maxBatchFinal / G);  // whole groups per launch (G <= maxBatchFinal), else parts of one group
+    const unsigned int slots = world > 1 ? nGroups : perLaunch;
+    const size_t floats = (world > 1 ? 4 * n : 0) + (size_t)slots * 7 * n;
+    if (ctx->d_partials.cap < floats || ctx->partialSlots != slots) {
+        HIP_CHECK(ctx->d_partials.reserve(floats));
+        ctx->partialSlots = slots;
+    }
+    HIP_CHECK(hipMemsetAsync(ctx->d_partials.p, 0, floats * 4, ctx->stream));
+    const unsigned int firstPassAbs = (unsigned int)ctx->passesRendered;
+    std::vector<unsigned int> mine;
+    for (unsigned int g = rank; g < nGroups; g += world) mine.push_back(g);
+    auto passesOf = [&](unsigned int g) { return std::min(G, (unsigned int)numPasses - g * G); };
+    bool stop = false;
+    for (size_t m = 0; m < mine.size() && !stop;) {
+        if (ctx->cancelled.load()) break;
+        if (G <= (unsigned int)ctx->maxBatchFinal) {
+            const size_t cnt = std::min<size_t>(perLaunch, mine.size() - m);
+            unsigned int batch = 0;
+            for (size_t q = 0; q < cnt; ++q) batch += passesOf(mine[m + q]);
+            GroupLaunch gl{firstPassAbs + mine[m] * G, G, world * G, world > 1 ? mine[m] : 0u, world > 1 ? world : 1u};
+            int rc = renderBatch(ctx, (int)batch, false, &gl);
+            if (rc) return rc;
+            ctx->samplesLocal += (uint64_t)n * batch * ctx->sppPerPass;
+            if (world == 1) addGroups(ctx, 0, (unsigned int)cnt);
+            m += cnt;
+        } else {  // a group larger than a launch: its parts accumulate into the same slot one after the other
+            const unsigned int g = mine[m], total = passesOf(g);
+            for (unsigned int done = 0; done < total;) {
+                if (ctx->cancelled.load()) { stop = true; break; }
+                const unsigned int batch = std::min((unsigned int)ctx->maxBatchFinal, total - done);
+                GroupLaunch gl{firstPassAbs + g * G + done, batch, batch, world > 1 ? g : 0u, 1u};
+                int rc = renderBatch(ctx, (int)batch, false, &gl);
+                if (rc) return rc;
+                ctx->samplesLocal += (uint64_t)n * batch * ctx->sppPerPass;
+                done += batch;
+            }
+            if (world == 1 && !stop) addGroups(ctx, 0, 1);
+            ++m;
+        }
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));  // bound the launch queue; lets ppg_cancel() take effect
+    }
+    ctx->passesRendered += numPasses; ctx->passesRenderedThisIter += numPasses; ctx->passesLocal += numPasses;
+    if (world > 1) { ctx->partialsPending = true; ctx->pendingGroups = nGroups; }
+    return ctx->cancelled.load() ? PPG_ERR_CANCELLED : PPG_OK;
 }
 
 int renderPassesNoStat(ppg_ctx *ctx, int numPasses) {  // GP:1217-1286
@@ -1280,16 +1373,26 @@ int renderPassesNoStat(ppg_ctx *ctx, int numPasses) {  // GP:1217-1286
     // rounds of the sampling-fraction optimiser (include/ppg.h): fractions frozen during a round, its records applied afterwards
     const bool rounds = ctx->loss != LOSS_NONE && ctx->isBuilt && !ctx->isFinalIter;
     const int roundPasses = rounds ? (int)ppg_adam_round_passes(ctx->sppPerPass, ctx->W, ctx->H, numPasses) : (ctx->isFinalIter ? ctx->maxBatchFinal : ctx->maxBatch);
+    ctx->samplesLocal = 0;
+    ctx->partialsPending = false; ctx->partialsExported = false;
+    if (ctx->isFinalIter && ctx->budgetType == 0 && numPasses > 0) return renderFinalGroups(ctx, numPasses);
+    // Cancelled while a round hook is installed (a sharded render with a learned sampling fraction): the other ranks enter the hook of
+    // EVERY remaining round of this call, so this rank keeps entering it too — with empty rounds (no paths, no records; the host marks its
+    // status word) — instead of leaving for an exchange the others are not in.  They all see the status and abort together.
+    bool drain = false;
     for (int i = 0; i < numPasses;) {
-        if (ctx->cancelled.load()) break;
+        if (ctx->cancelled.load()) { if (rounds && ctx->passHook) drain = true; else break; }
         const int batch = std::min(roundPasses, numPasses - i);
-        int rc = renderBatch(ctx, batch, rounds);
+        int rc = renderBatch(ctx, drain ? 0 : batch, rounds);
         if (rc) return rc;
         ctx->passesRendered += batch; ctx->passesRenderedThisIter += batch; ctx->passesLocal += batch;
+        ctx->samplesLocal += (uint64_t)ctx->nPix * batch * ctx->sppPerPass;
         i += batch;
         if (ctx->budgetType == 1) {  // seconds: the reference checks after every finished pass (GP:1259-1262)
             HIP_CHECK(hipStreamSynchronize(ctx->stream));
-            if ((int)elapsedSeconds(ctx->startTime) > ctx->budget) break;  // `progress = (int) elapsed; shouldAbort = progress > m_budget`
+            int stop = (int)elapsedSeconds(ctx->startTime) > ctx->budget ? 1 : 0;  // `progress = (int) elapsed; shouldAbort = progress > m_budget`
+            if (ctx->stopHook) stop = ctx->stopHook(ctx->stopHookUser, stop);           // sharded: the decision of rank 0 for all
+            if (stop) break;
         } else if ((i & 63) < batch) {
             HIP_CHECK(hipStreamSynchronize(ctx->stream));  // bound the launch queue; also lets ppg_cancel() take effect
         }
@@ -1298,6 +1401,7 @@ int renderPassesNoStat(ppg_ctx *ctx, int numPasses) {  // GP:1217-1286
 }
 
 int finishPasses(ppg_ctx *ctx, ppg_pass_stats *st) {  // GP:1288-1328
+    if (ctx->partialsPending) { ctx->error = "the groups of this final iteration were not exchanged: ppg_final_partials / ppg_final_partials_commit before ppg_finish_passes"; return PPG_ERR_STATE; }
     const int n = ctx->W * ctx->H;
     const int N = ctx->passesLocal * ctx->sppPerPass;
     if (ctx->sampleCombination == 2) {  // inversevar: m_images.push_back(image->clone())
@@ -1333,7 +1437,7 @@ int finishPasses(ppg_ctx *ctx, ppg_pass_stats *st) {  // GP:1288-1328
     ppg_pass_stats s{};
     s.seconds = elapsedSeconds(ctx->passStart);
     s.passes_rendered_total = ctx->passesRendered; s.passes_rendered_local = ctx->passesLocal; s.variance = variance;
-    s.samples = (uint64_t)ctx->nPix * ctx->passesLocal * ctx->sppPerPass;
+    s.samples = ctx->samplesLocal;
     s.rays = c.rays; s.path_length_sum = c.path_len; s.vertices_committed = c.committed;
     ctx->lastStats = s;
     if (st) *st = s;
@@ -2227,6 +2331,37 @@ int ppg_image_buffers(ppg_ctx *ctx, void **dev_image, void **dev_sq_image, void 
     return PPG_OK;
 }
 
+int ppg_set_stop_hook(ppg_ctx *ctx, ppg_stop_hook hook, void *user) { ctx->stopHook = hook; ctx->stopHookUser = user; return PPG_OK; }
+int ppg_exchange_stream(ppg_ctx *ctx, void **hip_stream) { *hip_stream = (void *)ctx->stream; return PPG_OK; }
+int32_t ppg_final_group_passes(int32_t n_passes) {
+    const int32_t n = std::max(1, n_passes);
+    return 16 * ((n + 1023) / 1024);
+}
+int ppg_final_partials(ppg_ctx *ctx, void **dev, uint64_t *n_floats) {
+    NEED_TREE
+    *dev = nullptr; *n_floats = 0;
+    if (!ctx->partialsPending) return PPG_OK;  // not a sharded final iteration: image / squared image / weights are exchanged as usual
+    const size_t n = ctx->nPixAll;
+    if (!ctx->partialsExported) {  // the film of this iteration so far (tile-sharded training passes of an `automatic` render) travels in the head
+        HIP_CHECK(hipMemcpyAsync(ctx->d_partials.p, ctx->d_film.p, 3 * n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        HIP_CHECK(hipMemcpyAsync(ctx->d_partials.p + 3 * n, ctx->d_filmW.p, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        ctx->partialsExported = true;
+    }
+    *dev = ctx->d_partials.p; *n_floats = 4 * n + (uint64_t)ctx->pendingGroups * 7 * n;
+    return PPG_OK;
+}
+int ppg_final_partials_commit(ppg_ctx *ctx) {
+    NEED_TREE
+    if (!ctx->partialsPending || !ctx->partialsExported) { ctx->error = "ppg_final_partials_commit: nothing to commit"; return PPG_ERR_STATE; }
+    const size_t n = ctx->nPixAll;
+    HIP_CHECK(hipMemcpyAsync(ctx->d_film.p, ctx->d_partials.p, 3 * n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_CHECK(hipMemcpyAsync(ctx->d_filmW.p, ctx->d_partials.p + 3 * n, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    addGroups(ctx, 0, ctx->pendingGroups);
+    HIP_CHECK(hipGetLastError());
+    ctx->partialsPending = false; ctx->partialsExported = false;
+    return PPG_OK;
+}
 int ppg_set_pass_hook(ppg_ctx *ctx, ppg_pass_hook hook, void *user) { ctx->passHook = hook; ctx->passHookUser = user; return PPG_OK; }
 int ppg_adam_records(ppg_ctx *ctx, void **dev_records, uint64_t *n) {
     NEED_TREE

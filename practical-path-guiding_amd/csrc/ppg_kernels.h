@@ -69,6 +69,10 @@ struct RenderParams {
     unsigned long long seed;
     unsigned int pass_index;  // m_passesRendered at the start of this pass
     unsigned int pass_index_spp;  // sample index of the batch's first sample = pass_index * sppPerPass
+    // Final iteration (nothing is recorded; include/ppg.h "Final iteration: groups of passes"): the launch holds whole GROUPS of passes, group k
+    // of the launch = samples [k * group_samples, (k + 1) * group_samples) of a pixel, whose sample indices start at
+    // pass_index_spp + k * group_stride (a rank of a sharded render holds every world-th group: stride = world * group_samples).  0: one run.
+    unsigned int group_samples, group_stride;
     int max_vertices;         // vertex slots allocated per path
     unsigned int img_pixels;  // width * height of the whole image (path ids of the Adam records)
 #ifdef PPG_PROBE
@@ -308,7 +312,8 @@ __global__ __launch_bounds__(PPG_BLOCK) void k_generate(PathState P, DevScene S,
     for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < P.n_paths; i += gridDim.x * blockDim.x) {
         unsigned int k = i % P.n_pix, j = i / P.n_pix;
         unsigned int pixel = P.pixels[k];
-        unsigned int key = ppg_path_key(R.seed, pixel, R.pass_index_spp + j);
+        const unsigned int sample = R.group_samples ? R.pass_index_spp + (j / R.group_samples) * R.group_stride + (j % R.group_samples) : R.pass_index_spp + j;
+        unsigned int key = ppg_path_key(R.seed, pixel, sample);
         unsigned int dim = 0;
         float u1 = ppg_rand(key, dim++);
         float u2 = ppg_rand(key, dim++);
@@ -1768,6 +1773,52 @@ static __global__ void k_film(PathState P, int spp, float *image, float *sq_imag
     sq_image[3 * pixel] = sr; sq_image[3 * pixel + 1] = sg; sq_image[3 * pixel + 2] = sb;
     film[3 * pixel] = fr; film[3 * pixel + 1] = fg; film[3 * pixel + 2] = fb;
     image_w[pixel] = iw; film_w[pixel] = fw;
+}
+
+// The same for the passes of a FINAL iteration (include/ppg.h "Final iteration: groups of passes"): the samples of a pixel are summed per GROUP
+// of passes, in sample order and from whatever the group's partial holds (zero, or an earlier launch's part of the same group), into the
+// group's slot of `partials` — one slot = image (3 n), squared image (3 n), weights (n), n = pixels of the whole film.  k_add_groups then adds
+// the slots to image / squared image / weights / film in group order.  On one GPU that is the same sum as k_film's up to the association of
+// the float additions; it is what lets the groups of a sharded render be rendered whole by different ranks and still add up to the same bits.
+static __global__ void k_film_groups(PathState P, int spp, unsigned int group_samples, float *partials, unsigned int slot0, unsigned int slot_stride, unsigned int n_img) {
+    unsigned int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= P.n_pix) return;
+    const unsigned int pixel = P.pixels[k];
+    for (int j0 = 0; j0 < spp; j0 += (int)group_samples) {
+        float *slot = partials + (size_t)(slot0 + (unsigned int)(j0 / (int)group_samples) * slot_stride) * 7u * n_img;
+        float *im = slot + 3 * (size_t)pixel, *sq = slot + 3 * (size_t)n_img + 3 * (size_t)pixel, *w = slot + 6 * (size_t)n_img + pixel;
+        float ir = im[0], ig = im[1], ib = im[2], sr = sq[0], sg = sq[1], sb = sq[2], iw = *w;
+        const int j1 = j0 + (int)group_samples < spp ? j0 + (int)group_samples : spp;
+        for (int j = j0; j < j1; ++j) {
+            const float4 l = P.li[(size_t)j * P.n_pix + k];
+            ir += l.x; ig += l.y; ib += l.z;
+            sr += l.x * l.x; sg += l.y * l.y; sb += l.z * l.z;
+            iw += 1.0f;
+        }
+        im[0] = ir; im[1] = ig; im[2] = ib; sq[0] = sr; sq[1] = sg; sq[2] = sb; *w = iw;
+    }
+}
+// image += slot, squared image += slot, weights += slot, film += slot (image part), film weights += slot, for slots first .. first + count - 1
+// in this order; the slots are zeroed.
+static __global__ void k_add_groups(unsigned int n_img, float *partials, unsigned int first, unsigned int count, float *image, float *sq_image, float *image_w,
+                                    float *film, float *film_w) {
+    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_img) return;
+    float im[3] = {image[3 * i], image[3 * i + 1], image[3 * i + 2]}, sq[3] = {sq_image[3 * i], sq_image[3 * i + 1], sq_image[3 * i + 2]};
+    float fi[3] = {film[3 * i], film[3 * i + 1], film[3 * i + 2]}, iw = image_w[i], fw = film_w[i];
+    for (unsigned int g = first; g < first + count; ++g) {
+        float *slot = partials + (size_t)g * 7u * n_img;
+        for (int c = 0; c < 3; ++c) {
+            const float a = slot[3 * (size_t)i + c], b = slot[3 * (size_t)n_img + 3 * (size_t)i + c];
+            im[c] += a; sq[c] += b; fi[c] += a;
+            slot[3 * (size_t)i + c] = 0.0f; slot[3 * (size_t)n_img + 3 * (size_t)i + c] = 0.0f;
+        }
+        const float w = slot[6 * (size_t)n_img + i];
+        iw += w; fw += w;
+        slot[6 * (size_t)n_img + i] = 0.0f;
+    }
+    for (int c = 0; c < 3; ++c) { image[3 * i + c] = im[c]; sq_image[3 * i + c] = sq[c]; film[3 * i + c] = fi[c]; }
+    image_w[i] = iw; film_w[i] = fw;
 }
 
 // per-pixel variance estimate of performRenderPasses (GP:1300-1311); the clamped luminance goes to `lum`, stored x-major

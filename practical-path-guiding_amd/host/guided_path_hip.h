@@ -14,6 +14,7 @@
 #define GUIDED_PATH_HIP_H
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdarg>
 #include <cmath>
@@ -92,6 +93,10 @@ public:
     virtual void reduceSDTree(ppg_ctx *ctx) = 0;                          // before buildSDTree (GP:1115)
     virtual void reduceAdamRecords(ppg_ctx *ctx) = 0;                     // round hook of the sampling-fraction optimiser (include/ppg.h)
     virtual void reduceFilm(ppg_ctx *ctx, int width, int height) = 0;     // before the film is read (not with inverse-variance combination)
+    // a final iteration's groups of passes (include/ppg.h "Final iteration: groups of passes"): all-reduce the n floats at dev, then ppg_final_partials_commit
+    virtual void reduceFinalPartials(ppg_ctx *ctx, void *dev, uint64_t nFloats) = 0;
+    virtual double broadcast(double value) = 0;                            // rank 0's value on every rank (clock readings / stop decisions of a time budget)
+    virtual void beginRender() {}                                         // a new render() starts: forget the status of the previous one
     virtual void setLocalStatus(int status) { (void)status; }             // != 0: this rank was cancelled / failed — announced to the others in the next exchange
     virtual int rank() const = 0;
     virtual int world() const = 0;
@@ -129,24 +134,27 @@ public:
     GuidedPathTracerHIP(const GuidedPathTracerHIP &) = delete;
     GuidedPathTracerHIP &operator=(const GuidedPathTracerHIP &) = delete;
 
-    void cancel() { ppg_cancel(m_ctx); }  // GP:1643-1648
+    void cancel() { m_cancelled.store(true); ppg_cancel(m_ctx); }  // GP:1643-1648
 
     // render(): GP:1516-1585.  Returns false when cancelled, throws on errors.  With a reducer the image is sharded by 32x32 tiles over
     // reducer->world() ranks (every rank calls render() on the same scene) and the film is complete on every rank afterwards.
     bool render(const SceneData &scene, const Log &log = Log(), Reducer *reducer = nullptr) {
         m_reducer = reducer;
+        m_cancelled.store(false);
+        m_filmComplete = false;
+        if (reducer) reducer->beginRender();
         const bool spp = std::string(m_cfg.budgetType) == "spp";
-        if (reducer && !spp)  // every control decision of renderTime (GP:1434-1514) reads a rank-local clock: the ranks' collectives would stop matching
-            throw std::runtime_error("sharded rendering needs budgetType = spp (a time budget is decided by rank-local clocks)");
         ppg_scene sv = scene.view();
         check(ppg_set_scene(m_ctx, &sv), "ppg_set_scene");
         if (reducer) check(ppg_set_shard(m_ctx, reducer->rank(), reducer->world(), 32), "ppg_set_shard");
         m_w = scene.camera.width; m_h = scene.camera.height;
         check(ppg_begin_render(m_ctx), "ppg_begin_render");
         if (reducer && std::string(m_cfg.bsdfSamplingFractionLoss) != "none") check(ppg_set_pass_hook(m_ctx, &GuidedPathTracerHIP::roundHook, this), "ppg_set_pass_hook");
+        // a time budget, sharded: every decision taken by a clock (GP:1259-1262, 1434-1514) is rank 0's, so that all ranks render the same passes
+        check(ppg_set_stop_hook(m_ctx, (reducer && !spp) ? &GuidedPathTracerHIP::stopHook : nullptr, this), "ppg_set_stop_hook");
         say(log, fmt("Starting render job (%ix%i, MI355X%s) ..", m_w, m_h, reducer ? fmt(", rank %d of %d", reducer->rank(), reducer->world()).c_str() : ""));
         bool ok = spp ? renderSPP(log) : renderTime(log);
-        if (ok && reducer && std::string(m_cfg.sampleCombination) != "inversevar") reducer->reduceFilm(m_ctx, m_w, m_h);
+        if (ok && reducer && !m_filmComplete && std::string(m_cfg.sampleCombination) != "inversevar") reducer->reduceFilm(m_ctx, m_w, m_h);
         if (ok) check(ppg_end_render(m_ctx), "ppg_end_render");
         return ok;
     }
@@ -171,7 +179,7 @@ private:
     }
 
     // performRenderPasses, GP:1210-1329
-    bool passes(int n, ppg_pass_stats &st, const Log &log) {
+    bool passes(int n, ppg_pass_stats &st, const Log &log, bool finalGroups = false) {
         say(log, fmt("Rendering %d render passes.", n));
         int rc;
         if (!m_reducer) {
@@ -181,8 +189,21 @@ private:
             rc = ppg_render_passes_nostat(m_ctx, n);
             // cancelled or failed here: the other ranks must not wait for this one in their next collective — tell them in it
             if (rc != PPG_OK || m_hookError) m_reducer->setLocalStatus(1);
-            try { m_reducer->reduceImages(m_ctx, m_w, m_h); } catch (...) { if (!m_hookError) m_hookError = std::current_exception(); }
-            if (rc == PPG_ERR_CANCELLED) { m_hookError = nullptr; return false; }  // (the exchange above told the others; they leave with an error)
+            try {
+                // Which exchange follows is decided by what EVERY rank knows — final flag, budget type, pass count — never by this rank's
+                // own outcome: a cancelled or failed rank still joins the collective the others are in (with its status word set).
+                if (finalGroups && m_reducer->world() > 1) {
+                    // a final iteration rendered in whole groups of passes by rank: their partial images instead of the tiles' image buffers
+                    const uint64_t px = (uint64_t)m_w * m_h, G = (uint64_t)ppg_final_group_passes(n);
+                    const uint64_t expect = 4 * px + (((uint64_t)n + G - 1) / G) * 7 * px;
+                    void *dev = nullptr;
+                    uint64_t nFloats = 0;
+                    if (ppg_final_partials(m_ctx, &dev, &nFloats) != PPG_OK || nFloats != expect) { m_reducer->setLocalStatus(1); dev = nullptr; }
+                    m_reducer->reduceFinalPartials(m_ctx, dev, expect);
+                    m_filmComplete = true;
+                } else m_reducer->reduceImages(m_ctx, m_w, m_h);
+            } catch (...) { if (!m_hookError) m_hookError = std::current_exception(); }
+            if (rc == PPG_ERR_CANCELLED || m_cancelled.load()) { m_hookError = nullptr; return false; }  // (the exchanges told the others; they leave with an error)
             check(rc, "ppg_render_passes_nostat");
             rethrowHookError();
             check(ppg_finish_passes(m_ctx, &st), "ppg_finish_passes");
@@ -192,8 +213,8 @@ private:
         m_passesRendered = st.passes_rendered_total;
         return rc == PPG_OK;
     }
-    void build(const Log &log, bool final = false) {  // buildSDTree, GP:1115-1189
-        if (m_reducer && !final) m_reducer->reduceSDTree(m_ctx);  // (the final iteration records nothing)
+    void build(const Log &log, bool nothingRecorded = false) {  // buildSDTree, GP:1115-1189
+        if (m_reducer && !nothingRecorded) m_reducer->reduceSDTree(m_ctx);  // (an iteration that was final from its first pass records nothing)
         say(log, "Building distributions for sampling.");
         ppg_tree_stats t;
         check(ppg_build_sdtree(m_ctx, &t), "ppg_build_sdtree");
@@ -224,9 +245,11 @@ private:
             say(log, fmt("ITERATION %d, %d passes", iter, passesThisIteration));
             say(log, "Resetting distributions for sampling.");
             bool isFinal = passesThisIteration >= remainingPasses;
+            const bool recorded = !isFinal;  // training passes of this iteration go into the building tree — also when FINAL passes follow them (GP:1400-1411)
             check(ppg_begin_iteration(m_ctx, isFinal), "ppg_begin_iteration");
+            m_filmComplete = false;
             ppg_pass_stats st;
-            if (!passes(passesThisIteration, st, log)) return false;
+            if (!passes(passesThisIteration, st, log, isFinal)) return false;
             const float lastVarAtEnd = currentVarAtEnd;
             currentVarAtEnd = passesThisIteration * st.variance / remainingPasses;
             say(log, fmt("Extrapolated var:\n  Last:    %f\n  Current: %f\n", lastVarAtEnd, currentVarAtEnd));
@@ -235,9 +258,9 @@ private:
                 say(log, fmt("FINAL %d passes", remainingPasses));
                 ppg_set_final(m_ctx, 1);
                 isFinal = true;
-                if (!passes(remainingPasses, st, log)) return false;
+                if (!passes(remainingPasses, st, log, true)) return false;
             }
-            build(log, isFinal);
+            build(log, !recorded);
             check(ppg_end_iteration(m_ctx), "ppg_end_iteration");
             ++iter;
         }
@@ -250,7 +273,8 @@ private:
         const bool automatic = std::string(m_cfg.sampleCombination) == "automatic";
         const auto start = std::chrono::steady_clock::now();
         auto elapsed = [&](std::chrono::steady_clock::time_point t0) {
-            return (float)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() / 1000;
+            const float local = (float)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() / 1000;
+            return m_reducer ? (float)m_reducer->broadcast(local) : local;  // sharded: rank 0's clock
         };
         float elapsedSeconds = 0;
         int iter = 0;
@@ -285,13 +309,22 @@ private:
         return true;
     }
 
+    static int stopHook(void *self, int localStop) {
+        GuidedPathTracerHIP *g = static_cast<GuidedPathTracerHIP *>(self);
+        try { return g->m_reducer->broadcast((double)localStop) != 0 ? 1 : 0; } catch (...) { if (!g->m_hookError) g->m_hookError = std::current_exception(); return 1; }
+    }
     static int roundHook(void *self) {  // C callback: no exception may cross the C-ABI
         GuidedPathTracerHIP *g = static_cast<GuidedPathTracerHIP *>(self);
-        try { g->m_reducer->reduceAdamRecords(g->m_ctx); return 0; } catch (...) { g->m_hookError = std::current_exception(); return 1; }
+        // (a cancelled rank stays in step with the others' round hooks — the library keeps calling this one with empty rounds — and says so
+        // in the exchange: every rank then sees the status and they abort together, none left waiting in a collective)
+        if (g->m_cancelled.load()) g->m_reducer->setLocalStatus(1);
+        try { g->m_reducer->reduceAdamRecords(g->m_ctx); return 0; } catch (...) { if (!g->m_hookError) g->m_hookError = std::current_exception(); return 1; }
     }
     void rethrowHookError() { if (m_hookError) { std::exception_ptr e = m_hookError; m_hookError = nullptr; std::rethrow_exception(e); } }
 
     Reducer *m_reducer = nullptr;
+    std::atomic<bool> m_cancelled{false};
+    bool m_filmComplete = false;  // the exchange of a final iteration's groups left the complete film on every rank
     std::exception_ptr m_hookError;
     ppg_config m_cfg;
     ppg_ctx *m_ctx = nullptr;

@@ -103,8 +103,25 @@ public:
         Piece p[2] = {{rgb, 3 * n * 4}, {w, n * 4}};
         allReduce(p, 2, ncclFloat);
     }
+    void reduceFinalPartials(ppg_ctx *ctx, void *dev, uint64_t nFloats) override {
+        // film head + every group's partial image: each slot is non-zero on one rank, the float sums are exact (include/ppg.h)
+        // (dev == nullptr: this rank has nothing to give — it failed or was cancelled — but joins the collective, zeros and its status word)
+        Piece p[1] = {{dev, (size_t)nFloats * 4}};
+        allReduce(p, 1, ncclFloat);
+        check(ctx, ppg_final_partials_commit(ctx), "ppg_final_partials_commit");
+    }
     // a rank that was cancelled or failed announces it in the next exchange (status word, see the header comment)
     void setLocalStatus(int status) override { m_status = status; }
+    void beginRender() override { m_status = 0; }
+    double broadcast(double value) override {
+        if (!m_counts) hip(hipMalloc(&m_counts, (size_t)m_world * ((size_t)m_world + 1) * 8), "hipMalloc");
+        hip(hipMemcpyAsync(m_counts, &value, 8, hipMemcpyHostToDevice, m_stream), "hipMemcpyAsync");
+        nccl(ncclBroadcast(m_counts, m_counts, 1, ncclDouble, 0, m_comm, m_stream), "ncclBroadcast");
+        hip(hipMemcpyAsync(&value, m_counts, 8, hipMemcpyDeviceToHost, m_stream), "hipMemcpyAsync");
+        hip(hipStreamSynchronize(m_stream), "hipStreamSynchronize");
+        ++m_collectives;
+        return value;
+    }
 
     // round hook of the sampling-fraction optimiser, called twice per round (include/ppg.h "Sharded optimiser")
     void reduceAdamRecords(ppg_ctx *ctx) override {
@@ -113,44 +130,56 @@ public:
         const size_t rec = sizeof(ppg_adam_record), W = (size_t)m_world;
         if (phase == 0) {
             // who gets how many of my records: one all-gather of a (world + 1)-vector per rank — counts per owner + my status
-            void *recs;
+            // (the exchanges of the hook run on the CONTEXT's stream: what the library enqueues next — sort, apply, commit — follows them
+            // in stream order, no host synchronisation in between except where the host needs the counts)
+            void *cs = nullptr;
+            check(ctx, ppg_exchange_stream(ctx, &cs), "ppg_exchange_stream");
+            hipStream_t st = (hipStream_t)cs;
+            void *recs = nullptr;
             std::vector<uint64_t> send(W, 0);
-            check(ctx, ppg_adam_records_by_owner(ctx, m_world, &recs, send.data()), "ppg_adam_records_by_owner");
+            // a rank that cannot take part (cancelled, or its records cannot be produced) still joins the count exchange — with zero records
+            // and its status word set —, so that all ranks see the same sum and leave the round together
+            std::string localError;
+            if (m_status == 0 && ppg_adam_records_by_owner(ctx, m_world, &recs, send.data()) != PPG_OK) {
+                localError = std::string("ppg_adam_records_by_owner: ") + ppg_last_error(ctx);
+                m_status = 1;
+            }
+            if (m_status) std::fill(send.begin(), send.end(), 0);
             const size_t row = W + 1;
             if (!m_counts) hip(hipMalloc(&m_counts, W * row * 8), "hipMalloc");
             std::vector<unsigned long long> mine(row, 0ull), all(W * row, 0ull);
             for (size_t r = 0; r < W; ++r) mine[r] = send[r];
             mine[W] = (unsigned long long)m_status;
             unsigned long long *dc = (unsigned long long *)m_counts;
-            hip(hipMemcpyAsync(dc + (size_t)m_rank * row, mine.data(), row * 8, hipMemcpyHostToDevice, m_stream), "hipMemcpyAsync");
-            nccl(ncclAllGather(dc + (size_t)m_rank * row, dc, row, ncclUint64, m_comm, m_stream), "ncclAllGather(counts)");
-            hip(hipMemcpyAsync(all.data(), dc, W * row * 8, hipMemcpyDeviceToHost, m_stream), "hipMemcpyAsync");
-            hip(hipStreamSynchronize(m_stream), "hipStreamSynchronize");
+            hip(hipMemcpyAsync(dc + (size_t)m_rank * row, mine.data(), row * 8, hipMemcpyHostToDevice, st), "hipMemcpyAsync");
+            nccl(ncclAllGather(dc + (size_t)m_rank * row, dc, row, ncclUint64, m_comm, st), "ncclAllGather(counts)");
+            hip(hipMemcpyAsync(all.data(), dc, W * row * 8, hipMemcpyDeviceToHost, st), "hipMemcpyAsync");
+            hip(hipStreamSynchronize(st), "hipStreamSynchronize");  // (the host sizes the messages by the counts)
             ++m_collectives;
             unsigned long long bad = 0, total = 0;
             std::vector<unsigned long long> recv(W, 0ull);
             for (size_t r = 0; r < W; ++r) { bad += all[r * row + W]; recv[r] = all[r * row + (size_t)m_rank]; total += recv[r]; }
-            if (bad) throw std::runtime_error("render aborted: a rank reported a failure or a cancellation");
+            if (bad) throw std::runtime_error(localError.empty() ? std::string("render aborted: a rank reported a failure or a cancellation") : localError);
             // all-to-all-v: grouped point-to-point, one message per pair of ranks that has records for each other
             reserve(std::max<size_t>((size_t)total * rec, 64));
             nccl(ncclGroupStart(), "ncclGroupStart");
             size_t soff = 0, roff = 0;
             for (size_t r = 0; r < W; ++r) {
-                if (send[r]) nccl(ncclSend((const char *)recs + soff, (size_t)send[r] * rec, ncclChar, (int)r, m_comm, m_stream), "ncclSend");
-                if (recv[r]) nccl(ncclRecv((char *)m_stage + roff, (size_t)recv[r] * rec, ncclChar, (int)r, m_comm, m_stream), "ncclRecv");
+                if (send[r]) nccl(ncclSend((const char *)recs + soff, (size_t)send[r] * rec, ncclChar, (int)r, m_comm, st), "ncclSend");
+                if (recv[r]) nccl(ncclRecv((char *)m_stage + roff, (size_t)recv[r] * rec, ncclChar, (int)r, m_comm, st), "ncclRecv");
                 soff += (size_t)send[r] * rec; roff += (size_t)recv[r] * rec;
             }
             nccl(ncclGroupEnd(), "ncclGroupEnd");
-            hip(hipStreamSynchronize(m_stream), "hipStreamSynchronize");
             ++m_collectives; m_bytes += (size_t)total * rec;
             check(ctx, ppg_adam_records_replace(ctx, m_stage, total), "ppg_adam_records_replace");
         } else {
             void *state;
             uint64_t seg = 0;
             check(ctx, ppg_adam_state(ctx, m_world, &state, &seg), "ppg_adam_state");
+            void *cs = nullptr;
+            check(ctx, ppg_exchange_stream(ctx, &cs), "ppg_exchange_stream");
             const size_t bytes = (size_t)seg * 24;
-            if (bytes) nccl(ncclAllGather((const char *)state + (size_t)m_rank * bytes, state, bytes, ncclChar, m_comm, m_stream), "ncclAllGather(state)");
-            hip(hipStreamSynchronize(m_stream), "hipStreamSynchronize");
+            if (bytes) nccl(ncclAllGather((const char *)state + (size_t)m_rank * bytes, state, bytes, ncclChar, m_comm, (hipStream_t)cs), "ncclAllGather(state)");
             ++m_collectives; m_bytes += bytes * W;
             check(ctx, ppg_adam_state_commit(ctx), "ppg_adam_state_commit");
         }
@@ -160,6 +189,7 @@ private:
     struct Piece { void *dev; size_t bytes; };
     void reserve(size_t bytes) {
         if (bytes <= m_stageBytes) return;
+        (void)hipDeviceSynchronize();  // (work enqueued on the context's stream may still read the old block)
         if (m_stage) (void)hipFree(m_stage);
         m_stageBytes = bytes + bytes / 4;
         hip(hipMalloc(&m_stage, m_stageBytes), "hipMalloc");
@@ -171,14 +201,18 @@ private:
         const size_t elem = type == ncclFloat ? 4 : 8;
         reserve(total + elem);  // + the status word (summed like the data: > 0 means some rank gave up)
         size_t off = 0;
-        for (int i = 0; i < count; ++i) { if (p[i].bytes) hip(hipMemcpyAsync((char *)m_stage + off, p[i].dev, p[i].bytes, hipMemcpyDeviceToDevice, m_stream), "hipMemcpyAsync"); off += p[i].bytes; }
+        for (int i = 0; i < count; ++i) {
+            if (p[i].bytes && p[i].dev) hip(hipMemcpyAsync((char *)m_stage + off, p[i].dev, p[i].bytes, hipMemcpyDeviceToDevice, m_stream), "hipMemcpyAsync");
+            else if (p[i].bytes) hip(hipMemsetAsync((char *)m_stage + off, 0, p[i].bytes, m_stream), "hipMemsetAsync");
+            off += p[i].bytes;
+        }
         const float sf = (float)m_status; const long long si = (long long)m_status;
         hip(hipMemcpyAsync((char *)m_stage + total, type == ncclFloat ? (const void *)&sf : (const void *)&si, elem, hipMemcpyHostToDevice, m_stream), "hipMemcpyAsync");
         nccl(ncclAllReduce(m_stage, m_stage, total / elem + 1, type, ncclSum, m_comm, m_stream), "ncclAllReduce");
         float rf = 0; long long ri = 0;
         hip(hipMemcpyAsync(type == ncclFloat ? (void *)&rf : (void *)&ri, (char *)m_stage + total, elem, hipMemcpyDeviceToHost, m_stream), "hipMemcpyAsync");
         off = 0;
-        for (int i = 0; i < count; ++i) { if (p[i].bytes) hip(hipMemcpyAsync(p[i].dev, (char *)m_stage + off, p[i].bytes, hipMemcpyDeviceToDevice, m_stream), "hipMemcpyAsync"); off += p[i].bytes; }
+        for (int i = 0; i < count; ++i) { if (p[i].bytes && p[i].dev) hip(hipMemcpyAsync(p[i].dev, (char *)m_stage + off, p[i].bytes, hipMemcpyDeviceToDevice, m_stream), "hipMemcpyAsync"); off += p[i].bytes; }
         hip(hipStreamSynchronize(m_stream), "hipStreamSynchronize");
         ++m_collectives; m_bytes += total;
         if (rf != 0 || ri != 0) throw std::runtime_error("render aborted: a rank reported a failure or a cancellation");

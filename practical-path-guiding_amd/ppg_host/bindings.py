@@ -447,6 +447,17 @@ class Engine:
         self.image_buffers()
         return self._image_w
 
+    def final_partials(self):
+        """Between render_passes_nostat() and finish_passes() of a sharded FINAL iteration (include/ppg.h "Final iteration: groups of passes"):
+        (pointer, float count) of the buffer to all-reduce — device memory for the HIP engine, host memory for the oracle —, (None, 0) when
+        this call's passes were not rendered in whole groups by rank."""
+        ptr, n = C.c_void_p(), C.c_uint64()
+        self._call("final_partials", C.byref(ptr), C.byref(n))
+        return ptr.value, n.value
+
+    def final_partials_commit(self):
+        self._call("final_partials_commit")
+
     def adam_records(self):
         """Inside the round hook: (pointer, count) of this rank's 32-byte ppg_adam_record array (device memory for the HIP engine,
         host memory for the oracle)."""
@@ -496,6 +507,20 @@ class Engine:
                 return 1
         self._hook_keep = HOOK(tramp) if fn is not None else HOOK(0)
         self._call("set_pass_hook", self._hook_keep, None)
+
+    def set_stop_hook(self, fn):
+        """fn(local_stop) -> stop: asked after every batch of passes of a budgetType = seconds render (include/ppg.h ppg_set_stop_hook)."""
+        HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)
+
+        def tramp(_user, local):
+            try:
+                return int(fn(int(local)))
+            except Exception:  # pragma: no cover
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._stop_keep = HOOK(tramp) if fn is not None else HOOK(0)
+        self._call("set_stop_hook", self._stop_keep, None)
 
     def enable_kernel_timing(self, on=True):
         self._call("enable_kernel_timing", C.c_int32(int(on)))

@@ -32,10 +32,42 @@ def _view(torch, ptr, n, typestr, device):
     return torch.as_tensor(_DevArray(ptr, n, typestr), device=device)
 
 
-class TorchReducer:
+class RenderAborted(RuntimeError):
+    """Some rank reported a failure or a cancellation in the status word of an exchange: every rank leaves the render at the same point."""
+
+
+class _Status:
+    """Every exchange BEGINS with the sum of the ranks' status words (one tiny all-reduce): a rank that was cancelled or failed sets
+    `status = 1` and still enters the exchange the others are in; all ranks then see a non-zero sum, raise RenderAborted before any
+    data moves, and none is left waiting in a collective (the protocol of host/rccl_reducer.h, where the word rides inside the data)."""
+    status = 0
+
+    def begin_render(self):
+        self.status = 0
+
+    def _check(self):
+        if self._status_sum() != 0:
+            raise RenderAborted("render aborted: a rank reported a failure or a cancellation")
+
+    def broadcast(self, value):
+        """rank 0's `value` (a float) on every rank: the clock readings and stop decisions of a sharded budgetType = seconds render"""
+        t = self.torch.tensor([float(value)], dtype=self.torch.float64, **self._tensor_kw())
+        self.dist.broadcast(t, src=0)
+        return float(t.item())
+
+
+class TorchReducer(_Status):
     def __init__(self, dist, device, gather_all=False):
         import torch
         self.torch, self.dist, self.device, self.gather_all = torch, dist, device, gather_all
+
+    def _tensor_kw(self):
+        return dict(device=self.device)
+
+    def _status_sum(self):
+        t = self.torch.tensor([self.status], dtype=self.torch.int32, device=self.device)
+        self.dist.all_reduce(t)
+        return int(t.item())
 
     def _all_reduce_fused(self, views):
         """ONE collective per exchange: the arrays are separate allocations of the context, so they are packed into a staging tensor,
@@ -54,15 +86,26 @@ class TorchReducer:
         self.torch.cuda.synchronize()
 
     def reduce_sdtree(self, e):
+        self._check()
         (ps, ns), (pw, nw) = e.stat_buffers()
         self._all_reduce_fused([_view(self.torch, ptr, n, "<i8", self.device) for ptr, n in ((ps, ns), (pw, nw)) if n])
 
     def reduce_images(self, e):
+        self._check()
         n = e.width * e.height
         a, b = e.image_buffers()
         w = e.image_weight_buffer()
         self._all_reduce_fused([_view(self.torch, a, 3 * n, "<f4", self.device), _view(self.torch, b, 3 * n, "<f4", self.device),
                                 _view(self.torch, w, n, "<f4", self.device)])
+
+    def reduce_final_partials(self, e, ptr, count):
+        """A final iteration's groups of passes (include/ppg.h "Final iteration: groups of passes"): every rank rendered every world-th group
+        over the whole film; ONE all-reduce of the film head + all group slots (each non-zero on one rank: exact), then the library adds
+        the slots in group order."""
+        self._check()
+        self.dist.all_reduce(_view(self.torch, ptr, count, "<f4", self.device))
+        self.torch.cuda.synchronize()
+        e.final_partials_commit()
 
     def reduce_adam(self, e):
         """Round hook of the sampling-fraction optimiser (called twice per round, include/ppg.h "Sharded optimiser").
@@ -72,6 +115,7 @@ class TorchReducer:
         place.  Same records in the same key order at the owner ⇒ the fractions stay bit-identical to a single-GPU render."""
         torch, dist = self.torch, self.dist
         world = dist.get_world_size()
+        self._check()
         if self.gather_all:
             return self._reduce_adam_gather_all(e)
         if e.hook_phase() == 0:
@@ -118,17 +162,26 @@ class TorchReducer:
     def reduce_film(self, e, inverse_variance=False):
         if inverse_variance:
             return  # the retained iteration images were already reduced by reduce_images
+        self._check()
         n = e.width * e.height
         a, w = e.film_buffers()
         self._all_reduce_fused([_view(self.torch, a, 3 * n, "<f4", self.device), _view(self.torch, w, n, "<f4", self.device)])
 
 
-class HostReducer:
+class HostReducer(_Status):
     """Same exchange for an oracle engine (host memory, gloo)."""
 
     def __init__(self, dist, gather_all=False):
         import torch
         self.torch, self.dist, self.gather_all = torch, dist, gather_all
+
+    def _tensor_kw(self):
+        return {}
+
+    def _status_sum(self):
+        t = self.torch.tensor([self.status], dtype=self.torch.int32)
+        self.dist.all_reduce(t)
+        return int(t.item())
 
     def _allreduce_np(self, arr):
         t = self.torch.from_numpy(arr)
@@ -136,6 +189,7 @@ class HostReducer:
         return arr
 
     def reduce_sdtree(self, e):
+        self._check()
         ns, nw = C.c_uint64(), C.c_uint64()
         e._call("stat_sizes", C.byref(ns), C.byref(nw))
         sums = np.zeros(ns.value, np.int64)
@@ -152,6 +206,7 @@ class HostReducer:
         return [np.ctypeslib.as_array(p, shape=(s,)) for p, s in zip((a, b), sizes)]
 
     def reduce_images(self, e):
+        self._check()
         n = e.width * e.height
         img, sq = self._ptr_arrays(e, "image_ptrs", (3 * n, 3 * n))
         self._allreduce_np(img)
@@ -160,10 +215,17 @@ class HostReducer:
         e._call("image_weight_ptr", C.byref(w))
         self._allreduce_np(np.ctypeslib.as_array(w, shape=(n,)))
 
+    def reduce_final_partials(self, e, ptr, count):
+        self._check()
+        arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), shape=(count,))
+        self._allreduce_np(arr)
+        e.final_partials_commit()
+
     def reduce_adam(self, e):
         """The same two-phase exchange as TorchReducer.reduce_adam, on host arrays."""
         torch, dist = self.torch, self.dist
         world, rank = dist.get_world_size(), dist.get_rank()
+        self._check()
         if self.gather_all:
             return self._reduce_adam_gather_all(e)
         if e.hook_phase() == 0:
@@ -208,6 +270,7 @@ class HostReducer:
     def reduce_film(self, e, inverse_variance=False):
         if inverse_variance:
             return
+        self._check()
         n = e.width * e.height
         film, w = self._ptr_arrays(e, "film_ptrs", (3 * n, n))
         self._allreduce_np(film)

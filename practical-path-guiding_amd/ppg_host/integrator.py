@@ -25,14 +25,37 @@ class GuidedPathTracer:
         e = self.engine
         if self.reducer is None:
             return e.render_passes(n)
-        e.render_passes_nostat(n)
-        self.reducer.reduce_images(e)
+        # A rank that is cancelled or fails here still enters the exchange the others are in — with its status word set (distributed._Status):
+        # every exchange begins with the sum of the status words, so all ranks leave at the same point.
+        failure = None
+        try:
+            e.render_passes_nostat(n)
+            ptr, count = e.final_partials() if self._final else (None, 0)
+        except Exception as ex:  # PPGError: cancelled, round hook failed, ...
+            failure, ptr, count = ex, None, 0
+            self.reducer.status = 1
+        try:
+            if count:  # a final iteration: whole groups of passes were dealt to the ranks; their partial images add up in group order
+                self.reducer.reduce_final_partials(e, ptr, count)
+                self._film_complete = True
+            else:
+                self.reducer.reduce_images(e)
+        except Exception:
+            if failure is None:
+                raise
+        if failure is not None:
+            raise failure
         return e.finish_passes()
 
     def _build(self):
-        if self.reducer is not None and not self._final:
+        if self.reducer is not None and self._recorded:  # (an iteration that was final from its first pass recorded nothing)
             self.reducer.reduce_sdtree(self.engine)
         return self.engine.build_sdtree()
+
+    def cancel(self):
+        """Integrator::cancel (GP:1643-1648), from any thread.  Sharded: the other ranks learn of it in the next exchange and leave too."""
+        self._cancelled = True
+        self.engine.cancel()
 
     def _do_nee(self, spp):
         nee = self.props["nee"]
@@ -43,13 +66,22 @@ class GuidedPathTracer:
         if scene is not None:
             e.set_scene(scene)
         e.begin_render()
+        # Sharded with a time budget: every control decision of renderTime() (guided_path.cpp:1434-1514) and the per-pass abort inside
+        # performRenderPasses (GP:1259-1262) reads a clock — rank 0's, broadcast, so that all ranks render the same passes and iterations
+        clock = (lambda v: self.reducer.broadcast(v)) if self.reducer is not None else (lambda v: v)
         if self.reducer is not None and p["budgetType"] != "spp":
-            # every control decision of renderTime() (guided_path.cpp:1434-1514) reads a rank-local clock: ranks would render
-            # different numbers of passes and iterations and their collectives would no longer match
-            raise ValueError("sharded rendering needs budgetType='spp' (a time budget is decided by rank-local clocks)")
+            e.set_stop_hook(lambda local: int(self.reducer.broadcast(local)))
+        self._cancelled = False
+        if self.reducer is not None:
+            self.reducer.begin_render()
         if self.reducer is not None and p["bsdfSamplingFractionLoss"] != "none":
-            e.set_pass_hook(lambda: self.reducer.reduce_adam(e))  # per round: records to the owners of their D-trees, the owners' state back to all
+            def round_hook():  # per round: records to the owners of their D-trees, the owners' state back to all
+                if self._cancelled:  # (the library keeps a cancelled rank in step with the others' round hooks, with empty rounds)
+                    self.reducer.status = 1
+                self.reducer.reduce_adam(e)
+            e.set_pass_hook(round_hook)
         self.iterations = []
+        self._film_complete = False  # the last iteration's film was completed by the exchange of a final iteration's groups
         spp = p["sppPerPass"]
         automatic = p["sampleCombination"] == "automatic"
         it, passes_rendered = 0, 0
@@ -65,6 +97,8 @@ class GuidedPathTracer:
                 if remaining - this_iter < 2 * this_iter:
                     this_iter = remaining
                 self._final = this_iter >= remaining
+                self._recorded = not self._final  # training passes of this iteration went into the building tree (also when FINAL passes follow, GP:1400-1411)
+                self._film_complete = False
                 e.begin_iteration(self._final)
                 st = self._passes(this_iter)
                 rec = dict(iter=it, passes=this_iter, stats=[st.as_dict()])
@@ -95,11 +129,12 @@ class GuidedPathTracer:
                 this_iter = 1 << it
                 t_iter = time.monotonic()
                 self._final = False
+                self._recorded = True
                 e.begin_iteration(False)
                 st = self._passes(this_iter)
                 rec = dict(iter=it, passes=this_iter, stats=[st.as_dict()])
                 passes_rendered += st.passes_rendered_local
-                seconds_iter = time.monotonic() - t_iter
+                seconds_iter = clock(time.monotonic() - t_iter)
                 last_var_at_end = current_var_at_end
                 current_var_at_end = seconds_iter * st.variance / remaining_time
                 remaining_time -= seconds_iter
@@ -110,7 +145,7 @@ class GuidedPathTracer:
                         st = self._passes(this_iter)
                         rec["stats"].append(st.as_dict())
                         passes_rendered += st.passes_rendered_local
-                        elapsed = time.monotonic() - t_start
+                        elapsed = clock(time.monotonic() - t_start)
                         if elapsed >= n_seconds:
                             break
                 rec["tree"] = self._build().as_dict()
@@ -119,8 +154,8 @@ class GuidedPathTracer:
                 if self.log:
                     self.log(rec)
                 it += 1
-                elapsed = time.monotonic() - t_start
-        if self.reducer is not None:
+                elapsed = clock(time.monotonic() - t_start)
+        if self.reducer is not None and not self._film_complete:
             self.reducer.reduce_film(e, inverse_variance=(p["sampleCombination"] == "inversevar"))
         e.end_render()
         return e.read_film()

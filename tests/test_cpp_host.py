@@ -183,10 +183,13 @@ def test_cpp_rccl_reducer_single_rank(ppg_render, tmp_path):
         n = int(re.search(r"RCCL: (\d+) collectives", r.stdout).group(1))
         assert n >= 2 * len(re.findall(r"ITERATION", r.stdout))
         assert np.array_equal(read_pfm(a), read_pfm(b))
-    # wall-clock budgets cannot be sharded (ranks would disagree on the number of passes): refused, not deadlocked
-    r = subprocess.run([ppg_render, "-q", "-o", a, "--rank", "0", "--world", "1", "--nccl-id", str(tmp_path / "id2"), "-D", "budgetType=seconds",
+    # a wall-clock budget, sharded: every decision taken by a clock is rank 0's, broadcast (ppg_set_stop_hook, Reducer::broadcast) — the render
+    # runs its iterations 1, 2, 4, ... until the second is up and ends normally
+    r = subprocess.run([ppg_render, "-o", a, "--rank", "0", "--world", "1", "--nccl-id", str(tmp_path / "id2"), "-D", "budgetType=seconds",
                         "-D", "budget=1", path], capture_output=True, text=True, timeout=300)
-    assert r.returncode != 0 and "spp" in r.stderr
+    assert r.returncode == 0, r.stderr
+    its = [int(m) for m in re.findall(r"ITERATION \d+, (\d+) passes", r.stdout)]
+    assert len(its) >= 3 and its == [1 << k for k in range(len(its))] and np.isfinite(read_pfm(a)).all()
 
 
 @pytest.mark.gpu

@@ -353,9 +353,12 @@ def test_sharded_contexts_on_one_gpu_equal_unsharded():
     from ppg_host.distributed import _view
     dev = torch.device("cuda", 0)
     scene = ppg_host.cbox_scene(96, 64)
-    props = dict(CBOX_PROPS, budget=60, seed=31)
+    props = dict(CBOX_PROPS, budget=111, sppPerPass=1, seed=31)  # iterations 1, 2, 4, 8, 16 and a final one of 80 passes = five groups of 16
     ref = hip(**props)
-    ref_img = ppg_host.GuidedPathTracer(engine=ref).render(scene)
+    ref_gpt = ppg_host.GuidedPathTracer(engine=ref)
+    ref_img = ref_gpt.render(scene)
+    schedule = [it["passes"] for it in ref_gpt.iterations]
+    assert schedule == [1, 2, 4, 8, 16, 80]
 
     class PairReducer:  # all-reduce over the two local contexts
         def __init__(self, engines):
@@ -382,30 +385,38 @@ def test_sharded_contexts_on_one_gpu_equal_unsharded():
                 self._sum(sel, [_view(torch, e.image_buffers()[sel], 3 * n, "<f4", dev) for e in self.engines])
             self._sum(2, [_view(torch, e.image_weight_buffer(), n, "<f4", dev) for e in self.engines])
 
-        def reduce_film(self):
-            n = 96 * 64
-            self._sum(0, [_view(torch, e.film_buffers()[0], 3 * n, "<f4", dev) for e in self.engines])
-            self._sum(1, [_view(torch, e.film_buffers()[1], n, "<f4", dev) for e in self.engines])
+        def reduce_final_partials(self):
+            # the final iteration: every context rendered every second GROUP of passes over the whole film (include/ppg.h "Final iteration:
+            # groups of passes"); the slots are summed — each is non-zero in one context only — and added in group order by the library
+            bufs = [e.final_partials() for e in self.engines]
+            assert bufs[0][1] == bufs[1][1] == 4 * 96 * 64 + 5 * 7 * 96 * 64
+            self._sum(0, [_view(torch, b[0], b[1], "<f4", dev) for b in bufs])
+            for e in self.engines:
+                e.final_partials_commit()
 
     engines = [hip(**props) for _ in range(2)]
     for r, e in enumerate(engines):
         e.set_scene(scene); e.set_shard(r, 2, 16); e.begin_render()
     red = PairReducer(engines)
-    for it, p in enumerate([1, 2, 4, 8]):
-        final = it == 3
+    for it, p in enumerate(schedule):
+        final = it == len(schedule) - 1
         for e in engines:
             e.begin_iteration(final)
         for e in engines:
             e.render_passes_nostat(p)
-        red.reduce_images()
+        if final:
+            red.reduce_final_partials()
+        else:
+            red.reduce_images()
         stats = [e.finish_passes() for e in engines]
         assert stats[0].variance == stats[1].variance
-        if not final:
+        if final:  # groups 0, 2 and 4 (48 passes) in context 0, groups 1 and 3 in context 1, all pixels each
+            assert [st.samples for st in stats] == [96 * 64 * 48, 96 * 64 * 32]
+        else:
             red.reduce_sdtree()
         for e in engines:
             e.build_sdtree(); e.end_iteration()
-    red.reduce_film()
-    for e in engines:
+    for e in engines:  # (the exchange of the final iteration's groups left the complete film in both contexts: no film exchange)
         e.end_render()
         assert np.array_equal(e.read_film(), ref_img)
         assert_tree_equal(e.read_sdtree(), ref.read_sdtree())
@@ -572,9 +583,15 @@ def test_sharded_contexts_with_learned_fraction_equal_unsharded(scheme):
         for e in engines:
             e.begin_iteration(final)
         both(lambda r: engines[r].render_passes_nostat(p))
-        for sel in (0, 1):
-            sum_views([_view(torch, e.image_buffers()[sel], 3 * n, "<f4", dev) for e in engines])
-        sum_views([_view(torch, e.image_weight_buffer(), n, "<f4", dev) for e in engines])
+        if final:  # one group of 16 passes, rendered by context 0 over the whole film (include/ppg.h "Final iteration: groups of passes")
+            bufs = [e.final_partials() for e in engines]
+            sum_views([_view(torch, b[0], b[1], "<f4", dev) for b in bufs])
+            for e in engines:
+                e.final_partials_commit()
+        else:
+            for sel in (0, 1):
+                sum_views([_view(torch, e.image_buffers()[sel], 3 * n, "<f4", dev) for e in engines])
+            sum_views([_view(torch, e.image_weight_buffer(), n, "<f4", dev) for e in engines])
         stats = [e.finish_passes() for e in engines]
         assert stats[0].variance == stats[1].variance or (np.isnan(stats[0].variance) and np.isnan(stats[1].variance))
         if not final:

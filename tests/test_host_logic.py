@@ -110,14 +110,21 @@ if sys.argv[4] == "improved":
     props.update(sampleCombination="inversevar", bsdfSamplingFractionLoss="kl", spatialFilter="stochastic", directionalFilter="box", sTreeThreshold=2000, sppPerPass=1)
 if sys.argv[4] in ("nee", "full-scene"):
     props.update(nee="kickstart", bsdfSamplingFractionLoss="var", spatialFilter="box", sTreeThreshold=2000)
+if sys.argv[4] == "auto-final":
+    props.update(budget=2044, seed=2, sampleCombination="automatic")
 e = ppg_host.Engine(lib, "ppgo_", **props)
 lib.ppgo_set_modes(e.ctx, 0, 0, 2)
-scene = ppg_host.cbox_scene(64, 48)
+scene = ppg_host.cbox_scene(24, 16) if sys.argv[4] == "auto-final" else ppg_host.cbox_scene(64, 48)
 if sys.argv[4] == "full-scene":
     from test_gpu_parity import _sphere_scene
     scene = _sphere_scene((64, 48), sky=True)
-e.set_scene(scene); e.set_shard(rank, world, 16)
-img = ppg_host.GuidedPathTracer(engine=e, reducer=HostReducer(dist, gather_all=(sys.argv[5] == "gather"))).render()
+e.set_scene(scene); e.set_shard(rank, world, 8 if sys.argv[4] == "auto-final" else 16)
+gpt = ppg_host.GuidedPathTracer(engine=e, reducer=HostReducer(dist, gather_all=(sys.argv[5] == "gather")))
+img = gpt.render()
+if sys.argv[4] == "auto-final":
+    assert gpt.iterations[-1].get("final_passes") == 256, [(it["passes"], it.get("final_passes")) for it in gpt.iterations]
+    own = gpt.iterations[-1]["stats"][-1]["samples"]  # 16 groups of 16 passes over the whole film: every rank rendered 16 / world of them
+    assert own == 24 * 16 * 4 * 256 // world, own
 t = e.read_sdtree()
 np.savez(os.path.join(sys.argv[3], "rank%d.npz" % rank), film=img, children=t["children"], dch=t["sampling"]["node_children"], dsum=t["sampling"]["node_sums"], theta=t["theta"])
 dist.barrier(); dist.destroy_process_group()
@@ -125,11 +132,15 @@ dist.barrier(); dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("mode,world,scheme", [("default", 2, "owner"), ("inversevar", 2, "owner"), ("improved", 2, "owner"), ("nee", 2, "owner"),
-                                               ("full-scene", 2, "owner"), ("improved", 4, "owner"), ("nee", 4, "owner"), ("improved", 2, "gather")])
+                                               ("full-scene", 2, "owner"), ("improved", 4, "owner"), ("nee", 4, "owner"), ("improved", 2, "gather"),
+                                               ("auto-final", 2, "owner"), ("auto-final", 4, "owner")])
 def test_sharded_render_over_gloo_equals_single_rank(oracle_lib, tmp_path, mode, world, scheme):
     """world_size 2 and 4, gloo: tiles sharded, SD-tree statistics all-reduced as int64, the optimiser's records sent to the OWNER of
     their D-tree (all-to-all) and the owners' optimiser state all-gathered ("owner"; "gather": round 2's gather-everything scheme) →
-    the merged render, the SD-tree and the learned fractions are bit-identical to the unsharded ones on every rank."""
+    the merged render, the SD-tree and the learned fractions are bit-identical to the unsharded ones on every rank.
+    The FINAL iteration is sharded by whole groups of passes, not by tiles (include/ppg.h "Final iteration: groups of passes"): "improved" has
+    three groups (16 + 16 + 13 passes), "auto-final" sixteen — after the tile-sharded training passes of the same iteration, whose film the
+    groups are added to (sampleCombination = automatic switching to FINAL in the middle of iteration 7, GP:1400-1411)."""
     import ppg_host
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
@@ -147,6 +158,9 @@ def test_sharded_render_over_gloo_equals_single_rank(oracle_lib, tmp_path, mode,
     if mode in ("nee", "full-scene"):  # direct-light vertices are committed inside Li's loop on whichever rank owns the pixel
         props.update(nee="kickstart", bsdfSamplingFractionLoss="var", spatialFilter="box", sTreeThreshold=2000)
     scene = ppg_host.cbox_scene(64, 48)
+    if mode == "auto-final":
+        props.update(budget=2044, seed=2, sampleCombination="automatic")
+        scene = ppg_host.cbox_scene(24, 16)
     if mode == "full-scene":  # analytic spheres (glass, rough gold, lamp) under an emitting sky dome: the S-tree spans the dome
         from test_gpu_parity import _sphere_scene
         scene = _sphere_scene((64, 48), sky=True)
@@ -159,6 +173,106 @@ def test_sharded_render_over_gloo_equals_single_rank(oracle_lib, tmp_path, mode,
         assert np.array_equal(got["dch"], ref_t["sampling"]["node_children"]) and np.array_equal(got["dsum"], ref_t["sampling"]["node_sums"])
         assert np.array_equal(got["film"], ref_img)
         assert np.array_equal(got["theta"], ref_t["theta"])
+
+
+CANCEL_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import ctypes, torch.distributed as dist
+import ppg_host
+from ppg_host.distributed import HostReducer, RenderAborted
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+lib = ctypes.CDLL(sys.argv[2])
+props = dict(budgetType="spp", maxDepth=10, rrDepth=10, strictNormals=1, budget=60, seed=17, sampleCombination="inversevar", bsdfSamplingFractionLoss="kl",
+             spatialFilter="stochastic", directionalFilter="box", sTreeThreshold=2000, sppPerPass=1)
+e = ppg_host.Engine(lib, "ppgo_", **props)
+lib.ppgo_set_modes(e.ctx, 0, 0, 2)
+e.set_scene(ppg_host.cbox_scene(48, 32)); e.set_shard(rank, world, 16)
+red = HostReducer(dist)
+gpt = ppg_host.GuidedPathTracer(engine=e, reducer=red)
+# rank `who` is cancelled after iteration 2; iteration 3 (8 passes) has two rounds of the optimiser, i.e. the OTHER ranks next enter a round
+# hook (counts all-to-all), not the image exchange a cancelled rank used to run off to
+who = int(sys.argv[4])
+gpt.log = lambda rec: gpt.cancel() if (rec["iter"] == 2 and rank == who) else None
+try:
+    gpt.render()
+    outcome = "finished"
+except ppg_host.PPGError as ex:
+    outcome = "ppg-error %d" % ex.code
+except RenderAborted:
+    outcome = "aborted"
+done = [it["iter"] for it in gpt.iterations]
+open(os.path.join(sys.argv[3], "cancel-rank%d.txt" % rank), "w").write("%s %s" % (outcome, done))
+# a second render with the same reducer works: the status word does not stick
+gpt.log = None
+img = gpt.render()
+open(os.path.join(sys.argv[3], "again-rank%d.txt" % rank), "w").write("%.6f" % float(img.mean()))
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("world,who", [(2, 1), (3, 0)])
+def test_cancelled_rank_takes_the_others_out_with_a_learned_fraction(oracle_lib, tmp_path, world, who):
+    """ADVICE r3: with the round hook active (bsdfSamplingFractionLoss = kl) a cancelled rank used to leave renderPassesNoStat between two
+    rounds and go to the image all-reduce while the others entered the next round's hook — different collectives on one communicator.  Now
+    the library keeps it in step (empty rounds), every exchange begins with the sum of the ranks' status words, and all ranks leave the render
+    at the same exchange — within the timeout, none hanging; the reducer is usable again afterwards."""
+    script = tmp_path / "cancel_worker.py"
+    script.write_text(CANCEL_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(31500 + os.getpid() % 2000), OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
+           "--master-port", env["MASTER_PORT"], str(script), os.path.join(ROOT, "practical-path-guiding_amd"),
+           os.path.join(ROOT, "oracle", "libppg_oracle.so"), str(tmp_path), str(who)]
+    subprocess.run(cmd, check=True, env=env, timeout=300, capture_output=True)
+    outcomes = [(tmp_path / ("cancel-rank%d.txt" % r)).read_text() for r in range(world)]
+    assert all(o.startswith(("ppg-error", "aborted")) and o.endswith("[0, 1, 2]") for o in outcomes), outcomes  # nobody finished, nobody got further
+    again = {(tmp_path / ("again-rank%d.txt" % r)).read_text() for r in range(world)}
+    assert len(again) == 1 and float(again.pop()) > 0.01
+
+
+SECONDS_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, sys.argv[1])
+import ctypes, numpy as np, torch.distributed as dist
+import ppg_host
+from ppg_host.distributed import HostReducer
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+lib = ctypes.CDLL(sys.argv[2])
+props = dict(budgetType="seconds", budget=1.2, maxDepth=6, rrDepth=10, strictNormals=1, seed=5, sampleCombination=sys.argv[4], sppPerPass=1,
+             bsdfSamplingFractionLoss="kl" if sys.argv[4] == "inversevar" else "none")
+e = ppg_host.Engine(lib, "ppgo_", **props)
+lib.ppgo_set_modes(e.ctx, 0, 0, 1 + rank)  # ranks of different speed: their own clocks would disagree
+e.set_scene(ppg_host.cbox_scene(32, 24)); e.set_shard(rank, world, 8)
+gpt = ppg_host.GuidedPathTracer(engine=e, reducer=HostReducer(dist))
+img = gpt.render()
+rec = [[it["passes"], [s["passes_rendered_total"] for s in it["stats"]]] for it in gpt.iterations]
+json.dump({"iterations": rec, "mean": float(np.nanmean(img)), "finite": bool(np.isfinite(img).all())}, open(os.path.join(sys.argv[3], "sec-rank%d.json" % rank), "w"))
+np.save(os.path.join(sys.argv[3], "sec-rank%d.npy" % rank), img)
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("combo", ["automatic", "inversevar"])
+def test_time_budget_sharded_over_gloo(oracle_lib, tmp_path, combo):
+    """budgetType = seconds — the reference's default — sharded over two ranks of different speed: every decision taken by a clock (the
+    per-pass abort of performRenderPasses GP:1259-1262, the iteration loop and the switch to FINAL of renderTime GP:1434-1514) is rank 0's,
+    broadcast (ppg_set_stop_hook + reducer.broadcast), so both ranks render the same iterations and the same number of passes in each,
+    their collectives match, and both hold the same complete picture.  With a learned sampling fraction the round hooks stay in step too."""
+    import json
+    script = tmp_path / "seconds_worker.py"
+    script.write_text(SECONDS_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(33500 + os.getpid() % 2000), OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", env["MASTER_PORT"], str(script), os.path.join(ROOT, "practical-path-guiding_amd"),
+           os.path.join(ROOT, "oracle", "libppg_oracle.so"), str(tmp_path), combo]
+    subprocess.run(cmd, check=True, env=env, timeout=300, capture_output=True)
+    a, b = (json.load(open(tmp_path / ("sec-rank%d.json" % r))) for r in range(2))
+    assert a["iterations"] == b["iterations"] and len(a["iterations"]) >= 3
+    assert [it[0] for it in a["iterations"]] == [1 << k for k in range(len(a["iterations"]))]
+    assert a["finite"] and b["finite"] and a["mean"] > 0.01
+    assert np.array_equal(np.load(tmp_path / "sec-rank0.npy"), np.load(tmp_path / "sec-rank1.npy"))
 
 
 def _time_budget_checks(make_engine, scene, budget):
