@@ -247,32 +247,34 @@ def run(args):
         make(args.warmup).render()
     # `value` is the MEDIAN of --repeats complete renders (new context each: nothing carries over but the process-wide block cache); boxes and
     # individual renders differ by more than a kernel change is worth (DESIGN.md §7 "Boxes differ"), min / max are reported beside it
+    # (one context at a time: a context of this workload holds ~50 GB of path state and vertex slots — five of them alive at once ran the
+    # later renders at a third of the speed)
     runs = []
     for _ in range(max(1, args.repeats)):
         g_ = make(args.steps)
         _, dt_ = timed_render(g_)
-        runs.append((dt_, g_))
+        runs.append((dt_, g_.iterations))
+        del g_
     order = sorted(range(len(runs)), key=lambda k: runs[k][0])
-    dt, gpt = runs[order[len(order) // 2]]
+    dt, iterations = runs[order[len(order) // 2]]
     all_dt = [r[0] for r in runs]
-    del runs, g_
+    del runs
     samples = args.width * args.height * spp * args.steps
-    rays = sum(s["rays"] for it in gpt.iterations for s in it["stats"])
-    own_samples = sum(s["samples"] for it in gpt.iterations for s in it["stats"])
-    plen = sum(s["path_length_sum"] for it in gpt.iterations for s in it["stats"])
-    var_last = gpt.iterations[-1]["stats"][-1]["variance"]
+    rays = sum(s["rays"] for it in iterations for s in it["stats"])
+    own_samples = sum(s["samples"] for it in iterations for s in it["stats"])
+    plen = sum(s["path_length_sum"] for it in iterations for s in it["stats"])
+    var_last = iterations[-1]["stats"][-1]["variance"]
     out = {
         "metric": "Msamples/s", "value": samples / dt / 1e6, "unit": "Msamples/s", "n_gpus": args.gpus, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload, "scene_file": scene_check, "headline_scene": scene_name == "kitchen",
-                   "iterations": [it["passes"] for it in gpt.iterations], "parallelism": "tiles%d" % args.gpus,
+                   "iterations": [it["passes"] for it in iterations], "parallelism": "tiles%d" % args.gpus,
                    "rays_per_sample": rays / max(1, own_samples), "avg_path_length": plen / max(1, own_samples), "variance_last_iteration": var_last},
         "tuning_env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("PPG_")},
         "repeats": {"n": len(all_dt), "value_is": "median", "values": [samples / t / 1e6 for t in all_dt],
                     "min": samples / max(all_dt) / 1e6, "max": samples / min(all_dt) / 1e6},
     }
-    del gpt
     if scene_name == "kitchen":
         out["reference_log"] = dict(REF_KITCHEN_LOG, triangle_ratio_of_this_scene=scene.n_triangles / REF_KITCHEN_LOG["primitives"],
                                     note="the reference binary on the complete scene (1 414 390 primitives) at 700x400; this run renders the %d triangles of the "
@@ -486,7 +488,7 @@ def main():
     ap.add_argument("--glossy", action="store_true", help="room scene with the S3 material mix (GGX alpha 0.1 metal, plastic) instead of Lambertian only")
     ap.add_argument("--cpu-passes", type=int, default=15, help="passes timed on the CPU baseline (bounded sample)")
     ap.add_argument("--secondary-passes", type=int, default=63)
-    ap.add_argument("--repeats", type=int, default=3, help="timed renders; value = their median (min / max reported)")
+    ap.add_argument("--repeats", type=int, default=5, help="timed renders; value = their median (min / max reported)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-rmse", action="store_true")

@@ -409,7 +409,7 @@ def test_sharded_contexts_on_one_gpu_equal_unsharded():
         else:
             red.reduce_images()
         stats = [e.finish_passes() for e in engines]
-        assert stats[0].variance == stats[1].variance
+        assert stats[0].variance == stats[1].variance or (np.isnan(stats[0].variance) and np.isnan(stats[1].variance))  # (1 spp: no estimate)
         if final:  # groups 0, 2 and 4 (48 passes) in context 0, groups 1 and 3 in context 1, all pixels each
             assert [st.samples for st in stats] == [96 * 64 * 48, 96 * 64 * 32]
         else:
