@@ -82,7 +82,7 @@ def algorithmic_bytes(work=None, rays=None, bvh=None):
 def measured_traffic(tag):
     """HBM bytes per unit from profiles/<tag>_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, calibrated as
     MI355X_MICROARCH.md prescribes; written by tools/collect_profiles.py on the GPU box) — a STORED calibration, not measured in this run."""
-    for name in ("r03_pmc_traffic_%s.json" % tag, "r02_pmc_traffic_%s.json" % tag, "r01_pmc_traffic.json" if tag == "cbox" else ""):
+    for name in ("r04_pmc_traffic_%s.json" % tag, "r03_pmc_traffic_%s.json" % tag, "r02_pmc_traffic_%s.json" % tag, "r01_pmc_traffic.json" if tag == "cbox" else ""):
         p = os.path.join(ROOT, "profiles", name)
         if name and os.path.exists(p):
             try:
@@ -347,9 +347,10 @@ def run(args):
             avg_units, avg_ms = units / k["launches"], k["ms"] / k["launches"]
             achieved = bpu * avg_units / (avg_ms * 1e-3) / 1e9
             traffic = None
-            if tr and name in tr.get("bytes_per_unit", {}):  # the stored calibration's unit (r03: the roofline's own unit for every kernel; r02: k_tail per path handed over)
+            tkey = k["name"] if tr and k["name"] in tr.get("bytes_per_unit", {}) else name   # (r04: k_shade<common> / k_shade<rest> on their own)
+            if tr and tkey in tr.get("bytes_per_unit", {}):  # the stored calibration's unit (r03 on: the roofline's own unit for every kernel; r02: k_tail per path handed over)
                 per_ray = "unit_of_work" in tr
-                traffic = tr["bytes_per_unit"][name] * (units if (per_ray or name != "k_tail") else k["units"]) / k["launches"]
+                traffic = tr["bytes_per_unit"][tkey] * (units if (per_ray or name != "k_tail") else k["units"]) / k["launches"]
             return {"kernel": k["name"], "ms": round(k["ms"], 3), "launches": k["launches"], "avg_launch_ms": avg_ms, "avg_units_per_launch": avg_units,
                     "algorithmic_bytes_per_unit": bpu, "achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "traffic": traffic}
 

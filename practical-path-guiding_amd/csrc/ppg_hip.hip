@@ -612,6 +612,7 @@ struct ppg_ctx {
     DevBuf<unsigned int> d_tailLongest;  // [PPG_TAIL_LOG] longest path (bounces) finished by each k_tail launch of the current performRenderPasses
     unsigned int tailLaunches = 0;
     uint64_t tailLongestSum = 0;  // sum over all k_tail launches of the longest path each finished (bounces): the tails' critical path
+    uint64_t shadeCommonRays = 0;  // rays through k_shade<.., MSET_COMMON> while kernel timing is on
     uint64_t bvhNodesVisited = 0, bvhTrisTested = 0;  // by k_trace while kernel timing is on (the roofline's node / triangle counts)
     ppg_pass_hook passHook = nullptr;
     void *passHookUser = nullptr;
@@ -1425,9 +1426,9 @@ int finishPasses(ppg_ctx *ctx, ppg_pass_stats *st) {  // GP:1288-1328
     if (nTails) HIP_CHECK(hipMemcpyAsync(tailLongest, ctx->d_tailLongest.p, nTails * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
     BlockStats c{};
-    for (int k = 0; k < ctx->nBlocks; ++k) { const BlockStats &x = bs[k]; c.rays += x.rays; c.path_len += x.path_len; c.committed += x.committed; c.bvh_nodes += x.bvh_nodes; c.bvh_tris += x.bvh_tris; c.max_len = std::max(c.max_len, x.max_len); }
+    for (int k = 0; k < ctx->nBlocks; ++k) { const BlockStats &x = bs[k]; c.rays += x.rays; c.path_len += x.path_len; c.committed += x.committed; c.bvh_nodes += x.bvh_nodes; c.bvh_tris += x.bvh_tris; c.max_len = std::max(c.max_len, x.max_len); c.shade_common += x.shade_common; }
     if (ctx->debugBatch) fprintf(stderr, "[ppg passes] iter %d passes %d rays %llu path_len_sum %llu longest path finished by k_tail %llu\n", ctx->iter, ctx->passesLocal, (unsigned long long)c.rays, (unsigned long long)c.path_len, (unsigned long long)c.max_len);
-    ctx->bvhNodesVisited += c.bvh_nodes; ctx->bvhTrisTested += c.bvh_tris;
+    ctx->bvhNodesVisited += c.bvh_nodes; ctx->bvhTrisTested += c.bvh_tris; ctx->shadeCommonRays += c.shade_common;
     for (unsigned int k = 0; k < nTails; ++k) ctx->tailLongestSum += tailLongest[k];
     float variance = 0;  // summed in the reference's x-major order (GP:1303-1311)
     for (int k = 0; k < n; ++k) variance += lum[k];  // k = x * H + y
@@ -2455,7 +2456,7 @@ int ppg_query_sample(ppg_ctx *ctx, uint32_t n, const float *positions, uint64_t 
 
 int ppg_enable_kernel_timing(ppg_ctx *ctx, int32_t enable) {
     ctx->timer.reset();
-    ctx->bvhNodesVisited = ctx->bvhTrisTested = 0; ctx->tailLongestSum = 0;
+    ctx->bvhNodesVisited = ctx->bvhTrisTested = 0; ctx->tailLongestSum = 0; ctx->shadeCommonRays = 0;
     ctx->timer.enabled = enable != 0;
     return PPG_OK;
 }
@@ -2464,6 +2465,9 @@ int ppg_kernel_times(ppg_ctx *ctx, ppg_kernel_time *out, uint32_t cap, uint32_t 
     uint32_t k = 0;
     for (size_t i = 0; i < ctx->timer.names.size() && k < cap; ++i, ++k) {
         out[k].name = ctx->timer.names[i].c_str(); out[k].ms = ctx->timer.ms[i]; out[k].launches = ctx->timer.launches[i]; out[k].units = ctx->timer.units[i];
+        // the two launches over a sorted slice were both booked with the slice's rays: the common classes' share was counted by k_sort_slices
+        if (ctx->timer.names[i] == "k_shade<common>") out[k].units = ctx->shadeCommonRays;
+        else if (ctx->timer.names[i] == "k_shade<rest>") out[k].units = ctx->timer.units[i] > ctx->shadeCommonRays ? ctx->timer.units[i] - ctx->shadeCommonRays : 0;
     }
     // two pseudo entries for the roofline of k_trace on BVH scenes: `units` = BVH4 nodes visited / triangles tested by its launches
     if (k + 2 <= cap && ctx->bvhNodesVisited) {

@@ -132,6 +132,7 @@ struct BlockStats {
     unsigned long long rays, path_len, committed;
     unsigned long long bvh_nodes, bvh_tris;  // k_trace<.., COUNT>: BVH4 nodes visited / triangles tested (kernel timing runs only: the roofline's n, t)
     unsigned long long max_len;              // longest path finished by k_tail (diagnostics: PPG_DEBUG_BATCH)
+    unsigned long long shade_common;         // rays k_sort_slices dealt to k_shade<.., MSET_COMMON> (the units of its roofline line)
 };
 
 // Queues.  Every wavefront bounce reads the DENSE list of live paths (items[1], dense_n entries), dealt to the persistent workgroups in
@@ -1453,7 +1454,7 @@ static __global__ __launch_bounds__(PPG_BLOCK) void k_sort_slices(PathState P, D
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned int acc = 0;
-        for (int j = 0; j < 16; ++j) { offs[j] = acc; acc += hist[j]; if (j == 7 && Q.n_common) Q.n_common[b] = acc; }
+        for (int j = 0; j < 16; ++j) { offs[j] = acc; acc += hist[j]; if (j == 7 && Q.n_common) { Q.n_common[b] = acc; Q.stats[b].shade_common += acc; } }
         Q.count[1][b] = acc;
     }
     __syncthreads();

@@ -1,0 +1,15 @@
+#!/bin/bash
+# GPU box, round 4, shipped build: the driver's command as the box's first process, the rocprofv3 evidence for profiles/r04_* (kernel stats of
+# the driver's command, PMC traffic and wave cycles of the SAME build), 127 and 1023 passes, the batch log, other workloads
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/r04_final
+mkdir -p $OUT $R/gpurun_out/profiles
+cd /tmp; export TMPDIR=/tmp; ulimit -c 0
+python $R/bench.py --steps 20 --warmup 5 > $R/gpurun_out/profiles/r04_bench_default_plain.json 2> $OUT/plain.err
+python $R/tools/collect_profiles_r04.py stats traffic wait > $OUT/collect.log 2>&1
+python $R/bench.py --steps 127 --warmup 5 --no-rmse > $R/gpurun_out/profiles/r04_bench_127_passes.json 2>> $OUT/err.log
+python $R/bench.py --steps 1023 --warmup 5 --no-rmse --no-cpu --no-secondary --repeats 3 > $R/gpurun_out/profiles/r04_bench_1023_passes.json 2>> $OUT/err.log
+PPG_DEBUG_BATCH=1 python $R/bench.py --steps 20 --warmup 0 --no-rmse --no-cpu --no-secondary --no-roofline --no-single-call --repeats 1 > $OUT/debug20.json 2> $R/gpurun_out/profiles/r04_batches_20_passes.log
+tail -12 $OUT/collect.log
+for f in r04_bench_default_plain r04_bench_127_passes r04_bench_1023_passes; do python -c "
+import json,sys; d=json.load(open('$R/gpurun_out/profiles/$f.json')); print('$f', d['value'], d['repeats']['values'], d.get('vs_reference_log'), d['roofline']['kernel'], round(d['roofline']['frac'],3), d['roofline']['kernels_ms'])"; done
