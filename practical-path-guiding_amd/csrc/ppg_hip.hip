@@ -523,6 +523,7 @@ struct ppg_ctx {
     DevBuf<float4> d_pathRec, d_vertexRec;  // interleaved layout (PathState Field, ppg_kernels.h): 8 float4 per path, 4 / 6 per vertex slot
     DevBuf<uint4> d_miscCompact;
     bool aosPaths = false;
+    int pathLayout = 1;  // 1 soa, 2 aos, 3 pack (allocPaths; PPG_PATH_LAYOUT)
     DevBuf<unsigned int> d_queue[2], d_qcount[2], d_qtotal, d_queueSorted, d_qcommon;
     DevBuf<unsigned char> d_sortKeys;
     int maxBatchFinal = 1;  // passes per batch in the final iteration (nothing is recorded: no vertex slots needed)
@@ -591,7 +592,7 @@ struct ppg_ctx {
     bool debugBatch = false;          // PPG_DEBUG_BATCH: one line per batch on stderr (paths, live paths after every bulk bounce, tail time)
     int tuneFinalBatch = 0;           // PPG_FINAL_BATCH: passes per batch of the final iteration (0 = 64)
     int tuneTailBlocks = 0;           // PPG_TAIL_BLOCKS: workgroups of k_tail when k_commit runs beside it (0 = automatic)
-    int tunePathLayout = 0;           // PPG_PATH_LAYOUT = aos: per-path state interleaved in 128-byte records instead of one array per field
+    int tunePathLayout = 0;           // PPG_PATH_LAYOUT = soa | aos | pack: layout of the per-path state (0 = automatic, allocPaths)
     int tuneBvhLeaf = 3;              // PPG_BVH_LEAF: triangles per BVH leaf (1..8).  KITCHEN 720p, driver's command: 4 -> 3 +3.5 % once the node test had become
                                       // cheap (130.9 -> 135.6, A/B on one box; with the world-space decode 2 / 3 / 4 / 6 / 8 gave 125.8 / 125.9 / 124.5 / 119.6 / 115.2)
     float tuneBvhPad = 2e-6f;         // PPG_BVH_PAD: box padding relative to the scene extent
@@ -914,10 +915,17 @@ int allocPaths(ppg_ctx *ctx) {
     size_t nn = std::max<size_t>(1, std::max(n, nFinal));
     ctx->maxVertices = PPG_MAX_VERTICES;
     if (ctx->maxDepth > 0) ctx->maxVertices = std::max(1, std::min(PPG_MAX_VERTICES, ctx->maxDepth - 1));
-    // layout of the per-path state: one array per field, or (PPG_PATH_LAYOUT=aos) interleaved 128-byte records.  Measured on MI355X:
-    // interleaving helps the late, scattered bounces (KITCHEN k_shade<FULL> 380 -> 340 ms per 127 passes) and hurts the early, coalesced
-    // ones (k_trace 387 -> 404 ms, k_sort_slices, k_generate): KITCHEN +1 %, SPACESHIP 1080p -10 %, cbox-720p -19 %.  Off by default.
-    ctx->aosPaths = ctx->tunePathLayout == 2;
+    // layout of the per-path state: one array per field (soa), interleaved 128-byte records (aos), or two 64-byte records (pack).  Interleaving
+    // helps the late, scattered bounces — after compaction and the sort by material a lane holds an arbitrary path, and five 16-byte accesses
+    // to five arrays cost five sectors — and hurts the early, coalesced ones.  Measured on MI355X, round 4 (profiles/r04_experiments.json,
+    // Msamples/s soa / pack / aos): KITCHEN 1023 passes 202 / 207 / 209, 127 passes 183 / 185 / 187, 20 passes equal; torus-class 1080p
+    // 129 / 138 / 142; SPACESHIP 1080p 1008 / 925 / 874; cbox-720p 1350 / 1170 / 1038.  So: interleaved for paths of unbounded depth over a BVH
+    // scene (long random walks: most bounces are late ones), one array per field otherwise; PPG_PATH_LAYOUT = soa | aos | pack overrides.
+    if (ctx->tunePathLayout == 0) ctx->pathLayout = (ctx->maxDepth < 0 && ctx->scene.n_tris > 64) ? 2 : 1; else ctx->pathLayout = ctx->tunePathLayout;
+    // PPG_PATH_LAYOUT=pack: two 64-byte records per path — (throughput, Li, key / flags) and (ray origin, direction, hit) — so that a scattered
+    // path costs k_shade two sectors to read and two to write instead of five and five, and k_trace one; the vertex slots stay one array per field
+    const bool packPaths = ctx->pathLayout == 3;
+    ctx->aosPaths = ctx->pathLayout == 2 || packPaths;
     if (ctx->aosPaths) { HIP_CHECK(ctx->d_pathRec.reserve(nn * 8)); HIP_CHECK(ctx->d_miscCompact.reserve(nn)); }
     else {
         HIP_CHECK(ctx->d_ray_o.reserve(nn)); HIP_CHECK(ctx->d_ray_d.reserve(nn)); HIP_CHECK(ctx->d_thr.reserve(nn));
@@ -947,7 +955,15 @@ int allocPaths(ppg_ctx *ctx) {
     const bool filtered = ctx->spatialFilter != SF_NEAREST;
     PathState &P = ctx->paths;
     P.n_paths = (unsigned int)n; P.n_pix = ctx->nPix; P.pixels = ctx->d_pixels.p;
-    if (ctx->aosPaths) {
+    if (packPaths) {
+        float4 *a = ctx->d_pathRec.p, *b = ctx->d_pathRec.p + 4 * nn;
+        P.thr = {a, 4}; P.li = {a + 1, 4}; P.misc = {reinterpret_cast<uint4 *>(a + 2), 4};
+        P.ray_o = {b, 4}; P.ray_d = {b + 1, 4}; P.hit = {b + 2, 4};
+        HIP_CHECK(ctx->d_vd.reserve(nv)); HIP_CHECK(ctx->d_vthr.reserve(nv)); HIP_CHECK(ctx->d_vbsdf.reserve(nv)); HIP_CHECK(ctx->d_vrad.reserve(nv));
+        if (filtered) { HIP_CHECK(ctx->d_vo.reserve(nv)); HIP_CHECK(ctx->d_vvox.reserve(nv)); }
+        P.v_d = {ctx->d_vd.p, 1}; P.v_thr = {ctx->d_vthr.p, 1}; P.v_bsdf = {ctx->d_vbsdf.p, 1}; P.v_rad = {ctx->d_vrad.p, 1};
+        P.v_o = {filtered ? ctx->d_vo.p : nullptr, 1}; P.v_vox = {filtered ? ctx->d_vvox.p : nullptr, 1};
+    } else if (ctx->aosPaths) {
         const unsigned int vs = filtered ? 6u : 4u;
         HIP_CHECK(ctx->d_vertexRec.reserve(nv * vs));
         float4 *r = ctx->d_pathRec.p, *v = ctx->d_vertexRec.p;
@@ -1777,7 +1793,7 @@ int ppg_create(const ppg_config *cfg, ppg_ctx **out) {
         c->debugBatch = getenv("PPG_DEBUG_BATCH") != nullptr;
         if (const char *e = getenv("PPG_TAIL_BLOCKS")) c->tuneTailBlocks = std::max(1, atoi(e));
         if (const char *e = getenv("PPG_FINAL_BATCH")) c->tuneFinalBatch = std::max(1, atoi(e));
-        if (const char *e = getenv("PPG_PATH_LAYOUT")) c->tunePathLayout = !strcmp(e, "aos") ? 2 : (!strcmp(e, "soa") ? 1 : 0);
+        if (const char *e = getenv("PPG_PATH_LAYOUT")) c->tunePathLayout = !strcmp(e, "aos") ? 2 : (!strcmp(e, "pack") ? 3 : (!strcmp(e, "soa") ? 1 : 0));
         if (const char *e = getenv("PPG_BVH_LEAF")) c->tuneBvhLeaf = std::max(1, std::min(8, atoi(e)));
         if (const char *e = getenv("PPG_BVH_PAD")) c->tuneBvhPad = (float)atof(e);
     }

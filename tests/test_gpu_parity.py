@@ -297,7 +297,8 @@ def test_tuning_switches_do_not_change_results(monkeypatch):
 
     base_img, base_tree = run()
     assert np.isfinite(base_img).all() and base_img.mean() > 1e-3
-    for env in (dict(PPG_PATH_LAYOUT="aos"), dict(PPG_NO_OVERLAP="1"), dict(PPG_NO_SORT="1"), dict(PPG_TAIL_MIN="1", PPG_TAIL_DIV="1000000"),
+    for env in (dict(PPG_PATH_LAYOUT="aos"), dict(PPG_PATH_LAYOUT="soa"), dict(PPG_PATH_LAYOUT="pack"), dict(PPG_NO_SPLIT="1"), dict(PPG_NO_SORT_FIRST="1"),
+                dict(PPG_NO_TOPCUT="1"), dict(PPG_NO_OVERLAP="1"), dict(PPG_NO_SORT="1"), dict(PPG_TAIL_MIN="1", PPG_TAIL_DIV="1000000"),
                 dict(PPG_TAIL_THRESHOLD="100000000"), dict(PPG_BLOCKS="512"), dict(PPG_BATCH_PATHS="20000"), dict(PPG_TAIL_BLOCKS="64"),
                 dict(PPG_BULK_BOUNCES="0"), dict(PPG_BULK_BOUNCES="3"), dict(PPG_BOUNCE_MARGIN="0"), dict(PPG_TAIL_MIN="200", PPG_TAIL_DIV="1000000"),
                 dict(PPG_BVH_LEAF="4")):
