@@ -579,7 +579,7 @@ public:
     Float bsdfSamplingFraction() const { return bsdfSamplingFraction(bsdfSamplingFractionOptimizer.variable()); }
 
     void optimizeBsdfSamplingFraction(const DTreeRecord &rec, Float ratioPower, const Modes &modes) {  // GP:672-697
-        if (modes.adam == PPGO_ADAM_ROUND) {  // deferred to the end of the round, applied in canonical order by applyAdamRound()
+        if (modes.adam == PPGO_ADAM_ROUND || modes.adam == PPGO_ADAM_HALF) {  // deferred to the end of the round, applied in canonical order by applyAdamRound()
             modes.sink->push_back(AdamRecord{this, modes.path, modes.code, rec.product, rec.woPdf, rec.bsdfPdf, rec.dTreePdf, rec.statisticalWeight});
             return;
         }
@@ -2588,7 +2588,10 @@ public:
         // ROUND mode: the passes are rendered in rounds of ppg_adam_round_passes() passes; the sampling fractions are frozen during
         // a round and its records are applied afterwards (applyAdamRound).  The time budget is checked once per round then
         // (the reference checks after every finished pass of a batch of up to 128 scheduled ones, GP:1235-1266).
-        const bool rounds = m_bsdfSamplingFractionLoss != ENone && modes.adam == PPGO_ADAM_ROUND && m_isBuilt && !m_isFinalIter;
+        const bool rounds = m_bsdfSamplingFractionLoss != ENone && (modes.adam == PPGO_ADAM_ROUND || modes.adam == PPGO_ADAM_HALF) && m_isBuilt && !m_isFinalIter;
+        // PPGO_ADAM_HALF (measurement only): in iteration 1 — two one-pass rounds — the optimiser is also applied after each HALF
+        // pass (pixels by parity of x + y), i.e. four rounds instead of two
+        const bool halves = rounds && modes.adam == PPGO_ADAM_HALF && numPasses == 2;
         const int roundPasses = rounds ? adamRoundPasses(numPasses) : 1;
         // (cancelled with a round hook installed: the remaining rounds are entered empty, so that this rank stays in step with the hooks of
         // the others until they have all seen its status — the product's rule, ppg_hip.hip renderPassesNoStat)
@@ -2600,6 +2603,8 @@ public:
             m_roundStartPass = m_passesRendered;
             for (int k = 0; k < n; ++k) {
                 if (drain) continue;
+                if (halves) { m_parity = 0; renderOnePass(); applyAdamRound(); m_parity = 1; renderOnePass(); m_parity = -1; }
+                else
                 renderOnePass();
                 ++m_passesRendered; ++m_passesRenderedThisIter; ++m_passesLocal;
                 m_samplesLocal += ownedPixels() * (uint64_t)m_sppPerPass;
@@ -2692,6 +2697,7 @@ public:
         if (passHook && ownerMode) { hookPhase = 1; if (passHook(passHookUser) != 0) m_hookFailed = true; hookPhase = 0; }  // the owners publish the state they computed
     }
     bool m_hookFailed = false;
+    int m_parity = -1;
     int hookPhase = 0;
     bool ownerMode = false;
     std::vector<uint32_t> m_adamState;  // [world * segment][6]
@@ -2759,6 +2765,7 @@ public:
             for (int y = y0; y < std::min(y0 + bs, h); ++y)
                 for (int x = x0; x < std::min(x0 + bs, w); ++x) {
                     if (!ownsPixel(x, y)) continue;
+                    if (m_parity >= 0 && ((x + y) & 1) != m_parity) continue;
                     const uint32_t pixel = (uint32_t)(y * w + x);
                     for (int j = 0; j < m_sppPerPass; ++j) {
                         Sampler sampler{ppg_path_key(m_seed, pixel, passIndex * (uint32_t)m_sppPerPass + (uint32_t)j), 0};

@@ -19,7 +19,7 @@ typedef struct ppgo_ctx ppgo_ctx;
 enum { PPGO_ACC_FIXED = 0, PPGO_ACC_FLOAT = 1 };
 /* ROUND: the product's rule (include/ppg.h "Learning the BSDF sampling fraction": records applied at the end of every round in
    key order).  SEQUENTIAL: GP:672-697 literally — every record is applied the moment its path commits it (single thread). */
-enum { PPGO_ADAM_ROUND = 0, PPGO_ADAM_SEQUENTIAL = 1 };
+enum { PPGO_ADAM_ROUND = 0, PPGO_ADAM_SEQUENTIAL = 1, PPGO_ADAM_HALF = 2 /* measurement only: half-pass rounds in iteration 1 */ };
 
 int ppgo_create(const ppg_config *cfg, ppgo_ctx **out);
 void ppgo_destroy(ppgo_ctx *ctx);

@@ -128,8 +128,13 @@ if "traffic" in what:
     film_known_rd = 16.0 * W * H * SPP * STEPS + (4 + 11 * 4) * units["k_film"]          # every li sample once + per launch and pixel: index + 11 accumulators
     wr_factor = gen_known_wr / (a3["k_generate"]["WRITE_SIZE"] * KB) if a3["k_generate"]["WRITE_SIZE"] else None
     rd_factor = film_known_rd / (a2["k_film"]["FETCH_SIZE"] * KB) if a2["k_film"]["FETCH_SIZE"] else None
+    raw_factors = {"k_film": rd_factor, "k_generate": wr_factor}
+    if os.environ.get("PPG_PATH_LAYOUT", "") != "soa":
+        # the automatic layout of this workload interleaves the path state: k_film / k_generate then touch 16 / 80 bytes of every 128-byte record and
+        # no longer stream a known byte count — the factors measured with PPG_PATH_LAYOUT=soa in this round (2.053 / 1.000) are applied instead
+        rd_factor, wr_factor = 2.0531788133671434, 1.0
     res = {"source": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE TCC_HIT TCC_MISS, one %d-pass render of the bench workload (kitchen-improved-720p)" % STEPS,
-           "calibration": {"read_factor_from_k_film": rd_factor, "write_factor_from_k_generate": wr_factor,
+           "calibration": {"read_factor": rd_factor, "write_factor": wr_factor, "raw_factors_of_this_collection": raw_factors,
                            "note": "factor = known streamed bytes / (counter * 1024); MI355X_MICROARCH.md §HBM expects ~2 for reads"},
            "unit_of_work": {"k_trace": "traced ray", "k_shade<common>": "traced ray that hit one of the common material classes", "k_shade<rest>": "any other traced ray", "k_tail": "ray traced and shaded inside the tail (the same unit as the roofline's)",
                             "k_commit": "recorded vertex"},
