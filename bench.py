@@ -244,7 +244,10 @@ def run(args):
         return img, dt
 
     if args.warmup > 0:
-        make(args.warmup).render()
+        w_ = make(args.warmup)
+        w_.render()
+        w_.engine.close()
+        del w_
     # `value` is the MEDIAN of --repeats complete renders (new context each: nothing carries over but the process-wide block cache); boxes and
     # individual renders differ by more than a kernel change is worth (DESIGN.md §7 "Boxes differ"), min / max are reported beside it
     # (one context at a time: a context of this workload holds ~50 GB of path state and vertex slots — five of them alive at once ran the
@@ -254,6 +257,7 @@ def run(args):
         g_ = make(args.steps)
         _, dt_ = timed_render(g_)
         runs.append((dt_, g_.iterations))
+        g_.engine.close()  # (not left to the garbage collector: the fifth render of five used to run beside the contexts of the four before it)
         del g_
     order = sorted(range(len(runs)), key=lambda k: runs[k][0])
     dt, iterations = runs[order[len(order) // 2]]

@@ -479,6 +479,7 @@ struct ppg_ctx {
     hipStream_t stream2 = nullptr;    // k_commit of the finished paths runs here while k_tail finishes the stragglers on `stream`
     hipEvent_t evFork = nullptr, evJoin = nullptr;
     DevBuf<unsigned char> d_straggler;  // [path] 1 = still alive when the persistent-thread tail took over
+    DevBuf<unsigned char> d_nv8;        // [path] vertex slots k_commit takes of the path (k_commit_prepare)
 
     // scene
     bool haveScene = false;
@@ -1218,19 +1219,22 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound, const GroupLaunch *gl =
     // interleaved path records: k_commit and k_path_nv sweep the per-path word once per (slot, path) item — from a contiguous copy
     PathState Pc = P;
     bool miscCopied = false;
-    auto copyMisc = [&] {
-        if (!ctx->aosPaths || miscCopied || P.n_paths == 0) return;
-        hipLaunchKernelGGL(k_copy_misc, dim3((P.n_paths + 255) / 256), dim3(256), 0, s, P, ctx->d_miscCompact.p);
-        Pc.misc = {ctx->d_miscCompact.p, 1};
+    auto copyMisc = [&] {  // k_commit_prepare: a byte per path for k_commit's work items (+ the contiguous copy of the path words)
+        if (miscCopied || P.n_paths == 0) return PPG_OK;
+        HIP_CHECK(ctx->d_nv8.reserve(P.n_paths));
+        hipLaunchKernelGGL(k_commit_prepare, dim3((P.n_paths + 255) / 256), dim3(256), 0, s, P, ctx->aosPaths ? ctx->d_miscCompact.p : (uint4 *)nullptr, ctx->d_nv8.p,
+                           overlap ? (const unsigned char *)ctx->d_straggler.p : (const unsigned char *)nullptr);
+        if (ctx->aosPaths) Pc.misc = {ctx->d_miscCompact.p, 1};
         miscCopied = true;
+        return PPG_OK;
     };
     // mode 0: every path; 1: paths not flagged as stragglers; 2: the paths of the dense list
     auto launchCommit = [&](hipStream_t st, int mode) {
-        const unsigned char *skip = mode == 1 ? ctx->d_straggler.p : nullptr;
+        const unsigned char *nv8 = mode == 2 ? nullptr : ctx->d_nv8.p;  // (mode 1: the stragglers' bytes are 0)
         const unsigned int *list = mode == 2 ? dense : nullptr;
         const unsigned long long *listN = mode == 2 ? ctx->d_total.p : nullptr;
         const PathState &PP = mode == 2 ? P : Pc;  // the stragglers' words changed in the tail: read them in place
-        CommitLaunch a{grid, st, PP, T, R, Q, skip, list, listN};
+        CommitLaunch a{grid, st, PP, T, R, Q, nv8, list, listN};
         ppg_launch_commit(ctx->spatialFilter, ctx->directionalFilter, a);
     };
     if (tail) {
@@ -1248,7 +1252,7 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound, const GroupLaunch *gl =
     if (fastRound) {
         // position of path i's records = exclusive scan of the vertex counts
         HIP_CHECK(ctx->d_adamNv.reserve(P.n_paths)); HIP_CHECK(ctx->d_adamBase.reserve(P.n_paths));
-        copyMisc();
+        { int rc = copyMisc(); if (rc) return rc; }
         hipLaunchKernelGGL(k_path_nv, dim3((P.n_paths + 255) / 256), dim3(256), 0, s, Pc, ctx->d_adamNv.p, overlap ? ctx->d_straggler.p : nullptr, (unsigned int)ctx->maxVertices);
         size_t bytes = 0;
         HIP_CHECK(rocprim::exclusive_scan(nullptr, bytes, ctx->d_adamNv.p, ctx->d_adamBase.p, 0u, (size_t)P.n_paths, rocprim::plus<unsigned int>(), s));
@@ -1280,7 +1284,7 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound, const GroupLaunch *gl =
             T = ctx->devTree();
         }
     }
-    if (commit) copyMisc();
+    if (commit) { int rc = copyMisc(); if (rc) return rc; }
     if (overlap) {
         HIP_CHECK(hipEventRecord(ctx->evFork, s));
         int rc = launchTail();

@@ -46,7 +46,7 @@ void ppg_launch_shade_common(const ShadeLaunch &a) {
 }
 #else
 void ppg_launch_commit_all(int sf, int df, const CommitLaunch &a) {
-#define PPG_COMMIT(SFV, DFV) hipLaunchKernelGGL((k_commit<SFV, DFV>), dim3(a.grid), dim3(PPG_BLOCK), 0, a.stream, a.P, a.T, a.R, a.Q, a.skip, a.list, a.list_n)
+#define PPG_COMMIT(SFV, DFV) hipLaunchKernelGGL((k_commit<SFV, DFV>), dim3(a.grid), dim3(PPG_BLOCK), 0, a.stream, a.P, a.T, a.R, a.Q, a.nv8, a.list, a.list_n)
     if (sf == SF_NEAREST && df == DF_NEAREST) PPG_COMMIT(SF_NEAREST, DF_NEAREST);
     else if (sf == SF_NEAREST) PPG_COMMIT(SF_NEAREST, DF_BOX);
     else if (sf == SF_STOCHASTIC && df == DF_NEAREST) PPG_COMMIT(SF_STOCHASTIC, DF_NEAREST);

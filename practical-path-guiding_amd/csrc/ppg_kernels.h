@@ -1518,7 +1518,7 @@ static __global__ __launch_bounds__(1024) void k_scan_counts(const unsigned int 
 // Which paths: all of them; or (skip) those not flagged — the paths that had ended when the persistent-thread tail took over, committed
 // on a second stream while k_tail runs —; or (list) the flagged ones afterwards.
 template <int SF, int DF>
-__global__ __launch_bounds__(PPG_BLOCK) void k_commit(PathState P, DevTree T, RenderParams R, Queues Q, const unsigned char *skip,
+__global__ __launch_bounds__(PPG_BLOCK) void k_commit(PathState P, DevTree T, RenderParams R, Queues Q, const unsigned char *nv8,
                                                       const unsigned int *list, const unsigned long long *list_n) {
     __shared__ unsigned long long acc;
     __shared__ unsigned long long box_lds[DF == DF_BOX ? PPG_BOX_STACK * PPG_BLOCK : 1];  // the box splat's stack, one column per lane
@@ -1535,8 +1535,8 @@ __global__ __launch_bounds__(PPG_BLOCK) void k_commit(PathState P, DevTree T, Re
         if (act) {
             v = (unsigned int)(w / n_sel); i = (unsigned int)(w % n_sel);
             if (list) i = list[i];
-            if (skip && skip[i]) act = false;
-            else {
+            if (nv8) act = v < (unsigned int)nv8[i];  // (k_commit_prepare: 0 for the paths this launch leaves to the one after the tail)
+            if (act) {
                 uint4 m = P.misc[i];
                 key = m.x; dim = m.y + 3u * v;
                 act = v < ((m.z & FL_NV_MASK) >> FL_NV_SHIFT);
@@ -1603,10 +1603,16 @@ static __global__ void k_path_nv(PathState P, unsigned int *nv, const unsigned c
     unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < P.n_paths) nv[i] = (straggler && straggler[i]) ? max_vertices : (P.misc[i].z & FL_NV_MASK) >> FL_NV_SHIFT;
 }
-// contiguous copy of the per-path word (key, dim, flags, leaf): k_commit tests it once per (slot, path) item
-static __global__ void k_copy_misc(PathState P, uint4 *out) {
+// Before k_commit: nv8[i] = how many vertex slots of path i this commit takes (0 for a path still alive when the persistent threads took over:
+// it is committed after the tail) — k_commit tests ONE BYTE per (slot, path) work item, and four fifths of the items lie beyond their path's
+// last vertex: reading the 16-byte path word for each of them was 30 GB of a 127-pass render.  With interleaved path records also the
+// contiguous copy of the per-path word (key, dim, flags, leaf) that the items that do commit read.
+static __global__ void k_commit_prepare(PathState P, uint4 *misc_out, unsigned char *nv8, const unsigned char *straggler) {
     unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < P.n_paths) out[i] = P.misc[i];
+    if (i >= P.n_paths) return;
+    const uint4 m = P.misc[i];
+    if (misc_out) misc_out[i] = m;
+    nv8[i] = (straggler && straggler[i]) ? (unsigned char)0 : (unsigned char)((m.z & FL_NV_MASK) >> FL_NV_SHIFT);
 }
 // flag[list[k]] = 1 for the n = *list_n entries of a dense path list
 static __global__ void k_mark_list(const unsigned int *list, const unsigned long long *list_n, unsigned char *flag) {

@@ -324,7 +324,9 @@ int main(int argc, char **argv) {
             if (world < 1 || rank < 0 || rank >= world) { std::cerr << "--rank / --world out of range\n"; return 2; }
             if (!props.values.count("device")) props.values["device"] = std::to_string(rank);  // one GPU per rank of the node
             const auto t0 = std::chrono::steady_clock::now();
-            if (runTag.empty() && getenv("PPG_RUN_TAG")) runTag = getenv("PPG_RUN_TAG");
+            // the run tag keeps a rank from accepting the id file a crashed earlier run left at the same path: any string all ranks of THIS run share
+            for (const char *v : {"PPG_RUN_TAG", "SLURM_JOB_ID", "TORCHELASTIC_RUN_ID"}) if (runTag.empty() && getenv(v)) runTag = getenv(v);
+            if (runTag.empty() && world > 1) { std::cerr << "--world > 1 needs --run-tag (or PPG_RUN_TAG / SLURM_JOB_ID): a string shared by the ranks of this run\n"; return 2; }
             reducer.reset(new RcclReducer(rank, world, std::stoi(props.values["device"]), ncclIdFile, runTag));
             if (!quiet) std::cout << "RCCL communicator: rank " << rank << " of " << world << " ready after "
                                   << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << " s" << std::endl;
