@@ -1230,7 +1230,8 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound, const GroupLaunch *gl =
     };
     // mode 0: every path; 1: paths not flagged as stragglers; 2: the paths of the dense list
     auto launchCommit = [&](hipStream_t st, int mode) {
-        const unsigned char *nv8 = mode == 2 ? nullptr : ctx->d_nv8.p;  // (mode 1: the stragglers' bytes are 0)
+        const unsigned char *nv8 = ctx->d_nv8.p;  // (mode 1: the stragglers' bytes are 0; mode 2: by list position, written just before)
+        if (mode == 2) hipLaunchKernelGGL(k_commit_prepare_list, dim3(std::max(1, std::min(grid, 1024))), dim3(256), 0, st, P, dense, ctx->d_total.p, ctx->d_nv8.p);
         const unsigned int *list = mode == 2 ? dense : nullptr;
         const unsigned long long *listN = mode == 2 ? ctx->d_total.p : nullptr;
         const PathState &PP = mode == 2 ? P : Pc;  // the stragglers' words changed in the tail: read them in place

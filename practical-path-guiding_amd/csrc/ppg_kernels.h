@@ -1534,8 +1534,8 @@ __global__ __launch_bounds__(PPG_BLOCK) void k_commit(PathState P, DevTree T, Re
         unsigned int v = 0, i = 0, key = 0, dim = 0;
         if (act) {
             v = (unsigned int)(w / n_sel); i = (unsigned int)(w % n_sel);
-            if (list) i = list[i];
-            if (nv8) act = v < (unsigned int)nv8[i];  // (k_commit_prepare: 0 for the paths this launch leaves to the one after the tail)
+            if (nv8) act = v < (unsigned int)nv8[i];  // (k_commit_prepare: 0 for the paths this launch leaves to the one after the tail; [_list]: by list position)
+            if (list && act) i = list[i];
             if (act) {
                 uint4 m = P.misc[i];
                 key = m.x; dim = m.y + 3u * v;
@@ -1613,6 +1613,12 @@ static __global__ void k_commit_prepare(PathState P, uint4 *misc_out, unsigned c
     const uint4 m = P.misc[i];
     if (misc_out) misc_out[i] = m;
     nv8[i] = (straggler && straggler[i]) ? (unsigned char)0 : (unsigned char)((m.z & FL_NV_MASK) >> FL_NV_SHIFT);
+}
+// the same for the launch over a LIST of paths (the tail's, after it): nv8[k] belongs to list[k] — the items read it in order
+static __global__ void k_commit_prepare_list(PathState P, const unsigned int *list, const unsigned long long *list_n, unsigned char *nv8) {
+    const unsigned int n = (unsigned int)*list_n;
+    for (unsigned int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x)
+        nv8[k] = (unsigned char)((P.misc[list[k]].z & FL_NV_MASK) >> FL_NV_SHIFT);
 }
 // flag[list[k]] = 1 for the n = *list_n entries of a dense path list
 static __global__ void k_mark_list(const unsigned int *list, const unsigned long long *list_n, unsigned char *flag) {

@@ -32,7 +32,7 @@ struct CommitLaunch {
     int grid;
     hipStream_t stream;
     PathState P; DevTree T; RenderParams R; Queues Q;
-    const unsigned char *nv8;   // k_commit_prepare's byte per path (nullptr with `list`)
+    const unsigned char *nv8;   // k_commit_prepare's byte per path, k_commit_prepare_list's per list entry
     const unsigned int *list;
     const unsigned long long *list_n;
 };
