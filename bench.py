@@ -36,6 +36,7 @@ Added to the JSON line (rank 0):
   secondary     cbox-720p (configs[1]) Msamples/s, for the record (N = 1 only; --no-secondary skips it)
 """
 import argparse
+import gc
 import json
 import math
 import os
@@ -253,8 +254,11 @@ def run(args):
     # (one context at a time: a context of this workload holds ~50 GB of path state and vertex slots — five of them alive at once ran the
     # later renders at a third of the speed)
     runs = []
-    for _ in range(max(1, args.repeats)):
+    for k_ in range(max(1, args.repeats)):
+        if os.environ.get("PPG_DEBUG_ALLOC"):
+            print("[bench] timed render %d" % k_, file=sys.stderr, flush=True)
         g_ = make(args.steps)
+        gc.collect()  # (a full collection of the interpreter's heap takes tens of ms with torch loaded: not inside a 120 ms render)
         _, dt_ = timed_render(g_)
         runs.append((dt_, g_.iterations))
         g_.engine.close()  # (not left to the garbage collector: the fifth render of five used to run beside the contexts of the four before it)
@@ -372,8 +376,9 @@ def run(args):
                                                    "us_per_bounce_of_the_longest_path": 1e3 * next((k["ms"] for k in times if k["name"] == "k_tail"), 0.0) / counts["tail_longest_paths_sum"],
                                                    "note": "a launch of k_tail cannot end before its longest path has: the sum over its launches of the longest path each finished "
                                                            "(bounces, counted from the camera: the first ones ran in the wavefront) against k_tail's total time — the average time per "
-                                                           "bounce of the lane that decides when a launch ends, crowd phase included.  k_tail is bound by this chain of dependent "
-                                                           "bounces (DESIGN.md section 7), not by bandwidth"}
+                                                           "bounce of the lane that decides when a launch ends, crowd phase included.  A large batch's k_tail is bound by this chain of "
+                                                           "dependent bounces, the k_tail of a small training round by the throughput of its crowded waves (DESIGN.md section 7) - "
+                                                           "neither by bandwidth"}
                                                   if counts.get("tail_longest_paths_sum") else None),
                            "operation_counts": alg["detail"], "kernels_ms": {k["name"]: round(k["ms"], 3) for k in times},
                            "per_kernel": {n: {q: (round(v, 4) if isinstance(v, float) else v) for q, v in e.items() if q != "kernel"} for n, e in per.items()

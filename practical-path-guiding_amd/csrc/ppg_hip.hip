@@ -89,6 +89,8 @@ struct BlockCache {
         {
             std::lock_guard<std::mutex> g(m);
             if (!maxHeld) { size_t fr = 0, tot = 0; maxHeld = hipMemGetInfo(&fr, &tot) == hipSuccess ? tot / 3 : ((size_t)32 << 30); }
+            static const bool debugAlloc = getenv("PPG_DEBUG_ALLOC") != nullptr;
+            if (debugAlloc && held + bytes > maxHeld) fprintf(stderr, "[ppg alloc] hipFree %zu MiB (cache full: %zu MiB)\n", bytes >> 20, held >> 20);
             if (held + bytes <= maxHeld) {
                 Block b{p, nullptr};
                 if (hipEventCreateWithFlags(&b.ready, hipEventDisableTiming) == hipSuccess) (void)hipEventRecord(b.ready, g_ctxStream);
@@ -143,6 +145,8 @@ template <typename T> struct DevBuf {
         hipError_t e = hipSuccess;
         if (!np) {
             e = hipMalloc(&np, want);
+            static const bool debugAlloc = getenv("PPG_DEBUG_ALLOC") != nullptr;  // every block asked of the driver (none in a steady state)
+            if (debugAlloc) fprintf(stderr, "[ppg alloc] hipMalloc %zu MiB -> %s (cache holds %zu MiB)\n", want >> 20, e == hipSuccess ? "ok" : "FAILED: cache released", g_blockCache.held >> 20);
             if (e != hipSuccess) {  // memory parked in the cache is memory the driver cannot hand out: release it and try once more
                 (void)hipGetLastError();
                 g_blockCache.trim();
