@@ -7,13 +7,15 @@ contraction) on the same counter-based sampler, and all shared accumulation is i
 """
 import ctypes as C
 import os
+import subprocess
+import sys
 import threading
 import time
 
 import numpy as np
 import pytest
 
-from conftest import CBOX_PROPS, GOLDEN, IMPROVED, make_oracle
+from conftest import CBOX_PROPS, GOLDEN, IMPROVED, ROOT, make_oracle
 
 pytestmark = pytest.mark.gpu
 
@@ -488,6 +490,51 @@ def test_round_hook_sees_the_records_of_every_round():
         # rounds: none before the first build, 2 x 1 pass, 2 x 2 passes, 2 x 4 passes, none in the final iteration
         assert len(seen) == 6 and min(n for n, _ in seen) > 0
         assert [p // (64 * 64) for _, p in seen] == [0, 0, 1, 1, 3, 3]  # path id = sample-in-round * pixels + pixel
+
+
+NCCL_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+import ppg_host
+from ppg_host.distributed import TorchReducer
+dist.init_process_group("nccl")
+props = dict(budgetType="spp", maxDepth=10, rrDepth=10, strictNormals=1, budget=45, seed=17, sampleCombination="inversevar", bsdfSamplingFractionLoss="kl",
+             spatialFilter="stochastic", directionalFilter="box", sTreeThreshold=2000, sppPerPass=1)
+e = ppg_host.Engine.hip(**props)
+e.set_scene(ppg_host.cbox_scene(64, 48)); e.set_shard(dist.get_rank(), dist.get_world_size(), 16)
+gpt = ppg_host.GuidedPathTracer(engine=e, reducer=TorchReducer(dist, torch.device("cuda", 0)))
+img = gpt.render()
+t = e.read_sdtree()
+np.savez(sys.argv[2], film=img, children=t["children"], dch=t["sampling"]["node_children"], dsum=t["sampling"]["node_sums"], theta=t["theta"])
+dist.barrier(); dist.destroy_process_group()
+"""
+
+
+def test_torch_reducer_over_rccl_one_rank_equals_unsharded(tmp_path):
+    """The reducer `bench.py --gpus N` renders with (ppg_host.distributed.TorchReducer: torch.distributed, backend "nccl" = RCCL, tensors
+    viewed over the library's device buffers) on a real communicator of ONE rank: the whole sharded control flow — SD-tree all-reduce,
+    the optimiser's records to the owners and their state back (round hook, both phases), the final iteration's groups of passes through
+    ppg_final_partials / all-reduce / ppg_final_partials_commit, the status word — with every exchange the identity.  Film, SD-tree and the
+    learned fractions equal the plain render's.  (Two ranks need two GPUs; the gloo tests of tests/test_host_logic.py cover world 2 and 4
+    with the host reducer.)"""
+    import ppg_host
+    script = tmp_path / "worker.py"
+    script.write_text(NCCL_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + os.getpid() % 2000), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, str(script), os.path.join(ROOT, "practical-path-guiding_amd"), str(tmp_path / "rank0.npz")], env=env, timeout=600,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    props = dict(CBOX_PROPS, budget=45, seed=17, sampleCombination="inversevar", bsdfSamplingFractionLoss="kl", spatialFilter="stochastic", directionalFilter="box",
+                 sTreeThreshold=2000, sppPerPass=1)
+    e = hip(**props)
+    ref_img = ppg_host.GuidedPathTracer(engine=e).render(ppg_host.cbox_scene(64, 48))
+    ref_t = e.read_sdtree()
+    got = np.load(tmp_path / "rank0.npz")
+    assert np.array_equal(got["children"], ref_t["children"])
+    assert np.array_equal(got["dch"], ref_t["sampling"]["node_children"]) and np.array_equal(got["dsum"], ref_t["sampling"]["node_sums"])
+    assert np.array_equal(got["theta"], ref_t["theta"])
+    assert np.array_equal(got["film"], ref_img, equal_nan=True)
 
 
 @pytest.mark.parametrize("scheme", ["owner", "gather"])
