@@ -1679,9 +1679,9 @@ static __global__ void k_count_valid(const unsigned long long *keys, unsigned in
 }
 
 // The deferred optimizeBsdfSamplingFraction calls of one round (include/ppg.h "Learning the BSDF sampling fraction"): one WAVE
-// per S-tree leaf walks that leaf's records in key order — 64 records are fetched at once, then applied one after the other with
-// the reference's arithmetic: the gradient at the current variable (GP:672-691), AdamOptimizer::append (GP:85-95) and step
-// (GP:97-109).  Every lane computes the same (scalar) sequence; lane 0 writes the state back.
+// per S-tree leaf walks that leaf's records in key order — 64 records are fetched at once, then applied in that order with
+// the reference's arithmetic: the gradient at the current variable (GP:672-691; every lane its own record, once per batch of append()),
+// AdamOptimizer::append (GP:85-95) and step (GP:97-109; the same scalar sequence in every lane).  Lane 0 writes the state back.
 static __global__ __launch_bounds__(256) void k_adam_apply(LeafHdr *hdr, const unsigned int *leaves, unsigned int n_leaves, const unsigned long long *keys,
                                                     const unsigned int *idx, const AdamRec *recs, unsigned int n, int loss) {
     const unsigned int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -1726,24 +1726,29 @@ static __global__ __launch_bounds__(256) void k_adam_apply(LeafHdr *hdr, const u
             const int it = iter + (int)__popcll(stepMask & ((2ull << lane) - 1ull));
             myLr = 0.01f * __builtin_sqrtf(1 - ppg_powi(0.999f, it)) / (1 - ppg_powi(0.9f, it));
         }
-        for (unsigned int t = 0; t < cnt; ++t) {
-            const float product = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pay.x), (int)t)), woPdf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pay.y), (int)t));
-            const float bsdfPdf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pay.z), (int)t)), dTreePdf = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pay.w), (int)t));
-            const float statisticalWeight = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wgt), (int)t));
-            // optimizeBsdfSamplingFraction, GP:672-691
-            const float mixPdf = samplingFraction * bsdfPdf + (1 - samplingFraction) * dTreePdf;
-            const float r = product / mixPdf;
+        for (unsigned int t = 0; t < cnt;) {
+            // Every lane: the gradient of ITS record at the current variable (optimizeBsdfSamplingFraction, GP:672-691).  The records up to the
+            // next step see the same variable, so one evaluation — two IEEE divisions, the longest links of the chain — serves the whole
+            // batch (two records at weight 1, three at the kick-start's 0.5) instead of one evaluation per record; the lanes beyond the
+            // batch compute values nobody reads.  Same expressions, same order of the sums: same bits.
+            const float mixPdf = samplingFraction * pay.z + (1 - samplingFraction) * pay.w;
+            const float r = pay.x / mixPdf;
             const float ratio = (loss == LOSS_KL) ? r : r * r;
-            const float dLoss_dSamplingFraction = -ratio / woPdf * (bsdfPdf - dTreePdf);
+            const float dLoss_dSamplingFraction = -ratio / pay.y * (pay.z - pay.w);
             const float dLoss_dVariable = dLoss_dSamplingFraction * dFraction;
             const float lossGradient = l2RegGradient + dLoss_dVariable;
-            // AdamOptimizer::append, GP:85-95 (batchSize = 1)
-            batchGradient += lossGradient * statisticalWeight;
-            batchAccumulation += statisticalWeight;
-            if (batchAccumulation > 1.0f) {
+            const float weighted = lossGradient * wgt;
+            bool step = false;
+            do {  // AdamOptimizer::append, GP:85-95 (batchSize = 1)
+                batchGradient += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(weighted), (int)t));
+                batchAccumulation += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wgt), (int)t));
+                step = batchAccumulation > 1.0f;
+                ++t;
+            } while (!step && t < cnt);
+            if (step) {
                 const float gradient = batchGradient / batchAccumulation;  // step(), GP:97-109
                 ++iter;
-                const float lr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myLr), (int)t));
+                const float lr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myLr), (int)(t - 1u)));
                 firstMoment = 0.9f * firstMoment + (1 - 0.9f) * gradient;
                 secondMoment = 0.999f * secondMoment + (1 - 0.999f) * gradient * gradient;
                 variable -= lr * firstMoment / (__builtin_sqrtf(secondMoment) + 1e-08f);
