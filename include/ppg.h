@@ -275,7 +275,9 @@ int ppg_end_iteration(ppg_ctx *ctx);                      /* GP:1417-1422: optio
 int ppg_end_render(ppg_ctx *ctx);                         /* GP:1567-1582: inverse-variance combination into the film */
 
 /* Integrator::cancel() (IH:84, GP:1643-1648).  Thread-safe; the running ppg_render / ppg_render_passes
-   call returns PPG_ERR_CANCELLED. */
+   call returns PPG_ERR_CANCELLED.  The request is sticky: with no render under way — the context exists and its scene is still being set
+   up, seconds of BVH build — it cancels the NEXT one (ppg_begin_render / ppg_render return PPG_ERR_CANCELLED at once and consume it).  A
+   request a render has acted on is spent and does not reach the render after it. */
 int ppg_cancel(ppg_ctx *ctx);
 /* Device blocks released by contexts (buffer growth, ppg_destroy) are kept by the library — at most a third of the device's memory —
    and handed to the next allocation that fits, of this or another context (hipMalloc / hipFree of hundreds of MB are synchronous,
@@ -360,17 +362,24 @@ int ppg_finish_passes(ppg_ctx *ctx, ppg_pass_stats *stats);   /* GP:1288-1328 on
  *     ppg_final_group_passes(n) = 16 * ceil(n / 1024) consecutive passes (at most 64 groups);
  *   - a group's samples are summed per pixel in sample order, from zero, into the group's partial (image, squared image, weight);
  *   - the call's image / squared image / weights and the iteration's film are the partials added in group order.
- * Sharded: group g is rendered by rank g % world; between ppg_render_passes_nostat() and ppg_finish_passes() the host all-reduces (sum,
- * float) the n_floats at `dev` — [film 3 n][film weights n][groups x (image 3 n, squared image 3 n, weights n)], n = pixels; every slot is
- * non-zero on one rank only and the film head (the tile-sharded training passes an `automatic` render adds to the same iteration, GP:1400-1405)
- * has disjoint supports, so the sums are exact — and calls ppg_final_partials_commit().  Afterwards image and film are complete on every
- * rank: no ppg_image_buffers / ppg_film_buffers exchange for this iteration.  n_floats = 0: not a sharded final iteration, exchange the
- * image buffers as usual.
+ * Sharded: WHO renders a group does not enter the sums, so it is chosen by count.  With at least two groups per rank (groups >= 2 * world)
+ * group g is rendered by rank g % world over the whole film; with fewer — a 13-pass final iteration is ONE group, one of 64 passes four —
+ * every rank renders every group on its own tiles (ppg_set_shard), or most ranks would idle through half of the render's samples.  Either
+ * way, between ppg_render_passes_nostat() and ppg_finish_passes() the host all-reduces (sum, float) the n_floats at `dev` —
+ * [film 3 n][film weights n][groups x (image 3 n, squared image 3 n, weights n)], n = pixels; every pixel of a slot is non-zero on one rank
+ * only and the film head (the tile-sharded training passes an `automatic` render adds to the same iteration, GP:1400-1405) has disjoint
+ * supports, so the sums are exact — and calls ppg_final_partials_commit().  Afterwards image and film are complete on every rank: no
+ * ppg_image_buffers / ppg_film_buffers exchange for this iteration.  n_floats = 0: not a sharded final iteration (one rank, or a time
+ * budget), exchange the image buffers as usual.  n_floats depends only on the film size and the pass count (4 n + groups * 7 n): a rank
+ * that failed can still join the collective, with zeros.
  * ---------------------------------------------------------------------------------------------- */
 /* budgetType = seconds in a sharded render: every decision the reference takes by its clock (GP:1259-1262 inside performRenderPasses,
    GP:1434-1514 in renderTime) must come out the same on all ranks, or they would render different numbers of passes and their collectives
    would stop matching.  The stop hook is asked after every batch of passes with this rank's own decision (elapsed whole seconds > budget) and
-   returns the one all ranks follow — rank 0's, broadcast.  The host loop does the same with the times it measures. */
+   returns the one all ranks follow — rank 0's.  The exchange behind it also carries the ranks' status words (host/rccl_reducer.h
+   stopDecision: one all-reduce of {decision, status}): a rank that was cancelled asks the hook once more (local_stop = 1) before it leaves
+   the batch loop, so it meets the others in the exchange they are in, every rank stops there, and the image exchange that follows aborts
+   the render on all of them.  The host loop passes the times it measures through a broadcast of rank 0's. */
 typedef int (*ppg_stop_hook)(void *user, int local_stop);
 int ppg_set_stop_hook(ppg_ctx *ctx, ppg_stop_hook hook, void *user);
 /* The HIP stream (hipStream_t) the context's kernels run on.  A reducer that enqueues its collectives on it needs no host synchronisation

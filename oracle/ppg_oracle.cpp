@@ -2483,6 +2483,8 @@ public:
     uint64_t m_work[CNT_N] = {};
     uint64_t m_lenHist[PPGO_LEN_HIST] = {};  // paths by final rRec.depth (last bin: that or longer) — sizes the GPU's tail phase
     volatile bool cancelled = false;
+    bool m_cancelSeen = false;  // the render under way has acted on the flag: beginRender does not apply it to the next one (the product's rule)
+    bool seesCancel() { if (!cancelled) return false; m_cancelSeen = true; return true; }
     ppg_pass_hook passHook = nullptr;
     void *passHookUser = nullptr;
     ppg_stop_hook stopHook = nullptr;
@@ -2598,7 +2600,13 @@ public:
         bool drain = false;
         m_hookFailed = false;
         for (int i = 0; i < numPasses;) {
-            if (cancelled) { if (rounds && passHook) drain = true; else break; }
+            if (seesCancel()) {
+                if (rounds && passHook) drain = true;
+                else {  // (a sharded time budget: meet the other ranks in the stop hook they are about to ask — the product's rule)
+                    if (m_budgetType == ESeconds && stopHook) (void)stopHook(stopHookUser, 1);
+                    break;
+                }
+            }
             const int n = std::min(roundPasses, numPasses - i);
             m_roundStartPass = m_passesRendered;
             for (int k = 0; k < n; ++k) {
@@ -2632,21 +2640,24 @@ public:
         for (size_t i = 0; i < n; ++i) { m_imageW[i] += slot[6 * n + i]; m_filmW[i] += slot[6 * n + i]; }
     }
     // The passes of a final iteration: groups of finalGroupPasses(numPasses) passes, each summed from zero, added in group order; rank r of a
-    // sharded render renders groups r, r + world, ... over the whole film and leaves its slots for the exchange.
+    // sharded render renders groups r, r + world, ... over the whole film — or, when there are fewer than two groups per rank, every group on
+    // its own tiles (the product's rule, ppg_hip.hip finalGroupsByRank) — and leaves its slots for the exchange.
     void renderFinalGroups(int numPasses) {
         const int G = finalGroupPasses(numPasses), nGroups = (numPasses + G - 1) / G;
         const size_t n = (size_t)W() * H();
         m_partials.assign(4 * n + (size_t)nGroups * 7 * n, 0.0f);
         const int firstPass = m_passesRendered;
-        m_allPixels = shardWorld > 1;
-        for (int g = shardRank; g < nGroups && !cancelled; g += shardWorld) {
+        const bool byRank = shardWorld > 1 && nGroups >= 2 * shardWorld;
+        m_allPixels = byRank;
+        const uint64_t pixelsMine = byRank || shardWorld <= 1 ? (uint64_t)n : ownedPixels();
+        for (int g = byRank ? shardRank : 0; g < nGroups && !seesCancel(); g += byRank ? shardWorld : 1) {
             Float *slot = m_partials.data() + 4 * n + (size_t)g * 7 * n;
             m_accImage = slot; m_accSq = slot + 3 * n; m_accW = slot + 6 * n;
             const int cnt = std::min(G, numPasses - g * G);
             for (int k = 0; k < cnt; ++k) {
                 m_passesRendered = firstPass + g * G + k;
                 renderOnePass();
-                m_samplesLocal += n * (uint64_t)m_sppPerPass;
+                m_samplesLocal += pixelsMine * (uint64_t)m_sppPerPass;
             }
             if (shardWorld <= 1) addGroup(slot);
         }
@@ -3099,7 +3110,8 @@ public:
     }
 
     // ---- render() and its drivers ----
-    void beginRender() {  // GP:1519-1550
+    // false: a cancel that arrived before the render began is consumed and cancels it (the product's sticky ppg_cancel)
+    bool beginRender() {  // GP:1519-1550
         m_sdTree.reset(new STree(scene.aabb));
         m_iter = 0;
         m_isFinalIter = false;
@@ -3110,7 +3122,12 @@ public:
         m_images.clear(); m_variances.clear();
         m_startTime = std::chrono::steady_clock::now();
         m_passesRendered = 0; m_passesRenderedThisIter = 0;
-        cancelled = false;
+        {
+            const bool pending = cancelled, spent = m_cancelSeen;
+            cancelled = false; m_cancelSeen = false;
+            if (pending && !spent) return false;
+        }
+        return true;
     }
     void beginIteration(bool isFinal) {  // GP:1378-1381
         m_isFinalIter = isFinal;
@@ -3163,7 +3180,7 @@ public:
             beginIteration(passesThisIteration >= remainingPasses);
             ppg_pass_stats st;
             renderPassesNoStat(passesThisIteration); finishPasses(&st);
-            if (cancelled) { result = false; break; }
+            if (seesCancel()) { result = false; break; }
             Float variance = st.variance;
             const Float lastVarAtEnd = currentVarAtEnd;
             currentVarAtEnd = passesThisIteration * variance / remainingPasses;
@@ -3172,7 +3189,7 @@ public:
                 (remainingPasses < passesThisIteration || (sppRendered > 256 && currentVarAtEnd > lastVarAtEnd))) {
                 m_isFinalIter = true;
                 renderPassesNoStat(remainingPasses); finishPasses(&st);
-                if (cancelled) { result = false; break; }
+                if (seesCancel()) { result = false; break; }
             }
             buildSDTree(nullptr);
             endIteration();
@@ -3194,7 +3211,7 @@ public:
             beginIteration(false);
             ppg_pass_stats st;
             renderPassesNoStat(passesThisIteration); finishPasses(&st);
-            if (cancelled) { result = false; break; }
+            if (seesCancel()) { result = false; break; }
             Float variance = st.variance;
             const Float secondsIter = computeElapsedSeconds(startIter);
             const Float lastVarAtEnd = currentVarAtEnd;
@@ -3205,7 +3222,7 @@ public:
                 m_isFinalIter = true;
                 do {
                     renderPassesNoStat(passesThisIteration); finishPasses(&st);
-                    if (cancelled) { result = false; break; }
+                    if (seesCancel()) { result = false; break; }
                     elapsedSeconds = computeElapsedSeconds(m_startTime);
                 } while (elapsedSeconds < nSeconds);
             }
@@ -3217,7 +3234,7 @@ public:
     }
 
     bool render() {  // GP:1516-1585
-        beginRender();
+        if (!beginRender()) return false;
         bool result = m_budgetType == ESpp ? renderSPP() : renderTime();
         endRender();
         return result;
@@ -3390,7 +3407,7 @@ int ppgo_set_shard(ppgo_ctx *ctx, int32_t rank, int32_t world, int32_t tile_size
 #define NEED_TREE if (!ctx->gpt.m_sdTree) { ctx->gpt.error = "render not begun"; return PPG_ERR_STATE; }
 
 int ppgo_render(ppgo_ctx *ctx) { NEED_SCENE return ctx->gpt.render() ? PPG_OK : PPG_ERR_CANCELLED; }
-int ppgo_begin_render(ppgo_ctx *ctx) { NEED_SCENE ctx->gpt.beginRender(); return PPG_OK; }
+int ppgo_begin_render(ppgo_ctx *ctx) { NEED_SCENE return ctx->gpt.beginRender() ? PPG_OK : PPG_ERR_CANCELLED; }
 int ppgo_begin_iteration(ppgo_ctx *ctx, int32_t is_final) { NEED_TREE ctx->gpt.beginIteration(is_final != 0); return PPG_OK; }
 int ppgo_set_final(ppgo_ctx *ctx, int32_t is_final) { ctx->gpt.m_isFinalIter = is_final != 0; return PPG_OK; }
 int ppgo_set_do_nee(ppgo_ctx *ctx, int32_t do_nee) { ctx->gpt.m_doNee = do_nee != 0; return PPG_OK; }
@@ -3398,14 +3415,14 @@ int ppgo_render_passes_nostat(ppgo_ctx *ctx, int32_t n) {
     NEED_TREE
     ctx->gpt.renderPassesNoStat(n);
     if (ctx->gpt.m_hookFailed) { ctx->gpt.error = "round hook failed"; return PPG_ERR_INVALID; }
-    return ctx->gpt.cancelled ? PPG_ERR_CANCELLED : PPG_OK;
+    return ctx->gpt.seesCancel() ? PPG_ERR_CANCELLED : PPG_OK;
 }
 int ppgo_finish_passes(ppgo_ctx *ctx, ppg_pass_stats *st) { NEED_TREE ctx->gpt.finishPasses(st); return PPG_OK; }
 int ppgo_render_passes(ppgo_ctx *ctx, int32_t n, ppg_pass_stats *st) {
     NEED_TREE
     ctx->gpt.renderPassesNoStat(n);
     ctx->gpt.finishPasses(st);
-    return ctx->gpt.cancelled ? PPG_ERR_CANCELLED : PPG_OK;
+    return ctx->gpt.seesCancel() ? PPG_ERR_CANCELLED : PPG_OK;
 }
 int ppgo_build_sdtree(ppgo_ctx *ctx, ppg_tree_stats *st) { NEED_TREE ctx->gpt.buildSDTree(st); return PPG_OK; }
 int ppgo_end_iteration(ppgo_ctx *ctx) { NEED_TREE ctx->gpt.endIteration(); return PPG_OK; }

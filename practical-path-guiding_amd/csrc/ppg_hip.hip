@@ -563,7 +563,11 @@ struct ppg_ctx {
     DevBuf<unsigned long long> d_adamKeys[2];
     DevBuf<unsigned int> d_adamIdx[2], d_adamNv, d_adamBase, d_adamCount;
     DevBuf<AdamRec> d_adamRecs, d_adamRecsOut;
+    DevBuf<float4> d_splat;       // a round's splat records (k_commit_records), at the positions of the optimiser's records
+    bool sortedCommit = false;    // this round commits through records + sort + k_splat_sorted instead of k_commit
+    unsigned int adamFlagShift = 0;  // key bit of "a splat only" in such a round: just above the leaf bits
     DevBuf<unsigned char> d_sortTemp;
+    DevBuf<unsigned int> d_adamLeafCount[2], d_adamLeafOrder[2];  // k_adam_apply's order of the D-trees: most records first
     size_t adamIota = 0;          // d_adamIdx[0][0 .. adamIota) holds the identity permutation
     bool adamFast = false;        // record positions known in advance (DevTree::adam_base)
     bool adamActive = false;      // a round of the optimiser is being rendered
@@ -593,6 +597,9 @@ struct ppg_ctx {
     bool tuneNoSortFirst = false;     // PPG_NO_SORT_FIRST: the first bounce of a batch unsorted through the complete k_shade<FULL>
     bool tuneNoSplit = false;         // PPG_NO_SPLIT: one k_shade<FULL> over the whole sorted slice instead of k_shade<.., MSET_COMMON> + the rest
     bool tuneNoOverlap = false;       // PPG_NO_OVERLAP: k_commit after k_tail on one stream instead of beside it
+    bool tuneNoSortedCommit = false;  // PPG_NO_SORTED_COMMIT: a round of the optimiser commits with k_commit (global atomics) instead of records + sort + k_splat_sorted
+    unsigned int tuneSplatLdsNodes = PPG_SPLAT_NODES;  // PPG_SPLAT_LDS_NODES: k_splat_sorted stages D-trees of up to this many nodes in LDS (<= PPG_SPLAT_NODES)
+    bool tuneAdamUnordered = false;   // PPG_ADAM_UNORDERED: k_adam_apply takes the D-trees in leaf order instead of busiest first
     int tuneBulkBounces = -1;         // PPG_BULK_BOUNCES: fixed number of wavefront bounces before k_tail takes over (-1 = adaptive)
     bool debugBatch = false;          // PPG_DEBUG_BATCH: one line per batch on stderr (paths, live paths after every bulk bounce, tail time)
     int tuneFinalBatch = 0;           // PPG_FINAL_BATCH: passes per batch of the final iteration (0 = 64)
@@ -611,6 +618,8 @@ struct ppg_ctx {
     int iter = 0, passesRendered = 0, passesRenderedThisIter = 0, passesLocal = 0;
     std::chrono::steady_clock::time_point startTime, passStart;
     std::atomic<bool> cancelled{false};
+    bool cancelSeen = false;  // the render under way has acted on the flag (seesCancel): ppg_begin_render then does not apply it to the next one
+    bool seesCancel() { if (!cancelled.load()) return false; cancelSeen = true; return true; }
     float lastVariance = 0;
     ppg_pass_stats lastStats{};
     KernelTimer timer;
@@ -675,6 +684,8 @@ void ppg_launch_tail(int variant, const TailLaunch &a) {
     }
 }
 void ppg_launch_commit(int sf, int df, const CommitLaunch &a) { ppg_launch_commit_all(sf, df, a); }
+void ppg_launch_commit_records(int sf, const CommitLaunch &a) { ppg_launch_commit_records_all(sf, a); }
+void ppg_launch_splat(int df, const SplatLaunch &a) { ppg_launch_splat_all(df, a); }
 namespace {
 
 template <typename F> void timedLaunch(ppg_ctx *ctx, const char *name, uint64_t units, F &&launch) {
@@ -1013,17 +1024,26 @@ int applyAdamRound(ppg_ctx *ctx, size_t nRecords) {
     unsigned int leafBits = 1;
     while ((1u << leafBits) <= nNodes) ++leafBits;  // every leaf index is below the all-ones pattern of a hole
     const unsigned int endBit = PPG_ADAM_LEAF_SHIFT + leafBits;
+    if (ctx->sortedCommit && ctx->adamFlagShift != endBit) { ctx->error = "internal: flag bit of the round's records"; return PPG_ERR_STATE; }
     size_t n = nRecords;
     if (n > 0) {
         int rc = PPG_OK;
-        timedLaunch(ctx, "adam_sort(rocprim)", n, [&] { rc = sortAdamRecords(ctx, n, ctx->adamFast ? PPG_ADAM_LEAF_SHIFT : 0u, endBit); });
+        // (a round committed through records: one more bit, "a splat only", just above the leaf — those records sort behind the optimiser's)
+        timedLaunch(ctx, "adam_sort(rocprim)", n, [&] { rc = sortAdamRecords(ctx, n, ctx->adamFast ? PPG_ADAM_LEAF_SHIFT : 0u, endBit + (ctx->sortedCommit ? 1u : 0u)); });
         if (rc) return rc;
+        if (ctx->sortedCommit) {  // DTree::recordIrradiance of every record of the round, D-tree by D-tree (ppg_kernels.h "The commit of a ROUND")
+            const unsigned int chunks = (unsigned int)((n + PPG_SPLAT_CHUNK - 1) / PPG_SPLAT_CHUNK);
+            SplatLaunch a{(int)std::max(1u, std::min(chunks, 256u * 8u)), s, ctx->devTree(), ctx->d_adamKeys[1].p, ctx->d_adamIdx[1].p, ctx->d_splat.p, (unsigned int)n, leafBits, ctx->tuneSplatLdsNodes};
+            timedLaunch(ctx, "k_splat_sorted", n, [&] { ppg_launch_splat(ctx->directionalFilter, a); });
+            HIP_CHECK(hipGetLastError());
+        }
     }
     if (ctx->passHook) {
         // hand the valid records over in key order, compact
         unsigned int nValid = 0;
         if (n > 0) {
-            hipLaunchKernelGGL(k_count_valid, dim3(1), dim3(1), 0, s, ctx->d_adamKeys[1].p, (unsigned int)n, ctx->d_adamCount.p);
+            hipLaunchKernelGGL(k_count_valid, dim3(1), dim3(1), 0, s, ctx->d_adamKeys[1].p, (unsigned int)n, ctx->d_adamCount.p,
+                               ctx->sortedCommit ? (1ull << ctx->adamFlagShift) : ~0ull);  // (the optimiser's records come first)
             HIP_CHECK(hipMemcpyAsync(&nValid, ctx->d_adamCount.p, 4, hipMemcpyDeviceToHost, s));
             HIP_CHECK(hipStreamSynchronize(s));
             HIP_CHECK(ctx->d_adamRecsOut.reserve(std::max<size_t>(1, nValid)));
@@ -1046,8 +1066,24 @@ int applyAdamRound(ppg_ctx *ctx, size_t nRecords) {
     }
     if (n > 0) {
         const unsigned int nl = (unsigned int)ctx->leaves.size();
+        // One wave per D-tree walks its records as a serial chain, so the launch lasts as long as its busiest D-tree — if that one starts
+        // last, everything else has finished by then: the D-trees are taken in descending order of their record counts.
+        const unsigned int *order = nullptr;
+        if (!ctx->tuneAdamUnordered && nl > 1) {
+            for (int k = 0; k < 2; ++k) { HIP_CHECK(ctx->d_adamLeafCount[k].reserve(nl)); HIP_CHECK(ctx->d_adamLeafOrder[k].reserve(nl)); }
+            size_t bytes = 0;
+            HIP_CHECK(rocprim::radix_sort_pairs_desc(nullptr, bytes, ctx->d_adamLeafCount[0].p, ctx->d_adamLeafCount[1].p, ctx->d_adamLeafOrder[0].p, ctx->d_adamLeafOrder[1].p, (size_t)nl, 0u, 32u, s));
+            HIP_CHECK(ctx->d_sortTemp.reserve(std::max<size_t>(bytes, 16)));
+            timedLaunch(ctx, "adam_order", nl, [&] {
+                hipLaunchKernelGGL(k_adam_counts, dim3((nl + 255u) / 256u), dim3(256), 0, s, ctx->d_leaves.p, nl, ctx->d_adamKeys[1].p, (unsigned int)n, ctx->d_adamLeafCount[0].p,
+                                   ctx->d_adamLeafOrder[0].p);
+                (void)rocprim::radix_sort_pairs_desc((void *)ctx->d_sortTemp.p, bytes, ctx->d_adamLeafCount[0].p, ctx->d_adamLeafCount[1].p, ctx->d_adamLeafOrder[0].p,
+                                                     ctx->d_adamLeafOrder[1].p, (size_t)nl, 0u, 32u, s);
+            });
+            order = ctx->d_adamLeafOrder[1].p;
+        }
         timedLaunch(ctx, "k_adam_apply", n, [&] {
-            hipLaunchKernelGGL(k_adam_apply, dim3((nl * 64u + 255u) / 256u), dim3(256), 0, s, ctx->d_hdr.p, ctx->d_leaves.p, nl, ctx->d_adamKeys[1].p, ctx->d_adamIdx[1].p,
+            hipLaunchKernelGGL(k_adam_apply, dim3((nl * 64u + 255u) / 256u), dim3(256), 0, s, ctx->d_hdr.p, ctx->d_leaves.p, order, nl, ctx->d_adamKeys[1].p, ctx->d_adamIdx[1].p,
                                ctx->d_adamRecs.p, (unsigned int)n, ctx->loss);
         });
         HIP_CHECK(hipGetLastError());
@@ -1067,11 +1103,11 @@ int applyAdamRound(ppg_ctx *ctx, size_t nRecords) {
 // A launch of whole groups of a final iteration's passes (include/ppg.h "Final iteration: groups of passes"): `batch` passes = groups of
 // groupPasses passes (the last one may be shorter; or a part of ONE group when groupPasses >= batch), the first starting at pass
 // firstPass of the render, consecutive groups of the launch stridePasses apart; group k accumulates into slot slot0 + k * slotStride.
-struct GroupLaunch { unsigned int firstPass, groupPasses, stridePasses, slot0, slotStride; };
+struct GroupLaunch { unsigned int firstPass, groupPasses, stridePasses, slot0, slotStride; bool wholeFilm; };
 
 int renderBatch(ppg_ctx *ctx, int batch, bool adamRound, const GroupLaunch *gl = nullptr) {
     PathState P = ctx->paths;
-    if (gl && ctx->shardWorld > 1) { P.n_pix = ctx->nPixAll; P.pixels = ctx->d_pixelsAll.p; }  // the whole film, not this rank's tiles
+    if (gl && gl->wholeFilm && ctx->shardWorld > 1) { P.n_pix = ctx->nPixAll; P.pixels = ctx->d_pixelsAll.p; }  // the whole film, not this rank's tiles
     P.n_paths = (unsigned int)((size_t)P.n_pix * ctx->sppPerPass * (size_t)batch);
     if (P.n_paths == 0 && !(adamRound && ctx->passHook)) return PPG_OK;
     hipStream_t s = ctx->stream;
@@ -1207,6 +1243,14 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound, const GroupLaunch *gl =
     const bool commit = !ctx->isFinalIter && P.n_paths > 0;
     const bool overlap = tail && commit && !ctx->timer.enabled && !ctx->tuneNoOverlap;
     const bool fastRound = adamRound && ctx->adamFast && P.n_paths > 0;
+    // A round whose record positions are known commits in three steps — records, the optimiser's sort, splats D-tree by D-tree
+    // (ppg_kernels.h "The commit of a ROUND") — instead of one lane per vertex adding to the pool with global atomics.
+    ctx->sortedCommit = adamRound && ctx->adamFast && !ctx->tuneNoSortedCommit;
+    {
+        unsigned int leafBits = 1;
+        while ((1u << leafBits) <= (unsigned int)ctx->snodes.size()) ++leafBits;
+        ctx->adamFlagShift = PPG_ADAM_LEAF_SHIFT + leafBits;
+    }
     size_t nRecords = 0;
     unsigned int *dense = Q.items[1];  // the live paths in one list (k_tail's work list)
     auto launchTail = [&] {
@@ -1239,8 +1283,9 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound, const GroupLaunch *gl =
         const unsigned int *list = mode == 2 ? dense : nullptr;
         const unsigned long long *listN = mode == 2 ? ctx->d_total.p : nullptr;
         const PathState &PP = mode == 2 ? P : Pc;  // the stragglers' words changed in the tail: read them in place
-        CommitLaunch a{grid, st, PP, T, R, Q, nv8, list, listN};
-        ppg_launch_commit(ctx->spatialFilter, ctx->directionalFilter, a);
+        CommitLaunch a{grid, st, PP, T, R, Q, nv8, list, listN, ctx->d_splat.p, ctx->adamFlagShift};
+        if (ctx->sortedCommit) ppg_launch_commit_records(ctx->spatialFilter, a);
+        else ppg_launch_commit(ctx->spatialFilter, ctx->directionalFilter, a);
     };
     if (tail) {
         if (bouncesRun == 0)  // no wavefront bounce was run: every path of the batch goes to the persistent threads
@@ -1285,6 +1330,7 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound, const GroupLaunch *gl =
             nRecords = (size_t)ctx->h_round[65] + ctx->h_round[66];
             if (nRecords > 0xfffffff0ull) { ctx->error = "too many Adam records in one round"; return PPG_ERR_NOMEM; }
             HIP_CHECK(ctx->d_adamKeys[0].reserve(std::max<size_t>(1, nRecords))); HIP_CHECK(ctx->d_adamRecs.reserve(std::max<size_t>(1, nRecords)));
+            if (ctx->sortedCommit) HIP_CHECK(ctx->d_splat.reserve(std::max<size_t>(1, nRecords)));
             if (nRecords) HIP_CHECK(hipMemsetAsync(ctx->d_adamKeys[0].p, 0xff, nRecords * 8, s));
             T = ctx->devTree();
         }
@@ -1300,7 +1346,7 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound, const GroupLaunch *gl =
         HIP_CHECK(hipStreamWaitEvent(s, ctx->evJoin, 0));
         launchCommit(s, 2);
     } else if (commit) {
-        timedLaunch(ctx, "k_commit", P.n_paths, [&] { launchCommit(s, 0); });
+        timedLaunch(ctx, ctx->sortedCommit ? "k_commit_records" : "k_commit", P.n_paths, [&] { launchCommit(s, 0); });
     }
     if (adamRound) {
         if (!ctx->adamFast) {
@@ -1335,9 +1381,16 @@ int addGroups(ppg_ctx *ctx, unsigned int first, unsigned int count) {
                        ctx->d_image.p, ctx->d_sq.p, ctx->d_imageW.p, ctx->d_film.p, ctx->d_filmW.p);
     return PPG_OK;
 }
+// How the groups of a sharded final iteration are dealt (include/ppg.h "Final iteration: groups of passes"): whole groups to the ranks when
+// there are at least two per rank, otherwise every group to every rank ON ITS TILES — a 13-pass final iteration is ONE group, which one rank
+// would render alone.  The sums a pixel's samples go through are the same either way (a group's partial per pixel, the partials in group
+// order), so the picture does not depend on the choice.
+static bool finalGroupsByRank(unsigned int nGroups, unsigned int world) { return world > 1 && nGroups >= 2u * world; }
+
 int renderFinalGroups(ppg_ctx *ctx, int numPasses) {
     const unsigned int G = (unsigned int)ppg_final_group_passes(numPasses), nGroups = ((unsigned int)numPasses + G - 1) / G;
     const unsigned int world = (unsigned int)ctx->shardWorld, rank = (unsigned int)ctx->shardRank;
+    const bool byRank = finalGroupsByRank(nGroups, world);  // else: all groups, this rank's tiles (world == 1: the whole film)
     const size_t n = ctx->nPixAll;
     const unsigned int perLaunch = std::max(1u, (unsigned int)ctx->maxBatchFinal / G);  // whole groups per launch (G <= maxBatchFinal), else parts of one group
     const unsigned int slots = world > 1 ? nGroups : perLaunch;
@@ -1349,30 +1402,32 @@ int renderFinalGroups(ppg_ctx *ctx, int numPasses) {
     HIP_CHECK(hipMemsetAsync(ctx->d_partials.p, 0, floats * 4, ctx->stream));
     const unsigned int firstPassAbs = (unsigned int)ctx->passesRendered;
     std::vector<unsigned int> mine;
-    for (unsigned int g = rank; g < nGroups; g += world) mine.push_back(g);
+    for (unsigned int g = byRank ? rank : 0u; g < nGroups; g += byRank ? world : 1u) mine.push_back(g);
+    const unsigned int step = byRank ? world : 1u;  // distance between this rank's consecutive groups
+    const uint64_t pixelsMine = byRank || world == 1 ? (uint64_t)n : (uint64_t)ctx->nPix;
     auto passesOf = [&](unsigned int g) { return std::min(G, (unsigned int)numPasses - g * G); };
     bool stop = false;
     for (size_t m = 0; m < mine.size() && !stop;) {
-        if (ctx->cancelled.load()) break;
+        if (ctx->seesCancel()) break;
         if (G <= (unsigned int)ctx->maxBatchFinal) {
             const size_t cnt = std::min<size_t>(perLaunch, mine.size() - m);
             unsigned int batch = 0;
             for (size_t q = 0; q < cnt; ++q) batch += passesOf(mine[m + q]);
-            GroupLaunch gl{firstPassAbs + mine[m] * G, G, world * G, world > 1 ? mine[m] : 0u, world > 1 ? world : 1u};
+            GroupLaunch gl{firstPassAbs + mine[m] * G, G, step * G, world > 1 ? mine[m] : 0u, world > 1 ? step : 1u, byRank};
             int rc = renderBatch(ctx, (int)batch, false, &gl);
             if (rc) return rc;
-            ctx->samplesLocal += (uint64_t)n * batch * ctx->sppPerPass;
+            ctx->samplesLocal += pixelsMine * batch * ctx->sppPerPass;
             if (world == 1) addGroups(ctx, 0, (unsigned int)cnt);
             m += cnt;
         } else {  // a group larger than a launch: its parts accumulate into the same slot one after the other
             const unsigned int g = mine[m], total = passesOf(g);
             for (unsigned int done = 0; done < total;) {
-                if (ctx->cancelled.load()) { stop = true; break; }
+                if (ctx->seesCancel()) { stop = true; break; }
                 const unsigned int batch = std::min((unsigned int)ctx->maxBatchFinal, total - done);
-                GroupLaunch gl{firstPassAbs + g * G + done, batch, batch, world > 1 ? g : 0u, 1u};
+                GroupLaunch gl{firstPassAbs + g * G + done, batch, batch, world > 1 ? g : 0u, 1u, byRank};
                 int rc = renderBatch(ctx, (int)batch, false, &gl);
                 if (rc) return rc;
-                ctx->samplesLocal += (uint64_t)n * batch * ctx->sppPerPass;
+                ctx->samplesLocal += pixelsMine * batch * ctx->sppPerPass;
                 done += batch;
             }
             if (world == 1 && !stop) addGroups(ctx, 0, 1);
@@ -1382,7 +1437,7 @@ int renderFinalGroups(ppg_ctx *ctx, int numPasses) {
     }
     ctx->passesRendered += numPasses; ctx->passesRenderedThisIter += numPasses; ctx->passesLocal += numPasses;
     if (world > 1) { ctx->partialsPending = true; ctx->pendingGroups = nGroups; }
-    return ctx->cancelled.load() ? PPG_ERR_CANCELLED : PPG_OK;
+    return ctx->seesCancel() ? PPG_ERR_CANCELLED : PPG_OK;
 }
 
 int renderPassesNoStat(ppg_ctx *ctx, int numPasses) {  // GP:1217-1286
@@ -1407,7 +1462,15 @@ int renderPassesNoStat(ppg_ctx *ctx, int numPasses) {  // GP:1217-1286
     // status word) — instead of leaving for an exchange the others are not in.  They all see the status and abort together.
     bool drain = false;
     for (int i = 0; i < numPasses;) {
-        if (ctx->cancelled.load()) { if (rounds && ctx->passHook) drain = true; else break; }
+        if (ctx->seesCancel()) {
+            if (rounds && ctx->passHook) drain = true;
+            else {
+                // (a sharded time budget: the other ranks are about to ask the stop hook after the batch they are rendering — this rank asks it
+                // too, once, so that they meet in the same exchange; the host's hook carries its status word there and every rank stops)
+                if (ctx->budgetType == 1 && ctx->stopHook) (void)ctx->stopHook(ctx->stopHookUser, 1);
+                break;
+            }
+        }
         const int batch = std::min(roundPasses, numPasses - i);
         int rc = renderBatch(ctx, drain ? 0 : batch, rounds);
         if (rc) return rc;
@@ -1423,7 +1486,7 @@ int renderPassesNoStat(ppg_ctx *ctx, int numPasses) {  // GP:1217-1286
             HIP_CHECK(hipStreamSynchronize(ctx->stream));  // bound the launch queue; also lets ppg_cancel() take effect
         }
     }
-    return ctx->cancelled.load() ? PPG_ERR_CANCELLED : PPG_OK;
+    return ctx->seesCancel() ? PPG_ERR_CANCELLED : PPG_OK;
 }
 
 int finishPasses(ppg_ctx *ctx, ppg_pass_stats *st) {  // GP:1288-1328
@@ -1536,8 +1599,15 @@ int beginRender(ppg_ctx *ctx) {  // GP:1519-1550
 #endif
     ctx->startTime = std::chrono::steady_clock::now();
     ctx->passesRendered = 0; ctx->passesRenderedThisIter = 0;
-    ctx->cancelled.store(false);
     ctx->treeAlive = true;
+    // ppg_cancel() is sticky: a cancel no render has acted on yet — it arrived while the scene was being set up, say, seconds of BVH build —
+    // cancels THIS render; the flag is consumed here (it used to be cleared, and that cancel was lost).  One the previous render DID act on
+    // (it returned PPG_ERR_CANCELLED, or left through a failing hook) is spent.
+    {
+        const bool pending = ctx->cancelled.exchange(false), spent = ctx->cancelSeen;
+        ctx->cancelSeen = false;
+        if (pending && !spent) { ctx->error = "cancelled before the render began"; return PPG_ERR_CANCELLED; }
+    }
     return PPG_OK;
 }
 
@@ -1797,6 +1867,9 @@ int ppg_create(const ppg_config *cfg, ppg_ctx **out) {
         c->tuneNoSplit = getenv("PPG_NO_SPLIT") != nullptr;
         c->tuneNoSortFirst = getenv("PPG_NO_SORT_FIRST") != nullptr;
         c->tuneNoOverlap = getenv("PPG_NO_OVERLAP") != nullptr;
+        c->tuneNoSortedCommit = getenv("PPG_NO_SORTED_COMMIT") != nullptr;
+        c->tuneAdamUnordered = getenv("PPG_ADAM_UNORDERED") != nullptr;
+        if (const char *e = getenv("PPG_SPLAT_LDS_NODES")) c->tuneSplatLdsNodes = (unsigned int)std::max(0, std::min((int)PPG_SPLAT_NODES, atoi(e)));
         if (const char *e = getenv("PPG_BULK_BOUNCES")) c->tuneBulkBounces = std::max(0, atoi(e));
         if (const char *e = getenv("PPG_BOUNCE_MARGIN")) c->bounceMargin = std::max(0, atoi(e));
         c->debugBatch = getenv("PPG_DEBUG_BATCH") != nullptr;

@@ -55,4 +55,14 @@ void ppg_launch_commit_all(int sf, int df, const CommitLaunch &a) {
     else PPG_COMMIT(SF_BOX, DF_BOX);
 #undef PPG_COMMIT
 }
+void ppg_launch_commit_records_all(int sf, const CommitLaunch &a) {
+    if (sf == SF_STOCHASTIC)
+        hipLaunchKernelGGL((k_commit_records<SF_STOCHASTIC>), dim3(a.grid), dim3(PPG_BLOCK), 0, a.stream, a.P, a.T, a.R, a.Q, a.nv8, a.list, a.list_n, a.splat, a.flag_shift);
+    else
+        hipLaunchKernelGGL((k_commit_records<SF_NEAREST>), dim3(a.grid), dim3(PPG_BLOCK), 0, a.stream, a.P, a.T, a.R, a.Q, a.nv8, a.list, a.list_n, a.splat, a.flag_shift);
+}
+void ppg_launch_splat_all(int df, const SplatLaunch &a) {
+    if (df == DF_BOX) hipLaunchKernelGGL((k_splat_sorted<DF_BOX>), dim3(a.grid), dim3(PPG_BLOCK), 0, a.stream, a.T, a.keys, a.idx, a.splat, a.n, a.leaf_bits, a.lds_nodes);
+    else hipLaunchKernelGGL((k_splat_sorted<DF_NEAREST>), dim3(a.grid), dim3(PPG_BLOCK), 0, a.stream, a.T, a.keys, a.idx, a.splat, a.n, a.leaf_bits, a.lds_nodes);
+}
 #endif

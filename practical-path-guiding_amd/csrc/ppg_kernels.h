@@ -513,20 +513,27 @@ static __global__ void k_build_grid(const int4 *stree, unsigned int *grid) {
 #ifndef PPG_BOX_STACK
 #define PPG_BOX_STACK 8
 #endif
-D void dtree_record(const DevTree &T, int leaf, float px, float py, float irradiance, float w, int dfilter, unsigned long long *box_stack = nullptr,
-                    int box_stride = 0) {
+// The building tree a record is splatted into: the pool in HBM (TreeGlobal: accumulation by global atomics) or one D-tree staged in LDS by
+// k_splat_sorted (TreeLds: topology and accumulators private to the workgroup, accumulation by LDS atomics, flushed once).  The sums are
+// integers: the order and the place of the additions do not show in the result.
+struct TreeGlobal {
+    const ushort4 *child;      // first node of this D-tree in the pool
+    unsigned long long *acc;   // its accumulators [node * 4 + slot]
+    D ushort4 node(unsigned int n) const { return child[n]; }
+    D void add(unsigned int n, int slot, unsigned long long v) const { atomicAdd(&acc[(size_t)n * 4 + slot], v); }
+};
+template <typename TR>
+D void dtree_record_t(const TR &tree, float px, float py, float irradiance, float w, int dfilter, unsigned long long *box_stack = nullptr, int box_stride = 0) {
     if (!(ppg_isfinite(w) && w > 0)) return;
     if (!(ppg_isfinite(irradiance) && irradiance > 0)) return;
-    const unsigned int base = T.hdr[leaf].b_base;
     if (dfilter == DF_NEAREST) {  // QuadTreeNode::record, GP:303-312
         unsigned int node = 0;
         for (;;) {
             int index = quad_child_index(px, py);
-            uint2 cw = *reinterpret_cast<const uint2 *>(&T.bchild[base + node]);
-            unsigned int w32 = (index & 2) ? cw.y : cw.x;
-            unsigned int c = (index & 1) ? (w32 >> 16) : (w32 & 0xffffu);
+            const ushort4 ch = tree.node(node);
+            const unsigned int c = index == 0 ? ch.x : (index == 1 ? ch.y : (index == 2 ? ch.z : ch.w));
             if (c == 0) {
-                atomicAdd(&T.bacc[(size_t)(base + node) * 4 + index], ppg_to_fixed(irradiance * w));
+                tree.add(node, index, ppg_to_fixed(irradiance * w));
                 break;
             }
             node = c;
@@ -540,7 +547,8 @@ D void dtree_record(const DevTree &T, int leaf, float px, float py, float irradi
             for (;;) {
                 int index = quad_child_index(qx, qy);
                 ++depth;
-                unsigned short c = ((const unsigned short *)&T.bchild[base + node])[index];
+                const ushort4 ch = tree.node(node);
+                const unsigned int c = index == 0 ? ch.x : (index == 1 ? ch.y : (index == 2 ? ch.z : ch.w));
                 if (c == 0) break;
                 node = c;
             }
@@ -550,8 +558,8 @@ D void dtree_record(const DevTree &T, int leaf, float px, float py, float irradi
         const float value = irradiance * w / (size * size);
         // Explicit stack of (node, cell) pairs.  A cell of level l is [ix, ix + 1) x [iy, iy + 1) * 2^-l — dyadic, so its float corner
         // ix * 2^-l is exactly what the reference's running `origin + childSize` additions produce — and an entry packs into 64 bits:
-        // node (16) | level (5) | ix (21) | iy (21).  With `box_stack` (k_commit: an LDS column per lane) the first PPG_BOX_STACK entries
-        // never leave the CU; a 64-entry array in scratch memory — 1 KB per lane, far beyond L1 — was the whole stack before.
+        // node (16) | level (5) | ix (21) | iy (21).  With `box_stack` (k_commit, k_splat_sorted: an LDS column per lane) the first
+        // PPG_BOX_STACK entries never leave the CU; a 64-entry array in scratch memory — 1 KB per lane, far beyond L1 — was the whole stack before.
         unsigned long long over[64];
         int sp = 0;
         auto push = [&](unsigned long long v) {
@@ -570,7 +578,7 @@ D void dtree_record(const DevTree &T, int leaf, float px, float py, float irradi
             const float es = ppg_exp2i(-(int)level);
             const float ex = (float)ix * es, ey = (float)iy * es;
             float childSize = es / 2;
-            ushort4 ch = T.bchild[base + enode];
+            ushort4 ch = tree.node(enode);
             const unsigned short cc[4] = {ch.x, ch.y, ch.z, ch.w};
             // the reference recurses depth-first in child order; contributions to distinct leaf slots commute (integer adds)
 #pragma unroll
@@ -582,13 +590,21 @@ D void dtree_record(const DevTree &T, int leaf, float px, float py, float irradi
                 float ly = ppg_max(ppg_min(oy + size, cy + childSize) - ppg_max(oy, cy), 0.0f);
                 float ww = lx * ly;
                 if (ww > 0.0f) {
-                    if (cc[i] == 0) atomicAdd(&T.bacc[(size_t)(base + enode) * 4 + i], ppg_to_fixed(value * ww));
+                    if (cc[i] == 0) tree.add(enode, i, ppg_to_fixed(value * ww));
                     else push((unsigned long long)cc[i] | ((unsigned long long)(level + 1) << 16) | ((unsigned long long)(2 * ix + (i & 1)) << 21) |
                               ((unsigned long long)(2 * iy + ((i >> 1) & 1)) << 42));
                 }
             }
         }
     }
+}
+D void dtree_record(const DevTree &T, int leaf, float px, float py, float irradiance, float w, int dfilter, unsigned long long *box_stack = nullptr,
+                    int box_stride = 0) {
+    if (!(ppg_isfinite(w) && w > 0)) return;
+    if (!(ppg_isfinite(irradiance) && irradiance > 0)) return;
+    const unsigned int base = T.hdr[leaf].b_base;
+    const TreeGlobal tree{T.bchild + base, T.bacc + (size_t)base * 4};
+    dtree_record_t(tree, px, py, irradiance, w, dfilter, box_stack, box_stride);
 }
 
 struct Rec {  // DTreeRecord, GP:562-568
@@ -1583,6 +1599,194 @@ __global__ __launch_bounds__(PPG_BLOCK) void k_commit(PathState P, DevTree T, Re
 }
 
 // ------------------------------------------------------------------------------------------------
+// The commit of a ROUND of the sampling-fraction optimiser: records first, splats by D-tree afterwards
+// ------------------------------------------------------------------------------------------------
+// In a round (include/ppg.h "Learning the BSDF sampling fraction") every committed vertex already leaves a record at a position known in
+// advance (DevTree::adam_base), and the round ends with a stable sort of the record keys by S-tree leaf.  So the splat into the building
+// tree (DTree::recordIrradiance, GP:395-413) need not happen where the vertex is read — one lane per vertex, every lane walking a different
+// D-tree through L2 and adding to it with global atomics: k_commit, bound by exactly that — but can follow the sort:
+//   k_commit_records  Vertex::commit (GP:1730-1768) up to the record: per (slot, path) item the vertex is read, turned into a DTreeRecord, the
+//                     stochastic filter's leaf looked up; written are the 64-bit key, the optimiser's 32-byte record (if product > 0) and a
+//                     16-byte SPLAT record (canonical direction, irradiance, statistical weight).  No atomics, no tree walk.
+//   radix sort        by (flag, leaf) — the sort the optimiser needs anyway; a record that is a splat only (product <= 0) carries a flag bit
+//                     just above its leaf bits and sorts behind all records of the optimiser, which therefore sees exactly the keys and the
+//                     order it saw before (k_adam_apply, the round hook's exchange).
+//   k_splat_sorted    the sorted records in chunks; a workgroup stages the building D-tree of a run of equal leaves in LDS (topology 8 B,
+//                     accumulators 32 B per node), its lanes splat into it with LDS atomics, and the non-zero accumulators are added to the
+//                     pool once per run.  Integer sums: the same bits as k_commit's.
+#define PPG_SPLAT_NODES 512    // D-trees of up to this many nodes are staged in LDS (20 KB); larger ones are splatted in the pool (TreeGlobal)
+#define PPG_SPLAT_PER_LANE 8   // records per lane and chunk
+#define PPG_SPLAT_CHUNK (PPG_BLOCK * PPG_SPLAT_PER_LANE)
+
+// PATH-major: a lane takes one path and walks its vertex slots; a wave's 64 neighbouring paths read slot v together (the slots are stored
+// [slot][path]) and own ONE contiguous run of record positions (adam_base is the scan of the vertex counts), which they fill within a few
+// iterations — the partial lines meet in L2 before they reach HBM.  (Work items (slot, path) as in k_commit — slot v of all paths, then slot
+// v + 1 — wrote every record into a line whose neighbours followed a whole sweep later, tested a byte for the 6 of 7 items beyond their
+// path's last vertex, and divided 64-bit item numbers: 48 ms of a 127-pass render)
+template <int SF>
+__global__ __launch_bounds__(PPG_BLOCK) void k_commit_records(PathState P, DevTree T, RenderParams R, Queues Q, const unsigned char *nv8,
+                                                              const unsigned int *list, const unsigned long long *list_n, float4 *splat,
+                                                              unsigned int flag_shift) {
+    __shared__ unsigned long long acc;
+    unsigned long long committed_sum = 0;
+    const float statisticalWeight = (R.nee == NEE_KICKSTART && R.do_nee) ? 0.5f : 1.0f;
+    const int loss = T.is_built ? R.loss : LOSS_NONE;
+    const unsigned int n_sel = list ? (unsigned int)*list_n : P.n_paths;
+    const unsigned int stride = gridDim.x * blockDim.x;
+    for (unsigned int k0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); k0 < n_sel; k0 += stride) {  // (k0: the wave's first entry)
+        const unsigned int k = k0 + (threadIdx.x & 63u);
+        unsigned int nv = 0, i = 0;
+        if (k < n_sel) {
+            nv = nv8[k];  // (k_commit_prepare: 0 for a path this launch leaves to the one after the tail; [_list]: by list position)
+            i = list ? list[k] : k;
+        }
+        if (!__any(nv != 0)) continue;
+        uint4 m = make_uint4(0, 0, 0, 0);
+        unsigned int base = 0, pathId = 0;
+        if (nv) {
+            m = P.misc[i];
+            const unsigned int have = (m.z & FL_NV_MASK) >> FL_NV_SHIFT;
+            nv = nv < have ? nv : have;
+            base = T.adam_base[i];
+            pathId = adam_path_id(P, R, i);
+        }
+        for (unsigned int v = 0; __any(v < nv); ++v) {
+            if (!(v < nv)) continue;
+            const size_t vi = (size_t)v * P.n_paths + i;
+            const float4 a = P.v_d[vi], b = P.v_thr[vi], c = P.v_bsdf[vi], e = P.v_rad[vi];
+            const unsigned int bits = __float_as_uint(e.w);
+            Rec rec;
+            if (!vertex_to_rec(f3(e.x, e.y, e.z), f3(c.x, c.y, c.z), f3(b.x, b.y, b.z), a.w, b.w, c.w, f3(a.x, a.y, a.z), (bits & 0x80000000u) != 0, statisticalWeight, rec))
+                continue;
+            ++committed_sum;
+            int leaf = (int)(bits & 0x7fffffffu);
+            if (SF == SF_STOCHASTIC) {  // GP:1746-1763
+                const float4 o4 = P.v_o[vi], x4 = P.v_vox[vi];
+                leaf = stochastic_leaf(T, f3(o4.x, o4.y, o4.z), f3(x4.x, x4.y, x4.z), m.x, m.y + 3u * v);
+            }
+            // DTreeWrapper::record (GP:575-584), written down: the splat ...
+            float irradiance = 0, px = 0, py = 0, sw = 0;
+            if (!rec.isDelta && ppg_isfinite(rec.statisticalWeight) && rec.statisticalWeight > 0) {
+                sw = rec.statisticalWeight;
+                irradiance = rec.radiance / rec.woPdf;
+                if (ppg_isfinite(irradiance) && irradiance > 0) dir_to_canonical(rec.d, px, py);
+                else irradiance = 0;  // the statistical weight only (recordIrradiance, GP:396-398)
+            }
+            // ... and the optimiser's call (GP:581-583)
+            const bool optimise = loss != LOSS_NONE && rec.product > 0;
+            if (!optimise && !(sw > 0)) continue;  // nothing to do for this vertex: its position stays a hole
+            const unsigned int pos = base + v;
+            unsigned long long key = ((unsigned long long)(unsigned int)leaf << PPG_ADAM_LEAF_SHIFT) | ((unsigned long long)pathId << PPG_ADAM_CODE_BITS) |
+                                     ((unsigned int)PPG_ADAM_CODE_VERTEX + v);
+            if (optimise) {
+                AdamRec r;
+                r.key = key; r.product = rec.product; r.woPdf = rec.woPdf; r.bsdfPdf = rec.bsdfPdf; r.dTreePdf = rec.dTreePdf; r.weight = rec.statisticalWeight; r.pad = 0.0f;
+                T.adam_recs[pos] = r;
+            } else key |= 1ull << flag_shift;
+            T.adam_keys[pos] = key;
+            splat[pos] = make_float4(px, py, irradiance, sw);
+        }
+    }
+    block_add_u64(&acc, &Q.stats[blockIdx.x].committed, committed_sum);
+}
+
+// one D-tree staged in LDS (k_splat_sorted)
+struct TreeLds {
+    const ushort4 *child;
+    unsigned long long *acc;
+    D ushort4 node(unsigned int n) const { return child[n]; }
+    D void add(unsigned int n, int slot, unsigned long long v) const { atomicAdd(&acc[n * 4u + (unsigned int)slot], v); }
+};
+
+// keys / idx: the round's records sorted by (flag, leaf), idx[t] = position of record t in `splat`; n = positions (holes, key ~0, at the end);
+// leaf_bits: the sort field is key >> PPG_ADAM_LEAF_SHIFT, leaf_bits + 1 wide
+template <int DF>
+__global__ __launch_bounds__(PPG_BLOCK) void k_splat_sorted(DevTree T, const unsigned long long *keys, const unsigned int *idx, const float4 *splat, unsigned int n,
+                                                            unsigned int leaf_bits, unsigned int lds_nodes) {
+    __shared__ ushort4 s_child[PPG_SPLAT_NODES];
+    __shared__ unsigned long long s_acc[4 * PPG_SPLAT_NODES];
+    __shared__ unsigned long long s_stack[DF == DF_BOX ? PPG_BOX_STACK * PPG_BLOCK : 1];
+    __shared__ unsigned long long s_weight;
+    __shared__ unsigned int s_field, s_end;
+    const unsigned int leaf_mask = (1u << leaf_bits) - 1u, field_mask = (2u << leaf_bits) - 1u;
+    const unsigned int chunks = (n + PPG_SPLAT_CHUNK - 1) / PPG_SPLAT_CHUNK;
+    const unsigned int t = threadIdx.x;
+    for (unsigned int c = blockIdx.x; c < chunks; c += gridDim.x) {
+        const unsigned int lo = c * PPG_SPLAT_CHUNK, hi = (n - lo) < PPG_SPLAT_CHUNK ? n : lo + PPG_SPLAT_CHUNK;
+        // this lane's records of the chunk: positions lo + t + j * PPG_BLOCK
+        unsigned int field[PPG_SPLAT_PER_LANE], src[PPG_SPLAT_PER_LANE];
+#pragma unroll
+        for (int j = 0; j < PPG_SPLAT_PER_LANE; ++j) {
+            const unsigned int p = lo + t + (unsigned int)j * PPG_BLOCK;
+            field[j] = 0xffffffffu; src[j] = 0;
+            if (p < hi) { field[j] = (unsigned int)(keys[p] >> PPG_ADAM_LEAF_SHIFT) & field_mask; src[j] = idx[p]; }
+        }
+        unsigned int pos = lo;
+        for (;;) {  // one run of equal (flag, leaf) after the other
+            __syncthreads();
+            if (t == (pos - lo) % PPG_BLOCK) {
+                unsigned int f = 0xffffffffu;
+#pragma unroll
+                for (int j = 0; j < PPG_SPLAT_PER_LANE; ++j) if ((pos - lo) / PPG_BLOCK == (unsigned int)j) f = field[j];
+                s_field = f; s_end = hi; s_weight = 0ull;
+            }
+            __syncthreads();
+            const unsigned int f0 = s_field;
+            if ((f0 & leaf_mask) == leaf_mask) break;  // holes from here to the end of the array
+            {   // the run ends at the first record of a larger field (the keys are sorted)
+                unsigned int mine = hi;
+#pragma unroll
+                for (int j = PPG_SPLAT_PER_LANE - 1; j >= 0; --j) {
+                    const unsigned int p = lo + t + (unsigned int)j * PPG_BLOCK;
+                    if (p < hi && field[j] > f0) mine = p;
+                }
+                for (int off = 32; off > 0; off >>= 1) { const unsigned int o = __shfl_xor(mine, off); mine = o < mine ? o : mine; }
+                if ((t & 63u) == 0 && mine < hi) atomicMin(&s_end, mine);
+            }
+            const unsigned int leaf = f0 & leaf_mask;
+            const unsigned int base = T.hdr[leaf].b_base, nn = T.hdr[leaf].b_num;
+            const bool staged = nn <= lds_nodes;  // (PPG_SPLAT_NODES, or fewer: PPG_SPLAT_LDS_NODES, so that tests reach the other branch with small trees)
+            if (staged)
+                for (unsigned int k = t; k < nn; k += PPG_BLOCK) {
+                    s_child[k] = T.bchild[base + k];
+                    s_acc[4 * k] = 0ull; s_acc[4 * k + 1] = 0ull; s_acc[4 * k + 2] = 0ull; s_acc[4 * k + 3] = 0ull;
+                }
+            __syncthreads();
+            const unsigned int end = s_end;
+            unsigned long long wsum = 0ull;
+#pragma unroll
+            for (int j = 0; j < PPG_SPLAT_PER_LANE; ++j) {
+                const unsigned int p = lo + t + (unsigned int)j * PPG_BLOCK;
+                if (p < pos || p >= end) continue;
+                const float4 r = splat[src[j]];  // (px, py, irradiance, statistical weight)
+                if (!(r.w > 0)) continue;
+                wsum += ppg_to_fixed(r.w);  // statisticalWeight += w, GP:396-398
+                if (!(r.z > 0)) continue;
+                if (staged) {
+                    const TreeLds tree{s_child, s_acc};
+                    dtree_record_t(tree, r.x, r.y, r.z, r.w, DF, DF == DF_BOX ? s_stack + t : nullptr, PPG_BLOCK);
+                } else {
+                    const TreeGlobal tree{T.bchild + base, T.bacc + (size_t)base * 4};
+                    dtree_record_t(tree, r.x, r.y, r.z, r.w, DF, DF == DF_BOX ? s_stack + t : nullptr, PPG_BLOCK);
+                }
+            }
+            for (int off = 32; off > 0; off >>= 1) wsum += __shfl_xor(wsum, off);
+            if ((t & 63u) == 0 && wsum) atomicAdd(&s_weight, wsum);
+            __syncthreads();
+            if (staged)
+                for (unsigned int k = t; k < 4 * nn; k += PPG_BLOCK) {
+                    const unsigned long long v = s_acc[k];
+                    if (v) atomicAdd(&T.bacc[(size_t)base * 4 + k], v);
+                }
+            if (t == 0 && s_weight) atomicAdd(&T.bweight[leaf], s_weight);
+            pos = end;
+            if (pos >= hi) break;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Per-round application of the sampling-fraction optimiser's records
 // ------------------------------------------------------------------------------------------------
 // compact[i] += Σ_r rep[i][r]; rep = 0.  Idempotent (a second call adds zeros).
@@ -1674,20 +1878,29 @@ __global__ void k_adam_state(LeafHdr *hdr, unsigned int n_nodes, unsigned int *s
         w[4] = __float_as_uint(h.adam_bg); w[5] = __float_as_uint(h.adam_ba);
     }
 }
-static __global__ void k_count_valid(const unsigned long long *keys, unsigned int n, unsigned int *out) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *out = adam_lower_bound(keys, n, ~0ull);
+static __global__ void k_count_valid(const unsigned long long *keys, unsigned int n, unsigned int *out, unsigned long long bound) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *out = adam_lower_bound(keys, n, bound);
+}
+// count[k] = records of the optimiser for the k-th S-tree leaf, order[k] = k: sorted by count (descending) they are k_adam_apply's schedule
+static __global__ void k_adam_counts(const unsigned int *leaves, unsigned int n_leaves, const unsigned long long *keys, unsigned int n, unsigned int *count, unsigned int *order) {
+    const unsigned int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_leaves) return;
+    const unsigned int leaf = leaves[k];
+    const unsigned int lo = adam_lower_bound(keys, n, (unsigned long long)leaf << PPG_ADAM_LEAF_SHIFT);
+    const unsigned int hi = adam_lower_bound(keys, n, (unsigned long long)(leaf + 1u) << PPG_ADAM_LEAF_SHIFT);
+    count[k] = hi - lo; order[k] = k;
 }
 
 // The deferred optimizeBsdfSamplingFraction calls of one round (include/ppg.h "Learning the BSDF sampling fraction"): one WAVE
 // per S-tree leaf walks that leaf's records in key order — 64 records are fetched at once, then applied in that order with
 // the reference's arithmetic: the gradient at the current variable (GP:672-691; every lane its own record, once per batch of append()),
 // AdamOptimizer::append (GP:85-95) and step (GP:97-109; the same scalar sequence in every lane).  Lane 0 writes the state back.
-static __global__ __launch_bounds__(256) void k_adam_apply(LeafHdr *hdr, const unsigned int *leaves, unsigned int n_leaves, const unsigned long long *keys,
-                                                    const unsigned int *idx, const AdamRec *recs, unsigned int n, int loss) {
+static __global__ __launch_bounds__(256) void k_adam_apply(LeafHdr *hdr, const unsigned int *leaves, const unsigned int *order, unsigned int n_leaves,
+                                                    const unsigned long long *keys, const unsigned int *idx, const AdamRec *recs, unsigned int n, int loss) {
     const unsigned int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const unsigned int lane = threadIdx.x & 63u;
     if (w >= n_leaves) return;
-    const unsigned int leaf = leaves[w];
+    const unsigned int leaf = leaves[order ? order[w] : w];  // (order: busiest D-trees first, k_adam_counts)
     const unsigned int lo = adam_lower_bound(keys, n, (unsigned long long)leaf << PPG_ADAM_LEAF_SHIFT);
     const unsigned int hi = adam_lower_bound(keys, n, (unsigned long long)(leaf + 1u) << PPG_ADAM_LEAF_SHIFT);
     if (lo == hi) return;

@@ -35,6 +35,18 @@ struct CommitLaunch {
     const unsigned char *nv8;   // k_commit_prepare's byte per path, k_commit_prepare_list's per list entry
     const unsigned int *list;
     const unsigned long long *list_n;
+    float4 *splat;              // k_commit_records: the round's splat records
+    unsigned int flag_shift;    // ... and the key bit of "a splat only"
+};
+struct SplatLaunch {
+    int grid;
+    hipStream_t stream;
+    DevTree T;
+    const unsigned long long *keys;
+    const unsigned int *idx;
+    const float4 *splat;
+    unsigned int n, leaf_bits;
+    unsigned int lds_nodes;     // D-trees of up to this many nodes are staged in LDS (<= PPG_SPLAT_NODES)
 };
 
 // variant = (FUSED ? 4 : 0) | (NEE ? 2 : 0) | (FULL ? 1 : 0)
@@ -42,6 +54,9 @@ void ppg_launch_shade(int variant, const ShadeLaunch &a);
 // variant = (SMALL ? 4 : 0) | (NEE ? 2 : 0) | (FULL ? 1 : 0)
 void ppg_launch_tail(int variant, const TailLaunch &a);
 void ppg_launch_commit(int spatial_filter, int directional_filter, const CommitLaunch &a);
+// a round of the optimiser: k_commit_records (nearest / stochastic spatial filter), then — after the sort — k_splat_sorted
+void ppg_launch_commit_records(int spatial_filter, const CommitLaunch &a);
+void ppg_launch_splat(int directional_filter, const SplatLaunch &a);
 
 // one function per translation unit (pair = variant >> 1)
 void ppg_launch_shade_pair0(int variant, const ShadeLaunch &a);
@@ -53,6 +68,8 @@ void ppg_launch_tail_pair1(int variant, const TailLaunch &a);
 void ppg_launch_tail_pair2(int variant, const TailLaunch &a);
 void ppg_launch_tail_pair3(int variant, const TailLaunch &a);
 void ppg_launch_commit_all(int spatial_filter, int directional_filter, const CommitLaunch &a);
+void ppg_launch_commit_records_all(int spatial_filter, const CommitLaunch &a);
+void ppg_launch_splat_all(int directional_filter, const SplatLaunch &a);
 // k_shade<false, false, FULL, MSET_COMMON> over the front part of the sorted slices (a.qin = QIN_SORTED_COMMON)
 void ppg_launch_shade_common(const ShadeLaunch &a);
 

@@ -95,7 +95,10 @@ public:
     virtual void reduceFilm(ppg_ctx *ctx, int width, int height) = 0;     // before the film is read (not with inverse-variance combination)
     // a final iteration's groups of passes (include/ppg.h "Final iteration: groups of passes"): all-reduce the n floats at dev, then ppg_final_partials_commit
     virtual void reduceFinalPartials(ppg_ctx *ctx, void *dev, uint64_t nFloats) = 0;
-    virtual double broadcast(double value) = 0;                            // rank 0's value on every rank (clock readings / stop decisions of a time budget)
+    virtual double broadcast(double value) = 0;                            // rank 0's value on every rank (the clock readings of a time budget)
+    // the stop decision of a time budget (include/ppg.h ppg_set_stop_hook): rank 0's `localStop`, or "stop" if any rank's status word is set —
+    // a cancelled rank meets the others HERE, and they all leave the batch loop for the image exchange, where the status aborts the render
+    virtual int stopDecision(int localStop) = 0;
     virtual void beginRender() {}                                         // a new render() starts: forget the status of the previous one
     virtual void setLocalStatus(int status) { (void)status; }             // != 0: this rank was cancelled / failed — announced to the others in the next exchange
     virtual int rank() const = 0;
@@ -140,7 +143,9 @@ public:
     // reducer->world() ranks (every rank calls render() on the same scene) and the film is complete on every rank afterwards.
     bool render(const SceneData &scene, const Log &log = Log(), Reducer *reducer = nullptr) {
         m_reducer = reducer;
-        m_cancelled.store(false);
+        // (cancel() is sticky in the library: one that arrived before this call — or during ppg_set_scene below — cancels this render,
+        // ppg_begin_render consumes it; m_cancelled, which the hooks read, is reset when the render is over)
+        struct Reset { std::atomic<bool> &f; ~Reset() { f.store(false); } } reset{m_cancelled};
         m_filmComplete = false;
         if (reducer) reducer->beginRender();
         const bool spp = std::string(m_cfg.budgetType) == "spp";
@@ -148,7 +153,11 @@ public:
         check(ppg_set_scene(m_ctx, &sv), "ppg_set_scene");
         if (reducer) check(ppg_set_shard(m_ctx, reducer->rank(), reducer->world(), 32), "ppg_set_shard");
         m_w = scene.camera.width; m_h = scene.camera.height;
-        check(ppg_begin_render(m_ctx), "ppg_begin_render");
+        {
+            const int rc = ppg_begin_render(m_ctx);
+            if (rc == PPG_ERR_CANCELLED) return false;  // GP:1584
+            check(rc, "ppg_begin_render");
+        }
         if (reducer && std::string(m_cfg.bsdfSamplingFractionLoss) != "none") check(ppg_set_pass_hook(m_ctx, &GuidedPathTracerHIP::roundHook, this), "ppg_set_pass_hook");
         // a time budget, sharded: every decision taken by a clock (GP:1259-1262, 1434-1514) is rank 0's, so that all ranks render the same passes
         check(ppg_set_stop_hook(m_ctx, (reducer && !spp) ? &GuidedPathTracerHIP::stopHook : nullptr, this), "ppg_set_stop_hook");
@@ -311,7 +320,8 @@ private:
 
     static int stopHook(void *self, int localStop) {
         GuidedPathTracerHIP *g = static_cast<GuidedPathTracerHIP *>(self);
-        try { return g->m_reducer->broadcast((double)localStop) != 0 ? 1 : 0; } catch (...) { if (!g->m_hookError) g->m_hookError = std::current_exception(); return 1; }
+        if (g->m_cancelled.load()) g->m_reducer->setLocalStatus(1);
+        try { return g->m_reducer->stopDecision(localStop); } catch (...) { if (!g->m_hookError) g->m_hookError = std::current_exception(); return 1; }
     }
     static int roundHook(void *self) {  // C callback: no exception may cross the C-ABI
         GuidedPathTracerHIP *g = static_cast<GuidedPathTracerHIP *>(self);

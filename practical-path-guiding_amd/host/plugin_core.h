@@ -81,12 +81,17 @@ public:
             m_ctx.store(ctx);
             if (m_cancelRequested.exchange(false)) return PPG_ERR_CANCELLED;
         }
-        rc = ppg_set_scene(ctx, &scene);
+        m_hasFilm = false;
+        rc = ppg_set_scene(ctx, &scene);  // (a cancel() during these seconds of BVH build stays set in the context: ppg_render returns at once)
         if (rc != PPG_OK) { err = ppg_last_error(ctx); return rc; }
+        m_hasFilm = true;  // (the film exists from here on: black if the cancel came before the first pass)
         rc = ppg_render(ctx);
         if (rc != PPG_OK && rc != PPG_ERR_CANCELLED) err = ppg_last_error(ctx);
         return rc;
     }
+    // is there a picture to read?  Not after a cancel() that arrived before the context had a scene: the plug-in then returns false (GP:1584)
+    // without touching the film
+    bool hasFilm() const { return m_hasFilm; }
 
     void cancel() {
         std::lock_guard<std::mutex> lock(m_mutex);
@@ -112,6 +117,7 @@ private:
     std::string m_s[6], m_dump;
     std::atomic<ppg_ctx *> m_ctx{nullptr};
     std::atomic<bool> m_cancelRequested{false};
+    bool m_hasFilm = false;
     std::mutex m_mutex;
 };
 

@@ -311,7 +311,7 @@ int main(int argc, char **argv) {
         if (canceller.joinable()) canceller.join();
         if (rc != PPG_OK && rc != PPG_ERR_CANCELLED) { std::cerr << "error: " << err << std::endl; return 3; }
         if (rc == PPG_ERR_CANCELLED && !quiet) std::cout << "(cancelled)" << std::endl;
-        if (core.context() && !(rc == PPG_ERR_CANCELLED && cancelAfterMs == 0)) {
+        if (core.hasFilm()) {  // (as the plug-in does: no picture after a cancel() that came before the context had a scene)
             std::vector<float> rgb((size_t)scene.camera.width * scene.camera.height * 3);
             if (core.readFilm(rgb.data(), err) != PPG_OK) { std::cerr << "error: " << err << std::endl; return 3; }
             writePFM(out.c_str(), rgb, scene.camera.width, scene.camera.height);

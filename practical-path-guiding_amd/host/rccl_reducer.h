@@ -106,8 +106,15 @@ public:
     void reduceFinalPartials(ppg_ctx *ctx, void *dev, uint64_t nFloats) override {
         // film head + every group's partial image: each slot is non-zero on one rank, the float sums are exact (include/ppg.h)
         // (dev == nullptr: this rank has nothing to give — it failed or was cancelled — but joins the collective, zeros and its status word)
-        Piece p[1] = {{dev, (size_t)nFloats * 4}};
-        allReduce(p, 1, ncclFloat);
+        // ONE piece: reduced in place (no staging copy of what can be gigabytes), the status word in a small collective of its own behind it
+        if (dev) {
+            nccl(ncclAllReduce(dev, dev, (size_t)nFloats, ncclFloat, ncclSum, m_comm, m_stream), "ncclAllReduce(partials)");
+            ++m_collectives; m_bytes += (size_t)nFloats * 4;
+            allReduce(nullptr, 0, ncclFloat);
+        } else {
+            Piece p[1] = {{nullptr, (size_t)nFloats * 4}};  // (zeros from the staging block)
+            allReduce(p, 1, ncclFloat, true);
+        }
         check(ctx, ppg_final_partials_commit(ctx), "ppg_final_partials_commit");
     }
     // a rank that was cancelled or failed announces it in the next exchange (status word, see the header comment)
@@ -121,6 +128,18 @@ public:
         hip(hipStreamSynchronize(m_stream), "hipStreamSynchronize");
         ++m_collectives;
         return value;
+    }
+
+    int stopDecision(int localStop) override {
+        // one all-reduce (sum) of {rank 0's decision, every rank's status word}
+        if (!m_counts) hip(hipMalloc(&m_counts, (size_t)m_world * ((size_t)m_world + 1) * 8), "hipMalloc");
+        long long v[2] = {m_rank == 0 ? (long long)(localStop != 0) : 0ll, (long long)m_status};
+        hip(hipMemcpyAsync(m_counts, v, 16, hipMemcpyHostToDevice, m_stream), "hipMemcpyAsync");
+        nccl(ncclAllReduce(m_counts, m_counts, 2, ncclInt64, ncclSum, m_comm, m_stream), "ncclAllReduce(stop)");
+        hip(hipMemcpyAsync(v, m_counts, 16, hipMemcpyDeviceToHost, m_stream), "hipMemcpyAsync");
+        hip(hipStreamSynchronize(m_stream), "hipStreamSynchronize");
+        ++m_collectives;
+        return (v[0] != 0 || v[1] != 0) ? 1 : 0;
     }
 
     // round hook of the sampling-fraction optimiser, called twice per round (include/ppg.h "Sharded optimiser")
@@ -195,7 +214,8 @@ private:
         hip(hipMalloc(&m_stage, m_stageBytes), "hipMalloc");
     }
     // pack → one in-place all-reduce → unpack
-    void allReduce(const Piece *p, int count, ncclDataType_t type) {
+    // statusApart: the status word travels in a second collective (the peers reduce their data in place and the word on its own)
+    void allReduce(const Piece *p, int count, ncclDataType_t type, bool statusApart = false) {
         size_t total = 0;
         for (int i = 0; i < count; ++i) total += p[i].bytes;
         const size_t elem = type == ncclFloat ? 4 : 8;
@@ -208,6 +228,10 @@ private:
         }
         const float sf = (float)m_status; const long long si = (long long)m_status;
         hip(hipMemcpyAsync((char *)m_stage + total, type == ncclFloat ? (const void *)&sf : (const void *)&si, elem, hipMemcpyHostToDevice, m_stream), "hipMemcpyAsync");
+        if (statusApart) {
+            nccl(ncclAllReduce(m_stage, m_stage, total / elem, type, ncclSum, m_comm, m_stream), "ncclAllReduce");
+            nccl(ncclAllReduce((char *)m_stage + total, (char *)m_stage + total, 1, type, ncclSum, m_comm, m_stream), "ncclAllReduce(status)");
+        } else
         nccl(ncclAllReduce(m_stage, m_stage, total / elem + 1, type, ncclSum, m_comm, m_stream), "ncclAllReduce");
         float rf = 0; long long ri = 0;
         hip(hipMemcpyAsync(type == ncclFloat ? (void *)&rf : (void *)&ri, (char *)m_stage + total, elem, hipMemcpyDeviceToHost, m_stream), "hipMemcpyAsync");

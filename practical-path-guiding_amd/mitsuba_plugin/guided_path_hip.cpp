@@ -80,6 +80,7 @@ public:
             Log(EError, "guided_path_hip: %s", why.c_str());   /* unknown enum strings: where GP:1023.. Assert(false) */
             return false;
         }
+        if (!m_core.hasFilm()) return false;   /* cancel() before the context had a scene: nothing to develop, GP:1584 */
         ref<Bitmap> out = new Bitmap(Bitmap::ERGB, Bitmap::EFloat32, film->getCropSize());
         if (m_core.readFilm(out->getFloat32Data(), why) != PPG_OK) {
             Log(EError, "guided_path_hip: %s", why.c_str());
@@ -158,16 +159,6 @@ private:
         data.materials.push_back(m);
         cache[bsdf] = (int) data.materials.size() - 1;
         return cache[bsdf];
-    }
-
-    static Float lookupIOR(const Properties &p, const std::string &name, const std::string &dflt) {   /* ior.h:95-111 */
-        if (p.hasProperty(name) && p.getType(name) == Properties::EFloat) return p.getFloat(name);
-        const std::string v = p.hasProperty(name) ? p.getString(name) : dflt;
-        static const struct { const char *n; float v; } table[] = {{"vacuum", 1.0f}, {"air", 1.000277f}, {"water", 1.3330f}, {"polypropylene", 1.49f},
-                                                                   {"bk7", 1.5046f}, {"diamond", 2.419f}};
-        for (size_t i = 0; i < sizeof table / sizeof table[0]; ++i) if (v == table[i].n) return table[i].v;
-        SLog(EError, "guided_path_hip: unknown material '%s'", v.c_str());
-        return 1.0f;
     }
 
     static std::string m_dataDir() {    /* data/microfacet/*.dat, data/ior/*.spd of the running Mitsuba */

@@ -458,6 +458,15 @@ class Engine:
     def final_partials_commit(self):
         self._call("final_partials_commit")
 
+    def final_partials_expected(self, n_passes):
+        """Float count of the buffer final_partials() hands over for a sharded final iteration of n_passes passes — a function of what every
+        rank knows (film size, pass count), so that a rank that failed can still join the others' collective with zeros."""
+        f = self._f("final_group_passes")
+        f.restype, f.argtypes = C.c_int32, [C.c_int32]
+        g = int(f(C.c_int32(int(n_passes))))
+        n = self.width * self.height
+        return 4 * n + (-(-int(n_passes) // g)) * 7 * n
+
     def adam_records(self):
         """Inside the round hook: (pointer, count) of this rank's 32-byte ppg_adam_record array (device memory for the HIP engine,
         host memory for the oracle)."""

@@ -25,18 +25,28 @@ class GuidedPathTracer:
         e = self.engine
         if self.reducer is None:
             return e.render_passes(n)
-        # A rank that is cancelled or fails here still enters the exchange the others are in — with its status word set (distributed._Status):
-        # every exchange begins with the sum of the status words, so all ranks leave at the same point.
+        # A rank that is cancelled or fails here still enters the exchange the others are in — with its status word set (distributed._Status),
+        # which travels with the data: all ranks see the same sum and leave at the same point.  WHICH exchange that is follows from what every
+        # rank knows (final flag, budget type, pass count), never from this rank's own outcome.
         failure = None
         try:
             e.render_passes_nostat(n)
-            ptr, count = e.final_partials() if self._final else (None, 0)
         except Exception as ex:  # PPGError: cancelled, round hook failed, ...
-            failure, ptr, count = ex, None, 0
+            failure = ex
             self.reducer.status = 1
         try:
-            if count:  # a final iteration: whole groups of passes were dealt to the ranks; their partial images add up in group order
-                self.reducer.reduce_final_partials(e, ptr, count)
+            if self._final and self.props["budgetType"] == "spp" and self.reducer.world > 1:
+                # a final iteration: the groups of passes were dealt to the ranks — whole, or by tiles —, their partial images add up in group order
+                expect = e.final_partials_expected(n)
+                ptr, count = None, 0
+                if failure is None:
+                    try:
+                        ptr, count = e.final_partials()
+                    except Exception as ex:
+                        failure = ex
+                if count != expect:
+                    self.reducer.status, ptr = 1, None
+                self.reducer.reduce_final_partials(e, ptr, expect)
                 self._film_complete = True
             else:
                 self.reducer.reduce_images(e)
@@ -69,8 +79,13 @@ class GuidedPathTracer:
         # Sharded with a time budget: every control decision of renderTime() (guided_path.cpp:1434-1514) and the per-pass abort inside
         # performRenderPasses (GP:1259-1262) reads a clock — rank 0's, broadcast, so that all ranks render the same passes and iterations
         clock = (lambda v: self.reducer.broadcast(v)) if self.reducer is not None else (lambda v: v)
-        if self.reducer is not None and p["budgetType"] != "spp":
-            e.set_stop_hook(lambda local: int(self.reducer.broadcast(local)))
+        def stop_hook(local):  # rank 0's decision for all — or "stop" when any rank's status word is set (a cancelled rank meets the others here)
+            if self._cancelled:
+                self.reducer.status = 1
+            return self.reducer.stop_decision(local)
+        # (hooks of an earlier render() of this engine with another reducer / budget must not survive it)
+        e.set_stop_hook(stop_hook if (self.reducer is not None and p["budgetType"] != "spp") else None)
+        e.set_pass_hook(None)
         self._cancelled = False
         if self.reducer is not None:
             self.reducer.begin_render()

@@ -280,6 +280,117 @@ def test_time_budget_sharded_over_gloo(oracle_lib, tmp_path, combo):
     assert np.array_equal(np.load(tmp_path / "sec-rank0.npy"), np.load(tmp_path / "sec-rank1.npy"))
 
 
+FINAL8_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, sys.argv[1])
+import ctypes, numpy as np, torch.distributed as dist
+import ppg_host
+from ppg_host.distributed import HostReducer
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+lib = ctypes.CDLL(sys.argv[2])
+props = dict(budgetType="spp", maxDepth=6, rrDepth=10, strictNormals=1, budget=int(sys.argv[4]), seed=9, sppPerPass=1, sampleCombination="automatic",
+             bsdfSamplingFractionLoss="kl", spatialFilter="stochastic", directionalFilter="box", sTreeThreshold=400)
+e = ppg_host.Engine(lib, "ppgo_", **props)
+lib.ppgo_set_modes(e.ctx, 0, 0, 1)
+e.set_scene(ppg_host.cbox_scene(32, 32)); e.set_shard(rank, world, 4)
+gpt = ppg_host.GuidedPathTracer(engine=e, reducer=HostReducer(dist))
+img = gpt.render()
+last = gpt.iterations[-1]
+json.dump({"passes": [it["passes"] for it in gpt.iterations], "final_samples": last["stats"][-1]["samples"]}, open(os.path.join(sys.argv[3], "f8-rank%d.json" % rank), "w"))
+np.save(os.path.join(sys.argv[3], "f8-rank%d.npy" % rank), img)
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("budget,final_passes", [(20, 13), (127, 64)])
+def test_final_iteration_of_few_groups_is_shared_by_eight_ranks(oracle_lib, tmp_path, budget, final_passes):
+    """VERDICT r4 / ADVICE r4: a final iteration of 13 passes (the driver's `--steps 20`) is ONE group of passes, one of 64 passes four — dealt
+    whole, one rank rendered most of the render alone while seven idled.  With fewer than two groups per rank every rank now renders every
+    group on its own TILES (include/ppg.h "Final iteration: groups of passes"); the sums a pixel goes through are the same, so the picture
+    still equals the single-rank one bit for bit, and every one of the eight ranks renders its share of the final samples."""
+    import json
+    import ppg_host
+    world = 8
+    script = tmp_path / "final8_worker.py"
+    script.write_text(FINAL8_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(35500 + os.getpid() % 2000), OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
+           "--master-port", env["MASTER_PORT"], str(script), os.path.join(ROOT, "practical-path-guiding_amd"),
+           os.path.join(ROOT, "oracle", "libppg_oracle.so"), str(tmp_path), str(budget)]
+    subprocess.run(cmd, check=True, env=env, timeout=900, capture_output=True)
+    props = dict(budgetType="spp", maxDepth=6, rrDepth=10, strictNormals=1, budget=budget, seed=9, sppPerPass=1, sampleCombination="automatic",
+                 bsdfSamplingFractionLoss="kl", spatialFilter="stochastic", directionalFilter="box", sTreeThreshold=400)
+    e = make_oracle(oracle_lib, threads=4, **props)
+    e.set_scene(ppg_host.cbox_scene(32, 32)); e.render()
+    ref = e.read_film()
+    total = 32 * 32 * final_passes
+    shares = []
+    for r in range(world):
+        got = json.load(open(tmp_path / ("f8-rank%d.json" % r)))
+        assert got["passes"][-1] == final_passes
+        shares.append(got["final_samples"])
+        assert np.array_equal(np.load(tmp_path / ("f8-rank%d.npy" % r)), ref) and np.isfinite(ref).all() and ref.mean() > 0.01
+    assert sum(shares) == total and min(shares) >= total // (2 * world), shares   # (64 tiles of 4 x 4 pixels over 8 ranks: an eighth each)
+
+
+SECONDS_CANCEL_WORKER = r'''
+import os, sys, threading
+sys.path.insert(0, sys.argv[1])
+import ctypes, torch.distributed as dist
+import ppg_host
+from ppg_host.distributed import HostReducer, RenderAborted
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+lib = ctypes.CDLL(sys.argv[2])
+props = dict(budgetType="seconds", budget=60.0, maxDepth=6, rrDepth=10, strictNormals=1, seed=5, sampleCombination=sys.argv[4], sppPerPass=1)  # loss = none: no round hook
+e = ppg_host.Engine(lib, "ppgo_", **props)
+lib.ppgo_set_modes(e.ctx, 0, 0, 1)
+e.set_scene(ppg_host.cbox_scene(32, 24)); e.set_shard(rank, world, 8)
+gpt = ppg_host.GuidedPathTracer(engine=e, reducer=HostReducer(dist))
+if rank == 1:
+    threading.Timer(1.5, gpt.cancel).start()   # in the middle of some iteration's passes: the others are in (or on their way to) a stop hook
+try:
+    gpt.render()
+    outcome = "finished"
+except ppg_host.PPGError as ex:
+    outcome = "ppg-error %d" % ex.code
+except RenderAborted:
+    outcome = "aborted"
+open(os.path.join(sys.argv[3], "sc-rank%d.txt" % rank), "w").write(outcome)
+# the reducer and the engine are usable again: a short render finishes on every rank
+e2 = ppg_host.Engine(lib, "ppgo_", **dict(props, budget=0.5))
+lib.ppgo_set_modes(e2.ctx, 0, 0, 1)
+e2.set_scene(ppg_host.cbox_scene(32, 24)); e2.set_shard(rank, world, 8)
+gpt2 = ppg_host.GuidedPathTracer(engine=e2, reducer=gpt.reducer)
+img = gpt2.render()
+open(os.path.join(sys.argv[3], "sc-again-rank%d.txt" % rank), "w").write("%.6f" % float(img.mean()))
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("combo", ["automatic", "discard"])
+def test_cancelled_rank_takes_the_others_out_of_a_time_budget(oracle_lib, tmp_path, combo):
+    """ADVICE r4: budgetType = seconds without a learned fraction — the reference's defaults — has no round hook; a cancelled rank used to
+    leave the batch loop for the image exchange while the others asked the stop hook (a broadcast without a status word): mismatched
+    collectives.  Now the stop decision is ONE all-reduce of (rank 0's decision, status words), a cancelled rank asks it once more before it
+    leaves, everybody stops there, and the image exchange that follows aborts the render on all ranks — long before the 60 s budget."""
+    import time
+    script = tmp_path / "seconds_cancel_worker.py"
+    script.write_text(SECONDS_CANCEL_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(37500 + os.getpid() % 2000), OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3", "--master-addr", "127.0.0.1",
+           "--master-port", env["MASTER_PORT"], str(script), os.path.join(ROOT, "practical-path-guiding_amd"),
+           os.path.join(ROOT, "oracle", "libppg_oracle.so"), str(tmp_path), combo]
+    t0 = time.monotonic()
+    subprocess.run(cmd, check=True, env=env, timeout=120, capture_output=True)
+    assert time.monotonic() - t0 < 50   # (nobody rendered out the 60 s)
+    outcomes = [(tmp_path / ("sc-rank%d.txt" % r)).read_text() for r in range(3)]
+    assert all(o.startswith(("ppg-error", "aborted")) for o in outcomes), outcomes
+    again = {(tmp_path / ("sc-again-rank%d.txt" % r)).read_text() for r in range(3)}
+    assert len(again) == 1 and float(again.pop()) > 0.01
+
+
 def _time_budget_checks(make_engine, scene, budget):
     """renderTime (GP:1434-1514): iterations of 1, 2, 4, ... passes until the budget is spent; with sampleCombination = automatic the
     last iteration keeps rendering batches of its own size until the time is up (GP:1482-1501)."""
