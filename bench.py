@@ -57,14 +57,35 @@ REF_KITCHEN_LOG = {"msamples_per_s": 1.34, "seconds": 500.9, "samples": 672.00e6
 KITCHEN_REFERENCE = os.path.join(ROOT, "tests", "golden", "ref_kitchen_reference.npz")
 
 
-def algorithmic_bytes(work=None, rays=None, bvh=None):
+def stored_operation_counts(tag):
+    """S-tree lookups / D-tree levels per ray of the same workload from the newest committed bench line that measured them with the CPU
+    restatement (profiles/rNN_bench_default.json) — what a run with --no-cpu prices its kernels with, instead of another scene's counts."""
+    if tag != "kitchen":
+        return None
+    for name in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_bench_default.json") or f.endswith("_bench_default_plain.json")), reverse=True):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", name)))
+            oc = d["roofline"]["operation_counts"]
+            if "cpu_baseline" in d and d["config"].get("headline_scene"):
+                return (oc["lookups_per_ray"], oc["dtree_sample_levels_per_ray"], oc["dtree_pdf_levels_per_ray"]), name
+        except Exception:
+            pass
+    return None
+
+
+def algorithmic_bytes(work=None, rays=None, bvh=None, tag=None):
     """ALGORITHMIC bytes per unit of each path kernel: bytes the kernel's algorithm touches per unit, cache-oblivious,
     from the data layout of ppg_kernels.h and operation counts of the same workload: `work` = ppgo_work_counters of the CPU restatement
     with `rays` rays traced (S-tree lookups, D-tree levels), `bvh` = (nodes visited, triangles tested, rays) counted by k_trace itself."""
+    source = "this run's cpu_baseline (ppgo_work_counters of the CPU restatement on the same scene and settings)"
     if work and rays:
         lookups, ds, dp = work[1] / rays, work[2] / rays, work[4] / rays
     else:
-        lookups, ds, dp = 0.70, 1.31, 2.48
+        stored = stored_operation_counts(tag)
+        if stored:
+            (lookups, ds, dp), source = stored[0], "profiles/%s (the newest committed line of this workload that ran the CPU restatement; this run had --no-cpu)" % stored[1]
+        else:
+            lookups, ds, dp, source = 0.70, 1.31, 2.48, "constants measured on cbox-720p (no CPU leg in this run and no committed line of this workload)"
     state_rd = 4 + 5 * 16                              # queue entry, ray_d, thr, li, hit, misc
     state_wr = 5 * 16 * lookups                        # ray_o, ray_d, thr, li (per surviving path) + misc
     shade = (state_rd + state_wr + 48 + 16             # + hit triangle (3 float4) + material
@@ -72,18 +93,23 @@ def algorithmic_bytes(work=None, rays=None, bvh=None):
              + (ds + dp) * 32                          # sampling-tree nodes
              + lookups * 64)                           # speculative vertex record (4 float4)
     trace = 32 + 16                                    # ray in, hit out (small scenes: the triangles are LDS resident)
-    detail = {"lookups_per_ray": lookups, "dtree_sample_levels_per_ray": ds, "dtree_pdf_levels_per_ray": dp}
+    detail = {"lookups_per_ray": lookups, "dtree_sample_levels_per_ray": ds, "dtree_pdf_levels_per_ray": dp, "source": source}
     if bvh and bvh[2]:
         n_bar, t_bar = bvh[0] / bvh[2], bvh[1] / bvh[2]
         trace += n_bar * 64 + t_bar * 48               # quantised BVH4 node = 64 B, TriAccel record = 48 B
         detail.update(bvh4_nodes_per_ray=n_bar, triangles_tested_per_ray=t_bar)
-    return {"k_shade": shade, "k_trace": trace, "k_tail": trace + shade, "k_commit": 16 + 64 + 5 * 8 + 16, "k_generate": 80, "k_film": 4 * 16 + 88, "detail": detail}
+    # the commit, per RECORDED VERTEX: k_commit reads the path word + the vertex slot (4 float4; 6 with a spatial filter) and adds to ~5 leaf
+    # accumulators + the weight; a round of the optimiser instead writes records (k_commit_records: path word amortised over the path's
+    # vertices + 6 float4 read, key 8 + optimiser record 32 + splat record 16 written), sorts them, and k_splat_sorted reads key 8 + index 4
+    # + splat record 16 per record (the D-tree is in LDS); k_adam_apply reads key 8 + index 4 + record 32
+    return {"k_shade": shade, "k_trace": trace, "k_tail": trace + shade, "k_commit": 16 + 64 + 5 * 8 + 16, "k_commit_records": 4 + 96 + 56, "k_splat_sorted": 28,
+            "k_adam_apply": 44, "k_generate": 80, "k_film": 4 * 16 + 88, "detail": detail}
 
 
 def measured_traffic(tag):
     """HBM bytes per unit from profiles/<tag>_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, calibrated as
     MI355X_MICROARCH.md prescribes; written by tools/collect_profiles.py on the GPU box) — a STORED calibration, not measured in this run."""
-    for name in ("r04_pmc_traffic_%s.json" % tag, "r03_pmc_traffic_%s.json" % tag, "r02_pmc_traffic_%s.json" % tag, "r01_pmc_traffic.json" if tag == "cbox" else ""):
+    for name in ("r05_pmc_traffic_%s.json" % tag, "r04_pmc_traffic_%s.json" % tag, "r03_pmc_traffic_%s.json" % tag, "r02_pmc_traffic_%s.json" % tag, "r01_pmc_traffic.json" if tag == "cbox" else ""):
         p = os.path.join(ROOT, "profiles", name)
         if name and os.path.exists(p):
             try:
@@ -275,7 +301,8 @@ def run(args):
     out = {
         "metric": "Msamples/s", "value": samples / dt / 1e6, "unit": "Msamples/s", "n_gpus": args.gpus, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+        "data": "real-scene" if scene_name in ("kitchen", "file") else "synthetic",  # (the reference's own scene data, converted; camera rays and samples are generated)
         "config": {"workload": workload, "scene_file": scene_check, "headline_scene": scene_name == "kitchen",
                    "iterations": [it["passes"] for it in iterations], "parallelism": "tiles%d" % args.gpus,
                    "rays_per_sample": rays / max(1, own_samples), "avg_path_length": plen / max(1, own_samples), "variance_last_iteration": var_last},
@@ -307,7 +334,7 @@ def run(args):
         import ctypes
         cores = os.cpu_count() or 1
         lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "libppg_oracle.so"))
-        cp = args.cpu_passes
+        cp = args.cpu_passes if args.cpu_passes > 0 else min(args.steps, 20)  # (the GPU's own pass schedule when the render is short enough)
         o = ppg_host.Engine(lib, "ppgo_", budget=float(cp * spp), **{k: v for k, v in props.items() if k != "device"})
         lib.ppgo_set_modes(o.ctx, 0, 0, cores)
         og = ppg_host.GuidedPathTracer(engine=o)
@@ -319,9 +346,26 @@ def run(args):
         lib.ppgo_work_counters(o.ctx, wk)
         work = list(wk)
         rays_cpu = sum(s["rays"] for it in og.iterations for s in it["stats"])
+        # ... and ONE core, for per-core normalisation: the same scene and settings on a film shrunk to 1/8 x 1/8 (same field of
+        # view), 3 passes — a whole film on one core would take minutes per pass
+        one = None
+        if hasattr(scene, "camera") and not args.no_cpu_1core:
+            import copy
+            small1 = copy.copy(scene)
+            w1, h1 = max(16, args.width // 8), max(9, args.height // 8)
+            small1.camera = ppg_host.resize_camera(scene.camera, w1, h1)
+            o1 = ppg_host.Engine(lib, "ppgo_", budget=float(3 * spp), **{k: v for k, v in props.items() if k != "device"})
+            lib.ppgo_set_modes(o1.ctx, 0, 0, 1)
+            o1.set_scene(small1)
+            t1 = time.perf_counter()
+            ppg_host.GuidedPathTracer(engine=o1).render()
+            dt1c = time.perf_counter() - t1
+            one = {"value": w1 * h1 * spp * 3 / dt1c / 1e6, "unit": "Msamples/s", "cores": 1, "seconds": dt1c,
+                   "sample": "3 passes of the same scene and settings on a %dx%d film (the full film on one core takes minutes per pass)" % (w1, h1)}
+            del o1
         out["cpu_baseline"] = {"value": args.width * args.height * spp * cp / dtc / 1e6, "unit": "Msamples/s", "cores": cores,
                                "kind": "port", "sample": "first %d passes (%d spp) of the same render(), oracle restatement, OpenMP over 32x32 blocks"
-                               % (cp, cp * spp), "seconds": dtc,
+                               % (cp, cp * spp), "seconds": dtc, "one_core": one,
                                "note": "a PORT on this box's host cores (brute-force / median-split BVH, software libm: slower than the reference binary was on 16 "
                                        "cores) — a reported baseline, not the yardstick; the reference's own figure is `reference_log`"}
         del og, o
@@ -334,6 +378,7 @@ def run(args):
         g2.render()
         times = g2.engine.kernel_times()
         rays2 = sum(s["rays"] for it in g2.iterations for s in it["stats"])
+        its2 = g2.iterations
         sync()
         del g2
     if rank == 0 and times:
@@ -341,7 +386,13 @@ def run(args):
         times = [k for k in times if k["launches"] > 0]
         trace_rays = sum(k["units"] for k in times if k["name"] == "k_trace")
         bvh = (counts.get("bvh_nodes_visited", 0), counts.get("bvh_triangles_tested", 0), trace_rays) if counts else None
-        alg = algorithmic_bytes(work, rays_cpu, bvh)
+        alg = algorithmic_bytes(work, rays_cpu, bvh, traffic_tag)
+        # the commit's unit is a recorded vertex (the library books its launches by paths): iterations rendered in rounds of the optimiser
+        # commit through k_commit_records / k_splat_sorted, the others (the first one; every one without a learned fraction) through k_commit
+        rounds_on = props.get("bsdfSamplingFractionLoss", "none") != "none" and props.get("spatialFilter", "nearest") != "box" and props.get("nee", "never") != "kickstart"
+        v_round = sum(s["vertices_committed"] for it in its2 for s in it["stats"] if rounds_on and it["iter"] > 0)
+        v_plain = sum(s["vertices_committed"] for it in its2 for s in it["stats"]) - v_round
+        commit_units = {"k_commit": v_plain, "k_commit_records": v_round, "k_splat_sorted": v_round}
         tr, tr_file = measured_traffic(traffic_tag)
 
         def entry(k):
@@ -349,6 +400,8 @@ def run(args):
             units = k["units"]
             if name == "k_tail":  # the persistent-thread tail traces AND shades: its unit is a ray it traced = all rays - those k_trace traced
                 units = max(0, rays2 - trace_rays)
+            if name in commit_units:
+                units = commit_units[name]
             bpu = alg.get(name)
             if bpu is None or not units:
                 return None
@@ -372,6 +425,7 @@ def run(args):
                            "avg_launch_ms": dom["avg_launch_ms"], "launches": dom["launches"],
                            "algorithmic_bytes_per_unit": dom["algorithmic_bytes_per_unit"], "avg_units_per_launch": dom["avg_units_per_launch"],
                            "unit_of_work": "ray traced and shaded inside the persistent-thread tail" if name == "k_tail" else ("traced ray" if name in ("k_trace", "k_shade") else "unit of " + name),
+                           "units_of_the_commit": "recorded vertex (k_commit, k_commit_records, k_splat_sorted); optimiser record (k_adam_apply)",
                            "tail_critical_path": ({"longest_paths_sum_bounces": counts["tail_longest_paths_sum"], "k_tail_ms": next((k["ms"] for k in times if k["name"] == "k_tail"), None),
                                                    "us_per_bounce_of_the_longest_path": 1e3 * next((k["ms"] for k in times if k["name"] == "k_tail"), 0.0) / counts["tail_longest_paths_sum"],
                                                    "note": "a launch of k_tail cannot end before its longest path has: the sum over its launches of the longest path each finished "
@@ -382,7 +436,7 @@ def run(args):
                                                   if counts.get("tail_longest_paths_sum") else None),
                            "operation_counts": alg["detail"], "kernels_ms": {k["name"]: round(k["ms"], 3) for k in times},
                            "per_kernel": {n: {q: (round(v, 4) if isinstance(v, float) else v) for q, v in e.items() if q != "kernel"} for n, e in per.items()
-                                          if n.split("<")[0] in ("k_trace", "k_shade", "k_tail", "k_commit")},
+                                          if n.split("<")[0] in ("k_trace", "k_shade", "k_tail", "k_commit", "k_commit_records", "k_splat_sorted", "k_adam_apply")},
                            "note": "the BVH and the SD-tree are L2 / Infinity-Cache resident: the algorithmic bytes are what the kernel must read per ray "
                                    "(cache-oblivious), `traffic` what reaches HBM.  k_tail finishes the paths still alive after the wavefront bounces, one lane per "
                                    "path: it is bound by the chain of dependent bounces of its longest path (`tail_critical_path`), not by bandwidth (DESIGN.md §7)"}
@@ -496,7 +550,8 @@ def main():
     ap.add_argument("--constant-env", help="with a scene file: R,G,B of a constant environment emitter (STAND-IN lighting)")
     ap.add_argument("--room-boxes", type=int, default=1820, help="boxes of the room scene (768 triangles each)")
     ap.add_argument("--glossy", action="store_true", help="room scene with the S3 material mix (GGX alpha 0.1 metal, plastic) instead of Lambertian only")
-    ap.add_argument("--cpu-passes", type=int, default=15, help="passes timed on the CPU baseline (bounded sample)")
+    ap.add_argument("--cpu-passes", type=int, default=0, help="passes timed on the CPU baseline (bounded sample); 0 = min(--steps, 20): the GPU's own schedule for the driver's command")
+    ap.add_argument("--no-cpu-1core", action="store_true", help="skip the one-core leg of the CPU baseline")
     ap.add_argument("--secondary-passes", type=int, default=63)
     ap.add_argument("--repeats", type=int, default=5, help="timed renders; value = their median (min / max reported)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -506,7 +561,18 @@ def main():
     ap.add_argument("--no-single-call", action="store_true", help="skip the extra render through ppg_render() (the single C-ABI call)")
     ap.add_argument("--all-diffuse", action="store_true", help="experiment: replace every BSDF of a scene file by a grey two-sided Lambertian")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the reducer even with one rank (plumbing check)")
-    run(ap.parse_args())
+    args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # the plain command `python bench.py --gpus N ...`: start the N ranks ourselves (one process per GPU over RCCL), as the launcher would
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
+    run(args)
 
 
 if __name__ == "__main__":

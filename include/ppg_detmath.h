@@ -134,6 +134,29 @@ PPG_HD float ppg_powi(float b, int n) {
     return r;
 }
 
+/* The bias-corrected learning rate of AdamOptimizer::step (GP:100):
+       Float actualLearningRate = learningRate * std::sqrt(1 - std::pow(beta2, iter)) / (1 - std::pow(beta1, iter));
+   std::pow(float, int) is the promoting overload of C++11 — both arguments become double — so the reference evaluates the whole right-hand
+   side in DOUBLE and rounds once, on the assignment to Float.  The same here: the powers by binary exponentiation in double (a few double
+   ulps from libm's pow), the square root by two Newton steps from the correctly rounded float root (IEEE +, *, / only: the same bits on
+   x86-64 and gfx950, whatever either does for a double sqrt), one rounding to float at the end — which, the double result being ~1e-15
+   accurate, is the reference's float except at a rounding tie. */
+PPG_HD double ppg_powi_d(double b, int n) {
+    double r = 1.0;
+    while (n > 0) {
+        if (n & 1) r = r * b;
+        b = b * b;
+        n >>= 1;
+    }
+    return r;
+}
+PPG_HD float ppg_adam_learning_rate(float learningRate, float beta1, float beta2, int iter) {
+    const double x = 1.0 - ppg_powi_d((double)beta2, iter);
+    double y = (double)__builtin_sqrtf((float)x);
+    if (y > 0.0) { y = 0.5 * (y + x / y); y = 0.5 * (y + x / y); }
+    return (float)((double)learningRate * y / (1.0 - ppg_powi_d((double)beta1, iter)));
+}
+
 /* Fixed-point accumulation of SD-tree statistics: round-to-nearest-even of x * 2^24 as uint64.
    Supported range of ONE contribution: [2^-25, 2^26) — smaller values round to 0, larger ones (and +inf) are clamped to 2^26 = 2^50
    fixed-point units, NaN contributes nothing.  A bin can therefore absorb 2^13 maximal contributions (or 2^39 of unit size) before the

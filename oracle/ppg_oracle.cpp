@@ -194,10 +194,10 @@ public:
         }
     }
 
-    void step(Float gradient) {  // GP:97-109 (pow → ppg_powi, see header)
+    void step(Float gradient) {  // GP:97-109
         ++m_state.iter;
-        Float actualLearningRate = m_hparams.learningRate * std::sqrt(1 - ppg_powi(m_hparams.beta2, m_state.iter)) /
-                                   (1 - ppg_powi(m_hparams.beta1, m_state.iter));
+        // GP:100: std::pow(float, int) promotes to double, the expression is evaluated in double and rounded once (ppg_detmath.h)
+        Float actualLearningRate = ppg_adam_learning_rate(m_hparams.learningRate, m_hparams.beta1, m_hparams.beta2, m_state.iter);
         m_state.firstMoment = m_hparams.beta1 * m_state.firstMoment + (1 - m_hparams.beta1) * gradient;
         m_state.secondMoment = m_hparams.beta2 * m_state.secondMoment + (1 - m_hparams.beta2) * gradient * gradient;
         m_state.variable -= actualLearningRate * m_state.firstMoment / (std::sqrt(m_state.secondMoment) + m_hparams.epsilon);
@@ -3695,6 +3695,7 @@ int ppgo_math_eval(int32_t op, uint32_t n, const float *a, const float *b, float
             case 3: out0[i] = ppg_from_fixed(ppg_to_fixed(a[i])); break;
             case 4: out0[i] = ppg_rand((uint32_t)i * 2654435761u + 17u, (uint32_t)b[i]); break;
             case 5: out0[i] = ppg_powi(a[i], (int)b[i]); break;
+            case 9: out0[i] = ppg_adam_learning_rate(0.01f, 0.9f, 0.999f, (int)a[i]); break;  // AdamOptimizer::step's learning rate at iteration a
             case 6: out0[i] = ppg_log(a[i]); break;
             case 7: out0[i] = ppg_pow(a[i], b[i]); break;
             case 8: {  // draw `dim` of the path (seed, pixel, sample index): a = pixel, b = seed << 16 | sample << 4 | dim, as bit patterns

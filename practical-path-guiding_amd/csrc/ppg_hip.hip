@@ -1026,6 +1026,14 @@ int applyAdamRound(ppg_ctx *ctx, size_t nRecords) {
     const unsigned int endBit = PPG_ADAM_LEAF_SHIFT + leafBits;
     if (ctx->sortedCommit && ctx->adamFlagShift != endBit) { ctx->error = "internal: flag bit of the round's records"; return PPG_ERR_STATE; }
     size_t n = nRecords;
+    // The splats and the optimiser read the same sorted records and write different things (the building tree; the leaf headers' optimiser
+    // state): k_splat_sorted runs on the second stream BESIDE the order / apply kernels — and beside the round hook's exchanges of a
+    // sharded render —, whose serial chains leave most of the GPU idle.  Joined before the sorted arrays are reused and before returning.
+    struct Join {
+        ppg_ctx *c; bool forked = false;
+        void now() { if (forked) { (void)hipStreamWaitEvent(c->stream, c->evJoin, 0); forked = false; } }
+        ~Join() { now(); }
+    } join{ctx};
     if (n > 0) {
         int rc = PPG_OK;
         // (a round committed through records: one more bit, "a splat only", just above the leaf — those records sort behind the optimiser's)
@@ -1034,7 +1042,14 @@ int applyAdamRound(ppg_ctx *ctx, size_t nRecords) {
         if (ctx->sortedCommit) {  // DTree::recordIrradiance of every record of the round, D-tree by D-tree (ppg_kernels.h "The commit of a ROUND")
             const unsigned int chunks = (unsigned int)((n + PPG_SPLAT_CHUNK - 1) / PPG_SPLAT_CHUNK);
             SplatLaunch a{(int)std::max(1u, std::min(chunks, 256u * 8u)), s, ctx->devTree(), ctx->d_adamKeys[1].p, ctx->d_adamIdx[1].p, ctx->d_splat.p, (unsigned int)n, leafBits, ctx->tuneSplatLdsNodes};
-            timedLaunch(ctx, "k_splat_sorted", n, [&] { ppg_launch_splat(ctx->directionalFilter, a); });
+            if (!ctx->timer.enabled && !ctx->tuneNoOverlap) {
+                HIP_CHECK(hipEventRecord(ctx->evFork, s));
+                HIP_CHECK(hipStreamWaitEvent(ctx->stream2, ctx->evFork, 0));
+                a.stream = ctx->stream2;
+                ppg_launch_splat(ctx->directionalFilter, a);
+                HIP_CHECK(hipEventRecord(ctx->evJoin, ctx->stream2));
+                join.forked = true;
+            } else timedLaunch(ctx, "k_splat_sorted", n, [&] { ppg_launch_splat(ctx->directionalFilter, a); });
             HIP_CHECK(hipGetLastError());
         }
     }
@@ -1055,6 +1070,7 @@ int applyAdamRound(ppg_ctx *ctx, size_t nRecords) {
         ctx->inHook = false;
         if (hrc != 0) { ctx->error = "round hook failed"; return PPG_ERR_INVALID; }
         if (ctx->hookReplaced) {  // the union over all ranks, in d_adamRecs: sort it by the whole key
+            join.now();  // (the sort below overwrites the arrays k_splat_sorted reads)
             n = (size_t)ctx->hookCount;
             if (n > 0) {
                 HIP_CHECK(ctx->d_adamKeys[0].reserve(n));

@@ -1937,7 +1937,7 @@ static __global__ __launch_bounds__(256) void k_adam_apply(LeafHdr *hdr, const u
         float myLr = 0.0f;
         if ((stepMask >> lane) & 1ull) {
             const int it = iter + (int)__popcll(stepMask & ((2ull << lane) - 1ull));
-            myLr = 0.01f * __builtin_sqrtf(1 - ppg_powi(0.999f, it)) / (1 - ppg_powi(0.9f, it));
+            myLr = ppg_adam_learning_rate(0.01f, 0.9f, 0.999f, it);  // GP:100, evaluated in double like the reference (ppg_detmath.h)
         }
         for (unsigned int t = 0; t < cnt;) {
             // Every lane: the gradient of ITS record at the current variable (optimizeBsdfSamplingFraction, GP:672-691).  The records up to the

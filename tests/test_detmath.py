@@ -53,6 +53,20 @@ def test_powi(oracle_lib):
     assert np.allclose(p, np.float64(np.float32(0.999)) ** n.astype(np.float64), rtol=1e-4)  # error grows ~ n * 2^-24; only feeds Adam's bias correction (GP:100)
 
 
+def test_adam_learning_rate_is_the_references_double_expression(oracle_lib):
+    """GP:100: learningRate * std::sqrt(1 - std::pow(beta2, iter)) / (1 - std::pow(beta1, iter)) — std::pow(float, int) promotes to double, so
+    the reference evaluates it in double and rounds once (the float powers of round 4 were 3e-5 off at iter = 2).  The shared
+    function must give that float: equal to numpy's double evaluation rounded to float, up to a rounding tie (none in this range)."""
+    it = np.arange(1, 20001, dtype=np.float32)
+    lr, _ = _eval(oracle_lib, 9, it)
+    b1, b2, l0 = np.float64(np.float32(0.9)), np.float64(np.float32(0.999)), np.float64(np.float32(0.01))
+    ref = (l0 * np.sqrt(1 - b2 ** it.astype(np.float64)) / (1 - b1 ** it.astype(np.float64))).astype(np.float32)
+    assert np.array_equal(lr, ref)
+    big = np.array([1 << 20, 1 << 24, (1 << 24) - 1], np.float32)  # the iteration count keeps growing over a render
+    lr, _ = _eval(oracle_lib, 9, big)
+    assert np.array_equal(lr, np.full(3, np.float32(0.01)))
+
+
 def test_rng_uniform(oracle_lib):
     dims = np.tile(np.arange(8, dtype=np.float32), 50000)
     u, _ = _eval(oracle_lib, 4, dims, dims)
