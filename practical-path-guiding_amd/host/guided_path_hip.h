@@ -107,7 +107,7 @@ public:
 
 class GuidedPathTracerHIP {
 public:
-    typedef std::function<void(const std::string &)> Log;
+    typedef std::function<void(const std::string &)> LogFn;  // (not "Log": that is a macro of Mitsuba's logger.h, and the plug-in includes this header)
 
     explicit GuidedPathTracerHIP(const Properties &props) {  // GP:1014-1085 + MonteCarloIntegrator (integrator.cpp:190-225)
         ppg_config_default(&m_cfg);
@@ -141,7 +141,7 @@ public:
 
     // render(): GP:1516-1585.  Returns false when cancelled, throws on errors.  With a reducer the image is sharded by 32x32 tiles over
     // reducer->world() ranks (every rank calls render() on the same scene) and the film is complete on every rank afterwards.
-    bool render(const SceneData &scene, const Log &log = Log(), Reducer *reducer = nullptr) {
+    bool render(const SceneData &scene, const LogFn &log = LogFn(), Reducer *reducer = nullptr) {
         m_reducer = reducer;
         // (cancel() is sticky in the library: one that arrived before this call — or during ppg_set_scene below — cancels this render,
         // ppg_begin_render consumes it; m_cancelled, which the hooks read, is reset when the render is over)
@@ -181,14 +181,14 @@ private:
         va_list ap; va_start(ap, f); vsnprintf(buf, sizeof buf, f, ap); va_end(ap);
         return buf;
     }
-    static void say(const Log &log, const std::string &s) { if (log) log(s); }
+    static void say(const LogFn &log, const std::string &s) { if (log) log(s); }
     void check(int rc, const char *what) {
         rethrowHookError();
         if (rc != PPG_OK && rc != PPG_ERR_CANCELLED) throw std::runtime_error(std::string(what) + ": " + ppg_last_error(m_ctx));
     }
 
     // performRenderPasses, GP:1210-1329
-    bool passes(int n, ppg_pass_stats &st, const Log &log, bool finalGroups = false) {
+    bool passes(int n, ppg_pass_stats &st, const LogFn &log, bool finalGroups = false) {
         say(log, fmt("Rendering %d render passes.", n));
         int rc;
         if (!m_reducer) {
@@ -222,7 +222,7 @@ private:
         m_passesRendered = st.passes_rendered_total;
         return rc == PPG_OK;
     }
-    void build(const Log &log, bool nothingRecorded = false) {  // buildSDTree, GP:1115-1189
+    void build(const LogFn &log, bool nothingRecorded = false) {  // buildSDTree, GP:1115-1189
         if (m_reducer && !nothingRecorded) m_reducer->reduceSDTree(m_ctx);  // (an iteration that was final from its first pass records nothing)
         say(log, "Building distributions for sampling.");
         ppg_tree_stats t;
@@ -238,7 +238,7 @@ private:
         return nee == "never" ? false : (nee == "kickstart" ? spp < 128 : true);
     }
 
-    bool renderSPP(const Log &log) {  // GP:1342-1426
+    bool renderSPP(const LogFn &log) {  // GP:1342-1426
         const size_t sampleCount = (size_t)m_cfg.budget;
         const int nPasses = (int)std::ceil(sampleCount / (float)m_cfg.sppPerPass);
         float currentVarAtEnd = std::numeric_limits<float>::infinity();
@@ -276,7 +276,7 @@ private:
         return true;
     }
 
-    bool renderTime(const Log &log) {  // GP:1434-1514
+    bool renderTime(const LogFn &log) {  // GP:1434-1514
         const float nSeconds = m_cfg.budget;
         float currentVarAtEnd = std::numeric_limits<float>::infinity();
         const bool automatic = std::string(m_cfg.sampleCombination) == "automatic";

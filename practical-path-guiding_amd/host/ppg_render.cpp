@@ -334,7 +334,7 @@ int main(int argc, char **argv) {
         GuidedPathTracerHIP gpt(props);
         const auto t0 = std::chrono::steady_clock::now();
         const bool talk = !quiet && rank == 0;
-        bool ok = gpt.render(scene, talk ? [](const std::string &s) { std::cout << s << std::endl; } : GuidedPathTracerHIP::Log(), reducer.get());
+        bool ok = gpt.render(scene, talk ? [](const std::string &s) { std::cout << s << std::endl; } : GuidedPathTracerHIP::LogFn(), reducer.get());
         const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (talk) std::cout << "Render time: " << sec << "s" << (ok ? "" : " (cancelled)") << std::endl;
         if (reducer && talk) std::cout << "RCCL: " << reducer->collectives() << " collectives, " << reducer->bytes() / 1e6 << " MB staged" << std::endl;

@@ -33,6 +33,7 @@
 #include <mitsuba/render/film.h>
 #include <mitsuba/render/emitter.h>
 #include <mitsuba/core/plugin.h>
+#include <mitsuba/core/fresolver.h>   /* Thread::getFileResolver()->resolve(): the running Mitsuba's data directory */
 #include <mitsuba/core/bitmap.h>
 #include <mitsuba/core/statistics.h>
 
