@@ -482,6 +482,19 @@ struct ppg_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;    // k_commit of the finished paths runs here while k_tail finishes the stragglers on `stream`
     hipEvent_t evFork = nullptr, evJoin = nullptr;
+    // The end of a round of the optimiser — k_splat_sorted on stream2, the order / apply kernels on stream3 — runs BESIDE the beginning of the
+    // next batch (k_generate and the first k_trace, which need neither the building tree nor the sampling fractions): k_adam_apply is a set
+    // of serial chains that leaves most of the GPU idle.  treePending: that work has been enqueued and not yet been waited for; joinTree()
+    // makes the context's stream wait for it — before the first kernel that reads the SD-tree or the fractions, and in every entry point.
+    hipStream_t stream3 = nullptr;
+    hipEvent_t evTreeFork = nullptr, evSplatDone = nullptr, evAdamDone = nullptr;
+    bool treePending = false;
+    void joinTree() {
+        if (!treePending) return;
+        (void)hipStreamWaitEvent(stream, evSplatDone, 0);
+        (void)hipStreamWaitEvent(stream, evAdamDone, 0);
+        treePending = false;
+    }
     DevBuf<unsigned char> d_straggler;  // [path] 1 = still alive when the persistent-thread tail took over
     DevBuf<unsigned char> d_nv8;        // [path] vertex slots k_commit takes of the path (k_commit_prepare)
 
@@ -566,7 +579,7 @@ struct ppg_ctx {
     DevBuf<float4> d_splat;       // a round's splat records (k_commit_records), at the positions of the optimiser's records
     bool sortedCommit = false;    // this round commits through records + sort + k_splat_sorted instead of k_commit
     unsigned int adamFlagShift = 0;  // key bit of "a splat only" in such a round: just above the leaf bits
-    DevBuf<unsigned char> d_sortTemp;
+    DevBuf<unsigned char> d_sortTemp, d_orderTemp;
     DevBuf<unsigned int> d_adamLeafCount[2], d_adamLeafOrder[2];  // k_adam_apply's order of the D-trees: most records first
     size_t adamIota = 0;          // d_adamIdx[0][0 .. adamIota) holds the identity permutation
     bool adamFast = false;        // record positions known in advance (DevTree::adam_base)
@@ -599,6 +612,7 @@ struct ppg_ctx {
     bool tuneNoOverlap = false;       // PPG_NO_OVERLAP: k_commit after k_tail on one stream instead of beside it
     bool tuneNoSortedCommit = false;  // PPG_NO_SORTED_COMMIT: a round of the optimiser commits with k_commit (global atomics) instead of records + sort + k_splat_sorted
     unsigned int tuneSplatLdsNodes = PPG_SPLAT_NODES;  // PPG_SPLAT_LDS_NODES: k_splat_sorted stages D-trees of up to this many nodes in LDS (<= PPG_SPLAT_NODES)
+    bool tuneNoAside = false;         // PPG_NO_ASIDE: the optimiser's order / apply kernels stay on the context's stream (k_splat_sorted still runs beside them)
     bool tuneAdamUnordered = false;   // PPG_ADAM_UNORDERED: k_adam_apply takes the D-trees in leaf order instead of busiest first
     int tuneBulkBounces = -1;         // PPG_BULK_BOUNCES: fixed number of wavefront bounces before k_tail takes over (-1 = adaptive)
     bool debugBatch = false;          // PPG_DEBUG_BATCH: one line per batch on stderr (paths, live paths after every bulk bounce, tail time)
@@ -779,6 +793,7 @@ int refineDevice(ppg_ctx *ctx, size_t sTreeThreshold, int maxMB) {
 }
 
 int resetSDTree(ppg_ctx *ctx) {  // GP:1108-1113
+    ctx->joinTree();
     double thr = std::sqrt(std::ldexp(1.0, ctx->iter) * ctx->sppPerPass / 4) * ctx->sTreeThreshold;
     int rc = refineDevice(ctx, (size_t)thr, ctx->sdTreeMaxMemory);
     if (rc) return rc;
@@ -813,6 +828,7 @@ int resetSDTree(ppg_ctx *ctx) {  // GP:1108-1113
 }
 
 int foldWeights(ppg_ctx *ctx) {
+    ctx->joinTree();
     unsigned int nn = (unsigned int)ctx->snodes.size();
     if (!ctx->d_bweightRep.p || nn == 0) return PPG_OK;
     hipLaunchKernelGGL(k_fold_replicas, dim3((nn + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_bweight.p, ctx->d_bweightRep.p, nn);
@@ -821,6 +837,7 @@ int foldWeights(ppg_ctx *ctx) {
 }
 
 int buildSDTree(ppg_ctx *ctx, ppg_tree_stats *st) {  // GP:1115-1189
+    ctx->joinTree();  // (the last round's splats and optimiser steps may still be running beside the context's stream)
     { int rc = foldWeights(ctx); if (rc) return rc; }
     unsigned int nl = (unsigned int)ctx->leaves.size();
     DevTree T = ctx->devTree();
@@ -1034,12 +1051,24 @@ int applyAdamRound(ppg_ctx *ctx, size_t nRecords) {
         void now() { if (forked) { (void)hipStreamWaitEvent(c->stream, c->evJoin, 0); forked = false; } }
         ~Join() { now(); }
     } join{ctx};
+    // (without a round hook the optimiser's kernels leave the context's stream too: ppg_ctx::treePending)
+    const bool aside = ctx->sortedCommit && !ctx->passHook && !ctx->timer.enabled && !ctx->tuneNoOverlap && !ctx->tuneNoAside;
+    hipStream_t sa = aside ? ctx->stream3 : s;  // where the order / apply kernels go
     if (n > 0) {
         int rc = PPG_OK;
         // (a round committed through records: one more bit, "a splat only", just above the leaf — those records sort behind the optimiser's)
         timedLaunch(ctx, "adam_sort(rocprim)", n, [&] { rc = sortAdamRecords(ctx, n, ctx->adamFast ? PPG_ADAM_LEAF_SHIFT : 0u, endBit + (ctx->sortedCommit ? 1u : 0u)); });
         if (rc) return rc;
-        if (ctx->sortedCommit) {  // DTree::recordIrradiance of every record of the round, D-tree by D-tree (ppg_kernels.h "The commit of a ROUND")
+        if (aside) {
+            HIP_CHECK(hipEventRecord(ctx->evTreeFork, s));
+            HIP_CHECK(hipStreamWaitEvent(ctx->stream2, ctx->evTreeFork, 0));
+            HIP_CHECK(hipStreamWaitEvent(ctx->stream3, ctx->evTreeFork, 0));
+            const unsigned int chunks = (unsigned int)((n + PPG_SPLAT_CHUNK - 1) / PPG_SPLAT_CHUNK);
+            SplatLaunch a{(int)std::max(1u, std::min(chunks, 256u * 8u)), ctx->stream2, ctx->devTree(), ctx->d_adamKeys[1].p, ctx->d_adamIdx[1].p, ctx->d_splat.p, (unsigned int)n, leafBits, ctx->tuneSplatLdsNodes};
+            ppg_launch_splat(ctx->directionalFilter, a);
+            HIP_CHECK(hipEventRecord(ctx->evSplatDone, ctx->stream2));
+            HIP_CHECK(hipGetLastError());
+        } else if (ctx->sortedCommit) {  // DTree::recordIrradiance of every record of the round, D-tree by D-tree (ppg_kernels.h "The commit of a ROUND")
             const unsigned int chunks = (unsigned int)((n + PPG_SPLAT_CHUNK - 1) / PPG_SPLAT_CHUNK);
             SplatLaunch a{(int)std::max(1u, std::min(chunks, 256u * 8u)), s, ctx->devTree(), ctx->d_adamKeys[1].p, ctx->d_adamIdx[1].p, ctx->d_splat.p, (unsigned int)n, leafBits, ctx->tuneSplatLdsNodes};
             if (!ctx->timer.enabled && !ctx->tuneNoOverlap) {
@@ -1088,21 +1117,25 @@ int applyAdamRound(ppg_ctx *ctx, size_t nRecords) {
         if (!ctx->tuneAdamUnordered && nl > 1) {
             for (int k = 0; k < 2; ++k) { HIP_CHECK(ctx->d_adamLeafCount[k].reserve(nl)); HIP_CHECK(ctx->d_adamLeafOrder[k].reserve(nl)); }
             size_t bytes = 0;
-            HIP_CHECK(rocprim::radix_sort_pairs_desc(nullptr, bytes, ctx->d_adamLeafCount[0].p, ctx->d_adamLeafCount[1].p, ctx->d_adamLeafOrder[0].p, ctx->d_adamLeafOrder[1].p, (size_t)nl, 0u, 32u, s));
-            HIP_CHECK(ctx->d_sortTemp.reserve(std::max<size_t>(bytes, 16)));
+            HIP_CHECK(rocprim::radix_sort_pairs_desc(nullptr, bytes, ctx->d_adamLeafCount[0].p, ctx->d_adamLeafCount[1].p, ctx->d_adamLeafOrder[0].p, ctx->d_adamLeafOrder[1].p, (size_t)nl, 0u, 32u, sa));
+            HIP_CHECK(ctx->d_orderTemp.reserve(std::max<size_t>(bytes, 16)));  // (its own scratch: the next batch's scans use d_sortTemp on the context's stream)
             timedLaunch(ctx, "adam_order", nl, [&] {
-                hipLaunchKernelGGL(k_adam_counts, dim3((nl + 255u) / 256u), dim3(256), 0, s, ctx->d_leaves.p, nl, ctx->d_adamKeys[1].p, (unsigned int)n, ctx->d_adamLeafCount[0].p,
+                hipLaunchKernelGGL(k_adam_counts, dim3((nl + 255u) / 256u), dim3(256), 0, sa, ctx->d_leaves.p, nl, ctx->d_adamKeys[1].p, (unsigned int)n, ctx->d_adamLeafCount[0].p,
                                    ctx->d_adamLeafOrder[0].p);
-                (void)rocprim::radix_sort_pairs_desc((void *)ctx->d_sortTemp.p, bytes, ctx->d_adamLeafCount[0].p, ctx->d_adamLeafCount[1].p, ctx->d_adamLeafOrder[0].p,
-                                                     ctx->d_adamLeafOrder[1].p, (size_t)nl, 0u, 32u, s);
+                (void)rocprim::radix_sort_pairs_desc((void *)ctx->d_orderTemp.p, bytes, ctx->d_adamLeafCount[0].p, ctx->d_adamLeafCount[1].p, ctx->d_adamLeafOrder[0].p,
+                                                     ctx->d_adamLeafOrder[1].p, (size_t)nl, 0u, 32u, sa);
             });
             order = ctx->d_adamLeafOrder[1].p;
         }
         timedLaunch(ctx, "k_adam_apply", n, [&] {
-            hipLaunchKernelGGL(k_adam_apply, dim3((nl * 64u + 255u) / 256u), dim3(256), 0, s, ctx->d_hdr.p, ctx->d_leaves.p, order, nl, ctx->d_adamKeys[1].p, ctx->d_adamIdx[1].p,
+            hipLaunchKernelGGL(k_adam_apply, dim3((nl * 64u + 255u) / 256u), dim3(256), 0, sa, ctx->d_hdr.p, ctx->d_leaves.p, order, nl, ctx->d_adamKeys[1].p, ctx->d_adamIdx[1].p,
                                ctx->d_adamRecs.p, (unsigned int)n, ctx->loss);
         });
         HIP_CHECK(hipGetLastError());
+        if (aside) {
+            HIP_CHECK(hipEventRecord(ctx->evAdamDone, ctx->stream3));
+            ctx->treePending = true;
+        }
     }
     if (ctx->passHook && ctx->ownerMode) {  // one owner per D-tree: the owners publish the state they computed
         HIP_CHECK(hipStreamSynchronize(s));
@@ -1217,6 +1250,7 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound, const GroupLaunch *gl =
                 });
                 shadeIn = QIN_SORTED;
             }
+            ctx->joinTree();  // (k_generate, the first k_trace and k_sort_slices ran beside the previous round's optimiser: k_shade needs its result)
             // FULL scene, sorted slice, no luminaire sampling: the common material classes first, in their own leaner kernel (MSET_COMMON)
             const bool split = shadeIn == QIN_SORTED && Q.n_common && !neeOn;
             if (split) {
@@ -1255,6 +1289,7 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound, const GroupLaunch *gl =
     // With both, k_commit for the paths that HAVE ended runs on a second stream beside k_tail, and a second, small k_commit takes the
     // stragglers afterwards.  Integer accumulation makes the split invisible in the result.  In a round of the optimiser, the record
     // positions must then be known before the tail has run: a straggler reserves max_vertices positions (unused ones stay holes).
+    ctx->joinTree();  // (a batch without a wavefront bounce)
     const bool tail = unbounded && !fused && P.n_paths > 0;
     const bool commit = !ctx->isFinalIter && P.n_paths > 0;
     const bool overlap = tail && commit && !ctx->timer.enabled && !ctx->tuneNoOverlap;
@@ -1566,6 +1601,7 @@ int allocFilm(ppg_ctx *ctx) {
 
 int beginRender(ppg_ctx *ctx) {  // GP:1519-1550
     HIP_CHECK(hipSetDevice(ctx->device));
+    ctx->joinTree();
     if (!ctx->pathsReady) {  // buffers are sized by scene + shard; normally done by ppg_set_scene / ppg_set_shard
         int rc = allocPaths(ctx);
         if (rc) return rc;
@@ -1650,6 +1686,7 @@ int endIteration(ppg_ctx *ctx) {  // GP:1417-1422
 }
 
 int endRender(ppg_ctx *ctx) {  // GP:1567-1582
+    ctx->joinTree();
 #ifdef PPG_PROBE
     if (ctx->d_probe.p) {
         unsigned long long h[PPG_PROBE_SLOTS];
@@ -1885,6 +1922,7 @@ int ppg_create(const ppg_config *cfg, ppg_ctx **out) {
         c->tuneNoOverlap = getenv("PPG_NO_OVERLAP") != nullptr;
         c->tuneNoSortedCommit = getenv("PPG_NO_SORTED_COMMIT") != nullptr;
         c->tuneAdamUnordered = getenv("PPG_ADAM_UNORDERED") != nullptr;
+        c->tuneNoAside = getenv("PPG_NO_ASIDE") != nullptr;
         if (const char *e = getenv("PPG_SPLAT_LDS_NODES")) c->tuneSplatLdsNodes = (unsigned int)std::max(0, std::min((int)PPG_SPLAT_NODES, atoi(e)));
         if (const char *e = getenv("PPG_BULK_BOUNCES")) c->tuneBulkBounces = std::max(0, atoi(e));
         if (const char *e = getenv("PPG_BOUNCE_MARGIN")) c->bounceMargin = std::max(0, atoi(e));
@@ -1901,7 +1939,9 @@ int ppg_create(const ppg_config *cfg, ppg_ctx **out) {
     if (e != hipSuccess || ndev <= 0) { g_createError = std::string("no HIP device available: ") + hipGetErrorString(e); return PPG_ERR_DEVICE; }
     if (c->device < 0 || c->device >= ndev) { g_createError = "device ordinal out of range"; return PPG_ERR_INVALID; }
     if ((e = hipSetDevice(c->device)) != hipSuccess || (e = hipStreamCreate(&c->stream)) != hipSuccess || (e = createSecondStream(&c->stream2)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming)) != hipSuccess) {
+        (e = hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipStreamCreate(&c->stream3)) != hipSuccess || (e = hipEventCreateWithFlags(&c->evTreeFork, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->evSplatDone, hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&c->evAdamDone, hipEventDisableTiming)) != hipSuccess) {
         g_createError = std::string("HIP init failed: ") + hipGetErrorString(e);
         return PPG_ERR_DEVICE;
     }
@@ -1914,7 +1954,12 @@ void ppg_destroy(ppg_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); }
     g_blockCache.settle();
-    if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
+    if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+    if (ctx->stream3) (void)hipStreamSynchronize(ctx->stream3);
+    g_blockCache.settle();
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
+    for (hipEvent_t ev : {ctx->evTreeFork, ctx->evSplatDone, ctx->evAdamDone}) if (ev) (void)hipEventDestroy(ev);
     if (ctx->evFork) (void)hipEventDestroy(ctx->evFork);
     if (ctx->evJoin) (void)hipEventDestroy(ctx->evJoin);
     ctx->timer.resolve();
@@ -2297,7 +2342,7 @@ int ppg_set_shard(ppg_ctx *ctx, int32_t rank, int32_t world, int32_t tile_size) 
 // every entry point re-selects the context's device: the caller (torch / RCCL in a multi-GPU process) may have changed it
 // ... and names the context's stream as the one buffer growth is ordered on (StreamScope)
 #define NEED_SCENE (void)hipSetDevice(ctx->device); StreamScope scope_(ctx->stream); if (!ctx->haveScene) { ctx->error = "no scene"; return PPG_ERR_STATE; }
-#define NEED_TREE (void)hipSetDevice(ctx->device); StreamScope scope_(ctx->stream); if (!ctx->treeAlive) { ctx->error = "render not begun"; return PPG_ERR_STATE; }
+#define NEED_TREE (void)hipSetDevice(ctx->device); StreamScope scope_(ctx->stream); if (!ctx->treeAlive) { ctx->error = "render not begun"; return PPG_ERR_STATE; } ctx->joinTree();
 
 int ppg_begin_render(ppg_ctx *ctx) { NEED_SCENE return beginRender(ctx); }
 int ppg_begin_iteration(ppg_ctx *ctx, int32_t is_final) { NEED_TREE return beginIteration(ctx, is_final != 0); }

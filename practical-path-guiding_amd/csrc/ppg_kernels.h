@@ -1618,9 +1618,9 @@ __global__ __launch_bounds__(PPG_BLOCK) void k_commit(PathState P, DevTree T, Re
 #define PPG_SPLAT_PER_LANE 8   // records per lane and chunk
 #define PPG_SPLAT_CHUNK (PPG_BLOCK * PPG_SPLAT_PER_LANE)
 
-// PATH-major: a lane takes one path and walks its vertex slots; a wave's 64 neighbouring paths read slot v together (the slots are stored
-// [slot][path]) and own ONE contiguous run of record positions (adam_base is the scan of the vertex counts), which they fill within a few
-// iterations — the partial lines meet in L2 before they reach HBM.  (Work items (slot, path) as in k_commit — slot v of all paths, then slot
+// PATH-major: four lanes take one path and walk its vertex slots; a wave's 16 neighbouring paths read four slots at a time (the slots are
+// stored [slot][path]) and own ONE contiguous run of record positions (adam_base is the scan of the vertex counts), which they fill within
+// a few iterations — the partial lines meet in L2 before they reach HBM.  (Work items (slot, path) as in k_commit — slot v of all paths, then slot
 // v + 1 — wrote every record into a line whose neighbours followed a whole sweep later, tested a byte for the 6 of 7 items beyond their
 // path's last vertex, and divided 64-bit item numbers: 48 ms of a 127-pass render)
 template <int SF>
@@ -1632,9 +1632,13 @@ __global__ __launch_bounds__(PPG_BLOCK) void k_commit_records(PathState P, DevTr
     const float statisticalWeight = (R.nee == NEE_KICKSTART && R.do_nee) ? 0.5f : 1.0f;
     const int loss = T.is_built ? R.loss : LOSS_NONE;
     const unsigned int n_sel = list ? (unsigned int)*list_n : P.n_paths;
-    const unsigned int stride = gridDim.x * blockDim.x;
-    for (unsigned int k0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); k0 < n_sel; k0 += stride) {  // (k0: the wave's first entry)
-        const unsigned int k = k0 + (threadIdx.x & 63u);
+    // FOUR lanes per path (q = lane & 3 takes vertices q, q + 4, ...): a path's records are adjacent, so each step of a quad writes up to
+    // four neighbouring keys (32 B), optimiser records (128 B) and splat records (64 B) — whole sectors instead of one record per line and
+    // step (profiles/r05_pmc_traffic_kitchen.json: 302 B of HBM traffic per vertex against 156 algorithmic with one lane per path)
+    const unsigned int q = threadIdx.x & 3u;
+    const unsigned int stride = (gridDim.x * blockDim.x) >> 2;
+    for (unsigned int k0 = (blockIdx.x * blockDim.x + (threadIdx.x & ~63u)) >> 2; k0 < n_sel; k0 += stride) {  // (k0: the wave's first entry)
+        const unsigned int k = k0 + ((threadIdx.x & 63u) >> 2);
         unsigned int nv = 0, i = 0;
         if (k < n_sel) {
             nv = nv8[k];  // (k_commit_prepare: 0 for a path this launch leaves to the one after the tail; [_list]: by list position)
@@ -1650,7 +1654,7 @@ __global__ __launch_bounds__(PPG_BLOCK) void k_commit_records(PathState P, DevTr
             base = T.adam_base[i];
             pathId = adam_path_id(P, R, i);
         }
-        for (unsigned int v = 0; __any(v < nv); ++v) {
+        for (unsigned int v = q; __any(v < nv); v += 4u) {
             if (!(v < nv)) continue;
             const size_t vi = (size_t)v * P.n_paths + i;
             const float4 a = P.v_d[vi], b = P.v_thr[vi], c = P.v_bsdf[vi], e = P.v_rad[vi];
