@@ -1,6 +1,6 @@
 """The quantised BVH4 of the traversal kernels, checked on the CPU (no GPU needed).
 
-`ppg_debug_build_bvh` (include/ppg.h) runs the builder of `ppg_set_scene` on a triangle soup.  The tests restate the kernels' node test
+`ppg_debug_build_bvh` (include/ppg_testhooks.h) runs the builder of `ppg_set_scene` on a triangle soup.  The tests restate the kernels' node test
 (csrc/ppg_device.h `bvh4_children`: the RAY is scaled to the node's power-of-two grid, t = (q - o') * (1/d'), near / far plane by the
 sign of 1/d, exit distance widened by 1 + 2 gamma_3) in numpy float32, operation for operation, and assert the property the closest
 hit rests on: on the way from the root to a triangle that a ray really hits, no child box is ever reported as missed.  Also the
