@@ -2295,7 +2295,8 @@ int ppg_set_scene(ppg_ctx *ctx, const ppg_scene *s) {
         S.em_area_cdf = ctx->d_emArea.p; S.em_tris = ctx->d_emTris.p; S.em_normals = enrm.empty() ? nullptr : ctx->d_emNrm.p;
     }
     DevScene &S = ctx->scene;
-    S.tris = ctx->d_tris.p; S.tri_class = getenv("PPG_NO_TRI_CLASS") ? nullptr : ctx->d_triClass.p; S.accel = ctx->d_accel.p;  // (PPG_NO_TRI_CLASS: k_sort_slices reads triangle + material, as until round 4) S.normals = s->normals ? ctx->d_normals.p : nullptr; S.bvh = ctx->d_bvh.p; S.bvh4 = ctx->d_bvh4.p; S.bvh_top = ctx->d_bvhTop.p; S.n_top = nTop;
+    S.tris = ctx->d_tris.p; S.accel = ctx->d_accel.p; S.normals = s->normals ? ctx->d_normals.p : nullptr; S.bvh = ctx->d_bvh.p; S.bvh4 = ctx->d_bvh4.p; S.bvh_top = ctx->d_bvhTop.p; S.n_top = nTop;
+    S.tri_class = getenv("PPG_NO_TRI_CLASS") ? nullptr : ctx->d_triClass.p;  // (PPG_NO_TRI_CLASS: k_sort_slices reads triangle + material, as until round 4)
     S.materials = ctx->d_materials.p; S.emitters = ctx->d_emitters.p; S.n_tris = (int)s->n_triangles; S.has_null = hasNull ? 1 : 0;
     S.rtrans = s->n_rtrans ? ctx->d_rtrans.p : nullptr; S.rtrans_n = (int)s->rtrans_samples;
     S.spheres = nullptr; S.n_spheres = (int)s->n_spheres;
