@@ -16,15 +16,17 @@ reference's iteration schedule 1, 2, 4, ... (guided_path.cpp:1342-1426): SD-tree
 rounds of the sampling-fraction optimiser ARE inside the timed region; scene upload and BVH build are not.
 Warm-up = one throw-away render of W passes.  value = pixels x spp x K / seconds, whole job over all GPUs.
 
-Multi-GPU (`torchrun ... bench.py --gpus N`): the fixed image is sharded by 32x32 tiles over the ranks (strong scaling); per
-iteration the building SD-tree statistics are all-reduced over RCCL, per round the optimiser's records are gathered
-(ppg_host/distributed.py).
+Multi-GPU (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`, or plain `python bench.py --gpus N`, which starts
+its N ranks itself): the fixed image is sharded by 32x32 tiles over the ranks (strong scaling); per iteration the building SD-tree
+statistics are all-reduced over RCCL, per round of the optimiser its records go to the owners of their D-trees, the final iteration's
+groups of passes are dealt whole to the ranks or rendered by tiles (ppg_host/distributed.py, include/ppg.h).
 
 Added to the JSON line (rank 0):
   roofline      the kernel with the largest accumulated time of an instrumented render of the same K passes: HIP-event durations on
                 the kernels' own stream, algorithmic bytes per DESIGN.md §3 — for k_trace on a BVH scene 48 B per ray + 64 B per
                 BVH4 node visited + 48 B per triangle tested, the visits counted by the kernel itself in that run
-  cpu_baseline  the oracle restatement timed on the host cores on the first passes of the same render (N = 1 only)
+  cpu_baseline  the oracle restatement timed on the host cores on the first passes of the same render — the GPU's own schedule when
+                --steps <= 20 — and `one_core`: one thread on a film shrunk to 1/8 x 1/8 (N = 1 only)
   reference_log the reference's OWN run of this configuration (its embedded render log: 1.34 Msamples/s on 16 CPU cores, the complete scene)
                 and vs_reference_log = value / that — the honest denominator; the triangle ratio of the checkout's scene is stated
   single_call   the same render through ppg_render(), the ONE C-ABI call a host in any language makes (no Python between the phases)

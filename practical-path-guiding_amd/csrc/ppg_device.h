@@ -136,7 +136,6 @@ struct DevTex {
 
 struct DevScene {
     const float4 *tris;     // 3 per triangle: positions (.w = material, emitter, original index) — intersection records only
-    const unsigned char *tri_class;  // per triangle (leaf order): the bin k_sort_slices puts a hit on it into (ppg_sort_class of its BSDF), or nullptr
     const float4 *accel;    // 3 per triangle: TriAccel (triaccel.h:36-58), what the traversal reads
     const float4 *accel_small;  // small scenes (brute force from LDS): the same records sorted by projection axis k,
     int small_n[3];             // n[k] of them per axis (degenerate triangles dropped); record[2].z = leaf-order index

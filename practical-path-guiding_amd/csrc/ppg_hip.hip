@@ -504,7 +504,6 @@ struct ppg_ctx {
     bool fullMaterials = false;
     DevBuf<float4> d_tris, d_accel, d_accelSmall, d_normals, d_materials, d_emitters, d_emTris, d_emNrm;
     DevBuf<float> d_rtrans;  // ppg_scene.rtrans (roughplastic slices)
-    DevBuf<unsigned char> d_triClass;  // DevScene::tri_class
     DevBuf<float4> d_spheres;  // 4 float4 per analytic sphere (DevScene::spheres)
     DevBuf<float2> d_uvs;  // bitmap textures: per-triangle texture coordinates, the texel arrays, the DevTex table
     std::vector<DevBuf<float4>> d_texTexels;
@@ -2172,15 +2171,6 @@ int ppg_set_scene(ppg_ctx *ctx, const ppg_scene *s) {
     }
     HIP_CHECK(ctx->d_materials.reserve(mats.size()));
     HIP_CHECK(hipMemcpy(ctx->d_materials.p, mats.data(), mats.size() * sizeof(float4), hipMemcpyHostToDevice));
-    {   // k_sort_slices' bin per triangle (leaf order), from the material words as the device sees them (ppg_sort_class)
-        std::vector<unsigned char> cls(std::max<size_t>(1, s->n_triangles));
-        for (uint32_t k = 0; k < s->n_triangles; ++k) {
-            const size_t m = s->tri_material[bb.order[k]];
-            cls[k] = (unsigned char)ppg_sort_class((int)mats[PPG_MAT_STRIDE * m].w, __builtin_bit_cast(int, mats[PPG_MAT_STRIDE * m + 2].w), __builtin_bit_cast(unsigned int, mats[PPG_MAT_STRIDE * m + 5].x));
-        }
-        HIP_CHECK(ctx->d_triClass.reserve(cls.size()));
-        HIP_CHECK(hipMemcpy(ctx->d_triClass.p, cls.data(), cls.size(), hipMemcpyHostToDevice));
-    }
     HIP_CHECK(ctx->d_emitters.reserve(ems.size()));
     HIP_CHECK(hipMemcpy(ctx->d_emitters.p, ems.data(), ems.size() * sizeof(float4), hipMemcpyHostToDevice));
     ctx->scene.em_texels = nullptr; ctx->scene.em_w = ctx->scene.em_h = 0;
@@ -2296,7 +2286,6 @@ int ppg_set_scene(ppg_ctx *ctx, const ppg_scene *s) {
     }
     DevScene &S = ctx->scene;
     S.tris = ctx->d_tris.p; S.accel = ctx->d_accel.p; S.normals = s->normals ? ctx->d_normals.p : nullptr; S.bvh = ctx->d_bvh.p; S.bvh4 = ctx->d_bvh4.p; S.bvh_top = ctx->d_bvhTop.p; S.n_top = nTop;
-    S.tri_class = getenv("PPG_NO_TRI_CLASS") ? nullptr : ctx->d_triClass.p;  // (PPG_NO_TRI_CLASS: k_sort_slices reads triangle + material, as until round 4)
     S.materials = ctx->d_materials.p; S.emitters = ctx->d_emitters.p; S.n_tris = (int)s->n_triangles; S.has_null = hasNull ? 1 : 0;
     S.rtrans = s->n_rtrans ? ctx->d_rtrans.p : nullptr; S.rtrans_n = (int)s->rtrans_samples;
     S.spheres = nullptr; S.n_spheres = (int)s->n_spheres;
@@ -2324,6 +2313,12 @@ int ppg_set_scene(ppg_ctx *ctx, const ppg_scene *s) {
         ctx->ldsNodes = (int)std::min<size_t>(bb.nodes.size(), budget / 64);
         size_t left = budget - (size_t)ctx->ldsNodes * 64;
         ctx->ldsTris = ((size_t)s->n_triangles * 48 <= left) ? (int)s->n_triangles : 0;
+    }
+    // Every array the path kernels walk must be there before a launch can chase it: an unset pointer here is a hung GPU, not a wrong pixel
+    // (round 5 lost 40 GPU minutes to five assignments that an edit had turned into a comment).
+    if (!S.materials || !S.bvh4 || (S.n_tris > 0 && (!S.tris || !S.accel || !S.bvh)) || (S.n_spheres > 0 && !S.spheres)) {
+        ctx->error = "internal: device scene incomplete";
+        return PPG_ERR_STATE;
     }
     ctx->haveScene = true;
     ctx->treeAlive = false;

@@ -43,18 +43,6 @@ D bool mset_common_type(int type) {
            type == PPG_BSDF_ROUGHCONDUCTOR || type == PPG_BSDF_PLASTIC || type == PPG_BSDF_ROUGHPLASTIC;
 }
 
-// The bin of k_sort_slices for a hit on a surface with this BSDF: 0..7 the COMMON classes (MSET_COMMON), by BSDF type; 8..13 everything
-// else — by type, then bump-mapped or masked surfaces.  (14: analytic spheres, 15: rays that left the scene.)  A function of the material
-// alone, so ppg_set_scene tabulates it per triangle (DevScene::tri_class): the sort then reads one byte per hit instead of the triangle
-// record and two material words, three dependent loads in a kernel that does nothing else (79 % of its wave-cycles parked on them).
-__host__ __device__ inline unsigned int ppg_sort_class(int type, int flags, unsigned int tex) {
-    if ((flags & PPG_MAT_MASK) || (tex >> 16)) return 13u;
-    if (type == PPG_BSDF_DIFFUSE || type == PPG_BSDF_TWOSIDED_DIFFUSE || type == PPG_BSDF_MIRROR || type == PPG_BSDF_CONDUCTOR ||
-        type == PPG_BSDF_ROUGHCONDUCTOR || type == PPG_BSDF_PLASTIC || type == PPG_BSDF_ROUGHPLASTIC)
-        return type == PPG_BSDF_ROUGHPLASTIC ? 6u : (unsigned int)type;  // 0..6
-    return 8u + ((unsigned int)type & 3u);  // dielectric 10, thin dielectric 11, rough dielectric 8
-}
-
 enum { NEE_NEVER = 0, NEE_KICKSTART = 1, NEE_ALWAYS = 2 };
 enum { SF_NEAREST = 0, SF_STOCHASTIC = 1, SF_BOX = 2 };
 enum { DF_NEAREST = 0, DF_BOX = 1 };
@@ -1465,11 +1453,14 @@ static __global__ __launch_bounds__(PPG_BLOCK) void k_sort_slices(PathState P, D
             key = 15u;
             if (prim >= 0) {
                 if (prim >= S.n_tris) key = 14u;
-                else if (S.tri_class) key = S.tri_class[prim];
                 else {
                     const int m = __float_as_int(S.tris[3 * (size_t)prim].w);
                     const float4 *mr = S.materials + PPG_MAT_STRIDE * (size_t)m;
-                    key = ppg_sort_class((int)mr[0].w, __float_as_int(mr[2].w), __float_as_uint(mr[5].x));
+                    const int type = (int)mr[0].w, flags = __float_as_int(mr[2].w);
+                    const unsigned int tex = __float_as_uint(mr[5].x);
+                    if ((flags & PPG_MAT_MASK) || (tex >> 16)) key = 13u;
+                    else if (mset_common_type(type)) key = type == PPG_BSDF_ROUGHPLASTIC ? 6u : (unsigned int)type;  // 0..6
+                    else key = 8u + ((unsigned int)type & 3u);  // dielectric 10, thin dielectric 11, rough dielectric 8
                 }
             }
             atomicAdd(&hist[key], 1u);
