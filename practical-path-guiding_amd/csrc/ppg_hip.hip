@@ -1297,12 +1297,13 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound, const GroupLaunch *gl =
     const bool fastRound = adamRound && ctx->adamFast && P.n_paths > 0;
     // A round whose record positions are known commits in three steps — records, the optimiser's sort, splats D-tree by D-tree
     // (ppg_kernels.h "The commit of a ROUND") — instead of one lane per vertex adding to the pool with global atomics.
-    ctx->sortedCommit = adamRound && ctx->adamFast && !ctx->tuneNoSortedCommit;
     {
         unsigned int leafBits = 1;
         while ((1u << leafBits) <= (unsigned int)ctx->snodes.size()) ++leafBits;
         ctx->adamFlagShift = PPG_ADAM_LEAF_SHIFT + leafBits;
     }
+    // (the flag needs a key bit above the leaf: an S-tree of 2^23 nodes or more — never seen — commits with k_commit)
+    ctx->sortedCommit = adamRound && ctx->adamFast && !ctx->tuneNoSortedCommit && ctx->adamFlagShift < 63u;
     size_t nRecords = 0;
     unsigned int *dense = Q.items[1];  // the live paths in one list (k_tail's work list)
     auto launchTail = [&] {
