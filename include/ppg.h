@@ -403,6 +403,11 @@ int ppg_final_partials_commit(ppg_ctx *ctx);
  *     code = PPG_ADAM_CODE_VERTEX + i for path vertex i (Vertex::commit, GP:2150-2154), min(rRec.depth, PPG_ADAM_CODE_VERTEX - 1)
  *     for the direct-light vertex of next-event estimation (GP:1994-2010).  Keys are unique, so the order is total: a valid
  *     serialisation of the reference's critical sections that does not depend on wave scheduling, thread or GPU count.
+ * What the fixed order costs (measured against the reference's own render logs): under the reference's rule the
+ * variable follows the records of the last ~100 paths — of the image region being rendered —, which a value frozen for a round cannot; the
+ * variance estimate of the EARLY iterations is up to twice the reference's on spaceship-improved (equal from iteration 6, 64 passes, on),
+ * unaffected from iteration 2 on on kitchen-improved.  The oracle implements the literal rule too (PPGO_ADAM_SEQUENTIAL) and reproduces the
+ * reference's logs with it to 1 - 4 %.
  * AdamOptimizer::State (incl. the partial batch) survives rounds, iterations and STree subdivision (GP:890) as in the reference.
  * Limits: width * height * sppPerPass <= 2^PPG_ADAM_PATH_BITS and at most 2^24 S-tree nodes while a loss is set.
  * ---------------------------------------------------------------------------------------------- */
