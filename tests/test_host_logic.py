@@ -391,6 +391,33 @@ def test_cancelled_rank_takes_the_others_out_of_a_time_budget(oracle_lib, tmp_pa
     assert len(again) == 1 and float(again.pop()) > 0.01
 
 
+def test_final_partials_size_is_a_function_of_film_and_pass_count(oracle_lib):
+    """What lets a rank that failed still join the final groups' collective (include/ppg.h): the float count of the exchange buffer follows from
+    the film size and the pass count alone — 4 n + groups * 7 n, groups = ceil(passes / ppg_final_group_passes(passes)) — and is what the
+    library hands out, whether the groups were dealt whole to the ranks or rendered by tiles."""
+    import ppg_host
+    for budget, world in ((20, 2), (45, 2), (300, 2)):
+        props = dict(CBOX_PROPS, budget=budget, seed=1, sppPerPass=1, sampleCombination="discard")
+        e = make_oracle(oracle_lib, threads=2, **props)
+        e.set_scene(ppg_host.cbox_scene(16, 12)); e.set_shard(0, world, 4); e.begin_render()
+        passes, it = 0, 0
+        while passes < budget:  # renderSPP's schedule (GP:1367-1374)
+            remaining = budget - passes
+            n = min(remaining, 1 << it)
+            if remaining - n < 2 * n:
+                n = remaining
+            final = n >= remaining
+            e.begin_iteration(final)
+            e.render_passes_nostat(n)
+            if final:
+                ptr, count = e.final_partials()
+                g = oracle_lib.ppgo_final_group_passes(n)
+                assert count == e.final_partials_expected(n) == 4 * 192 + (-(-n // g)) * 7 * 192 and ptr
+                e.final_partials_commit()
+            e.finish_passes(); e.build_sdtree(); e.end_iteration()
+            passes += n; it += 1
+
+
 def _time_budget_checks(make_engine, scene, budget):
     """renderTime (GP:1434-1514): iterations of 1, 2, 4, ... passes until the budget is spent; with sampleCombination = automatic the
     last iteration keeps rendering batches of its own size until the time is up (GP:1482-1501)."""
