@@ -71,6 +71,11 @@ class _Status:
 
 
 class TorchReducer(_Status):
+    """The exchanges of a sharded render over torch.distributed.  ONE class holds the protocol — what is exchanged when, the status word, the two
+    phases of the round hook, the final iteration's groups, the stop decision; where the arrays live is four small accessors: device memory of
+    the HIP engine here (backend nccl = RCCL), host memory of the oracle in `HostReducer` (gloo), so that the world-2 / 3 / 4 / 8 CPU tests run the
+    protocol code `bench.py --gpus N` runs."""
+
     def __init__(self, dist, device, gather_all=False):
         import torch
         self.torch, self.dist, self.device, self.gather_all = torch, dist, device, gather_all
@@ -78,6 +83,30 @@ class TorchReducer(_Status):
     def _tensor_kw(self):
         return dict(device=self.device)
 
+    # ---- where the arrays live -------------------------------------------------------------------------------------------------------
+    def _sync(self):
+        self.torch.cuda.synchronize()
+
+    def _view(self, ptr, n, typestr):
+        return _view(self.torch, ptr, n, typestr, self.device)
+
+    def _sdtree_views(self, e):
+        """([views of the building tree's sums and weights as int64], what to call once they are reduced)"""
+        (ps, ns), (pw, nw) = e.stat_buffers()
+        return [self._view(ptr, n, "<i8") for ptr, n in ((ps, ns), (pw, nw)) if n], None
+
+    def _image_views(self, e):
+        n = e.width * e.height
+        a, b = e.image_buffers()
+        w = e.image_weight_buffer()
+        return [self._view(a, 3 * n, "<f4"), self._view(b, 3 * n, "<f4"), self._view(w, n, "<f4")]
+
+    def _film_views(self, e):
+        n = e.width * e.height
+        a, w = e.film_buffers()
+        return [self._view(a, 3 * n, "<f4"), self._view(w, n, "<f4")]
+
+    # ---- the protocol ------------------------------------------------------------------------------------------------------------------
     def _exchange(self, views):
         """ONE exchange: the arrays all-reduced (sum) together with the status word.  Several arrays are separate allocations of the context,
         so they are packed into a staging tensor with the word as its last element, reduced in ONE collective and copied back — the xGMI
@@ -87,7 +116,7 @@ class TorchReducer(_Status):
         torch = self.torch
         views = [v for v in views if v.numel()]
         dtype = views[0].dtype if views else torch.int64
-        st = torch.tensor([self.status], dtype=dtype, device=self.device)
+        st = torch.tensor([self.status], dtype=dtype, **self._tensor_kw())
         if len(views) <= 1:
             for v in views:
                 self.dist.all_reduce(v)
@@ -104,18 +133,18 @@ class TorchReducer(_Status):
         self._abort_if(float(bad.item()))  # (.item() is the exchange's one host synchronisation)
 
     def reduce_sdtree(self, e):
-        (ps, ns), (pw, nw) = e.stat_buffers()
-        self._exchange([_view(self.torch, ptr, n, "<i8", self.device) for ptr, n in ((ps, ns), (pw, nw)) if n])
+        views, done = self._sdtree_views(e)
+        self._exchange(views)
+        if done:
+            done()
 
     def reduce_images(self, e):
         n = e.width * e.height
         try:
-            a, b = e.image_buffers()
-            w = e.image_weight_buffer()
-            views = [_view(self.torch, a, 3 * n, "<f4", self.device), _view(self.torch, b, 3 * n, "<f4", self.device), _view(self.torch, w, n, "<f4", self.device)]
+            views = self._image_views(e)
         except Exception:  # this rank cannot produce its buffers: zeros of the same sizes and its status word
             self.status = 1
-            views = [self.torch.zeros(k, dtype=self.torch.float32, device=self.device) for k in (3 * n, 3 * n, n)]
+            views = [self.torch.zeros(k, dtype=self.torch.float32, **self._tensor_kw()) for k in (3 * n, 3 * n, n)]
         self._exchange(views)
 
     def reduce_final_partials(self, e, ptr, count):
@@ -123,7 +152,7 @@ class TorchReducer(_Status):
         ones over the whole film, or all of them on its tiles —; ONE all-reduce of the film head + all group slots (each pixel of a slot is
         non-zero on one rank: exact), in place, then the library adds the slots in group order.  ptr = None: this rank has nothing to give
         (it failed or was cancelled) and joins with zeros and its status word."""
-        buf = _view(self.torch, ptr, count, "<f4", self.device) if ptr else self.torch.zeros(count, dtype=self.torch.float32, device=self.device)
+        buf = self._view(ptr, count, "<f4") if ptr else self.torch.zeros(count, dtype=self.torch.float32, **self._tensor_kw())
         self._exchange([buf])
         e.final_partials_commit()
 
@@ -147,24 +176,24 @@ class TorchReducer(_Status):
                     self.status = 1
             if self.status:
                 send = [0] * world
-            row = torch.tensor(send + [int(self.status)], dtype=torch.int64, device=self.device)
-            rows = torch.empty(world * (world + 1), dtype=torch.int64, device=self.device)
+            row = torch.tensor(send + [int(self.status)], dtype=torch.int64, **self._tensor_kw())
+            rows = torch.empty(world * (world + 1), dtype=torch.int64, **self._tensor_kw())
             dist.all_gather_into_tensor(rows, row)
             table = rows.view(world, world + 1).tolist()             # (the host sizes the messages by the counts: the one synchronisation)
             self._abort_if(sum(r[world] for r in table))
             recv = [int(table[r][rank]) for r in range(world)]
             n_send, n_recv = sum(send), sum(recv)
-            src = _view(torch, ptr, 4 * n_send, "<i8", self.device) if n_send else torch.empty(0, dtype=torch.int64, device=self.device)
-            self._adam_recv = torch.empty(4 * max(n_recv, 1), dtype=torch.int64, device=self.device)
-            dist.all_to_all_single(self._adam_recv[:4 * n_recv], src, [4 * c for c in recv], [4 * c for c in send])
-            torch.cuda.synchronize()
-            e.adam_records_replace(self._adam_recv.data_ptr(), n_recv)
+            src = self._view(ptr, 4 * n_send, "<i8") if n_send else torch.empty(0, dtype=torch.int64, **self._tensor_kw())
+            self._adam_recv = torch.empty(4 * max(n_recv, 1), dtype=torch.int64, **self._tensor_kw())
+            dist.all_to_all_single(self._adam_recv[:4 * n_recv], src.contiguous(), [4 * c for c in recv], [4 * c for c in send])
+            self._sync()
+            e.adam_records_replace(self._adam_recv.data_ptr() if n_recv else 0, n_recv)
         else:
             ptr, seg = e.adam_state(world)
-            state = _view(torch, ptr, 3 * seg * world, "<i8", self.device)      # 24 bytes per node = three int64
+            state = self._view(ptr, 3 * seg * world, "<i8")      # 24 bytes per node = three int64
             mine = state[3 * seg * rank:3 * seg * (rank + 1)].clone()
             dist.all_gather_into_tensor(state, mine)
-            torch.cuda.synchronize()
+            self._sync()
             e.adam_state_commit()
 
     def _reduce_adam_gather_all(self, e):
@@ -172,7 +201,7 @@ class TorchReducer(_Status):
         torch, dist = self.torch, self.dist
         ptr, n = (None, 0) if self.status else e.adam_records()
         world = dist.get_world_size()
-        counts = torch.zeros(world + 1, dtype=torch.int64, device=self.device)
+        counts = torch.zeros(world + 1, dtype=torch.int64, **self._tensor_kw())
         counts[dist.get_rank()] = n
         counts[world] = int(self.status)
         dist.all_reduce(counts)
@@ -181,131 +210,60 @@ class TorchReducer(_Status):
         most = max(counts)
         if most == 0:
             return
-        mine = torch.zeros(4 * most, dtype=torch.int64, device=self.device)
+        mine = torch.zeros(4 * most, dtype=torch.int64, **self._tensor_kw())
         if n:
-            mine[:4 * n] = _view(torch, ptr, 4 * n, "<i8", self.device)
+            mine[:4 * n] = self._view(ptr, 4 * n, "<i8")
         parts = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(parts, mine)
-        union = torch.cat([p[:4 * c] for p, c in zip(parts, counts)])
-        torch.cuda.synchronize()
-        e.adam_records_replace(union.data_ptr(), sum(counts))
+        self._union = torch.cat([p[:4 * c] for p, c in zip(parts, counts)]).contiguous()
+        self._sync()
+        e.adam_records_replace(self._union.data_ptr(), sum(counts))
 
     def reduce_film(self, e, inverse_variance=False):
         if inverse_variance:
             return  # the retained iteration images were already reduced by reduce_images
-        n = e.width * e.height
-        a, w = e.film_buffers()
-        self._exchange([_view(self.torch, a, 3 * n, "<f4", self.device), _view(self.torch, w, n, "<f4", self.device)])
+        self._exchange(self._film_views(e))
 
 
-class HostReducer(_Status):
-    """Same exchange for an oracle engine (host memory, gloo)."""
+class HostReducer(TorchReducer):
+    """The same protocol for an oracle engine: host memory, gloo.  Only the accessors differ — the oracle's statistics are per-node objects
+    (exported into arrays, reduced, imported), its images and film plain host arrays."""
 
     def __init__(self, dist, gather_all=False):
         import torch
-        self.torch, self.dist, self.gather_all = torch, dist, gather_all
+        super().__init__(dist, torch.device("cpu"), gather_all)
 
     def _tensor_kw(self):
         return {}
 
-    def _exchange(self, arrays):
-        """the arrays (numpy, reduced in place) and the status word in ONE all-reduce"""
-        arrays = [a for a in arrays if a.size]
-        dtype = arrays[0].dtype if arrays else np.dtype(np.int64)
-        flat = np.concatenate([a.reshape(-1) for a in arrays] + [np.array([self.status], dtype)])
-        self.dist.all_reduce(self.torch.from_numpy(flat))
-        off = 0
-        for a in arrays:
-            a.reshape(-1)[:] = flat[off:off + a.size]
-            off += a.size
-        self._abort_if(float(flat[-1]))
+    def _sync(self):
+        pass
 
-    def reduce_sdtree(self, e):
+    def _view(self, ptr, n, typestr):
+        ct = {"<i8": C.c_int64, "<f4": C.c_float}[typestr]
+        return self.torch.from_numpy(np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ct)), shape=(int(n),)))  # (shares the memory)
+
+    def _sdtree_views(self, e):
         ns, nw = C.c_uint64(), C.c_uint64()
         e._call("stat_sizes", C.byref(ns), C.byref(nw))
-        sums = np.zeros(ns.value, np.int64)
-        wts = np.zeros(nw.value, np.int64)
+        sums, wts = np.zeros(ns.value, np.int64), np.zeros(nw.value, np.int64)
         u64 = C.POINTER(C.c_uint64)
         e._call("stat_export", sums.ctypes.data_as(u64), ns, wts.ctypes.data_as(u64), nw)
-        self._exchange([sums, wts])
-        e._call("stat_import", sums.ctypes.data_as(u64), ns, wts.ctypes.data_as(u64), nw)
+        return [self.torch.from_numpy(sums), self.torch.from_numpy(wts)], lambda: e._call("stat_import", sums.ctypes.data_as(u64), ns, wts.ctypes.data_as(u64), nw)
 
-    def _ptr_arrays(self, e, fn, sizes):
+    def _two(self, e, fn):
         a, b = C.POINTER(C.c_float)(), C.POINTER(C.c_float)()
         e._call(fn, C.byref(a), C.byref(b))
-        return [np.ctypeslib.as_array(p, shape=(s,)) for p, s in zip((a, b), sizes)]
+        return C.cast(a, C.c_void_p).value, C.cast(b, C.c_void_p).value
 
-    def reduce_images(self, e):
+    def _image_views(self, e):
         n = e.width * e.height
-        img, sq = self._ptr_arrays(e, "image_ptrs", (3 * n, 3 * n))
+        a, b = self._two(e, "image_ptrs")
         w = C.POINTER(C.c_float)()
         e._call("image_weight_ptr", C.byref(w))
-        self._exchange([img, sq, np.ctypeslib.as_array(w, shape=(n,))])
+        return [self._view(a, 3 * n, "<f4"), self._view(b, 3 * n, "<f4"), self._view(C.cast(w, C.c_void_p).value, n, "<f4")]
 
-    def reduce_final_partials(self, e, ptr, count):
-        arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), shape=(count,)) if ptr else np.zeros(count, np.float32)
-        self._exchange([arr])
-        e.final_partials_commit()
-
-    def reduce_adam(self, e):
-        """The same two-phase exchange as TorchReducer.reduce_adam, on host arrays."""
-        torch, dist = self.torch, self.dist
-        world, rank = dist.get_world_size(), dist.get_rank()
-        if self.gather_all:
-            return self._reduce_adam_gather_all(e)
-        if e.hook_phase() == 0:
-            ptr, send = None, [0] * world
-            if not self.status:
-                try:
-                    ptr, send = e.adam_records_by_owner(world)
-                except Exception:
-                    self.status = 1
-            if self.status:
-                send = [0] * world
-            rows = [torch.empty(world + 1, dtype=torch.int64) for _ in range(world)]
-            dist.all_gather(rows, torch.tensor(send + [int(self.status)], dtype=torch.int64))
-            table = [r.tolist() for r in rows]
-            self._abort_if(sum(r[world] for r in table))
-            recv = [int(table[r][rank]) for r in range(world)]
-            n_send, n_recv = sum(send), sum(recv)
-            src = torch.from_numpy(np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int64)), shape=(4 * n_send,)).copy()) if n_send else torch.empty(0, dtype=torch.int64)
-            got = torch.empty(4 * n_recv, dtype=torch.int64)
-            dist.all_to_all_single(got, src, [4 * c for c in recv], [4 * c for c in send])
-            self._adam_recv = np.ascontiguousarray(got.numpy())
-            e.adam_records_replace(self._adam_recv.ctypes.data if n_recv else 0, n_recv)
-        else:
-            ptr, seg = e.adam_state(world)
-            state = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int64)), shape=(3 * seg * world,))
-            parts = [torch.empty(3 * seg, dtype=torch.int64) for _ in range(world)]
-            dist.all_gather(parts, torch.from_numpy(state[3 * seg * rank:3 * seg * (rank + 1)].copy()))
-            for r, part in enumerate(parts):
-                state[3 * seg * r:3 * seg * (r + 1)] = part.numpy()
-            e.adam_state_commit()
-
-    def _reduce_adam_gather_all(self, e):
-        torch, dist = self.torch, self.dist
-        ptr, n = (None, 0) if self.status else e.adam_records()
-        world = dist.get_world_size()
-        counts = torch.zeros(world + 1, dtype=torch.int64)
-        counts[dist.get_rank()] = n
-        counts[world] = int(self.status)
-        dist.all_reduce(counts)
-        counts = [int(c) for c in counts.tolist()]
-        self._abort_if(counts.pop())
-        most = max(counts)
-        if most == 0:
-            return
-        mine = np.zeros(4 * most, np.int64)
-        if n:
-            mine[:4 * n] = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int64)), shape=(4 * n,))
-        parts = [torch.empty(4 * most, dtype=torch.int64) for _ in range(world)]
-        dist.all_gather(parts, torch.from_numpy(mine))
-        union = np.ascontiguousarray(np.concatenate([p.numpy()[:4 * c] for p, c in zip(parts, counts)]))
-        e.adam_records_replace(union.ctypes.data, sum(counts))
-
-    def reduce_film(self, e, inverse_variance=False):
-        if inverse_variance:
-            return
+    def _film_views(self, e):
         n = e.width * e.height
-        film, w = self._ptr_arrays(e, "film_ptrs", (3 * n, n))
-        self._exchange([film, w])
+        a, w = self._two(e, "film_ptrs")
+        return [self._view(a, 3 * n, "<f4"), self._view(w, n, "<f4")]
