@@ -368,9 +368,11 @@ int ppg_finish_passes(ppg_ctx *ctx, ppg_pass_stats *stats);   /* GP:1288-1328 on
    GP:1434-1514 in renderTime) must come out the same on all ranks, or they would render different numbers of passes and their collectives
    would stop matching.  The stop hook is asked after every batch of passes with this rank's own decision (elapsed whole seconds > budget) and
    returns the one all ranks follow — rank 0's.  The exchange behind it also carries the ranks' status words (host/rccl_reducer.h
-   stopDecision: one all-reduce of {decision, status}): a rank that was cancelled asks the hook once more (local_stop = 1) before it leaves
-   the batch loop, so it meets the others in the exchange they are in, every rank stops there, and the image exchange that follows aborts
-   the render on all of them.  The host loop passes the times it measures through a broadcast of rank 0's. */
+   stopDecision: one all-reduce of {decision, status}): a rank that was cancelled asks the hook once more before it leaves the batch loop —
+   with local_stop = PPG_STOP_CANCELLED (2) instead of a 0 / 1 decision, so that the host sets its status word even when the cancel did not
+   come through the host's own cancel() —, so it meets the others in the exchange they are in, every rank stops there, and the image exchange
+   that follows aborts the render on all of them.  The host loop passes the times it measures through a broadcast of rank 0's. */
+#define PPG_STOP_CANCELLED 2
 typedef int (*ppg_stop_hook)(void *user, int local_stop);
 int ppg_set_stop_hook(ppg_ctx *ctx, ppg_stop_hook hook, void *user);
 /* The HIP stream (hipStream_t) the context's kernels run on.  A reducer that enqueues its collectives on it needs no host synchronisation
@@ -409,7 +411,24 @@ int ppg_final_partials_commit(ppg_ctx *ctx);
  * unaffected from iteration 2 on on kitchen-improved.  The oracle implements the literal rule too (PPGO_ADAM_SEQUENTIAL) and reproduces the
  * reference's logs with it to 1 - 4 %.
  * AdamOptimizer::State (incl. the partial batch) survives rounds, iterations and STree subdivision (GP:890) as in the reference.
- * Limits: width * height * sppPerPass <= 2^PPG_ADAM_PATH_BITS and at most 2^24 S-tree nodes while a loss is set.
+ *
+ * STRAGGLERS (round 6).  With maxDepth = -1 a guided path survives Russian roulette with probability 0.99 (GP:2124-2139): one path in
+ * ten thousand runs for hundreds of bounces, and a round that waits for it before its records may be applied idles the GPU for
+ * milliseconds — on every GPU of a sharded render alike.  The reference applies a path's records when that path happens to finish
+ * (Vertex::commit at the end of Li, GP:2150-2154, under the lock of GP:719-737): records of long paths arrive late there too.  The rule
+ * here, deterministic and independent of wave scheduling, batch size, thread and GPU count:
+ *   - in a round whose record positions are known in advance (spatialFilter != box, no kick-start luminaire sampling in effect) of a
+ *     render with maxDepth = -1, a path whose FINAL rRec.depth (the value Li adds to avgPathLength, GP:2147-2148) exceeds
+ *     PPG_ADAM_DEFER_DEPTH is a straggler;
+ *   - a straggler's optimiser records are applied with the NEXT round of the same ppg_render_passes() call — per D-tree after that
+ *     round's own records: their keys carry PPG_ADAM_DEFER_PATH_BIT in the path field, so "ascending key order" says exactly that —,
+ *     and those of the call's last round in a round of their own at the end of the call (the sharded render's round hook is called for
+ *     it on every rank, with or without records);
+ *   - nothing else moves: the straggler's splats reach the building tree before ppg_build_sdtree (integer sums: the same bits whenever
+ *     they land), its radiance reaches image and film in its sample's place in the sums.
+ * On KITCHEN one path in 10^4 is a straggler (16-pass round at 1280x720: 1 481 of 14.7 M); the product finishes them on a side stream
+ * beside the next round's paths (ppg_hip.hip "Stragglers").  The oracle implements the same rule.
+ * Limits: width * height * sppPerPass <= 2^(PPG_ADAM_PATH_BITS - 1) and at most 2^24 S-tree nodes while a loss is set.
  * ---------------------------------------------------------------------------------------------- */
 #define PPG_ADAM_ROUND_MAX_PASSES 16
 #define PPG_ADAM_ROUND_MAX_PATHS (1u << 24)
@@ -417,6 +436,8 @@ int ppg_final_partials_commit(ppg_ctx *ctx);
 #define PPG_ADAM_PATH_BITS 27
 #define PPG_ADAM_LEAF_SHIFT (PPG_ADAM_CODE_BITS + PPG_ADAM_PATH_BITS)
 #define PPG_ADAM_CODE_VERTEX 4096
+#define PPG_ADAM_DEFER_DEPTH 64
+#define PPG_ADAM_DEFER_PATH_BIT (1u << (PPG_ADAM_PATH_BITS - 1))   /* in the path field of the key: a straggler's record, applied one round late */
 /* passes per round for a call that renders n_passes: the largest power of two <= min(PPG_ADAM_ROUND_MAX_PASSES, n_passes / 2)
    whose paths (passes * sppPerPass * pixels of the whole image, not of a shard) stay within PPG_ADAM_ROUND_MAX_PATHS; at least 1 */
 int32_t ppg_adam_round_passes(int32_t spp_per_pass, int32_t width, int32_t height, int32_t n_passes);

@@ -20,6 +20,13 @@ extern "C" {
 int ppg_debug_build_bvh(const float *positions, const uint32_t *indices, uint32_t n_triangles, float pad_abs, int32_t max_leaf,
                         void *nodes_out, uint32_t nodes_cap, uint32_t *n_nodes, uint32_t *order_out);
 
+/* The depth beyond which a path is a STRAGGLER (include/ppg.h: PPG_ADAM_DEFER_DEPTH = 64, part of the result).  One path in 10^4 gets there
+   in a real scene and none in most test scenes; the parity tests lower it (1 .. 64; the oracle has the same switch, ppgo_debug_set_defer_depth)
+   so that thousands of paths go through the stragglers' machinery — hand-over inside k_tail, the second launch beside the next round, the
+   records applied one round late — and must still come out bit-equal to the oracle. */
+struct ppg_ctx;
+int ppg_debug_set_defer_depth(struct ppg_ctx *ctx, int32_t depth);
+
 #ifdef __cplusplus
 }
 #endif

@@ -2595,6 +2595,9 @@ public:
         // pass (pixels by parity of x + y), i.e. four rounds instead of two
         const bool halves = rounds && modes.adam == PPGO_ADAM_HALF && numPasses == 2;
         const int roundPasses = rounds ? adamRoundPasses(numPasses) : 1;
+        // include/ppg.h "STRAGGLERS": the rounds of a render of unbounded paths whose record positions are known in advance
+        m_deferRound = rounds && m_maxDepth < 0 && m_spatialFilter != ESBox && !(m_doNee && m_nee == EKickstart);
+        m_deferredRecords.clear();  // (nothing is carried from one call to the next)
         // (cancelled with a round hook installed: the remaining rounds are entered empty, so that this rank stays in step with the hooks of
         // the others until they have all seen its status — the product's rule, ppg_hip.hip renderPassesNoStat)
         bool drain = false;
@@ -2603,7 +2606,7 @@ public:
             if (seesCancel()) {
                 if (rounds && passHook) drain = true;
                 else {  // (a sharded time budget: meet the other ranks in the stop hook they are about to ask — the product's rule)
-                    if (m_budgetType == ESeconds && stopHook) (void)stopHook(stopHookUser, 1);
+                    if (m_budgetType == ESeconds && stopHook) (void)stopHook(stopHookUser, PPG_STOP_CANCELLED);
                     break;
                 }
             }
@@ -2626,7 +2629,12 @@ public:
                 if (stop) break;
             }
         }
+        // the records of the last round's stragglers: a round of their own (sharded: the round hook is called for it on every rank)
+        if (m_deferRound && !m_hookFailed && (passHook || !m_deferredRecords.empty())) applyAdamRound();
+        m_deferRound = false;
     }
+    bool m_deferRound = false;
+    int m_deferDepth = PPG_ADAM_DEFER_DEPTH;  // (ppgo_debug_set_defer_depth: the tests' switch, include/ppg_testhooks.h)
 
     uint64_t ownedPixels() const {
         uint64_t c = 0;
@@ -2684,18 +2692,23 @@ public:
     int m_roundStartPass = 0;
     std::vector<std::vector<AdamRecord>> m_blockSinks;  // one per image block: filled by whichever thread renders the block
     struct PackedAdamRecord { uint64_t key; float product, woPdf, bsdfPdf, dTreePdf, weight, pad; };  // = ppg_adam_record
-    std::vector<PackedAdamRecord> m_adamRecords;
+    std::vector<PackedAdamRecord> m_adamRecords, m_deferredRecords;
     void applyAdamRound() {
         auto &nodes = m_sdTree->nodes();
         m_adamRecords.clear();
+        std::vector<PackedAdamRecord> late;  // this round's stragglers' records (include/ppg.h "STRAGGLERS"): applied with the next round
         for (auto &sink : m_blockSinks) {
             for (const AdamRecord &r : sink) {
                 const uint64_t leaf = (uint64_t)(((const char *)r.dTree - (const char *)&nodes[0].dTree) / sizeof(STreeNode));
-                m_adamRecords.push_back(PackedAdamRecord{(leaf << PPG_ADAM_LEAF_SHIFT) | ((uint64_t)r.path << PPG_ADAM_CODE_BITS) | r.code,
-                                                         r.product, r.woPdf, r.bsdfPdf, r.dTreePdf, r.weight, 0.0f});
+                const PackedAdamRecord pr{(leaf << PPG_ADAM_LEAF_SHIFT) | ((uint64_t)r.path << PPG_ADAM_CODE_BITS) | r.code,
+                                          r.product, r.woPdf, r.bsdfPdf, r.dTreePdf, r.weight, 0.0f};
+                if (r.path & PPG_ADAM_DEFER_PATH_BIT) late.push_back(pr); else m_adamRecords.push_back(pr);
             }
             sink.clear();
         }
+        // ... and the previous round's, now: the bit in their keys puts them behind this round's own records of the same D-tree
+        m_adamRecords.insert(m_adamRecords.end(), m_deferredRecords.begin(), m_deferredRecords.end());
+        m_deferredRecords.swap(late);
         // sharded rendering: the driver replaces the records by the union over all ranks — or, with one owner per D-tree
         // (ppgo_adam_records_by_owner), by the records of the D-trees this rank owns
         hookPhase = 0; ownerMode = false;
@@ -3097,6 +3110,9 @@ public:
         pc.pathLen += (uint64_t)depth;  // avgPathLength += rRec.depth, GP:2147-2148
         __atomic_fetch_add(&m_lenHist[std::min(depth, (int)PPGO_LEN_HIST - 1)], (uint64_t)1, __ATOMIC_RELAXED);
 
+        // include/ppg.h "STRAGGLERS": in a round whose stragglers' records are deferred, a path whose final rRec.depth exceeds
+        // PPG_ADAM_DEFER_DEPTH leaves its optimiser records marked — applyAdamRound() applies them with the NEXT round
+        if (m_deferRound && depth > m_deferDepth) modes.path |= PPG_ADAM_DEFER_PATH_BIT;
         if (nVertices > 0 && !m_isFinalIter) {  // GP:2150-2154
             const uint32_t dimEnd = sampler.dim;
             for (int i = 0; i < nVertices; ++i) {
@@ -3547,6 +3563,7 @@ int ppgo_stat_import(ppgo_ctx *ctx, const uint64_t *sums, uint64_t n_sums, const
     return PPG_OK;
 }
 int ppgo_work_counters(ppgo_ctx *ctx, uint64_t *out8) { memcpy(out8, ctx->gpt.m_work, sizeof ctx->gpt.m_work); return PPG_OK; }
+int ppgo_debug_set_defer_depth(ppgo_ctx *ctx, int32_t depth) { if (depth < 1 || depth > 64) return PPG_ERR_INVALID; ctx->gpt.m_deferDepth = depth; return PPG_OK; }
 int ppgo_path_length_histogram(ppgo_ctx *ctx, uint64_t *out) { memcpy(out, ctx->gpt.m_lenHist, sizeof ctx->gpt.m_lenHist); return PPG_OK; }
 int ppgo_set_stop_hook(ppgo_ctx *ctx, ppg_stop_hook hook, void *user) { ctx->gpt.stopHook = hook; ctx->gpt.stopHookUser = user; return PPG_OK; }
 int ppgo_set_pass_hook(ppgo_ctx *ctx, ppg_pass_hook hook, void *user) { ctx->gpt.passHook = hook; ctx->gpt.passHookUser = user; return PPG_OK; }

@@ -1765,6 +1765,10 @@ struct DevTree {
     // are determined by the top GRID_BITS bits of each normalised coordinate.  grid[cell] = node reached after
     // min(3*GRID_BITS, depth of the leaf) levels | levels << 27.  One read replaces up to 18 dependent ones.
     const unsigned int *grid;
+    // The optimiser's variable per S-tree node as it was when the round began (nullptr: read it in the leaf header).  A round's stragglers are
+    // finished BESIDE the application of that round's records and the next round's (ppg_hip.hip "Stragglers"), which rewrite the headers;
+    // they must go on sampling with the fractions of their own round (include/ppg.h: all paths of a round see the fractions in effect at its start).
+    const float *theta_frozen;
 };
 #define PPG_REPLICAS 32
 #define PPG_GRID_BITS 6

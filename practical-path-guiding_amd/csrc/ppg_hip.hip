@@ -21,6 +21,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <map>
 #include <memory>
@@ -471,6 +472,12 @@ struct KernelTimer {
 
 }  // namespace
 
+// A launch of whole groups of a final iteration's passes (include/ppg.h "Final iteration: groups of passes"): `batch` passes = groups of
+// groupPasses passes (the last one may be shorter; or a part of ONE group when groupPasses >= batch), the first starting at pass
+// firstPass of the render, consecutive groups of the launch stridePasses apart; group k accumulates into slot slot0 + k * slotStride.
+// addCount > 0 (one GPU): the launch's slots are added to image and film right after its film kernel (k_add_groups).
+struct GroupLaunch { unsigned int firstPass, groupPasses, stridePasses, slot0, slotStride; bool wholeFilm; unsigned int addCount; };
+
 struct ppg_ctx {
     // properties (GP:1014-1085)
     int nee = 0, sampleCombination = 1, spatialFilter = 0, directionalFilter = 0, loss = 0, budgetType = 1;
@@ -495,6 +502,48 @@ struct ppg_ctx {
         (void)hipStreamWaitEvent(stream, evSplatDone, 0);
         (void)hipStreamWaitEvent(stream, evAdamDone, 0);
         treePending = false;
+    }
+    // Entry points that re-size or release buffers (ppg_set_scene, ppg_set_shard, ppg_begin_render): a render that was cancelled or failed
+    // may have left kernels on the side streams that no join has waited for — wait for all of them on the host, then forget what they owed.
+    void quiesce() {
+        joinTree();
+        if (stream2) (void)hipStreamSynchronize(stream2);
+        if (stream3) (void)hipStreamSynchronize(stream3);
+        if (stream4) (void)hipStreamSynchronize(stream4);
+        if (stream) (void)hipStreamSynchronize(stream);
+        for (Stragglers &g : strag) { g.pending = false; g.aside = false; g.film = nullptr; }
+    }
+    // STRAGGLERS (see "Stragglers" below renderBatch's helpers): the handful of paths of a batch that are still alive at depth `defer_depth`
+    // leave k_tail, are finished by a second k_tail on stream4 BESIDE the next batch, and what the batch still owes — its film kernel, the
+    // stragglers' commit — is done by the next batch (drainStragglers) or at the end of the call (flushStragglers).
+    hipStream_t stream4 = nullptr;
+    hipEvent_t evStragFork = nullptr, evStragDone = nullptr;
+    struct Stragglers {
+        DevBuf<float4> rec, vert;           // [cap][8] path records as k_tail wrote them; [maxVertices][n][4 | 6] vertex slots
+        DevBuf<unsigned int> orig, iota, ticket, base, origSorted, perm;
+        DevBuf<unsigned long long> count;   // [0] stragglers (k_tail's StragOut), as k_tail's `total` afterwards
+        DevBuf<unsigned char> nv8;
+        DevBuf<float> neeCos, theta;        // theta: the optimiser's variables of the stragglers' round (DevTree::theta_frozen)
+        size_t iotaN = 0;
+        PathState P{};                      // the compact state: n paths, path j = path orig[j] of the batch
+        unsigned int n = 0;
+        bool pending = false;               // a batch is owed its film kernel (and its stragglers' commit)
+        bool aside = false;                 // ... and their k_tail was put on stream4 (evStragDone)
+        bool commit = false, adam = false;  // the stragglers recorded vertices / those leave optimiser records (a round)
+        std::function<void()> film;         // the batch's film kernel(s), reading liKeep
+    } strag[2];                             // [stragCur]: the set the current batch fills; the other one: the previous batch's, while it is pending
+    int stragCur = 0;
+    DevBuf<float4> d_liKeep;                // Li of every path of the batch whose film kernel is owed (consumed before the next copy is taken)
+    Stragglers &stragPrev() { return strag[stragCur ^ 1]; }
+    int tuneSplitDepth = PPG_ADAM_DEFER_DEPTH;  // PPG_SPLIT_DEPTH: the depth at which a batch WITHOUT optimiser records hands its stragglers over (pure
+                                                // scheduling: final iterations, renders without a learned fraction; 0 = never).  Rounds of the
+                                                // optimiser use PPG_ADAM_DEFER_DEPTH — there the depth is part of the result (include/ppg.h)
+    bool tuneFinalHalves = false;               // PPG_FINAL_HALVES: a final iteration that fits one launch is rendered in two (renderFinalGroups)
+    int deferDepthAdam = PPG_ADAM_DEFER_DEPTH;  // (tests lower it through ppg_debug_set_defer_depth to meet many stragglers in small scenes)
+    int joinStragglers() {  // the side stream's work is over as far as the context's stream is concerned (entry points, error paths)
+        int rc = 0;
+        for (Stragglers &g : strag) if (g.pending && g.aside) { g.aside = false; rc = (int)hipStreamWaitEvent(stream, evStragDone, 0); }
+        return rc;
     }
     DevBuf<unsigned char> d_straggler;  // [path] 1 = still alive when the persistent-thread tail took over
     DevBuf<unsigned char> d_nv8;        // [path] vertex slots k_commit takes of the path (k_commit_prepare)
@@ -593,7 +642,7 @@ struct ppg_ctx {
     DevBuf<unsigned long long> d_ownerBounds;     // [world + 1] first record of every owner
     // unbounded paths: live paths after each bulk bounce of the last batch → how many bulk bounces the next batch runs before k_tail
     DevBuf<unsigned int> d_bounceCounts, d_ticket;
-    unsigned int *h_round = nullptr;  // pinned: [0..63] bounce counts, [64] Adam record count / overflow, [65] Σ nV
+    unsigned int *h_round = nullptr;  // pinned: [0..63] bounce counts, [64] Adam record count / overflow, [65] Σ nV, [68..69] paths handed to k_tail, [70..71] stragglers
     // the previous batch's survival curve (live paths after each wavefront bounce it ran) sizes the schedule of the next batch
     int prevBounces = 0;
     unsigned int prevPaths = 0, prevLive[64] = {};
@@ -976,7 +1025,7 @@ int allocPaths(ppg_ctx *ctx) {
     HIP_CHECK(ctx->d_offsets.reserve(nb)); HIP_CHECK(ctx->d_total.reserve(2));
     HIP_CHECK(ctx->d_bounceCounts.reserve(72)); HIP_CHECK(ctx->d_ticket.reserve(1));
     HIP_CHECK(ctx->d_adamCount.reserve(2));
-    if (!ctx->h_round) HIP_CHECK(hipHostMalloc((void **)&ctx->h_round, 68 * sizeof(unsigned int), hipHostMallocDefault));
+    if (!ctx->h_round) HIP_CHECK(hipHostMalloc((void **)&ctx->h_round, 72 * sizeof(unsigned int), hipHostMallocDefault));
     ctx->queues.items[0] = ctx->d_queue[0].p; ctx->queues.items[1] = ctx->d_queue[1].p;
     ctx->queues.count[0] = ctx->d_qcount[0].p; ctx->queues.count[1] = ctx->d_qcount[1].p;
     ctx->queues.cap = (unsigned int)cap; ctx->queues.stats = ctx->d_stats.p; ctx->queues.n_blocks = (unsigned int)nb;
@@ -1055,6 +1104,10 @@ int applyAdamRound(ppg_ctx *ctx, size_t nRecords) {
     // (without a round hook the optimiser's kernels leave the context's stream too: ppg_ctx::treePending)
     const bool aside = ctx->sortedCommit && !ctx->passHook && !ctx->timer.enabled && !ctx->tuneNoOverlap && !ctx->tuneNoAside;
     hipStream_t sa = aside ? ctx->stream3 : s;  // where the order / apply kernels go
+    struct AsideGuard {  // an early return with kernels already on stream3: the event joinTree() waits for must lie behind them
+        ppg_ctx *c; bool on;
+        ~AsideGuard() { if (on && c->treePending) (void)hipEventRecord(c->evAdamDone, c->stream3); }
+    } asideGuard{ctx, aside};
     if (n > 0) {
         int rc = PPG_OK;
         // (a round committed through records: one more bit, "a splat only", just above the leaf — those records sort behind the optimiser's)
@@ -1068,6 +1121,10 @@ int applyAdamRound(ppg_ctx *ctx, size_t nRecords) {
             SplatLaunch a{(int)std::max(1u, std::min(chunks, 256u * 8u)), ctx->stream2, ctx->devTree(), ctx->d_adamKeys[1].p, ctx->d_adamIdx[1].p, ctx->d_splat.p, (unsigned int)n, leafBits, ctx->tuneSplatLdsNodes};
             ppg_launch_splat(ctx->directionalFilter, a);
             HIP_CHECK(hipEventRecord(ctx->evSplatDone, ctx->stream2));
+            // (from here on work is in flight beside the context's stream: whatever happens below — an early return included — joinTree()
+            // must wait for both side streams; the optimiser's event is recorded again behind its kernels)
+            HIP_CHECK(hipEventRecord(ctx->evAdamDone, ctx->stream3));
+            ctx->treePending = true;
             HIP_CHECK(hipGetLastError());
         } else if (ctx->sortedCommit) {  // DTree::recordIrradiance of every record of the round, D-tree by D-tree (ppg_kernels.h "The commit of a ROUND")
             const unsigned int chunks = (unsigned int)((n + PPG_SPLAT_CHUNK - 1) / PPG_SPLAT_CHUNK);
@@ -1148,14 +1205,164 @@ int applyAdamRound(ppg_ctx *ctx, size_t nRecords) {
     return PPG_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Stragglers
+// ------------------------------------------------------------------------------------------------
+// A guided path survives Russian roulette with probability 0.99 (GP:2124-2139): of the millions of paths of a batch a few hundred are still
+// alive after 64 bounces and the longest runs for 300-900 — dependent bounces of ~12 us each, during which one wave works and the GPU waits
+// (KITCHEN: 8 % of a 1023-pass render on one GPU, and the term that does not shrink when the image is sharded over eight).  So k_tail runs
+// the handed-over paths only up to depth `deferDepth`; the STRAGGLERS — alive at that depth — are written to a compact set (path record by
+// k_tail itself, vertex slots by k_extract_vertices), and a second k_tail finishes them on stream4 BESIDE the next batch's kernels, one path
+// per wave.  What the batch still owes then — its film kernel (which needs the stragglers' radiance: the batch's Li values are kept in
+// d_liKeep and the stragglers' scattered into it), the stragglers' commit — is done by the NEXT batch once its own tail has run
+// (drainStragglers), or at the end of the ppg_render_passes call (flushStragglers).  The film sums keep their order and the building tree's
+// sums are integers: for a batch without optimiser records nothing changes but the schedule.  In a round of the optimiser the stragglers'
+// records are applied one round late — part of the result, the rule is in include/ppg.h ("STRAGGLERS") and in the oracle.
+int addGroups(ppg_ctx *ctx, unsigned int first, unsigned int count);
+
+// the compact state of n stragglers over the set's buffers (path records interleaved as k_tail wrote them; vertex slots [slot][path])
+int stragglerState(ppg_ctx *ctx, ppg_ctx::Stragglers &G, const PathState &batch, unsigned int n, bool withVertices) {
+    const bool filtered = ctx->spatialFilter != SF_NEAREST;
+    const unsigned int vs = filtered ? 6u : 4u;
+    if (withVertices) HIP_CHECK(G.vert.reserve((size_t)n * (size_t)ctx->maxVertices * vs));
+    HIP_CHECK(G.nv8.reserve(n)); HIP_CHECK(G.base.reserve(n));
+    if (batch.nee_cos) HIP_CHECK(G.neeCos.reserve(n));
+    PathState &Ps = G.P;
+    Ps = batch;  // n_pix, pixels: the batch's (adam_path_id)
+    Ps.n_paths = n;
+    float4 *r = G.rec.p, *v = G.vert.p;
+    Ps.ray_o = {r, 8}; Ps.ray_d = {r + 1, 8}; Ps.thr = {r + 2, 8}; Ps.li = {r + 3, 8}; Ps.hit = {r + 4, 8}; Ps.misc = {reinterpret_cast<uint4 *>(r + 5), 8};
+    Ps.v_d = {v, vs}; Ps.v_thr = {v + 1, vs}; Ps.v_bsdf = {v + 2, vs}; Ps.v_rad = {v + 3, vs};
+    Ps.v_o = {filtered ? v + 4 : nullptr, vs}; Ps.v_vox = {filtered ? v + 5 : nullptr, vs};
+    Ps.nee_cos = batch.nee_cos ? G.neeCos.p : nullptr;
+    Ps.orig = G.orig.p;
+    return PPG_OK;
+}
+
+// After the first k_tail of a batch: nStrag paths wait in the current set.  Take their vertex slots and the batch's radiance, start their own
+// k_tail (on stream4 when side streams are allowed), and leave the set pending.
+int launchStragglers(ppg_ctx *ctx, const PathState &P, const DevScene &S, const DevTree &T, const RenderParams &R, unsigned int nStrag, bool commit, bool adam,
+                     bool beside, int tailVariant, size_t ldsBytes) {
+    hipStream_t s = ctx->stream;
+    ppg_ctx::Stragglers &G = ctx->strag[ctx->stragCur];
+    { int rc = stragglerState(ctx, G, P, nStrag, commit); if (rc) return rc; }
+    G.n = nStrag; G.commit = commit; G.adam = adam && commit;
+    const int small = gridFor(nStrag, 64, 1024);
+    if (commit) hipLaunchKernelGGL(k_extract_vertices, dim3(small), dim3(256), 0, s, P, G.P, nStrag, (unsigned int)ctx->maxVertices);
+    else if (P.nee_cos) hipLaunchKernelGGL(k_extract_nee_cos, dim3(small), dim3(256), 0, s, P, G.P, nStrag);  // (nothing recorded: a final iteration)
+    HIP_CHECK(ctx->d_liKeep.reserve(P.n_paths));
+    hipLaunchKernelGGL(k_copy_li, dim3(gridFor(P.n_paths)), dim3(256), 0, s, P, ctx->d_liKeep.p);
+    if (G.iotaN < nStrag) {
+        HIP_CHECK(G.iota.reserve(nStrag));
+        const unsigned int m = (unsigned int)G.iota.cap;
+        hipLaunchKernelGGL(k_iota, dim3((m + 255) / 256), dim3(256), 0, s, G.iota.p, m);
+        G.iotaN = m;
+    }
+    HIP_CHECK(hipMemsetAsync(G.ticket.p, 0, 4, s));
+    // thinly: as many waves as there are stragglers while the GPU has room for them (a lone path's bounce is 12 us, 64 in one wave 120)
+    const unsigned int waves = 1024u * (PPG_BLOCK / 64u);
+    const unsigned int laneLimit = std::max(1u, std::min(64u, (nStrag + waves - 1u) / waves));
+    const int tailGrid = (int)std::max(1u, std::min(1024u, (nStrag + laneLimit * (PPG_BLOCK / 64u) - 1u) / (laneLimit * (PPG_BLOCK / 64u))));
+    DevTree Tt = T;
+    if (ctx->loss != LOSS_NONE && ctx->isBuilt) {  // the fractions of THIS round, whatever the optimiser does to the headers meanwhile
+        const unsigned int nn = (unsigned int)ctx->snodes.size();
+        HIP_CHECK(G.theta.reserve(nn));
+        hipLaunchKernelGGL(k_copy_theta, dim3(gridFor(nn, 256, 256)), dim3(256), 0, s, ctx->d_hdr.p, nn, G.theta.p);
+        Tt.theta_frozen = G.theta.p;
+    }
+    hipStream_t st = s;
+    if (beside) {
+        HIP_CHECK(hipEventRecord(ctx->evStragFork, s));
+        HIP_CHECK(hipStreamWaitEvent(ctx->stream4, ctx->evStragFork, 0));
+        st = ctx->stream4;
+    }
+    auto launch = [&] {
+        RenderParams Rt = R;
+        Rt.defer_depth = 0u;
+        TailLaunch a{tailGrid, ldsBytes, st, G.P, S, Tt, Rt, G.iota.p, G.count.p, G.ticket.p, ctx->queues.stats, ctx->ldsTris,
+                     ctx->d_tailLongest.p + (ctx->tailLaunches++ % PPG_TAIL_LOG), StragOut{nullptr, nullptr, nullptr}, laneLimit};
+        ppg_launch_tail(tailVariant, a);
+    };
+    if (beside) { launch(); HIP_CHECK(hipEventRecord(ctx->evStragDone, ctx->stream4)); }
+    else timedLaunch(ctx, "k_tail", nStrag, launch);
+    G.pending = true; G.aside = beside;
+    ctx->stragCur ^= 1;
+    HIP_CHECK(hipGetLastError());
+    return PPG_OK;
+}
+
+// What the previous batch still owes: its stragglers have ended (or the context's stream waits until they have) — their radiance into the
+// kept copy, the batch's film kernel, their vertices' commit.  In a round of the optimiser their records take the positions from
+// recordsFirst on of the round's arrays (sized for them by the caller).
+int drainStragglers(ppg_ctx *ctx, size_t recordsFirst) {
+    ppg_ctx::Stragglers &G = ctx->stragPrev();
+    if (!G.pending) return PPG_OK;
+    hipStream_t s = ctx->stream;
+    if (G.aside) HIP_CHECK(hipStreamWaitEvent(s, ctx->evStragDone, 0));
+    G.pending = false; G.aside = false;
+    const int small = gridFor(G.n, 256, 1024);
+    hipLaunchKernelGGL(k_scatter_li, dim3(small), dim3(256), 0, s, G.P, G.n, ctx->d_liKeep.p);
+    if (G.film) { G.film(); G.film = nullptr; }
+    if (G.commit) {
+        hipLaunchKernelGGL(k_commit_prepare, dim3((G.n + 255) / 256), dim3(256), 0, s, G.P, (uint4 *)nullptr, G.nv8.p, (const unsigned char *)nullptr);
+        DevTree T = ctx->devTree();
+        const RenderParams R = ctx->params();
+        if (G.adam) {
+            if (!T.adam_keys) { ctx->error = "internal: stragglers' records outside a round"; return PPG_ERR_STATE; }
+            // Record positions are key order within a D-tree (the round's sort is stable and looks at the leaf bits only): the stragglers take
+            // theirs in the order of their paths' ids — k_tail handed them over in whatever order its waves got there.
+            HIP_CHECK(G.origSorted.reserve(G.n)); HIP_CHECK(G.perm.reserve(G.n));
+            size_t bytes = 0;
+            HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, G.orig.p, G.origSorted.p, G.iota.p, G.perm.p, (size_t)G.n, 0u, 32u, s));
+            HIP_CHECK(ctx->d_sortTemp.reserve(std::max<size_t>(bytes, 16)));
+            HIP_CHECK(rocprim::radix_sort_pairs((void *)ctx->d_sortTemp.p, bytes, G.orig.p, G.origSorted.p, G.iota.p, G.perm.p, (size_t)G.n, 0u, 32u, s));
+            hipLaunchKernelGGL(k_ranked_base, dim3(small), dim3(256), 0, s, G.base.p, G.perm.p, G.n, (unsigned int)recordsFirst, (unsigned int)ctx->maxVertices);
+            T.adam_base = G.base.p;
+        }
+        CommitLaunch a{gridFor(G.n, 64, ctx->nBlocks), s, G.P, T, R, ctx->queues, G.nv8.p, nullptr, nullptr, ctx->d_splat.p, ctx->adamFlagShift};
+        timedLaunch(ctx, (G.adam && ctx->sortedCommit) ? "k_commit_records" : "k_commit", 0, [&] {
+            if (G.adam && ctx->sortedCommit) ppg_launch_commit_records(ctx->spatialFilter, a);
+            else ppg_launch_commit(ctx->spatialFilter, ctx->directionalFilter, a);
+        });
+    }
+    HIP_CHECK(hipGetLastError());
+    return PPG_OK;
+}
+
+// End of a ppg_render_passes call: nothing may stay owed (the variance estimate reads the image, ppg_build_sdtree the building tree).  The
+// records of the last round's stragglers are applied in a round of their own (include/ppg.h "STRAGGLERS"); `hookRound`: a sharded render's
+// round hook is called for it on every rank, with or without records.
+int flushStragglers(ppg_ctx *ctx, bool hookRound) {
+    ppg_ctx::Stragglers &G = ctx->stragPrev();
+    const bool records = G.pending && G.adam;
+    if (!G.pending && !hookRound) return PPG_OK;
+    hipStream_t s = ctx->stream;
+    ctx->joinTree();  // (the last round's splats and optimiser steps read the record arrays this round is about to overwrite)
+    size_t n = 0;
+    if (records || hookRound) {
+        ctx->adamActive = true; ctx->adamFast = true;
+        unsigned int leafBits = 1;
+        while ((1u << leafBits) <= (unsigned int)ctx->snodes.size()) ++leafBits;
+        ctx->adamFlagShift = PPG_ADAM_LEAF_SHIFT + leafBits;
+        // (a few thousand vertices spread over all D-trees: k_commit's global atomics — k_splat_sorted would stage a D-tree in LDS for every
+        // record or two, 5 ms for the 50 000 record positions of KITCHEN's 2-pass rounds; integer sums, the same bits)
+        ctx->sortedCommit = false;
+        n = records ? (size_t)G.n * (size_t)ctx->maxVertices : 0;
+        HIP_CHECK(ctx->d_adamKeys[0].reserve(std::max<size_t>(1, n))); HIP_CHECK(ctx->d_adamRecs.reserve(std::max<size_t>(1, n)));
+        if (n) HIP_CHECK(hipMemsetAsync(ctx->d_adamKeys[0].p, 0xff, n * 8, s));
+    }
+    int rc = drainStragglers(ctx, 0);
+    if (!rc && (records || hookRound)) rc = applyAdamRound(ctx, n);
+    ctx->adamActive = false;
+    return rc;
+}
+
 // `batch` BlockedRenderProcesses (GP:1087-1106 / renderBlock GP:1587-1641) over all owned pixels in one set of launches.
 // adamRound: this batch is one round of the sampling-fraction optimiser.
 // A launch of whole groups of a final iteration's passes (include/ppg.h "Final iteration: groups of passes"): `batch` passes = groups of
 // groupPasses passes (the last one may be shorter; or a part of ONE group when groupPasses >= batch), the first starting at pass
 // firstPass of the render, consecutive groups of the launch stridePasses apart; group k accumulates into slot slot0 + k * slotStride.
-struct GroupLaunch { unsigned int firstPass, groupPasses, stridePasses, slot0, slotStride; bool wholeFilm; };
-
-int renderBatch(ppg_ctx *ctx, int batch, bool adamRound, const GroupLaunch *gl = nullptr) {
+int renderBatch(ppg_ctx *ctx, int batch, bool adamRound, const GroupLaunch *gl = nullptr, bool last = true) {
     PathState P = ctx->paths;
     if (gl && gl->wholeFilm && ctx->shardWorld > 1) { P.n_pix = ctx->nPixAll; P.pixels = ctx->d_pixelsAll.p; }  // the whole film, not this rank's tiles
     P.n_paths = (unsigned int)((size_t)P.n_pix * ctx->sppPerPass * (size_t)batch);
@@ -1230,6 +1437,9 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound, const GroupLaunch *gl =
                 }
                 maxBounces = std::max(1, std::min(64, need + ctx->bounceMargin));
             }
+            // (a round whose stragglers' records are deferred: a path alive after wavefront bounce b has depth b, and which paths are
+            // stragglers is decided where k_tail takes them — never beyond the depth of the rule, include/ppg.h "STRAGGLERS")
+            if (adamRound && ctx->adamFast && !fused) maxBounces = std::min(maxBounces, std::max(1, ctx->deferDepthAdam));
         }
         const bool liveCount = ctx->timer.enabled || (unbounded && fused);  // kernel timing wants the units of every launch
         unsigned int *counts = ctx->d_bounceCounts.p;  // [0..63] live paths after bounce b, [64] the stop flag
@@ -1293,8 +1503,18 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound, const GroupLaunch *gl =
     ctx->joinTree();  // (a batch without a wavefront bounce)
     const bool tail = unbounded && !fused && P.n_paths > 0;
     const bool commit = !ctx->isFinalIter && P.n_paths > 0;
-    const bool overlap = tail && commit && !ctx->timer.enabled && !ctx->tuneNoOverlap;
     const bool fastRound = adamRound && ctx->adamFast && P.n_paths > 0;
+    // STRAGGLERS.  k_tail hands the paths still alive at depth `deferDepth` over to a second launch that runs beside the NEXT batch (see
+    // "Stragglers" above drainStragglers).  In a round of the optimiser whose record positions are known the depth is part of the result
+    // (include/ppg.h "STRAGGLERS": their records are applied one round late); elsewhere it is scheduling only, and worth it only when another
+    // batch follows at once (`last` = false).
+    const bool deferRecords = adamRound && ctx->adamFast && unbounded;
+    const unsigned int deferDepth = !tail ? 0u : (deferRecords ? (unsigned int)ctx->deferDepthAdam : ((!last && !adamRound && !ctx->timer.enabled && !ctx->tuneNoOverlap) ? (unsigned int)ctx->tuneSplitDepth : 0u));
+    const bool splitTail = deferDepth > 0;
+    const bool beside = !ctx->timer.enabled && !ctx->tuneNoOverlap;  // side streams may be used
+    // k_commit of the paths that HAVE ended when k_tail takes over runs beside it; with a split tail the two-phase commit is needed anyway
+    // (the hand-over must be known before the tail runs)
+    const bool overlap = tail && commit && (beside || splitTail);
     // A round whose record positions are known commits in three steps — records, the optimiser's sort, splats D-tree by D-tree
     // (ppg_kernels.h "The commit of a ROUND") — instead of one lane per vertex adding to the pool with global atomics.
     {
@@ -1306,13 +1526,18 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound, const GroupLaunch *gl =
     ctx->sortedCommit = adamRound && ctx->adamFast && !ctx->tuneNoSortedCommit && ctx->adamFlagShift < 63u;
     size_t nRecords = 0;
     unsigned int *dense = Q.items[1];  // the live paths in one list (k_tail's work list)
-    auto launchTail = [&] {
+    ppg_ctx::Stragglers &G = ctx->strag[ctx->stragCur];  // the set this batch's stragglers go to (the other one may be pending: the previous batch's)
+    // the records of the PREVIOUS round's stragglers are applied with this round's: they take the positions behind its own
+    const size_t nDeferredIn = (adamRound && ctx->adamFast && ctx->stragPrev().pending && ctx->stragPrev().adam) ? (size_t)ctx->stragPrev().n * (size_t)ctx->maxVertices : 0;
+    auto launchTail = [&](unsigned int depth) {
         HIP_CHECK(hipMemsetAsync(ctx->d_ticket.p, 0, 4, s));
         // (the persistent workgroups of k_tail hold their registers until their last path has ended: no more of them than fit the GPU at once)
         const int tailGrid = std::min(grid, ctx->tuneTailBlocks ? ctx->tuneTailBlocks : 1024);
         timedLaunch(ctx, "k_tail", hostCount, [&] {
-            TailLaunch a{tailGrid, ldsBytes, s, P, S, T, R, dense, ctx->d_total.p, ctx->d_ticket.p, Q.stats, ctx->ldsTris,
-                         ctx->d_tailLongest.p + (ctx->tailLaunches++ % PPG_TAIL_LOG)};
+            RenderParams Rt = R;
+            Rt.defer_depth = depth;
+            TailLaunch a{tailGrid, ldsBytes, s, P, S, T, Rt, dense, ctx->d_total.p, ctx->d_ticket.p, Q.stats, ctx->ldsTris,
+                         ctx->d_tailLongest.p + (ctx->tailLaunches++ % PPG_TAIL_LOG), StragOut{G.rec.p, G.orig.p, G.count.p}, 64u};
             ppg_launch_tail((smallScene ? 4 : 0) | (neeOn ? 2 : 0) | (fullMats ? 1 : 0), a);
         });
         return PPG_OK;
@@ -1347,8 +1572,8 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound, const GroupLaunch *gl =
             HIP_CHECK(ctx->d_straggler.reserve(P.n_paths));
             HIP_CHECK(hipMemsetAsync(ctx->d_straggler.p, 0, P.n_paths, s));
             hipLaunchKernelGGL(k_mark_list, dim3(grid), dim3(PPG_BLOCK), 0, s, dense, ctx->d_total.p, ctx->d_straggler.p);
-        } else {
-            int rc = launchTail();
+        } else if (!splitTail) {
+            int rc = launchTail(0u);
             if (rc) return rc;
         }
     }
@@ -1364,8 +1589,10 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound, const GroupLaunch *gl =
         HIP_CHECK(hipMemcpyAsync(ctx->h_round + 65, ctx->d_adamBase.p + (P.n_paths - 1), 4, hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipMemcpyAsync(ctx->h_round + 66, ctx->d_adamNv.p + (P.n_paths - 1), 4, hipMemcpyDeviceToHost, s));
     }
+    size_t nRecordsOwn = 0;
     if (tail || fastRound) {
         if (unbounded) HIP_CHECK(hipMemcpyAsync(ctx->h_round, ctx->d_bounceCounts.p, 64 * 4, hipMemcpyDeviceToHost, s));
+        if (splitTail) HIP_CHECK(hipMemcpyAsync(ctx->h_round + 68, ctx->d_total.p, 8, hipMemcpyDeviceToHost, s));  // the paths handed to k_tail
         HIP_CHECK(hipStreamSynchronize(s));  // the one host round trip of a batch of unbounded paths / of a round
         if (tail) {
             // the survival curve of this batch sizes the schedule of the next one
@@ -1380,7 +1607,8 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound, const GroupLaunch *gl =
             }
         }
         if (fastRound) {
-            nRecords = (size_t)ctx->h_round[65] + ctx->h_round[66];
+            nRecordsOwn = (size_t)ctx->h_round[65] + ctx->h_round[66];
+            nRecords = nRecordsOwn + nDeferredIn;
             if (nRecords > 0xfffffff0ull) { ctx->error = "too many Adam records in one round"; return PPG_ERR_NOMEM; }
             HIP_CHECK(ctx->d_adamKeys[0].reserve(std::max<size_t>(1, nRecords))); HIP_CHECK(ctx->d_adamRecs.reserve(std::max<size_t>(1, nRecords)));
             if (ctx->sortedCommit) HIP_CHECK(ctx->d_splat.reserve(std::max<size_t>(1, nRecords)));
@@ -1388,10 +1616,48 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound, const GroupLaunch *gl =
             T = ctx->devTree();
         }
     }
+    if (adamRound && ctx->adamFast && !fastRound && nDeferredIn) {  // an empty round (a cancelled rank kept in step) that still owes the previous round's stragglers
+        nRecords = nDeferredIn;
+        HIP_CHECK(ctx->d_adamKeys[0].reserve(nRecords)); HIP_CHECK(ctx->d_adamRecs.reserve(nRecords));
+        if (ctx->sortedCommit) HIP_CHECK(ctx->d_splat.reserve(nRecords));
+        HIP_CHECK(hipMemsetAsync(ctx->d_adamKeys[0].p, 0xff, nRecords * 8, s));
+        T = ctx->devTree();
+    }
     if (commit) { int rc = copyMisc(); if (rc) return rc; }
-    if (overlap) {
+    unsigned int nStrag = 0;
+    if (splitTail) {
+        // k_tail up to depth deferDepth; what is alive then is written to the straggler set (at most every path handed over)
+        const size_t handed = (size_t)(((unsigned long long)ctx->h_round[69] << 32) | ctx->h_round[68]);
+        HIP_CHECK(G.rec.reserve(std::max<size_t>(1, handed) * 8)); HIP_CHECK(G.orig.reserve(std::max<size_t>(1, handed)));
+        HIP_CHECK(G.count.reserve(2)); HIP_CHECK(G.ticket.reserve(1));
+        HIP_CHECK(hipMemsetAsync(G.count.p, 0, 16, s));
+        if (overlap) HIP_CHECK(hipEventRecord(ctx->evFork, s));
+        { int rc = launchTail(deferDepth); if (rc) return rc; }
+        if (overlap) {
+            if (beside) {
+                HIP_CHECK(hipStreamWaitEvent(ctx->stream2, ctx->evFork, 0));
+                launchCommit(ctx->stream2, 1);
+                HIP_CHECK(hipEventRecord(ctx->evJoin, ctx->stream2));
+                HIP_CHECK(hipStreamWaitEvent(s, ctx->evJoin, 0));
+            } else timedLaunch(ctx, ctx->sortedCommit ? "k_commit_records" : "k_commit", P.n_paths, [&] { launchCommit(s, 1); });
+        }
+        HIP_CHECK(hipMemcpyAsync(ctx->h_round + 70, G.count.p, 8, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));  // the second host round trip of a batch with a split tail: how many stragglers
+        nStrag = ctx->h_round[70];
+        if (ctx->debugBatch) fprintf(stderr, "[ppg batch] iter %d stragglers %u of %zu handed over at depth %u\n", ctx->iter, nStrag, handed, deferDepth);
+        // (the previous batch's set is consumed before this batch's stragglers start: one event, one kept copy of the radiance)
+        if (nStrag) { int rc = drainStragglers(ctx, nRecordsOwn); if (rc) return rc; }
+        if (nStrag) {
+            int rc = launchStragglers(ctx, P, S, T, R, nStrag, commit, deferRecords, beside, (smallScene ? 4 : 0) | (neeOn ? 2 : 0) | (fullMats ? 1 : 0), ldsBytes);
+            if (rc) return rc;
+        }
+        if (overlap) {
+            if (beside) launchCommit(s, 2);
+            else timedLaunch(ctx, ctx->sortedCommit ? "k_commit_records" : "k_commit", 0, [&] { launchCommit(s, 2); });
+        }
+    } else if (overlap) {
         HIP_CHECK(hipEventRecord(ctx->evFork, s));
-        int rc = launchTail();
+        int rc = launchTail(0u);
         if (rc) return rc;
         HIP_CHECK(hipStreamWaitEvent(ctx->stream2, ctx->evFork, 0));
         launchCommit(ctx->stream2, 1);
@@ -1401,6 +1667,8 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound, const GroupLaunch *gl =
     } else if (commit) {
         timedLaunch(ctx, ctx->sortedCommit ? "k_commit_records" : "k_commit", P.n_paths, [&] { launchCommit(s, 0); });
     }
+    // what an earlier batch still owes (its film kernel, its stragglers' commit) comes before this batch's own sort and film kernel
+    if (!(splitTail && nStrag)) { int rc = drainStragglers(ctx, nRecordsOwn); if (rc) return rc; }  // (a batch with stragglers of its own consumed it above)
     if (adamRound) {
         if (!ctx->adamFast) {
             HIP_CHECK(hipMemcpyAsync(ctx->h_round + 64, ctx->d_adamCount.p, 8, hipMemcpyDeviceToHost, s));
@@ -1412,13 +1680,27 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound, const GroupLaunch *gl =
         ctx->adamActive = false;
         if (rc) return rc;
     }
-    if (P.n_paths > 0)
-    timedLaunch(ctx, "k_film", P.n_pix, [&] {
-        if (gl) hipLaunchKernelGGL(k_film_groups, dim3((P.n_pix + 255) / 256), dim3(256), 0, s, P, ctx->sppPerPass * batch, gl->groupPasses * (unsigned int)ctx->sppPerPass,
-                                   ctx->d_partials.p + (ctx->shardWorld > 1 ? 4 * (size_t)ctx->nPixAll : 0), gl->slot0, gl->slotStride, ctx->nPixAll);
-        else hipLaunchKernelGGL(k_film, dim3((P.n_pix + 255) / 256), dim3(256), 0, s, P, ctx->sppPerPass * batch, ctx->d_image.p, ctx->d_sq.p, ctx->d_imageW.p,
-                           ctx->d_film.p, ctx->d_filmW.p);
-    });
+    if (P.n_paths > 0) {
+        // the batch's film kernel — at once, or, when stragglers of this batch are still running, from the copy of its paths' radiance once
+        // they have ended (drainStragglers): the sums a pixel's samples go through are the same either way
+        PathState Pf = P;
+        const bool defer = splitTail && nStrag > 0;
+        if (defer) Pf.li = {ctx->d_liKeep.p, 1};
+        const int sppBatch = ctx->sppPerPass * batch;
+        const bool hasGl = gl != nullptr;
+        const GroupLaunch glv = gl ? *gl : GroupLaunch{};
+        auto film = [ctx, Pf, sppBatch, hasGl, glv] {
+            hipStream_t st = ctx->stream;
+            timedLaunch(ctx, "k_film", Pf.n_pix, [&] {
+                if (hasGl) hipLaunchKernelGGL(k_film_groups, dim3((Pf.n_pix + 255) / 256), dim3(256), 0, st, Pf, sppBatch, glv.groupPasses * (unsigned int)ctx->sppPerPass,
+                                              ctx->d_partials.p + (ctx->shardWorld > 1 ? 4 * (size_t)ctx->nPixAll : 0), glv.slot0, glv.slotStride, ctx->nPixAll);
+                else hipLaunchKernelGGL(k_film, dim3((Pf.n_pix + 255) / 256), dim3(256), 0, st, Pf, sppBatch, ctx->d_image.p, ctx->d_sq.p, ctx->d_imageW.p,
+                                        ctx->d_film.p, ctx->d_filmW.p);
+            });
+            if (hasGl && glv.addCount) (void)addGroups(ctx, 0, glv.addCount);
+        };
+        if (defer) ctx->stragPrev().film = film; else film();  // (launchStragglers made this batch's set the previous one)
+    }
     HIP_CHECK(hipGetLastError());
     return PPG_OK;
 }
@@ -1445,8 +1727,27 @@ int renderFinalGroups(ppg_ctx *ctx, int numPasses) {
     const unsigned int world = (unsigned int)ctx->shardWorld, rank = (unsigned int)ctx->shardRank;
     const bool byRank = finalGroupsByRank(nGroups, world);  // else: all groups, this rank's tiles (world == 1: the whole film)
     const size_t n = ctx->nPixAll;
-    const unsigned int perLaunch = std::max(1u, (unsigned int)ctx->maxBatchFinal / G);  // whole groups per launch (G <= maxBatchFinal), else parts of one group
-    const unsigned int slots = world > 1 ? nGroups : perLaunch;
+    std::vector<unsigned int> mine;
+    for (unsigned int g = byRank ? rank : 0u; g < nGroups; g += byRank ? world : 1u) mine.push_back(g);
+    auto passesOf = [&](unsigned int g) { return std::min(G, (unsigned int)numPasses - g * G); };
+    // Passes per launch: maxBatchFinal.  PPG_FINAL_HALVES=1: when this rank's share of the iteration would fit ONE launch, half of it, so that the
+    // stragglers of the first half finish beside the second half's paths ("Stragglers") — measured and NOT the default: each half hands its own
+    // 2 M paths to k_tail (the floor below which wavefront bounces no longer fill the GPU), and that crowd phase, 10-12 ms of throughput on
+    // KITCHEN, is then paid twice to hide 4 ms of a lone path (driver's command: 146 vs 154 Msamples/s, profiles/r06_experiments.json).  How the
+    // passes are cut into launches does not enter any sum (a group's samples are added to its slot in sample order, launch after launch).
+    unsigned int launchPasses = (unsigned int)ctx->maxBatchFinal;
+    {
+        unsigned int minePasses = 0;
+        for (unsigned int g : mine) minePasses += passesOf(g);
+        const size_t pixels = byRank || world == 1 ? n : (size_t)ctx->nPix;
+        if (ctx->tuneFinalHalves && ctx->maxDepth < 0 && ctx->tuneSplitDepth > 0 && !ctx->timer.enabled && !ctx->tuneNoOverlap && minePasses >= 2 && minePasses <= launchPasses &&
+            pixels * (size_t)ctx->sppPerPass * (size_t)(minePasses / 2) >= ((size_t)1 << 21)) {
+            launchPasses = (minePasses + 1) / 2;
+            if (G < launchPasses) launchPasses = std::max(G, launchPasses / G * G);  // whole groups per launch
+        }
+    }
+    const unsigned int perLaunch = std::max(1u, launchPasses / G);  // whole groups per launch (G <= launchPasses), else parts of one group
+    const unsigned int slots = world > 1 ? nGroups : std::max(perLaunch, std::max(1u, (unsigned int)ctx->maxBatchFinal / G));
     const size_t floats = (world > 1 ? 4 * n : 0) + (size_t)slots * 7 * n;
     if (ctx->d_partials.cap < floats || ctx->partialSlots != slots) {
         HIP_CHECK(ctx->d_partials.reserve(floats));
@@ -1454,40 +1755,38 @@ int renderFinalGroups(ppg_ctx *ctx, int numPasses) {
     }
     HIP_CHECK(hipMemsetAsync(ctx->d_partials.p, 0, floats * 4, ctx->stream));
     const unsigned int firstPassAbs = (unsigned int)ctx->passesRendered;
-    std::vector<unsigned int> mine;
-    for (unsigned int g = byRank ? rank : 0u; g < nGroups; g += byRank ? world : 1u) mine.push_back(g);
     const unsigned int step = byRank ? world : 1u;  // distance between this rank's consecutive groups
     const uint64_t pixelsMine = byRank || world == 1 ? (uint64_t)n : (uint64_t)ctx->nPix;
-    auto passesOf = [&](unsigned int g) { return std::min(G, (unsigned int)numPasses - g * G); };
     bool stop = false;
     for (size_t m = 0; m < mine.size() && !stop;) {
         if (ctx->seesCancel()) break;
-        if (G <= (unsigned int)ctx->maxBatchFinal) {
+        if (G <= launchPasses) {
             const size_t cnt = std::min<size_t>(perLaunch, mine.size() - m);
             unsigned int batch = 0;
             for (size_t q = 0; q < cnt; ++q) batch += passesOf(mine[m + q]);
-            GroupLaunch gl{firstPassAbs + mine[m] * G, G, step * G, world > 1 ? mine[m] : 0u, world > 1 ? step : 1u, byRank};
-            int rc = renderBatch(ctx, (int)batch, false, &gl);
+            // (one GPU: the launch's slots are added to image and film right behind its film kernel)
+            GroupLaunch gl{firstPassAbs + mine[m] * G, G, step * G, world > 1 ? mine[m] : 0u, world > 1 ? step : 1u, byRank, world == 1 ? (unsigned int)cnt : 0u};
+            int rc = renderBatch(ctx, (int)batch, false, &gl, m + cnt >= mine.size());
             if (rc) return rc;
             ctx->samplesLocal += pixelsMine * batch * ctx->sppPerPass;
-            if (world == 1) addGroups(ctx, 0, (unsigned int)cnt);
             m += cnt;
         } else {  // a group larger than a launch: its parts accumulate into the same slot one after the other
             const unsigned int g = mine[m], total = passesOf(g);
             for (unsigned int done = 0; done < total;) {
                 if (ctx->seesCancel()) { stop = true; break; }
-                const unsigned int batch = std::min((unsigned int)ctx->maxBatchFinal, total - done);
-                GroupLaunch gl{firstPassAbs + g * G + done, batch, batch, world > 1 ? g : 0u, 1u, byRank};
-                int rc = renderBatch(ctx, (int)batch, false, &gl);
+                const unsigned int batch = std::min(launchPasses, total - done);
+                const bool lastPart = done + batch >= total;
+                GroupLaunch gl{firstPassAbs + g * G + done, batch, batch, world > 1 ? g : 0u, 1u, byRank, (world == 1 && lastPart) ? 1u : 0u};
+                int rc = renderBatch(ctx, (int)batch, false, &gl, lastPart && m + 1 >= mine.size());
                 if (rc) return rc;
                 ctx->samplesLocal += pixelsMine * batch * ctx->sppPerPass;
                 done += batch;
             }
-            if (world == 1 && !stop) addGroups(ctx, 0, 1);
             ++m;
         }
         HIP_CHECK(hipStreamSynchronize(ctx->stream));  // bound the launch queue; lets ppg_cancel() take effect
     }
+    { int rc = flushStragglers(ctx, false); if (rc) return rc; }
     ctx->passesRendered += numPasses; ctx->passesRenderedThisIter += numPasses; ctx->passesLocal += numPasses;
     if (world > 1) { ctx->partialsPending = true; ctx->pendingGroups = nGroups; }
     return ctx->seesCancel() ? PPG_ERR_CANCELLED : PPG_OK;
@@ -1520,12 +1819,12 @@ int renderPassesNoStat(ppg_ctx *ctx, int numPasses) {  // GP:1217-1286
             else {
                 // (a sharded time budget: the other ranks are about to ask the stop hook after the batch they are rendering — this rank asks it
                 // too, once, so that they meet in the same exchange; the host's hook carries its status word there and every rank stops)
-                if (ctx->budgetType == 1 && ctx->stopHook) (void)ctx->stopHook(ctx->stopHookUser, 1);
+                if (ctx->budgetType == 1 && ctx->stopHook) (void)ctx->stopHook(ctx->stopHookUser, PPG_STOP_CANCELLED);
                 break;
             }
         }
         const int batch = std::min(roundPasses, numPasses - i);
-        int rc = renderBatch(ctx, drain ? 0 : batch, rounds);
+        int rc = renderBatch(ctx, drain ? 0 : batch, rounds, nullptr, i + batch >= numPasses);
         if (rc) return rc;
         ctx->passesRendered += batch; ctx->passesRenderedThisIter += batch; ctx->passesLocal += batch;
         ctx->samplesLocal += (uint64_t)ctx->nPix * batch * ctx->sppPerPass;
@@ -1538,6 +1837,13 @@ int renderPassesNoStat(ppg_ctx *ctx, int numPasses) {  // GP:1217-1286
         } else if ((i & 63) < batch) {
             HIP_CHECK(hipStreamSynchronize(ctx->stream));  // bound the launch queue; also lets ppg_cancel() take effect
         }
+    }
+    // what the last batch still owes ("Stragglers"); in a sharded render with rounds whose stragglers' records are deferred, the round of the
+    // last stragglers' records is one more call of the round hook on EVERY rank (include/ppg.h "STRAGGLERS")
+    {
+        const bool deferRounds = rounds && ctx->maxDepth < 0 && ctx->spatialFilter != SF_BOX && !(ctx->doNee && ctx->nee == NEE_KICKSTART);
+        int rc = flushStragglers(ctx, deferRounds && ctx->passHook != nullptr);
+        if (rc) return rc;
     }
     return ctx->seesCancel() ? PPG_ERR_CANCELLED : PPG_OK;
 }
@@ -1603,7 +1909,7 @@ int allocFilm(ppg_ctx *ctx) {
 
 int beginRender(ppg_ctx *ctx) {  // GP:1519-1550
     HIP_CHECK(hipSetDevice(ctx->device));
-    ctx->joinTree();
+    ctx->quiesce();
     if (!ctx->pathsReady) {  // buffers are sized by scene + shard; normally done by ppg_set_scene / ppg_set_shard
         int rc = allocPaths(ctx);
         if (rc) return rc;
@@ -1934,6 +2240,8 @@ int ppg_create(const ppg_config *cfg, ppg_ctx **out) {
         if (const char *e = getenv("PPG_PATH_LAYOUT")) c->tunePathLayout = !strcmp(e, "aos") ? 2 : (!strcmp(e, "pack") ? 3 : (!strcmp(e, "soa") ? 1 : 0));
         if (const char *e = getenv("PPG_BVH_LEAF")) c->tuneBvhLeaf = std::max(1, std::min(8, atoi(e)));
         if (const char *e = getenv("PPG_BVH_PAD")) c->tuneBvhPad = (float)atof(e);
+        if (const char *e = getenv("PPG_SPLIT_DEPTH")) c->tuneSplitDepth = std::max(0, atoi(e));
+        c->tuneFinalHalves = getenv("PPG_FINAL_HALVES") != nullptr;
     }
     if (c->sppPerPass <= 0) { g_createError = "sppPerPass must be > 0"; return PPG_ERR_INVALID; }
     int ndev = 0;
@@ -1943,6 +2251,8 @@ int ppg_create(const ppg_config *cfg, ppg_ctx **out) {
     if ((e = hipSetDevice(c->device)) != hipSuccess || (e = hipStreamCreate(&c->stream)) != hipSuccess || (e = createSecondStream(&c->stream2)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming)) != hipSuccess ||
         (e = hipStreamCreate(&c->stream3)) != hipSuccess || (e = hipEventCreateWithFlags(&c->evTreeFork, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipStreamCreate(&c->stream4)) != hipSuccess || (e = hipEventCreateWithFlags(&c->evStragFork, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->evStragDone, hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&c->evSplatDone, hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&c->evAdamDone, hipEventDisableTiming)) != hipSuccess) {
         g_createError = std::string("HIP init failed: ") + hipGetErrorString(e);
         return PPG_ERR_DEVICE;
@@ -1958,9 +2268,12 @@ void ppg_destroy(ppg_ctx *ctx) {
     g_blockCache.settle();
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     if (ctx->stream3) (void)hipStreamSynchronize(ctx->stream3);
+    if (ctx->stream4) (void)hipStreamSynchronize(ctx->stream4);
     g_blockCache.settle();
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
+    if (ctx->stream4) (void)hipStreamDestroy(ctx->stream4);
+    for (hipEvent_t ev : {ctx->evStragFork, ctx->evStragDone}) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : {ctx->evTreeFork, ctx->evSplatDone, ctx->evAdamDone}) if (ev) (void)hipEventDestroy(ev);
     if (ctx->evFork) (void)hipEventDestroy(ctx->evFork);
     if (ctx->evJoin) (void)hipEventDestroy(ctx->evJoin);
@@ -1984,6 +2297,7 @@ int ppg_set_scene(ppg_ctx *ctx, const ppg_scene *s) {
         return PPG_ERR_INVALID;
     }
     HIP_CHECK(hipSetDevice(ctx->device));
+    ctx->quiesce();
     for (uint32_t t = 0; t < s->n_triangles; ++t) {
         if (s->tri_material[t] >= s->n_materials || s->tri_emitter[t] >= (int32_t)s->n_emitters) { ctx->error = "index out of range"; return PPG_ERR_INVALID; }
         if (s->materials[s->tri_material[t]].type < 0 || s->materials[s->tri_material[t]].type > PPG_BSDF_LAST) { ctx->error = "unsupported BSDF type"; return PPG_ERR_INVALID; }
@@ -2335,6 +2649,7 @@ int ppg_set_scene(ppg_ctx *ctx, const ppg_scene *s) {
 
 int ppg_set_shard(ppg_ctx *ctx, int32_t rank, int32_t world, int32_t tile_size) {
     (void)hipSetDevice(ctx->device);
+    ctx->quiesce();
     if (world < 1 || rank < 0 || rank >= world || tile_size < 1) { ctx->error = "bad shard"; return PPG_ERR_INVALID; }
     ctx->shardRank = rank; ctx->shardWorld = world; ctx->tileSize = tile_size;
     ctx->pathsReady = false;
@@ -2618,6 +2933,12 @@ int ppg_query_sample(ppg_ctx *ctx, uint32_t n, const float *positions, uint64_t 
     hipLaunchKernelGGL(k_query_sample, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->devTree(), n, dp.p, (unsigned long long)seed, dout.p);
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
     HIP_CHECK(hipMemcpy(dirs_out, dout.p, 12 * (size_t)n, hipMemcpyDeviceToHost));
+    return PPG_OK;
+}
+
+int ppg_debug_set_defer_depth(ppg_ctx *ctx, int32_t depth) {  // include/ppg_testhooks.h
+    if (!ctx || depth < 1 || depth > 64) return PPG_ERR_INVALID;
+    ctx->deferDepthAdam = depth;
     return PPG_OK;
 }
 

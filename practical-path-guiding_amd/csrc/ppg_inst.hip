@@ -36,9 +36,9 @@ void PPG_CAT(ppg_launch_shade_pair, PPG_INST)(int variant, const ShadeLaunch &a)
 #endif
 void PPG_TAIL_FN(int variant, const TailLaunch &a) {
     if (variant & 1)
-        hipLaunchKernelGGL((k_tail<PAIR_S, PAIR_N, true>), dim3(a.grid), dim3(PPG_BLOCK), a.lds, a.stream, a.P, a.S, a.T, a.R, a.dense, a.total, a.ticket, a.stats, a.lds_tris, a.longest);
+        hipLaunchKernelGGL((k_tail<PAIR_S, PAIR_N, true>), dim3(a.grid), dim3(PPG_BLOCK), a.lds, a.stream, a.P, a.S, a.T, a.R, a.dense, a.total, a.ticket, a.stats, a.lds_tris, a.longest, a.strag, a.lane_limit);
     else
-        hipLaunchKernelGGL((k_tail<PAIR_S, PAIR_N, false>), dim3(a.grid), dim3(PPG_BLOCK), a.lds, a.stream, a.P, a.S, a.T, a.R, a.dense, a.total, a.ticket, a.stats, a.lds_tris, a.longest);
+        hipLaunchKernelGGL((k_tail<PAIR_S, PAIR_N, false>), dim3(a.grid), dim3(PPG_BLOCK), a.lds, a.stream, a.P, a.S, a.T, a.R, a.dense, a.total, a.ticket, a.stats, a.lds_tris, a.longest, a.strag, a.lane_limit);
 }
 #elif PPG_INST == 9
 void ppg_launch_shade_common(const ShadeLaunch &a) {

@@ -75,6 +75,9 @@ struct RenderParams {
     unsigned int group_samples, group_stride;
     int max_vertices;         // vertex slots allocated per path
     unsigned int img_pixels;  // width * height of the whole image (path ids of the Adam records)
+    // k_tail: a path still alive when its rRec.depth has reached this value leaves the launch as a STRAGGLER — its state goes to the compact
+    // straggler set (StragOut) and a second k_tail finishes it beside the next batch (ppg_hip.hip "Stragglers").  0: every path runs to its end.
+    unsigned int defer_depth;
 #ifdef PPG_PROBE
     unsigned long long *probe;  // development builds only (make EXTRA=-DPPG_PROBE): cycle sums per section of a LONE path's bounce in k_tail
 #endif
@@ -123,6 +126,17 @@ struct PathState {
     Field<float4> v_vox;   // (voxel size, -)   only if spatial filter != nearest
     float *nee_cos;  // dot(ray.d, dRec.refN) of the pending bounce (-2 when refN = 0): ConstantBackgroundEmitter::pdfDirect needs the
                      // value, not just its sign; only allocated for scenes with an environment emitter
+    // The compact state of a batch's STRAGGLERS (ppg_hip.hip "Stragglers"): path j of this state is path orig[j] of the batch it was taken
+    // from, whose n_pix / pixels stay in force — the Adam records it leaves carry that path's id and the "deferred" bit.  nullptr: a batch.
+    const unsigned int *orig;
+};
+
+// Where k_tail puts a straggler (RenderParams::defer_depth): one interleaved record of eight float4 per path — ray origin, direction,
+// throughput, Li, hit, (key, dim, flags, leaf), two unused — at position j = atomic count, and the path's index in its batch.
+struct StragOut {
+    float4 *rec;
+    unsigned int *orig;
+    unsigned long long *count;
 };
 
 // Per-workgroup statistics (zeroed per ppg_render_passes, summed on the host).  A single global counter
@@ -617,7 +631,12 @@ struct Rec {  // DTreeRecord, GP:562-568
 };
 
 // path id of the Adam records: (sample index within the round) * (pixels of the whole image) + pixel index
+// (a straggler — P.orig — committed one round late carries the "deferred" bit above the path bits: include/ppg.h "Stragglers")
 D unsigned int adam_path_id(const PathState &P, const RenderParams &R, unsigned int i) {
+    if (P.orig) {
+        const unsigned int o = P.orig[i];
+        return ((o / P.n_pix) * R.img_pixels + P.pixels[o % P.n_pix]) | PPG_ADAM_DEFER_PATH_BIT;
+    }
     return (i / P.n_pix) * R.img_pixels + P.pixels[i % P.n_pix];
 }
 
@@ -1040,7 +1059,7 @@ D bool shade_one(const PathState &P, const DevScene &S, const DevTree &T, const 
             leaf = stree_lookup(T, I.p, vox);  // GP:1942-1944
             const float4 h4 = *reinterpret_cast<const float4 *>(&T.hdr[leaf]);  // {s_base, s_num, s_sum, s_statw}
             hd.s_base = __float_as_uint(h4.x); hd.s_sum = h4.z; hd.s_statw = h4.w;
-            if (R.loss != LOSS_NONE) frac = logistic(T.hdr[leaf].theta);
+            if (R.loss != LOSS_NONE) frac = logistic(T.theta_frozen ? T.theta_frozen[leaf] : T.hdr[leaf].theta);
         }
 
         PROBE_MARK(cs, 5);
@@ -1312,7 +1331,7 @@ __global__ __launch_bounds__(PPG_BLOCK, (MSET == MSET_COMMON ? PPG_SHADE_WAVES_C
 template <bool SMALL, bool NEE, bool FULL>
 __global__ __launch_bounds__(PPG_BLOCK, (FULL ? PPG_SHADE_WAVES_FULL : PPG_SHADE_WAVES)) void k_tail(PathState P, DevScene S, DevTree T, RenderParams R, const unsigned int *dense,
                                                                     const unsigned long long *total_ptr, unsigned int *ticket, BlockStats *stats,
-                                                                    int lds_tris, unsigned int *longest) {
+                                                                    int lds_tris, unsigned int *longest, StragOut so, unsigned int lane_limit) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __shared__ float pdf_factors[20 * PPG_BLOCK];
     __shared__ unsigned long long acc;
@@ -1332,7 +1351,9 @@ __global__ __launch_bounds__(PPG_BLOCK, (FULL ? PPG_SHADE_WAVES_FULL : PPG_SHADE
     unsigned long long plen_sum = 0, committed = 0, plen_max = 0;
     unsigned int traced = 0;
     const int lane = threadIdx.x & 63;
-    bool have = false, drained = false;
+    // (lane_limit < 64: a launch over a FEW paths — the stragglers' — deals them thinly, lane_limit paths per wave, so that every one of them
+    // runs at the speed of a lone path (cooperative traversal, no union of branches) instead of 64 of them sharing a wave)
+    bool have = false, drained = (unsigned int)lane >= lane_limit;
     unsigned int i = 0;
     Carried cs;
     cs.misc = make_uint4(0u, 0u, 0u, 0u);
@@ -1362,8 +1383,35 @@ __global__ __launch_bounds__(PPG_BLOCK, (FULL ? PPG_SHADE_WAVES_FULL : PPG_SHADE
                 } else drained = true;
             }
         }
+        bool spilled = false;  // (wave-uniform)
+        if (R.defer_depth) {
+            // A path that is alive at depth defer_depth — just taken from the list at that depth, or after the bounce below — leaves this
+            // launch: its state, as carried, goes to the straggler set (one wave-aggregated ticket), and the word of the batch's own state
+            // says "no vertices" — the batch's commit passes it by.  Its lane takes the next path in the next iteration.
+            const bool spill = have && (cs.misc.z & FL_DEPTH_MASK) >= R.defer_depth;
+            const unsigned long long sm = __ballot(spill);
+            if (sm) {
+                spilled = true;
+                const int leader = __ffsll((long long)sm) - 1;
+                unsigned long long base = 0;
+                if (lane == leader) base = atomicAdd(so.count, (unsigned long long)__popcll(sm));
+                base = __shfl(base, leader);
+                if (spill) {
+                    const size_t j = (size_t)base + (size_t)__popcll(sm & ((1ull << lane) - 1ull));
+                    float4 *r = so.rec + 8 * j;
+                    r[0] = cs.ro; r[1] = cs.rd; r[2] = cs.thr; r[3] = cs.li; r[4] = cs.hit;
+                    r[5] = make_float4(__uint_as_float(cs.misc.x), __uint_as_float(cs.misc.y), __uint_as_float(cs.misc.z), __uint_as_float(cs.misc.w));
+                    so.orig[j] = i;
+                    P.misc[i] = make_uint4(cs.misc.x, cs.misc.y, cs.misc.z & ~FL_NV_MASK, cs.misc.w);
+                    have = false;
+                }
+            }
+        }
         const unsigned long long live = __ballot(have);
-        if (!live) break;
+        if (!live) {
+            if (spilled) continue;  // (the lanes that just gave their paths away have not asked for new ones yet)
+            break;
+        }
         PROBE_MARK(&cs, 0);
         bool traced_coop = false;
         if (!SMALL && __popcll(live) <= PPG_COOP_MAX) {
@@ -1617,6 +1665,9 @@ __global__ __launch_bounds__(PPG_BLOCK) void k_commit(PathState P, DevTree T, Re
 #define PPG_SPLAT_NODES 512    // D-trees of up to this many nodes are staged in LDS (20 KB); larger ones are splatted in the pool (TreeGlobal)
 #define PPG_SPLAT_PER_LANE 8   // records per lane and chunk
 #define PPG_SPLAT_CHUNK (PPG_BLOCK * PPG_SPLAT_PER_LANE)
+static_assert(PPG_BLOCK % 64 == 0, "k_splat_sorted / k_commit_records reduce over full waves");
+static_assert(PPG_SPLAT_NODES * (sizeof(ushort4) + 4 * sizeof(unsigned long long)) + PPG_BOX_STACK * PPG_BLOCK * sizeof(unsigned long long) + 64 <= 64 * 1024,
+              "k_splat_sorted: the staged D-tree and the box stacks must fit the workgroup's LDS");
 
 // PATH-major: four lanes take one path and walk its vertex slots; a wave's 16 neighbouring paths read four slots at a time (the slots are
 // stored [slot][path]) and own ONE contiguous run of record positions (adam_base is the scan of the vertex counts), which they fill within
@@ -1712,8 +1763,10 @@ __global__ __launch_bounds__(PPG_BLOCK) void k_splat_sorted(DevTree T, const uns
     __shared__ unsigned long long s_stack[DF == DF_BOX ? PPG_BOX_STACK * PPG_BLOCK : 1];
     __shared__ unsigned long long s_weight;
     __shared__ unsigned int s_field, s_end;
+    // (leaf_bits <= 22: flag + leaf fit the 24 key bits above PPG_ADAM_LEAF_SHIFT — the host commits larger S-trees with k_commit; n <= 0xfffffff0:
+    // lo + t + j * PPG_BLOCK stays below 2^32)
     const unsigned int leaf_mask = (1u << leaf_bits) - 1u, field_mask = (2u << leaf_bits) - 1u;
-    const unsigned int chunks = (n + PPG_SPLAT_CHUNK - 1) / PPG_SPLAT_CHUNK;
+    const unsigned int chunks = n / PPG_SPLAT_CHUNK + (n % PPG_SPLAT_CHUNK ? 1u : 0u);
     const unsigned int t = threadIdx.x;
     for (unsigned int c = blockIdx.x; c < chunks; c += gridDim.x) {
         const unsigned int lo = c * PPG_SPLAT_CHUNK, hi = (n - lo) < PPG_SPLAT_CHUNK ? n : lo + PPG_SPLAT_CHUNK;
@@ -1841,6 +1894,44 @@ static __global__ void k_iota_total(unsigned int *a, unsigned int n, unsigned lo
 static __global__ void k_iota(unsigned int *a, unsigned int n) {
     unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) a[i] = i;
+}
+// ---- stragglers (ppg_hip.hip "Stragglers") ----
+// The vertex slots of the n stragglers, from the batch's slots (path orig[j]) to the compact state's (path j); four lanes per path.
+static __global__ void k_extract_vertices(PathState P, PathState Ps, unsigned int n, unsigned int max_vertices) {
+    const unsigned int q = threadIdx.x & 3u;
+    for (unsigned int j = (blockIdx.x * blockDim.x + threadIdx.x) >> 2; j < n; j += (gridDim.x * blockDim.x) >> 2) {
+        const unsigned int i = Ps.orig[j];
+        // (the recorded vertices AND the slot behind them: a live path has a bounce pending, whose vertex was half written when it was sampled —
+        // direction, throughput, BSDF value — and is completed, and counted, by the next k_shade step)
+        unsigned int nv = ((Ps.misc[j].z & FL_NV_MASK) >> FL_NV_SHIFT) + 1u;
+        if (nv > max_vertices) nv = max_vertices;
+        for (unsigned int v = q; v < nv; v += 4u) {
+            const size_t a = (size_t)v * P.n_paths + i, b = (size_t)v * Ps.n_paths + j;
+            Ps.v_d[b] = P.v_d[a]; Ps.v_thr[b] = P.v_thr[a]; Ps.v_bsdf[b] = P.v_bsdf[a]; Ps.v_rad[b] = P.v_rad[a];
+            if (P.v_o) { Ps.v_o[b] = P.v_o[a]; Ps.v_vox[b] = P.v_vox[a]; }
+        }
+        if (q == 0 && P.nee_cos) Ps.nee_cos[j] = P.nee_cos[i];
+    }
+}
+static __global__ void k_extract_nee_cos(PathState P, PathState Ps, unsigned int n) {
+    for (unsigned int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) Ps.nee_cos[j] = P.nee_cos[Ps.orig[j]];
+}
+// out[i] = the optimiser's variable of S-tree node i (DevTree::theta_frozen)
+static __global__ void k_copy_theta(const LeafHdr *hdr, unsigned int n, float *out) {
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = hdr[i].theta;
+}
+// keep[i] = Li of path i of the batch (its film kernel runs after the stragglers have ended, when the batch's own state is gone)
+static __global__ void k_copy_li(PathState P, float4 *keep) {
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < P.n_paths; i += gridDim.x * blockDim.x) keep[i] = P.li[i];
+}
+// ... and the stragglers' own, once they have ended
+static __global__ void k_scatter_li(PathState Ps, unsigned int n, float4 *keep) {
+    for (unsigned int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) keep[Ps.orig[j]] = Ps.li[j];
+}
+// base[perm[r]] = first + r * stride: the record positions of the stragglers' vertices in the round that applies them, in the order of
+// their paths (perm = the stragglers sorted by their path's index in its batch)
+static __global__ void k_ranked_base(unsigned int *base, const unsigned int *perm, unsigned int n, unsigned int first, unsigned int stride) {
+    for (unsigned int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) base[perm[r]] = first + r * stride;
 }
 static __global__ void k_record_keys(const AdamRec *recs, unsigned long long *keys, unsigned int n) {
     unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -27,6 +27,8 @@ struct TailLaunch {
     BlockStats *stats;
     int lds_tris;
     unsigned int *longest;   // the longest path (bounces) this launch finishes: what its duration is made of
+    StragOut strag;          // R.defer_depth > 0: where the paths still alive at that depth go
+    unsigned int lane_limit; // paths a wave takes at a time (64; fewer for a launch over a handful of stragglers)
 };
 struct CommitLaunch {
     int grid;

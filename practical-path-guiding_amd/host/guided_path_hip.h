@@ -155,8 +155,19 @@ public:
         m_w = scene.camera.width; m_h = scene.camera.height;
         {
             const int rc = ppg_begin_render(m_ctx);
-            if (rc == PPG_ERR_CANCELLED) return false;  // GP:1584
-            check(rc, "ppg_begin_render");
+            if (reducer) {
+                // Sharded: a cancel() that arrived before this call cancels THIS rank's render here, before any exchange — the peers would wait for
+                // it in their first collective.  So every sharded render starts with one status exchange (the all-reduce of stopDecision with
+                // "no stop" from every rank): a rank that cannot start says so, and all of them leave together.
+                if (rc != PPG_OK) reducer->setLocalStatus(1);
+                const int bad = reducer->stopDecision(0);
+                if (rc == PPG_ERR_CANCELLED) return false;  // GP:1584
+                check(rc, "ppg_begin_render");
+                if (bad) throw std::runtime_error("render aborted: a rank could not start (cancelled or failed before its first exchange)");
+            } else {
+                if (rc == PPG_ERR_CANCELLED) return false;  // GP:1584
+                check(rc, "ppg_begin_render");
+            }
         }
         if (reducer && std::string(m_cfg.bsdfSamplingFractionLoss) != "none") check(ppg_set_pass_hook(m_ctx, &GuidedPathTracerHIP::roundHook, this), "ppg_set_pass_hook");
         // a time budget, sharded: every decision taken by a clock (GP:1259-1262, 1434-1514) is rank 0's, so that all ranks render the same passes
@@ -320,7 +331,8 @@ private:
 
     static int stopHook(void *self, int localStop) {
         GuidedPathTracerHIP *g = static_cast<GuidedPathTracerHIP *>(self);
-        if (g->m_cancelled.load()) g->m_reducer->setLocalStatus(1);
+        // (PPG_STOP_CANCELLED: the library's render was cancelled — also by a ppg_cancel() that did not come through cancel())
+        if (g->m_cancelled.load() || localStop == PPG_STOP_CANCELLED) g->m_reducer->setLocalStatus(1);
         try { return g->m_reducer->stopDecision(localStop); } catch (...) { if (!g->m_hookError) g->m_hookError = std::current_exception(); return 1; }
     }
     static int roundHook(void *self) {  // C callback: no exception may cross the C-ABI

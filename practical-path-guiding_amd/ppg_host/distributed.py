@@ -50,10 +50,24 @@ class _Status:
         if total != 0:
             raise RenderAborted("render aborted: a rank reported a failure or a cancellation")
 
+    # ---- the collectives themselves: torch.distributed on the tensors as they are (RCCL on device tensors, gloo on host tensors);
+    # `StagedReducer` overrides these four to carry DEVICE tensors through host memory over gloo --------------------------------------
+    def _all_reduce(self, t):
+        self.dist.all_reduce(t)
+
+    def _all_gather_into(self, out, inp):
+        self.dist.all_gather_into_tensor(out, inp)
+
+    def _all_to_all(self, out, inp, recv_splits, send_splits):
+        self.dist.all_to_all_single(out, inp, recv_splits, send_splits)
+
+    def _broadcast(self, t):
+        self.dist.broadcast(t, src=0)
+
     def broadcast(self, value):
         """rank 0's `value` (a float) on every rank: the clock readings of a sharded budgetType = seconds render"""
         t = self.torch.tensor([float(value)], dtype=self.torch.float64, **self._tensor_kw())
-        self.dist.broadcast(t, src=0)
+        self._broadcast(t)
         return float(t.item())
 
     def stop_decision(self, local_stop):
@@ -61,7 +75,7 @@ class _Status:
         set — ONE all-reduce of (decision, status).  A cancelled rank meets the others here; they all leave the batch loop for the image
         exchange, where the status aborts the render."""
         t = self.torch.tensor([int(bool(local_stop)) if self.dist.get_rank() == 0 else 0, int(self.status)], dtype=self.torch.int64, **self._tensor_kw())
-        self.dist.all_reduce(t)
+        self._all_reduce(t)
         stop, bad = (int(v) for v in t.tolist())
         return 1 if (stop or bad) else 0
 
@@ -119,12 +133,12 @@ class TorchReducer(_Status):
         st = torch.tensor([self.status], dtype=dtype, **self._tensor_kw())
         if len(views) <= 1:
             for v in views:
-                self.dist.all_reduce(v)
-            self.dist.all_reduce(st)
+                self._all_reduce(v)
+            self._all_reduce(st)
             bad = st
         else:
             flat = torch.cat(views + [st])
-            self.dist.all_reduce(flat)
+            self._all_reduce(flat)
             off = 0
             for v in views:
                 v.copy_(flat[off:off + v.numel()])
@@ -178,21 +192,21 @@ class TorchReducer(_Status):
                 send = [0] * world
             row = torch.tensor(send + [int(self.status)], dtype=torch.int64, **self._tensor_kw())
             rows = torch.empty(world * (world + 1), dtype=torch.int64, **self._tensor_kw())
-            dist.all_gather_into_tensor(rows, row)
+            self._all_gather_into(rows, row)
             table = rows.view(world, world + 1).tolist()             # (the host sizes the messages by the counts: the one synchronisation)
             self._abort_if(sum(r[world] for r in table))
             recv = [int(table[r][rank]) for r in range(world)]
             n_send, n_recv = sum(send), sum(recv)
             src = self._view(ptr, 4 * n_send, "<i8") if n_send else torch.empty(0, dtype=torch.int64, **self._tensor_kw())
             self._adam_recv = torch.empty(4 * max(n_recv, 1), dtype=torch.int64, **self._tensor_kw())
-            dist.all_to_all_single(self._adam_recv[:4 * n_recv], src.contiguous(), [4 * c for c in recv], [4 * c for c in send])
+            self._all_to_all(self._adam_recv[:4 * n_recv], src.contiguous(), [4 * c for c in recv], [4 * c for c in send])
             self._sync()
             e.adam_records_replace(self._adam_recv.data_ptr() if n_recv else 0, n_recv)
         else:
             ptr, seg = e.adam_state(world)
             state = self._view(ptr, 3 * seg * world, "<i8")      # 24 bytes per node = three int64
             mine = state[3 * seg * rank:3 * seg * (rank + 1)].clone()
-            dist.all_gather_into_tensor(state, mine)
+            self._all_gather_into(state, mine)
             self._sync()
             e.adam_state_commit()
 
@@ -204,7 +218,7 @@ class TorchReducer(_Status):
         counts = torch.zeros(world + 1, dtype=torch.int64, **self._tensor_kw())
         counts[dist.get_rank()] = n
         counts[world] = int(self.status)
-        dist.all_reduce(counts)
+        self._all_reduce(counts)
         counts = [int(c) for c in counts.tolist()]
         self._abort_if(counts.pop())
         most = max(counts)
@@ -213,8 +227,9 @@ class TorchReducer(_Status):
         mine = torch.zeros(4 * most, dtype=torch.int64, **self._tensor_kw())
         if n:
             mine[:4 * n] = self._view(ptr, 4 * n, "<i8")
-        parts = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(parts, mine)
+        gathered = torch.empty(world * mine.numel(), dtype=mine.dtype, **self._tensor_kw())
+        self._all_gather_into(gathered, mine)
+        parts = gathered.view(world, -1)
         self._union = torch.cat([p[:4 * c] for p, c in zip(parts, counts)]).contiguous()
         self._sync()
         e.adam_records_replace(self._union.data_ptr(), sum(counts))
@@ -223,6 +238,34 @@ class TorchReducer(_Status):
         if inverse_variance:
             return  # the retained iteration images were already reduced by reduce_images
         self._exchange(self._film_views(e))
+
+
+class StagedReducer(TorchReducer):
+    """The HIP engine under the reducer WITHOUT RCCL: the arrays stay in device memory (the accessors of TorchReducer), every collective is
+    carried through host memory over a gloo process group — copy out, exchange, copy back.  Two ranks can then share ONE GPU
+    (tests/test_two_ranks_one_gpu.py): the stream ordering between the library's kernels and the exchanges — the round hook on the context's
+    stream, the splats beside it, the stragglers' side stream — is exercised by real, concurrent processes, which neither the in-process
+    two-context tests nor the oracle-over-gloo tests can.  Not a production path: RCCL over xGMI is (TorchReducer with backend nccl)."""
+
+    def _all_reduce(self, t):
+        h = t.cpu()  # (synchronises with the device work that produced t)
+        self.dist.all_reduce(h)
+        t.copy_(h)
+
+    def _all_gather_into(self, out, inp):
+        ho = self.torch.empty(out.shape, dtype=out.dtype)
+        self.dist.all_gather_into_tensor(ho, inp.cpu())
+        out.copy_(ho)
+
+    def _all_to_all(self, out, inp, recv_splits, send_splits):
+        ho = self.torch.empty(out.shape, dtype=out.dtype)
+        self.dist.all_to_all_single(ho, inp.cpu(), recv_splits, send_splits)
+        out.copy_(ho)
+
+    def _broadcast(self, t):
+        h = t.cpu()
+        self.dist.broadcast(h, src=0)
+        t.copy_(h)
 
 
 class HostReducer(TorchReducer):

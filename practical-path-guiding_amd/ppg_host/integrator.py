@@ -75,20 +75,34 @@ class GuidedPathTracer:
         e, p = self.engine, self.props
         if scene is not None:
             e.set_scene(scene)
-        e.begin_render()
+        # (cancel() is sticky in the library: one that arrived before this call cancels this render in begin_render below; the flag the hooks
+        # read is cleared BEFORE that, so that a cancel() arriving any time after this line is seen by them)
+        self._cancelled = False
+        if self.reducer is not None:
+            self.reducer.begin_render()
+        try:
+            e.begin_render()
+        except Exception:
+            if self.reducer is None:
+                raise
+            # Sharded: this rank cannot start (a cancel that arrived before the call, an error) — the peers would wait for it in their first
+            # collective.  Every sharded render therefore starts with ONE status exchange; all ranks leave together.
+            self.reducer.status = 1
+            self.reducer.stop_decision(0)
+            raise
+        if self.reducer is not None and self.reducer.stop_decision(0):
+            from .distributed import RenderAborted
+            raise RenderAborted("render aborted: a rank could not start (cancelled or failed before its first exchange)")
         # Sharded with a time budget: every control decision of renderTime() (guided_path.cpp:1434-1514) and the per-pass abort inside
         # performRenderPasses (GP:1259-1262) reads a clock — rank 0's, broadcast, so that all ranks render the same passes and iterations
         clock = (lambda v: self.reducer.broadcast(v)) if self.reducer is not None else (lambda v: v)
         def stop_hook(local):  # rank 0's decision for all — or "stop" when any rank's status word is set (a cancelled rank meets the others here)
-            if self._cancelled:
+            if self._cancelled or local == 2:  # (2 = PPG_STOP_CANCELLED: the library's render was cancelled, by whatever route)
                 self.reducer.status = 1
             return self.reducer.stop_decision(local)
         # (hooks of an earlier render() of this engine with another reducer / budget must not survive it)
         e.set_stop_hook(stop_hook if (self.reducer is not None and p["budgetType"] != "spp") else None)
         e.set_pass_hook(None)
-        self._cancelled = False
-        if self.reducer is not None:
-            self.reducer.begin_render()
         if self.reducer is not None and p["bsdfSamplingFractionLoss"] != "none":
             def round_hook():  # per round: records to the owners of their D-trees, the owners' state back to all
                 if self._cancelled:  # (the library keeps a cancelled rank in step with the others' round hooks, with empty rounds)

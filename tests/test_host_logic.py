@@ -1,6 +1,7 @@
 """Host logic on CPU: the Python mirror of render() equals the single-call render(), oracle determinism
 across thread counts (fixed-point accumulation), sharded rendering over gloo equals single-rank rendering,
 .sdt dump format, and the committed golden vectors still match the oracle."""
+import ctypes
 import os
 import struct
 import subprocess
@@ -117,7 +118,12 @@ if sys.argv[4] in ("nee", "full-scene"):
     props.update(nee="kickstart", bsdfSamplingFractionLoss="var", spatialFilter="box", sTreeThreshold=2000)
 if sys.argv[4] == "auto-final":
     props.update(budget=2044, seed=2, sampleCombination="automatic")
+if sys.argv[4] == "stragglers":
+    props.update(sampleCombination="inversevar", bsdfSamplingFractionLoss="kl", spatialFilter="stochastic", directionalFilter="box", sTreeThreshold=2000, sppPerPass=1,
+                 maxDepth=-1, rrDepth=3, budget=63)
 e = ppg_host.Engine(lib, "ppgo_", **props)
+if sys.argv[4] == "stragglers":
+    e._call("debug_set_defer_depth", ctypes.c_int32(6))
 lib.ppgo_set_modes(e.ctx, 0, 0, 2)
 scene = ppg_host.cbox_scene(24, 16) if sys.argv[4] == "auto-final" else ppg_host.cbox_scene(64, 48)
 if sys.argv[4] == "full-scene":
@@ -138,14 +144,17 @@ dist.barrier(); dist.destroy_process_group()
 
 @pytest.mark.parametrize("mode,world,scheme", [("default", 2, "owner"), ("inversevar", 2, "owner"), ("improved", 2, "owner"), ("nee", 2, "owner"),
                                                ("full-scene", 2, "owner"), ("improved", 4, "owner"), ("nee", 4, "owner"), ("improved", 2, "gather"),
-                                               ("auto-final", 2, "owner"), ("auto-final", 4, "owner")])
+                                               ("auto-final", 2, "owner"), ("auto-final", 4, "owner"), ("stragglers", 2, "owner"), ("stragglers", 3, "owner"),
+                                               ("stragglers", 2, "gather")])
 def test_sharded_render_over_gloo_equals_single_rank(oracle_lib, tmp_path, mode, world, scheme):
     """world_size 2 and 4, gloo: tiles sharded, SD-tree statistics all-reduced as int64, the optimiser's records sent to the OWNER of
     their D-tree (all-to-all) and the owners' optimiser state all-gathered ("owner"; "gather": round 2's gather-everything scheme) →
     the merged render, the SD-tree and the learned fractions are bit-identical to the unsharded ones on every rank.
     The FINAL iteration is sharded by whole groups of passes, not by tiles (include/ppg.h "Final iteration: groups of passes"): "improved" has
     three groups (16 + 16 + 13 passes), "auto-final" sixteen — after the tile-sharded training passes of the same iteration, whose film the
-    groups are added to (sampleCombination = automatic switching to FINAL in the middle of iteration 7, GP:1400-1411)."""
+    groups are added to (sampleCombination = automatic switching to FINAL in the middle of iteration 7, GP:1400-1411).
+    "stragglers": unbounded paths, and the tests' switch lowers the depth of include/ppg.h "STRAGGLERS" to 6 — a quarter of the paths' records
+    are applied one round late, those of an iteration's last round in a round of their own for which every rank's hook is called."""
     import ppg_host
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
@@ -169,8 +178,17 @@ def test_sharded_render_over_gloo_equals_single_rank(oracle_lib, tmp_path, mode,
     if mode == "full-scene":  # analytic spheres (glass, rough gold, lamp) under an emitting sky dome: the S-tree spans the dome
         from test_gpu_parity import _sphere_scene
         scene = _sphere_scene((64, 48), sky=True)
+    if mode == "stragglers":
+        props.update(sampleCombination="inversevar", bsdfSamplingFractionLoss="kl", spatialFilter="stochastic", directionalFilter="box", sTreeThreshold=2000,
+                     sppPerPass=1, maxDepth=-1, rrDepth=3, budget=63)
     e = make_oracle(oracle_lib, threads=4, **props)
+    if mode == "stragglers":
+        e._call("debug_set_defer_depth", ctypes.c_int32(6))
     e.set_scene(scene); e.render()
+    if mode == "stragglers":
+        hist = (ctypes.c_uint64 * 4096)()
+        oracle_lib.ppgo_path_length_histogram(e.ctx, hist)
+        assert sum(hist[7:]) > 10000  # (the test needs stragglers)
     ref_img, ref_t = e.read_film(), e.read_sdtree()
     for r in range(world):
         got = np.load(tmp_path / ("rank%d.npz" % r))
@@ -232,6 +250,59 @@ def test_cancelled_rank_takes_the_others_out_with_a_learned_fraction(oracle_lib,
     subprocess.run(cmd, check=True, env=env, timeout=300, capture_output=True)
     outcomes = [(tmp_path / ("cancel-rank%d.txt" % r)).read_text() for r in range(world)]
     assert all(o.startswith(("ppg-error", "aborted")) and o.endswith("[0, 1, 2]") for o in outcomes), outcomes  # nobody finished, nobody got further
+    again = {(tmp_path / ("again-rank%d.txt" % r)).read_text() for r in range(world)}
+    assert len(again) == 1 and float(again.pop()) > 0.01
+
+
+EARLY_CANCEL_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import ctypes, torch.distributed as dist
+import ppg_host
+from ppg_host.distributed import HostReducer, RenderAborted
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+lib = ctypes.CDLL(sys.argv[2])
+props = dict(budgetType=sys.argv[5], maxDepth=6, rrDepth=10, strictNormals=1, budget=(60 if sys.argv[5] == "spp" else 600.0), seed=17, sppPerPass=1,
+             bsdfSamplingFractionLoss=sys.argv[6], sampleCombination="inversevar")
+e = ppg_host.Engine(lib, "ppgo_", **props)
+lib.ppgo_set_modes(e.ctx, 0, 0, 2)
+e.set_scene(ppg_host.cbox_scene(48, 32)); e.set_shard(rank, world, 16)
+gpt = ppg_host.GuidedPathTracer(engine=e, reducer=HostReducer(dist))
+who = int(sys.argv[4])
+if rank == who:
+    gpt.cancel()  # BEFORE render(): the library's cancel is sticky and ppg_begin_render consumes it — this rank never reaches an exchange of the render itself
+try:
+    gpt.render()
+    outcome = "finished"
+except ppg_host.PPGError as ex:
+    outcome = "ppg-error %d" % ex.code
+except RenderAborted:
+    outcome = "aborted"
+open(os.path.join(sys.argv[3], "early-rank%d.txt" % rank), "w").write("%s %d" % (outcome, len(gpt.iterations)))
+img = gpt.render() if sys.argv[5] == "spp" else None  # the reducer and the engine are usable again
+open(os.path.join(sys.argv[3], "again-rank%d.txt" % rank), "w").write("%.6f" % (float(img.mean()) if img is not None else 1.0))
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("world,who,budget,loss", [(2, 1, "spp", "kl"), (2, 0, "spp", "none"), (3, 2, "seconds", "none")])
+def test_rank_cancelled_before_render_takes_the_others_out(oracle_lib, tmp_path, world, who, budget, loss):
+    """ADVICE r5: ppg_cancel is sticky, so a cancel() that arrives before render() makes ppg_begin_render return PPG_ERR_CANCELLED — and that
+    rank used to leave render() without having joined any exchange, its peers waiting for it in their first collective until the timeout.
+    Every sharded render now begins with one status exchange (the all-reduce of stop_decision): the rank that cannot start says so there and
+    all ranks leave together — before a single pass is rendered, whatever the budget type or the loss (the peers' first exchange would have
+    been the image all-reduce, the stop hook or a round hook)."""
+    script = tmp_path / "early_cancel_worker.py"
+    script.write_text(EARLY_CANCEL_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(33500 + os.getpid() % 2000), OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
+           "--master-port", env["MASTER_PORT"], str(script), os.path.join(ROOT, "practical-path-guiding_amd"),
+           os.path.join(ROOT, "oracle", "libppg_oracle.so"), str(tmp_path), str(who), budget, loss]
+    subprocess.run(cmd, check=True, env=env, timeout=120, capture_output=True)
+    outcomes = [(tmp_path / ("early-rank%d.txt" % r)).read_text() for r in range(world)]
+    assert outcomes[who].startswith("ppg-error") and outcomes[who].endswith(" 0"), outcomes
+    assert all(o == "aborted 0" for r, o in enumerate(outcomes) if r != who), outcomes
     again = {(tmp_path / ("again-rank%d.txt" % r)).read_text() for r in range(world)}
     assert len(again) == 1 and float(again.pop()) > 0.01
 
