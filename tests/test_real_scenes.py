@@ -178,3 +178,41 @@ def test_tree_statistics_follow_the_reference_logs(which):
             assert abs(t[k]["avg_depth"] - ref[k]["depth"][1]) < 0.2 and abs(t[k]["avg_nodes"] - ref[k]["node_count"][1]) < 2, (k, t[k])
         for k in (3, 4, 5):
             assert rel(var[k], ref[k]["var"][0]) < 0.3, (k, var)
+
+
+def test_kitchen_default_configuration_picture_matches_the_reference():
+    """KITCHEN with the DEFAULT settings of scenes/kitchen/kitchen.xml (strictNormals, spp budget 2400; everything else the plug-in's
+    defaults: 4 spp per pass, nearest filters, no learned fraction, sampleCombination = automatic, maxDepth = -1), pinned by its PICTURE — until
+    round 6 this configuration on the real scene was pinned by tree statistics only (test_tree_statistics_follow_the_reference_logs; its log's
+    variance column is not comparable).  At the reference's 700 x 400, per seed (tools/kitchen_default_probe.py, three seeds
+    on the MI355X: profiles/r06_kitchen_default_picture.json):
+      * the error against the reference's converged kitchen-reference.exr over the pixels outside the six missing meshes' footprint is the
+        error of the reference's OWN render of this configuration, kitchen.exr: MAPE 0.0934, RMSE 0.115 (tests/golden/ref_kitchen_reference.npz)
+        — within 8 %;
+      * the 50 x 50-pixel block means agree with kitchen.exr's, block by block, wherever no missing mesh shows."""
+    import ppg_host
+    from test_gpu_parity import hip
+    if not os.path.exists(KITCHEN):
+        pytest.skip("scene file not present")
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "ref_kitchen_reference.npz"))
+    ref = fx["rgb"].astype(np.float64)
+    blk = int(fx["mask_block"])
+    keep = ~np.kron(fx["mask_blocks"], np.ones((blk, blk), np.uint8)).astype(bool)
+    keep50 = keep.reshape(8, 50, 14, 50).all((1, 3))
+    assert keep50.sum() >= 60
+    scene = _load(KITCHEN, 700, 400)
+    for seed in (1234, 98765):
+        e = hip(budgetType="spp", strictNormals=1, budget=2400.0, seed=seed)  # kitchen.xml:4-18
+        gpt = ppg_host.GuidedPathTracer(engine=e)
+        img = gpt.render(scene).astype(np.float64)
+        assert sum(it["passes"] + it.get("final_passes", 0) for it in gpt.iterations) == 600
+        d = (img - ref)[keep]
+        mape, rmse = float((np.abs(d) / (ref[keep] + 0.01)).mean()), float(np.sqrt((d * d).mean()))
+        # measured, three seeds: MAPE 0.0940 / 0.0992 / 0.0972 against the reference's own 0.0934; RMSE (a few fireflies' worth either way) 0.120 /
+        # 0.152 / 0.146 against 0.115; block means of the 71 blocks clear of the missing meshes within 0.9 - 1.3 % of kitchen.exr's on average,
+        # 7.8 - 12.8 % in the worst block (two renders of 2400 spp each, the default configuration's fireflies in either)
+        assert abs(mape / float(fx["kitchen_mape_unmasked"]) - 1) < 0.08, (seed, mape, float(fx["kitchen_mape_unmasked"]))
+        assert rmse < 1.5 * float(fx["kitchen_rmse_unmasked"]), (seed, rmse)
+        b50 = img.reshape(8, 50, 14, 50, 3).mean((1, 3)).mean(-1)
+        rel = np.abs(b50 / fx["kitchen_blocks50"].astype(np.float64).mean(-1) - 1)
+        assert rel[keep50].mean() < 0.02 and rel[keep50].max() < 0.2, (seed, float(rel[keep50].mean()), float(rel[keep50].max()))

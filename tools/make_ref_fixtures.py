@@ -119,6 +119,10 @@ def main():
             d = (rgb[n] - ref)[keep]
             err[n.replace("-", "_") + "_rmse_unmasked"] = np.float64(np.sqrt((d * d).mean()))
             err[n.replace("-", "_") + "_mape_unmasked"] = np.float64((np.abs(d) / (ref[keep] + 0.01)).mean())
+    # 50x50-pixel block means of the reference's two guided renders (8 x 14 blocks): what the GPU tests compare this build's pictures of the
+    # same configurations with, block by block (tests/test_real_scenes.py)
+    for n in ("kitchen", "kitchen-improved"):
+        err[n.replace("-", "_") + "_blocks50"] = rgb[n].reshape(8, 50, 14, 50, 3).mean((1, 3)).astype(np.float32)
     np.savez_compressed(os.path.join(OUT, "ref_kitchen_reference.npz"), rgb=ref.astype(np.float16), mean_rgb=ref.mean((0, 1)), **err)
     print("kitchen-reference", ref.shape, ref.mean((0, 1)), float(ref.max()), {k: v for k, v in err.items() if np.ndim(v) == 0})
     for k, v in logs.items():
