@@ -111,7 +111,7 @@ def algorithmic_bytes(work=None, rays=None, bvh=None, tag=None):
 def measured_traffic(tag):
     """HBM bytes per unit from profiles/<tag>_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, calibrated as
     MI355X_MICROARCH.md prescribes; written by tools/collect_profiles.py on the GPU box) — a STORED calibration, not measured in this run."""
-    for name in ("r05_pmc_traffic_%s.json" % tag, "r04_pmc_traffic_%s.json" % tag, "r03_pmc_traffic_%s.json" % tag, "r02_pmc_traffic_%s.json" % tag, "r01_pmc_traffic.json" if tag == "cbox" else ""):
+    for name in ("r06_pmc_traffic_%s.json" % tag, "r05_pmc_traffic_%s.json" % tag, "r04_pmc_traffic_%s.json" % tag, "r03_pmc_traffic_%s.json" % tag, "r02_pmc_traffic_%s.json" % tag, "r01_pmc_traffic.json" if tag == "cbox" else ""):
         p = os.path.join(ROOT, "profiles", name)
         if name and os.path.exists(p):
             try:

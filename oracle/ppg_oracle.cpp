@@ -579,7 +579,7 @@ public:
     Float bsdfSamplingFraction() const { return bsdfSamplingFraction(bsdfSamplingFractionOptimizer.variable()); }
 
     void optimizeBsdfSamplingFraction(const DTreeRecord &rec, Float ratioPower, const Modes &modes) {  // GP:672-697
-        if (modes.adam == PPGO_ADAM_ROUND || modes.adam == PPGO_ADAM_HALF) {  // deferred to the end of the round, applied in canonical order by applyAdamRound()
+        if (modes.adam != PPGO_ADAM_SEQUENTIAL) {  // deferred to the end of the round, applied in canonical order by applyAdamRound()
             modes.sink->push_back(AdamRecord{this, modes.path, modes.code, rec.product, rec.woPdf, rec.bsdfPdf, rec.dTreePdf, rec.statisticalWeight});
             return;
         }
@@ -2590,11 +2590,14 @@ public:
         // ROUND mode: the passes are rendered in rounds of ppg_adam_round_passes() passes; the sampling fractions are frozen during
         // a round and its records are applied afterwards (applyAdamRound).  The time budget is checked once per round then
         // (the reference checks after every finished pass of a batch of up to 128 scheduled ones, GP:1235-1266).
-        const bool rounds = m_bsdfSamplingFractionLoss != ENone && (modes.adam == PPGO_ADAM_ROUND || modes.adam == PPGO_ADAM_HALF) && m_isBuilt && !m_isFinalIter;
+        const bool rounds = m_bsdfSamplingFractionLoss != ENone && modes.adam != PPGO_ADAM_SEQUENTIAL && m_isBuilt && !m_isFinalIter;
         // PPGO_ADAM_HALF (measurement only): in iteration 1 — two one-pass rounds — the optimiser is also applied after each HALF
         // pass (pixels by parity of x + y), i.e. four rounds instead of two
         const bool halves = rounds && modes.adam == PPGO_ADAM_HALF && numPasses == 2;
-        const int roundPasses = rounds ? adamRoundPasses(numPasses) : 1;
+        // PPGO_ADAM_REGIONS + R (measurement only): iterations of up to 16 passes render every pass in R groups of blocks in spiral order, the
+        // optimiser applied after each
+        const int regions = (rounds && modes.adam > PPGO_ADAM_REGIONS && numPasses <= 16) ? modes.adam - PPGO_ADAM_REGIONS : 0;
+        const int roundPasses = regions ? 1 : (rounds ? adamRoundPasses(numPasses) : 1);
         // include/ppg.h "STRAGGLERS": the rounds of a render of unbounded paths whose record positions are known in advance
         m_deferRound = rounds && m_maxDepth < 0 && m_spatialFilter != ESBox && !(m_doNee && m_nee == EKickstart);
         m_deferredRecords.clear();  // (nothing is carried from one call to the next)
@@ -2615,7 +2618,11 @@ public:
             for (int k = 0; k < n; ++k) {
                 if (drain) continue;
                 if (halves) { m_parity = 0; renderOnePass(); applyAdamRound(); m_parity = 1; renderOnePass(); m_parity = -1; }
-                else
+                else if (regions) {
+                    m_regions = regions;
+                    for (m_region = 0; m_region < regions; ++m_region) { renderOnePass(); if (m_region + 1 < regions) applyAdamRound(); }
+                    m_regions = 0; m_region = -1;
+                } else
                 renderOnePass();
                 ++m_passesRendered; ++m_passesRenderedThisIter; ++m_passesLocal;
                 m_samplesLocal += ownedPixels() * (uint64_t)m_sppPerPass;
@@ -2722,6 +2729,27 @@ public:
     }
     bool m_hookFailed = false;
     int m_parity = -1;
+    int m_region = -1, m_regions = 0;
+    std::vector<int> m_spiralRank;  // [block] position of the block in the reference scheduler's spiral (center outwards)
+    void buildSpiral(int bx, int by) {
+        m_spiralRank.assign((size_t)bx * by, -1);
+        // BlockedImageProcess: start at the central block, walk right, down, left, up with growing run lengths (imageproc.cpp:29-80)
+        int x = bx / 2, y = by / 2, rank = 0, run = 1, dir = 0;
+        const int dx[4] = {1, 0, -1, 0}, dy[4] = {0, 1, 0, -1};
+        const int total = bx * by;
+        while (rank < total) {
+            for (int rep = 0; rep < 2 && rank < total; ++rep) {
+                for (int k = 0; k < run && rank < total; ++k) {
+                    if (x >= 0 && x < bx && y >= 0 && y < by && m_spiralRank[(size_t)y * bx + x] < 0) m_spiralRank[(size_t)y * bx + x] = rank++;
+                    x += dx[dir]; y += dy[dir];
+                }
+                dir = (dir + 1) & 3;
+            }
+            ++run;
+            if (run > 4 * (bx + by)) break;
+        }
+        for (auto &r : m_spiralRank) if (r < 0) r = rank++;
+    }
     int hookPhase = 0;
     bool ownerMode = false;
     std::vector<uint32_t> m_adamState;  // [world * segment][6]
@@ -2776,10 +2804,12 @@ public:
         const uint32_t sampleInRound0 = (uint32_t)(m_passesRendered - m_roundStartPass) * (uint32_t)m_sppPerPass;
         if (m_blockSinks.size() != (size_t)bx * by) m_blockSinks.assign((size_t)bx * by, std::vector<AdamRecord>());
         uint64_t rays = 0, plen = 0, comm = 0;
+        if (m_regions > 0 && m_spiralRank.size() != (size_t)bx * by) buildSpiral(bx, by);
 #ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads) reduction(+ : rays, plen, comm)
 #endif
         for (int b = 0; b < bx * by; ++b) {
+            if (m_regions > 0 && (int)((long long)m_spiralRank[b] * m_regions / (bx * by)) != m_region) continue;
             PathCounters pc;
             Modes tm = modes;
             tm.sink = &m_blockSinks[b];

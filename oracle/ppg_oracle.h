@@ -19,7 +19,11 @@ typedef struct ppgo_ctx ppgo_ctx;
 enum { PPGO_ACC_FIXED = 0, PPGO_ACC_FLOAT = 1 };
 /* ROUND: the product's rule (include/ppg.h "Learning the BSDF sampling fraction": records applied at the end of every round in
    key order).  SEQUENTIAL: GP:672-697 literally — every record is applied the moment its path commits it (single thread). */
-enum { PPGO_ADAM_ROUND = 0, PPGO_ADAM_SEQUENTIAL = 1, PPGO_ADAM_HALF = 2 /* measurement only: half-pass rounds in iteration 1 */ };
+enum { PPGO_ADAM_ROUND = 0, PPGO_ADAM_SEQUENTIAL = 1, PPGO_ADAM_HALF = 2 /* measurement only: half-pass rounds in iteration 1 */,
+       /* measurement only (round 6): PPGO_ADAM_REGIONS + R — in the iterations of up to 16 passes every pass is rendered in R
+          groups of image blocks, consecutive in the spiral order in which the reference's scheduler hands blocks out (imageproc.cpp:29-80), and
+          the optimiser is applied after every group: the variable then follows the image REGION being rendered, as the reference's does */
+       PPGO_ADAM_REGIONS = 16 };
 
 int ppgo_create(const ppg_config *cfg, ppgo_ctx **out);
 void ppgo_destroy(ppgo_ctx *ctx);

@@ -1536,8 +1536,10 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound, const GroupLaunch *gl =
         timedLaunch(ctx, "k_tail", hostCount, [&] {
             RenderParams Rt = R;
             Rt.defer_depth = depth;
+            // (the launch's longest path is logged for launches that run their paths to the END: the sum is the tails' critical path; a launch that
+            // hands its stragglers over writes to a spare slot nobody reads)
             TailLaunch a{tailGrid, ldsBytes, s, P, S, T, Rt, dense, ctx->d_total.p, ctx->d_ticket.p, Q.stats, ctx->ldsTris,
-                         ctx->d_tailLongest.p + (ctx->tailLaunches++ % PPG_TAIL_LOG), StragOut{G.rec.p, G.orig.p, G.count.p}, 64u};
+                         ctx->d_tailLongest.p + (depth ? PPG_TAIL_LOG : (ctx->tailLaunches++ % PPG_TAIL_LOG)), StragOut{G.rec.p, G.orig.p, G.count.p}, 64u};
             ppg_launch_tail((smallScene ? 4 : 0) | (neeOn ? 2 : 0) | (fullMats ? 1 : 0), a);
         });
         return PPG_OK;
@@ -1798,8 +1800,8 @@ int renderPassesNoStat(ppg_ctx *ctx, int numPasses) {  // GP:1217-1286
     HIP_CHECK(hipMemsetAsync(ctx->d_sq.p, 0, 3 * n * 4, ctx->stream));
     HIP_CHECK(hipMemsetAsync(ctx->d_imageW.p, 0, n * 4, ctx->stream));
     HIP_CHECK(hipMemsetAsync(ctx->d_stats.p, 0, sizeof(BlockStats) * (size_t)ctx->nBlocks, ctx->stream));
-    HIP_CHECK(ctx->d_tailLongest.reserve(PPG_TAIL_LOG));
-    HIP_CHECK(hipMemsetAsync(ctx->d_tailLongest.p, 0, PPG_TAIL_LOG * 4, ctx->stream));
+    HIP_CHECK(ctx->d_tailLongest.reserve(PPG_TAIL_LOG + 1));
+    HIP_CHECK(hipMemsetAsync(ctx->d_tailLongest.p, 0, (PPG_TAIL_LOG + 1) * 4, ctx->stream));
     ctx->tailLaunches = 0;
     ctx->passStart = std::chrono::steady_clock::now();
     ctx->passesLocal = 0;

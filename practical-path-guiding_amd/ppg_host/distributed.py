@@ -46,6 +46,22 @@ class _Status:
     def begin_render(self):
         self.status = 0
 
+    def _small(self, values, dtype):
+        """A few numbers for a collective, where the collective wants them (device memory for RCCL): through a cached pinned staging buffer —
+        torch.tensor(list, device=cuda) is a pageable, synchronous copy of ~0.3 ms, paid two or three times per round of the optimiser."""
+        t = self.torch.tensor(values, dtype=dtype)
+        kw = self._tensor_kw()
+        if not kw:
+            return t
+        cache = self.__dict__.setdefault("_smalls", {})
+        key = (dtype, len(values))
+        if key not in cache:
+            cache[key] = (self.torch.empty(len(values), dtype=dtype).pin_memory(), self.torch.empty(len(values), dtype=dtype, **kw))
+        pin, dev = cache[key]
+        pin.copy_(t)
+        dev.copy_(pin, non_blocking=True)
+        return dev
+
     def _abort_if(self, total):
         if total != 0:
             raise RenderAborted("render aborted: a rank reported a failure or a cancellation")
@@ -66,7 +82,7 @@ class _Status:
 
     def broadcast(self, value):
         """rank 0's `value` (a float) on every rank: the clock readings of a sharded budgetType = seconds render"""
-        t = self.torch.tensor([float(value)], dtype=self.torch.float64, **self._tensor_kw())
+        t = self._small([float(value)], self.torch.float64)
         self._broadcast(t)
         return float(t.item())
 
@@ -74,7 +90,7 @@ class _Status:
         """The stop decision of a time budget (include/ppg.h ppg_set_stop_hook): rank 0's, or "stop" as soon as any rank's status word is
         set — ONE all-reduce of (decision, status).  A cancelled rank meets the others here; they all leave the batch loop for the image
         exchange, where the status aborts the render."""
-        t = self.torch.tensor([int(bool(local_stop)) if self.dist.get_rank() == 0 else 0, int(self.status)], dtype=self.torch.int64, **self._tensor_kw())
+        t = self._small([int(bool(local_stop)) if self.dist.get_rank() == 0 else 0, int(self.status)], self.torch.int64)
         self._all_reduce(t)
         stop, bad = (int(v) for v in t.tolist())
         return 1 if (stop or bad) else 0
@@ -130,7 +146,7 @@ class TorchReducer(_Status):
         torch = self.torch
         views = [v for v in views if v.numel()]
         dtype = views[0].dtype if views else torch.int64
-        st = torch.tensor([self.status], dtype=dtype, **self._tensor_kw())
+        st = self._small([self.status], dtype)
         if len(views) <= 1:
             for v in views:
                 self._all_reduce(v)
@@ -190,7 +206,7 @@ class TorchReducer(_Status):
                     self.status = 1
             if self.status:
                 send = [0] * world
-            row = torch.tensor(send + [int(self.status)], dtype=torch.int64, **self._tensor_kw())
+            row = self._small(send + [int(self.status)], torch.int64)
             rows = torch.empty(world * (world + 1), dtype=torch.int64, **self._tensor_kw())
             self._all_gather_into(rows, row)
             table = rows.view(world, world + 1).tolist()             # (the host sizes the messages by the counts: the one synchronisation)
