@@ -1066,6 +1066,39 @@ int allocPaths(ppg_ctx *ctx) {
     return PPG_OK;
 }
 
+// Buffers that otherwise grow with the first large round of the optimiser — the record arrays and the sort's — sized where the path state is
+// sized (scene set-up), from the pass schedule an spp budget implies (renderSPP): a render then finds them in place instead of paying
+// hipMalloc + first touch of a few GB in its second and third iteration (the first 20-pass render after a 5-pass warm-up ran 6 % below the
+// later ones).  An estimate — 7 records per path plus max_vertices positions for every path k_tail may be handed —, not a limit: reserve()
+// still grows what turns out too small.
+int presizeRounds(ppg_ctx *ctx) {
+    if (ctx->loss == LOSS_NONE || ctx->budgetType != 0 || ctx->spatialFilter == SF_BOX) return PPG_OK;
+    const int nPasses = (int)std::ceil((size_t)ctx->budget / (float)ctx->sppPerPass);
+    int rendered = 0, largest = 0;
+    for (int it = 0; rendered < nPasses; ++it) {  // renderSPP, GP:1342-1426
+        const int remaining = nPasses - rendered;
+        int n = std::min(remaining, 1 << std::min(it, 30));
+        if (remaining - n < 2 * n) n = remaining;
+        if (n < remaining && it > 0) largest = std::max(largest, n);  // a training iteration with rounds (the first one has none: not built yet)
+        rendered += n;
+    }
+    if (largest == 0) return PPG_OK;
+    const size_t roundPaths = (size_t)ppg_adam_round_passes(ctx->sppPerPass, ctx->W, ctx->H, largest) * ctx->nPix * ctx->sppPerPass;
+    const size_t handed = ctx->maxDepth < 0 ? std::min(roundPaths, std::max<size_t>(ctx->tailMin, roundPaths / ctx->tailDiv)) : 0;
+    const size_t positions = std::min<size_t>(roundPaths * 7 + handed * (size_t)ctx->maxVertices, 0xfffffff0u);
+    for (int k = 0; k < 2; ++k) { HIP_CHECK(ctx->d_adamKeys[k].reserve(positions)); HIP_CHECK(ctx->d_adamIdx[k].reserve(positions)); }
+    HIP_CHECK(ctx->d_adamRecs.reserve(positions)); HIP_CHECK(ctx->d_splat.reserve(positions));
+    HIP_CHECK(ctx->d_adamNv.reserve(roundPaths)); HIP_CHECK(ctx->d_adamBase.reserve(roundPaths));
+    HIP_CHECK(ctx->d_nv8.reserve(roundPaths)); HIP_CHECK(ctx->d_straggler.reserve(roundPaths));
+    if (handed) for (auto &g : ctx->strag) { HIP_CHECK(g.rec.reserve(handed * 8)); HIP_CHECK(g.orig.reserve(handed)); HIP_CHECK(g.count.reserve(2)); HIP_CHECK(g.ticket.reserve(1)); }
+    {
+        size_t bytes = 0;
+        HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, ctx->d_adamKeys[0].p, ctx->d_adamKeys[1].p, ctx->d_adamIdx[0].p, ctx->d_adamIdx[1].p, positions, 0u, 64u, ctx->stream));
+        HIP_CHECK(ctx->d_sortTemp.reserve(std::max<size_t>(bytes, 16)));
+    }
+    return PPG_OK;
+}
+
 // stable LSD radix sort of the round's (key, record index) pairs on bits [beginBit, endBit); result in d_adamKeys[1] / d_adamIdx[1]
 int sortAdamRecords(ppg_ctx *ctx, size_t n, unsigned int beginBit, unsigned int endBit) {
     hipStream_t s = ctx->stream;
@@ -1284,7 +1317,7 @@ int launchStragglers(ppg_ctx *ctx, const PathState &P, const DevScene &S, const 
         ppg_launch_tail(tailVariant, a);
     };
     if (beside) { launch(); HIP_CHECK(hipEventRecord(ctx->evStragDone, ctx->stream4)); }
-    else timedLaunch(ctx, "k_tail", nStrag, launch);
+    else timedLaunch(ctx, "k_tail(stragglers)", nStrag, launch);  // (its own timer entry: in the product it runs beside the next batch, not on the critical path)
     G.pending = true; G.aside = beside;
     ctx->stragCur ^= 1;
     HIP_CHECK(hipGetLastError());
@@ -2644,6 +2677,7 @@ int ppg_set_scene(ppg_ctx *ctx, const ppg_scene *s) {
         int rc = allocPaths(ctx);
         if (rc) return rc;
         if ((rc = allocFilm(ctx))) return rc;
+        if ((rc = presizeRounds(ctx))) return rc;
         ctx->pathsReady = true;
     }
     return PPG_OK;
@@ -2659,6 +2693,7 @@ int ppg_set_shard(ppg_ctx *ctx, int32_t rank, int32_t world, int32_t tile_size) 
         int rc = allocPaths(ctx);
         if (rc) return rc;
         if ((rc = allocFilm(ctx))) return rc;
+        if ((rc = presizeRounds(ctx))) return rc;
         ctx->pathsReady = true;
     }
     return PPG_OK;
