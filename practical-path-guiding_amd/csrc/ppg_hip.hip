@@ -12,6 +12,7 @@
 #include <cstring>  // rocprim's texture iterator calls memset from host code
 #include <map>
 #include <mutex>
+#include <set>
 
 #include <rocprim/rocprim.hpp>
 
@@ -113,6 +114,27 @@ struct BlockCache {
         for (auto &kv : blocks[dev])
             if (kv.second.ready) { (void)hipEventSynchronize(kv.second.ready); (void)hipEventDestroy(kv.second.ready); kv.second.ready = nullptr; }
     }
+    // Scene set-up: spare blocks for what a render grows as it goes — the SD-tree's pools, the per-iteration images, the straggler sets' small
+    // arrays: dozens of allocations of 2 - 30 MB whose sizes depend on the scene.  Each is a synchronous hipMalloc of 0.1 - 0.2 ms when the cache
+    // is empty, i.e. in the FIRST render of a process (5 % of a 20-pass KITCHEN render); with spares in the cache they are not.  Once per device.
+    void prewarm() {
+        int dev = 0; (void)hipGetDevice(&dev);
+        {
+            std::lock_guard<std::mutex> g(m);
+            if (warmed.count(dev)) return;
+            warmed.insert(dev);
+        }
+        static const struct { size_t mib; int n; } kSpares[] = {{2, 64}, {8, 24}, {32, 8}, {128, 2}};
+        for (const auto &sp : kSpares)
+            for (int k = 0; k < sp.n; ++k) {
+                void *q = nullptr;
+                const size_t bytes = sp.mib << 20;
+                if (hipMalloc(&q, bytes) != hipSuccess) { (void)hipGetLastError(); return; }
+                (void)hipMemsetAsync(q, 0, bytes, g_ctxStream);
+                give(q, bytes);
+            }
+    }
+    std::set<int> warmed;
     // give every cached block of the current device back to the driver (ppg_release_cached_memory; also when hipMalloc fails)
     void trim() {
         int dev = 0; (void)hipGetDevice(&dev);
@@ -1072,6 +1094,7 @@ int allocPaths(ppg_ctx *ctx) {
 // later ones).  An estimate — 7 records per path plus max_vertices positions for every path k_tail may be handed —, not a limit: reserve()
 // still grows what turns out too small.
 int presizeRounds(ppg_ctx *ctx) {
+    g_blockCache.prewarm();
     if (ctx->loss == LOSS_NONE || ctx->budgetType != 0 || ctx->spatialFilter == SF_BOX) return PPG_OK;
     const int nPasses = (int)std::ceil((size_t)ctx->budget / (float)ctx->sppPerPass);
     int rendered = 0, largest = 0;
