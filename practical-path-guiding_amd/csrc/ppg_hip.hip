@@ -1450,7 +1450,8 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound, const GroupLaunch *gl =
     // Tracing inside k_generate / k_shade (no k_trace launch, no ray/hit round trip) was measured SLOWER on MI355X
     // (cbox-720p, 63 passes: 184 ms vs 172 ms for generate+trace+shade): the fused kernel needs 142 VGPRs (3 waves/SIMD)
     // and only the surviving lanes trace.  Kept selectable for re-measurement on other scenes.
-    const bool fused = smallScene && ctx->tuneFuse;
+    // (not in a round whose stragglers' records are deferred: which paths those are is decided where k_tail takes them, include/ppg.h "STRAGGLERS")
+    const bool fused = smallScene && ctx->tuneFuse && !(adamRound && ctx->adamFast && ctx->maxDepth < 0);
     const bool neeOn = ctx->doNee;  // m_doNee of this iteration (doNeeWithSpp, GP:1331-1340)
     const bool fullMats = ctx->fullMaterials;  // any BSDF beyond diffuse / two-sided diffuse / mirror: the FULL kernel variants
     const size_t triBytes = (size_t)ctx->scene.n_tris * 48;

@@ -346,6 +346,34 @@ def test_stragglers_records_one_round_late_against_oracle(oracle_lib, scene_name
     assert not np.array_equal(o64.read_sdtree()["theta"], o.read_sdtree()["theta"])
 
 
+@pytest.mark.parametrize("extra,env", [(dict(nee="always", **IMPROVED), {}), (dict(nee="always"), dict(PPG_SPLIT_DEPTH="3", PPG_BATCH_PATHS="6000"))], ids=["rounds", "scheduling-only"])
+def test_stragglers_under_an_environment_emitter_with_luminaire_sampling(oracle_lib, monkeypatch, extra, env):
+    """The per-path cosine that ConstantBackgroundEmitter::pdfDirect needs (`PathState::nee_cos`, scenes with an environment emitter and
+    luminaire sampling only) must travel with a straggler into its set: an open scene under a constant sky, unbounded paths, nee = always —
+    once with rounds of the optimiser (the tests' switch lowers the depth of the rule to 4) and once without a learned fraction, where the
+    split is scheduling only (PPG_SPLIT_DEPTH = 3, batches of 6000 paths so that every batch but the last hands its stragglers over) and
+    must not show in any result."""
+    import ppg_host
+    scene = _pane_scene((56, 56))
+    keep = np.ones(len(scene.indices), bool)
+    keep[4:8] = False          # drop ceiling and back wall
+    scene.indices, scene.tri_material, scene.tri_emitter = scene.indices[keep], scene.tri_material[keep], scene.tri_emitter[keep]
+    scene.environment = (0.5, 0.7, 1.1)
+    props = dict(budgetType="spp", budget=60 if "sppPerPass" not in extra else 31, maxDepth=-1, rrDepth=3, strictNormals=1, seed=41, **extra)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    g, o = hip(**props), make_oracle(oracle_lib, threads=os.cpu_count() or 8, **props)
+    if not env:
+        g._call("debug_set_defer_depth", C.c_int32(4))
+        o._call("debug_set_defer_depth", C.c_int32(4))
+    gg, go = ppg_host.GuidedPathTracer(engine=g), ppg_host.GuidedPathTracer(engine=o)
+    ig, io = gg.render(scene), go.render(scene)
+    assert _length_histogram(oracle_lib, o)[5:].sum() > 1000
+    assert _stats(gg) == _stats(go)
+    assert np.array_equal(ig, io, equal_nan=True) and np.isfinite(ig).all()
+    assert_tree_equal(g.read_sdtree(), o.read_sdtree())
+
+
 def test_stragglers_phase_calls_and_time_budget(oracle_lib):
     """The same through ppg_render() in one call, and with a time budget (every batch may be the last: whatever is owed is settled at the end
     of each ppg_render_passes): deterministic from run to run."""
