@@ -394,6 +394,26 @@ def test_stragglers_phase_calls_and_time_budget(oracle_lib):
     assert np.isfinite(img).all() and img.mean() > 1e-3
 
 
+@pytest.mark.parametrize("dfilter", ["nearest", "box"])
+def test_sorted_splat_with_dtrees_beyond_the_lds_stage_and_runs_across_chunks(oracle_lib, dfilter):
+    """k_splat_sorted (ppg_kernels.h "The commit of a ROUND") stages the building D-tree of a run of equal leaves in LDS when it has at most
+    PPG_SPLAT_NODES = 512 nodes and splats in the pool otherwise, and a run may span many chunks of 2048 records.  A coarse S-tree (a
+    handful of leaves: tens of thousands of records per run, i.e. dozens of chunks) with fine D-trees (dTreeThreshold 0.0015: 561 - 587 nodes in
+    the largest) puts both branches and the chunk boundaries on the path, for the nearest and the box directional filter."""
+    import ppg_host
+    scene = ppg_host.cbox_scene(64, 64)
+    props = dict(CBOX_PROPS, budget=124, seed=13, sppPerPass=4, sTreeThreshold=40000, dTreeThreshold=0.0015, bsdfSamplingFractionLoss="kl", spatialFilter="stochastic",
+                 directionalFilter=dfilter, sampleCombination="inversevar")
+    g, o = hip(**props), make_oracle(oracle_lib, threads=os.cpu_count() or 8, **props)
+    gg, go = ppg_host.GuidedPathTracer(engine=g), ppg_host.GuidedPathTracer(engine=o)
+    ig, io = gg.render(scene), go.render(scene)
+    t = o.read_sdtree()
+    assert t["building"]["num_nodes"].max() > 512 and t["building"]["num_nodes"].min() <= 512 and t["n_leaves"] <= 16
+    assert _stats(gg) == _stats(go)
+    assert np.array_equal(ig, io, equal_nan=True)
+    assert_tree_equal(g.read_sdtree(), t)
+
+
 def test_edge_cases(oracle_lib):
     import ppg_host
     # 1x1 film; 1 spp and a single pass (N - 1 = 0 → non-finite variance like the reference's "-1.#INF"); maxDepth = 1
