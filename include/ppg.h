@@ -442,6 +442,19 @@ int ppg_final_partials_commit(ppg_ctx *ctx);
    whose paths (passes * sppPerPass * pixels of the whole image, not of a shard) stay within PPG_ADAM_ROUND_MAX_PATHS; at least 1 */
 int32_t ppg_adam_round_passes(int32_t spp_per_pass, int32_t width, int32_t height, int32_t n_passes);
 
+/* Rounds by image REGION — an extension, off by default (regions = 0), for renders whose EARLY iterations must follow the reference's.
+   Under the reference's rule the optimiser's variable follows the records of the last ~100 paths, i.e. of the image region its 16 threads are
+   rendering; a variable frozen for a whole pass cannot, and the variance estimate of iterations 1 - 4 is up to twice the reference's
+   (above).  With regions = R >= 2, in every ppg_render_passes() call of at most PPG_ADAM_REGION_MAX_PASSES passes that is rendered in rounds,
+   a round is ONE pass over ONE of R groups of 32x32-pixel blocks — consecutive in the spiral order in which the reference's scheduler hands
+   blocks out (ppg_spiral_block_ranks, include/ppg_detmath.h; group of block b = rank(b) * R / blocks) — and the optimiser is applied after
+   every group: R rounds per pass.  Measured against the reference's own log of spaceship-improved: variance estimate
+   of iterations 1 - 4 within 2 - 13 % with R = 16 (2x with R = 0).  The price: R rounds of pixels / R paths each instead of one round of
+   1 - 8 passes — on one MI355X the early iterations of KITCHEN at 1280x720 take several times longer.  Keys, stragglers,
+   sharding (a rank renders its tiles of a group; R hook calls per pass on every rank) as for any round.  R is clamped to the number of blocks. */
+#define PPG_ADAM_REGION_MAX_PASSES 16
+int ppg_set_adam_regions(ppg_ctx *ctx, int32_t regions);
+
 typedef struct ppg_adam_record { /* one deferred optimizeBsdfSamplingFraction() call: DTreeRecord's fields it reads (GP:562-568) */
     uint64_t key;
     float product, wo_pdf, bsdf_pdf, dtree_pdf, statistical_weight, _pad;

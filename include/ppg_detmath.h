@@ -178,6 +178,27 @@ PPG_HD int64_t ppg_to_sfixed(float x) {
 }
 PPG_HD float ppg_from_sfixed(int64_t a) { return (float)a * 9.5367431640625e-7f; /* 2^-20 */ }
 
+/* Rounds by image region (include/ppg.h "Rounds by image region"): rank[by * bx] receives, for every 32x32 block (row-major), its position
+   in the spiral in which the reference's scheduler hands blocks out — from the central block outwards: right, down, left, up with growing run
+   lengths (BlockedImageProcess, imageproc.cpp:29-80).  Host only; shared by product and oracle like the sampler. */
+inline void ppg_spiral_block_ranks(int bx, int by, int *rank) {
+    const int total = bx * by;
+    for (int k = 0; k < total; ++k) rank[k] = -1;
+    int x = bx / 2, y = by / 2, next = 0, run = 1, dir = 0;
+    const int dx[4] = {1, 0, -1, 0}, dy[4] = {0, 1, 0, -1};
+    while (next < total && run <= 4 * (bx + by)) {
+        for (int rep = 0; rep < 2 && next < total; ++rep) {
+            for (int k = 0; k < run && next < total; ++k) {
+                if (x >= 0 && x < bx && y >= 0 && y < by && rank[y * bx + x] < 0) rank[y * bx + x] = next++;
+                x += dx[dir]; y += dy[dir];
+            }
+            dir = (dir + 1) & 3;
+        }
+        ++run;
+    }
+    for (int k = 0; k < total; ++k) if (rank[k] < 0) rank[k] = next++;
+}
+
 /* Scene-setup constant of the plastic BSDF: fresnelDiffuseReflectance(eta, fast = false) (util.cpp:797-861), the
    hemispherical average ∫0^1 F(sqrt(xi), eta) dxi of the unpolarised dielectric Fresnel reflectance
    (fresnelDielectricExt, util.cpp:651-681).  The reference integrates adaptively (Gauss-Lobatto, 1e-5); here composite

@@ -2596,7 +2596,8 @@ public:
         const bool halves = rounds && modes.adam == PPGO_ADAM_HALF && numPasses == 2;
         // PPGO_ADAM_REGIONS + R (measurement only): iterations of up to 16 passes render every pass in R groups of blocks in spiral order, the
         // optimiser applied after each
-        const int regions = (rounds && modes.adam > PPGO_ADAM_REGIONS && numPasses <= 16) ? modes.adam - PPGO_ADAM_REGIONS : 0;
+        const int regions = (rounds && modes.adam > PPGO_ADAM_REGIONS + 1 && numPasses <= PPG_ADAM_REGION_MAX_PASSES)
+                                ? std::min(modes.adam - PPGO_ADAM_REGIONS, ((W() + 31) / 32) * ((H() + 31) / 32)) : 0;
         const int roundPasses = regions ? 1 : (rounds ? adamRoundPasses(numPasses) : 1);
         // include/ppg.h "STRAGGLERS": the rounds of a render of unbounded paths whose record positions are known in advance
         m_deferRound = rounds && m_maxDepth < 0 && m_spatialFilter != ESBox && !(m_doNee && m_nee == EKickstart);
@@ -2616,13 +2617,18 @@ public:
             const int n = std::min(roundPasses, numPasses - i);
             m_roundStartPass = m_passesRendered;
             for (int k = 0; k < n; ++k) {
+                if (regions) {  // (a cancelled rank kept in step enters every group's round too, empty: the hook calls must match across ranks)
+                    m_regions = regions;
+                    for (m_region = 0; m_region < regions; ++m_region) { if (!drain) renderOnePass(); if (m_region + 1 < regions) applyAdamRound(); }
+                    m_regions = 0; m_region = -1;
+                    if (drain) continue;
+                    ++m_passesRendered; ++m_passesRenderedThisIter; ++m_passesLocal;
+                    m_samplesLocal += ownedPixels() * (uint64_t)m_sppPerPass;
+                    continue;
+                }
                 if (drain) continue;
                 if (halves) { m_parity = 0; renderOnePass(); applyAdamRound(); m_parity = 1; renderOnePass(); m_parity = -1; }
-                else if (regions) {
-                    m_regions = regions;
-                    for (m_region = 0; m_region < regions; ++m_region) { renderOnePass(); if (m_region + 1 < regions) applyAdamRound(); }
-                    m_regions = 0; m_region = -1;
-                } else
+                else
                 renderOnePass();
                 ++m_passesRendered; ++m_passesRenderedThisIter; ++m_passesLocal;
                 m_samplesLocal += ownedPixels() * (uint64_t)m_sppPerPass;
@@ -2730,25 +2736,10 @@ public:
     bool m_hookFailed = false;
     int m_parity = -1;
     int m_region = -1, m_regions = 0;
-    std::vector<int> m_spiralRank;  // [block] position of the block in the reference scheduler's spiral (center outwards)
+    std::vector<int> m_spiralRank;  // [block] position of the block in the reference scheduler's spiral (ppg_spiral_block_ranks)
     void buildSpiral(int bx, int by) {
         m_spiralRank.assign((size_t)bx * by, -1);
-        // BlockedImageProcess: start at the central block, walk right, down, left, up with growing run lengths (imageproc.cpp:29-80)
-        int x = bx / 2, y = by / 2, rank = 0, run = 1, dir = 0;
-        const int dx[4] = {1, 0, -1, 0}, dy[4] = {0, 1, 0, -1};
-        const int total = bx * by;
-        while (rank < total) {
-            for (int rep = 0; rep < 2 && rank < total; ++rep) {
-                for (int k = 0; k < run && rank < total; ++k) {
-                    if (x >= 0 && x < bx && y >= 0 && y < by && m_spiralRank[(size_t)y * bx + x] < 0) m_spiralRank[(size_t)y * bx + x] = rank++;
-                    x += dx[dir]; y += dy[dir];
-                }
-                dir = (dir + 1) & 3;
-            }
-            ++run;
-            if (run > 4 * (bx + by)) break;
-        }
-        for (auto &r : m_spiralRank) if (r < 0) r = rank++;
+        ppg_spiral_block_ranks(bx, by, m_spiralRank.data());
     }
     int hookPhase = 0;
     bool ownerMode = false;
@@ -3593,6 +3584,12 @@ int ppgo_stat_import(ppgo_ctx *ctx, const uint64_t *sums, uint64_t n_sums, const
     return PPG_OK;
 }
 int ppgo_work_counters(ppgo_ctx *ctx, uint64_t *out8) { memcpy(out8, ctx->gpt.m_work, sizeof ctx->gpt.m_work); return PPG_OK; }
+int ppgo_set_adam_regions(ppgo_ctx *ctx, int32_t regions) {  // include/ppg.h "Rounds by image region"
+    if (regions < 0 || regions > 4096) { ctx->gpt.error = "ppg_set_adam_regions: 0 .. 4096"; return PPG_ERR_INVALID; }
+    if (ctx->gpt.modes.adam == PPGO_ADAM_SEQUENTIAL) return PPG_OK;  // (the literal rule has no rounds)
+    ctx->gpt.modes.adam = regions >= 2 ? PPGO_ADAM_REGIONS + regions : PPGO_ADAM_ROUND;
+    return PPG_OK;
+}
 int ppgo_debug_set_defer_depth(ppgo_ctx *ctx, int32_t depth) { if (depth < 1 || depth > 64) return PPG_ERR_INVALID; ctx->gpt.m_deferDepth = depth; return PPG_OK; }
 int ppgo_path_length_histogram(ppgo_ctx *ctx, uint64_t *out) { memcpy(out, ctx->gpt.m_lenHist, sizeof ctx->gpt.m_lenHist); return PPG_OK; }
 int ppgo_set_stop_hook(ppgo_ctx *ctx, ppg_stop_hook hook, void *user) { ctx->gpt.stopHook = hook; ctx->gpt.stopHookUser = user; return PPG_OK; }

@@ -73,6 +73,7 @@ int ppgo_work_counters(ppgo_ctx *ctx, uint64_t *out8);
 int ppgo_path_length_histogram(ppgo_ctx *ctx, uint64_t *out);
 /* the tests' switch of include/ppg_testhooks.h (ppg_debug_set_defer_depth), same meaning */
 int ppgo_debug_set_defer_depth(ppgo_ctx *ctx, int32_t depth);
+int ppgo_set_adam_regions(ppgo_ctx *ctx, int32_t regions);  /* = ppg_set_adam_regions */
 int ppgo_set_pass_hook(ppgo_ctx *ctx, ppg_pass_hook hook, void *user);
 /* host-memory counterparts of ppg_adam_records / ppg_adam_records_replace (valid inside the round hook) */
 int ppgo_adam_records(ppgo_ctx *ctx, void **records, uint64_t *n);

@@ -561,6 +561,11 @@ struct ppg_ctx {
                                                 // scheduling: final iterations, renders without a learned fraction; 0 = never).  Rounds of the
                                                 // optimiser use PPG_ADAM_DEFER_DEPTH — there the depth is part of the result (include/ppg.h)
     bool tuneFinalHalves = false;               // PPG_FINAL_HALVES: a final iteration that fits one launch is rendered in two (renderFinalGroups)
+    // rounds by image region (include/ppg.h ppg_set_adam_regions): the owned pixels grouped by the region of their 32x32 block
+    int adamRegions = 0;
+    DevBuf<unsigned int> d_regionPixels;
+    std::vector<unsigned int> regionOffset;   // [regions + 1] into d_regionPixels
+    int regionsBuilt = 0;                     // the lists are valid for this many regions (0: none; reset when the shard or the film changes)
     int deferDepthAdam = PPG_ADAM_DEFER_DEPTH;  // (tests lower it through ppg_debug_set_defer_depth to meet many stragglers in small scenes)
     int joinStragglers() {  // the side stream's work is over as far as the context's stream is concerned (entry points, error paths)
         int rc = 0;
@@ -971,6 +976,7 @@ int allocPaths(ppg_ctx *ctx) {
             if (ctx->shardWorld <= 1 || t % ctx->shardWorld == ctx->shardRank) pix.push_back((unsigned int)(y * ctx->W + x));
         }
     ctx->nPix = (unsigned int)pix.size();
+    ctx->regionsBuilt = 0;
     HIP_CHECK(ctx->d_pixels.reserve(std::max<size_t>(1, pix.size())));
     if (!pix.empty()) HIP_CHECK(hipMemcpy(ctx->d_pixels.p, pix.data(), pix.size() * 4, hipMemcpyHostToDevice));
     ctx->nPixAll = (unsigned int)((size_t)ctx->W * ctx->H);
@@ -1418,8 +1424,10 @@ int flushStragglers(ppg_ctx *ctx, bool hookRound) {
 // A launch of whole groups of a final iteration's passes (include/ppg.h "Final iteration: groups of passes"): `batch` passes = groups of
 // groupPasses passes (the last one may be shorter; or a part of ONE group when groupPasses >= batch), the first starting at pass
 // firstPass of the render, consecutive groups of the launch stridePasses apart; group k accumulates into slot slot0 + k * slotStride.
-int renderBatch(ppg_ctx *ctx, int batch, bool adamRound, const GroupLaunch *gl = nullptr, bool last = true) {
+int renderBatch(ppg_ctx *ctx, int batch, bool adamRound, const GroupLaunch *gl = nullptr, bool last = true, const unsigned int *regionPixels = nullptr,
+                unsigned int regionCount = 0) {
     PathState P = ctx->paths;
+    if (regionPixels) { P.n_pix = regionCount; P.pixels = regionPixels; }  // a round over ONE group of blocks (include/ppg.h "Rounds by image region")
     if (gl && gl->wholeFilm && ctx->shardWorld > 1) { P.n_pix = ctx->nPixAll; P.pixels = ctx->d_pixelsAll.p; }  // the whole film, not this rank's tiles
     P.n_paths = (unsigned int)((size_t)P.n_pix * ctx->sppPerPass * (size_t)batch);
     if (P.n_paths == 0 && !(adamRound && ctx->passHook)) return PPG_OK;
@@ -1851,6 +1859,33 @@ int renderFinalGroups(ppg_ctx *ctx, int numPasses) {
     return ctx->seesCancel() ? PPG_ERR_CANCELLED : PPG_OK;
 }
 
+// The owned pixels grouped by region: region of a pixel = spiral rank of its 32x32 block * regions / blocks (include/ppg.h "Rounds by image
+// region"); inside a group in the order of the owned-pixel list (row-major), so that a wave is still 64 neighbouring pixels of a row.
+int buildRegionLists(ppg_ctx *ctx, int regions) {
+    if (ctx->regionsBuilt == regions) return PPG_OK;
+    const int bs = 32, bx = (ctx->W + bs - 1) / bs, by = (ctx->H + bs - 1) / bs;
+    std::vector<int> rank((size_t)bx * by);
+    ppg_spiral_block_ranks(bx, by, rank.data());
+    std::vector<unsigned int> own(ctx->nPix);
+    if (ctx->nPix) HIP_CHECK(hipMemcpy(own.data(), ctx->d_pixels.p, (size_t)ctx->nPix * 4, hipMemcpyDeviceToHost));
+    std::vector<std::vector<unsigned int>> lists((size_t)regions);
+    for (unsigned int p : own) {
+        const int x = (int)(p % (unsigned int)ctx->W), y = (int)(p / (unsigned int)ctx->W);
+        const int r = (int)((long long)rank[(size_t)(y / bs) * bx + (x / bs)] * regions / (bx * by));
+        lists[(size_t)r].push_back(p);
+    }
+    ctx->regionOffset.assign((size_t)regions + 1, 0u);
+    std::vector<unsigned int> flat;
+    flat.reserve(own.size());
+    for (int r = 0; r < regions; ++r) { ctx->regionOffset[(size_t)r] = (unsigned int)flat.size(); flat.insert(flat.end(), lists[(size_t)r].begin(), lists[(size_t)r].end()); }
+    ctx->regionOffset[(size_t)regions] = (unsigned int)flat.size();
+    HIP_CHECK(ctx->d_regionPixels.reserve(std::max<size_t>(1, flat.size())));
+    if (!flat.empty()) HIP_CHECK(hipMemcpyAsync(ctx->d_regionPixels.p, flat.data(), flat.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));  // (`flat` is pageable host memory)
+    ctx->regionsBuilt = regions;
+    return PPG_OK;
+}
+
 int renderPassesNoStat(ppg_ctx *ctx, int numPasses) {  // GP:1217-1286
     size_t n = (size_t)ctx->W * ctx->H;
     HIP_CHECK(hipMemsetAsync(ctx->d_image.p, 0, 3 * n * 4, ctx->stream));
@@ -1871,6 +1906,14 @@ int renderPassesNoStat(ppg_ctx *ctx, int numPasses) {  // GP:1217-1286
     // Cancelled while a round hook is installed (a sharded render with a learned sampling fraction): the other ranks enter the hook of
     // EVERY remaining round of this call, so this rank keeps entering it too — with empty rounds (no paths, no records; the host marks its
     // status word) — instead of leaving for an exchange the others are not in.  They all see the status and abort together.
+    // rounds by image region (include/ppg.h ppg_set_adam_regions): in a call of at most PPG_ADAM_REGION_MAX_PASSES passes a round is one pass
+    // over one group of blocks
+    int regions = 0;
+    if (rounds && ctx->adamRegions > 1 && numPasses <= PPG_ADAM_REGION_MAX_PASSES) {
+        regions = std::min(ctx->adamRegions, ((ctx->W + 31) / 32) * ((ctx->H + 31) / 32));
+        int rc = buildRegionLists(ctx, regions);
+        if (rc) return rc;
+    }
     bool drain = false;
     for (int i = 0; i < numPasses;) {
         if (ctx->seesCancel()) {
@@ -1882,8 +1925,15 @@ int renderPassesNoStat(ppg_ctx *ctx, int numPasses) {  // GP:1217-1286
                 break;
             }
         }
-        const int batch = std::min(roundPasses, numPasses - i);
-        int rc = renderBatch(ctx, drain ? 0 : batch, rounds, nullptr, i + batch >= numPasses);
+        const int batch = regions ? 1 : std::min(roundPasses, numPasses - i);
+        int rc = PPG_OK;
+        if (regions) {
+            for (int r = 0; r < regions && !rc; ++r) {
+                const unsigned int first = ctx->regionOffset[(size_t)r], count = ctx->regionOffset[(size_t)r + 1] - first;
+                // (a group without pixels of this rank — or a cancelled rank kept in step — is an empty round: the hook calls match across ranks)
+                rc = renderBatch(ctx, drain ? 0 : 1, true, nullptr, i + 1 >= numPasses && r + 1 == regions, ctx->d_regionPixels.p + first, drain ? 0u : count);
+            }
+        } else rc = renderBatch(ctx, drain ? 0 : batch, rounds, nullptr, i + batch >= numPasses);
         if (rc) return rc;
         ctx->passesRendered += batch; ctx->passesRenderedThisIter += batch; ctx->passesLocal += batch;
         ctx->samplesLocal += (uint64_t)ctx->nPix * batch * ctx->sppPerPass;
@@ -2994,6 +3044,12 @@ int ppg_query_sample(ppg_ctx *ctx, uint32_t n, const float *positions, uint64_t 
     hipLaunchKernelGGL(k_query_sample, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->devTree(), n, dp.p, (unsigned long long)seed, dout.p);
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
     HIP_CHECK(hipMemcpy(dirs_out, dout.p, 12 * (size_t)n, hipMemcpyDeviceToHost));
+    return PPG_OK;
+}
+
+int ppg_set_adam_regions(ppg_ctx *ctx, int32_t regions) {  // include/ppg.h "Rounds by image region"
+    if (!ctx || regions < 0 || regions > 4096) { if (ctx) ctx->error = "ppg_set_adam_regions: 0 .. 4096"; return PPG_ERR_INVALID; }
+    ctx->adamRegions = regions >= 2 ? regions : 0;
     return PPG_OK;
 }
 

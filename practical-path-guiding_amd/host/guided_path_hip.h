@@ -132,6 +132,9 @@ public:
         m_cfg.seed = (uint64_t)std::stoull(props.getString("seed", "0"));
         m_cfg.device = props.getInteger("device", 0);
         if (ppg_create(&m_cfg, &m_ctx) != PPG_OK) throw std::runtime_error(std::string("ppg_create: ") + ppg_last_error(nullptr));
+        // not a property of the reference: rounds by image region in the early iterations (include/ppg.h ppg_set_adam_regions), 0 = off
+        const int regions = props.getInteger("adamRegions", 0);
+        if (regions && ppg_set_adam_regions(m_ctx, regions) != PPG_OK) throw std::runtime_error(std::string("adamRegions: ") + ppg_last_error(m_ctx));
     }
     ~GuidedPathTracerHIP() { ppg_destroy(m_ctx); }
     GuidedPathTracerHIP(const GuidedPathTracerHIP &) = delete;

@@ -334,6 +334,10 @@ class Engine:
     def set_final(self, is_final):
         self._call("set_final", C.c_int32(int(is_final)))
 
+    def set_adam_regions(self, regions):
+        """Rounds by image region (include/ppg.h ppg_set_adam_regions): 0 = off (default), R >= 2 = R rounds per pass in the early iterations."""
+        self._call("set_adam_regions", C.c_int32(int(regions)))
+
     def set_do_nee(self, v):
         self._call("set_do_nee", C.c_int32(int(v)))
 

@@ -118,13 +118,15 @@ if sys.argv[4] in ("nee", "full-scene"):
     props.update(nee="kickstart", bsdfSamplingFractionLoss="var", spatialFilter="box", sTreeThreshold=2000)
 if sys.argv[4] == "auto-final":
     props.update(budget=2044, seed=2, sampleCombination="automatic")
-if sys.argv[4] == "stragglers":
+if sys.argv[4] in ("stragglers", "regions"):
     props.update(sampleCombination="inversevar", bsdfSamplingFractionLoss="kl", spatialFilter="stochastic", directionalFilter="box", sTreeThreshold=2000, sppPerPass=1,
                  maxDepth=-1, rrDepth=3, budget=63)
 e = ppg_host.Engine(lib, "ppgo_", **props)
 if sys.argv[4] == "stragglers":
     e._call("debug_set_defer_depth", ctypes.c_int32(6))
 lib.ppgo_set_modes(e.ctx, 0, 0, 2)
+if sys.argv[4] == "regions":
+    e.set_adam_regions(5)
 scene = ppg_host.cbox_scene(24, 16) if sys.argv[4] == "auto-final" else ppg_host.cbox_scene(64, 48)
 if sys.argv[4] == "full-scene":
     from test_gpu_parity import _sphere_scene
@@ -145,7 +147,7 @@ dist.barrier(); dist.destroy_process_group()
 @pytest.mark.parametrize("mode,world,scheme", [("default", 2, "owner"), ("inversevar", 2, "owner"), ("improved", 2, "owner"), ("nee", 2, "owner"),
                                                ("full-scene", 2, "owner"), ("improved", 4, "owner"), ("nee", 4, "owner"), ("improved", 2, "gather"),
                                                ("auto-final", 2, "owner"), ("auto-final", 4, "owner"), ("stragglers", 2, "owner"), ("stragglers", 3, "owner"),
-                                               ("stragglers", 2, "gather")])
+                                               ("stragglers", 2, "gather"), ("regions", 2, "owner"), ("regions", 3, "owner")])
 def test_sharded_render_over_gloo_equals_single_rank(oracle_lib, tmp_path, mode, world, scheme):
     """world_size 2 and 4, gloo: tiles sharded, SD-tree statistics all-reduced as int64, the optimiser's records sent to the OWNER of
     their D-tree (all-to-all) and the owners' optimiser state all-gathered ("owner"; "gather": round 2's gather-everything scheme) →
@@ -153,6 +155,7 @@ def test_sharded_render_over_gloo_equals_single_rank(oracle_lib, tmp_path, mode,
     The FINAL iteration is sharded by whole groups of passes, not by tiles (include/ppg.h "Final iteration: groups of passes"): "improved" has
     three groups (16 + 16 + 13 passes), "auto-final" sixteen — after the tile-sharded training passes of the same iteration, whose film the
     groups are added to (sampleCombination = automatic switching to FINAL in the middle of iteration 7, GP:1400-1411).
+    "regions": rounds by image region (ppg_set_adam_regions) — R hook calls per pass on every rank, also on a rank that owns no tile of a group.
     "stragglers": unbounded paths, and the tests' switch lowers the depth of include/ppg.h "STRAGGLERS" to 6 — a quarter of the paths' records
     are applied one round late, those of an iteration's last round in a round of their own for which every rank's hook is called."""
     import ppg_host
@@ -178,10 +181,12 @@ def test_sharded_render_over_gloo_equals_single_rank(oracle_lib, tmp_path, mode,
     if mode == "full-scene":  # analytic spheres (glass, rough gold, lamp) under an emitting sky dome: the S-tree spans the dome
         from test_gpu_parity import _sphere_scene
         scene = _sphere_scene((64, 48), sky=True)
-    if mode == "stragglers":
+    if mode in ("stragglers", "regions"):
         props.update(sampleCombination="inversevar", bsdfSamplingFractionLoss="kl", spatialFilter="stochastic", directionalFilter="box", sTreeThreshold=2000,
                      sppPerPass=1, maxDepth=-1, rrDepth=3, budget=63)
     e = make_oracle(oracle_lib, threads=4, **props)
+    if mode == "regions":  # rounds by image region (include/ppg.h): five groups over 2 x 2 blocks -> clamped to four; a rank's tiles of a group may be none
+        e.set_adam_regions(5)
     if mode == "stragglers":
         e._call("debug_set_defer_depth", ctypes.c_int32(6))
     e.set_scene(scene); e.render()

@@ -216,3 +216,35 @@ def test_kitchen_default_configuration_picture_matches_the_reference():
         b50 = img.reshape(8, 50, 14, 50, 3).mean((1, 3)).mean(-1)
         rel = np.abs(b50 / fx["kitchen_blocks50"].astype(np.float64).mean(-1) - 1)
         assert rel[keep50].mean() < 0.02 and rel[keep50].max() < 0.2, (seed, float(rel[keep50].mean()), float(rel[keep50].max()))
+
+
+def test_region_rounds_follow_the_reference_log_of_spaceship_improved():
+    """The PRODUCT against the reference's own log where the shipped round rule is known to lag (a14): spaceship-improved
+    (the bundled scene with the improved preset, 640 x 360) with `ppg_set_adam_regions(16)` — the variance estimate of iterations 1 - 3 follows
+    the log (0.0976 / 0.0399 / 0.0180) within the spread the oracle showed for this rule (+7 / +13 / +8 %, seeds 3 and 4), where the default
+    rounds give 2.0 / 1.6 - 2.5 / 3 - 5 x; average statistical weight per leaf within 6 %."""
+    import json
+    import ppg_host
+    from test_gpu_parity import hip
+    if not os.path.exists(SPACESHIP):
+        pytest.skip("scene file not present")
+    log = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_logs.json")))["scenes"]["spaceship-improved"]
+    scene = _load(SPACESHIP, log["width"], log["height"])
+    props = dict(_props(SPACESHIP, seed=3), budget=31.0, sampleCombination="inversevar", bsdfSamplingFractionLoss="kl", spatialFilter="stochastic",
+                 directionalFilter="box", sTreeThreshold=4000, sppPerPass=1)   # spaceship-improved.xml = spaceship.xml + the improved preset
+    ref = log["iterations"]
+
+    def run(regions):
+        e = hip(**props)
+        e.set_adam_regions(regions)
+        g = ppg_host.GuidedPathTracer(engine=e)
+        g.render(scene)
+        assert [it["passes"] for it in g.iterations] == [1, 2, 4, 8, 16]
+        return [it["stats"][-1]["variance"] for it in g.iterations], [it["tree"]["avg_stat_weight"] for it in g.iterations]
+
+    var, sw = run(16)
+    for k in (1, 2, 3):
+        assert abs(var[k] / ref[k]["var"][0] - 1) < 0.25, (k, var)
+        assert abs(sw[k] / ref[k]["stat_weight"][1] - 1) < 0.06, (k, sw)
+    var0, _ = run(0)
+    assert var0[1] / ref[1]["var"][0] > 1.5   # the default rounds: the lag this option removes
