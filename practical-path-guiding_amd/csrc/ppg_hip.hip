@@ -1594,17 +1594,23 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound, const GroupLaunch *gl =
     ppg_ctx::Stragglers &G = ctx->strag[ctx->stragCur];  // the set this batch's stragglers go to (the other one may be pending: the previous batch's)
     // the records of the PREVIOUS round's stragglers are applied with this round's: they take the positions behind its own
     const size_t nDeferredIn = (adamRound && ctx->adamFast && ctx->stragPrev().pending && ctx->stragPrev().adam) ? (size_t)ctx->stragPrev().n * (size_t)ctx->maxVertices : 0;
-    auto launchTail = [&](unsigned int depth) {
+    // (handedPaths: how many paths the launch will find in the list, when the host knows — 0 = unknown)
+    auto launchTail = [&](unsigned int depth, size_t handedPaths = 0) {
         HIP_CHECK(hipMemsetAsync(ctx->d_ticket.p, 0, 4, s));
         // (the persistent workgroups of k_tail hold their registers until their last path has ended: no more of them than fit the GPU at once)
         const int tailGrid = std::min(grid, ctx->tuneTailBlocks ? ctx->tuneTailBlocks : 1024);
+        // Fewer paths than lanes — a rank's share of a small round, a round over one group of blocks —: dealt THINLY, the same number of
+        // lanes in every wave, instead of 64 to the first waves and none to the rest: a wave's bounce costs the union of its lanes' branches
+        // and its longest traversal, and idle SIMDs cost nothing.
+        const size_t tailWaves = (size_t)tailGrid * (PPG_BLOCK / 64);
+        const unsigned int laneLimit = handedPaths ? (unsigned int)std::max<size_t>(1, std::min<size_t>(64, (handedPaths + tailWaves - 1) / tailWaves)) : 64u;
         timedLaunch(ctx, "k_tail", hostCount, [&] {
             RenderParams Rt = R;
             Rt.defer_depth = depth;
             // (the launch's longest path is logged for launches that run their paths to the END: the sum is the tails' critical path; a launch that
             // hands its stragglers over writes to a spare slot nobody reads)
             TailLaunch a{tailGrid, ldsBytes, s, P, S, T, Rt, dense, ctx->d_total.p, ctx->d_ticket.p, Q.stats, ctx->ldsTris,
-                         ctx->d_tailLongest.p + (depth ? PPG_TAIL_LOG : (ctx->tailLaunches++ % PPG_TAIL_LOG)), StragOut{G.rec.p, G.orig.p, G.count.p}, 64u};
+                         ctx->d_tailLongest.p + (depth ? PPG_TAIL_LOG : (ctx->tailLaunches++ % PPG_TAIL_LOG)), StragOut{G.rec.p, G.orig.p, G.count.p}, laneLimit};
             ppg_launch_tail((smallScene ? 4 : 0) | (neeOn ? 2 : 0) | (fullMats ? 1 : 0), a);
         });
         return PPG_OK;
@@ -1699,7 +1705,7 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound, const GroupLaunch *gl =
         HIP_CHECK(G.count.reserve(2)); HIP_CHECK(G.ticket.reserve(1));
         HIP_CHECK(hipMemsetAsync(G.count.p, 0, 16, s));
         if (overlap) HIP_CHECK(hipEventRecord(ctx->evFork, s));
-        { int rc = launchTail(deferDepth); if (rc) return rc; }
+        { int rc = launchTail(deferDepth, handed); if (rc) return rc; }
         if (overlap) {
             if (beside) {
                 HIP_CHECK(hipStreamWaitEvent(ctx->stream2, ctx->evFork, 0));
