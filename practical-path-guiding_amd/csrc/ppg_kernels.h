@@ -1665,6 +1665,12 @@ __global__ __launch_bounds__(PPG_BLOCK) void k_commit(PathState P, DevTree T, Re
 #define PPG_SPLAT_NODES 512    // D-trees of up to this many nodes are staged in LDS (20 KB); larger ones are splatted in the pool (TreeGlobal)
 #define PPG_SPLAT_PER_LANE 8   // records per lane and chunk
 #define PPG_SPLAT_CHUNK (PPG_BLOCK * PPG_SPLAT_PER_LANE)
+#ifndef PPG_SPLAT_MAX_RUNS
+#define PPG_SPLAT_MAX_RUNS 64   // a chunk (2048 records) of more runs than this is splatted record by record
+#endif
+#ifndef PPG_SPLAT_RUN_FACTOR
+#define PPG_SPLAT_RUN_FACTOR 4   // a run is staged in LDS when it holds at least nodes / 4 records
+#endif
 static_assert(PPG_BLOCK % 64 == 0, "k_splat_sorted / k_commit_records reduce over full waves");
 static_assert(PPG_SPLAT_NODES * (sizeof(ushort4) + 4 * sizeof(unsigned long long)) + PPG_BOX_STACK * PPG_BLOCK * sizeof(unsigned long long) + 64 <= 64 * 1024,
               "k_splat_sorted: the staged D-tree and the box stacks must fit the workgroup's LDS");
@@ -1762,7 +1768,7 @@ __global__ __launch_bounds__(PPG_BLOCK) void k_splat_sorted(DevTree T, const uns
     __shared__ unsigned long long s_acc[4 * PPG_SPLAT_NODES];
     __shared__ unsigned long long s_stack[DF == DF_BOX ? PPG_BOX_STACK * PPG_BLOCK : 1];
     __shared__ unsigned long long s_weight;
-    __shared__ unsigned int s_field, s_end;
+    __shared__ unsigned int s_field, s_end, s_runs;
     // (leaf_bits <= 22: flag + leaf fit the 24 key bits above PPG_ADAM_LEAF_SHIFT — the host commits larger S-trees with k_commit; n <= 0xfffffff0:
     // lo + t + j * PPG_BLOCK stays below 2^32)
     const unsigned int leaf_mask = (1u << leaf_bits) - 1u, field_mask = (2u << leaf_bits) - 1u;
@@ -1777,6 +1783,48 @@ __global__ __launch_bounds__(PPG_BLOCK) void k_splat_sorted(DevTree T, const uns
             const unsigned int p = lo + t + (unsigned int)j * PPG_BLOCK;
             field[j] = 0xffffffffu; src[j] = 0;
             if (p < hi) { field[j] = (unsigned int)(keys[p] >> PPG_ADAM_LEAF_SHIFT) & field_mask; src[j] = idx[p]; }
+        }
+        // How many runs does the chunk hold?  (A record starts a run when the record before it — the previous chunk's last one included — has
+        // another field.)  Many short runs — the records that are splats only, a few per leaf; any record of a small round — are not worth a
+        // barrier-synchronised pass each: the chunk is then splatted record by record, every lane walking the D-tree of its own record's leaf in
+        // the pool (what k_commit does), the statistical weights combined per wave.
+        // (a chunk whose first and last record lie a few leaves apart cannot hold many runs: the large rounds' chunks — one or two leaves each —
+        // skip the count)
+        const unsigned int f_first = (unsigned int)(keys[lo] >> PPG_ADAM_LEAF_SHIFT) & field_mask, f_last = (unsigned int)(keys[hi - 1u] >> PPG_ADAM_LEAF_SHIFT) & field_mask;
+        const bool count_runs = (f_last & leaf_mask) == leaf_mask || f_last - f_first >= PPG_SPLAT_MAX_RUNS;
+        if (t == 0) s_runs = 0u;
+        if (count_runs) {
+            __syncthreads();
+            unsigned int starts = 0;
+#pragma unroll
+            for (int j = 0; j < PPG_SPLAT_PER_LANE; ++j) {
+                const unsigned int p = lo + t + (unsigned int)j * PPG_BLOCK;
+                if (p < hi && (field[j] & leaf_mask) != leaf_mask) {
+                    const unsigned int before = p == 0 ? 0xffffffffu : ((unsigned int)(keys[p - 1] >> PPG_ADAM_LEAF_SHIFT) & field_mask);
+                    starts += before != field[j] ? 1u : 0u;
+                }
+            }
+            for (int off = 32; off > 0; off >>= 1) starts += __shfl_xor(starts, off);
+            if ((t & 63u) == 0 && starts) atomicAdd(&s_runs, starts);
+            __syncthreads();
+        }
+        if (count_runs && s_runs > PPG_SPLAT_MAX_RUNS) {
+#pragma unroll
+            for (int j = 0; j < PPG_SPLAT_PER_LANE; ++j) {
+                const unsigned int leaf = field[j] & leaf_mask;
+                const bool valid = field[j] != 0xffffffffu && leaf != leaf_mask;
+                float4 r = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (valid) r = splat[src[j]];
+                const bool act = valid && r.w > 0;
+                wave_key_add<3>(T.bweight, leaf, act ? ppg_to_fixed(r.w) : 0ull, act);  // statisticalWeight += w, GP:396-398
+                if (act && r.z > 0) {
+                    const unsigned int base = T.hdr[leaf].b_base;
+                    const TreeGlobal tree{T.bchild + base, T.bacc + (size_t)base * 4};
+                    dtree_record_t(tree, r.x, r.y, r.z, r.w, DF, DF == DF_BOX ? s_stack + t : nullptr, PPG_BLOCK);
+                }
+            }
+            __syncthreads();
+            continue;
         }
         unsigned int pos = lo;
         for (;;) {  // one run of equal (flag, leaf) after the other
@@ -1802,14 +1850,21 @@ __global__ __launch_bounds__(PPG_BLOCK) void k_splat_sorted(DevTree T, const uns
             }
             const unsigned int leaf = f0 & leaf_mask;
             const unsigned int base = T.hdr[leaf].b_base, nn = T.hdr[leaf].b_num;
-            const bool staged = nn <= lds_nodes;  // (PPG_SPLAT_NODES, or fewer: PPG_SPLAT_LDS_NODES, so that tests reach the other branch with small trees)
-            if (staged)
+            __syncthreads();
+            const unsigned int end = s_end;
+            // Staging pays for a LONG run: the D-tree's topology in, its accumulators zeroed, every non-zero one added to the pool afterwards —
+            // a few microseconds whatever the run holds.  A small round (a rank's share, a round over one group of blocks) leaves a handful of
+            // records per leaf, and the records that are splats only (the flag bit: they sort behind the optimiser's, leaf by leaf) come a few
+            // per leaf in ANY round: a chunk of 2048 of them was 500 runs, 2 ms for one workgroup while the launch waited (round 6: 2.3 ms of a
+            // 4.5 ms region round).  Short runs splat straight into the pool.  Integer sums: the same bits either way.
+            const bool staged = nn <= lds_nodes && (end - pos) * PPG_SPLAT_RUN_FACTOR >= nn;  // (lds_nodes: PPG_SPLAT_NODES, or fewer: PPG_SPLAT_LDS_NODES, for the tests)
+            if (staged) {
                 for (unsigned int k = t; k < nn; k += PPG_BLOCK) {
                     s_child[k] = T.bchild[base + k];
                     s_acc[4 * k] = 0ull; s_acc[4 * k + 1] = 0ull; s_acc[4 * k + 2] = 0ull; s_acc[4 * k + 3] = 0ull;
                 }
-            __syncthreads();
-            const unsigned int end = s_end;
+                __syncthreads();
+            }
             unsigned long long wsum = 0ull;
 #pragma unroll
             for (int j = 0; j < PPG_SPLAT_PER_LANE; ++j) {
