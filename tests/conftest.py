@@ -50,5 +50,8 @@ IMPROVED = dict(sampleCombination="inversevar", bsdfSamplingFractionLoss="kl", s
 def make_oracle(lib, threads=8, acc=0, adam=0, **props):
     import ppg_host
     e = ppg_host.Engine(lib, "ppgo_", **props)
+    # (the oracle's passes are OpenMP loops over 32x32 blocks: on the GPU box's 256 hardware threads a test film of a few blocks made
+    # 250 threads wait for six — the region-round tests took 49 s each, 0.5 s with 16 threads; PPG_TEST_ORACLE_THREADS overrides the cap)
+    threads = max(1, min(int(threads), int(os.environ.get("PPG_TEST_ORACLE_THREADS", "32"))))
     lib.ppgo_set_modes(e.ctx, acc, adam, threads)
     return e

@@ -331,7 +331,8 @@ def test_stragglers_records_one_round_late_against_oracle(oracle_lib, scene_name
     import ppg_host
     scene = ppg_host.cbox_scene(96, 96) if scene_name == "cbox" else ppg_host.room_scene(96, 54, n_boxes=60, tess=2, glossy=True)
     props = dict(budgetType="spp", budget=63, maxDepth=-1, rrDepth=3, strictNormals=1, seed=29, **dict(IMPROVED, **extra))
-    g, o = hip(**props), make_oracle(oracle_lib, threads=os.cpu_count() or 8, **props)
+    threads = min(32, os.cpu_count() or 8)  # (96 x 54 pixels are six blocks: more threads only wait for each other)
+    g, o = hip(**props), make_oracle(oracle_lib, threads=threads, **props)
     g._call("debug_set_defer_depth", C.c_int32(depth))
     o._call("debug_set_defer_depth", C.c_int32(depth))
     gg, go = ppg_host.GuidedPathTracer(engine=g), ppg_host.GuidedPathTracer(engine=o)
@@ -341,7 +342,7 @@ def test_stragglers_records_one_round_late_against_oracle(oracle_lib, scene_name
     assert _stats(gg) == _stats(go)
     assert np.array_equal(ig, io, equal_nan=True) and np.isfinite(ig).all()
     assert_tree_equal(g.read_sdtree(), o.read_sdtree())
-    o64 = make_oracle(oracle_lib, threads=os.cpu_count() or 8, **props)
+    o64 = make_oracle(oracle_lib, threads=threads, **props)
     ppg_host.GuidedPathTracer(engine=o64).render(scene)
     assert not np.array_equal(o64.read_sdtree()["theta"], o.read_sdtree()["theta"])
 
@@ -414,8 +415,8 @@ def test_sorted_splat_with_dtrees_beyond_the_lds_stage_and_runs_across_chunks(or
     assert_tree_equal(g.read_sdtree(), t)
 
 
-@pytest.mark.parametrize("scene_name,regions,extra,depth", [("cbox", 8, {}, 0), ("cbox", 25, dict(directionalFilter="nearest", bsdfSamplingFractionLoss="var"), 0),
-                                                            ("room", 5, dict(maxDepth=-1, rrDepth=3), 6), ("cbox", 1000, dict(seed=20), 0)])
+@pytest.mark.parametrize("scene_name,regions,extra,depth", [("cbox", 8, {}, 0), ("cbox-96", 9, dict(directionalFilter="nearest", bsdfSamplingFractionLoss="var"), 0),
+                                                            ("room", 5, dict(maxDepth=-1, rrDepth=3), 6), ("cbox-96", 1000, dict(seed=20), 0)])
 def test_rounds_by_image_region_against_oracle(oracle_lib, scene_name, regions, extra, depth):
     """include/ppg.h "Rounds by image region" (ppg_set_adam_regions, an extension, off by default): in the iterations of at most 16 passes a
     round is one pass over one of R groups of 32x32 blocks in the spiral order of the reference's scheduler, the optimiser applied after every
@@ -423,10 +424,12 @@ def test_rounds_by_image_region_against_oracle(oracle_lib, scene_name, regions, 
     travel from group to group (the tests' switch lowers the depth), R clamped to the number of blocks — and differ from the render without
     regions (the rule acts)."""
     import ppg_host
-    scene = ppg_host.cbox_scene(160, 160) if scene_name == "cbox" else ppg_host.room_scene(160, 96, n_boxes=60, tess=2, glossy=True)
+    scene = (ppg_host.cbox_scene(160, 160) if scene_name == "cbox" else ppg_host.cbox_scene(96, 96) if scene_name == "cbox-96"
+             else ppg_host.room_scene(160, 96, n_boxes=60, tess=2, glossy=True))
     props = dict(CBOX_PROPS, budget=31.0, seed=19, **IMPROVED)
     props.update(extra)
-    g, o = hip(**props), make_oracle(oracle_lib, threads=os.cpu_count() or 8, **props)
+    threads = min(16, os.cpu_count() or 8)  # (a round over one group of blocks is a few blocks of work: hundreds of threads only wait for each other)
+    g, o = hip(**props), make_oracle(oracle_lib, threads=threads, **props)
     for e in (g, o):
         e.set_adam_regions(regions)
         if depth:
@@ -436,7 +439,7 @@ def test_rounds_by_image_region_against_oracle(oracle_lib, scene_name, regions, 
     assert _stats(gg) == _stats(go)
     assert np.array_equal(ig, io, equal_nan=True) and np.isfinite(ig).all()
     assert_tree_equal(g.read_sdtree(), o.read_sdtree())
-    plain = make_oracle(oracle_lib, threads=os.cpu_count() or 8, **props)
+    plain = make_oracle(oracle_lib, threads=threads, **props)
     if depth:
         plain._call("debug_set_defer_depth", C.c_int32(depth))
     ppg_host.GuidedPathTracer(engine=plain).render(scene)
