@@ -334,7 +334,10 @@ def run(args):
         # CPU baseline: the oracle (a port, not the reference binary) on the host cores, bounded sample:
         # the same scene / resolution / settings, the first `cpu_passes` passes of the same schedule.
         import ctypes
-        cores = os.cpu_count() or 1
+        # (threads: the port does not scale beyond a few dozen — measured on the MI355X box's 256 hardware threads, 7 passes of this render: 0.461
+        # Msamples/s with 256 threads, 0.680 with 128, 0.821 with 64, 0.891 with 32 (profiles/r06_experiments.json) — so it runs with the count
+        # that is fastest there, and `cores` says which)
+        cores = min(os.cpu_count() or 1, args.cpu_threads) if args.cpu_threads > 0 else (os.cpu_count() or 1)
         lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "libppg_oracle.so"))
         cp = args.cpu_passes if args.cpu_passes > 0 else min(args.steps, 20)  # (the GPU's own pass schedule when the render is short enough)
         o = ppg_host.Engine(lib, "ppgo_", budget=float(cp * spp), **{k: v for k, v in props.items() if k != "device"})
@@ -368,8 +371,10 @@ def run(args):
         out["cpu_baseline"] = {"value": args.width * args.height * spp * cp / dtc / 1e6, "unit": "Msamples/s", "cores": cores,
                                "kind": "port", "sample": "first %d passes (%d spp) of the same render(), oracle restatement, OpenMP over 32x32 blocks"
                                % (cp, cp * spp), "seconds": dtc, "one_core": one,
+                               "host_hardware_threads": os.cpu_count(),
                                "note": "a PORT on this box's host cores (brute-force / median-split BVH, software libm: slower than the reference binary was on 16 "
-                                       "cores) — a reported baseline, not the yardstick; the reference's own figure is `reference_log`"}
+                                       "cores), run with the thread count at which it is fastest on this box (--cpu-threads; all 256 hardware threads give half of "
+                                       "it) — a reported baseline, not the yardstick; the reference's own figure is `reference_log`"}
         del og, o
 
     times = None
@@ -556,6 +561,7 @@ def run(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--cpu-threads", type=int, default=32, help="OpenMP threads of the cpu_baseline leg (0 = all hardware threads)")
     ap.add_argument("--steps", type=int, default=127, help="render passes in the timed render() (budget = steps * spp)")
     ap.add_argument("--warmup", type=int, default=3, help="passes of the throw-away warm-up render")
     ap.add_argument("--width", type=int, default=1280)
