@@ -248,3 +248,41 @@ def test_region_rounds_follow_the_reference_log_of_spaceship_improved():
         assert abs(sw[k] / ref[k]["stat_weight"][1] - 1) < 0.06, (k, sw)
     var0, _ = run(0)
     assert var0[1] / ref[1]["var"][0] > 1.5   # the default rounds: the lag this option removes
+
+
+def test_stragglers_invariants_at_the_benchmark_size(monkeypatch):
+    """The stragglers' machinery at the bench's full size (KITCHEN scene-improved, 1280 x 720, 20 passes), where the oracle cannot follow:
+    scheduling-only splits do not show in any result (the final iteration in two launches with stragglers handed over at depth 8; one stream and no
+    split at all: picture, SD-tree, fractions and counters of the default schedule bit for bit), a render with a THIRD of all paths as stragglers
+    (the tests' switch: depth 8) is deterministic from run to run, and it differs from the default one from the first round on only."""
+    import ctypes as C
+    import ppg_host
+    from test_gpu_parity import hip
+    if not os.path.exists(KITCHEN):
+        pytest.skip("scene file not present")
+    scene = ppg_host.load_scene_file(KITCHEN)
+    props = _props(KITCHEN, budget=20.0, seed=1234)
+
+    def run(env, depth=0):
+        with monkeypatch.context() as m:
+            for k, v in env.items():
+                m.setenv(k, v)
+            e = hip(**props)
+        if depth:
+            e._call("debug_set_defer_depth", C.c_int32(depth))
+        g = ppg_host.GuidedPathTracer(engine=e)
+        img = g.render(scene)
+        t = e.read_sdtree()
+        stats = np.array([[s["rays"], s["path_length_sum"], s["vertices_committed"], s["samples"]] for it in g.iterations for s in it["stats"]], np.uint64)
+        return img, t["theta"], t["children"], t["sampling"]["node_sums"], stats
+
+    def same(a, b):
+        return all(np.array_equal(x, y, equal_nan=True) for x, y in zip(a, b))
+
+    base = run({})
+    assert [int(v) for v in base[4][:, 3]] == [1280 * 720 * n for n in (1, 2, 4, 13)]
+    assert same(base, run(dict(PPG_FINAL_HALVES="1", PPG_SPLIT_DEPTH="8")))
+    assert same(base, run(dict(PPG_SPLIT_DEPTH="0", PPG_NO_OVERLAP="1")))
+    d8 = run({}, 8)
+    assert same(d8, run({}, 8))
+    assert not np.array_equal(d8[1], base[1]) and np.array_equal(d8[4][:1], base[4][:1]) and np.array_equal(d8[4][:, 3], base[4][:, 3])
