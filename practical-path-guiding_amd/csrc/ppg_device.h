@@ -247,6 +247,7 @@ struct LdsScene {
 #ifndef PPG_LDS_STACK
 #define PPG_LDS_STACK 24
 #endif
+#define PPG_STACK_OVER (48 - PPG_LDS_STACK)  // entries of a lane's overflow array: LDS column + overflow = 48 entries, whatever the split
 #ifndef PPG_LEAF_VOTE_TAIL
 #define PPG_LEAF_VOTE_TAIL 8  // leaf vote of trace_closest4<.., VOTE> (k_tail: waves are sparsely populated there)
 #endif
@@ -255,13 +256,14 @@ struct LdsScene {
 struct TStack {
     int *lds;      // this lane's column, stride blockDim.x
     int stride;
-    int *over;     // int[24] of the caller
+    int *over;     // int[48 - cap] of the caller
     int sp;
-    D void push(int v) { if (sp < PPG_LDS_STACK) lds[sp * stride] = v; else over[sp - PPG_LDS_STACK] = v; ++sp; }
-    D int pop() { --sp; return sp < PPG_LDS_STACK ? lds[sp * stride] : over[sp - PPG_LDS_STACK]; }
+    int cap;       // rows of the LDS column (PPG_LDS_STACK; k_trace: PPG_TRACE_STACK) — a constant after inlining
+    D void push(int v) { if (sp < cap) lds[sp * stride] = v; else over[sp - cap] = v; ++sp; }
+    D int pop() { --sp; return sp < cap ? lds[sp * stride] : over[sp - cap]; }
     // the children of a node that were hit, farthest first (c1 ends on top): one range check for all three instead of one per push
     D void push_children(int m, int c1, int c2, int c3) {
-        if (sp + 3 <= PPG_LDS_STACK) {
+        if (sp + 3 <= cap) {
             int *q = lds + sp * stride;
             if (m > 3) { *q = c3; q += stride; }
             if (m > 2) { *q = c2; q += stride; }
@@ -372,6 +374,67 @@ D Bvh4Hits bvh4_children(const Bvh4QNode *node, F3 o, F3 id, float mint, float t
     return r;
 }
 
+// (ray, triangle)-PAIR compaction of a wave's leaf phase (k_trace).  When the leaf vote passes, some 16 – 30 lanes of the wave hold a leaf
+// of 1 – 8 triangles; tested lane by lane the wave runs the triangle test max(cnt) times for a quarter of its lanes.  Here the wave lists
+// its (lane, k-th triangle of that lane's leaf) pairs, deals them to ALL its lanes — a lane fetches the owner's ray with ds_bpermute —
+// and runs the test once per 64 pairs.  A pair's result goes to its owner through an LDS minimum on the 64-bit key (bits of t, original
+// index): the order of tri_hit's callers' update rule  t < best.t || (t == best.t && orig < bestOrig)  for t >= 0, so the closest hit is
+// the same bit for bit (every pair is tested against the owner's bound at the time of the vote instead of a bound shrinking inside the
+// leaf: that only admits candidates which lose the minimum).  Wave-synchronous: must be called by all 64 lanes, converged.
+struct PairLds {
+    unsigned long long key[64];  // per owner lane: the best (t, orig) so far
+    float2 uv[64];               // ... and its barycentrics / leaf-order triangle index, written by the lane that holds the minimum
+    int prim[64];
+    unsigned char map[512];      // pair -> owner lane
+};
+// exclusive prefix sum and total of cnt (0..8) over the wave: four ballots
+D void pair_prefix(int cnt, unsigned int &off, unsigned int &total) {
+    off = 0; total = 0;
+#pragma unroll
+    for (int bit = 0; bit < 4; ++bit) {
+        const unsigned long long m = __ballot((cnt >> bit) & 1);
+        off += __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u)) << bit;
+        total += (unsigned int)__popcll(m) << bit;
+    }
+}
+// cnt = this lane's triangles (0 = it holds no leaf), off / total = pair_prefix(cnt)
+D void leaf_pairs(PairLds *W, const float4 *accel, int first, int cnt, unsigned int off, unsigned int total, F3 o, F3 d, float mint, float tmax, Hit &best,
+                  int &bestOrig) {
+    const int lane = threadIdx.x & 63;
+    const bool isLeaf = cnt > 0;
+    const unsigned long long own = ((unsigned long long)__float_as_uint(best.t) << 32) | (unsigned int)bestOrig;
+    for (int k = 0; k < cnt; ++k) W->map[off + k] = (unsigned char)lane;
+    if (isLeaf) W->key[lane] = own;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (unsigned int base = 0; base < total; base += 64) {  // (uniform)
+        const unsigned int p = base + lane;
+        const bool mine = p < total;
+        const int src = mine ? (int)W->map[p] : lane;
+        const int k = (int)(p - __shfl(off, src));
+        const F3 os = f3(__shfl(o.x, src), __shfl(o.y, src), __shfl(o.z, src));
+        const F3 dsv = f3(__shfl(d.x, src), __shfl(d.y, src), __shfl(d.z, src));
+        const float mint_s = __shfl(mint, src), tmax_s = __shfl(tmax, src);
+        const int q = __shfl(first, src) + k;
+        float tt = 0, uu = 0, vv = 0;
+        int orig = 0;
+        const bool hit = mine && tri_hit(accel + 3 * q, os, dsv, mint_s, tmax_s, tt, uu, vv, orig);
+        const unsigned long long key = ((unsigned long long)__float_as_uint(tt) << 32) | (unsigned int)orig;
+        if (hit) atomicMin(&W->key[src], key);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (hit && W->key[src] == key) { W->uv[src] = make_float2(uu, vv); W->prim[src] = q; }  // (keys are unique: a triangle is in one leaf)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    if (isLeaf) {
+        const unsigned long long kk = W->key[lane];
+        if (kk != own) {
+            const float2 uv = W->uv[lane];
+            best.t = __uint_as_float((unsigned int)(kk >> 32)); best.u = uv.x; best.v = uv.y; best.prim = W->prim[lane];
+            bestOrig = (int)(unsigned int)kk;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
 // Closest hit by (t, original primitive index) through the BVH4 — equals brute force (conservative culling).
 // ANY: return at the first triangle hit (shadow rays; only prim >= 0 is meaningful then).
 // VOTE: as in k_trace, lanes holding a leaf wait until PPG_LEAF_VOTE lanes of the wave do (or none has an interior node left) — for callers
@@ -383,9 +446,9 @@ D Hit trace_closest4(const DevScene &S, int *lds_stack_col, int stride, F3 o, F3
     int bestOrig = 0x7fffffff;
     const F3 id = f3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
     TStack st;
-    int st_over[24];
+    int st_over[PPG_STACK_OVER];
     st.over = st_over;
-    st.lds = lds_stack_col; st.stride = stride; st.sp = 0;
+    st.lds = lds_stack_col; st.stride = stride; st.sp = 0; st.cap = PPG_LDS_STACK;
     int cur = 0;
     for (;;) {  // one step per iteration: an interior node or a leaf popped from the stack (see trace_slice_bvh4)
         bool doLeaves = true;
@@ -422,6 +485,9 @@ D Hit trace_closest4(const DevScene &S, int *lds_stack_col, int stride, F3 o, F3
     return best;
 }
 
+#ifndef PPG_PAIR_VOTE
+#define PPG_PAIR_VOTE 32       // k_trace: the leaf phase runs when the wave's leaves hold this many triangles (or no lane has an interior node)
+#endif
 // ONE ray traversed by a whole WAVE (k_tail, when a wave carries only a handful of live paths).  A lone lane's traversal is a chain of
 // ~17 dependent node / leaf fetches, almost every one an L2 miss (the BVH and the triangle records are 70 MB against 4 MB of L2 per XCD):
 // measured 36 k cycles of a lone path's 54 k-cycle bounce.  Here the wave works on up to 16 stack entries at once — four lanes

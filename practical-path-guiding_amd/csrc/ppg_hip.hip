@@ -1465,6 +1465,7 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound, const GroupLaunch *gl =
     const size_t triBytes = (size_t)ctx->scene.n_tris * 48;
     const bool unbounded = ctx->maxDepth < 0;
     const size_t ldsBytes = smallScene ? (size_t)ctx->ldsTris * 48 : (size_t)PPG_LDS_STACK * PPG_BLOCK * 4;
+    const size_t traceLds = smallScene ? ldsBytes : (size_t)PPG_TRACE_STACK * PPG_BLOCK * 4 + (PPG_TRACE_PAIRS ? (PPG_BLOCK / 64) * sizeof(PairLds) : 0);  // k_trace: + a wave's pair scratch
     // live paths below which the wavefront stops (unbounded paths: k_tail takes over; bounded paths: nothing is left)
     const unsigned int stopBelow = unbounded ? (ctx->tailThreshold ? ctx->tailThreshold : std::max(ctx->tailMin, P.n_paths / ctx->tailDiv)) : 1u;
     unsigned int hostCount = P.n_paths;
@@ -1514,9 +1515,9 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound, const GroupLaunch *gl =
         for (int b = 0; b < maxBounces; ++b) {
             if (!fused)
                 timedLaunch(ctx, "k_trace", hostCount, [&] {
-                    if (smallScene) hipLaunchKernelGGL((k_trace<true, false>), dim3(grid), dim3(PPG_BLOCK), ldsBytes, s, P, S, Q, qin, 0, ctx->ldsTris);
-                    else if (ctx->timer.enabled) hipLaunchKernelGGL((k_trace<false, true>), dim3(grid), dim3(PPG_BLOCK), ldsBytes, s, P, S, Q, qin, ctx->ldsNodes, ctx->ldsTris);
-                    else hipLaunchKernelGGL((k_trace<false, false>), dim3(grid), dim3(PPG_BLOCK), ldsBytes, s, P, S, Q, qin, ctx->ldsNodes, ctx->ldsTris);
+                    if (smallScene) hipLaunchKernelGGL((k_trace<true, false>), dim3(grid), dim3(PPG_BLOCK), traceLds, s, P, S, Q, qin, 0, ctx->ldsTris);
+                    else if (ctx->timer.enabled) hipLaunchKernelGGL((k_trace<false, true>), dim3(grid), dim3(PPG_BLOCK), traceLds, s, P, S, Q, qin, ctx->ldsNodes, ctx->ldsTris);
+                    else hipLaunchKernelGGL((k_trace<false, false>), dim3(grid), dim3(PPG_BLOCK), traceLds, s, P, S, Q, qin, ctx->ldsNodes, ctx->ldsTris);
                 });
             int shadeIn = qin;
             // (the first bounce — every path of the batch, camera rays — is sorted only for the sake of the split into material classes)

@@ -376,6 +376,82 @@ D LdsScene stage_scene(const DevScene &S, unsigned char *lds_raw, int lds_nodes,
 // BVH4 traversal of one queue slice with ray replacement: a lane whose ray is finished immediately takes the next
 // entry of the slice (LDS ticket), so a wave stays full until the slice is empty instead of idling until its
 // longest ray is done — secondary rays are incoherent and their traversal lengths differ by an order of magnitude.
+#ifndef PPG_TRACE_PAIRS
+#define PPG_TRACE_PAIRS 1  // k_trace: the leaf phase of a wave tests compacted (ray, triangle) pairs (leaf_pairs, ppg_device.h); 0 = a leaf per lane
+#endif
+#ifndef PPG_TRACE_STACK
+#define PPG_TRACE_STACK (PPG_TRACE_PAIRS ? 12 : 16)  // rows of k_trace's LDS stack columns (with the pair scratch: 19 KB a workgroup, eight to a CU)
+#endif
+#if PPG_TRACE_PAIRS
+// The traversal with (ray, triangle)-pair compaction.  Lanes stay in the loop until the whole wave is out of rays (a lane without a ray
+// still tests other lanes' triangles); per iteration the wave first runs its leaf phase if the vote passes, then the node step of every
+// lane holding an interior node — a lane that popped a node after its leaf takes that step in the same iteration.
+template <bool COUNT>
+D void trace_slice_bvh4(const PathState &P, const DevScene &S, int *lds_stack, unsigned int *ticket, const Work &work,
+                        unsigned int b, unsigned int nb, unsigned int &traced, unsigned long long &n_nodes, unsigned long long &n_tris) {
+    const unsigned int count = work.count;
+    if (threadIdx.x == 0) *ticket = 0;
+    __syncthreads();
+    PairLds *W = reinterpret_cast<PairLds *>(lds_stack + PPG_TRACE_STACK * PPG_BLOCK) + (threadIdx.x >> 6);
+    TStack st;
+    int st_over[48 - PPG_TRACE_STACK];
+    st.over = st_over;
+    st.lds = lds_stack + threadIdx.x; st.stride = PPG_BLOCK; st.sp = 0; st.cap = PPG_TRACE_STACK;
+    bool have = false, done = false;
+    unsigned int i = 0;
+    F3 o = f3s(0.0f), d = f3s(0.0f), id = f3s(0.0f);
+    float mint = 0, maxt = 0;
+    Hit best;
+    best.t = 0; best.u = 0; best.v = 0; best.prim = -1;
+    int bestOrig = 0, cur = PPG_BVH4_EMPTY;
+    for (;;) {
+        if (!have && !done) {
+            unsigned int k = atomicAdd(ticket, 1u);
+            if (k >= count) done = true;
+            else {
+                i = work_item(work, k, b, nb);
+                if (i < P.n_paths) {
+                    float4 ro = P.ray_o[i], rd = P.ray_d[i];
+                    o = f3(ro.x, ro.y, ro.z); d = f3(rd.x, rd.y, rd.z);
+                    mint = ro.w; maxt = rd.w;
+                    if (mint == PPG_EPSILON)  // adaptive ray epsilon
+                        mint *= ppg_max(ppg_max(ppg_max(ppg_abs(o.x), ppg_abs(o.y)), ppg_abs(o.z)), PPG_EPSILON);
+                    id = f3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
+                    best.t = __builtin_inff(); best.u = 0; best.v = 0; best.prim = -1;
+                    bestOrig = 0x7fffffff; cur = 0; st.sp = 0;
+                    have = true;
+                }
+            }
+        }
+        if (__ballot(!done) == 0ull) break;
+        const bool isLeaf = have && cur < 0;
+        const int code = ~cur;
+        const int first = code >> 3, cnt = isLeaf ? (code & 7) + 1 : 0;
+        unsigned int off, total;
+        pair_prefix(cnt, off, total);
+        if (total >= PPG_PAIR_VOTE || (total != 0u && __ballot(have && cur >= 0) == 0ull)) {  // (uniform)
+            if (COUNT) n_tris += (unsigned long long)cnt;
+            leaf_pairs(W, S.accel, first, cnt, off, total, o, d, mint, fminf(maxt, best.t), best, bestOrig);
+            if (isLeaf) cur = st.sp > 0 ? st.pop() : PPG_BVH4_EMPTY;
+        }
+        if (have && cur >= 0 && cur != PPG_BVH4_EMPTY) {
+            if (COUNT) ++n_nodes;
+            const Bvh4Hits hc = bvh4_children(S.bvh4 + cur, o, id, mint, fminf(maxt, best.t));
+            if (hc.m > 0) {
+                st.push_children(hc.m, hc.c1, hc.c2, hc.c3);
+                cur = hc.c0;
+            } else cur = st.sp > 0 ? st.pop() : PPG_BVH4_EMPTY;
+        }
+        if (have && cur == PPG_BVH4_EMPTY) {  // stack empty: this ray is done
+            if (S.n_spheres) sphere_pass<false>(S, o, d, mint, maxt, best);
+            P.hit[i] = make_float4(best.t, best.u, best.v, __int_as_float(best.prim));
+            ++traced;
+            have = false;
+        }
+    }
+    __syncthreads();
+}
+#else
 template <bool COUNT>
 D void trace_slice_bvh4(const PathState &P, const DevScene &S, int *lds_stack, unsigned int *ticket, const Work &work,
                         unsigned int b, unsigned int nb, unsigned int &traced, unsigned long long &n_nodes, unsigned long long &n_tris) {
@@ -383,9 +459,9 @@ D void trace_slice_bvh4(const PathState &P, const DevScene &S, int *lds_stack, u
     if (threadIdx.x == 0) *ticket = 0;
     __syncthreads();
     TStack st;
-    int st_over[24];
+    int st_over[48 - PPG_TRACE_STACK];
     st.over = st_over;
-    st.lds = lds_stack + threadIdx.x; st.stride = PPG_BLOCK; st.sp = 0;
+    st.lds = lds_stack + threadIdx.x; st.stride = PPG_BLOCK; st.sp = 0; st.cap = PPG_TRACE_STACK;
     bool have = false;
     unsigned int i = 0;
     F3 o = f3s(0.0f), d = f3s(0.0f), id = f3s(0.0f);
@@ -452,6 +528,7 @@ D void trace_slice_bvh4(const PathState &P, const DevScene &S, int *lds_stack, u
     }
     __syncthreads();
 }
+#endif
 
 // trace the rays of one queue slice
 template <bool SMALL, bool COUNT>
@@ -478,6 +555,11 @@ D void trace_slice(const PathState &P, const DevScene &S, const LdsScene &L, int
 }
 
 // SMALL: the whole scene (<= 64 triangles) is tested from LDS without a BVH.
+// (with the pair compaction the kernel would take 72 VGPRs and seven waves a SIMD; held to 64 and eight it spills nothing and was measured
+// 1.3 % (20 passes) / 1.7 % (127) faster on KITCHEN — profiles/r06_experiments.json)
+#if !defined(PPG_TRACE_WAVES) && PPG_TRACE_PAIRS
+#define PPG_TRACE_WAVES 8
+#endif
 template <bool SMALL, bool COUNT = false>
 #ifdef PPG_TRACE_WAVES
 __attribute__((amdgpu_waves_per_eu(PPG_TRACE_WAVES, PPG_TRACE_WAVES)))
