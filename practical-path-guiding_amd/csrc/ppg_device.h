@@ -488,6 +488,62 @@ D Hit trace_closest4(const DevScene &S, int *lds_stack_col, int stride, F3 o, F3
 #ifndef PPG_PAIR_VOTE
 #define PPG_PAIR_VOTE 32       // k_trace: the leaf phase runs when the wave's leaves hold this many triangles (or no lane has an interior node)
 #endif
+// trace_closest4<false, SPH, VOTE> that can be SUSPENDED (k_tail's crowd phase).  A wave's lanes trace one ray each and the lengths of
+// the traversals differ by an order of magnitude: without this the wave waits for its longest ray with most lanes idle.  When no more than
+// `suspend_lanes` lanes are still traversing (of more than twice as many that began), they park their state — node / leaf at hand, stack
+// pointer, original index of the best hit in `park`, the best hit in `best`, the stack where it is, in the lane's LDS column — and return
+// false; the caller shades the other lanes' hits and calls again with resume = true together with those lanes' next rays: a long ray spans
+// several rounds of the wave instead of holding one up.  A lane whose stack has overflowed into its private array is waited for (rare).
+// The closest hit is the same bit for bit: the traversal is the same, only interleaved differently with other lanes' work.
+#ifndef PPG_TAIL_SUSPEND
+#define PPG_TAIL_SUSPEND 8
+#endif
+template <bool SPH>
+D bool trace_closest4_resume(const DevScene &S, int *lds_stack_col, int stride, F3 o, F3 d, float mint, float maxt, bool resume, int *park, int pstride,
+                             Hit &best, int suspend_lanes) {
+    int bestOrig = 0x7fffffff, cur = 0;
+    const F3 id = f3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
+    TStack st;
+    int st_over[PPG_STACK_OVER];
+    st.over = st_over;
+    st.lds = lds_stack_col; st.stride = stride; st.sp = 0; st.cap = PPG_LDS_STACK;
+    if (resume) { cur = park[0]; st.sp = park[pstride]; bestOrig = park[2 * pstride]; }
+    else { best.t = __builtin_inff(); best.u = 0; best.v = 0; best.prim = -1; }
+    const int n0 = (int)__popcll(__ballot(true));
+    for (;;) {
+        const unsigned long long leafLanes = __ballot(cur < 0), nodeLanes = __ballot(cur >= 0);
+        if (suspend_lanes && n0 > 2 * suspend_lanes && (int)__popcll(leafLanes | nodeLanes) <= suspend_lanes && __ballot(st.sp > PPG_LDS_STACK) == 0ull) {
+            park[0] = cur; park[pstride] = st.sp; park[2 * pstride] = bestOrig;
+            return false;
+        }
+        const bool doLeaves = __popcll(leafLanes) >= PPG_LEAF_VOTE_TAIL || nodeLanes == 0ull;
+        if (cur >= 0) {
+            const Bvh4Hits hc = bvh4_children(S.bvh4 + cur, o, id, mint, fminf(maxt, best.t));
+            if (hc.m > 0) {
+                st.push_children(hc.m, hc.c1, hc.c2, hc.c3);
+                cur = hc.c0;
+            } else {
+                if (st.sp == 0) break;
+                cur = st.pop();
+            }
+        } else if (doLeaves) {
+            const int code = ~cur;
+            const int first = code >> 3, cnt = (code & 7) + 1;
+            for (int q = first; q < first + cnt; ++q) {
+                float tt, uu, vv;
+                int orig;
+                if (tri_hit(S.accel + 3 * q, o, d, mint, fminf(maxt, best.t), tt, uu, vv, orig)) {
+                    if (tt < best.t || (tt == best.t && orig < bestOrig)) { best.t = tt; best.u = uu; best.v = vv; best.prim = q; bestOrig = orig; }
+                }
+            }
+            if (st.sp == 0) break;
+            cur = st.pop();
+        }
+    }
+    if (SPH && S.n_spheres) sphere_pass<false>(S, o, d, mint, maxt, best);
+    return true;
+}
+
 // ONE ray traversed by a whole WAVE (k_tail, when a wave carries only a handful of live paths).  A lone lane's traversal is a chain of
 // ~17 dependent node / leaf fetches, almost every one an L2 miss (the BVH and the triangle records are 70 MB against 4 MB of L2 per XCD):
 // measured 36 k cycles of a lone path's 54 k-cycle bounce.  Here the wave works on up to 16 stack entries at once — four lanes

@@ -696,7 +696,7 @@ struct ppg_ctx {
     int tuneFinalBatch = 0;           // PPG_FINAL_BATCH: passes per batch of the final iteration (0 = 64)
     int tuneTailBlocks = 0;           // PPG_TAIL_BLOCKS: workgroups of k_tail when k_commit runs beside it (0 = automatic)
     int tunePathLayout = 0;           // PPG_PATH_LAYOUT = soa | aos | pack: layout of the per-path state (0 = automatic, allocPaths)
-    int tuneBvhLeaf = 3;              // PPG_BVH_LEAF: triangles per BVH leaf (1..8).  KITCHEN 720p, driver's command: 4 -> 3 +3.5 % once the node test had become
+    int tuneBvhLeaf = 4;              // PPG_BVH_LEAF: triangles per BVH leaf (1..8).  KITCHEN 720p, driver's command: 4 -> 3 +3.5 % once the node test had become
                                       // cheap (130.9 -> 135.6, A/B on one box; with the world-space decode 2 / 3 / 4 / 6 / 8 gave 125.8 / 125.9 / 124.5 / 119.6 / 115.2)
     float tuneBvhPad = 2e-6f;         // PPG_BVH_PAD: box padding relative to the scene extent
     DevBuf<unsigned int> d_leaves, d_counts, d_offsets, d_grid;

@@ -1416,6 +1416,7 @@ __global__ __launch_bounds__(PPG_BLOCK, (FULL ? PPG_SHADE_WAVES_FULL : PPG_SHADE
                                                                     int lds_tris, unsigned int *longest, StragOut so, unsigned int lane_limit) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __shared__ float pdf_factors[20 * PPG_BLOCK];
+    __shared__ int trace_park[3 * PPG_BLOCK];  // a suspended traversal's (entry at hand, stack pointer, original index of the best hit): trace_closest4_resume
     __shared__ unsigned long long acc;
 #ifdef PPG_PROBE
     __shared__ unsigned long long probe_lds[PPG_PROBE_SLOTS];
@@ -1436,6 +1437,7 @@ __global__ __launch_bounds__(PPG_BLOCK, (FULL ? PPG_SHADE_WAVES_FULL : PPG_SHADE
     // (lane_limit < 64: a launch over a FEW paths — the stragglers' — deals them thinly, lane_limit paths per wave, so that every one of them
     // runs at the speed of a lone path (cooperative traversal, no union of branches) instead of 64 of them sharing a wave)
     bool have = false, drained = (unsigned int)lane >= lane_limit;
+    bool pending = false;  // this lane's traversal is suspended (its path sits out the shading of this iteration)
     unsigned int i = 0;
     Carried cs;
     cs.misc = make_uint4(0u, 0u, 0u, 0u);
@@ -1460,7 +1462,7 @@ __global__ __launch_bounds__(PPG_BLOCK, (FULL ? PPG_SHADE_WAVES_FULL : PPG_SHADE
             if (!have && !drained) {
                 const unsigned int k = base + (unsigned int)__popcll(need & ((1ull << lane) - 1ull));
                 if (k < total) {
-                    i = dense[k]; have = true;
+                    i = dense[k]; have = true; pending = false;
                     cs.misc = P.misc[i]; cs.thr = P.thr[i]; cs.li = P.li[i]; cs.ro = P.ray_o[i]; cs.rd = P.ray_d[i];
                 } else drained = true;
             }
@@ -1485,7 +1487,7 @@ __global__ __launch_bounds__(PPG_BLOCK, (FULL ? PPG_SHADE_WAVES_FULL : PPG_SHADE
                     r[5] = make_float4(__uint_as_float(cs.misc.x), __uint_as_float(cs.misc.y), __uint_as_float(cs.misc.z), __uint_as_float(cs.misc.w));
                     so.orig[j] = i;
                     P.misc[i] = make_uint4(cs.misc.x, cs.misc.y, cs.misc.z & ~FL_NV_MASK, cs.misc.w);
-                    have = false;
+                    have = false; pending = false;  // (a suspended traversal is not carried over: the stragglers' launch traces the ray anew)
                 }
             }
         }
@@ -1514,6 +1516,7 @@ __global__ __launch_bounds__(PPG_BLOCK, (FULL ? PPG_SHADE_WAVES_FULL : PPG_SHADE
                 const Hit h = trace_closest4_wave(S, (int *)lds_raw + (threadIdx.x & ~63), PPG_BLOCK, o, d, mint, maxt);
 #endif
                 if (lane == src) {
+                    pending = false;  // (a suspended traversal is dropped: the wave has traced the ray from its origin)
                     Hit hs = h;
                     if (h.prim == -2) hs = trace_closest4<false, true, false>(S, nee.stack_col, PPG_BLOCK, o, d, mint, maxt);  // wave stack overrun: this lane alone
                     cs.hit = make_float4(hs.t, hs.u, hs.v, __int_as_float(hs.prim)); ++traced;
@@ -1534,14 +1537,17 @@ __global__ __launch_bounds__(PPG_BLOCK, (FULL ? PPG_SHADE_WAVES_FULL : PPG_SHADE
                 float mint = ro.w;
                 if (mint == PPG_EPSILON)  // adaptive ray epsilon, skdtree.cpp:125-129
                     mint *= ppg_max(ppg_max(ppg_max(ppg_abs(o.x), ppg_abs(o.y)), ppg_abs(o.z)), PPG_EPSILON);
-                h = trace_closest4<false, true, true>(S, nee.stack_col, PPG_BLOCK, o, d, mint, rd.w);
+                if (pending) { h.t = cs.hit.x; h.u = cs.hit.y; h.v = cs.hit.z; h.prim = __float_as_int(cs.hit.w); }
+                pending = !trace_closest4_resume<true>(S, nee.stack_col, PPG_BLOCK, o, d, mint, rd.w, pending, trace_park + threadIdx.x, PPG_BLOCK, h, PPG_TAIL_SUSPEND);
             }
-            if (!traced_coop) { cs.hit = make_float4(h.t, h.u, h.v, __int_as_float(h.prim)); ++traced; }
-            unsigned long long plen = 0;
-            const bool alive = shade_one<false, NEE, FULL, true>(P, S, T, R, i, fcol, L.tris, plen, traced, nee, committed, &cs);
-            plen_sum += plen;
-            if (plen > plen_max) plen_max = plen;
-            if (!alive) have = false;
+            if (!traced_coop) { cs.hit = make_float4(h.t, h.u, h.v, __int_as_float(h.prim)); if (!pending) ++traced; }
+            if (!pending) {
+                unsigned long long plen = 0;
+                const bool alive = shade_one<false, NEE, FULL, true>(P, S, T, R, i, fcol, L.tris, plen, traced, nee, committed, &cs);
+                plen_sum += plen;
+                if (plen > plen_max) plen_max = plen;
+                if (!alive) have = false;
+            }
         }
         PROBE_MARK(&cs, 10);
 #ifdef PPG_PROBE
