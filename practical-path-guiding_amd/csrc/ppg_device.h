@@ -249,7 +249,8 @@ struct LdsScene {
 #endif
 #define PPG_STACK_OVER (48 - PPG_LDS_STACK)  // entries of a lane's overflow array: LDS column + overflow = 48 entries, whatever the split
 #ifndef PPG_LEAF_VOTE_TAIL
-#define PPG_LEAF_VOTE_TAIL 8  // leaf vote of trace_closest4<.., VOTE> (k_tail: waves are sparsely populated there)
+#define PPG_LEAF_VOTE_TAIL 16  // leaf vote of k_tail's traversals (trace_closest4<.., VOTE>, trace_closest4_resume).  8 until leaves held up to 4 triangles
+                               // and a wave's last traversals were suspended (round 6: 16 +0.8 %, 24 +0.4 % on the driver's command)
 #endif
 // (the overflow array is a separate object: as a member it kept the whole struct — stack pointer included — in scratch memory, and
 // every push / pop went through a scratch load and store)
@@ -553,7 +554,8 @@ D bool trace_closest4_resume(const DevScene &S, int *lds_stack_col, int stride, 
 // per-lane walk, which costs nothing in a wave that would otherwise idle.  Same box arithmetic, same triangle test, same (t, original
 // index) minimum as trace_closest4, so the hit is the same bit for bit.  Must be called by all 64 lanes with identical arguments.
 #ifndef PPG_COOP_MAX
-#define PPG_COOP_MAX 6  // live lanes of a wave up to which k_tail traces cooperatively (measured per-iteration cycles, §7: 1 lane 36 k per-lane vs ~14 k)
+#define PPG_COOP_MAX 16  // live lanes of a wave up to which k_tail traces cooperatively (measured per-iteration cycles, §7: 1 lane 36 k per-lane vs ~14 k).
+                         // 6 until round 6; with the suspended traversals (which need more than 2 x PPG_TAIL_SUSPEND lanes) 10 and 16 measured +0.7 / +0.9 %
 #endif
 D Hit trace_closest4_wave(const DevScene &S, int *wave_stack /* this wave's column 0 */, int stride, F3 o, F3 d, float mint, float maxt,
                           int *probe_steps = nullptr) {
