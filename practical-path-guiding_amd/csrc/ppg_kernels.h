@@ -398,6 +398,7 @@ D void trace_slice_bvh4(const PathState &P, const DevScene &S, int *lds_stack, u
     st.over = st_over;
     st.lds = lds_stack + threadIdx.x; st.stride = PPG_BLOCK; st.sp = 0; st.cap = PPG_TRACE_STACK;
     bool have = false, done = false;
+    unsigned int w_nodes = 0, w_tris = 0;  // COUNT: this WAVE's node steps and triangle tests (uniform: the timed kernel keeps the registers of the other)
     unsigned int i = 0;
     F3 o = f3s(0.0f), d = f3s(0.0f), id = f3s(0.0f);
     float mint = 0, maxt = 0;
@@ -430,12 +431,13 @@ D void trace_slice_bvh4(const PathState &P, const DevScene &S, int *lds_stack, u
         unsigned int off, total;
         pair_prefix(cnt, off, total);
         if (total >= PPG_PAIR_VOTE || (total != 0u && __ballot(have && cur >= 0) == 0ull)) {  // (uniform)
-            if (COUNT) n_tris += (unsigned long long)cnt;
+            if (COUNT) w_tris += total;
             leaf_pairs(W, S.accel, first, cnt, off, total, o, d, mint, fminf(maxt, best.t), best, bestOrig);
             if (isLeaf) cur = st.sp > 0 ? st.pop() : PPG_BVH4_EMPTY;
         }
-        if (have && cur >= 0 && cur != PPG_BVH4_EMPTY) {
-            if (COUNT) ++n_nodes;
+        const bool nodeStep = have && cur >= 0 && cur != PPG_BVH4_EMPTY;
+        if (COUNT) w_nodes += (unsigned int)__popcll(__ballot(nodeStep));
+        if (nodeStep) {
             const Bvh4Hits hc = bvh4_children(S.bvh4 + cur, o, id, mint, fminf(maxt, best.t));
             if (hc.m > 0) {
                 st.push_children(hc.m, hc.c1, hc.c2, hc.c3);
@@ -449,6 +451,7 @@ D void trace_slice_bvh4(const PathState &P, const DevScene &S, int *lds_stack, u
             have = false;
         }
     }
+    if (COUNT && (threadIdx.x & 63) == 0) { n_nodes += w_nodes; n_tris += w_tris; }
     __syncthreads();
 }
 #else
