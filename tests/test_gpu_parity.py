@@ -303,7 +303,7 @@ def test_tuning_switches_do_not_change_results(monkeypatch):
                 dict(PPG_NO_TOPCUT="1"), dict(PPG_NO_OVERLAP="1"), dict(PPG_NO_SORT="1"), dict(PPG_TAIL_MIN="1", PPG_TAIL_DIV="1000000"),
                 dict(PPG_TAIL_THRESHOLD="100000000"), dict(PPG_BLOCKS="512"), dict(PPG_BATCH_PATHS="20000"), dict(PPG_TAIL_BLOCKS="64"),
                 dict(PPG_BULK_BOUNCES="0"), dict(PPG_BULK_BOUNCES="3"), dict(PPG_BOUNCE_MARGIN="0"), dict(PPG_TAIL_MIN="200", PPG_TAIL_DIV="1000000"),
-                dict(PPG_BVH_LEAF="4"), dict(PPG_NO_SORTED_COMMIT="1"), dict(PPG_ADAM_UNORDERED="1"), dict(PPG_SPLAT_LDS_NODES="4"), dict(PPG_NO_ASIDE="1"),
+                dict(PPG_BVH_LEAF="3"), dict(PPG_BVH_LEAF="8"), dict(PPG_NO_SORTED_COMMIT="1"), dict(PPG_ADAM_UNORDERED="1"), dict(PPG_SPLAT_LDS_NODES="4"), dict(PPG_NO_ASIDE="1"),
                 dict(PPG_SPLIT_DEPTH="0"), dict(PPG_SPLIT_DEPTH="6"), dict(PPG_FINAL_HALVES="1", PPG_SPLIT_DEPTH="4"), dict(PPG_SPLIT_DEPTH="6", PPG_NO_OVERLAP="1"), dict(PPG_SPLIT_DEPTH="2", PPG_BULK_BOUNCES="5")):
         with monkeypatch.context() as m:
             for k, v in env.items():
@@ -393,6 +393,41 @@ def test_stragglers_phase_calls_and_time_budget(oracle_lib):
     e._call("debug_set_defer_depth", C.c_int32(6))
     img = ppg_host.GuidedPathTracer(engine=e).render(scene)
     assert np.isfinite(img).all() and img.mean() > 1e-3
+
+
+@pytest.mark.parametrize("leaf,depth", [(8, 6), (1, 6), (8, -1), (3, -1)])
+def test_closest_hit_with_coincident_triangles_and_full_leaves_against_oracle(oracle_lib, monkeypatch, leaf, depth):
+    """k_trace tests compacted (ray, triangle) pairs: the wave's leaves are dealt to all its lanes and a pair's result reaches its ray
+    through an LDS minimum on (t, original index) (leaf_pairs, ppg_device.h); k_tail suspends a wave's last traversals and resumes them
+    beside the lanes' next rays (trace_closest4_resume).  The closest hit must stay the reference's — the FIRST of several triangles hit at the
+    same distance (skdtree.cpp:112-142 visits a leaf's triangles in order and keeps a hit only if it is closer).  Every box of the scene is
+    there TWICE, the copy with another material and its triangles in reverse order, so that every hit on a box is a tie whose loser shows
+    in the picture; leaves of 8 triangles make a wave collect more than 64 pairs (several rounds), leaves of 1 the other extreme.
+    Bounded paths run in k_trace only, unbounded ones mostly in k_tail (the batches are smaller than its hand-over threshold)."""
+    import ppg_host
+    scene = ppg_host.room_scene(96, 54, n_boxes=50, tess=2, glossy=True)
+    idx, mat, em = np.asarray(scene.indices).reshape(-1, 3), np.asarray(scene.tri_material), np.asarray(scene.tri_emitter)
+    boxes = np.arange(24, len(idx))  # (the room itself is the first 24 triangles)
+    nmat = len(scene.materials)
+    twin_mat = np.where(mat[boxes] == nmat - 1, nmat - 3, mat[boxes] + 1).astype(mat.dtype)  # b0 -> b1 -> b2 -> b0: metal / plastic / diffuse swap
+    scene.indices = np.concatenate([idx, idx[boxes][::-1]]).astype(idx.dtype)
+    scene.tri_material = np.concatenate([mat, twin_mat[::-1]])
+    scene.tri_emitter = np.concatenate([em, em[boxes][::-1]])
+    monkeypatch.setenv("PPG_BVH_LEAF", str(leaf))
+    props = dict(budgetType="spp", budget=31, maxDepth=depth, rrDepth=4, strictNormals=1, seed=41, **IMPROVED)
+    g, o = hip(**props), make_oracle(oracle_lib, threads=min(32, os.cpu_count() or 8), **props)
+    gg, go = ppg_host.GuidedPathTracer(engine=g), ppg_host.GuidedPathTracer(engine=o)
+    ig, io = gg.render(scene), go.render(scene)
+    assert _stats(gg) == _stats(go)
+    assert np.isfinite(ig).all() and ig.mean() > 1e-3
+    assert np.array_equal(ig, io)
+    assert_tree_equal(g.read_sdtree(), o.read_sdtree())
+    # ... and the tie rule is visible: with the copies FIRST the picture is another one
+    order = np.concatenate([np.arange(24), np.arange(len(idx), len(scene.indices)), boxes])
+    scene.indices, scene.tri_material, scene.tri_emitter = scene.indices[order], scene.tri_material[order], scene.tri_emitter[order]
+    g2 = hip(**props)
+    i2 = ppg_host.GuidedPathTracer(engine=g2).render(scene)
+    assert not np.array_equal(i2, ig)
 
 
 @pytest.mark.parametrize("dfilter", ["nearest", "box"])
