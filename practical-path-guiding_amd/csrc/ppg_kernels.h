@@ -28,6 +28,10 @@
                                 // spills 257 of them (KITCHEN 720p: 4 waves 76.5, 3 waves 81.3, 2 waves 79.6 Msamples/s)
 #endif
 
+#ifndef PPG_TAIL_WAVES_FULL
+#define PPG_TAIL_WAVES_FULL PPG_SHADE_WAVES_FULL  // ... for k_tail<.., FULL> on its own
+#endif
+
 #ifndef PPG_SHADE_WAVES_COMMON
 #define PPG_SHADE_WAVES_COMMON 3  // ... for k_shade<.., FULL, MSET_COMMON>: the common lobes of a FULL scene (see MSET_COMMON)
 #endif
@@ -1414,7 +1418,7 @@ __global__ __launch_bounds__(PPG_BLOCK, (MSET == MSET_COMMON ? PPG_SHADE_WAVES_C
 // "one lane per path, until it ends" beat every re-compaction of the survivors into dense waves that was tried (generations of launches
 // on shrinking or on full grids, tails on side streams beside the next sub-batch's wavefront: profiles/r03_tail_experiments.json).
 template <bool SMALL, bool NEE, bool FULL>
-__global__ __launch_bounds__(PPG_BLOCK, (FULL ? PPG_SHADE_WAVES_FULL : PPG_SHADE_WAVES)) void k_tail(PathState P, DevScene S, DevTree T, RenderParams R, const unsigned int *dense,
+__global__ __launch_bounds__(PPG_BLOCK, (FULL ? PPG_TAIL_WAVES_FULL : PPG_SHADE_WAVES)) void k_tail(PathState P, DevScene S, DevTree T, RenderParams R, const unsigned int *dense,
                                                                     const unsigned long long *total_ptr, unsigned int *ticket, BlockStats *stats,
                                                                     int lds_tris, unsigned int *longest, StragOut so, unsigned int lane_limit) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
