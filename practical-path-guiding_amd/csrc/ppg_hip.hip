@@ -696,6 +696,7 @@ struct ppg_ctx {
     int tuneFinalBatch = 0;           // PPG_FINAL_BATCH: passes per batch of the final iteration (0 = 64)
     int tuneTailBlocks = 0;           // PPG_TAIL_BLOCKS: workgroups of k_tail when k_commit runs beside it (0 = automatic)
     int tunePathLayout = 0;           // PPG_PATH_LAYOUT = soa | aos | pack: layout of the per-path state (0 = automatic, allocPaths)
+    bool tuneSortKernel = false;      // PPG_SORT_KERNEL=1: the BSDF-type sort of the queue slices as a launch of its own (k_sort_slices) instead of inside k_trace
     int tuneBvhLeaf = 4;              // PPG_BVH_LEAF: triangles per BVH leaf (1..8).  KITCHEN 720p, driver's command: 4 -> 3 +3.5 % once the node test had become
                                       // cheap (130.9 -> 135.6, A/B on one box; with the world-space decode 2 / 3 / 4 / 6 / 8 gave 125.8 / 125.9 / 124.5 / 119.6 / 115.2)
     float tuneBvhPad = 2e-6f;         // PPG_BVH_PAD: box padding relative to the scene extent
@@ -1513,18 +1514,24 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound, const GroupLaunch *gl =
         Q.stop = counts + 64;
         Q.dense_n = ctx->d_total.p;
         for (int b = 0; b < maxBounces; ++b) {
+            // (the first bounce — every path of the batch, camera rays — is sorted only for the sake of the split into material classes)
+            const bool sortSlices = fullMats && !fused && (qin == QIN_DENSE || (Q.n_common && !neeOn && !ctx->tuneNoSortFirst)) && ctx->d_queueSorted.p;
+            // k_trace sorts its own slices when it has traced them (sort_slice, ppg_kernels.h); PPG_SORT_KERNEL=1: k_sort_slices as a launch of its own
+            const bool sortInTrace = sortSlices && !ctx->tuneSortKernel;
+            unsigned int *const trSorted = sortInTrace ? ctx->d_queueSorted.p : nullptr;
+            unsigned char *const trKeys = sortInTrace ? ctx->d_sortKeys.p : nullptr;
             if (!fused)
                 timedLaunch(ctx, "k_trace", hostCount, [&] {
-                    if (smallScene) hipLaunchKernelGGL((k_trace<true, false>), dim3(grid), dim3(PPG_BLOCK), traceLds, s, P, S, Q, qin, 0, ctx->ldsTris);
-                    else if (ctx->timer.enabled) hipLaunchKernelGGL((k_trace<false, true>), dim3(grid), dim3(PPG_BLOCK), traceLds, s, P, S, Q, qin, ctx->ldsNodes, ctx->ldsTris);
-                    else hipLaunchKernelGGL((k_trace<false, false>), dim3(grid), dim3(PPG_BLOCK), traceLds, s, P, S, Q, qin, ctx->ldsNodes, ctx->ldsTris);
+                    if (smallScene) hipLaunchKernelGGL((k_trace<true, false>), dim3(grid), dim3(PPG_BLOCK), traceLds, s, P, S, Q, qin, 0, ctx->ldsTris, trSorted, trKeys);
+                    else if (ctx->timer.enabled) hipLaunchKernelGGL((k_trace<false, true>), dim3(grid), dim3(PPG_BLOCK), traceLds, s, P, S, Q, qin, ctx->ldsNodes, ctx->ldsTris, trSorted, trKeys);
+                    else hipLaunchKernelGGL((k_trace<false, false>), dim3(grid), dim3(PPG_BLOCK), traceLds, s, P, S, Q, qin, ctx->ldsNodes, ctx->ldsTris, trSorted, trKeys);
                 });
             int shadeIn = qin;
-            // (the first bounce — every path of the batch, camera rays — is sorted only for the sake of the split into material classes)
-            if (fullMats && !fused && (qin == QIN_DENSE || (Q.n_common && !neeOn && !ctx->tuneNoSortFirst)) && ctx->d_queueSorted.p) {
-                timedLaunch(ctx, "k_sort_slices", hostCount, [&] {
-                    hipLaunchKernelGGL(k_sort_slices, dim3(grid), dim3(PPG_BLOCK), 0, s, P, S, Q, qin, ctx->d_queueSorted.p, ctx->d_sortKeys.p);
-                });
+            if (sortSlices) {
+                if (!sortInTrace)
+                    timedLaunch(ctx, "k_sort_slices", hostCount, [&] {
+                        hipLaunchKernelGGL(k_sort_slices, dim3(grid), dim3(PPG_BLOCK), 0, s, P, S, Q, qin, ctx->d_queueSorted.p, ctx->d_sortKeys.p);
+                    });
                 shadeIn = QIN_SORTED;
             }
             ctx->joinTree();  // (k_generate, the first k_trace and k_sort_slices ran beside the previous round's optimiser: k_shade needs its result)
@@ -2354,6 +2361,7 @@ int ppg_create(const ppg_config *cfg, ppg_ctx **out) {
         if (const char *e = getenv("PPG_TAIL_BLOCKS")) c->tuneTailBlocks = std::max(1, atoi(e));
         if (const char *e = getenv("PPG_FINAL_BATCH")) c->tuneFinalBatch = std::max(1, atoi(e));
         if (const char *e = getenv("PPG_PATH_LAYOUT")) c->tunePathLayout = !strcmp(e, "aos") ? 2 : (!strcmp(e, "pack") ? 3 : (!strcmp(e, "soa") ? 1 : 0));
+        if (const char *e = getenv("PPG_SORT_KERNEL")) c->tuneSortKernel = atoi(e) != 0;
         if (const char *e = getenv("PPG_BVH_LEAF")) c->tuneBvhLeaf = std::max(1, std::min(8, atoi(e)));
         if (const char *e = getenv("PPG_BVH_PAD")) c->tuneBvhPad = (float)atof(e);
         if (const char *e = getenv("PPG_SPLIT_DEPTH")) c->tuneSplitDepth = std::max(0, atoi(e));

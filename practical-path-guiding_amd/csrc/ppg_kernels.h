@@ -537,6 +537,69 @@ D void trace_slice_bvh4(const PathState &P, const DevScene &S, int *lds_stack, u
 }
 #endif
 
+// The counting sort of one workgroup's queue slice by the BSDF type at the new hit (see k_sort_slices below, which is this function as a
+// kernel).  Since round 6 k_trace runs it for its own slice when the slice is traced: one launch per bounce fewer, and a workgroup that
+// waits for its three dependent loads per ray (hit -> triangle -> material) does so while the CU's other workgroups still trace.
+struct SortArgs {
+    Field<float4> hit;
+    const float4 *tris, *materials;
+    unsigned int *out;        // this workgroup's slice of the sorted list
+    unsigned char *kk;        // ... and of the key scratch
+    unsigned int *count1, *n_common;  // this workgroup's entries
+    BlockStats *stats;
+    unsigned int n_paths;
+    int n_tris;
+};
+D SortArgs sort_args(const PathState &P, const DevScene &S, const Queues &Q, unsigned int b, unsigned int *sorted, unsigned char *keys) {
+    SortArgs a;
+    a.hit = P.hit; a.tris = S.tris; a.materials = S.materials;
+    a.out = sorted + (size_t)b * Q.cap; a.kk = keys + (size_t)b * Q.cap;
+    a.count1 = Q.count[1] + b; a.n_common = Q.n_common ? Q.n_common + b : nullptr; a.stats = Q.stats + b;
+    a.n_paths = P.n_paths; a.n_tris = S.n_tris;
+    return a;
+}
+D void sort_slice(const SortArgs &a, const Work &work, unsigned int b, unsigned int nb, unsigned int *hist, unsigned int *offs) {
+    if (threadIdx.x < 16) hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (unsigned int k = threadIdx.x; k < work.count; k += blockDim.x) {
+        const unsigned int i = work_item(work, k, b, nb);
+        unsigned int key = 255u;  // no path at this position (partial last chunk)
+        if (i < a.n_paths) {
+            // bins 0..7: the COMMON classes (MSET_COMMON), by BSDF type; 8..15: everything else — by type, then bump-mapped or masked
+            // surfaces, spheres, and last the rays that left the scene
+            const int prim = __float_as_int(a.hit[i].w);
+            key = 15u;
+            if (prim >= 0) {
+                if (prim >= a.n_tris) key = 14u;
+                else {
+                    const int m = __float_as_int(a.tris[3 * (size_t)prim].w);
+                    const float4 *mr = a.materials + PPG_MAT_STRIDE * (size_t)m;
+                    const int type = (int)mr[0].w, flags = __float_as_int(mr[2].w);
+                    const unsigned int tex = __float_as_uint(mr[5].x);
+                    if ((flags & PPG_MAT_MASK) || (tex >> 16)) key = 13u;
+                    else if (mset_common_type(type)) key = type == PPG_BSDF_ROUGHPLASTIC ? 6u : (unsigned int)type;  // 0..6
+                    else key = 8u + ((unsigned int)type & 3u);  // dielectric 10, thin dielectric 11, rough dielectric 8
+                }
+            }
+            atomicAdd(&hist[key], 1u);
+        }
+        a.kk[k] = (unsigned char)key;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int acc = 0;
+        for (int j = 0; j < 16; ++j) { offs[j] = acc; acc += hist[j]; if (j == 7 && a.n_common) { *a.n_common = acc; a.stats->shade_common += acc; } }
+        *a.count1 = acc;
+    }
+    __syncthreads();
+    for (unsigned int k = threadIdx.x; k < work.count; k += blockDim.x) {
+        const unsigned int key = a.kk[k];
+        if (key == 255u) continue;
+        const unsigned int pos = atomicAdd(&offs[key], 1u);
+        a.out[pos] = work_item(work, k, b, nb);
+    }
+}
+
 // trace the rays of one queue slice
 template <bool SMALL, bool COUNT>
 D void trace_slice(const PathState &P, const DevScene &S, const LdsScene &L, int *lds_stack, unsigned int *ticket, const Work &work,
@@ -571,15 +634,22 @@ template <bool SMALL, bool COUNT = false>
 #ifdef PPG_TRACE_WAVES
 __attribute__((amdgpu_waves_per_eu(PPG_TRACE_WAVES, PPG_TRACE_WAVES)))
 #endif
-__global__ __launch_bounds__(PPG_BLOCK) void k_trace(PathState P, DevScene S, Queues Q, int qin, int lds_nodes, int lds_tris) {
+__global__ __launch_bounds__(PPG_BLOCK) void k_trace(PathState P, DevScene S, Queues Q, int qin, int lds_nodes, int lds_tris, unsigned int *sorted, unsigned char *sort_keys) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __shared__ unsigned long long acc;
     __shared__ unsigned int ticket;
+    __shared__ unsigned int sort_hist[16], sort_offs[16];
+    __shared__ SortArgs sort_lds;
     const unsigned int b = blockIdx.x, nb = gridDim.x;
-    const bool stopped = Q.stop && *Q.stop;
-    Work work = work_of(P, Q, qin, nullptr, b, nb);
-    if (stopped) work.count = 0;
-    if (work.count == 0) return;  // (uniform per workgroup)
+    if (Q.stop && *Q.stop) return;  // (uniform per workgroup)
+    const Work work = work_of(P, Q, qin, nullptr, b, nb);
+    if (work.count == 0) {
+        if (sorted && threadIdx.x == 0) { Q.count[1][b] = 0; if (Q.n_common) Q.n_common[b] = 0; }
+        return;
+    }
+    // what the sort at the end needs is put into LDS now and read back then: kept in scalar registers across the traversal loop (where the
+    // compiler's merged kernel-argument loads leave it) it made the loop spill — k_trace 19.1 -> 20.8 ms with the sort switched off
+    if (sorted && threadIdx.x == 0) sort_lds = sort_args(P, S, Q, b, sorted, sort_keys);
     // dynamic LDS: SMALL → the triangles; otherwise the traversal stacks [PPG_LDS_STACK][PPG_BLOCK]
     LdsScene L;
     if (SMALL) L = stage_scene(S, lds_raw, 0, lds_tris);
@@ -589,6 +659,8 @@ __global__ __launch_bounds__(PPG_BLOCK) void k_trace(PathState P, DevScene S, Qu
     trace_slice<SMALL, COUNT>(P, S, L, (int *)lds_raw, &ticket, work, b, nb, traced, n_nodes, n_tris);
     block_add_u64(&acc, &Q.stats[b].rays, traced);
     if (COUNT) { block_add_u64(&acc, &Q.stats[b].bvh_nodes, n_nodes); block_add_u64(&acc, &Q.stats[b].bvh_tris, n_tris); }
+    // the slice's hits are written (and visible to the workgroup: the barriers of trace_slice / block_add_u64): sort it for k_shade
+    if (sorted) { const SortArgs sa = sort_lds; sort_slice(sa, work, b, nb, sort_hist, sort_offs); }
 }
 
 // grid[cell] for stree_lookup: descend at most PPG_GRID_LEVELS levels along the cell's coordinate bits
@@ -1582,47 +1654,7 @@ static __global__ __launch_bounds__(PPG_BLOCK) void k_sort_slices(PathState P, D
     if (Q.stop && *Q.stop) return;
     const Work work = work_of(P, Q, qin, nullptr, b, nb);  // QIN_FIRST (every path of the batch) or QIN_DENSE
     if (work.count == 0) { if (threadIdx.x == 0) { Q.count[1][b] = 0; if (Q.n_common) Q.n_common[b] = 0; } return; }
-    unsigned int *out = sorted + (size_t)b * Q.cap;
-    unsigned char *kk = keys + (size_t)b * Q.cap;
-    if (threadIdx.x < 16) hist[threadIdx.x] = 0;
-    __syncthreads();
-    for (unsigned int k = threadIdx.x; k < work.count; k += blockDim.x) {
-        const unsigned int i = work_item(work, k, b, nb);
-        unsigned int key = 255u;  // no path at this position (partial last chunk)
-        if (i < P.n_paths) {
-            // bins 0..7: the COMMON classes (MSET_COMMON), by BSDF type; 8..15: everything else — by type, then bump-mapped or masked
-            // surfaces, spheres, and last the rays that left the scene
-            const int prim = __float_as_int(P.hit[i].w);
-            key = 15u;
-            if (prim >= 0) {
-                if (prim >= S.n_tris) key = 14u;
-                else {
-                    const int m = __float_as_int(S.tris[3 * (size_t)prim].w);
-                    const float4 *mr = S.materials + PPG_MAT_STRIDE * (size_t)m;
-                    const int type = (int)mr[0].w, flags = __float_as_int(mr[2].w);
-                    const unsigned int tex = __float_as_uint(mr[5].x);
-                    if ((flags & PPG_MAT_MASK) || (tex >> 16)) key = 13u;
-                    else if (mset_common_type(type)) key = type == PPG_BSDF_ROUGHPLASTIC ? 6u : (unsigned int)type;  // 0..6
-                    else key = 8u + ((unsigned int)type & 3u);  // dielectric 10, thin dielectric 11, rough dielectric 8
-                }
-            }
-            atomicAdd(&hist[key], 1u);
-        }
-        kk[k] = (unsigned char)key;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned int acc = 0;
-        for (int j = 0; j < 16; ++j) { offs[j] = acc; acc += hist[j]; if (j == 7 && Q.n_common) { Q.n_common[b] = acc; Q.stats[b].shade_common += acc; } }
-        Q.count[1][b] = acc;
-    }
-    __syncthreads();
-    for (unsigned int k = threadIdx.x; k < work.count; k += blockDim.x) {
-        const unsigned int key = kk[k];
-        if (key == 255u) continue;
-        const unsigned int pos = atomicAdd(&offs[key], 1u);
-        out[pos] = work_item(work, k, b, nb);
-    }
+    sort_slice(sort_args(P, S, Q, b, sorted, keys), work, b, nb, hist, offs);
 }
 
 // copy every workgroup's queue slice into one dense array (offsets = exclusive scan of the slice counts)
