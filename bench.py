@@ -75,7 +75,7 @@ def stored_operation_counts(tag):
     return None
 
 
-def algorithmic_bytes(work=None, rays=None, bvh=None, tag=None):
+def algorithmic_bytes(work=None, rays=None, bvh=None, tag=None, sort_in_trace=False):
     """ALGORITHMIC bytes per unit of each path kernel: bytes the kernel's algorithm touches per unit, cache-oblivious,
     from the data layout of ppg_kernels.h and operation counts of the same workload: `work` = ppgo_work_counters of the CPU restatement
     with `rays` rays traced (S-tree lookups, D-tree levels), `bvh` = (nodes visited, triangles tested, rays) counted by k_trace itself."""
@@ -100,6 +100,9 @@ def algorithmic_bytes(work=None, rays=None, bvh=None, tag=None):
         n_bar, t_bar = bvh[0] / bvh[2], bvh[1] / bvh[2]
         trace += n_bar * 64 + t_bar * 48               # quantised BVH4 node = 64 B, TriAccel record = 48 B
         detail.update(bvh4_nodes_per_ray=n_bar, triangles_tested_per_ray=t_bar)
+    if sort_in_trace:                                  # k_trace also sorts its queue slices by BSDF type (sort_slice):
+        trace += 4 + 16 + 16 + 4 + 1                   # hit word, triangle word, material words read; sorted index + key byte written
+        detail.update(slice_sort_inside_k_trace=True)
     # the commit, per RECORDED VERTEX: k_commit reads the path word + the vertex slot (4 float4; 6 with a spatial filter) and adds to ~5 leaf
     # accumulators + the weight; a round of the optimiser instead writes records (k_commit_records: path word amortised over the path's
     # vertices + 6 float4 read, key 8 + optimiser record 32 + splat record 16 written), sorts them, and k_splat_sorted reads key 8 + index 4
@@ -393,7 +396,9 @@ def run(args):
         times = [k for k in times if k["launches"] > 0]
         trace_rays = sum(k["units"] for k in times if k["name"] == "k_trace")
         bvh = (counts.get("bvh_nodes_visited", 0), counts.get("bvh_triangles_tested", 0), trace_rays) if counts else None
-        alg = algorithmic_bytes(work, rays_cpu, bvh, traffic_tag)
+        # (FULL scenes sort every bounce's queue slices by BSDF type: inside k_trace since round 6, unless PPG_SORT_KERNEL=1 launches k_sort_slices)
+        sort_in_trace = any(k["name"].startswith("k_shade<common>") for k in times) and not any(k["name"] == "k_sort_slices" for k in times)
+        alg = algorithmic_bytes(work, rays_cpu, bvh, traffic_tag, sort_in_trace)
         # the commit's unit is a recorded vertex (the library books its launches by paths): iterations rendered in rounds of the optimiser
         # commit through k_commit_records / k_splat_sorted, the others (the first one; every one without a learned fraction) through k_commit
         rounds_on = props.get("bsdfSamplingFractionLoss", "none") != "none" and props.get("spatialFilter", "nearest") != "box" and props.get("nee", "never") != "kickstart"
