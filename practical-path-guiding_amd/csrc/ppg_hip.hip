@@ -696,6 +696,9 @@ struct ppg_ctx {
     int tuneFinalBatch = 0;           // PPG_FINAL_BATCH: passes per batch of the final iteration (0 = 64)
     int tuneTailBlocks = 0;           // PPG_TAIL_BLOCKS: workgroups of k_tail when k_commit runs beside it (0 = automatic)
     int tunePathLayout = 0;           // PPG_PATH_LAYOUT = soa | aos | pack: layout of the per-path state (0 = automatic, allocPaths)
+    int tuneBlocksSmall = 2048;       // PPG_BLOCKS_SMALL: workgroups of the wavefront kernels for batches of at most tuneSmallPaths paths (0 = nBlocks for every batch)
+    size_t tuneSmallPaths = 13000000; // PPG_SMALL_PATHS.  KITCHEN 720p (r06_experiments.json s23, s27): 2048 for batches up to 4 M / 16 M / 32 M paths: +0.1 / +1.1 / +1.2 % on the
+                                      // driver's command (its final iteration is one batch of 12 M), +0.2 % at 127 passes, -0.3 % at 1023 with 16 M (its 14.7 M-path rounds): 13 M
     bool tuneSortKernel = false;      // PPG_SORT_KERNEL=1: the BSDF-type sort of the queue slices as a launch of its own (k_sort_slices) instead of inside k_trace
     int tuneBvhLeaf = 4;              // PPG_BVH_LEAF: triangles per BVH leaf (1..8).  KITCHEN 720p, driver's command: 4 -> 3 +3.5 % once the node test had become
                                       // cheap (130.9 -> 135.6, A/B on one box; with the world-space decode 2 / 3 / 4 / 6 / 8 gave 125.8 / 125.9 / 124.5 / 119.6 / 115.2)
@@ -1453,7 +1456,15 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound, const GroupLaunch *gl =
         R.group_stride = gl->stridePasses * (unsigned int)ctx->sppPerPass;
     }
     Queues Q = ctx->queues;
-    const int grid = ctx->nBlocks;
+    // Workgroups of this batch's wavefront kernels.  A batch of a few million paths runs faster on fewer, larger queue slices (ray replacement
+    // and the slice sort have more to work with, fewer half-empty workgroups per launch: +1 % on the driver's command with 2048), the 59 M-path
+    // launches of a long render on more (4096: +1.6 % at 1023 passes) — so the grid follows the batch.  Slices are sized for the largest batch on
+    // nBlocks workgroups: a smaller grid is taken only if this batch's slices still fit.
+    int grid = ctx->nBlocks;
+    if (ctx->tuneBlocksSmall > 0 && ctx->tuneBlocksSmall < ctx->nBlocks && (size_t)P.n_paths <= ctx->tuneSmallPaths) {
+        const size_t chunks = ((size_t)P.n_paths + PPG_DCHUNK - 1) / PPG_DCHUNK;
+        if (((chunks + (size_t)ctx->tuneBlocksSmall - 1) / (size_t)ctx->tuneBlocksSmall) * PPG_DCHUNK <= (size_t)ctx->queues.cap) grid = ctx->tuneBlocksSmall;
+    }
     const int gridAll = gridFor(P.n_paths);
     const bool smallScene = ctx->scene.n_tris <= 64 && ctx->ldsTris == ctx->scene.n_tris && ctx->scene.n_spheres == 0 && !ctx->tuneForceBvh;
     // Tracing inside k_generate / k_shade (no k_trace launch, no ray/hit round trip) was measured SLOWER on MI355X
@@ -2362,6 +2373,8 @@ int ppg_create(const ppg_config *cfg, ppg_ctx **out) {
         if (const char *e = getenv("PPG_FINAL_BATCH")) c->tuneFinalBatch = std::max(1, atoi(e));
         if (const char *e = getenv("PPG_PATH_LAYOUT")) c->tunePathLayout = !strcmp(e, "aos") ? 2 : (!strcmp(e, "pack") ? 3 : (!strcmp(e, "soa") ? 1 : 0));
         if (const char *e = getenv("PPG_SORT_KERNEL")) c->tuneSortKernel = atoi(e) != 0;
+        if (const char *e = getenv("PPG_BLOCKS_SMALL")) c->tuneBlocksSmall = std::max(0, atoi(e));
+        if (const char *e = getenv("PPG_SMALL_PATHS")) c->tuneSmallPaths = (size_t)std::max(0ll, atoll(e));
         if (const char *e = getenv("PPG_BVH_LEAF")) c->tuneBvhLeaf = std::max(1, std::min(8, atoi(e)));
         if (const char *e = getenv("PPG_BVH_PAD")) c->tuneBvhPad = (float)atof(e);
         if (const char *e = getenv("PPG_SPLIT_DEPTH")) c->tuneSplitDepth = std::max(0, atoi(e));

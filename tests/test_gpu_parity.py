@@ -303,7 +303,7 @@ def test_tuning_switches_do_not_change_results(monkeypatch):
                 dict(PPG_NO_TOPCUT="1"), dict(PPG_NO_OVERLAP="1"), dict(PPG_NO_SORT="1"), dict(PPG_TAIL_MIN="1", PPG_TAIL_DIV="1000000"),
                 dict(PPG_TAIL_THRESHOLD="100000000"), dict(PPG_BLOCKS="512"), dict(PPG_BATCH_PATHS="20000"), dict(PPG_TAIL_BLOCKS="64"),
                 dict(PPG_BULK_BOUNCES="0"), dict(PPG_BULK_BOUNCES="3"), dict(PPG_BOUNCE_MARGIN="0"), dict(PPG_TAIL_MIN="200", PPG_TAIL_DIV="1000000"),
-                dict(PPG_BVH_LEAF="3"), dict(PPG_BVH_LEAF="8"), dict(PPG_SORT_KERNEL="1"), dict(PPG_NO_SORTED_COMMIT="1"), dict(PPG_ADAM_UNORDERED="1"), dict(PPG_SPLAT_LDS_NODES="4"), dict(PPG_NO_ASIDE="1"),
+                dict(PPG_BVH_LEAF="3"), dict(PPG_BVH_LEAF="8"), dict(PPG_SORT_KERNEL="1"), dict(PPG_BLOCKS_SMALL="1024", PPG_SMALL_PATHS="100000000"), dict(PPG_BLOCKS_SMALL="0"), dict(PPG_NO_SORTED_COMMIT="1"), dict(PPG_ADAM_UNORDERED="1"), dict(PPG_SPLAT_LDS_NODES="4"), dict(PPG_NO_ASIDE="1"),
                 dict(PPG_SPLIT_DEPTH="0"), dict(PPG_SPLIT_DEPTH="6"), dict(PPG_FINAL_HALVES="1", PPG_SPLIT_DEPTH="4"), dict(PPG_SPLIT_DEPTH="6", PPG_NO_OVERLAP="1"), dict(PPG_SPLIT_DEPTH="2", PPG_BULK_BOUNCES="5")):
         with monkeypatch.context() as m:
             for k, v in env.items():
