@@ -1514,6 +1514,9 @@ int renderBatch(ppg_ctx *ctx, int batch, bool adamRound, const GroupLaunch *gl =
                     }
                 }
                 maxBounces = std::max(1, std::min(64, need + ctx->bounceMargin));
+                // (a batch smaller than the hand-over threshold stops after its first bounce whatever happens: no margin — every launch beyond the
+                // stop returns at once, but three kernels and two small ones per bounce are still 30 us of launches, 0.5 ms in a first batch)
+                if (P.n_paths < stopBelow) maxBounces = 1;
             }
             // (a round whose stragglers' records are deferred: a path alive after wavefront bounce b has depth b, and which paths are
             // stragglers is decided where k_tail takes them — never beyond the depth of the rule, include/ppg.h "STRAGGLERS")
